@@ -1,0 +1,46 @@
+"""Helpers to load tests/golden/*.npz fixtures (made by tests/golden/make_golden.py)."""
+from __future__ import annotations
+
+import glob
+import json
+import os
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN_DIR, f"{name}.npz"))
+    meta = json.loads(str(z["meta"]))
+    params = {k[len("param:"):]: z[k] for k in z.files if k.startswith("param:")}
+    return dict(name=name, meta=meta, x=z["x"], edge_index=z["edge_index"], out=z["out"], params=params)
+
+
+def oracle_forward(g, orc, return_intermediates=False):
+    """Run the numpy oracle on a golden fixture's inputs/params."""
+    m, p = g["meta"], g["params"]
+    if m["kind"] == "lay":
+        bw = [p[f"bases_weight.{b}"] for b in range(m["B"])]
+        return orc.efficient_graph_conv_forward(
+            g["x"], g["edge_index"], bw, p["comb_weights.weight"], p["comb_weights.bias"], p.get("bias"),
+            m["H"], m["aggrs"], softmax_weights=m["softmax"], sigmoid_weights=m["sigmoid"],
+            hardtanh_weights=m["hardtanh"], add_self_loops=m["add_self_loops"],
+            return_intermediates=return_intermediates)
+    return orc.egconv_forward(
+        g["x"], g["edge_index"], p["bases_weight"], p["comb_weight.weight"], p["comb_weight.bias"], p.get("bias"),
+        m["H"], m["B"], m["aggrs"], add_self_loops=m["add_self_loops"], sigmoid=m["sigmoid"],
+        return_intermediates=return_intermediates)
+
+
+def rel_err(a, b):
+    """max |a-b| / max(1, max|b|)  -- the scale-relative error used across the parity tests."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    if a.size == 0:
+        return 0.0
+    return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
