@@ -1,0 +1,15 @@
+"""egc_amd -- the EGC message-passing layer's hot path, native to MI355X (gfx950).
+
+Public surface (mirrors the reference's layer API):
+  EfficientGraphConv   drop-in for experiments/layers.py:EfficientGraphConv
+  EGConv               drop-in for experiments/optimized_layers.py:EGConv
+  SparseTensor         minimal adj_t container (torch_sparse is not required)
+  CSRGraph             device CSR + degree statistics + long-row plan
+  egc_layer_forward    operator-level call into libegc_hip.so
+"""
+from .graph import CSRGraph, SparseTensor, GLOBAL_GRAPH_CACHE  # noqa: F401
+from .functional import egc_layer_forward, make_spec, LayerSpec  # noqa: F401
+from .layers import EfficientGraphConv  # noqa: F401
+from .optimized_layers import EGConv  # noqa: F401
+
+__version__ = "0.1.0"

@@ -1,0 +1,557 @@
+// Fused multi-aggregator neighbourhood reduction + per-node combine for the EGC layer (gfx950).
+//
+// Reference behaviour replaced, in ONE pass over a destination-keyed CSR (no [E, B*L] temporaries):
+//   x_j gather                         MessagePassing.__collect__ via propagate (layers.py:191-193)
+//   symnorm message scaling            layers.py:195-199, optimized_layers.py:226-230
+//   scatter / spmm per aggregator      layers.py:201-225, optimized_layers.py:215-278
+//   var / std epilogue                 layers.py:202-216, optimized_layers.py:237-244
+//   stack, weight nonlinearity, weighted sum / bmm, bias
+//                                      layers.py:109-138, optimized_layers.py:183-208
+//
+// Mapping to the hardware.  A basis row (B*L floats, leading dimension ldb, 16-byte slots) is read by
+// `lpr` lanes with one buffer_load_dwordx4 each, so a wavefront-instruction gathers G = 64/lpr
+// neighbour rows at once (4 rows of 256 B at the north-star shape).  Each lane keeps running
+// sum / sum-of-squares / max / min / symnorm-weighted-sum for its 4 columns in registers; the G
+// lane groups are merged with xor-shuffles; the finished row goes through LDS once for the
+// [H, A*B] x [A*B, L] combine and is written as one contiguous F_out row.  Invalid lanes use an
+// out-of-range buffer offset (hardware returns 0, no memory traffic) instead of divergent branches.
+//
+// Degree skew: rows with more than EGC_LONG_ROW_THRESHOLD entries are cut into
+// EGC_LONG_ROW_CHUNK-entry chunks (plan from egc_csr_prepare); one wavefront reduces one chunk to a
+// partial record, and a merge kernel folds a row's partials in chunk order (deterministic) before the
+// same epilogue.
+#include <math.h>
+
+#include "egc_common.h"
+
+// hipcc defaults to -ffp-contract=fast, which would fuse the reference's separately rounded
+// x*x / mean*mean products into FMAs (var of a single neighbour must be EXACTLY 0).  Every fused
+// multiply-add in this file is an explicit fmaf().
+#pragma clang fp contract(off)
+
+namespace egc {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+
+constexpr unsigned OOB = 0xFFFFFFF0u;  // any offset >= num_records makes a buffer load return 0
+
+struct AggArgs {
+  const int* rowptr;
+  const int* col;
+  const float* dis;        // deg^-1/2 of the symnorm edge set, or nullptr
+  const int* max_index;    // device scalar (used when !loops_all)
+  const int* plan;
+  const float* bases;
+  const float* weightings;
+  const float* bias;
+  float* out;
+  float* partial;          // [cap_chunks][5][slots] float4
+  int* partial_nself;      // [cap_chunks]
+  int n_nodes;
+  int ldb, slots;          // slots = ldb / 4
+  int F_out, W, H, B, A, L;
+  int aggr[EGC_MAX_AGGRS];
+  int x_looped, y_looped, loops_all;
+  int sa, sb;              // strides of (aggregator, basis) inside one head's weight block
+  int act;
+  int lpr_log2;
+  unsigned magic_L;        // floor(2^32 / L) + 1: o / L == umulhi(o, magic_L) for o, L < 2^16 (L > 1)
+  unsigned bases_bytes;
+  int lds_floats_per_wave;
+};
+
+template <int CHUNKS>
+struct Acc {
+  f4 sum[CHUNKS], sq[CHUNKS], mx[CHUNKS], mn[CHUNKS], ws[CHUNKS];
+  __device__ inline void init() {
+#pragma unroll
+    for (int k = 0; k < CHUNKS; ++k) {
+      sum[k] = 0.f; sq[k] = 0.f; ws[k] = 0.f;
+      mx[k] = -INFINITY; mn[k] = INFINITY;
+    }
+  }
+};
+
+__device__ inline f4 f4_max(f4 a, f4 b) {
+  return f4{fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)};
+}
+__device__ inline f4 f4_min(f4 a, f4 b) {
+  return f4{fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z), fminf(a.w, b.w)};
+}
+__device__ inline f4 f4_fma(f4 a, f4 b, f4 c) {
+  return f4{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w)};
+}
+__device__ inline f4 f4_shfl_xor(f4 v, int off) {
+  return f4{__shfl_xor(v.x, off), __shfl_xor(v.y, off), __shfl_xor(v.z, off), __shfl_xor(v.w, off)};
+}
+
+__device__ inline f4 load_slot(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+  return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0));
+}
+
+// Fold one gathered neighbour slot into the lane's running aggregates.
+__device__ inline void fold(f4& sum, f4& sq, f4& mx, f4& mn, f4& ws, f4 v, bool in_x, bool in_y, float w) {
+  const f4 vx = in_x ? v : f4{0.f, 0.f, 0.f, 0.f};
+  sum += vx;
+  // x*x rounded on its own, then added -- as scatter(inputs * inputs) does (layers.py:206-212); a fused
+  // multiply-add here makes var of identical neighbours non-zero, which std amplifies 158x at var = 0.
+  sq += f4{__fmul_rn(vx.x, vx.x), __fmul_rn(vx.y, vx.y), __fmul_rn(vx.z, vx.z), __fmul_rn(vx.w, vx.w)};
+  mx = f4_max(mx, in_x ? v : f4{-INFINITY, -INFINITY, -INFINITY, -INFINITY});
+  mn = f4_min(mn, in_x ? v : f4{INFINITY, INFINITY, INFINITY, INFINITY});
+  const float wy = in_y ? w : 0.f;
+  ws = f4_fma(f4{wy, wy, wy, wy}, v, ws);
+}
+
+// Reduce CSR entries [start, end) of `row` into per-lane partial aggregates.
+// Lane (g, q): group g = lane >> lpr_log2 takes entries g, g+G, ...; q = slot inside the basis row.
+template <int CHUNKS, int U>
+__device__ inline void accumulate_range(const AggArgs& a, __amdgpu_buffer_rsrc_t rsrc, int row, int start, int end,
+                                        int lane, Acc<CHUNKS>& acc, int& nself) {
+  const int G = 64 >> a.lpr_log2;
+  const int g = lane >> a.lpr_log2;
+  const int q = lane & ((1 << a.lpr_log2) - 1);
+  const float dis_i = a.dis != nullptr ? a.dis[row] : 0.f;
+  const bool xl = a.x_looped != 0, yl = a.y_looped != 0;
+  unsigned slot_off[CHUNKS];
+#pragma unroll
+  for (int k = 0; k < CHUNKS; ++k) {
+    const int s = k * 64 + q;
+    slot_off[k] = s < a.slots ? (unsigned)s * 16u : OOB;
+  }
+  const unsigned row_bytes = (unsigned)a.ldb * 4u;
+
+  for (int base = start; base < end; base += 64) {
+    // stage up to 64 (col, dis[col]) pairs of this row, one per lane, coalesced
+    const int p = base + lane;
+    const bool pv = p < end;
+    const int jj = pv ? a.col[p] : row;
+    const float dd = a.dis != nullptr ? a.dis[jj] : 0.f;
+    nself += __popcll(__ballot(pv && jj == row));
+    const int cnt = min(64, end - base);
+    for (int t0 = 0; t0 < cnt; t0 += U * G) {
+      int j[U];
+      float w[U];
+      bool valid[U];
+      f4 v[U][CHUNKS];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int idx = t0 + u * G + g;
+        valid[u] = idx < cnt;
+        j[u] = __shfl(jj, idx & 63);
+        w[u] = __shfl(dd, idx & 63) * dis_i;
+        const unsigned rb = (unsigned)j[u] * row_bytes;
+#pragma unroll
+        for (int k = 0; k < CHUNKS; ++k)
+          v[u][k] = load_slot(rsrc, (valid[u] && slot_off[k] != OOB) ? rb + slot_off[k] : OOB);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool is_self = j[u] == row;
+        const bool in_x = valid[u] && !(xl && is_self);
+        const bool in_y = valid[u] && !(yl && is_self);
+#pragma unroll
+        for (int k = 0; k < CHUNKS; ++k)
+          fold(acc.sum[k], acc.sq[k], acc.mx[k], acc.mn[k], acc.ws[k], v[u][k], in_x, in_y, w[u]);
+      }
+    }
+  }
+}
+
+// Merge the G lane groups so that every lane holds the aggregates of its slot over all entries.
+template <int CHUNKS>
+__device__ inline void reduce_groups(const AggArgs& a, Acc<CHUNKS>& acc) {
+  if (CHUNKS > 1) return;  // lpr == 64: a single group
+  for (int off = 1 << a.lpr_log2; off < 64; off <<= 1) {
+    acc.sum[0] += f4_shfl_xor(acc.sum[0], off);
+    acc.sq[0] += f4_shfl_xor(acc.sq[0], off);
+    acc.ws[0] += f4_shfl_xor(acc.ws[0], off);
+    acc.mx[0] = f4_max(acc.mx[0], f4_shfl_xor(acc.mx[0], off));
+    acc.mn[0] = f4_min(acc.mn[0], f4_shfl_xor(acc.mn[0], off));
+  }
+}
+
+__device__ inline f4 f4_div(f4 a, float d) { return f4{a.x / d, a.y / d, a.z / d, a.w / d}; }
+
+// var = E[x^2] - E[x]^2 with separately rounded product and difference (layers.py:203-214).
+__device__ inline f4 f4_var(f4 mean_sq, f4 mean) {
+  return f4{__fsub_rn(mean_sq.x, __fmul_rn(mean.x, mean.x)), __fsub_rn(mean_sq.y, __fmul_rn(mean.y, mean.y)),
+            __fsub_rn(mean_sq.z, __fmul_rn(mean.z, mean.z)), __fsub_rn(mean_sq.w, __fmul_rn(mean.w, mean.w))};
+}
+__device__ inline f4 f4_std(f4 var) {
+  return f4{sqrtf(fmaxf(var.x, 0.f) + 1e-5f), sqrtf(fmaxf(var.y, 0.f) + 1e-5f), sqrtf(fmaxf(var.z, 0.f) + 1e-5f),
+            sqrtf(fmaxf(var.w, 0.f) + 1e-5f)};
+}
+
+// Self-loop term, aggregator finalisation, weight nonlinearity, combine, bias, store.
+// `acc` must already be merged over lane groups; `deg` / `nself` are the row's entry and self-entry counts.
+template <int CHUNKS>
+__device__ inline void finish_row(const AggArgs& a, __amdgpu_buffer_rsrc_t rsrc, int row, Acc<CHUNKS>& acc, int deg,
+                                  int nself, int lane, float* lds) {
+  const int q = lane & ((1 << a.lpr_log2) - 1);
+  const int g = lane >> a.lpr_log2;
+  const int nloop = a.loops_all ? a.n_nodes : (*a.max_index + 1);
+  const bool has_self = row < nloop;
+  int cnt = deg;
+  if (a.x_looped) cnt = deg - nself + (has_self ? 1 : 0);
+
+  if ((a.x_looped || a.y_looped) && has_self) {
+    const float dis_i = a.dis != nullptr ? a.dis[row] : 0.f;
+    const float wself = dis_i * dis_i;
+#pragma unroll
+    for (int k = 0; k < CHUNKS; ++k) {
+      const int s = k * 64 + q;
+      const f4 v = load_slot(rsrc, s < a.slots ? (unsigned)row * (unsigned)a.ldb * 4u + (unsigned)s * 16u : OOB);
+      fold(acc.sum[k], acc.sq[k], acc.mx[k], acc.mn[k], acc.ws[k], v, a.x_looped != 0, a.y_looped != 0, wself);
+    }
+  }
+
+  float* lds_agg = lds;
+  float* lds_w = lds + a.A * a.ldb;
+
+  // (1) finalise every aggregator for this lane's slot(s) and park it in LDS as [A][ldb]
+  const float cntf = (float)max(cnt, 1);
+  if (g == 0) {
+#pragma unroll
+    for (int k = 0; k < CHUNKS; ++k) {
+      const int s = k * 64 + q;
+      if (s < a.slots) {
+        const f4 mean = f4_div(acc.sum[k], cntf);
+        const f4 var = f4_var(f4_div(acc.sq[k], cntf), mean);
+        const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < a.A; ++t) {
+          f4 val;
+          switch (a.aggr[t]) {
+            case EGC_AGGR_SUM: val = acc.sum[k]; break;
+            case EGC_AGGR_MEAN: val = mean; break;
+            case EGC_AGGR_MAX: val = cnt > 0 ? acc.mx[k] : zero; break;
+            case EGC_AGGR_MIN: val = cnt > 0 ? acc.mn[k] : zero; break;
+            case EGC_AGGR_VAR: val = var; break;
+            case EGC_AGGR_STD: val = f4_std(var); break;
+            default: val = acc.ws[k]; break;  // EGC_AGGR_SYMNORM
+          }
+          *reinterpret_cast<f4*>(lds_agg + t * a.ldb + 4 * s) = val;
+        }
+      }
+    }
+  }
+  // (2) the node's weightings row, nonlinearity applied, into LDS
+  const float* wrow_g = a.weightings + (int64_t)row * a.W;
+  for (int k = lane; k < a.W; k += 64) {
+    float w = wrow_g[k];
+    if (a.act == EGC_ACT_SIGMOID) w = 1.0f / (1.0f + expf(-w));
+    else if (a.act == EGC_ACT_HARDTANH) w = fminf(fmaxf(w, -1.0f), 1.0f);
+    lds_w[k] = w;
+  }
+  const int AB = a.A * a.B;
+  if (a.act == EGC_ACT_SOFTMAX) {
+    // softmax over the joint B*A axis of each head (layers.py:112-117)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int h = lane; h < a.H; h += 64) {
+      float* wh = lds_w + h * AB;
+      float m = -INFINITY;
+      for (int k = 0; k < AB; ++k) m = fmaxf(m, wh[k]);
+      float s = 0.f;
+      for (int k = 0; k < AB; ++k) {
+        const float e = expf(wh[k] - m);
+        wh[k] = e;
+        s += e;
+      }
+      for (int k = 0; k < AB; ++k) wh[k] = wh[k] / s;
+    }
+  }
+  // LDS is per-wavefront here and LDS ops of one wavefront complete in order.
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+  // (3) combine: out[h*L + l] = sum_{a,b} w[h][a][b] * agg[a][b*L + l] (+ bias)
+  float* orow = a.out + (int64_t)row * a.F_out;
+  for (int o = lane; o < a.F_out; o += 64) {
+    const int h = a.L == 1 ? o : (int)__umulhi((unsigned)o, a.magic_L);
+    const int l = o - h * a.L;
+    const float* wh = lds_w + h * AB;
+    const float* ag = lds_agg + l;
+    float z = 0.f;
+    for (int t = 0; t < a.A; ++t) {
+      const float* agt = ag + t * a.ldb;
+      const float* wt = wh + t * a.sa;
+      for (int b = 0; b < a.B; ++b) z = fmaf(wt[b * a.sb], agt[b * a.L], z);
+    }
+    if (a.bias != nullptr) z += a.bias[o];
+    orow[o] = z;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+__device__ inline __amdgpu_buffer_rsrc_t bases_rsrc(const AggArgs& a) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)a.bases, 0, a.bases_bytes, 0x00020000);
+}
+
+// One wavefront per CSR row (rows above the long-row threshold are left to the chunk/merge kernels).
+template <int CHUNKS, int U>
+__global__ void __launch_bounds__(256) agg_rows_kernel(AggArgs a) {
+  extern __shared__ float smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wpb = blockDim.x >> 6;
+  const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * wpb + wave);
+  if (row >= a.n_nodes) return;
+  const int start = __builtin_amdgcn_readfirstlane(a.rowptr[row]);
+  const int end = __builtin_amdgcn_readfirstlane(a.rowptr[row + 1]);
+  const int deg = end - start;
+  if (deg > EGC_LONG_ROW_THRESHOLD) return;
+  const __amdgpu_buffer_rsrc_t rsrc = bases_rsrc(a);
+  Acc<CHUNKS> acc;
+  acc.init();
+  int nself = 0;
+  accumulate_range<CHUNKS, U>(a, rsrc, row, start, end, lane, acc, nself);
+  reduce_groups<CHUNKS>(a, acc);
+  finish_row<CHUNKS>(a, rsrc, row, acc, deg, nself, lane, smem + wave * a.lds_floats_per_wave);
+}
+
+// One wavefront per long-row chunk -> partial record.
+template <int CHUNKS, int U>
+__global__ void __launch_bounds__(256) agg_chunks_kernel(AggArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int c = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+  const int n_chunks = a.plan[1];
+  if (c >= n_chunks) return;
+  const int cap_long = a.plan[2], cap_chunks = a.plan[3];
+  const int* long_row = a.plan + 4;
+  const int* chunk_slot = long_row + 2 * cap_long;
+  const int* chunk_begin = chunk_slot + cap_chunks;
+  const int row = __builtin_amdgcn_readfirstlane(long_row[chunk_slot[c]]);
+  const int start = __builtin_amdgcn_readfirstlane(chunk_begin[c]);
+  const int end = min(start + EGC_LONG_ROW_CHUNK, __builtin_amdgcn_readfirstlane(a.rowptr[row + 1]));
+  const __amdgpu_buffer_rsrc_t rsrc = bases_rsrc(a);
+  Acc<CHUNKS> acc;
+  acc.init();
+  int nself = 0;
+  accumulate_range<CHUNKS, U>(a, rsrc, row, start, end, lane, acc, nself);
+  reduce_groups<CHUNKS>(a, acc);
+  const int q = lane & ((1 << a.lpr_log2) - 1);
+  if ((lane >> a.lpr_log2) == 0) {
+    f4* rec = reinterpret_cast<f4*>(a.partial) + (int64_t)c * 5 * a.slots;
+#pragma unroll
+    for (int k = 0; k < CHUNKS; ++k) {
+      const int s = k * 64 + q;
+      if (s < a.slots) {
+        rec[0 * a.slots + s] = acc.sum[k];
+        rec[1 * a.slots + s] = acc.sq[k];
+        rec[2 * a.slots + s] = acc.mx[k];
+        rec[3 * a.slots + s] = acc.mn[k];
+        rec[4 * a.slots + s] = acc.ws[k];
+      }
+    }
+  }
+  if (lane == 0) a.partial_nself[c] = nself;
+}
+
+// One wavefront per long row: fold its partial records in chunk order, then the common epilogue.
+template <int CHUNKS>
+__global__ void __launch_bounds__(256) agg_merge_kernel(AggArgs a) {
+  extern __shared__ float smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int slot = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + wave);
+  if (slot >= a.plan[0]) return;
+  const int cap_long = a.plan[2];
+  const int* long_row = a.plan + 4;
+  const int* long_chunk0 = long_row + cap_long;
+  const int row = __builtin_amdgcn_readfirstlane(long_row[slot]);
+  const int c0 = __builtin_amdgcn_readfirstlane(long_chunk0[slot]);
+  const int deg = __builtin_amdgcn_readfirstlane(a.rowptr[row + 1] - a.rowptr[row]);
+  const int nch = (deg + EGC_LONG_ROW_CHUNK - 1) / EGC_LONG_ROW_CHUNK;
+  const int G = 64 >> a.lpr_log2;
+  const int g = lane >> a.lpr_log2;
+  const int q = lane & ((1 << a.lpr_log2) - 1);
+  Acc<CHUNKS> acc;
+  acc.init();
+  for (int k0 = g; k0 < nch; k0 += G) {
+    const f4* rec = reinterpret_cast<const f4*>(a.partial) + (int64_t)(c0 + k0) * 5 * a.slots;
+#pragma unroll
+    for (int k = 0; k < CHUNKS; ++k) {
+      const int s = k * 64 + q;
+      if (s < a.slots) {
+        acc.sum[k] += rec[0 * a.slots + s];
+        acc.sq[k] += rec[1 * a.slots + s];
+        acc.mx[k] = f4_max(acc.mx[k], rec[2 * a.slots + s]);
+        acc.mn[k] = f4_min(acc.mn[k], rec[3 * a.slots + s]);
+        acc.ws[k] += rec[4 * a.slots + s];
+      }
+    }
+  }
+  reduce_groups<CHUNKS>(a, acc);
+  int nself = 0;
+  for (int k = lane; k < nch; k += 64) nself += a.partial_nself[c0 + k];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) nself += __shfl_xor(nself, off);
+  const __amdgpu_buffer_rsrc_t rsrc = bases_rsrc(a);
+  finish_row<CHUNKS>(a, rsrc, row, acc, deg, nself, lane, smem + wave * a.lds_floats_per_wave);
+}
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static int validate_layer(const egc_layer* L) {
+  if (L == nullptr) return EGC_ERR_INVALID;
+  if (L->in_channels <= 0 || L->out_channels <= 0 || L->num_heads <= 0 || L->num_bases <= 0) return EGC_ERR_INVALID;
+  if (L->num_aggrs <= 0 || L->num_aggrs > EGC_MAX_AGGRS) return EGC_ERR_INVALID;
+  if (L->out_channels % L->num_heads != 0) return EGC_ERR_INVALID;
+  for (int t = 0; t < L->num_aggrs; ++t)
+    if (L->aggrs[t] < EGC_AGGR_SUM || L->aggrs[t] > EGC_AGGR_SYMNORM) return EGC_ERR_INVALID;
+  if (L->agg_set != EGC_SET_RAW && L->agg_set != EGC_SET_LOOPED) return EGC_ERR_INVALID;
+  if (L->sym_set != EGC_SET_RAW && L->sym_set != EGC_SET_LOOPED) return EGC_ERR_INVALID;
+  if (L->weight_layout != EGC_LAYOUT_HBA && L->weight_layout != EGC_LAYOUT_HAB) return EGC_ERR_INVALID;
+  if (L->weight_act < EGC_ACT_NONE || L->weight_act > EGC_ACT_HARDTANH) return EGC_ERR_INVALID;
+  const int64_t fg = (int64_t)L->num_bases * (L->out_channels / L->num_heads);
+  const int64_t w = (int64_t)L->num_heads * L->num_bases * L->num_aggrs;
+  if (fg > EGC_MAX_BASIS_WIDTH || w > EGC_MAX_WEIGHT_WIDTH || L->out_channels > EGC_MAX_OUT_CHANNELS)
+    return EGC_ERR_UNSUPPORTED;
+  return EGC_OK;
+}
+
+static bool layer_uses_symnorm(const egc_layer* L) {
+  for (int t = 0; t < L->num_aggrs; ++t)
+    if (L->aggrs[t] == EGC_AGGR_SYMNORM) return true;
+  return false;
+}
+
+struct WsLayout {
+  size_t partial_bytes, nself_bytes, total;
+};
+static WsLayout ws_layout(const egc_layer* L, int64_t n_nodes, int64_t n_edges) {
+  const int ldb = egc_bases_ld(L);
+  PlanCaps c = plan_caps(n_nodes, n_edges);
+  WsLayout w;
+  w.partial_bytes = align256((size_t)c.cap_chunks * 5 * ldb * sizeof(float));
+  w.nself_bytes = align256((size_t)c.cap_chunks * sizeof(int));
+  w.total = w.partial_bytes + w.nself_bytes;
+  return w;
+}
+
+template <int CHUNKS>
+static int launch_all(const AggArgs& a, int64_t n_nodes, const PlanCaps& caps, int wpb, size_t lds_bytes,
+                      hipStream_t stream) {
+  constexpr int U = 4;
+  const int threads = wpb * 64;
+  // long-row chunks first (they are the longest work items), then the per-row kernel, then the merge
+  agg_chunks_kernel<CHUNKS, U><<<(unsigned)ceil_div(caps.cap_chunks, 4), 256, 0, stream>>>(a);
+  EGC_LAUNCH_CHECK("agg_chunks_kernel");
+  agg_rows_kernel<CHUNKS, U><<<(unsigned)ceil_div(n_nodes, wpb), threads, lds_bytes, stream>>>(a);
+  EGC_LAUNCH_CHECK("agg_rows_kernel");
+  agg_merge_kernel<CHUNKS><<<(unsigned)ceil_div(caps.cap_long, wpb), threads, lds_bytes, stream>>>(a);
+  EGC_LAUNCH_CHECK("agg_merge_kernel");
+  return EGC_OK;
+}
+
+}  // namespace egc
+
+using namespace egc;
+
+extern "C" {
+
+int32_t egc_bases_ld(const egc_layer* layer) {
+  if (layer == nullptr || layer->num_heads <= 0) return -1;
+  const int fg = layer->num_bases * (layer->out_channels / layer->num_heads);
+  return (fg + 3) & ~3;
+}
+
+size_t egc_aggregate_workspace_bytes(const egc_layer* layer, int64_t n_nodes, int64_t n_edges) {
+  if (validate_layer(layer) != EGC_OK || n_nodes < 0 || n_edges < 0) return 0;
+  return ws_layout(layer, n_nodes, n_edges).total;
+}
+
+int egc_aggregate_combine_f32(const egc_graph* graph, const egc_layer* layer, const float* bases, int32_t ldb,
+                              const float* weightings, const float* bias, float* out, int32_t* arg_max,
+                              int32_t* arg_min, void* workspace, size_t workspace_bytes, egc_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (graph == nullptr) return EGC_ERR_INVALID;
+  int st = validate_layer(layer);
+  if (st != EGC_OK) return st;
+  if (arg_max != nullptr || arg_min != nullptr) return EGC_ERR_UNSUPPORTED;
+  const int64_t n = graph->n_nodes, e = graph->n_edges;
+  if (n < 0 || e < 0 || n >= ((int64_t)1 << 31) - 1 || e >= ((int64_t)1 << 31) - 1) return EGC_ERR_INVALID;
+  if (n == 0) return EGC_OK;
+  if (graph->rowptr == nullptr || graph->plan == nullptr || (e > 0 && graph->col == nullptr)) return EGC_ERR_INVALID;
+  if (bases == nullptr || weightings == nullptr || out == nullptr) return EGC_ERR_INVALID;
+  if (ldb != egc_bases_ld(layer)) return EGC_ERR_INVALID;
+  if ((reinterpret_cast<uintptr_t>(bases) & 15) != 0) return EGC_ERR_INVALID;
+  if ((uint64_t)n * (uint64_t)ldb * 4ull > (uint64_t)OOB) return EGC_ERR_UNSUPPORTED;  // 32-bit buffer offsets
+
+  AggArgs a;
+  a.rowptr = graph->rowptr;
+  a.col = graph->col;
+  a.dis = nullptr;
+  if (layer_uses_symnorm(layer)) {
+    a.dis = layer->sym_set == EGC_SET_LOOPED ? graph->dis_looped : graph->dis_raw;
+    if (a.dis == nullptr) return EGC_ERR_INVALID;
+  }
+  a.loops_all = layer->loops_all_nodes != 0;
+  a.max_index = graph->max_index;
+  if (!a.loops_all && graph->max_index == nullptr) return EGC_ERR_INVALID;
+  a.plan = graph->plan;
+  a.bases = bases;
+  a.weightings = weightings;
+  a.bias = bias;
+  a.out = out;
+  a.n_nodes = (int)n;
+  a.ldb = ldb;
+  a.slots = ldb / 4;
+  a.F_out = layer->out_channels;
+  a.H = layer->num_heads;
+  a.B = layer->num_bases;
+  a.A = layer->num_aggrs;
+  a.L = layer->out_channels / layer->num_heads;
+  a.W = a.H * a.B * a.A;
+  for (int t = 0; t < EGC_MAX_AGGRS; ++t) a.aggr[t] = t < a.A ? layer->aggrs[t] : 0;
+  a.x_looped = layer->agg_set == EGC_SET_LOOPED;
+  a.y_looped = layer->sym_set == EGC_SET_LOOPED;
+  if (layer->weight_layout == EGC_LAYOUT_HAB) { a.sa = a.B; a.sb = 1; } else { a.sa = 1; a.sb = a.A; }
+  a.act = layer->weight_act;
+  a.magic_L = a.L > 1 ? (unsigned)(((uint64_t)1 << 32) / (uint64_t)a.L) + 1u : 0u;  // L == 1: h = o in-kernel
+  a.bases_bytes = (unsigned)((uint64_t)n * ldb * 4ull);
+
+  int chunks = 1;
+  if (a.slots <= 64) {
+    int lg = 0;
+    while ((1 << lg) < a.slots) ++lg;
+    a.lpr_log2 = lg;
+  } else {
+    a.lpr_log2 = 6;
+    chunks = (a.slots + 63) / 64;
+  }
+  a.lds_floats_per_wave = a.A * ldb + ((a.W + 3) & ~3);
+  int wpb = 4;
+  if ((size_t)wpb * a.lds_floats_per_wave * sizeof(float) > 40 * 1024) wpb = 1;
+  const size_t lds_bytes = (size_t)wpb * a.lds_floats_per_wave * sizeof(float);
+  if (lds_bytes > 64 * 1024) return EGC_ERR_UNSUPPORTED;
+
+  WsLayout w = ws_layout(layer, n, e);
+  if (workspace == nullptr || workspace_bytes < w.total) return EGC_ERR_WORKSPACE;
+  a.partial = (float*)workspace;
+  a.partial_nself = (int*)((char*)workspace + w.partial_bytes);
+  PlanCaps caps = plan_caps(n, e);
+
+  switch (chunks) {
+    case 1: return launch_all<1>(a, n, caps, wpb, lds_bytes, stream);
+    case 2: return launch_all<2>(a, n, caps, wpb, lds_bytes, stream);
+    case 3: return launch_all<3>(a, n, caps, wpb, lds_bytes, stream);
+    case 4: return launch_all<4>(a, n, caps, wpb, lds_bytes, stream);
+    default: return EGC_ERR_UNSUPPORTED;
+  }
+}
+
+int egc_layer_forward_f32(const egc_graph* graph, const egc_layer* layer, const float* x, const float* wcat,
+                          const float* bcat, const float* bias, float* bases, int32_t ldb, float* weightings,
+                          float* out, void* workspace, size_t workspace_bytes, egc_stream_t stream) {
+  if (graph == nullptr) return EGC_ERR_INVALID;
+  int st = validate_layer(layer);
+  if (st != EGC_OK) return st;
+  const int fg = layer->num_bases * (layer->out_channels / layer->num_heads);
+  const int w = layer->num_heads * layer->num_bases * layer->num_aggrs;
+  st = egc_basis_transform_f32(x, wcat, bcat, graph->n_nodes, layer->in_channels, fg, w, bases, ldb, weightings, stream);
+  if (st != EGC_OK) return st;
+  return egc_aggregate_combine_f32(graph, layer, bases, ldb, weightings, bias, out, nullptr, nullptr, workspace,
+                                   workspace_bytes, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,102 @@
+"""Operator-level entry point: one EGC layer forward on the current HIP stream.
+
+``egc_layer_forward`` is the Python face of ``egc_layer_forward_f32`` in include/egc_hip.h -- basis
+GEMM, fused multi-aggregator reduction and combine -- and mirrors the tail of
+``EfficientGraphConv.forward`` (experiments/layers.py:97-138) / ``EGConv.forward``
+(optimized_layers.py:177-210).  Torch is used for device memory and the current stream only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import torch
+
+from . import _C
+from .graph import CSRGraph, _require_cuda, _stream_ptr
+
+
+@dataclass
+class LayerSpec:
+    """Static shape/semantics of one layer, pre-packed for the C ABI."""
+    c: _C.EgcLayer
+    f_in: int
+    f_out: int
+    f_g: int      # B * (F_out / H)
+    w_cols: int   # H * B * A
+
+    @property
+    def ldb(self) -> int:
+        return (self.f_g + 3) & ~3
+
+
+def make_spec(in_channels, out_channels, num_heads, num_bases, aggr_codes, agg_set, sym_set, loops_all_nodes,
+              weight_layout, weight_act) -> LayerSpec:
+    c = _C.make_layer(in_channels, out_channels, num_heads, num_bases, aggr_codes, agg_set, sym_set,
+                      loops_all_nodes, weight_layout, weight_act)
+    return LayerSpec(c, in_channels, out_channels, num_bases * (out_channels // num_heads),
+                     num_heads * num_bases * len(aggr_codes))
+
+
+def _check_f32(t, name, shape=None):
+    _require_cuda(t, name)
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"egc_amd: {name} must be float32 (got {t.dtype})")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise RuntimeError(f"egc_amd: {name} has shape {tuple(t.shape)}, expected {tuple(shape)}")
+
+
+def egc_layer_forward(graph: CSRGraph, spec: LayerSpec, x: torch.Tensor, wcat: torch.Tensor,
+                      bcat: torch.Tensor | None, bias: torch.Tensor | None, return_intermediates: bool = False):
+    """out[N, F_out] for one layer.  wcat = [bases_weight | comb.weight^T]  ([F_in, F_g + W]),
+    bcat = comb.bias ([W]) or None, bias = layer bias ([F_out]) or None."""
+    lib = _C.load()
+    n = graph.n_nodes
+    _check_f32(x, "x", (n, spec.f_in))
+    _check_f32(wcat, "wcat", (spec.f_in, spec.f_g + spec.w_cols))
+    if bcat is not None:
+        _check_f32(bcat, "bcat", (spec.w_cols,))
+    if bias is not None:
+        _check_f32(bias, "bias", (spec.f_out,))
+    if x.device != graph.device:
+        raise RuntimeError(f"egc_amd: x is on {x.device} but the graph is on {graph.device}")
+    dev = x.device
+    x = x.contiguous()
+    wcat = wcat.contiguous()
+    with torch.cuda.device(dev):
+        bases = torch.empty((n, spec.ldb), dtype=torch.float32, device=dev)
+        weightings = torch.empty((n, spec.w_cols), dtype=torch.float32, device=dev)
+        out = torch.empty((n, spec.f_out), dtype=torch.float32, device=dev)
+        ws_bytes = lib.egc_aggregate_workspace_bytes(C.byref(spec.c), n, graph.n_edges)
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+        g = graph.c_struct()
+        _C.check(lib.egc_layer_forward_f32(
+            C.byref(g), C.byref(spec.c), x.data_ptr(), wcat.data_ptr(),
+            bcat.contiguous().data_ptr() if bcat is not None else None,
+            bias.contiguous().data_ptr() if bias is not None else None,
+            bases.data_ptr(), spec.ldb, weightings.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(),
+            _stream_ptr(dev)), "egc_layer_forward_f32")
+    if return_intermediates:
+        return out, bases, weightings
+    return out
+
+
+class _EGCLayerFunction(torch.autograd.Function):
+    """Autograd shell around the fused forward.  The backward of the fused op is SURVEY.md 8(f)
+    rank 1 ("next"); until it lands a backward call fails loudly instead of returning wrong grads."""
+
+    @staticmethod
+    def forward(ctx, x, wcat, bcat, bias, graph, spec):
+        return egc_layer_forward(graph, spec, x, wcat, bcat, bias)
+
+    @staticmethod
+    def backward(ctx, grad_out):  # pragma: no cover
+        raise NotImplementedError(
+            "egc_amd: backward of the fused EGC layer is not implemented yet (forward-only build); "
+            "run under torch.no_grad() / model.eval() for inference")
+
+
+def egc_layer_apply(graph, spec, x, wcat, bcat, bias):
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, wcat, bcat, bias)):
+        return _EGCLayerFunction.apply(x, wcat, bcat, bias, graph, spec)
+    return egc_layer_forward(graph, spec, x, wcat, bcat, bias)

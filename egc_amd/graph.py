@@ -1,0 +1,165 @@
+"""Device-resident CSR graph container for the EGC hot path.
+
+``CSRGraph`` owns the destination-keyed CSR (stable inside a row), the deg^-1/2 arrays for the
+symnorm aggregator and the long-row work plan -- everything ``libegc_hip.so`` needs about the graph.
+It replaces what the reference keeps in ``_AggLayer.cached_vals`` (experiments/layers.py:163,186-188),
+``EGConv._cached_edge_index`` / ``_cached_adj_t`` (optimized_layers.py:71-72,138-175) and
+``torch_sparse.SparseTensor`` storage (experiments/utils.py:107-113).  All buffers are torch tensors
+(caching allocator); the kernels never allocate.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+
+import torch
+
+from . import _C
+
+
+def _stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _require_cuda(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"egc_amd: {what} must live on a ROCm device (got {t.device}); the EGC hot path is HIP-only "
+            "and has no CPU fallback")
+
+
+class CSRGraph:
+    """CSR by destination + degree statistics + long-row plan, all on one GPU."""
+
+    def __init__(self, n_nodes, n_edges, rowptr, col, edge_id, dis_raw, dis_looped, max_index, plan):
+        self.n_nodes, self.n_edges = int(n_nodes), int(n_edges)
+        self.rowptr, self.col, self.edge_id = rowptr, col, edge_id
+        self.dis_raw, self.dis_looped, self.max_index, self.plan = dis_raw, dis_looped, max_index, plan
+        self.device = rowptr.device
+
+    # -- construction ---------------------------------------------------------------------
+    @classmethod
+    def from_edge_index(cls, edge_index: torch.Tensor, num_nodes: int) -> "CSRGraph":
+        """COO ``edge_index`` (int64 [2, E], row 0 = source, row 1 = destination) -> CSRGraph."""
+        _require_cuda(edge_index, "edge_index")
+        if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.size(0) != 2:
+            raise RuntimeError("egc_amd: edge_index must be an int64 tensor of shape [2, E]")
+        lib = _C.load()
+        dev = edge_index.device
+        ei = edge_index.contiguous()
+        n, e = int(num_nodes), int(ei.size(1))
+        with torch.cuda.device(dev):
+            rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+            col = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
+            edge_id = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
+            max_index = torch.empty(1, dtype=torch.int32, device=dev)
+            ws_bytes = lib.egc_coo_to_csr_workspace_bytes(n, e)
+            ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+            _C.check(lib.egc_coo_to_csr(ei[0].data_ptr(), ei[1].data_ptr(), e, n, rowptr.data_ptr(), col.data_ptr(),
+                                        edge_id.data_ptr(), max_index.data_ptr(), ws.data_ptr(), ws.numel(),
+                                        _stream_ptr(dev)), "egc_coo_to_csr")
+            return cls._prepare(n, e, rowptr, col, edge_id, max_index)
+
+    @classmethod
+    def from_csr(cls, rowptr: torch.Tensor, col: torch.Tensor, num_nodes: int | None = None) -> "CSRGraph":
+        """Existing CSR keyed by destination (``adj_t``: row = destination, col = source)."""
+        _require_cuda(rowptr, "rowptr")
+        dev = rowptr.device
+        n = int(rowptr.numel() - 1) if num_nodes is None else int(num_nodes)
+        e = int(col.numel())
+        rowptr = rowptr.to(torch.int32).contiguous()
+        col32 = col.to(torch.int32).contiguous() if e > 0 else torch.empty(1, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            edge_id = torch.arange(max(e, 1), dtype=torch.int32, device=dev)
+            max_index = torch.full((1,), n - 1, dtype=torch.int32, device=dev)
+            return cls._prepare(n, e, rowptr, col32, edge_id, max_index)
+
+    @classmethod
+    def _prepare(cls, n, e, rowptr, col, edge_id, max_index) -> "CSRGraph":
+        lib = _C.load()
+        dev = rowptr.device
+        dis_raw = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
+        dis_looped = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
+        plan = torch.empty(lib.egc_plan_ints(n, e), dtype=torch.int32, device=dev)
+        _C.check(lib.egc_csr_prepare(n, e, rowptr.data_ptr(), col.data_ptr(), dis_raw.data_ptr(),
+                                     dis_looped.data_ptr(), plan.data_ptr(), _stream_ptr(dev)), "egc_csr_prepare")
+        return cls(n, e, rowptr, col, edge_id, dis_raw, dis_looped, max_index, plan)
+
+    # -- C view -----------------------------------------------------------------------------
+    def c_struct(self) -> _C.EgcGraph:
+        return _C.EgcGraph(self.n_nodes, self.n_edges, self.rowptr.data_ptr(), self.col.data_ptr(),
+                           self.edge_id.data_ptr(), self.dis_raw.data_ptr(), self.dis_looped.data_ptr(),
+                           self.max_index.data_ptr(), self.plan.data_ptr())
+
+    def long_row_stats(self):
+        """(n_long_rows, n_chunks) -- synchronises; diagnostics only."""
+        h = self.plan[:2].cpu()
+        return int(h[0]), int(h[1])
+
+
+class SparseTensor:
+    """Stand-in for ``torch_sparse.SparseTensor`` restricted to what the EGC layers need: an
+    ``adj_t`` whose rows are destinations and columns are sources (experiments/utils.py:107-113,
+    mag/configs.py:84-85).  Values are ignored -- the reference drops them too (utils.py:103-104)."""
+
+    def __init__(self, row: torch.Tensor = None, col: torch.Tensor = None, value=None, sparse_sizes=None,
+                 is_sorted: bool = False, rowptr: torch.Tensor = None):
+        if sparse_sizes is None:
+            raise RuntimeError("egc_amd.SparseTensor: sparse_sizes=(N, N) is required")
+        self._sizes = (int(sparse_sizes[0]), int(sparse_sizes[1]))
+        if rowptr is not None:
+            self.graph = CSRGraph.from_csr(rowptr, col, self._sizes[0])
+        else:
+            # row = destination, col = source  ->  edge_index = [col; row]
+            self.graph = CSRGraph.from_edge_index(torch.stack([col.long(), row.long()]), self._sizes[0])
+
+    def sparse_sizes(self):
+        return self._sizes
+
+    def sparse_size(self, dim):
+        return self._sizes[dim]
+
+    def size(self, dim):
+        return self._sizes[dim]
+
+
+class GraphCache:
+    """Small LRU of CSRGraphs keyed by the identity of the ``edge_index`` tensor, so that the
+    layers of one network share one COO->CSR conversion per batch (SURVEY.md call stack d).
+    The cache keeps a reference to the key tensor, so its storage cannot be recycled under us."""
+
+    def __init__(self, capacity: int = 4):
+        self.capacity = capacity
+        self._items: "OrderedDict[tuple, tuple]" = OrderedDict()
+
+    def get(self, edge_index: torch.Tensor, num_nodes: int) -> CSRGraph:
+        key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), int(num_nodes),
+               edge_index.device)
+        hit = self._items.get(key)
+        if hit is not None and hit[0] is edge_index:
+            self._items.move_to_end(key)
+            return hit[1]
+        g = CSRGraph.from_edge_index(edge_index, num_nodes)
+        self._items[key] = (edge_index, g)
+        while len(self._items) > self.capacity:
+            self._items.popitem(last=False)
+        return g
+
+    def clear(self):
+        self._items.clear()
+
+
+GLOBAL_GRAPH_CACHE = GraphCache()
+
+
+def graph_from_input(edge_index, num_nodes: int) -> CSRGraph:
+    """Dispatch on the two input forms of the reference layers (Tensor COO or SparseTensor adj_t)."""
+    if isinstance(edge_index, CSRGraph):
+        return edge_index
+    if isinstance(edge_index, SparseTensor):
+        return edge_index.graph
+    if isinstance(edge_index, torch.Tensor):
+        if edge_index.layout == torch.sparse_csr:
+            return CSRGraph.from_csr(edge_index.crow_indices(), edge_index.col_indices(), num_nodes)
+        return GLOBAL_GRAPH_CACHE.get(edge_index, num_nodes)
+    raise RuntimeError(f"egc_amd: unsupported edge_index type {type(edge_index)}")

@@ -1,0 +1,107 @@
+"""Drop-in ``EGConv`` backed by the fused gfx950 kernels.
+
+Mirrors the constructor signature, attributes, parameter names/shapes, ``__repr__`` and error
+behaviour of the reference class (experiments/optimized_layers.py:19-286, the version upstreamed to
+PyG); ``forward`` hands (x, graph, parameters) to ``libegc_hip.so``.
+
+Semantics carried over from the reference (SURVEY.md 8a notes):
+  * weightings column order is h*A*B + a*B + b (optimized_layers.py:195-202);
+  * with ``symnorm`` among the aggregators the gcn_norm edge set (self-loops replaced by exactly one
+    per node when ``add_self_loops``) is used by EVERY aggregator (optimized_layers.py:127-156);
+  * without ``symnorm`` but with ``add_self_loops`` the loops come from
+    ``add_remaining_self_loops(edge_index)``, which infers the node count from the largest index
+    present, so trailing isolated nodes get none (optimized_layers.py:158-166) -- a SparseTensor
+    input goes through ``fill_diag`` instead and every node gets one (168-175);
+  * ``cached=True`` pins the first graph seen (optimized_layers.py:138-139, 153-154).
+"""
+from __future__ import annotations
+
+from typing import Iterable
+
+import torch
+import torch.nn as nn
+
+from . import _C
+from .functional import egc_layer_apply, make_spec
+from .graph import CSRGraph, SparseTensor, graph_from_input
+from .layers import glorot_
+
+_AGGR_CODE = {"sum": _C.AGGR_SUM, "mean": _C.AGGR_MEAN, "symnorm": _C.AGGR_SYMNORM, "min": _C.AGGR_MIN,
+              "max": _C.AGGR_MAX, "var": _C.AGGR_VAR, "std": _C.AGGR_STD}
+
+
+class EGConv(nn.Module):
+    """Efficient Graph Convolution (reference: experiments/optimized_layers.py:19)."""
+
+    def __init__(self, in_channels: int, out_channels: int, aggrs: Iterable[str] = ("symnorm",),
+                 num_heads: int = 8, num_bases: int = 4, cached: bool = False, add_self_loops: bool = True,
+                 bias: bool = True, sigmoid: bool = False, **kwargs):
+        super().__init__()
+        if out_channels % num_heads != 0:
+            raise ValueError("out_channels must be divisible by the number of heads")
+        for a in aggrs:
+            if a not in _AGGR_CODE:
+                raise ValueError("Unsupported aggregator: {}".format(a))
+
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.num_heads, self.num_bases = num_heads, num_bases
+        self.cached, self.add_self_loops = cached, add_self_loops
+        self.aggregators = list(aggrs)
+        self.sigmoid = sigmoid
+        self.node_dim = 0
+
+        self.bases_weight = nn.Parameter(torch.empty(in_channels, (out_channels // num_heads) * num_bases))
+        self.comb_weight = nn.Linear(in_channels, num_heads * num_bases * len(self.aggregators))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter("bias", None)
+
+        codes = [_AGGR_CODE[a] for a in self.aggregators]
+        act = _C.ACT_SIGMOID if sigmoid else _C.ACT_NONE
+        has_sym = "symnorm" in self.aggregators
+        edge_set = _C.SET_LOOPED if add_self_loops else _C.SET_RAW
+        common = dict(weight_layout=_C.LAYOUT_HAB, weight_act=act)
+        # COO input: loops for every node only when gcn_norm (which knows num_nodes) adds them
+        self._spec_coo = make_spec(in_channels, out_channels, num_heads, num_bases, codes, agg_set=edge_set,
+                                   sym_set=edge_set, loops_all_nodes=has_sym, **common)
+        # adj_t input: gcn_norm(SparseTensor) / fill_diag put a loop on every node
+        self._spec_adj = make_spec(in_channels, out_channels, num_heads, num_bases, codes, agg_set=edge_set,
+                                   sym_set=edge_set, loops_all_nodes=True, **common)
+        self._cached_graph = None
+        self._wcat_key, self._wcat = None, None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        glorot_(self.bases_weight)
+        self.comb_weight.reset_parameters()
+        if self.bias is not None:
+            nn.init.zeros_(self.bias)
+        self._cached_graph = None
+        self._wcat_key, self._wcat = None, None
+
+    def _packed_weights(self):
+        params = [self.bases_weight, self.comb_weight.weight]
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            return torch.cat([self.bases_weight, self.comb_weight.weight.t()], dim=1)
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if key != self._wcat_key:
+            with torch.no_grad():
+                self._wcat = torch.cat([self.bases_weight, self.comb_weight.weight.t()], dim=1).contiguous()
+            self._wcat_key = key
+        return self._wcat
+
+    def forward(self, x, edge_index):
+        if self.cached and self._cached_graph is not None:
+            graph, spec = self._cached_graph
+        else:
+            graph = graph_from_input(edge_index, x.size(self.node_dim))
+            is_coo = isinstance(edge_index, torch.Tensor) and edge_index.layout == torch.strided
+            spec = self._spec_coo if is_coo else self._spec_adj
+            if self.cached:
+                self._cached_graph = (graph, spec)
+        return egc_layer_apply(graph, spec, x, self._packed_weights(), self.comb_weight.bias, self.bias)
+
+    def __repr__(self):
+        return "{}({}, {}, {})".format(self.__class__.__name__, self.in_channels, self.out_channels,
+                                       self.aggregators)

@@ -1,0 +1,91 @@
+"""Synthetic workloads shaped like the BASELINE.json configs.  Datasets are not
+available offline, so every benchmark / full-size parity input is generated here, seeded, on the CPU."""
+from __future__ import annotations
+
+import torch
+
+ARXIV_NODES = 169_343
+ARXIV_DIRECTED_EDGES = 1_166_243
+
+
+def heavy_tailed_graph(n_nodes: int, n_directed: int, seed: int = 0) -> torch.Tensor:
+    """Directed pairs with a heavy-tailed destination distribution (dst = floor(N u^3)), uniform
+    sources; then symmetrised, coalesced, self-pairs removed -- the preprocessing the reference
+    applies to ogbn-arxiv (``to_undirected``, experiments/arxiv/configs.py:100).  Returns int64 [2, E]
+    sorted by (source, destination)."""
+    g = torch.Generator().manual_seed(seed)
+    u = torch.rand(n_directed, generator=g, dtype=torch.float64)
+    dst = (n_nodes * u ** 3).long().clamp_(max=n_nodes - 1)
+    src = torch.randint(0, n_nodes, (n_directed,), generator=g)
+    a = torch.cat([src, dst])
+    b = torch.cat([dst, src])
+    keep = a != b
+    key = torch.unique(a[keep] * n_nodes + b[keep])
+    return torch.stack([key // n_nodes, key % n_nodes])
+
+
+def arxiv_like(seed: int = 0) -> tuple[torch.Tensor, int]:
+    """BASELINE config 2 graph: N = 169,343, ~2.3 M symmetrised edges."""
+    return heavy_tailed_graph(ARXIV_NODES, ARXIV_DIRECTED_EDGES, seed), ARXIV_NODES
+
+
+def molecule_batch(n_graphs: int = 2048, mean_nodes: float = 25.5, std_nodes: float = 12.0, min_nodes: int = 2,
+                   max_nodes: int = 222, seed: int = 0) -> tuple[torch.Tensor, int, torch.Tensor]:
+    """BASELINE config 3 (molhiv-like): disjoint union of small tree-plus-a-few-rings graphs, about
+    2.15 directed edges per node.  Returns (edge_index, n_nodes, batch)."""
+    g = torch.Generator().manual_seed(seed)
+    sizes = (torch.randn(n_graphs, generator=g) * std_nodes + mean_nodes).round().long().clamp_(min_nodes, max_nodes)
+    offs = torch.cumsum(sizes, 0) - sizes
+    srcs, dsts = [], []
+    for k in range(n_graphs):
+        n, o = int(sizes[k]), int(offs[k])
+        if n < 2:
+            continue
+        child = torch.arange(1, n)
+        parent = (torch.rand(n - 1, generator=g) * child).long()  # random recursive tree
+        extra = max(0, int(round(0.075 * n)))
+        ea = torch.randint(0, n, (extra,), generator=g)
+        eb = torch.randint(0, n, (extra,), generator=g)
+        ok = ea != eb
+        s = torch.cat([child, parent, ea[ok], eb[ok]]) + o
+        d = torch.cat([parent, child, eb[ok], ea[ok]]) + o
+        srcs.append(s)
+        dsts.append(d)
+    ei = torch.stack([torch.cat(srcs), torch.cat(dsts)])
+    batch = torch.repeat_interleave(torch.arange(n_graphs), sizes)
+    return ei, int(sizes.sum()), batch
+
+
+def knn_superpixel_batch(n_graphs: int = 2048, k: int = 8, lo: int = 85, hi: int = 150, seed: int = 0):
+    """BASELINE config 4 (CIFAR10-superpixel-like): k-NN graphs of random 2-D points, k in-neighbours
+    per node.  Returns (edge_index, n_nodes, batch)."""
+    g = torch.Generator().manual_seed(seed)
+    sizes = torch.randint(lo, hi + 1, (n_graphs,), generator=g)
+    offs = torch.cumsum(sizes, 0) - sizes
+    srcs, dsts = [], []
+    for i in range(n_graphs):
+        n, o = int(sizes[i]), int(offs[i])
+        pts = torch.rand(n, 2, generator=g)
+        d = torch.cdist(pts, pts)
+        d.fill_diagonal_(float("inf"))
+        nbr = d.topk(k, largest=False).indices  # [n, k] sources for each destination
+        dsts.append(torch.arange(n).repeat_interleave(k) + o)
+        srcs.append(nbr.reshape(-1) + o)
+    ei = torch.stack([torch.cat(srcs), torch.cat(dsts)])
+    batch = torch.repeat_interleave(torch.arange(n_graphs), sizes)
+    return ei, int(sizes.sum()), batch
+
+
+def algorithmic_bytes(n_nodes: int, e_eff: int, f_in: int, f_g: int, f_out: int, w_cols: int, symnorm: bool,
+                      idx_bytes: int = 4) -> dict:
+    """SURVEY.md 8(d) byte model, term by term.  ``layer`` is the figure of the survey (weightings
+    counted as fused); ``aggregate_kernel`` is what the aggregate+combine launch itself must move
+    (it reads the materialised weightings instead of x, and does not write bases)."""
+    t = dict(
+        gather=e_eff * f_g * 4, col=e_eff * idx_bytes, rowptr=(n_nodes + 1) * idx_bytes,
+        deg=n_nodes * 4 if symnorm else 0, x=n_nodes * f_in * 4, bases_write=n_nodes * f_g * 4,
+        out=n_nodes * f_out * 4, weightings=n_nodes * w_cols * 4)
+    t["layer"] = t["gather"] + t["col"] + t["rowptr"] + t["deg"] + t["x"] + t["bases_write"] + t["out"]
+    t["aggregate_kernel"] = t["gather"] + t["col"] + t["rowptr"] + t["deg"] + t["weightings"] + t["out"]
+    t["gemm_kernel"] = t["x"] + t["bases_write"] + t["weightings"]
+    return t

@@ -1,0 +1,177 @@
+/*
+ * egc_hip.h -- C ABI of libegc_hip.so: the MI355X (gfx950) native hot path of the EGC layer.
+ *
+ * This is the drop-in boundary.  The reference
+ * (shyam196/egc) is pure Python; its layer classes reach native code only
+ * through third-party torch extensions.  Each entry point below names the
+ * reference call site(s) whose native work it replaces.  All pointers are
+ * DEVICE pointers unless stated otherwise; all float tensors are fp32,
+ * contiguous, row-major; indices handed IN are int64 (PyG edge_index), indices
+ * held by the library's CSR are int32.  No torch types cross this boundary.
+ * Nothing here allocates, frees or synchronises: every launch goes to the
+ * caller's stream and is safe to capture into a hipGraph.
+ *
+ * Error convention: every function returns an egc_status (0 = ok).  The Python
+ * host (egc_amd/_C.py) turns non-zero codes into RuntimeError, mirroring
+ * TORCH_CHECK failures of the torch_scatter / torch_sparse ops it replaces.
+ */
+#ifndef EGC_HIP_H
+#define EGC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* egc_stream_t; /* a hipStream_t */
+
+typedef enum {
+  EGC_OK = 0,
+  EGC_ERR_INVALID = 1,     /* bad argument (null pointer, negative size, unknown enum, shape limits) */
+  EGC_ERR_WORKSPACE = 2,   /* caller workspace too small */
+  EGC_ERR_HIP = 3,         /* a HIP runtime call / launch failed; see egc_last_error() */
+  EGC_ERR_UNSUPPORTED = 4  /* valid request outside the implemented envelope */
+} egc_status;
+
+/* Aggregators: union of layers.py:154-159 (add, mean, max, min, symadd, var, std) and
+ * optimized_layers.py:92-94 (sum, mean, symnorm, min, max, var, std). */
+typedef enum {
+  EGC_AGGR_SUM = 0, EGC_AGGR_MEAN = 1, EGC_AGGR_MAX = 2, EGC_AGGR_MIN = 3,
+  EGC_AGGR_VAR = 4, EGC_AGGR_STD = 5, EGC_AGGR_SYMNORM = 6
+} egc_aggr;
+
+/* Which edge set an aggregator reduces over (SURVEY.md 8a note 2):
+ *   RAW    -- the CSR entries as given (duplicates and self-loops included);
+ *   LOOPED -- the CSR entries minus every self-loop, plus exactly one self-loop per node
+ *             (what gcn_norm / add_remaining_self_loops / fill_diag produce). */
+typedef enum { EGC_SET_RAW = 0, EGC_SET_LOOPED = 1 } egc_edge_set;
+
+/* Column order of the per-node weightings row:
+ *   HBA: column = h*B*A + b*A + a   (EfficientGraphConv, layers.py:127-129)
+ *   HAB: column = h*A*B + a*B + b   (EGConv, optimized_layers.py:195-202) */
+typedef enum { EGC_LAYOUT_HBA = 0, EGC_LAYOUT_HAB = 1 } egc_weight_layout;
+
+/* Nonlinearity on the weightings (layers.py:112-125, optimized_layers.py:183-184).
+ * SOFTMAX is over the joint B*A axis per head. */
+typedef enum { EGC_ACT_NONE = 0, EGC_ACT_SOFTMAX = 1, EGC_ACT_SIGMOID = 2, EGC_ACT_HARDTANH = 3 } egc_weight_act;
+
+#define EGC_MAX_AGGRS 8
+#define EGC_MAX_BASIS_WIDTH 1024   /* B * (F_out / H) */
+#define EGC_MAX_WEIGHT_WIDTH 2048  /* H * B * A */
+#define EGC_MAX_OUT_CHANNELS 2048
+
+/* Rows with more than EGC_LONG_ROW_THRESHOLD entries are reduced in chunks of
+ * EGC_LONG_ROW_CHUNK entries by separate wavefronts and merged (degree-skew handling). */
+#define EGC_LONG_ROW_THRESHOLD 128
+#define EGC_LONG_ROW_CHUNK 128
+
+/* ------------------------------------------------------------------------------------------
+ * Graph: CSR keyed by DESTINATION, entries of one row kept in input (edge_index) order.
+ * Replaces torch_sparse.SparseTensor storage (rowptr / col; experiments/utils.py:107-113),
+ * the gather index of MessagePassing.propagate and the degree pass of gcn_norm.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  int64_t n_nodes;
+  int64_t n_edges;
+  const int32_t* rowptr;      /* [n_nodes+1] */
+  const int32_t* col;         /* [n_edges] source node of each entry */
+  const int32_t* edge_id;     /* [n_edges] position of the entry in the input edge list; may be NULL */
+  const float* dis_raw;       /* [n_nodes] indeg^-1/2 over RAW entries (0 where indeg==0); NULL if unused */
+  const float* dis_looped;    /* [n_nodes] (non-self indeg + 1)^-1/2; NULL if unused */
+  const int32_t* max_index;   /* device scalar: largest node id present in edge_index (-1 if none) */
+  const int32_t* plan;        /* [egc_plan_ints(n_nodes,n_edges)] long-row work plan from egc_csr_prepare */
+} egc_graph;
+
+/* int32 words the caller must allocate for egc_graph.plan. */
+int64_t egc_plan_ints(int64_t n_nodes, int64_t n_edges);
+
+/* Bytes of scratch egc_coo_to_csr needs (device). */
+size_t egc_coo_to_csr_workspace_bytes(int64_t n_nodes, int64_t n_edges);
+
+/* COO (edge_index[0]=src, edge_index[1]=dst, int64, any order, duplicates and self-loops allowed)
+ * -> CSR by destination with a STABLE order inside each row.  Replaces the per-call
+ * index_select/scatter index handling of MessagePassing.propagate (layers.py:191-193,
+ * optimized_layers.py:191-193) and ToSparseTensor (experiments/utils.py:95-113).
+ * Writes rowptr[n_nodes+1], col[n_edges], edge_id[n_edges], max_index[1].
+ * Returns EGC_ERR_INVALID if n_nodes or n_edges >= 2^31.  Out-of-range node ids are NOT detected. */
+int egc_coo_to_csr(const int64_t* src, const int64_t* dst, int64_t n_edges, int64_t n_nodes,
+                   int32_t* rowptr, int32_t* col, int32_t* edge_id, int32_t* max_index,
+                   void* workspace, size_t workspace_bytes, egc_stream_t stream);
+
+/* Degree statistics + long-row plan for an existing CSR.  Replaces gcn_norm's degree scatter and
+ * pow(-0.5) (layers.py:173-178, optimized_layers.py:131-137) -- the per-edge weight
+ * dis[src]*dis[dst] is formed inside the aggregate kernel, never materialised.
+ * dis_raw / dis_looped may be NULL (skipped). */
+int egc_csr_prepare(int64_t n_nodes, int64_t n_edges, const int32_t* rowptr, const int32_t* col,
+                    float* dis_raw, float* dis_looped, int32_t* plan, egc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Layer description (the arguments of EfficientGraphConv.__init__ layers.py:13-27 /
+ * EGConv.__init__ optimized_layers.py:74-86 that shape the computation).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t in_channels;
+  int32_t out_channels;
+  int32_t num_heads;
+  int32_t num_bases;
+  int32_t num_aggrs;
+  int32_t aggrs[EGC_MAX_AGGRS];   /* egc_aggr codes, in the layer's aggregator order */
+  int32_t agg_set;                /* egc_edge_set for sum/mean/max/min/var/std */
+  int32_t sym_set;                /* egc_edge_set for symnorm */
+  int32_t loops_all_nodes;        /* LOOPED self-loop for every node (1) or only ids <= *max_index (0):
+                                     add_remaining_self_loops without num_nodes, optimized_layers.py:164 */
+  int32_t weight_layout;          /* egc_weight_layout */
+  int32_t weight_act;             /* egc_weight_act */
+} egc_layer;
+
+/* Leading dimension (floats) the library wants for the `bases` intermediate: B*L rounded up to 4. */
+int32_t egc_bases_ld(const egc_layer* layer);
+
+/* Step 1 -- basis transform + weightings Linear as ONE fp32 MFMA GEMM:
+ *   [bases | weightings] = x[N,F_in] @ wcat[F_in, F_g+W]  (+ bcat on the W columns)
+ * Replaces torch.matmul(x, bases_weight) (layers.py:97-101, optimized_layers.py:180) and
+ * comb_weights(x) (layers.py:110, optimized_layers.py:182).
+ * wcat = [bases_weight (F_in x F_g) | comb.weight^T (F_in x W)] row-major; bcat = comb.bias [W] or NULL.
+ * bases is written with leading dimension ldb (>= F_g, pad columns zeroed); weightings dense [N,W]. */
+int egc_basis_transform_f32(const float* x, const float* wcat, const float* bcat, int64_t n_nodes,
+                            int32_t f_in, int32_t f_g, int32_t w_cols, float* bases, int32_t ldb,
+                            float* weightings, egc_stream_t stream);
+
+/* Scratch bytes egc_aggregate_combine_f32 needs for this layer on this graph. */
+size_t egc_aggregate_workspace_bytes(const egc_layer* layer, int64_t n_nodes, int64_t n_edges);
+
+/* Step 2+3 -- fused multi-aggregator neighbourhood reduction + per-node head x basis x aggregator
+ * combine (+ weight nonlinearity, + bias).  Replaces, in one pass over the CSR:
+ *   gather x_j                      MessagePassing.__collect__ (via propagate, layers.py:191-193)
+ *   symnorm message scaling         layers.py:195-199, optimized_layers.py:226-230
+ *   scatter / spmm per aggregator   layers.py:201-225, optimized_layers.py:215-278
+ *   stack + softmax/sigmoid/hardtanh + weighted sum / bmm + bias
+ *                                   layers.py:109-138, optimized_layers.py:183-208
+ * out is [n_nodes, out_channels].  arg_max / arg_min (each [n_nodes, ldb] int32, or NULL) receive, per
+ * basis column, the INPUT edge position (graph.edge_id) of the first entry attaining the extremum
+ * (n_edges for the self-loop of a LOOPED set, -1 for an empty row) -- what torch_scatter's
+ * scatter_max/min return as `arg` and autograd routes the gradient through. */
+int egc_aggregate_combine_f32(const egc_graph* graph, const egc_layer* layer, const float* bases, int32_t ldb,
+                              const float* weightings, const float* bias, float* out,
+                              int32_t* arg_max, int32_t* arg_min,
+                              void* workspace, size_t workspace_bytes, egc_stream_t stream);
+
+/* Whole layer forward = egc_basis_transform_f32 + egc_aggregate_combine_f32
+ * (EfficientGraphConv.forward layers.py:89-140 / EGConv.forward optimized_layers.py:177-210
+ * after graph preparation).  bases [N,ldb] and weightings [N,W] are caller-provided intermediates. */
+int egc_layer_forward_f32(const egc_graph* graph, const egc_layer* layer, const float* x, const float* wcat,
+                          const float* bcat, const float* bias, float* bases, int32_t ldb, float* weightings,
+                          float* out, void* workspace, size_t workspace_bytes, egc_stream_t stream);
+
+/* Human-readable text of the last HIP failure seen on the calling thread ("" if none). */
+const char* egc_last_error(void);
+
+/* Library build tag: "egc_hip <version> gfx950". */
+const char* egc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EGC_HIP_H */

@@ -1,0 +1,161 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol of
+include/egc_hip.h (no compute calls without a GPU), and the drop-in modules mirror the reference's
+constructor contract, parameter names/shapes, repr and error behaviour."""
+import json
+import os
+import re
+
+import pytest
+import torch
+
+import egc_amd
+from egc_amd import _C
+from golden_util import golden_names, load_golden
+from oracle import egc_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "egc_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(egc_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_C.SYMBOLS), (declared ^ set(_C.SYMBOLS))
+    lib = _C.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.egc_version().decode().endswith("gfx950")
+    # pure host-side size queries (no GPU touched)
+    assert lib.egc_plan_ints(10, 0) == 4 + 2 * 1 + 2 * 1
+    assert lib.egc_plan_ints(-1, 0) == -1
+
+
+def test_header_constants_match_python_binding():
+    hdr = open(os.path.join(ROOT, "include", "egc_hip.h")).read()
+    assert int(re.search(r"#define EGC_MAX_AGGRS (\d+)", hdr).group(1)) == _C.EGC_MAX_AGGRS
+    assert int(re.search(r"#define EGC_LONG_ROW_THRESHOLD (\d+)", hdr).group(1)) == _C.LONG_ROW_THRESHOLD
+    assert int(re.search(r"#define EGC_LONG_ROW_CHUNK (\d+)", hdr).group(1)) == _C.LONG_ROW_CHUNK
+
+
+def test_no_cpu_fallback():
+    conv = egc_amd.EGConv(8, 8, aggrs=["sum"], num_heads=2, num_bases=2)
+    x = torch.randn(4, 8)
+    ei = torch.tensor([[0, 1], [1, 2]])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        conv(x, ei)
+    lay = egc_amd.EfficientGraphConv(8, 8, 2, 2, False, aggrs=["add"])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        lay(x=x, edge_index=ei)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_C, "_lib", None)
+    monkeypatch.setattr(_C, "_LIB_PATH", "/nonexistent/libegc_hip.so")
+    with pytest.raises(RuntimeError, match="not built"):
+        _C.load()
+
+
+def test_product_package_never_imports_the_oracle():
+    pat = re.compile(r"^\s*(from|import)\s+\S*oracle", re.M)
+    for fn in os.listdir(os.path.join(ROOT, "egc_amd")):
+        if fn.endswith(".py"):
+            assert not pat.search(open(os.path.join(ROOT, "egc_amd", fn)).read()), fn
+
+
+# ---- EfficientGraphConv contract (experiments/layers.py:13-80, 142-147) ----------------------
+
+def test_efficient_graph_conv_state_dict_and_repr():
+    conv = egc_amd.EfficientGraphConv(168, 168, num_heads=8, num_bases=4, softmax_weights=False, aggrs=["symadd"])
+    sd = conv.state_dict()
+    assert list(sd.keys()) == ["bias", "comb_weights.weight", "comb_weights.bias", "bases_weight.0",
+                               "bases_weight.1", "bases_weight.2", "bases_weight.3"]
+    assert tuple(sd["comb_weights.weight"].shape) == (32, 168)
+    assert all(tuple(sd[f"bases_weight.{b}"].shape) == (168, 21) for b in range(4))
+    assert sum(p.numel() for p in conv.parameters()) == orc.layer_param_count(168, 168, 8, 4, 1)
+    # format of output/pretrained.txt:47-60
+    assert conv.extra_repr() == "(In=168, Out=168, H=8, B=4, SL=True, SM=False, Bias=True)"
+    assert "(0): _AggLayer(symadd)" in repr(conv)
+    assert float(conv.bias.abs().sum()) == 0.0
+    bound = orc.glorot_bound(168, 21)
+    assert all(float(w.abs().max()) <= bound for w in conv.bases_weight)
+
+
+def test_efficient_graph_conv_ctor_errors():
+    with pytest.raises(AssertionError):
+        egc_amd.EfficientGraphConv(8, 8, 2, 2, False)  # aggrs is None (layers.py:29)
+    with pytest.raises(AssertionError):
+        egc_amd.EfficientGraphConv(8, 8, 2, 2, True, aggrs=["add"], sigmoid_weights=True)
+    with pytest.raises(AssertionError):
+        egc_amd.EfficientGraphConv(8, 8, 2, 2, False, aggrs=["add"], sigmoid_weights=True, hardtanh_weights=True)
+    with pytest.raises(AssertionError):
+        egc_amd.EfficientGraphConv(8, 9, 2, 2, False, aggrs=["add"])  # out % heads
+    conv = egc_amd.EfficientGraphConv(8, 8, 2, 2, False, aggrs=["add"], bias=False, some_future_kwarg=1)
+    assert conv.bias is None and "bias" not in conv.state_dict()
+
+
+def test_import_paths_of_the_reference_resolve():
+    from experiments.layers import EfficientGraphConv
+    from experiments.optimized_layers import EGConv
+    assert EfficientGraphConv is egc_amd.EfficientGraphConv and EGConv is egc_amd.EGConv
+
+
+# ---- EGConv contract (experiments/optimized_layers.py:74-122, 280-286) -----------------------
+
+def test_egconv_state_dict_repr_and_defaults():
+    conv = egc_amd.EGConv(128, 352, aggrs=["mean"], num_heads=8, num_bases=4, cached=True)
+    sd = conv.state_dict()
+    assert list(sd.keys()) == ["bases_weight", "bias", "comb_weight.weight", "comb_weight.bias"]
+    assert tuple(sd["bases_weight"].shape) == (128, 176) and tuple(sd["comb_weight.weight"].shape) == (32, 128)
+    assert repr(conv) == "EGConv(128, 352, ['mean'])"
+    d = egc_amd.EGConv(16, 16)
+    assert d.aggregators == ["symnorm"] and d.num_heads == 8 and d.num_bases == 4 and not d.cached
+    assert d.add_self_loops and d.bias is not None and not d.sigmoid
+
+
+def test_egconv_ctor_errors():
+    with pytest.raises(ValueError, match="divisible"):
+        egc_amd.EGConv(8, 9, num_heads=2)
+    with pytest.raises(ValueError, match="Unsupported aggregator"):
+        egc_amd.EGConv(8, 8, aggrs=["add"], num_heads=2)  # 'add' is the layers.py name, not EGConv's
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_state_dicts_load_strictly(name):
+    """Parameter names/shapes saved from the REFERENCE modules load into the drop-ins unchanged."""
+    g = load_golden(name)
+    m = g["meta"]
+    if m["kind"] == "lay":
+        layer = egc_amd.EfficientGraphConv(m["fin"], m["fout"], m["H"], m["B"], m["softmax"], aggrs=m["aggrs"],
+                                           add_self_loops=m["add_self_loops"], bias=m["bias"],
+                                           sigmoid_weights=m["sigmoid"], hardtanh_weights=m["hardtanh"])
+        ref_repr = m["repr"]
+        # the reference prints '_AggLayer(<name>)' children and the same extra_repr line
+        assert layer.extra_repr() in ref_repr
+        for a in m["aggrs"]:
+            assert f"_AggLayer({a})" in ref_repr and f"_AggLayer({a})" in repr(layer)
+    else:
+        layer = egc_amd.EGConv(m["fin"], m["fout"], aggrs=m["aggrs"], num_heads=m["H"], num_bases=m["B"],
+                               add_self_loops=m["add_self_loops"], bias=m["bias"], sigmoid=m["sigmoid"])
+        assert repr(layer) == m["repr"]
+    layer.load_state_dict({k: torch.from_numpy(v) for k, v in g["params"].items()}, strict=True)
+
+
+def test_packed_weight_layout_matches_oracle_bases():
+    """[bases_weight | comb.weight^T] packing: column b*L + l of the bases block is basis b, channel l."""
+    conv = egc_amd.EfficientGraphConv(12, 8, 2, 3, False, aggrs=["add", "max"])
+    w = conv._packed_weights()
+    assert tuple(w.shape) == (12, 3 * 4 + 2 * 3 * 2)
+    for b in range(3):
+        assert torch.equal(w[:, b * 4:(b + 1) * 4], conv.bases_weight[b].detach())
+    assert torch.equal(w[:, 12:], conv.comb_weights.weight.detach().t())
+    # cache invalidates on in-place parameter updates
+    with torch.no_grad():
+        conv.bases_weight[0].add_(1.0)
+    assert torch.equal(conv._packed_weights()[:, :4], conv.bases_weight[0].detach())
+
+
+def test_workload_byte_model_matches_survey_config2():
+    """SURVEY.md 8(d) worked example: 864.2 MB at E_eff = 2,484,941."""
+    from egc_amd.workloads import algorithmic_bytes
+    t = algorithmic_bytes(169343, 2484941, 128, 64, 128, 128, True)
+    assert abs(t["layer"] / 1e6 - 864.2) < 0.2

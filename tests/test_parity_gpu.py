@@ -1,0 +1,295 @@
+"""GPU parity tests: the HIP path (through the C ABI, via the drop-in modules) against
+  (1) the committed golden vectors produced by the reference's own layer code, and
+  (2) the numpy oracle on seeded inputs (edge cases, long rows, wide shapes, full config-2 size).
+
+Tolerance (north_star): fp32 results within 1e-5 of the reference, measured scale-relative
+(max |diff| / max(1, max |ref|)); integer outputs (CSR, argmax) bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import golden_names, load_golden, oracle_forward, rel_err
+from oracle import egc_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def build_layer(meta, params, dev):
+    import egc_amd
+    if meta["kind"] == "lay":
+        layer = egc_amd.EfficientGraphConv(
+            meta["fin"], meta["fout"], num_heads=meta["H"], num_bases=meta["B"], softmax_weights=meta["softmax"],
+            add_self_loops=meta["add_self_loops"], bias=meta["bias"], aggrs=meta["aggrs"],
+            sigmoid_weights=meta["sigmoid"], hardtanh_weights=meta["hardtanh"])
+    else:
+        layer = egc_amd.EGConv(meta["fin"], meta["fout"], aggrs=meta["aggrs"], num_heads=meta["H"],
+                               num_bases=meta["B"], add_self_loops=meta["add_self_loops"], bias=meta["bias"],
+                               sigmoid=meta["sigmoid"])
+    layer.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    return layer.to(dev).eval()
+
+
+def run_layer(layer, g, dev):
+    import egc_amd
+    x = torch.from_numpy(g["x"]).to(dev)
+    ei = torch.from_numpy(g["edge_index"]).to(dev)
+    n = g["x"].shape[0]
+    if g["meta"]["sparse"]:
+        arg = egc_amd.SparseTensor(row=ei[1], col=ei[0], sparse_sizes=(n, n))
+    else:
+        arg = ei
+    with torch.no_grad():
+        out = layer(x, arg) if g["meta"]["kind"] == "opt" else layer(x=x, edge_index=arg)
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_golden(name):
+    """HIP layer == output of the reference's own layer code on the committed fixture."""
+    dev = _dev()
+    g = load_golden(name)
+    layer = build_layer(g["meta"], g["params"], dev)
+    out = run_layer(layer, g, dev)
+    assert out.shape == g["out"].shape
+    assert rel_err(out, g["out"]) <= TOL, f"{name}: rel err {rel_err(out, g['out']):.3e}"
+    # and against the oracle (pins the oracle and the HIP path to each other as well)
+    assert rel_err(out, oracle_forward(g, orc)) <= TOL
+
+
+def test_repr_matches_reference_goldens():
+    for name in golden_names():
+        g = load_golden(name)
+        layer = build_layer(g["meta"], g["params"], torch.device("cpu"))
+        if g["meta"]["kind"] == "opt":
+            assert repr(layer) == g["meta"]["repr"]
+
+
+def _rand_graph(rng, n, e):
+    ei = rng.integers(0, n, size=(2, e)).astype(np.int64)
+    return ei
+
+
+@pytest.mark.parametrize("n,e", [(1, 0), (7, 0), (64, 500), (1000, 20000), (50000, 400000)])
+def test_coo_to_csr_bit_exact(n, e):
+    """CSR build is integer work: rowptr / col / edge_id must equal the stable-sort oracle exactly."""
+    import egc_amd
+    dev = _dev()
+    rng = np.random.default_rng(n + e)
+    ei = _rand_graph(rng, n, e)
+    g = egc_amd.CSRGraph.from_edge_index(torch.from_numpy(ei).to(dev), n)
+    torch.cuda.synchronize()
+    rowptr, col, eid = orc.csr_from_coo(ei, n)
+    assert np.array_equal(g.rowptr.cpu().numpy().astype(np.int64), rowptr)
+    if e:
+        assert np.array_equal(g.col.cpu().numpy()[:e].astype(np.int64), col)
+        assert np.array_equal(g.edge_id.cpu().numpy()[:e].astype(np.int64), eid)
+        assert int(g.max_index.cpu()) == int(ei.max())
+    else:
+        assert int(g.max_index.cpu()) == -1
+    # degree statistics (gcn_norm's deg^-1/2), raw and self-looped conventions
+    deg = np.diff(rowptr).astype(np.float32)
+    with np.errstate(divide="ignore"):
+        dis_raw = np.where(deg > 0, 1.0 / np.sqrt(deg), 0).astype(np.float32)
+    nonself = np.bincount(ei[1][ei[0] != ei[1]], minlength=n).astype(np.float32)
+    dis_looped = (1.0 / np.sqrt(nonself + 1)).astype(np.float32)
+    np.testing.assert_allclose(g.dis_raw.cpu().numpy()[:n], dis_raw, rtol=2e-7)
+    np.testing.assert_allclose(g.dis_looped.cpu().numpy()[:n], dis_looped, rtol=2e-7)
+
+
+def _oracle_case(kind, rng, n, ei, fin, fout, H, B, aggrs, dev, **flags):
+    """Random parameters -> (HIP output, oracle output)."""
+    import egc_amd
+    torch.manual_seed(int(rng.integers(1 << 30)))
+    if kind == "lay":
+        layer = egc_amd.EfficientGraphConv(fin, fout, H, B, flags.get("softmax", False), aggrs=aggrs,
+                                           add_self_loops=flags.get("add_self_loops", True),
+                                           sigmoid_weights=flags.get("sigmoid", False),
+                                           hardtanh_weights=flags.get("hardtanh", False))
+    else:
+        layer = egc_amd.EGConv(fin, fout, aggrs=aggrs, num_heads=H, num_bases=B,
+                               add_self_loops=flags.get("add_self_loops", True), sigmoid=flags.get("sigmoid", False))
+    with torch.no_grad():
+        layer.bias.normal_()
+    x = rng.standard_normal((n, fin)).astype(np.float32)
+    sd = {k: v.numpy() for k, v in layer.state_dict().items()}
+    meta = dict(kind=kind, fin=fin, fout=fout, H=H, B=B, aggrs=aggrs, softmax=flags.get("softmax", False),
+                sigmoid=flags.get("sigmoid", False), hardtanh=flags.get("hardtanh", False),
+                add_self_loops=flags.get("add_self_loops", True), bias=True, sparse=False)
+    g = dict(meta=meta, params=sd, x=x, edge_index=ei)
+    out = run_layer(layer.to(dev).eval(), g, dev)
+    return out, oracle_forward(g, orc)
+
+
+def _hub_graph(rng, n, e, hubs):
+    """Random graph plus a few destination hubs with in-degree far above the long-row threshold."""
+    parts = [rng.integers(0, n, size=(2, e))]
+    for node, deg in hubs:
+        parts.append(np.stack([rng.integers(0, n, size=deg), np.full(deg, node)]))
+    ei = np.concatenate(parts, axis=1).astype(np.int64)
+    return ei[:, rng.permutation(ei.shape[1])]
+
+
+@pytest.mark.parametrize("kind,aggrs", [
+    ("opt", ["sum", "mean", "max", "symnorm"]), ("opt", ["min", "std", "var"]),
+    ("lay", ["symadd", "std", "max"]), ("lay", ["add", "mean", "min", "var"]),
+])
+def test_long_rows_chunk_merge_path(kind, aggrs):
+    """Rows above EGC_LONG_ROW_THRESHOLD go through the chunk + merge kernels (hubs of 129..5000)."""
+    dev = _dev()
+    rng = np.random.default_rng(7)
+    n = 3000
+    hubs = [(0, 5000), (17, 129), (18, 128), (999, 1300), (n - 1, 257), (5, 4096)]
+    ei = _hub_graph(rng, n, 12000, hubs)
+    out, ref = _oracle_case(kind, rng, n, ei, 64, 64, 8, 4, aggrs, dev)
+    assert rel_err(out, ref) <= TOL
+
+
+@pytest.mark.parametrize("hidden,H,B", [(304, 8, 8), (300, 4, 4), (352, 8, 4), (168, 8, 4), (124, 4, 4),
+                                        (296, 8, 4), (224, 4, 4), (136, 4, 4), (21, 1, 1), (16, 16, 16), (6, 2, 1)])
+def test_shipped_and_odd_shapes(hidden, H, B):
+    """(hidden, H, B) from run_pretrained.sh / train_main_table.sh incl. basis widths > 256 floats
+    (multi-slot lanes) and widths that are not multiples of 4 (padded leading dimension)."""
+    dev = _dev()
+    rng = np.random.default_rng(hidden * 31 + H)
+    n = 400
+    ei = _hub_graph(rng, n, 3000, [(3, 300)])
+    out, ref = _oracle_case("opt", rng, n, ei, hidden, hidden, H, B, ["symnorm", "max", "std"], dev)
+    assert rel_err(out, ref) <= TOL
+    out, ref = _oracle_case("lay", rng, n, ei, hidden, hidden, H, B, ["symadd", "min", "mean"], dev, softmax=True)
+    assert rel_err(out, ref) <= TOL
+
+
+def test_fin_not_multiple_of_4_and_fin_ne_fout():
+    dev = _dev()
+    rng = np.random.default_rng(3)
+    n = 257
+    ei = _rand_graph(rng, n, 2000)
+    for fin, fout in [(5, 32), (37, 64), (128, 352), (130, 16)]:
+        out, ref = _oracle_case("opt", rng, n, ei, fin, fout, 8, 4, ["sum", "max"], dev)
+        assert rel_err(out, ref) <= TOL
+
+
+def test_intermediates_match_oracle():
+    """bases / weightings written by the MFMA GEMM == oracle's fp32 matmuls (within GEMM reordering)."""
+    import egc_amd
+    from egc_amd.functional import egc_layer_forward
+    dev = _dev()
+    g = load_golden("opt_northstar_small")
+    layer = build_layer(g["meta"], g["params"], dev)
+    x = torch.from_numpy(g["x"]).to(dev)
+    graph = egc_amd.CSRGraph.from_edge_index(torch.from_numpy(g["edge_index"]).to(dev), x.size(0))
+    with torch.no_grad():
+        out, bases, weightings = egc_layer_forward(graph, layer._spec_coo, x, layer._packed_weights(),
+                                                   layer.comb_weight.bias, layer.bias, return_intermediates=True)
+    _, inter = oracle_forward(g, orc, return_intermediates=True)
+    assert rel_err(bases.cpu().numpy()[:, :inter["bases"].shape[1]], inter["bases"]) <= TOL
+    assert rel_err(weightings.cpu().numpy(), inter["weightings"]) <= TOL
+    assert rel_err(out.cpu().numpy(), g["out"]) <= TOL
+
+
+def test_cached_graph_and_shared_graph_cache():
+    """cached=True pins the first graph (optimized_layers.py:138-139); un-cached layers share one
+    CSR per edge_index tensor through the global cache."""
+    import egc_amd
+    dev = _dev()
+    rng = np.random.default_rng(11)
+    n = 100
+    ei1 = torch.from_numpy(_rand_graph(rng, n, 700)).to(dev)
+    ei2 = torch.from_numpy(_rand_graph(rng, n, 700)).to(dev)
+    x = torch.randn(n, 32, device=dev)
+    conv = egc_amd.EGConv(32, 32, aggrs=["symnorm", "max"], num_heads=4, num_bases=4, cached=True).to(dev)
+    plain = egc_amd.EGConv(32, 32, aggrs=["symnorm", "max"], num_heads=4, num_bases=4).to(dev)
+    plain.load_state_dict(conv.state_dict())
+    with torch.no_grad():
+        a1, a2 = conv(x, ei1), conv(x, ei2)      # second call must reuse graph 1
+        b1, b2 = plain(x, ei1), plain(x, ei2)
+    assert torch.equal(a1, a2) and torch.equal(a1, b1) and not torch.equal(b1, b2)
+    conv.reset_parameters()
+    assert conv._cached_graph is None
+    g_a = egc_amd.graph.GLOBAL_GRAPH_CACHE.get(ei1, n)
+    g_b = egc_amd.graph.GLOBAL_GRAPH_CACHE.get(ei1, n)
+    assert g_a is g_b
+
+
+def test_two_reference_layers_agree_through_hip():
+    """SURVEY.md 8a notes 1-2: with W_opt = W_lay.view(H,B,A,F).permute(0,2,1,3) and pre-self-looped edges
+    the two layer classes compute the same function."""
+    import egc_amd
+    dev = _dev()
+    rng = np.random.default_rng(5)
+    n, f, H, B = 300, 64, 8, 4
+    ei = _rand_graph(rng, n, 3000)
+    ei = ei[:, ei[0] != ei[1]]
+    looped = np.concatenate([ei, np.stack([np.arange(n), np.arange(n)])], axis=1)
+    lay = egc_amd.EfficientGraphConv(f, f, H, B, False, aggrs=["symadd", "max", "mean"]).to(dev)
+    opt = egc_amd.EGConv(f, f, aggrs=["symnorm", "max", "mean"], num_heads=H, num_bases=B).to(dev)
+    A = 3
+    with torch.no_grad():
+        opt.bases_weight.copy_(torch.cat(list(lay.bases_weight), dim=1))
+        opt.comb_weight.weight.copy_(lay.comb_weights.weight.view(H, B, A, f).permute(0, 2, 1, 3).reshape(H * A * B, f))
+        opt.comb_weight.bias.copy_(lay.comb_weights.bias.view(H, B, A).permute(0, 2, 1).reshape(-1))
+        x = torch.randn(n, f, device=dev)
+        o_lay = lay(x, torch.from_numpy(looped).to(dev))   # raw aggregators see the explicit loops
+        o_opt = opt(x, torch.from_numpy(ei).to(dev))       # EGConv adds them itself
+    assert rel_err(o_lay.cpu().numpy(), o_opt.cpu().numpy()) <= TOL
+
+
+def test_config2_full_size_against_oracle():
+    """BASELINE config 2 at full size (N = 169,343, ~2.33 M edges + self loops, d=128, H=8, B=4,
+    sum+mean+max+symnorm): HIP vs numpy oracle, plus size-independent properties."""
+    import egc_amd
+    from egc_amd.workloads import arxiv_like
+    dev = _dev()
+    ei, n = arxiv_like(seed=0)
+    torch.manual_seed(0)
+    conv = egc_amd.EGConv(128, 128, aggrs=["sum", "mean", "max", "symnorm"], num_heads=8, num_bases=4)
+    with torch.no_grad():
+        conv.bias.normal_()
+    x = torch.randn(n, 128)
+    sd = {k: v.numpy() for k, v in conv.state_dict().items()}
+    ref = orc.egconv_forward(x.numpy(), ei.numpy(), sd["bases_weight"], sd["comb_weight.weight"],
+                             sd["comb_weight.bias"], sd["bias"], 8, 4, conv.aggregators)
+    conv = conv.to(dev).eval()
+    with torch.no_grad():
+        out = conv(x.to(dev), ei.to(dev))
+        # property: permuting the edge list changes nothing for max, and sums only within rounding
+        perm = torch.randperm(ei.size(1))
+        out_p = conv(x.to(dev), ei[:, perm].to(dev))
+    out, out_p = out.cpu().numpy(), out_p.cpu().numpy()
+    assert rel_err(out, ref) <= TOL, rel_err(out, ref)
+    assert rel_err(out_p, out) <= TOL
+
+
+def test_linearity_and_max_idempotence_properties():
+    """Size-independent properties on a config-2-shaped layer: sum/mean/symnorm are linear in x
+    through the bases; max-aggregation of a constant feature field returns the constant."""
+    import egc_amd
+    from egc_amd.workloads import heavy_tailed_graph
+    dev = _dev()
+    n = 20000
+    ei = heavy_tailed_graph(n, 150000, seed=1).to(dev)
+    conv = egc_amd.EGConv(64, 64, aggrs=["sum", "mean", "symnorm"], num_heads=4, num_bases=4, bias=False).to(dev)
+    with torch.no_grad():
+        # make the weightings independent of x so the whole layer is linear in x
+        conv.comb_weight.weight.zero_()
+        conv.comb_weight.bias.normal_()
+        x1, x2 = torch.randn(n, 64, device=dev), torch.randn(n, 64, device=dev)
+        lhs = conv(2.0 * x1 + x2, ei)
+        rhs = 2.0 * conv(x1, ei) + conv(x2, ei)
+    assert rel_err(lhs.cpu().numpy(), rhs.cpu().numpy()) <= 5e-5
+    mx = egc_amd.EGConv(8, 8, aggrs=["max", "min"], num_heads=1, num_bases=1, bias=False).to(dev)
+    with torch.no_grad():
+        mx.bases_weight.copy_(torch.eye(8, device=dev))
+        mx.comb_weight.weight.zero_()
+        mx.comb_weight.bias.copy_(torch.tensor([1.0, 0.0], device=dev))  # picks 'max'
+        const = torch.full((n, 8), 3.25, device=dev)
+        assert torch.equal(mx(const, ei), const)
