@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""Benchmark of the one hot path: EGC-M layer forward on an ogbn-arxiv-shaped graph (BASELINE
+config 2: N = 169,343, ~2.33 M symmetrised edges + N self loops, d = 128, H = 8, B = 4,
+aggregators sum+mean+max+symnorm, fp32).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one full layer forward through the C ABI (fp32-MFMA basis GEMM + fused aggregate/combine)
+with every input already resident in HBM and the CSR pre-built (static graph, the reference's
+``cached=True``).  Rank 0 prints ONE JSON line.  For N > 1 the driver launches this file under
+torch.distributed.run (one rank per GPU, RCCL).
+
+Extra objects on the JSON line:
+  roofline     -- the dominant kernel (fused aggregate+combine launch): algorithmic bytes per launch
+                  (SURVEY.md 8d model, every term printed on stderr) / HIP-event time of that launch.
+  cpu_baseline -- the oracle's multi-threaded CPU port of the reference op sequence
+                  (oracle/egc_cpu_port.py), timed on this host's cores on the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import statistics
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy ceiling)
+AGGRS = ["sum", "mean", "max", "symnorm"]
+F_IN = F_OUT = 128
+HEADS, BASES = 8, 4
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def dist_setup(n_gpus):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    elif n_gpus > 1:
+        raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    return world, rank, local
+
+
+def time_region(fn, iters, sync):
+    """HIP-event timing of `iters` back-to-back calls on the current stream; returns ms per call."""
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    sync()
+    start.record()
+    for _ in range(iters):
+        fn()
+    end.record()
+    end.synchronize()
+    return start.elapsed_time(end) / iters
+
+
+def cpu_baseline(ei, n, x, conv_state, runs=5):
+    """Time the CPU port (oracle) on the same workload: full config-2 layer forward, graph prep cached."""
+    from oracle.egc_cpu_port import egconv_forward_cpu
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    args = (x, ei, conv_state["bases_weight"], conv_state["comb_weight.weight"], conv_state["comb_weight.bias"],
+            conv_state["bias"], HEADS, BASES, AGGRS)
+    out, cached = egconv_forward_cpu(*args)  # warm-up; also builds the cached gcn_norm edge set
+    times = []
+    for _ in range(runs):
+        t0 = time.perf_counter()
+        out, _ = egconv_forward_cpu(*args, cached=cached)
+        times.append(time.perf_counter() - t0)
+    return out, statistics.median(times), threads, int(cached[0].size(1))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+
+    world, rank, local = dist_setup(args.gpus)
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    import egc_amd
+    from egc_amd import _C
+    from egc_amd.functional import LayerSpec
+    from egc_amd.workloads import algorithmic_bytes, arxiv_like
+
+    lib = _C.load()
+
+    # ---- workload (per rank: one arxiv-shaped vertex partition; see DESIGN.md multi-GPU) ----
+    ei_cpu, n = arxiv_like(seed=args.seed + rank)
+    torch.manual_seed(args.seed)
+    conv = egc_amd.EGConv(F_IN, F_OUT, aggrs=AGGRS, num_heads=HEADS, num_bases=BASES, cached=True)
+    with torch.no_grad():
+        conv.bias.normal_()
+    x_cpu = torch.randn(n, F_IN)
+    state_cpu = {k: v.detach().clone() for k, v in conv.state_dict().items()}
+    conv = conv.to(dev).eval()
+    x = x_cpu.to(dev)
+    ei = ei_cpu.to(dev)
+    e_in = int(ei.size(1))
+    e_eff = e_in + n  # EGConv convention: every aggregator also traverses one self loop per node
+
+    graph = egc_amd.CSRGraph.from_edge_index(ei, n)
+    spec: LayerSpec = conv._spec_coo
+    wcat, bcat = conv._packed_weights()
+    bias = conv.bias.detach()
+    ldb = spec.ldb
+    bases = torch.empty((n, ldb), device=dev)
+    weightings = torch.empty((n, spec.w_cols), device=dev)
+    out = torch.empty((n, F_OUT), device=dev)
+    ws = torch.zeros(max(lib.egc_aggregate_workspace_bytes(C.byref(spec.c), n, e_in), 1), dtype=torch.uint8, device=dev)
+    g = graph.c_struct()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def step():  # one full layer forward through the C ABI
+        _C.check(lib.egc_layer_forward_f32(C.byref(g), C.byref(spec.c), x.data_ptr(), wcat.data_ptr(),
+                                           bcat.data_ptr(), bias.data_ptr(), bases.data_ptr(), ldb,
+                                           weightings.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), stream),
+                 "egc_layer_forward_f32")
+
+    def gemm_only():
+        _C.check(lib.egc_basis_transform_f32(x.data_ptr(), wcat.data_ptr(), bcat.data_ptr(), n, F_IN, spec.f_g,
+                                             spec.w_cols, bases.data_ptr(), ldb, weightings.data_ptr(), stream),
+                 "egc_basis_transform_f32")
+
+    def agg_only():
+        _C.check(lib.egc_aggregate_combine_f32(C.byref(g), C.byref(spec.c), bases.data_ptr(), ldb,
+                                               weightings.data_ptr(), bias.data_ptr(), out.data_ptr(), None, None,
+                                               ws.data_ptr(), ws.numel(), stream), "egc_aggregate_combine_f32")
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # ---- warm-up, then EXACTLY --steps timed steps bracketed by barrier + synchronize ----
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tot = torch.tensor([float(e_eff)], device=dev, dtype=torch.float64)
+        dist.all_reduce(tot)
+        total_e_eff = float(tot.item())
+    else:
+        total_e_eff = float(e_eff)
+    ms_per_step = elapsed / args.steps * 1e3
+    value = total_e_eff / (elapsed / args.steps)
+
+    # ---- per-kernel HIP-event timing on the launch stream (rank 0 reports) ----
+    reps = max(20, min(args.steps, 200))
+    agg_ms = time_region(agg_only, reps, lambda: torch.cuda.synchronize(dev))
+    gemm_ms = time_region(gemm_only, reps, lambda: torch.cuda.synchronize(dev))
+    step_ms_events = time_region(step, reps, lambda: torch.cuda.synchronize(dev))
+
+    terms = algorithmic_bytes(n, e_eff, F_IN, spec.f_g, F_OUT, spec.w_cols, symnorm=True)
+    agg_gbs = terms["aggregate_kernel"] / (agg_ms * 1e-3) / 1e9
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_file):
+        try:
+            traffic = json.load(open(pmc_file)).get("aggregate_kernel_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    result = {
+        "metric": "EGC-M layer fwd edges/sec on ogbn-arxiv; achieved HBM GB/s vs roofline",
+        "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "ogbn-arxiv-shaped full graph per GPU: N=169343, heavy-tailed symmetrised "
+                               f"E_in={e_in} (+N self loops => E_eff={e_eff}), EGC-M d=128 H=8 B=4 "
+                               "aggrs=sum+mean+max+symnorm, CSR cached",
+                   "n_nodes": n, "e_in": e_in, "e_eff": e_eff, "layer": "EGConv", "parallelism": f"dp{world}"},
+        "roofline": {"bound": "hbm", "kernel": "egc aggregate+combine launch", "achieved": agg_gbs,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": agg_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": terms["aggregate_kernel"], "launch_ms": agg_ms},
+        "kernels_ms": {"basis_gemm": gemm_ms, "aggregate_combine": agg_ms, "layer_forward": step_ms_events},
+        "layer_algorithmic_bytes": terms["layer"],
+        "layer_achieved_gbs": terms["layer"] / (step_ms_events * 1e-3) / 1e9,
+    }
+
+    if rank == 0:
+        log("algorithmic bytes (SURVEY.md 8d), per forward:")
+        for k, v in terms.items():
+            log(f"  {k:18s} {v / 1e6:10.2f} MB")
+        log(f"kernel ms: gemm {gemm_ms:.4f}  aggregate+combine {agg_ms:.4f}  layer {step_ms_events:.4f}")
+        if not args.no_cpu_baseline:
+            ref_out, cpu_s, threads, e_cached = cpu_baseline(ei_cpu, n, x_cpu, state_cpu)
+            err = float((out.cpu() - ref_out).abs().max() / max(1.0, float(ref_out.abs().max())))
+            log(f"cpu port: {cpu_s * 1e3:.1f} ms/forward on {threads} threads; HIP vs CPU port rel err {err:.2e}")
+            result["cpu_baseline"] = {
+                "value": e_eff / cpu_s, "unit": "edges/s", "cores": threads, "kind": "port",
+                "sample": f"full config-2 layer forward (E_eff={e_cached}), gcn_norm cached, median of 5 runs "
+                          f"after 1 warm-up; {cpu_s * 1e3:.1f} ms each",
+                "hip_vs_port_rel_err": err}
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

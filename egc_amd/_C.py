@@ -8,7 +8,8 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libegc_hip.so")
+_LIB_PATH = os.environ.get("EGC_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib",
+                                                         "libegc_hip.so")
 _lib = None
 
 EGC_MAX_AGGRS = 8

@@ -20,88 +20,11 @@
 // EGC_LONG_ROW_CHUNK-entry chunks (plan from egc_csr_prepare); one wavefront reduces one chunk to a
 // partial record, and a merge kernel folds a row's partials in chunk order (deterministic) before the
 // same epilogue.
-#include <math.h>
+#include <stdlib.h>
 
-#include "egc_common.h"
-
-// hipcc defaults to -ffp-contract=fast, which would fuse the reference's separately rounded
-// x*x / mean*mean products into FMAs (var of a single neighbour must be EXACTLY 0).  Every fused
-// multiply-add in this file is an explicit fmaf().
-#pragma clang fp contract(off)
+#include "egc_aggregate_dev.h"
 
 namespace egc {
-
-typedef float f4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-
-constexpr unsigned OOB = 0xFFFFFFF0u;  // any offset >= num_records makes a buffer load return 0
-
-struct AggArgs {
-  const int* rowptr;
-  const int* col;
-  const float* dis;        // deg^-1/2 of the symnorm edge set, or nullptr
-  const int* max_index;    // device scalar (used when !loops_all)
-  const int* plan;
-  const float* bases;
-  const float* weightings;
-  const float* bias;
-  float* out;
-  float* partial;          // [cap_chunks][5][slots] float4
-  int* partial_nself;      // [cap_chunks]
-  int n_nodes;
-  int ldb, slots;          // slots = ldb / 4
-  int F_out, W, H, B, A, L;
-  int aggr[EGC_MAX_AGGRS];
-  int x_looped, y_looped, loops_all;
-  int sa, sb;              // strides of (aggregator, basis) inside one head's weight block
-  int act;
-  int lpr_log2;
-  unsigned magic_L;        // floor(2^32 / L) + 1: o / L == umulhi(o, magic_L) for o, L < 2^16 (L > 1)
-  unsigned bases_bytes;
-  int lds_floats_per_wave;
-};
-
-template <int CHUNKS>
-struct Acc {
-  f4 sum[CHUNKS], sq[CHUNKS], mx[CHUNKS], mn[CHUNKS], ws[CHUNKS];
-  __device__ inline void init() {
-#pragma unroll
-    for (int k = 0; k < CHUNKS; ++k) {
-      sum[k] = 0.f; sq[k] = 0.f; ws[k] = 0.f;
-      mx[k] = -INFINITY; mn[k] = INFINITY;
-    }
-  }
-};
-
-__device__ inline f4 f4_max(f4 a, f4 b) {
-  return f4{fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)};
-}
-__device__ inline f4 f4_min(f4 a, f4 b) {
-  return f4{fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z), fminf(a.w, b.w)};
-}
-__device__ inline f4 f4_fma(f4 a, f4 b, f4 c) {
-  return f4{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w)};
-}
-__device__ inline f4 f4_shfl_xor(f4 v, int off) {
-  return f4{__shfl_xor(v.x, off), __shfl_xor(v.y, off), __shfl_xor(v.z, off), __shfl_xor(v.w, off)};
-}
-
-__device__ inline f4 load_slot(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
-  return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0));
-}
-
-// Fold one gathered neighbour slot into the lane's running aggregates.
-__device__ inline void fold(f4& sum, f4& sq, f4& mx, f4& mn, f4& ws, f4 v, bool in_x, bool in_y, float w) {
-  const f4 vx = in_x ? v : f4{0.f, 0.f, 0.f, 0.f};
-  sum += vx;
-  // x*x rounded on its own, then added -- as scatter(inputs * inputs) does (layers.py:206-212); a fused
-  // multiply-add here makes var of identical neighbours non-zero, which std amplifies 158x at var = 0.
-  sq += f4{__fmul_rn(vx.x, vx.x), __fmul_rn(vx.y, vx.y), __fmul_rn(vx.z, vx.z), __fmul_rn(vx.w, vx.w)};
-  mx = f4_max(mx, in_x ? v : f4{-INFINITY, -INFINITY, -INFINITY, -INFINITY});
-  mn = f4_min(mn, in_x ? v : f4{INFINITY, INFINITY, INFINITY, INFINITY});
-  const float wy = in_y ? w : 0.f;
-  ws = f4_fma(f4{wy, wy, wy, wy}, v, ws);
-}
 
 // Reduce CSR entries [start, end) of `row` into per-lane partial aggregates.
 // Lane (g, q): group g = lane >> lpr_log2 takes entries g, g+G, ...; q = slot inside the basis row.
@@ -169,18 +92,6 @@ __device__ inline void reduce_groups(const AggArgs& a, Acc<CHUNKS>& acc) {
     acc.mx[0] = f4_max(acc.mx[0], f4_shfl_xor(acc.mx[0], off));
     acc.mn[0] = f4_min(acc.mn[0], f4_shfl_xor(acc.mn[0], off));
   }
-}
-
-__device__ inline f4 f4_div(f4 a, float d) { return f4{a.x / d, a.y / d, a.z / d, a.w / d}; }
-
-// var = E[x^2] - E[x]^2 with separately rounded product and difference (layers.py:203-214).
-__device__ inline f4 f4_var(f4 mean_sq, f4 mean) {
-  return f4{__fsub_rn(mean_sq.x, __fmul_rn(mean.x, mean.x)), __fsub_rn(mean_sq.y, __fmul_rn(mean.y, mean.y)),
-            __fsub_rn(mean_sq.z, __fmul_rn(mean.z, mean.z)), __fsub_rn(mean_sq.w, __fmul_rn(mean.w, mean.w))};
-}
-__device__ inline f4 f4_std(f4 var) {
-  return f4{sqrtf(fmaxf(var.x, 0.f) + 1e-5f), sqrtf(fmaxf(var.y, 0.f) + 1e-5f), sqrtf(fmaxf(var.z, 0.f) + 1e-5f),
-            sqrtf(fmaxf(var.w, 0.f) + 1e-5f)};
 }
 
 // Self-loop term, aggregator finalisation, weight nonlinearity, combine, bias, store.
@@ -282,10 +193,6 @@ __device__ inline void finish_row(const AggArgs& a, __amdgpu_buffer_rsrc_t rsrc,
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-__device__ inline __amdgpu_buffer_rsrc_t bases_rsrc(const AggArgs& a) {
-  return __builtin_amdgcn_make_buffer_rsrc((void*)a.bases, 0, a.bases_bytes, 0x00020000);
-}
-
 // One wavefront per CSR row (rows above the long-row threshold are left to the chunk/merge kernels).
 template <int CHUNKS, int U>
 __global__ void __launch_bounds__(256) agg_rows_kernel(AggArgs a) {
@@ -303,9 +210,17 @@ __global__ void __launch_bounds__(256) agg_rows_kernel(AggArgs a) {
   Acc<CHUNKS> acc;
   acc.init();
   int nself = 0;
+#ifndef EGC_ABLATE_NO_GATHER
   accumulate_range<CHUNKS, U>(a, rsrc, row, start, end, lane, acc, nself);
+#endif
+#ifndef EGC_ABLATE_NO_REDUCE
   reduce_groups<CHUNKS>(a, acc);
+#endif
+#ifndef EGC_ABLATE_NO_EPILOGUE
   finish_row<CHUNKS>(a, rsrc, row, acc, deg, nself, lane, smem + wave * a.lds_floats_per_wave);
+#else
+  if (lane < 16) *reinterpret_cast<f4*>(a.out + (int64_t)row * a.F_out + 4 * lane) = acc.sum[0] + acc.mx[0] + acc.ws[0] + acc.sq[0] + acc.mn[0];
+#endif
 }
 
 // One wavefront per long-row chunk -> partial record.
@@ -416,15 +331,16 @@ static bool layer_uses_symnorm(const egc_layer* L) {
 }
 
 struct WsLayout {
-  size_t partial_bytes, nself_bytes, total;
+  size_t counter_bytes, partial_bytes, nself_bytes, total;
 };
 static WsLayout ws_layout(const egc_layer* L, int64_t n_nodes, int64_t n_edges) {
   const int ldb = egc_bases_ld(L);
   PlanCaps c = plan_caps(n_nodes, n_edges);
   WsLayout w;
+  w.counter_bytes = align256((size_t)c.cap_long * sizeof(int));
   w.partial_bytes = align256((size_t)c.cap_chunks * 5 * ldb * sizeof(float));
   w.nself_bytes = align256((size_t)c.cap_chunks * sizeof(int));
-  w.total = w.partial_bytes + w.nself_bytes;
+  w.total = w.counter_bytes + w.partial_bytes + w.nself_bytes;
   return w;
 }
 
@@ -527,9 +443,14 @@ int egc_aggregate_combine_f32(const egc_graph* graph, const egc_layer* layer, co
 
   WsLayout w = ws_layout(layer, n, e);
   if (workspace == nullptr || workspace_bytes < w.total) return EGC_ERR_WORKSPACE;
-  a.partial = (float*)workspace;
-  a.partial_nself = (int*)((char*)workspace + w.partial_bytes);
+  a.counters = (int*)workspace;
+  a.partial = (float*)((char*)workspace + w.counter_bytes);
+  a.partial_nself = (int*)((char*)workspace + w.counter_bytes + w.partial_bytes);
   PlanCaps caps = plan_caps(n, e);
+  a.rows_per_wave = 0;
+  if (const char* env = getenv("EGC_ROWS_PER_WAVE")) a.rows_per_wave = atoi(env);
+  const bool force_generic = getenv("EGC_FORCE_GENERIC") != nullptr;
+  if (!force_generic && fast_path_supported(a, layer->weight_layout, chunks)) return launch_fast(a, n, caps, stream);
 
   switch (chunks) {
     case 1: return launch_all<1>(a, n, caps, wpb, lds_bytes, stream);

@@ -1,0 +1,115 @@
+// Device-side building blocks shared by the generic and the register-resident EGC aggregate kernels.
+#pragma once
+#include <math.h>
+
+#include "egc_common.h"
+
+// hipcc defaults to -ffp-contract=fast, which would fuse the reference's separately rounded
+// x*x / mean*mean products into FMAs (var of a single neighbour must be EXACTLY 0).  Every fused
+// multiply-add in the aggregate kernels is an explicit fmaf().
+#pragma clang fp contract(off)
+
+namespace egc {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+
+constexpr unsigned OOB = 0xFFFFFFF0u;  // any offset >= num_records makes a buffer load return 0
+
+struct AggArgs {
+  const int* rowptr;
+  const int* col;
+  const float* dis;        // deg^-1/2 of the symnorm edge set, or nullptr
+  const int* max_index;    // device scalar (used when !loops_all)
+  const int* plan;
+  const float* bases;
+  const float* weightings;
+  const float* bias;
+  float* out;
+  float* partial;          // [cap_chunks][5][slots] float4
+  int* partial_nself;      // [cap_chunks]
+  int* counters;           // [cap_long] arrival counters of the fused kernel (zero on entry, zero on exit)
+  int n_nodes;
+  int ldb, slots;          // slots = ldb / 4
+  int F_out, W, H, B, A, L;
+  int aggr[EGC_MAX_AGGRS];
+  int x_looped, y_looped, loops_all;
+  int sa, sb;              // strides of (aggregator, basis) inside one head's weight block
+  int act;
+  int lpr_log2;
+  unsigned magic_L;        // floor(2^32 / L) + 1: o / L == umulhi(o, magic_L) for o, L < 2^16 (L > 1)
+  unsigned bases_bytes;
+  int lds_floats_per_wave;
+  // register-resident ("fast") kernel family only
+  int lpb_log2;            // log2(lanes per basis block) = log2(L / 4)
+  int hpg;                 // heads per lane group = ceil(H / G)
+  int rows_per_wave;
+  int chunk_blocks;        // leading blocks of the grid that take long-row chunks
+  int need_mean, need_var;
+};
+
+template <int CHUNKS>
+struct Acc {
+  f4 sum[CHUNKS], sq[CHUNKS], mx[CHUNKS], mn[CHUNKS], ws[CHUNKS];
+  __device__ inline void init() {
+#pragma unroll
+    for (int k = 0; k < CHUNKS; ++k) {
+      sum[k] = 0.f; sq[k] = 0.f; ws[k] = 0.f;
+      mx[k] = -INFINITY; mn[k] = INFINITY;
+    }
+  }
+};
+
+__device__ inline f4 f4_max(f4 a, f4 b) {
+  return f4{fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)};
+}
+__device__ inline f4 f4_min(f4 a, f4 b) {
+  return f4{fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z), fminf(a.w, b.w)};
+}
+__device__ inline f4 f4_fma(f4 a, f4 b, f4 c) {
+  return f4{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w)};
+}
+__device__ inline f4 f4_shfl_xor(f4 v, int off) {
+  return f4{__shfl_xor(v.x, off), __shfl_xor(v.y, off), __shfl_xor(v.z, off), __shfl_xor(v.w, off)};
+}
+
+__device__ inline f4 load_slot(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+  return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0));
+}
+
+// Fold one gathered neighbour slot into the lane's running aggregates.
+__device__ inline void fold(f4& sum, f4& sq, f4& mx, f4& mn, f4& ws, f4 v, bool in_x, bool in_y, float w) {
+  const f4 vx = in_x ? v : f4{0.f, 0.f, 0.f, 0.f};
+  sum += vx;
+  // x*x rounded on its own, then added -- as scatter(inputs * inputs) does (layers.py:206-212); a fused
+  // multiply-add here makes var of identical neighbours non-zero, which std amplifies 158x at var = 0.
+  sq += f4{__fmul_rn(vx.x, vx.x), __fmul_rn(vx.y, vx.y), __fmul_rn(vx.z, vx.z), __fmul_rn(vx.w, vx.w)};
+  mx = f4_max(mx, in_x ? v : f4{-INFINITY, -INFINITY, -INFINITY, -INFINITY});
+  mn = f4_min(mn, in_x ? v : f4{INFINITY, INFINITY, INFINITY, INFINITY});
+  const float wy = in_y ? w : 0.f;
+  ws = f4_fma(f4{wy, wy, wy, wy}, v, ws);
+}
+
+
+__device__ inline f4 f4_div(f4 a, float d) { return f4{a.x / d, a.y / d, a.z / d, a.w / d}; }
+
+// var = E[x^2] - E[x]^2 with separately rounded product and difference (layers.py:203-214).
+__device__ inline f4 f4_var(f4 mean_sq, f4 mean) {
+  return f4{__fsub_rn(mean_sq.x, __fmul_rn(mean.x, mean.x)), __fsub_rn(mean_sq.y, __fmul_rn(mean.y, mean.y)),
+            __fsub_rn(mean_sq.z, __fmul_rn(mean.z, mean.z)), __fsub_rn(mean_sq.w, __fmul_rn(mean.w, mean.w))};
+}
+__device__ inline f4 f4_std(f4 var) {
+  return f4{sqrtf(fmaxf(var.x, 0.f) + 1e-5f), sqrtf(fmaxf(var.y, 0.f) + 1e-5f), sqrtf(fmaxf(var.z, 0.f) + 1e-5f),
+            sqrtf(fmaxf(var.w, 0.f) + 1e-5f)};
+}
+
+__device__ inline __amdgpu_buffer_rsrc_t bases_rsrc(const AggArgs& a) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)a.bases, 0, a.bases_bytes, 0x00020000);
+}
+
+// Launches the register-resident kernel family (egc_aggregate_fast.hip) if the layer shape qualifies.
+// Returns EGC_OK, an error, or EGC_ERR_UNSUPPORTED when the generic path must be used instead.
+bool fast_path_supported(const AggArgs& a, int layout, int chunks);
+int launch_fast(AggArgs a, int64_t n_nodes, const PlanCaps& caps, hipStream_t stream);
+
+}  // namespace egc

@@ -67,8 +67,7 @@ def egc_layer_forward(graph: CSRGraph, spec: LayerSpec, x: torch.Tensor, wcat: t
         bases = torch.empty((n, spec.ldb), dtype=torch.float32, device=dev)
         weightings = torch.empty((n, spec.w_cols), dtype=torch.float32, device=dev)
         out = torch.empty((n, spec.f_out), dtype=torch.float32, device=dev)
-        ws_bytes = lib.egc_aggregate_workspace_bytes(C.byref(spec.c), n, graph.n_edges)
-        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+        ws = graph.workspace(lib.egc_aggregate_workspace_bytes(C.byref(spec.c), n, graph.n_edges))
         g = graph.c_struct()
         _C.check(lib.egc_layer_forward_f32(
             C.byref(g), C.byref(spec.c), x.data_ptr(), wcat.data_ptr(),

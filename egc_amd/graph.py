@@ -36,6 +36,7 @@ class CSRGraph:
         self.rowptr, self.col, self.edge_id = rowptr, col, edge_id
         self.dis_raw, self.dis_looped, self.max_index, self.plan = dis_raw, dis_looped, max_index, plan
         self.device = rowptr.device
+        self._workspaces = {}
 
     # -- construction ---------------------------------------------------------------------
     @classmethod
@@ -84,6 +85,16 @@ class CSRGraph:
         _C.check(lib.egc_csr_prepare(n, e, rowptr.data_ptr(), col.data_ptr(), dis_raw.data_ptr(),
                                      dis_looped.data_ptr(), plan.data_ptr(), _stream_ptr(dev)), "egc_csr_prepare")
         return cls(n, e, rowptr, col, edge_id, dis_raw, dis_looped, max_index, plan)
+
+    def workspace(self, nbytes: int) -> torch.Tensor:
+        """Scratch for egc_aggregate_combine_f32.  The C ABI wants it zero-filled before its first use
+        and leaves it reusable afterwards, so it is zeroed once and kept per (size, stream)."""
+        key = (int(nbytes), torch.cuda.current_stream(self.device).cuda_stream)
+        ws = self._workspaces.get(key)
+        if ws is None:
+            ws = torch.zeros(max(int(nbytes), 1), dtype=torch.uint8, device=self.device)
+            self._workspaces[key] = ws
+        return ws
 
     # -- C view -----------------------------------------------------------------------------
     def c_struct(self) -> _C.EgcGraph:

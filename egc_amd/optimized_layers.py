@@ -61,7 +61,10 @@ class EGConv(nn.Module):
         act = _C.ACT_SIGMOID if sigmoid else _C.ACT_NONE
         has_sym = "symnorm" in self.aggregators
         edge_set = _C.SET_LOOPED if add_self_loops else _C.SET_RAW
-        common = dict(weight_layout=_C.LAYOUT_HAB, weight_act=act)
+        # The weightings tensor is an internal intermediate, so its column order is ours to choose: the
+        # comb_weight rows are permuted from the reference's h*A*B + a*B + b (optimized_layers.py:195-202)
+        # to h*B*A + b*A + a when packed, which lets the kernel fetch w[h][b][0..A) with one 16-byte load.
+        common = dict(weight_layout=_C.LAYOUT_HBA, weight_act=act)
         # COO input: loops for every node only when gcn_norm (which knows num_nodes) adds them
         self._spec_coo = make_spec(in_channels, out_channels, num_heads, num_bases, codes, agg_set=edge_set,
                                    sym_set=edge_set, loops_all_nodes=has_sym, **common)
@@ -80,14 +83,22 @@ class EGConv(nn.Module):
         self._cached_graph = None
         self._wcat_key, self._wcat = None, None
 
+    def _pack(self):
+        H, A, B, F = self.num_heads, len(self.aggregators), self.num_bases, self.in_channels
+        w = self.comb_weight.weight.view(H, A, B, F).permute(0, 2, 1, 3).reshape(H * B * A, F)
+        b = self.comb_weight.bias.view(H, A, B).permute(0, 2, 1).reshape(H * B * A)
+        return torch.cat([self.bases_weight, w.t()], dim=1).contiguous(), b.contiguous()
+
     def _packed_weights(self):
-        params = [self.bases_weight, self.comb_weight.weight]
+        """([bases_weight | permuted comb_weight.weight^T], permuted comb_weight.bias), cached until a
+        parameter changes in place."""
+        params = [self.bases_weight, self.comb_weight.weight, self.comb_weight.bias]
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
-            return torch.cat([self.bases_weight, self.comb_weight.weight.t()], dim=1)
+            return self._pack()
         key = tuple((p.data_ptr(), p._version) for p in params)
         if key != self._wcat_key:
             with torch.no_grad():
-                self._wcat = torch.cat([self.bases_weight, self.comb_weight.weight.t()], dim=1).contiguous()
+                self._wcat = self._pack()
             self._wcat_key = key
         return self._wcat
 
@@ -100,7 +111,8 @@ class EGConv(nn.Module):
             spec = self._spec_coo if is_coo else self._spec_adj
             if self.cached:
                 self._cached_graph = (graph, spec)
-        return egc_layer_apply(graph, spec, x, self._packed_weights(), self.comb_weight.bias, self.bias)
+        wcat, bcat = self._packed_weights()
+        return egc_layer_apply(graph, spec, x, wcat, bcat, self.bias)
 
     def __repr__(self):
         return "{}({}, {}, {})".format(self.__class__.__name__, self.in_channels, self.out_channels,

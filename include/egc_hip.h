@@ -139,7 +139,10 @@ int egc_basis_transform_f32(const float* x, const float* wcat, const float* bcat
                             int32_t f_in, int32_t f_g, int32_t w_cols, float* bases, int32_t ldb,
                             float* weightings, egc_stream_t stream);
 
-/* Scratch bytes egc_aggregate_combine_f32 needs for this layer on this graph. */
+/* Scratch bytes egc_aggregate_combine_f32 needs for this layer on this graph.
+ * CONTRACT: the workspace must be zero-filled before its FIRST use (it holds the long-row arrival
+ * counters of the fused kernel); every call leaves it ready for the next call on the same stream.
+ * One workspace must not be shared by calls that may run concurrently on different streams. */
 size_t egc_aggregate_workspace_bytes(const egc_layer* layer, int64_t n_nodes, int64_t n_edges);
 
 /* Step 2+3 -- fused multi-aggregator neighbourhood reduction + per-node head x basis x aggregator

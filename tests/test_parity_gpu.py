@@ -154,7 +154,10 @@ def test_long_rows_chunk_merge_path(kind, aggrs):
 
 
 @pytest.mark.parametrize("hidden,H,B", [(304, 8, 8), (300, 4, 4), (352, 8, 4), (168, 8, 4), (124, 4, 4),
-                                        (296, 8, 4), (224, 4, 4), (136, 4, 4), (21, 1, 1), (16, 16, 16), (6, 2, 1)])
+                                        (296, 8, 4), (224, 4, 4), (136, 4, 4), (21, 1, 1), (16, 16, 16), (6, 2, 1),
+                                        # power-of-two shapes -> register-resident kernel family
+                                        (128, 8, 4), (128, 4, 4), (256, 4, 4), (64, 4, 4), (128, 16, 8), (64, 2, 8),
+                                        (64, 1, 1), (512, 8, 2), (32, 2, 4)])
 def test_shipped_and_odd_shapes(hidden, H, B):
     """(hidden, H, B) from run_pretrained.sh / train_main_table.sh incl. basis widths > 256 floats
     (multi-slot lanes) and widths that are not multiples of 4 (padded leading dimension)."""
@@ -188,11 +191,16 @@ def test_intermediates_match_oracle():
     x = torch.from_numpy(g["x"]).to(dev)
     graph = egc_amd.CSRGraph.from_edge_index(torch.from_numpy(g["edge_index"]).to(dev), x.size(0))
     with torch.no_grad():
-        out, bases, weightings = egc_layer_forward(graph, layer._spec_coo, x, layer._packed_weights(),
-                                                   layer.comb_weight.bias, layer.bias, return_intermediates=True)
+        wcat, bcat = layer._packed_weights()
+        out, bases, weightings = egc_layer_forward(graph, layer._spec_coo, x, wcat, bcat, layer.bias,
+                                                   return_intermediates=True)
     _, inter = oracle_forward(g, orc, return_intermediates=True)
     assert rel_err(bases.cpu().numpy()[:, :inter["bases"].shape[1]], inter["bases"]) <= TOL
-    assert rel_err(weightings.cpu().numpy(), inter["weightings"]) <= TOL
+    # internal weightings order is [h][b][a]; the reference's is [h][a][b] (optimized_layers.py:195-202)
+    m = g["meta"]
+    H, B, A = m["H"], m["B"], len(m["aggrs"])
+    w_ref = inter["weightings"].reshape(-1, H, A, B).transpose(0, 1, 3, 2).reshape(-1, H * B * A)
+    assert rel_err(weightings.cpu().numpy(), w_ref) <= TOL
     assert rel_err(out.cpu().numpy(), g["out"]) <= TOL
 
 
