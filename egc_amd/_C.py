@@ -13,7 +13,7 @@ _LIB_PATH = os.environ.get("EGC_HIP_LIB") or os.path.join(os.path.dirname(os.pat
 _lib = None
 
 EGC_MAX_AGGRS = 8
-LONG_ROW_THRESHOLD = 128
+LONG_ROW_THRESHOLD = 32
 LONG_ROW_CHUNK = 128
 
 # enum egc_aggr

@@ -62,9 +62,9 @@ typedef enum { EGC_ACT_NONE = 0, EGC_ACT_SOFTMAX = 1, EGC_ACT_SIGMOID = 2, EGC_A
 #define EGC_MAX_WEIGHT_WIDTH 2048  /* H * B * A */
 #define EGC_MAX_OUT_CHANNELS 2048
 
-/* Rows with more than EGC_LONG_ROW_THRESHOLD entries are reduced in chunks of
+/* Rows with more than EGC_LONG_ROW_THRESHOLD entries are handled by whole wavefronts, in chunks of
  * EGC_LONG_ROW_CHUNK entries by separate wavefronts and merged (degree-skew handling). */
-#define EGC_LONG_ROW_THRESHOLD 128
+#define EGC_LONG_ROW_THRESHOLD 32
 #define EGC_LONG_ROW_CHUNK 128
 
 /* ------------------------------------------------------------------------------------------
