@@ -33,7 +33,7 @@ class EgcGraph(C.Structure):
         ("n_nodes", C.c_int64), ("n_edges", C.c_int64),
         ("rowptr", C.c_void_p), ("col", C.c_void_p), ("edge_id", C.c_void_p),
         ("dis_raw", C.c_void_p), ("dis_looped", C.c_void_p),
-        ("max_index", C.c_void_p), ("plan", C.c_void_p),
+        ("max_index", C.c_void_p), ("plan", C.c_void_p), ("n_chunks", C.c_int64),
     ]
 
 

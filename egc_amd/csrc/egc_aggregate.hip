@@ -448,6 +448,7 @@ int egc_aggregate_combine_f32(const egc_graph* graph, const egc_layer* layer, co
   a.partial_nself = (int*)((char*)workspace + w.counter_bytes + w.partial_bytes);
   PlanCaps caps = plan_caps(n, e);
   a.rows_per_wave = 0;
+  a.n_chunks_hint = (graph->n_chunks >= 0 && graph->n_chunks <= caps.cap_chunks) ? (int)graph->n_chunks : -1;
   if (const char* env = getenv("EGC_ROWS_PER_WAVE")) a.rows_per_wave = atoi(env);
   const bool force_generic = getenv("EGC_FORCE_GENERIC") != nullptr;
   if (!force_generic && fast_path_supported(a, layer->weight_layout, chunks)) return launch_fast(a, n, caps, stream);

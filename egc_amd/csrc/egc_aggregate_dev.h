@@ -46,6 +46,7 @@ struct AggArgs {
   int rows_per_wave;
   int chunk_blocks;        // leading blocks of the grid that take long-row chunks
   int need_mean, need_var;
+  int n_chunks_hint;       // host-known number of long-row chunks, or -1 (launch for the capacity)
   int w_lds_stride;        // floats between the per-group weight strips in LDS
 };
 

@@ -11,20 +11,26 @@
 //     16-byte slots, so a wavefront holds G = 64/LPR rows at once (4 at the north-star shape); every
 //     wave-instruction gathers one neighbour row for each of its G rows, the running aggregates of a row
 //     never leave its lane group (no cross-group merge), and the per-row fixed work (self-loop term,
-//     finalisation, combine, store) is paid once per G rows.  With ~15 neighbours per row this is what
-//     keeps both the instruction count and the number of gathers in flight per wavefront healthy.
+//     finalisation, combine, store) is paid once per G rows.
 //   * long rows: leading blocks reduce EGC_LONG_ROW_CHUNK-entry chunks with all G groups of a wavefront
 //     splitting the entries; the wavefront that completes a row's last chunk (agent-scope release ->
 //     arrival counter -> acquire; cdna guide Guideline 16) merges the partial records in chunk order
 //     (deterministic) and finishes the row with the same epilogue.
 // Epilogue (no LDS round trip for the aggregates): a lane holds 4 columns (one basis b, channels
 // l..l+3) of every aggregator; for head h it forms sum_a w[h][b][a] * agg_a, a butterfly over the lanes
-// that share l sums over b, and the lane with b == h mod B keeps the result -> each lane ends up with
-// ceil(H/B) 16-byte pieces of the output row.  The weightings row is staged through LDS once per row.
-// Instruction diet: wave-instructions whose G neighbour slots are all valid fold without masks
-// (out-of-range buffer offsets return 0, neutral for the sums); only ragged tails and rows containing
-// self-entries take the masked fold; cross-lane moves are ds_bpermute with precomputed byte addresses;
-// v_max/v_min are emitted raw (no canonicalisation).
+// that share l sums over b (DPP row rotations at L = 16), and the lane with b == h mod B keeps the
+// result -> each lane ends up with ceil(H/B) 16-byte pieces of the output row.  The weightings row is
+// staged through LDS once per row.
+//
+// The kernel is VALU-issue bound (~15 neighbours per row leave little to amortise the per-row work), so
+//   * folds are straight-line: out-of-range buffer offsets return 0 (neutral for the sums) and the
+//     extrema are updated under EXEC masking -- no select chains, no register copies at merges;
+//   * every layer constant is read through a config accessor `C`.  `StCfg<...>` makes them compile-time
+//     constants (aggregator list, head/basis counts, nonlinearity, edge-set flags) for a curated list of
+//     layer configurations -- everything generic folds away; `RtCfg` reads them from the kernel
+//     arguments and serves every other qualifying layer with the same code.
+#include <stdlib.h>
+
 #include "egc_aggregate_dev.h"
 
 namespace egc {
@@ -37,6 +43,56 @@ constexpr int HPB_MAX = 4;  // ceil(H / B) supported
 constexpr int NEED_SQ = 1;   // sum of squares  (var, std)
 constexpr int NEED_MN = 2;   // running minimum (min)
 
+// ---------------------------------------------------------------------------------------------
+// layer-constant accessors
+// ---------------------------------------------------------------------------------------------
+struct RtCfg {
+  static __device__ inline int H(const AggArgs& a) { return a.H; }
+  static __device__ inline int B(const AggArgs& a) { return a.B; }
+  static __device__ inline int L(const AggArgs& a) { return a.L; }
+  static __device__ inline int A(const AggArgs& a) { return a.A; }
+  static __device__ inline int W(const AggArgs& a) { return a.W; }
+  static __device__ inline int F_out(const AggArgs& a) { return a.F_out; }
+  static __device__ inline int lpb_log2(const AggArgs& a) { return a.lpb_log2; }
+  static __device__ inline int act(const AggArgs& a) { return a.act; }
+  static __device__ inline bool xl(const AggArgs& a) { return a.x_looped != 0; }
+  static __device__ inline bool yl(const AggArgs& a) { return a.y_looped != 0; }
+  static __device__ inline bool loops_all(const AggArgs& a) { return a.loops_all != 0; }
+  static __device__ inline bool need_mean(const AggArgs& a) { return a.need_mean != 0; }
+  static __device__ inline int aggr(const AggArgs& a, int t) { return a.aggr[t]; }
+};
+
+constexpr int ilog2(int x) { return x <= 1 ? 0 : 1 + ilog2(x >> 1); }
+
+// AGG packs the aggregator codes, 3 bits each, first aggregator in the low bits.
+template <int H_, int B_, int L_, int A_, unsigned AGG, int ACT_, bool XL_, bool YL_, bool LOOPS_ALL_>
+struct StCfg {
+  static constexpr int agg_at(int t) { return (int)((AGG >> (3 * t)) & 7u); }
+  static constexpr bool has(int code) {
+    for (int t = 0; t < A_; ++t)
+      if (agg_at(t) == code) return true;
+    return false;
+  }
+  static __device__ inline constexpr int H(const AggArgs&) { return H_; }
+  static __device__ inline constexpr int B(const AggArgs&) { return B_; }
+  static __device__ inline constexpr int L(const AggArgs&) { return L_; }
+  static __device__ inline constexpr int A(const AggArgs&) { return A_; }
+  static __device__ inline constexpr int W(const AggArgs&) { return H_ * B_ * A_; }
+  static __device__ inline constexpr int F_out(const AggArgs&) { return H_ * L_; }
+  static __device__ inline constexpr int lpb_log2(const AggArgs&) { return ilog2(L_ / 4); }
+  static __device__ inline constexpr int act(const AggArgs&) { return ACT_; }
+  static __device__ inline constexpr bool xl(const AggArgs&) { return XL_; }
+  static __device__ inline constexpr bool yl(const AggArgs&) { return YL_; }
+  static __device__ inline constexpr bool loops_all(const AggArgs&) { return LOOPS_ALL_; }
+  static __device__ inline constexpr bool need_mean(const AggArgs&) {
+    return has(EGC_AGGR_MEAN) || has(EGC_AGGR_VAR) || has(EGC_AGGR_STD);
+  }
+  static __device__ inline constexpr int aggr(const AggArgs&, int t) { return agg_at(t); }
+};
+
+// ---------------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------------
 __device__ inline float vmax_raw(float a, float b) {
   float r;
   asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -53,6 +109,37 @@ __device__ inline f4 f4_vmax(f4 a, f4 b) {
 __device__ inline f4 f4_vmin(f4 a, f4 b) {
   return f4{vmin_raw(a.x, b.x), vmin_raw(a.y, b.y), vmin_raw(a.z, b.z), vmin_raw(a.w, b.w)};
 }
+__device__ inline f4 f4_sqr_rn(f4 v) {
+  return f4{__fmul_rn(v.x, v.x), __fmul_rn(v.y, v.y), __fmul_rn(v.z, v.z), __fmul_rn(v.w, v.w)};
+}
+__device__ inline f4 splat(float w) { return f4{w, w, w, w}; }
+
+__device__ inline float bperm(int byte_addr, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_addr, __builtin_bit_cast(int, v)));
+}
+__device__ inline int bperm(int byte_addr, int v) { return __builtin_amdgcn_ds_bpermute(byte_addr, v); }
+__device__ inline f4 bperm(int byte_addr, f4 v) {
+  return f4{bperm(byte_addr, v.x), bperm(byte_addr, v.y), bperm(byte_addr, v.z), bperm(byte_addr, v.w)};
+}
+
+// v += (v rotated by 8 lanes) ; v += (v rotated by 4 lanes), inside each 16-lane DPP row: afterwards
+// every lane holds the sum over the 4 lanes {q, q^4, q^8, q^12}.  One VALU instruction per component
+// and stage (the compiler otherwise emits v_mov + v_mov_dpp + v_add).  The leading s_nop covers the
+// VALU-write -> DPP-read hazard of the inputs; inside the block 4 instructions separate each write
+// from its DPP read.
+__device__ inline void dpp_sum_over_4_bases(f4& v) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 row_ror:4 row_mask:0xf bank_mask:0xf"
+      : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+}
 
 template <int NEED>
 struct FAcc {
@@ -65,37 +152,18 @@ struct FAcc {
   }
 };
 
-__device__ inline f4 f4_sqr_rn(f4 v) {
-  return f4{__fmul_rn(v.x, v.x), __fmul_rn(v.y, v.y), __fmul_rn(v.z, v.z), __fmul_rn(v.w, v.w)};
-}
-
-// Every lane of the wave-instruction holds a valid, non-excluded neighbour slot.
+// Fold one gathered slot.  `v` is 0 where the entry is absent or excluded (out-of-range buffer offset),
+// which is neutral for the sums, so only the extrema need the lane mask -- applied through EXEC
+// (a divergent `if`), which costs two scalar instructions and no register copies.
 template <int NEED>
-__device__ inline void fold_plain(FAcc<NEED>& acc, f4 v, float w) {
+__device__ inline void fold(FAcc<NEED>& acc, f4 v, float w, bool in_x) {
   acc.sum += v;
-  acc.mx = f4_vmax(acc.mx, v);
-  acc.ws = f4_fma(f4{w, w, w, w}, v, acc.ws);
+  acc.ws = f4_fma(splat(w), v, acc.ws);
   if constexpr (NEED & NEED_SQ) acc.sq += f4_sqr_rn(v);
-  if constexpr (NEED & NEED_MN) acc.mn = f4_vmin(acc.mn, v);
-}
-
-template <int NEED>
-__device__ inline void fold_masked(FAcc<NEED>& acc, f4 v, float w, bool in_x, bool in_y) {
-  const f4 vx = in_x ? v : f4{0.f, 0.f, 0.f, 0.f};
-  acc.sum += vx;
-  acc.mx = f4_vmax(acc.mx, in_x ? v : f4{-INFINITY, -INFINITY, -INFINITY, -INFINITY});
-  const float wy = in_y ? w : 0.f;
-  acc.ws = f4_fma(f4{wy, wy, wy, wy}, v, acc.ws);
-  if constexpr (NEED & NEED_SQ) acc.sq += f4_sqr_rn(vx);
-  if constexpr (NEED & NEED_MN) acc.mn = f4_vmin(acc.mn, in_x ? v : f4{INFINITY, INFINITY, INFINITY, INFINITY});
-}
-
-__device__ inline float bperm(int byte_addr, float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_addr, __builtin_bit_cast(int, v)));
-}
-__device__ inline int bperm(int byte_addr, int v) { return __builtin_amdgcn_ds_bpermute(byte_addr, v); }
-__device__ inline f4 bperm(int byte_addr, f4 v) {
-  return f4{bperm(byte_addr, v.x), bperm(byte_addr, v.y), bperm(byte_addr, v.z), bperm(byte_addr, v.w)};
+  if (in_x) {
+    acc.mx = f4_vmax(acc.mx, v);
+    if constexpr (NEED & NEED_MN) acc.mn = f4_vmin(acc.mn, v);
+  }
 }
 
 // Merge the G lane groups (every lane ends with the aggregates of its slot over all entries).
@@ -112,35 +180,70 @@ __device__ inline void all_reduce_groups(FAcc<NEED>& acc, int lane) {
   }
 }
 
+// 16-byte load that bypasses L1/L2 residency (sc0 sc1): used for records other wavefronts just published.
+__device__ inline f4 load_slot_wt(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+  return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0x11));
+}
+
 struct FastRsrc {
   __amdgpu_buffer_rsrc_t bases, out;
 };
+
+// Issue + fold one batch of FU wave-instructions.  `addr0` is the ds_bpermute byte address of the lane
+// holding this lane's first entry of the batch, `step` the byte distance to the next one; entry u of
+// the batch is valid iff first + u * vstep < n_valid (lane-dependent); jj / dd are the staged source
+// ids / deg^-1/2.
+template <int NEED, class C>
+__device__ inline void gather_batch(const AggArgs& a, const FastRsrc& R, FAcc<NEED>& acc, int addr0, int step, int row,
+                                    int jj, float dd, float dis_i, int n_valid, int first, int vstep,
+                                    unsigned row_bytes, unsigned slot_off) {
+  f4 v[FU];
+  float w[FU];
+  bool in_x[FU];
+#pragma unroll
+  for (int u = 0; u < FU; ++u) {
+    const int addr = addr0 + u * step;
+    const int j = bperm(addr, jj);
+    const bool is_self = j == row;
+    in_x[u] = (first + u * vstep < n_valid) && !(C::xl(a) && is_self);
+#ifdef EGC_ABL_NOGATHER
+    v[u] = f4{1.f, 2.f, 3.f, (float)j};
+#else
+    v[u] = load_slot(R.bases, in_x[u] ? (unsigned)j * row_bytes + slot_off : OOB);
+#endif
+    w[u] = bperm(addr, dd) * dis_i;
+    if (C::yl(a) && !C::xl(a)) w[u] = is_self ? 0.f : w[u];  // mixed sets: self-entry counts for sum/max only
+  }
+#pragma unroll
+  for (int u = 0; u < FU; ++u) fold<NEED>(acc, v[u], w[u], in_x[u]);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Epilogue shared by both roles.  Per lane group: `row` (same in all lanes of the group), the group's
 // merged aggregates, its entry count `deg` and self-entry count `nself`; `store` masks the output.
 // ---------------------------------------------------------------------------------------------
-template <int LPR_LOG2, int HPB, int NEED>
+template <int LPR_LOG2, int HPB, int NEED, class C>
 __device__ inline void finish_group(const AggArgs& a, const FastRsrc& R, int lane, int row, bool row_ok, FAcc<NEED>& acc,
                                     int deg, int nself, float dis_i, f4 vself, bool has_self, const f4 (&wpre)[2],
                                     bool store, float* lds_w, const float* lds_bias) {
   constexpr int LPR = 1 << LPR_LOG2;
   const int g = lane >> LPR_LOG2;
   const int q = lane & (LPR - 1);
-  const int b = q >> a.lpb_log2;
-  const int l4 = q & ((1 << a.lpb_log2) - 1);
+  const int b = q >> C::lpb_log2(a);
+  const int l4 = q & ((1 << C::lpb_log2(a)) - 1);
+  const int A = C::A(a), B = C::B(a), H = C::H(a), W = C::W(a);
 
   // (1) the row's weightings (nonlinearity applied) -> this group's LDS strip, 32 bytes per lane
   float* wl = lds_w + g * a.w_lds_stride;
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int c0 = (q + k * LPR) * 4;
-    if (c0 < a.W) {
+    if (c0 < W) {
       f4 t = wpre[k];
-      if (a.act == EGC_ACT_SIGMOID) {
+      if (C::act(a) == EGC_ACT_SIGMOID) {
         t = f4{1.0f / (1.0f + expf(-t.x)), 1.0f / (1.0f + expf(-t.y)), 1.0f / (1.0f + expf(-t.z)),
                1.0f / (1.0f + expf(-t.w))};
-      } else if (a.act == EGC_ACT_HARDTANH) {
+      } else if (C::act(a) == EGC_ACT_HARDTANH) {
         t = f4{fminf(fmaxf(t.x, -1.f), 1.f), fminf(fmaxf(t.y, -1.f), 1.f), fminf(fmaxf(t.z, -1.f), 1.f),
                fminf(fmaxf(t.w, -1.f), 1.f)};
       }
@@ -150,10 +253,11 @@ __device__ inline void finish_group(const AggArgs& a, const FastRsrc& R, int lan
 
   // (2) self-loop term and aggregator finalisation
   int cnt = deg;
-  if (a.x_looped) cnt = deg - nself + (has_self ? 1 : 0);
-  if ((a.x_looped || a.y_looped) && has_self) {
-    if (a.x_looped && a.y_looped) fold_plain<NEED>(acc, vself, dis_i * dis_i);  // vself is 0 where !has_self
-    else fold_masked<NEED>(acc, vself, dis_i * dis_i, a.x_looped != 0, a.y_looped != 0);
+  if (C::xl(a)) cnt = deg - nself + (has_self ? 1 : 0);
+  if (C::xl(a)) {
+    fold<NEED>(acc, vself, dis_i * dis_i, has_self);  // vself is 0 where the row has no self-loop
+  } else if (C::yl(a)) {
+    acc.ws = f4_fma(splat(dis_i * dis_i), vself, acc.ws);
   }
   const float cntf = (float)max(cnt, 1);
   const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
@@ -162,21 +266,21 @@ __device__ inline void finish_group(const AggArgs& a, const FastRsrc& R, int lan
     // exact divisions: var of identical neighbours must cancel to exactly 0 (see egc_aggregate_dev.h)
     mean = f4_div(acc.sum, cntf);
     var = f4_var(f4_div(acc.sq, cntf), mean);
-  } else if (a.need_mean) {
+  } else if (C::need_mean(a)) {
     // no var/std in this layer: one reciprocal instead of four IEEE divisions (<= 1 ulp from sum / cnt)
-    const float inv = 1.0f / cntf;
-    mean = acc.sum * f4{inv, inv, inv, inv};
+    mean = acc.sum * splat(__builtin_amdgcn_rcpf(cntf));
   }
+  const bool nonempty = cnt > 0;
   f4 val[AMAX];
 #pragma unroll
   for (int t = 0; t < AMAX; ++t) {
     val[t] = zero;
-    if (t < a.A) {  // wave-uniform
-      switch (a.aggr[t]) {
+    if (t < A) {  // wave-uniform
+      switch (C::aggr(a, t)) {
         case EGC_AGGR_SUM: val[t] = acc.sum; break;
         case EGC_AGGR_MEAN: val[t] = mean; break;
-        case EGC_AGGR_MAX: val[t] = cnt > 0 ? acc.mx : zero; break;
-        case EGC_AGGR_MIN: if constexpr (NEED & NEED_MN) val[t] = cnt > 0 ? acc.mn : zero; break;
+        case EGC_AGGR_MAX: val[t] = nonempty ? acc.mx : zero; break;
+        case EGC_AGGR_MIN: if constexpr (NEED & NEED_MN) val[t] = nonempty ? acc.mn : zero; break;
         case EGC_AGGR_VAR: val[t] = var; break;
         case EGC_AGGR_STD: val[t] = f4_std(var); break;
         default: val[t] = acc.ws; break;  // EGC_AGGR_SYMNORM
@@ -191,37 +295,38 @@ __device__ inline void finish_group(const AggArgs& a, const FastRsrc& R, int lan
 #pragma unroll
   for (int hb = 0; hb < HPB; ++hb) {
     o[hb] = zero;
-    for (int bb = 0; bb < a.B; ++bb) {
-      const int h = hb * a.B + bb;
-      if (h >= a.H) break;  // wave-uniform
-      const float* wp = wl + (h * a.B + b) * a.A;
+#pragma unroll 4
+    for (int bb = 0; bb < B; ++bb) {
+      const int h = hb * B + bb;
+      if (h >= H) break;  // wave-uniform
+      const float* wp = wl + (h * B + b) * A;
       f4 part;
-      if (a.A == 4) {  // wave-uniform
+      if (A == 4) {  // wave-uniform
         const f4 wv = *reinterpret_cast<const f4*>(wp);
-        part = val[0] * f4{wv.x, wv.x, wv.x, wv.x};
-        part = f4_fma(f4{wv.y, wv.y, wv.y, wv.y}, val[1], part);
-        part = f4_fma(f4{wv.z, wv.z, wv.z, wv.z}, val[2], part);
-        part = f4_fma(f4{wv.w, wv.w, wv.w, wv.w}, val[3], part);
+        part = val[0] * splat(wv.x);
+        part = f4_fma(splat(wv.y), val[1], part);
+        part = f4_fma(splat(wv.z), val[2], part);
+        part = f4_fma(splat(wv.w), val[3], part);
       } else {
-        part = zero;
-#pragma unroll
-        for (int t = 0; t < AMAX - 1; ++t)
-          if (t < a.A) {
-            const float w = wp[t];
-            part = f4_fma(f4{w, w, w, w}, val[t], part);
-          }
+        part = val[0] * splat(wp[0]);
+        if (A > 1) part = f4_fma(splat(wp[1]), val[1], part);
+        if (A > 2) part = f4_fma(splat(wp[2]), val[2], part);
       }
-      for (int off = 1 << a.lpb_log2; off < LPR; off <<= 1) part += bperm((lane ^ off) << 2, part);
+      if (LPR == 16 && C::lpb_log2(a) == 2) {
+        dpp_sum_over_4_bases(part);  // 4 bases x 4 slots inside one 16-lane DPP row: no LDS traffic
+      } else {
+        for (int off = 1 << C::lpb_log2(a); off < LPR; off <<= 1) part += bperm((lane ^ off) << 2, part);
+      }
       if (b == bb) o[hb] = part;
     }
   }
   // (4) bias + store: lane (b, l4) owns out[row, (hb*B + b)*L + 4*l4 ..+3]
-  const unsigned orow = (unsigned)row * (unsigned)a.F_out * 4u;
+  const unsigned orow = (unsigned)row * (unsigned)C::F_out(a) * 4u;
 #pragma unroll
   for (int hb = 0; hb < HPB; ++hb) {
-    const int h = hb * a.B + b;
-    const bool mine = store && row_ok && h < a.H;
-    const int oc = h * a.L + 4 * l4;
+    const int h = hb * B + b;
+    const bool mine = store && row_ok && h < H;
+    const int oc = h * C::L(a) + 4 * l4;
     const f4 r = o[hb] + *reinterpret_cast<const f4*>(lds_bias + (mine ? oc : 0));
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, r), R.out, mine ? orow + (unsigned)oc * 4u : OOB, 0, 0);
   }
@@ -229,25 +334,26 @@ __device__ inline void finish_group(const AggArgs& a, const FastRsrc& R, int lan
 }
 
 // Row-only operands of the epilogue (weightings row as 2 x 16 bytes per lane, own basis slot).
-template <int LPR_LOG2>
+template <int LPR_LOG2, class C>
 __device__ inline void load_row_operands(const AggArgs& a, const FastRsrc& R, int lane, int row, bool row_ok,
                                          f4 (&wpre)[2], f4& vself, bool& has_self) {
   constexpr int LPR = 1 << LPR_LOG2;
   const int q = lane & (LPR - 1);
-  const int nloop = a.loops_all ? a.n_nodes : (*a.max_index + 1);
+  const int W = C::W(a);
+  const int nloop = C::loops_all(a) ? a.n_nodes : (*a.max_index + 1);
   has_self = row_ok && row < nloop;
-  const bool want_self = (a.x_looped || a.y_looped) && has_self;
+  const bool want_self = (C::xl(a) || C::yl(a)) && has_self;
   vself = load_slot(R.bases, want_self ? (unsigned)row * (unsigned)a.ldb * 4u + (unsigned)q * 16u : OOB);
-  const float* wrow = a.weightings + (int64_t)(row_ok ? row : 0) * a.W;
+  const float* wrow = a.weightings + (int64_t)(row_ok ? row : 0) * W;
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int c0 = (q + k * LPR) * 4;
     wpre[k] = f4{0.f, 0.f, 0.f, 0.f};
-    if (c0 + 3 < a.W) wpre[k] = *reinterpret_cast<const f4*>(wrow + c0);
-    else if (c0 < a.W) {  // W not a multiple of 4: ragged last piece
+    if (c0 + 3 < W) wpre[k] = *reinterpret_cast<const f4*>(wrow + c0);
+    else if (c0 < W) {  // W not a multiple of 4: ragged last piece
       wpre[k].x = wrow[c0];
-      if (c0 + 1 < a.W) wpre[k].y = wrow[c0 + 1];
-      if (c0 + 2 < a.W) wpre[k].z = wrow[c0 + 2];
+      if (c0 + 1 < W) wpre[k].y = wrow[c0 + 1];
+      if (c0 + 2 < W) wpre[k].z = wrow[c0 + 2];
     }
   }
 }
@@ -255,10 +361,16 @@ __device__ inline void load_row_operands(const AggArgs& a, const FastRsrc& R, in
 // ---------------------------------------------------------------------------------------------
 // kernel
 // ---------------------------------------------------------------------------------------------
-template <int LPR_LOG2, int HPB, int NEED>
+template <int LPR_LOG2, int HPB, int NEED, class C>
 __global__ void __launch_bounds__(256) agg_fast_kernel(AggArgs a) {
   constexpr int LPR = 1 << LPR_LOG2, G = 64 / LPR;
   extern __shared__ float smem[];
+#ifdef EGC_ABL_NOCHUNK
+  if ((int)blockIdx.x < a.chunk_blocks) return;
+#endif
+#ifdef EGC_ABL_NOROWS
+  if ((int)blockIdx.x >= a.chunk_blocks) return;
+#endif
   if ((int)blockIdx.x < a.chunk_blocks && (int)blockIdx.x * 4 >= a.plan[1]) return;  // unused chunk slots
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -266,15 +378,16 @@ __global__ void __launch_bounds__(256) agg_fast_kernel(AggArgs a) {
   const int q = lane & (LPR - 1);
   const unsigned slot_off = (unsigned)q * 16u;
   const unsigned row_bytes = (unsigned)a.ldb * 4u;
+  const int F_out = C::F_out(a);
   // per-wavefront LDS: [bias F_out][G weight strips]
   float* lds_bias = smem + wave * a.lds_floats_per_wave;
-  float* lds_w = lds_bias + ((a.F_out + 3) & ~3);
-  for (int o = lane; o < a.F_out; o += 64) lds_bias[o] = a.bias != nullptr ? a.bias[o] : 0.f;
+  float* lds_w = lds_bias + ((F_out + 3) & ~3);
+  for (int o = lane; o < F_out; o += 64) lds_bias[o] = a.bias != nullptr ? a.bias[o] : 0.f;
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   FastRsrc R;
   R.bases = bases_rsrc(a);
-  R.out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (unsigned)a.n_nodes * (unsigned)a.F_out * 4u, 0x00020000);
-  const bool xl = a.x_looped != 0, yl = a.y_looped != 0;
+  R.out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (unsigned)a.n_nodes * (unsigned)F_out * 4u, 0x00020000);
+  const bool looped_any = C::xl(a) || C::yl(a);
 
   if ((int)blockIdx.x < a.chunk_blocks) {
     // ---------------- long-row chunk role: the G groups split one chunk's entries ----------------
@@ -294,6 +407,12 @@ __global__ void __launch_bounds__(256) agg_fast_kernel(AggArgs a) {
     const int deg = row_end - row_start;
     const int nch = (deg + EGC_LONG_ROW_CHUNK - 1) / EGC_LONG_ROW_CHUNK;
     const float dis_i = a.dis != nullptr ? a.dis[row] : 0.f;
+#ifdef EGC_ABL_C_SINGLE
+    if (nch > 1) return;
+#endif
+#ifdef EGC_ABL_C_MULTI
+    if (nch == 1) return;
+#endif
     FAcc<NEED> acc;
     acc.init();
     int nself = 0;
@@ -302,46 +421,31 @@ __global__ void __launch_bounds__(256) agg_fast_kernel(AggArgs a) {
       const bool pv = p < end;
       const int jj = pv ? a.col[p] : row;
       const float dd = a.dis != nullptr ? a.dis[jj] : 0.f;
-      const int ns = __popcll(__ballot(pv && jj == row));
-      nself += ns;
-      const bool masked_all = ns > 0 && (xl || yl);
+      if (looped_any) nself += __popcll(__ballot(pv && jj == row));
       const int cnt = min(64, end - base);
-      for (int t0 = 0; t0 < cnt; t0 += FU * G) {
-        f4 v[FU];
-        const int n_in = min(cnt - t0, FU * G);
-#pragma unroll
-        for (int u = 0; u < FU; ++u) {
-          const int j = bperm((g + t0 + u * G) << 2, jj);
-          v[u] = load_slot(R.bases, (u * G + g < n_in) ? (unsigned)j * row_bytes + slot_off : OOB);
-        }
-#pragma unroll
-        for (int u = 0; u < FU; ++u) {
-          if (u * G >= n_in) break;
-          const float w = bperm((g + t0 + u * G) << 2, dd) * dis_i;
-          if (!masked_all && (u + 1) * G <= n_in) {
-            fold_plain<NEED>(acc, v[u], w);
-          } else {
-            const bool ok = u * G + g < n_in;
-            const bool is_self = bperm((g + t0 + u * G) << 2, jj) == row;
-            fold_masked<NEED>(acc, v[u], w, ok && !(xl && is_self), ok && !(yl && is_self));
-          }
-        }
-      }
+      for (int t0 = 0; t0 < cnt; t0 += FU * G)
+        gather_batch<NEED, C>(a, R, acc, (g + t0) << 2, G << 2, row, jj, dd, dis_i, cnt, t0 + g, G, row_bytes, slot_off);
     }
     all_reduce_groups<LPR_LOG2, NEED>(acc, lane);
     if (nch > 1) {
-      if (g == 0) {
-        f4* rec = reinterpret_cast<f4*>(a.partial) + (int64_t)c * 5 * LPR;
-        rec[0 * LPR + q] = acc.sum;
-        rec[2 * LPR + q] = acc.mx;
-        rec[4 * LPR + q] = acc.ws;
-        if constexpr (NEED & NEED_SQ) rec[1 * LPR + q] = acc.sq;
-        if constexpr (NEED & NEED_MN) rec[3 * LPR + q] = acc.mn;
-      }
-      if (lane == 0) a.partial_nself[c] = nself;
-      // publish: stores drained -> agent-scope release -> arrival counter
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      // Publish this chunk's record with write-through (sc0 sc1) stores and drain them before the
+      // arrival counter is bumped: the data then sits at the memory side without an agent-scope release
+      // fence -- a whole-L2 write-back that costs tens of microseconds when hundreds of chunks publish
+      // (cdna guide, Guideline 16 "valid forms": sc1 stores + drained + counter; consumer keeps its acquire).
+      constexpr int WT = 0x11;  // aux bits: sc0 | sc1
+      const __amdgpu_buffer_rsrc_t pw = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(reinterpret_cast<f4*>(a.partial) + (int64_t)c * 5 * LPR), 0, 5u * LPR * 16u, 0x00020000);
+      const unsigned po = g == 0 ? (unsigned)q * 16u : OOB;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, acc.sum), pw, po, 0 * LPR * 16, WT);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, acc.mx), pw, po, 2 * LPR * 16, WT);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, acc.ws), pw, po, 4 * LPR * 16, WT);
+      if constexpr (NEED & NEED_SQ)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, acc.sq), pw, po, 1 * LPR * 16, WT);
+      if constexpr (NEED & NEED_MN)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, acc.mn), pw, po, 3 * LPR * 16, WT);
+      const __amdgpu_buffer_rsrc_t pn =
+          __builtin_amdgcn_make_buffer_rsrc((void*)(a.partial_nself + c), 0, 4u, 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b32(nself, pn, lane == 0 ? 0u : OOB, 0, WT);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       int arrived = 0;
       if (lane == 0) arrived = __hip_atomic_fetch_add(&a.counters[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -353,26 +457,47 @@ __global__ void __launch_bounds__(256) agg_fast_kernel(AggArgs a) {
       if (lane == 0) __hip_atomic_store(&a.counters[slot], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int c0 = __builtin_amdgcn_readfirstlane(long_chunk0[slot]);
       acc.init();
-      for (int k0 = g; k0 < nch; k0 += G) {
-        const f4* rec = reinterpret_cast<const f4*>(a.partial) + (int64_t)(c0 + k0) * 5 * LPR;
-        acc.sum += rec[0 * LPR + q];
-        acc.mx = f4_vmax(acc.mx, rec[2 * LPR + q]);
-        acc.ws += rec[4 * LPR + q];
-        if constexpr (NEED & NEED_SQ) acc.sq += rec[1 * LPR + q];
-        if constexpr (NEED & NEED_MN) acc.mn = f4_vmin(acc.mn, rec[3 * LPR + q]);
+      // MU records per group in flight (a hub row has hundreds of chunks)
+      constexpr int MU = 4;
+      const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(reinterpret_cast<const f4*>(a.partial) + (int64_t)c0 * 5 * LPR), 0,
+          (unsigned)nch * 5u * LPR * 16u, 0x00020000);
+      for (int k0 = g; k0 < nch; k0 += G * MU) {
+        f4 rs[MU], rm[MU], rw[MU], rq[MU], rn[MU];
+#pragma unroll
+        for (int m = 0; m < MU; ++m) {
+          const int kk = k0 + m * G;
+          const unsigned off = kk < nch ? ((unsigned)kk * 5u * LPR + (unsigned)q) * 16u : OOB;
+          rs[m] = load_slot_wt(prs, off);
+          rm[m] = load_slot_wt(prs, off == OOB ? OOB : off + 2u * LPR * 16u);
+          rw[m] = load_slot_wt(prs, off == OOB ? OOB : off + 4u * LPR * 16u);
+          if constexpr (NEED & NEED_SQ) rq[m] = load_slot_wt(prs, off == OOB ? OOB : off + 1u * LPR * 16u);
+          if constexpr (NEED & NEED_MN) rn[m] = load_slot_wt(prs, off == OOB ? OOB : off + 3u * LPR * 16u);
+        }
+#pragma unroll
+        for (int m = 0; m < MU; ++m) {
+          acc.sum += rs[m];  // out-of-range records read as 0: neutral for the sums
+          acc.ws += rw[m];
+          if constexpr (NEED & NEED_SQ) acc.sq += rq[m];
+          if (k0 + m * G < nch) {
+            acc.mx = f4_vmax(acc.mx, rm[m]);
+            if constexpr (NEED & NEED_MN) acc.mn = f4_vmin(acc.mn, rn[m]);
+          }
+        }
       }
       all_reduce_groups<LPR_LOG2, NEED>(acc, lane);
       nself = 0;
-      for (int k = lane; k < nch; k += 64) nself += a.partial_nself[c0 + k];
+      for (int k = lane; k < nch; k += 64)
+        nself += __hip_atomic_load(&a.partial_nself[c0 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) nself += bperm((lane ^ off) << 2, nself);
     }
     // every group now holds the whole row: all run the epilogue, group 0 stores
     f4 wpre[2], vself;
     bool has_self;
-    load_row_operands<LPR_LOG2>(a, R, lane, row, true, wpre, vself, has_self);
-    finish_group<LPR_LOG2, HPB, NEED>(a, R, lane, row, true, acc, deg, nself, dis_i, vself, has_self, wpre, g == 0,
-                                      lds_w, lds_bias);
+    load_row_operands<LPR_LOG2, C>(a, R, lane, row, true, wpre, vself, has_self);
+    finish_group<LPR_LOG2, HPB, NEED, C>(a, R, lane, row, true, acc, deg, nself, dis_i, vself, has_self, wpre, g == 0,
+                                         lds_w, lds_bias);
     return;
   }
 
@@ -404,20 +529,20 @@ __global__ void __launch_bounds__(256) agg_fast_kernel(AggArgs a) {
       nd_n = (rbase + G + g < a.n_nodes && deg <= EGC_LONG_ROW_THRESHOLD) ? deg : 0;
       jj_n = q < nd_n ? a.col[start_n + q] : 0;
     }
-    // wave-uniform trip counts: entries still valid in every group / in any group
-    int maxd = nd, mind = nd;
+    // wave-uniform trip count: entries still valid in any group
+    int maxd = nd;
 #pragma unroll
-    for (int off = LPR; off < 64; off <<= 1) {
-      maxd = max(maxd, bperm((lane ^ off) << 2, maxd));
-      mind = min(mind, bperm((lane ^ off) << 2, mind));
-    }
+    for (int off = LPR; off < 64; off <<= 1) maxd = max(maxd, bperm((lane ^ off) << 2, maxd));
     maxd = __builtin_amdgcn_readfirstlane(maxd);
-    mind = __builtin_amdgcn_readfirstlane(mind);
     // row-only operands, issued ahead of the gathers
     f4 wpre[2], vself;
     bool has_self;
     const float dis_i = (a.dis != nullptr && row_ok) ? a.dis[row] : 0.f;
-    load_row_operands<LPR_LOG2>(a, R, lane, row, row_ok, wpre, vself, has_self);
+#ifdef EGC_ABL_NOOPER
+    wpre[0] = wpre[1] = vself = f4{1.f, 1.f, 1.f, 1.f}; has_self = row_ok;
+#else
+    load_row_operands<LPR_LOG2, C>(a, R, lane, row, row_ok, wpre, vself, has_self);
+#endif
 
     FAcc<NEED> acc;
     acc.init();
@@ -426,34 +551,13 @@ __global__ void __launch_bounds__(256) agg_fast_kernel(AggArgs a) {
       if (ts > 0) jj = (ts + q < nd) ? a.col[start + ts + q] : 0;  // rows of more than LPR entries
       const bool pv = ts + q < nd;
       const float dd = (a.dis != nullptr && pv) ? a.dis[jj] : 0.f;
-      bool masked_all = false;
-      if (xl || yl) {  // self-entries are excluded from LOOPED sets: count them per group
+      if (looped_any) {  // self-entries are excluded from LOOPED sets: count them per group
         const unsigned long long sb = __ballot(pv && jj == row);
-        masked_all = sb != 0;
         nself += __popcll((sb >> (g << LPR_LOG2)) & ((LPR == 64) ? ~0ull : ((1ull << LPR) - 1ull)));
       }
       const int cnt = min(LPR, maxd - ts);  // wave-uniform
-      for (int t0 = 0; t0 < cnt; t0 += FU) {
-        f4 v[FU];
-#pragma unroll
-        for (int u = 0; u < FU; ++u) {
-          const int j = bperm(grp_addr + ((t0 + u) << 2), jj);
-          v[u] = load_slot(R.bases, (ts + t0 + u < nd) ? (unsigned)j * row_bytes + slot_off : OOB);
-        }
-#pragma unroll
-        for (int u = 0; u < FU; ++u) {
-          const int e = ts + t0 + u;  // wave-uniform entry index inside each group's row
-          if (e >= maxd) break;
-          const float w = bperm(grp_addr + ((t0 + u) << 2), dd) * dis_i;
-          if (!masked_all && e < mind) {
-            fold_plain<NEED>(acc, v[u], w);
-          } else {
-            const bool ok = e < nd;
-            const bool is_self = bperm(grp_addr + ((t0 + u) << 2), jj) == row;
-            fold_masked<NEED>(acc, v[u], w, ok && !(xl && is_self), ok && !(yl && is_self));
-          }
-        }
-      }
+      for (int t0 = 0; t0 < cnt; t0 += FU)
+        gather_batch<NEED, C>(a, R, acc, grp_addr + (t0 << 2), 4, row, jj, dd, dis_i, nd, ts + t0, 1, row_bytes, slot_off);
     }
     // Opaque copy of the lane id: keeps the compiler from hoisting the epilogue's lane arithmetic out
     // of the row loop, where it would stay live across the gathers and cost occupancy.
@@ -461,13 +565,18 @@ __global__ void __launch_bounds__(256) agg_fast_kernel(AggArgs a) {
     asm volatile("" : "+v"(ln));
     const int deg_all = bperm((k * G + g + 1) << 2, rp) - start;
     const bool is_short = deg_all <= EGC_LONG_ROW_THRESHOLD;
-    finish_group<LPR_LOG2, HPB, NEED>(a, R, ln, row, row_ok, acc, nd, nself, dis_i, vself, has_self, wpre, is_short,
-                                      lds_w, lds_bias);
+#ifdef EGC_ABL_NOEPI
+    if (is_short && row_ok) a.out[(int64_t)row * F_out + q * 4] = acc.sum.x + acc.mx.y + acc.ws.z + wpre[0].x + wpre[1].y + vself.x + nself;
+#else
+    finish_group<LPR_LOG2, HPB, NEED, C>(a, R, ln, row, row_ok, acc, nd, nself, dis_i, vself, has_self, wpre, is_short,
+                                         lds_w, lds_bias);
+#endif
   }
 }
 
 bool fast_path_supported(const AggArgs& a, int layout, int chunks) {
   if (chunks != 1 || layout != EGC_LAYOUT_HBA || a.act == EGC_ACT_SOFTMAX) return false;
+  if (a.x_looped && !a.y_looped) return false;  // never produced by either layer class
   if (a.slots != 16 && a.slots != 32 && a.slots != 64) return false;
   if (a.ldb != a.B * a.L) return false;
   if (a.L < 4 || (a.L & (a.L - 1)) != 0 || (a.B & (a.B - 1)) != 0) return false;
@@ -479,35 +588,59 @@ bool fast_path_supported(const AggArgs& a, int layout, int chunks) {
   return true;
 }
 
-template <int LPR_LOG2, int HPB, int NEED>
+template <int LPR_LOG2, int HPB, int NEED, class C>
 static int launch_one(const AggArgs& a, unsigned grid, size_t lds, hipStream_t stream) {
-  agg_fast_kernel<LPR_LOG2, HPB, NEED><<<grid, 256, lds, stream>>>(a);
+  agg_fast_kernel<LPR_LOG2, HPB, NEED, C><<<grid, 256, lds, stream>>>(a);
   EGC_LAUNCH_CHECK("agg_fast_kernel");
   return EGC_OK;
 }
 
 template <int LPR_LOG2, int HPB>
 static int launch_need(const AggArgs& a, int need, unsigned grid, size_t lds, hipStream_t stream) {
-  if (need == 0) return launch_one<LPR_LOG2, HPB, 0>(a, grid, lds, stream);
-  return launch_one<LPR_LOG2, HPB, NEED_SQ | NEED_MN>(a, grid, lds, stream);
+  if (need == 0) return launch_one<LPR_LOG2, HPB, 0, RtCfg>(a, grid, lds, stream);
+  return launch_one<LPR_LOG2, HPB, NEED_SQ | NEED_MN, RtCfg>(a, grid, lds, stream);
 }
 
 template <int LPR_LOG2>
-static int launch_a(const AggArgs& a, int need, unsigned grid, size_t lds, hipStream_t stream) {
+static int launch_rt(const AggArgs& a, int need, unsigned grid, size_t lds, hipStream_t stream) {
   const int hpb = (a.H + a.B - 1) / a.B;
   if (hpb <= 1) return launch_need<LPR_LOG2, 1>(a, need, grid, lds, stream);
   if (hpb <= 2) return launch_need<LPR_LOG2, 2>(a, need, grid, lds, stream);
   return launch_need<LPR_LOG2, 4>(a, need, grid, lds, stream);
 }
 
+constexpr unsigned agg_pack(int a0, int a1 = 0, int a2 = 0, int a3 = 0) {
+  return (unsigned)a0 | ((unsigned)a1 << 3) | ((unsigned)a2 << 6) | ((unsigned)a3 << 9);
+}
+
+// Statically specialised configurations (H, B, L, aggregator list, nonlinearity, edge sets).  Adding a
+// line to launch_fast() buys the constant-folded kernel for that layer; everything else runs RtCfg.
+template <class C, int LPR_LOG2, int HPB, int NEED>
+static bool try_static(const AggArgs& a, int h, int b, int l, int na, unsigned agg, int act, bool xl, bool yl,
+                       bool loops_all, unsigned grid, size_t lds, hipStream_t stream, int* status) {
+  unsigned packed = 0;
+  for (int t = 0; t < a.A; ++t) packed |= (unsigned)a.aggr[t] << (3 * t);
+  if (a.H != h || a.B != b || a.L != l || a.A != na || packed != agg || a.act != act ||
+      (a.x_looped != 0) != xl || (a.y_looped != 0) != yl || (a.loops_all != 0) != loops_all ||
+      a.slots != (1 << LPR_LOG2))
+    return false;
+  *status = launch_one<LPR_LOG2, HPB, NEED, C>(a, grid, lds, stream);
+  return true;
+}
+
+#define EGC_STATIC_CFG(H, B, L, A, AGG, ACT, XL, YL, LA, NEED)                                                      \
+  if (try_static<StCfg<H, B, L, A, AGG, ACT, XL, YL, LA>, ilog2((B) * (L) / 4), ((H) + (B)-1) / (B), NEED>(         \
+          a, H, B, L, A, AGG, ACT, XL, YL, LA, grid, lds, stream, &status))                                         \
+    return status;
+
 int launch_fast(AggArgs a, int64_t n_nodes, const PlanCaps& caps, hipStream_t stream) {
   const int G = 64 / a.slots;
   int lg = 0;
   while ((4 << lg) < a.L) ++lg;
   a.lpb_log2 = lg;
-  if (a.rows_per_wave <= 0) a.rows_per_wave = 4;
+  if (a.rows_per_wave <= 0) a.rows_per_wave = 1;
   if (a.rows_per_wave * G > 60) a.rows_per_wave = 60 / G;
-  a.chunk_blocks = (int)ceil_div(caps.cap_chunks, 4);
+  a.chunk_blocks = (int)ceil_div(a.n_chunks_hint >= 0 ? a.n_chunks_hint : caps.cap_chunks, 4);
   a.need_mean = a.need_var = 0;
   int need = 0;
   for (int t = 0; t < a.A; ++t) {
@@ -521,10 +654,22 @@ int launch_fast(AggArgs a, int64_t n_nodes, const PlanCaps& caps, hipStream_t st
   if (lds > 64 * 1024) return EGC_ERR_UNSUPPORTED;
   const int64_t row_blocks = ceil_div(n_nodes, (int64_t)4 * a.rows_per_wave * G);
   const unsigned grid = (unsigned)(a.chunk_blocks + row_blocks);
+
+  if (getenv("EGC_NO_STATIC_CFG") == nullptr) {
+    int status = EGC_OK;
+    constexpr int S = EGC_AGGR_SUM, M = EGC_AGGR_MEAN, X = EGC_AGGR_MAX, Y = EGC_AGGR_SYMNORM;
+    // EGConv / EGC-M north star: d=128, H=8, B=4, sum+mean+max+symnorm, gcn_norm self-loops on every node
+    EGC_STATIC_CFG(8, 4, 16, 4, agg_pack(S, M, X, Y), EGC_ACT_NONE, true, true, true, 0)
+    // EGConv / EGC-S default: symnorm only (optimized_layers.py:77)
+    EGC_STATIC_CFG(8, 4, 16, 1, agg_pack(Y), EGC_ACT_NONE, true, true, true, 0)
+    // EfficientGraphConv EGC-M / EGC-S flavours at d=128 (symadd looped, the others raw): layers.py:166-193
+    EGC_STATIC_CFG(8, 4, 16, 3, agg_pack(Y, X, M), EGC_ACT_NONE, false, true, true, 0)
+    EGC_STATIC_CFG(8, 4, 16, 1, agg_pack(Y), EGC_ACT_NONE, false, true, true, 0)
+  }
   switch (a.slots) {
-    case 16: return launch_a<4>(a, need, grid, lds, stream);
-    case 32: return launch_a<5>(a, need, grid, lds, stream);
-    case 64: return launch_a<6>(a, need, grid, lds, stream);
+    case 16: return launch_rt<4>(a, need, grid, lds, stream);
+    case 32: return launch_rt<5>(a, need, grid, lds, stream);
+    case 64: return launch_rt<6>(a, need, grid, lds, stream);
     default: return EGC_ERR_UNSUPPORTED;
   }
 }

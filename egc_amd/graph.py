@@ -37,6 +37,7 @@ class CSRGraph:
         self.dis_raw, self.dis_looped, self.max_index, self.plan = dis_raw, dis_looped, max_index, plan
         self.device = rowptr.device
         self._workspaces = {}
+        self._n_chunks = None  # host copy of plan[1], read back lazily (one synchronisation per graph)
 
     # -- construction ---------------------------------------------------------------------
     @classmethod
@@ -98,9 +99,11 @@ class CSRGraph:
 
     # -- C view -----------------------------------------------------------------------------
     def c_struct(self) -> _C.EgcGraph:
+        if self._n_chunks is None:
+            self._n_chunks = int(self.plan[1].item())
         return _C.EgcGraph(self.n_nodes, self.n_edges, self.rowptr.data_ptr(), self.col.data_ptr(),
                            self.edge_id.data_ptr(), self.dis_raw.data_ptr(), self.dis_looped.data_ptr(),
-                           self.max_index.data_ptr(), self.plan.data_ptr())
+                           self.max_index.data_ptr(), self.plan.data_ptr(), self._n_chunks)
 
     def long_row_stats(self):
         """(n_long_rows, n_chunks) -- synchronises; diagnostics only."""

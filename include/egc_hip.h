@@ -82,6 +82,8 @@ typedef struct {
   const float* dis_looped;    /* [n_nodes] (non-self indeg + 1)^-1/2; NULL if unused */
   const int32_t* max_index;   /* device scalar: largest node id present in edge_index (-1 if none) */
   const int32_t* plan;        /* [egc_plan_ints(n_nodes,n_edges)] long-row work plan from egc_csr_prepare */
+  int64_t n_chunks;           /* HOST copy of plan[1] (number of long-row chunks) if the caller has read it
+                                 back, else -1: the launch is then sized for the plan's capacity */
 } egc_graph;
 
 /* int32 words the caller must allocate for egc_graph.plan. */
