@@ -120,7 +120,9 @@ def main():
 
     graph = egc_amd.CSRGraph.from_edge_index(ei, n)
     spec: LayerSpec = conv._spec_coo
+    from egc_amd.functional import pack_weights
     wcat, bcat = conv._packed_weights()
+    planes = pack_weights(spec, wcat)  # bf16x3 weight planes, rebuilt only when parameters change
     bias = conv.bias.detach()
     ldb = spec.ldb
     bases = torch.empty((n, ldb), device=dev)
@@ -131,15 +133,15 @@ def main():
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     def step():  # one full layer forward through the C ABI
-        _C.check(lib.egc_layer_forward_f32(C.byref(g), C.byref(spec.c), x.data_ptr(), wcat.data_ptr(),
-                                           bcat.data_ptr(), bias.data_ptr(), bases.data_ptr(), ldb,
-                                           weightings.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), stream),
-                 "egc_layer_forward_f32")
+        _C.check(lib.egc_layer_forward_packed(C.byref(g), C.byref(spec.c), x.data_ptr(), planes.data_ptr(),
+                                              bcat.data_ptr(), bias.data_ptr(), bases.data_ptr(), ldb,
+                                              weightings.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), stream),
+                 "egc_layer_forward_packed")
 
     def gemm_only():
-        _C.check(lib.egc_basis_transform_f32(x.data_ptr(), wcat.data_ptr(), bcat.data_ptr(), n, F_IN, spec.f_g,
-                                             spec.w_cols, bases.data_ptr(), ldb, weightings.data_ptr(), stream),
-                 "egc_basis_transform_f32")
+        _C.check(lib.egc_basis_transform_packed(x.data_ptr(), planes.data_ptr(), bcat.data_ptr(), n, F_IN, spec.f_g,
+                                                spec.w_cols, bases.data_ptr(), ldb, weightings.data_ptr(), stream),
+                 "egc_basis_transform_packed")
 
     def agg_only():
         _C.check(lib.egc_aggregate_combine_f32(C.byref(g), C.byref(spec.c), bases.data_ptr(), ldb,

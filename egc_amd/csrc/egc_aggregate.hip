@@ -476,4 +476,19 @@ int egc_layer_forward_f32(const egc_graph* graph, const egc_layer* layer, const 
                                    workspace_bytes, stream);
 }
 
+int egc_layer_forward_packed(const egc_graph* graph, const egc_layer* layer, const float* x, const void* packed,
+                             const float* bcat, const float* bias, float* bases, int32_t ldb, float* weightings,
+                             float* out, void* workspace, size_t workspace_bytes, egc_stream_t stream) {
+  if (graph == nullptr) return EGC_ERR_INVALID;
+  int st = validate_layer(layer);
+  if (st != EGC_OK) return st;
+  const int fg = layer->num_bases * (layer->out_channels / layer->num_heads);
+  const int w = layer->num_heads * layer->num_bases * layer->num_aggrs;
+  st = egc_basis_transform_packed(x, packed, bcat, graph->n_nodes, layer->in_channels, fg, w, bases, ldb, weightings,
+                                  stream);
+  if (st != EGC_OK) return st;
+  return egc_aggregate_combine_f32(graph, layer, bases, ldb, weightings, bias, out, nullptr, nullptr, workspace,
+                                   workspace_bytes, stream);
+}
+
 }  // extern "C"

@@ -1,0 +1,705 @@
+// Basis transform + weightings Linear on the bf16 matrix cores with fp32-level accuracy (gfx950).
+//
+//     [bases | weightings] = x[N,F_in] @ [bases_weight | comb.weight^T]  (+ comb.bias)
+//
+// Reference behaviour replaced: torch.matmul(x, bases_weight) (experiments/layers.py:97-101,
+// optimized_layers.py:180) and comb_weights(x) (layers.py:110, optimized_layers.py:182).
+//
+// Why not the fp32 MFMA: v_mfma_f32_32x32x2_f32 runs at the fp32 vector rate (157 TF), which makes this
+// 8.3-GFLOP GEMM the largest item of the layer (~125 us); on bf16 MFMA (2.5 PF dense) it is bound by its
+// 217 MB of HBM traffic instead.  Accuracy is kept by splitting BOTH operands into three bf16 planes,
+//     x = xh + xm + xl,   w = wh + wm + wl     (each plane = round-to-nearest of the running remainder,
+//                                               so the three planes carry ~24 significand bits)
+// and accumulating the six products  xl*wh, xh*wl, xm*wm, xm*wh, xh*wm, xh*wh  (smallest first) in the
+// MFMA's fp32 accumulators.  The dropped terms (xm*wl, xl*wm, xl*wl) are < 2^-23 relative to |x||w|, the
+// same order as one fp32 rounding, so the result is within GEMM-reordering distance of the reference's
+// fp32 GEMM (parity tests: <= 1e-5, measured ~2e-7).
+//
+// The weight planes are split once per parameter update by egc_basis_pack_bf16x3 into the staging
+// layout [k-step][plane][virtual column][32 k] (bf16), so the kernel copies them to LDS as 16-byte
+// pieces.  The virtual column space is the one of egc_gemm.hip: [0,F_g) bases, [F_g,ldb) zero pad,
+// [ldb,ldb+W) weightings, zero-padded to a multiple of 32.
+//
+// Tiling: 128 x 192 block tile (all columns of the north-star shape in one pass over x), K walked in
+// steps of 32; 4 wavefronts stacked along M, each 32 rows x 6 column tiles = 6 accumulators of 32x32.
+#include <stdlib.h>
+
+#include "egc_common.h"
+
+namespace egc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int XBM = 128;      // rows per block
+constexpr int XBN = 192;      // virtual columns per block (6 MFMA tiles)
+constexpr int XKT = 32;       // k per staging step
+constexpr int XLD = 40;       // LDS row stride in bf16 (80 B: conflict-free ds_read_b128 of 16-byte k-runs)
+
+__device__ inline u16 bf16_rn(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u16)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ inline float bf16_f(u16 h) { return __uint_as_float((unsigned)h << 16); }
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Two floats -> three packed bf16 pairs (h, m, l planes) with v_cvt_pk_bf16_f32 (round to nearest even):
+// 9 VALU instructions per pair.  Element 0 sits in the low half of each packed word.
+__device__ inline void split3_pk(f32x2 v, unsigned& h, unsigned& m, unsigned& l) {
+  h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+  const f32x2 r1 = v - f32x2{__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)};
+  m = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
+  const f32x2 r2 = r1 - f32x2{__uint_as_float(m << 16), __uint_as_float(m & 0xffff0000u)};
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
+}
+
+// f = h + m + l up to ~2^-25 |f|
+__device__ inline void split3(float f, u16& h, u16& m, u16& l) {
+  h = bf16_rn(f);
+  const float r1 = f - bf16_f(h);
+  m = bf16_rn(r1);
+  l = bf16_rn(r1 - bf16_f(m));
+}
+
+// packed[ks][plane][v][32] : plane p of w[k = 32*ks + kk][source column of v]
+__global__ void __launch_bounds__(256) pack_bf16x3_kernel(const float* __restrict__ wcat, int K, int F_g, int W, int ldb,
+                                                          int NV, int KS, u16* __restrict__ packed) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (ks, v, kk)
+  const int total = KS * NV * XKT;
+  if (idx >= total) return;
+  const int kk = idx % XKT;
+  const int v = (idx / XKT) % NV;
+  const int ks = idx / (XKT * NV);
+  const int k = ks * XKT + kk;
+  const int src = (v < F_g) ? v : ((v < ldb || v >= ldb + W) ? -1 : v - ldb + F_g);
+  const float w = (src >= 0 && k < K) ? wcat[(int64_t)k * (F_g + W) + src] : 0.f;
+  u16 h, m, l;
+  split3(w, h, m, l);
+  const int64_t base = ((int64_t)ks * 3 * NV + v) * XKT + kk;
+  packed[base] = h;
+  packed[base + (int64_t)NV * XKT] = m;
+  packed[base + 2 * (int64_t)NV * XKT] = l;
+}
+
+template <bool A_VEC4>
+__global__ void __launch_bounds__(256) basis_gemm_bf16x3_kernel(const float* __restrict__ x, const u16* __restrict__ packed,
+                                                                const float* __restrict__ bcat, int64_t M, int K,
+                                                                int W, float* __restrict__ bases, int ldb,
+                                                                float* __restrict__ weightings, int NV, int KS) {
+  // one LDS allocation, carved explicitly (the epilogue re-uses it as the transpose buffer)
+  constexpr int A_ELEMS = 3 * XBM * XLD, B_ELEMS = 3 * XBN * XLD;
+  __shared__ __attribute__((aligned(16))) u16 lds_raw[A_ELEMS + B_ELEMS];
+  u16 (*As)[XBM][XLD] = reinterpret_cast<u16 (*)[XBM][XLD]>(lds_raw);
+  u16 (*Bs)[XBN][XLD] = reinterpret_cast<u16 (*)[XBN][XLD]>(lds_raw + A_ELEMS);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int64_t m0 = (int64_t)blockIdx.x * XBM;
+  const int v0 = blockIdx.y * XBN;
+  const int nvb = min(XBN, NV - v0);  // virtual columns of this block (multiple of 32)
+  const int ntile = nvb >> 5;
+
+  f32x16 acc[6];
+#pragma unroll
+  for (int t = 0; t < 6; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // x tile of one k-step: 4 x float4 per thread, loaded unconditionally (clamped address, masked after)
+  // so the four loads are in flight together; the tile of step ks+1 is fetched before the MFMAs of step ks.
+  float4 xv[4];
+  auto load_x = [&](int ks) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (tid >> 3) + 32 * i;
+      const int k4 = (tid & 7) * 4;
+      const int64_t gm = m0 + row;
+      const bool ok = gm < M && ks * XKT + k4 < K;
+      const float4 v = *reinterpret_cast<const float4*>(ok ? x + gm * K + ks * XKT + k4 : x);
+      xv[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  // packed weight planes of one k-step: 3 x [nvb x 32] bf16 as 16-byte pieces, nine per thread, all issued
+  // back to back (clamped index instead of a guard)
+  const int pieces = nvb * 4;  // 16-byte pieces per plane (<= 768)
+  u32x4 wreg[3][3];
+  auto load_w = [&](int ks) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const u16* src = packed + (((int64_t)ks * 3 + p) * NV + v0) * XKT;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int i = min(tid + 256 * j, pieces - 1);
+        wreg[p][j] = *reinterpret_cast<const u32x4*>(src + (int64_t)i * 8);
+      }
+    }
+  };
+  if (A_VEC4) load_x(0);
+  load_w(0);
+
+  for (int ks = 0; ks < KS; ++ks) {
+    const int k0 = ks * XKT;
+    // ---- stage x[m0 .. m0+128, k0 .. k0+32) as three bf16 planes
+    if (A_VEC4) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = (tid >> 3) + 32 * i;
+        const int k4 = (tid & 7) * 4;
+        unsigned h0, m0_, l0, h1, m1, l1;
+        split3_pk(f32x2{xv[i].x, xv[i].y}, h0, m0_, l0);
+        split3_pk(f32x2{xv[i].z, xv[i].w}, h1, m1, l1);
+        *reinterpret_cast<u32x2*>(&As[0][row][k4]) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2*>(&As[1][row][k4]) = u32x2{m0_, m1};
+        *reinterpret_cast<u32x2*>(&As[2][row][k4]) = u32x2{l0, l1};
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int idx = tid + 256 * i;
+        const int row = idx >> 5;
+        const int kk = idx & 31;
+        const int64_t gm = m0 + row;
+        const bool ok = gm < M && k0 + kk < K;
+        const float val = ok ? x[gm * K + k0 + kk] : 0.f;
+        u16 h, m, l;
+        split3(val, h, m, l);
+        As[0][row][kk] = h;
+        As[1][row][kk] = m;
+        As[2][row][kk] = l;
+      }
+    }
+    // ---- weight planes of this k-step (fetched during the previous step's MFMAs) -> LDS
+    {
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const int i = tid + 256 * j;
+          if (i < pieces) *reinterpret_cast<u32x4*>(&Bs[p][i >> 2][(i & 3) * 8]) = wreg[p][j];
+        }
+    }
+    __syncthreads();
+    if (ks + 1 < KS) {  // next step's operands: in flight during the MFMAs below
+      if (A_VEC4) load_x(ks + 1);
+      load_w(ks + 1);
+    }
+    // ---- 2 MFMA k-substeps of 16
+    const int arow = 32 * wave + (lane & 31);
+    const int koff = 8 * (lane >> 5);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&As[0][arow][16 * s + koff]);
+      const bf16x8 am = *reinterpret_cast<const bf16x8*>(&As[1][arow][16 * s + koff]);
+      const bf16x8 al = *reinterpret_cast<const bf16x8*>(&As[2][arow][16 * s + koff]);
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        if (t < ntile) {  // block-uniform
+          const int bcol = 32 * t + (lane & 31);
+          const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&Bs[0][bcol][16 * s + koff]);
+          const bf16x8 bm = *reinterpret_cast<const bf16x8*>(&Bs[1][bcol][16 * s + koff]);
+          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&Bs[2][bcol][16 * s + koff]);
+          f32x16 c = acc[t];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+          acc[t] = c;
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+  const bool wide = (ntile == 6) && (W % 4 == 0) && (bcat == nullptr || (reinterpret_cast<uintptr_t>(bcat) & 15) == 0);
+  if (wide) {
+    // Transpose the wavefront's 32 x 192 tile through the (now idle) LDS in two halves of 96 columns and
+    // write it as 16-byte pieces of contiguous rows: 24 dwordx4 stores per lane instead of 96 dword stores.
+    constexpr int CLD = 100;  // floats per staged row (96 + 4: rows land on different banks)
+    float* cs = reinterpret_cast<float*>(lds_raw) + wave * (32 * CLD);  // 12.8 KB per wavefront
+    static_assert(4 * 32 * CLD * 4 <= (A_ELEMS + B_ELEMS) * 2, "epilogue staging must fit the operand LDS");
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int tt = 0; tt < 3; ++tt) {
+        const int t = 3 * half + tt;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          cs[row * CLD + 32 * tt + (lane & 31)] = acc[t][r];
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // per-wavefront region: LDS ops of a wave complete in order
+#pragma unroll
+      for (int j = 0; j < 12; ++j) {
+        const int idx = lane + 64 * j;   // 32 rows x 24 pieces
+        const int row = idx / 24;
+        const int c4 = (idx - row * 24) * 4;
+        const int64_t gm = m0 + 32 * wave + row;
+        const int vc = v0 + 96 * half + c4;
+        float4 val = *reinterpret_cast<const float4*>(cs + row * CLD + c4);
+        if (gm < M && vc < ldb + W) {
+          if (vc < ldb) {
+            *reinterpret_cast<float4*>(bases + gm * ldb + vc) = val;
+          } else {
+            if (bcat != nullptr) {
+              const float4 bb = *reinterpret_cast<const float4*>(bcat + (vc - ldb));
+              val.x += bb.x; val.y += bb.y; val.z += bb.z; val.w += bb.w;
+            }
+            *reinterpret_cast<float4*>(weightings + gm * (int64_t)W + (vc - ldb)) = val;
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    return;
+  }
+#pragma unroll
+  for (int t = 0; t < 6; ++t) {
+    if (t >= ntile) break;
+    const int vc = v0 + 32 * t + (lane & 31);
+    if (vc >= ldb + W) continue;
+    const bool to_bases = vc < ldb;
+    const float badd = (!to_bases && bcat != nullptr) ? bcat[vc - ldb] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int64_t gm = m0 + 32 * wave + row;
+      if (gm >= M) continue;
+      if (to_bases) bases[gm * ldb + vc] = acc[t][r];
+      else weightings[gm * (int64_t)W + (vc - ldb)] = acc[t][r] + badd;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight-stationary form for F_in <= 128 (the common case: hidden sizes up to 128).
+//
+// C^T = W^T x^T: wavefront w of a block owns virtual columns [32w, 32w+32) and keeps that weight tile --
+// all three bf16 planes, every k -- in registers as the MFMA A operand for the whole kernel.  The block
+// streams 32-row tiles of x (persistent loop over tiles), splits each into bf16 planes once, and shares it
+// through double-buffered LDS as the B operand of all its wavefronts: one barrier per tile, weights never
+// re-staged, global loads of tile t+1 in flight during the MFMAs of tile t.  In the transposed result a
+// lane holds, for ONE x row, columns {8j + 4*(lane>>5) + 0..3}: four 16-byte stores per tile, no LDS
+// transpose; comb.bias is preloaded into the accumulators.
+// ---------------------------------------------------------------------------------------------
+constexpr int WS_ROWS = 32;
+
+template <int KSUB>  // number of 16-k MFMA sub-steps kept in registers: F_in <= 16 * KSUB
+__global__ void __launch_bounds__(512) basis_gemm_ws_kernel(const float* __restrict__ x, const u16* __restrict__ packed,
+                                                             const float* __restrict__ bcat, int64_t M, int K, int W,
+                                                             float* __restrict__ bases, int ldb,
+                                                             float* __restrict__ weightings, int NV, int n_tiles,
+                                                             int x_vec4) {
+  constexpr int KP = 16 * KSUB;  // padded K held per row
+  constexpr int LDX = KP + 8;    // bf16 per staged x row (+16 B: conflict-free ds_read_b128)
+  extern __shared__ __attribute__((aligned(16))) u16 xs[];  // [2 buffers][3 planes][32 rows][LDX]
+  const int tid = threadIdx.x;
+  const int nthreads = blockDim.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int hh = lane >> 5;
+  const int cb = 32 * wave;  // first virtual column of this wavefront
+  const bool bias_vec4 = bcat == nullptr || (reinterpret_cast<uintptr_t>(bcat) & 15) == 0;
+
+  // ---- this wavefront's weight tile -> registers (A operand: lane holds W[k = 16s + 8hh + j][cb + (lane&31)])
+  bf16x8 wf[KSUB][3];
+#pragma unroll
+  for (int s = 0; s < KSUB; ++s)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const u16* src = packed + ((((int64_t)(s >> 1) * 3 + p) * NV + cb + (lane & 31)) * XKT + 16 * (s & 1) + 8 * hh);
+      wf[s][p] = *reinterpret_cast<const bf16x8*>(src);
+    }
+  // ---- x tile staging: 32 rows x KP floats = 8 * KP float4 pieces, spread over the block
+  constexpr int PIECES = WS_ROWS * KP / 4;
+  constexpr int PPT = 4;  // pieces per thread (needs nthreads * PPT >= PIECES; host guarantees)
+  auto load_tile = [&](int tile, float4 (&xr)[PPT]) {
+    const int64_t m0 = (int64_t)tile * WS_ROWS;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int pc = tid + nthreads * i;
+      const int row = pc / (KP / 4);
+      const int k4 = (pc - row * (KP / 4)) * 4;
+      const int64_t gm = m0 + row;
+      const bool ok = tile < n_tiles && pc < PIECES && gm < M && k4 < K;
+      if (x_vec4) {
+        const float4 v = *reinterpret_cast<const float4*>(ok ? x + gm * K + k4 : x);
+        xr[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) {
+          const float* px = x + gm * K + k4;
+          v.x = px[0];
+          if (k4 + 1 < K) v.y = px[1];
+          if (k4 + 2 < K) v.z = px[2];
+          if (k4 + 3 < K) v.w = px[3];
+        }
+        xr[i] = v;
+      }
+    }
+  };
+  auto stage_tile = [&](int buf, const float4 (&xr)[PPT]) {
+    u16* base = xs + buf * (3 * WS_ROWS * LDX);
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int pc = tid + nthreads * i;
+      if (pc < PIECES) {
+        const int row = pc / (KP / 4);
+        const int k4 = (pc - row * (KP / 4)) * 4;
+        unsigned h0, m0_, l0, h1, m1, l1;
+        split3_pk(f32x2{xr[i].x, xr[i].y}, h0, m0_, l0);
+        split3_pk(f32x2{xr[i].z, xr[i].w}, h1, m1, l1);
+        u16* dst = base + row * LDX + k4;
+        *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2*>(dst + WS_ROWS * LDX) = u32x2{m0_, m1};
+        *reinterpret_cast<u32x2*>(dst + 2 * WS_ROWS * LDX) = u32x2{l0, l1};
+      }
+    }
+  };
+  // MFMAs + stores of the tile staged in LDS buffer `buf`
+  auto compute_tile = [&](int tile, int buf) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const u16* xb = xs + buf * (3 * WS_ROWS * LDX) + (lane & 31) * LDX + 8 * hh;
+#pragma unroll
+    for (int s = 0; s < KSUB; ++s) {
+      const bf16x8 xh = *reinterpret_cast<const bf16x8*>(xb + 16 * s);
+      const bf16x8 xm = *reinterpret_cast<const bf16x8*>(xb + 16 * s + WS_ROWS * LDX);
+      const bf16x8 xl = *reinterpret_cast<const bf16x8*>(xb + 16 * s + 2 * WS_ROWS * LDX);
+#ifdef EGC_ABL_G_NOMFMA
+      acc[s] += (float)xl[0] + (float)xh[1] + (float)xm[2];
+#else
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][0], xl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][2], xh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][1], xm, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][0], xm, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][1], xh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][0], xh, acc, 0, 0, 0);
+#endif
+    }
+    // lane (row i = lane&31, half hh) owns columns cb + 8j + 4hh + 0..3, j = 0..3
+    const int64_t gm = (int64_t)tile * WS_ROWS + (lane & 31);
+#ifdef EGC_ABL_G_NOSTORE
+    if (gm < M && acc[0] == 123456.f) {
+#else
+    if (gm < M) {
+#endif
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int vc = cb + 8 * j + 4 * hh;
+        const float4 val = make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
+        if (vc < ldb) {
+          *reinterpret_cast<float4*>(bases + gm * ldb + vc) = val;
+        } else if (vc + 3 < ldb + W && (W & 3) == 0 && bias_vec4) {
+          float4 o = val;
+          if (bcat != nullptr) {  // comb.bias, 16 bytes from L1 (row-invariant)
+            const float4 bb = *reinterpret_cast<const float4*>(bcat + (vc - ldb));
+            o.x += bb.x; o.y += bb.y; o.z += bb.z; o.w += bb.w;
+          }
+          *reinterpret_cast<float4*>(weightings + gm * (int64_t)W + (vc - ldb)) = o;
+        } else {
+          float* wrow = weightings + gm * (int64_t)W;
+          const float v4[4] = {val.x, val.y, val.z, val.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (vc + e < ldb + W) wrow[vc + e - ldb] = v4[e] + (bcat != nullptr ? bcat[vc + e - ldb] : 0.f);
+        }
+      }
+    }
+  };
+
+  // Persistent loop: while tile i is multiplied out of one LDS buffer, tile i+1 is in flight / being split
+  // into the other; two blocks per CU (3 wavefronts on every SIMD) cover each other's barriers and waits.
+  const int stride = gridDim.x;
+  int tile = blockIdx.x;
+  if (tile >= n_tiles) return;
+  float4 xr[PPT];
+  load_tile(tile, xr);
+  stage_tile(0, xr);
+  __syncthreads();
+  int buf = 0;
+  for (; tile < n_tiles; tile += stride) {
+    load_tile(tile + stride, xr);  // masked past the end
+    compute_tile(tile, buf);
+    if (tile + stride < n_tiles) stage_tile(buf ^ 1, xr);
+    __syncthreads();
+    buf ^= 1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight-stationary, 64-row tiles: wavefront (ct, rt) of a block owns column tile ct for row half rt of a
+// 64-row x tile, so a block of 2*NT wavefronts (12 at the north-star shape) puts the same number of
+// wavefronts on every SIMD.  To stay under 168 registers (3 wavefronts per SIMD) only the h and m planes of
+// the weight tile live in registers; the l plane -- used by one of the six products -- is kept once per
+// block in LDS next to the double-buffered x planes.
+// ---------------------------------------------------------------------------------------------
+constexpr int WS2_ROWS = 64;
+
+template <int KSUB>
+__global__ void __launch_bounds__(768, 3) basis_gemm_ws2_kernel(const float* __restrict__ x, const u16* __restrict__ packed,
+                                                                const float* __restrict__ bcat, int64_t M, int K, int W,
+                                                                float* __restrict__ bases, int ldb,
+                                                                float* __restrict__ weightings, int NV, int n_tiles,
+                                                                int x_vec4) {
+  constexpr int KP = 16 * KSUB;
+  constexpr int LDX = KP + 8;
+  constexpr int XBUF = 3 * WS2_ROWS * LDX;  // bf16 elements of one x buffer (3 planes)
+  extern __shared__ __attribute__((aligned(16))) u16 smem2[];  // [2][3][64][LDX] x planes, then [NV][LDX] Wl
+  u16* xs = smem2;
+  u16* wls = smem2 + 2 * XBUF;
+  const int tid = threadIdx.x;
+  const int nthreads = blockDim.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int NT = NV >> 5;
+  const int ct = wave % NT, rt = wave / NT;
+  const int hh = lane >> 5;
+  const int cb = 32 * ct;
+  const bool bias_vec4 = bcat == nullptr || (reinterpret_cast<uintptr_t>(bcat) & 15) == 0;
+
+  // h / m planes of this wavefront's weight tile -> registers; l plane of the whole block -> LDS
+  bf16x8 wf[KSUB][2];
+#pragma unroll
+  for (int s = 0; s < KSUB; ++s)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const u16* src = packed + ((((int64_t)(s >> 1) * 3 + p) * NV + cb + (lane & 31)) * XKT + 16 * (s & 1) + 8 * hh);
+      wf[s][p] = *reinterpret_cast<const bf16x8*>(src);
+    }
+  for (int i = tid; i < NV * (KP / 8); i += nthreads) {  // 16-byte pieces of the l plane
+    const int v = i / (KP / 8);
+    const int k8 = (i - v * (KP / 8)) * 8;
+    const u16* src = packed + ((((int64_t)(k8 >> 5) * 3 + 2) * NV + v) * XKT + (k8 & 31));
+    *reinterpret_cast<u32x4*>(wls + v * LDX + k8) = *reinterpret_cast<const u32x4*>(src);
+  }
+
+  constexpr int PIECES = WS2_ROWS * KP / 4;
+  constexpr int PPT = 3;  // host guarantees nthreads * PPT >= PIECES
+  auto load_tile = [&](int tile, float4 (&xr)[PPT]) {
+    const int64_t m0 = (int64_t)tile * WS2_ROWS;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int pc = tid + nthreads * i;
+      const int row = pc / (KP / 4);
+      const int k4 = (pc - row * (KP / 4)) * 4;
+      const int64_t gm = m0 + row;
+      const bool ok = tile < n_tiles && pc < PIECES && gm < M && k4 < K;
+      if (x_vec4) {
+        const float4 v = *reinterpret_cast<const float4*>(ok ? x + gm * K + k4 : x);
+        xr[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) {
+          const float* px = x + gm * K + k4;
+          v.x = px[0];
+          if (k4 + 1 < K) v.y = px[1];
+          if (k4 + 2 < K) v.z = px[2];
+          if (k4 + 3 < K) v.w = px[3];
+        }
+        xr[i] = v;
+      }
+    }
+  };
+  auto stage_tile = [&](int buf, const float4 (&xr)[PPT]) {
+    u16* base = xs + buf * XBUF;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int pc = tid + nthreads * i;
+      if (pc < PIECES) {
+        const int row = pc / (KP / 4);
+        const int k4 = (pc - row * (KP / 4)) * 4;
+        unsigned h0, m0_, l0, h1, m1, l1;
+        split3_pk(f32x2{xr[i].x, xr[i].y}, h0, m0_, l0);
+        split3_pk(f32x2{xr[i].z, xr[i].w}, h1, m1, l1);
+        u16* dst = base + row * LDX + k4;
+        *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2*>(dst + WS2_ROWS * LDX) = u32x2{m0_, m1};
+        *reinterpret_cast<u32x2*>(dst + 2 * WS2_ROWS * LDX) = u32x2{l0, l1};
+      }
+    }
+  };
+  auto compute_tile = [&](int tile, int buf) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const u16* xb = xs + buf * XBUF + (32 * rt + (lane & 31)) * LDX + 8 * hh;
+    const u16* wlb = wls + (cb + (lane & 31)) * LDX + 8 * hh;
+#pragma unroll
+    for (int s = 0; s < KSUB; ++s) {
+      const bf16x8 xh = *reinterpret_cast<const bf16x8*>(xb + 16 * s);
+      const bf16x8 xm = *reinterpret_cast<const bf16x8*>(xb + 16 * s + WS2_ROWS * LDX);
+      const bf16x8 xl = *reinterpret_cast<const bf16x8*>(xb + 16 * s + 2 * WS2_ROWS * LDX);
+      const bf16x8 wl = *reinterpret_cast<const bf16x8*>(wlb + 16 * s);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][0], xl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][1], xm, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][0], xm, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][1], xh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][0], xh, acc, 0, 0, 0);
+    }
+    const int64_t gm = (int64_t)tile * WS2_ROWS + 32 * rt + (lane & 31);
+    if (gm < M) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int vc = cb + 8 * j + 4 * hh;
+        const float4 val = make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
+        if (vc < ldb) {
+          *reinterpret_cast<float4*>(bases + gm * ldb + vc) = val;
+        } else if (vc + 3 < ldb + W && (W & 3) == 0 && bias_vec4) {
+          float4 o = val;
+          if (bcat != nullptr) {
+            const float4 bb = *reinterpret_cast<const float4*>(bcat + (vc - ldb));
+            o.x += bb.x; o.y += bb.y; o.z += bb.z; o.w += bb.w;
+          }
+          *reinterpret_cast<float4*>(weightings + gm * (int64_t)W + (vc - ldb)) = o;
+        } else {
+          float* wrow = weightings + gm * (int64_t)W;
+          const float v4[4] = {val.x, val.y, val.z, val.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (vc + e < ldb + W) wrow[vc + e - ldb] = v4[e] + (bcat != nullptr ? bcat[vc + e - ldb] : 0.f);
+        }
+      }
+    }
+  };
+
+  const int stride = gridDim.x;
+  int tile = blockIdx.x;
+  if (tile >= n_tiles) return;
+  float4 xr[PPT];
+  load_tile(tile, xr);
+  stage_tile(0, xr);
+  __syncthreads();
+  int buf = 0;
+  for (; tile < n_tiles; tile += stride) {
+    load_tile(tile + stride, xr);  // masked past the end
+    compute_tile(tile, buf);
+    if (tile + stride < n_tiles) stage_tile(buf ^ 1, xr);
+    __syncthreads();
+    buf ^= 1;
+  }
+}
+
+template <int KSUB>
+static int launch_ws2(const float* x, const u16* packed, const float* bcat, int64_t M, int K, int W, float* bases, int ldb,
+                      float* weightings, int NV, hipStream_t stream) {
+  const int nt = NV / 32;
+  const int threads = 128 * nt;  // two row halves per column tile
+  constexpr int KP = 16 * KSUB, LDX = KP + 8;
+  if (threads * 3 < WS2_ROWS * KP / 4 || threads > 768) return EGC_ERR_UNSUPPORTED;
+  const int64_t n_tiles64 = ceil_div(M, WS2_ROWS);
+  if (n_tiles64 >= ((int64_t)1 << 31)) return EGC_ERR_INVALID;
+  const int n_tiles = (int)n_tiles64;
+  const size_t lds = ((size_t)2 * 3 * WS2_ROWS * LDX + (size_t)NV * LDX) * sizeof(u16);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&basis_gemm_ws2_kernel<KSUB>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) { set_last_error("hipFuncSetAttribute(ws2)", e); return EGC_ERR_HIP; }
+    attr_set = true;
+  }
+  int grid = 256;  // one resident block (12 wavefronts) per CU, each walks tiles with stride gridDim
+  if (grid > n_tiles) grid = n_tiles;
+  const int x_vec4 = (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  basis_gemm_ws2_kernel<KSUB><<<grid, threads, lds, stream>>>(x, packed, bcat, M, K, W, bases, ldb, weightings, NV, n_tiles,
+                                                              x_vec4);
+  EGC_LAUNCH_CHECK("basis_gemm_ws2_kernel");
+  return EGC_OK;
+}
+
+template <int KSUB>
+static int launch_ws(const float* x, const u16* packed, const float* bcat, int64_t M, int K, int W, float* bases, int ldb,
+                     float* weightings, int NV, hipStream_t stream) {
+  const int nt = NV / 32;               // wavefronts per block (<= 16)
+  const int threads = 64 * nt;
+  const int pieces = WS_ROWS * (16 * KSUB) / 4;
+  if (threads * 4 < pieces) return EGC_ERR_UNSUPPORTED;
+  const int64_t n_tiles64 = ceil_div(M, WS_ROWS);
+  if (n_tiles64 >= ((int64_t)1 << 31)) return EGC_ERR_INVALID;
+  const int n_tiles = (int)n_tiles64;
+  const size_t lds = (size_t)2 * 3 * WS_ROWS * (16 * KSUB + 8) * sizeof(u16);
+  // persistent grid: enough blocks to fill the chip a few times over, each walks tiles with stride gridDim
+  int blocks_per_cu = nt <= 4 ? 4 : (nt <= 8 ? 2 : 1);
+  int grid = 256 * blocks_per_cu;
+  if (grid > n_tiles) grid = n_tiles;
+  const int x_vec4 = (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  basis_gemm_ws_kernel<KSUB><<<grid, threads, lds, stream>>>(x, packed, bcat, M, K, W, bases, ldb, weightings, NV, n_tiles,
+                                                             x_vec4);
+  EGC_LAUNCH_CHECK("basis_gemm_ws_kernel");
+  return EGC_OK;
+}
+
+static inline int round_up32(int v) { return (v + 31) & ~31; }
+
+}  // namespace egc
+
+using namespace egc;
+
+extern "C" {
+
+size_t egc_basis_pack_bytes(int32_t f_in, int32_t f_g, int32_t w_cols) {
+  if (f_in <= 0 || f_g <= 0 || w_cols < 0) return 0;
+  const int ldb = (f_g + 3) & ~3;
+  const int NV = round_up32(ldb + w_cols);
+  const int KS = (f_in + XKT - 1) / XKT;
+  return (size_t)KS * 3 * NV * XKT * sizeof(u16);
+}
+
+int egc_basis_pack_bf16x3(const float* wcat, int32_t f_in, int32_t f_g, int32_t w_cols, void* packed, size_t packed_bytes,
+                          egc_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (wcat == nullptr || packed == nullptr || f_in <= 0 || f_g <= 0 || w_cols < 0) return EGC_ERR_INVALID;
+  if (packed_bytes < egc_basis_pack_bytes(f_in, f_g, w_cols)) return EGC_ERR_WORKSPACE;
+  const int ldb = (f_g + 3) & ~3;
+  const int NV = round_up32(ldb + w_cols);
+  const int KS = (f_in + XKT - 1) / XKT;
+  const int total = KS * NV * XKT;
+  pack_bf16x3_kernel<<<(total + 255) / 256, 256, 0, stream>>>(wcat, f_in, f_g, w_cols, ldb, NV, KS, (u16*)packed);
+  EGC_LAUNCH_CHECK("pack_bf16x3_kernel");
+  return EGC_OK;
+}
+
+int egc_basis_transform_packed(const float* x, const void* packed, const float* bcat, int64_t n_nodes, int32_t f_in,
+                               int32_t f_g, int32_t w_cols, float* bases, int32_t ldb, float* weightings,
+                               egc_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_nodes < 0 || f_in <= 0 || f_g <= 0 || w_cols < 0 || ldb != ((f_g + 3) & ~3)) return EGC_ERR_INVALID;
+  if (n_nodes == 0) return EGC_OK;
+  if (x == nullptr || packed == nullptr || bases == nullptr || (w_cols > 0 && weightings == nullptr)) return EGC_ERR_INVALID;
+  const int NV = round_up32(ldb + w_cols);
+  const int KS = (f_in + XKT - 1) / XKT;
+  if (f_in > 96 && f_in <= 128 && NV == 192 && getenv("EGC_GEMM_NO_WS2") == nullptr)  // 12-wavefront form
+    return launch_ws2<8>(x, (const u16*)packed, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, stream);
+  if (f_in <= 128 && NV <= 256 && getenv("EGC_GEMM_NO_WS") == nullptr) {  // weight-stationary form (<= 8 wavefronts)
+    const u16* pk = (const u16*)packed;
+    if (f_in <= 32) return launch_ws<2>(x, pk, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, stream);
+    if (f_in <= 64) return launch_ws<4>(x, pk, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, stream);
+    if (f_in <= 96) return launch_ws<6>(x, pk, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, stream);
+    return launch_ws<8>(x, pk, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, stream);
+  }
+  const int64_t mblocks = ceil_div(n_nodes, XBM);
+  if (mblocks >= ((int64_t)1 << 31)) return EGC_ERR_INVALID;
+  dim3 grid((unsigned)mblocks, (unsigned)ceil_div(NV, XBN));
+  const bool vec4 = (f_in % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  if (vec4)
+    basis_gemm_bf16x3_kernel<true><<<grid, 256, 0, stream>>>(x, (const u16*)packed, bcat, n_nodes, f_in, w_cols, bases, ldb,
+                                                             weightings, NV, KS);
+  else
+    basis_gemm_bf16x3_kernel<false><<<grid, 256, 0, stream>>>(x, (const u16*)packed, bcat, n_nodes, f_in, w_cols, bases,
+                                                              ldb, weightings, NV, KS);
+  EGC_LAUNCH_CHECK("basis_gemm_bf16x3_kernel");
+  return EGC_OK;
+}
+
+}  // extern "C"

@@ -8,6 +8,7 @@ GEMM, fused multi-aggregator reduction and combine -- and mirrors the tail of
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import torch
@@ -46,10 +47,32 @@ def _check_f32(t, name, shape=None):
         raise RuntimeError(f"egc_amd: {name} has shape {tuple(t.shape)}, expected {tuple(shape)}")
 
 
+def pack_weights(spec: LayerSpec, wcat: torch.Tensor) -> torch.Tensor:
+    """Split wcat ([F_in, F_g + W], fp32) into the three bf16 planes the matrix-core GEMM stages
+    (egc_basis_pack_bf16x3).  Done once per parameter update; the result is an opaque byte buffer."""
+    lib = _C.load()
+    _check_f32(wcat, "wcat", (spec.f_in, spec.f_g + spec.w_cols))
+    dev = wcat.device
+    wcat = wcat.contiguous()
+    with torch.cuda.device(dev):
+        nbytes = lib.egc_basis_pack_bytes(spec.f_in, spec.f_g, spec.w_cols)
+        packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _C.check(lib.egc_basis_pack_bf16x3(wcat.data_ptr(), spec.f_in, spec.f_g, spec.w_cols, packed.data_ptr(),
+                                           nbytes, _stream_ptr(dev)), "egc_basis_pack_bf16x3")
+    return packed
+
+
+def gemm_exact() -> bool:
+    """EGC_GEMM_EXACT=1 selects the plain fp32-MFMA GEMM instead of the bf16x3 matrix-core form."""
+    return os.environ.get("EGC_GEMM_EXACT", "0") not in ("", "0")
+
+
 def egc_layer_forward(graph: CSRGraph, spec: LayerSpec, x: torch.Tensor, wcat: torch.Tensor,
-                      bcat: torch.Tensor | None, bias: torch.Tensor | None, return_intermediates: bool = False):
+                      bcat: torch.Tensor | None, bias: torch.Tensor | None, return_intermediates: bool = False,
+                      packed: torch.Tensor | None = None):
     """out[N, F_out] for one layer.  wcat = [bases_weight | comb.weight^T]  ([F_in, F_g + W]),
-    bcat = comb.bias ([W]) or None, bias = layer bias ([F_out]) or None."""
+    bcat = comb.bias ([W]) or None, bias = layer bias ([F_out]) or None; ``packed`` = pack_weights(wcat)
+    if the caller keeps one (otherwise it is produced here)."""
     lib = _C.load()
     n = graph.n_nodes
     _check_f32(x, "x", (n, spec.f_in))
@@ -69,12 +92,20 @@ def egc_layer_forward(graph: CSRGraph, spec: LayerSpec, x: torch.Tensor, wcat: t
         out = torch.empty((n, spec.f_out), dtype=torch.float32, device=dev)
         ws = graph.workspace(lib.egc_aggregate_workspace_bytes(C.byref(spec.c), n, graph.n_edges))
         g = graph.c_struct()
-        _C.check(lib.egc_layer_forward_f32(
-            C.byref(g), C.byref(spec.c), x.data_ptr(), wcat.data_ptr(),
-            bcat.contiguous().data_ptr() if bcat is not None else None,
-            bias.contiguous().data_ptr() if bias is not None else None,
-            bases.data_ptr(), spec.ldb, weightings.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(),
-            _stream_ptr(dev)), "egc_layer_forward_f32")
+        bcat_p = bcat.contiguous().data_ptr() if bcat is not None else None
+        bias_p = bias.contiguous().data_ptr() if bias is not None else None
+        if gemm_exact():
+            _C.check(lib.egc_layer_forward_f32(
+                C.byref(g), C.byref(spec.c), x.data_ptr(), wcat.data_ptr(), bcat_p, bias_p, bases.data_ptr(), spec.ldb,
+                weightings.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(dev)),
+                "egc_layer_forward_f32")
+        else:
+            if packed is None:
+                packed = pack_weights(spec, wcat)
+            _C.check(lib.egc_layer_forward_packed(
+                C.byref(g), C.byref(spec.c), x.data_ptr(), packed.data_ptr(), bcat_p, bias_p, bases.data_ptr(),
+                spec.ldb, weightings.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(dev)),
+                "egc_layer_forward_packed")
     if return_intermediates:
         return out, bases, weightings
     return out
@@ -95,7 +126,7 @@ class _EGCLayerFunction(torch.autograd.Function):
             "run under torch.no_grad() / model.eval() for inference")
 
 
-def egc_layer_apply(graph, spec, x, wcat, bcat, bias):
+def egc_layer_apply(graph, spec, x, wcat, bcat, bias, packed=None):
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, wcat, bcat, bias)):
         return _EGCLayerFunction.apply(x, wcat, bcat, bias, graph, spec)
-    return egc_layer_forward(graph, spec, x, wcat, bcat, bias)
+    return egc_layer_forward(graph, spec, x, wcat, bcat, bias, packed=packed)

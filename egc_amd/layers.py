@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import _C
-from .functional import egc_layer_apply, make_spec
+from .functional import egc_layer_apply, gemm_exact, make_spec, pack_weights
 from .graph import SparseTensor, graph_from_input
 
 _AGGR_CODE = {"add": _C.AGGR_SUM, "mean": _C.AGGR_MEAN, "max": _C.AGGR_MAX, "min": _C.AGGR_MIN,
@@ -81,7 +81,7 @@ class EfficientGraphConv(nn.Module):
             agg_set=_C.SET_RAW, sym_set=_C.SET_LOOPED if add_self_loops else _C.SET_RAW, loops_all_nodes=True,
             weight_layout=_C.LAYOUT_HBA, weight_act=act)
         self._cached_graph = None
-        self._wcat_key, self._wcat = None, None
+        self._wcat_key, self._wcat, self._planes = None, None, None
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -91,7 +91,7 @@ class EfficientGraphConv(nn.Module):
         if self.bias is not None:
             nn.init.zeros_(self.bias)
         self._cached_graph = None
-        self._wcat_key, self._wcat = None, None
+        self._wcat_key, self._wcat, self._planes = None, None, None
 
     # [bases_weight.0 | ... | bases_weight.B-1 | comb_weights.weight^T], rebuilt when a parameter changes
     def _packed_weights(self):
@@ -103,7 +103,16 @@ class EfficientGraphConv(nn.Module):
             with torch.no_grad():
                 self._wcat = torch.cat([*self.bases_weight, self.comb_weights.weight.t()], dim=1).contiguous()
             self._wcat_key = key
+            self._planes = None
         return self._wcat
+
+    def _weight_planes(self, wcat):
+        """bf16x3 planes of wcat for the matrix-core GEMM, rebuilt with the packed weights."""
+        if not wcat.is_cuda or gemm_exact() or wcat.requires_grad:
+            return None
+        if self._planes is None or self._planes.device != wcat.device:
+            self._planes = pack_weights(self._spec, wcat)
+        return self._planes
 
     def forward(self, x, edge_index):
         if isinstance(edge_index, SparseTensor) and any(a.aggr_fun in ("var", "std") for a in self.aggs):
@@ -114,7 +123,9 @@ class EfficientGraphConv(nn.Module):
             graph = graph_from_input(edge_index, x.size(0))
             if self.cache:
                 self._cached_graph = graph
-        return egc_layer_apply(graph, self._spec, x, self._packed_weights(), self.comb_weights.bias, self.bias)
+        wcat = self._packed_weights()
+        return egc_layer_apply(graph, self._spec, x, wcat, self.comb_weights.bias, self.bias,
+                               packed=self._weight_planes(wcat))
 
     def extra_repr(self):
         return (f"(In={self.in_channels}, Out={self.out_channels}, H={self.num_heads}, B={self.num_bases}, "

@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from . import _C
-from .functional import egc_layer_apply, make_spec
+from .functional import egc_layer_apply, gemm_exact, make_spec, pack_weights
 from .graph import CSRGraph, SparseTensor, graph_from_input
 from .layers import glorot_
 
@@ -72,7 +72,7 @@ class EGConv(nn.Module):
         self._spec_adj = make_spec(in_channels, out_channels, num_heads, num_bases, codes, agg_set=edge_set,
                                    sym_set=edge_set, loops_all_nodes=True, **common)
         self._cached_graph = None
-        self._wcat_key, self._wcat = None, None
+        self._wcat_key, self._wcat, self._planes = None, None, None
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -81,7 +81,7 @@ class EGConv(nn.Module):
         if self.bias is not None:
             nn.init.zeros_(self.bias)
         self._cached_graph = None
-        self._wcat_key, self._wcat = None, None
+        self._wcat_key, self._wcat, self._planes = None, None, None
 
     def _pack(self):
         H, A, B, F = self.num_heads, len(self.aggregators), self.num_bases, self.in_channels
@@ -100,7 +100,16 @@ class EGConv(nn.Module):
             with torch.no_grad():
                 self._wcat = self._pack()
             self._wcat_key = key
+            self._planes = None
         return self._wcat
+
+    def _weight_planes(self, spec, wcat):
+        """bf16x3 planes of wcat for the matrix-core GEMM, rebuilt with the packed weights."""
+        if not wcat.is_cuda or gemm_exact() or wcat.requires_grad:
+            return None
+        if self._planes is None or self._planes.device != wcat.device:
+            self._planes = pack_weights(spec, wcat)
+        return self._planes
 
     def forward(self, x, edge_index):
         if self.cached and self._cached_graph is not None:
@@ -112,7 +121,7 @@ class EGConv(nn.Module):
             if self.cached:
                 self._cached_graph = (graph, spec)
         wcat, bcat = self._packed_weights()
-        return egc_layer_apply(graph, spec, x, wcat, bcat, self.bias)
+        return egc_layer_apply(graph, spec, x, wcat, bcat, self.bias, packed=self._weight_planes(spec, wcat))
 
     def __repr__(self):
         return "{}({}, {}, {})".format(self.__class__.__name__, self.in_channels, self.out_channels,

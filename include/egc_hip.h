@@ -141,6 +141,19 @@ int egc_basis_transform_f32(const float* x, const float* wcat, const float* bcat
                             int32_t f_in, int32_t f_g, int32_t w_cols, float* bases, int32_t ldb,
                             float* weightings, egc_stream_t stream);
 
+/* Step 1, fast form -- the same GEMM on the bf16 matrix cores with fp32-level accuracy: both operands are
+ * split into three bf16 planes (x = xh+xm+xl, w = wh+wm+wl) and the six significant cross products are
+ * accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (error ~2^-23 |x||w|, the order of one fp32 rounding).
+ * The weight planes are produced once per parameter update by egc_basis_pack_bf16x3 into a caller buffer
+ * of egc_basis_pack_bytes() bytes; egc_basis_transform_packed then has the contract of
+ * egc_basis_transform_f32 (same reference call sites) with `packed` in place of `wcat`. */
+size_t egc_basis_pack_bytes(int32_t f_in, int32_t f_g, int32_t w_cols);
+int egc_basis_pack_bf16x3(const float* wcat, int32_t f_in, int32_t f_g, int32_t w_cols, void* packed,
+                          size_t packed_bytes, egc_stream_t stream);
+int egc_basis_transform_packed(const float* x, const void* packed, const float* bcat, int64_t n_nodes,
+                               int32_t f_in, int32_t f_g, int32_t w_cols, float* bases, int32_t ldb,
+                               float* weightings, egc_stream_t stream);
+
 /* Scratch bytes egc_aggregate_combine_f32 needs for this layer on this graph.
  * CONTRACT: the workspace must be zero-filled before its FIRST use (it holds the long-row arrival
  * counters of the fused kernel); every call leaves it ready for the next call on the same stream.
@@ -169,6 +182,11 @@ int egc_aggregate_combine_f32(const egc_graph* graph, const egc_layer* layer, co
 int egc_layer_forward_f32(const egc_graph* graph, const egc_layer* layer, const float* x, const float* wcat,
                           const float* bcat, const float* bias, float* bases, int32_t ldb, float* weightings,
                           float* out, void* workspace, size_t workspace_bytes, egc_stream_t stream);
+
+/* Same as egc_layer_forward_f32 with the GEMM in its packed bf16x3 form (the default production path). */
+int egc_layer_forward_packed(const egc_graph* graph, const egc_layer* layer, const float* x, const void* packed,
+                             const float* bcat, const float* bias, float* bases, int32_t ldb, float* weightings,
+                             float* out, void* workspace, size_t workspace_bytes, egc_stream_t stream);
 
 /* Human-readable text of the last HIP failure seen on the calling thread ("" if none). */
 const char* egc_last_error(void);
