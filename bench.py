@@ -67,20 +67,30 @@ def time_region(fn, iters, sync):
     return start.elapsed_time(end) / iters
 
 
-def cpu_baseline(ei, n, x, conv_state, runs=5):
-    """Time the CPU port (oracle) on the same workload: full config-2 layer forward, graph prep cached."""
+def cpu_baseline(ei, n, x, conv_state, runs=3):
+    """Time the CPU port (oracle) on the same workload: full config-2 layer forward, graph prep cached.
+    torch's scatter kernels do not scale to hundreds of threads, so a few thread counts are tried and the
+    best one is reported (with the number of threads it used)."""
     from oracle.egc_cpu_port import egconv_forward_cpu
-    threads = os.cpu_count() or 1
-    torch.set_num_threads(threads)
+    ncpu = os.cpu_count() or 1
     args = (x, ei, conv_state["bases_weight"], conv_state["comb_weight.weight"], conv_state["comb_weight.bias"],
             conv_state["bias"], HEADS, BASES, AGGRS)
+    torch.set_num_threads(min(16, ncpu))
     out, cached = egconv_forward_cpu(*args)  # warm-up; also builds the cached gcn_norm edge set
-    times = []
-    for _ in range(runs):
-        t0 = time.perf_counter()
-        out, _ = egconv_forward_cpu(*args, cached=cached)
-        times.append(time.perf_counter() - t0)
-    return out, statistics.median(times), threads, int(cached[0].size(1))
+    best = None
+    for threads in sorted({min(t, ncpu) for t in (8, 16, 32, 64)}):
+        torch.set_num_threads(threads)
+        egconv_forward_cpu(*args, cached=cached)
+        times = []
+        for _ in range(runs):
+            t0 = time.perf_counter()
+            out, _ = egconv_forward_cpu(*args, cached=cached)
+            times.append(time.perf_counter() - t0)
+        med = statistics.median(times)
+        log(f"  cpu port, {threads:3d} threads: {med * 1e3:8.1f} ms/forward")
+        if best is None or med < best[0]:
+            best = (med, threads)
+    return out, best[0], best[1], int(cached[0].size(1))
 
 
 def main():
@@ -202,7 +212,7 @@ def main():
                                f"E_in={e_in} (+N self loops => E_eff={e_eff}), EGC-M d=128 H=8 B=4 "
                                "aggrs=sum+mean+max+symnorm, CSR cached",
                    "n_nodes": n, "e_in": e_in, "e_eff": e_eff, "layer": "EGConv", "parallelism": f"dp{world}"},
-        "roofline": {"bound": "hbm", "kernel": "egc aggregate+combine launch", "achieved": agg_gbs,
+        "roofline": {"bound": "hbm", "kernel": "egc::agg_fast_kernel (fused aggregate+combine, one launch)", "achieved": agg_gbs,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": agg_gbs / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": terms["aggregate_kernel"], "launch_ms": agg_ms},
         "kernels_ms": {"basis_gemm": gemm_ms, "aggregate_combine": agg_ms, "layer_forward": step_ms_events},
@@ -221,8 +231,9 @@ def main():
             log(f"cpu port: {cpu_s * 1e3:.1f} ms/forward on {threads} threads; HIP vs CPU port rel err {err:.2e}")
             result["cpu_baseline"] = {
                 "value": e_eff / cpu_s, "unit": "edges/s", "cores": threads, "kind": "port",
-                "sample": f"full config-2 layer forward (E_eff={e_cached}), gcn_norm cached, median of 5 runs "
-                          f"after 1 warm-up; {cpu_s * 1e3:.1f} ms each",
+                "sample": f"full config-2 layer forward (E_eff={e_cached}), gcn_norm cached; best of 8/16/32/64 "
+                          f"torch threads, median of 3 runs each after a warm-up; {cpu_s * 1e3:.1f} ms per forward "
+                          f"on a {os.cpu_count()}-core host",
                 "hip_vs_port_rel_err": err}
         print(json.dumps(result), flush=True)
     if world > 1:
