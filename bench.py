@@ -48,8 +48,13 @@ def dist_setup(n_gpus):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         import torch.distributed as dist
+        backend = os.environ.get("EGC_BENCH_BACKEND", "nccl")  # "gloo": functional smoke test on a shared GPU
+        local = local % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     elif n_gpus > 1:
         raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     return world, rank, local
@@ -114,39 +119,48 @@ def main():
 
     lib = _C.load()
 
-    # ---- workload (per rank: one arxiv-shaped vertex partition; see DESIGN.md multi-GPU) ----
-    ei_cpu, n = arxiv_like(seed=args.seed + rank)
+    # ---- workload -------------------------------------------------------------------------------
+    # N = 1: BASELINE config 2.  N > 1 (weak scaling): every rank owns one arxiv-sized vertex range of a
+    # graph N times larger (5 % cross-partition edges); the halo rows of `bases` travel by one RCCL
+    # all-to-all-v inside the timed step (egc_amd/partition.py).
+    from egc_amd.functional import egc_layer_forward, pack_weights
+    from egc_amd.workloads import partitioned_arxiv_like
     torch.manual_seed(args.seed)
     conv = egc_amd.EGConv(F_IN, F_OUT, aggrs=AGGRS, num_heads=HEADS, num_bases=BASES, cached=True)
     with torch.no_grad():
         conv.bias.normal_()
-    x_cpu = torch.randn(n, F_IN)
     state_cpu = {k: v.detach().clone() for k, v in conv.state_dict().items()}
     conv = conv.to(dev).eval()
-    x = x_cpu.to(dev)
-    ei = ei_cpu.to(dev)
-    e_in = int(ei.size(1))
-    e_eff = e_in + n  # EGConv convention: every aggregator also traverses one self loop per node
-
-    graph = egc_amd.CSRGraph.from_edge_index(ei, n)
     spec: LayerSpec = conv._spec_coo
-    from egc_amd.functional import pack_weights
     wcat, bcat = conv._packed_weights()
     planes = pack_weights(spec, wcat)  # bf16x3 weight planes, rebuilt only when parameters change
     bias = conv.bias.detach()
     ldb = spec.ldb
-    bases = torch.empty((n, ldb), device=dev)
+    halo_stats = None
+    if world == 1:
+        ei_cpu, n = arxiv_like(seed=args.seed)
+        ei = ei_cpu.to(dev)
+        graph = egc_amd.CSRGraph.from_edge_index(ei, n)
+    else:
+        from egc_amd import partition
+        ei_cpu, n_global = partitioned_arxiv_like(rank, world, seed=args.seed)
+        ei_local, plan = partition.build_distributed(ei_cpu.to(dev), n_global)
+        graph = egc_amd.CSRGraph.from_partition(ei_local, plan, global_max_index=n_global - 1)
+        n = plan.n_local
+        ei = ei_local
+        halo_stats = plan.stats
+    torch.manual_seed(args.seed + 1 + rank)
+    x_cpu = torch.randn(n, F_IN)
+    x = x_cpu.to(dev)
+    e_in = int(ei.size(1))
+    e_eff = e_in + n  # EGConv convention: every aggregator also traverses one self loop per node
+
+    bases = torch.empty((graph.n_src_rows, ldb), device=dev)
     weightings = torch.empty((n, spec.w_cols), device=dev)
     out = torch.empty((n, F_OUT), device=dev)
     ws = torch.zeros(max(lib.egc_aggregate_workspace_bytes(C.byref(spec.c), n, e_in), 1), dtype=torch.uint8, device=dev)
     g = graph.c_struct()
     stream = torch.cuda.current_stream(dev).cuda_stream
-
-    def step():  # one full layer forward through the C ABI
-        _C.check(lib.egc_layer_forward_packed(C.byref(g), C.byref(spec.c), x.data_ptr(), planes.data_ptr(),
-                                              bcat.data_ptr(), bias.data_ptr(), bases.data_ptr(), ldb,
-                                              weightings.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), stream),
-                 "egc_layer_forward_packed")
 
     def gemm_only():
         _C.check(lib.egc_basis_transform_packed(x.data_ptr(), planes.data_ptr(), bcat.data_ptr(), n, F_IN, spec.f_g,
@@ -157,6 +171,18 @@ def main():
         _C.check(lib.egc_aggregate_combine_f32(C.byref(g), C.byref(spec.c), bases.data_ptr(), ldb,
                                                weightings.data_ptr(), bias.data_ptr(), out.data_ptr(), None, None,
                                                ws.data_ptr(), ws.numel(), stream), "egc_aggregate_combine_f32")
+
+    if world == 1:
+        def step():  # one full layer forward through the C ABI
+            _C.check(lib.egc_layer_forward_packed(C.byref(g), C.byref(spec.c), x.data_ptr(), planes.data_ptr(),
+                                                  bcat.data_ptr(), bias.data_ptr(), bases.data_ptr(), ldb,
+                                                  weightings.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                  stream), "egc_layer_forward_packed")
+    else:
+        def step():  # GEMM on owned rows -> halo all-to-all-v -> fused aggregate/combine
+            gemm_only()
+            graph.halo.exchange(bases)
+            agg_only()
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -208,10 +234,13 @@ def main():
         "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "ogbn-arxiv-shaped full graph per GPU: N=169343, heavy-tailed symmetrised "
+        "config": {"workload": "ogbn-arxiv-shaped full graph (per GPU at N>1: one arxiv-sized vertex range of an N-times "
+                               "larger graph, 5% cross-partition edges): N=169343, heavy-tailed symmetrised "
                                f"E_in={e_in} (+N self loops => E_eff={e_eff}), EGC-M d=128 H=8 B=4 "
                                "aggrs=sum+mean+max+symnorm, CSR cached",
-                   "n_nodes": n, "e_in": e_in, "e_eff": e_eff, "layer": "EGConv", "parallelism": f"dp{world}"},
+                   "n_nodes": n, "e_in": e_in, "e_eff": e_eff, "layer": "EGConv",
+                   "parallelism": "single GPU" if world == 1 else f"1-D vertex partition x{world}, halo all-to-all-v",
+                   "halo": halo_stats},
         "roofline": {"bound": "hbm", "kernel": "egc::agg_fast_kernel (fused aggregate+combine, one launch)", "achieved": agg_gbs,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": agg_gbs / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": terms["aggregate_kernel"], "launch_ms": agg_ms},
@@ -225,7 +254,7 @@ def main():
         for k, v in terms.items():
             log(f"  {k:18s} {v / 1e6:10.2f} MB")
         log(f"kernel ms: gemm {gemm_ms:.4f}  aggregate+combine {agg_ms:.4f}  layer {step_ms_events:.4f}")
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             ref_out, cpu_s, threads, e_cached = cpu_baseline(ei_cpu, n, x_cpu, state_cpu)
             err = float((out.cpu() - ref_out).abs().max() / max(1.0, float(ref_out.abs().max())))
             log(f"cpu port: {cpu_s * 1e3:.1f} ms/forward on {threads} threads; HIP vs CPU port rel err {err:.2e}")

@@ -34,6 +34,7 @@ class EgcGraph(C.Structure):
         ("rowptr", C.c_void_p), ("col", C.c_void_p), ("edge_id", C.c_void_p),
         ("dis_raw", C.c_void_p), ("dis_looped", C.c_void_p),
         ("max_index", C.c_void_p), ("plan", C.c_void_p), ("n_chunks", C.c_int64),
+        ("n_src_rows", C.c_int64),
     ]
 
 

@@ -391,7 +391,9 @@ int egc_aggregate_combine_f32(const egc_graph* graph, const egc_layer* layer, co
   if (bases == nullptr || weightings == nullptr || out == nullptr) return EGC_ERR_INVALID;
   if (ldb != egc_bases_ld(layer)) return EGC_ERR_INVALID;
   if ((reinterpret_cast<uintptr_t>(bases) & 15) != 0) return EGC_ERR_INVALID;
-  if ((uint64_t)n * (uint64_t)ldb * 4ull > (uint64_t)OOB) return EGC_ERR_UNSUPPORTED;  // 32-bit buffer offsets
+  const int64_t n_src = graph->n_src_rows > 0 ? graph->n_src_rows : n;  // owned rows + halo rows
+  if (n_src < n) return EGC_ERR_INVALID;
+  if ((uint64_t)n_src * (uint64_t)ldb * 4ull > (uint64_t)OOB) return EGC_ERR_UNSUPPORTED;  // 32-bit buffer offsets
 
   AggArgs a;
   a.rowptr = graph->rowptr;
@@ -424,7 +426,7 @@ int egc_aggregate_combine_f32(const egc_graph* graph, const egc_layer* layer, co
   if (layer->weight_layout == EGC_LAYOUT_HAB) { a.sa = a.B; a.sb = 1; } else { a.sa = 1; a.sb = a.A; }
   a.act = layer->weight_act;
   a.magic_L = a.L > 1 ? (unsigned)(((uint64_t)1 << 32) / (uint64_t)a.L) + 1u : 0u;  // L == 1: h = o in-kernel
-  a.bases_bytes = (unsigned)((uint64_t)n * ldb * 4ull);
+  a.bases_bytes = (unsigned)((uint64_t)n_src * ldb * 4ull);
 
   int chunks = 1;
   if (a.slots <= 64) {

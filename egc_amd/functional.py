@@ -67,45 +67,71 @@ def gemm_exact() -> bool:
     return os.environ.get("EGC_GEMM_EXACT", "0") not in ("", "0")
 
 
-def egc_layer_forward(graph: CSRGraph, spec: LayerSpec, x: torch.Tensor, wcat: torch.Tensor,
-                      bcat: torch.Tensor | None, bias: torch.Tensor | None, return_intermediates: bool = False,
-                      packed: torch.Tensor | None = None):
-    """out[N, F_out] for one layer.  wcat = [bases_weight | comb.weight^T]  ([F_in, F_g + W]),
-    bcat = comb.bias ([W]) or None, bias = layer bias ([F_out]) or None; ``packed`` = pack_weights(wcat)
-    if the caller keeps one (otherwise it is produced here)."""
+def egc_basis_transform(graph: CSRGraph, spec: LayerSpec, x: torch.Tensor, wcat: torch.Tensor,
+                        bcat: torch.Tensor | None, packed: torch.Tensor | None = None):
+    """Step 1 (egc_basis_transform_packed / _f32): returns (bases [n_src_rows, ldb], weightings [N, W]).
+    Only the first N rows of bases are written; halo rows are the caller's (partitioned runs)."""
     lib = _C.load()
     n = graph.n_nodes
     _check_f32(x, "x", (n, spec.f_in))
     _check_f32(wcat, "wcat", (spec.f_in, spec.f_g + spec.w_cols))
     if bcat is not None:
         _check_f32(bcat, "bcat", (spec.w_cols,))
-    if bias is not None:
-        _check_f32(bias, "bias", (spec.f_out,))
     if x.device != graph.device:
         raise RuntimeError(f"egc_amd: x is on {x.device} but the graph is on {graph.device}")
     dev = x.device
     x = x.contiguous()
     wcat = wcat.contiguous()
     with torch.cuda.device(dev):
-        bases = torch.empty((n, spec.ldb), dtype=torch.float32, device=dev)
+        bases = torch.empty((graph.n_src_rows, spec.ldb), dtype=torch.float32, device=dev)  # owned | halo rows
         weightings = torch.empty((n, spec.w_cols), dtype=torch.float32, device=dev)
-        out = torch.empty((n, spec.f_out), dtype=torch.float32, device=dev)
-        ws = graph.workspace(lib.egc_aggregate_workspace_bytes(C.byref(spec.c), n, graph.n_edges))
-        g = graph.c_struct()
         bcat_p = bcat.contiguous().data_ptr() if bcat is not None else None
-        bias_p = bias.contiguous().data_ptr() if bias is not None else None
         if gemm_exact():
-            _C.check(lib.egc_layer_forward_f32(
-                C.byref(g), C.byref(spec.c), x.data_ptr(), wcat.data_ptr(), bcat_p, bias_p, bases.data_ptr(), spec.ldb,
-                weightings.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(dev)),
-                "egc_layer_forward_f32")
+            _C.check(lib.egc_basis_transform_f32(x.data_ptr(), wcat.data_ptr(), bcat_p, n, spec.f_in, spec.f_g,
+                                                 spec.w_cols, bases.data_ptr(), spec.ldb, weightings.data_ptr(),
+                                                 _stream_ptr(dev)), "egc_basis_transform_f32")
         else:
             if packed is None:
                 packed = pack_weights(spec, wcat)
-            _C.check(lib.egc_layer_forward_packed(
-                C.byref(g), C.byref(spec.c), x.data_ptr(), packed.data_ptr(), bcat_p, bias_p, bases.data_ptr(),
-                spec.ldb, weightings.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(dev)),
-                "egc_layer_forward_packed")
+            _C.check(lib.egc_basis_transform_packed(x.data_ptr(), packed.data_ptr(), bcat_p, n, spec.f_in, spec.f_g,
+                                                    spec.w_cols, bases.data_ptr(), spec.ldb, weightings.data_ptr(),
+                                                    _stream_ptr(dev)), "egc_basis_transform_packed")
+    return bases, weightings
+
+
+def egc_aggregate_combine(graph: CSRGraph, spec: LayerSpec, bases: torch.Tensor, weightings: torch.Tensor,
+                          bias: torch.Tensor | None):
+    """Steps 2+3 (egc_aggregate_combine_f32): fused multi-aggregator reduction + combine -> out [N, F_out]."""
+    lib = _C.load()
+    n = graph.n_nodes
+    _check_f32(bases, "bases", (graph.n_src_rows, spec.ldb))
+    _check_f32(weightings, "weightings", (n, spec.w_cols))
+    if bias is not None:
+        _check_f32(bias, "bias", (spec.f_out,))
+    dev = bases.device
+    with torch.cuda.device(dev):
+        out = torch.empty((n, spec.f_out), dtype=torch.float32, device=dev)
+        ws = graph.workspace(lib.egc_aggregate_workspace_bytes(C.byref(spec.c), n, graph.n_edges))
+        g = graph.c_struct()
+        _C.check(lib.egc_aggregate_combine_f32(C.byref(g), C.byref(spec.c), bases.data_ptr(), spec.ldb,
+                                               weightings.data_ptr(),
+                                               bias.contiguous().data_ptr() if bias is not None else None,
+                                               out.data_ptr(), None, None, ws.data_ptr(), ws.numel(),
+                                               _stream_ptr(dev)), "egc_aggregate_combine_f32")
+    return out
+
+
+def egc_layer_forward(graph: CSRGraph, spec: LayerSpec, x: torch.Tensor, wcat: torch.Tensor,
+                      bcat: torch.Tensor | None, bias: torch.Tensor | None, return_intermediates: bool = False,
+                      packed: torch.Tensor | None = None):
+    """out[N, F_out] for one layer.  wcat = [bases_weight | comb.weight^T]  ([F_in, F_g + W]),
+    bcat = comb.bias ([W]) or None, bias = layer bias ([F_out]) or None; ``packed`` = pack_weights(wcat)
+    if the caller keeps one (otherwise it is produced here).  On a vertex-partitioned graph the halo rows
+    of ``bases`` are exchanged (one all-to-all-v) between the two steps."""
+    bases, weightings = egc_basis_transform(graph, spec, x, wcat, bcat, packed)
+    if graph.halo is not None and graph.n_src_rows > graph.n_nodes:
+        graph.halo.exchange(bases)
+    out = egc_aggregate_combine(graph, spec, bases, weightings, bias)
     if return_intermediates:
         return out, bases, weightings
     return out

@@ -31,8 +31,11 @@ def _require_cuda(t: torch.Tensor, what: str):
 class CSRGraph:
     """CSR by destination + degree statistics + long-row plan, all on one GPU."""
 
-    def __init__(self, n_nodes, n_edges, rowptr, col, edge_id, dis_raw, dis_looped, max_index, plan):
+    def __init__(self, n_nodes, n_edges, rowptr, col, edge_id, dis_raw, dis_looped, max_index, plan, n_src_rows=None):
         self.n_nodes, self.n_edges = int(n_nodes), int(n_edges)
+        # rows of the tables `col` indexes: owned rows first, then halo rows (vertex-partitioned runs)
+        self.n_src_rows = int(n_src_rows) if n_src_rows is not None else int(n_nodes)
+        self.halo = None  # egc_amd.partition.HaloPlan when the graph is one rank's partition
         self.rowptr, self.col, self.edge_id = rowptr, col, edge_id
         self.dis_raw, self.dis_looped, self.max_index, self.plan = dis_raw, dis_looped, max_index, plan
         self.device = rowptr.device
@@ -41,8 +44,10 @@ class CSRGraph:
 
     # -- construction ---------------------------------------------------------------------
     @classmethod
-    def from_edge_index(cls, edge_index: torch.Tensor, num_nodes: int) -> "CSRGraph":
-        """COO ``edge_index`` (int64 [2, E], row 0 = source, row 1 = destination) -> CSRGraph."""
+    def from_edge_index(cls, edge_index: torch.Tensor, num_nodes: int, num_src_rows: int | None = None) -> "CSRGraph":
+        """COO ``edge_index`` (int64 [2, E], row 0 = source, row 1 = destination) -> CSRGraph.
+        ``num_src_rows`` (>= num_nodes) is the size of the source index space when it is larger than the
+        set of rows (owned + halo vertices of a partition)."""
         _require_cuda(edge_index, "edge_index")
         if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.size(0) != 2:
             raise RuntimeError("egc_amd: edge_index must be an int64 tensor of shape [2, E]")
@@ -60,7 +65,22 @@ class CSRGraph:
             _C.check(lib.egc_coo_to_csr(ei[0].data_ptr(), ei[1].data_ptr(), e, n, rowptr.data_ptr(), col.data_ptr(),
                                         edge_id.data_ptr(), max_index.data_ptr(), ws.data_ptr(), ws.numel(),
                                         _stream_ptr(dev)), "egc_coo_to_csr")
-            return cls._prepare(n, e, rowptr, col, edge_id, max_index)
+            return cls._prepare(n, e, rowptr, col, edge_id, max_index, num_src_rows)
+
+    @classmethod
+    def from_partition(cls, edge_index_local: torch.Tensor, plan, global_max_index: int | None = None,
+                       exchange_dis: bool = True) -> "CSRGraph":
+        """One rank's share of a vertex-partitioned graph (egc_amd.partition): rows = owned vertices,
+        source ids in [owned | halo] order.  The halo entries of the deg^-1/2 tables come from their owners
+        (one all-to-all-v at setup; pass exchange_dis=False when the caller simulates the exchange)."""
+        g = cls.from_edge_index(edge_index_local, plan.n_local, plan.n_local + plan.n_halo)
+        g.halo = plan
+        if global_max_index is not None:  # add_remaining_self_loops infers N from the GLOBAL largest index
+            g.max_index.fill_(max(-1, min(int(global_max_index) - plan.lo, plan.n_local - 1)))
+        if exchange_dis and plan.n_halo >= 0 and plan.world > 1:
+            plan.exchange(g.dis_raw)
+            plan.exchange(g.dis_looped)
+        return g
 
     @classmethod
     def from_csr(cls, rowptr: torch.Tensor, col: torch.Tensor, num_nodes: int | None = None) -> "CSRGraph":
@@ -77,15 +97,18 @@ class CSRGraph:
             return cls._prepare(n, e, rowptr, col32, edge_id, max_index)
 
     @classmethod
-    def _prepare(cls, n, e, rowptr, col, edge_id, max_index) -> "CSRGraph":
+    def _prepare(cls, n, e, rowptr, col, edge_id, max_index, n_src_rows=None) -> "CSRGraph":
         lib = _C.load()
         dev = rowptr.device
-        dis_raw = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
-        dis_looped = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
+        ns = n if n_src_rows is None else int(n_src_rows)
+        if ns < n:
+            raise RuntimeError("egc_amd: num_src_rows must be >= num_nodes")
+        dis_raw = torch.zeros(max(ns, 1), dtype=torch.float32, device=dev)
+        dis_looped = torch.zeros(max(ns, 1), dtype=torch.float32, device=dev)
         plan = torch.empty(lib.egc_plan_ints(n, e), dtype=torch.int32, device=dev)
         _C.check(lib.egc_csr_prepare(n, e, rowptr.data_ptr(), col.data_ptr(), dis_raw.data_ptr(),
                                      dis_looped.data_ptr(), plan.data_ptr(), _stream_ptr(dev)), "egc_csr_prepare")
-        return cls(n, e, rowptr, col, edge_id, dis_raw, dis_looped, max_index, plan)
+        return cls(n, e, rowptr, col, edge_id, dis_raw, dis_looped, max_index, plan, ns)
 
     def workspace(self, nbytes: int) -> torch.Tensor:
         """Scratch for egc_aggregate_combine_f32.  The C ABI wants it zero-filled before its first use
@@ -103,7 +126,7 @@ class CSRGraph:
             self._n_chunks = int(self.plan[1].item())
         return _C.EgcGraph(self.n_nodes, self.n_edges, self.rowptr.data_ptr(), self.col.data_ptr(),
                            self.edge_id.data_ptr(), self.dis_raw.data_ptr(), self.dis_looped.data_ptr(),
-                           self.max_index.data_ptr(), self.plan.data_ptr(), self._n_chunks)
+                           self.max_index.data_ptr(), self.plan.data_ptr(), self._n_chunks, self.n_src_rows)
 
     def long_row_stats(self):
         """(n_long_rows, n_chunks) -- synchronises; diagnostics only."""

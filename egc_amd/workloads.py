@@ -29,6 +29,32 @@ def arxiv_like(seed: int = 0) -> tuple[torch.Tensor, int]:
     return heavy_tailed_graph(ARXIV_NODES, ARXIV_DIRECTED_EDGES, seed), ARXIV_NODES
 
 
+def partitioned_arxiv_like(rank: int, world: int, seed: int = 0, cross_frac: float = 0.05):
+    """Weak-scaling workload for the vertex-partitioned run: a graph of ``world`` arxiv-sized vertex ranges.
+    Rank r owns ids [r*N0, (r+1)*N0); inside its range it has its own arxiv-like graph (seed + r); on top,
+    ``cross_frac`` x (directed edges of one range) x world/2 undirected pairs connect different ranges
+    (uniform endpoint on one side, heavy-tailed endpoint on the other -- hubs attract remote neighbours too).
+    Every rank draws the SAME cross list from a shared seed and keeps the directions whose destination it
+    owns.  Returns (edges with GLOBAL ids whose destination rank `rank` owns, n_global)."""
+    n0 = ARXIV_NODES
+    n_global = n0 * world
+    local = heavy_tailed_graph(n0, ARXIV_DIRECTED_EDGES, seed + rank) + rank * n0
+    if world == 1 or cross_frac <= 0:
+        return local, n_global
+    g = torch.Generator().manual_seed(seed + 7919)
+    n_pairs = int(cross_frac * ARXIV_DIRECTED_EDGES * world / 2)
+    ra = torch.randint(0, world, (n_pairs,), generator=g)
+    rb = (ra + torch.randint(1, world, (n_pairs,), generator=g)) % world
+    a = ra * n0 + torch.randint(0, n0, (n_pairs,), generator=g)
+    u = torch.rand(n_pairs, generator=g, dtype=torch.float64)
+    b = rb * n0 + (n0 * u ** 3).long().clamp_(max=n0 - 1)
+    src = torch.cat([a, b])
+    dst = torch.cat([b, a])
+    mine = (dst >= rank * n0) & (dst < (rank + 1) * n0)
+    cross = torch.stack([src[mine], dst[mine]])
+    return torch.cat([local, cross], dim=1), n_global
+
+
 def molecule_batch(n_graphs: int = 2048, mean_nodes: float = 25.5, std_nodes: float = 12.0, min_nodes: int = 2,
                    max_nodes: int = 222, seed: int = 0) -> tuple[torch.Tensor, int, torch.Tensor]:
     """BASELINE config 3 (molhiv-like): disjoint union of small tree-plus-a-few-rings graphs, about

@@ -84,6 +84,9 @@ typedef struct {
   const int32_t* plan;        /* [egc_plan_ints(n_nodes,n_edges)] long-row work plan from egc_csr_prepare */
   int64_t n_chunks;           /* HOST copy of plan[1] (number of long-row chunks) if the caller has read it
                                  back, else -1: the launch is then sized for the plan's capacity */
+  int64_t n_src_rows;         /* rows of the tables that `col` indexes (bases, dis_*): n_nodes on one GPU; in a
+                                 vertex-partitioned run the owned rows come first and the halo rows received
+                                 from other ranks follow (n_src_rows >= n_nodes).  0 means n_nodes. */
 } egc_graph;
 
 /* int32 words the caller must allocate for egc_graph.plan. */
