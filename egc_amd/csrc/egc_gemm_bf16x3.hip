@@ -24,6 +24,10 @@
 // steps of 32; 4 wavefronts stacked along M, each 32 rows x 6 column tiles = 6 accumulators of 32x32.
 #include <stdlib.h>
 
+#include <algorithm>
+#include <cstdio>
+#include <vector>
+
 #include "egc_common.h"
 
 namespace egc {
@@ -33,11 +37,20 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 constexpr int XBM = 128;      // rows per block
 constexpr int XBN = 192;      // virtual columns per block (6 MFMA tiles)
 constexpr int XKT = 32;       // k per staging step
 constexpr int XLD = 40;       // LDS row stride in bf16 (80 B: conflict-free ds_read_b128 of 16-byte k-runs)
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding
+// GLOBAL access of the wavefront (s_waitcnt vmcnt(0)): in a streaming kernel that drains the stores of the
+// tile just finished and the prefetch of the next one at every barrier -- microseconds of HBM latency per
+// tile.  The tiles exchanged between wavefronts live in LDS, so lgkmcnt(0) + s_barrier is all that is needed.
+__device__ inline void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 __device__ inline u16 bf16_rn(float f) {
   const unsigned u = __float_as_uint(f);
@@ -184,7 +197,7 @@ __global__ void __launch_bounds__(256) basis_gemm_bf16x3_kernel(const float* __r
           if (i < pieces) *reinterpret_cast<u32x4*>(&Bs[p][i >> 2][(i & 3) * 8]) = wreg[p][j];
         }
     }
-    __syncthreads();
+    lds_barrier();
     if (ks + 1 < KS) {  // next step's operands: in flight during the MFMAs below
       if (A_VEC4) load_x(ks + 1);
       load_w(ks + 1);
@@ -215,7 +228,7 @@ __global__ void __launch_bounds__(256) basis_gemm_bf16x3_kernel(const float* __r
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
   }
 
   // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
@@ -426,13 +439,13 @@ __global__ void __launch_bounds__(512) basis_gemm_ws_kernel(const float* __restr
   float4 xr[PPT];
   load_tile(tile, xr);
   stage_tile(0, xr);
-  __syncthreads();
+  lds_barrier();
   int buf = 0;
   for (; tile < n_tiles; tile += stride) {
     load_tile(tile + stride, xr);  // masked past the end
     compute_tile(tile, buf);
     if (tile + stride < n_tiles) stage_tile(buf ^ 1, xr);
-    __syncthreads();
+    lds_barrier();
     buf ^= 1;
   }
 }
@@ -444,9 +457,14 @@ __global__ void __launch_bounds__(512) basis_gemm_ws_kernel(const float* __restr
 // the weight tile live in registers; the l plane -- used by one of the six products -- is kept once per
 // block in LDS next to the double-buffered x planes.
 // ---------------------------------------------------------------------------------------------
-constexpr int WS2_ROWS = 64;
 
-template <int KSUB>
+// RT = 32-row halves per tile (ROWS = 32 RT); DBUF = double-buffered x planes (one barrier per tile) or a
+// single buffer (two barriers per tile, half the LDS: two blocks fit per CU and cover each other's phases).
+#ifdef EGC_GEMM_STAMPS
+__device__ unsigned long long* egc_stamp_buf = nullptr;  // diagnostic build only
+#endif
+
+template <int KSUB, int RT, bool DBUF>
 __global__ void __launch_bounds__(768, 3) basis_gemm_ws2_kernel(const float* __restrict__ x, const u16* __restrict__ packed,
                                                                 const float* __restrict__ bcat, int64_t M, int K, int W,
                                                                 float* __restrict__ bases, int ldb,
@@ -454,10 +472,15 @@ __global__ void __launch_bounds__(768, 3) basis_gemm_ws2_kernel(const float* __r
                                                                 int x_vec4) {
   constexpr int KP = 16 * KSUB;
   constexpr int LDX = KP + 8;
+  constexpr int WS2_ROWS = 32 * RT;
   constexpr int XBUF = 3 * WS2_ROWS * LDX;  // bf16 elements of one x buffer (3 planes)
-  extern __shared__ __attribute__((aligned(16))) u16 smem2[];  // [2][3][64][LDX] x planes, then [NV][LDX] Wl
+  extern __shared__ __attribute__((aligned(16))) u16 smem2[];  // [1|2][3][ROWS][LDX] x planes, then [NV][LDX] Wl
   u16* xs = smem2;
-  u16* wls = smem2 + 2 * XBUF;
+  u16* wls = smem2 + (DBUF ? 2 : 1) * XBUF;
+  // comb.bias per virtual column (0 for the bases columns), read back with ds_read_b128 at store time: a
+  // global load there would sit behind `s_waitcnt vmcnt(0)`, and the in-order vmcnt would drain the previous
+  // tile's stores and the next tile's prefetch with it
+  float* bias_lds = reinterpret_cast<float*>(wls + NV * LDX);
   const int tid = threadIdx.x;
   const int nthreads = blockDim.x;
   const int lane = tid & 63;
@@ -466,7 +489,6 @@ __global__ void __launch_bounds__(768, 3) basis_gemm_ws2_kernel(const float* __r
   const int ct = wave % NT, rt = wave / NT;
   const int hh = lane >> 5;
   const int cb = 32 * ct;
-  const bool bias_vec4 = bcat == nullptr || (reinterpret_cast<uintptr_t>(bcat) & 15) == 0;
 
   // h / m planes of this wavefront's weight tile -> registers; l plane of the whole block -> LDS
   bf16x8 wf[KSUB][2];
@@ -477,6 +499,8 @@ __global__ void __launch_bounds__(768, 3) basis_gemm_ws2_kernel(const float* __r
       const u16* src = packed + ((((int64_t)(s >> 1) * 3 + p) * NV + cb + (lane & 31)) * XKT + 16 * (s & 1) + 8 * hh);
       wf[s][p] = *reinterpret_cast<const bf16x8*>(src);
     }
+  for (int i = tid; i < NV; i += nthreads)
+    bias_lds[i] = (bcat != nullptr && i >= ldb && i < ldb + W) ? bcat[i - ldb] : 0.f;
   for (int i = tid; i < NV * (KP / 8); i += nthreads) {  // 16-byte pieces of the l plane
     const int v = i / (KP / 8);
     const int k8 = (i - v * (KP / 8)) * 8;
@@ -486,6 +510,14 @@ __global__ void __launch_bounds__(768, 3) basis_gemm_ws2_kernel(const float* __r
 
   constexpr int PIECES = WS2_ROWS * KP / 4;
   constexpr int PPT = 3;  // host guarantees nthreads * PPT >= PIECES
+  // All global traffic of the tile loop goes through buffer instructions with an out-of-range offset for
+  // masked lanes (loads return 0, stores are dropped): no branches, so the compiler can count the in-flight
+  // operations and waits for the prefetched tile with vmcnt(N) instead of draining the stores with vmcnt(0).
+  constexpr unsigned GOOB = 0xFFFFFFF0u;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (unsigned)(M * K * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)bases, 0, (unsigned)(M * ldb * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw =
+      __builtin_amdgcn_make_buffer_rsrc((void*)weightings, 0, (unsigned)(M * (int64_t)W * 4), 0x00020000);
   auto load_tile = [&](int tile, float4 (&xr)[PPT]) {
     const int64_t m0 = (int64_t)tile * WS2_ROWS;
 #pragma unroll
@@ -495,20 +527,8 @@ __global__ void __launch_bounds__(768, 3) basis_gemm_ws2_kernel(const float* __r
       const int k4 = (pc - row * (KP / 4)) * 4;
       const int64_t gm = m0 + row;
       const bool ok = tile < n_tiles && pc < PIECES && gm < M && k4 < K;
-      if (x_vec4) {
-        const float4 v = *reinterpret_cast<const float4*>(ok ? x + gm * K + k4 : x);
-        xr[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-      } else {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) {
-          const float* px = x + gm * K + k4;
-          v.x = px[0];
-          if (k4 + 1 < K) v.y = px[1];
-          if (k4 + 2 < K) v.z = px[2];
-          if (k4 + 3 < K) v.w = px[3];
-        }
-        xr[i] = v;
-      }
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? (unsigned)((gm * K + k4) * 4) : GOOB, 0, 0);
+      xr[i] = __builtin_bit_cast(float4, v);
     }
   };
   auto stage_tile = [&](int buf, const float4 (&xr)[PPT]) {
@@ -541,36 +561,35 @@ __global__ void __launch_bounds__(768, 3) basis_gemm_ws2_kernel(const float* __r
       const bf16x8 xm = *reinterpret_cast<const bf16x8*>(xb + 16 * s + WS2_ROWS * LDX);
       const bf16x8 xl = *reinterpret_cast<const bf16x8*>(xb + 16 * s + 2 * WS2_ROWS * LDX);
       const bf16x8 wl = *reinterpret_cast<const bf16x8*>(wlb + 16 * s);
+#ifdef EGC_ABL_G_NOMFMA
+      acc[s] += (float)xl[0] + (float)xh[1] + (float)xm[2] + (float)wl[3];
+#else
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][0], xl, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][1], xm, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][0], xm, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][1], xh, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][0], xh, acc, 0, 0, 0);
+#endif
     }
     const int64_t gm = (int64_t)tile * WS2_ROWS + 32 * rt + (lane & 31);
-    if (gm < M) {
+#ifdef EGC_ABL_G_NOSTORE
+    const bool row_ok = gm < M && acc[0] == 123456.f;
+#else
+    const bool row_ok = gm < M;
+#endif
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int vc = cb + 8 * j + 4 * hh;
-        const float4 val = make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
-        if (vc < ldb) {
-          *reinterpret_cast<float4*>(bases + gm * ldb + vc) = val;
-        } else if (vc + 3 < ldb + W && (W & 3) == 0 && bias_vec4) {
-          float4 o = val;
-          if (bcat != nullptr) {
-            const float4 bb = *reinterpret_cast<const float4*>(bcat + (vc - ldb));
-            o.x += bb.x; o.y += bb.y; o.z += bb.z; o.w += bb.w;
-          }
-          *reinterpret_cast<float4*>(weightings + gm * (int64_t)W + (vc - ldb)) = o;
-        } else {
-          float* wrow = weightings + gm * (int64_t)W;
-          const float v4[4] = {val.x, val.y, val.z, val.w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (vc + e < ldb + W) wrow[vc + e - ldb] = v4[e] + (bcat != nullptr ? bcat[vc + e - ldb] : 0.f);
-        }
-      }
+    for (int j = 0; j < 4; ++j) {
+      const int vc = cb + 8 * j + 4 * hh;
+      const float4 bb = *reinterpret_cast<const float4*>(bias_lds + vc);
+      const f32x4v val = {acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]};
+      const f32x4v o = {val[0] + bb.x, val[1] + bb.y, val[2] + bb.z, val[3] + bb.w};
+      const bool to_b = row_ok && vc < ldb;
+      const bool to_w = row_ok && vc >= ldb && vc + 3 < ldb + W;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rb,
+                                             to_b ? (unsigned)((gm * ldb + vc) * 4) : GOOB, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rw,
+                                             to_w ? (unsigned)((gm * W + (vc - ldb)) * 4) : GOOB, 0, 0);
     }
   };
 
@@ -579,42 +598,104 @@ __global__ void __launch_bounds__(768, 3) basis_gemm_ws2_kernel(const float* __r
   if (tile >= n_tiles) return;
   float4 xr[PPT];
   load_tile(tile, xr);
-  stage_tile(0, xr);
-  __syncthreads();
-  int buf = 0;
-  for (; tile < n_tiles; tile += stride) {
-    load_tile(tile + stride, xr);  // masked past the end
-    compute_tile(tile, buf);
-    if (tile + stride < n_tiles) stage_tile(buf ^ 1, xr);
-    __syncthreads();
-    buf ^= 1;
+  if (DBUF) {
+    stage_tile(0, xr);
+    lds_barrier();
+    int buf = 0;
+#ifdef EGC_GEMM_STAMPS
+    unsigned long long tsum[4] = {0, 0, 0, 0}, t0, t1;
+#define EGC_STAMP(k) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory"); tsum[k] += t1 - t0; t0 = t1; }
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0) :: "memory");
+#else
+#define EGC_STAMP(k)
+#endif
+    for (; tile < n_tiles; tile += stride) {
+      load_tile(tile + stride, xr);  // masked (all lanes out of range) past the end
+      // keep the prefetch HERE: sunk below the epilogue stores it could only be consumed after
+      // s_waitcnt vmcnt(0), i.e. after the stores of this tile have completed
+      __builtin_amdgcn_sched_barrier(0);
+      EGC_STAMP(0)
+      compute_tile(tile, buf);
+      __builtin_amdgcn_sched_barrier(0);
+      EGC_STAMP(1)
+      stage_tile(buf ^ 1, xr);       // zeros past the end: harmless, keeps the loop branch-free
+      EGC_STAMP(2)
+      lds_barrier();
+      EGC_STAMP(3)
+      buf ^= 1;
+    }
+#ifdef EGC_GEMM_STAMPS
+    if (lane == 0 && egc_stamp_buf != nullptr)
+      for (int k = 0; k < 4; ++k) egc_stamp_buf[(blockIdx.x * 16 + wave) * 4 + k] = tsum[k];
+#endif
+  } else {
+    lds_barrier();  // l plane of the weights is in LDS
+    for (; tile < n_tiles; tile += stride) {
+      stage_tile(0, xr);
+      lds_barrier();
+      load_tile(tile + stride, xr);  // next tile in flight during the MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+      compute_tile(tile, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      lds_barrier();               // everyone is done with the buffer before it is overwritten
+    }
   }
 }
 
-template <int KSUB>
+template <int KSUB, int RT, bool DBUF>
 static int launch_ws2(const float* x, const u16* packed, const float* bcat, int64_t M, int K, int W, float* bases, int ldb,
                       float* weightings, int NV, hipStream_t stream) {
   const int nt = NV / 32;
-  const int threads = 128 * nt;  // two row halves per column tile
-  constexpr int KP = 16 * KSUB, LDX = KP + 8;
-  if (threads * 3 < WS2_ROWS * KP / 4 || threads > 768) return EGC_ERR_UNSUPPORTED;
-  const int64_t n_tiles64 = ceil_div(M, WS2_ROWS);
+  const int threads = 64 * nt * RT;
+  constexpr int KP = 16 * KSUB, LDX = KP + 8, ROWS = 32 * RT;
+  if (threads * 3 < ROWS * KP / 4 || threads > 768) return EGC_ERR_UNSUPPORTED;
+  const int64_t n_tiles64 = ceil_div(M, ROWS);
   if (n_tiles64 >= ((int64_t)1 << 31)) return EGC_ERR_INVALID;
   const int n_tiles = (int)n_tiles64;
-  const size_t lds = ((size_t)2 * 3 * WS2_ROWS * LDX + (size_t)NV * LDX) * sizeof(u16);
+  const size_t lds = ((size_t)(DBUF ? 2 : 1) * 3 * ROWS * LDX + (size_t)NV * LDX) * sizeof(u16) + (size_t)NV * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&basis_gemm_ws2_kernel<KSUB>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&basis_gemm_ws2_kernel<KSUB, RT, DBUF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { set_last_error("hipFuncSetAttribute(ws2)", e); return EGC_ERR_HIP; }
     attr_set = true;
   }
-  int grid = 256;  // one resident block (12 wavefronts) per CU, each walks tiles with stride gridDim
+  // persistent grid: as many blocks as are resident (LDS-limited), each walks tiles with stride gridDim
+  int grid = 256 * (int)((160 * 1024) / lds);
+  if (const char* e = getenv("EGC_GEMM_GRID")) grid = atoi(e);
   if (grid > n_tiles) grid = n_tiles;
   const int x_vec4 = (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-  basis_gemm_ws2_kernel<KSUB><<<grid, threads, lds, stream>>>(x, packed, bcat, M, K, W, bases, ldb, weightings, NV, n_tiles,
-                                                              x_vec4);
+#ifdef EGC_GEMM_STAMPS
+  static unsigned long long* dbuf = nullptr;
+  if (dbuf == nullptr) {
+    hipMalloc(&dbuf, 1024 * 16 * 4 * 8);
+    hipMemcpyToSymbol(HIP_SYMBOL(egc_stamp_buf), &dbuf, sizeof(dbuf));
+  }
+  hipMemset(dbuf, 0, 1024 * 16 * 4 * 8);
+#endif
+  basis_gemm_ws2_kernel<KSUB, RT, DBUF><<<grid, threads, lds, stream>>>(x, packed, bcat, M, K, W, bases, ldb, weightings,
+                                                                       NV, n_tiles, x_vec4);
   EGC_LAUNCH_CHECK("basis_gemm_ws2_kernel");
+#ifdef EGC_GEMM_STAMPS
+  {
+    hipDeviceSynchronize();
+    static int calls = 0;
+    if (++calls == 20) {
+      std::vector<unsigned long long> h(1024 * 16 * 4);
+      hipMemcpy(h.data(), dbuf, h.size() * 8, hipMemcpyDeviceToHost);
+      double sum[4] = {0, 0, 0, 0}; int nw = 0;
+      for (int b = 0; b < grid; ++b)
+        for (int w = 0; w < threads / 64; ++w) {
+          for (int k = 0; k < 4; ++k) sum[k] += (double)h[(b * 16 + w) * 4 + k];
+          ++nw;
+        }
+      const double tiles_per_block = (double)n_tiles / grid;
+      fprintf(stderr, "[stamps] per tile per wave (cycles): load-issue %.0f  mfma+stores %.0f  wait+stage %.0f  barrier %.0f  (tiles/block %.1f)\n",
+              sum[0] / nw / tiles_per_block, sum[1] / nw / tiles_per_block, sum[2] / nw / tiles_per_block,
+              sum[3] / nw / tiles_per_block, tiles_per_block);
+    }
+  }
+#endif
   return EGC_OK;
 }
 
@@ -679,8 +760,16 @@ int egc_basis_transform_packed(const float* x, const void* packed, const float* 
   if (x == nullptr || packed == nullptr || bases == nullptr || (w_cols > 0 && weightings == nullptr)) return EGC_ERR_INVALID;
   const int NV = round_up32(ldb + w_cols);
   const int KS = (f_in + XKT - 1) / XKT;
-  if (f_in > 96 && f_in <= 128 && NV == 192 && getenv("EGC_GEMM_NO_WS2") == nullptr)  // 12-wavefront form
-    return launch_ws2<8>(x, (const u16*)packed, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, stream);
+  const bool buf_ok = (f_in % 4 == 0) && (w_cols % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
+                      (uint64_t)n_nodes * (uint64_t)std::max(std::max(f_in, ldb), w_cols) * 4ull < 0xFFFFFFF0ull;
+  if (f_in > 96 && f_in <= 128 && NV == 192 && buf_ok && getenv("EGC_GEMM_NO_WS2") == nullptr)
+  {
+    const char* v = getenv("EGC_GEMM_WS2");
+    if (v != nullptr && v[0] == '1')  // 32-row tiles, single x buffer, two 6-wavefront blocks per CU (measured slower)
+      return launch_ws2<8, 1, false>(x, (const u16*)packed, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, stream);
+    // default: 64-row tiles, double-buffered x planes, one 12-wavefront block per CU (3 wavefronts per SIMD)
+    return launch_ws2<8, 2, true>(x, (const u16*)packed, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, stream);
+  }
   if (f_in <= 128 && NV <= 256 && getenv("EGC_GEMM_NO_WS") == nullptr) {  // weight-stationary form (<= 8 wavefronts)
     const u16* pk = (const u16*)packed;
     if (f_in <= 32) return launch_ws<2>(x, pk, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, stream);
