@@ -72,6 +72,10 @@ SYMBOLS = {
     "egc_layer_forward_f32": (C.c_int, [C.POINTER(EgcGraph), C.POINTER(EgcLayer), C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_size_t, C.c_void_p]),
+    "egc_backward_workspace_bytes": (C.c_size_t, [C.POINTER(EgcLayer), C.c_int64]),
+    "egc_aggregate_combine_backward_f32": (C.c_int, [C.POINTER(EgcGraph), C.c_void_p, C.c_void_p, C.POINTER(EgcLayer),
+                                                     C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                     C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "egc_last_error": (C.c_char_p, []),
     "egc_version": (C.c_char_p, []),
 }

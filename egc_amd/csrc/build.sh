@@ -8,12 +8,12 @@ mkdir -p "$OUT" "$HERE/obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -ffp-contract=off -I$ROOT/include -I$HERE -Wall -Wno-unused-function ${EGC_EXTRA_FLAGS:-}"
 pids=()
-for src in egc_graph egc_gemm egc_gemm_bf16x3 egc_aggregate egc_aggregate_fast; do
+for src in egc_graph egc_gemm egc_gemm_bf16x3 egc_aggregate egc_aggregate_fast egc_backward; do
   if [ ! -f "$HERE/obj/$src.o" ] || [ "$HERE/$src.hip" -nt "$HERE/obj/$src.o" ] || [ "$HERE/egc_common.h" -nt "$HERE/obj/$src.o" ] || [ "$HERE/egc_aggregate_dev.h" -nt "$HERE/obj/$src.o" ] || [ "$ROOT/include/egc_hip.h" -nt "$HERE/obj/$src.o" ]; then
     $HIPCC $FLAGS -c "$HERE/$src.hip" -o "$HERE/obj/$src.o" &
     pids+=($!)
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libegc_hip.so" "$HERE/obj/egc_graph.o" "$HERE/obj/egc_gemm.o" "$HERE/obj/egc_gemm_bf16x3.o" "$HERE/obj/egc_aggregate.o" "$HERE/obj/egc_aggregate_fast.o"
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libegc_hip.so" "$HERE/obj/egc_graph.o" "$HERE/obj/egc_gemm.o" "$HERE/obj/egc_gemm_bf16x3.o" "$HERE/obj/egc_aggregate.o" "$HERE/obj/egc_aggregate_fast.o" "$HERE/obj/egc_backward.o"
 echo "built $OUT/libegc_hip.so"

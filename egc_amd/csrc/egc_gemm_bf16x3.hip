@@ -772,10 +772,12 @@ int egc_basis_transform_packed(const float* x, const void* packed, const float* 
   }
   if (f_in <= 128 && NV <= 256 && getenv("EGC_GEMM_NO_WS") == nullptr) {  // weight-stationary form (<= 8 wavefronts)
     const u16* pk = (const u16*)packed;
-    if (f_in <= 32) return launch_ws<2>(x, pk, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, stream);
-    if (f_in <= 64) return launch_ws<4>(x, pk, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, stream);
-    if (f_in <= 96) return launch_ws<6>(x, pk, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, stream);
-    return launch_ws<8>(x, pk, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, stream);
+    int st;
+    if (f_in <= 32) st = launch_ws<2>(x, pk, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, stream);
+    else if (f_in <= 64) st = launch_ws<4>(x, pk, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, stream);
+    else if (f_in <= 96) st = launch_ws<6>(x, pk, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, stream);
+    else st = launch_ws<8>(x, pk, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, stream);
+    if (st != EGC_ERR_UNSUPPORTED) return st;  // too few wavefronts to stage a tile: use the LDS-staged kernel
   }
   const int64_t mblocks = ceil_div(n_nodes, XBM);
   if (mblocks >= ((int64_t)1 << 31)) return EGC_ERR_INVALID;

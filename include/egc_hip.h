@@ -191,6 +191,21 @@ int egc_layer_forward_packed(const egc_graph* graph, const egc_layer* layer, con
                              const float* bcat, const float* bias, float* bases, int32_t ldb, float* weightings,
                              float* out, void* workspace, size_t workspace_bytes, egc_stream_t stream);
 
+/* Backward of egc_aggregate_combine_f32 (in the reference PyTorch autograd derives it
+ * through layers.py:103-138 / optimized_layers.py:186-208).  Inputs: the forward's `bases` and
+ * PRE-activation `weightings` (layout HBA), grad_out = dL/d out [n_nodes, out_channels], and the TRANSPOSED
+ * CSR of the graph (rows = sources, entries = destinations: egc_coo_to_csr with src/dst swapped).
+ * Outputs: d_bases [n_nodes, ldb] -- MUST be zero-filled by the caller (max/min gradients arrive by float
+ * atomics at the first entry attaining the extremum, torch_scatter's arg semantics) -- and d_weightings
+ * [n_nodes, H*B*A] (gradient w.r.t. the pre-activation weightings).  The dense gradients
+ * (x, bases_weight, comb weight/bias, bias) are plain GEMMs / column sums left to the caller. */
+size_t egc_backward_workspace_bytes(const egc_layer* layer, int64_t n_nodes);
+int egc_aggregate_combine_backward_f32(const egc_graph* graph, const int32_t* t_rowptr, const int32_t* t_col,
+                                       const egc_layer* layer, const float* bases, int32_t ldb,
+                                       const float* weightings, const float* grad_out, float* d_bases,
+                                       float* d_weightings, void* workspace, size_t workspace_bytes,
+                                       egc_stream_t stream);
+
 /* Human-readable text of the last HIP failure seen on the calling thread ("" if none). */
 const char* egc_last_error(void);
 

@@ -176,7 +176,7 @@ def test_fin_not_multiple_of_4_and_fin_ne_fout():
     rng = np.random.default_rng(3)
     n = 257
     ei = _rand_graph(rng, n, 2000)
-    for fin, fout in [(5, 32), (37, 64), (128, 352), (130, 16)]:
+    for fin, fout in [(5, 32), (37, 64), (128, 352), (130, 16), (64, 8), (32, 16), (96, 24)]:
         out, ref = _oracle_case("opt", rng, n, ei, fin, fout, 8, 4, ["sum", "max"], dev)
         assert rel_err(out, ref) <= TOL
 
