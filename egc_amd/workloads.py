@@ -82,6 +82,14 @@ def molecule_batch(n_graphs: int = 2048, mean_nodes: float = 25.5, std_nodes: fl
     return ei, int(sizes.sum()), batch
 
 
+def zinc_like_batch(n_graphs: int = 128, seed: int = 0):
+    """BASELINE config 1 (ZINC-12k-like): molecule graphs of ~23 nodes, integer atom types in [0, 28).
+    Returns (atom_type [N] int64, edge_index, n_nodes, batch)."""
+    ei, n, batch = molecule_batch(n_graphs, mean_nodes=23.2, std_nodes=4.5, min_nodes=9, max_nodes=37, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    return torch.randint(0, 28, (n,), generator=g), ei, n, batch
+
+
 def knn_superpixel_batch(n_graphs: int = 2048, k: int = 8, lo: int = 85, hi: int = 150, seed: int = 0):
     """BASELINE config 4 (CIFAR10-superpixel-like): k-NN graphs of random 2-D points, k in-neighbours
     per node.  Returns (edge_index, n_nodes, batch)."""

@@ -3,9 +3,9 @@
 Same algorithm as oracle/egc_oracle.py (reference call sites cited there), written with torch ops so
 that autograd yields the gradients the reference's training loops rely on (zinc/configs.py:64-67,
 arxiv/configs.py:52-57).  Run in float64 it is the gradient oracle for the HIP backward
-(tests/test_backward_gpu.py).  Max/min gradients follow torch's scatter_reduce (ties share the gradient),
-torch_scatter routes them to the FIRST maximal entry -- identical whenever the maximum is unique, which
-the tests arrange; the tie rule itself is tested separately against a hand-built expectation.
+(tests/test_backward_gpu.py).  Max/min gradients go to the FIRST entry (edge order; an appended self loop
+is last) that attains the extremum -- torch_scatter's CPU arg rule (scatter_max/segment_csr update only on
+a strict improvement), which the reference's layers inherit (layers.py:208-219, optimized_layers.py:215-244).
 Parity status: unpinned by reference tests (see oracle/egc_oracle.py header).  Never imported by egc_amd.
 """
 from __future__ import annotations
@@ -25,8 +25,16 @@ def _scatter(src, index, n, reduce):
         cnt = torch.zeros(n, dtype=src.dtype).index_add(0, index, torch.ones(index.numel(), dtype=src.dtype))
         return out / cnt.clamp(min=1).view(-1, 1)
     red = "amax" if reduce == "max" else "amin"
-    return torch.zeros(n, f, dtype=src.dtype).scatter_reduce(0, index.view(-1, 1).expand(-1, f), src, red,
-                                                             include_self=False)
+    idx = index.view(-1, 1).expand(-1, f)
+    with torch.no_grad():
+        ext = torch.zeros(n, f, dtype=src.dtype).scatter_reduce(0, idx, src, red, include_self=False)
+        e = src.size(0)
+        pos = torch.arange(e).view(-1, 1).expand(-1, f)
+        pos = torch.where(src == ext[index], pos, torch.full_like(pos, e))
+        first = torch.full((n, f), e, dtype=torch.int64).scatter_reduce(0, idx, pos, "amin", include_self=True)
+        empty = first >= e
+    picked = torch.gather(src, 0, first.clamp(max=max(e - 1, 0))) if e > 0 else torch.zeros(n, f, dtype=src.dtype)
+    return torch.where(empty, torch.zeros_like(picked), picked)
 
 
 def _aggregate(a, x_j, index, n, weight):
