@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "egc_common.h"
+#include "egc_gemm_split.h"
 
 namespace egc {
 
@@ -734,7 +735,11 @@ size_t egc_basis_pack_bytes(int32_t f_in, int32_t f_g, int32_t w_cols) {
   const int ldb = (f_g + 3) & ~3;
   const int NV = round_up32(ldb + w_cols);
   const int KS = (f_in + XKT - 1) / XKT;
-  return (size_t)KS * 3 * NV * XKT * sizeof(u16);
+  return std::max((size_t)KS * 3 * NV * XKT * sizeof(u16), f16x2_pack_bytes(KS, NV));
+}
+
+static bool use_f16x2(int f_in, int ldb, int NV) {
+  return f16x2_shape(f_in, ldb, NV) && getenv("EGC_GEMM_BF16X3") == nullptr;
 }
 
 int egc_basis_pack_bf16x3(const float* wcat, int32_t f_in, int32_t f_g, int32_t w_cols, void* packed, size_t packed_bytes,
@@ -745,6 +750,7 @@ int egc_basis_pack_bf16x3(const float* wcat, int32_t f_in, int32_t f_g, int32_t 
   const int ldb = (f_g + 3) & ~3;
   const int NV = round_up32(ldb + w_cols);
   const int KS = (f_in + XKT - 1) / XKT;
+  if (use_f16x2(f_in, ldb, NV)) return f16x2_pack(wcat, f_in, f_g, w_cols, ldb, NV, KS, packed, stream);
   const int total = KS * NV * XKT;
   pack_bf16x3_kernel<<<(total + 255) / 256, 256, 0, stream>>>(wcat, f_in, f_g, w_cols, ldb, NV, KS, (u16*)packed);
   EGC_LAUNCH_CHECK("pack_bf16x3_kernel");
@@ -762,6 +768,10 @@ int egc_basis_transform_packed(const float* x, const void* packed, const float* 
   const int KS = (f_in + XKT - 1) / XKT;
   const bool buf_ok = (f_in % 4 == 0) && (w_cols % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
                       (uint64_t)n_nodes * (uint64_t)std::max(std::max(f_in, ldb), w_cols) * 4ull < 0xFFFFFFF0ull;
+  if (use_f16x2(f_in, ldb, NV)) {
+    if (!buf_ok) return EGC_ERR_UNSUPPORTED;  // (x alignment / 4 GiB buffer range; see egc_hip.h)
+    return f16x2_launch(x, packed, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, stream);
+  }
   if (f_in > 96 && f_in <= 128 && NV == 192 && buf_ok && getenv("EGC_GEMM_NO_WS2") == nullptr)
   {
     const char* v = getenv("EGC_GEMM_WS2");

@@ -1,0 +1,21 @@
+// Shared between the split-precision GEMM translation units (egc_gemm_bf16x3.hip, egc_gemm_f16x2.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace egc {
+
+constexpr int GEMM_KT = 32;  // k per packed staging step
+
+// Shapes served by the fp16x2 register-stationary kernel: everything else uses the bf16x3 planes.
+inline bool f16x2_shape(int f_in, int ldb, int NV) {
+  return f_in > 96 && f_in <= 128 && f_in % 4 == 0 && NV == 192 && ldb % 32 == 0;
+}
+
+size_t f16x2_pack_bytes(int KS, int NV);
+int f16x2_pack(const float* wcat, int f_in, int f_g, int w_cols, int ldb, int NV, int KS, void* packed, hipStream_t stream);
+int f16x2_launch(const float* x, const void* packed, const float* bcat, int64_t M, int K, int W, float* bases, int ldb,
+                 float* weightings, int NV, hipStream_t stream);
+
+}  // namespace egc
