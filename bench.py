@@ -133,7 +133,7 @@ def main():
     conv = conv.to(dev).eval()
     spec: LayerSpec = conv._spec_coo
     wcat, bcat = conv._packed_weights()
-    planes = pack_weights(spec, wcat)  # bf16x3 weight planes, rebuilt only when parameters change
+    planes = pack_weights(spec, wcat)  # split-precision weight planes, rebuilt only when parameters change
     bias = conv.bias.detach()
     ldb = spec.ldb
     halo_stats = None

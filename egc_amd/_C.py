@@ -59,7 +59,7 @@ SYMBOLS = {
     "egc_basis_transform_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                           C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "egc_basis_pack_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
-    "egc_basis_pack_bf16x3": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "egc_basis_pack": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "egc_basis_transform_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                              C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "egc_layer_forward_packed": (C.c_int, [C.POINTER(EgcGraph), C.POINTER(EgcLayer), C.c_void_p, C.c_void_p,

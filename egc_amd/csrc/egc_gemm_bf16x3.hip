@@ -15,7 +15,7 @@
 // same order as one fp32 rounding, so the result is within GEMM-reordering distance of the reference's
 // fp32 GEMM (parity tests: <= 1e-5, measured ~2e-7).
 //
-// The weight planes are split once per parameter update by egc_basis_pack_bf16x3 into the staging
+// The weight planes are split once per parameter update by egc_basis_pack into the staging
 // layout [k-step][plane][virtual column][32 k] (bf16), so the kernel copies them to LDS as 16-byte
 // pieces.  The virtual column space is the one of egc_gemm.hip: [0,F_g) bases, [F_g,ldb) zero pad,
 // [ldb,ldb+W) weightings, zero-padded to a multiple of 32.
@@ -742,8 +742,8 @@ static bool use_f16x2(int f_in, int ldb, int NV) {
   return f16x2_shape(f_in, ldb, NV) && getenv("EGC_GEMM_BF16X3") == nullptr;
 }
 
-int egc_basis_pack_bf16x3(const float* wcat, int32_t f_in, int32_t f_g, int32_t w_cols, void* packed, size_t packed_bytes,
-                          egc_stream_t stream_) {
+int egc_basis_pack(const float* wcat, int32_t f_in, int32_t f_g, int32_t w_cols, void* packed, size_t packed_bytes,
+                   egc_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (wcat == nullptr || packed == nullptr || f_in <= 0 || f_g <= 0 || w_cols < 0) return EGC_ERR_INVALID;
   if (packed_bytes < egc_basis_pack_bytes(f_in, f_g, w_cols)) return EGC_ERR_WORKSPACE;
@@ -768,10 +768,8 @@ int egc_basis_transform_packed(const float* x, const void* packed, const float* 
   const int KS = (f_in + XKT - 1) / XKT;
   const bool buf_ok = (f_in % 4 == 0) && (w_cols % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
                       (uint64_t)n_nodes * (uint64_t)std::max(std::max(f_in, ldb), w_cols) * 4ull < 0xFFFFFFF0ull;
-  if (use_f16x2(f_in, ldb, NV)) {
-    if (!buf_ok) return EGC_ERR_UNSUPPORTED;  // (x alignment / 4 GiB buffer range; see egc_hip.h)
+  if (use_f16x2(f_in, ldb, NV))  // the planes were packed for this kernel: no other form can read them
     return f16x2_launch(x, packed, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, stream);
-  }
   if (f_in > 96 && f_in <= 128 && NV == 192 && buf_ok && getenv("EGC_GEMM_NO_WS2") == nullptr)
   {
     const char* v = getenv("EGC_GEMM_WS2");

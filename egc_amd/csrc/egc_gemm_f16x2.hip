@@ -142,23 +142,8 @@ __global__ void __launch_bounds__(F16X2_THREADS) basis_gemm_f16x2_kernel(const f
   const int l31 = lane & 31, hh = lane >> 5;
   const int cb = 32 * ct;
 
-  // both planes of this wavefront's 128 x 32 weight block, as B operands of v_mfma_f32_32x32x16_f16:
-  // lane -> column cb + l31, k = 16 s + 8 hh .. + 7
   f16x8 wf[KSUB][2];
-#pragma unroll
-  for (int s = 0; s < KSUB; ++s)
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const u16* src = packed + ((((int64_t)(s >> 1) * 2 + p) * NV + cb + l31) * GEMM_KT + 16 * (s & 1) + 8 * hh);
-      wf[s][p] = *reinterpret_cast<const f16x8*>(src);
-    }
-  // every output element of a lane belongs to ONE column (cb + l31): its inverse scale and bias stay in registers
-  const float col_inv = reinterpret_cast<const float*>(packed + (int64_t)(KP / GEMM_KT) * 2 * NV * GEMM_KT)[cb + l31];
-  const int wcol = cb + l31 - ldb;
-  const float col_bias = (bcat != nullptr && wcol >= 0 && wcol < W) ? bcat[wcol] : 0.f;
-  // the ring starts as zeros: columns k >= K of a tile are out of range for the DMA and must read as 0
-  for (int i = tid; i < 2 * F16X2_RAW_BYTES / 16; i += nthreads) reinterpret_cast<u32x4*>(raw)[i] = u32x4{0, 0, 0, 0};
-
+  float col_inv, col_bias;
   // 16-byte pieces of a tile: piece pc = tid + 768 i  <->  (row pc / 32, k 4 (pc % 32)); i = 2 exists for
   // wavefronts 0-7 only (2048 pieces)
   constexpr unsigned GOOB = 0xFFFFFFF0u;  // out-of-range offset: loads return 0 -- no branches
@@ -215,7 +200,8 @@ __global__ void __launch_bounds__(F16X2_THREADS) basis_gemm_f16x2_kernel(const f
     const int pc = tid + nthreads * i;
     const int row = pc >> 5;
     const int k4 = (pc & 31) * 4;
-    // exponent field of the row maximum, kept where both 2^-e and 2^(11-e) are normal numbers
+    // exponent field of the row maximum, kept where both 2^-e and 2^(11-e) are normal numbers (rows below
+    // 2^-113 are scaled by 2^114 only and keep fewer bits; rows above 2^126 overflow as they would in fp32)
     unsigned e = amax & 0x7f800000u;
     e = min(max(e, 13u << 23), 253u << 23);
     const float sc = __uint_as_float(0x7f000000u - e);                  // 2^-e
@@ -277,10 +263,34 @@ __global__ void __launch_bounds__(F16X2_THREADS) basis_gemm_f16x2_kernel(const f
   const int stride = gridDim.x;
   int tile = blockIdx.x;
   if (tile >= n_tiles) return;
-  lds_barrier2();  // ring zeroed before the first DMA lands
+  if (K < KP) {  // columns k >= K of a tile are out of range for the DMA and must read as 0
+    for (int i = tid; i < 2 * F16X2_RAW_BYTES / 16; i += nthreads) reinterpret_cast<u32x4*>(raw)[i] = u32x4{0, 0, 0, 0};
+    lds_barrier2();
+  }
+  // first two tiles on their way before anything else: the weight loads below overlap their latency
   dma_tile(tile, 0);
   dma_tile(tile + stride, 1);
+#ifdef EGC_GEMM_STAMPS
+  unsigned long long t_a, t_b;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_a) :: "memory");
+#endif
+  // both planes of this wavefront's 128 x 32 weight block, as B operands of v_mfma_f32_32x32x16_f16:
+  // lane -> column cb + l31, k = 16 s + 8 hh .. + 7
+#pragma unroll
+  for (int s = 0; s < KSUB; ++s)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const u16* src = packed + ((((int64_t)(s >> 1) * 2 + p) * NV + cb + l31) * GEMM_KT + 16 * (s & 1) + 8 * hh);
+      wf[s][p] = *reinterpret_cast<const f16x8*>(src);
+    }
+  // every output element of a lane belongs to ONE column (cb + l31): its inverse scale and bias stay in registers
+  col_inv = reinterpret_cast<const float*>(packed + (int64_t)(KP / GEMM_KT) * 2 * NV * GEMM_KT)[cb + l31];
+  const int wcol = cb + l31 - ldb;
+  col_bias = (bcat != nullptr && wcol >= 0 && wcol < W) ? bcat[wcol] : 0.f;
   EGC_VMCNT(0);
+#ifdef EGC_GEMM_STAMPS
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_b) :: "memory");
+#endif
   stage(0, 0, 0, 0);
   stage(0, 0, 0, 1);
   if (third) stage(0, 0, 0, 2);
@@ -373,6 +383,8 @@ __global__ void __launch_bounds__(F16X2_THREADS) basis_gemm_f16x2_kernel(const f
     for (int k = 0; k < 6; ++k) egc_stamp_buf2[(blockIdx.x * 16 + wave) * 6 + k] = tsum[k];
     egc_stamp_buf2[1024 * 16 * 6 + (blockIdx.x * 16 + wave) * 2] = t_entry;
     egc_stamp_buf2[1024 * 16 * 6 + (blockIdx.x * 16 + wave) * 2 + 1] = r1;
+    egc_stamp_buf2[(blockIdx.x * 16 + wave) * 6 + 4] = r0 - t_entry;
+    egc_stamp_buf2[(blockIdx.x * 16 + wave) * 6 + 3] = ((t_a - t_entry) << 32) | (t_b - t_entry);
   }
 #endif
 }
@@ -385,12 +397,10 @@ int f16x2_pack(const float* wcat, int f_in, int f_g, int w_cols, int ldb, int NV
   return EGC_OK;
 }
 
-int f16x2_launch(const float* x, const void* packed, const float* bcat, int64_t M, int K, int W, float* bases, int ldb,
-                 float* weightings, int NV, hipStream_t stream) {
+static int f16x2_launch_rows(const float* x, const void* packed, const float* bcat, int64_t M, int K, int W, float* bases,
+                             int ldb, float* weightings, int NV, hipStream_t stream) {
   constexpr int ROWS = F16X2_ROWS;
   const int threads = F16X2_THREADS;
-  if (NV != 192 || K > F16X2_KP || ldb % 32 != 0) return EGC_ERR_UNSUPPORTED;
-  if ((uint64_t)M * (uint64_t)std::max(ldb, W) * 4ull >= 0x7FFFFFF0ull) return EGC_ERR_UNSUPPORTED;  // SOOB + scalar offset
   const int64_t n_tiles64 = (M + ROWS - 1) / ROWS;
   if (n_tiles64 >= ((int64_t)1 << 31)) return EGC_ERR_INVALID;
   const int n_tiles = (int)n_tiles64;
@@ -437,16 +447,42 @@ int f16x2_launch(const float* x, const void* packed, const float* bcat, int64_t 
           if (x > hi) hi = x;
           if (e - lo < 300) ++early;  // entered within 3 us of the first block
         }
-        fprintf(stderr, "[stamps f16x2] kernel span %.1f us, %d of %d blocks entered within 3 us\n", (hi - lo) * 0.01, early, grid);
+        double pro = 0, lmin = 1e30, lmax = 0, pa = 0, pb = 0;
+        for (int b = 0; b < grid; ++b) {
+          pro += (double)h[(b * 16) * 6 + 4];
+          pa += (double)(h[(b * 16) * 6 + 3] >> 32); pb += (double)(h[(b * 16) * 6 + 3] & 0xffffffffull);
+          lmin = std::min(lmin, (double)h[(b * 16) * 6 + 5]);
+          lmax = std::max(lmax, (double)h[(b * 16) * 6 + 5]);
+        }
+        fprintf(stderr, "[stamps f16x2] kernel span %.1f us, %d of %d blocks entered within 3 us; prologue avg %.1f us (dma issued %.1f, all landed %.1f); loop min %.1f max %.1f us\n",
+                (hi - lo) * 0.01, early, grid, pro / grid * 0.01, pa / grid * 0.01, pb / grid * 0.01, lmin * 0.01, lmax * 0.01);
       }
       const double tpb = (double)n_tiles / grid;
-      const double cyc = sum[0] + sum[1] + sum[2] + sum[3] + sum[4];
+      const double cyc = sum[0] + sum[1] + sum[2] + sum[3];
       fprintf(stderr, "[stamps f16x2] per tile per wave (cycles): k0-3+epi %.0f  k4-7+stage %.0f  t-fma %.0f  barrier %.0f  (-) %.0f "
               "(tiles/block %.1f)  clock %.2f GHz  loop %.1f us\n", sum[0] / nw / tpb, sum[1] / nw / tpb, sum[2] / nw / tpb,
               sum[3] / nw / tpb, sum[4] / nw / tpb, tpb, cyc / sum[5] * 0.1, sum[5] / nw * 0.01);
     }
   }
 #endif
+  return EGC_OK;
+}
+
+// The kernel addresses x, bases and weightings through 32-bit buffer offsets (and drops masked stores at
+// offset 2^31 + scalar row offset): row ranges of less than 2 GiB per array are launched one after another.
+int f16x2_launch(const float* x, const void* packed, const float* bcat, int64_t M, int K, int W, float* bases, int ldb,
+                 float* weightings, int NV, hipStream_t stream) {
+  if (NV != 192 || K > F16X2_KP || K % 4 != 0 || ldb % 32 != 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0)
+    return EGC_ERR_UNSUPPORTED;
+  const int64_t widest = std::max(std::max(K, ldb), W);
+  int64_t max_rows = ((int64_t)0x7FFFFFF0 / (4 * widest)) & ~(int64_t)(F16X2_ROWS - 1);
+  if (const char* e = getenv("EGC_GEMM_MAX_ROWS")) max_rows = std::max<int64_t>(F16X2_ROWS, atoll(e) & ~(int64_t)(F16X2_ROWS - 1));  // tests
+  for (int64_t r0 = 0; r0 < M; r0 += max_rows) {
+    const int64_t rows = std::min(max_rows, M - r0);
+    const int st = f16x2_launch_rows(x + r0 * K, packed, bcat, rows, K, W, bases + r0 * ldb, ldb,
+                                     weightings != nullptr ? weightings + r0 * W : nullptr, NV, stream);
+    if (st != EGC_OK) return st;
+  }
   return EGC_OK;
 }
 

@@ -49,7 +49,7 @@ def _check_f32(t, name, shape=None):
 
 def pack_weights(spec: LayerSpec, wcat: torch.Tensor) -> torch.Tensor:
     """Split wcat ([F_in, F_g + W], fp32) into the three bf16 planes the matrix-core GEMM stages
-    (egc_basis_pack_bf16x3).  Done once per parameter update; the result is an opaque byte buffer."""
+    (egc_basis_pack).  Done once per parameter update; the result is an opaque byte buffer."""
     lib = _C.load()
     _check_f32(wcat, "wcat", (spec.f_in, spec.f_g + spec.w_cols))
     dev = wcat.device
@@ -57,13 +57,13 @@ def pack_weights(spec: LayerSpec, wcat: torch.Tensor) -> torch.Tensor:
     with torch.cuda.device(dev):
         nbytes = lib.egc_basis_pack_bytes(spec.f_in, spec.f_g, spec.w_cols)
         packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        _C.check(lib.egc_basis_pack_bf16x3(wcat.data_ptr(), spec.f_in, spec.f_g, spec.w_cols, packed.data_ptr(),
-                                           nbytes, _stream_ptr(dev)), "egc_basis_pack_bf16x3")
+        _C.check(lib.egc_basis_pack(wcat.data_ptr(), spec.f_in, spec.f_g, spec.w_cols, packed.data_ptr(),
+                                    nbytes, _stream_ptr(dev)), "egc_basis_pack")
     return packed
 
 
 def gemm_exact() -> bool:
-    """EGC_GEMM_EXACT=1 selects the plain fp32-MFMA GEMM instead of the bf16x3 matrix-core form."""
+    """EGC_GEMM_EXACT=1 selects the plain fp32-MFMA GEMM instead of the split-precision matrix-core form."""
     return os.environ.get("EGC_GEMM_EXACT", "0") not in ("", "0")
 
 

@@ -104,7 +104,7 @@ class EGConv(nn.Module):
         return self._wcat
 
     def _weight_planes(self, spec, wcat):
-        """bf16x3 planes of wcat for the matrix-core GEMM, rebuilt with the packed weights."""
+        """split-precision planes of wcat for the matrix-core GEMM, rebuilt with the packed weights."""
         if not wcat.is_cuda or gemm_exact() or wcat.requires_grad:
             return None
         if self._planes is None or self._planes.device != wcat.device:

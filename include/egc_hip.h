@@ -144,15 +144,19 @@ int egc_basis_transform_f32(const float* x, const float* wcat, const float* bcat
                             int32_t f_in, int32_t f_g, int32_t w_cols, float* bases, int32_t ldb,
                             float* weightings, egc_stream_t stream);
 
-/* Step 1, fast form -- the same GEMM on the bf16 matrix cores with fp32-level accuracy: both operands are
- * split into three bf16 planes (x = xh+xm+xl, w = wh+wm+wl) and the six significant cross products are
- * accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (error ~2^-23 |x||w|, the order of one fp32 rounding).
- * The weight planes are produced once per parameter update by egc_basis_pack_bf16x3 into a caller buffer
- * of egc_basis_pack_bytes() bytes; egc_basis_transform_packed then has the contract of
- * egc_basis_transform_f32 (same reference call sites) with `packed` in place of `wcat`. */
+/* Step 1, fast form -- the same GEMM on the 16-bit matrix cores with fp32-level accuracy (split precision).
+ * North-star shapes (96 < F_in <= 128, F_g % 32 == 0, 192 padded output columns): every x row and every
+ * weight column is scaled by a power of two and split into two fp16 planes (22 significand bits); three
+ * cross products are accumulated in fp32 by v_mfma_f32_32x32x16_f16 (egc_gemm_f16x2.hip).  Other shapes:
+ * three bf16 planes per operand, six products on v_mfma_f32_32x32x16_bf16 (egc_gemm_bf16x3.hip).  Either way
+ * the dropped terms are of the order of one fp32 rounding of |x||w| (parity tests: <= 1e-5 of the output scale).
+ * The weight planes are produced once per parameter update by egc_basis_pack into a caller buffer of
+ * egc_basis_pack_bytes() bytes (opaque; its layout depends on the shape); egc_basis_transform_packed then
+ * has the contract of egc_basis_transform_f32 (same reference call sites) with `packed` in place of `wcat`.
+ * On the fp16 path egc_basis_transform_packed needs x 16-byte aligned (EGC_ERR_UNSUPPORTED otherwise). */
 size_t egc_basis_pack_bytes(int32_t f_in, int32_t f_g, int32_t w_cols);
-int egc_basis_pack_bf16x3(const float* wcat, int32_t f_in, int32_t f_g, int32_t w_cols, void* packed,
-                          size_t packed_bytes, egc_stream_t stream);
+int egc_basis_pack(const float* wcat, int32_t f_in, int32_t f_g, int32_t w_cols, void* packed,
+                   size_t packed_bytes, egc_stream_t stream);
 int egc_basis_transform_packed(const float* x, const void* packed, const float* bcat, int64_t n_nodes,
                                int32_t f_in, int32_t f_g, int32_t w_cols, float* bases, int32_t ldb,
                                float* weightings, egc_stream_t stream);
@@ -186,7 +190,7 @@ int egc_layer_forward_f32(const egc_graph* graph, const egc_layer* layer, const 
                           const float* bcat, const float* bias, float* bases, int32_t ldb, float* weightings,
                           float* out, void* workspace, size_t workspace_bytes, egc_stream_t stream);
 
-/* Same as egc_layer_forward_f32 with the GEMM in its packed bf16x3 form (the default production path). */
+/* Same as egc_layer_forward_f32 with the GEMM in its packed split-precision form (the default production path). */
 int egc_layer_forward_packed(const egc_graph* graph, const egc_layer* layer, const float* x, const void* packed,
                              const float* bcat, const float* bias, float* bases, int32_t ldb, float* weightings,
                              float* out, void* workspace, size_t workspace_bytes, egc_stream_t stream);

@@ -133,5 +133,5 @@ def test_training_step_reduces_loss():
         loss = ((l2(torch.relu(l1(x, ei)), ei) - y) ** 2).mean()
         loss.backward()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     assert losses[-1] < 0.7 * losses[0], losses[::6]

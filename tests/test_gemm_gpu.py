@@ -1,0 +1,125 @@
+"""The basis-transform GEMM through the C ABI (egc_basis_pack / egc_basis_transform_packed and the exact
+fp32 form) against float64: fp32-level accuracy on every shape path -- the fp16x2 register-stationary kernel
+(96 < F_in <= 128, F_g % 32 == 0, 192 padded columns), the bf16x3 kernels (everything else) -- including rows
+and columns of wildly different magnitude, zero rows, ragged sizes and non-finite inputs.
+
+Tolerance: componentwise |got - ref| <= 4e-6 * (|x| @ |w| + |b|), i.e. a few fp32 roundings of the products
+that went into each output (north_star's 1e-5 bound is on the output scale; this one is stricter)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _transform(x, wcat, bcat, f_g, w_cols, exact=False):
+    import ctypes as C
+    from egc_amd import _C
+    lib = _C.load()
+    n, f_in = x.shape
+    ldb = (f_g + 3) & ~3
+    bases = torch.full((n, ldb), float("nan"), device=DEV)
+    wt = torch.full((n, w_cols), float("nan"), device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    if exact:
+        _C.check(lib.egc_basis_transform_f32(x.data_ptr(), wcat.data_ptr(), bcat.data_ptr(), n, f_in, f_g, w_cols,
+                                             bases.data_ptr(), ldb, wt.data_ptr(), st), "f32")
+    else:
+        nb = lib.egc_basis_pack_bytes(f_in, f_g, w_cols)
+        planes = torch.empty(nb, dtype=torch.uint8, device=DEV)
+        _C.check(lib.egc_basis_pack(wcat.data_ptr(), f_in, f_g, w_cols, planes.data_ptr(), nb, st), "pack")
+        _C.check(lib.egc_basis_transform_packed(x.data_ptr(), planes.data_ptr(), bcat.data_ptr(), n, f_in, f_g, w_cols,
+                                                bases.data_ptr(), ldb, wt.data_ptr(), st), "packed")
+    torch.cuda.synchronize()
+    return bases, wt
+
+
+def _check(x, wcat, bcat, f_g, w_cols, bases, wt, tol=4e-6):
+    ref = x.double() @ wcat.double()
+    budget = x.double().abs() @ wcat.double().abs()
+    rb, rw = ref[:, :f_g], ref[:, f_g:] + bcat.double()
+    bb, bw = budget[:, :f_g], budget[:, f_g:] + bcat.double().abs()
+    tiny = torch.finfo(torch.float32).tiny
+    eb = ((bases[:, :f_g].double() - rb).abs() / (bb + tiny)).max() if bases.numel() else 0.0
+    ew = ((wt.double() - rw).abs() / (bw + tiny)).max() if wt.numel() else 0.0
+    assert float(eb) <= tol and float(ew) <= tol, (float(eb), float(ew))
+    if bases.size(1) > f_g:
+        assert bool((bases[:, f_g:] == 0).all())  # pad columns are written as zeros
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 16391])
+@pytest.mark.parametrize("f_in,f_g,w_cols", [
+    (128, 64, 128),   # north star: fp16x2 kernel
+    (100, 64, 126),   # fp16x2 kernel, F_in < 128 (zero-filled ring), W not a multiple of 4
+    (128, 32, 160),   # fp16x2 kernel, 1 bases tile + 5 weightings tiles
+    (124, 124, 48),   # bf16x3 (F_g % 32 != 0)
+    (168, 84, 32),    # bf16x3, LDS-staged general kernel
+    (7, 5, 3),        # tiny ragged
+])
+def test_packed_gemm_matches_float64(n, f_in, f_g, w_cols):
+    g = torch.Generator(device="cpu").manual_seed(1000 * n + f_in)
+    x = torch.randn(n, f_in, generator=g).to(DEV)
+    wcat = (torch.randn(f_in, f_g + w_cols, generator=g) * 0.2).to(DEV)
+    bcat = torch.randn(w_cols, generator=g).to(DEV)
+    _check(x, wcat, bcat, f_g, w_cols, *_transform(x, wcat, bcat, f_g, w_cols))
+
+
+def test_rows_and_columns_of_wildly_different_magnitude():
+    g = torch.Generator(device="cpu").manual_seed(7)
+    n, f_in, f_g, w_cols = 4099, 128, 64, 128
+    x = torch.randn(n, f_in, generator=g) * torch.exp2(torch.randint(-100, 100, (n, 1), generator=g).float())
+    x[:, ::7] *= 1e-4                      # small elements next to large ones inside a row
+    x[5] = 0.0                             # an all-zero row
+    x[6] = 1e-42                           # a denormal row
+    wcat = torch.randn(f_in, f_g + w_cols, generator=g) * torch.exp2(torch.randint(-20, 20, (1, f_g + w_cols), generator=g).float())
+    wcat[:, 3] = 0.0                       # an all-zero column
+    bcat = torch.zeros(w_cols)
+    x, wcat, bcat = x.to(DEV), wcat.to(DEV), bcat.to(DEV)
+    bases, wt = _transform(x, wcat, bcat, f_g, w_cols)
+    keep = torch.ones(n, dtype=torch.bool, device=DEV)
+    keep[6] = False
+    _check(x[keep], wcat, bcat, f_g, w_cols, bases[keep], wt[keep])
+    assert bool((bases[5] == 0).all()) and bool((wt[5] == 0).all())
+    assert bool((bases[:, 3] == 0).all())
+    # a row whose largest magnitude is below 2^-113 is scaled by 2^114 only: it keeps its order of magnitude
+    # but not 24 bits (the fp32 GEMMs of the matrix cores flush such inputs altogether)
+    ref6 = (x[6].double() @ wcat.double())[:f_g]
+    assert float((bases[6, :f_g].double() - ref6).abs().max()) <= 1e-3 * float((x[6].double().abs() @ wcat.double().abs()).max())
+
+
+def test_non_finite_inputs_stay_in_their_rows():
+    g = torch.Generator(device="cpu").manual_seed(9)
+    n, f_in, f_g, w_cols = 300, 128, 64, 128
+    x = torch.randn(n, f_in, generator=g)
+    x[17, 5] = float("inf")
+    x[130, 77] = float("nan")
+    wcat = torch.randn(f_in, f_g + w_cols, generator=g)
+    bcat = torch.randn(w_cols, generator=g)
+    x, wcat, bcat = x.to(DEV), wcat.to(DEV), bcat.to(DEV)
+    bases, wt = _transform(x, wcat, bcat, f_g, w_cols)
+    bad = torch.zeros(n, dtype=torch.bool, device=DEV)
+    bad[17] = bad[130] = True
+    assert not bool(torch.isfinite(bases[17]).all()) and not bool(torch.isfinite(wt[130]).all())
+    keep = ~bad
+    _check(x[keep], wcat, bcat, f_g, w_cols, bases[keep], wt[keep])
+
+
+def test_exact_fp32_form_agrees():
+    g = torch.Generator(device="cpu").manual_seed(11)
+    n, f_in, f_g, w_cols = 2000, 128, 64, 128
+    x, wcat, bcat = (torch.randn(n, f_in, generator=g).to(DEV), torch.randn(f_in, f_g + w_cols, generator=g).to(DEV),
+                     torch.randn(w_cols, generator=g).to(DEV))
+    _check(x, wcat, bcat, f_g, w_cols, *_transform(x, wcat, bcat, f_g, w_cols, exact=True))
+
+
+def test_row_ranges_launched_separately(monkeypatch):
+    """Arrays past the 2 GiB buffer-offset range are processed as consecutive row ranges: force tiny ranges."""
+    monkeypatch.setenv("EGC_GEMM_MAX_ROWS", "192")
+    g = torch.Generator(device="cpu").manual_seed(13)
+    n, f_in, f_g, w_cols = 1000, 128, 64, 128
+    x, wcat, bcat = (torch.randn(n, f_in, generator=g).to(DEV), torch.randn(f_in, f_g + w_cols, generator=g).to(DEV),
+                     torch.randn(w_cols, generator=g).to(DEV))
+    _check(x, wcat, bcat, f_g, w_cols, *_transform(x, wcat, bcat, f_g, w_cols))
