@@ -59,18 +59,22 @@ __device__ inline void split2_pk(f32x2 v, unsigned& h, unsigned& l) {
   l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
 }
 
-// packed[ks][plane][v][32] (fp16 bits) followed by float inv_scale[NV]; one thread per virtual column
+// packed[ks][plane][v][32] (fp16 bits) followed by float inv_scale[NV].  One wavefront per virtual column
+// (runs once per parameter update -- every step when training): lanes stride over k, the column maximum is a
+// wavefront all-reduce.
 __global__ void __launch_bounds__(64) pack_f16x2_kernel(const float* __restrict__ wcat, int K, int F_g, int W, int ldb,
                                                         int NV, int KS, u16* __restrict__ packed) {
-  const int v = blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= NV) return;
+  const int v = blockIdx.x;
+  const int lane = threadIdx.x;
   const int src = (v < F_g) ? v : ((v < ldb || v >= ldb + W) ? -1 : v - ldb + F_g);
   unsigned amax = 0;
   if (src >= 0)
-    for (int k = 0; k < K; ++k) amax = max(amax, __float_as_uint(wcat[(int64_t)k * (F_g + W) + src]) & 0x7fffffffu);
+    for (int k = lane; k < K; k += 64) amax = max(amax, __float_as_uint(wcat[(int64_t)k * (F_g + W) + src]) & 0x7fffffffu);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) amax = max(amax, (unsigned)__shfl_xor((int)amax, d));
   float scale, inv;
   scales_of(amax, scale, inv);
-  for (int k = 0; k < KS * GEMM_KT; ++k) {
+  for (int k = lane; k < KS * GEMM_KT; k += 64) {
     const float w = (src >= 0 && k < K) ? wcat[(int64_t)k * (F_g + W) + src] * scale : 0.f;
     const _Float16 h = (_Float16)w;
     const _Float16 l = (_Float16)((w - (float)h) * 2048.f);
@@ -78,7 +82,7 @@ __global__ void __launch_bounds__(64) pack_f16x2_kernel(const float* __restrict_
     packed[base] = __builtin_bit_cast(u16, h);
     packed[base + (int64_t)NV * GEMM_KT] = __builtin_bit_cast(u16, l);
   }
-  reinterpret_cast<float*>(packed + (int64_t)KS * 2 * NV * GEMM_KT)[v] = inv;
+  if (lane == 0) reinterpret_cast<float*>(packed + (int64_t)KS * 2 * NV * GEMM_KT)[v] = inv;
 }
 
 #ifdef EGC_GEMM_STAMPS
@@ -288,6 +292,11 @@ __global__ void __launch_bounds__(F16X2_THREADS) basis_gemm_f16x2_kernel(const f
   const int wcol = cb + l31 - ldb;
   col_bias = (bcat != nullptr && wcol >= 0 && wcol < W) ? bcat[wcol] : 0.f;
   EGC_VMCNT(0);
+  // the compiler counts only its own loads: let it retire the weight loads HERE (the counter is already zero),
+  // or its waits in the first tile would also drain the DMAs issued below
+  asm volatile("" : "+v"(wf[0][0]), "+v"(wf[0][1]), "+v"(wf[1][0]), "+v"(wf[1][1]), "+v"(wf[2][0]), "+v"(wf[2][1]),
+               "+v"(wf[3][0]), "+v"(wf[3][1]), "+v"(wf[4][0]), "+v"(wf[4][1]), "+v"(wf[5][0]), "+v"(wf[5][1]),
+               "+v"(wf[6][0]), "+v"(wf[6][1]), "+v"(wf[7][0]), "+v"(wf[7][1]), "+v"(col_inv), "+v"(col_bias));
 #ifdef EGC_GEMM_STAMPS
   asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_b) :: "memory");
 #endif
@@ -392,7 +401,7 @@ __global__ void __launch_bounds__(F16X2_THREADS) basis_gemm_f16x2_kernel(const f
 size_t f16x2_pack_bytes(int KS, int NV) { return (size_t)KS * 2 * NV * GEMM_KT * sizeof(u16) + (size_t)NV * sizeof(float); }
 
 int f16x2_pack(const float* wcat, int f_in, int f_g, int w_cols, int ldb, int NV, int KS, void* packed, hipStream_t stream) {
-  pack_f16x2_kernel<<<(NV + 63) / 64, 64, 0, stream>>>(wcat, f_in, f_g, w_cols, ldb, NV, KS, (u16*)packed);
+  pack_f16x2_kernel<<<NV, 64, 0, stream>>>(wcat, f_in, f_g, w_cols, ldb, NV, KS, (u16*)packed);
   EGC_LAUNCH_CHECK("pack_f16x2_kernel");
   return EGC_OK;
 }
