@@ -28,9 +28,11 @@ void set_last_error(const char* what, hipError_t err) {
 // ---------------------------------------------------------------------------------------------
 
 // keys[e] = dst[e] as u32; running max of every node id seen (src and dst) -> *max_index.
+// One atomic per BLOCK (the launch caps the grid): thousands of same-address atomics cost more than the read.
 __global__ void __launch_bounds__(256) coo_keys_kernel(const int64_t* __restrict__ src,
                                                        const int64_t* __restrict__ dst, int64_t n_edges,
                                                        uint32_t* __restrict__ keys, int32_t* __restrict__ max_index) {
+  __shared__ int wave_max[4];
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int m = -1;
   for (; e < n_edges; e += (int64_t)gridDim.x * blockDim.x) {
@@ -40,7 +42,12 @@ __global__ void __launch_bounds__(256) coo_keys_kernel(const int64_t* __restrict
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
-  if ((threadIdx.x & 63) == 0 && m >= 0) atomicMax(max_index, m);
+  if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
+    if (m >= 0) atomicMax(max_index, m);
+  }
 }
 
 // col[p] = src[edge_id[p]]
@@ -64,40 +71,79 @@ __global__ void __launch_bounds__(256) rowptr_kernel(const uint32_t* __restrict_
   rowptr[i] = (int32_t)lo;
 }
 
-// One wavefront per row: non-self in-degree, deg^-1/2 arrays, long-row plan entries.
-__global__ void __launch_bounds__(256) prepare_kernel(int64_t n_nodes, const int32_t* __restrict__ rowptr,
-                                                      const int32_t* __restrict__ col, float* __restrict__ dis_raw,
-                                                      float* __restrict__ dis_looped, int32_t* __restrict__ plan,
-                                                      int cap_long, int cap_chunks) {
-  const int lane = threadIdx.x & 63;
-  int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (row >= n_nodes) return;
-  const int start = rowptr[row], end = rowptr[row + 1];
+// 16 lanes per row, 64 rows per block: non-self in-degree, deg^-1/2 arrays, long-row plan entries.  Long rows
+// reserve their plan entries with LDS atomics inside the block and ONE pair of global atomics per block.
+constexpr int PREP_ROWS = 64;
+constexpr int PREP_HUGE = 2048;  // rows longer than this are counted by all 1024 threads of the block
+__global__ void __launch_bounds__(16 * PREP_ROWS) prepare_kernel(int64_t n_nodes, const int32_t* __restrict__ rowptr,
+                                                                 const int32_t* __restrict__ col,
+                                                                 float* __restrict__ dis_raw, float* __restrict__ dis_looped,
+                                                                 int32_t* __restrict__ plan, int cap_long, int cap_chunks) {
+  __shared__ int s_long, s_chunks, s_base_long, s_base_chunk;
+  __shared__ int s_huge_n, s_huge_row[PREP_ROWS], s_huge_cnt[PREP_ROWS];  // hub rows: counted by the whole block
+  const int sl = threadIdx.x & 15;
+  const int64_t row = (int64_t)blockIdx.x * PREP_ROWS + (threadIdx.x >> 4);
+  const bool live = row < n_nodes;
+  if (threadIdx.x == 0) { s_long = 0; s_chunks = 0; s_huge_n = 0; }
+  __syncthreads();
+  const int start = live ? rowptr[row] : 0, end = live ? rowptr[row + 1] : 0;
   const int deg = end - start;
   if (dis_looped != nullptr) {
-    int nonself = 0;
-    for (int p = start + lane; p < end; p += 64) nonself += (col[p] != (int)row);
+    if (deg > PREP_HUGE) {  // a hub row would keep its 16 lanes busy long after the rest of the grid has finished
+      if (sl == 0) {
+        const int h = atomicAdd(&s_huge_n, 1);
+        s_huge_row[h] = (int)(threadIdx.x >> 4);
+        s_huge_cnt[h] = 0;
+      }
+    } else {
+      int nonself = 0;
+      for (int p = start + sl; p < end; p += 16) nonself += (col[p] != (int)row);
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) nonself += __shfl_xor(nonself, off);
-    if (lane == 0) dis_looped[row] = 1.0f / sqrtf((float)(nonself + 1));
+      for (int off = 8; off > 0; off >>= 1) nonself += __shfl_xor(nonself, off);
+      if (live && sl == 0) dis_looped[row] = 1.0f / sqrtf((float)(nonself + 1));
+    }
+    __syncthreads();
+    for (int h = 0; h < s_huge_n; ++h) {
+      const int64_t hr = (int64_t)blockIdx.x * PREP_ROWS + s_huge_row[h];
+      const int hs = rowptr[hr], he = rowptr[hr + 1];
+      int nonself = 0;
+      for (int p = hs + (int)threadIdx.x; p < he; p += 16 * PREP_ROWS) nonself += (col[p] != (int)hr);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) nonself += __shfl_xor(nonself, off);
+      if ((threadIdx.x & 63) == 0 && nonself != 0) atomicAdd(&s_huge_cnt[h], nonself);
+      __syncthreads();
+      if (threadIdx.x == 0) dis_looped[hr] = 1.0f / sqrtf((float)(s_huge_cnt[h] + 1));
+    }
   }
-  if (lane == 0) {
-    if (dis_raw != nullptr) dis_raw[row] = deg > 0 ? 1.0f / sqrtf((float)deg) : 0.0f;
-    if (deg > EGC_LONG_ROW_THRESHOLD) {
-      const int nch = (deg + EGC_LONG_ROW_CHUNK - 1) / EGC_LONG_ROW_CHUNK;
-      const int slot = atomicAdd(&plan[0], 1);
-      const int c0 = atomicAdd(&plan[1], nch);
-      int32_t* long_row = plan + 4;
-      int32_t* long_chunk0 = long_row + cap_long;
-      int32_t* chunk_slot = long_chunk0 + cap_long;
-      int32_t* chunk_begin = chunk_slot + cap_chunks;
-      if (slot < cap_long && c0 + nch <= cap_chunks) {  // always true by construction of the caps
+  if (live && sl == 0 && dis_raw != nullptr) dis_raw[row] = deg > 0 ? 1.0f / sqrtf((float)deg) : 0.0f;
+  const bool is_long = live && deg > EGC_LONG_ROW_THRESHOLD;
+  const int nch = is_long ? (deg + EGC_LONG_ROW_CHUNK - 1) / EGC_LONG_ROW_CHUNK : 0;
+  int slot = 0, c0 = 0;
+  if (is_long && sl == 0) {
+    slot = atomicAdd(&s_long, 1);
+    c0 = atomicAdd(&s_chunks, nch);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && s_long > 0) {
+    s_base_long = atomicAdd(&plan[0], s_long);
+    s_base_chunk = atomicAdd(&plan[1], s_chunks);
+  }
+  __syncthreads();
+  if (is_long) {
+    slot = __shfl(slot, threadIdx.x & 48) + s_base_long;   // lane 0 of this 16-lane group
+    c0 = __shfl(c0, threadIdx.x & 48) + s_base_chunk;
+    int32_t* long_row = plan + 4;
+    int32_t* long_chunk0 = long_row + cap_long;
+    int32_t* chunk_slot = long_chunk0 + cap_long;
+    int32_t* chunk_begin = chunk_slot + cap_chunks;
+    if (slot < cap_long && c0 + nch <= cap_chunks) {  // always true by construction of the caps
+      if (sl == 0) {
         long_row[slot] = (int32_t)row;
         long_chunk0[slot] = c0;
-        for (int k = 0; k < nch; ++k) {
-          chunk_slot[c0 + k] = slot;
-          chunk_begin[c0 + k] = start + k * EGC_LONG_ROW_CHUNK;
-        }
+      }
+      for (int k = sl; k < nch; k += 16) {
+        chunk_slot[c0 + k] = slot;
+        chunk_begin[c0 + k] = start + k * EGC_LONG_ROW_CHUNK;
       }
     }
   }
@@ -178,7 +224,8 @@ int egc_coo_to_csr(const int64_t* src, const int64_t* dst, int64_t n_edges, int6
 
   const int threads = 256;
   const int blocks = (int)std::min<int64_t>(ceil_div(n_edges, threads), 256 * 8);
-  coo_keys_kernel<<<blocks, threads, 0, stream>>>(src, dst, n_edges, keys_in, max_index);
+  const int key_blocks = std::min(blocks, 512);
+  coo_keys_kernel<<<key_blocks, threads, 0, stream>>>(src, dst, n_edges, keys_in, max_index);
   EGC_LAUNCH_CHECK("coo_keys_kernel");
   // Stable LSD radix sort of (dst, input position): the value array IS edge_id.
   EGC_HIP_TRY(rocprim::radix_sort_pairs(sort_temp, temp, (const uint32_t*)keys_in, keys_out,
@@ -200,8 +247,7 @@ int egc_csr_prepare(int64_t n_nodes, int64_t n_edges, const int32_t* rowptr, con
   plan_header_kernel<<<1, 1, 0, stream>>>(plan, (int)c.cap_long, (int)c.cap_chunks);
   EGC_LAUNCH_CHECK("plan_header_kernel");
   if (n_nodes == 0) return EGC_OK;
-  const int waves_per_block = 4;
-  prepare_kernel<<<(int)ceil_div(n_nodes, waves_per_block), waves_per_block * 64, 0, stream>>>(
+  prepare_kernel<<<(int)ceil_div(n_nodes, (int64_t)PREP_ROWS), 16 * PREP_ROWS, 0, stream>>>(
       n_nodes, rowptr, col, dis_raw, dis_looped, plan, (int)c.cap_long, (int)c.cap_chunks);
   EGC_LAUNCH_CHECK("prepare_kernel");
   return EGC_OK;

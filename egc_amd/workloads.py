@@ -123,3 +123,12 @@ def algorithmic_bytes(n_nodes: int, e_eff: int, f_in: int, f_g: int, f_out: int,
     t["aggregate_kernel"] = t["gather"] + t["col"] + t["rowptr"] + t["deg"] + t["weightings"] + t["out"]
     t["gemm_kernel"] = t["x"] + t["bases_write"] + t["weightings"]
     return t
+
+
+MAG_NODES = 736_389            # ogbn-mag paper nodes (what `main.py egc mag` trains on, mag/configs.py:73-88)
+MAG_DIRECTED_EDGES = 5_416_271
+
+
+def mag_like(seed: int = 0) -> tuple[torch.Tensor, int]:
+    """BASELINE config 5, homogeneous form: N = 736,389, ~10.8 M symmetrised heavy-tailed edges."""
+    return heavy_tailed_graph(MAG_NODES, MAG_DIRECTED_EDGES, seed), MAG_NODES
