@@ -324,12 +324,6 @@ static int validate_layer(const egc_layer* L) {
   return EGC_OK;
 }
 
-static bool layer_uses_symnorm(const egc_layer* L) {
-  for (int t = 0; t < L->num_aggrs; ++t)
-    if (L->aggrs[t] == EGC_AGGR_SYMNORM) return true;
-  return false;
-}
-
 struct WsLayout {
   size_t counter_bytes, partial_bytes, nself_bytes, total;
 };
@@ -392,7 +386,9 @@ int egc_aggregate_combine_f32(const egc_graph* graph, const egc_layer* layer, co
   if (ldb != egc_bases_ld(layer)) return EGC_ERR_INVALID;
   if ((reinterpret_cast<uintptr_t>(bases) & 15) != 0) return EGC_ERR_INVALID;
   const int64_t n_src = graph->n_src_rows > 0 ? graph->n_src_rows : n;  // owned rows + halo rows
-  if (n_src < n) return EGC_ERR_INVALID;
+  // a rectangular adjacency (relation between two node types; fewer sources than rows is possible) has no
+  // self loops and no symmetric normalisation: nothing then indexes the source tables by a ROW id
+  if (n_src < n && (layer->agg_set == EGC_SET_LOOPED || layer_uses_symnorm(layer))) return EGC_ERR_INVALID;
   if ((uint64_t)n_src * (uint64_t)ldb * 4ull > (uint64_t)OOB) return EGC_ERR_UNSUPPORTED;  // 32-bit buffer offsets
 
   AggArgs a;

@@ -254,7 +254,9 @@ int egc_aggregate_combine_backward_f32(const egc_graph* graph, const int32_t* t_
   const int64_t n = graph->n_nodes;
   const int64_t n_src = graph->n_src_rows > 0 ? graph->n_src_rows : n;
   if (n == 0) return EGC_OK;
-  if (n_src != n) return EGC_ERR_UNSUPPORTED;  // partitioned backward: not yet
+  // t_rowptr has n_src + 1 entries.  Rectangular adjacencies (n_src != n) carry no self loops / symnorm; on a
+  // vertex partition the caller owns the reverse exchange of the halo rows of d_bases.
+  if (n_src < n && (layer->agg_set == EGC_SET_LOOPED || layer_uses_symnorm(layer))) return EGC_ERR_INVALID;
   if (bases == nullptr || weightings == nullptr || grad_out == nullptr || d_bases == nullptr || d_weightings == nullptr)
     return EGC_ERR_INVALID;
   if (ldb != egc_bases_ld(layer)) return EGC_ERR_INVALID;

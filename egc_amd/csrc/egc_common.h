@@ -32,6 +32,12 @@ void set_last_error(const char* what, hipError_t err);
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+static inline bool layer_uses_symnorm(const egc_layer* L) {
+  for (int t = 0; t < L->num_aggrs; ++t)
+    if (L->aggrs[t] == EGC_AGGR_SYMNORM) return true;
+  return false;
+}
+
 // Long-row plan layout (int32 words), shared by egc_csr_prepare and the aggregate kernels:
 //   [0] n_long   [1] n_chunks   [2] cap_long   [3] cap_chunks
 //   [4 .. 4+cap_long)                 long_row[s]      row id of long-row slot s

@@ -144,7 +144,7 @@ def egc_aggregate_combine_backward(graph: CSRGraph, spec: LayerSpec, bases, weig
     dev = bases.device
     t_rowptr, t_col = graph.transposed()
     with torch.cuda.device(dev):
-        d_bases = torch.zeros((n, spec.ldb), dtype=torch.float32, device=dev)  # atomics land here
+        d_bases = torch.zeros((graph.n_src_rows, spec.ldb), dtype=torch.float32, device=dev)  # atomics land here
         d_w = torch.empty((n, spec.w_cols), dtype=torch.float32, device=dev)
         nbytes = lib.egc_backward_workspace_bytes(C.byref(spec.c), n)
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
@@ -186,6 +186,34 @@ class _EGCLayerFunction(torch.autograd.Function):
         dbcat = d_w.sum(0) if (ctx.has_bcat and ctx.needs_input_grad[2]) else None
         dbias = grad_out.sum(0) if (ctx.has_bias and ctx.needs_input_grad[3]) else None
         return dx, dwcat, dbcat, dbias, None, None
+
+
+class _AggregateCombineFunction(torch.autograd.Function):
+    """Autograd around the fused aggregate/combine alone: ``bases`` [n_src_rows, ldb] and the pre-activation
+    ``weightings`` [N, W] (layout [h][b][a]) come from differentiable torch ops of the caller (relational EGC:
+    the basis table of the SOURCE node type, the combination Linear of the TARGET type)."""
+
+    @staticmethod
+    def forward(ctx, bases, weightings, bias, graph, spec):
+        out = egc_aggregate_combine(graph, spec, bases, weightings, bias)
+        ctx.save_for_backward(bases, weightings)
+        ctx.graph, ctx.spec, ctx.has_bias = graph, spec, bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        bases, weightings = ctx.saved_tensors
+        grad_out = grad_out.contiguous()
+        d_bases, d_w = egc_aggregate_combine_backward(ctx.graph, ctx.spec, bases, weightings, grad_out)
+        dbias = grad_out.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return d_bases, d_w, dbias, None, None
+
+
+def egc_aggregate_combine_apply(graph, spec, bases, weightings, bias=None):
+    """egc_aggregate_combine with autograd when any input requires a gradient."""
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (bases, weightings, bias)):
+        return _AggregateCombineFunction.apply(bases, weightings, bias, graph, spec)
+    return egc_aggregate_combine(graph, spec, bases, weightings, bias)
 
 
 def egc_layer_apply(graph, spec, x, wcat, bcat, bias, packed=None):

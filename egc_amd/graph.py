@@ -83,7 +83,8 @@ class CSRGraph:
         return g
 
     @classmethod
-    def from_csr(cls, rowptr: torch.Tensor, col: torch.Tensor, num_nodes: int | None = None) -> "CSRGraph":
+    def from_csr(cls, rowptr: torch.Tensor, col: torch.Tensor, num_nodes: int | None = None,
+                 num_src_rows: int | None = None) -> "CSRGraph":
         """Existing CSR keyed by destination (``adj_t``: row = destination, col = source)."""
         _require_cuda(rowptr, "rowptr")
         dev = rowptr.device
@@ -94,17 +95,18 @@ class CSRGraph:
         with torch.cuda.device(dev):
             edge_id = torch.arange(max(e, 1), dtype=torch.int32, device=dev)
             max_index = torch.full((1,), n - 1, dtype=torch.int32, device=dev)
-            return cls._prepare(n, e, rowptr, col32, edge_id, max_index)
+            return cls._prepare(n, e, rowptr, col32, edge_id, max_index, num_src_rows)
 
     @classmethod
     def _prepare(cls, n, e, rowptr, col, edge_id, max_index, n_src_rows=None) -> "CSRGraph":
         lib = _C.load()
         dev = rowptr.device
         ns = n if n_src_rows is None else int(n_src_rows)
-        if ns < n:
-            raise RuntimeError("egc_amd: num_src_rows must be >= num_nodes")
-        dis_raw = torch.zeros(max(ns, 1), dtype=torch.float32, device=dev)
-        dis_looped = torch.zeros(max(ns, 1), dtype=torch.float32, device=dev)
+        if ns <= 0 and e > 0:
+            raise RuntimeError("egc_amd: num_src_rows must be positive")
+        # deg^-1/2 tables: rows first, then (partitioned runs) the halo entries filled in by their owners
+        dis_raw = torch.zeros(max(n, ns, 1), dtype=torch.float32, device=dev)
+        dis_looped = torch.zeros(max(n, ns, 1), dtype=torch.float32, device=dev)
         plan = torch.empty(lib.egc_plan_ints(n, e), dtype=torch.int32, device=dev)
         _C.check(lib.egc_csr_prepare(n, e, rowptr.data_ptr(), col.data_ptr(), dis_raw.data_ptr(),
                                      dis_looped.data_ptr(), plan.data_ptr(), _stream_ptr(dev)), "egc_csr_prepare")
@@ -114,23 +116,23 @@ class CSRGraph:
         """(t_rowptr, t_col): CSR with rows = SOURCES and entries = destinations, needed by the backward
         (d bases[j] gathers over j's out-neighbours).  Built on first use from the destination-keyed CSR."""
         if getattr(self, "_transposed", None) is None:
-            if self.n_src_rows != self.n_nodes:
+            if self.halo is not None:
                 raise RuntimeError("egc_amd: backward on a vertex-partitioned graph is not implemented")
             lib = _C.load()
             dev = self.device
-            n, e = self.n_nodes, self.n_edges
+            n, e, ns = self.n_nodes, self.n_edges, self.n_src_rows
             with torch.cuda.device(dev):
                 # destination id of every CSR entry = its row index
                 counts = (self.rowptr[1:] - self.rowptr[:-1]).long()
                 dst = torch.repeat_interleave(torch.arange(n, device=dev), counts)
                 src = self.col[:e].long()
-                t_rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+                t_rowptr = torch.empty(ns + 1, dtype=torch.int32, device=dev)
                 t_col = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
                 t_eid = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
                 t_max = torch.empty(1, dtype=torch.int32, device=dev)
-                ws = torch.empty(max(lib.egc_coo_to_csr_workspace_bytes(n, e), 1), dtype=torch.uint8, device=dev)
+                ws = torch.empty(max(lib.egc_coo_to_csr_workspace_bytes(ns, e), 1), dtype=torch.uint8, device=dev)
                 # swap roles: "source" = dst (becomes the entry), "destination" = src (becomes the row)
-                _C.check(lib.egc_coo_to_csr(dst.data_ptr(), src.data_ptr(), e, n, t_rowptr.data_ptr(),
+                _C.check(lib.egc_coo_to_csr(dst.data_ptr(), src.data_ptr(), e, ns, t_rowptr.data_ptr(),
                                             t_col.data_ptr(), t_eid.data_ptr(), t_max.data_ptr(), ws.data_ptr(),
                                             ws.numel(), _stream_ptr(dev)), "egc_coo_to_csr(transposed)")
             self._transposed = (t_rowptr, t_col)
@@ -168,13 +170,13 @@ class SparseTensor:
     def __init__(self, row: torch.Tensor = None, col: torch.Tensor = None, value=None, sparse_sizes=None,
                  is_sorted: bool = False, rowptr: torch.Tensor = None):
         if sparse_sizes is None:
-            raise RuntimeError("egc_amd.SparseTensor: sparse_sizes=(N, N) is required")
+            raise RuntimeError("egc_amd.SparseTensor: sparse_sizes=(N_dst, N_src) is required")
         self._sizes = (int(sparse_sizes[0]), int(sparse_sizes[1]))
         if rowptr is not None:
-            self.graph = CSRGraph.from_csr(rowptr, col, self._sizes[0])
+            self.graph = CSRGraph.from_csr(rowptr, col, self._sizes[0], self._sizes[1])
         else:
             # row = destination, col = source  ->  edge_index = [col; row]
-            self.graph = CSRGraph.from_edge_index(torch.stack([col.long(), row.long()]), self._sizes[0])
+            self.graph = CSRGraph.from_edge_index(torch.stack([col.long(), row.long()]), self._sizes[0], self._sizes[1])
 
     def sparse_sizes(self):
         return self._sizes

@@ -1,0 +1,117 @@
+"""Relational EGC on the gfx950 kernels: ``REGConv`` (reference experiments/rmag/models.py:75-148).
+
+One shared basis matrix for every node type; per node type a "root" combination of the node's own bases;
+per relation (source type, name, target type) the ``mean`` and ``max`` of the source type's bases over the
+relation's rectangular adjacency, combined with weightings computed from the TARGET node's features and
+accumulated into the target type's output.  The sparse part of every term is the fused aggregate/combine
+kernel of this repository (``egc_aggregate_combine_f32`` through the C ABI): the root term runs it on an
+identity adjacency, a relation on its ``[N_target, N_source]`` CSR (``egc_graph.n_src_rows``).  The dense
+Linears are plain GEMMs (torch.matmul -> rocBLAS), as in the reference.
+
+Interface = the reference's: ``REGConv(in_channels, out_channels, num_heads, num_bases)``,
+``forward(x_dict, adj_t_dict)`` with ``adj_t_dict[(src, rel, dst)]`` an ``adj_t`` whose rows are targets
+(here ``egc_amd.SparseTensor`` / ``CSRGraph`` / ``torch.sparse_csr``); parameter names ``bases_weight``,
+``rel_combs.<src>_<rel>_<dst>.{weight,bias}``, ``root_combs.<type>.{weight,bias}`` (state dicts interchange).
+The node / edge type lists are the reference's module constants (rmag/models.py:10-26) and may be overridden.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _C
+from .functional import egc_aggregate_combine_apply, make_spec
+from .graph import CSRGraph, SparseTensor
+from .layers import glorot_
+
+NODE_TYPES = ["author", "field_of_study", "institution", "paper"]          # rmag/models.py:17
+EDGE_TYPES = [                                                             # rmag/models.py:18-26
+    ("author", "affiliated_with", "institution"),
+    ("institution", "to", "author"),
+    ("author", "writes", "paper"),
+    ("paper", "to", "author"),
+    ("paper", "cites", "paper"),
+    ("paper", "has_topic", "field_of_study"),
+    ("field_of_study", "to", "paper"),
+]
+
+
+def _as_graph(adj_t, n_dst: int, n_src: int) -> CSRGraph:
+    if isinstance(adj_t, CSRGraph):
+        g = adj_t
+    elif isinstance(adj_t, SparseTensor):
+        g = adj_t.graph
+    elif isinstance(adj_t, torch.Tensor) and adj_t.layout == torch.sparse_csr:
+        g = CSRGraph.from_csr(adj_t.crow_indices(), adj_t.col_indices(), n_dst, n_src)
+    else:
+        raise RuntimeError(f"egc_amd.REGConv: unsupported adjacency type {type(adj_t)}")
+    if g.n_nodes != n_dst or g.n_src_rows != n_src:
+        raise RuntimeError(f"egc_amd.REGConv: adjacency is [{g.n_nodes}, {g.n_src_rows}], features say [{n_dst}, {n_src}]")
+    return g
+
+
+class REGConv(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, num_heads: int, num_bases: int,
+                 node_types=None, edge_types=None):
+        super().__init__()
+        if out_channels % num_heads != 0:
+            raise ValueError("out_channels must be divisible by num_heads")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.num_heads, self.num_bases = num_heads, num_bases
+        self.node_types = list(NODE_TYPES if node_types is None else node_types)
+        self.edge_types = [tuple(k) for k in (EDGE_TYPES if edge_types is None else edge_types)]
+        self.bases_weight = nn.Parameter(torch.empty(in_channels, (out_channels // num_heads) * num_bases))
+        self.rel_combs = nn.ModuleDict({f"{k[0]}_{k[1]}_{k[2]}": nn.Linear(in_channels, 2 * num_heads * num_bases)
+                                        for k in self.edge_types})
+        self.root_combs = nn.ModuleDict({k: nn.Linear(in_channels, num_heads * num_bases) for k in self.node_types})
+        H, B = num_heads, num_bases
+        # the reference's relation weightings are [h][a][b] (stack of mean, max viewed as 2B rows,
+        # rmag/models.py:135-143); the kernels read [h][b][a]: permute the Linear's output rows
+        perm = torch.arange(H * 2 * B).view(H, 2, B).transpose(1, 2).reshape(-1)
+        self.register_buffer("_hba_rows", perm, persistent=False)
+        self._spec_root = make_spec(in_channels, out_channels, H, B, [_C.AGGR_SUM], _C.SET_RAW, _C.SET_RAW,
+                                    True, _C.LAYOUT_HBA, _C.ACT_NONE)
+        self._spec_rel = make_spec(in_channels, out_channels, H, B, [_C.AGGR_MEAN, _C.AGGR_MAX],
+                                   _C.SET_RAW, _C.SET_RAW, True, _C.LAYOUT_HBA, _C.ACT_NONE)
+        self._identity = {}
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        glorot_(self.bases_weight)
+        for lin in self.rel_combs.values():
+            lin.reset_parameters()
+        for lin in self.root_combs.values():
+            lin.reset_parameters()
+
+    def _identity_graph(self, n: int, device) -> CSRGraph:
+        key = (n, device)
+        g = self._identity.get(key)
+        if g is None:
+            g = CSRGraph.from_csr(torch.arange(n + 1, dtype=torch.int32, device=device),
+                                  torch.arange(n, dtype=torch.int32, device=device), n)
+            self._identity = {key: g} if len(self._identity) > 8 else {**self._identity, key: g}
+        return g
+
+    def forward(self, x_dict, adj_t_dict):
+        ldb = self._spec_root.ldb
+        f_g = self._spec_root.f_g
+        bases, out = {}, {}
+        for key, x in x_dict.items():
+            b = torch.matmul(x, self.bases_weight)                                   # rmag/models.py:113-115
+            bases[key] = b if ldb == f_g else F.pad(b, (0, ldb - f_g))
+            w_root = self.root_combs[key](x)                                         # [N, H*B] = [h][b] (A = 1)
+            out[key] = egc_aggregate_combine_apply(self._identity_graph(x.size(0), x.device), self._spec_root,
+                                                   bases[key].contiguous(), w_root.contiguous())  # :117-129
+        for key, adj_t in adj_t_dict.items():
+            src, _, dst = key
+            lin = self.rel_combs[f"{key[0]}_{key[1]}_{key[2]}"]
+            w_rel = F.linear(x_dict[dst], lin.weight[self._hba_rows], lin.bias[self._hba_rows])   # :141-143
+            g = _as_graph(adj_t, x_dict[dst].size(0), x_dict[src].size(0))
+            out[dst] = out[dst] + egc_aggregate_combine_apply(g, self._spec_rel, bases[src].contiguous(),
+                                                              w_rel.contiguous())    # :131-144
+        return out
+
+    def __repr__(self):
+        return (f"{self.__class__.__name__}({self.in_channels}, {self.out_channels}, num_heads={self.num_heads}, "
+                f"num_bases={self.num_bases})")

@@ -86,7 +86,9 @@ typedef struct {
                                  back, else -1: the launch is then sized for the plan's capacity */
   int64_t n_src_rows;         /* rows of the tables that `col` indexes (bases, dis_*): n_nodes on one GPU; in a
                                  vertex-partitioned run the owned rows come first and the halo rows received
-                                 from other ranks follow (n_src_rows >= n_nodes).  0 means n_nodes. */
+                                 from other ranks follow (n_src_rows >= n_nodes).  0 means n_nodes.  A rectangular
+                                 adjacency between two node types (relational EGC, rmag/models.py:131-134) may have
+                                 any n_src_rows > 0, with the RAW edge set and without symnorm. */
 } egc_graph;
 
 /* int32 words the caller must allocate for egc_graph.plan. */

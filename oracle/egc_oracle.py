@@ -347,3 +347,35 @@ def layer_param_count(f_in, f_out, num_heads, num_bases, num_aggrs, bias=True) -
     comb Linear (F_in*HBA + HBA) + B bases of F_in x (F_out/H) + bias."""
     hba = num_heads * num_bases * num_aggrs
     return f_in * hba + hba + num_bases * f_in * (f_out // num_heads) + (f_out if bias else 0)
+
+
+# ---------------------------------------------------------------------------------------------
+# relational EGC
+# ---------------------------------------------------------------------------------------------
+def regconv_forward(x_dict, adj_dict, bases_weight, rel_combs, root_combs, num_heads: int, num_bases: int):
+    """REGConv.forward (reference experiments/rmag/models.py:112-148), float32 numpy.
+
+    x_dict[type] = [N_type, F_in]; adj_dict[(src, rel, dst)] = int64 [2, E] with row 0 = SOURCE ids (columns of
+    the reference's adj_t) and row 1 = TARGET ids (rows of adj_t); rel_combs["src_rel_dst"] / root_combs[type]
+    = (weight [out, in], bias [out]) of the reference's Linears.  ``adj_t.matmul(x, reduce=...)`` is the
+    per-target-row reduction of x[source] (torch_sparse spmm), empty rows giving 0 (``scatter`` above)."""
+    H, B = num_heads, num_bases
+    f32 = np.float32
+    bases = {k: (x.astype(f32) @ bases_weight.astype(f32)) for k, x in x_dict.items()}            # :113-115
+    L = bases_weight.shape[1] // B
+    out = {}
+    for k, x in x_dict.items():                                                                    # :117-129
+        w, b = root_combs[k]
+        weightings = (x.astype(f32) @ w.astype(f32).T + b.astype(f32)).reshape(-1, H, B)
+        out[k] = np.matmul(weightings, bases[k].reshape(-1, B, L))                                 # [N, H, L]
+    for key, ei in adj_dict.items():                                                               # :131-144
+        src, _, dst = key
+        n_dst = x_dict[dst].shape[0]
+        gathered = bases[src][ei[0]]
+        mean, _ = scatter(gathered, ei[1], n_dst, "mean")
+        mx, _ = scatter(gathered, ei[1], n_dst, "max")
+        aggregated = np.stack([mean, mx], axis=1).reshape(-1, 2 * B, L)
+        w, b = rel_combs[f"{key[0]}_{key[1]}_{key[2]}"]
+        weightings = (x_dict[dst].astype(f32) @ w.astype(f32).T + b.astype(f32)).reshape(-1, H, 2 * B)
+        out[dst] = out[dst] + np.matmul(weightings, aggregated)
+    return {k: v.reshape(v.shape[0], -1).astype(f32) for k, v in out.items()}                       # :146-148

@@ -11,7 +11,25 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def golden_names():
-    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    """Single-layer fixtures (make_golden.py); the relational ones (make_golden_rel.py) are rel_*."""
+    names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    return [n for n in names if not n.startswith("rel_")]
+
+
+def rel_golden_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "rel_*.npz")))
+
+
+def load_rel_golden(name):
+    """-> dict(meta, x {type: array}, ei {(src, rel, dst): [2, E] (source ids, target ids)}, params, out)."""
+    z = np.load(os.path.join(GOLDEN_DIR, f"{name}.npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    edge_types = [tuple(k) for k in meta["edge_types"]]
+    return dict(name=name, meta=meta,
+                x={k: z[f"x_{k}"] for k in meta["node_types"]},
+                out={k: z[f"out_{k}"] for k in meta["node_types"]},
+                ei={k: z[f"ei_{i}"] for i, k in enumerate(edge_types)},
+                params={k[2:]: z[k] for k in z.files if k.startswith("p_")})
 
 
 def load_golden(name):

@@ -76,7 +76,7 @@ def test_zinc_net_forward_and_gradients_match_cpu_restatement(hidden, H, B, aggr
     def rel(a, b):
         return float((a.detach().cpu().double() - b.detach().double()).abs().max()) / max(1e-6, float(b.abs().max()))
 
-    scale = max(1.0, float(out_ref.abs().max()))
+    scale = max(1.0, float(out_ref.detach().abs().max()))
     assert float((out.detach().cpu().double() - out_ref.detach()).abs().max()) / scale <= 2e-4
     for got, want, cal in [
         (net.embedding.weight.grad, ref.embedding.weight.grad, ref32.embedding.weight.grad),
