@@ -123,10 +123,19 @@ __device__ inline void finish_row(const AggArgs& a, __amdgpu_buffer_rsrc_t rsrc,
   // (1) finalise every aggregator for this lane's slot(s) and park it in LDS as [A][ldb]
   const float cntf = (float)max(cnt, 1);
   if (g == 0) {
+    if (a.stats != nullptr && lane == 0) a.cnt_out[row] = cnt;
 #pragma unroll
     for (int k = 0; k < CHUNKS; ++k) {
       const int s = k * 64 + q;
       if (s < a.slots) {
+        if (a.stats != nullptr) {  // training forward: keep the raw aggregates for the backward
+          float* st = a.stats + ((int64_t)row * a.stat_k) * a.ldb + 4 * s;
+          if (a.stat_slot[STAT_SUM] >= 0) *reinterpret_cast<f4*>(st + a.stat_slot[STAT_SUM] * a.ldb) = acc.sum[k];
+          if (a.stat_slot[STAT_SQ] >= 0) *reinterpret_cast<f4*>(st + a.stat_slot[STAT_SQ] * a.ldb) = acc.sq[k];
+          if (a.stat_slot[STAT_MX] >= 0) *reinterpret_cast<f4*>(st + a.stat_slot[STAT_MX] * a.ldb) = acc.mx[k];
+          if (a.stat_slot[STAT_MN] >= 0) *reinterpret_cast<f4*>(st + a.stat_slot[STAT_MN] * a.ldb) = acc.mn[k];
+          if (a.stat_slot[STAT_WS] >= 0) *reinterpret_cast<f4*>(st + a.stat_slot[STAT_WS] * a.ldb) = acc.ws[k];
+        }
         const f4 mean = f4_div(acc.sum[k], cntf);
         const f4 var = f4_var(f4_div(acc.sq[k], cntf), mean);
         const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
@@ -370,14 +379,43 @@ size_t egc_aggregate_workspace_bytes(const egc_layer* layer, int64_t n_nodes, in
   return ws_layout(layer, n_nodes, n_edges).total;
 }
 
+int64_t egc_train_stats_floats(const egc_layer* layer) {
+  if (validate_layer(layer) != EGC_OK) return 0;
+  int slot[5];
+  return (int64_t)stat_layout(layer->aggrs, layer->num_aggrs, slot) * egc_bases_ld(layer);
+}
+
+static int aggregate_combine_impl(const egc_graph* graph, const egc_layer* layer, const float* bases, int32_t ldb,
+                                  const float* weightings, const float* bias, float* out, float* stats,
+                                  int32_t* cnt_out, void* workspace, size_t workspace_bytes, egc_stream_t stream_);
+
 int egc_aggregate_combine_f32(const egc_graph* graph, const egc_layer* layer, const float* bases, int32_t ldb,
                               const float* weightings, const float* bias, float* out, int32_t* arg_max,
-                              int32_t* arg_min, void* workspace, size_t workspace_bytes, egc_stream_t stream_) {
+                              int32_t* arg_min, void* workspace, size_t workspace_bytes, egc_stream_t stream) {
+  // the arg-extremum indices need the extrema themselves: egc_aggregate_combine_train_f32 keeps them
+  if (arg_max != nullptr || arg_min != nullptr) return EGC_ERR_UNSUPPORTED;
+  return aggregate_combine_impl(graph, layer, bases, ldb, weightings, bias, out, nullptr, nullptr, workspace,
+                                workspace_bytes, stream);
+}
+
+int egc_aggregate_combine_train_f32(const egc_graph* graph, const egc_layer* layer, const float* bases, int32_t ldb,
+                                    const float* weightings, const float* bias, float* out, float* stats,
+                                    int32_t* cnt, int32_t* arg_max, int32_t* arg_min, void* workspace,
+                                    size_t workspace_bytes, egc_stream_t stream) {
+  if (graph == nullptr || layer == nullptr || stats == nullptr || cnt == nullptr) return EGC_ERR_INVALID;
+  int st = aggregate_combine_impl(graph, layer, bases, ldb, weightings, bias, out, stats, cnt, workspace,
+                                  workspace_bytes, stream);
+  if (st != EGC_OK) return st;
+  return egc::arg_extrema(graph, layer, bases, ldb, stats, cnt, arg_max, arg_min, (hipStream_t)stream);
+}
+
+static int aggregate_combine_impl(const egc_graph* graph, const egc_layer* layer, const float* bases, int32_t ldb,
+                                  const float* weightings, const float* bias, float* out, float* stats,
+                                  int32_t* cnt_out, void* workspace, size_t workspace_bytes, egc_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (graph == nullptr) return EGC_ERR_INVALID;
   int st = validate_layer(layer);
   if (st != EGC_OK) return st;
-  if (arg_max != nullptr || arg_min != nullptr) return EGC_ERR_UNSUPPORTED;
   const int64_t n = graph->n_nodes, e = graph->n_edges;
   if (n < 0 || e < 0 || n >= ((int64_t)1 << 31) - 1 || e >= ((int64_t)1 << 31) - 1) return EGC_ERR_INVALID;
   if (n == 0) return EGC_OK;
@@ -423,6 +461,9 @@ int egc_aggregate_combine_f32(const egc_graph* graph, const egc_layer* layer, co
   a.act = layer->weight_act;
   a.magic_L = a.L > 1 ? (unsigned)(((uint64_t)1 << 32) / (uint64_t)a.L) + 1u : 0u;  // L == 1: h = o in-kernel
   a.bases_bytes = (unsigned)((uint64_t)n_src * ldb * 4ull);
+  a.stats = stats;
+  a.cnt_out = cnt_out;
+  a.stat_k = stat_layout(a.aggr, a.A, a.stat_slot);
 
   int chunks = 1;
   if (a.slots <= 64) {

@@ -48,7 +48,33 @@ struct AggArgs {
   int need_mean, need_var;
   int n_chunks_hint;       // host-known number of long-row chunks, or -1 (launch for the capacity)
   int w_lds_stride;        // floats between the per-group weight strips in LDS
+  // training forward only (egc_aggregate_combine_train_f32): the row's raw running aggregates, after the
+  // self-loop term, as [n_nodes][stat_k][ldb], and its entry count -- what the backward needs instead of a
+  // second gather.  stat_slot[s] = position of statistic s (STAT_*) inside a row's block, or -1.
+  float* stats;
+  int* cnt_out;
+  int stat_slot[5];
+  int stat_k;
 };
+
+enum { STAT_SUM = 0, STAT_SQ = 1, STAT_MX = 2, STAT_MN = 3, STAT_WS = 4 };
+
+// Which raw statistics a layer's aggregator list needs (shared by the forward store and the backward load).
+static inline int stat_layout(const int* aggr, int A, int (&slot)[5]) {
+  bool need[5] = {false, false, false, false, false};
+  for (int t = 0; t < A; ++t) {
+    switch (aggr[t]) {
+      case EGC_AGGR_SUM: case EGC_AGGR_MEAN: need[STAT_SUM] = true; break;
+      case EGC_AGGR_VAR: case EGC_AGGR_STD: need[STAT_SUM] = need[STAT_SQ] = true; break;
+      case EGC_AGGR_MAX: need[STAT_MX] = true; break;
+      case EGC_AGGR_MIN: need[STAT_MN] = true; break;
+      default: need[STAT_WS] = true; break;
+    }
+  }
+  int k = 0;
+  for (int s = 0; s < 5; ++s) slot[s] = need[s] ? k++ : -1;
+  return k;
+}
 
 template <int CHUNKS>
 struct Acc {

@@ -259,6 +259,17 @@ __device__ inline void finish_group(const AggArgs& a, const FastRsrc& R, int lan
   } else if (C::yl(a)) {
     acc.ws = f4_fma(splat(dis_i * dis_i), vself, acc.ws);
   }
+  if (a.stats != nullptr && store && row_ok) {  // training forward: keep the raw aggregates for the backward
+    float* st = a.stats + ((int64_t)row * a.stat_k) * a.ldb + 4 * q;
+    if (a.stat_slot[STAT_SUM] >= 0) *reinterpret_cast<f4*>(st + a.stat_slot[STAT_SUM] * a.ldb) = acc.sum;
+    if (a.stat_slot[STAT_MX] >= 0) *reinterpret_cast<f4*>(st + a.stat_slot[STAT_MX] * a.ldb) = acc.mx;
+    if (a.stat_slot[STAT_WS] >= 0) *reinterpret_cast<f4*>(st + a.stat_slot[STAT_WS] * a.ldb) = acc.ws;
+    if constexpr (NEED & NEED_SQ)
+      if (a.stat_slot[STAT_SQ] >= 0) *reinterpret_cast<f4*>(st + a.stat_slot[STAT_SQ] * a.ldb) = acc.sq;
+    if constexpr (NEED & NEED_MN)
+      if (a.stat_slot[STAT_MN] >= 0) *reinterpret_cast<f4*>(st + a.stat_slot[STAT_MN] * a.ldb) = acc.mn;
+    if (q == 0) a.cnt_out[row] = cnt;
+  }
   const float cntf = (float)max(cnt, 1);
   const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
   f4 mean = zero, var = zero;

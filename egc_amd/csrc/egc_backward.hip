@@ -2,8 +2,7 @@
 // derives it implicitly through experiments/layers.py:103-138 / optimized_layers.py:186-208 (gather ->
 // scatter per aggregator -> stack -> weighted sum).  SURVEY.md 8(f) rank 1.
 //
-// Given g = dL/d out [N, F_out], per destination row i with aggregates agg_a (recomputed by re-gathering,
-// nothing but `bases` and the pre-activation `weightings` is kept from the forward):
+// Given g = dL/d out [N, F_out], per destination row i with aggregates agg_a:
 //   d w'[h,b,a] = sum_l g[h,l] * agg_a[b,l]                (then through the weight nonlinearity)
 //   d agg_a[b,l] = sum_h w'[h,b,a] * g[h,l]
 // and per source row j (all aggregators that are linear in the messages collapse into three
@@ -15,43 +14,159 @@
 //   max / min: the gradient goes to the FIRST entry (input order; the self-loop of a LOOPED set is last)
 //   attaining the extremum -- torch_scatter's arg semantics -- with one float atomic per (row, column).
 //
-// Two launches: `bwd_dst_kernel` (one wavefront per destination row, lane = basis column) and
-// `bwd_src_kernel` (one wavefront per source row over the transposed CSR).  Written for generality and
-// correctness first (any H, B, L, A; all nonlinearities); it is not yet tuned like the forward.
+// Nothing is gathered twice: the training forward (egc_aggregate_combine_train_f32) keeps every row's raw
+// running aggregates (`stats`, `cnt`), so the destination side is ROW-LOCAL, and the source side is a sum-only
+// SpMM of the tables over the transposed CSR.  Three kernels:
+//   arg_extrema_kernel   (part of the training forward, only with max / min): entry-parallel, compares each
+//                        gathered slot with the row's extremum and keeps the smallest CSR position (atomicMin)
+//   bwd_dst_kernel       one wavefront per destination row, lane = basis column: d w', tables T/S/V, and the
+//                        max/min gradients as float atomics into d_bases
+//   bwd_src_kernel       lane group per source row (several rows per wavefront, FU loads in flight); rows
+//                        longer than EGC_LONG_ROW_THRESHOLD are cut into chunks (plan of the transposed graph)
+//                        whose partial sums arrive by float atomics
+// Any H, B, L, A and every weight nonlinearity; deterministic except for the order of float atomics on hub rows.
 #include "egc_aggregate_dev.h"
 
 namespace egc {
 
-struct BwdArgs {
-  // destination-side graph
+constexpr int ARG_INIT = 0x7f7f7f7f;  // memset pattern of the arg buffers: "no entry found yet"
+
+// ---------------------------------------------------------------------------------------------
+// arg-extrema (training forward)
+// ---------------------------------------------------------------------------------------------
+struct ArgArgs {
   const int* rowptr;
   const int* col;
-  const float* dis;       // deg^-1/2 of the symnorm edge set or nullptr
+  const float* bases;
+  const float* stats;
+  int* arg_max;
+  int* arg_min;
+  int n_nodes, n_edges;
+  int ldb, slots, lpr_log2, stat_k, slot_mx, slot_mn;
+  int x_looped;
+  unsigned bases_bytes;
+};
+
+// One wavefront per 64 consecutive CSR entries; a lane group of 2^lpr_log2 lanes compares one entry's basis
+// row (16 bytes per lane) with its destination row's extrema.
+__global__ void __launch_bounds__(256) arg_extrema_kernel(ArgArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+  if (base >= a.n_edges) return;
+  const int p = base + lane;
+  const bool pv = p < a.n_edges;
+  const int jj = pv ? a.col[p] : 0;
+  int lo = 0, hi = a.n_nodes;  // largest i with rowptr[i] <= p
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (a.rowptr[mid] <= (pv ? p : 0)) lo = mid; else hi = mid;
+  }
+  const int ii = lo;
+  const int LPR = 1 << a.lpr_log2, G = 64 >> a.lpr_log2;
+  const int g = lane >> a.lpr_log2, q = lane & (LPR - 1);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)a.bases, 0, a.bases_bytes, 0x00020000);
+  const int cnt = min(64, a.n_edges - base);
+  for (int t0 = 0; t0 < cnt; t0 += G) {  // wave-uniform trip count: every lane takes part in the shuffles
+    const int t = t0 + g;
+    const int j = __shfl(jj, t & 63), i = __shfl(ii, t & 63);
+    if (t >= cnt) continue;
+    if (a.x_looped && j == i) continue;  // excluded from the LOOPED set; its self-loop is appended LAST
+    for (int s = q; s < a.slots; s += LPR) {
+      const f4 v = load_slot(rb, (unsigned)j * (unsigned)a.ldb * 4u + (unsigned)s * 16u);
+      const float* st = a.stats + ((int64_t)i * a.stat_k) * a.ldb + 4 * s;
+      const int o = i * a.ldb + 4 * s;
+      if (a.arg_max != nullptr) {
+        const f4 m = *reinterpret_cast<const f4*>(st + a.slot_mx * a.ldb);
+        if (v.x == m.x) atomicMin(&a.arg_max[o], base + t);
+        if (v.y == m.y) atomicMin(&a.arg_max[o + 1], base + t);
+        if (v.z == m.z) atomicMin(&a.arg_max[o + 2], base + t);
+        if (v.w == m.w) atomicMin(&a.arg_max[o + 3], base + t);
+      }
+      if (a.arg_min != nullptr) {
+        const f4 m = *reinterpret_cast<const f4*>(st + a.slot_mn * a.ldb);
+        if (v.x == m.x) atomicMin(&a.arg_min[o], base + t);
+        if (v.y == m.y) atomicMin(&a.arg_min[o + 1], base + t);
+        if (v.z == m.z) atomicMin(&a.arg_min[o + 2], base + t);
+        if (v.w == m.w) atomicMin(&a.arg_min[o + 3], base + t);
+      }
+    }
+  }
+}
+
+// ARG_INIT -> n_edges (the appended self-loop attains the extremum) or -1 (empty row)
+__global__ void __launch_bounds__(256) arg_finalize_kernel(int* arg, const int* cnt, int64_t total, int ldb, int n_edges) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= total) return;
+  if (arg[k] == ARG_INIT) arg[k] = cnt[k / ldb] > 0 ? n_edges : -1;
+}
+
+int arg_extrema(const egc_graph* graph, const egc_layer* layer, const float* bases, int32_t ldb, const float* stats,
+                const int32_t* cnt, int32_t* arg_max, int32_t* arg_min, hipStream_t stream) {
+  int slot[5];
+  const int k = stat_layout(layer->aggrs, layer->num_aggrs, slot);
+  if (slot[STAT_MX] < 0) arg_max = nullptr;
+  if (slot[STAT_MN] < 0) arg_min = nullptr;
+  if (arg_max == nullptr && arg_min == nullptr) return EGC_OK;
+  const int64_t n = graph->n_nodes, e = graph->n_edges;
+  if (n == 0) return EGC_OK;
+  const size_t bytes = (size_t)n * ldb * sizeof(int32_t);
+  if (arg_max != nullptr) EGC_HIP_TRY(hipMemsetAsync(arg_max, 0x7f, bytes, stream));
+  if (arg_min != nullptr) EGC_HIP_TRY(hipMemsetAsync(arg_min, 0x7f, bytes, stream));
+  const int64_t n_src = graph->n_src_rows > 0 ? graph->n_src_rows : n;
+  ArgArgs a;
+  a.rowptr = graph->rowptr; a.col = graph->col; a.bases = bases; a.stats = stats;
+  a.arg_max = arg_max; a.arg_min = arg_min;
+  a.n_nodes = (int)n; a.n_edges = (int)e;
+  a.ldb = ldb; a.slots = ldb / 4; a.stat_k = k; a.slot_mx = slot[STAT_MX]; a.slot_mn = slot[STAT_MN];
+  a.x_looped = layer->agg_set == EGC_SET_LOOPED;
+  a.bases_bytes = (unsigned)((uint64_t)n_src * ldb * 4ull);
+  int lg = 0;
+  while ((1 << lg) < a.slots && lg < 6) ++lg;
+  a.lpr_log2 = lg;
+  if (e > 0) {
+    arg_extrema_kernel<<<(unsigned)ceil_div(e, 256), 256, 0, stream>>>(a);
+    EGC_LAUNCH_CHECK("arg_extrema_kernel");
+  }
+  const int64_t total = n * ldb;
+  if (arg_max != nullptr) arg_finalize_kernel<<<(unsigned)ceil_div(total, 256), 256, 0, stream>>>(arg_max, cnt, total, ldb, (int)e);
+  if (arg_min != nullptr) arg_finalize_kernel<<<(unsigned)ceil_div(total, 256), 256, 0, stream>>>(arg_min, cnt, total, ldb, (int)e);
+  EGC_LAUNCH_CHECK("arg_finalize_kernel");
+  return EGC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------
+struct BwdArgs {
+  const int* col;            // destination-side CSR entries (arg positions -> source ids)
+  const float* dis;          // deg^-1/2 of the symnorm edge set or nullptr
   const int* max_index;
-  // transposed graph (rows = sources, entries = destinations)
+  // transposed graph (rows = sources, entries = destinations) with its own long-row plan
   const int* t_rowptr;
   const int* t_col;
+  const int* t_plan;
   const float* bases;        // [n_src_rows, ldb]
   const float* weightings;   // [N, W] pre-activation
   const float* grad_out;     // [N, F_out]
+  const float* stats;        // [N, stat_k, ldb] raw aggregates of the forward
+  const int* cnt;            // [N] entries of the row's aggregation set
+  const int* arg_max;        // [N, ldb] CSR position / n_edges (self loop) / -1, or nullptr
+  const int* arg_min;
   float* d_bases;            // [n_src_rows, ldb]  (zero-initialised by the host)
   float* d_weightings;       // [N, W]
   float* tab_t;              // [N, ldb]
   float* tab_s;              // [N, ldb] or nullptr
   float* tab_v;              // [N, ldb] or nullptr
-  int n_nodes, n_src_rows;
-  int ldb, F_g, F_out, W, H, B, A, L;
+  int n_nodes, n_src_rows, n_edges;
+  int ldb, slots, F_g, F_out, W, H, B, A, L;
   int aggr[EGC_MAX_AGGRS];
+  int stat_slot[5], stat_k;
   int x_looped, y_looped, loops_all;
   int act;
   int lds_floats_per_wave;
+  int lpr_log2, chunk_blocks;
+  unsigned tab_bytes;
 };
-
-__device__ inline float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-  return v;
-}
 
 // One wavefront per destination row.  LDS per wavefront: agg [A][ldb], g [F_out], w' [W], d w' [W].
 __global__ void __launch_bounds__(256) bwd_dst_kernel(BwdArgs a) {
@@ -64,11 +179,6 @@ __global__ void __launch_bounds__(256) bwd_dst_kernel(BwdArgs a) {
   float* lds_g = lds_agg + a.A * a.ldb;
   float* lds_w = lds_g + ((a.F_out + 3) & ~3);
   float* lds_dagg = lds_w + ((a.W + 3) & ~3);  // d w' scratch [W]
-
-  const int start = a.rowptr[row], end = a.rowptr[row + 1];
-  const bool xl = a.x_looped != 0, yl = a.y_looped != 0;
-  const int nloop = a.loops_all ? a.n_nodes : (*a.max_index + 1);
-  const bool has_self = row < nloop;
   const float dis_i = a.dis != nullptr ? a.dis[row] : 0.f;
   const int AB = a.A * a.B;
 
@@ -93,81 +203,60 @@ __global__ void __launch_bounds__(256) bwd_dst_kernel(BwdArgs a) {
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
-  // count of self entries (excluded from LOOPED sets)
-  int nself = 0;
-  if (xl || yl) {
-    for (int p = start + lane; p < end; p += 64) nself += (a.col[p] == row);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) nself += __shfl_xor(nself, off);
-  }
-  const int deg = end - start;
-  const int cnt = xl ? deg - nself + (has_self ? 1 : 0) : deg;
+  const int cnt = a.cnt[row];
   const float cntf = (float)max(cnt, 1);
-
+  const float* st = a.stats + ((int64_t)row * a.stat_k) * a.ldb;
   for (int c0 = 0; c0 < a.F_g; c0 += 64) {
     const int c = c0 + lane;
-    const bool cv = c < a.F_g;
-    // ---- re-gather: aggregates of this column + first-attaining sources for max / min
-    float sum = 0.f, sq = 0.f, ws = 0.f, mx = -INFINITY, mn = INFINITY;
-    int amx = -1, amn = -1;
-    for (int p = start; p < end; ++p) {
-      const int j = a.col[p];
-      const bool is_self = j == row;
-      const float v = cv ? a.bases[(int64_t)j * a.ldb + c] : 0.f;
-      if (!(xl && is_self)) {
-        sum += v;
-        sq += __fmul_rn(v, v);
-        if (v > mx) { mx = v; amx = j; }
-        if (v < mn) { mn = v; amn = j; }
-      }
-      if (!(yl && is_self) && a.dis != nullptr) ws = fmaf(a.dis[j] * dis_i, v, ws);
-    }
-    const float vself = cv ? a.bases[(int64_t)row * a.ldb + c] : 0.f;
-    if (xl && has_self) {
-      sum += vself;
-      sq += __fmul_rn(vself, vself);
-      if (vself > mx) { mx = vself; amx = row; }
-      if (vself < mn) { mn = vself; amn = row; }
-    }
-    if (yl && has_self) ws = fmaf(dis_i * dis_i, vself, ws);
+    if (c >= a.F_g) continue;
+    const float sum = a.stat_slot[STAT_SUM] >= 0 ? st[a.stat_slot[STAT_SUM] * a.ldb + c] : 0.f;
+    const float sq = a.stat_slot[STAT_SQ] >= 0 ? st[a.stat_slot[STAT_SQ] * a.ldb + c] : 0.f;
+    const float mx = a.stat_slot[STAT_MX] >= 0 ? st[a.stat_slot[STAT_MX] * a.ldb + c] : 0.f;
+    const float mn = a.stat_slot[STAT_MN] >= 0 ? st[a.stat_slot[STAT_MN] * a.ldb + c] : 0.f;
+    const float ws = a.stat_slot[STAT_WS] >= 0 ? st[a.stat_slot[STAT_WS] * a.ldb + c] : 0.f;
     const float mean = sum / cntf;
     const float var = __fsub_rn(sq / cntf, __fmul_rn(mean, mean));
     const float sd = sqrtf(fmaxf(var, 0.f) + 1e-5f);
-    if (cv) {
-      for (int t = 0; t < a.A; ++t) {
-        float val;
-        switch (a.aggr[t]) {
-          case EGC_AGGR_SUM: val = sum; break;
-          case EGC_AGGR_MEAN: val = mean; break;
-          case EGC_AGGR_MAX: val = cnt > 0 ? mx : 0.f; break;
-          case EGC_AGGR_MIN: val = cnt > 0 ? mn : 0.f; break;
-          case EGC_AGGR_VAR: val = var; break;
-          case EGC_AGGR_STD: val = sd; break;
-          default: val = ws; break;
-        }
-        lds_agg[t * a.ldb + c] = val;
+    for (int t = 0; t < a.A; ++t) {
+      float val;
+      switch (a.aggr[t]) {
+        case EGC_AGGR_SUM: val = sum; break;
+        case EGC_AGGR_MEAN: val = mean; break;
+        case EGC_AGGR_MAX: val = cnt > 0 ? mx : 0.f; break;
+        case EGC_AGGR_MIN: val = cnt > 0 ? mn : 0.f; break;
+        case EGC_AGGR_VAR: val = var; break;
+        case EGC_AGGR_STD: val = sd; break;
+        default: val = ws; break;
       }
-      // d agg_t[c] = sum_h w'[h][b][t] * g[h*L + l]
-      const int b = c / a.L, l = c - b * a.L;
-      float d_t = 0.f, d_s = 0.f, d_v = 0.f;
-      for (int t = 0; t < a.A; ++t) {
-        float d = 0.f;
-        for (int h = 0; h < a.H; ++h) d = fmaf(lds_w[h * AB + b * a.A + t], lds_g[h * a.L + l], d);
-        switch (a.aggr[t]) {
-          case EGC_AGGR_SUM: d_t += d; break;
-          case EGC_AGGR_MEAN: d_t += d / cntf; break;
-          case EGC_AGGR_MAX: if (cnt > 0 && amx >= 0) atomicAdd(&a.d_bases[(int64_t)amx * a.ldb + c], d); break;
-          case EGC_AGGR_MIN: if (cnt > 0 && amn >= 0) atomicAdd(&a.d_bases[(int64_t)amn * a.ldb + c], d); break;
-          case EGC_AGGR_VAR: d_v += d; break;
-          case EGC_AGGR_STD: d_v += (var > 0.f) ? d / (2.0f * sd) : 0.f; break;
-          default: d_s += d * dis_i; break;
-        }
-      }
-      // var = E[x^2] - mean^2:  d/dx_j = 2 (x_j - mean) / cnt
-      a.tab_t[(int64_t)row * a.ldb + c] = d_t - 2.0f * mean * d_v / cntf;
-      if (a.tab_s != nullptr) a.tab_s[(int64_t)row * a.ldb + c] = d_s;
-      if (a.tab_v != nullptr) a.tab_v[(int64_t)row * a.ldb + c] = 2.0f * d_v / cntf;
+      lds_agg[t * a.ldb + c] = val;
     }
+    // d agg_t[c] = sum_h w'[h][b][t] * g[h*L + l]
+    const int b = c / a.L, l = c - b * a.L;
+    float d_t = 0.f, d_s = 0.f, d_v = 0.f;
+    for (int t = 0; t < a.A; ++t) {
+      float d = 0.f;
+      for (int h = 0; h < a.H; ++h) d = fmaf(lds_w[h * AB + b * a.A + t], lds_g[h * a.L + l], d);
+      switch (a.aggr[t]) {
+        case EGC_AGGR_SUM: d_t += d; break;
+        case EGC_AGGR_MEAN: d_t += d / cntf; break;
+        case EGC_AGGR_MAX:
+        case EGC_AGGR_MIN: {
+          const int pos = (a.aggr[t] == EGC_AGGR_MAX ? a.arg_max : a.arg_min)[(int64_t)row * a.ldb + c];
+          if (cnt > 0 && pos >= 0) {
+            const int j = pos < a.n_edges ? a.col[pos] : row;  // n_edges: the appended self-loop
+            atomicAdd(&a.d_bases[(int64_t)j * a.ldb + c], d);
+          }
+          break;
+        }
+        case EGC_AGGR_VAR: d_v += d; break;
+        case EGC_AGGR_STD: d_v += (var > 0.f) ? d / (2.0f * sd) : 0.f; break;
+        default: d_s += d * dis_i; break;
+      }
+    }
+    // var = E[x^2] - mean^2:  d/dx_j = 2 (x_j - mean) / cnt
+    a.tab_t[(int64_t)row * a.ldb + c] = d_t - 2.0f * mean * d_v / cntf;
+    if (a.tab_s != nullptr) a.tab_s[(int64_t)row * a.ldb + c] = d_s;
+    if (a.tab_v != nullptr) a.tab_v[(int64_t)row * a.ldb + c] = 2.0f * d_v / cntf;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
@@ -176,7 +265,7 @@ __global__ void __launch_bounds__(256) bwd_dst_kernel(BwdArgs a) {
     const int h = k / AB, r = k - h * AB, b = r / a.A, t = r - b * a.A;
     float d = 0.f;
     for (int l = 0; l < a.L; ++l) d = fmaf(lds_g[h * a.L + l], lds_agg[t * a.ldb + b * a.L + l], d);
-    lds_dagg[k] = d;  // re-used as scratch for d w'
+    lds_dagg[k] = d;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   for (int k = lane; k < a.W; k += 64) {
@@ -196,37 +285,121 @@ __global__ void __launch_bounds__(256) bwd_dst_kernel(BwdArgs a) {
   }
 }
 
-// One wavefront per source row j: d bases[j] += sum over out-neighbours of the tables (+ self-loop terms).
+// Sum of the destination tables over one source row's out-entries [start, end), entries t, t + step, ...:
+// lane q of the group holds slot(s) q, q + LPR, ... (NS of them).
+constexpr int BWD_FU = 4;
+template <int NS>
+__device__ inline void sum_tables(const BwdArgs& a, const __amdgpu_buffer_rsrc_t (&rt)[3], int row, int start, int end,
+                                  int first, int step, int q, int LPR, bool xl, bool yl, f4 (&at)[NS], f4 (&as)[NS],
+                                  f4 (&av)[NS]) {
+  for (int p0 = start + first; p0 < end; p0 += step * BWD_FU) {
+    int dst[BWD_FU];
+#pragma unroll
+    for (int u = 0; u < BWD_FU; ++u) {
+      const int p = p0 + u * step;
+      dst[u] = p < end ? a.t_col[p] : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      const int s = q + k * LPR;
+      f4 vt[BWD_FU], vs[BWD_FU], vv[BWD_FU];
+#pragma unroll
+      for (int u = 0; u < BWD_FU; ++u) {
+        const bool live = dst[u] >= 0 && s < a.slots;
+        const bool is_self = dst[u] == row;
+        const unsigned off = (unsigned)dst[u] * (unsigned)a.ldb * 4u + (unsigned)s * 16u;
+        vt[u] = load_slot(rt[0], (live && !(xl && is_self)) ? off : OOB);
+        if (a.tab_v != nullptr) vv[u] = load_slot(rt[2], (live && !(xl && is_self)) ? off : OOB);
+        if (a.tab_s != nullptr) vs[u] = load_slot(rt[1], (live && !(yl && is_self)) ? off : OOB);
+      }
+#pragma unroll
+      for (int u = 0; u < BWD_FU; ++u) {
+        at[k] += vt[u];
+        if (a.tab_v != nullptr) av[k] += vv[u];
+        if (a.tab_s != nullptr) as[k] += vs[u];
+      }
+    }
+  }
+}
+
+// d bases[j] += sum over out-neighbours of the tables (+ self-loop terms).  Leading blocks: one wavefront per
+// 128-entry chunk of a long row, partial sums by float atomics; the other blocks: one lane group per short row.
+template <int NS>
 __global__ void __launch_bounds__(256) bwd_src_kernel(BwdArgs a) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (row >= a.n_src_rows) return;
-  const bool owned = row < a.n_nodes;
-  const int start = a.t_rowptr[row], end = a.t_rowptr[row + 1];
+  const int wave = threadIdx.x >> 6;
+  const int LPR = 1 << a.lpr_log2, G = 64 >> a.lpr_log2;
+  const int g = lane >> a.lpr_log2, q = lane & (LPR - 1);
   const bool xl = a.x_looped != 0, yl = a.y_looped != 0;
   const int nloop = a.loops_all ? a.n_nodes : (*a.max_index + 1);
-  const bool has_self = owned && row < nloop;
-  const float dis_j = a.dis != nullptr ? a.dis[row] : 0.f;
-  for (int c0 = 0; c0 < a.F_g; c0 += 64) {
-    const int c = c0 + lane;
-    if (c >= a.F_g) continue;
-    float st = 0.f, ss = 0.f, sv = 0.f;
-    for (int p = start; p < end; ++p) {
-      const int i = a.t_col[p];
-      const bool is_self = i == row;
-      if (!(xl && is_self)) {
-        st += a.tab_t[(int64_t)i * a.ldb + c];
-        if (a.tab_v != nullptr) sv += a.tab_v[(int64_t)i * a.ldb + c];
+  __amdgpu_buffer_rsrc_t rt[3];
+  rt[0] = __builtin_amdgcn_make_buffer_rsrc((void*)a.tab_t, 0, a.tab_bytes, 0x00020000);
+  rt[1] = __builtin_amdgcn_make_buffer_rsrc((void*)(a.tab_s != nullptr ? a.tab_s : a.tab_t), 0, a.tab_bytes, 0x00020000);
+  rt[2] = __builtin_amdgcn_make_buffer_rsrc((void*)(a.tab_v != nullptr ? a.tab_v : a.tab_t), 0, a.tab_bytes, 0x00020000);
+  const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
+
+  int row, start, end, first, step;
+  bool add_self, atomic;
+  if ((int)blockIdx.x < a.chunk_blocks) {
+    const int c = blockIdx.x * 4 + wave;
+    if (c >= a.t_plan[1]) return;
+    const int cap_long = a.t_plan[2], cap_chunks = a.t_plan[3];
+    const int* long_row = a.t_plan + 4;
+    const int* chunk_slot = long_row + 2 * cap_long;
+    const int* chunk_begin = chunk_slot + cap_chunks;
+    row = long_row[chunk_slot[c]];
+    start = chunk_begin[c];
+    end = min(start + EGC_LONG_ROW_CHUNK, a.t_rowptr[row + 1]);
+    first = g; step = G;
+    add_self = start == a.t_rowptr[row];  // the row's first chunk also carries the self-loop terms
+    atomic = true;
+  } else {
+    row = (((int)blockIdx.x - a.chunk_blocks) * 4 + wave) * G + g;
+    if (row >= a.n_src_rows) { row = -1; start = end = 0; } else { start = a.t_rowptr[row]; end = a.t_rowptr[row + 1]; }
+    // long rows belong to the chunk blocks: this group must not even read-modify-write their d_bases row
+    if (end - start > EGC_LONG_ROW_THRESHOLD) { row = -1; start = end = 0; }
+    first = 0; step = 1;
+    add_self = true;
+    atomic = false;
+  }
+  f4 at[NS], as[NS], av[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) at[k] = as[k] = av[k] = zero;
+  sum_tables<NS>(a, rt, row, start, end, first, step, q, LPR, xl, yl, at, as, av);
+  if (atomic) {  // merge the G groups of the chunk
+    for (int off = LPR; off < 64; off <<= 1) {
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        at[k] += f4_shfl_xor(at[k], off);
+        as[k] += f4_shfl_xor(as[k], off);
+        av[k] += f4_shfl_xor(av[k], off);
       }
-      if (a.tab_s != nullptr && !(yl && is_self)) ss += a.tab_s[(int64_t)i * a.ldb + c];
     }
+    if (g != 0) return;
+  }
+  if (row < 0) return;
+  const bool has_self = add_self && row < a.n_nodes && row < nloop;
+  const float dis_j = a.dis != nullptr ? a.dis[row] : 0.f;
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const int s = q + k * LPR;
+    if (s >= a.slots) continue;
+    const int64_t o = (int64_t)row * a.ldb + 4 * s;
+    f4 t = at[k], sv = as[k], vv = av[k];
     if (xl && has_self) {
-      st += a.tab_t[(int64_t)row * a.ldb + c];
-      if (a.tab_v != nullptr) sv += a.tab_v[(int64_t)row * a.ldb + c];
+      t += *reinterpret_cast<const f4*>(a.tab_t + o);
+      if (a.tab_v != nullptr) vv += *reinterpret_cast<const f4*>(a.tab_v + o);
     }
-    if (yl && has_self && a.tab_s != nullptr) ss += a.tab_s[(int64_t)row * a.ldb + c];
-    const float own = a.bases[(int64_t)row * a.ldb + c];
-    a.d_bases[(int64_t)row * a.ldb + c] += st + dis_j * ss + own * sv;
+    if (yl && has_self && a.tab_s != nullptr) sv += *reinterpret_cast<const f4*>(a.tab_s + o);
+    f4 d = t;
+    if (a.tab_s != nullptr) d = f4_fma(f4{dis_j, dis_j, dis_j, dis_j}, sv, d);
+    if (a.tab_v != nullptr) d = f4_fma(*reinterpret_cast<const f4*>(a.bases + o), vv, d);
+    float* dst = a.d_bases + o;
+    if (atomic) {
+      atomicAdd(dst, d.x); atomicAdd(dst + 1, d.y); atomicAdd(dst + 2, d.z); atomicAdd(dst + 3, d.w);
+    } else {
+      *reinterpret_cast<f4*>(dst) += d;  // short rows are owned by this lane group; atomics of other kernels are done
+    }
   }
 }
 
@@ -242,41 +415,50 @@ size_t egc_backward_workspace_bytes(const egc_layer* layer, int64_t n_nodes) {
   return (size_t)3 * (size_t)n_nodes * ldb * sizeof(float) + 256;
 }
 
-int egc_aggregate_combine_backward_f32(const egc_graph* graph, const int32_t* t_rowptr, const int32_t* t_col,
-                                       const egc_layer* layer, const float* bases, int32_t ldb,
-                                       const float* weightings, const float* grad_out, float* d_bases,
-                                       float* d_weightings, void* workspace, size_t workspace_bytes,
-                                       egc_stream_t stream_) {
+int egc_aggregate_combine_backward_f32(const egc_graph* graph, const egc_graph* t_graph, const egc_layer* layer,
+                                       const float* bases, int32_t ldb, const float* weightings, const float* grad_out,
+                                       const float* stats, const int32_t* cnt, const int32_t* arg_max,
+                                       const int32_t* arg_min, float* d_bases, float* d_weightings, void* workspace,
+                                       size_t workspace_bytes, egc_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (graph == nullptr || layer == nullptr || t_rowptr == nullptr) return EGC_ERR_INVALID;
+  if (graph == nullptr || t_graph == nullptr || layer == nullptr) return EGC_ERR_INVALID;
   if (layer->num_aggrs <= 0 || layer->num_aggrs > EGC_MAX_AGGRS || layer->out_channels % layer->num_heads != 0)
     return EGC_ERR_INVALID;
   const int64_t n = graph->n_nodes;
   const int64_t n_src = graph->n_src_rows > 0 ? graph->n_src_rows : n;
   if (n == 0) return EGC_OK;
-  // t_rowptr has n_src + 1 entries.  Rectangular adjacencies (n_src != n) carry no self loops / symnorm; on a
-  // vertex partition the caller owns the reverse exchange of the halo rows of d_bases.
+  // Rectangular adjacencies (n_src != n) carry no self loops / symnorm; on a vertex partition the caller owns
+  // the reverse exchange of the halo rows of d_bases.
   if (n_src < n && (layer->agg_set == EGC_SET_LOOPED || layer_uses_symnorm(layer))) return EGC_ERR_INVALID;
-  if (bases == nullptr || weightings == nullptr || grad_out == nullptr || d_bases == nullptr || d_weightings == nullptr)
+  if (t_graph->n_nodes != n_src || t_graph->rowptr == nullptr || t_graph->plan == nullptr) return EGC_ERR_INVALID;
+  if (bases == nullptr || weightings == nullptr || grad_out == nullptr || d_bases == nullptr || d_weightings == nullptr ||
+      stats == nullptr || cnt == nullptr)
     return EGC_ERR_INVALID;
   if (ldb != egc_bases_ld(layer)) return EGC_ERR_INVALID;
   if (layer->weight_layout != EGC_LAYOUT_HBA) return EGC_ERR_UNSUPPORTED;  // the host packs [h][b][a]
   if (workspace == nullptr || workspace_bytes < egc_backward_workspace_bytes(layer, n)) return EGC_ERR_WORKSPACE;
+  if ((uint64_t)n * (uint64_t)ldb * 4ull > (uint64_t)OOB) return EGC_ERR_UNSUPPORTED;  // 32-bit buffer offsets
 
   BwdArgs a;
-  a.rowptr = graph->rowptr;
   a.col = graph->col;
   a.max_index = graph->max_index;
-  a.t_rowptr = t_rowptr;
-  a.t_col = t_col;
+  a.t_rowptr = t_graph->rowptr;
+  a.t_col = t_graph->col;
+  a.t_plan = t_graph->plan;
   a.bases = bases;
   a.weightings = weightings;
   a.grad_out = grad_out;
+  a.stats = stats;
+  a.cnt = cnt;
+  a.arg_max = arg_max;
+  a.arg_min = arg_min;
   a.d_bases = d_bases;
   a.d_weightings = d_weightings;
   a.n_nodes = (int)n;
   a.n_src_rows = (int)n_src;
+  a.n_edges = (int)graph->n_edges;
   a.ldb = ldb;
+  a.slots = ldb / 4;
   a.H = layer->num_heads;
   a.B = layer->num_bases;
   a.A = layer->num_aggrs;
@@ -289,7 +471,10 @@ int egc_aggregate_combine_backward_f32(const egc_graph* graph, const int32_t* t_
     a.aggr[t] = t < a.A ? layer->aggrs[t] : 0;
     if (t < a.A && layer->aggrs[t] == EGC_AGGR_SYMNORM) sym = true;
     if (t < a.A && (layer->aggrs[t] == EGC_AGGR_VAR || layer->aggrs[t] == EGC_AGGR_STD)) var = true;
+    if (t < a.A && layer->aggrs[t] == EGC_AGGR_MAX && arg_max == nullptr) return EGC_ERR_INVALID;
+    if (t < a.A && layer->aggrs[t] == EGC_AGGR_MIN && arg_min == nullptr) return EGC_ERR_INVALID;
   }
+  a.stat_k = stat_layout(a.aggr, a.A, a.stat_slot);
   a.x_looped = layer->agg_set == EGC_SET_LOOPED;
   a.y_looped = layer->sym_set == EGC_SET_LOOPED;
   a.loops_all = layer->loops_all_nodes != 0;
@@ -304,6 +489,7 @@ int egc_aggregate_combine_backward_f32(const egc_graph* graph, const int32_t* t_
   a.tab_t = ws;
   a.tab_s = sym ? ws + (size_t)n * ldb : nullptr;
   a.tab_v = var ? ws + (size_t)2 * n * ldb : nullptr;
+  a.tab_bytes = (unsigned)((uint64_t)n * ldb * 4ull);
   a.lds_floats_per_wave = a.A * ldb + ((a.F_out + 3) & ~3) + 2 * ((a.W + 3) & ~3);
   int wpb = 4;
   if ((size_t)wpb * a.lds_floats_per_wave * sizeof(float) > 48 * 1024) wpb = 1;
@@ -311,7 +497,24 @@ int egc_aggregate_combine_backward_f32(const egc_graph* graph, const int32_t* t_
   if (lds > 64 * 1024) return EGC_ERR_UNSUPPORTED;
   bwd_dst_kernel<<<(unsigned)ceil_div(n, wpb), wpb * 64, lds, stream>>>(a);
   EGC_LAUNCH_CHECK("bwd_dst_kernel");
-  bwd_src_kernel<<<(unsigned)ceil_div(n_src, 4), 256, 0, stream>>>(a);
+
+  int lg = 0;
+  while ((1 << lg) < a.slots && lg < 6) ++lg;
+  if (lg < 4) lg = 4;
+  a.lpr_log2 = lg;
+  const int G = 64 >> lg;
+  const int ns = (a.slots + (1 << lg) - 1) >> lg;  // slots per lane
+  const PlanCaps caps = plan_caps(n_src, t_graph->n_edges);
+  const int64_t n_chunks = (t_graph->n_chunks >= 0 && t_graph->n_chunks <= caps.cap_chunks) ? t_graph->n_chunks : caps.cap_chunks;
+  a.chunk_blocks = (int)ceil_div(n_chunks, 4);
+  const unsigned grid = (unsigned)(a.chunk_blocks + ceil_div(n_src, (int64_t)4 * G));
+  switch (ns) {
+    case 1: bwd_src_kernel<1><<<grid, 256, 0, stream>>>(a); break;
+    case 2: bwd_src_kernel<2><<<grid, 256, 0, stream>>>(a); break;
+    case 3: bwd_src_kernel<3><<<grid, 256, 0, stream>>>(a); break;
+    case 4: bwd_src_kernel<4><<<grid, 256, 0, stream>>>(a); break;
+    default: return EGC_ERR_UNSUPPORTED;
+  }
   EGC_LAUNCH_CHECK("bwd_src_kernel");
   return EGC_OK;
 }

@@ -137,22 +137,53 @@ def egc_layer_forward(graph: CSRGraph, spec: LayerSpec, x: torch.Tensor, wcat: t
     return out
 
 
-def egc_aggregate_combine_backward(graph: CSRGraph, spec: LayerSpec, bases, weightings, grad_out):
-    """(d_bases [N, ldb], d_weightings [N, W]) through egc_aggregate_combine_backward_f32."""
+def egc_aggregate_combine_train(graph: CSRGraph, spec: LayerSpec, bases: torch.Tensor, weightings: torch.Tensor,
+                                bias: torch.Tensor | None):
+    """Training form of egc_aggregate_combine (egc_aggregate_combine_train_f32): returns
+    (out, saved) where ``saved`` = (stats, cnt, arg_max, arg_min) is what the backward consumes."""
+    lib = _C.load()
+    n = graph.n_nodes
+    _check_f32(bases, "bases", (graph.n_src_rows, spec.ldb))
+    _check_f32(weightings, "weightings", (n, spec.w_cols))
+    dev = bases.device
+    codes = [spec.c.aggrs[t] for t in range(spec.c.num_aggrs)]
+    with torch.cuda.device(dev):
+        out = torch.empty((n, spec.f_out), dtype=torch.float32, device=dev)
+        stats = torch.empty((n, max(int(lib.egc_train_stats_floats(C.byref(spec.c))), 1)), dtype=torch.float32, device=dev)
+        cnt = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        arg_max = torch.empty((n, spec.ldb), dtype=torch.int32, device=dev) if _C.AGGR_MAX in codes else None
+        arg_min = torch.empty((n, spec.ldb), dtype=torch.int32, device=dev) if _C.AGGR_MIN in codes else None
+        ws = graph.workspace(lib.egc_aggregate_workspace_bytes(C.byref(spec.c), n, graph.n_edges))
+        g = graph.c_struct()
+        _C.check(lib.egc_aggregate_combine_train_f32(
+            C.byref(g), C.byref(spec.c), bases.data_ptr(), spec.ldb, weightings.data_ptr(),
+            bias.contiguous().data_ptr() if bias is not None else None, out.data_ptr(), stats.data_ptr(),
+            cnt.data_ptr(), arg_max.data_ptr() if arg_max is not None else None,
+            arg_min.data_ptr() if arg_min is not None else None, ws.data_ptr(), ws.numel(), _stream_ptr(dev)),
+            "egc_aggregate_combine_train_f32")
+    return out, (stats, cnt, arg_max, arg_min)
+
+
+def egc_aggregate_combine_backward(graph: CSRGraph, spec: LayerSpec, bases, weightings, grad_out, saved):
+    """(d_bases [n_src_rows, ldb], d_weightings [N, W]) through egc_aggregate_combine_backward_f32;
+    ``saved`` comes from egc_aggregate_combine_train."""
     lib = _C.load()
     n = graph.n_nodes
     dev = bases.device
-    t_rowptr, t_col = graph.transposed()
+    stats, cnt, arg_max, arg_min = saved
+    tg = graph.transposed()
     with torch.cuda.device(dev):
         d_bases = torch.zeros((graph.n_src_rows, spec.ldb), dtype=torch.float32, device=dev)  # atomics land here
         d_w = torch.empty((n, spec.w_cols), dtype=torch.float32, device=dev)
         nbytes = lib.egc_backward_workspace_bytes(C.byref(spec.c), n)
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
-        g = graph.c_struct()
+        g, t = graph.c_struct(), tg.c_struct()
         _C.check(lib.egc_aggregate_combine_backward_f32(
-            C.byref(g), t_rowptr.data_ptr(), t_col.data_ptr(), C.byref(spec.c), bases.data_ptr(), spec.ldb,
-            weightings.data_ptr(), grad_out.contiguous().data_ptr(), d_bases.data_ptr(), d_w.data_ptr(),
-            ws.data_ptr(), ws.numel(), _stream_ptr(dev)), "egc_aggregate_combine_backward_f32")
+            C.byref(g), C.byref(t), C.byref(spec.c), bases.data_ptr(), spec.ldb, weightings.data_ptr(),
+            grad_out.contiguous().data_ptr(), stats.data_ptr(), cnt.data_ptr(),
+            arg_max.data_ptr() if arg_max is not None else None, arg_min.data_ptr() if arg_min is not None else None,
+            d_bases.data_ptr(), d_w.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(dev)),
+            "egc_aggregate_combine_backward_f32")
     return d_bases, d_w
 
 
@@ -168,9 +199,9 @@ class _EGCLayerFunction(torch.autograd.Function):
         bases, weightings = egc_basis_transform(graph, spec, x, wcat, bcat, None)
         if graph.halo is not None and graph.n_src_rows > graph.n_nodes:
             raise RuntimeError("egc_amd: training on a vertex-partitioned graph is not implemented")
-        out = egc_aggregate_combine(graph, spec, bases, weightings, bias)
+        out, saved = egc_aggregate_combine_train(graph, spec, bases, weightings, bias)
         ctx.save_for_backward(x, wcat, bases, weightings)
-        ctx.graph, ctx.spec = graph, spec
+        ctx.graph, ctx.spec, ctx.saved = graph, spec, saved
         ctx.has_bcat, ctx.has_bias = bcat is not None, bias is not None
         return out
 
@@ -179,7 +210,7 @@ class _EGCLayerFunction(torch.autograd.Function):
         x, wcat, bases, weightings = ctx.saved_tensors
         spec = ctx.spec
         grad_out = grad_out.contiguous()
-        d_bases, d_w = egc_aggregate_combine_backward(ctx.graph, spec, bases, weightings, grad_out)
+        d_bases, d_w = egc_aggregate_combine_backward(ctx.graph, spec, bases, weightings, grad_out, ctx.saved)
         d_cat = torch.cat([d_bases[:, :spec.f_g], d_w], dim=1)             # [N, F_g + W]
         dx = d_cat @ wcat.t() if ctx.needs_input_grad[0] else None
         dwcat = x.t() @ d_cat if ctx.needs_input_grad[1] else None
@@ -195,16 +226,16 @@ class _AggregateCombineFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, bases, weightings, bias, graph, spec):
-        out = egc_aggregate_combine(graph, spec, bases, weightings, bias)
+        out, saved = egc_aggregate_combine_train(graph, spec, bases, weightings, bias)
         ctx.save_for_backward(bases, weightings)
-        ctx.graph, ctx.spec, ctx.has_bias = graph, spec, bias is not None
+        ctx.graph, ctx.spec, ctx.saved, ctx.has_bias = graph, spec, saved, bias is not None
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         bases, weightings = ctx.saved_tensors
         grad_out = grad_out.contiguous()
-        d_bases, d_w = egc_aggregate_combine_backward(ctx.graph, ctx.spec, bases, weightings, grad_out)
+        d_bases, d_w = egc_aggregate_combine_backward(ctx.graph, ctx.spec, bases, weightings, grad_out, ctx.saved)
         dbias = grad_out.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return d_bases, d_w, dbias, None, None
 

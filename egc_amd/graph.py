@@ -112,13 +112,13 @@ class CSRGraph:
                                      dis_looped.data_ptr(), plan.data_ptr(), _stream_ptr(dev)), "egc_csr_prepare")
         return cls(n, e, rowptr, col, edge_id, dis_raw, dis_looped, max_index, plan, ns)
 
-    def transposed(self):
-        """(t_rowptr, t_col): CSR with rows = SOURCES and entries = destinations, needed by the backward
-        (d bases[j] gathers over j's out-neighbours).  Built on first use from the destination-keyed CSR."""
+    def transposed(self) -> "CSRGraph":
+        """The transposed graph as a CSRGraph (rows = SOURCES, entries = destinations, with its own long-row
+        plan), needed by the backward: d bases[j] sums the destination tables over j's out-neighbours.
+        Built on first use from the destination-keyed CSR and kept."""
         if getattr(self, "_transposed", None) is None:
             if self.halo is not None:
                 raise RuntimeError("egc_amd: backward on a vertex-partitioned graph is not implemented")
-            lib = _C.load()
             dev = self.device
             n, e, ns = self.n_nodes, self.n_edges, self.n_src_rows
             with torch.cuda.device(dev):
@@ -126,16 +126,8 @@ class CSRGraph:
                 counts = (self.rowptr[1:] - self.rowptr[:-1]).long()
                 dst = torch.repeat_interleave(torch.arange(n, device=dev), counts)
                 src = self.col[:e].long()
-                t_rowptr = torch.empty(ns + 1, dtype=torch.int32, device=dev)
-                t_col = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
-                t_eid = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
-                t_max = torch.empty(1, dtype=torch.int32, device=dev)
-                ws = torch.empty(max(lib.egc_coo_to_csr_workspace_bytes(ns, e), 1), dtype=torch.uint8, device=dev)
                 # swap roles: "source" = dst (becomes the entry), "destination" = src (becomes the row)
-                _C.check(lib.egc_coo_to_csr(dst.data_ptr(), src.data_ptr(), e, ns, t_rowptr.data_ptr(),
-                                            t_col.data_ptr(), t_eid.data_ptr(), t_max.data_ptr(), ws.data_ptr(),
-                                            ws.numel(), _stream_ptr(dev)), "egc_coo_to_csr(transposed)")
-            self._transposed = (t_rowptr, t_col)
+                self._transposed = CSRGraph.from_edge_index(torch.stack([dst, src]), ns, max(n, 1))
         return self._transposed
 
     def workspace(self, nbytes: int) -> torch.Tensor:

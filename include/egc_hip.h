@@ -176,14 +176,27 @@ size_t egc_aggregate_workspace_bytes(const egc_layer* layer, int64_t n_nodes, in
  *   scatter / spmm per aggregator   layers.py:201-225, optimized_layers.py:215-278
  *   stack + softmax/sigmoid/hardtanh + weighted sum / bmm + bias
  *                                   layers.py:109-138, optimized_layers.py:183-208
- * out is [n_nodes, out_channels].  arg_max / arg_min (each [n_nodes, ldb] int32, or NULL) receive, per
- * basis column, the INPUT edge position (graph.edge_id) of the first entry attaining the extremum
- * (n_edges for the self-loop of a LOOPED set, -1 for an empty row) -- what torch_scatter's
- * scatter_max/min return as `arg` and autograd routes the gradient through. */
+ * out is [n_nodes, out_channels].  arg_max / arg_min must be NULL here: the arg-extremum indices are an
+ * output of the training form below (EGC_ERR_UNSUPPORTED otherwise). */
 int egc_aggregate_combine_f32(const egc_graph* graph, const egc_layer* layer, const float* bases, int32_t ldb,
                               const float* weightings, const float* bias, float* out,
                               int32_t* arg_max, int32_t* arg_min,
                               void* workspace, size_t workspace_bytes, egc_stream_t stream);
+
+/* Training form of egc_aggregate_combine_f32: same `out`, plus what the backward needs instead of a second
+ * gather.  stats [n_nodes, egc_train_stats_floats(layer)] receives every row's raw running aggregates after
+ * the self-loop term (those of sum / sum of squares / max / min / symnorm-weighted sum that the aggregator
+ * list uses, each [ldb] wide), cnt [n_nodes] the size of the row's aggregation set.  arg_max / arg_min
+ * (each [n_nodes, ldb] int32; NULL allowed when the layer has no max / min aggregator) receive, per basis
+ * column, the CSR entry position of the FIRST entry attaining the extremum -- graph.col[pos] is its source,
+ * graph.edge_id[pos] its position in the input edge list, i.e. what torch_scatter's scatter_max/min return
+ * as `arg` and autograd routes the gradient through -- n_edges for the appended self-loop of a LOOPED set,
+ * -1 for an empty row. */
+int64_t egc_train_stats_floats(const egc_layer* layer);
+int egc_aggregate_combine_train_f32(const egc_graph* graph, const egc_layer* layer, const float* bases, int32_t ldb,
+                                    const float* weightings, const float* bias, float* out, float* stats,
+                                    int32_t* cnt, int32_t* arg_max, int32_t* arg_min, void* workspace,
+                                    size_t workspace_bytes, egc_stream_t stream);
 
 /* Whole layer forward = egc_basis_transform_f32 + egc_aggregate_combine_f32
  * (EfficientGraphConv.forward layers.py:89-140 / EGConv.forward optimized_layers.py:177-210
@@ -197,18 +210,20 @@ int egc_layer_forward_packed(const egc_graph* graph, const egc_layer* layer, con
                              const float* bcat, const float* bias, float* bases, int32_t ldb, float* weightings,
                              float* out, void* workspace, size_t workspace_bytes, egc_stream_t stream);
 
-/* Backward of egc_aggregate_combine_f32 (in the reference PyTorch autograd derives it
- * through layers.py:103-138 / optimized_layers.py:186-208).  Inputs: the forward's `bases` and
- * PRE-activation `weightings` (layout HBA), grad_out = dL/d out [n_nodes, out_channels], and the TRANSPOSED
- * CSR of the graph (rows = sources, entries = destinations: egc_coo_to_csr with src/dst swapped).
- * Outputs: d_bases [n_nodes, ldb] -- MUST be zero-filled by the caller (max/min gradients arrive by float
- * atomics at the first entry attaining the extremum, torch_scatter's arg semantics) -- and d_weightings
- * [n_nodes, H*B*A] (gradient w.r.t. the pre-activation weightings).  The dense gradients
- * (x, bases_weight, comb weight/bias, bias) are plain GEMMs / column sums left to the caller. */
+/* Backward of egc_aggregate_combine_train_f32 (in the reference PyTorch autograd derives
+ * it through layers.py:103-138 / optimized_layers.py:186-208).  Inputs: the forward's `bases`, PRE-activation
+ * `weightings` (layout HBA), `stats`, `cnt`, `arg_max` / `arg_min`; grad_out = dL/d out [n_nodes, out_channels];
+ * and t_graph = the TRANSPOSED graph (rows = sources, entries = destinations: egc_coo_to_csr with src/dst
+ * swapped, then egc_csr_prepare for its long-row plan; its dis_* arrays are not used).
+ * Outputs: d_bases [n_src_rows, ldb] -- MUST be zero-filled by the caller (max/min gradients and the partial
+ * sums of hub rows arrive by float atomics) -- and d_weightings [n_nodes, H*B*A] (gradient w.r.t. the
+ * pre-activation weightings).  The dense gradients (x, bases_weight, comb weight/bias, bias) are plain
+ * GEMMs / column sums left to the caller. */
 size_t egc_backward_workspace_bytes(const egc_layer* layer, int64_t n_nodes);
-int egc_aggregate_combine_backward_f32(const egc_graph* graph, const int32_t* t_rowptr, const int32_t* t_col,
-                                       const egc_layer* layer, const float* bases, int32_t ldb,
-                                       const float* weightings, const float* grad_out, float* d_bases,
+int egc_aggregate_combine_backward_f32(const egc_graph* graph, const egc_graph* t_graph, const egc_layer* layer,
+                                       const float* bases, int32_t ldb, const float* weightings,
+                                       const float* grad_out, const float* stats, const int32_t* cnt,
+                                       const int32_t* arg_max, const int32_t* arg_min, float* d_bases,
                                        float* d_weightings, void* workspace, size_t workspace_bytes,
                                        egc_stream_t stream);
 
