@@ -17,10 +17,10 @@
 // Nothing is gathered twice: the training forward (egc_aggregate_combine_train_f32) keeps every row's raw
 // running aggregates (`stats`, `cnt`), so the destination side is ROW-LOCAL, and the source side is a sum-only
 // SpMM of the tables over the transposed CSR.  Three kernels:
-//   arg_extrema_kernel   (part of the training forward, only with max / min): entry-parallel, compares each
-//                        gathered slot with the row's extremum and keeps the smallest CSR position (atomicMin)
-//   bwd_dst_kernel       one wavefront per destination row, lane = basis column: d w', tables T/S/V, and the
-//                        max/min gradients as float atomics into d_bases
+//   arg_extrema_kernel   (part of the training forward, only with max / min): lane group per row, compares each
+//                        gathered slot with the row's extremum and keeps the first CSR position that matches
+//   bwd_dst_kernel       one wavefront per destination row, lane = basis column: d w' and the tables T/S/V,
+//                        plus X/N = d agg_max / d agg_min, which the source side routes by the arg positions
 //   bwd_src_kernel       lane group per source row (several rows per wavefront, FU loads in flight); rows
 //                        longer than EGC_LONG_ROW_THRESHOLD are cut into chunks (plan of the transposed graph)
 //                        whose partial sums arrive by float atomics
@@ -39,55 +39,106 @@ struct ArgArgs {
   const int* col;
   const float* bases;
   const float* stats;
+  const int* plan;
   int* arg_max;
   int* arg_min;
-  int n_nodes, n_edges;
+  int n_nodes, n_edges, chunk_blocks;
   int ldb, slots, lpr_log2, stat_k, slot_mx, slot_mn;
   int x_looped;
   unsigned bases_bytes;
 };
 
-// One wavefront per 64 consecutive CSR entries; a lane group of 2^lpr_log2 lanes compares one entry's basis
-// row (16 bytes per lane) with its destination row's extrema.
+// Lane group per destination row (G rows per wavefront): the group walks its row in order and keeps, per
+// column, the first position whose gathered value equals the row's extremum -- no atomics.  Rows longer than
+// EGC_LONG_ROW_THRESHOLD are cut into the plan's chunks (leading blocks, one wavefront per chunk, the G groups
+// splitting its entries); their candidates meet in an atomicMin on the position.
+constexpr int ARG_FU = 4;
+template <int NS>
 __global__ void __launch_bounds__(256) arg_extrema_kernel(ArgArgs a) {
   const int lane = threadIdx.x & 63;
-  const int base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
-  if (base >= a.n_edges) return;
-  const int p = base + lane;
-  const bool pv = p < a.n_edges;
-  const int jj = pv ? a.col[p] : 0;
-  int lo = 0, hi = a.n_nodes;  // largest i with rowptr[i] <= p
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (a.rowptr[mid] <= (pv ? p : 0)) lo = mid; else hi = mid;
-  }
-  const int ii = lo;
+  const int wave = threadIdx.x >> 6;
   const int LPR = 1 << a.lpr_log2, G = 64 >> a.lpr_log2;
   const int g = lane >> a.lpr_log2, q = lane & (LPR - 1);
   const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)a.bases, 0, a.bases_bytes, 0x00020000);
-  const int cnt = min(64, a.n_edges - base);
-  for (int t0 = 0; t0 < cnt; t0 += G) {  // wave-uniform trip count: every lane takes part in the shuffles
-    const int t = t0 + g;
-    const int j = __shfl(jj, t & 63), i = __shfl(ii, t & 63);
-    if (t >= cnt) continue;
-    if (a.x_looped && j == i) continue;  // excluded from the LOOPED set; its self-loop is appended LAST
-    for (int s = q; s < a.slots; s += LPR) {
-      const f4 v = load_slot(rb, (unsigned)j * (unsigned)a.ldb * 4u + (unsigned)s * 16u);
-      const float* st = a.stats + ((int64_t)i * a.stat_k) * a.ldb + 4 * s;
-      const int o = i * a.ldb + 4 * s;
+  int row, start, end, first, step;
+  bool atomic;
+  if ((int)blockIdx.x < a.chunk_blocks) {
+    const int c = blockIdx.x * 4 + wave;
+    if (c >= a.plan[1]) return;
+    const int cap_long = a.plan[2], cap_chunks = a.plan[3];
+    const int* long_row = a.plan + 4;
+    const int* chunk_slot = long_row + 2 * cap_long;
+    const int* chunk_begin = chunk_slot + cap_chunks;
+    row = long_row[chunk_slot[c]];
+    start = chunk_begin[c];
+    end = min(start + EGC_LONG_ROW_CHUNK, a.rowptr[row + 1]);
+    first = g; step = G;
+    atomic = true;
+  } else {
+    row = (((int)blockIdx.x - a.chunk_blocks) * 4 + wave) * G + g;
+    if (row >= a.n_nodes) return;
+    start = a.rowptr[row]; end = a.rowptr[row + 1];
+    if (end - start > EGC_LONG_ROW_THRESHOLD) return;  // the chunk blocks own this row (arg pre-set to ARG_INIT)
+    first = 0; step = 1;
+    atomic = false;
+  }
+  f4 mx[NS], mn[NS];
+  int4 ax[NS], an[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const int s = q + k * LPR;
+    const float* st = a.stats + ((int64_t)row * a.stat_k) * a.ldb + 4 * s;
+    const f4 nanv = f4{NAN, NAN, NAN, NAN};  // never equal: idle slots / unused extremum
+    mx[k] = (a.arg_max != nullptr && s < a.slots) ? *reinterpret_cast<const f4*>(st + a.slot_mx * a.ldb) : nanv;
+    mn[k] = (a.arg_min != nullptr && s < a.slots) ? *reinterpret_cast<const f4*>(st + a.slot_mn * a.ldb) : nanv;
+    ax[k] = an[k] = int4{ARG_INIT, ARG_INIT, ARG_INIT, ARG_INIT};
+  }
+  for (int p0 = start + first; p0 < end; p0 += step * ARG_FU) {
+    int j[ARG_FU];
+#pragma unroll
+    for (int u = 0; u < ARG_FU; ++u) {
+      const int p = p0 + u * step;
+      j[u] = p < end ? a.col[p] : -1;
+      if (a.x_looped && j[u] == row) j[u] = -1;  // excluded from the LOOPED set; its self-loop is appended LAST
+    }
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      const int s = q + k * LPR;
+      f4 v[ARG_FU];
+#pragma unroll
+      for (int u = 0; u < ARG_FU; ++u)
+        v[u] = load_slot(rb, (j[u] >= 0 && s < a.slots) ? (unsigned)j[u] * (unsigned)a.ldb * 4u + (unsigned)s * 16u : OOB);
+#pragma unroll
+      for (int u = 0; u < ARG_FU; ++u) {
+        if (j[u] < 0) continue;
+        const int p = p0 + u * step;   // increasing: min() keeps the first hit
+        ax[k].x = min(ax[k].x, v[u].x == mx[k].x ? p : ARG_INIT); ax[k].y = min(ax[k].y, v[u].y == mx[k].y ? p : ARG_INIT);
+        ax[k].z = min(ax[k].z, v[u].z == mx[k].z ? p : ARG_INIT); ax[k].w = min(ax[k].w, v[u].w == mx[k].w ? p : ARG_INIT);
+        an[k].x = min(an[k].x, v[u].x == mn[k].x ? p : ARG_INIT); an[k].y = min(an[k].y, v[u].y == mn[k].y ? p : ARG_INIT);
+        an[k].z = min(an[k].z, v[u].z == mn[k].z ? p : ARG_INIT); an[k].w = min(an[k].w, v[u].w == mn[k].w ? p : ARG_INIT);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const int s = q + k * LPR;
+    if (s >= a.slots) continue;
+    const int64_t o = (int64_t)row * a.ldb + 4 * s;
+    if (!atomic) {
+      if (a.arg_max != nullptr) *reinterpret_cast<int4*>(a.arg_max + o) = ax[k];
+      if (a.arg_min != nullptr) *reinterpret_cast<int4*>(a.arg_min + o) = an[k];
+    } else {
       if (a.arg_max != nullptr) {
-        const f4 m = *reinterpret_cast<const f4*>(st + a.slot_mx * a.ldb);
-        if (v.x == m.x) atomicMin(&a.arg_max[o], base + t);
-        if (v.y == m.y) atomicMin(&a.arg_max[o + 1], base + t);
-        if (v.z == m.z) atomicMin(&a.arg_max[o + 2], base + t);
-        if (v.w == m.w) atomicMin(&a.arg_max[o + 3], base + t);
+        if (ax[k].x != ARG_INIT) atomicMin(&a.arg_max[o], ax[k].x);
+        if (ax[k].y != ARG_INIT) atomicMin(&a.arg_max[o + 1], ax[k].y);
+        if (ax[k].z != ARG_INIT) atomicMin(&a.arg_max[o + 2], ax[k].z);
+        if (ax[k].w != ARG_INIT) atomicMin(&a.arg_max[o + 3], ax[k].w);
       }
       if (a.arg_min != nullptr) {
-        const f4 m = *reinterpret_cast<const f4*>(st + a.slot_mn * a.ldb);
-        if (v.x == m.x) atomicMin(&a.arg_min[o], base + t);
-        if (v.y == m.y) atomicMin(&a.arg_min[o + 1], base + t);
-        if (v.z == m.z) atomicMin(&a.arg_min[o + 2], base + t);
-        if (v.w == m.w) atomicMin(&a.arg_min[o + 3], base + t);
+        if (an[k].x != ARG_INIT) atomicMin(&a.arg_min[o], an[k].x);
+        if (an[k].y != ARG_INIT) atomicMin(&a.arg_min[o + 1], an[k].y);
+        if (an[k].z != ARG_INIT) atomicMin(&a.arg_min[o + 2], an[k].z);
+        if (an[k].w != ARG_INIT) atomicMin(&a.arg_min[o + 3], an[k].w);
       }
     }
   }
@@ -120,11 +171,23 @@ int arg_extrema(const egc_graph* graph, const egc_layer* layer, const float* bas
   a.ldb = ldb; a.slots = ldb / 4; a.stat_k = k; a.slot_mx = slot[STAT_MX]; a.slot_mn = slot[STAT_MN];
   a.x_looped = layer->agg_set == EGC_SET_LOOPED;
   a.bases_bytes = (unsigned)((uint64_t)n_src * ldb * 4ull);
-  int lg = 0;
+  int lg = 4;
   while ((1 << lg) < a.slots && lg < 6) ++lg;
   a.lpr_log2 = lg;
+  a.plan = graph->plan;
   if (e > 0) {
-    arg_extrema_kernel<<<(unsigned)ceil_div(e, 256), 256, 0, stream>>>(a);
+    if (graph->plan == nullptr) return EGC_ERR_INVALID;
+    const PlanCaps caps = plan_caps(n, e);
+    const int64_t n_chunks = (graph->n_chunks >= 0 && graph->n_chunks <= caps.cap_chunks) ? graph->n_chunks : caps.cap_chunks;
+    a.chunk_blocks = (int)ceil_div(n_chunks, 4);
+    const unsigned grid = (unsigned)(a.chunk_blocks + ceil_div(n, (int64_t)4 * (64 >> lg)));
+    switch ((a.slots + (1 << lg) - 1) >> lg) {
+      case 1: arg_extrema_kernel<1><<<grid, 256, 0, stream>>>(a); break;
+      case 2: arg_extrema_kernel<2><<<grid, 256, 0, stream>>>(a); break;
+      case 3: arg_extrema_kernel<3><<<grid, 256, 0, stream>>>(a); break;
+      case 4: arg_extrema_kernel<4><<<grid, 256, 0, stream>>>(a); break;
+      default: return EGC_ERR_UNSUPPORTED;
+    }
     EGC_LAUNCH_CHECK("arg_extrema_kernel");
   }
   const int64_t total = n * ldb;
@@ -157,6 +220,9 @@ struct BwdArgs {
   float* tab_t;              // [N, ldb]
   float* tab_s;              // [N, ldb] or nullptr
   float* tab_v;              // [N, ldb] or nullptr
+  float* tab_x;              // [N, ldb] d agg_max, or nullptr
+  float* tab_n;              // [N, ldb] d agg_min, or nullptr
+  const int* t_edge_id;      // transposed entry -> position of the same edge in the destination-side CSR
   int n_nodes, n_src_rows, n_edges;
   int ldb, slots, F_g, F_out, W, H, B, A, L;
   int aggr[EGC_MAX_AGGRS];
@@ -239,15 +305,8 @@ __global__ void __launch_bounds__(256) bwd_dst_kernel(BwdArgs a) {
       switch (a.aggr[t]) {
         case EGC_AGGR_SUM: d_t += d; break;
         case EGC_AGGR_MEAN: d_t += d / cntf; break;
-        case EGC_AGGR_MAX:
-        case EGC_AGGR_MIN: {
-          const int pos = (a.aggr[t] == EGC_AGGR_MAX ? a.arg_max : a.arg_min)[(int64_t)row * a.ldb + c];
-          if (cnt > 0 && pos >= 0) {
-            const int j = pos < a.n_edges ? a.col[pos] : row;  // n_edges: the appended self-loop
-            atomicAdd(&a.d_bases[(int64_t)j * a.ldb + c], d);
-          }
-          break;
-        }
+        case EGC_AGGR_MAX: a.tab_x[(int64_t)row * a.ldb + c] = cnt > 0 ? d : 0.f; break;
+        case EGC_AGGR_MIN: a.tab_n[(int64_t)row * a.ldb + c] = cnt > 0 ? d : 0.f; break;
         case EGC_AGGR_VAR: d_v += d; break;
         case EGC_AGGR_STD: d_v += (var > 0.f) ? d / (2.0f * sd) : 0.f; break;
         default: d_s += d * dis_i; break;
@@ -292,12 +351,14 @@ template <int NS>
 __device__ inline void sum_tables(const BwdArgs& a, const __amdgpu_buffer_rsrc_t (&rt)[3], int row, int start, int end,
                                   int first, int step, int q, int LPR, bool xl, bool yl, f4 (&at)[NS], f4 (&as)[NS],
                                   f4 (&av)[NS]) {
+  const bool ext = a.tab_x != nullptr || a.tab_n != nullptr;
   for (int p0 = start + first; p0 < end; p0 += step * BWD_FU) {
-    int dst[BWD_FU];
+    int dst[BWD_FU], pos[BWD_FU];
 #pragma unroll
     for (int u = 0; u < BWD_FU; ++u) {
       const int p = p0 + u * step;
       dst[u] = p < end ? a.t_col[p] : -1;
+      pos[u] = (ext && p < end) ? a.t_edge_id[p] : -2;
     }
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
@@ -317,6 +378,26 @@ __device__ inline void sum_tables(const BwdArgs& a, const __amdgpu_buffer_rsrc_t
         at[k] += vt[u];
         if (a.tab_v != nullptr) av[k] += vv[u];
         if (a.tab_s != nullptr) as[k] += vs[u];
+      }
+      // max / min: the whole gradient of (destination, column) goes to the entry its arg position names
+      if (ext) {
+#pragma unroll
+        for (int u = 0; u < BWD_FU; ++u) {
+          if (dst[u] < 0 || s >= a.slots) continue;
+          const int64_t o = (int64_t)dst[u] * a.ldb + 4 * s;
+          if (a.tab_x != nullptr) {
+            const int4 ar = *reinterpret_cast<const int4*>(a.arg_max + o);
+            const f4 gx = *reinterpret_cast<const f4*>(a.tab_x + o);
+            at[k].x += ar.x == pos[u] ? gx.x : 0.f; at[k].y += ar.y == pos[u] ? gx.y : 0.f;
+            at[k].z += ar.z == pos[u] ? gx.z : 0.f; at[k].w += ar.w == pos[u] ? gx.w : 0.f;
+          }
+          if (a.tab_n != nullptr) {
+            const int4 ar = *reinterpret_cast<const int4*>(a.arg_min + o);
+            const f4 gn = *reinterpret_cast<const f4*>(a.tab_n + o);
+            at[k].x += ar.x == pos[u] ? gn.x : 0.f; at[k].y += ar.y == pos[u] ? gn.y : 0.f;
+            at[k].z += ar.z == pos[u] ? gn.z : 0.f; at[k].w += ar.w == pos[u] ? gn.w : 0.f;
+          }
+        }
       }
     }
   }
@@ -391,6 +472,20 @@ __global__ void __launch_bounds__(256) bwd_src_kernel(BwdArgs a) {
       if (a.tab_v != nullptr) vv += *reinterpret_cast<const f4*>(a.tab_v + o);
     }
     if (yl && has_self && a.tab_s != nullptr) sv += *reinterpret_cast<const f4*>(a.tab_s + o);
+    if (xl && has_self) {  // the appended self-loop attained the extremum: arg == n_edges
+      if (a.tab_x != nullptr) {
+        const int4 ar = *reinterpret_cast<const int4*>(a.arg_max + o);
+        const f4 gx = *reinterpret_cast<const f4*>(a.tab_x + o);
+        t.x += ar.x == a.n_edges ? gx.x : 0.f; t.y += ar.y == a.n_edges ? gx.y : 0.f;
+        t.z += ar.z == a.n_edges ? gx.z : 0.f; t.w += ar.w == a.n_edges ? gx.w : 0.f;
+      }
+      if (a.tab_n != nullptr) {
+        const int4 ar = *reinterpret_cast<const int4*>(a.arg_min + o);
+        const f4 gn = *reinterpret_cast<const f4*>(a.tab_n + o);
+        t.x += ar.x == a.n_edges ? gn.x : 0.f; t.y += ar.y == a.n_edges ? gn.y : 0.f;
+        t.z += ar.z == a.n_edges ? gn.z : 0.f; t.w += ar.w == a.n_edges ? gn.w : 0.f;
+      }
+    }
     f4 d = t;
     if (a.tab_s != nullptr) d = f4_fma(f4{dis_j, dis_j, dis_j, dis_j}, sv, d);
     if (a.tab_v != nullptr) d = f4_fma(*reinterpret_cast<const f4*>(a.bases + o), vv, d);
@@ -412,7 +507,7 @@ extern "C" {
 size_t egc_backward_workspace_bytes(const egc_layer* layer, int64_t n_nodes) {
   if (layer == nullptr || n_nodes < 0 || layer->num_heads <= 0) return 0;
   const int ldb = egc_bases_ld(layer);
-  return (size_t)3 * (size_t)n_nodes * ldb * sizeof(float) + 256;
+  return (size_t)5 * (size_t)n_nodes * ldb * sizeof(float) + 256;  // tables T, S, V, X, N
 }
 
 int egc_aggregate_combine_backward_f32(const egc_graph* graph, const egc_graph* t_graph, const egc_layer* layer,
@@ -489,6 +584,10 @@ int egc_aggregate_combine_backward_f32(const egc_graph* graph, const egc_graph* 
   a.tab_t = ws;
   a.tab_s = sym ? ws + (size_t)n * ldb : nullptr;
   a.tab_v = var ? ws + (size_t)2 * n * ldb : nullptr;
+  a.tab_x = a.stat_slot[STAT_MX] >= 0 ? ws + (size_t)3 * n * ldb : nullptr;
+  a.tab_n = a.stat_slot[STAT_MN] >= 0 ? ws + (size_t)4 * n * ldb : nullptr;
+  a.t_edge_id = t_graph->edge_id;
+  if ((a.tab_x != nullptr || a.tab_n != nullptr) && a.t_edge_id == nullptr) return EGC_ERR_INVALID;
   a.tab_bytes = (unsigned)((uint64_t)n * ldb * 4ull);
   a.lds_floats_per_wave = a.A * ldb + ((a.F_out + 3) & ~3) + 2 * ((a.W + 3) & ~3);
   int wpb = 4;

@@ -214,9 +214,12 @@ int egc_layer_forward_packed(const egc_graph* graph, const egc_layer* layer, con
  * it through layers.py:103-138 / optimized_layers.py:186-208).  Inputs: the forward's `bases`, PRE-activation
  * `weightings` (layout HBA), `stats`, `cnt`, `arg_max` / `arg_min`; grad_out = dL/d out [n_nodes, out_channels];
  * and t_graph = the TRANSPOSED graph (rows = sources, entries = destinations: egc_coo_to_csr with src/dst
- * swapped, then egc_csr_prepare for its long-row plan; its dis_* arrays are not used).
- * Outputs: d_bases [n_src_rows, ldb] -- MUST be zero-filled by the caller (max/min gradients and the partial
- * sums of hub rows arrive by float atomics) -- and d_weightings [n_nodes, H*B*A] (gradient w.r.t. the
+ * swapped, then egc_csr_prepare for its long-row plan; its dis_* arrays are not used).  With max / min
+ * aggregators the transposed graph must be built from the edge list in DESTINATION-CSR ORDER (edge k = CSR
+ * entry k: source graph.col[k], destination = k's row), so that t_graph.edge_id maps a transposed entry to the
+ * CSR position that arg_max / arg_min name.
+ * Outputs: d_bases [n_src_rows, ldb] -- MUST be zero-filled by the caller (the partial sums of hub rows
+ * arrive by float atomics) -- and d_weightings [n_nodes, H*B*A] (gradient w.r.t. the
  * pre-activation weightings).  The dense gradients (x, bases_weight, comb weight/bias, bias) are plain
  * GEMMs / column sums left to the caller. */
 size_t egc_backward_workspace_bytes(const egc_layer* layer, int64_t n_nodes);
