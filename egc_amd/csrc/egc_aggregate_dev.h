@@ -41,7 +41,9 @@ struct AggArgs {
   unsigned bases_bytes;
   int lds_floats_per_wave;
   // register-resident ("fast") kernel family only
-  int lpb_log2;            // log2(lanes per basis block) = log2(L / 4)
+  int lpb_log2;            // log2(lanes per basis block) = log2(L / 4), or -1: not a power-of-two layout
+  int lanes_pb;            // L / 4
+  unsigned magic_P;        // floor(2^32 / lanes_pb) + 1
   int hpg;                 // heads per lane group = ceil(H / G)
   int rows_per_wave;
   int chunk_blocks;        // leading blocks of the grid that take long-row chunks

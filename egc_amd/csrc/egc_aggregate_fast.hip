@@ -1,10 +1,14 @@
-// Register-resident EGC aggregate+combine kernel family for power-of-two layer shapes (gfx950).
+// Register-resident EGC aggregate+combine kernel family (gfx950).
 //
 // Same contract as the generic kernels in egc_aggregate.hip (and the same reference call sites:
 // layers.py:109-138,191-225; optimized_layers.py:183-278), specialised for
-//     B*L == 4 * LPR with LPR in {16, 32, 64},  L a power of two >= 4,  weightings laid out [h][b][a],
-//     A <= 4, weight nonlinearity in {none, sigmoid, hardtanh}
-// -- which covers the north-star shape (d=128, H=8, B=4, A=4: LPR=16, L=16).
+//     L a multiple of 4,  B a power of two,  S = B*L/4 <= 64 basis slots per row,  weightings laid out
+//     [h][b][a],  A <= 4,  weight nonlinearity in {none, sigmoid, hardtanh}
+// -- the north-star shape (d=128, H=8, B=4, A=4: S = 16, L = 16) and e.g. the reference's ogbn-mag layer
+// (352/H8/B4: L = 44, S = 44) and its molhiv EGC-M layer (224/H4/B4: L = 56, S = 56).  A row occupies a lane
+// group of LPR = 16 / 32 / 64 lanes (the power of two >= S; lanes S..LPR-1 idle); when L/4 is a power of
+// two the lane <-> (basis, channel) arithmetic is shifts and the sum over bases a DPP / xor butterfly,
+// otherwise a division and a rotation butterfly over the S live lanes.
 //
 // Work decomposition -- ONE launch, two roles selected by blockIdx:
 //   * short rows (<= EGC_LONG_ROW_THRESHOLD entries): one LANE GROUP per row.  A basis row is LPR
@@ -54,6 +58,8 @@ struct RtCfg {
   static __device__ inline int W(const AggArgs& a) { return a.W; }
   static __device__ inline int F_out(const AggArgs& a) { return a.F_out; }
   static __device__ inline int lpb_log2(const AggArgs& a) { return a.lpb_log2; }
+  static __device__ inline bool pow2(const AggArgs& a) { return a.lpb_log2 >= 0; }
+  static __device__ inline int slots(const AggArgs& a) { return a.slots; }
   static __device__ inline int act(const AggArgs& a) { return a.act; }
   static __device__ inline bool xl(const AggArgs& a) { return a.x_looped != 0; }
   static __device__ inline bool yl(const AggArgs& a) { return a.y_looped != 0; }
@@ -80,6 +86,8 @@ struct StCfg {
   static __device__ inline constexpr int W(const AggArgs&) { return H_ * B_ * A_; }
   static __device__ inline constexpr int F_out(const AggArgs&) { return H_ * L_; }
   static __device__ inline constexpr int lpb_log2(const AggArgs&) { return ilog2(L_ / 4); }
+  static __device__ inline constexpr bool pow2(const AggArgs&) { return true; }
+  static __device__ inline constexpr int slots(const AggArgs&) { return B_ * L_ / 4; }
   static __device__ inline constexpr int act(const AggArgs&) { return ACT_; }
   static __device__ inline constexpr bool xl(const AggArgs&) { return XL_; }
   static __device__ inline constexpr bool yl(const AggArgs&) { return YL_; }
@@ -229,9 +237,17 @@ __device__ inline void finish_group(const AggArgs& a, const FastRsrc& R, int lan
   constexpr int LPR = 1 << LPR_LOG2;
   const int g = lane >> LPR_LOG2;
   const int q = lane & (LPR - 1);
-  const int b = q >> C::lpb_log2(a);
-  const int l4 = q & ((1 << C::lpb_log2(a)) - 1);
   const int A = C::A(a), B = C::B(a), H = C::H(a), W = C::W(a);
+  // lane q <-> (basis b, channels 4 l4 .. 4 l4 + 3); lanes q >= S hold no slot
+  int b, l4;
+  const bool live = q < C::slots(a);
+  if (C::pow2(a)) {
+    b = min(q >> C::lpb_log2(a), B - 1);
+    l4 = q & ((1 << C::lpb_log2(a)) - 1);
+  } else {
+    b = min((int)__umulhi((unsigned)q, a.magic_P), B - 1);
+    l4 = q - b * a.lanes_pb;
+  }
 
   // (1) the row's weightings (nonlinearity applied) -> this group's LDS strip, 32 bytes per lane
   float* wl = lds_w + g * a.w_lds_stride;
@@ -259,7 +275,7 @@ __device__ inline void finish_group(const AggArgs& a, const FastRsrc& R, int lan
   } else if (C::yl(a)) {
     acc.ws = f4_fma(splat(dis_i * dis_i), vself, acc.ws);
   }
-  if (a.stats != nullptr && store && row_ok) {  // training forward: keep the raw aggregates for the backward
+  if (a.stats != nullptr && store && row_ok && live) {  // training forward: keep the raw aggregates for the backward
     float* st = a.stats + ((int64_t)row * a.stat_k) * a.ldb + 4 * q;
     if (a.stat_slot[STAT_SUM] >= 0) *reinterpret_cast<f4*>(st + a.stat_slot[STAT_SUM] * a.ldb) = acc.sum;
     if (a.stat_slot[STAT_MX] >= 0) *reinterpret_cast<f4*>(st + a.stat_slot[STAT_MX] * a.ldb) = acc.mx;
@@ -323,10 +339,18 @@ __device__ inline void finish_group(const AggArgs& a, const FastRsrc& R, int lan
         if (A > 1) part = f4_fma(splat(wp[1]), val[1], part);
         if (A > 2) part = f4_fma(splat(wp[2]), val[2], part);
       }
-      if (LPR == 16 && C::lpb_log2(a) == 2) {
+      if (!C::pow2(a)) {
+        // rotation butterfly over the S live lanes of the group: after log2(B) steps every lane holds the sum
+        // over the B lanes that share its l4
+        for (int rot = a.lanes_pb; rot < a.slots; rot <<= 1) {
+          int src = q + rot;
+          src = src >= a.slots ? src - a.slots : src;
+          part += bperm(((g << LPR_LOG2) + (live ? src : q)) << 2, part);
+        }
+      } else if (LPR == 16 && C::lpb_log2(a) == 2 && C::slots(a) == 16) {
         dpp_sum_over_4_bases(part);  // 4 bases x 4 slots inside one 16-lane DPP row: no LDS traffic
       } else {
-        for (int off = 1 << C::lpb_log2(a); off < LPR; off <<= 1) part += bperm((lane ^ off) << 2, part);
+        for (int off = 1 << C::lpb_log2(a); off < C::slots(a); off <<= 1) part += bperm((lane ^ off) << 2, part);
       }
       if (b == bb) o[hb] = part;
     }
@@ -336,7 +360,7 @@ __device__ inline void finish_group(const AggArgs& a, const FastRsrc& R, int lan
 #pragma unroll
   for (int hb = 0; hb < HPB; ++hb) {
     const int h = hb * B + b;
-    const bool mine = store && row_ok && h < H;
+    const bool mine = store && row_ok && live && h < H;
     const int oc = h * C::L(a) + 4 * l4;
     const f4 r = o[hb] + *reinterpret_cast<const f4*>(lds_bias + (mine ? oc : 0));
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, r), R.out, mine ? orow + (unsigned)oc * 4u : OOB, 0, 0);
@@ -354,7 +378,7 @@ __device__ inline void load_row_operands(const AggArgs& a, const FastRsrc& R, in
   const int nloop = C::loops_all(a) ? a.n_nodes : (*a.max_index + 1);
   has_self = row_ok && row < nloop;
   const bool want_self = (C::xl(a) || C::yl(a)) && has_self;
-  vself = load_slot(R.bases, want_self ? (unsigned)row * (unsigned)a.ldb * 4u + (unsigned)q * 16u : OOB);
+  vself = load_slot(R.bases, (want_self && q < a.slots) ? (unsigned)row * (unsigned)a.ldb * 4u + (unsigned)q * 16u : OOB);
   const float* wrow = a.weightings + (int64_t)(row_ok ? row : 0) * W;
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
@@ -389,6 +413,7 @@ __global__ void __launch_bounds__(256) agg_fast_kernel(AggArgs a) {
   const int q = lane & (LPR - 1);
   const unsigned slot_off = (unsigned)q * 16u;
   const unsigned row_bytes = (unsigned)a.ldb * 4u;
+  const bool lane_live = q < C::slots(a);  // lanes beyond the row's S slots gather nothing
   const int F_out = C::F_out(a);
   // per-wavefront LDS: [bias F_out][G weight strips]
   float* lds_bias = smem + wave * a.lds_floats_per_wave;
@@ -435,7 +460,8 @@ __global__ void __launch_bounds__(256) agg_fast_kernel(AggArgs a) {
       if (looped_any) nself += __popcll(__ballot(pv && jj == row));
       const int cnt = min(64, end - base);
       for (int t0 = 0; t0 < cnt; t0 += FU * G)
-        gather_batch<NEED, C>(a, R, acc, (g + t0) << 2, G << 2, row, jj, dd, dis_i, cnt, t0 + g, G, row_bytes, slot_off);
+        gather_batch<NEED, C>(a, R, acc, (g + t0) << 2, G << 2, row, jj, dd, dis_i, lane_live ? cnt : 0, t0 + g, G, row_bytes,
+                              slot_off);
     }
     all_reduce_groups<LPR_LOG2, NEED>(acc, lane);
     if (nch > 1) {
@@ -446,7 +472,7 @@ __global__ void __launch_bounds__(256) agg_fast_kernel(AggArgs a) {
       constexpr int WT = 0x11;  // aux bits: sc0 | sc1
       const __amdgpu_buffer_rsrc_t pw = __builtin_amdgcn_make_buffer_rsrc(
           (void*)(reinterpret_cast<f4*>(a.partial) + (int64_t)c * 5 * LPR), 0, 5u * LPR * 16u, 0x00020000);
-      const unsigned po = g == 0 ? (unsigned)q * 16u : OOB;
+      const unsigned po = (g == 0 && lane_live) ? (unsigned)q * 16u : OOB;
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, acc.sum), pw, po, 0 * LPR * 16, WT);
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, acc.mx), pw, po, 2 * LPR * 16, WT);
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, acc.ws), pw, po, 4 * LPR * 16, WT);
@@ -478,7 +504,7 @@ __global__ void __launch_bounds__(256) agg_fast_kernel(AggArgs a) {
 #pragma unroll
         for (int m = 0; m < MU; ++m) {
           const int kk = k0 + m * G;
-          const unsigned off = kk < nch ? ((unsigned)kk * 5u * LPR + (unsigned)q) * 16u : OOB;
+          const unsigned off = (kk < nch && lane_live) ? ((unsigned)kk * 5u * LPR + (unsigned)q) * 16u : OOB;
           rs[m] = load_slot_wt(prs, off);
           rm[m] = load_slot_wt(prs, off == OOB ? OOB : off + 2u * LPR * 16u);
           rw[m] = load_slot_wt(prs, off == OOB ? OOB : off + 4u * LPR * 16u);
@@ -568,7 +594,8 @@ __global__ void __launch_bounds__(256) agg_fast_kernel(AggArgs a) {
       }
       const int cnt = min(LPR, maxd - ts);  // wave-uniform
       for (int t0 = 0; t0 < cnt; t0 += FU)
-        gather_batch<NEED, C>(a, R, acc, grp_addr + (t0 << 2), 4, row, jj, dd, dis_i, nd, ts + t0, 1, row_bytes, slot_off);
+        gather_batch<NEED, C>(a, R, acc, grp_addr + (t0 << 2), 4, row, jj, dd, dis_i, lane_live ? nd : 0, ts + t0, 1, row_bytes,
+                              slot_off);
     }
     // Opaque copy of the lane id: keeps the compiler from hoisting the epilogue's lane arithmetic out
     // of the row loop, where it would stay live across the gathers and cost occupancy.
@@ -588,12 +615,12 @@ __global__ void __launch_bounds__(256) agg_fast_kernel(AggArgs a) {
 bool fast_path_supported(const AggArgs& a, int layout, int chunks) {
   if (chunks != 1 || layout != EGC_LAYOUT_HBA || a.act == EGC_ACT_SOFTMAX) return false;
   if (a.x_looped && !a.y_looped) return false;  // never produced by either layer class
-  if (a.slots != 16 && a.slots != 32 && a.slots != 64) return false;
-  if (a.ldb != a.B * a.L) return false;
-  if (a.L < 4 || (a.L & (a.L - 1)) != 0 || (a.B & (a.B - 1)) != 0) return false;
+  if (a.slots < 1 || a.slots > 64) return false;
+  if (a.ldb != a.B * a.L) return false;  // L % 4 == 0: every 16-byte slot belongs to one basis
+  if (a.L < 4 || (a.L & 3) != 0 || (a.B & (a.B - 1)) != 0) return false;
   if (a.A < 1 || a.A > AMAX) return false;
   if ((a.H + a.B - 1) / a.B > HPB_MAX) return false;
-  if (a.W > 8 * a.slots) return false;  // weightings row staged as 2 x 16 bytes per lane of a group
+  if (a.W > 8 * (a.slots <= 16 ? 16 : a.slots <= 32 ? 32 : 64)) return false;  // weightings row: 2 x 16 bytes per lane of a group
   // the buffer descriptor addresses `out` with 32-bit byte offsets
   if ((uint64_t)a.n_nodes * (uint64_t)a.F_out * 4ull > (uint64_t)OOB) return false;
   return true;
@@ -645,10 +672,18 @@ static bool try_static(const AggArgs& a, int h, int b, int l, int na, unsigned a
     return status;
 
 int launch_fast(AggArgs a, int64_t n_nodes, const PlanCaps& caps, hipStream_t stream) {
-  const int G = 64 / a.slots;
-  int lg = 0;
-  while ((4 << lg) < a.L) ++lg;
-  a.lpb_log2 = lg;
+  const int lpr = a.slots <= 16 ? 16 : a.slots <= 32 ? 32 : 64;
+  const int G = 64 / lpr;
+  // lanes per basis: shifts and an xor butterfly when L / 4 is a power of two, else division + rotation butterfly
+  a.lanes_pb = a.L / 4;
+  a.magic_P = (unsigned)(((uint64_t)1 << 32) / (uint64_t)a.lanes_pb) + 1u;  // q / lanes_pb == umulhi(q, magic_P), q < 64
+  if ((a.lanes_pb & (a.lanes_pb - 1)) == 0) {
+    int lg = 0;
+    while ((4 << lg) < a.L) ++lg;
+    a.lpb_log2 = lg;
+  } else {
+    a.lpb_log2 = -1;
+  }
   if (a.rows_per_wave <= 0) a.rows_per_wave = 1;
   if (a.rows_per_wave * G > 60) a.rows_per_wave = 60 / G;
   a.chunk_blocks = (int)ceil_div(a.n_chunks_hint >= 0 ? a.n_chunks_hint : caps.cap_chunks, 4);
@@ -677,11 +712,10 @@ int launch_fast(AggArgs a, int64_t n_nodes, const PlanCaps& caps, hipStream_t st
     EGC_STATIC_CFG(8, 4, 16, 3, agg_pack(Y, X, M), EGC_ACT_NONE, false, true, true, 0)
     EGC_STATIC_CFG(8, 4, 16, 1, agg_pack(Y), EGC_ACT_NONE, false, true, true, 0)
   }
-  switch (a.slots) {
+  switch (lpr) {
     case 16: return launch_rt<4>(a, need, grid, lds, stream);
     case 32: return launch_rt<5>(a, need, grid, lds, stream);
-    case 64: return launch_rt<6>(a, need, grid, lds, stream);
-    default: return EGC_ERR_UNSUPPORTED;
+    default: return launch_rt<6>(a, need, grid, lds, stream);
   }
 }
 

@@ -137,7 +137,7 @@ def test_training_step_reduces_loss():
     assert losses[-1] < 0.7 * losses[0], losses[::6]
 
 
-@pytest.mark.parametrize("hidden,H,B", [(64, 8, 4), (42, 6, 3)])  # register-resident / generic forward kernels
+@pytest.mark.parametrize("hidden,H,B", [(64, 8, 4), (42, 6, 3), (88, 2, 2)])  # register (2^k) / generic / register (44 slots)
 def test_arg_extrema_match_scatter_arg_bit_exact(hidden, H, B):
     """arg_max / arg_min of the training forward == the `arg` of torch_scatter's scatter_max / scatter_min as
     restated by the oracle (first entry in input order attaining the extremum; E for an empty row there, -1

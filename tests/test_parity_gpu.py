@@ -171,6 +171,30 @@ def test_shipped_and_odd_shapes(hidden, H, B):
     assert rel_err(out, ref) <= TOL
 
 
+@pytest.mark.parametrize("hidden,H,B", [(352, 8, 4), (224, 4, 4), (96, 8, 4), (48, 2, 2), (40, 2, 1), (480, 8, 4)])
+@pytest.mark.parametrize("kind,aggrs", [("opt", ["sum", "mean", "max", "symnorm"]), ("opt", ["min", "std"]),
+                                        ("lay", ["symadd", "max", "mean"]), ("lay", ["add"])])
+def test_register_kernels_on_non_power_of_two_rows(hidden, H, B, kind, aggrs):
+    """L a multiple of 4 but B*L/4 not a power of two (ogbn-mag 352/H8/B4: 44 slots, molhiv 224/H4/B4: 56):
+    idle lanes, division-based lane mapping, rotation butterfly -- short rows, chunked hub rows, and the
+    result must equal the LDS-based generic kernels' bit for bit apart from summation order."""
+    import os
+    dev = _dev()
+    rng = np.random.default_rng(hidden + 13 * len(aggrs))
+    n = 1500
+    ei = _hub_graph(rng, n, 9000, [(0, 2100), (77, 129), (n - 1, 40), (400, 33)])
+    out, ref = _oracle_case(kind, rng, n, ei, hidden, hidden, H, B, aggrs, dev)
+    assert rel_err(out, ref) <= TOL
+    os.environ["EGC_FORCE_GENERIC"] = "1"
+    try:
+        rng = np.random.default_rng(hidden + 13 * len(aggrs))
+        ei = _hub_graph(rng, n, 9000, [(0, 2100), (77, 129), (n - 1, 40), (400, 33)])
+        out_g, _ = _oracle_case(kind, rng, n, ei, hidden, hidden, H, B, aggrs, dev)
+    finally:
+        del os.environ["EGC_FORCE_GENERIC"]
+    assert rel_err(out, out_g) <= 2e-6
+
+
 def test_fin_not_multiple_of_4_and_fin_ne_fout():
     dev = _dev()
     rng = np.random.default_rng(3)
