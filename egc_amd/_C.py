@@ -43,7 +43,7 @@ class EgcLayer(C.Structure):
         ("in_channels", C.c_int32), ("out_channels", C.c_int32), ("num_heads", C.c_int32),
         ("num_bases", C.c_int32), ("num_aggrs", C.c_int32), ("aggrs", C.c_int32 * EGC_MAX_AGGRS),
         ("agg_set", C.c_int32), ("sym_set", C.c_int32), ("loops_all_nodes", C.c_int32),
-        ("weight_layout", C.c_int32), ("weight_act", C.c_int32),
+        ("weight_layout", C.c_int32), ("weight_act", C.c_int32), ("basis_stride", C.c_int32),
     ]
 
 
@@ -118,9 +118,9 @@ def check(status: int, what: str):
 
 
 def make_layer(in_channels, out_channels, num_heads, num_bases, aggr_codes, agg_set, sym_set, loops_all_nodes,
-               weight_layout, weight_act) -> EgcLayer:
+               weight_layout, weight_act, basis_stride=0) -> EgcLayer:
     if len(aggr_codes) > EGC_MAX_AGGRS:
         raise RuntimeError(f"egc_amd: at most {EGC_MAX_AGGRS} aggregators are supported")
     arr = (C.c_int32 * EGC_MAX_AGGRS)(*(list(aggr_codes) + [0] * (EGC_MAX_AGGRS - len(aggr_codes))))
     return EgcLayer(in_channels, out_channels, num_heads, num_bases, len(aggr_codes), arr, agg_set, sym_set,
-                    int(loops_all_nodes), weight_layout, weight_act)
+                    int(loops_all_nodes), weight_layout, weight_act, int(basis_stride))

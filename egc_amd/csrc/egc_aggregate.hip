@@ -194,7 +194,7 @@ __device__ inline void finish_row(const AggArgs& a, __amdgpu_buffer_rsrc_t rsrc,
     for (int t = 0; t < a.A; ++t) {
       const float* agt = ag + t * a.ldb;
       const float* wt = wh + t * a.sa;
-      for (int b = 0; b < a.B; ++b) z = fmaf(wt[b * a.sb], agt[b * a.L], z);
+      for (int b = 0; b < a.B; ++b) z = fmaf(wt[b * a.sb], agt[b * a.Ls], z);
     }
     if (a.bias != nullptr) z += a.bias[o];
     orow[o] = z;
@@ -326,7 +326,9 @@ static int validate_layer(const egc_layer* L) {
   if (L->sym_set != EGC_SET_RAW && L->sym_set != EGC_SET_LOOPED) return EGC_ERR_INVALID;
   if (L->weight_layout != EGC_LAYOUT_HBA && L->weight_layout != EGC_LAYOUT_HAB) return EGC_ERR_INVALID;
   if (L->weight_act < EGC_ACT_NONE || L->weight_act > EGC_ACT_HARDTANH) return EGC_ERR_INVALID;
-  const int64_t fg = (int64_t)L->num_bases * (L->out_channels / L->num_heads);
+  const int len = L->out_channels / L->num_heads;
+  if (L->basis_stride < 0 || (L->basis_stride > len && (L->basis_stride & 3) != 0)) return EGC_ERR_INVALID;
+  const int64_t fg = (int64_t)L->num_bases * layer_basis_stride(L);
   const int64_t w = (int64_t)L->num_heads * L->num_bases * L->num_aggrs;
   if (fg > EGC_MAX_BASIS_WIDTH || w > EGC_MAX_WEIGHT_WIDTH || L->out_channels > EGC_MAX_OUT_CHANNELS)
     return EGC_ERR_UNSUPPORTED;
@@ -370,7 +372,7 @@ extern "C" {
 
 int32_t egc_bases_ld(const egc_layer* layer) {
   if (layer == nullptr || layer->num_heads <= 0) return -1;
-  const int fg = layer->num_bases * (layer->out_channels / layer->num_heads);
+  const int fg = layer->num_bases * layer_basis_stride(layer);
   return (fg + 3) & ~3;
 }
 
@@ -453,6 +455,7 @@ static int aggregate_combine_impl(const egc_graph* graph, const egc_layer* layer
   a.B = layer->num_bases;
   a.A = layer->num_aggrs;
   a.L = layer->out_channels / layer->num_heads;
+  a.Ls = layer_basis_stride(layer);
   a.W = a.H * a.B * a.A;
   for (int t = 0; t < EGC_MAX_AGGRS; ++t) a.aggr[t] = t < a.A ? layer->aggrs[t] : 0;
   a.x_looped = layer->agg_set == EGC_SET_LOOPED;
@@ -507,7 +510,7 @@ int egc_layer_forward_f32(const egc_graph* graph, const egc_layer* layer, const 
   if (graph == nullptr) return EGC_ERR_INVALID;
   int st = validate_layer(layer);
   if (st != EGC_OK) return st;
-  const int fg = layer->num_bases * (layer->out_channels / layer->num_heads);
+  const int fg = layer->num_bases * layer_basis_stride(layer);  // padded bases are GEMM columns too (zero weights)
   const int w = layer->num_heads * layer->num_bases * layer->num_aggrs;
   st = egc_basis_transform_f32(x, wcat, bcat, graph->n_nodes, layer->in_channels, fg, w, bases, ldb, weightings, stream);
   if (st != EGC_OK) return st;
@@ -521,7 +524,7 @@ int egc_layer_forward_packed(const egc_graph* graph, const egc_layer* layer, con
   if (graph == nullptr) return EGC_ERR_INVALID;
   int st = validate_layer(layer);
   if (st != EGC_OK) return st;
-  const int fg = layer->num_bases * (layer->out_channels / layer->num_heads);
+  const int fg = layer->num_bases * layer_basis_stride(layer);  // padded bases are GEMM columns too (zero weights)
   const int w = layer->num_heads * layer->num_bases * layer->num_aggrs;
   st = egc_basis_transform_packed(x, packed, bcat, graph->n_nodes, layer->in_channels, fg, w, bases, ldb, weightings,
                                   stream);

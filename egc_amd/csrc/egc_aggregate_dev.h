@@ -32,6 +32,7 @@ struct AggArgs {
   int n_nodes;
   int ldb, slots;          // slots = ldb / 4
   int F_out, W, H, B, A, L;
+  int Ls;                  // floats between consecutive bases in a row (>= L; == L when contiguous)
   int aggr[EGC_MAX_AGGRS];
   int x_looped, y_looped, loops_all;
   int sa, sb;              // strides of (aggregator, basis) inside one head's weight block

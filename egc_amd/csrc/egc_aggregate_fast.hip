@@ -616,7 +616,7 @@ bool fast_path_supported(const AggArgs& a, int layout, int chunks) {
   if (chunks != 1 || layout != EGC_LAYOUT_HBA || a.act == EGC_ACT_SOFTMAX) return false;
   if (a.x_looped && !a.y_looped) return false;  // never produced by either layer class
   if (a.slots < 1 || a.slots > 64) return false;
-  if (a.ldb != a.B * a.L) return false;  // L % 4 == 0: every 16-byte slot belongs to one basis
+  if (a.Ls != a.L || a.ldb != a.B * a.L) return false;  // L % 4 == 0: every 16-byte slot belongs to one basis
   if (a.L < 4 || (a.L & 3) != 0 || (a.B & (a.B - 1)) != 0) return false;
   if (a.A < 1 || a.A > AMAX) return false;
   if ((a.H + a.B - 1) / a.B > HPB_MAX) return false;

@@ -224,7 +224,7 @@ struct BwdArgs {
   float* tab_n;              // [N, ldb] d agg_min, or nullptr
   const int* t_edge_id;      // transposed entry -> position of the same edge in the destination-side CSR
   int n_nodes, n_src_rows, n_edges;
-  int ldb, slots, F_g, F_out, W, H, B, A, L;
+  int ldb, slots, F_g, F_out, W, H, B, A, L, Ls;  // F_g = B * Ls: bases columns incl. per-basis padding
   int aggr[EGC_MAX_AGGRS];
   int stat_slot[5], stat_k;
   int x_looped, y_looped, loops_all;
@@ -275,6 +275,16 @@ __global__ void __launch_bounds__(256) bwd_dst_kernel(BwdArgs a) {
   for (int c0 = 0; c0 < a.F_g; c0 += 64) {
     const int c = c0 + lane;
     if (c >= a.F_g) continue;
+    const int b = c / a.Ls, l = c - b * a.Ls;
+    if (l >= a.L) {  // padding column of a padded basis: nothing flows through it
+      for (int t = 0; t < a.A; ++t) lds_agg[t * a.ldb + c] = 0.f;
+      a.tab_t[(int64_t)row * a.ldb + c] = 0.f;
+      if (a.tab_s != nullptr) a.tab_s[(int64_t)row * a.ldb + c] = 0.f;
+      if (a.tab_v != nullptr) a.tab_v[(int64_t)row * a.ldb + c] = 0.f;
+      if (a.tab_x != nullptr) a.tab_x[(int64_t)row * a.ldb + c] = 0.f;
+      if (a.tab_n != nullptr) a.tab_n[(int64_t)row * a.ldb + c] = 0.f;
+      continue;
+    }
     const float sum = a.stat_slot[STAT_SUM] >= 0 ? st[a.stat_slot[STAT_SUM] * a.ldb + c] : 0.f;
     const float sq = a.stat_slot[STAT_SQ] >= 0 ? st[a.stat_slot[STAT_SQ] * a.ldb + c] : 0.f;
     const float mx = a.stat_slot[STAT_MX] >= 0 ? st[a.stat_slot[STAT_MX] * a.ldb + c] : 0.f;
@@ -297,7 +307,6 @@ __global__ void __launch_bounds__(256) bwd_dst_kernel(BwdArgs a) {
       lds_agg[t * a.ldb + c] = val;
     }
     // d agg_t[c] = sum_h w'[h][b][t] * g[h*L + l]
-    const int b = c / a.L, l = c - b * a.L;
     float d_t = 0.f, d_s = 0.f, d_v = 0.f;
     for (int t = 0; t < a.A; ++t) {
       float d = 0.f;
@@ -323,7 +332,7 @@ __global__ void __launch_bounds__(256) bwd_dst_kernel(BwdArgs a) {
   for (int k = lane; k < a.W; k += 64) {
     const int h = k / AB, r = k - h * AB, b = r / a.A, t = r - b * a.A;
     float d = 0.f;
-    for (int l = 0; l < a.L; ++l) d = fmaf(lds_g[h * a.L + l], lds_agg[t * a.ldb + b * a.L + l], d);
+    for (int l = 0; l < a.L; ++l) d = fmaf(lds_g[h * a.L + l], lds_agg[t * a.ldb + b * a.Ls + l], d);
     lds_dagg[k] = d;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -558,7 +567,8 @@ int egc_aggregate_combine_backward_f32(const egc_graph* graph, const egc_graph* 
   a.B = layer->num_bases;
   a.A = layer->num_aggrs;
   a.L = layer->out_channels / layer->num_heads;
-  a.F_g = a.B * a.L;
+  a.Ls = layer_basis_stride(layer);
+  a.F_g = a.B * a.Ls;
   a.F_out = layer->out_channels;
   a.W = a.H * a.B * a.A;
   bool sym = false, var = false;

@@ -32,6 +32,12 @@ void set_last_error(const char* what, hipError_t err);
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// floats between consecutive bases of a `bases` row (egc_layer.basis_stride; 0 = contiguous)
+static inline int layer_basis_stride(const egc_layer* L) {
+  const int len = L->out_channels / L->num_heads;
+  return L->basis_stride > len ? L->basis_stride : len;
+}
+
 static inline bool layer_uses_symnorm(const egc_layer* L) {
   for (int t = 0; t < L->num_aggrs; ++t)
     if (L->aggrs[t] == EGC_AGGR_SYMNORM) return true;

@@ -23,20 +23,41 @@ class LayerSpec:
     c: _C.EgcLayer
     f_in: int
     f_out: int
-    f_g: int      # B * (F_out / H)
+    f_g: int      # bases columns of the GEMM: B * basis_stride (= B * F_out / H when the bases are contiguous)
     w_cols: int   # H * B * A
+    basis_len: int = 0      # L = F_out / H
+    basis_stride: int = 0   # floats between consecutive bases inside a row (>= L)
 
     @property
     def ldb(self) -> int:
         return (self.f_g + 3) & ~3
 
 
+def padded_basis_stride(out_channels: int, num_heads: int, num_bases: int) -> int:
+    """Basis stride the layers use: L itself when it is a multiple of 4; otherwise L rounded up to 4 -- each
+    basis then owns whole 16-byte slots and the register-resident kernels apply -- as long as the padded row
+    still fits their 64 slots (beyond that the LDS-based kernels run either way and padding buys nothing)."""
+    L = out_channels // num_heads
+    Lp = (L + 3) & ~3
+    return Lp if (Lp != L and num_bases * Lp <= 256) else L
+
+
+def pad_bases_columns(w: torch.Tensor, num_bases: int, basis_len: int, basis_stride: int) -> torch.Tensor:
+    """[F_in, B * L] -> [F_in, B * stride]: zero weight columns after every basis (differentiable), so the
+    GEMM itself writes the padded `bases` layout."""
+    if basis_stride == basis_len:
+        return w
+    f_in = w.size(0)
+    return torch.nn.functional.pad(w.reshape(f_in, num_bases, basis_len), (0, basis_stride - basis_len)).reshape(f_in, -1)
+
+
 def make_spec(in_channels, out_channels, num_heads, num_bases, aggr_codes, agg_set, sym_set, loops_all_nodes,
-              weight_layout, weight_act) -> LayerSpec:
+              weight_layout, weight_act, basis_stride: int = 0) -> LayerSpec:
+    L = out_channels // num_heads
+    stride = basis_stride if basis_stride > L else L
     c = _C.make_layer(in_channels, out_channels, num_heads, num_bases, aggr_codes, agg_set, sym_set,
-                      loops_all_nodes, weight_layout, weight_act)
-    return LayerSpec(c, in_channels, out_channels, num_bases * (out_channels // num_heads),
-                     num_heads * num_bases * len(aggr_codes))
+                      loops_all_nodes, weight_layout, weight_act, stride if stride != L else 0)
+    return LayerSpec(c, in_channels, out_channels, num_bases * stride, num_heads * num_bases * len(aggr_codes), L, stride)
 
 
 def _check_f32(t, name, shape=None):

@@ -19,7 +19,8 @@ import torch
 import torch.nn as nn
 
 from . import _C
-from .functional import egc_layer_apply, gemm_exact, make_spec, pack_weights
+from .functional import (egc_layer_apply, gemm_exact, make_spec, pack_weights, pad_bases_columns,
+                         padded_basis_stride)
 from .graph import SparseTensor, graph_from_input
 
 _AGGR_CODE = {"add": _C.AGGR_SUM, "mean": _C.AGGR_MEAN, "max": _C.AGGR_MAX, "min": _C.AGGR_MIN,
@@ -79,7 +80,8 @@ class EfficientGraphConv(nn.Module):
         self._spec = make_spec(
             in_channels, out_channels, num_heads, num_bases, [_AGGR_CODE[a] for a in aggrs],
             agg_set=_C.SET_RAW, sym_set=_C.SET_LOOPED if add_self_loops else _C.SET_RAW, loops_all_nodes=True,
-            weight_layout=_C.LAYOUT_HBA, weight_act=act)
+            weight_layout=_C.LAYOUT_HBA, weight_act=act,
+            basis_stride=padded_basis_stride(out_channels, num_heads, num_bases))
         self._cached_graph = None
         self._wcat_key, self._wcat, self._planes = None, None, None
         self.reset_parameters()
@@ -94,14 +96,19 @@ class EfficientGraphConv(nn.Module):
         self._wcat_key, self._wcat, self._planes = None, None, None
 
     # [bases_weight.0 | ... | bases_weight.B-1 | comb_weights.weight^T], rebuilt when a parameter changes
+    def _cat_weights(self):
+        sp = self._spec
+        bases = pad_bases_columns(torch.cat(list(self.bases_weight), dim=1), self.num_bases, sp.basis_len, sp.basis_stride)
+        return torch.cat([bases, self.comb_weights.weight.t()], dim=1)
+
     def _packed_weights(self):
         params = list(self.bases_weight) + [self.comb_weights.weight]
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
-            return torch.cat([*self.bases_weight, self.comb_weights.weight.t()], dim=1)
+            return self._cat_weights()
         key = tuple((p.data_ptr(), p._version) for p in params)
         if key != self._wcat_key:
             with torch.no_grad():
-                self._wcat = torch.cat([*self.bases_weight, self.comb_weights.weight.t()], dim=1).contiguous()
+                self._wcat = self._cat_weights().contiguous()
             self._wcat_key = key
             self._planes = None
         return self._wcat

@@ -22,7 +22,8 @@ import torch
 import torch.nn as nn
 
 from . import _C
-from .functional import egc_layer_apply, gemm_exact, make_spec, pack_weights
+from .functional import (egc_layer_apply, gemm_exact, make_spec, pack_weights, pad_bases_columns,
+                         padded_basis_stride)
 from .graph import CSRGraph, SparseTensor, graph_from_input
 from .layers import glorot_
 
@@ -64,7 +65,8 @@ class EGConv(nn.Module):
         # The weightings tensor is an internal intermediate, so its column order is ours to choose: the
         # comb_weight rows are permuted from the reference's h*A*B + a*B + b (optimized_layers.py:195-202)
         # to h*B*A + b*A + a when packed, which lets the kernel fetch w[h][b][0..A) with one 16-byte load.
-        common = dict(weight_layout=_C.LAYOUT_HBA, weight_act=act)
+        common = dict(weight_layout=_C.LAYOUT_HBA, weight_act=act,
+                      basis_stride=padded_basis_stride(out_channels, num_heads, num_bases))
         # COO input: loops for every node only when gcn_norm (which knows num_nodes) adds them
         self._spec_coo = make_spec(in_channels, out_channels, num_heads, num_bases, codes, agg_set=edge_set,
                                    sym_set=edge_set, loops_all_nodes=has_sym, **common)
@@ -87,7 +89,9 @@ class EGConv(nn.Module):
         H, A, B, F = self.num_heads, len(self.aggregators), self.num_bases, self.in_channels
         w = self.comb_weight.weight.view(H, A, B, F).permute(0, 2, 1, 3).reshape(H * B * A, F)
         b = self.comb_weight.bias.view(H, A, B).permute(0, 2, 1).reshape(H * B * A)
-        return torch.cat([self.bases_weight, w.t()], dim=1).contiguous(), b.contiguous()
+        sp = self._spec_coo
+        bases = pad_bases_columns(self.bases_weight, B, sp.basis_len, sp.basis_stride)
+        return torch.cat([bases, w.t()], dim=1).contiguous(), b.contiguous()
 
     def _packed_weights(self):
         """([bases_weight | permuted comb_weight.weight^T], permuted comb_weight.bias), cached until a

@@ -131,6 +131,11 @@ typedef struct {
                                      add_remaining_self_loops without num_nodes, optimized_layers.py:164 */
   int32_t weight_layout;          /* egc_weight_layout */
   int32_t weight_act;             /* egc_weight_act */
+  int32_t basis_stride;           /* floats from one basis to the next inside a `bases` row: 0 (or L = F_out / H)
+                                     = contiguous, as torch.matmul(x, bases_weight) lays them out; a multiple of 4
+                                     >= L = each basis padded with zero columns to 16-byte slots, which lets the
+                                     register-resident kernels serve L that is not a multiple of 4 (the caller pads
+                                     bases_weight with zero columns; egc_bases_ld() reports the row length) */
 } egc_layer;
 
 /* Leading dimension (floats) the library wants for the `bases` intermediate: B*L rounded up to 4. */

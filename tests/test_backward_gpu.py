@@ -155,9 +155,9 @@ def test_arg_extrema_match_scatter_arg_bit_exact(hidden, H, B):
     bases_np[rng.integers(0, n, size=150)] = bases_np[7]      # exact ties between many sources
     conv = egc_amd.EfficientGraphConv(hidden, hidden, num_heads=H, num_bases=B, softmax_weights=False, aggrs=["max", "min"])
     spec = conv._spec
-    ldb = spec.ldb
+    ldb, L, Ls = spec.ldb, spec.basis_len, spec.basis_stride   # each basis may be padded to whole 16-byte slots
     bases = torch.zeros(n, ldb)
-    bases[:, :f_g] = torch.from_numpy(bases_np)
+    bases[:, :B * Ls].view(n, B, Ls)[:, :, :L] = torch.from_numpy(bases_np).view(n, B, L)
     g = egc_amd.CSRGraph.from_edge_index(torch.from_numpy(ei).to(dev), n)
     wt = torch.randn(n, spec.w_cols, device=dev)
     _, (stats, cnt, arg_max, arg_min) = egc_aggregate_combine_train(g, spec, bases.to(dev), wt, None)
@@ -165,7 +165,7 @@ def test_arg_extrema_match_scatter_arg_bit_exact(hidden, H, B):
     e = ei.shape[1]
     for name, arg in (("max", arg_max), ("min", arg_min)):
         _, ref = orc.scatter(bases_np[ei[0]], ei[1], n, name)
-        got = arg.cpu().numpy()[:, :f_g]
+        got = arg.cpu()[:, :B * Ls].view(n, B, Ls)[:, :, :L].reshape(n, f_g).numpy()
         got_edges = np.where(got >= 0, edge_id[np.clip(got, 0, e - 1)], e)   # CSR position -> input edge; empty -> E
         assert np.array_equal(got_edges, ref), name
     deg = np.bincount(ei[1], minlength=n)
