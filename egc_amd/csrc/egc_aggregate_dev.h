@@ -51,6 +51,7 @@ struct AggArgs {
   int need_mean, need_var;
   int n_chunks_hint;       // host-known number of long-row chunks, or -1 (launch for the capacity)
   int w_lds_stride;        // floats between the per-group weight strips in LDS
+  int bias_lds_floats;     // floats of the per-wavefront bias strip in LDS
   // training forward only (egc_aggregate_combine_train_f32): the row's raw running aggregates, after the
   // self-loop term, as [n_nodes][stat_k][ldb], and its entry count -- what the backward needs instead of a
   // second gather.  stat_slot[s] = position of statistic s (STAT_*) inside a row's block, or -1.

@@ -60,6 +60,7 @@ struct RtCfg {
   static __device__ inline int lpb_log2(const AggArgs& a) { return a.lpb_log2; }
   static __device__ inline bool pow2(const AggArgs& a) { return a.lpb_log2 >= 0; }
   static __device__ inline int slots(const AggArgs& a) { return a.slots; }
+  static __device__ inline bool padded(const AggArgs& a) { return a.Ls != a.L; }  // bases padded to whole slots
   static __device__ inline int act(const AggArgs& a) { return a.act; }
   static __device__ inline bool xl(const AggArgs& a) { return a.x_looped != 0; }
   static __device__ inline bool yl(const AggArgs& a) { return a.y_looped != 0; }
@@ -88,6 +89,7 @@ struct StCfg {
   static __device__ inline constexpr int lpb_log2(const AggArgs&) { return ilog2(L_ / 4); }
   static __device__ inline constexpr bool pow2(const AggArgs&) { return true; }
   static __device__ inline constexpr int slots(const AggArgs&) { return B_ * L_ / 4; }
+  static __device__ inline constexpr bool padded(const AggArgs&) { return false; }
   static __device__ inline constexpr int act(const AggArgs&) { return ACT_; }
   static __device__ inline constexpr bool xl(const AggArgs&) { return XL_; }
   static __device__ inline constexpr bool yl(const AggArgs&) { return YL_; }
@@ -362,8 +364,21 @@ __device__ inline void finish_group(const AggArgs& a, const FastRsrc& R, int lan
     const int h = hb * B + b;
     const bool mine = store && row_ok && live && h < H;
     const int oc = h * C::L(a) + 4 * l4;
-    const f4 r = o[hb] + *reinterpret_cast<const f4*>(lds_bias + (mine ? oc : 0));
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, r), R.out, mine ? orow + (unsigned)oc * 4u : OOB, 0, 0);
+    if (!C::padded(a)) {
+      const f4 r = o[hb] + *reinterpret_cast<const f4*>(lds_bias + (mine ? oc : 0));
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, r), R.out, mine ? orow + (unsigned)oc * 4u : OOB, 0, 0);
+    } else {
+      // padded bases (L % 4 != 0): the bias strip is padded the same way, head rows are only 4-byte aligned
+      // and the last slot of a head is ragged -> four dword stores, out-of-range where the channel does not exist
+      const f4 r = o[hb] + *reinterpret_cast<const f4*>(lds_bias + (mine ? h * a.Ls + 4 * l4 : 0));
+      const float rx = r.x, ry = r.y, rz = r.z, rw = r.w;  // (bit_cast of a vector-element expression picks element 0)
+      const int left = mine ? C::L(a) - 4 * l4 : 0;
+      const unsigned base = orow + (unsigned)oc * 4u;
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rx), R.out, left > 0 ? base : OOB, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ry), R.out, left > 1 ? base + 4u : OOB, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rz), R.out, left > 2 ? base + 8u : OOB, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rw), R.out, left > 3 ? base + 12u : OOB, 0, 0);
+    }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // strip reads done before the next row overwrites it
 }
@@ -417,8 +432,15 @@ __global__ void __launch_bounds__(256) agg_fast_kernel(AggArgs a) {
   const int F_out = C::F_out(a);
   // per-wavefront LDS: [bias F_out][G weight strips]
   float* lds_bias = smem + wave * a.lds_floats_per_wave;
-  float* lds_w = lds_bias + ((F_out + 3) & ~3);
-  for (int o = lane; o < F_out; o += 64) lds_bias[o] = a.bias != nullptr ? a.bias[o] : 0.f;
+  float* lds_w = lds_bias + a.bias_lds_floats;
+  if (!C::padded(a)) {
+    for (int o = lane; o < F_out; o += 64) lds_bias[o] = a.bias != nullptr ? a.bias[o] : 0.f;
+  } else {  // bias strip in the padded head layout [h][Ls]
+    for (int o = lane; o < C::H(a) * a.Ls; o += 64) {
+      const int h = o / a.Ls, l = o - h * a.Ls;
+      lds_bias[o] = (a.bias != nullptr && l < C::L(a)) ? a.bias[h * C::L(a) + l] : 0.f;
+    }
+  }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   FastRsrc R;
   R.bases = bases_rsrc(a);
@@ -616,8 +638,8 @@ bool fast_path_supported(const AggArgs& a, int layout, int chunks) {
   if (chunks != 1 || layout != EGC_LAYOUT_HBA || a.act == EGC_ACT_SOFTMAX) return false;
   if (a.x_looped && !a.y_looped) return false;  // never produced by either layer class
   if (a.slots < 1 || a.slots > 64) return false;
-  if (a.Ls != a.L || a.ldb != a.B * a.L) return false;  // L % 4 == 0: every 16-byte slot belongs to one basis
-  if (a.L < 4 || (a.L & 3) != 0 || (a.B & (a.B - 1)) != 0) return false;
+  if ((a.Ls & 3) != 0 || a.ldb != a.B * a.Ls) return false;  // every 16-byte slot belongs to one basis
+  if ((a.B & (a.B - 1)) != 0) return false;
   if (a.A < 1 || a.A > AMAX) return false;
   if ((a.H + a.B - 1) / a.B > HPB_MAX) return false;
   if (a.W > 8 * (a.slots <= 16 ? 16 : a.slots <= 32 ? 32 : 64)) return false;  // weightings row: 2 x 16 bytes per lane of a group
@@ -660,7 +682,7 @@ static bool try_static(const AggArgs& a, int h, int b, int l, int na, unsigned a
   for (int t = 0; t < a.A; ++t) packed |= (unsigned)a.aggr[t] << (3 * t);
   if (a.H != h || a.B != b || a.L != l || a.A != na || packed != agg || a.act != act ||
       (a.x_looped != 0) != xl || (a.y_looped != 0) != yl || (a.loops_all != 0) != loops_all ||
-      a.slots != (1 << LPR_LOG2))
+      a.slots != (1 << LPR_LOG2) || a.Ls != a.L)
     return false;
   *status = launch_one<LPR_LOG2, HPB, NEED, C>(a, grid, lds, stream);
   return true;
@@ -675,11 +697,11 @@ int launch_fast(AggArgs a, int64_t n_nodes, const PlanCaps& caps, hipStream_t st
   const int lpr = a.slots <= 16 ? 16 : a.slots <= 32 ? 32 : 64;
   const int G = 64 / lpr;
   // lanes per basis: shifts and an xor butterfly when L / 4 is a power of two, else division + rotation butterfly
-  a.lanes_pb = a.L / 4;
+  a.lanes_pb = a.Ls / 4;
   a.magic_P = (unsigned)(((uint64_t)1 << 32) / (uint64_t)a.lanes_pb) + 1u;  // q / lanes_pb == umulhi(q, magic_P), q < 64
   if ((a.lanes_pb & (a.lanes_pb - 1)) == 0) {
     int lg = 0;
-    while ((4 << lg) < a.L) ++lg;
+    while ((4 << lg) < a.Ls) ++lg;
     a.lpb_log2 = lg;
   } else {
     a.lpb_log2 = -1;
@@ -695,7 +717,8 @@ int launch_fast(AggArgs a, int64_t n_nodes, const PlanCaps& caps, hipStream_t st
     if (a.aggr[t] == EGC_AGGR_MIN) need |= NEED_MN;
   }
   a.w_lds_stride = (a.W + 3) & ~3;
-  a.lds_floats_per_wave = ((a.F_out + 3) & ~3) + G * a.w_lds_stride;
+  a.bias_lds_floats = (a.H * a.Ls + 3) & ~3;  // >= F_out: the bias strip follows the (padded) head layout
+  a.lds_floats_per_wave = a.bias_lds_floats + G * a.w_lds_stride;
   const size_t lds = (size_t)4 * a.lds_floats_per_wave * sizeof(float);
   if (lds > 64 * 1024) return EGC_ERR_UNSUPPORTED;
   const int64_t row_blocks = ceil_div(n_nodes, (int64_t)4 * a.rows_per_wave * G);

@@ -171,13 +171,16 @@ def test_shipped_and_odd_shapes(hidden, H, B):
     assert rel_err(out, ref) <= TOL
 
 
-@pytest.mark.parametrize("hidden,H,B", [(352, 8, 4), (224, 4, 4), (96, 8, 4), (48, 2, 2), (40, 2, 1), (480, 8, 4)])
+@pytest.mark.parametrize("hidden,H,B", [(352, 8, 4), (224, 4, 4), (96, 8, 4), (48, 2, 2), (40, 2, 1), (480, 8, 4),
+                                        # L % 4 != 0: per-basis padded rows, ragged head tails
+                                        (184, 8, 4), (168, 8, 4), (124, 4, 4), (136, 4, 4), (21, 1, 1), (6, 2, 1)])
 @pytest.mark.parametrize("kind,aggrs", [("opt", ["sum", "mean", "max", "symnorm"]), ("opt", ["min", "std"]),
                                         ("lay", ["symadd", "max", "mean"]), ("lay", ["add"])])
 def test_register_kernels_on_non_power_of_two_rows(hidden, H, B, kind, aggrs):
-    """L a multiple of 4 but B*L/4 not a power of two (ogbn-mag 352/H8/B4: 44 slots, molhiv 224/H4/B4: 56):
-    idle lanes, division-based lane mapping, rotation butterfly -- short rows, chunked hub rows, and the
-    result must equal the LDS-based generic kernels' bit for bit apart from summation order."""
+    """Slot counts that are not powers of two (ogbn-mag 352/H8/B4: 44 slots, molhiv 224/H4/B4: 56) and basis
+    lengths that are not multiples of 4 (arxiv 184/H8/B4: L = 23, zinc 168/H8/B4: L = 21, ...): idle lanes,
+    division-based lane mapping, rotation butterfly, padded bases with ragged head tails -- short rows, chunked
+    hub rows, and the result must equal the LDS-based generic kernels' apart from summation order."""
     import os
     dev = _dev()
     rng = np.random.default_rng(hidden + 13 * len(aggrs))
