@@ -61,6 +61,9 @@ struct RtCfg {
   static __device__ inline bool pow2(const AggArgs& a) { return a.lpb_log2 >= 0; }
   static __device__ inline int slots(const AggArgs& a) { return a.slots; }
   static __device__ inline bool padded(const AggArgs& a) { return a.Ls != a.L; }  // bases padded to whole slots
+  static __device__ inline int Ls(const AggArgs& a) { return a.Ls; }
+  static __device__ inline int lanes_pb(const AggArgs& a) { return a.lanes_pb; }
+  static __device__ inline int basis_of(const AggArgs& a, int q) { return (int)__umulhi((unsigned)q, a.magic_P); }
   static __device__ inline int act(const AggArgs& a) { return a.act; }
   static __device__ inline bool xl(const AggArgs& a) { return a.x_looped != 0; }
   static __device__ inline bool yl(const AggArgs& a) { return a.y_looped != 0; }
@@ -72,8 +75,11 @@ struct RtCfg {
 constexpr int ilog2(int x) { return x <= 1 ? 0 : 1 + ilog2(x >> 1); }
 
 // AGG packs the aggregator codes, 3 bits each, first aggregator in the low bits.
-template <int H_, int B_, int L_, int A_, unsigned AGG, int ACT_, bool XL_, bool YL_, bool LOOPS_ALL_>
+// LS_ = floats between consecutive bases in a row (L_ rounded up to 4 when the layer pads them).
+template <int H_, int B_, int L_, int A_, unsigned AGG, int ACT_, bool XL_, bool YL_, bool LOOPS_ALL_, int LS_ = L_>
 struct StCfg {
+  static constexpr int P_ = LS_ / 4;                       // lanes per basis
+  static constexpr bool POW2_ = (P_ & (P_ - 1)) == 0;
   static constexpr int agg_at(int t) { return (int)((AGG >> (3 * t)) & 7u); }
   static constexpr bool has(int code) {
     for (int t = 0; t < A_; ++t)
@@ -86,10 +92,13 @@ struct StCfg {
   static __device__ inline constexpr int A(const AggArgs&) { return A_; }
   static __device__ inline constexpr int W(const AggArgs&) { return H_ * B_ * A_; }
   static __device__ inline constexpr int F_out(const AggArgs&) { return H_ * L_; }
-  static __device__ inline constexpr int lpb_log2(const AggArgs&) { return ilog2(L_ / 4); }
-  static __device__ inline constexpr bool pow2(const AggArgs&) { return true; }
-  static __device__ inline constexpr int slots(const AggArgs&) { return B_ * L_ / 4; }
-  static __device__ inline constexpr bool padded(const AggArgs&) { return false; }
+  static __device__ inline constexpr int lpb_log2(const AggArgs&) { return ilog2(P_); }
+  static __device__ inline constexpr bool pow2(const AggArgs&) { return POW2_; }
+  static __device__ inline constexpr int slots(const AggArgs&) { return B_ * P_; }
+  static __device__ inline constexpr bool padded(const AggArgs&) { return LS_ != L_; }
+  static __device__ inline constexpr int Ls(const AggArgs&) { return LS_; }
+  static __device__ inline constexpr int lanes_pb(const AggArgs&) { return P_; }
+  static __device__ inline constexpr int basis_of(const AggArgs&, int q) { return q / P_; }
   static __device__ inline constexpr int act(const AggArgs&) { return ACT_; }
   static __device__ inline constexpr bool xl(const AggArgs&) { return XL_; }
   static __device__ inline constexpr bool yl(const AggArgs&) { return YL_; }
@@ -247,8 +256,8 @@ __device__ inline void finish_group(const AggArgs& a, const FastRsrc& R, int lan
     b = min(q >> C::lpb_log2(a), B - 1);
     l4 = q & ((1 << C::lpb_log2(a)) - 1);
   } else {
-    b = min((int)__umulhi((unsigned)q, a.magic_P), B - 1);
-    l4 = q - b * a.lanes_pb;
+    b = min(C::basis_of(a, q), B - 1);
+    l4 = q - b * C::lanes_pb(a);
   }
 
   // (1) the row's weightings (nonlinearity applied) -> this group's LDS strip, 32 bytes per lane
@@ -344,9 +353,9 @@ __device__ inline void finish_group(const AggArgs& a, const FastRsrc& R, int lan
       if (!C::pow2(a)) {
         // rotation butterfly over the S live lanes of the group: after log2(B) steps every lane holds the sum
         // over the B lanes that share its l4
-        for (int rot = a.lanes_pb; rot < a.slots; rot <<= 1) {
+        for (int rot = C::lanes_pb(a); rot < C::slots(a); rot <<= 1) {
           int src = q + rot;
-          src = src >= a.slots ? src - a.slots : src;
+          src = src >= C::slots(a) ? src - C::slots(a) : src;
           part += bperm(((g << LPR_LOG2) + (live ? src : q)) << 2, part);
         }
       } else if (LPR == 16 && C::lpb_log2(a) == 2 && C::slots(a) == 16) {
@@ -370,7 +379,7 @@ __device__ inline void finish_group(const AggArgs& a, const FastRsrc& R, int lan
     } else {
       // padded bases (L % 4 != 0): the bias strip is padded the same way, head rows are only 4-byte aligned
       // and the last slot of a head is ragged -> four dword stores, out-of-range where the channel does not exist
-      const f4 r = o[hb] + *reinterpret_cast<const f4*>(lds_bias + (mine ? h * a.Ls + 4 * l4 : 0));
+      const f4 r = o[hb] + *reinterpret_cast<const f4*>(lds_bias + (mine ? h * C::Ls(a) + 4 * l4 : 0));
       const float rx = r.x, ry = r.y, rz = r.z, rw = r.w;  // (bit_cast of a vector-element expression picks element 0)
       const int left = mine ? C::L(a) - 4 * l4 : 0;
       const unsigned base = orow + (unsigned)oc * 4u;
@@ -393,7 +402,7 @@ __device__ inline void load_row_operands(const AggArgs& a, const FastRsrc& R, in
   const int nloop = C::loops_all(a) ? a.n_nodes : (*a.max_index + 1);
   has_self = row_ok && row < nloop;
   const bool want_self = (C::xl(a) || C::yl(a)) && has_self;
-  vself = load_slot(R.bases, (want_self && q < a.slots) ? (unsigned)row * (unsigned)a.ldb * 4u + (unsigned)q * 16u : OOB);
+  vself = load_slot(R.bases, (want_self && q < C::slots(a)) ? (unsigned)row * (unsigned)a.ldb * 4u + (unsigned)q * 16u : OOB);
   const float* wrow = a.weightings + (int64_t)(row_ok ? row : 0) * W;
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
@@ -436,8 +445,8 @@ __global__ void __launch_bounds__(256) agg_fast_kernel(AggArgs a) {
   if (!C::padded(a)) {
     for (int o = lane; o < F_out; o += 64) lds_bias[o] = a.bias != nullptr ? a.bias[o] : 0.f;
   } else {  // bias strip in the padded head layout [h][Ls]
-    for (int o = lane; o < C::H(a) * a.Ls; o += 64) {
-      const int h = o / a.Ls, l = o - h * a.Ls;
+    for (int o = lane; o < C::H(a) * C::Ls(a); o += 64) {
+      const int h = o / C::Ls(a), l = o - h * C::Ls(a);
       lds_bias[o] = (a.bias != nullptr && l < C::L(a)) ? a.bias[h * C::L(a) + l] : 0.f;
     }
   }
@@ -676,21 +685,23 @@ constexpr unsigned agg_pack(int a0, int a1 = 0, int a2 = 0, int a3 = 0) {
 // Statically specialised configurations (H, B, L, aggregator list, nonlinearity, edge sets).  Adding a
 // line to launch_fast() buys the constant-folded kernel for that layer; everything else runs RtCfg.
 template <class C, int LPR_LOG2, int HPB, int NEED>
-static bool try_static(const AggArgs& a, int h, int b, int l, int na, unsigned agg, int act, bool xl, bool yl,
+static bool try_static(const AggArgs& a, int h, int b, int l, int ls, int na, unsigned agg, int act, bool xl, bool yl,
                        bool loops_all, unsigned grid, size_t lds, hipStream_t stream, int* status) {
   unsigned packed = 0;
   for (int t = 0; t < a.A; ++t) packed |= (unsigned)a.aggr[t] << (3 * t);
   if (a.H != h || a.B != b || a.L != l || a.A != na || packed != agg || a.act != act ||
       (a.x_looped != 0) != xl || (a.y_looped != 0) != yl || (a.loops_all != 0) != loops_all ||
-      a.slots != (1 << LPR_LOG2) || a.Ls != a.L)
+      a.Ls != ls || a.slots > (1 << LPR_LOG2) || 2 * a.slots <= (1 << LPR_LOG2))
     return false;
   *status = launch_one<LPR_LOG2, HPB, NEED, C>(a, grid, lds, stream);
   return true;
 }
 
+constexpr int lpr_log2_of(int slots) { return slots <= 16 ? 4 : slots <= 32 ? 5 : 6; }
 #define EGC_STATIC_CFG(H, B, L, A, AGG, ACT, XL, YL, LA, NEED)                                                      \
-  if (try_static<StCfg<H, B, L, A, AGG, ACT, XL, YL, LA>, ilog2((B) * (L) / 4), ((H) + (B)-1) / (B), NEED>(         \
-          a, H, B, L, A, AGG, ACT, XL, YL, LA, grid, lds, stream, &status))                                         \
+  if (try_static<StCfg<H, B, L, A, AGG, ACT, XL, YL, LA, ((L) + 3) / 4 * 4>,                                        \
+                 lpr_log2_of((B) * (((L) + 3) / 4)), ((H) + (B)-1) / (B), NEED>(                                   \
+          a, H, B, L, ((L) + 3) / 4 * 4, A, AGG, ACT, XL, YL, LA, grid, lds, stream, &status))                      \
     return status;
 
 int launch_fast(AggArgs a, int64_t n_nodes, const PlanCaps& caps, hipStream_t stream) {
@@ -734,6 +745,13 @@ int launch_fast(AggArgs a, int64_t n_nodes, const PlanCaps& caps, hipStream_t st
     // EfficientGraphConv EGC-M / EGC-S flavours at d=128 (symadd looped, the others raw): layers.py:166-193
     EGC_STATIC_CFG(8, 4, 16, 3, agg_pack(Y, X, M), EGC_ACT_NONE, false, true, true, 0)
     EGC_STATIC_CFG(8, 4, 16, 1, agg_pack(Y), EGC_ACT_NONE, false, true, true, 0)
+    // the reference's trained nets (run_pretrained.sh / output/pretrained.txt), EfficientGraphConv:
+    EGC_STATIC_CFG(8, 4, 23, 1, agg_pack(Y), EGC_ACT_NONE, false, true, true, 0)            // arxiv EGC-S 184/H8/B4 symadd
+    EGC_STATIC_CFG(4, 4, 34, 3, agg_pack(Y, X, M), EGC_ACT_NONE, false, true, true, 0)      // arxiv EGC-M 136/H4/B4
+    EGC_STATIC_CFG(8, 4, 21, 1, agg_pack(Y), EGC_ACT_NONE, false, true, true, 0)            // zinc EGC-S 168/H8/B4 symadd
+    // EGConv on ogbn-mag (mag/models.py:24-53; train_main_table.sh:53-54): 352/H8/B4, symnorm or mean
+    EGC_STATIC_CFG(8, 4, 44, 1, agg_pack(Y), EGC_ACT_NONE, true, true, true, 0)
+    EGC_STATIC_CFG(8, 4, 44, 1, agg_pack(M), EGC_ACT_NONE, true, true, true, 0)
   }
   switch (lpr) {
     case 16: return launch_rt<4>(a, need, grid, lds, stream);
