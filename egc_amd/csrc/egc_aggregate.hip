@@ -219,17 +219,9 @@ __global__ void __launch_bounds__(256) agg_rows_kernel(AggArgs a) {
   Acc<CHUNKS> acc;
   acc.init();
   int nself = 0;
-#ifndef EGC_ABLATE_NO_GATHER
   accumulate_range<CHUNKS, U>(a, rsrc, row, start, end, lane, acc, nself);
-#endif
-#ifndef EGC_ABLATE_NO_REDUCE
   reduce_groups<CHUNKS>(a, acc);
-#endif
-#ifndef EGC_ABLATE_NO_EPILOGUE
   finish_row<CHUNKS>(a, rsrc, row, acc, deg, nself, lane, smem + wave * a.lds_floats_per_wave);
-#else
-  if (lane < 16) *reinterpret_cast<f4*>(a.out + (int64_t)row * a.F_out + 4 * lane) = acc.sum[0] + acc.mx[0] + acc.ws[0] + acc.sq[0] + acc.mn[0];
-#endif
 }
 
 // One wavefront per long-row chunk -> partial record.

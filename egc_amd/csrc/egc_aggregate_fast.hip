@@ -225,11 +225,7 @@ __device__ inline void gather_batch(const AggArgs& a, const FastRsrc& R, FAcc<NE
     const int j = bperm(addr, jj);
     const bool is_self = j == row;
     in_x[u] = (first + u * vstep < n_valid) && !(C::xl(a) && is_self);
-#ifdef EGC_ABL_NOGATHER
-    v[u] = f4{1.f, 2.f, 3.f, (float)j};
-#else
     v[u] = load_slot(R.bases, in_x[u] ? (unsigned)j * row_bytes + slot_off : OOB);
-#endif
     w[u] = bperm(addr, dd) * dis_i;
     if (C::yl(a) && !C::xl(a)) w[u] = is_self ? 0.f : w[u];  // mixed sets: self-entry counts for sum/max only
   }
@@ -424,12 +420,6 @@ template <int LPR_LOG2, int HPB, int NEED, class C>
 __global__ void __launch_bounds__(256) agg_fast_kernel(AggArgs a) {
   constexpr int LPR = 1 << LPR_LOG2, G = 64 / LPR;
   extern __shared__ float smem[];
-#ifdef EGC_ABL_NOCHUNK
-  if ((int)blockIdx.x < a.chunk_blocks) return;
-#endif
-#ifdef EGC_ABL_NOROWS
-  if ((int)blockIdx.x >= a.chunk_blocks) return;
-#endif
   if ((int)blockIdx.x < a.chunk_blocks && (int)blockIdx.x * 4 >= a.plan[1]) return;  // unused chunk slots
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -474,12 +464,6 @@ __global__ void __launch_bounds__(256) agg_fast_kernel(AggArgs a) {
     const int deg = row_end - row_start;
     const int nch = (deg + EGC_LONG_ROW_CHUNK - 1) / EGC_LONG_ROW_CHUNK;
     const float dis_i = a.dis != nullptr ? a.dis[row] : 0.f;
-#ifdef EGC_ABL_C_SINGLE
-    if (nch > 1) return;
-#endif
-#ifdef EGC_ABL_C_MULTI
-    if (nch == 1) return;
-#endif
     FAcc<NEED> acc;
     acc.init();
     int nself = 0;
@@ -606,11 +590,7 @@ __global__ void __launch_bounds__(256) agg_fast_kernel(AggArgs a) {
     f4 wpre[2], vself;
     bool has_self;
     const float dis_i = (a.dis != nullptr && row_ok) ? a.dis[row] : 0.f;
-#ifdef EGC_ABL_NOOPER
-    wpre[0] = wpre[1] = vself = f4{1.f, 1.f, 1.f, 1.f}; has_self = row_ok;
-#else
     load_row_operands<LPR_LOG2, C>(a, R, lane, row, row_ok, wpre, vself, has_self);
-#endif
 
     FAcc<NEED> acc;
     acc.init();
@@ -634,12 +614,8 @@ __global__ void __launch_bounds__(256) agg_fast_kernel(AggArgs a) {
     asm volatile("" : "+v"(ln));
     const int deg_all = bperm((k * G + g + 1) << 2, rp) - start;
     const bool is_short = deg_all <= EGC_LONG_ROW_THRESHOLD;
-#ifdef EGC_ABL_NOEPI
-    if (is_short && row_ok) a.out[(int64_t)row * F_out + q * 4] = acc.sum.x + acc.mx.y + acc.ws.z + wpre[0].x + wpre[1].y + vself.x + nself;
-#else
     finish_group<LPR_LOG2, HPB, NEED, C>(a, R, ln, row, row_ok, acc, nd, nself, dis_i, vself, has_self, wpre, is_short,
                                          lds_w, lds_bias);
-#endif
   }
 }
 

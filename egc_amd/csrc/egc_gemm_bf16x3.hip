@@ -390,24 +390,16 @@ __global__ void __launch_bounds__(512) basis_gemm_ws_kernel(const float* __restr
       const bf16x8 xh = *reinterpret_cast<const bf16x8*>(xb + 16 * s);
       const bf16x8 xm = *reinterpret_cast<const bf16x8*>(xb + 16 * s + WS_ROWS * LDX);
       const bf16x8 xl = *reinterpret_cast<const bf16x8*>(xb + 16 * s + 2 * WS_ROWS * LDX);
-#ifdef EGC_ABL_G_NOMFMA
-      acc[s] += (float)xl[0] + (float)xh[1] + (float)xm[2];
-#else
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][0], xl, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][2], xh, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][1], xm, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][0], xm, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][1], xh, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][0], xh, acc, 0, 0, 0);
-#endif
     }
     // lane (row i = lane&31, half hh) owns columns cb + 8j + 4hh + 0..3, j = 0..3
     const int64_t gm = (int64_t)tile * WS_ROWS + (lane & 31);
-#ifdef EGC_ABL_G_NOSTORE
-    if (gm < M && acc[0] == 123456.f) {
-#else
     if (gm < M) {
-#endif
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int vc = cb + 8 * j + 4 * hh;
@@ -461,9 +453,6 @@ __global__ void __launch_bounds__(512) basis_gemm_ws_kernel(const float* __restr
 
 // RT = 32-row halves per tile (ROWS = 32 RT); DBUF = double-buffered x planes (one barrier per tile) or a
 // single buffer (two barriers per tile, half the LDS: two blocks fit per CU and cover each other's phases).
-#ifdef EGC_GEMM_STAMPS
-__device__ unsigned long long* egc_stamp_buf = nullptr;  // diagnostic build only
-#endif
 
 template <int KSUB, int RT, bool DBUF>
 __global__ void __launch_bounds__(768, 3) basis_gemm_ws2_kernel(const float* __restrict__ x, const u16* __restrict__ packed,
@@ -562,23 +551,15 @@ __global__ void __launch_bounds__(768, 3) basis_gemm_ws2_kernel(const float* __r
       const bf16x8 xm = *reinterpret_cast<const bf16x8*>(xb + 16 * s + WS2_ROWS * LDX);
       const bf16x8 xl = *reinterpret_cast<const bf16x8*>(xb + 16 * s + 2 * WS2_ROWS * LDX);
       const bf16x8 wl = *reinterpret_cast<const bf16x8*>(wlb + 16 * s);
-#ifdef EGC_ABL_G_NOMFMA
-      acc[s] += (float)xl[0] + (float)xh[1] + (float)xm[2] + (float)wl[3];
-#else
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][0], xl, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][1], xm, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][0], xm, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][1], xh, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][0], xh, acc, 0, 0, 0);
-#endif
     }
     const int64_t gm = (int64_t)tile * WS2_ROWS + 32 * rt + (lane & 31);
-#ifdef EGC_ABL_G_NOSTORE
-    const bool row_ok = gm < M && acc[0] == 123456.f;
-#else
     const bool row_ok = gm < M;
-#endif
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int vc = cb + 8 * j + 4 * hh;
@@ -603,32 +584,17 @@ __global__ void __launch_bounds__(768, 3) basis_gemm_ws2_kernel(const float* __r
     stage_tile(0, xr);
     lds_barrier();
     int buf = 0;
-#ifdef EGC_GEMM_STAMPS
-    unsigned long long tsum[4] = {0, 0, 0, 0}, t0, t1;
-#define EGC_STAMP(k) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory"); tsum[k] += t1 - t0; t0 = t1; }
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0) :: "memory");
-#else
-#define EGC_STAMP(k)
-#endif
     for (; tile < n_tiles; tile += stride) {
       load_tile(tile + stride, xr);  // masked (all lanes out of range) past the end
       // keep the prefetch HERE: sunk below the epilogue stores it could only be consumed after
       // s_waitcnt vmcnt(0), i.e. after the stores of this tile have completed
       __builtin_amdgcn_sched_barrier(0);
-      EGC_STAMP(0)
       compute_tile(tile, buf);
       __builtin_amdgcn_sched_barrier(0);
-      EGC_STAMP(1)
       stage_tile(buf ^ 1, xr);       // zeros past the end: harmless, keeps the loop branch-free
-      EGC_STAMP(2)
       lds_barrier();
-      EGC_STAMP(3)
       buf ^= 1;
     }
-#ifdef EGC_GEMM_STAMPS
-    if (lane == 0 && egc_stamp_buf != nullptr)
-      for (int k = 0; k < 4; ++k) egc_stamp_buf[(blockIdx.x * 16 + wave) * 4 + k] = tsum[k];
-#endif
   } else {
     lds_barrier();  // l plane of the weights is in LDS
     for (; tile < n_tiles; tile += stride) {
@@ -666,37 +632,9 @@ static int launch_ws2(const float* x, const u16* packed, const float* bcat, int6
   if (const char* e = getenv("EGC_GEMM_GRID")) grid = atoi(e);
   if (grid > n_tiles) grid = n_tiles;
   const int x_vec4 = (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-#ifdef EGC_GEMM_STAMPS
-  static unsigned long long* dbuf = nullptr;
-  if (dbuf == nullptr) {
-    hipMalloc(&dbuf, 1024 * 16 * 4 * 8);
-    hipMemcpyToSymbol(HIP_SYMBOL(egc_stamp_buf), &dbuf, sizeof(dbuf));
-  }
-  hipMemset(dbuf, 0, 1024 * 16 * 4 * 8);
-#endif
   basis_gemm_ws2_kernel<KSUB, RT, DBUF><<<grid, threads, lds, stream>>>(x, packed, bcat, M, K, W, bases, ldb, weightings,
                                                                        NV, n_tiles, x_vec4);
   EGC_LAUNCH_CHECK("basis_gemm_ws2_kernel");
-#ifdef EGC_GEMM_STAMPS
-  {
-    hipDeviceSynchronize();
-    static int calls = 0;
-    if (++calls == 20) {
-      std::vector<unsigned long long> h(1024 * 16 * 4);
-      hipMemcpy(h.data(), dbuf, h.size() * 8, hipMemcpyDeviceToHost);
-      double sum[4] = {0, 0, 0, 0}; int nw = 0;
-      for (int b = 0; b < grid; ++b)
-        for (int w = 0; w < threads / 64; ++w) {
-          for (int k = 0; k < 4; ++k) sum[k] += (double)h[(b * 16 + w) * 4 + k];
-          ++nw;
-        }
-      const double tiles_per_block = (double)n_tiles / grid;
-      fprintf(stderr, "[stamps] per tile per wave (cycles): load-issue %.0f  mfma+stores %.0f  wait+stage %.0f  barrier %.0f  (tiles/block %.1f)\n",
-              sum[0] / nw / tiles_per_block, sum[1] / nw / tiles_per_block, sum[2] / nw / tiles_per_block,
-              sum[3] / nw / tiles_per_block, tiles_per_block);
-    }
-  }
-#endif
   return EGC_OK;
 }
 
