@@ -47,6 +47,10 @@ class EgcLayer(C.Structure):
     ]
 
 
+class EgcPost(C.Structure):
+    _fields_ = [("scale", C.c_void_p), ("shift", C.c_void_p), ("residual", C.c_void_p), ("relu", C.c_int32)]
+
+
 # name -> (restype, argtypes): exactly the symbols include/egc_hip.h declares
 SYMBOLS = {
     "egc_plan_ints": (C.c_int64, [C.c_int64, C.c_int64]),
@@ -73,6 +77,10 @@ SYMBOLS = {
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_size_t, C.c_void_p]),
     "egc_backward_workspace_bytes": (C.c_size_t, [C.POINTER(EgcLayer), C.c_int64]),
+    "egc_aggregate_combine_post_f32": (C.c_int, [C.POINTER(EgcGraph), C.POINTER(EgcLayer), C.c_void_p, C.c_int32,
+                                                 C.c_void_p, C.c_void_p, C.POINTER(EgcPost), C.c_void_p,
+                                                 C.c_void_p, C.c_size_t, C.c_void_p]),
+    "egc_segment_mean_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "egc_train_stats_floats": (C.c_int64, [C.POINTER(EgcLayer)]),
     "egc_aggregate_combine_train_f32": (C.c_int, [C.POINTER(EgcGraph), C.POINTER(EgcLayer), C.c_void_p, C.c_int32,
                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

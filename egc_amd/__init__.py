@@ -4,6 +4,7 @@ Public surface (mirrors the reference's layer API):
   EfficientGraphConv   drop-in for experiments/layers.py:EfficientGraphConv
   EGConv               drop-in for experiments/optimized_layers.py:EGConv
   REGConv              drop-in for experiments/rmag/models.py:REGConv (relational EGC)
+  FusedEGCBlock        conv -> BatchNorm1d(eval) -> ReLU -> + identity in the kernel's store; global_mean_pool
   SparseTensor         minimal adj_t container (torch_sparse is not required)
   CSRGraph             device CSR + degree statistics + long-row plan
   egc_layer_forward    operator-level call into libegc_hip.so
@@ -13,5 +14,6 @@ from .functional import egc_layer_forward, make_spec, LayerSpec  # noqa: F401
 from .layers import EfficientGraphConv  # noqa: F401
 from .optimized_layers import EGConv  # noqa: F401
 from .relational import REGConv  # noqa: F401
+from .fusion import FusedEGCBlock, global_mean_pool  # noqa: F401
 
 __version__ = "0.1.0"

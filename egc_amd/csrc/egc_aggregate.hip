@@ -197,6 +197,9 @@ __device__ inline void finish_row(const AggArgs& a, __amdgpu_buffer_rsrc_t rsrc,
       for (int b = 0; b < a.B; ++b) z = fmaf(wt[b * a.sb], agt[b * a.Ls], z);
     }
     if (a.bias != nullptr) z += a.bias[o];
+    if (a.post_scale != nullptr) z = fmaf(z, a.post_scale[o], a.post_shift[o]);
+    if (a.post_relu) z = fmaxf(z, 0.f);
+    if (a.residual != nullptr) z += a.residual[(int64_t)row * a.F_out + o];
     orow[o] = z;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -305,6 +308,21 @@ __global__ void __launch_bounds__(256) agg_merge_kernel(AggArgs a) {
   finish_row<CHUNKS>(a, rsrc, row, acc, deg, nself, lane, smem + wave * a.lds_floats_per_wave);
 }
 
+// One wavefront per segment: lanes stride over the columns, rows are summed in order (deterministic).
+__global__ void __launch_bounds__(256) segment_mean_kernel(const float* __restrict__ x, const int64_t* __restrict__ seg_ptr,
+                                                           int64_t n_segments, int width, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= n_segments) return;
+  const int64_t r0 = seg_ptr[g], r1 = seg_ptr[g + 1];
+  const float cnt = (float)(r1 > r0 ? r1 - r0 : 1);  // scatter-mean divides the sum by the count
+  for (int c = lane; c < width; c += 64) {
+    float s = 0.f;
+    for (int64_t r = r0; r < r1; ++r) s += x[r * width + c];
+    out[g * width + c] = s / cnt;
+  }
+}
+
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static int validate_layer(const egc_layer* L) {
@@ -373,6 +391,17 @@ size_t egc_aggregate_workspace_bytes(const egc_layer* layer, int64_t n_nodes, in
   return ws_layout(layer, n_nodes, n_edges).total;
 }
 
+int egc_segment_mean_f32(const float* x, const int64_t* seg_ptr, int64_t n_segments, int32_t width, float* out,
+                         egc_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_segments < 0 || width <= 0 || n_segments >= ((int64_t)1 << 31)) return EGC_ERR_INVALID;
+  if (n_segments == 0) return EGC_OK;
+  if (x == nullptr || seg_ptr == nullptr || out == nullptr) return EGC_ERR_INVALID;
+  segment_mean_kernel<<<(unsigned)ceil_div(n_segments, 4), 256, 0, stream>>>(x, seg_ptr, n_segments, width, out);
+  EGC_LAUNCH_CHECK("segment_mean_kernel");
+  return EGC_OK;
+}
+
 int64_t egc_train_stats_floats(const egc_layer* layer) {
   if (validate_layer(layer) != EGC_OK) return 0;
   int slot[5];
@@ -380,15 +409,24 @@ int64_t egc_train_stats_floats(const egc_layer* layer) {
 }
 
 static int aggregate_combine_impl(const egc_graph* graph, const egc_layer* layer, const float* bases, int32_t ldb,
-                                  const float* weightings, const float* bias, float* out, float* stats,
-                                  int32_t* cnt_out, void* workspace, size_t workspace_bytes, egc_stream_t stream_);
+                                  const float* weightings, const float* bias, const egc_post* post, float* out,
+                                  float* stats, int32_t* cnt_out, void* workspace, size_t workspace_bytes,
+                                  egc_stream_t stream_);
 
 int egc_aggregate_combine_f32(const egc_graph* graph, const egc_layer* layer, const float* bases, int32_t ldb,
                               const float* weightings, const float* bias, float* out, int32_t* arg_max,
                               int32_t* arg_min, void* workspace, size_t workspace_bytes, egc_stream_t stream) {
   // the arg-extremum indices need the extrema themselves: egc_aggregate_combine_train_f32 keeps them
   if (arg_max != nullptr || arg_min != nullptr) return EGC_ERR_UNSUPPORTED;
-  return aggregate_combine_impl(graph, layer, bases, ldb, weightings, bias, out, nullptr, nullptr, workspace,
+  return aggregate_combine_impl(graph, layer, bases, ldb, weightings, bias, nullptr, out, nullptr, nullptr, workspace,
+                                workspace_bytes, stream);
+}
+
+int egc_aggregate_combine_post_f32(const egc_graph* graph, const egc_layer* layer, const float* bases, int32_t ldb,
+                                   const float* weightings, const float* bias, const egc_post* post, float* out,
+                                   void* workspace, size_t workspace_bytes, egc_stream_t stream) {
+  if (post != nullptr && ((post->scale == nullptr) != (post->shift == nullptr))) return EGC_ERR_INVALID;
+  return aggregate_combine_impl(graph, layer, bases, ldb, weightings, bias, post, out, nullptr, nullptr, workspace,
                                 workspace_bytes, stream);
 }
 
@@ -397,15 +435,16 @@ int egc_aggregate_combine_train_f32(const egc_graph* graph, const egc_layer* lay
                                     int32_t* cnt, int32_t* arg_max, int32_t* arg_min, void* workspace,
                                     size_t workspace_bytes, egc_stream_t stream) {
   if (graph == nullptr || layer == nullptr || stats == nullptr || cnt == nullptr) return EGC_ERR_INVALID;
-  int st = aggregate_combine_impl(graph, layer, bases, ldb, weightings, bias, out, stats, cnt, workspace,
+  int st = aggregate_combine_impl(graph, layer, bases, ldb, weightings, bias, nullptr, out, stats, cnt, workspace,
                                   workspace_bytes, stream);
   if (st != EGC_OK) return st;
   return egc::arg_extrema(graph, layer, bases, ldb, stats, cnt, arg_max, arg_min, (hipStream_t)stream);
 }
 
 static int aggregate_combine_impl(const egc_graph* graph, const egc_layer* layer, const float* bases, int32_t ldb,
-                                  const float* weightings, const float* bias, float* out, float* stats,
-                                  int32_t* cnt_out, void* workspace, size_t workspace_bytes, egc_stream_t stream_) {
+                                  const float* weightings, const float* bias, const egc_post* post, float* out,
+                                  float* stats, int32_t* cnt_out, void* workspace, size_t workspace_bytes,
+                                  egc_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (graph == nullptr) return EGC_ERR_INVALID;
   int st = validate_layer(layer);
@@ -456,6 +495,10 @@ static int aggregate_combine_impl(const egc_graph* graph, const egc_layer* layer
   a.act = layer->weight_act;
   a.magic_L = a.L > 1 ? (unsigned)(((uint64_t)1 << 32) / (uint64_t)a.L) + 1u : 0u;  // L == 1: h = o in-kernel
   a.bases_bytes = (unsigned)((uint64_t)n_src * ldb * 4ull);
+  a.post_scale = post != nullptr ? post->scale : nullptr;
+  a.post_shift = post != nullptr ? post->shift : nullptr;
+  a.residual = post != nullptr ? post->residual : nullptr;
+  a.post_relu = post != nullptr && post->relu != 0;
   a.stats = stats;
   a.cnt_out = cnt_out;
   a.stat_k = stat_layout(a.aggr, a.A, a.stat_slot);

@@ -55,6 +55,11 @@ struct AggArgs {
   // training forward only (egc_aggregate_combine_train_f32): the row's raw running aggregates, after the
   // self-loop term, as [n_nodes][stat_k][ldb], and its entry count -- what the backward needs instead of a
   // second gather.  stat_slot[s] = position of statistic s (STAT_*) inside a row's block, or -1.
+  // fused caller-side epilogue (egc_post; all optional): out = act((z + bias) * post_scale + post_shift) + residual
+  const float* post_scale;   // [F_out]
+  const float* post_shift;   // [F_out]
+  const float* residual;     // [n_nodes, F_out]
+  int post_relu;
   float* stats;
   int* cnt_out;
   int stat_slot[5];

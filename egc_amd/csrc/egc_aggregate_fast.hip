@@ -205,7 +205,7 @@ __device__ inline f4 load_slot_wt(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off
 }
 
 struct FastRsrc {
-  __amdgpu_buffer_rsrc_t bases, out;
+  __amdgpu_buffer_rsrc_t bases, out, res;
 };
 
 // Issue + fold one batch of FU wave-instructions.  `addr0` is the ds_bpermute byte address of the lane
@@ -240,7 +240,7 @@ __device__ inline void gather_batch(const AggArgs& a, const FastRsrc& R, FAcc<NE
 template <int LPR_LOG2, int HPB, int NEED, class C>
 __device__ inline void finish_group(const AggArgs& a, const FastRsrc& R, int lane, int row, bool row_ok, FAcc<NEED>& acc,
                                     int deg, int nself, float dis_i, f4 vself, bool has_self, const f4 (&wpre)[2],
-                                    bool store, float* lds_w, const float* lds_bias) {
+                                    bool store, float* lds_w, const float* lds_bias, const float* lds_scale) {
   constexpr int LPR = 1 << LPR_LOG2;
   const int g = lane >> LPR_LOG2;
   const int q = lane & (LPR - 1);
@@ -370,15 +370,26 @@ __device__ inline void finish_group(const AggArgs& a, const FastRsrc& R, int lan
     const bool mine = store && row_ok && live && h < H;
     const int oc = h * C::L(a) + 4 * l4;
     if (!C::padded(a)) {
-      const f4 r = o[hb] + *reinterpret_cast<const f4*>(lds_bias + (mine ? oc : 0));
+      f4 r = o[hb];
+      if (a.post_scale != nullptr) r = r * *reinterpret_cast<const f4*>(lds_scale + (mine ? oc : 0));
+      r = r + *reinterpret_cast<const f4*>(lds_bias + (mine ? oc : 0));
+      if (a.post_relu) r = f4{fmaxf(r.x, 0.f), fmaxf(r.y, 0.f), fmaxf(r.z, 0.f), fmaxf(r.w, 0.f)};
+      if (a.residual != nullptr) r = r + load_slot(R.res, mine ? orow + (unsigned)oc * 4u : OOB);
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, r), R.out, mine ? orow + (unsigned)oc * 4u : OOB, 0, 0);
     } else {
       // padded bases (L % 4 != 0): the bias strip is padded the same way, head rows are only 4-byte aligned
       // and the last slot of a head is ragged -> four dword stores, out-of-range where the channel does not exist
-      const f4 r = o[hb] + *reinterpret_cast<const f4*>(lds_bias + (mine ? h * C::Ls(a) + 4 * l4 : 0));
-      const float rx = r.x, ry = r.y, rz = r.z, rw = r.w;  // (bit_cast of a vector-element expression picks element 0)
+      f4 r = o[hb];
+      if (a.post_scale != nullptr) r = r * *reinterpret_cast<const f4*>(lds_scale + (mine ? h * C::Ls(a) + 4 * l4 : 0));
+      r = r + *reinterpret_cast<const f4*>(lds_bias + (mine ? h * C::Ls(a) + 4 * l4 : 0));
+      if (a.post_relu) r = f4{fmaxf(r.x, 0.f), fmaxf(r.y, 0.f), fmaxf(r.z, 0.f), fmaxf(r.w, 0.f)};
       const int left = mine ? C::L(a) - 4 * l4 : 0;
       const unsigned base = orow + (unsigned)oc * 4u;
+      float rx = r.x, ry = r.y, rz = r.z, rw = r.w;  // (bit_cast of a vector-element expression picks element 0)
+      if (a.residual != nullptr) {
+        const float* rr = a.residual + (int64_t)(mine ? row : 0) * C::F_out(a) + (mine ? oc : 0);
+        rx += left > 0 ? rr[0] : 0.f; ry += left > 1 ? rr[1] : 0.f; rz += left > 2 ? rr[2] : 0.f; rw += left > 3 ? rr[3] : 0.f;
+      }
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rx), R.out, left > 0 ? base : OOB, 0, 0);
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ry), R.out, left > 1 ? base + 4u : OOB, 0, 0);
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rz), R.out, left > 2 ? base + 8u : OOB, 0, 0);
@@ -431,19 +442,28 @@ __global__ void __launch_bounds__(256) agg_fast_kernel(AggArgs a) {
   const int F_out = C::F_out(a);
   // per-wavefront LDS: [bias F_out][G weight strips]
   float* lds_bias = smem + wave * a.lds_floats_per_wave;
-  float* lds_w = lds_bias + a.bias_lds_floats;
-  if (!C::padded(a)) {
-    for (int o = lane; o < F_out; o += 64) lds_bias[o] = a.bias != nullptr ? a.bias[o] : 0.f;
-  } else {  // bias strip in the padded head layout [h][Ls]
-    for (int o = lane; o < C::H(a) * C::Ls(a); o += 64) {
-      const int h = o / C::Ls(a), l = o - h * C::Ls(a);
-      lds_bias[o] = (a.bias != nullptr && l < C::L(a)) ? a.bias[h * C::L(a) + l] : 0.f;
+  // with a fused post-op the strip holds bias * scale + shift and a second strip the scale itself
+  const bool post = a.post_scale != nullptr;
+  float* lds_scale = lds_bias + a.bias_lds_floats;
+  float* lds_w = lds_bias + (post ? 2 : 1) * a.bias_lds_floats;
+  for (int o = lane; o < C::H(a) * C::Ls(a); o += 64) {  // padded head layout [h][Ls] (== [F_out] when contiguous)
+    const int h = o / C::Ls(a), l = o - h * C::Ls(a);
+    const int c = h * C::L(a) + l;
+    const bool real = l < C::L(a);
+    float bv = (a.bias != nullptr && real) ? a.bias[c] : 0.f;
+    if (post) {
+      const float sc = real ? a.post_scale[c] : 0.f;
+      bv = fmaf(bv, sc, real ? a.post_shift[c] : 0.f);
+      lds_scale[o] = sc;
     }
+    lds_bias[o] = bv;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   FastRsrc R;
   R.bases = bases_rsrc(a);
   R.out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (unsigned)a.n_nodes * (unsigned)F_out * 4u, 0x00020000);
+  R.res = __builtin_amdgcn_make_buffer_rsrc((void*)(a.residual != nullptr ? a.residual : a.out), 0,
+                                            (unsigned)a.n_nodes * (unsigned)F_out * 4u, 0x00020000);
   const bool looped_any = C::xl(a) || C::yl(a);
 
   if ((int)blockIdx.x < a.chunk_blocks) {
@@ -549,7 +569,7 @@ __global__ void __launch_bounds__(256) agg_fast_kernel(AggArgs a) {
     bool has_self;
     load_row_operands<LPR_LOG2, C>(a, R, lane, row, true, wpre, vself, has_self);
     finish_group<LPR_LOG2, HPB, NEED, C>(a, R, lane, row, true, acc, deg, nself, dis_i, vself, has_self, wpre, g == 0,
-                                         lds_w, lds_bias);
+                                         lds_w, lds_bias, lds_scale);
     return;
   }
 
@@ -615,7 +635,7 @@ __global__ void __launch_bounds__(256) agg_fast_kernel(AggArgs a) {
     const int deg_all = bperm((k * G + g + 1) << 2, rp) - start;
     const bool is_short = deg_all <= EGC_LONG_ROW_THRESHOLD;
     finish_group<LPR_LOG2, HPB, NEED, C>(a, R, ln, row, row_ok, acc, nd, nself, dis_i, vself, has_self, wpre, is_short,
-                                         lds_w, lds_bias);
+                                         lds_w, lds_bias, lds_scale);
   }
 }
 
@@ -705,7 +725,7 @@ int launch_fast(AggArgs a, int64_t n_nodes, const PlanCaps& caps, hipStream_t st
   }
   a.w_lds_stride = (a.W + 3) & ~3;
   a.bias_lds_floats = (a.H * a.Ls + 3) & ~3;  // >= F_out: the bias strip follows the (padded) head layout
-  a.lds_floats_per_wave = a.bias_lds_floats + G * a.w_lds_stride;
+  a.lds_floats_per_wave = (a.post_scale != nullptr ? 2 : 1) * a.bias_lds_floats + G * a.w_lds_stride;
   const size_t lds = (size_t)4 * a.lds_floats_per_wave * sizeof(float);
   if (lds > 64 * 1024) return EGC_ERR_UNSUPPORTED;
   const int64_t row_blocks = ceil_div(n_nodes, (int64_t)4 * a.rows_per_wave * G);

@@ -120,9 +120,20 @@ def egc_basis_transform(graph: CSRGraph, spec: LayerSpec, x: torch.Tensor, wcat:
     return bases, weightings
 
 
+@dataclass
+class PostOp:
+    """Caller-side elementwise tail fused into the layer's store (egc_post in include/egc_hip.h):
+    out = act((z + bias) * scale + shift) + residual."""
+    scale: torch.Tensor | None = None      # [F_out]
+    shift: torch.Tensor | None = None      # [F_out]
+    residual: torch.Tensor | None = None   # [N, F_out]
+    relu: bool = False
+
+
 def egc_aggregate_combine(graph: CSRGraph, spec: LayerSpec, bases: torch.Tensor, weightings: torch.Tensor,
-                          bias: torch.Tensor | None):
-    """Steps 2+3 (egc_aggregate_combine_f32): fused multi-aggregator reduction + combine -> out [N, F_out]."""
+                          bias: torch.Tensor | None, post: PostOp | None = None):
+    """Steps 2+3 (egc_aggregate_combine_f32 / _post_f32): fused multi-aggregator reduction + combine (+ fused
+    caller epilogue) -> out [N, F_out]."""
     lib = _C.load()
     n = graph.n_nodes
     _check_f32(bases, "bases", (graph.n_src_rows, spec.ldb))
@@ -134,17 +145,47 @@ def egc_aggregate_combine(graph: CSRGraph, spec: LayerSpec, bases: torch.Tensor,
         out = torch.empty((n, spec.f_out), dtype=torch.float32, device=dev)
         ws = graph.workspace(lib.egc_aggregate_workspace_bytes(C.byref(spec.c), n, graph.n_edges))
         g = graph.c_struct()
-        _C.check(lib.egc_aggregate_combine_f32(C.byref(g), C.byref(spec.c), bases.data_ptr(), spec.ldb,
-                                               weightings.data_ptr(),
-                                               bias.contiguous().data_ptr() if bias is not None else None,
-                                               out.data_ptr(), None, None, ws.data_ptr(), ws.numel(),
-                                               _stream_ptr(dev)), "egc_aggregate_combine_f32")
+        bias_p = bias.contiguous().data_ptr() if bias is not None else None
+        if post is None:
+            _C.check(lib.egc_aggregate_combine_f32(C.byref(g), C.byref(spec.c), bases.data_ptr(), spec.ldb,
+                                                   weightings.data_ptr(), bias_p, out.data_ptr(), None, None,
+                                                   ws.data_ptr(), ws.numel(), _stream_ptr(dev)),
+                     "egc_aggregate_combine_f32")
+        else:
+            keep = []  # contiguous copies must outlive the launch
+
+            def ptr(t, shape, name):
+                if t is None:
+                    return None
+                _check_f32(t, name, shape)
+                keep.append(t.contiguous())
+                return keep[-1].data_ptr()
+            p = _C.EgcPost(ptr(post.scale, (spec.f_out,), "post.scale"), ptr(post.shift, (spec.f_out,), "post.shift"),
+                           ptr(post.residual, (n, spec.f_out), "post.residual"), int(bool(post.relu)))
+            _C.check(lib.egc_aggregate_combine_post_f32(C.byref(g), C.byref(spec.c), bases.data_ptr(), spec.ldb,
+                                                        weightings.data_ptr(), bias_p, C.byref(p), out.data_ptr(),
+                                                        ws.data_ptr(), ws.numel(), _stream_ptr(dev)),
+                     "egc_aggregate_combine_post_f32")
+    return out
+
+
+def segment_mean(x: torch.Tensor, seg_ptr: torch.Tensor) -> torch.Tensor:
+    """Mean of consecutive row segments of x [N, C]: out[g] = mean(x[seg_ptr[g]:seg_ptr[g+1]]) (egc_segment_mean_f32)."""
+    lib = _C.load()
+    _check_f32(x, "x")
+    x = x.contiguous()
+    seg_ptr = seg_ptr.to(device=x.device, dtype=torch.int64).contiguous()
+    n_seg = int(seg_ptr.numel()) - 1
+    with torch.cuda.device(x.device):
+        out = torch.empty((n_seg, x.size(1)), dtype=torch.float32, device=x.device)
+        _C.check(lib.egc_segment_mean_f32(x.data_ptr(), seg_ptr.data_ptr(), n_seg, x.size(1), out.data_ptr(),
+                                          _stream_ptr(x.device)), "egc_segment_mean_f32")
     return out
 
 
 def egc_layer_forward(graph: CSRGraph, spec: LayerSpec, x: torch.Tensor, wcat: torch.Tensor,
                       bcat: torch.Tensor | None, bias: torch.Tensor | None, return_intermediates: bool = False,
-                      packed: torch.Tensor | None = None):
+                      packed: torch.Tensor | None = None, post: PostOp | None = None):
     """out[N, F_out] for one layer.  wcat = [bases_weight | comb.weight^T]  ([F_in, F_g + W]),
     bcat = comb.bias ([W]) or None, bias = layer bias ([F_out]) or None; ``packed`` = pack_weights(wcat)
     if the caller keeps one (otherwise it is produced here).  On a vertex-partitioned graph the halo rows
@@ -152,7 +193,7 @@ def egc_layer_forward(graph: CSRGraph, spec: LayerSpec, x: torch.Tensor, wcat: t
     bases, weightings = egc_basis_transform(graph, spec, x, wcat, bcat, packed)
     if graph.halo is not None and graph.n_src_rows > graph.n_nodes:
         graph.halo.exchange(bases)
-    out = egc_aggregate_combine(graph, spec, bases, weightings, bias)
+    out = egc_aggregate_combine(graph, spec, bases, weightings, bias, post)
     if return_intermediates:
         return out, bases, weightings
     return out

@@ -1,0 +1,65 @@
+"""Caller-side pieces around the layer, fused.
+
+The reference's graph nets wrap every EGC layer the same way (zinc/models.py:66-72, mol/pna_style_models.py:71-78,
+cifar/models.py:67-74):   x = conv(x, edge_index);  x = bn(x);  x = relu(x);  x = x + identity   and finish with
+``global_mean_pool(x, batch)``.  In eval mode BatchNorm1d is a per-channel affine map, so the whole tail folds into the
+store of the fused aggregate/combine kernel (``egc_aggregate_combine_post_f32``): three elementwise passes over
+[N, F_out] and three launches less per layer.  In training mode the block runs the plain sequence (batch statistics
+need the un-normalised activations anyway).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .functional import PostOp, egc_layer_forward, segment_mean
+from .graph import graph_from_input
+
+
+class FusedEGCBlock(nn.Module):
+    """conv -> BatchNorm1d -> ReLU (-> + input) as one module; ``conv`` is an ``egc_amd.EfficientGraphConv`` or
+    ``egc_amd.EGConv``, ``bn`` the ``nn.BatchNorm1d`` that follows it in the reference nets (shared, not copied:
+    state dicts keep their keys)."""
+
+    def __init__(self, conv: nn.Module, bn: nn.BatchNorm1d | None = None, relu: bool = True, residual: bool = True):
+        super().__init__()
+        self.conv, self.bn, self.relu, self.residual = conv, bn, relu, residual
+
+    def _plain(self, x, edge_index):
+        h = self.conv(x=x, edge_index=edge_index) if hasattr(self.conv, "aggs") else self.conv(x, edge_index)
+        if self.bn is not None:
+            h = self.bn(h)
+        if self.relu:
+            h = torch.relu(h)
+        return x + h if self.residual else h
+
+    def forward(self, x, edge_index):
+        bn = self.bn
+        fusable = not (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())))
+        if bn is not None and (bn.training or not bn.track_running_stats):
+            fusable = False
+        if not fusable:
+            return self._plain(x, edge_index)
+        conv = self.conv
+        scale = shift = None
+        if bn is not None:
+            inv = torch.rsqrt(bn.running_var + bn.eps)
+            scale = inv * bn.weight if bn.affine else inv
+            shift = (bn.bias if bn.affine else 0) - bn.running_mean * scale
+        post = PostOp(scale, shift, x if self.residual else None, self.relu)
+        graph = graph_from_input(edge_index, x.size(0))
+        if hasattr(conv, "aggs"):      # EfficientGraphConv
+            wcat = conv._packed_weights()
+            return egc_layer_forward(graph, conv._spec, x, wcat, conv.comb_weights.bias, conv.bias,
+                                     packed=conv._weight_planes(wcat), post=post)
+        wcat, bcat = conv._packed_weights()   # EGConv
+        spec = conv._spec_coo if isinstance(edge_index, torch.Tensor) and edge_index.layout == torch.strided else conv._spec_adj
+        return egc_layer_forward(graph, spec, x, wcat, bcat, conv.bias, packed=conv._weight_planes(spec, wcat), post=post)
+
+
+def global_mean_pool(x: torch.Tensor, batch: torch.Tensor, size: int | None = None) -> torch.Tensor:
+    """torch_geometric.nn.global_mean_pool for a SORTED batch vector (graphs are contiguous in a PyG batch):
+    a segmented mean on the device (``egc_segment_mean_f32``); differentiable callers should use torch ops."""
+    n_graphs = int(batch.max()) + 1 if size is None else int(size)
+    seg = torch.searchsorted(batch, torch.arange(n_graphs + 1, device=batch.device, dtype=batch.dtype))
+    return segment_mean(x, seg)

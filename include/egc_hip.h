@@ -188,6 +188,28 @@ int egc_aggregate_combine_f32(const egc_graph* graph, const egc_layer* layer, co
                               int32_t* arg_max, int32_t* arg_min,
                               void* workspace, size_t workspace_bytes, egc_stream_t stream);
 
+/* egc_aggregate_combine_f32 with the caller's elementwise tail fused into the store: the
+ * reference's nets follow every layer with BatchNorm1d -> ReLU -> + identity (zinc/models.py:66-72,
+ * mol/pna_style_models.py:71-78, cifar/models.py:67-74); in eval mode the normalisation is a per-channel affine
+ * map, so   out = act((z + bias) * scale + shift) + residual   with z the layer's combine result.
+ * scale / shift ([out_channels], both or neither), residual ([n_nodes, out_channels]) may be NULL; relu != 0
+ * applies max(., 0) before the residual.  post == NULL is egc_aggregate_combine_f32. */
+typedef struct {
+  const float* scale;
+  const float* shift;
+  const float* residual;
+  int32_t relu;
+} egc_post;
+int egc_aggregate_combine_post_f32(const egc_graph* graph, const egc_layer* layer, const float* bases, int32_t ldb,
+                                   const float* weightings, const float* bias, const egc_post* post, float* out,
+                                   void* workspace, size_t workspace_bytes, egc_stream_t stream);
+
+/* Mean of the rows of x [n_rows, width] over consecutive segments: out[g] = mean(x[seg_ptr[g] : seg_ptr[g+1]])
+ * (0 for an empty segment).  global_mean_pool over a PyG batch vector, whose graphs are contiguous
+ * (zinc/models.py:73, mol/pna_style_models.py:79, cifar/models.py:75); seg_ptr is int64 [n_segments + 1]. */
+int egc_segment_mean_f32(const float* x, const int64_t* seg_ptr, int64_t n_segments, int32_t width, float* out,
+                         egc_stream_t stream);
+
 /* Training form of egc_aggregate_combine_f32: same `out`, plus what the backward needs instead of a second
  * gather.  stats [n_nodes, egc_train_stats_floats(layer)] receives every row's raw running aggregates after
  * the self-loop term (those of sum / sum of squares / max / min / symnorm-weighted sum that the aggregator

@@ -91,3 +91,46 @@ def test_zinc_net_forward_and_gradients_match_cpu_restatement(hidden, H, B, aggr
         # fp32 evaluations (the fp32 CPU restatement itself is 2.4e-2 from float64 on a single such layer)
         floor = 1e-2 if set(aggrs) & {"std", "max", "min"} else 2e-3
         assert rel(got, want) <= max(floor, 4.0 * rel(cal, want)), (rel(got, want), rel(cal, want))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hidden,H,B,aggrs", [(128, 8, 4, ["symadd", "max", "mean"]), (168, 8, 4, ["symadd"]),
+                                              (42, 6, 3, ["add", "std"])])   # register / padded register / generic kernels
+def test_fused_block_equals_conv_bn_relu_residual(hidden, H, B, aggrs):
+    """FusedEGCBlock (eval): the BatchNorm1d-eval affine map, ReLU and the residual add inside the kernel's store
+    == the reference nets' separate conv -> bn -> relu -> + identity (zinc/models.py:66-72)."""
+    dev = torch.device("cuda:0")
+    atom, ei, n, batch = zinc_like_batch(64, seed=5)
+    torch.manual_seed(1)
+    conv = egc_amd.EfficientGraphConv(hidden, hidden, num_heads=H, num_bases=B, softmax_weights=False, aggrs=aggrs).to(dev)
+    bn = nn.BatchNorm1d(hidden).to(dev)
+    with torch.no_grad():
+        bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0); bn.weight.normal_(); bn.bias.normal_()
+        conv.bias.normal_()
+    x = torch.randn(n, hidden, device=dev)
+    ei = ei.to(dev)
+    for relu, residual, use_bn in [(True, True, True), (False, True, True), (True, False, False), (False, False, True)]:
+        block = egc_amd.FusedEGCBlock(conv, bn if use_bn else None, relu=relu, residual=residual).eval()
+        with torch.no_grad():
+            got = block(x, ei)
+            ref = block._plain(x, ei)
+        scale = max(1.0, float(ref.abs().max()))
+        assert float((got - ref).abs().max()) / scale <= 1e-5, (relu, residual, use_bn)
+    # training mode (or grad needed): the block runs the plain sequence and stays differentiable
+    block = egc_amd.FusedEGCBlock(conv, bn).train()
+    xg = x.clone().requires_grad_(True)
+    block(xg, ei).sum().backward()
+    assert xg.grad is not None and bool(torch.isfinite(xg.grad).all())
+
+
+@pytest.mark.gpu
+def test_global_mean_pool_matches_index_add():
+    dev = torch.device("cuda:0")
+    _, _, n, batch = zinc_like_batch(200, seed=2)
+    x = torch.randn(n, 77, device=dev)
+    batch = batch.to(dev)
+    n_graphs = int(batch.max()) + 1
+    got = egc_amd.global_mean_pool(x, batch)
+    ref = torch.zeros(n_graphs, 77, device=dev).index_add_(0, batch, x) / torch.bincount(batch, minlength=n_graphs).view(-1, 1)
+    assert float((got - ref).abs().max()) <= 1e-5
+    assert egc_amd.global_mean_pool(x, batch, size=n_graphs + 3).shape == (n_graphs + 3, 77)   # trailing empty graphs -> 0
