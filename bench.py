@@ -144,7 +144,9 @@ def main():
     else:
         from egc_amd import partition
         ei_cpu, n_global = partitioned_arxiv_like(rank, world, seed=args.seed)
-        ei_local, plan = partition.build_distributed(ei_cpu.to(dev), n_global)
+        # interior rows first: they are aggregated while the halo rows of `bases` are in flight
+        overlap = os.environ.get("EGC_BENCH_NO_OVERLAP", "0") in ("", "0")
+        ei_local, plan = partition.build_distributed(ei_cpu.to(dev), n_global, interior_first=overlap)
         graph = egc_amd.CSRGraph.from_partition(ei_local, plan, global_max_index=n_global - 1)
         n = plan.n_local
         ei = ei_local
@@ -179,10 +181,24 @@ def main():
                                                   weightings.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(),
                                                   stream), "egc_layer_forward_packed")
     else:
-        def step():  # GEMM on owned rows -> halo all-to-all-v -> fused aggregate/combine
+        def agg_rows(lo, hi):
+            _C.check(lib.egc_aggregate_combine_rows_f32(C.byref(g), C.byref(spec.c), bases.data_ptr(), ldb,
+                                                        weightings.data_ptr(), bias.data_ptr(), out.data_ptr(), lo, hi,
+                                                        ws.data_ptr(), ws.numel(), stream),
+                     "egc_aggregate_combine_rows_f32")
+
+        n_int = graph.halo.n_interior
+
+        def step():  # GEMM on owned rows -> halo all-to-all-v (RCCL) || interior rows -> boundary rows
             gemm_only()
-            graph.halo.exchange(bases)
-            agg_only()
+            if n_int is None:
+                graph.halo.exchange(bases)
+                agg_only()
+            else:
+                handle = graph.halo.exchange_start(bases)
+                agg_rows(0, n_int)
+                graph.halo.exchange_finish(handle)
+                agg_rows(n_int, n)
 
     def sync_all():
         torch.cuda.synchronize(dev)

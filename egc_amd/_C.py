@@ -77,6 +77,9 @@ SYMBOLS = {
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_size_t, C.c_void_p]),
     "egc_backward_workspace_bytes": (C.c_size_t, [C.POINTER(EgcLayer), C.c_int64]),
+    "egc_aggregate_combine_rows_f32": (C.c_int, [C.POINTER(EgcGraph), C.POINTER(EgcLayer), C.c_void_p, C.c_int32,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                                 C.c_void_p, C.c_size_t, C.c_void_p]),
     "egc_aggregate_combine_post_f32": (C.c_int, [C.POINTER(EgcGraph), C.POINTER(EgcLayer), C.c_void_p, C.c_int32,
                                                  C.c_void_p, C.c_void_p, C.POINTER(EgcPost), C.c_void_p,
                                                  C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -212,8 +212,8 @@ __global__ void __launch_bounds__(256) agg_rows_kernel(AggArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wpb = blockDim.x >> 6;
-  const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * wpb + wave);
-  if (row >= a.n_nodes) return;
+  const int row = __builtin_amdgcn_readfirstlane(a.row_begin + blockIdx.x * wpb + wave);
+  if (row >= a.row_end) return;
   const int start = __builtin_amdgcn_readfirstlane(a.rowptr[row]);
   const int end = __builtin_amdgcn_readfirstlane(a.rowptr[row + 1]);
   const int deg = end - start;
@@ -239,6 +239,7 @@ __global__ void __launch_bounds__(256) agg_chunks_kernel(AggArgs a) {
   const int* chunk_slot = long_row + 2 * cap_long;
   const int* chunk_begin = chunk_slot + cap_chunks;
   const int row = __builtin_amdgcn_readfirstlane(long_row[chunk_slot[c]]);
+  if (row < a.row_begin || row >= a.row_end) return;
   const int start = __builtin_amdgcn_readfirstlane(chunk_begin[c]);
   const int end = min(start + EGC_LONG_ROW_CHUNK, __builtin_amdgcn_readfirstlane(a.rowptr[row + 1]));
   const __amdgpu_buffer_rsrc_t rsrc = bases_rsrc(a);
@@ -277,6 +278,7 @@ __global__ void __launch_bounds__(256) agg_merge_kernel(AggArgs a) {
   const int* long_row = a.plan + 4;
   const int* long_chunk0 = long_row + cap_long;
   const int row = __builtin_amdgcn_readfirstlane(long_row[slot]);
+  if (row < a.row_begin || row >= a.row_end) return;
   const int c0 = __builtin_amdgcn_readfirstlane(long_chunk0[slot]);
   const int deg = __builtin_amdgcn_readfirstlane(a.rowptr[row + 1] - a.rowptr[row]);
   const int nch = (deg + EGC_LONG_ROW_CHUNK - 1) / EGC_LONG_ROW_CHUNK;
@@ -367,7 +369,7 @@ static int launch_all(const AggArgs& a, int64_t n_nodes, const PlanCaps& caps, i
   // long-row chunks first (they are the longest work items), then the per-row kernel, then the merge
   agg_chunks_kernel<CHUNKS, U><<<(unsigned)ceil_div(caps.cap_chunks, 4), 256, 0, stream>>>(a);
   EGC_LAUNCH_CHECK("agg_chunks_kernel");
-  agg_rows_kernel<CHUNKS, U><<<(unsigned)ceil_div(n_nodes, wpb), threads, lds_bytes, stream>>>(a);
+  agg_rows_kernel<CHUNKS, U><<<(unsigned)ceil_div(a.row_end - a.row_begin, wpb), threads, lds_bytes, stream>>>(a);
   EGC_LAUNCH_CHECK("agg_rows_kernel");
   agg_merge_kernel<CHUNKS><<<(unsigned)ceil_div(caps.cap_long, wpb), threads, lds_bytes, stream>>>(a);
   EGC_LAUNCH_CHECK("agg_merge_kernel");
@@ -410,23 +412,31 @@ int64_t egc_train_stats_floats(const egc_layer* layer) {
 
 static int aggregate_combine_impl(const egc_graph* graph, const egc_layer* layer, const float* bases, int32_t ldb,
                                   const float* weightings, const float* bias, const egc_post* post, float* out,
-                                  float* stats, int32_t* cnt_out, void* workspace, size_t workspace_bytes,
-                                  egc_stream_t stream_);
+                                  float* stats, int32_t* cnt_out, int64_t row_begin, int64_t row_end, void* workspace,
+                                  size_t workspace_bytes, egc_stream_t stream_);
 
 int egc_aggregate_combine_f32(const egc_graph* graph, const egc_layer* layer, const float* bases, int32_t ldb,
                               const float* weightings, const float* bias, float* out, int32_t* arg_max,
                               int32_t* arg_min, void* workspace, size_t workspace_bytes, egc_stream_t stream) {
   // the arg-extremum indices need the extrema themselves: egc_aggregate_combine_train_f32 keeps them
   if (arg_max != nullptr || arg_min != nullptr) return EGC_ERR_UNSUPPORTED;
-  return aggregate_combine_impl(graph, layer, bases, ldb, weightings, bias, nullptr, out, nullptr, nullptr, workspace,
+  return aggregate_combine_impl(graph, layer, bases, ldb, weightings, bias, nullptr, out, nullptr, nullptr, 0, -1, workspace,
                                 workspace_bytes, stream);
+}
+
+int egc_aggregate_combine_rows_f32(const egc_graph* graph, const egc_layer* layer, const float* bases, int32_t ldb,
+                                   const float* weightings, const float* bias, float* out, int64_t row_begin,
+                                   int64_t row_end, void* workspace, size_t workspace_bytes, egc_stream_t stream) {
+  if (row_end < 0) return EGC_ERR_INVALID;
+  return aggregate_combine_impl(graph, layer, bases, ldb, weightings, bias, nullptr, out, nullptr, nullptr, row_begin,
+                                row_end, workspace, workspace_bytes, stream);
 }
 
 int egc_aggregate_combine_post_f32(const egc_graph* graph, const egc_layer* layer, const float* bases, int32_t ldb,
                                    const float* weightings, const float* bias, const egc_post* post, float* out,
                                    void* workspace, size_t workspace_bytes, egc_stream_t stream) {
   if (post != nullptr && ((post->scale == nullptr) != (post->shift == nullptr))) return EGC_ERR_INVALID;
-  return aggregate_combine_impl(graph, layer, bases, ldb, weightings, bias, post, out, nullptr, nullptr, workspace,
+  return aggregate_combine_impl(graph, layer, bases, ldb, weightings, bias, post, out, nullptr, nullptr, 0, -1, workspace,
                                 workspace_bytes, stream);
 }
 
@@ -435,7 +445,7 @@ int egc_aggregate_combine_train_f32(const egc_graph* graph, const egc_layer* lay
                                     int32_t* cnt, int32_t* arg_max, int32_t* arg_min, void* workspace,
                                     size_t workspace_bytes, egc_stream_t stream) {
   if (graph == nullptr || layer == nullptr || stats == nullptr || cnt == nullptr) return EGC_ERR_INVALID;
-  int st = aggregate_combine_impl(graph, layer, bases, ldb, weightings, bias, nullptr, out, stats, cnt, workspace,
+  int st = aggregate_combine_impl(graph, layer, bases, ldb, weightings, bias, nullptr, out, stats, cnt, 0, -1, workspace,
                                   workspace_bytes, stream);
   if (st != EGC_OK) return st;
   return egc::arg_extrema(graph, layer, bases, ldb, stats, cnt, arg_max, arg_min, (hipStream_t)stream);
@@ -443,8 +453,8 @@ int egc_aggregate_combine_train_f32(const egc_graph* graph, const egc_layer* lay
 
 static int aggregate_combine_impl(const egc_graph* graph, const egc_layer* layer, const float* bases, int32_t ldb,
                                   const float* weightings, const float* bias, const egc_post* post, float* out,
-                                  float* stats, int32_t* cnt_out, void* workspace, size_t workspace_bytes,
-                                  egc_stream_t stream_) {
+                                  float* stats, int32_t* cnt_out, int64_t row_begin, int64_t row_end, void* workspace,
+                                  size_t workspace_bytes, egc_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (graph == nullptr) return EGC_ERR_INVALID;
   int st = validate_layer(layer);
@@ -479,6 +489,10 @@ static int aggregate_combine_impl(const egc_graph* graph, const egc_layer* layer
   a.bias = bias;
   a.out = out;
   a.n_nodes = (int)n;
+  a.row_begin = (int)row_begin;
+  a.row_end = row_end < 0 ? (int)n : (int)row_end;
+  if (a.row_begin < 0 || a.row_end > (int)n) return EGC_ERR_INVALID;
+  if (a.row_begin >= a.row_end) return EGC_OK;
   a.ldb = ldb;
   a.slots = ldb / 4;
   a.F_out = layer->out_channels;

@@ -30,6 +30,7 @@ struct AggArgs {
   int* partial_nself;      // [cap_chunks]
   int* counters;           // [cap_long] arrival counters of the fused kernel (zero on entry, zero on exit)
   int n_nodes;
+  int row_begin, row_end;  // rows this launch finishes ([0, n_nodes) unless the caller splits the rows)
   int ldb, slots;          // slots = ldb / 4
   int F_out, W, H, B, A, L;
   int Ls;                  // floats between consecutive bases in a row (>= L; == L when contiguous)

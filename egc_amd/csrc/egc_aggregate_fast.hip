@@ -477,6 +477,7 @@ __global__ void __launch_bounds__(256) agg_fast_kernel(AggArgs a) {
     const int* chunk_begin = chunk_slot + cap_chunks;
     const int slot = __builtin_amdgcn_readfirstlane(chunk_slot[c]);
     const int row = __builtin_amdgcn_readfirstlane(long_row[slot]);
+    if (row < a.row_begin || row >= a.row_end) return;  // every chunk of a row takes the same exit
     const int start = __builtin_amdgcn_readfirstlane(chunk_begin[c]);
     const int row_start = __builtin_amdgcn_readfirstlane(a.rowptr[row]);
     const int row_end = __builtin_amdgcn_readfirstlane(a.rowptr[row + 1]);
@@ -576,8 +577,9 @@ __global__ void __launch_bounds__(256) agg_fast_kernel(AggArgs a) {
   // ---------------- short-row role: one lane group per row, G rows per wavefront at a time ----------------
   const int Q = a.rows_per_wave;  // row groups (of G rows) per wavefront; Q * G <= 63
   const int gw = ((int)blockIdx.x - a.chunk_blocks) * 4 + wave;
-  const int r0 = __builtin_amdgcn_readfirstlane(gw * Q * G);
-  if (r0 >= a.n_nodes) return;
+  const int r0 = __builtin_amdgcn_readfirstlane(a.row_begin + gw * Q * G);
+  const int n_end = a.row_end;
+  if (r0 >= n_end) return;
   const int rp = a.rowptr[min(r0 + lane, a.n_nodes)];  // lanes 0..Q*G hold this wavefront's row pointers
   const int grp_addr = (g << LPR_LOG2) << 2;            // ds_bpermute byte address of the group's lane 0
   // stage the first row group's column indices (lane q of group g <- entry q of row r0 + g)
@@ -585,20 +587,20 @@ __global__ void __launch_bounds__(256) agg_fast_kernel(AggArgs a) {
   int nd_n;  // entries of the group's row handled here (0 for long or out-of-range rows)
   {
     const int deg = bperm((g + 1) << 2, rp) - start_n;
-    nd_n = (r0 + g < a.n_nodes && deg <= EGC_LONG_ROW_THRESHOLD) ? deg : 0;
+    nd_n = (r0 + g < n_end && deg <= EGC_LONG_ROW_THRESHOLD) ? deg : 0;
   }
   int jj_n = q < nd_n ? a.col[start_n + q] : 0;
   for (int k = 0; k < Q; ++k) {
     const int rbase = r0 + k * G;
-    if (rbase >= a.n_nodes) break;
+    if (rbase >= n_end) break;
     const int row = rbase + g;
-    const bool row_ok = row < a.n_nodes;
+    const bool row_ok = row < n_end;
     const int start = start_n, nd = nd_n;
     int jj = jj_n;
     if (k + 1 < Q) {  // prefetch the next row group's bounds and first LPR column indices
       start_n = bperm(((k + 1) * G + g) << 2, rp);
       const int deg = bperm(((k + 1) * G + g + 1) << 2, rp) - start_n;
-      nd_n = (rbase + G + g < a.n_nodes && deg <= EGC_LONG_ROW_THRESHOLD) ? deg : 0;
+      nd_n = (rbase + G + g < n_end && deg <= EGC_LONG_ROW_THRESHOLD) ? deg : 0;
       jj_n = q < nd_n ? a.col[start_n + q] : 0;
     }
     // wave-uniform trip count: entries still valid in any group
@@ -728,7 +730,7 @@ int launch_fast(AggArgs a, int64_t n_nodes, const PlanCaps& caps, hipStream_t st
   a.lds_floats_per_wave = (a.post_scale != nullptr ? 2 : 1) * a.bias_lds_floats + G * a.w_lds_stride;
   const size_t lds = (size_t)4 * a.lds_floats_per_wave * sizeof(float);
   if (lds > 64 * 1024) return EGC_ERR_UNSUPPORTED;
-  const int64_t row_blocks = ceil_div(n_nodes, (int64_t)4 * a.rows_per_wave * G);
+  const int64_t row_blocks = ceil_div((int64_t)a.row_end - a.row_begin, (int64_t)4 * a.rows_per_wave * G);
   const unsigned grid = (unsigned)(a.chunk_blocks + row_blocks);
 
   if (getenv("EGC_NO_STATIC_CFG") == nullptr) {

@@ -131,9 +131,10 @@ class PostOp:
 
 
 def egc_aggregate_combine(graph: CSRGraph, spec: LayerSpec, bases: torch.Tensor, weightings: torch.Tensor,
-                          bias: torch.Tensor | None, post: PostOp | None = None):
-    """Steps 2+3 (egc_aggregate_combine_f32 / _post_f32): fused multi-aggregator reduction + combine (+ fused
-    caller epilogue) -> out [N, F_out]."""
+                          bias: torch.Tensor | None, post: PostOp | None = None, rows: tuple | None = None,
+                          out: torch.Tensor | None = None):
+    """Steps 2+3 (egc_aggregate_combine_f32 / _post_f32 / _rows_f32): fused multi-aggregator reduction + combine
+    (+ fused caller epilogue) -> out [N, F_out].  ``rows = (begin, end)`` finishes only those rows of ``out``."""
     lib = _C.load()
     n = graph.n_nodes
     _check_f32(bases, "bases", (graph.n_src_rows, spec.ldb))
@@ -142,11 +143,19 @@ def egc_aggregate_combine(graph: CSRGraph, spec: LayerSpec, bases: torch.Tensor,
         _check_f32(bias, "bias", (spec.f_out,))
     dev = bases.device
     with torch.cuda.device(dev):
-        out = torch.empty((n, spec.f_out), dtype=torch.float32, device=dev)
+        if out is None:
+            out = torch.empty((n, spec.f_out), dtype=torch.float32, device=dev)
         ws = graph.workspace(lib.egc_aggregate_workspace_bytes(C.byref(spec.c), n, graph.n_edges))
         g = graph.c_struct()
         bias_p = bias.contiguous().data_ptr() if bias is not None else None
-        if post is None:
+        if rows is not None:
+            if post is not None:
+                raise RuntimeError("egc_amd: a row range and a fused post-op cannot be combined")
+            _C.check(lib.egc_aggregate_combine_rows_f32(C.byref(g), C.byref(spec.c), bases.data_ptr(), spec.ldb,
+                                                        weightings.data_ptr(), bias_p, out.data_ptr(), int(rows[0]),
+                                                        int(rows[1]), ws.data_ptr(), ws.numel(), _stream_ptr(dev)),
+                     "egc_aggregate_combine_rows_f32")
+        elif post is None:
             _C.check(lib.egc_aggregate_combine_f32(C.byref(g), C.byref(spec.c), bases.data_ptr(), spec.ldb,
                                                    weightings.data_ptr(), bias_p, out.data_ptr(), None, None,
                                                    ws.data_ptr(), ws.numel(), _stream_ptr(dev)),
@@ -191,9 +200,17 @@ def egc_layer_forward(graph: CSRGraph, spec: LayerSpec, x: torch.Tensor, wcat: t
     if the caller keeps one (otherwise it is produced here).  On a vertex-partitioned graph the halo rows
     of ``bases`` are exchanged (one all-to-all-v) between the two steps."""
     bases, weightings = egc_basis_transform(graph, spec, x, wcat, bcat, packed)
-    if graph.halo is not None and graph.n_src_rows > graph.n_nodes:
-        graph.halo.exchange(bases)
-    out = egc_aggregate_combine(graph, spec, bases, weightings, bias, post)
+    halo = graph.halo if graph.n_src_rows > graph.n_nodes else None
+    if halo is not None and halo.n_interior is not None and post is None:
+        # interior rows (no halo source) are finished while the halo rows of `bases` travel
+        handle = halo.exchange_start(bases)
+        out = egc_aggregate_combine(graph, spec, bases, weightings, bias, rows=(0, halo.n_interior))
+        halo.exchange_finish(handle)
+        out = egc_aggregate_combine(graph, spec, bases, weightings, bias, rows=(halo.n_interior, graph.n_nodes), out=out)
+    else:
+        if halo is not None:
+            halo.exchange(bases)
+        out = egc_aggregate_combine(graph, spec, bases, weightings, bias, post)
     if return_intermediates:
         return out, bases, weightings
     return out

@@ -8,6 +8,12 @@ all-to-all-v (``torch.distributed.all_to_all_single``: RCCL over xGMI on GPUs, g
 No other collective is on the forward path.  Partition, send/receive lists and the halo ``deg^-1/2`` are
 static and built once per graph (the analogue of the reference's ``cached=True``).
 
+Overlap: with ``interior_first=True`` the owned vertices are renumbered so that INTERIOR rows (every source
+owned) come first and BOUNDARY rows (at least one halo source) last.  The forward then starts the all-to-all-v
+right after the GEMM, finishes the interior rows while the halo rows travel (``egc_aggregate_combine_rows_f32``),
+and only the boundary rows wait for the exchange.  ``HaloPlan.order`` maps new local positions to the old ones
+(``x_new = x_owned[order]``, ``out_owned[order] = out_new``): a network permutes its inputs once and its outputs once.
+
 Correctness criterion: concatenating the per-rank outputs reproduces the single-GPU output (max/min
 exactly, sums to rounding since a row's neighbour order is unchanged).
 """
@@ -42,6 +48,10 @@ class HaloPlan:
     send_splits: List[int]                   # rows shipped to each rank
     group: Optional[object] = None           # torch.distributed process group (None = default / local simulation)
     stats: dict = field(default_factory=dict)
+    # interior-first renumbering of the owned vertices (None: natural order)
+    order: Optional[torch.Tensor] = None       # [n_local] old local id at each new position
+    new_of_old: Optional[torch.Tensor] = None  # [n_local] inverse
+    n_interior: Optional[int] = None           # rows [0, n_interior) read no halo row
 
     @property
     def n_local(self) -> int:
@@ -52,9 +62,10 @@ class HaloPlan:
         return int(self.halo_global_ids.numel())
 
     # -- the one collective of the forward path ------------------------------------------------
-    def exchange(self, table: torch.Tensor):
-        """Fill rows [n_local, n_local + n_halo) of `table` with the owners' rows; rows [0, n_local) are
-        this rank's.  `table` is [n_local + n_halo, width] (bases) or [n_local + n_halo] (deg^-1/2)."""
+    def exchange_start(self, table: torch.Tensor):
+        """Begin filling rows [n_local, n_local + n_halo) of `table` with the owners' rows (rows [0, n_local) are
+        this rank's); returns a handle for exchange_finish.  Work queued on the current stream after this call
+        runs concurrently with the transfer and must not touch the halo rows."""
         import torch.distributed as dist
         n = self.n_local
         send = table[:n].index_select(0, self.send_idx).contiguous()
@@ -67,8 +78,21 @@ class HaloPlan:
             r_cpu = torch.empty(recv.numel(), dtype=recv.dtype)
             dist.all_to_all_single(r_cpu, send.view(-1).cpu(), out_splits, in_splits, group=self.group)
             recv.view(-1).copy_(r_cpu)
-        else:
-            dist.all_to_all_single(recv.view(-1), send.view(-1), out_splits, in_splits, group=self.group)
+            return None
+        work = dist.all_to_all_single(recv.view(-1), send.view(-1), out_splits, in_splits, group=self.group,
+                                      async_op=True)
+        return work, send  # `send` must stay alive until the transfer has completed
+
+    @staticmethod
+    def exchange_finish(handle):
+        """Make the current stream wait for the transfer started by exchange_start."""
+        if handle is not None:
+            handle[0].wait()
+
+    def exchange(self, table: torch.Tensor):
+        """exchange_start + exchange_finish.  `table` is [n_local + n_halo, width] (bases) or
+        [n_local + n_halo] (deg^-1/2)."""
+        self.exchange_finish(self.exchange_start(table))
         return table
 
 
@@ -96,7 +120,25 @@ def _halo_ids(ei_local: torch.Tensor, lo: int, hi: int, bounds: List[int]):
     return halo, [int(c) for c in owner_counts.tolist()]
 
 
-def build_distributed(edge_index_owned: torch.Tensor, n_global: int, group=None):
+def _interior_first(ei_local: torch.Tensor, plan: "HaloPlan"):
+    """Renumber the owned vertices: rows without a halo source first.  Returns the renamed edge list."""
+    n = plan.n_local
+    dev = ei_local.device
+    boundary = torch.zeros(n, dtype=torch.bool, device=dev)
+    boundary[ei_local[1][ei_local[0] >= n]] = True
+    order = torch.argsort(boundary.to(torch.int8), stable=True)          # old ids, interior rows first
+    new_of_old = torch.empty_like(order)
+    new_of_old[order] = torch.arange(n, device=dev)
+    src = ei_local[0]
+    src = torch.where(src < n, new_of_old[src.clamp(max=max(n - 1, 0))], src)
+    plan.order, plan.new_of_old, plan.n_interior = order, new_of_old, int((~boundary).sum())
+    if plan.send_idx.numel() > 0:
+        plan.send_idx = new_of_old[plan.send_idx.to(dev)].contiguous()
+    plan.stats["n_interior"] = plan.n_interior
+    return torch.stack([src, new_of_old[ei_local[1]]])
+
+
+def build_distributed(edge_index_owned: torch.Tensor, n_global: int, group=None, interior_first: bool = False):
     """Collective setup.  `edge_index_owned`: the edges (GLOBAL ids, int64 [2, E_p]) whose destination this
     rank owns.  Returns (edge_index with [owned|halo] source ids and local destination ids, HaloPlan)."""
     import torch.distributed as dist
@@ -119,10 +161,11 @@ def build_distributed(edge_index_owned: torch.Tensor, n_global: int, group=None)
     plan.stats = dict(n_local=hi - lo, n_halo=int(halo.numel()), n_send=int(req.numel()),
                       max_peer_rows=max(recv_splits) if recv_splits else 0)
     src = remap_sources(edge_index_owned[0], lo, hi, halo)
-    return torch.stack([src, edge_index_owned[1] - lo]), plan
+    ei_local = torch.stack([src, edge_index_owned[1] - lo])
+    return (_interior_first(ei_local, plan) if interior_first else ei_local), plan
 
 
-def build_local_simulation(edge_index: torch.Tensor, n_global: int, world: int):
+def build_local_simulation(edge_index: torch.Tensor, n_global: int, world: int, interior_first: bool = False):
     """All `world` partitions of a global graph inside ONE process (tests, single-GPU validation): returns
     a list of (edge_index_local, HaloPlan); exchange them with `simulate_exchange`."""
     bounds = vertex_ranges(n_global, world)
@@ -133,7 +176,8 @@ def build_local_simulation(edge_index: torch.Tensor, n_global: int, world: int):
         halo, recv_splits = _halo_ids(ei, lo, hi, bounds)
         plan = HaloPlan(p, world, lo, hi, n_global, halo, recv_splits, torch.empty(0, dtype=torch.int64), [0] * world)
         src = remap_sources(ei[0], lo, hi, halo)
-        parts.append((torch.stack([src, ei[1] - lo]), plan))
+        ei_local = torch.stack([src, ei[1] - lo])
+        parts.append((_interior_first(ei_local, plan) if interior_first else ei_local, plan))
     return parts
 
 
@@ -145,5 +189,7 @@ def simulate_exchange(tables: List[torch.Tensor], plans: List[HaloPlan]):
             sel = (plan.halo_global_ids >= other.lo) & (plan.halo_global_ids < other.hi)
             if bool(sel.any()):
                 rows = plan.halo_global_ids[sel] - other.lo
+                if other.new_of_old is not None:
+                    rows = other.new_of_old.to(rows.device)[rows]
                 t[n:n + plan.n_halo][sel] = tables[q][:other.n_local].index_select(0, rows)
     return tables

@@ -188,6 +188,13 @@ int egc_aggregate_combine_f32(const egc_graph* graph, const egc_layer* layer, co
                               int32_t* arg_max, int32_t* arg_min,
                               void* workspace, size_t workspace_bytes, egc_stream_t stream);
 
+/* egc_aggregate_combine_f32 restricted to the rows [row_begin, row_end): the other rows of `out` are not touched.
+ * A vertex-partitioned run numbers its interior rows (all sources owned) first and finishes them while the halo
+ * rows of `bases` are still in flight, then the boundary rows (egc_amd/partition.py). */
+int egc_aggregate_combine_rows_f32(const egc_graph* graph, const egc_layer* layer, const float* bases, int32_t ldb,
+                                   const float* weightings, const float* bias, float* out, int64_t row_begin,
+                                   int64_t row_end, void* workspace, size_t workspace_bytes, egc_stream_t stream);
+
 /* egc_aggregate_combine_f32 with the caller's elementwise tail fused into the store: the
  * reference's nets follow every layer with BatchNorm1d -> ReLU -> + identity (zinc/models.py:66-72,
  * mol/pna_style_models.py:71-78, cifar/models.py:67-74); in eval mode the normalisation is a per-channel affine

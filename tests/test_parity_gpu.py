@@ -360,6 +360,51 @@ def test_vertex_partition_equals_single_gpu(world):
     assert rel_err(got.cpu().numpy(), ref.cpu().numpy()) <= TOL
 
 
+@pytest.mark.parametrize("world", [2, 5])
+def test_interior_first_partition_and_row_ranges(world):
+    """The overlap form of the partitioned forward: owned vertices renumbered interior-first, interior rows
+    finished from the owned basis rows ALONE (the halo region still holds NaN), boundary rows after the exchange;
+    un-permuted and concatenated it equals the single-GPU output."""
+    import egc_amd
+    from egc_amd import partition as P
+    from egc_amd.functional import egc_aggregate_combine, egc_basis_transform
+    from egc_amd.workloads import heavy_tailed_graph
+    dev = _dev()
+    n = 6000
+    ei = heavy_tailed_graph(n, 40000, seed=3)
+    torch.manual_seed(2)
+    conv = egc_amd.EGConv(128, 128, aggrs=["sum", "mean", "max", "symnorm"], num_heads=8, num_bases=4).to(dev).eval()
+    x = torch.randn(n, 128, device=dev)
+    with torch.no_grad():
+        ref = conv(x, ei.to(dev))
+        wcat, bcat = conv._packed_weights()
+        parts = P.build_local_simulation(ei, n, world, interior_first=True)
+        plans = [p for _, p in parts]
+        for p in plans:
+            p.order, p.new_of_old = p.order.to(dev), p.new_of_old.to(dev)
+        graphs = [egc_amd.CSRGraph.from_partition(e.to(dev), plan, global_max_index=int(ei.max()), exchange_dis=False)
+                  for e, plan in parts]
+        for key in ("dis_raw", "dis_looped"):
+            P.simulate_exchange([getattr(g, key) for g in graphs], plans_on(plans, dev))
+        stage = [egc_basis_transform(g, conv._spec_coo, x[pl.lo:pl.hi][pl.order], wcat, bcat) for g, pl in zip(graphs, plans)]
+        outs = []
+        for g, pl, (b, w) in zip(graphs, plans, stage):
+            assert 0 <= pl.n_interior <= pl.n_local
+            b[pl.n_local:] = float("nan")                      # halo rows have not arrived yet
+            out = torch.full((pl.n_local, 128), float("nan"), device=dev)
+            egc_aggregate_combine(g, conv._spec_coo, b, w, conv.bias, rows=(0, pl.n_interior), out=out)
+            assert bool(torch.isfinite(out[:pl.n_interior]).all()) and bool(torch.isnan(out[pl.n_interior:]).all())
+            outs.append(out)
+        P.simulate_exchange([b for b, _ in stage], plans)
+        got = []
+        for g, pl, (b, w), out in zip(graphs, plans, stage, outs):
+            egc_aggregate_combine(g, conv._spec_coo, b, w, conv.bias, rows=(pl.n_interior, pl.n_local), out=out)
+            back = torch.empty_like(out)
+            back[pl.order] = out
+            got.append(back)
+    assert rel_err(torch.cat(got).cpu().numpy(), ref.cpu().numpy()) <= TOL
+
+
 def plans_on(plans, dev):
     for p in plans:
         p.halo_global_ids = p.halo_global_ids.to(dev)

@@ -107,17 +107,22 @@ def _worker(rank, world, port, ret):
         bounds = P.vertex_ranges(n, world)
         lo, hi = bounds[rank], bounds[rank + 1]
         owned = P.local_edges(ei, lo, hi)
-        ei_l, plan = P.build_distributed(owned, n)          # collective setup (two all-to-alls)
+        ei_l, plan = P.build_distributed(owned, n, interior_first=(rank % 2 == 1))  # collective setup (two all-to-alls)
         table = torch.arange(n * 6, dtype=torch.float32).view(n, 6)
+        own = torch.arange(lo, hi) if plan.order is None else torch.arange(lo, hi)[plan.order]  # renumbered ranks
         ext = torch.zeros(plan.n_local + plan.n_halo, 6)
-        ext[:plan.n_local] = table[lo:hi]
-        plan.exchange(ext)                                   # THE forward-path collective
+        ext[:plan.n_local] = table[own]
+        handle = plan.exchange_start(ext)                    # THE forward-path collective, split form
+        plan.exchange_finish(handle)
         vec = torch.zeros(plan.n_local + plan.n_halo)
-        vec[:plan.n_local] = torch.arange(lo, hi, dtype=torch.float32)
+        vec[:plan.n_local] = own.float()
         plan.exchange(vec)                                   # 1-D tables (deg^-1/2) go the same way
-        ext_ids = torch.cat([torch.arange(lo, hi), plan.halo_global_ids])
+        ext_ids = torch.cat([own, plan.halo_global_ids])
         ok = torch.equal(ext, table[ext_ids]) and torch.equal(vec, ext_ids.float())
-        ok = ok and torch.equal(ext_ids[ei_l[0]], owned[0]) and torch.equal(ei_l[1] + lo, owned[1])
+        ok = ok and torch.equal(ext_ids[ei_l[0]], owned[0]) and torch.equal(own[ei_l[1]], owned[1])
+        if plan.order is not None:   # interior rows: no halo source
+            interior_rows = ei_l[1] < plan.n_interior
+            ok = ok and bool((ei_l[0][interior_rows] < plan.n_local).all())
         ok = ok and sum(plan.send_splits) == plan.send_idx.numel() and plan.send_splits[rank] == 0
         ret[rank] = bool(ok)
     finally:
