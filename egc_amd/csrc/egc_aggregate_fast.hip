@@ -406,8 +406,8 @@ __device__ inline void load_row_operands(const AggArgs& a, const FastRsrc& R, in
   constexpr int LPR = 1 << LPR_LOG2;
   const int q = lane & (LPR - 1);
   const int W = C::W(a);
-  const int nloop = C::loops_all(a) ? a.n_nodes : (*a.max_index + 1);
-  has_self = row_ok && row < nloop;
+  // row_ok already says row < n_nodes: with a loop on every node there is nothing left to compare
+  has_self = row_ok && (C::loops_all(a) || row <= *a.max_index);
   const bool want_self = (C::xl(a) || C::yl(a)) && has_self;
   vself = load_slot(R.bases, (want_self && q < C::slots(a)) ? (unsigned)row * (unsigned)a.ldb * 4u + (unsigned)q * 16u : OOB);
   const float* wrow = a.weightings + (int64_t)(row_ok ? row : 0) * W;
