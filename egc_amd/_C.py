@@ -34,7 +34,7 @@ class EgcGraph(C.Structure):
         ("rowptr", C.c_void_p), ("col", C.c_void_p), ("edge_id", C.c_void_p),
         ("dis_raw", C.c_void_p), ("dis_looped", C.c_void_p),
         ("max_index", C.c_void_p), ("plan", C.c_void_p), ("n_chunks", C.c_int64),
-        ("n_src_rows", C.c_int64),
+        ("n_src_rows", C.c_int64), ("edge_dis_raw", C.c_void_p), ("edge_dis_looped", C.c_void_p),
     ]
 
 
@@ -57,6 +57,7 @@ SYMBOLS = {
     "egc_coo_to_csr_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "egc_coo_to_csr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "egc_csr_edge_dis": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "egc_csr_prepare": (C.c_int, [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p]),
     "egc_bases_ld": (C.c_int32, [C.POINTER(EgcLayer)]),

@@ -476,8 +476,10 @@ static int aggregate_combine_impl(const egc_graph* graph, const egc_layer* layer
   a.rowptr = graph->rowptr;
   a.col = graph->col;
   a.dis = nullptr;
+  a.edis = nullptr;
   if (layer_uses_symnorm(layer)) {
     a.dis = layer->sym_set == EGC_SET_LOOPED ? graph->dis_looped : graph->dis_raw;
+    a.edis = layer->sym_set == EGC_SET_LOOPED ? graph->edge_dis_looped : graph->edge_dis_raw;
     if (a.dis == nullptr) return EGC_ERR_INVALID;
   }
   a.loops_all = layer->loops_all_nodes != 0;

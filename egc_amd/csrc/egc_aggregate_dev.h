@@ -20,6 +20,7 @@ struct AggArgs {
   const int* rowptr;
   const int* col;
   const float* dis;        // deg^-1/2 of the symnorm edge set, or nullptr
+  const float* edis;       // dis[col[p]] per CSR entry (egc_graph.edge_dis_*), or nullptr: gather dis[col[p]] instead
   const int* max_index;    // device scalar (used when !loops_all)
   const int* plan;
   const float* bases;

@@ -492,7 +492,8 @@ __global__ void __launch_bounds__(256) agg_fast_kernel(AggArgs a) {
       const int p = base + lane;
       const bool pv = p < end;
       const int jj = pv ? a.col[p] : row;
-      const float dd = a.dis != nullptr ? a.dis[jj] : 0.f;
+      // source-side deg^-1/2: streamed per entry when the graph carries it, else gathered
+      const float dd = a.edis != nullptr ? (pv ? a.edis[p] : 0.f) : (a.dis != nullptr ? a.dis[jj] : 0.f);
       if (looped_any) nself += __popcll(__ballot(pv && jj == row));
       const int cnt = min(64, end - base);
       for (int t0 = 0; t0 < cnt; t0 += FU * G)
@@ -620,7 +621,7 @@ __global__ void __launch_bounds__(256) agg_fast_kernel(AggArgs a) {
     for (int ts = 0; ts < maxd; ts += LPR) {
       if (ts > 0) jj = (ts + q < nd) ? a.col[start + ts + q] : 0;  // rows of more than LPR entries
       const bool pv = ts + q < nd;
-      const float dd = (a.dis != nullptr && pv) ? a.dis[jj] : 0.f;
+      const float dd = !pv ? 0.f : a.edis != nullptr ? a.edis[start + ts + q] : a.dis != nullptr ? a.dis[jj] : 0.f;
       if (looped_any) {  // self-entries are excluded from LOOPED sets: count them per group
         const unsigned long long sb = __ballot(pv && jj == row);
         nself += __popcll((sb >> (g << LPR_LOG2)) & ((LPR == 64) ? ~0ull : ((1ull << LPR) - 1ull)));

@@ -149,6 +149,18 @@ __global__ void __launch_bounds__(16 * PREP_ROWS) prepare_kernel(int64_t n_nodes
   }
 }
 
+// out[p] = dis[col[p]] for the two deg^-1/2 tables (either may be absent)
+__global__ void __launch_bounds__(256) edge_dis_kernel(int64_t n_edges, const int32_t* __restrict__ col,
+                                                       const float* __restrict__ dis_raw, const float* __restrict__ dis_looped,
+                                                       float* __restrict__ out_raw, float* __restrict__ out_looped) {
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; p < n_edges; p += (int64_t)gridDim.x * blockDim.x) {
+    const int j = col[p];
+    if (out_raw != nullptr) out_raw[p] = dis_raw[j];
+    if (out_looped != nullptr) out_looped[p] = dis_looped[j];
+  }
+}
+
 __global__ void plan_header_kernel(int32_t* plan, int cap_long, int cap_chunks) {
   plan[0] = 0;
   plan[1] = 0;
@@ -235,6 +247,20 @@ int egc_coo_to_csr(const int64_t* src, const int64_t* dst, int64_t n_edges, int6
   EGC_LAUNCH_CHECK("gather_col_kernel");
   rowptr_kernel<<<(int)ceil_div(n_nodes + 1, threads), threads, 0, stream>>>(keys_out, n_edges, n_nodes, rowptr);
   EGC_LAUNCH_CHECK("rowptr_kernel");
+  return EGC_OK;
+}
+
+int egc_csr_edge_dis(int64_t n_edges, const int32_t* col, const float* dis_raw, const float* dis_looped,
+                     float* edge_dis_raw, float* edge_dis_looped, egc_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_edges < 0) return EGC_ERR_INVALID;
+  if (dis_raw == nullptr) edge_dis_raw = nullptr;
+  if (dis_looped == nullptr) edge_dis_looped = nullptr;
+  if (n_edges == 0 || (edge_dis_raw == nullptr && edge_dis_looped == nullptr)) return EGC_OK;
+  if (col == nullptr) return EGC_ERR_INVALID;
+  const int blocks = (int)std::min<int64_t>(ceil_div(n_edges, 256), 256 * 8);
+  edge_dis_kernel<<<blocks, 256, 0, stream>>>(n_edges, col, dis_raw, dis_looped, edge_dis_raw, edge_dis_looped);
+  EGC_LAUNCH_CHECK("edge_dis_kernel");
   return EGC_OK;
 }
 

@@ -39,6 +39,7 @@ class CSRGraph:
         self.rowptr, self.col, self.edge_id = rowptr, col, edge_id
         self.dis_raw, self.dis_looped, self.max_index, self.plan = dis_raw, dis_looped, max_index, plan
         self.device = rowptr.device
+        self.edge_dis_raw = self.edge_dis_looped = None  # dis_*[col[p]] per entry (refresh_edge_dis)
         self._workspaces = {}
         self._n_chunks = None  # host copy of plan[1], read back lazily (one synchronisation per graph)
 
@@ -80,6 +81,7 @@ class CSRGraph:
         if exchange_dis and plan.n_halo >= 0 and plan.world > 1:
             plan.exchange(g.dis_raw)
             plan.exchange(g.dis_looped)
+            g.refresh_edge_dis()
         return g
 
     @classmethod
@@ -110,7 +112,24 @@ class CSRGraph:
         plan = torch.empty(lib.egc_plan_ints(n, e), dtype=torch.int32, device=dev)
         _C.check(lib.egc_csr_prepare(n, e, rowptr.data_ptr(), col.data_ptr(), dis_raw.data_ptr(),
                                      dis_looped.data_ptr(), plan.data_ptr(), _stream_ptr(dev)), "egc_csr_prepare")
-        return cls(n, e, rowptr, col, edge_id, dis_raw, dis_looped, max_index, plan, ns)
+        g = cls(n, e, rowptr, col, edge_id, dis_raw, dis_looped, max_index, plan, ns)
+        if ns == n:  # square adjacency: symnorm is meaningful; partitions refresh after the halo exchange of dis
+            g.refresh_edge_dis()
+        return g
+
+    def refresh_edge_dis(self):
+        """(Re)build the per-entry copies of the source-side deg^-1/2 (egc_csr_edge_dis): the aggregate kernel then
+        streams them instead of gathering dis[col[p]].  Call again whenever dis_raw / dis_looped change."""
+        lib = _C.load()
+        dev = self.device
+        e = self.n_edges
+        with torch.cuda.device(dev):
+            if self.edge_dis_raw is None:
+                self.edge_dis_raw = torch.empty(max(e, 1), dtype=torch.float32, device=dev)
+                self.edge_dis_looped = torch.empty(max(e, 1), dtype=torch.float32, device=dev)
+            _C.check(lib.egc_csr_edge_dis(e, self.col.data_ptr(), self.dis_raw.data_ptr(), self.dis_looped.data_ptr(),
+                                          self.edge_dis_raw.data_ptr(), self.edge_dis_looped.data_ptr(),
+                                          _stream_ptr(dev)), "egc_csr_edge_dis")
 
     def transposed(self) -> "CSRGraph":
         """The transposed graph as a CSRGraph (rows = SOURCES, entries = destinations, with its own long-row
@@ -146,7 +165,9 @@ class CSRGraph:
             self._n_chunks = int(self.plan[1].item())
         return _C.EgcGraph(self.n_nodes, self.n_edges, self.rowptr.data_ptr(), self.col.data_ptr(),
                            self.edge_id.data_ptr(), self.dis_raw.data_ptr(), self.dis_looped.data_ptr(),
-                           self.max_index.data_ptr(), self.plan.data_ptr(), self._n_chunks, self.n_src_rows)
+                           self.max_index.data_ptr(), self.plan.data_ptr(), self._n_chunks, self.n_src_rows,
+                           self.edge_dis_raw.data_ptr() if self.edge_dis_raw is not None else None,
+                           self.edge_dis_looped.data_ptr() if self.edge_dis_looped is not None else None)
 
     def long_row_stats(self):
         """(n_long_rows, n_chunks) -- synchronises; diagnostics only."""

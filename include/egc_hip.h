@@ -89,6 +89,11 @@ typedef struct {
                                  from other ranks follow (n_src_rows >= n_nodes).  0 means n_nodes.  A rectangular
                                  adjacency between two node types (relational EGC, rmag/models.py:131-134) may have
                                  any n_src_rows > 0, with the RAW edge set and without symnorm. */
+  const float* edge_dis_raw;  /* [n_edges] dis_raw[col[p]] per CSR entry, or NULL: the source-side deg^-1/2 factor of the
+                                 symnorm weight laid out in traversal order (egc_csr_edge_dis), so that the aggregate
+                                 kernel streams it instead of gathering 4 bytes per entry; the weight itself,
+                                 dis[src] * dis[dst], is still formed in the kernel */
+  const float* edge_dis_looped; /* [n_edges] the same for dis_looped, or NULL */
 } egc_graph;
 
 /* int32 words the caller must allocate for egc_graph.plan. */
@@ -113,6 +118,11 @@ int egc_coo_to_csr(const int64_t* src, const int64_t* dst, int64_t n_edges, int6
  * dis_raw / dis_looped may be NULL (skipped). */
 int egc_csr_prepare(int64_t n_nodes, int64_t n_edges, const int32_t* rowptr, const int32_t* col,
                     float* dis_raw, float* dis_looped, int32_t* plan, egc_stream_t stream);
+
+/* Per-entry copies of the source-side deg^-1/2 (egc_graph.edge_dis_*): out[p] = dis[col[p]].  Call after the
+ * dis_* arrays are final (on a vertex partition: after their halo entries have arrived).  Either pair may be NULL. */
+int egc_csr_edge_dis(int64_t n_edges, const int32_t* col, const float* dis_raw, const float* dis_looped,
+                     float* edge_dis_raw, float* edge_dis_looped, egc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Layer description (the arguments of EfficientGraphConv.__init__ layers.py:13-27 /

@@ -386,6 +386,8 @@ def test_interior_first_partition_and_row_ranges(world):
                   for e, plan in parts]
         for key in ("dis_raw", "dis_looped"):
             P.simulate_exchange([getattr(g, key) for g in graphs], plans_on(plans, dev))
+        for g in graphs:
+            g.refresh_edge_dis()   # per-entry deg^-1/2 copies follow the exchanged tables
         stage = [egc_basis_transform(g, conv._spec_coo, x[pl.lo:pl.hi][pl.order], wcat, bcat) for g, pl in zip(graphs, plans)]
         outs = []
         for g, pl, (b, w) in zip(graphs, plans, stage):
