@@ -200,7 +200,7 @@ __device__ inline void finish_row(const AggArgs& a, __amdgpu_buffer_rsrc_t rsrc,
     if (a.post_scale != nullptr) z = fmaf(z, a.post_scale[o], a.post_shift[o]);
     if (a.post_relu) z = fmaxf(z, 0.f);
     if (a.residual != nullptr) z += a.residual[(int64_t)row * a.F_out + o];
-    orow[o] = z;
+    __builtin_nontemporal_store(z, &orow[o]);  // written once, read by a later kernel: keep it out of the L2 write-back at kernel end
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }

@@ -40,6 +40,9 @@
 namespace egc {
 
 constexpr int AMAX = 4;     // aggregators supported by the register-resident combine
+// `out` is written once and read by a LATER kernel: non-temporal stores (aux bit 1) keep the rows from piling up
+// as dirty lines in the XCDs' L2s, whose write-back at the end of the kernel otherwise costs ~3 us per launch.
+constexpr int OUT_NT = 2;
 constexpr int FU = 4;       // neighbour-row loads in flight per lane group
 constexpr int HPB_MAX = 4;  // ceil(H / B) supported
 
@@ -375,7 +378,7 @@ __device__ inline void finish_group(const AggArgs& a, const FastRsrc& R, int lan
       r = r + *reinterpret_cast<const f4*>(lds_bias + (mine ? oc : 0));
       if (a.post_relu) r = f4{fmaxf(r.x, 0.f), fmaxf(r.y, 0.f), fmaxf(r.z, 0.f), fmaxf(r.w, 0.f)};
       if (a.residual != nullptr) r = r + load_slot(R.res, mine ? orow + (unsigned)oc * 4u : OOB);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, r), R.out, mine ? orow + (unsigned)oc * 4u : OOB, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, r), R.out, mine ? orow + (unsigned)oc * 4u : OOB, 0, OUT_NT);
     } else {
       // padded bases (L % 4 != 0): the bias strip is padded the same way, head rows are only 4-byte aligned
       // and the last slot of a head is ragged -> four dword stores, out-of-range where the channel does not exist
@@ -390,10 +393,10 @@ __device__ inline void finish_group(const AggArgs& a, const FastRsrc& R, int lan
         const float* rr = a.residual + (int64_t)(mine ? row : 0) * C::F_out(a) + (mine ? oc : 0);
         rx += left > 0 ? rr[0] : 0.f; ry += left > 1 ? rr[1] : 0.f; rz += left > 2 ? rr[2] : 0.f; rw += left > 3 ? rr[3] : 0.f;
       }
-      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rx), R.out, left > 0 ? base : OOB, 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ry), R.out, left > 1 ? base + 4u : OOB, 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rz), R.out, left > 2 ? base + 8u : OOB, 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rw), R.out, left > 3 ? base + 12u : OOB, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rx), R.out, left > 0 ? base : OOB, 0, OUT_NT);
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ry), R.out, left > 1 ? base + 4u : OOB, 0, OUT_NT);
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rz), R.out, left > 2 ? base + 8u : OOB, 0, OUT_NT);
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rw), R.out, left > 3 ? base + 12u : OOB, 0, OUT_NT);
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // strip reads done before the next row overwrites it
