@@ -278,11 +278,11 @@ __global__ void __launch_bounds__(256) bwd_dst_kernel(BwdArgs a) {
     const int b = c / a.Ls, l = c - b * a.Ls;
     if (l >= a.L) {  // padding column of a padded basis: nothing flows through it
       for (int t = 0; t < a.A; ++t) lds_agg[t * a.ldb + c] = 0.f;
-      a.tab_t[(int64_t)row * a.ldb + c] = 0.f;
-      if (a.tab_s != nullptr) a.tab_s[(int64_t)row * a.ldb + c] = 0.f;
-      if (a.tab_v != nullptr) a.tab_v[(int64_t)row * a.ldb + c] = 0.f;
-      if (a.tab_x != nullptr) a.tab_x[(int64_t)row * a.ldb + c] = 0.f;
-      if (a.tab_n != nullptr) a.tab_n[(int64_t)row * a.ldb + c] = 0.f;
+      __builtin_nontemporal_store((float)(0.f), &a.tab_t[(int64_t)row * a.ldb + c]);
+      if (a.tab_s != nullptr) __builtin_nontemporal_store((float)(0.f), &a.tab_s[(int64_t)row * a.ldb + c]);
+      if (a.tab_v != nullptr) __builtin_nontemporal_store((float)(0.f), &a.tab_v[(int64_t)row * a.ldb + c]);
+      if (a.tab_x != nullptr) __builtin_nontemporal_store((float)(0.f), &a.tab_x[(int64_t)row * a.ldb + c]);
+      if (a.tab_n != nullptr) __builtin_nontemporal_store((float)(0.f), &a.tab_n[(int64_t)row * a.ldb + c]);
       continue;
     }
     const float sum = a.stat_slot[STAT_SUM] >= 0 ? st[a.stat_slot[STAT_SUM] * a.ldb + c] : 0.f;
@@ -314,17 +314,17 @@ __global__ void __launch_bounds__(256) bwd_dst_kernel(BwdArgs a) {
       switch (a.aggr[t]) {
         case EGC_AGGR_SUM: d_t += d; break;
         case EGC_AGGR_MEAN: d_t += d / cntf; break;
-        case EGC_AGGR_MAX: a.tab_x[(int64_t)row * a.ldb + c] = cnt > 0 ? d : 0.f; break;
-        case EGC_AGGR_MIN: a.tab_n[(int64_t)row * a.ldb + c] = cnt > 0 ? d : 0.f; break;
+        case EGC_AGGR_MAX: __builtin_nontemporal_store((float)(cnt > 0 ? d : 0.f), &a.tab_x[(int64_t)row * a.ldb + c]); break;
+        case EGC_AGGR_MIN: __builtin_nontemporal_store((float)(cnt > 0 ? d : 0.f), &a.tab_n[(int64_t)row * a.ldb + c]); break;
         case EGC_AGGR_VAR: d_v += d; break;
         case EGC_AGGR_STD: d_v += (var > 0.f) ? d / (2.0f * sd) : 0.f; break;
         default: d_s += d * dis_i; break;
       }
     }
     // var = E[x^2] - mean^2:  d/dx_j = 2 (x_j - mean) / cnt
-    a.tab_t[(int64_t)row * a.ldb + c] = d_t - 2.0f * mean * d_v / cntf;
-    if (a.tab_s != nullptr) a.tab_s[(int64_t)row * a.ldb + c] = d_s;
-    if (a.tab_v != nullptr) a.tab_v[(int64_t)row * a.ldb + c] = 2.0f * d_v / cntf;
+    __builtin_nontemporal_store((float)(d_t - 2.0f * mean * d_v / cntf), &a.tab_t[(int64_t)row * a.ldb + c]);
+    if (a.tab_s != nullptr) __builtin_nontemporal_store((float)(d_s), &a.tab_s[(int64_t)row * a.ldb + c]);
+    if (a.tab_v != nullptr) __builtin_nontemporal_store((float)(2.0f * d_v / cntf), &a.tab_v[(int64_t)row * a.ldb + c]);
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(256) bwd_dst_kernel(BwdArgs a) {
       for (int q = 0; q < AB; ++q) dot = fmaf(lds_dagg[h * AB + q], lds_w[h * AB + q], dot);
       d = w * (d - dot);
     }
-    a.d_weightings[(int64_t)row * a.W + k] = d;
+    __builtin_nontemporal_store(d, &a.d_weightings[(int64_t)row * a.W + k]);
   }
 }
 
