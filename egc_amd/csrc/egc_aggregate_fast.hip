@@ -287,13 +287,13 @@ __device__ inline void finish_group(const AggArgs& a, const FastRsrc& R, int lan
   }
   if (a.stats != nullptr && store && row_ok && live) {  // training forward: keep the raw aggregates for the backward
     float* st = a.stats + ((int64_t)row * a.stat_k) * a.ldb + 4 * q;
-    if (a.stat_slot[STAT_SUM] >= 0) *reinterpret_cast<f4*>(st + a.stat_slot[STAT_SUM] * a.ldb) = acc.sum;
-    if (a.stat_slot[STAT_MX] >= 0) *reinterpret_cast<f4*>(st + a.stat_slot[STAT_MX] * a.ldb) = acc.mx;
-    if (a.stat_slot[STAT_WS] >= 0) *reinterpret_cast<f4*>(st + a.stat_slot[STAT_WS] * a.ldb) = acc.ws;
+    if (a.stat_slot[STAT_SUM] >= 0) __builtin_nontemporal_store(acc.sum, reinterpret_cast<f4*>(st + a.stat_slot[STAT_SUM] * a.ldb));
+    if (a.stat_slot[STAT_MX] >= 0) __builtin_nontemporal_store(acc.mx, reinterpret_cast<f4*>(st + a.stat_slot[STAT_MX] * a.ldb));
+    if (a.stat_slot[STAT_WS] >= 0) __builtin_nontemporal_store(acc.ws, reinterpret_cast<f4*>(st + a.stat_slot[STAT_WS] * a.ldb));
     if constexpr (NEED & NEED_SQ)
-      if (a.stat_slot[STAT_SQ] >= 0) *reinterpret_cast<f4*>(st + a.stat_slot[STAT_SQ] * a.ldb) = acc.sq;
+      if (a.stat_slot[STAT_SQ] >= 0) __builtin_nontemporal_store(acc.sq, reinterpret_cast<f4*>(st + a.stat_slot[STAT_SQ] * a.ldb));
     if constexpr (NEED & NEED_MN)
-      if (a.stat_slot[STAT_MN] >= 0) *reinterpret_cast<f4*>(st + a.stat_slot[STAT_MN] * a.ldb) = acc.mn;
+      if (a.stat_slot[STAT_MN] >= 0) __builtin_nontemporal_store(acc.mn, reinterpret_cast<f4*>(st + a.stat_slot[STAT_MN] * a.ldb));
     if (q == 0) a.cnt_out[row] = cnt;
   }
   const float cntf = (float)max(cnt, 1);
