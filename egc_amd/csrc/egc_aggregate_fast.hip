@@ -418,7 +418,7 @@ __device__ inline void load_row_operands(const AggArgs& a, const FastRsrc& R, in
   for (int k = 0; k < 2; ++k) {
     const int c0 = (q + k * LPR) * 4;
     wpre[k] = f4{0.f, 0.f, 0.f, 0.f};
-    if (c0 + 3 < W) wpre[k] = *reinterpret_cast<const f4*>(wrow + c0);
+    if (c0 + 3 < W) wpre[k] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(wrow + c0));  // read once: leave L2 to `bases`
     else if (c0 < W) {  // W not a multiple of 4: ragged last piece
       wpre[k].x = wrow[c0];
       if (c0 + 1 < W) wpre[k].y = wrow[c0 + 1];
