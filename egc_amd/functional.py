@@ -291,7 +291,7 @@ class _EGCLayerFunction(torch.autograd.Function):
     def forward(ctx, x, wcat, bcat, bias, graph, spec):
         bases, weightings = egc_basis_transform(graph, spec, x, wcat, bcat, None)
         if graph.halo is not None and graph.n_src_rows > graph.n_nodes:
-            raise RuntimeError("egc_amd: training on a vertex-partitioned graph is not implemented")
+            graph.halo.exchange(bases)   # vertex partition: halo rows of `bases` from their owners
         out, saved = egc_aggregate_combine_train(graph, spec, bases, weightings, bias)
         ctx.save_for_backward(x, wcat, bases, weightings)
         ctx.graph, ctx.spec, ctx.saved = graph, spec, saved
@@ -304,6 +304,11 @@ class _EGCLayerFunction(torch.autograd.Function):
         spec = ctx.spec
         grad_out = grad_out.contiguous()
         d_bases, d_w = egc_aggregate_combine_backward(ctx.graph, spec, bases, weightings, grad_out, ctx.saved)
+        halo = ctx.graph.halo
+        if halo is not None and ctx.graph.n_src_rows > ctx.graph.n_nodes:
+            # gradients collected for other ranks' vertices go home (reverse all-to-all-v) and are added there
+            back = halo.exchange_reverse(d_bases)
+            d_bases = d_bases[:ctx.graph.n_nodes].index_add(0, halo.send_idx, back)
         d_cat = torch.cat([d_bases[:, :spec.f_g], d_w], dim=1)             # [N, F_g + W]
         dx = d_cat @ wcat.t() if ctx.needs_input_grad[0] else None
         dwcat = _xt_matmul(x, d_cat) if ctx.needs_input_grad[1] else None

@@ -136,8 +136,6 @@ class CSRGraph:
         plan), needed by the backward: d bases[j] sums the destination tables over j's out-neighbours.
         Built on first use from the destination-keyed CSR and kept."""
         if getattr(self, "_transposed", None) is None:
-            if self.halo is not None:
-                raise RuntimeError("egc_amd: backward on a vertex-partitioned graph is not implemented")
             dev = self.device
             n, e, ns = self.n_nodes, self.n_edges, self.n_src_rows
             with torch.cuda.device(dev):

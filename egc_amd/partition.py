@@ -89,6 +89,25 @@ class HaloPlan:
         if handle is not None:
             handle[0].wait()
 
+    def exchange_reverse(self, table: torch.Tensor) -> torch.Tensor:
+        """The adjoint of `exchange` (backward pass): ship rows [n_local, n_local + n_halo) of `table` -- gradients
+        accumulated for OTHER ranks' vertices -- back to their owners.  Returns [n_send, width]: row k belongs to
+        the owned vertex send_idx[k] (one vertex may appear several times: once per rank that reads it)."""
+        import torch.distributed as dist
+        n = self.n_local
+        send = table[n:n + self.n_halo].contiguous()
+        width = 1 if table.dim() == 1 else table.size(1)
+        recv = torch.empty((int(self.send_idx.numel()),) + tuple(table.shape[1:]), dtype=table.dtype, device=table.device)
+        out_splits = [s * width for s in self.send_splits]
+        in_splits = [r * width for r in self.recv_splits]
+        if table.is_cuda and dist.get_backend(self.group) == "gloo":   # testing aid, see exchange_start
+            r_cpu = torch.empty(recv.numel(), dtype=recv.dtype)
+            dist.all_to_all_single(r_cpu, send.view(-1).cpu(), out_splits, in_splits, group=self.group)
+            recv.view(-1).copy_(r_cpu)
+        else:
+            dist.all_to_all_single(recv.view(-1), send.view(-1), out_splits, in_splits, group=self.group)
+        return recv
+
     def exchange(self, table: torch.Tensor):
         """exchange_start + exchange_finish.  `table` is [n_local + n_halo, width] (bases) or
         [n_local + n_halo] (deg^-1/2)."""
