@@ -411,3 +411,52 @@ def plans_on(plans, dev):
     for p in plans:
         p.halo_global_ids = p.halo_global_ids.to(dev)
     return plans
+
+
+def test_layer_forward_is_graph_capturable():
+    """The library never allocates or synchronises and launches on the caller's stream, so a whole layer forward
+    (GEMM + fused aggregate, incl. the long-row handshake) can be captured in a HIP graph and replayed."""
+    import ctypes as C
+    import egc_amd
+    from egc_amd import _C
+    from egc_amd.functional import pack_weights
+    from egc_amd.workloads import heavy_tailed_graph
+    dev = _dev()
+    lib = _C.load()
+    n = 30000
+    ei = heavy_tailed_graph(n, 250000, seed=5).to(dev)
+    conv = egc_amd.EGConv(128, 128, aggrs=["sum", "mean", "max", "symnorm"]).to(dev).eval()
+    graph = egc_amd.CSRGraph.from_edge_index(ei, n)
+    spec = conv._spec_coo
+    with torch.no_grad():
+        wcat, bcat = conv._packed_weights()
+        planes = pack_weights(spec, wcat)
+        x = torch.randn(n, 128, device=dev)
+        ref = conv(x, graph)
+    bases = torch.empty((n, spec.ldb), device=dev)
+    wt = torch.empty((n, spec.w_cols), device=dev)
+    out = torch.zeros((n, 128), device=dev)
+    ws = torch.zeros(max(lib.egc_aggregate_workspace_bytes(C.byref(spec.c), n, ei.size(1)), 1), dtype=torch.uint8, device=dev)
+    g = graph.c_struct()
+
+    def step(stream):
+        _C.check(lib.egc_layer_forward_packed(C.byref(g), C.byref(spec.c), x.data_ptr(), planes.data_ptr(), bcat.data_ptr(),
+                                              conv.bias.data_ptr(), bases.data_ptr(), spec.ldb, wt.data_ptr(), out.data_ptr(),
+                                              ws.data_ptr(), ws.numel(), stream), "egc_layer_forward_packed")
+
+    step(torch.cuda.current_stream().cuda_stream)   # one eager call first (one-time function attributes)
+    torch.cuda.synchronize()
+    cg = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(cg):
+        step(torch.cuda.current_stream().cuda_stream)
+    for _ in range(3):
+        out.zero_()
+        x.mul_(1.0)          # same values, new launch order
+        cg.replay()
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) <= TOL
+    x.copy_(torch.randn(n, 128, device=dev))   # new inputs through the same captured graph
+    cg.replay()
+    with torch.no_grad():
+        ref2 = conv(x, graph)
+    assert rel_err(out.cpu().numpy(), ref2.cpu().numpy()) <= TOL
