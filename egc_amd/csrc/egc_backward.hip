@@ -25,6 +25,8 @@
 //                        longer than EGC_LONG_ROW_THRESHOLD are cut into chunks (plan of the transposed graph)
 //                        whose partial sums arrive by float atomics
 // Any H, B, L, A and every weight nonlinearity; deterministic except for the order of float atomics on hub rows.
+#include <stdlib.h>
+
 #include "egc_aggregate_dev.h"
 
 namespace egc {
@@ -353,6 +355,163 @@ __global__ void __launch_bounds__(256) bwd_dst_kernel(BwdArgs a) {
   }
 }
 
+// Register-resident form of bwd_dst_kernel for the layouts the forward's register kernels serve with shifts:
+// every basis spans a power-of-two number P of 16-byte slots (L or the padded stride a multiple of 4), B a power
+// of two, S = B P <= 64 slots, and P divides H.  One LANE GROUP per destination row (G = 64 / LPR rows per wavefront,
+// as in the forward): lane q = b P + l4 owns columns 4 l4 .. 4 l4 + 3 of basis b.  The row's g and activated
+// weights sit in per-group LDS strips; a lane forms  d agg_t = sum_h w'[h][b][t] g[h][l..l+3]  and its share of
+// d w'[h][b][t] = sum_l g[h][l] agg_t[b][l]  in one pass over h, the shares meet in an xor butterfly over the P
+// lanes of the basis, and lane l4 stores the heads l4 H/P .. (l4+1) H/P - 1.
+constexpr int BWD_HMAX = 16;   // heads supported by the register form
+// HT / AT: compile-time head and aggregator counts (the d = 128, H = 8 layers; everything else: bwd_dst_kernel)
+template <int LPR_LOG2, int HT, int AT>
+__global__ void __launch_bounds__(256) bwd_dst_fast_kernel(BwdArgs a) {
+  extern __shared__ float smem[];
+  constexpr int LPR = 1 << LPR_LOG2, G = 64 / LPR;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int g = lane >> LPR_LOG2, q = lane & (LPR - 1);
+  const int P = a.Ls >> 2;                      // lanes per basis (power of two)
+  const int plog = 31 - __builtin_clz(P);
+  const bool live = q < a.slots;
+  const int b = min(q >> plog, a.B - 1), l4 = q & (P - 1);
+  const int row = (blockIdx.x * 4 + wave) * G + g;
+  const bool row_ok = row < a.n_nodes;
+  const int rr = row_ok ? row : 0;
+  const int gpad = (a.H * a.Ls + 3) & ~3, wpad = (a.W + 3) & ~3;
+  float* lds_g = smem + (wave * G + g) * (gpad + wpad);    // g in the padded head layout [h][Ls]
+  float* lds_w = lds_g + gpad;                              // activated weights [h][b][a]
+  const int A = AT > 0 ? AT : a.A, H = HT > 0 ? HT : a.H;
+  constexpr int HM = HT > 0 ? HT : BWD_HMAX;
+
+  // ---- stage the row's g and w' (LPR lanes, 16 bytes each per step)
+  for (int o = 4 * q; o < H * a.Ls; o += 4 * LPR) {
+    const int h = (o >> 2) >> plog, l = o - h * a.Ls;       // 4 consecutive channels of one head (Ls = 4 P)
+    f4 v = f4{0.f, 0.f, 0.f, 0.f};
+    const float* gp = a.grad_out + (int64_t)rr * a.F_out + h * a.L + l;
+    if (l + 3 < a.L) { v.x = gp[0]; v.y = gp[1]; v.z = gp[2]; v.w = gp[3]; }
+    else { if (l < a.L) v.x = gp[0]; if (l + 1 < a.L) v.y = gp[1]; if (l + 2 < a.L) v.z = gp[2]; }
+    *reinterpret_cast<f4*>(lds_g + o) = v;
+  }
+  for (int k = q; k < a.W; k += LPR) {
+    float w = a.weightings[(int64_t)rr * a.W + k];
+    if (a.act == EGC_ACT_SIGMOID) w = 1.0f / (1.0f + expf(-w));
+    else if (a.act == EGC_ACT_HARDTANH) w = fminf(fmaxf(w, -1.0f), 1.0f);
+    lds_w[k] = w;
+  }
+  // ---- this lane's slot of the saved aggregates
+  const int cnt = row_ok ? a.cnt[rr] : 0;
+  const float cntf = (float)max(cnt, 1);
+  const float dis_i = a.dis != nullptr ? a.dis[rr] : 0.f;
+  const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
+  const float* st = a.stats + ((int64_t)rr * a.stat_k) * a.ldb + 4 * q;
+  auto stat = [&](int s) -> f4 {
+    return (a.stat_slot[s] >= 0 && live) ? *reinterpret_cast<const f4*>(st + a.stat_slot[s] * a.ldb) : zero;
+  };
+  const f4 sum = stat(STAT_SUM), sq = stat(STAT_SQ), mx = stat(STAT_MX), mn = stat(STAT_MN), ws = stat(STAT_WS);
+  // exact divisions only where the forward needs them bit for bit (var / std); a reciprocal otherwise
+  const bool has_sq = a.stat_slot[STAT_SQ] >= 0;
+  const float rcnt = 1.0f / cntf;
+  const f4 mean = has_sq ? f4_div(sum, cntf) : sum * f4{rcnt, rcnt, rcnt, rcnt};
+  const f4 var = has_sq ? f4_var(f4_div(sq, cntf), mean) : zero;
+  const f4 sd = has_sq ? f4_std(var) : zero;
+  f4 val[4], dagg[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    val[t] = dagg[t] = zero;
+    if (t < A) {
+      switch (a.aggr[t]) {
+        case EGC_AGGR_SUM: val[t] = sum; break;
+        case EGC_AGGR_MEAN: val[t] = mean; break;
+        case EGC_AGGR_MAX: val[t] = cnt > 0 ? mx : zero; break;
+        case EGC_AGGR_MIN: val[t] = cnt > 0 ? mn : zero; break;
+        case EGC_AGGR_VAR: val[t] = var; break;
+        case EGC_AGGR_STD: val[t] = sd; break;
+        default: val[t] = ws; break;
+      }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // strips of this group written (one wavefront: in order)
+
+  // ---- one pass over the heads
+  float dwp[HM][4];   // this lane's share of d w'[h][b][t]
+#pragma unroll
+  for (int h = 0; h < HM; ++h) {
+    if (h < H) {
+      const f4 gv = *reinterpret_cast<const f4*>(lds_g + h * a.Ls + 4 * l4);
+      const float* wp = lds_w + (h * a.B + b) * A;
+      f4 wv = zero;
+      if (A == 4) wv = *reinterpret_cast<const f4*>(wp);
+      else { wv.x = wp[0]; if (A > 1) wv.y = wp[1]; if (A > 2) wv.z = wp[2]; }
+      dagg[0] = f4_fma(f4{wv.x, wv.x, wv.x, wv.x}, gv, dagg[0]);
+      if (A > 1) dagg[1] = f4_fma(f4{wv.y, wv.y, wv.y, wv.y}, gv, dagg[1]);
+      if (A > 2) dagg[2] = f4_fma(f4{wv.z, wv.z, wv.z, wv.z}, gv, dagg[2]);
+      if (A > 3) dagg[3] = f4_fma(f4{wv.w, wv.w, wv.w, wv.w}, gv, dagg[3]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        dwp[h][t] = t < A ? fmaf(gv.w, val[t].w, fmaf(gv.z, val[t].z, fmaf(gv.y, val[t].y, gv.x * val[t].x))) : 0.f;
+    }
+  }
+
+  // ---- tables for the source side
+  f4 d_t = zero, d_s = zero, d_v = zero;
+  const int64_t o = (int64_t)rr * a.ldb + 4 * q;
+  const bool wr = row_ok && live;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (t >= A) break;
+    const f4 d = dagg[t];
+    switch (a.aggr[t]) {
+      case EGC_AGGR_SUM: d_t += d; break;
+      case EGC_AGGR_MEAN: d_t += d * f4{rcnt, rcnt, rcnt, rcnt}; break;
+      case EGC_AGGR_MAX: if (wr) __builtin_nontemporal_store(cnt > 0 ? d : zero, reinterpret_cast<f4*>(a.tab_x + o)); break;
+      case EGC_AGGR_MIN: if (wr) __builtin_nontemporal_store(cnt > 0 ? d : zero, reinterpret_cast<f4*>(a.tab_n + o)); break;
+      case EGC_AGGR_VAR: d_v += d; break;
+      case EGC_AGGR_STD:
+        d_v += f4{var.x > 0.f ? d.x / (2.0f * sd.x) : 0.f, var.y > 0.f ? d.y / (2.0f * sd.y) : 0.f,
+                  var.z > 0.f ? d.z / (2.0f * sd.z) : 0.f, var.w > 0.f ? d.w / (2.0f * sd.w) : 0.f};
+        break;
+      default: d_s += d * f4{dis_i, dis_i, dis_i, dis_i}; break;
+    }
+  }
+  if (wr) {
+    const f4 two_dv = d_v * f4{2.f * rcnt, 2.f * rcnt, 2.f * rcnt, 2.f * rcnt};
+    __builtin_nontemporal_store(d_t - mean * two_dv, reinterpret_cast<f4*>(a.tab_t + o));
+    if (a.tab_s != nullptr) __builtin_nontemporal_store(d_s, reinterpret_cast<f4*>(a.tab_s + o));
+    if (a.tab_v != nullptr) __builtin_nontemporal_store(two_dv, reinterpret_cast<f4*>(a.tab_v + o));
+  }
+
+  // ---- d w': butterfly over the P lanes of a basis, then lane l4 keeps heads [l4 H/P, (l4+1) H/P)
+  for (int off = 1; off < P; off <<= 1) {
+#pragma unroll
+    for (int h = 0; h < HM; ++h)
+      if (h < H) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          if (t < A) dwp[h][t] += __shfl_xor(dwp[h][t], off);
+      }
+  }
+  const int hpl = H / P;   // heads per lane (host: P divides H)
+#pragma unroll
+  for (int h = 0; h < HM; ++h) {
+    if (h >= H) break;
+    if (!(wr && h / hpl == l4)) continue;
+    const int k0 = (h * a.B + b) * A;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (t >= A) break;
+      float d = dwp[h][t];
+      const float w = lds_w[k0 + t];
+      if (a.act == EGC_ACT_SIGMOID) d = d * w * (1.0f - w);
+      else if (a.act == EGC_ACT_HARDTANH) {
+        const float pre = a.weightings[(int64_t)row * a.W + k0 + t];
+        d = (pre > -1.0f && pre < 1.0f) ? d : 0.f;
+      }
+      __builtin_nontemporal_store(d, &a.d_weightings[(int64_t)row * a.W + k0 + t]);
+    }
+  }
+}
+
 // Sum of the destination tables over one source row's out-entries [start, end), entries t, t + step, ...:
 // lane q of the group holds slot(s) q, q + LPR, ... (NS of them).
 constexpr int BWD_FU = 4;
@@ -604,8 +763,29 @@ int egc_aggregate_combine_backward_f32(const egc_graph* graph, const egc_graph* 
   if ((size_t)wpb * a.lds_floats_per_wave * sizeof(float) > 48 * 1024) wpb = 1;
   const size_t lds = (size_t)wpb * a.lds_floats_per_wave * sizeof(float);
   if (lds > 64 * 1024) return EGC_ERR_UNSUPPORTED;
-  bwd_dst_kernel<<<(unsigned)ceil_div(n, wpb), wpb * 64, lds, stream>>>(a);
-  EGC_LAUNCH_CHECK("bwd_dst_kernel");
+  {
+    // register-resident form when the layout allows (see bwd_dst_fast_kernel), else the LDS-based kernel
+    const int P = a.Ls / 4;
+    const bool fast = getenv("EGC_BWD_GENERIC") == nullptr && (a.Ls & 3) == 0 && a.ldb == a.B * a.Ls && P >= 1 &&
+                      (P & (P - 1)) == 0 && (a.B & (a.B - 1)) == 0 && a.slots <= 64 && a.A <= 4 && a.H <= BWD_HMAX &&
+                      a.H % P == 0 && a.act != EGC_ACT_SOFTMAX &&
+                      // only the compiled head / aggregator counts: with run-time counts the LDS kernel is faster
+                      a.slots <= 16 && a.H == 8 && (a.A == 1 || a.A == 3 || a.A == 4);
+    if (fast) {
+      const int lpr = a.slots <= 16 ? 16 : a.slots <= 32 ? 32 : 64;
+      const int G = 64 / lpr;
+      const size_t flds = (size_t)4 * G * (((a.H * a.Ls + 3) & ~3) + ((a.W + 3) & ~3)) * sizeof(float);
+      const unsigned fgrid = (unsigned)ceil_div(n, (int64_t)4 * G);
+      if (flds > 64 * 1024) return EGC_ERR_UNSUPPORTED;
+      if (a.A == 4) bwd_dst_fast_kernel<4, 8, 4><<<fgrid, 256, flds, stream>>>(a);   // north star: EGC-M, 4 aggregators
+      else if (a.A == 3) bwd_dst_fast_kernel<4, 8, 3><<<fgrid, 256, flds, stream>>>(a);
+      else bwd_dst_fast_kernel<4, 8, 1><<<fgrid, 256, flds, stream>>>(a);
+      EGC_LAUNCH_CHECK("bwd_dst_fast_kernel");
+    } else {
+      bwd_dst_kernel<<<(unsigned)ceil_div(n, wpb), wpb * 64, lds, stream>>>(a);
+      EGC_LAUNCH_CHECK("bwd_dst_kernel");
+    }
+  }
 
   int lg = 0;
   while ((1 << lg) < a.slots && lg < 6) ++lg;
