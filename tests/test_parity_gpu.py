@@ -460,3 +460,37 @@ def test_layer_forward_is_graph_capturable():
     with torch.no_grad():
         ref2 = conv(x, graph)
     assert rel_err(out.cpu().numpy(), ref2.cpu().numpy()) <= TOL
+
+
+def test_arrays_beyond_two_gib_sampled_rows_against_float64():
+    """N = 4.3 M nodes: x, weightings and out exceed 2 GiB each (the GEMM runs in row ranges, the aggregate's
+    32-bit buffer offsets pass 2^31), a hub row of ~10^5 entries.  Sampled rows -- the first, the last, the hub,
+    random ones -- are recomputed in float64."""
+    import egc_amd
+    dev = _dev()
+    n, e = 4_300_000, 20_000_000
+    g = torch.Generator(device="cpu").manual_seed(1)
+    src = torch.randint(0, n, (e,), generator=g)
+    dst = (n * torch.rand(e, generator=g) ** 3).long().clamp_(max=n - 1)
+    ei = torch.stack([src, dst]).to(dev)
+    torch.manual_seed(0)
+    conv = egc_amd.EGConv(128, 128, aggrs=["sum", "mean", "max", "symnorm"]).to(dev).eval()
+    x = torch.randn(n, 128, device=dev)
+    H, B, A = 8, 4, 4
+    with torch.no_grad():
+        out = conv(x, ei)
+        rows = torch.cat([torch.tensor([0, 1, n - 1, n - 2]), torch.randint(0, n, (200,), generator=g)]).to(dev)
+        nonself = torch.bincount(ei[1][ei[0] != ei[1]], minlength=n).double() + 1   # gcn_norm: self loops replaced
+        dis = nonself.pow(-0.5)
+        sel = torch.isin(ei[1], rows) & (ei[0] != ei[1])
+        s_sel, d_sel = ei[0][sel], ei[1][sel]
+        W = conv.bases_weight.double()
+        worst = 0.0
+        for r in rows.tolist():
+            nb = torch.cat([s_sel[d_sel == r], torch.tensor([r], device=dev)])
+            bj = x[nb].double() @ W
+            aggs = torch.stack([bj.sum(0), bj.mean(0), bj.max(0).values, (bj * (dis[nb] * dis[r])[:, None]).sum(0)])
+            wt = (x[r].double() @ conv.comb_weight.weight.double().t() + conv.comb_weight.bias.double()).view(H, A, B)
+            ref = torch.einsum("hab,abl->hl", wt, aggs.view(A, B, 16)).reshape(-1) + conv.bias.double()
+            worst = max(worst, float((out[r].double() - ref).abs().max() / ref.abs().max().clamp(min=1)))
+    assert worst <= TOL, worst
