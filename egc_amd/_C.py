@@ -13,8 +13,8 @@ _LIB_PATH = os.environ.get("EGC_HIP_LIB") or os.path.join(os.path.dirname(os.pat
 _lib = None
 
 EGC_MAX_AGGRS = 8
-LONG_ROW_THRESHOLD = 32
-LONG_ROW_CHUNK = 128
+LONG_ROW_THRESHOLD = 64
+LONG_ROW_CHUNK = 256
 
 # enum egc_aggr
 AGGR_SUM, AGGR_MEAN, AGGR_MAX, AGGR_MIN, AGGR_VAR, AGGR_STD, AGGR_SYMNORM = range(7)

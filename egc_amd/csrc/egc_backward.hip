@@ -572,7 +572,7 @@ __device__ inline void sum_tables(const BwdArgs& a, const __amdgpu_buffer_rsrc_t
 }
 
 // d bases[j] += sum over out-neighbours of the tables (+ self-loop terms).  Leading blocks: one wavefront per
-// 128-entry chunk of a long row, partial sums by float atomics; the other blocks: one lane group per short row.
+// EGC_LONG_ROW_CHUNK-entry chunk of a long row, partial sums by float atomics; the other blocks: one lane group per short row.
 template <int NS>
 __global__ void __launch_bounds__(256) bwd_src_kernel(BwdArgs a) {
   const int lane = threadIdx.x & 63;

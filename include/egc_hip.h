@@ -64,8 +64,8 @@ typedef enum { EGC_ACT_NONE = 0, EGC_ACT_SOFTMAX = 1, EGC_ACT_SIGMOID = 2, EGC_A
 
 /* Rows with more than EGC_LONG_ROW_THRESHOLD entries are handled by whole wavefronts, in chunks of
  * EGC_LONG_ROW_CHUNK entries by separate wavefronts and merged (degree-skew handling). */
-#define EGC_LONG_ROW_THRESHOLD 32
-#define EGC_LONG_ROW_CHUNK 128
+#define EGC_LONG_ROW_THRESHOLD 64
+#define EGC_LONG_ROW_CHUNK 256
 
 /* ------------------------------------------------------------------------------------------
  * Graph: CSR keyed by DESTINATION, entries of one row kept in input (edge_index) order.

@@ -143,11 +143,14 @@ def _hub_graph(rng, n, e, hubs):
     ("lay", ["symadd", "std", "max"]), ("lay", ["add", "mean", "min", "var"]),
 ])
 def test_long_rows_chunk_merge_path(kind, aggrs):
-    """Rows above EGC_LONG_ROW_THRESHOLD go through the chunk + merge kernels (hubs of 129..5000)."""
+    """Rows above EGC_LONG_ROW_THRESHOLD go through the chunk + merge kernels (hubs around every boundary of
+    the threshold and the chunk length, up to 5000 entries)."""
     dev = _dev()
     rng = np.random.default_rng(7)
     n = 3000
-    hubs = [(0, 5000), (17, 129), (18, 128), (999, 1300), (n - 1, 257), (5, 4096)]
+    from egc_amd import _C
+    T, K = _C.LONG_ROW_THRESHOLD, _C.LONG_ROW_CHUNK
+    hubs = [(0, 5000), (17, K + 1), (18, K), (19, T), (20, T + 1), (21, 2 * K), (22, 2 * K + 1), (999, 1300), (n - 1, 257), (5, 4096)]
     ei = _hub_graph(rng, n, 12000, hubs)
     out, ref = _oracle_case(kind, rng, n, ei, 64, 64, 8, 4, aggrs, dev)
     assert rel_err(out, ref) <= TOL
