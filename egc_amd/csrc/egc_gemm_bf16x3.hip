@@ -1,4 +1,5 @@
-// Basis transform + weightings Linear on the bf16 matrix cores with fp32-level accuracy (gfx950).
+// Basis transform + weightings Linear on the bf16 matrix cores with fp32-level accuracy (gfx950), for every
+// shape the fp16x2 kernel (egc_gemm_f16x2.hip: the north-star layer) does not take.
 //
 //     [bases | weightings] = x[N,F_in] @ [bases_weight | comb.weight^T]  (+ comb.bias)
 //
@@ -25,8 +26,6 @@
 #include <stdlib.h>
 
 #include <algorithm>
-#include <cstdio>
-#include <vector>
 
 #include "egc_common.h"
 #include "egc_gemm_split.h"
@@ -443,201 +442,6 @@ __global__ void __launch_bounds__(512) basis_gemm_ws_kernel(const float* __restr
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Weight-stationary, 64-row tiles: wavefront (ct, rt) of a block owns column tile ct for row half rt of a
-// 64-row x tile, so a block of 2*NT wavefronts (12 at the north-star shape) puts the same number of
-// wavefronts on every SIMD.  To stay under 168 registers (3 wavefronts per SIMD) only the h and m planes of
-// the weight tile live in registers; the l plane -- used by one of the six products -- is kept once per
-// block in LDS next to the double-buffered x planes.
-// ---------------------------------------------------------------------------------------------
-
-// RT = 32-row halves per tile (ROWS = 32 RT); DBUF = double-buffered x planes (one barrier per tile) or a
-// single buffer (two barriers per tile, half the LDS: two blocks fit per CU and cover each other's phases).
-
-template <int KSUB, int RT, bool DBUF>
-__global__ void __launch_bounds__(768, 3) basis_gemm_ws2_kernel(const float* __restrict__ x, const u16* __restrict__ packed,
-                                                                const float* __restrict__ bcat, int64_t M, int K, int W,
-                                                                float* __restrict__ bases, int ldb,
-                                                                float* __restrict__ weightings, int NV, int n_tiles,
-                                                                int x_vec4) {
-  constexpr int KP = 16 * KSUB;
-  constexpr int LDX = KP + 8;
-  constexpr int WS2_ROWS = 32 * RT;
-  constexpr int XBUF = 3 * WS2_ROWS * LDX;  // bf16 elements of one x buffer (3 planes)
-  extern __shared__ __attribute__((aligned(16))) u16 smem2[];  // [1|2][3][ROWS][LDX] x planes, then [NV][LDX] Wl
-  u16* xs = smem2;
-  u16* wls = smem2 + (DBUF ? 2 : 1) * XBUF;
-  // comb.bias per virtual column (0 for the bases columns), read back with ds_read_b128 at store time: a
-  // global load there would sit behind `s_waitcnt vmcnt(0)`, and the in-order vmcnt would drain the previous
-  // tile's stores and the next tile's prefetch with it
-  float* bias_lds = reinterpret_cast<float*>(wls + NV * LDX);
-  const int tid = threadIdx.x;
-  const int nthreads = blockDim.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int NT = NV >> 5;
-  const int ct = wave % NT, rt = wave / NT;
-  const int hh = lane >> 5;
-  const int cb = 32 * ct;
-
-  // h / m planes of this wavefront's weight tile -> registers; l plane of the whole block -> LDS
-  bf16x8 wf[KSUB][2];
-#pragma unroll
-  for (int s = 0; s < KSUB; ++s)
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const u16* src = packed + ((((int64_t)(s >> 1) * 3 + p) * NV + cb + (lane & 31)) * XKT + 16 * (s & 1) + 8 * hh);
-      wf[s][p] = *reinterpret_cast<const bf16x8*>(src);
-    }
-  for (int i = tid; i < NV; i += nthreads)
-    bias_lds[i] = (bcat != nullptr && i >= ldb && i < ldb + W) ? bcat[i - ldb] : 0.f;
-  for (int i = tid; i < NV * (KP / 8); i += nthreads) {  // 16-byte pieces of the l plane
-    const int v = i / (KP / 8);
-    const int k8 = (i - v * (KP / 8)) * 8;
-    const u16* src = packed + ((((int64_t)(k8 >> 5) * 3 + 2) * NV + v) * XKT + (k8 & 31));
-    *reinterpret_cast<u32x4*>(wls + v * LDX + k8) = *reinterpret_cast<const u32x4*>(src);
-  }
-
-  constexpr int PIECES = WS2_ROWS * KP / 4;
-  constexpr int PPT = 3;  // host guarantees nthreads * PPT >= PIECES
-  // All global traffic of the tile loop goes through buffer instructions with an out-of-range offset for
-  // masked lanes (loads return 0, stores are dropped): no branches, so the compiler can count the in-flight
-  // operations and waits for the prefetched tile with vmcnt(N) instead of draining the stores with vmcnt(0).
-  constexpr unsigned GOOB = 0xFFFFFFF0u;
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (unsigned)(M * K * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)bases, 0, (unsigned)(M * ldb * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rw =
-      __builtin_amdgcn_make_buffer_rsrc((void*)weightings, 0, (unsigned)(M * (int64_t)W * 4), 0x00020000);
-  auto load_tile = [&](int tile, float4 (&xr)[PPT]) {
-    const int64_t m0 = (int64_t)tile * WS2_ROWS;
-#pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-      const int pc = tid + nthreads * i;
-      const int row = pc / (KP / 4);
-      const int k4 = (pc - row * (KP / 4)) * 4;
-      const int64_t gm = m0 + row;
-      const bool ok = tile < n_tiles && pc < PIECES && gm < M && k4 < K;
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? (unsigned)((gm * K + k4) * 4) : GOOB, 0, 0);
-      xr[i] = __builtin_bit_cast(float4, v);
-    }
-  };
-  auto stage_tile = [&](int buf, const float4 (&xr)[PPT]) {
-    u16* base = xs + buf * XBUF;
-#pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-      const int pc = tid + nthreads * i;
-      if (pc < PIECES) {
-        const int row = pc / (KP / 4);
-        const int k4 = (pc - row * (KP / 4)) * 4;
-        unsigned h0, m0_, l0, h1, m1, l1;
-        split3_pk(f32x2{xr[i].x, xr[i].y}, h0, m0_, l0);
-        split3_pk(f32x2{xr[i].z, xr[i].w}, h1, m1, l1);
-        u16* dst = base + row * LDX + k4;
-        *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
-        *reinterpret_cast<u32x2*>(dst + WS2_ROWS * LDX) = u32x2{m0_, m1};
-        *reinterpret_cast<u32x2*>(dst + 2 * WS2_ROWS * LDX) = u32x2{l0, l1};
-      }
-    }
-  };
-  auto compute_tile = [&](int tile, int buf) {
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const u16* xb = xs + buf * XBUF + (32 * rt + (lane & 31)) * LDX + 8 * hh;
-    const u16* wlb = wls + (cb + (lane & 31)) * LDX + 8 * hh;
-#pragma unroll
-    for (int s = 0; s < KSUB; ++s) {
-      const bf16x8 xh = *reinterpret_cast<const bf16x8*>(xb + 16 * s);
-      const bf16x8 xm = *reinterpret_cast<const bf16x8*>(xb + 16 * s + WS2_ROWS * LDX);
-      const bf16x8 xl = *reinterpret_cast<const bf16x8*>(xb + 16 * s + 2 * WS2_ROWS * LDX);
-      const bf16x8 wl = *reinterpret_cast<const bf16x8*>(wlb + 16 * s);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][0], xl, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][1], xm, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][0], xm, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][1], xh, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][0], xh, acc, 0, 0, 0);
-    }
-    const int64_t gm = (int64_t)tile * WS2_ROWS + 32 * rt + (lane & 31);
-    const bool row_ok = gm < M;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int vc = cb + 8 * j + 4 * hh;
-      const float4 bb = *reinterpret_cast<const float4*>(bias_lds + vc);
-      const f32x4v val = {acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]};
-      const f32x4v o = {val[0] + bb.x, val[1] + bb.y, val[2] + bb.z, val[3] + bb.w};
-      const bool to_b = row_ok && vc < ldb;
-      const bool to_w = row_ok && vc >= ldb && vc + 3 < ldb + W;
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rb,
-                                             to_b ? (unsigned)((gm * ldb + vc) * 4) : GOOB, 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rw,
-                                             to_w ? (unsigned)((gm * W + (vc - ldb)) * 4) : GOOB, 0, 0);
-    }
-  };
-
-  const int stride = gridDim.x;
-  int tile = blockIdx.x;
-  if (tile >= n_tiles) return;
-  float4 xr[PPT];
-  load_tile(tile, xr);
-  if (DBUF) {
-    stage_tile(0, xr);
-    lds_barrier();
-    int buf = 0;
-    for (; tile < n_tiles; tile += stride) {
-      load_tile(tile + stride, xr);  // masked (all lanes out of range) past the end
-      // keep the prefetch HERE: sunk below the epilogue stores it could only be consumed after
-      // s_waitcnt vmcnt(0), i.e. after the stores of this tile have completed
-      __builtin_amdgcn_sched_barrier(0);
-      compute_tile(tile, buf);
-      __builtin_amdgcn_sched_barrier(0);
-      stage_tile(buf ^ 1, xr);       // zeros past the end: harmless, keeps the loop branch-free
-      lds_barrier();
-      buf ^= 1;
-    }
-  } else {
-    lds_barrier();  // l plane of the weights is in LDS
-    for (; tile < n_tiles; tile += stride) {
-      stage_tile(0, xr);
-      lds_barrier();
-      load_tile(tile + stride, xr);  // next tile in flight during the MFMAs
-      __builtin_amdgcn_sched_barrier(0);
-      compute_tile(tile, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      lds_barrier();               // everyone is done with the buffer before it is overwritten
-    }
-  }
-}
-
-template <int KSUB, int RT, bool DBUF>
-static int launch_ws2(const float* x, const u16* packed, const float* bcat, int64_t M, int K, int W, float* bases, int ldb,
-                      float* weightings, int NV, hipStream_t stream) {
-  const int nt = NV / 32;
-  const int threads = 64 * nt * RT;
-  constexpr int KP = 16 * KSUB, LDX = KP + 8, ROWS = 32 * RT;
-  if (threads * 3 < ROWS * KP / 4 || threads > 768) return EGC_ERR_UNSUPPORTED;
-  const int64_t n_tiles64 = ceil_div(M, ROWS);
-  if (n_tiles64 >= ((int64_t)1 << 31)) return EGC_ERR_INVALID;
-  const int n_tiles = (int)n_tiles64;
-  const size_t lds = ((size_t)(DBUF ? 2 : 1) * 3 * ROWS * LDX + (size_t)NV * LDX) * sizeof(u16) + (size_t)NV * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&basis_gemm_ws2_kernel<KSUB, RT, DBUF>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) { set_last_error("hipFuncSetAttribute(ws2)", e); return EGC_ERR_HIP; }
-    attr_set = true;
-  }
-  // persistent grid: as many blocks as are resident (LDS-limited), each walks tiles with stride gridDim
-  int grid = 256 * (int)((160 * 1024) / lds);
-  if (const char* e = getenv("EGC_GEMM_GRID")) grid = atoi(e);
-  if (grid > n_tiles) grid = n_tiles;
-  const int x_vec4 = (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-  basis_gemm_ws2_kernel<KSUB, RT, DBUF><<<grid, threads, lds, stream>>>(x, packed, bcat, M, K, W, bases, ldb, weightings,
-                                                                       NV, n_tiles, x_vec4);
-  EGC_LAUNCH_CHECK("basis_gemm_ws2_kernel");
-  return EGC_OK;
-}
-
 template <int KSUB>
 static int launch_ws(const float* x, const u16* packed, const float* bcat, int64_t M, int K, int W, float* bases, int ldb,
                      float* weightings, int NV, hipStream_t stream) {
@@ -704,18 +508,8 @@ int egc_basis_transform_packed(const float* x, const void* packed, const float* 
   if (x == nullptr || packed == nullptr || bases == nullptr || (w_cols > 0 && weightings == nullptr)) return EGC_ERR_INVALID;
   const int NV = round_up32(ldb + w_cols);
   const int KS = (f_in + XKT - 1) / XKT;
-  const bool buf_ok = (f_in % 4 == 0) && (w_cols % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
-                      (uint64_t)n_nodes * (uint64_t)std::max(std::max(f_in, ldb), w_cols) * 4ull < 0xFFFFFFF0ull;
   if (use_f16x2(f_in, ldb, NV))  // the planes were packed for this kernel: no other form can read them
     return f16x2_launch(x, packed, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, stream);
-  if (f_in > 96 && f_in <= 128 && NV == 192 && buf_ok && getenv("EGC_GEMM_NO_WS2") == nullptr)
-  {
-    const char* v = getenv("EGC_GEMM_WS2");
-    if (v != nullptr && v[0] == '1')  // 32-row tiles, single x buffer, two 6-wavefront blocks per CU (measured slower)
-      return launch_ws2<8, 1, false>(x, (const u16*)packed, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, stream);
-    // default: 64-row tiles, double-buffered x planes, one 12-wavefront block per CU (3 wavefronts per SIMD)
-    return launch_ws2<8, 2, true>(x, (const u16*)packed, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, stream);
-  }
   if (f_in <= 128 && NV <= 256 && getenv("EGC_GEMM_NO_WS") == nullptr) {  // weight-stationary form (<= 8 wavefronts)
     const u16* pk = (const u16*)packed;
     int st;
