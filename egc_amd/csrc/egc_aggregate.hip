@@ -398,7 +398,8 @@ int egc_segment_mean_f32(const float* x, const int64_t* seg_ptr, int64_t n_segme
   hipStream_t stream = (hipStream_t)stream_;
   if (n_segments < 0 || width <= 0 || n_segments >= ((int64_t)1 << 31)) return EGC_ERR_INVALID;
   if (n_segments == 0) return EGC_OK;
-  if (x == nullptr || seg_ptr == nullptr || out == nullptr) return EGC_ERR_INVALID;
+  // x may be NULL when every segment is empty (a zero-row tensor has no storage); the kernel then reads nothing
+  if (seg_ptr == nullptr || out == nullptr) return EGC_ERR_INVALID;
   segment_mean_kernel<<<(unsigned)ceil_div(n_segments, 4), 256, 0, stream>>>(x, seg_ptr, n_segments, width, out);
   EGC_LAUNCH_CHECK("segment_mean_kernel");
   return EGC_OK;

@@ -222,7 +222,8 @@ int egc_aggregate_combine_post_f32(const egc_graph* graph, const egc_layer* laye
                                    void* workspace, size_t workspace_bytes, egc_stream_t stream);
 
 /* Mean of the rows of x [n_rows, width] over consecutive segments: out[g] = mean(x[seg_ptr[g] : seg_ptr[g+1]])
- * (0 for an empty segment).  global_mean_pool over a PyG batch vector, whose graphs are contiguous
+ * (0 for an empty segment; x may be NULL when every segment is empty).  global_mean_pool over a PyG batch
+ * vector, whose graphs are contiguous
  * (zinc/models.py:73, mol/pna_style_models.py:79, cifar/models.py:75); seg_ptr is int64 [n_segments + 1]. */
 int egc_segment_mean_f32(const float* x, const int64_t* seg_ptr, int64_t n_segments, int32_t width, float* out,
                          egc_stream_t stream);

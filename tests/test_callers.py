@@ -134,3 +134,5 @@ def test_global_mean_pool_matches_index_add():
     ref = torch.zeros(n_graphs, 77, device=dev).index_add_(0, batch, x) / torch.bincount(batch, minlength=n_graphs).view(-1, 1)
     assert float((got - ref).abs().max()) <= 1e-5
     assert egc_amd.global_mean_pool(x, batch, size=n_graphs + 3).shape == (n_graphs + 3, 77)   # trailing empty graphs -> 0
+    empty = egc_amd.global_mean_pool(x[:0], batch[:0], size=2)                                 # no nodes at all
+    assert empty.shape == (2, 77) and not empty.any()
