@@ -754,6 +754,12 @@ int launch_fast(AggArgs a, int64_t n_nodes, const PlanCaps& caps, hipStream_t st
     // EGConv on ogbn-mag (mag/models.py:24-53; train_main_table.sh:53-54): 352/H8/B4, symnorm or mean
     EGC_STATIC_CFG(8, 4, 44, 1, agg_pack(Y), EGC_ACT_NONE, true, true, true, 0)
     EGC_STATIC_CFG(8, 4, 44, 1, agg_pack(M), EGC_ACT_NONE, true, true, true, 0)
+    // relational EGC (rmag/models.py:75-148): mean+max over a relation's raw rectangular adjacency, and the
+    // root term (sum over an identity adjacency), at 128/H8/B4 and 64/H4/B4
+    EGC_STATIC_CFG(8, 4, 16, 2, agg_pack(M, X), EGC_ACT_NONE, false, false, true, 0)
+    EGC_STATIC_CFG(8, 4, 16, 1, agg_pack(S), EGC_ACT_NONE, false, false, true, 0)
+    EGC_STATIC_CFG(4, 4, 16, 2, agg_pack(M, X), EGC_ACT_NONE, false, false, true, 0)
+    EGC_STATIC_CFG(4, 4, 16, 1, agg_pack(S), EGC_ACT_NONE, false, false, true, 0)
   }
   switch (lpr) {
     case 16: return launch_rt<4>(a, need, grid, lds, stream);

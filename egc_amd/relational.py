@@ -21,7 +21,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _C
-from .functional import egc_aggregate_combine_apply, make_spec
+from .functional import PostOp, egc_aggregate_combine, egc_aggregate_combine_apply, make_spec
 from .graph import CSRGraph, SparseTensor
 from .layers import glorot_
 
@@ -108,8 +108,12 @@ class REGConv(nn.Module):
             lin = self.rel_combs[f"{key[0]}_{key[1]}_{key[2]}"]
             w_rel = F.linear(x_dict[dst], lin.weight[self._hba_rows], lin.bias[self._hba_rows])   # :141-143
             g = _as_graph(adj_t, x_dict[dst].size(0), x_dict[src].size(0))
-            out[dst] = out[dst] + egc_aggregate_combine_apply(g, self._spec_rel, bases[src].contiguous(),
-                                                              w_rel.contiguous())    # :131-144
+            b_src, w_rel = bases[src].contiguous(), w_rel.contiguous()
+            if torch.is_grad_enabled() and any(t.requires_grad for t in (b_src, w_rel)):
+                out[dst] = out[dst] + egc_aggregate_combine_apply(g, self._spec_rel, b_src, w_rel)    # :131-144
+            else:  # inference: the kernel's store adds the terms accumulated so far (egc_post.residual, in place)
+                egc_aggregate_combine(g, self._spec_rel, b_src, w_rel, None, post=PostOp(residual=out[dst]),
+                                      out=out[dst])
         return out
 
     def __repr__(self):

@@ -132,3 +132,38 @@ MAG_DIRECTED_EDGES = 5_416_271
 def mag_like(seed: int = 0) -> tuple[torch.Tensor, int]:
     """BASELINE config 5, homogeneous form: N = 736,389, ~10.8 M symmetrised heavy-tailed edges."""
     return heavy_tailed_graph(MAG_NODES, MAG_DIRECTED_EDGES, seed), MAG_NODES
+
+
+RMAG_NODES = {"paper": 736_389, "author": 1_134_649, "institution": 8_740, "field_of_study": 59_965}
+RMAG_RELATIONS = {  # ogbn-mag's four edge types and their sizes (21.1 M directed edges in all)
+    ("author", "affiliated_with", "institution"): 1_043_998,
+    ("author", "writes", "paper"): 7_145_660,
+    ("paper", "cites", "paper"): 5_416_271,
+    ("paper", "has_topic", "field_of_study"): 7_505_078,
+}
+
+
+def rmag_like(seed: int = 0, scale: float = 1.0):
+    """BASELINE config 5, heterogeneous form (the "~21 M edge" graph the relational path takes,
+    rmag/models.py:10-26): ogbn-mag's node and edge counts, heavy-tailed destinations, uniform sources, plus
+    the reverse of every relation except ``cites`` (which is symmetrised) -- the seven relations of the
+    reference.  Returns ({node type: count}, {(src, rel, dst): int64 [2, E] with row 0 = source ids, row 1 =
+    destination ids}).  ``scale`` shrinks every count (tests)."""
+    g = torch.Generator().manual_seed(seed)
+    nodes = {k: max(2, int(v * scale)) for k, v in RMAG_NODES.items()}
+    rel = {}
+    for (s, name, d), e in RMAG_RELATIONS.items():
+        e = max(1, int(e * scale))
+        u = torch.rand(e, generator=g, dtype=torch.float64)
+        dst = (nodes[d] * u ** 3).long().clamp_(max=nodes[d] - 1)
+        src = torch.randint(0, nodes[s], (e,), generator=g)
+        if s == d:
+            a, b = torch.cat([src, dst]), torch.cat([dst, src])
+            key = torch.unique(a * nodes[d] + b)
+            rel[(s, name, d)] = torch.stack([key // nodes[d], key % nodes[d]])
+        else:
+            key = torch.unique(src * nodes[d] + dst)
+            src, dst = key // nodes[d], key % nodes[d]
+            rel[(s, name, d)] = torch.stack([src, dst])
+            rel[(d, "to", s)] = torch.stack([dst, src])
+    return nodes, rel

@@ -210,7 +210,9 @@ int egc_aggregate_combine_rows_f32(const egc_graph* graph, const egc_layer* laye
  * mol/pna_style_models.py:71-78, cifar/models.py:67-74); in eval mode the normalisation is a per-channel affine
  * map, so   out = act((z + bias) * scale + shift) + residual   with z the layer's combine result.
  * scale / shift ([out_channels], both or neither), residual ([n_nodes, out_channels]) may be NULL; relu != 0
- * applies max(., 0) before the residual.  post == NULL is egc_aggregate_combine_f32. */
+ * applies max(., 0) before the residual.  residual may be `out` itself: every element is read by the lane that
+ * then writes it, so a sum of terms accumulates in place (relational EGC, rmag/models.py:131-144).
+ * post == NULL is egc_aggregate_combine_f32. */
 typedef struct {
   const float* scale;
   const float* shift;

@@ -159,3 +159,20 @@ def test_workload_byte_model_matches_survey_config2():
     from egc_amd.workloads import algorithmic_bytes
     t = algorithmic_bytes(169343, 2484941, 128, 64, 128, 128, True)
     assert abs(t["layer"] / 1e6 - 864.2) < 0.2
+
+
+def test_rmag_like_workload_has_the_reference_relations():
+    """The heterogeneous ogbn-mag-shaped workload carries exactly the seven relations REGConv iterates
+    (rmag/models.py:18-26), with ids inside the node counts and each reverse relation the transpose."""
+    from egc_amd.relational import EDGE_TYPES
+    from egc_amd.workloads import rmag_like
+    nodes, rel = rmag_like(seed=1, scale=0.001)
+    assert set(rel) == set(EDGE_TYPES)
+    for (s, _, d), ei in rel.items():
+        assert ei.dtype == torch.int64 and ei.shape[0] == 2 and ei.shape[1] > 0
+        assert int(ei[0].max()) < nodes[s] and int(ei[1].max()) < nodes[d] and int(ei.min()) >= 0
+    fwd, rev = rel[("author", "writes", "paper")], rel[("paper", "to", "author")]
+    assert torch.equal(fwd[0], rev[1]) and torch.equal(fwd[1], rev[0])
+    c = rel[("paper", "cites", "paper")]
+    key = c[0] * nodes["paper"] + c[1]
+    assert torch.equal(torch.sort(key).values, torch.sort(c[1] * nodes["paper"] + c[0]).values)   # symmetric
