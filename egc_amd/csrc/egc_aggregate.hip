@@ -355,7 +355,7 @@ static WsLayout ws_layout(const egc_layer* L, int64_t n_nodes, int64_t n_edges) 
   PlanCaps c = plan_caps(n_nodes, n_edges);
   WsLayout w;
   w.counter_bytes = align256((size_t)c.cap_long * sizeof(int));
-  w.partial_bytes = align256((size_t)c.cap_chunks * 5 * ldb * sizeof(float));
+  w.partial_bytes = align256((size_t)c.cap_chunks * 7 * ldb * sizeof(float));  // 5 aggregates + 2 arg records
   w.nself_bytes = align256((size_t)c.cap_chunks * sizeof(int));
   w.total = w.counter_bytes + w.partial_bytes + w.nself_bytes;
   return w;
@@ -414,7 +414,8 @@ int64_t egc_train_stats_floats(const egc_layer* layer) {
 static int aggregate_combine_impl(const egc_graph* graph, const egc_layer* layer, const float* bases, int32_t ldb,
                                   const float* weightings, const float* bias, const egc_post* post, float* out,
                                   float* stats, int32_t* cnt_out, int64_t row_begin, int64_t row_end, void* workspace,
-                                  size_t workspace_bytes, egc_stream_t stream_);
+                                  size_t workspace_bytes, egc_stream_t stream_, int32_t* arg_max = nullptr,
+                                  int32_t* arg_min = nullptr, bool* arg_done = nullptr);
 
 int egc_aggregate_combine_f32(const egc_graph* graph, const egc_layer* layer, const float* bases, int32_t ldb,
                               const float* weightings, const float* bias, float* out, int32_t* arg_max,
@@ -446,16 +447,18 @@ int egc_aggregate_combine_train_f32(const egc_graph* graph, const egc_layer* lay
                                     int32_t* cnt, int32_t* arg_max, int32_t* arg_min, void* workspace,
                                     size_t workspace_bytes, egc_stream_t stream) {
   if (graph == nullptr || layer == nullptr || stats == nullptr || cnt == nullptr) return EGC_ERR_INVALID;
+  bool arg_done = false;
   int st = aggregate_combine_impl(graph, layer, bases, ldb, weightings, bias, nullptr, out, stats, cnt, 0, -1, workspace,
-                                  workspace_bytes, stream);
-  if (st != EGC_OK) return st;
+                                  workspace_bytes, stream, arg_max, arg_min, &arg_done);
+  if (st != EGC_OK || arg_done) return st;
   return egc::arg_extrema(graph, layer, bases, ldb, stats, cnt, arg_max, arg_min, (hipStream_t)stream);
 }
 
 static int aggregate_combine_impl(const egc_graph* graph, const egc_layer* layer, const float* bases, int32_t ldb,
                                   const float* weightings, const float* bias, const egc_post* post, float* out,
                                   float* stats, int32_t* cnt_out, int64_t row_begin, int64_t row_end, void* workspace,
-                                  size_t workspace_bytes, egc_stream_t stream_) {
+                                  size_t workspace_bytes, egc_stream_t stream_, int32_t* arg_max, int32_t* arg_min,
+                                  bool* arg_done) {
   hipStream_t stream = (hipStream_t)stream_;
   if (graph == nullptr) return EGC_ERR_INVALID;
   int st = validate_layer(layer);
@@ -519,6 +522,9 @@ static int aggregate_combine_impl(const egc_graph* graph, const egc_layer* layer
   a.stats = stats;
   a.cnt_out = cnt_out;
   a.stat_k = stat_layout(a.aggr, a.A, a.stat_slot);
+  a.arg_max = a.stat_slot[STAT_MX] >= 0 ? arg_max : nullptr;
+  a.arg_min = a.stat_slot[STAT_MN] >= 0 ? arg_min : nullptr;
+  a.self_pos = (int)e;
 
   int chunks = 1;
   if (a.slots <= 64) {
@@ -545,7 +551,10 @@ static int aggregate_combine_impl(const egc_graph* graph, const egc_layer* layer
   a.n_chunks_hint = (graph->n_chunks >= 0 && graph->n_chunks <= caps.cap_chunks) ? (int)graph->n_chunks : -1;
   if (const char* env = getenv("EGC_ROWS_PER_WAVE")) a.rows_per_wave = atoi(env);
   const bool force_generic = getenv("EGC_FORCE_GENERIC") != nullptr;
-  if (!force_generic && fast_path_supported(a, layer->weight_layout, chunks)) return launch_fast(a, n, caps, stream);
+  if (!force_generic && fast_path_supported(a, layer->weight_layout, chunks)) {
+    if (arg_done != nullptr) *arg_done = true;  // the register-resident kernels track the arg positions themselves
+    return launch_fast(a, n, caps, stream);
+  }
 
   switch (chunks) {
     case 1: return launch_all<1>(a, n, caps, wpb, lds_bytes, stream);

@@ -27,7 +27,7 @@ struct AggArgs {
   const float* weightings;
   const float* bias;
   float* out;
-  float* partial;          // [cap_chunks][5][slots] float4
+  float* partial;          // [cap_chunks][5 (7 with arg tracking)][slots] float4
   int* partial_nself;      // [cap_chunks]
   int* counters;           // [cap_long] arrival counters of the fused kernel (zero on entry, zero on exit)
   int n_nodes;
@@ -66,6 +66,12 @@ struct AggArgs {
   int* cnt_out;
   int stat_slot[5];
   int stat_k;
+  // register-resident kernels, training forward of a layer with max / min: CSR position of the first entry
+  // attaining the row's extremum per bases column ([n_nodes, ldb]; self_pos = the appended self-loop, -1 = empty
+  // row), tracked inside the aggregation.  The generic kernels leave them to arg_extrema().
+  int* arg_max;
+  int* arg_min;
+  int self_pos;              // = n_edges
 };
 
 enum { STAT_SUM = 0, STAT_SQ = 1, STAT_MX = 2, STAT_MN = 3, STAT_WS = 4 };

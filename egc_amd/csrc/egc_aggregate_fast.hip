@@ -49,6 +49,8 @@ constexpr int HPB_MAX = 4;  // ceil(H / B) supported
 // Which optional running aggregates a layer needs (template mask: unused ones cost no registers).
 constexpr int NEED_SQ = 1;   // sum of squares  (var, std)
 constexpr int NEED_MN = 2;   // running minimum (min)
+constexpr int NEED_ARG = 4;  // training forward: CSR position of the first entry attaining max (and min with NEED_MN)
+constexpr int ARG_NONE = 0x7fffffff;  // "no entry yet": loses every position comparison
 
 // ---------------------------------------------------------------------------------------------
 // layer-constant accessors
@@ -143,6 +145,10 @@ __device__ inline int bperm(int byte_addr, int v) { return __builtin_amdgcn_ds_b
 __device__ inline f4 bperm(int byte_addr, f4 v) {
   return f4{bperm(byte_addr, v.x), bperm(byte_addr, v.y), bperm(byte_addr, v.z), bperm(byte_addr, v.w)};
 }
+typedef int i4 __attribute__((ext_vector_type(4)));
+__device__ inline i4 bperm(int byte_addr, i4 v) {
+  return i4{bperm(byte_addr, v.x), bperm(byte_addr, v.y), bperm(byte_addr, v.z), bperm(byte_addr, v.w)};
+}
 
 // v += (v rotated by 8 lanes) ; v += (v rotated by 4 lanes), inside each 16-lane DPP row: afterwards
 // every lane holds the sum over the 4 lanes {q, q^4, q^8, q^12}.  One VALU instruction per component
@@ -167,24 +173,57 @@ template <int NEED>
 struct FAcc {
   f4 sum, mx, ws;
   f4 sq, mn;  // only touched when NEED says so; dead otherwise
+  i4 ax, an;  // NEED_ARG: positions of the running max / min
   __device__ inline void init() {
     sum = 0.f; ws = 0.f; mx = -INFINITY;
     if constexpr (NEED & NEED_SQ) sq = 0.f;
     if constexpr (NEED & NEED_MN) mn = INFINITY;
+    if constexpr (NEED & NEED_ARG) ax = an = ARG_NONE;
   }
 };
+
+// Running extremum with its position.  Strictly-better updates keep the FIRST entry attaining the extremum as
+// long as positions arrive in increasing order (torch_scatter's arg rule); merges of independently built
+// candidates compare (value, position) lexicographically.
+__device__ inline void take_gt4(f4& m, i4& ar, f4 v, int pos) {
+  const bool cx = v.x > m.x, cy = v.y > m.y, cz = v.z > m.z, cw = v.w > m.w;
+  m = f4{cx ? v.x : m.x, cy ? v.y : m.y, cz ? v.z : m.z, cw ? v.w : m.w};
+  ar = i4{cx ? pos : ar.x, cy ? pos : ar.y, cz ? pos : ar.z, cw ? pos : ar.w};
+}
+__device__ inline void take_lt4(f4& m, i4& ar, f4 v, int pos) {
+  const bool cx = v.x < m.x, cy = v.y < m.y, cz = v.z < m.z, cw = v.w < m.w;
+  m = f4{cx ? v.x : m.x, cy ? v.y : m.y, cz ? v.z : m.z, cw ? v.w : m.w};
+  ar = i4{cx ? pos : ar.x, cy ? pos : ar.y, cz ? pos : ar.z, cw ? pos : ar.w};
+}
+__device__ inline void merge_gt4(f4& m, i4& ar, f4 om, i4 oa) {
+  const bool cx = om.x > m.x || (om.x == m.x && oa.x < ar.x), cy = om.y > m.y || (om.y == m.y && oa.y < ar.y);
+  const bool cz = om.z > m.z || (om.z == m.z && oa.z < ar.z), cw = om.w > m.w || (om.w == m.w && oa.w < ar.w);
+  m = f4{cx ? om.x : m.x, cy ? om.y : m.y, cz ? om.z : m.z, cw ? om.w : m.w};
+  ar = i4{cx ? oa.x : ar.x, cy ? oa.y : ar.y, cz ? oa.z : ar.z, cw ? oa.w : ar.w};
+}
+__device__ inline void merge_lt4(f4& m, i4& ar, f4 om, i4 oa) {
+  const bool cx = om.x < m.x || (om.x == m.x && oa.x < ar.x), cy = om.y < m.y || (om.y == m.y && oa.y < ar.y);
+  const bool cz = om.z < m.z || (om.z == m.z && oa.z < ar.z), cw = om.w < m.w || (om.w == m.w && oa.w < ar.w);
+  m = f4{cx ? om.x : m.x, cy ? om.y : m.y, cz ? om.z : m.z, cw ? om.w : m.w};
+  ar = i4{cx ? oa.x : ar.x, cy ? oa.y : ar.y, cz ? oa.z : ar.z, cw ? oa.w : ar.w};
+}
 
 // Fold one gathered slot.  `v` is 0 where the entry is absent or excluded (out-of-range buffer offset),
 // which is neutral for the sums, so only the extrema need the lane mask -- applied through EXEC
 // (a divergent `if`), which costs two scalar instructions and no register copies.
 template <int NEED>
-__device__ inline void fold(FAcc<NEED>& acc, f4 v, float w, bool in_x) {
+__device__ inline void fold(FAcc<NEED>& acc, f4 v, float w, bool in_x, int pos) {
   acc.sum += v;
   acc.ws = f4_fma(splat(w), v, acc.ws);
   if constexpr (NEED & NEED_SQ) acc.sq += f4_sqr_rn(v);
   if (in_x) {
-    acc.mx = f4_vmax(acc.mx, v);
-    if constexpr (NEED & NEED_MN) acc.mn = f4_vmin(acc.mn, v);
+    if constexpr (NEED & NEED_ARG) {
+      take_gt4(acc.mx, acc.ax, v, pos);
+      if constexpr (NEED & NEED_MN) take_lt4(acc.mn, acc.an, v, pos);
+    } else {
+      acc.mx = f4_vmax(acc.mx, v);
+      if constexpr (NEED & NEED_MN) acc.mn = f4_vmin(acc.mn, v);
+    }
   }
 }
 
@@ -196,9 +235,14 @@ __device__ inline void all_reduce_groups(FAcc<NEED>& acc, int lane) {
     const int addr = (lane ^ off) << 2;
     acc.sum += bperm(addr, acc.sum);
     acc.ws += bperm(addr, acc.ws);
-    acc.mx = f4_vmax(acc.mx, bperm(addr, acc.mx));
     if constexpr (NEED & NEED_SQ) acc.sq += bperm(addr, acc.sq);
-    if constexpr (NEED & NEED_MN) acc.mn = f4_vmin(acc.mn, bperm(addr, acc.mn));
+    if constexpr (NEED & NEED_ARG) {
+      merge_gt4(acc.mx, acc.ax, bperm(addr, acc.mx), bperm(addr, acc.ax));
+      if constexpr (NEED & NEED_MN) merge_lt4(acc.mn, acc.an, bperm(addr, acc.mn), bperm(addr, acc.an));
+    } else {
+      acc.mx = f4_vmax(acc.mx, bperm(addr, acc.mx));
+      if constexpr (NEED & NEED_MN) acc.mn = f4_vmin(acc.mn, bperm(addr, acc.mn));
+    }
   }
 }
 
@@ -213,12 +257,12 @@ struct FastRsrc {
 
 // Issue + fold one batch of FU wave-instructions.  `addr0` is the ds_bpermute byte address of the lane
 // holding this lane's first entry of the batch, `step` the byte distance to the next one; entry u of
-// the batch is valid iff first + u * vstep < n_valid (lane-dependent); jj / dd are the staged source
-// ids / deg^-1/2.
+// the batch is valid iff first + u * vstep < n_valid (lane-dependent), and its CSR position is
+// pos_base + first + u * vstep; jj / dd are the staged source ids / deg^-1/2.
 template <int NEED, class C>
 __device__ inline void gather_batch(const AggArgs& a, const FastRsrc& R, FAcc<NEED>& acc, int addr0, int step, int row,
                                     int jj, float dd, float dis_i, int n_valid, int first, int vstep,
-                                    unsigned row_bytes, unsigned slot_off) {
+                                    unsigned row_bytes, unsigned slot_off, int pos_base) {
   f4 v[FU];
   float w[FU];
   bool in_x[FU];
@@ -233,7 +277,7 @@ __device__ inline void gather_batch(const AggArgs& a, const FastRsrc& R, FAcc<NE
     if (C::yl(a) && !C::xl(a)) w[u] = is_self ? 0.f : w[u];  // mixed sets: self-entry counts for sum/max only
   }
 #pragma unroll
-  for (int u = 0; u < FU; ++u) fold<NEED>(acc, v[u], w[u], in_x[u]);
+  for (int u = 0; u < FU; ++u) fold<NEED>(acc, v[u], w[u], in_x[u], pos_base + first + u * vstep);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -281,7 +325,7 @@ __device__ inline void finish_group(const AggArgs& a, const FastRsrc& R, int lan
   int cnt = deg;
   if (C::xl(a)) cnt = deg - nself + (has_self ? 1 : 0);
   if (C::xl(a)) {
-    fold<NEED>(acc, vself, dis_i * dis_i, has_self);  // vself is 0 where the row has no self-loop
+    fold<NEED>(acc, vself, dis_i * dis_i, has_self, a.self_pos);  // vself is 0 where the row has no self-loop
   } else if (C::yl(a)) {
     acc.ws = f4_fma(splat(dis_i * dis_i), vself, acc.ws);
   }
@@ -295,6 +339,22 @@ __device__ inline void finish_group(const AggArgs& a, const FastRsrc& R, int lan
     if constexpr (NEED & NEED_MN)
       if (a.stat_slot[STAT_MN] >= 0) __builtin_nontemporal_store(acc.mn, reinterpret_cast<f4*>(st + a.stat_slot[STAT_MN] * a.ldb));
     if (q == 0) a.cnt_out[row] = cnt;
+    if constexpr (NEED & NEED_ARG) {
+      // first position attaining the extremum; self_pos = the appended self-loop; -1 for an empty row
+      const int none = cnt > 0 ? a.self_pos : -1;
+      const int64_t ao = (int64_t)row * a.ldb + 4 * q;
+      if (a.arg_max != nullptr) {
+        const i4 r = i4{acc.ax.x == ARG_NONE ? none : acc.ax.x, acc.ax.y == ARG_NONE ? none : acc.ax.y,
+                        acc.ax.z == ARG_NONE ? none : acc.ax.z, acc.ax.w == ARG_NONE ? none : acc.ax.w};
+        __builtin_nontemporal_store(r, reinterpret_cast<i4*>(a.arg_max + ao));
+      }
+      if constexpr (NEED & NEED_MN)
+        if (a.arg_min != nullptr) {
+          const i4 r = i4{acc.an.x == ARG_NONE ? none : acc.an.x, acc.an.y == ARG_NONE ? none : acc.an.y,
+                          acc.an.z == ARG_NONE ? none : acc.an.z, acc.an.w == ARG_NONE ? none : acc.an.w};
+          __builtin_nontemporal_store(r, reinterpret_cast<i4*>(a.arg_min + ao));
+        }
+    }
   }
   const float cntf = (float)max(cnt, 1);
   const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
@@ -431,7 +491,10 @@ __device__ inline void load_row_operands(const AggArgs& a, const FastRsrc& R, in
 // kernel
 // ---------------------------------------------------------------------------------------------
 template <int LPR_LOG2, int HPB, int NEED, class C>
-__global__ void __launch_bounds__(256) agg_fast_kernel(AggArgs a) {
+// Inference variants (NEED == 0) fit 80 VGPRs without spilling when asked to, which buys the sixth wavefront per
+// SIMD; the variants carrying more running aggregates are left to the register allocator.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NEED == 0 ? 6 : ((NEED & NEED_ARG) && (NEED & NEED_SQ)) ? 2 : 4)))
+agg_fast_kernel(AggArgs a) {
   constexpr int LPR = 1 << LPR_LOG2, G = 64 / LPR;
   extern __shared__ float smem[];
   if ((int)blockIdx.x < a.chunk_blocks && (int)blockIdx.x * 4 >= a.plan[1]) return;  // unused chunk slots
@@ -501,7 +564,7 @@ __global__ void __launch_bounds__(256) agg_fast_kernel(AggArgs a) {
       const int cnt = min(64, end - base);
       for (int t0 = 0; t0 < cnt; t0 += FU * G)
         gather_batch<NEED, C>(a, R, acc, (g + t0) << 2, G << 2, row, jj, dd, dis_i, lane_live ? cnt : 0, t0 + g, G, row_bytes,
-                              slot_off);
+                              slot_off, base);
     }
     all_reduce_groups<LPR_LOG2, NEED>(acc, lane);
     if (nch > 1) {
@@ -510,8 +573,9 @@ __global__ void __launch_bounds__(256) agg_fast_kernel(AggArgs a) {
       // fence -- a whole-L2 write-back that costs tens of microseconds when hundreds of chunks publish
       // (cdna guide, Guideline 16 "valid forms": sc1 stores + drained + counter; consumer keeps its acquire).
       constexpr int WT = 0x11;  // aux bits: sc0 | sc1
+      constexpr int REC = (NEED & NEED_ARG) ? 7 : 5;  // 16-byte slots per lane in a chunk record (workspace holds 7)
       const __amdgpu_buffer_rsrc_t pw = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(reinterpret_cast<f4*>(a.partial) + (int64_t)c * 5 * LPR), 0, 5u * LPR * 16u, 0x00020000);
+          (void*)(reinterpret_cast<f4*>(a.partial) + (int64_t)c * REC * LPR), 0, (unsigned)REC * LPR * 16u, 0x00020000);
       const unsigned po = (g == 0 && lane_live) ? (unsigned)q * 16u : OOB;
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, acc.sum), pw, po, 0 * LPR * 16, WT);
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, acc.mx), pw, po, 2 * LPR * 16, WT);
@@ -520,6 +584,11 @@ __global__ void __launch_bounds__(256) agg_fast_kernel(AggArgs a) {
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, acc.sq), pw, po, 1 * LPR * 16, WT);
       if constexpr (NEED & NEED_MN)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, acc.mn), pw, po, 3 * LPR * 16, WT);
+      if constexpr (NEED & NEED_ARG) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, acc.ax), pw, po, 5 * LPR * 16, WT);
+        if constexpr (NEED & NEED_MN)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, acc.an), pw, po, 6 * LPR * 16, WT);
+      }
       const __amdgpu_buffer_rsrc_t pn =
           __builtin_amdgcn_make_buffer_rsrc((void*)(a.partial_nself + c), 0, 4u, 0x00020000);
       __builtin_amdgcn_raw_buffer_store_b32(nself, pn, lane == 0 ? 0u : OOB, 0, WT);
@@ -537,19 +606,23 @@ __global__ void __launch_bounds__(256) agg_fast_kernel(AggArgs a) {
       // MU records per group in flight (a hub row has hundreds of chunks)
       constexpr int MU = 4;
       const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(reinterpret_cast<const f4*>(a.partial) + (int64_t)c0 * 5 * LPR), 0,
-          (unsigned)nch * 5u * LPR * 16u, 0x00020000);
+          (void*)(reinterpret_cast<const f4*>(a.partial) + (int64_t)c0 * REC * LPR), 0,
+          (unsigned)nch * (unsigned)REC * LPR * 16u, 0x00020000);
       for (int k0 = g; k0 < nch; k0 += G * MU) {
-        f4 rs[MU], rm[MU], rw[MU], rq[MU], rn[MU];
+        f4 rs[MU], rm[MU], rw[MU], rq[MU], rn[MU], rax[MU], ran[MU];
 #pragma unroll
         for (int m = 0; m < MU; ++m) {
           const int kk = k0 + m * G;
-          const unsigned off = (kk < nch && lane_live) ? ((unsigned)kk * 5u * LPR + (unsigned)q) * 16u : OOB;
+          const unsigned off = (kk < nch && lane_live) ? ((unsigned)kk * (unsigned)REC * LPR + (unsigned)q) * 16u : OOB;
           rs[m] = load_slot_wt(prs, off);
           rm[m] = load_slot_wt(prs, off == OOB ? OOB : off + 2u * LPR * 16u);
           rw[m] = load_slot_wt(prs, off == OOB ? OOB : off + 4u * LPR * 16u);
           if constexpr (NEED & NEED_SQ) rq[m] = load_slot_wt(prs, off == OOB ? OOB : off + 1u * LPR * 16u);
           if constexpr (NEED & NEED_MN) rn[m] = load_slot_wt(prs, off == OOB ? OOB : off + 3u * LPR * 16u);
+          if constexpr (NEED & NEED_ARG) {
+            rax[m] = load_slot_wt(prs, off == OOB ? OOB : off + 5u * LPR * 16u);
+            if constexpr (NEED & NEED_MN) ran[m] = load_slot_wt(prs, off == OOB ? OOB : off + 6u * LPR * 16u);
+          }
         }
 #pragma unroll
         for (int m = 0; m < MU; ++m) {
@@ -557,8 +630,13 @@ __global__ void __launch_bounds__(256) agg_fast_kernel(AggArgs a) {
           acc.ws += rw[m];
           if constexpr (NEED & NEED_SQ) acc.sq += rq[m];
           if (k0 + m * G < nch) {
-            acc.mx = f4_vmax(acc.mx, rm[m]);
-            if constexpr (NEED & NEED_MN) acc.mn = f4_vmin(acc.mn, rn[m]);
+            if constexpr (NEED & NEED_ARG) {
+              merge_gt4(acc.mx, acc.ax, rm[m], __builtin_bit_cast(i4, rax[m]));
+              if constexpr (NEED & NEED_MN) merge_lt4(acc.mn, acc.an, rn[m], __builtin_bit_cast(i4, ran[m]));
+            } else {
+              acc.mx = f4_vmax(acc.mx, rm[m]);
+              if constexpr (NEED & NEED_MN) acc.mn = f4_vmin(acc.mn, rn[m]);
+            }
           }
         }
       }
@@ -632,7 +710,7 @@ __global__ void __launch_bounds__(256) agg_fast_kernel(AggArgs a) {
       const int cnt = min(LPR, maxd - ts);  // wave-uniform
       for (int t0 = 0; t0 < cnt; t0 += FU)
         gather_batch<NEED, C>(a, R, acc, grp_addr + (t0 << 2), 4, row, jj, dd, dis_i, lane_live ? nd : 0, ts + t0, 1, row_bytes,
-                              slot_off);
+                              slot_off, start);
     }
     // Opaque copy of the lane id: keeps the compiler from hoisting the epilogue's lane arithmetic out
     // of the row loop, where it would stay live across the gathers and cost occupancy.
@@ -668,6 +746,10 @@ static int launch_one(const AggArgs& a, unsigned grid, size_t lds, hipStream_t s
 
 template <int LPR_LOG2, int HPB>
 static int launch_need(const AggArgs& a, int need, unsigned grid, size_t lds, hipStream_t stream) {
+  if (a.arg_max != nullptr || a.arg_min != nullptr) {  // training forward of a layer with max / min
+    if (need == 0) return launch_one<LPR_LOG2, HPB, NEED_ARG, RtCfg>(a, grid, lds, stream);
+    return launch_one<LPR_LOG2, HPB, NEED_SQ | NEED_MN | NEED_ARG, RtCfg>(a, grid, lds, stream);
+  }
   if (need == 0) return launch_one<LPR_LOG2, HPB, 0, RtCfg>(a, grid, lds, stream);
   return launch_one<LPR_LOG2, HPB, NEED_SQ | NEED_MN, RtCfg>(a, grid, lds, stream);
 }
@@ -695,6 +777,12 @@ static bool try_static(const AggArgs& a, int h, int b, int l, int ls, int na, un
       (a.x_looped != 0) != xl || (a.y_looped != 0) != yl || (a.loops_all != 0) != loops_all ||
       a.Ls != ls || a.slots > (1 << LPR_LOG2) || 2 * a.slots <= (1 << LPR_LOG2))
     return false;
+  if constexpr (C::has(EGC_AGGR_MAX)) {
+    if (a.arg_max != nullptr) {  // training forward: the variant that also tracks the arg positions
+      *status = launch_one<LPR_LOG2, HPB, NEED | NEED_ARG, C>(a, grid, lds, stream);
+      return true;
+    }
+  }
   *status = launch_one<LPR_LOG2, HPB, NEED, C>(a, grid, lds, stream);
   return true;
 }
