@@ -91,8 +91,8 @@ SYMBOLS = {
                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "egc_aggregate_combine_backward_f32": (C.c_int, [C.POINTER(EgcGraph), C.POINTER(EgcGraph), C.POINTER(EgcLayer),
                                                      C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
-                                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                                     C.c_void_p, C.c_size_t, C.c_void_p]),
+                                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                                     C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "egc_last_error": (C.c_char_p, []),
     "egc_version": (C.c_char_p, []),
 }

@@ -217,8 +217,9 @@ struct BwdArgs {
   const int* cnt;            // [N] entries of the row's aggregation set
   const int* arg_max;        // [N, ldb] CSR position / n_edges (self loop) / -1, or nullptr
   const int* arg_min;
-  float* d_bases;            // [n_src_rows, ldb]  (zero-initialised by the host)
-  float* d_weightings;       // [N, W]
+  float* d_bases;            // [n_src_rows, ld_db >= ldb]  (zero-initialised by the host)
+  float* d_weightings;       // [N, ld_dw >= W]
+  int ld_db, ld_dw;          // row strides (floats) of the two gradient arrays
   float* tab_t;              // [N, ldb]
   float* tab_s;              // [N, ldb] or nullptr
   float* tab_v;              // [N, ldb] or nullptr
@@ -351,7 +352,7 @@ __global__ void __launch_bounds__(256) bwd_dst_kernel(BwdArgs a) {
       for (int q = 0; q < AB; ++q) dot = fmaf(lds_dagg[h * AB + q], lds_w[h * AB + q], dot);
       d = w * (d - dot);
     }
-    __builtin_nontemporal_store(d, &a.d_weightings[(int64_t)row * a.W + k]);
+    __builtin_nontemporal_store(d, &a.d_weightings[(int64_t)row * a.ld_dw + k]);
   }
 }
 
@@ -507,7 +508,7 @@ __global__ void __launch_bounds__(256) bwd_dst_fast_kernel(BwdArgs a) {
         const float pre = a.weightings[(int64_t)row * a.W + k0 + t];
         d = (pre > -1.0f && pre < 1.0f) ? d : 0.f;
       }
-      __builtin_nontemporal_store(d, &a.d_weightings[(int64_t)row * a.W + k0 + t]);
+      __builtin_nontemporal_store(d, &a.d_weightings[(int64_t)row * a.ld_dw + k0 + t]);
     }
   }
 }
@@ -657,7 +658,7 @@ __global__ void __launch_bounds__(256) bwd_src_kernel(BwdArgs a) {
     f4 d = t;
     if (a.tab_s != nullptr) d = f4_fma(f4{dis_j, dis_j, dis_j, dis_j}, sv, d);
     if (a.tab_v != nullptr) d = f4_fma(*reinterpret_cast<const f4*>(a.bases + o), vv, d);
-    float* dst = a.d_bases + o;
+    float* dst = a.d_bases + (int64_t)row * a.ld_db + 4 * s;
     if (atomic) {
       atomicAdd(dst, d.x); atomicAdd(dst + 1, d.y); atomicAdd(dst + 2, d.z); atomicAdd(dst + 3, d.w);
     } else {
@@ -681,8 +682,9 @@ size_t egc_backward_workspace_bytes(const egc_layer* layer, int64_t n_nodes) {
 int egc_aggregate_combine_backward_f32(const egc_graph* graph, const egc_graph* t_graph, const egc_layer* layer,
                                        const float* bases, int32_t ldb, const float* weightings, const float* grad_out,
                                        const float* stats, const int32_t* cnt, const int32_t* arg_max,
-                                       const int32_t* arg_min, float* d_bases, float* d_weightings, void* workspace,
-                                       size_t workspace_bytes, egc_stream_t stream_) {
+                                       const int32_t* arg_min, float* d_bases, int32_t ld_d_bases, float* d_weightings,
+                                       int32_t ld_d_weightings, void* workspace, size_t workspace_bytes,
+                                       egc_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (graph == nullptr || t_graph == nullptr || layer == nullptr) return EGC_ERR_INVALID;
   if (layer->num_aggrs <= 0 || layer->num_aggrs > EGC_MAX_AGGRS || layer->out_channels % layer->num_heads != 0)
@@ -717,6 +719,12 @@ int egc_aggregate_combine_backward_f32(const egc_graph* graph, const egc_graph* 
   a.arg_min = arg_min;
   a.d_bases = d_bases;
   a.d_weightings = d_weightings;
+  a.ld_db = ld_d_bases > 0 ? ld_d_bases : ldb;
+  a.ld_dw = ld_d_weightings > 0 ? ld_d_weightings : layer->num_heads * layer->num_bases * layer->num_aggrs;
+  // 16-byte row accesses of d_bases; both arrays at least as wide as what is written
+  if (a.ld_db < ldb || (a.ld_db & 3) != 0 || (reinterpret_cast<uintptr_t>(d_bases) & 15) != 0 ||
+      a.ld_dw < layer->num_heads * layer->num_bases * layer->num_aggrs)
+    return EGC_ERR_INVALID;
   a.n_nodes = (int)n;
   a.n_src_rows = (int)n_src;
   a.n_edges = (int)graph->n_edges;

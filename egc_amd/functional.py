@@ -243,17 +243,25 @@ def egc_aggregate_combine_train(graph: CSRGraph, spec: LayerSpec, bases: torch.T
     return out, (stats, cnt, arg_max, arg_min)
 
 
-def egc_aggregate_combine_backward(graph: CSRGraph, spec: LayerSpec, bases, weightings, grad_out, saved):
+def egc_aggregate_combine_backward(graph: CSRGraph, spec: LayerSpec, bases, weightings, grad_out, saved,
+                                   joint: bool = False):
     """(d_bases [n_src_rows, ldb], d_weightings [N, W]) through egc_aggregate_combine_backward_f32;
-    ``saved`` comes from egc_aggregate_combine_train."""
+    ``saved`` comes from egc_aggregate_combine_train.  ``joint`` (square graphs): both are column blocks of
+    one [N, ldb + W] array, returned third -- the left operand of the dense gradient GEMMs, no concatenation."""
     lib = _C.load()
     n = graph.n_nodes
     dev = bases.device
     stats, cnt, arg_max, arg_min = saved
     tg = graph.transposed()
     with torch.cuda.device(dev):
-        d_bases = torch.zeros((graph.n_src_rows, spec.ldb), dtype=torch.float32, device=dev)  # atomics land here
-        d_w = torch.empty((n, spec.w_cols), dtype=torch.float32, device=dev)
+        d_cat = None
+        if joint and graph.n_src_rows == n and (spec.ldb + spec.w_cols) % 4 == 0:
+            d_cat = torch.empty((n, spec.ldb + spec.w_cols), dtype=torch.float32, device=dev)
+            d_bases, d_w = d_cat[:, :spec.ldb], d_cat[:, spec.ldb:]
+            d_bases.zero_()                                                                       # atomics land here
+        else:
+            d_bases = torch.zeros((graph.n_src_rows, spec.ldb), dtype=torch.float32, device=dev)  # atomics land here
+            d_w = torch.empty((n, spec.w_cols), dtype=torch.float32, device=dev)
         nbytes = lib.egc_backward_workspace_bytes(C.byref(spec.c), n)
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
         g, t = graph.c_struct(), tg.c_struct()
@@ -261,9 +269,9 @@ def egc_aggregate_combine_backward(graph: CSRGraph, spec: LayerSpec, bases, weig
             C.byref(g), C.byref(t), C.byref(spec.c), bases.data_ptr(), spec.ldb, weightings.data_ptr(),
             grad_out.contiguous().data_ptr(), stats.data_ptr(), cnt.data_ptr(),
             arg_max.data_ptr() if arg_max is not None else None, arg_min.data_ptr() if arg_min is not None else None,
-            d_bases.data_ptr(), d_w.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(dev)),
-            "egc_aggregate_combine_backward_f32")
-    return d_bases, d_w
+            d_bases.data_ptr(), d_bases.stride(0), d_w.data_ptr(), d_w.stride(0), ws.data_ptr(), ws.numel(),
+            _stream_ptr(dev)), "egc_aggregate_combine_backward_f32")
+    return (d_bases, d_w, d_cat) if joint else (d_bases, d_w)
 
 
 def _xt_matmul(x: torch.Tensor, d: torch.Tensor) -> torch.Tensor:
@@ -303,13 +311,15 @@ class _EGCLayerFunction(torch.autograd.Function):
         x, wcat, bases, weightings = ctx.saved_tensors
         spec = ctx.spec
         grad_out = grad_out.contiguous()
-        d_bases, d_w = egc_aggregate_combine_backward(ctx.graph, spec, bases, weightings, grad_out, ctx.saved)
+        d_bases, d_w, d_cat = egc_aggregate_combine_backward(ctx.graph, spec, bases, weightings, grad_out, ctx.saved,
+                                                             joint=spec.ldb == spec.f_g)
         halo = ctx.graph.halo
         if halo is not None and ctx.graph.n_src_rows > ctx.graph.n_nodes:
             # gradients collected for other ranks' vertices go home (reverse all-to-all-v) and are added there
             back = halo.exchange_reverse(d_bases)
             d_bases = d_bases[:ctx.graph.n_nodes].index_add(0, halo.send_idx, back)
-        d_cat = torch.cat([d_bases[:, :spec.f_g], d_w], dim=1)             # [N, F_g + W]
+        if d_cat is None:
+            d_cat = torch.cat([d_bases[:, :spec.f_g], d_w], dim=1)         # [N, F_g + W]
         dx = d_cat @ wcat.t() if ctx.needs_input_grad[0] else None
         dwcat = _xt_matmul(x, d_cat) if ctx.needs_input_grad[1] else None
         dbcat = d_w.sum(0) if (ctx.has_bcat and ctx.needs_input_grad[2]) else None

@@ -267,15 +267,18 @@ int egc_layer_forward_packed(const egc_graph* graph, const egc_layer* layer, con
  * CSR position that arg_max / arg_min name.
  * Outputs: d_bases [n_src_rows, ldb] -- MUST be zero-filled by the caller (the partial sums of hub rows
  * arrive by float atomics) -- and d_weightings [n_nodes, H*B*A] (gradient w.r.t. the
- * pre-activation weightings).  The dense gradients (x, bases_weight, comb weight/bias, bias) are plain
- * GEMMs / column sums left to the caller. */
+ * pre-activation weightings).  ld_d_bases / ld_d_weightings are their row strides in floats (0 = dense: ldb
+ * and H*B*A; ld_d_bases a multiple of 4, d_bases 16-byte aligned): a caller whose next step is a GEMM with
+ * the concatenated weight matrix [bases_weight | comb_weight^T] passes two column blocks of ONE
+ * [n_nodes, ldb + H*B*A] array and saves the concatenation.  The dense gradients (x, bases_weight, comb
+ * weight/bias, bias) are plain GEMMs / column sums left to the caller. */
 size_t egc_backward_workspace_bytes(const egc_layer* layer, int64_t n_nodes);
 int egc_aggregate_combine_backward_f32(const egc_graph* graph, const egc_graph* t_graph, const egc_layer* layer,
                                        const float* bases, int32_t ldb, const float* weightings,
                                        const float* grad_out, const float* stats, const int32_t* cnt,
                                        const int32_t* arg_max, const int32_t* arg_min, float* d_bases,
-                                       float* d_weightings, void* workspace, size_t workspace_bytes,
-                                       egc_stream_t stream);
+                                       int32_t ld_d_bases, float* d_weightings, int32_t ld_d_weightings,
+                                       void* workspace, size_t workspace_bytes, egc_stream_t stream);
 
 /* Human-readable text of the last HIP failure seen on the calling thread ("" if none). */
 const char* egc_last_error(void);
