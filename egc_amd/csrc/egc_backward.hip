@@ -517,9 +517,9 @@ __global__ void __launch_bounds__(256) bwd_dst_fast_kernel(BwdArgs a) {
 // lane q of the group holds slot(s) q, q + LPR, ... (NS of them).
 constexpr int BWD_FU = 4;
 template <int NS>
-__device__ inline void sum_tables(const BwdArgs& a, const __amdgpu_buffer_rsrc_t (&rt)[3], int row, int start, int end,
-                                  int first, int step, int q, int LPR, bool xl, bool yl, f4 (&at)[NS], f4 (&as)[NS],
-                                  f4 (&av)[NS]) {
+__device__ inline void sum_tables(const BwdArgs& a, const __amdgpu_buffer_rsrc_t (&rt)[3],
+                                  const __amdgpu_buffer_rsrc_t (&rx)[4], int row, int start, int end, int first, int step,
+                                  int q, int LPR, bool xl, bool yl, f4 (&at)[NS], f4 (&as)[NS], f4 (&av)[NS]) {
   const bool ext = a.tab_x != nullptr || a.tab_n != nullptr;
   for (int p0 = start + first; p0 < end; p0 += step * BWD_FU) {
     int dst[BWD_FU], pos[BWD_FU];
@@ -548,23 +548,33 @@ __device__ inline void sum_tables(const BwdArgs& a, const __amdgpu_buffer_rsrc_t
         if (a.tab_v != nullptr) av[k] += vv[u];
         if (a.tab_s != nullptr) as[k] += vs[u];
       }
-      // max / min: the whole gradient of (destination, column) goes to the entry its arg position names
+      // max / min: the whole gradient of (destination, column) goes to the entry its arg position names.  The arg
+      // rows are gathered first; the gradient slot only where one of the lane's four columns names this entry
+      // (into a hub destination almost none does), through an out-of-range offset otherwise.
       if (ext) {
 #pragma unroll
-        for (int u = 0; u < BWD_FU; ++u) {
-          if (dst[u] < 0 || s >= a.slots) continue;
-          const int64_t o = (int64_t)dst[u] * a.ldb + 4 * s;
-          if (a.tab_x != nullptr) {
-            const int4 ar = *reinterpret_cast<const int4*>(a.arg_max + o);
-            const f4 gx = *reinterpret_cast<const f4*>(a.tab_x + o);
-            at[k].x += ar.x == pos[u] ? gx.x : 0.f; at[k].y += ar.y == pos[u] ? gx.y : 0.f;
-            at[k].z += ar.z == pos[u] ? gx.z : 0.f; at[k].w += ar.w == pos[u] ? gx.w : 0.f;
+        for (int e = 0; e < 2; ++e) {
+          const float* tab = e == 0 ? a.tab_x : a.tab_n;
+          if (tab == nullptr) continue;
+          int4 ar[BWD_FU];
+          f4 gv[BWD_FU];
+          bool lv[BWD_FU];
+#pragma unroll
+          for (int u = 0; u < BWD_FU; ++u) {
+            lv[u] = dst[u] >= 0 && s < a.slots;
+            const unsigned off = (unsigned)dst[u] * (unsigned)a.ldb * 4u + (unsigned)s * 16u;
+            ar[u] = __builtin_bit_cast(int4, load_slot(rx[2 * e], lv[u] ? off : OOB));
           }
-          if (a.tab_n != nullptr) {
-            const int4 ar = *reinterpret_cast<const int4*>(a.arg_min + o);
-            const f4 gn = *reinterpret_cast<const f4*>(a.tab_n + o);
-            at[k].x += ar.x == pos[u] ? gn.x : 0.f; at[k].y += ar.y == pos[u] ? gn.y : 0.f;
-            at[k].z += ar.z == pos[u] ? gn.z : 0.f; at[k].w += ar.w == pos[u] ? gn.w : 0.f;
+#pragma unroll
+          for (int u = 0; u < BWD_FU; ++u) {
+            const bool hit = lv[u] && (ar[u].x == pos[u] || ar[u].y == pos[u] || ar[u].z == pos[u] || ar[u].w == pos[u]);
+            const unsigned off = (unsigned)dst[u] * (unsigned)a.ldb * 4u + (unsigned)s * 16u;
+            gv[u] = load_slot(rx[2 * e + 1], hit ? off : OOB);
+          }
+#pragma unroll
+          for (int u = 0; u < BWD_FU; ++u) {
+            at[k].x += ar[u].x == pos[u] ? gv[u].x : 0.f; at[k].y += ar[u].y == pos[u] ? gv[u].y : 0.f;
+            at[k].z += ar[u].z == pos[u] ? gv[u].z : 0.f; at[k].w += ar[u].w == pos[u] ? gv[u].w : 0.f;
           }
         }
       }
@@ -586,6 +596,12 @@ __global__ void __launch_bounds__(256) bwd_src_kernel(BwdArgs a) {
   rt[0] = __builtin_amdgcn_make_buffer_rsrc((void*)a.tab_t, 0, a.tab_bytes, 0x00020000);
   rt[1] = __builtin_amdgcn_make_buffer_rsrc((void*)(a.tab_s != nullptr ? a.tab_s : a.tab_t), 0, a.tab_bytes, 0x00020000);
   rt[2] = __builtin_amdgcn_make_buffer_rsrc((void*)(a.tab_v != nullptr ? a.tab_v : a.tab_t), 0, a.tab_bytes, 0x00020000);
+  // arg positions and extremum gradients: {arg_max, tab_x, arg_min, tab_n}
+  __amdgpu_buffer_rsrc_t rx[4];
+  rx[0] = __builtin_amdgcn_make_buffer_rsrc((void*)(a.arg_max != nullptr ? (const void*)a.arg_max : (const void*)a.tab_t), 0, a.tab_bytes, 0x00020000);
+  rx[1] = __builtin_amdgcn_make_buffer_rsrc((void*)(a.tab_x != nullptr ? a.tab_x : a.tab_t), 0, a.tab_bytes, 0x00020000);
+  rx[2] = __builtin_amdgcn_make_buffer_rsrc((void*)(a.arg_min != nullptr ? (const void*)a.arg_min : (const void*)a.tab_t), 0, a.tab_bytes, 0x00020000);
+  rx[3] = __builtin_amdgcn_make_buffer_rsrc((void*)(a.tab_n != nullptr ? a.tab_n : a.tab_t), 0, a.tab_bytes, 0x00020000);
   const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
 
   int row, start, end, first, step;
@@ -615,7 +631,7 @@ __global__ void __launch_bounds__(256) bwd_src_kernel(BwdArgs a) {
   f4 at[NS], as[NS], av[NS];
 #pragma unroll
   for (int k = 0; k < NS; ++k) at[k] = as[k] = av[k] = zero;
-  sum_tables<NS>(a, rt, row, start, end, first, step, q, LPR, xl, yl, at, as, av);
+  sum_tables<NS>(a, rt, rx, row, start, end, first, step, q, LPR, xl, yl, at, as, av);
   if (atomic) {  // merge the G groups of the chunk
     for (int off = LPR; off < 64; off <<= 1) {
 #pragma unroll
