@@ -170,3 +170,41 @@ def test_arg_extrema_match_scatter_arg_bit_exact(hidden, H, B):
         assert np.array_equal(got_edges, ref), name
     deg = np.bincount(ei[1], minlength=n)
     assert np.array_equal(cnt.cpu().numpy()[:n], deg)
+
+
+@pytest.mark.parametrize("generic", [False, True])
+def test_arg_extrema_with_appended_self_loops_bit_exact(generic, monkeypatch):
+    """EGConv's edge set (gcn_norm: existing self-loops dropped, one appended per node at the END of the edge
+    list): the arg of a column whose maximum is the node's own feature is n_edges, pre-existing self entries are
+    never named, ties go to the earliest remaining entry.  Register-resident kernels (arg tracked inside the
+    aggregation) and generic kernels (separate arg pass) must agree with a numpy restatement bit for bit."""
+    import egc_amd
+    from egc_amd.functional import egc_aggregate_combine_train
+    if generic:
+        monkeypatch.setenv("EGC_FORCE_GENERIC", "1")
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(9)
+    n, hidden, H, B = 300, 64, 8, 4
+    ei = _graph(rng, n, 2400, hub=180, self_loops=40)
+    conv = egc_amd.EGConv(hidden, hidden, aggrs=["symnorm", "max", "min"], num_heads=H, num_bases=B)
+    spec = conv._spec_coo
+    f_g = spec.f_g
+    bases_np = rng.standard_normal((n, f_g)).astype(np.float32)
+    bases_np[rng.integers(0, n, size=100)] = bases_np[11]          # exact ties between sources
+    bases_np[::7] += 4.0                                            # nodes whose own feature wins (self-loop)
+    g = egc_amd.CSRGraph.from_edge_index(torch.from_numpy(ei).to(dev), n)
+    wt = torch.randn(n, spec.w_cols, device=dev)
+    _, (stats, cnt, arg_max, arg_min) = egc_aggregate_combine_train(g, spec, torch.from_numpy(bases_np).to(dev), wt, None)
+    rowptr, col = g.rowptr.cpu().numpy(), g.col.cpu().numpy()
+    e = ei.shape[1]
+    want_max = np.empty((n, f_g), dtype=np.int64)
+    want_min = np.empty((n, f_g), dtype=np.int64)
+    for i in range(n):
+        pos = np.array([p for p in range(rowptr[i], rowptr[i + 1]) if col[p] != i] + [e])
+        src = np.array([col[p] for p in pos[:-1]] + [i])
+        vals = bases_np[src]                                        # [k, f_g] in edge order, self-loop last
+        want_max[i] = pos[np.argmax(vals, axis=0)]                  # argmax / argmin return the FIRST extremum
+        want_min[i] = pos[np.argmin(vals, axis=0)]
+    assert np.array_equal(arg_max.cpu().numpy()[:, :f_g], want_max)
+    assert np.array_equal(arg_min.cpu().numpy()[:, :f_g], want_min)
+    assert int((want_max == e).sum()) > 100                         # the self-loop case is really exercised
