@@ -99,11 +99,53 @@ __global__ void __launch_bounds__(256) pack_bf16x3_kernel(const float* __restric
   packed[base + 2 * (int64_t)NV * XKT] = l;
 }
 
-template <bool A_VEC4>
+// LDS operand read with an immediate offset (one address register for the whole tile loop)
+constexpr unsigned A_PLANE = XBM * XLD * 2, B_PLANE = XBN * XLD * 2, B_TILE = 32 * XLD * 2, SUB = 16 * 2;
+template <unsigned OFF>
+__device__ inline void lds_rd(bf16x8& dst, unsigned addr) {
+  static_assert(OFF < 65536, "ds_read offset field");
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+// Step IDX = (substep IDX / 6, tile IDX % 6) of a full-width block: issue the B reads of step IDX + 1, wait
+// (counted) for this step's operands, six MFMAs.
+template <int IDX>
+__device__ inline void mfma_step(f32x16 (&acc)[6], bf16x8 (&a3)[2][3], bf16x8 (&bq)[2][3], unsigned b_lds) {
+  constexpr int s = IDX / 6, t = IDX % 6, cur = IDX & 1, nxt = (IDX + 1) & 1;
+  if constexpr (IDX + 1 < 12) {
+    constexpr unsigned off = ((IDX + 1) % 6) * B_TILE + ((IDX + 1) / 6) * SUB;
+    lds_rd<off>(bq[nxt][0], b_lds);
+    lds_rd<off + B_PLANE>(bq[nxt][1], b_lds);
+    lds_rd<off + 2 * B_PLANE>(bq[nxt][2], b_lds);
+  }
+  if constexpr (IDX == 0)
+    asm volatile("s_waitcnt lgkmcnt(3)"
+                 : "+v"(a3[0][0]), "+v"(a3[0][1]), "+v"(a3[0][2]), "+v"(a3[1][0]), "+v"(a3[1][1]), "+v"(a3[1][2]),
+                   "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[0][2]));
+  else if constexpr (IDX + 1 < 12)
+    asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(bq[cur][0]), "+v"(bq[cur][1]), "+v"(bq[cur][2]));
+  else
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[cur][0]), "+v"(bq[cur][1]), "+v"(bq[cur][2]));
+  const bf16x8 ah = a3[s][0], am = a3[s][1], al = a3[s][2];
+  const bf16x8 bh = bq[cur][0], bm = bq[cur][1], bl = bq[cur][2];
+  f32x16 c = acc[t];
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+  acc[t] = c;
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// FULL: every block of the launch spans XBN columns (six MFMA tiles) -> the pipelined straight-line MFMA loop;
+// otherwise the block's tile count is a run-time value (the last, narrower column block of a layer).
+template <bool A_VEC4, bool FULL>
 __global__ void __launch_bounds__(256) basis_gemm_bf16x3_kernel(const float* __restrict__ x, const u16* __restrict__ packed,
                                                                 const float* __restrict__ bcat, int64_t M, int K,
                                                                 int W, float* __restrict__ bases, int ldb,
-                                                                float* __restrict__ weightings, int NV, int KS) {
+                                                                float* __restrict__ weightings, int NV, int KS,
+                                                                int vblock0) {
   // one LDS allocation, carved explicitly (the epilogue re-uses it as the transpose buffer)
   constexpr int A_ELEMS = 3 * XBM * XLD, B_ELEMS = 3 * XBN * XLD;
   __shared__ __attribute__((aligned(16))) u16 lds_raw[A_ELEMS + B_ELEMS];
@@ -114,8 +156,8 @@ __global__ void __launch_bounds__(256) basis_gemm_bf16x3_kernel(const float* __r
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int64_t m0 = (int64_t)blockIdx.x * XBM;
-  const int v0 = blockIdx.y * XBN;
-  const int nvb = min(XBN, NV - v0);  // virtual columns of this block (multiple of 32)
+  const int v0 = (blockIdx.y + vblock0) * XBN;
+  const int nvb = FULL ? XBN : min(XBN, NV - v0);  // virtual columns of this block (multiple of 32)
   const int ntile = nvb >> 5;
 
   f32x16 acc[6];
@@ -202,29 +244,55 @@ __global__ void __launch_bounds__(256) basis_gemm_bf16x3_kernel(const float* __r
       if (A_VEC4) load_x(ks + 1);
       load_w(ks + 1);
     }
-    // ---- 2 MFMA k-substeps of 16
+    // ---- 2 MFMA k-substeps of 16 x up to 6 column tiles
     const int arow = 32 * wave + (lane & 31);
     const int koff = 8 * (lane >> 5);
+    if constexpr (FULL) {
+      // Full-width block: straight-line code in which the B operand of the NEXT (substep, tile) is read from LDS
+      // before the six MFMAs of the current one are issued.  Reads and counted waits are inline assembly: the
+      // compiler sinks its own ds_reads next to their first use and, when pinned, still waits for lgkmcnt(0) --
+      // either way every tile sits out an LDS round trip.  LDS operations complete in order, so "at most 3
+      // outstanding" after issuing the next tile's three reads means everything older has landed.
+      bf16x8 a3[2][3], bq[2][3];
+      const unsigned a_lds = (unsigned)(uintptr_t)&As[0][arow][koff];        // LDS byte addresses: plane 0, substep 0
+      const unsigned b_lds = (unsigned)(uintptr_t)&Bs[0][lane & 31][koff];   // ... and tile 0
+      lds_rd<0>(a3[0][0], a_lds); lds_rd<A_PLANE>(a3[0][1], a_lds); lds_rd<2 * A_PLANE>(a3[0][2], a_lds);
+      lds_rd<SUB>(a3[1][0], a_lds); lds_rd<A_PLANE + SUB>(a3[1][1], a_lds); lds_rd<2 * A_PLANE + SUB>(a3[1][2], a_lds);
+      lds_rd<0>(bq[0][0], b_lds); lds_rd<B_PLANE>(bq[0][1], b_lds); lds_rd<2 * B_PLANE>(bq[0][2], b_lds);
+      mfma_step<0>(acc, a3, bq, b_lds);
+      mfma_step<1>(acc, a3, bq, b_lds);
+      mfma_step<2>(acc, a3, bq, b_lds);
+      mfma_step<3>(acc, a3, bq, b_lds);
+      mfma_step<4>(acc, a3, bq, b_lds);
+      mfma_step<5>(acc, a3, bq, b_lds);
+      mfma_step<6>(acc, a3, bq, b_lds);
+      mfma_step<7>(acc, a3, bq, b_lds);
+      mfma_step<8>(acc, a3, bq, b_lds);
+      mfma_step<9>(acc, a3, bq, b_lds);
+      mfma_step<10>(acc, a3, bq, b_lds);
+      mfma_step<11>(acc, a3, bq, b_lds);
+    } else {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&As[0][arow][16 * s + koff]);
-      const bf16x8 am = *reinterpret_cast<const bf16x8*>(&As[1][arow][16 * s + koff]);
-      const bf16x8 al = *reinterpret_cast<const bf16x8*>(&As[2][arow][16 * s + koff]);
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&As[0][arow][16 * s + koff]);
+        const bf16x8 am = *reinterpret_cast<const bf16x8*>(&As[1][arow][16 * s + koff]);
+        const bf16x8 al = *reinterpret_cast<const bf16x8*>(&As[2][arow][16 * s + koff]);
 #pragma unroll
-      for (int t = 0; t < 6; ++t) {
-        if (t < ntile) {  // block-uniform
-          const int bcol = 32 * t + (lane & 31);
-          const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&Bs[0][bcol][16 * s + koff]);
-          const bf16x8 bm = *reinterpret_cast<const bf16x8*>(&Bs[1][bcol][16 * s + koff]);
-          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&Bs[2][bcol][16 * s + koff]);
-          f32x16 c = acc[t];
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
-          acc[t] = c;
+        for (int t = 0; t < 6; ++t) {
+          if (t < ntile) {  // block-uniform
+            const int bcol = 32 * t + (lane & 31);
+            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&Bs[0][bcol][16 * s + koff]);
+            const bf16x8 bm = *reinterpret_cast<const bf16x8*>(&Bs[1][bcol][16 * s + koff]);
+            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&Bs[2][bcol][16 * s + koff]);
+            f32x16 c = acc[t];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+            acc[t] = c;
+          }
         }
       }
     }
@@ -521,15 +589,25 @@ int egc_basis_transform_packed(const float* x, const void* packed, const float* 
   }
   const int64_t mblocks = ceil_div(n_nodes, XBM);
   if (mblocks >= ((int64_t)1 << 31)) return EGC_ERR_INVALID;
-  dim3 grid((unsigned)mblocks, (unsigned)ceil_div(NV, XBN));
   const bool vec4 = (f_in % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-  if (vec4)
-    basis_gemm_bf16x3_kernel<true><<<grid, 256, 0, stream>>>(x, (const u16*)packed, bcat, n_nodes, f_in, w_cols, bases, ldb,
-                                                             weightings, NV, KS);
-  else
-    basis_gemm_bf16x3_kernel<false><<<grid, 256, 0, stream>>>(x, (const u16*)packed, bcat, n_nodes, f_in, w_cols, bases,
-                                                              ldb, weightings, NV, KS);
-  EGC_LAUNCH_CHECK("basis_gemm_bf16x3_kernel");
+  const int full = NV / XBN;  // column blocks of the full 192 columns; a narrower remainder block follows
+  const u16* pk = (const u16*)packed;
+  if (full > 0) {
+    dim3 grid((unsigned)mblocks, (unsigned)full);
+    if (vec4)
+      basis_gemm_bf16x3_kernel<true, true><<<grid, 256, 0, stream>>>(x, pk, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, KS, 0);
+    else
+      basis_gemm_bf16x3_kernel<false, true><<<grid, 256, 0, stream>>>(x, pk, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, KS, 0);
+    EGC_LAUNCH_CHECK("basis_gemm_bf16x3_kernel");
+  }
+  if (NV % XBN != 0) {
+    dim3 grid((unsigned)mblocks, 1);
+    if (vec4)
+      basis_gemm_bf16x3_kernel<true, false><<<grid, 256, 0, stream>>>(x, pk, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, KS, full);
+    else
+      basis_gemm_bf16x3_kernel<false, false><<<grid, 256, 0, stream>>>(x, pk, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, KS, full);
+    EGC_LAUNCH_CHECK("basis_gemm_bf16x3_kernel");
+  }
   return EGC_OK;
 }
 
