@@ -28,6 +28,8 @@
 #include <algorithm>
 
 #include "egc_common.h"
+#include <stdio.h>
+
 #include "egc_gemm_split.h"
 
 namespace egc {
@@ -98,6 +100,13 @@ __global__ void __launch_bounds__(256) pack_bf16x3_kernel(const float* __restric
   packed[base + (int64_t)NV * XKT] = m;
   packed[base + 2 * (int64_t)NV * XKT] = l;
 }
+
+#ifdef EGC_GEMM3_STAMPS
+__device__ unsigned long long egc_stamp3[8];  // diagnostic build only: cycles per phase, summed over wavefronts
+#define EGC_ST3(k) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); st3[k] += _t - st3_t0; st3_t0 = _t; }
+#else
+#define EGC_ST3(k)
+#endif
 
 // LDS operand read with an immediate offset (one address register for the whole tile loop)
 constexpr unsigned A_PLANE = XBM * XLD * 2, B_PLANE = XBN * XLD * 2, B_TILE = 32 * XLD * 2, SUB = 16 * 2;
@@ -197,9 +206,17 @@ __global__ void __launch_bounds__(256) basis_gemm_bf16x3_kernel(const float* __r
   };
   if (A_VEC4) load_x(0);
   load_w(0);
+#ifdef EGC_GEMM3_STAMPS
+  unsigned long long st3[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st3_t0;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st3_t0) :: "memory");
+#endif
 
   for (int ks = 0; ks < KS; ++ks) {
     const int k0 = ks * XKT;
+#ifdef EGC_GEMM3_STAMPS
+    if (A_VEC4) { asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); }  // x tile landed (the 9 weight pieces may still fly)
+#endif
+    EGC_ST3(0)
     // ---- stage x[m0 .. m0+128, k0 .. k0+32) as three bf16 planes
     if (A_VEC4) {
 #pragma unroll
@@ -229,6 +246,11 @@ __global__ void __launch_bounds__(256) basis_gemm_bf16x3_kernel(const float* __r
         As[2][row][kk] = l;
       }
     }
+    EGC_ST3(1)
+#ifdef EGC_GEMM3_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    EGC_ST3(2)
     // ---- weight planes of this k-step (fetched during the previous step's MFMAs) -> LDS
     {
 #pragma unroll
@@ -239,7 +261,9 @@ __global__ void __launch_bounds__(256) basis_gemm_bf16x3_kernel(const float* __r
           if (i < pieces) *reinterpret_cast<u32x4*>(&Bs[p][i >> 2][(i & 3) * 8]) = wreg[p][j];
         }
     }
+    EGC_ST3(3)
     lds_barrier();
+    EGC_ST3(4)
     if (ks + 1 < KS) {  // next step's operands: in flight during the MFMAs below
       if (A_VEC4) load_x(ks + 1);
       load_w(ks + 1);
@@ -296,8 +320,14 @@ __global__ void __launch_bounds__(256) basis_gemm_bf16x3_kernel(const float* __r
         }
       }
     }
+    EGC_ST3(5)
     lds_barrier();
+    EGC_ST3(6)
   }
+#ifdef EGC_GEMM3_STAMPS
+  if (lane == 0)
+    for (int k = 0; k < 7; ++k) atomicAdd(&egc_stamp3[k], st3[k]);
+#endif
 
   // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
   const bool wide = (ntile == 6) && (W % 4 == 0) && (bcat == nullptr || (reinterpret_cast<uintptr_t>(bcat) & 15) == 0);
@@ -600,6 +630,19 @@ int egc_basis_transform_packed(const float* x, const void* packed, const float* 
       basis_gemm_bf16x3_kernel<false, true><<<grid, 256, 0, stream>>>(x, pk, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, KS, 0);
     EGC_LAUNCH_CHECK("basis_gemm_bf16x3_kernel");
   }
+#ifdef EGC_GEMM3_STAMPS
+  {
+    hipDeviceSynchronize();
+    unsigned long long h[8];
+    hipMemcpyFromSymbol(h, HIP_SYMBOL(egc_stamp3), sizeof(h));
+    static int calls = 0;
+    if (++calls % 10 == 0) {
+      const double waves = (double)mblocks * full * 4 * calls;
+      fprintf(stderr, "[gemm3 stamps] K=%d NV=%d per wavefront per k-step (cycles of s_memtime @100MHz x?): xwait %.0f split %.0f wwait %.0f wstage %.0f bar1 %.0f mfma %.0f bar2 %.0f\n",
+              f_in, NV, h[0] / waves / KS, h[1] / waves / KS, h[2] / waves / KS, h[3] / waves / KS, h[4] / waves / KS, h[5] / waves / KS, h[6] / waves / KS);
+    }
+  }
+#endif
   if (NV % XBN != 0) {
     dim3 grid((unsigned)mblocks, 1);
     if (vec4)
