@@ -365,8 +365,42 @@ __global__ void __launch_bounds__(256) bwd_dst_kernel(BwdArgs a) {
 // lanes of the basis, and lane l4 stores the heads l4 H/P .. (l4+1) H/P - 1.
 constexpr int BWD_HMAX = 16;   // heads supported by the register form
 // HT / AT: compile-time head and aggregator counts (the d = 128, H = 8 layers; everything else: bwd_dst_kernel)
-template <int LPR_LOG2, int HT, int AT>
+// AGG: the aggregator codes packed 3 bits each (first in the low bits) with bit 31 set, or 0 = read them from
+// the arguments.  With the list compiled in, the per-aggregator switches, the statistics layout and the weight
+// nonlinearity (none) fold away -- the run-time form is mostly scalar branches.
+constexpr unsigned BWD_STATIC = 0x80000000u;
+constexpr unsigned bwd_agg_pack(int a0, int a1 = 0, int a2 = 0, int a3 = 0) {
+  return BWD_STATIC | (unsigned)a0 | ((unsigned)a1 << 3) | ((unsigned)a2 << 6) | ((unsigned)a3 << 9);
+}
+template <unsigned AGG, int AT>
+struct BwdAggs {
+  static constexpr bool fixed = (AGG & BWD_STATIC) != 0;
+  static constexpr int code(int t) { return (int)((AGG >> (3 * t)) & 7u); }
+  static constexpr bool needs(int s) {  // stat_layout()'s rule for statistic s
+    for (int t = 0; t < AT; ++t) {
+      const int c = code(t);
+      const bool sum = c == EGC_AGGR_SUM || c == EGC_AGGR_MEAN || c == EGC_AGGR_VAR || c == EGC_AGGR_STD;
+      const bool sq = c == EGC_AGGR_VAR || c == EGC_AGGR_STD;
+      if ((s == STAT_SUM && sum) || (s == STAT_SQ && sq) || (s == STAT_MX && c == EGC_AGGR_MAX) ||
+          (s == STAT_MN && c == EGC_AGGR_MIN) || (s == STAT_WS && c == EGC_AGGR_SYMNORM))
+        return true;
+    }
+    return false;
+  }
+  static constexpr int slot(int s) {
+    if (!needs(s)) return -1;
+    int k = 0;
+    for (int u = 0; u < s; ++u) k += needs(u) ? 1 : 0;
+    return k;
+  }
+  static __device__ inline int aggr(const BwdArgs& a, int t) { return fixed ? code(t) : a.aggr[t]; }
+  static __device__ inline int stat_slot(const BwdArgs& a, int s) { return fixed ? slot(s) : a.stat_slot[s]; }
+  static __device__ inline int act(const BwdArgs& a) { return fixed ? (int)EGC_ACT_NONE : a.act; }
+};
+
+template <int LPR_LOG2, int HT, int AT, unsigned AGG = 0>
 __global__ void __launch_bounds__(256) bwd_dst_fast_kernel(BwdArgs a) {
+  using AG = BwdAggs<AGG, AT>;
   extern __shared__ float smem[];
   constexpr int LPR = 1 << LPR_LOG2, G = 64 / LPR;
   const int lane = threadIdx.x & 63;
@@ -396,8 +430,8 @@ __global__ void __launch_bounds__(256) bwd_dst_fast_kernel(BwdArgs a) {
   }
   for (int k = q; k < a.W; k += LPR) {
     float w = a.weightings[(int64_t)rr * a.W + k];
-    if (a.act == EGC_ACT_SIGMOID) w = 1.0f / (1.0f + expf(-w));
-    else if (a.act == EGC_ACT_HARDTANH) w = fminf(fmaxf(w, -1.0f), 1.0f);
+    if (AG::act(a) == EGC_ACT_SIGMOID) w = 1.0f / (1.0f + expf(-w));
+    else if (AG::act(a) == EGC_ACT_HARDTANH) w = fminf(fmaxf(w, -1.0f), 1.0f);
     lds_w[k] = w;
   }
   // ---- this lane's slot of the saved aggregates
@@ -407,11 +441,11 @@ __global__ void __launch_bounds__(256) bwd_dst_fast_kernel(BwdArgs a) {
   const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
   const float* st = a.stats + ((int64_t)rr * a.stat_k) * a.ldb + 4 * q;
   auto stat = [&](int s) -> f4 {
-    return (a.stat_slot[s] >= 0 && live) ? *reinterpret_cast<const f4*>(st + a.stat_slot[s] * a.ldb) : zero;
+    return (AG::stat_slot(a, s) >= 0 && live) ? *reinterpret_cast<const f4*>(st + AG::stat_slot(a, s) * a.ldb) : zero;
   };
   const f4 sum = stat(STAT_SUM), sq = stat(STAT_SQ), mx = stat(STAT_MX), mn = stat(STAT_MN), ws = stat(STAT_WS);
   // exact divisions only where the forward needs them bit for bit (var / std); a reciprocal otherwise
-  const bool has_sq = a.stat_slot[STAT_SQ] >= 0;
+  const bool has_sq = AG::stat_slot(a, STAT_SQ) >= 0;
   const float rcnt = 1.0f / cntf;
   const f4 mean = has_sq ? f4_div(sum, cntf) : sum * f4{rcnt, rcnt, rcnt, rcnt};
   const f4 var = has_sq ? f4_var(f4_div(sq, cntf), mean) : zero;
@@ -421,7 +455,7 @@ __global__ void __launch_bounds__(256) bwd_dst_fast_kernel(BwdArgs a) {
   for (int t = 0; t < 4; ++t) {
     val[t] = dagg[t] = zero;
     if (t < A) {
-      switch (a.aggr[t]) {
+      switch (AG::aggr(a, t)) {
         case EGC_AGGR_SUM: val[t] = sum; break;
         case EGC_AGGR_MEAN: val[t] = mean; break;
         case EGC_AGGR_MAX: val[t] = cnt > 0 ? mx : zero; break;
@@ -462,7 +496,7 @@ __global__ void __launch_bounds__(256) bwd_dst_fast_kernel(BwdArgs a) {
   for (int t = 0; t < 4; ++t) {
     if (t >= A) break;
     const f4 d = dagg[t];
-    switch (a.aggr[t]) {
+    switch (AG::aggr(a, t)) {
       case EGC_AGGR_SUM: d_t += d; break;
       case EGC_AGGR_MEAN: d_t += d * f4{rcnt, rcnt, rcnt, rcnt}; break;
       case EGC_AGGR_MAX: if (wr) __builtin_nontemporal_store(cnt > 0 ? d : zero, reinterpret_cast<f4*>(a.tab_x + o)); break;
@@ -503,8 +537,8 @@ __global__ void __launch_bounds__(256) bwd_dst_fast_kernel(BwdArgs a) {
       if (t >= A) break;
       float d = dwp[h][t];
       const float w = lds_w[k0 + t];
-      if (a.act == EGC_ACT_SIGMOID) d = d * w * (1.0f - w);
-      else if (a.act == EGC_ACT_HARDTANH) {
+      if (AG::act(a) == EGC_ACT_SIGMOID) d = d * w * (1.0f - w);
+      else if (AG::act(a) == EGC_ACT_HARDTANH) {
         const float pre = a.weightings[(int64_t)row * a.W + k0 + t];
         d = (pre > -1.0f && pre < 1.0f) ? d : 0.f;
       }
@@ -801,7 +835,16 @@ int egc_aggregate_combine_backward_f32(const egc_graph* graph, const egc_graph* 
       const size_t flds = (size_t)4 * G * (((a.H * a.Ls + 3) & ~3) + ((a.W + 3) & ~3)) * sizeof(float);
       const unsigned fgrid = (unsigned)ceil_div(n, (int64_t)4 * G);
       if (flds > 64 * 1024) return EGC_ERR_UNSUPPORTED;
-      if (a.A == 4) bwd_dst_fast_kernel<4, 8, 4><<<fgrid, 256, flds, stream>>>(a);   // north star: EGC-M, 4 aggregators
+      unsigned packed = BWD_STATIC;
+      for (int t = 0; t < a.A; ++t) packed |= (unsigned)a.aggr[t] << (3 * t);
+      constexpr int S = EGC_AGGR_SUM, M = EGC_AGGR_MEAN, X = EGC_AGGR_MAX, Y = EGC_AGGR_SYMNORM;
+      if (a.A == 4 && a.act == EGC_ACT_NONE && packed == bwd_agg_pack(S, M, X, Y))      // EGConv north star, compiled in
+        bwd_dst_fast_kernel<4, 8, 4, bwd_agg_pack(S, M, X, Y)><<<fgrid, 256, flds, stream>>>(a);
+      else if (a.A == 3 && a.act == EGC_ACT_NONE && packed == bwd_agg_pack(Y, X, M))    // EfficientGraphConv EGC-M
+        bwd_dst_fast_kernel<4, 8, 3, bwd_agg_pack(Y, X, M)><<<fgrid, 256, flds, stream>>>(a);
+      else if (a.A == 1 && a.act == EGC_ACT_NONE && packed == bwd_agg_pack(Y))          // EGC-S
+        bwd_dst_fast_kernel<4, 8, 1, bwd_agg_pack(Y)><<<fgrid, 256, flds, stream>>>(a);
+      else if (a.A == 4) bwd_dst_fast_kernel<4, 8, 4><<<fgrid, 256, flds, stream>>>(a);
       else if (a.A == 3) bwd_dst_fast_kernel<4, 8, 3><<<fgrid, 256, flds, stream>>>(a);
       else bwd_dst_fast_kernel<4, 8, 1><<<fgrid, 256, flds, stream>>>(a);
       EGC_LAUNCH_CHECK("bwd_dst_fast_kernel");
