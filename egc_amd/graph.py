@@ -57,16 +57,23 @@ class CSRGraph:
         ei = edge_index.contiguous()
         n, e = int(num_nodes), int(ei.size(1))
         with torch.cuda.device(dev):
-            rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
-            col = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
-            edge_id = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
-            max_index = torch.empty(1, dtype=torch.int32, device=dev)
+            # one int32 slab for everything integer (per-batch graphs: allocator calls and fills cost as much as
+            # the kernels): rowptr | col | edge_id | max_index | long-row plan, each piece 16-byte aligned
+            e1 = max(e, 1)
+            plan_ints = int(lib.egc_plan_ints(n, e))
+            sizes = (n + 1, e1, e1, 1, plan_ints)
+            offs, total = [], 0
+            for sz in sizes:
+                offs.append(total)
+                total += (sz + 3) & ~3
+            slab = torch.empty(total, dtype=torch.int32, device=dev)
+            rowptr, col, edge_id, max_index, plan = (slab[o:o + sz] for o, sz in zip(offs, sizes))
             ws_bytes = lib.egc_coo_to_csr_workspace_bytes(n, e)
             ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
             _C.check(lib.egc_coo_to_csr(ei[0].data_ptr(), ei[1].data_ptr(), e, n, rowptr.data_ptr(), col.data_ptr(),
                                         edge_id.data_ptr(), max_index.data_ptr(), ws.data_ptr(), ws.numel(),
                                         _stream_ptr(dev)), "egc_coo_to_csr")
-            return cls._prepare(n, e, rowptr, col, edge_id, max_index, num_src_rows)
+            return cls._prepare(n, e, rowptr, col, edge_id, max_index, num_src_rows, plan=plan)
 
     @classmethod
     def from_partition(cls, edge_index_local: torch.Tensor, plan, global_max_index: int | None = None,
@@ -100,20 +107,28 @@ class CSRGraph:
             return cls._prepare(n, e, rowptr, col32, edge_id, max_index, num_src_rows)
 
     @classmethod
-    def _prepare(cls, n, e, rowptr, col, edge_id, max_index, n_src_rows=None) -> "CSRGraph":
+    def _prepare(cls, n, e, rowptr, col, edge_id, max_index, n_src_rows=None, plan=None) -> "CSRGraph":
         lib = _C.load()
         dev = rowptr.device
         ns = n if n_src_rows is None else int(n_src_rows)
         if ns <= 0 and e > 0:
             raise RuntimeError("egc_amd: num_src_rows must be positive")
-        # deg^-1/2 tables: rows first, then (partitioned runs) the halo entries filled in by their owners
-        dis_raw = torch.zeros(max(n, ns, 1), dtype=torch.float32, device=dev)
-        dis_looped = torch.zeros(max(n, ns, 1), dtype=torch.float32, device=dev)
-        plan = torch.empty(lib.egc_plan_ints(n, e), dtype=torch.int32, device=dev)
+        # one float slab: deg^-1/2 tables (rows first, then -- partitioned runs -- the halo entries filled in by
+        # their owners) | their per-entry copies (refresh_edge_dis)
+        nd, e1 = (max(n, ns, 1) + 3) & ~3, (max(e, 1) + 3) & ~3
+        square = ns == n
+        fslab = torch.empty(2 * nd + (2 * e1 if square else 0), dtype=torch.float32, device=dev)
+        dis_raw, dis_looped = fslab[:max(n, ns, 1)], fslab[nd:nd + max(n, ns, 1)]
+        if max(n, ns, 1) > n:      # entries beyond the rows are not written by egc_csr_prepare
+            fslab[:2 * nd].zero_()
+        if plan is None:
+            plan = torch.empty(lib.egc_plan_ints(n, e), dtype=torch.int32, device=dev)
         _C.check(lib.egc_csr_prepare(n, e, rowptr.data_ptr(), col.data_ptr(), dis_raw.data_ptr(),
                                      dis_looped.data_ptr(), plan.data_ptr(), _stream_ptr(dev)), "egc_csr_prepare")
         g = cls(n, e, rowptr, col, edge_id, dis_raw, dis_looped, max_index, plan, ns)
-        if ns == n:  # square adjacency: symnorm is meaningful; partitions refresh after the halo exchange of dis
+        if square:  # square adjacency: symnorm is meaningful; partitions refresh after the halo exchange of dis
+            g.edge_dis_raw = fslab[2 * nd:2 * nd + max(e, 1)]
+            g.edge_dis_looped = fslab[2 * nd + e1:2 * nd + e1 + max(e, 1)]
             g.refresh_edge_dis()
         return g
 
