@@ -156,7 +156,7 @@ __device__ inline void finish_row(const AggArgs& a, __amdgpu_buffer_rsrc_t rsrc,
     }
   }
   // (2) the node's weightings row, nonlinearity applied, into LDS
-  const float* wrow_g = a.weightings + (int64_t)row * a.W;
+  const float* wrow_g = a.weightings + (int64_t)row * a.ldw;
   for (int k = lane; k < a.W; k += 64) {
     float w = wrow_g[k];
     if (a.act == EGC_ACT_SIGMOID) w = 1.0f / (1.0f + expf(-w));
@@ -415,7 +415,7 @@ static int aggregate_combine_impl(const egc_graph* graph, const egc_layer* layer
                                   const float* weightings, const float* bias, const egc_post* post, float* out,
                                   float* stats, int32_t* cnt_out, int64_t row_begin, int64_t row_end, void* workspace,
                                   size_t workspace_bytes, egc_stream_t stream_, int32_t* arg_max = nullptr,
-                                  int32_t* arg_min = nullptr, bool* arg_done = nullptr);
+                                  int32_t* arg_min = nullptr, bool* arg_done = nullptr, int32_t ldw = 0);
 
 int egc_aggregate_combine_f32(const egc_graph* graph, const egc_layer* layer, const float* bases, int32_t ldb,
                               const float* weightings, const float* bias, float* out, int32_t* arg_max,
@@ -442,6 +442,14 @@ int egc_aggregate_combine_post_f32(const egc_graph* graph, const egc_layer* laye
                                 workspace_bytes, stream);
 }
 
+int egc_aggregate_combine_strided_f32(const egc_graph* graph, const egc_layer* layer, const float* bases, int32_t ldb,
+                                      const float* weightings, int32_t ldw, const float* bias, const egc_post* post,
+                                      float* out, void* workspace, size_t workspace_bytes, egc_stream_t stream) {
+  if (post != nullptr && ((post->scale == nullptr) != (post->shift == nullptr))) return EGC_ERR_INVALID;
+  return aggregate_combine_impl(graph, layer, bases, ldb, weightings, bias, post, out, nullptr, nullptr, 0, -1, workspace,
+                                workspace_bytes, stream, nullptr, nullptr, nullptr, ldw);
+}
+
 int egc_aggregate_combine_train_f32(const egc_graph* graph, const egc_layer* layer, const float* bases, int32_t ldb,
                                     const float* weightings, const float* bias, float* out, float* stats,
                                     int32_t* cnt, int32_t* arg_max, int32_t* arg_min, void* workspace,
@@ -458,7 +466,7 @@ static int aggregate_combine_impl(const egc_graph* graph, const egc_layer* layer
                                   const float* weightings, const float* bias, const egc_post* post, float* out,
                                   float* stats, int32_t* cnt_out, int64_t row_begin, int64_t row_end, void* workspace,
                                   size_t workspace_bytes, egc_stream_t stream_, int32_t* arg_max, int32_t* arg_min,
-                                  bool* arg_done) {
+                                  bool* arg_done, int32_t ldw) {
   hipStream_t stream = (hipStream_t)stream_;
   if (graph == nullptr) return EGC_ERR_INVALID;
   int st = validate_layer(layer);
@@ -508,6 +516,9 @@ static int aggregate_combine_impl(const egc_graph* graph, const egc_layer* layer
   a.L = layer->out_channels / layer->num_heads;
   a.Ls = layer_basis_stride(layer);
   a.W = a.H * a.B * a.A;
+  a.ldw = ldw > 0 ? ldw : a.W;  // row stride of `weightings` (a column block of a wider array when > W)
+  if (a.ldw != a.W && (a.ldw < a.W || (a.ldw & 3) != 0 || (reinterpret_cast<uintptr_t>(weightings) & 15) != 0))
+    return EGC_ERR_INVALID;
   for (int t = 0; t < EGC_MAX_AGGRS; ++t) a.aggr[t] = t < a.A ? layer->aggrs[t] : 0;
   a.x_looped = layer->agg_set == EGC_SET_LOOPED;
   a.y_looped = layer->sym_set == EGC_SET_LOOPED;

@@ -34,6 +34,7 @@ struct AggArgs {
   int row_begin, row_end;  // rows this launch finishes ([0, n_nodes) unless the caller splits the rows)
   int ldb, slots;          // slots = ldb / 4
   int F_out, W, H, B, A, L;
+  int ldw;                 // floats between consecutive rows of `weightings` (>= W)
   int Ls;                  // floats between consecutive bases in a row (>= L; == L when contiguous)
   int aggr[EGC_MAX_AGGRS];
   int x_looped, y_looped, loops_all;

@@ -473,7 +473,7 @@ __device__ inline void load_row_operands(const AggArgs& a, const FastRsrc& R, in
   has_self = row_ok && (C::loops_all(a) || row <= *a.max_index);
   const bool want_self = (C::xl(a) || C::yl(a)) && has_self;
   vself = load_slot(R.bases, (want_self && q < C::slots(a)) ? (unsigned)row * (unsigned)a.ldb * 4u + (unsigned)q * 16u : OOB);
-  const float* wrow = a.weightings + (int64_t)(row_ok ? row : 0) * W;
+  const float* wrow = a.weightings + (int64_t)(row_ok ? row : 0) * a.ldw;
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int c0 = (q + k * LPR) * 4;

@@ -142,13 +142,36 @@ def egc_aggregate_combine(graph: CSRGraph, spec: LayerSpec, bases: torch.Tensor,
     if bias is not None:
         _check_f32(bias, "bias", (spec.f_out,))
     dev = bases.device
+    # a column block of a wider array (several terms' weightings from one GEMM) is read in place
+    ldw = spec.w_cols
+    if n > 1 and weightings.stride(1) == 1 and weightings.stride(0) != spec.w_cols and rows is None:
+        ldw = int(weightings.stride(0))
+    elif not weightings.is_contiguous():
+        weightings = weightings.contiguous()
     with torch.cuda.device(dev):
         if out is None:
             out = torch.empty((n, spec.f_out), dtype=torch.float32, device=dev)
         ws = graph.workspace(lib.egc_aggregate_workspace_bytes(C.byref(spec.c), n, graph.n_edges))
         g = graph.c_struct()
         bias_p = bias.contiguous().data_ptr() if bias is not None else None
-        if rows is not None:
+        if ldw != spec.w_cols:
+            keep = []
+            p = None
+            if post is not None:
+                def sptr(t, shape, name):
+                    if t is None:
+                        return None
+                    _check_f32(t, name, shape)
+                    keep.append(t.contiguous())
+                    return keep[-1].data_ptr()
+                p = _C.EgcPost(sptr(post.scale, (spec.f_out,), "post.scale"), sptr(post.shift, (spec.f_out,), "post.shift"),
+                               sptr(post.residual, (n, spec.f_out), "post.residual"), int(bool(post.relu)))
+            _C.check(lib.egc_aggregate_combine_strided_f32(C.byref(g), C.byref(spec.c), bases.data_ptr(), spec.ldb,
+                                                           weightings.data_ptr(), ldw, bias_p,
+                                                           C.byref(p) if p is not None else None, out.data_ptr(),
+                                                           ws.data_ptr(), ws.numel(), _stream_ptr(dev)),
+                     "egc_aggregate_combine_strided_f32")
+        elif rows is not None:
             if post is not None:
                 raise RuntimeError("egc_amd: a row range and a fused post-op cannot be combined")
             _C.check(lib.egc_aggregate_combine_rows_f32(C.byref(g), C.byref(spec.c), bases.data_ptr(), spec.ldb,

@@ -16,12 +16,15 @@ The node / edge type lists are the reference's module constants (rmag/models.py:
 """
 from __future__ import annotations
 
+from types import SimpleNamespace
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _C
-from .functional import PostOp, egc_aggregate_combine, egc_aggregate_combine_apply, make_spec
+from .functional import (PostOp, egc_aggregate_combine, egc_aggregate_combine_apply, egc_basis_transform, gemm_exact,
+                         make_spec, pack_weights)
 from .graph import CSRGraph, SparseTensor
 from .layers import glorot_
 
@@ -75,6 +78,7 @@ class REGConv(nn.Module):
         self._spec_rel = make_spec(in_channels, out_channels, H, B, [_C.AGGR_MEAN, _C.AGGR_MAX],
                                    _C.SET_RAW, _C.SET_RAW, True, _C.LAYOUT_HBA, _C.ACT_NONE)
         self._identity = {}
+        self._type_cache = {}
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -83,6 +87,7 @@ class REGConv(nn.Module):
             lin.reset_parameters()
         for lin in self.root_combs.values():
             lin.reset_parameters()
+        self._type_cache = {}
 
     def _identity_graph(self, n: int, device) -> CSRGraph:
         key = (n, device)
@@ -93,7 +98,52 @@ class REGConv(nn.Module):
             self._identity = {key: g} if len(self._identity) > 8 else {**self._identity, key: g}
         return g
 
+    def _type_weights(self, ntype: str):
+        """Inference: everything computed from one node type's features -- its bases, its root weightings and the
+        weightings of every relation that targets the type -- as ONE GEMM: ([bases_weight | root^T | rel^T ...],
+        biases, split-precision planes), cached until a parameter changes in place."""
+        rels = [k for k in self.edge_types if k[2] == ntype]
+        lins = [self.root_combs[ntype]] + [self.rel_combs[f"{k[0]}_{k[1]}_{k[2]}"] for k in rels]
+        params = [self.bases_weight] + [p for lin in lins for p in (lin.weight, lin.bias)]
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        hit = self._type_cache.get(ntype)
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                perm = self._hba_rows
+                cols = [self.bases_weight, lins[0].weight.t()] + [lin.weight[perm].t() for lin in lins[1:]]
+                wcat = torch.cat(cols, dim=1).contiguous()
+                bcat = torch.cat([lins[0].bias] + [lin.bias[perm] for lin in lins[1:]]).contiguous()
+                gspec = SimpleNamespace(f_in=self.in_channels, f_g=self._spec_root.f_g,
+                                        w_cols=wcat.size(1) - self._spec_root.f_g, ldb=self._spec_root.ldb)
+                planes = None if gemm_exact() else pack_weights(gspec, wcat)
+            hit = (key, wcat, bcat, planes, gspec, rels)
+            self._type_cache[ntype] = hit
+        return hit[1:]
+
+    def _forward_inference(self, x_dict, adj_t_dict):
+        HB = self.num_heads * self.num_bases
+        bases, wt, out, offs = {}, {}, {}, {}
+        for key, x in x_dict.items():
+            wcat, bcat, planes, gspec, rels = self._type_weights(key)
+            ident = self._identity_graph(x.size(0), x.device)
+            bases[key], wt[key] = egc_basis_transform(ident, gspec, x, wcat, bcat, planes)   # rmag/models.py:113-143
+            offs[key] = {k: HB + 2 * HB * i for i, k in enumerate(rels)}
+            out[key] = egc_aggregate_combine(ident, self._spec_root, bases[key], wt[key][:, :HB], None)
+        for key, adj_t in adj_t_dict.items():
+            src, _, dst = key
+            g = _as_graph(adj_t, x_dict[dst].size(0), x_dict[src].size(0))
+            o = offs[dst][tuple(key)]
+            # the store adds the terms accumulated so far (egc_post.residual, in place)
+            egc_aggregate_combine(g, self._spec_rel, bases[src], wt[dst][:, o:o + 2 * HB], None,
+                                  post=PostOp(residual=out[dst]), out=out[dst])
+        return out
+
     def forward(self, x_dict, adj_t_dict):
+        needs_grad = torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters()) or
+                                                  any(x.requires_grad for x in x_dict.values()))
+        if not needs_grad and (self.num_heads * self.num_bases) % 4 == 0 and \
+                all(tuple(k) in self.edge_types for k in adj_t_dict):
+            return self._forward_inference(x_dict, adj_t_dict)
         ldb = self._spec_root.ldb
         f_g = self._spec_root.f_g
         bases, out = {}, {}

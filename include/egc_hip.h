@@ -223,6 +223,15 @@ int egc_aggregate_combine_post_f32(const egc_graph* graph, const egc_layer* laye
                                    const float* weightings, const float* bias, const egc_post* post, float* out,
                                    void* workspace, size_t workspace_bytes, egc_stream_t stream);
 
+/* egc_aggregate_combine_post_f32 whose `weightings` rows are ldw floats apart (ldw >= H*B*A, a multiple of 4,
+ * weightings 16-byte aligned): the weightings of several terms computed by ONE GEMM share an array and each term
+ * reads its column block.  Relational EGC (rmag/models.py:117-144) computes, per node type, the bases, the root
+ * weightings and the weightings of every relation that targets the type from the same x -- one
+ * egc_basis_transform_packed with w_cols = all of them, then one call of this per term.  post may be NULL. */
+int egc_aggregate_combine_strided_f32(const egc_graph* graph, const egc_layer* layer, const float* bases, int32_t ldb,
+                                      const float* weightings, int32_t ldw, const float* bias, const egc_post* post,
+                                      float* out, void* workspace, size_t workspace_bytes, egc_stream_t stream);
+
 /* Mean of the rows of x [n_rows, width] over consecutive segments: out[g] = mean(x[seg_ptr[g] : seg_ptr[g+1]])
  * (0 for an empty segment; x may be NULL when every segment is empty).  global_mean_pool over a PyG batch
  * vector, whose graphs are contiguous
