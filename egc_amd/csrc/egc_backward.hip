@@ -549,12 +549,27 @@ __global__ void __launch_bounds__(256) bwd_dst_fast_kernel(BwdArgs a) {
 
 // Sum of the destination tables over one source row's out-entries [start, end), entries t, t + step, ...:
 // lane q of the group holds slot(s) q, q + LPR, ... (NS of them).
+// FL: which tables exist and which edge sets are LOOPED, compiled in (bit 0 set) or read from the arguments (0).
+// The run-time form makes the compiler clone the gather loop per flag combination (9,000 lines of ISA, SGPR
+// spills); the shipped layer kinds get a lean kernel each.
+constexpr unsigned SRC_STATIC = 1u, SRC_S = 2u, SRC_V = 4u, SRC_X = 8u, SRC_N = 16u, SRC_XL = 32u, SRC_YL = 64u;
+template <unsigned FL>
+struct SrcCfg {
+  static constexpr bool fixed = (FL & SRC_STATIC) != 0;
+  static __device__ inline bool has_s(const BwdArgs& a) { return fixed ? (FL & SRC_S) != 0 : a.tab_s != nullptr; }
+  static __device__ inline bool has_v(const BwdArgs& a) { return fixed ? (FL & SRC_V) != 0 : a.tab_v != nullptr; }
+  static __device__ inline bool has_x(const BwdArgs& a) { return fixed ? (FL & SRC_X) != 0 : a.tab_x != nullptr; }
+  static __device__ inline bool has_n(const BwdArgs& a) { return fixed ? (FL & SRC_N) != 0 : a.tab_n != nullptr; }
+  static __device__ inline bool xl(const BwdArgs& a) { return fixed ? (FL & SRC_XL) != 0 : a.x_looped != 0; }
+  static __device__ inline bool yl(const BwdArgs& a) { return fixed ? (FL & SRC_YL) != 0 : a.y_looped != 0; }
+};
+
 constexpr int BWD_FU = 4;
-template <int NS>
+template <int NS, class SC>
 __device__ inline void sum_tables(const BwdArgs& a, const __amdgpu_buffer_rsrc_t (&rt)[3],
                                   const __amdgpu_buffer_rsrc_t (&rx)[4], int row, int start, int end, int first, int step,
                                   int q, int LPR, bool xl, bool yl, f4 (&at)[NS], f4 (&as)[NS], f4 (&av)[NS]) {
-  const bool ext = a.tab_x != nullptr || a.tab_n != nullptr;
+  const bool ext = SC::has_x(a) || SC::has_n(a);
   for (int p0 = start + first; p0 < end; p0 += step * BWD_FU) {
     int dst[BWD_FU], pos[BWD_FU];
 #pragma unroll
@@ -573,14 +588,14 @@ __device__ inline void sum_tables(const BwdArgs& a, const __amdgpu_buffer_rsrc_t
         const bool is_self = dst[u] == row;
         const unsigned off = (unsigned)dst[u] * (unsigned)a.ldb * 4u + (unsigned)s * 16u;
         vt[u] = load_slot(rt[0], (live && !(xl && is_self)) ? off : OOB);
-        if (a.tab_v != nullptr) vv[u] = load_slot(rt[2], (live && !(xl && is_self)) ? off : OOB);
-        if (a.tab_s != nullptr) vs[u] = load_slot(rt[1], (live && !(yl && is_self)) ? off : OOB);
+        if (SC::has_v(a)) vv[u] = load_slot(rt[2], (live && !(xl && is_self)) ? off : OOB);
+        if (SC::has_s(a)) vs[u] = load_slot(rt[1], (live && !(yl && is_self)) ? off : OOB);
       }
 #pragma unroll
       for (int u = 0; u < BWD_FU; ++u) {
         at[k] += vt[u];
-        if (a.tab_v != nullptr) av[k] += vv[u];
-        if (a.tab_s != nullptr) as[k] += vs[u];
+        if (SC::has_v(a)) av[k] += vv[u];
+        if (SC::has_s(a)) as[k] += vs[u];
       }
       // max / min: the whole gradient of (destination, column) goes to the entry its arg position names.  The arg
       // rows are gathered first; the gradient slot only where one of the lane's four columns names this entry
@@ -588,8 +603,7 @@ __device__ inline void sum_tables(const BwdArgs& a, const __amdgpu_buffer_rsrc_t
       if (ext) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-          const float* tab = e == 0 ? a.tab_x : a.tab_n;
-          if (tab == nullptr) continue;
+          if (!(e == 0 ? SC::has_x(a) : SC::has_n(a))) continue;
           int4 ar[BWD_FU];
           f4 gv[BWD_FU];
           bool lv[BWD_FU];
@@ -618,13 +632,14 @@ __device__ inline void sum_tables(const BwdArgs& a, const __amdgpu_buffer_rsrc_t
 
 // d bases[j] += sum over out-neighbours of the tables (+ self-loop terms).  Leading blocks: one wavefront per
 // EGC_LONG_ROW_CHUNK-entry chunk of a long row, partial sums by float atomics; the other blocks: one lane group per short row.
-template <int NS>
+template <int NS, unsigned FL = 0>
 __global__ void __launch_bounds__(256) bwd_src_kernel(BwdArgs a) {
+  using SC = SrcCfg<FL>;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int LPR = 1 << a.lpr_log2, G = 64 >> a.lpr_log2;
   const int g = lane >> a.lpr_log2, q = lane & (LPR - 1);
-  const bool xl = a.x_looped != 0, yl = a.y_looped != 0;
+  const bool xl = SC::xl(a), yl = SC::yl(a);
   const int nloop = a.loops_all ? a.n_nodes : (*a.max_index + 1);
   __amdgpu_buffer_rsrc_t rt[3];
   rt[0] = __builtin_amdgcn_make_buffer_rsrc((void*)a.tab_t, 0, a.tab_bytes, 0x00020000);
@@ -665,7 +680,7 @@ __global__ void __launch_bounds__(256) bwd_src_kernel(BwdArgs a) {
   f4 at[NS], as[NS], av[NS];
 #pragma unroll
   for (int k = 0; k < NS; ++k) at[k] = as[k] = av[k] = zero;
-  sum_tables<NS>(a, rt, rx, row, start, end, first, step, q, LPR, xl, yl, at, as, av);
+  sum_tables<NS, SC>(a, rt, rx, row, start, end, first, step, q, LPR, xl, yl, at, as, av);
   if (atomic) {  // merge the G groups of the chunk
     for (int off = LPR; off < 64; off <<= 1) {
 #pragma unroll
@@ -688,17 +703,17 @@ __global__ void __launch_bounds__(256) bwd_src_kernel(BwdArgs a) {
     f4 t = at[k], sv = as[k], vv = av[k];
     if (xl && has_self) {
       t += *reinterpret_cast<const f4*>(a.tab_t + o);
-      if (a.tab_v != nullptr) vv += *reinterpret_cast<const f4*>(a.tab_v + o);
+      if (SC::has_v(a)) vv += *reinterpret_cast<const f4*>(a.tab_v + o);
     }
-    if (yl && has_self && a.tab_s != nullptr) sv += *reinterpret_cast<const f4*>(a.tab_s + o);
+    if (yl && has_self && SC::has_s(a)) sv += *reinterpret_cast<const f4*>(a.tab_s + o);
     if (xl && has_self) {  // the appended self-loop attained the extremum: arg == n_edges
-      if (a.tab_x != nullptr) {
+      if (SC::has_x(a)) {
         const int4 ar = *reinterpret_cast<const int4*>(a.arg_max + o);
         const f4 gx = *reinterpret_cast<const f4*>(a.tab_x + o);
         t.x += ar.x == a.n_edges ? gx.x : 0.f; t.y += ar.y == a.n_edges ? gx.y : 0.f;
         t.z += ar.z == a.n_edges ? gx.z : 0.f; t.w += ar.w == a.n_edges ? gx.w : 0.f;
       }
-      if (a.tab_n != nullptr) {
+      if (SC::has_n(a)) {
         const int4 ar = *reinterpret_cast<const int4*>(a.arg_min + o);
         const f4 gn = *reinterpret_cast<const f4*>(a.tab_n + o);
         t.x += ar.x == a.n_edges ? gn.x : 0.f; t.y += ar.y == a.n_edges ? gn.y : 0.f;
@@ -706,8 +721,8 @@ __global__ void __launch_bounds__(256) bwd_src_kernel(BwdArgs a) {
       }
     }
     f4 d = t;
-    if (a.tab_s != nullptr) d = f4_fma(f4{dis_j, dis_j, dis_j, dis_j}, sv, d);
-    if (a.tab_v != nullptr) d = f4_fma(*reinterpret_cast<const f4*>(a.bases + o), vv, d);
+    if (SC::has_s(a)) d = f4_fma(f4{dis_j, dis_j, dis_j, dis_j}, sv, d);
+    if (SC::has_v(a)) d = f4_fma(*reinterpret_cast<const f4*>(a.bases + o), vv, d);
     float* dst = a.d_bases + (int64_t)row * a.ld_db + 4 * s;
     if (atomic) {
       atomicAdd(dst, d.x); atomicAdd(dst + 1, d.y); atomicAdd(dst + 2, d.z); atomicAdd(dst + 3, d.w);
@@ -864,6 +879,21 @@ int egc_aggregate_combine_backward_f32(const egc_graph* graph, const egc_graph* 
   const int64_t n_chunks = (t_graph->n_chunks >= 0 && t_graph->n_chunks <= caps.cap_chunks) ? t_graph->n_chunks : caps.cap_chunks;
   a.chunk_blocks = (int)ceil_div(n_chunks, 4);
   const unsigned grid = (unsigned)(a.chunk_blocks + ceil_div(n_src, (int64_t)4 * G));
+  unsigned fl = SRC_STATIC | (a.tab_s != nullptr ? SRC_S : 0u) | (a.tab_v != nullptr ? SRC_V : 0u) |
+                (a.tab_x != nullptr ? SRC_X : 0u) | (a.tab_n != nullptr ? SRC_N : 0u) | (a.x_looped ? SRC_XL : 0u) |
+                (a.y_looped ? SRC_YL : 0u);
+  if (getenv("EGC_BWD_GENERIC") != nullptr) fl = 0;
+  if (ns == 1 && fl == (SRC_STATIC | SRC_S | SRC_X | SRC_XL | SRC_YL)) {          // EGConv sum+mean+max+symnorm (north star)
+    bwd_src_kernel<1, SRC_STATIC | SRC_S | SRC_X | SRC_XL | SRC_YL><<<grid, 256, 0, stream>>>(a);
+  } else if (ns == 1 && fl == (SRC_STATIC | SRC_S | SRC_X | SRC_YL)) {             // EfficientGraphConv symadd+max+mean
+    bwd_src_kernel<1, SRC_STATIC | SRC_S | SRC_X | SRC_YL><<<grid, 256, 0, stream>>>(a);
+  } else if (ns == 1 && fl == (SRC_STATIC | SRC_S | SRC_YL)) {                     // EfficientGraphConv symadd (EGC-S)
+    bwd_src_kernel<1, SRC_STATIC | SRC_S | SRC_YL><<<grid, 256, 0, stream>>>(a);
+  } else if (ns == 1 && fl == (SRC_STATIC | SRC_S | SRC_XL | SRC_YL)) {            // EGConv symnorm
+    bwd_src_kernel<1, SRC_STATIC | SRC_S | SRC_XL | SRC_YL><<<grid, 256, 0, stream>>>(a);
+  } else if (ns == 1 && fl == (SRC_STATIC | SRC_X)) {                              // relational EGC: mean+max, raw
+    bwd_src_kernel<1, SRC_STATIC | SRC_X><<<grid, 256, 0, stream>>>(a);
+  } else
   switch (ns) {
     case 1: bwd_src_kernel<1><<<grid, 256, 0, stream>>>(a); break;
     case 2: bwd_src_kernel<2><<<grid, 256, 0, stream>>>(a); break;
