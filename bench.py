@@ -140,14 +140,14 @@ def main():
     if world == 1:
         ei_cpu, n = arxiv_like(seed=args.seed)
         ei = ei_cpu.to(dev)
-        graph = egc_amd.CSRGraph.from_edge_index(ei, n)
+        graph = egc_amd.CSRGraph.from_edge_index(ei, n).trim_launches()  # static graph (the reference's cached=True)
     else:
         from egc_amd import partition
         ei_cpu, n_global = partitioned_arxiv_like(rank, world, seed=args.seed)
         # interior rows first: they are aggregated while the halo rows of `bases` are in flight
         overlap = os.environ.get("EGC_BENCH_NO_OVERLAP", "0") in ("", "0")
         ei_local, plan = partition.build_distributed(ei_cpu.to(dev), n_global, interior_first=overlap)
-        graph = egc_amd.CSRGraph.from_partition(ei_local, plan, global_max_index=n_global - 1)
+        graph = egc_amd.CSRGraph.from_partition(ei_local, plan, global_max_index=n_global - 1).trim_launches()
         n = plan.n_local
         ei = ei_local
         halo_stats = plan.stats

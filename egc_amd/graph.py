@@ -10,6 +10,7 @@ It replaces what the reference keeps in ``_AggLayer.cached_vals`` (experiments/l
 from __future__ import annotations
 
 import ctypes as C
+import os
 from collections import OrderedDict
 
 import torch
@@ -41,7 +42,7 @@ class CSRGraph:
         self.device = rowptr.device
         self.edge_dis_raw = self.edge_dis_looped = None  # dis_*[col[p]] per entry (refresh_edge_dis)
         self._workspaces = {}
-        self._n_chunks = None  # host copy of plan[1], read back lazily (one synchronisation per graph)
+        self._n_chunks = None  # host copy of plan[1]; -1 = not read back (see c_struct)
 
     # -- construction ---------------------------------------------------------------------
     @classmethod
@@ -160,6 +161,8 @@ class CSRGraph:
                 src = self.col[:e].long()
                 # swap roles: "source" = dst (becomes the entry), "destination" = src (becomes the row)
                 self._transposed = CSRGraph.from_edge_index(torch.stack([dst, src]), ns, max(n, 1))
+        if self._n_chunks is not None and self._n_chunks >= 0:   # a static graph: its transpose is one too
+            self._transposed.trim_launches()
         return self._transposed
 
     def workspace(self, nbytes: int) -> torch.Tensor:
@@ -175,12 +178,27 @@ class CSRGraph:
     # -- C view -----------------------------------------------------------------------------
     def c_struct(self) -> _C.EgcGraph:
         if self._n_chunks is None:
-            self._n_chunks = int(self.plan[1].item())
+            # A host copy of the chunk count would trim the launch to the chunks that exist, at the price of one
+            # synchronisation per graph.  Measured (ogbn-mag shape: 208 k chunk slots, 52 k idle workgroups per
+            # launch), the idle workgroups cost nothing that shows, so by default nothing is read back and no
+            # call ever synchronises; EGC_SYNC_MIN_CHUNKS=<capacity> switches the read-back on above that capacity.
+            cap_long = min(self.n_edges // (_C.LONG_ROW_THRESHOLD + 1) + 1, self.n_nodes + 1)
+            cap_chunks = self.n_edges // _C.LONG_ROW_CHUNK + cap_long
+            sync_min = int(os.environ.get("EGC_SYNC_MIN_CHUNKS", "0"))
+            self._n_chunks = int(self.plan[1].item()) if (sync_min > 0 and cap_chunks > sync_min) else -1
         return _C.EgcGraph(self.n_nodes, self.n_edges, self.rowptr.data_ptr(), self.col.data_ptr(),
                            self.edge_id.data_ptr(), self.dis_raw.data_ptr(), self.dis_looped.data_ptr(),
                            self.max_index.data_ptr(), self.plan.data_ptr(), self._n_chunks, self.n_src_rows,
                            self.edge_dis_raw.data_ptr() if self.edge_dis_raw is not None else None,
                            self.edge_dis_looped.data_ptr() if self.edge_dis_looped is not None else None)
+
+    def trim_launches(self) -> "CSRGraph":
+        """Read the long-row chunk count back to the host (ONE synchronisation) so that later launches carry only
+        the chunk workgroups that exist instead of the plan's capacity -- for a graph that is built once and used
+        many times (``cached=True`` layers, full-graph training); about 4 us per launch at ogbn-arxiv size."""
+        if self._n_chunks is None or self._n_chunks < 0:
+            self._n_chunks = int(self.plan[1].item())
+        return self
 
     def long_row_stats(self):
         """(n_long_rows, n_chunks) -- synchronises; diagnostics only."""
@@ -203,6 +221,7 @@ class SparseTensor:
         else:
             # row = destination, col = source  ->  edge_index = [col; row]
             self.graph = CSRGraph.from_edge_index(torch.stack([col.long(), row.long()]), self._sizes[0], self._sizes[1])
+        self.graph.trim_launches()   # an adj_t is built once per graph (ToSparseTensor): one synchronisation here
 
     def sparse_sizes(self):
         return self._sizes

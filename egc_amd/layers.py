@@ -129,7 +129,7 @@ class EfficientGraphConv(nn.Module):
         else:
             graph = graph_from_input(edge_index, x.size(0))
             if self.cache:
-                self._cached_graph = graph
+                self._cached_graph = graph.trim_launches()
         wcat = self._packed_weights()
         return egc_layer_apply(graph, self._spec, x, wcat, self.comb_weights.bias, self.bias,
                                packed=self._weight_planes(wcat))

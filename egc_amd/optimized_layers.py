@@ -123,7 +123,7 @@ class EGConv(nn.Module):
             is_coo = isinstance(edge_index, torch.Tensor) and edge_index.layout == torch.strided
             spec = self._spec_coo if is_coo else self._spec_adj
             if self.cached:
-                self._cached_graph = (graph, spec)
+                self._cached_graph = (graph.trim_launches(), spec)
         wcat, bcat = self._packed_weights()
         return egc_layer_apply(graph, spec, x, wcat, bcat, self.bias, packed=self._weight_planes(spec, wcat))
 
