@@ -14,7 +14,7 @@ from dataclasses import dataclass
 import torch
 
 from . import _C
-from .graph import CSRGraph, _require_cuda, _stream_ptr
+from .graph import CSRGraph, _require_cuda, _stream_ptr, _device_guard
 
 
 @dataclass
@@ -75,7 +75,7 @@ def pack_weights(spec: LayerSpec, wcat: torch.Tensor) -> torch.Tensor:
     _check_f32(wcat, "wcat", (spec.f_in, spec.f_g + spec.w_cols))
     dev = wcat.device
     wcat = wcat.contiguous()
-    with torch.cuda.device(dev):
+    with _device_guard(dev):
         nbytes = lib.egc_basis_pack_bytes(spec.f_in, spec.f_g, spec.w_cols)
         packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         _C.check(lib.egc_basis_pack(wcat.data_ptr(), spec.f_in, spec.f_g, spec.w_cols, packed.data_ptr(),
@@ -103,7 +103,7 @@ def egc_basis_transform(graph: CSRGraph, spec: LayerSpec, x: torch.Tensor, wcat:
     dev = x.device
     x = x.contiguous()
     wcat = wcat.contiguous()
-    with torch.cuda.device(dev):
+    with _device_guard(dev):
         bases = torch.empty((graph.n_src_rows, spec.ldb), dtype=torch.float32, device=dev)  # owned | halo rows
         weightings = torch.empty((n, spec.w_cols), dtype=torch.float32, device=dev)
         bcat_p = bcat.contiguous().data_ptr() if bcat is not None else None
@@ -148,7 +148,7 @@ def egc_aggregate_combine(graph: CSRGraph, spec: LayerSpec, bases: torch.Tensor,
         ldw = int(weightings.stride(0))
     elif not weightings.is_contiguous():
         weightings = weightings.contiguous()
-    with torch.cuda.device(dev):
+    with _device_guard(dev):
         if out is None:
             out = torch.empty((n, spec.f_out), dtype=torch.float32, device=dev)
         ws = graph.workspace(lib.egc_aggregate_workspace_bytes(C.byref(spec.c), n, graph.n_edges))
@@ -208,7 +208,7 @@ def segment_mean(x: torch.Tensor, seg_ptr: torch.Tensor) -> torch.Tensor:
     x = x.contiguous()
     seg_ptr = seg_ptr.to(device=x.device, dtype=torch.int64).contiguous()
     n_seg = int(seg_ptr.numel()) - 1
-    with torch.cuda.device(x.device):
+    with _device_guard(x.device):
         out = torch.empty((n_seg, x.size(1)), dtype=torch.float32, device=x.device)
         _C.check(lib.egc_segment_mean_f32(x.data_ptr(), seg_ptr.data_ptr(), n_seg, x.size(1), out.data_ptr(),
                                           _stream_ptr(x.device)), "egc_segment_mean_f32")
@@ -249,7 +249,7 @@ def egc_aggregate_combine_train(graph: CSRGraph, spec: LayerSpec, bases: torch.T
     _check_f32(weightings, "weightings", (n, spec.w_cols))
     dev = bases.device
     codes = [spec.c.aggrs[t] for t in range(spec.c.num_aggrs)]
-    with torch.cuda.device(dev):
+    with _device_guard(dev):
         out = torch.empty((n, spec.f_out), dtype=torch.float32, device=dev)
         stats = torch.empty((n, max(int(lib.egc_train_stats_floats(C.byref(spec.c))), 1)), dtype=torch.float32, device=dev)
         cnt = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
@@ -276,7 +276,7 @@ def egc_aggregate_combine_backward(graph: CSRGraph, spec: LayerSpec, bases, weig
     dev = bases.device
     stats, cnt, arg_max, arg_min = saved
     tg = graph.transposed()
-    with torch.cuda.device(dev):
+    with _device_guard(dev):
         d_cat = None
         if joint and graph.n_src_rows == n and (spec.ldb + spec.w_cols) % 4 == 0:
             d_cat = torch.empty((n, spec.ldb + spec.w_cols), dtype=torch.float32, device=dev)

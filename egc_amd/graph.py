@@ -19,7 +19,31 @@ from . import _C
 
 
 def _stream_ptr(device) -> int:
-    return torch.cuda.current_stream(device).cuda_stream
+    """Raw hipStream_t of the caller's current stream on `device` (every launch of the library goes there)."""
+    idx = device.index if isinstance(device, torch.device) else device
+    if idx is None:
+        idx = torch.cuda.current_device()
+    return torch._C._cuda_getCurrentRawStream(idx)
+
+
+class _NoGuard:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def _device_guard(device):
+    """``torch.cuda.device(device)`` only when `device` is not already current (the context manager costs
+    several microseconds per layer call, which is what small batched graphs are bound by)."""
+    idx = device.index if isinstance(device, torch.device) else device
+    if idx is None or idx == torch.cuda.current_device():
+        return _NO_GUARD
+    return torch.cuda.device(device)
 
 
 def _require_cuda(t: torch.Tensor, what: str):
@@ -57,7 +81,7 @@ class CSRGraph:
         dev = edge_index.device
         ei = edge_index.contiguous()
         n, e = int(num_nodes), int(ei.size(1))
-        with torch.cuda.device(dev):
+        with _device_guard(dev):
             # one int32 slab for everything integer (per-batch graphs: allocator calls and fills cost as much as
             # the kernels): rowptr | col | edge_id | max_index | long-row plan, each piece 16-byte aligned
             e1 = max(e, 1)
@@ -102,7 +126,7 @@ class CSRGraph:
         e = int(col.numel())
         rowptr = rowptr.to(torch.int32).contiguous()
         col32 = col.to(torch.int32).contiguous() if e > 0 else torch.empty(1, dtype=torch.int32, device=dev)
-        with torch.cuda.device(dev):
+        with _device_guard(dev):
             edge_id = torch.arange(max(e, 1), dtype=torch.int32, device=dev)
             max_index = torch.full((1,), n - 1, dtype=torch.int32, device=dev)
             return cls._prepare(n, e, rowptr, col32, edge_id, max_index, num_src_rows)
@@ -139,7 +163,7 @@ class CSRGraph:
         lib = _C.load()
         dev = self.device
         e = self.n_edges
-        with torch.cuda.device(dev):
+        with _device_guard(dev):
             if self.edge_dis_raw is None:
                 self.edge_dis_raw = torch.empty(max(e, 1), dtype=torch.float32, device=dev)
                 self.edge_dis_looped = torch.empty(max(e, 1), dtype=torch.float32, device=dev)
@@ -154,7 +178,7 @@ class CSRGraph:
         if getattr(self, "_transposed", None) is None:
             dev = self.device
             n, e, ns = self.n_nodes, self.n_edges, self.n_src_rows
-            with torch.cuda.device(dev):
+            with _device_guard(dev):
                 # destination id of every CSR entry = its row index
                 counts = (self.rowptr[1:] - self.rowptr[:-1]).long()
                 dst = torch.repeat_interleave(torch.arange(n, device=dev), counts)
@@ -168,7 +192,7 @@ class CSRGraph:
     def workspace(self, nbytes: int) -> torch.Tensor:
         """Scratch for egc_aggregate_combine_f32.  The C ABI wants it zero-filled before its first use
         and leaves it reusable afterwards, so it is zeroed once and kept per (size, stream)."""
-        key = (int(nbytes), torch.cuda.current_stream(self.device).cuda_stream)
+        key = (int(nbytes), _stream_ptr(self.device))
         ws = self._workspaces.get(key)
         if ws is None:
             ws = torch.zeros(max(int(nbytes), 1), dtype=torch.uint8, device=self.device)

@@ -102,7 +102,7 @@ class EfficientGraphConv(nn.Module):
         return torch.cat([bases, self.comb_weights.weight.t()], dim=1)
 
     def _packed_weights(self):
-        params = list(self.bases_weight) + [self.comb_weights.weight]
+        params = list(self.bases_weight._parameters.values()) + [self.comb_weights.weight]  # (ParameterList.__getitem__ is slow)
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
             return self._cat_weights()
         key = tuple((p.data_ptr(), p._version) for p in params)
