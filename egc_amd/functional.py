@@ -215,6 +215,31 @@ def segment_mean(x: torch.Tensor, seg_ptr: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def _layer_forward_one_call(graph: CSRGraph, spec: LayerSpec, x, packed, bcat, bias):
+    """The common inference case (one GPU, packed weights at hand, no fused tail) as ONE library call
+    (egc_layer_forward_packed: both launches from C) -- small batched graphs are bound by the host side."""
+    lib = _C.load()
+    n = graph.n_nodes
+    _check_f32(x, "x", (n, spec.f_in))
+    if x.device != graph.device:
+        raise RuntimeError(f"egc_amd: x is on {x.device} but the graph is on {graph.device}")
+    dev = x.device
+    x = x.contiguous()
+    with _device_guard(dev):
+        bases = torch.empty((n, spec.ldb), dtype=torch.float32, device=dev)
+        weightings = torch.empty((n, spec.w_cols), dtype=torch.float32, device=dev)
+        out = torch.empty((n, spec.f_out), dtype=torch.float32, device=dev)
+        ws = graph.workspace(lib.egc_aggregate_workspace_bytes(C.byref(spec.c), n, graph.n_edges))
+        g = graph.c_struct()
+        _C.check(lib.egc_layer_forward_packed(
+            C.byref(g), C.byref(spec.c), x.data_ptr(), packed.data_ptr(),
+            bcat.contiguous().data_ptr() if bcat is not None else None,
+            bias.contiguous().data_ptr() if bias is not None else None, bases.data_ptr(), spec.ldb,
+            weightings.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(dev)),
+            "egc_layer_forward_packed")
+    return out
+
+
 def egc_layer_forward(graph: CSRGraph, spec: LayerSpec, x: torch.Tensor, wcat: torch.Tensor,
                       bcat: torch.Tensor | None, bias: torch.Tensor | None, return_intermediates: bool = False,
                       packed: torch.Tensor | None = None, post: PostOp | None = None):
@@ -222,8 +247,11 @@ def egc_layer_forward(graph: CSRGraph, spec: LayerSpec, x: torch.Tensor, wcat: t
     bcat = comb.bias ([W]) or None, bias = layer bias ([F_out]) or None; ``packed`` = pack_weights(wcat)
     if the caller keeps one (otherwise it is produced here).  On a vertex-partitioned graph the halo rows
     of ``bases`` are exchanged (one all-to-all-v) between the two steps."""
-    bases, weightings = egc_basis_transform(graph, spec, x, wcat, bcat, packed)
     halo = graph.halo if graph.n_src_rows > graph.n_nodes else None
+    if (halo is None and post is None and packed is not None and not return_intermediates and not gemm_exact()
+            and graph.n_src_rows == graph.n_nodes):
+        return _layer_forward_one_call(graph, spec, x, packed, bcat, bias)
+    bases, weightings = egc_basis_transform(graph, spec, x, wcat, bcat, packed)
     if halo is not None and halo.n_interior is not None and post is None:
         # interior rows (no halo source) are finished while the halo rows of `bases` travel
         handle = halo.exchange_start(bases)
