@@ -497,3 +497,39 @@ def test_arrays_beyond_two_gib_sampled_rows_against_float64():
             ref = torch.einsum("hab,abl->hl", wt, aggs.view(A, B, 16)).reshape(-1) + conv.bias.double()
             worst = max(worst, float((out[r].double() - ref).abs().max() / ref.abs().max().clamp(min=1)))
     assert worst <= TOL, worst
+
+
+@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("hidden,H,B,aggrs", [(64, 8, 4, ["mean", "max"]), (42, 6, 3, ["sum", "std", "min"])])
+def test_weightings_read_as_a_column_block(hidden, H, B, aggrs, generic, monkeypatch):
+    """egc_aggregate_combine_strided_f32: the weightings of a term are a column block of a wider array (several
+    terms from one GEMM, relational EGC) -- same bits as with a dense copy, on both kernel families."""
+    import egc_amd
+    from egc_amd.functional import PostOp, egc_aggregate_combine
+    if generic:
+        monkeypatch.setenv("EGC_FORCE_GENERIC", "1")
+    dev = _dev()
+    rng = np.random.default_rng(hidden)
+    n = 500
+    ei = torch.from_numpy(_hub_graph(rng, n, 4000, [(5, 400)])).to(dev)
+    g = egc_amd.CSRGraph.from_edge_index(ei, n)
+    conv = egc_amd.EGConv(hidden, hidden, aggrs=aggrs, num_heads=H, num_bases=B, add_self_loops=False)
+    spec = conv._spec_coo
+    torch.manual_seed(0)
+    bases = torch.zeros(n, spec.ldb, device=dev)
+    bases[:, :spec.f_g] = torch.randn(n, spec.f_g, device=dev)
+    if spec.basis_stride != spec.basis_len:    # padded layout: pad columns must be zero
+        bases.view(n, -1)[:, :B * spec.basis_stride].view(n, B, spec.basis_stride)[:, :, spec.basis_len:] = 0
+    W = spec.w_cols
+    pad = (-W) % 4
+    wide = torch.randn(n, 8 + W + pad + 12, device=dev)          # the block starts at column 8 (32-byte offset)
+    block = wide[:, 8:8 + W]
+    res = torch.randn(n, hidden, device=dev)
+    if W % 4 == 0:
+        assert block.stride(0) != W and block.data_ptr() % 16 == 0
+    dense = egc_aggregate_combine(g, spec, bases, block.contiguous(), None)
+    strided = egc_aggregate_combine(g, spec, bases, block, None)
+    assert torch.equal(dense, strided)
+    dense_p = egc_aggregate_combine(g, spec, bases, block.contiguous(), None, post=PostOp(residual=res, relu=True))
+    strided_p = egc_aggregate_combine(g, spec, bases, block, None, post=PostOp(residual=res, relu=True))
+    assert torch.equal(dense_p, strided_p)
