@@ -221,6 +221,7 @@ struct BwdArgs {
   float* d_weightings;       // [N, ld_dw >= W]
   int ld_db, ld_dw;          // row strides (floats) of the two gradient arrays
   float* tab_t;              // [N, ldb]
+  int need_t;                // some aggregator is linear in the plain messages (sum / mean / var / std): T is not all zero
   float* tab_s;              // [N, ldb] or nullptr
   float* tab_v;              // [N, ldb] or nullptr
   float* tab_x;              // [N, ldb] d agg_max, or nullptr
@@ -281,7 +282,7 @@ __global__ void __launch_bounds__(256) bwd_dst_kernel(BwdArgs a) {
     const int b = c / a.Ls, l = c - b * a.Ls;
     if (l >= a.L) {  // padding column of a padded basis: nothing flows through it
       for (int t = 0; t < a.A; ++t) lds_agg[t * a.ldb + c] = 0.f;
-      __builtin_nontemporal_store((float)(0.f), &a.tab_t[(int64_t)row * a.ldb + c]);
+      if (a.need_t) __builtin_nontemporal_store((float)(0.f), &a.tab_t[(int64_t)row * a.ldb + c]);
       if (a.tab_s != nullptr) __builtin_nontemporal_store((float)(0.f), &a.tab_s[(int64_t)row * a.ldb + c]);
       if (a.tab_v != nullptr) __builtin_nontemporal_store((float)(0.f), &a.tab_v[(int64_t)row * a.ldb + c]);
       if (a.tab_x != nullptr) __builtin_nontemporal_store((float)(0.f), &a.tab_x[(int64_t)row * a.ldb + c]);
@@ -325,7 +326,7 @@ __global__ void __launch_bounds__(256) bwd_dst_kernel(BwdArgs a) {
       }
     }
     // var = E[x^2] - mean^2:  d/dx_j = 2 (x_j - mean) / cnt
-    __builtin_nontemporal_store((float)(d_t - 2.0f * mean * d_v / cntf), &a.tab_t[(int64_t)row * a.ldb + c]);
+    if (a.need_t) __builtin_nontemporal_store((float)(d_t - 2.0f * mean * d_v / cntf), &a.tab_t[(int64_t)row * a.ldb + c]);
     if (a.tab_s != nullptr) __builtin_nontemporal_store((float)(d_s), &a.tab_s[(int64_t)row * a.ldb + c]);
     if (a.tab_v != nullptr) __builtin_nontemporal_store((float)(2.0f * d_v / cntf), &a.tab_v[(int64_t)row * a.ldb + c]);
   }
@@ -511,7 +512,7 @@ __global__ void __launch_bounds__(256) bwd_dst_fast_kernel(BwdArgs a) {
   }
   if (wr) {
     const f4 two_dv = d_v * f4{2.f * rcnt, 2.f * rcnt, 2.f * rcnt, 2.f * rcnt};
-    __builtin_nontemporal_store(d_t - mean * two_dv, reinterpret_cast<f4*>(a.tab_t + o));
+    if (a.need_t) __builtin_nontemporal_store(d_t - mean * two_dv, reinterpret_cast<f4*>(a.tab_t + o));  // else never read
     if (a.tab_s != nullptr) __builtin_nontemporal_store(d_s, reinterpret_cast<f4*>(a.tab_s + o));
     if (a.tab_v != nullptr) __builtin_nontemporal_store(two_dv, reinterpret_cast<f4*>(a.tab_v + o));
   }
@@ -552,10 +553,11 @@ __global__ void __launch_bounds__(256) bwd_dst_fast_kernel(BwdArgs a) {
 // FL: which tables exist and which edge sets are LOOPED, compiled in (bit 0 set) or read from the arguments (0).
 // The run-time form makes the compiler clone the gather loop per flag combination (9,000 lines of ISA, SGPR
 // spills); the shipped layer kinds get a lean kernel each.
-constexpr unsigned SRC_STATIC = 1u, SRC_S = 2u, SRC_V = 4u, SRC_X = 8u, SRC_N = 16u, SRC_XL = 32u, SRC_YL = 64u;
+constexpr unsigned SRC_STATIC = 1u, SRC_S = 2u, SRC_V = 4u, SRC_X = 8u, SRC_N = 16u, SRC_XL = 32u, SRC_YL = 64u, SRC_T = 128u;
 template <unsigned FL>
 struct SrcCfg {
   static constexpr bool fixed = (FL & SRC_STATIC) != 0;
+  static __device__ inline bool has_t(const BwdArgs& a) { return fixed ? (FL & SRC_T) != 0 : a.need_t != 0; }
   static __device__ inline bool has_s(const BwdArgs& a) { return fixed ? (FL & SRC_S) != 0 : a.tab_s != nullptr; }
   static __device__ inline bool has_v(const BwdArgs& a) { return fixed ? (FL & SRC_V) != 0 : a.tab_v != nullptr; }
   static __device__ inline bool has_x(const BwdArgs& a) { return fixed ? (FL & SRC_X) != 0 : a.tab_x != nullptr; }
@@ -587,7 +589,7 @@ __device__ inline void sum_tables(const BwdArgs& a, const __amdgpu_buffer_rsrc_t
         const bool live = dst[u] >= 0 && s < a.slots;
         const bool is_self = dst[u] == row;
         const unsigned off = (unsigned)dst[u] * (unsigned)a.ldb * 4u + (unsigned)s * 16u;
-        vt[u] = load_slot(rt[0], (live && !(xl && is_self)) ? off : OOB);
+        vt[u] = load_slot(rt[0], (SC::has_t(a) && live && !(xl && is_self)) ? off : OOB);
         if (SC::has_v(a)) vv[u] = load_slot(rt[2], (live && !(xl && is_self)) ? off : OOB);
         if (SC::has_s(a)) vs[u] = load_slot(rt[1], (live && !(yl && is_self)) ? off : OOB);
       }
@@ -702,7 +704,7 @@ __global__ void __launch_bounds__(256) bwd_src_kernel(BwdArgs a) {
     const int64_t o = (int64_t)row * a.ldb + 4 * s;
     f4 t = at[k], sv = as[k], vv = av[k];
     if (xl && has_self) {
-      t += *reinterpret_cast<const f4*>(a.tab_t + o);
+      if (SC::has_t(a)) t += *reinterpret_cast<const f4*>(a.tab_t + o);
       if (SC::has_v(a)) vv += *reinterpret_cast<const f4*>(a.tab_v + o);
     }
     if (yl && has_self && SC::has_s(a)) sv += *reinterpret_cast<const f4*>(a.tab_s + o);
@@ -824,6 +826,10 @@ int egc_aggregate_combine_backward_f32(const egc_graph* graph, const egc_graph* 
   }
   float* ws = (float*)workspace;
   a.tab_t = ws;
+  a.need_t = 0;
+  for (int t = 0; t < a.A; ++t)
+    if (a.aggr[t] == EGC_AGGR_SUM || a.aggr[t] == EGC_AGGR_MEAN || a.aggr[t] == EGC_AGGR_VAR || a.aggr[t] == EGC_AGGR_STD)
+      a.need_t = 1;
   a.tab_s = sym ? ws + (size_t)n * ldb : nullptr;
   a.tab_v = var ? ws + (size_t)2 * n * ldb : nullptr;
   a.tab_x = a.stat_slot[STAT_MX] >= 0 ? ws + (size_t)3 * n * ldb : nullptr;
@@ -879,20 +885,20 @@ int egc_aggregate_combine_backward_f32(const egc_graph* graph, const egc_graph* 
   const int64_t n_chunks = (t_graph->n_chunks >= 0 && t_graph->n_chunks <= caps.cap_chunks) ? t_graph->n_chunks : caps.cap_chunks;
   a.chunk_blocks = (int)ceil_div(n_chunks, 4);
   const unsigned grid = (unsigned)(a.chunk_blocks + ceil_div(n_src, (int64_t)4 * G));
-  unsigned fl = SRC_STATIC | (a.tab_s != nullptr ? SRC_S : 0u) | (a.tab_v != nullptr ? SRC_V : 0u) |
+  unsigned fl = SRC_STATIC | (a.need_t ? SRC_T : 0u) | (a.tab_s != nullptr ? SRC_S : 0u) | (a.tab_v != nullptr ? SRC_V : 0u) |
                 (a.tab_x != nullptr ? SRC_X : 0u) | (a.tab_n != nullptr ? SRC_N : 0u) | (a.x_looped ? SRC_XL : 0u) |
                 (a.y_looped ? SRC_YL : 0u);
   if (getenv("EGC_BWD_GENERIC") != nullptr) fl = 0;
-  if (ns == 1 && fl == (SRC_STATIC | SRC_S | SRC_X | SRC_XL | SRC_YL)) {          // EGConv sum+mean+max+symnorm (north star)
-    bwd_src_kernel<1, SRC_STATIC | SRC_S | SRC_X | SRC_XL | SRC_YL><<<grid, 256, 0, stream>>>(a);
-  } else if (ns == 1 && fl == (SRC_STATIC | SRC_S | SRC_X | SRC_YL)) {             // EfficientGraphConv symadd+max+mean
-    bwd_src_kernel<1, SRC_STATIC | SRC_S | SRC_X | SRC_YL><<<grid, 256, 0, stream>>>(a);
+  if (ns == 1 && fl == (SRC_STATIC | SRC_T | SRC_S | SRC_X | SRC_XL | SRC_YL)) {  // EGConv sum+mean+max+symnorm (north star)
+    bwd_src_kernel<1, SRC_STATIC | SRC_T | SRC_S | SRC_X | SRC_XL | SRC_YL><<<grid, 256, 0, stream>>>(a);
+  } else if (ns == 1 && fl == (SRC_STATIC | SRC_T | SRC_S | SRC_X | SRC_YL)) {     // EfficientGraphConv symadd+max+mean
+    bwd_src_kernel<1, SRC_STATIC | SRC_T | SRC_S | SRC_X | SRC_YL><<<grid, 256, 0, stream>>>(a);
   } else if (ns == 1 && fl == (SRC_STATIC | SRC_S | SRC_YL)) {                     // EfficientGraphConv symadd (EGC-S)
     bwd_src_kernel<1, SRC_STATIC | SRC_S | SRC_YL><<<grid, 256, 0, stream>>>(a);
   } else if (ns == 1 && fl == (SRC_STATIC | SRC_S | SRC_XL | SRC_YL)) {            // EGConv symnorm
     bwd_src_kernel<1, SRC_STATIC | SRC_S | SRC_XL | SRC_YL><<<grid, 256, 0, stream>>>(a);
-  } else if (ns == 1 && fl == (SRC_STATIC | SRC_X)) {                              // relational EGC: mean+max, raw
-    bwd_src_kernel<1, SRC_STATIC | SRC_X><<<grid, 256, 0, stream>>>(a);
+  } else if (ns == 1 && fl == (SRC_STATIC | SRC_T | SRC_X)) {                      // relational EGC: mean+max, raw
+    bwd_src_kernel<1, SRC_STATIC | SRC_T | SRC_X><<<grid, 256, 0, stream>>>(a);
   } else
   switch (ns) {
     case 1: bwd_src_kernel<1><<<grid, 256, 0, stream>>>(a); break;
