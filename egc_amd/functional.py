@@ -339,6 +339,28 @@ def _xt_matmul(x: torch.Tensor, d: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def _dx_matmul(d_cat: torch.Tensor, wcat: torch.Tensor) -> torch.Tensor:
+    """d_cat [N, F_g + W] @ wcat^T [F_g + W, F_in] (the gradient w.r.t. x) on the split-precision matrix-core GEMM
+    of the forward (egc_basis_pack / egc_basis_transform_packed with no weightings block): 95 us instead of the
+    128 us of the fp32 library GEMM at config 2, 44 instead of 79 for an EGC-S layer; same fp32-level accuracy."""
+    f_in, k = wcat.size(0), wcat.size(1)
+    n = d_cat.size(0)
+    if gemm_exact() or f_in % 4 != 0 or n == 0 or not d_cat.is_cuda or not d_cat.is_contiguous() or d_cat.data_ptr() % 16:
+        return d_cat @ wcat.t()
+    lib = _C.load()
+    dev = d_cat.device
+    with _device_guard(dev):
+        wt = wcat.detach().t().contiguous()
+        nbytes = lib.egc_basis_pack_bytes(k, f_in, 0)
+        packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        dx = torch.empty((n, f_in), dtype=torch.float32, device=dev)
+        stream = _stream_ptr(dev)
+        _C.check(lib.egc_basis_pack(wt.data_ptr(), k, f_in, 0, packed.data_ptr(), nbytes, stream), "egc_basis_pack")
+        _C.check(lib.egc_basis_transform_packed(d_cat.data_ptr(), packed.data_ptr(), None, n, k, f_in, 0, dx.data_ptr(),
+                                                f_in, None, stream), "egc_basis_transform_packed")
+    return dx
+
+
 class _EGCLayerFunction(torch.autograd.Function):
     """Autograd around the fused forward.  The sparse part of the backward (gradients w.r.t. bases and the
     pre-activation weightings) runs in the HIP kernels of egc_backward.hip; the dense rest is three plain
@@ -371,7 +393,7 @@ class _EGCLayerFunction(torch.autograd.Function):
             d_bases = d_bases[:ctx.graph.n_nodes].index_add(0, halo.send_idx, back)
         if d_cat is None:
             d_cat = torch.cat([d_bases[:, :spec.f_g], d_w], dim=1)         # [N, F_g + W]
-        dx = d_cat @ wcat.t() if ctx.needs_input_grad[0] else None
+        dx = _dx_matmul(d_cat, wcat) if ctx.needs_input_grad[0] else None
         dwcat = _xt_matmul(x, d_cat) if ctx.needs_input_grad[1] else None
         dbcat = d_w.sum(0) if (ctx.has_bcat and ctx.needs_input_grad[2]) else None
         dbias = grad_out.sum(0) if (ctx.has_bias and ctx.needs_input_grad[3]) else None
