@@ -115,13 +115,13 @@ __device__ inline void lds_rd(bf16x8& dst, unsigned addr) {
   static_assert(OFF < 65536, "ds_read offset field");
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
 }
-// Step IDX = (substep IDX / 6, tile IDX % 6) of a full-width block: issue the B reads of step IDX + 1, wait
+// Step IDX = (substep IDX / NT, tile IDX % NT) of a block of NT column tiles: issue the B reads of step IDX + 1, wait
 // (counted) for this step's operands, six MFMAs.
-template <int IDX>
+template <int IDX, int NT>
 __device__ inline void mfma_step(f32x16 (&acc)[6], bf16x8 (&a3)[2][3], bf16x8 (&bq)[2][3], unsigned b_lds) {
-  constexpr int s = IDX / 6, t = IDX % 6, cur = IDX & 1, nxt = (IDX + 1) & 1;
-  if constexpr (IDX + 1 < 12) {
-    constexpr unsigned off = ((IDX + 1) % 6) * B_TILE + ((IDX + 1) / 6) * SUB;
+  constexpr int s = IDX / NT, t = IDX % NT, cur = IDX & 1, nxt = (IDX + 1) & 1;
+  if constexpr (IDX + 1 < 2 * NT) {
+    constexpr unsigned off = ((IDX + 1) % NT) * B_TILE + ((IDX + 1) / NT) * SUB;
     lds_rd<off>(bq[nxt][0], b_lds);
     lds_rd<off + B_PLANE>(bq[nxt][1], b_lds);
     lds_rd<off + 2 * B_PLANE>(bq[nxt][2], b_lds);
@@ -130,7 +130,7 @@ __device__ inline void mfma_step(f32x16 (&acc)[6], bf16x8 (&a3)[2][3], bf16x8 (&
     asm volatile("s_waitcnt lgkmcnt(3)"
                  : "+v"(a3[0][0]), "+v"(a3[0][1]), "+v"(a3[0][2]), "+v"(a3[1][0]), "+v"(a3[1][1]), "+v"(a3[1][2]),
                    "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[0][2]));
-  else if constexpr (IDX + 1 < 12)
+  else if constexpr (IDX + 1 < 2 * NT)
     asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(bq[cur][0]), "+v"(bq[cur][1]), "+v"(bq[cur][2]));
   else
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[cur][0]), "+v"(bq[cur][1]), "+v"(bq[cur][2]));
@@ -147,9 +147,9 @@ __device__ inline void mfma_step(f32x16 (&acc)[6], bf16x8 (&a3)[2][3], bf16x8 (&
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// FULL: every block of the launch spans XBN columns (six MFMA tiles) -> the pipelined straight-line MFMA loop;
-// otherwise the block's tile count is a run-time value (the last, narrower column block of a layer).
-template <bool A_VEC4, bool FULL>
+// NT > 0: every block of the launch spans NT column tiles (6 = the full XBN columns, 4 = a 128-column remainder or
+// a 128-column GEMM) -> the pipelined straight-line MFMA loop; NT = 0: the block's tile count is a run-time value.
+template <bool A_VEC4, int NT>
 __global__ void __launch_bounds__(256) basis_gemm_bf16x3_kernel(const float* __restrict__ x, const u16* __restrict__ packed,
                                                                 const float* __restrict__ bcat, int64_t M, int K,
                                                                 int W, float* __restrict__ bases, int ldb,
@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(256) basis_gemm_bf16x3_kernel(const float* __r
   const int wave = tid >> 6;
   const int64_t m0 = (int64_t)blockIdx.x * XBM;
   const int v0 = (blockIdx.y + vblock0) * XBN;
-  const int nvb = FULL ? XBN : min(XBN, NV - v0);  // virtual columns of this block (multiple of 32)
+  const int nvb = NT > 0 ? 32 * NT : min(XBN, NV - v0);  // virtual columns of this block (multiple of 32)
   const int ntile = nvb >> 5;
 
   f32x16 acc[6];
@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(256) basis_gemm_bf16x3_kernel(const float* __r
     // ---- 2 MFMA k-substeps of 16 x up to 6 column tiles
     const int arow = 32 * wave + (lane & 31);
     const int koff = 8 * (lane >> 5);
-    if constexpr (FULL) {
+    if constexpr (NT > 0) {
       // Full-width block: straight-line code in which the B operand of the NEXT (substep, tile) is read from LDS
       // before the six MFMAs of the current one are issued.  Reads and counted waits are inline assembly: the
       // compiler sinks its own ds_reads next to their first use and, when pinned, still waits for lgkmcnt(0) --
@@ -283,18 +283,21 @@ __global__ void __launch_bounds__(256) basis_gemm_bf16x3_kernel(const float* __r
       lds_rd<0>(a3[0][0], a_lds); lds_rd<A_PLANE>(a3[0][1], a_lds); lds_rd<2 * A_PLANE>(a3[0][2], a_lds);
       lds_rd<SUB>(a3[1][0], a_lds); lds_rd<A_PLANE + SUB>(a3[1][1], a_lds); lds_rd<2 * A_PLANE + SUB>(a3[1][2], a_lds);
       lds_rd<0>(bq[0][0], b_lds); lds_rd<B_PLANE>(bq[0][1], b_lds); lds_rd<2 * B_PLANE>(bq[0][2], b_lds);
-      mfma_step<0>(acc, a3, bq, b_lds);
-      mfma_step<1>(acc, a3, bq, b_lds);
-      mfma_step<2>(acc, a3, bq, b_lds);
-      mfma_step<3>(acc, a3, bq, b_lds);
-      mfma_step<4>(acc, a3, bq, b_lds);
-      mfma_step<5>(acc, a3, bq, b_lds);
-      mfma_step<6>(acc, a3, bq, b_lds);
-      mfma_step<7>(acc, a3, bq, b_lds);
-      mfma_step<8>(acc, a3, bq, b_lds);
-      mfma_step<9>(acc, a3, bq, b_lds);
-      mfma_step<10>(acc, a3, bq, b_lds);
-      mfma_step<11>(acc, a3, bq, b_lds);
+      mfma_step<0, NT>(acc, a3, bq, b_lds);
+      mfma_step<1, NT>(acc, a3, bq, b_lds);
+      mfma_step<2, NT>(acc, a3, bq, b_lds);
+      mfma_step<3, NT>(acc, a3, bq, b_lds);
+      mfma_step<4, NT>(acc, a3, bq, b_lds);
+      mfma_step<5, NT>(acc, a3, bq, b_lds);
+      mfma_step<6, NT>(acc, a3, bq, b_lds);
+      mfma_step<7, NT>(acc, a3, bq, b_lds);
+      if constexpr (NT == 6) {
+        mfma_step<8, NT>(acc, a3, bq, b_lds);
+        mfma_step<9, NT>(acc, a3, bq, b_lds);
+        mfma_step<10, NT>(acc, a3, bq, b_lds);
+        mfma_step<11, NT>(acc, a3, bq, b_lds);
+      }
+      static_assert(NT == 4 || NT == 6 || NT == 0, "pipelined MFMA loop: 4 or 6 column tiles");
     } else {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -625,9 +628,9 @@ int egc_basis_transform_packed(const float* x, const void* packed, const float* 
   if (full > 0) {
     dim3 grid((unsigned)mblocks, (unsigned)full);
     if (vec4)
-      basis_gemm_bf16x3_kernel<true, true><<<grid, 256, 0, stream>>>(x, pk, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, KS, 0);
+      basis_gemm_bf16x3_kernel<true, 6><<<grid, 256, 0, stream>>>(x, pk, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, KS, 0);
     else
-      basis_gemm_bf16x3_kernel<false, true><<<grid, 256, 0, stream>>>(x, pk, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, KS, 0);
+      basis_gemm_bf16x3_kernel<false, 6><<<grid, 256, 0, stream>>>(x, pk, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, KS, 0);
     EGC_LAUNCH_CHECK("basis_gemm_bf16x3_kernel");
   }
 #ifdef EGC_GEMM3_STAMPS
@@ -645,10 +648,13 @@ int egc_basis_transform_packed(const float* x, const void* packed, const float* 
 #endif
   if (NV % XBN != 0) {
     dim3 grid((unsigned)mblocks, 1);
-    if (vec4)
-      basis_gemm_bf16x3_kernel<true, false><<<grid, 256, 0, stream>>>(x, pk, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, KS, full);
+    const bool four = (NV - full * XBN) == 128;  // a 128-column remainder (or a 128-column GEMM): pipelined too
+    if (vec4 && four)
+      basis_gemm_bf16x3_kernel<true, 4><<<grid, 256, 0, stream>>>(x, pk, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, KS, full);
+    else if (vec4)
+      basis_gemm_bf16x3_kernel<true, 0><<<grid, 256, 0, stream>>>(x, pk, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, KS, full);
     else
-      basis_gemm_bf16x3_kernel<false, false><<<grid, 256, 0, stream>>>(x, pk, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, KS, full);
+      basis_gemm_bf16x3_kernel<false, 0><<<grid, 256, 0, stream>>>(x, pk, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, KS, full);
     EGC_LAUNCH_CHECK("basis_gemm_bf16x3_kernel");
   }
   return EGC_OK;
