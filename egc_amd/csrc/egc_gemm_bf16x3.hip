@@ -109,7 +109,7 @@ __device__ unsigned long long egc_stamp3[8];  // diagnostic build only: cycles p
 #endif
 
 // LDS operand read with an immediate offset (one address register for the whole tile loop)
-constexpr unsigned A_PLANE = XBM * XLD * 2, B_PLANE = XBN * XLD * 2, B_TILE = 32 * XLD * 2, SUB = 16 * 2;
+constexpr unsigned A_PLANE = XBM * XLD * 2, B_TILE = 32 * XLD * 2, SUB = 16 * 2;
 template <unsigned OFF>
 __device__ inline void lds_rd(bf16x8& dst, unsigned addr) {
   static_assert(OFF < 65536, "ds_read offset field");
@@ -117,9 +117,10 @@ __device__ inline void lds_rd(bf16x8& dst, unsigned addr) {
 }
 // Step IDX = (substep IDX / NT, tile IDX % NT) of a block of NT column tiles: issue the B reads of step IDX + 1, wait
 // (counted) for this step's operands, six MFMAs.
-template <int IDX, int NT>
-__device__ inline void mfma_step(f32x16 (&acc)[6], bf16x8 (&a3)[2][3], bf16x8 (&bq)[2][3], unsigned b_lds) {
+template <int IDX, int NT, int NACC>
+__device__ inline void mfma_step(f32x16 (&acc)[NACC], bf16x8 (&a3)[2][3], bf16x8 (&bq)[2][3], unsigned b_lds) {
   constexpr int s = IDX / NT, t = IDX % NT, cur = IDX & 1, nxt = (IDX + 1) & 1;
+  constexpr unsigned B_PLANE = (NT == 7 ? 224 : XBN) * XLD * 2;  // the 7-tile block keeps 224 columns of B in LDS
   if constexpr (IDX + 1 < 2 * NT) {
     constexpr unsigned off = ((IDX + 1) % NT) * B_TILE + ((IDX + 1) / NT) * SUB;
     lds_rd<off>(bq[nxt][0], b_lds);
@@ -156,10 +157,14 @@ __global__ void __launch_bounds__(256) basis_gemm_bf16x3_kernel(const float* __r
                                                                 float* __restrict__ weightings, int NV, int KS,
                                                                 int vblock0) {
   // one LDS allocation, carved explicitly (the epilogue re-uses it as the transpose buffer)
-  constexpr int A_ELEMS = 3 * XBM * XLD, B_ELEMS = 3 * XBN * XLD;
+  // NT = 7: ONE block of 224 columns (1 block per CU: 84 KB of LDS) instead of a 192-column pass plus a second
+  // pass over x for the last 32 -- the ogbn-mag layers (176 bases + 32 weightings columns).
+  constexpr int BN = NT == 7 ? 224 : XBN, NACC = NT == 7 ? 7 : 6, WJ = NT == 7 ? 4 : 3;
+  constexpr unsigned B_PLANE = BN * XLD * 2;
+  constexpr int A_ELEMS = 3 * XBM * XLD, B_ELEMS = 3 * BN * XLD;
   __shared__ __attribute__((aligned(16))) u16 lds_raw[A_ELEMS + B_ELEMS];
   u16 (*As)[XBM][XLD] = reinterpret_cast<u16 (*)[XBM][XLD]>(lds_raw);
-  u16 (*Bs)[XBN][XLD] = reinterpret_cast<u16 (*)[XBN][XLD]>(lds_raw + A_ELEMS);
+  u16 (*Bs)[BN][XLD] = reinterpret_cast<u16 (*)[BN][XLD]>(lds_raw + A_ELEMS);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -167,11 +172,12 @@ __global__ void __launch_bounds__(256) basis_gemm_bf16x3_kernel(const float* __r
   const int64_t m0 = (int64_t)blockIdx.x * XBM;
   const int v0 = (blockIdx.y + vblock0) * XBN;
   const int nvb = NT > 0 ? 32 * NT : min(XBN, NV - v0);  // virtual columns of this block (multiple of 32)
+  static_assert(NT == 0 || NT == 4 || NT == 6 || NT == 7, "pipelined MFMA loop: 4, 6 or 7 column tiles");
   const int ntile = nvb >> 5;
 
-  f32x16 acc[6];
+  f32x16 acc[NACC];
 #pragma unroll
-  for (int t = 0; t < 6; ++t)
+  for (int t = 0; t < NACC; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -191,14 +197,14 @@ __global__ void __launch_bounds__(256) basis_gemm_bf16x3_kernel(const float* __r
   };
   // packed weight planes of one k-step: 3 x [nvb x 32] bf16 as 16-byte pieces, nine per thread, all issued
   // back to back (clamped index instead of a guard)
-  const int pieces = nvb * 4;  // 16-byte pieces per plane (<= 768)
-  u32x4 wreg[3][3];
+  const int pieces = nvb * 4;  // 16-byte pieces per plane (<= 256 WJ)
+  u32x4 wreg[3][WJ];
   auto load_w = [&](int ks) {
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
       const u16* src = packed + (((int64_t)ks * 3 + p) * NV + v0) * XKT;
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
+      for (int j = 0; j < WJ; ++j) {
         const int i = min(tid + 256 * j, pieces - 1);
         wreg[p][j] = *reinterpret_cast<const u32x4*>(src + (int64_t)i * 8);
       }
@@ -256,7 +262,7 @@ __global__ void __launch_bounds__(256) basis_gemm_bf16x3_kernel(const float* __r
 #pragma unroll
       for (int p = 0; p < 3; ++p)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
+        for (int j = 0; j < WJ; ++j) {
           const int i = tid + 256 * j;
           if (i < pieces) *reinterpret_cast<u32x4*>(&Bs[p][i >> 2][(i & 3) * 8]) = wreg[p][j];
         }
@@ -283,21 +289,24 @@ __global__ void __launch_bounds__(256) basis_gemm_bf16x3_kernel(const float* __r
       lds_rd<0>(a3[0][0], a_lds); lds_rd<A_PLANE>(a3[0][1], a_lds); lds_rd<2 * A_PLANE>(a3[0][2], a_lds);
       lds_rd<SUB>(a3[1][0], a_lds); lds_rd<A_PLANE + SUB>(a3[1][1], a_lds); lds_rd<2 * A_PLANE + SUB>(a3[1][2], a_lds);
       lds_rd<0>(bq[0][0], b_lds); lds_rd<B_PLANE>(bq[0][1], b_lds); lds_rd<2 * B_PLANE>(bq[0][2], b_lds);
-      mfma_step<0, NT>(acc, a3, bq, b_lds);
-      mfma_step<1, NT>(acc, a3, bq, b_lds);
-      mfma_step<2, NT>(acc, a3, bq, b_lds);
-      mfma_step<3, NT>(acc, a3, bq, b_lds);
-      mfma_step<4, NT>(acc, a3, bq, b_lds);
-      mfma_step<5, NT>(acc, a3, bq, b_lds);
-      mfma_step<6, NT>(acc, a3, bq, b_lds);
-      mfma_step<7, NT>(acc, a3, bq, b_lds);
-      if constexpr (NT == 6) {
-        mfma_step<8, NT>(acc, a3, bq, b_lds);
-        mfma_step<9, NT>(acc, a3, bq, b_lds);
-        mfma_step<10, NT>(acc, a3, bq, b_lds);
-        mfma_step<11, NT>(acc, a3, bq, b_lds);
+      mfma_step<0, NT, NACC>(acc, a3, bq, b_lds);
+      mfma_step<1, NT, NACC>(acc, a3, bq, b_lds);
+      mfma_step<2, NT, NACC>(acc, a3, bq, b_lds);
+      mfma_step<3, NT, NACC>(acc, a3, bq, b_lds);
+      mfma_step<4, NT, NACC>(acc, a3, bq, b_lds);
+      mfma_step<5, NT, NACC>(acc, a3, bq, b_lds);
+      mfma_step<6, NT, NACC>(acc, a3, bq, b_lds);
+      mfma_step<7, NT, NACC>(acc, a3, bq, b_lds);
+      if constexpr (NT >= 6) {
+        mfma_step<8, NT, NACC>(acc, a3, bq, b_lds);
+        mfma_step<9, NT, NACC>(acc, a3, bq, b_lds);
+        mfma_step<10, NT, NACC>(acc, a3, bq, b_lds);
+        mfma_step<11, NT, NACC>(acc, a3, bq, b_lds);
       }
-      static_assert(NT == 4 || NT == 6 || NT == 0, "pipelined MFMA loop: 4 or 6 column tiles");
+      if constexpr (NT == 7) {
+        mfma_step<12, NT, NACC>(acc, a3, bq, b_lds);
+        mfma_step<13, NT, NACC>(acc, a3, bq, b_lds);
+      }
     } else {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -305,7 +314,7 @@ __global__ void __launch_bounds__(256) basis_gemm_bf16x3_kernel(const float* __r
         const bf16x8 am = *reinterpret_cast<const bf16x8*>(&As[1][arow][16 * s + koff]);
         const bf16x8 al = *reinterpret_cast<const bf16x8*>(&As[2][arow][16 * s + koff]);
 #pragma unroll
-        for (int t = 0; t < 6; ++t) {
+        for (int t = 0; t < NACC; ++t) {
           if (t < ntile) {  // block-uniform
             const int bcol = 32 * t + (lane & 31);
             const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&Bs[0][bcol][16 * s + koff]);
@@ -333,7 +342,7 @@ __global__ void __launch_bounds__(256) basis_gemm_bf16x3_kernel(const float* __r
 #endif
 
   // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
-  const bool wide = (ntile == 6) && (W % 4 == 0) && (bcat == nullptr || (reinterpret_cast<uintptr_t>(bcat) & 15) == 0);
+  const bool wide = (ntile >= 6) && (W % 4 == 0) && (bcat == nullptr || (reinterpret_cast<uintptr_t>(bcat) & 15) == 0);
   if (wide) {
     // Transpose the wavefront's 32 x 192 tile through the (now idle) LDS in two halves of 96 columns and
     // write it as 16-byte pieces of contiguous rows: 24 dwordx4 stores per lane instead of 96 dword stores.
@@ -374,11 +383,12 @@ __global__ void __launch_bounds__(256) basis_gemm_bf16x3_kernel(const float* __r
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    return;
+    if (NACC == 6) return;  // a 7-tile block: the last tile goes out element by element below
   }
 #pragma unroll
-  for (int t = 0; t < 6; ++t) {
+  for (int t = 0; t < NACC; ++t) {
     if (t >= ntile) break;
+    if (wide && t < 6) continue;
     const int vc = v0 + 32 * t + (lane & 31);
     if (vc >= ldb + W) continue;
     const bool to_bases = vc < ldb;
@@ -625,6 +635,12 @@ int egc_basis_transform_packed(const float* x, const void* packed, const float* 
   const bool vec4 = (f_in % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
   const int full = NV / XBN;  // column blocks of the full 192 columns; a narrower remainder block follows
   const u16* pk = (const u16*)packed;
+  if (NV == 224 && vec4 && getenv("EGC_GEMM_NO_NT7") == nullptr) {  // 193..224 columns: one 7-tile block, one pass over x
+    dim3 grid((unsigned)mblocks, 1);
+    basis_gemm_bf16x3_kernel<true, 7><<<grid, 256, 0, stream>>>(x, pk, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, KS, 0);
+    EGC_LAUNCH_CHECK("basis_gemm_bf16x3_kernel");
+    return EGC_OK;
+  }
   if (full > 0) {
     dim3 grid((unsigned)mblocks, (unsigned)full);
     if (vec4)
