@@ -208,3 +208,29 @@ def test_arg_extrema_with_appended_self_loops_bit_exact(generic, monkeypatch):
     assert np.array_equal(arg_max.cpu().numpy()[:, :f_g], want_max)
     assert np.array_equal(arg_min.cpu().numpy()[:, :f_g], want_min)
     assert int((want_max == e).sum()) > 100                         # the self-loop case is really exercised
+
+
+@pytest.mark.parametrize("fin,aggrs", [(192, ["symnorm"]), (192, ["sum", "max"]), (128, ["sum", "mean", "max", "symnorm"])])
+def test_input_gradient_through_the_packed_gemm(fin, aggrs):
+    """d x = [d bases | d weightings] @ [bases_weight | comb_weight^T]^T runs on the forward's split-precision GEMM
+    with no weightings block: K = F_g + W = 128 (the fp16x2 kernel, 192 output columns), 160 and 192 (bf16x3)."""
+    import egc_amd
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(fin + len(aggrs))
+    n, H, B = 1500, 8, 4
+    ei = _graph(rng, n, 12000, hub=300, self_loops=20)
+    torch.manual_seed(3)
+    conv = egc_amd.EGConv(fin, fin, aggrs=aggrs, num_heads=H, num_bases=B).to(dev)
+    x = torch.randn(n, fin, device=dev, requires_grad=True)
+    gout = torch.randn(n, fin, device=dev)
+    out = conv(x, torch.from_numpy(ei).to(dev))
+    out.backward(gout)
+    p64 = {k: v.detach().double().cpu().requires_grad_(True) for k, v in conv.named_parameters()}
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    ref = tref.egconv_forward(x64, ei, p64["bases_weight"], p64["comb_weight.weight"], p64["comb_weight.bias"],
+                              p64["bias"], H, B, aggrs)
+    ref.backward(gout.double().cpu())
+    assert _rel(out, ref) <= 1e-5
+    assert _rel(x.grad, x64.grad) <= GTOL
+    for k, v in conv.named_parameters():
+        assert _rel(v.grad, p64[k].grad) <= GTOL, k
