@@ -355,7 +355,12 @@ static WsLayout ws_layout(const egc_layer* L, int64_t n_nodes, int64_t n_edges) 
   PlanCaps c = plan_caps(n_nodes, n_edges);
   WsLayout w;
   w.counter_bytes = align256((size_t)c.cap_long * sizeof(int));
-  w.partial_bytes = align256((size_t)c.cap_chunks * 7 * ldb * sizeof(float));  // 5 aggregates + 2 arg records
+  // One chunk record = up to 7 slots-of-16-bytes (5 aggregates + 2 arg positions) per LANE of the lane group that
+  // publishes it.  The register-resident kernels lay a record out by their lane-group size (16 / 32 / 64 lanes),
+  // which exceeds the row's slot count whenever that is not 16, 32 or 64 -- size the buffer by the larger of the two.
+  const int slots = ldb / 4;
+  const int rec_lanes = slots <= 16 ? 16 : slots <= 32 ? 32 : slots <= 64 ? 64 : slots;
+  w.partial_bytes = align256((size_t)c.cap_chunks * 7 * rec_lanes * 16);
   w.nself_bytes = align256((size_t)c.cap_chunks * sizeof(int));
   w.total = w.counter_bytes + w.partial_bytes + w.nself_bytes;
   return w;

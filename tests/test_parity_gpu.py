@@ -533,3 +533,17 @@ def test_weightings_read_as_a_column_block(hidden, H, B, aggrs, generic, monkeyp
     dense_p = egc_aggregate_combine(g, spec, bases, block.contiguous(), None, post=PostOp(residual=res, relu=True))
     strided_p = egc_aggregate_combine(g, spec, bases, block, None, post=PostOp(residual=res, relu=True))
     assert torch.equal(dense_p, strided_p)
+
+
+@pytest.mark.parametrize("hidden,H,B", [(4, 1, 1), (8, 1, 1), (16, 4, 1), (8, 2, 2), (24, 2, 1), (48, 2, 1), (80, 2, 1)])
+@pytest.mark.parametrize("kind,aggrs", [("lay", ["mean"]), ("lay", ["var", "symadd", "min"]), ("opt", ["std", "max", "sum"])])
+def test_multi_chunk_hub_rows_with_few_slots_on_small_graphs(hidden, H, B, kind, aggrs):
+    """Rows cut into several chunks publish one record per chunk, laid out by the kernels' lane-group size (16 / 32 /
+    64 lanes) -- more than the row's slot count when that is 1, 2, 6, 12 or 20: on a SMALL graph (little spare
+    capacity in the workspace) an undersized record area was overrun (found by the randomised sweep)."""
+    dev = _dev()
+    rng = np.random.default_rng(hidden * 7 + len(aggrs))
+    n = 200
+    ei = _hub_graph(rng, n, 500, [(3, 300), (77, 700)])
+    out, ref = _oracle_case(kind, rng, n, ei, hidden, hidden, H, B, aggrs, dev)
+    assert rel_err(out, ref) <= (1e-4 if any(a in ("std", "var") for a in aggrs) else TOL)
