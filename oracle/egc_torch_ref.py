@@ -27,10 +27,14 @@ def _scatter(src, index, n, reduce):
     red = "amax" if reduce == "max" else "amin"
     idx = index.view(-1, 1).expand(-1, f)
     with torch.no_grad():
-        ext = torch.zeros(n, f, dtype=src.dtype).scatter_reduce(0, idx, src, red, include_self=False)
+        # Ties are decided on the values ROUNDED TO FLOAT32, the precision the reference computes in: in float64 two
+        # sources with identical features can differ in the last bit of x @ W (the BLAS blocks rows differently),
+        # which would break an exact tie at random instead of by edge order.
+        s32 = src.float()
+        ext = torch.zeros(n, f, dtype=s32.dtype).scatter_reduce(0, idx, s32, red, include_self=False)
         e = src.size(0)
         pos = torch.arange(e).view(-1, 1).expand(-1, f)
-        pos = torch.where(src == ext[index], pos, torch.full_like(pos, e))
+        pos = torch.where(s32 == ext[index], pos, torch.full_like(pos, e))
         first = torch.full((n, f), e, dtype=torch.int64).scatter_reduce(0, idx, pos, "amin", include_self=True)
         empty = first >= e
     picked = torch.gather(src, 0, first.clamp(max=max(e - 1, 0))) if e > 0 else torch.zeros(n, f, dtype=src.dtype)
