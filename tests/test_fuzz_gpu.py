@@ -17,9 +17,12 @@ from oracle import egc_torch_ref as tref
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed", [11, 12, 13])
-def test_random_layers_and_graphs_match_the_oracles(seed):
+@pytest.mark.parametrize("seed,generic", [(11, False), (12, False), (13, False), (14, True), (15, True)])
+def test_random_layers_and_graphs_match_the_oracles(seed, generic, monkeypatch):
     import egc_amd
+    if generic:   # the generic forward kernels + separate arg pass, and the run-time forms of the backward kernels
+        monkeypatch.setenv("EGC_FORCE_GENERIC", "1")
+        monkeypatch.setenv("EGC_BWD_GENERIC", "1")
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(seed)
     n_cases = 120
