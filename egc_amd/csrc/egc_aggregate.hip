@@ -350,7 +350,7 @@ static int validate_layer(const egc_layer* L) {
 struct WsLayout {
   size_t counter_bytes, partial_bytes, nself_bytes, total;
 };
-static WsLayout ws_layout(const egc_layer* L, int64_t n_nodes, int64_t n_edges) {
+static WsLayout ws_layout(const egc_layer* L, int64_t n_nodes, int64_t n_edges, int64_t n_chunks = -1) {
   const int ldb = egc_bases_ld(L);
   PlanCaps c = plan_caps(n_nodes, n_edges);
   WsLayout w;
@@ -360,8 +360,10 @@ static WsLayout ws_layout(const egc_layer* L, int64_t n_nodes, int64_t n_edges) 
   // which exceeds the row's slot count whenever that is not 16, 32 or 64 -- size the buffer by the larger of the two.
   const int slots = ldb / 4;
   const int rec_lanes = slots <= 16 ? 16 : slots <= 32 ? 32 : slots <= 64 ? 64 : slots;
-  w.partial_bytes = align256((size_t)c.cap_chunks * 7 * rec_lanes * 16);
-  w.nself_bytes = align256((size_t)c.cap_chunks * sizeof(int));
+  // chunk slots that can be written: the plan's capacity, or the host-known chunk count of this graph
+  const int64_t rec_chunks = (n_chunks >= 0 && n_chunks <= c.cap_chunks) ? n_chunks : c.cap_chunks;
+  w.partial_bytes = align256((size_t)rec_chunks * 7 * rec_lanes * 16);
+  w.nself_bytes = align256((size_t)rec_chunks * sizeof(int));
   w.total = w.counter_bytes + w.partial_bytes + w.nself_bytes;
   return w;
 }
@@ -391,6 +393,11 @@ int32_t egc_bases_ld(const egc_layer* layer) {
   if (layer == nullptr || layer->num_heads <= 0) return -1;
   const int fg = layer->num_bases * layer_basis_stride(layer);
   return (fg + 3) & ~3;
+}
+
+size_t egc_aggregate_workspace_bytes_for(const egc_layer* layer, const egc_graph* graph) {
+  if (graph == nullptr || validate_layer(layer) != EGC_OK || graph->n_nodes < 0 || graph->n_edges < 0) return 0;
+  return ws_layout(layer, graph->n_nodes, graph->n_edges, graph->n_chunks).total;
 }
 
 size_t egc_aggregate_workspace_bytes(const egc_layer* layer, int64_t n_nodes, int64_t n_edges) {
@@ -557,7 +564,7 @@ static int aggregate_combine_impl(const egc_graph* graph, const egc_layer* layer
   const size_t lds_bytes = (size_t)wpb * a.lds_floats_per_wave * sizeof(float);
   if (lds_bytes > 64 * 1024) return EGC_ERR_UNSUPPORTED;
 
-  WsLayout w = ws_layout(layer, n, e);
+  WsLayout w = ws_layout(layer, n, e, graph->n_chunks);
   if (workspace == nullptr || workspace_bytes < w.total) return EGC_ERR_WORKSPACE;
   a.counters = (int*)workspace;
   a.partial = (float*)((char*)workspace + w.counter_bytes);

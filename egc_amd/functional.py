@@ -151,8 +151,8 @@ def egc_aggregate_combine(graph: CSRGraph, spec: LayerSpec, bases: torch.Tensor,
     with _device_guard(dev):
         if out is None:
             out = torch.empty((n, spec.f_out), dtype=torch.float32, device=dev)
-        ws = graph.workspace(lib.egc_aggregate_workspace_bytes(C.byref(spec.c), n, graph.n_edges))
         g = graph.c_struct()
+        ws = graph.workspace(lib.egc_aggregate_workspace_bytes_for(C.byref(spec.c), C.byref(g)))
         bias_p = bias.contiguous().data_ptr() if bias is not None else None
         if ldw != spec.w_cols:
             keep = []
@@ -229,8 +229,8 @@ def _layer_forward_one_call(graph: CSRGraph, spec: LayerSpec, x, packed, bcat, b
         bases = torch.empty((n, spec.ldb), dtype=torch.float32, device=dev)
         weightings = torch.empty((n, spec.w_cols), dtype=torch.float32, device=dev)
         out = torch.empty((n, spec.f_out), dtype=torch.float32, device=dev)
-        ws = graph.workspace(lib.egc_aggregate_workspace_bytes(C.byref(spec.c), n, graph.n_edges))
         g = graph.c_struct()
+        ws = graph.workspace(lib.egc_aggregate_workspace_bytes_for(C.byref(spec.c), C.byref(g)))
         _C.check(lib.egc_layer_forward_packed(
             C.byref(g), C.byref(spec.c), x.data_ptr(), packed.data_ptr(),
             bcat.contiguous().data_ptr() if bcat is not None else None,
@@ -283,8 +283,8 @@ def egc_aggregate_combine_train(graph: CSRGraph, spec: LayerSpec, bases: torch.T
         cnt = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
         arg_max = torch.empty((n, spec.ldb), dtype=torch.int32, device=dev) if _C.AGGR_MAX in codes else None
         arg_min = torch.empty((n, spec.ldb), dtype=torch.int32, device=dev) if _C.AGGR_MIN in codes else None
-        ws = graph.workspace(lib.egc_aggregate_workspace_bytes(C.byref(spec.c), n, graph.n_edges))
         g = graph.c_struct()
+        ws = graph.workspace(lib.egc_aggregate_workspace_bytes_for(C.byref(spec.c), C.byref(g)))
         _C.check(lib.egc_aggregate_combine_train_f32(
             C.byref(g), C.byref(spec.c), bases.data_ptr(), spec.ldb, weightings.data_ptr(),
             bias.contiguous().data_ptr() if bias is not None else None, out.data_ptr(), stats.data_ptr(),

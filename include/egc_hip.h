@@ -183,6 +183,10 @@ int egc_basis_transform_packed(const float* x, const void* packed, const float* 
  * counters of the fused kernel); every call leaves it ready for the next call on the same stream.
  * One workspace must not be shared by calls that may run concurrently on different streams. */
 size_t egc_aggregate_workspace_bytes(const egc_layer* layer, int64_t n_nodes, int64_t n_edges);
+/* The same for one graph: when egc_graph.n_chunks carries the host copy of the plan's chunk count, the records of
+ * chunk slots that do not exist are not allocated (ogbn-mag shape: 0.2 GB instead of 1.5 GB); with n_chunks = -1 it
+ * equals egc_aggregate_workspace_bytes.  A workspace of this size serves exactly this graph. */
+size_t egc_aggregate_workspace_bytes_for(const egc_layer* layer, const egc_graph* graph);
 
 /* Step 2+3 -- fused multi-aggregator neighbourhood reduction + per-node head x basis x aggregator
  * combine (+ weight nonlinearity, + bias).  Replaces, in one pass over the CSR:
