@@ -22,6 +22,8 @@
 // same epilogue.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "egc_aggregate_dev.h"
 
 namespace egc {
@@ -311,6 +313,27 @@ __global__ void __launch_bounds__(256) agg_merge_kernel(AggArgs a) {
 }
 
 // One wavefront per segment: lanes stride over the columns, rows are summed in order (deterministic).
+// out[block, c] = sum over this block's rows of x[r, c] (c < cols, cols a multiple of 4): thread = (16-byte column
+// group, row lane); rows strided over the row lanes, float4 accumulators, LDS reduction over the row lanes.  Bias gradients of the training step (column sums of grad_out and of d weightings).
+__global__ void __launch_bounds__(256) column_sums_kernel(const float* __restrict__ x, int64_t n_rows, int ld, int cols,
+                                                          int rows_per_block, float* __restrict__ out) {
+  __shared__ f4 red[256];
+  const int cg = cols >> 2;                 // 16-byte column groups (<= 256)
+  const int rl = 256 / cg;                  // row lanes
+  const int g = threadIdx.x % cg, lane_r = threadIdx.x / cg;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = min(r0 + rows_per_block, n_rows);
+  f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+  if (lane_r < rl)
+    for (int64_t r = r0 + lane_r; r < r1; r += rl) acc += __builtin_nontemporal_load(reinterpret_cast<const f4*>(x + r * ld) + g);
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (lane_r == 0) {
+    for (int k = 1; k < rl; ++k) acc += red[k * cg + g];
+    reinterpret_cast<f4*>(out + (int64_t)blockIdx.x * cols)[g] = acc;   // this block's partial row
+  }
+}
+
 __global__ void __launch_bounds__(256) segment_mean_kernel(const float* __restrict__ x, const int64_t* __restrict__ seg_ptr,
                                                            int64_t n_segments, int width, float* __restrict__ out) {
   const int lane = threadIdx.x & 63;
@@ -403,6 +426,20 @@ size_t egc_aggregate_workspace_bytes_for(const egc_layer* layer, const egc_graph
 size_t egc_aggregate_workspace_bytes(const egc_layer* layer, int64_t n_nodes, int64_t n_edges) {
   if (validate_layer(layer) != EGC_OK || n_nodes < 0 || n_edges < 0) return 0;
   return ws_layout(layer, n_nodes, n_edges).total;
+}
+
+int egc_column_sums_f32(const float* x, int64_t n_rows, int32_t ld, int32_t cols, float* partials, int32_t n_partials,
+                        egc_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_rows < 0 || cols <= 0 || ld < cols || partials == nullptr || n_partials <= 0) return EGC_ERR_INVALID;
+  if ((cols & 3) != 0 || (ld & 3) != 0 || cols > 1024 || (reinterpret_cast<uintptr_t>(x) & 15) != 0 ||
+      (reinterpret_cast<uintptr_t>(partials) & 15) != 0)
+    return EGC_ERR_UNSUPPORTED;
+  if (n_rows > 0 && x == nullptr) return EGC_ERR_INVALID;
+  const int rows_per_block = (int)std::max<int64_t>(ceil_div(n_rows, (int64_t)n_partials), 1);  // empty blocks write zeros
+  column_sums_kernel<<<(unsigned)n_partials, 256, 0, stream>>>(x, n_rows, ld, cols, rows_per_block, partials);
+  EGC_LAUNCH_CHECK("column_sums_kernel");
+  return EGC_OK;
 }
 
 int egc_segment_mean_f32(const float* x, const int64_t* seg_ptr, int64_t n_segments, int32_t width, float* out,

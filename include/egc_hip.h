@@ -236,6 +236,15 @@ int egc_aggregate_combine_strided_f32(const egc_graph* graph, const egc_layer* l
                                       const float* weightings, int32_t ldw, const float* bias, const egc_post* post,
                                       float* out, void* workspace, size_t workspace_bytes, egc_stream_t stream);
 
+/* Column sums of a row-major array with row stride ld (floats), as n_partials partial rows:
+ * partials[p, c] = sum of x[r, c] over the p-th block of rows, c < cols; the caller adds the few partial rows up.
+ * The bias gradients of a training step (grad_out summed over the nodes for `bias`, d_weightings for the
+ * combination Linear's bias -- what autograd's sum-to-size does behind layers.py:137-138 /
+ * optimized_layers.py:182,207-208).  cols and ld multiples of 4, cols <= 1024, x and partials 16-byte aligned
+ * (EGC_ERR_UNSUPPORTED otherwise); deterministic (no atomics). */
+int egc_column_sums_f32(const float* x, int64_t n_rows, int32_t ld, int32_t cols, float* partials, int32_t n_partials,
+                        egc_stream_t stream);
+
 /* Mean of the rows of x [n_rows, width] over consecutive segments: out[g] = mean(x[seg_ptr[g] : seg_ptr[g+1]])
  * (0 for an empty segment; x may be NULL when every segment is empty).  global_mean_pool over a PyG batch
  * vector, whose graphs are contiguous
