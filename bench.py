@@ -5,16 +5,20 @@ aggregators sum+mean+max+symnorm, fp32).
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one full layer forward through the C ABI (fp32-MFMA basis GEMM + fused aggregate/combine)
-with every input already resident in HBM and the CSR pre-built (static graph, the reference's
-``cached=True``).  Rank 0 prints ONE JSON line.  For N > 1 the driver launches this file under
-torch.distributed.run (one rank per GPU, RCCL).
+A "step" is one full layer forward through the C ABI (basis GEMM + fused aggregate/combine) with every input
+already resident in HBM and the CSR pre-built (static graph, the reference's ``cached=True``).  Rank 0 prints
+ONE JSON line.  For N > 1 the driver launches this file under torch.distributed.run (one rank per GPU, RCCL)
+and the workload is BASELINE config 5: ONE ogbn-mag-shaped graph, vertex-partitioned over the ranks (strong
+scaling; ``--workload arxiv-weak`` keeps round 1's weak-scaling synthetic).
 
 Extra objects on the JSON line:
-  roofline     -- the dominant kernel (fused aggregate+combine launch): algorithmic bytes per launch
-                  (SURVEY.md 8d model, every term printed on stderr) / HIP-event time of that launch.
-  cpu_baseline -- the oracle's multi-threaded CPU port of the reference op sequence
-                  (oracle/egc_cpu_port.py), timed on this host's cores on the same workload.
+  roofline      -- the dominant kernel (fused aggregate+combine launch): SURVEY.md 8(d) algorithmic bytes of
+                   that launch (gather + col + rowptr + deg + out; `weightings` are NOT algorithmic) / its
+                   HIP-event time, against the 8 TB/s HBM peak.
+  cpu_baseline  -- the oracle's multi-threaded CPU port of the reference op sequence
+                   (oracle/egc_cpu_port.py), timed on this host's cores on the same workload.
+  other_configs -- measured in this run: configs 3 / 4 (per-batch CSR build reported separately), config 5
+                   (homogeneous ogbn-mag shape) and the training step of config 2.
 """
 from __future__ import annotations
 
@@ -37,6 +41,7 @@ HBM_COPY_CEILING_GBS = 6290.0  # measured float4-copy ceiling of the same guide 
 AGGRS = ["sum", "mean", "max", "symnorm"]
 F_IN = F_OUT = 128
 HEADS, BASES = 8, 4
+METRIC = "EGC-M layer fwd edges/sec on ogbn-arxiv; achieved HBM GB/s vs roofline"
 
 
 def log(*a):
@@ -61,10 +66,11 @@ def dist_setup(n_gpus):
     return world, rank, local
 
 
-def time_region(fn, iters, sync):
-    """HIP-event timing of `iters` back-to-back calls on the current stream; returns ms per call."""
+def time_region(fn, iters, sync=None):
+    """HIP-event timing of `iters` back-to-back calls on the current stream (the stream the library launches
+    on: torch's current stream is what is handed to the C ABI); returns ms per call."""
     start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    sync()
+    (sync or torch.cuda.synchronize)()
     start.record()
     for _ in range(iters):
         fn()
@@ -73,7 +79,7 @@ def time_region(fn, iters, sync):
     return start.elapsed_time(end) / iters
 
 
-def cpu_baseline(ei, n, x, conv_state, runs=3):
+def cpu_baseline(ei, n, x, conv_state, runs=5):
     """Time the CPU port (oracle) on the same workload: full config-2 layer forward, graph prep cached.
     torch's scatter kernels do not scale to hundreds of threads, so a few thread counts are tried and the
     best one is reported (with the number of threads it used)."""
@@ -93,10 +99,94 @@ def cpu_baseline(ei, n, x, conv_state, runs=3):
             out, _ = egconv_forward_cpu(*args, cached=cached)
             times.append(time.perf_counter() - t0)
         med = statistics.median(times)
-        log(f"  cpu port, {threads:3d} threads: {med * 1e3:8.1f} ms/forward")
+        log(f"  cpu port, {threads:3d} threads: {med * 1e3:8.1f} ms/forward (median of {runs})")
         if best is None or med < best[0]:
             best = (med, threads)
     return out, best[0], best[1], int(cached[0].size(1))
+
+
+def roofline_terms(n, e_eff, f_in, f_g, f_out, w_cols, symnorm):
+    """SURVEY.md 8(d) bytes.  `aggregate_launch` = what the fused aggregate+combine launch must move by that
+    model (weightings are "counted as fused (not materialised)"); `layer` = the survey's whole-layer figure."""
+    from egc_amd.workloads import algorithmic_bytes
+    t = algorithmic_bytes(n, e_eff, f_in, f_g, f_out, w_cols, symnorm=symnorm)
+    t["aggregate_launch"] = t["gather"] + t["col"] + t["rowptr"] + t["deg"] + t["out"]
+    return t
+
+
+# -------------------------------------------------------------------------------------------------
+# other configs (N = 1): measured in the same run, module-level calls (what a caller of the layer pays)
+# -------------------------------------------------------------------------------------------------
+def measure_layer_config(name, ei_cpu, n, conv, f_in, dev, per_batch_csr, iters=30):
+    import egc_amd
+    ei = ei_cpu.to(dev)
+    x = torch.randn(n, f_in, device=dev)
+    conv = conv.to(dev).eval()
+    spec = conv._spec_coo
+    e_in = int(ei.size(1))
+    e_eff = e_in + n   # EGConv convention (optimized_layers.py:127-175): every aggregator traverses one self loop per node
+    rec = {"workload": name, "n_nodes": n, "e_in": e_in, "e_eff": e_eff}
+    with torch.no_grad():
+        if per_batch_csr:
+            for _ in range(3):
+                egc_amd.CSRGraph.from_edge_index(ei, n)
+            rec["csr_build_ms"] = time_region(lambda: egc_amd.CSRGraph.from_edge_index(ei, n), 10)
+            g = egc_amd.CSRGraph.from_edge_index(ei, n)     # a per-batch graph: nothing is read back to the host
+        else:
+            g = egc_amd.CSRGraph.from_edge_index(ei, n).trim_launches()   # static graph (cached=True)
+        for _ in range(5):
+            conv(x, g)
+        rec["layer_ms"] = time_region(lambda: conv(x, g), iters)
+    has_sym = "symnorm" in conv.aggregators
+    t = roofline_terms(n, e_eff, f_in, spec.f_g, conv.out_channels, spec.w_cols, has_sym)
+    rec["algorithmic_bytes"] = t["layer"]
+    rec["edges_per_s"] = e_eff / (rec["layer_ms"] * 1e-3)
+    rec["layer_frac"] = t["layer"] / (rec["layer_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+    if per_batch_csr:
+        tot = rec["layer_ms"] + rec["csr_build_ms"]
+        rec["edges_per_s_incl_csr"] = e_eff / (tot * 1e-3)
+        rec["frac_incl_csr"] = t["layer"] / (tot * 1e-3) / 1e9 / HBM_PEAK_GBS
+    log(f"  {name}: " + ", ".join(f"{k}={v:.4g}" if isinstance(v, float) else f"{k}={v}" for k, v in rec.items()
+                                  if k != "workload"))
+    del g, x, ei
+    torch.cuda.empty_cache()
+    return rec
+
+
+def other_configs(dev, seed):
+    import egc_amd
+    from egc_amd import workloads as wl
+    out = {}
+    torch.manual_seed(seed)
+    ns = lambda: egc_amd.EGConv(F_IN, F_OUT, aggrs=AGGRS, num_heads=HEADS, num_bases=BASES)   # north-star layer
+    ei, n, _ = wl.molecule_batch(2048, seed=seed)
+    out["config3_molhiv_b2048"] = measure_layer_config(
+        "ogbg-molhiv-shaped batch of 2048 graphs, EGC-M d=128 H=8 B=4 sum+mean+max+symnorm", ei, n, ns(), F_IN, dev, True)
+    ei, n, _ = wl.knn_superpixel_batch(2048, seed=seed)
+    out["config4_cifar_b2048"] = measure_layer_config(
+        "CIFAR10-superpixel-shaped batch of 2048 8-NN graphs, EGC-M d=128 H=8 B=4 sum+mean+max+symnorm", ei, n, ns(),
+        F_IN, dev, True)
+    ei, n = wl.mag_like(seed=seed)
+    out["config5_mag_homogeneous_1gpu"] = measure_layer_config(
+        "ogbn-mag-shaped homogeneous graph (mag/configs.py:73-88), EGConv 352->352 H=8 B=4 symnorm (mag/models.py:23-53)",
+        ei, n, egc_amd.EGConv(352, 352, aggrs=["symnorm"], num_heads=8, num_bases=4), 352, dev, False, iters=10)
+    # training step of config 2: forward + backward of one north-star layer through autograd
+    ei, n = wl.arxiv_like(seed=seed)
+    ei = ei.to(dev)
+    g = egc_amd.CSRGraph.from_edge_index(ei, n).trim_launches()
+    layer = ns().to(dev)
+    x = torch.randn(n, F_IN, device=dev, requires_grad=True)
+    go = torch.randn(n, F_OUT, device=dev)
+
+    def fwd_bwd():
+        layer(x, g).backward(go)
+    for _ in range(3):
+        fwd_bwd()
+    ms = time_region(fwd_bwd, 10)
+    out["config2_training_step"] = {"workload": "config 2, forward + backward of one EGConv layer through autograd",
+                                    "step_ms": ms, "edges_per_s": (int(ei.size(1)) + n) / (ms * 1e-3)}
+    log(f"  training step (config 2): {ms:.4f} ms")
+    return out
 
 
 def main():
@@ -105,6 +195,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--workload", default=None, choices=[None, "arxiv", "mag", "arxiv-weak"],
+                    help="default: arxiv (config 2) on one GPU, mag (config 5, strong scaling) on several")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
 
@@ -112,20 +205,17 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    workload = args.workload or ("arxiv" if world == 1 else "mag")
+    if workload != "arxiv" or world > 1:
+        import bench_multi  # the partitioned workloads live in their own file
+        return bench_multi.run(args, world, rank, local, workload)
 
     import egc_amd
     from egc_amd import _C
-    from egc_amd.functional import LayerSpec
-    from egc_amd.workloads import algorithmic_bytes, arxiv_like
+    from egc_amd.functional import LayerSpec, gemm_exact, pack_weights
+    from egc_amd.workloads import arxiv_like
 
     lib = _C.load()
-
-    # ---- workload -------------------------------------------------------------------------------
-    # N = 1: BASELINE config 2.  N > 1 (weak scaling): every rank owns one arxiv-sized vertex range of a
-    # graph N times larger (5 % cross-partition edges); the halo rows of `bases` travel by one RCCL
-    # all-to-all-v inside the timed step (egc_amd/partition.py).
-    from egc_amd.functional import egc_layer_forward, pack_weights
-    from egc_amd.workloads import partitioned_arxiv_like
     torch.manual_seed(args.seed)
     conv = egc_amd.EGConv(F_IN, F_OUT, aggrs=AGGRS, num_heads=HEADS, num_bases=BASES, cached=True)
     with torch.no_grad():
@@ -137,22 +227,10 @@ def main():
     planes = pack_weights(spec, wcat)  # split-precision weight planes, rebuilt only when parameters change
     bias = conv.bias.detach()
     ldb = spec.ldb
-    halo_stats = None
-    if world == 1:
-        ei_cpu, n = arxiv_like(seed=args.seed)
-        ei = ei_cpu.to(dev)
-        graph = egc_amd.CSRGraph.from_edge_index(ei, n).trim_launches()  # static graph (the reference's cached=True)
-    else:
-        from egc_amd import partition
-        ei_cpu, n_global = partitioned_arxiv_like(rank, world, seed=args.seed)
-        # interior rows first: they are aggregated while the halo rows of `bases` are in flight
-        overlap = os.environ.get("EGC_BENCH_NO_OVERLAP", "0") in ("", "0")
-        ei_local, plan = partition.build_distributed(ei_cpu.to(dev), n_global, interior_first=overlap)
-        graph = egc_amd.CSRGraph.from_partition(ei_local, plan, global_max_index=n_global - 1).trim_launches()
-        n = plan.n_local
-        ei = ei_local
-        halo_stats = plan.stats
-    torch.manual_seed(args.seed + 1 + rank)
+    ei_cpu, n = arxiv_like(seed=args.seed)
+    ei = ei_cpu.to(dev)
+    graph = egc_amd.CSRGraph.from_edge_index(ei, n).trim_launches()  # static graph (the reference's cached=True)
+    torch.manual_seed(args.seed + 1)
     x_cpu = torch.randn(n, F_IN)
     x = x_cpu.to(dev)
     e_in = int(ei.size(1))
@@ -170,55 +248,38 @@ def main():
                                                 spec.w_cols, bases.data_ptr(), ldb, weightings.data_ptr(), stream),
                  "egc_basis_transform_packed")
 
+    def gemm_exact_only():   # the plain fp32-MFMA GEMM (EGC_GEMM_EXACT=1), for the side field
+        _C.check(lib.egc_basis_transform_f32(x.data_ptr(), wcat.data_ptr(), bcat.data_ptr(), n, F_IN, spec.f_g,
+                                             spec.w_cols, bases.data_ptr(), ldb, weightings.data_ptr(), stream),
+                 "egc_basis_transform_f32")
+
     def agg_only():
         _C.check(lib.egc_aggregate_combine_f32(C.byref(g), C.byref(spec.c), bases.data_ptr(), ldb,
                                                weightings.data_ptr(), bias.data_ptr(), out.data_ptr(), None, None,
                                                ws.data_ptr(), ws.numel(), stream), "egc_aggregate_combine_f32")
 
-    if world == 1:
-        def step():  # one full layer forward through the C ABI
-            _C.check(lib.egc_layer_forward_packed(C.byref(g), C.byref(spec.c), x.data_ptr(), planes.data_ptr(),
-                                                  bcat.data_ptr(), bias.data_ptr(), bases.data_ptr(), ldb,
-                                                  weightings.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(),
-                                                  stream), "egc_layer_forward_packed")
-    else:
-        def agg_rows(lo, hi):
-            _C.check(lib.egc_aggregate_combine_rows_f32(C.byref(g), C.byref(spec.c), bases.data_ptr(), ldb,
-                                                        weightings.data_ptr(), bias.data_ptr(), out.data_ptr(), lo, hi,
-                                                        ws.data_ptr(), ws.numel(), stream),
-                     "egc_aggregate_combine_rows_f32")
-
-        n_int = graph.halo.n_interior
-
-        def step():  # GEMM on owned rows -> halo all-to-all-v (RCCL) || interior rows -> boundary rows
-            gemm_only()
-            if n_int is None:
-                graph.halo.exchange(bases)
-                agg_only()
-            else:
-                handle = graph.halo.exchange_start(bases)
-                agg_rows(0, n_int)
-                graph.halo.exchange_finish(handle)
-                agg_rows(n_int, n)
+    def step():  # one full layer forward through the C ABI
+        _C.check(lib.egc_layer_forward_packed(C.byref(g), C.byref(spec.c), x.data_ptr(), planes.data_ptr(),
+                                              bcat.data_ptr(), bias.data_ptr(), bases.data_ptr(), ldb,
+                                              weightings.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                              stream), "egc_layer_forward_packed")
 
     def sync_all():
         torch.cuda.synchronize(dev)
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-        torch.cuda.synchronize(dev)
 
-    # ---- per-kernel HIP-event timing on the launch stream (rank 0 reports).  Done BEFORE the contract's
-    # warm-up + timed region, so that region runs at the clocks the chip holds in steady state rather than
-    # during the first milliseconds after idle (the whole region is ~30 ms at the default step count).
+    # ---- per-kernel HIP-event timing on the launch stream.  Done BEFORE the contract's warm-up + timed region,
+    # so that region runs at the clocks the chip holds in steady state rather than during the first
+    # milliseconds after idle (the whole region is ~30 ms at the default step count).
     for _ in range(100):  # untimed: bring the chip out of idle clocks before anything is measured
         step()
     reps = max(50, min(args.steps, 200))
-    agg_ms = time_region(agg_only, reps, lambda: torch.cuda.synchronize(dev))
-    gemm_ms = time_region(gemm_only, reps, lambda: torch.cuda.synchronize(dev))
-    step_ms_events = time_region(step, reps, lambda: torch.cuda.synchronize(dev))
+    agg_ms = time_region(agg_only, reps)
+    gemm_ms = time_region(gemm_only, reps)
+    gemm_exact_ms = time_region(gemm_exact_only, 20)
+    gemm_only()  # leave the split-precision intermediates in place
+    step_ms_events = time_region(step, reps)
 
-    # ---- warm-up, then EXACTLY --steps timed steps bracketed by barrier + synchronize ----
+    # ---- warm-up, then EXACTLY --steps timed steps bracketed by synchronize ----
     for _ in range(args.warmup):
         step()
     sync_all()
@@ -227,73 +288,67 @@ def main():
         step()
     sync_all()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        tot = torch.tensor([float(e_eff)], device=dev, dtype=torch.float64)
-        dist.all_reduce(tot)
-        total_e_eff = float(tot.item())
-    else:
-        total_e_eff = float(e_eff)
     ms_per_step = elapsed / args.steps * 1e3
-    value = total_e_eff / (elapsed / args.steps)
+    value = float(e_eff) / (elapsed / args.steps)
 
-    terms = algorithmic_bytes(n, e_eff, F_IN, spec.f_g, F_OUT, spec.w_cols, symnorm=True)
-    agg_gbs = terms["aggregate_kernel"] / (agg_ms * 1e-3) / 1e9
-    traffic = None
+    terms = roofline_terms(n, e_eff, F_IN, spec.f_g, F_OUT, spec.w_cols, symnorm=True)
+    agg_bytes = terms["aggregate_launch"]
+    agg_gbs = agg_bytes / (agg_ms * 1e-3) / 1e9
+    traffic, traffic_src = None, None
     pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_file):
         try:
-            traffic = json.load(open(pmc_file)).get("aggregate_kernel_hbm_bytes_per_launch")
+            pj = json.load(open(pmc_file))
+            traffic = pj.get("aggregate_kernel_hbm_bytes_per_launch")
+            traffic_src = "profiles/pmc_traffic.json (" + pj.get("collected", "rocprofv3 --pmc passes, not this run") + ")"
         except Exception:
             traffic = None
 
     result = {
-        "metric": "EGC-M layer fwd edges/sec on ogbn-arxiv; achieved HBM GB/s vs roofline",
-        "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "metric": METRIC,
+        "value": value, "unit": "edges/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "ogbn-arxiv-shaped full graph (per GPU at N>1: one arxiv-sized vertex range of an N-times "
-                               "larger graph, 5% cross-partition edges): N=169343, heavy-tailed symmetrised "
+        "dtype": "f32", "gemm": "exact fp32 MFMA" if gemm_exact() else
+                 "fp16x2-split (3 x v_mfma_f32_32x32x16_f16 per k-step, fp32 accumulate, 22-bit operands)",
+        "data": "synthetic",
+        "config": {"workload": "ogbn-arxiv-shaped full graph: N=169343, heavy-tailed symmetrised "
                                f"E_in={e_in} (+N self loops => E_eff={e_eff}), EGC-M d=128 H=8 B=4 "
                                "aggrs=sum+mean+max+symnorm, CSR cached",
-                   "n_nodes": n, "e_in": e_in, "e_eff": e_eff, "layer": "EGConv",
-                   "parallelism": "single GPU" if world == 1 else f"1-D vertex partition x{world}, halo all-to-all-v",
-                   "halo": halo_stats},
-        "roofline": {"bound": "hbm", "kernel": "egc::agg_fast_kernel (fused aggregate+combine, one launch)", "achieved": agg_gbs,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": agg_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                   "n_nodes": n, "e_in": e_in, "e_eff": e_eff, "layer": "EGConv", "parallelism": "single GPU"},
+        "roofline": {"bound": "hbm", "kernel": "egc::agg_fast_kernel (fused aggregate+combine, one launch)",
+                     "achieved": agg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": agg_gbs / HBM_PEAK_GBS,
+                     "traffic": traffic, "traffic_source": traffic_src,
+                     "algorithmic_bytes_per_launch": agg_bytes, "launch_ms": agg_ms,
                      "frac_vs_measured_copy_ceiling": agg_gbs / HBM_COPY_CEILING_GBS,
-                     "algorithmic_bytes_per_launch": terms["aggregate_kernel"], "launch_ms": agg_ms,
-                     "note": "achieved = algorithmic bytes / launch time; the 43 MB gather table is L2 / Infinity-Cache "
-                             "resident, so the HBM-side bytes (`traffic`, PMC) are fewer and frac can exceed 1"},
-        "kernels_ms": {"basis_gemm": gemm_ms, "aggregate_combine": agg_ms, "layer_forward": step_ms_events},
+                     "frac_incl_materialised_weightings": (agg_bytes + terms["weightings"]) / (agg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "note": "SURVEY.md 8(d): gather + col + rowptr + deg + out of the launch; the materialised "
+                             "weightings it also reads are waste, not algorithmic bytes"},
+        "kernels_ms": {"basis_gemm": gemm_ms, "aggregate_combine": agg_ms, "layer_forward": step_ms_events,
+                       "basis_gemm_exact_fp32": gemm_exact_ms, "layer_forward_gemm_exact_fp32": gemm_exact_ms + agg_ms},
         "layer_algorithmic_bytes": terms["layer"],
         "layer_achieved_gbs": terms["layer"] / (step_ms_events * 1e-3) / 1e9,
         "layer_frac": terms["layer"] / (step_ms_events * 1e-3) / 1e9 / HBM_PEAK_GBS,
     }
 
-    if rank == 0:
-        log("algorithmic bytes (SURVEY.md 8d), per forward:")
-        for k, v in terms.items():
-            log(f"  {k:18s} {v / 1e6:10.2f} MB")
-        log(f"kernel ms: gemm {gemm_ms:.4f}  aggregate+combine {agg_ms:.4f}  layer {step_ms_events:.4f}")
-        if not args.no_cpu_baseline and world == 1:
-            ref_out, cpu_s, threads, e_cached = cpu_baseline(ei_cpu, n, x_cpu, state_cpu)
-            err = float((out.cpu() - ref_out).abs().max() / max(1.0, float(ref_out.abs().max())))
-            log(f"cpu port: {cpu_s * 1e3:.1f} ms/forward on {threads} threads; HIP vs CPU port rel err {err:.2e}")
-            result["cpu_baseline"] = {
-                "value": e_eff / cpu_s, "unit": "edges/s", "cores": threads, "kind": "port",
-                "sample": f"full config-2 layer forward (E_eff={e_cached}), gcn_norm cached; best of 8/16/32/64 "
-                          f"torch threads, median of 3 runs each after a warm-up; {cpu_s * 1e3:.1f} ms per forward "
-                          f"on a {os.cpu_count()}-core host",
-                "hip_vs_port_rel_err": err}
-        print(json.dumps(result), flush=True)
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
+    log("algorithmic bytes (SURVEY.md 8d), per forward:")
+    for k, v in terms.items():
+        log(f"  {k:18s} {v / 1e6:10.2f} MB")
+    log(f"kernel ms: gemm {gemm_ms:.4f} (exact fp32: {gemm_exact_ms:.4f})  aggregate+combine {agg_ms:.4f}  layer {step_ms_events:.4f}")
+    out_main = out.clone()
+    if not args.no_other_configs:
+        log("other configs:")
+        result["other_configs"] = other_configs(dev, args.seed)
+    if not args.no_cpu_baseline:
+        ref_out, cpu_s, threads, e_cached = cpu_baseline(ei_cpu, n, x_cpu, state_cpu)
+        err = float((out_main.cpu() - ref_out).abs().max() / max(1.0, float(ref_out.abs().max())))
+        log(f"cpu port: {cpu_s * 1e3:.1f} ms/forward on {threads} threads; HIP vs CPU port rel err {err:.2e}")
+        result["cpu_baseline"] = {
+            "value": e_eff / cpu_s, "unit": "edges/s", "cores": threads, "kind": "port",
+            "sample": f"full config-2 layer forward (E_eff={e_cached}), gcn_norm cached; best of 8/16/32/64 "
+                      f"torch threads, median of 5 runs each after a warm-up; {cpu_s * 1e3:.1f} ms per forward "
+                      f"on a {os.cpu_count()}-core host",
+            "hip_vs_port_rel_err": err}
+    print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

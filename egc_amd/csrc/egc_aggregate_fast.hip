@@ -43,8 +43,14 @@ constexpr int AMAX = 4;     // aggregators supported by the register-resident co
 // `out` is written once and read by a LATER kernel: non-temporal stores (aux bit 1) keep the rows from piling up
 // as dirty lines in the XCDs' L2s, whose write-back at the end of the kernel otherwise costs ~3 us per launch.
 constexpr int OUT_NT = 2;
-constexpr int FU = 4;       // neighbour-row loads in flight per lane group
+#ifndef EGC_AGG_FU
+#define EGC_AGG_FU 4
+#endif
+constexpr int FU = EGC_AGG_FU;  // neighbour-row loads in flight per lane group
 constexpr int HPB_MAX = 4;  // ceil(H / B) supported
+#ifndef EGC_AGG_WAVES
+#define EGC_AGG_WAVES 6   // wavefronts per SIMD the inference variants are register-limited to
+#endif
 
 // Which optional running aggregates a layer needs (template mask: unused ones cost no registers).
 constexpr int NEED_SQ = 1;   // sum of squares  (var, std)
@@ -493,7 +499,7 @@ __device__ inline void load_row_operands(const AggArgs& a, const FastRsrc& R, in
 template <int LPR_LOG2, int HPB, int NEED, class C>
 // Inference variants (NEED == 0) fit 80 VGPRs without spilling when asked to, which buys the sixth wavefront per
 // SIMD; the variants carrying more running aggregates are left to the register allocator.
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NEED == 0 ? 6 : ((NEED & NEED_ARG) && (NEED & NEED_SQ)) ? 2 : 4)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NEED == 0 ? EGC_AGG_WAVES : ((NEED & NEED_ARG) && (NEED & NEED_SQ)) ? 2 : 4)))
 agg_fast_kernel(AggArgs a) {
   constexpr int LPR = 1 << LPR_LOG2, G = 64 / LPR;
   extern __shared__ float smem[];
@@ -820,7 +826,8 @@ int launch_fast(AggArgs a, int64_t n_nodes, const PlanCaps& caps, hipStream_t st
   a.w_lds_stride = (a.W + 3) & ~3;
   a.bias_lds_floats = (a.H * a.Ls + 3) & ~3;  // >= F_out: the bias strip follows the (padded) head layout
   a.lds_floats_per_wave = (a.post_scale != nullptr ? 2 : 1) * a.bias_lds_floats + G * a.w_lds_stride;
-  const size_t lds = (size_t)4 * a.lds_floats_per_wave * sizeof(float);
+  size_t lds = (size_t)4 * a.lds_floats_per_wave * sizeof(float);
+  if (const char* e = getenv("EGC_AGG_LDS_PAD")) lds += (size_t)atoi(e);  // experiments: caps the blocks per CU
   if (lds > 64 * 1024) return EGC_ERR_UNSUPPORTED;
   const int64_t row_blocks = ceil_div((int64_t)a.row_end - a.row_begin, (int64_t)4 * a.rows_per_wave * G);
   const unsigned grid = (unsigned)(a.chunk_blocks + row_blocks);

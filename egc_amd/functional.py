@@ -275,6 +275,8 @@ def egc_aggregate_combine_train(graph: CSRGraph, spec: LayerSpec, bases: torch.T
     n = graph.n_nodes
     _check_f32(bases, "bases", (graph.n_src_rows, spec.ldb))
     _check_f32(weightings, "weightings", (n, spec.w_cols))
+    # the training kernels take dense rows (strides ldb / W): a column-block view would be read at the wrong rows
+    bases, weightings = bases.contiguous(), weightings.contiguous()
     dev = bases.device
     codes = [spec.c.aggrs[t] for t in range(spec.c.num_aggrs)]
     with _device_guard(dev):
@@ -297,10 +299,15 @@ def egc_aggregate_combine_train(graph: CSRGraph, spec: LayerSpec, bases: torch.T
 def egc_aggregate_combine_backward(graph: CSRGraph, spec: LayerSpec, bases, weightings, grad_out, saved,
                                    joint: bool = False):
     """(d_bases [n_src_rows, ldb], d_weightings [N, W]) through egc_aggregate_combine_backward_f32;
-    ``saved`` comes from egc_aggregate_combine_train.  ``joint`` (square graphs): both are column blocks of
-    one [N, ldb + W] array, returned third -- the left operand of the dense gradient GEMMs, no concatenation."""
+    ``saved`` comes from egc_aggregate_combine_train.  Always returns (d_bases, d_weightings, d_cat): with
+    ``joint`` (square graphs) both are column blocks of one [N, ldb + W] array ``d_cat`` -- the left operand of
+    the dense gradient GEMMs, no concatenation -- otherwise ``d_cat`` is None."""
     lib = _C.load()
     n = graph.n_nodes
+    _check_f32(bases, "bases", (graph.n_src_rows, spec.ldb))
+    _check_f32(weightings, "weightings", (n, spec.w_cols))
+    _check_f32(grad_out, "grad_out", (n, spec.f_out))
+    bases, weightings = bases.contiguous(), weightings.contiguous()  # dense rows, as in the training forward
     dev = bases.device
     stats, cnt, arg_max, arg_min = saved
     tg = graph.transposed()
@@ -322,7 +329,7 @@ def egc_aggregate_combine_backward(graph: CSRGraph, spec: LayerSpec, bases, weig
             arg_max.data_ptr() if arg_max is not None else None, arg_min.data_ptr() if arg_min is not None else None,
             d_bases.data_ptr(), d_bases.stride(0), d_w.data_ptr(), d_w.stride(0), ws.data_ptr(), ws.numel(),
             _stream_ptr(dev)), "egc_aggregate_combine_backward_f32")
-    return (d_bases, d_w, d_cat) if joint else (d_bases, d_w)
+    return d_bases, d_w, d_cat   # d_cat is None unless the joint layout was asked for and applies
 
 
 def _xt_matmul(x: torch.Tensor, d: torch.Tensor) -> torch.Tensor:
@@ -433,7 +440,7 @@ class _AggregateCombineFunction(torch.autograd.Function):
     def backward(ctx, grad_out):
         bases, weightings = ctx.saved_tensors
         grad_out = grad_out.contiguous()
-        d_bases, d_w = egc_aggregate_combine_backward(ctx.graph, ctx.spec, bases, weightings, grad_out, ctx.saved)
+        d_bases, d_w, _ = egc_aggregate_combine_backward(ctx.graph, ctx.spec, bases, weightings, grad_out, ctx.saved)
         dbias = _column_sums(grad_out) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return d_bases, d_w, dbias, None, None
 

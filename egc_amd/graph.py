@@ -109,6 +109,11 @@ class CSRGraph:
         g = cls.from_edge_index(edge_index_local, plan.n_local, plan.n_local + plan.n_halo)
         g.halo = plan
         if global_max_index is not None:  # add_remaining_self_loops infers N from the GLOBAL largest index
+            if plan.order is not None and int(global_max_index) < plan.n_global - 1:
+                # `row <= max_index` names the vertices with a global id <= the largest index only while local row i
+                # is global vertex lo + i; interior-first renumbering breaks that for layers with loops_all_nodes = 0
+                raise RuntimeError("egc_amd: interior_first partitions need global_max_index == n_global - 1 "
+                                   "(trailing isolated vertices: build the partition with interior_first=False)")
             g.max_index.fill_(max(-1, min(int(global_max_index) - plan.lo, plan.n_local - 1)))
         if exchange_dis and plan.n_halo >= 0 and plan.world > 1:
             plan.exchange(g.dis_raw)

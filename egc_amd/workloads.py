@@ -8,15 +8,25 @@ ARXIV_NODES = 169_343
 ARXIV_DIRECTED_EDGES = 1_166_243
 
 
-def heavy_tailed_graph(n_nodes: int, n_directed: int, seed: int = 0) -> torch.Tensor:
+def heavy_tailed_graph(n_nodes: int, n_directed: int, seed: int = 0, communities: int = 0, p_in: float = 0.0) -> torch.Tensor:
     """Directed pairs with a heavy-tailed destination distribution (dst = floor(N u^3)), uniform
     sources; then symmetrised, coalesced, self-pairs removed -- the preprocessing the reference
     applies to ogbn-arxiv (``to_undirected``, experiments/arxiv/configs.py:100).  Returns int64 [2, E]
-    sorted by (source, destination)."""
+    sorted by (source, destination).
+
+    ``communities`` > 0 plants community structure the way citation graphs have it (papers cite inside their
+    field): vertex v belongs to community v mod K -- interleaved, so that a contiguous split of the ids sees
+    none of it -- and a fraction ``p_in`` of the pairs draws its source from the destination's community."""
     g = torch.Generator().manual_seed(seed)
     u = torch.rand(n_directed, generator=g, dtype=torch.float64)
     dst = (n_nodes * u ** 3).long().clamp_(max=n_nodes - 1)
     src = torch.randint(0, n_nodes, (n_directed,), generator=g)
+    if communities > 0 and p_in > 0:
+        inside = torch.rand(n_directed, generator=g) < p_in
+        k = communities
+        per = (n_nodes - 1 - dst % k) // k + 1                      # members of dst's community
+        pick = (torch.rand(n_directed, generator=g, dtype=torch.float64) * per).long()
+        src = torch.where(inside, dst % k + k * pick, src)
     a = torch.cat([src, dst])
     b = torch.cat([dst, src])
     keep = a != b
@@ -129,9 +139,10 @@ MAG_NODES = 736_389            # ogbn-mag paper nodes (what `main.py egc mag` tr
 MAG_DIRECTED_EDGES = 5_416_271
 
 
-def mag_like(seed: int = 0) -> tuple[torch.Tensor, int]:
-    """BASELINE config 5, homogeneous form: N = 736,389, ~10.8 M symmetrised heavy-tailed edges."""
-    return heavy_tailed_graph(MAG_NODES, MAG_DIRECTED_EDGES, seed), MAG_NODES
+def mag_like(seed: int = 0, communities: int = 0, p_in: float = 0.0) -> tuple[torch.Tensor, int]:
+    """BASELINE config 5, homogeneous form: N = 736,389, ~10.8 M symmetrised heavy-tailed edges (SURVEY.md 8d);
+    ``communities`` / ``p_in``: the variant with planted community structure (see heavy_tailed_graph)."""
+    return heavy_tailed_graph(MAG_NODES, MAG_DIRECTED_EDGES, seed, communities, p_in), MAG_NODES
 
 
 RMAG_NODES = {"paper": 736_389, "author": 1_134_649, "institution": 8_740, "field_of_study": 59_965}

@@ -162,3 +162,57 @@ def test_config5_heterogeneous_full_size_sampled_rows():
                 ref = ref.reshape(-1)
                 worst = max(worst, float((out[t][r].double() - ref).abs().max() / ref.abs().max().clamp(min=1)))
     assert worst <= TOL, worst
+
+
+@pytest.mark.parametrize("world", [8])
+def test_config5_partitioned_at_mag_size_equals_single_gpu(world):
+    """BASELINE config 5 as it is benchmarked at --gpus N: ONE ogbn-mag-sized graph, renumbered by
+    partition.locality_partition, split into cost-balanced contiguous ranges, interior rows first; every rank's
+    pieces run one after the other on this GPU (the all-to-all-v is simulated; the collective itself is covered by
+    the gloo tests).  Un-permuted and concatenated, the per-rank outputs equal the single-GPU layer output:
+    bit-exact is not required (a row's neighbour order changes with the renumbering), 1e-5 is."""
+    import egc_amd
+    from egc_amd import partition as P
+    from egc_amd.functional import egc_aggregate_combine, egc_basis_transform
+    from egc_amd.workloads import mag_like
+    dev = _dev()
+    ei, n = mag_like(seed=0)
+    torch.manual_seed(5)
+    conv = egc_amd.EGConv(352, 352, aggrs=["symnorm"], num_heads=8, num_bases=4).to(dev).eval()
+    with torch.no_grad():
+        conv.bias.normal_()
+    x = torch.randn(n, 352, device=dev)
+    ei_d = ei.to(dev)
+    with torch.no_grad():
+        ref = conv(x, ei_d)
+        order, new_of_old, bounds = P.locality_partition(ei_d, n, world)
+        q = P.partition_quality(new_of_old[ei_d], bounds)
+        assert max(q["entries_per_rank"]) <= 1.2 * ei.size(1) / world
+        ei2 = new_of_old[ei_d]
+        x2 = x[order]                                   # features follow the renumbering
+        wcat, bcat = conv._packed_weights()
+        parts = P.build_local_simulation(ei2, n, world, interior_first=True, bounds=bounds)
+        plans = [p for _, p in parts]
+        graphs = [egc_amd.CSRGraph.from_partition(e, plan, global_max_index=n - 1, exchange_dis=False) for e, plan in parts]
+        for key in ("dis_raw", "dis_looped"):
+            P.simulate_exchange([getattr(g, key) for g in graphs], plans)
+        for g in graphs:
+            g.refresh_edge_dis()
+        stage = [egc_basis_transform(g, conv._spec_coo, x2[pl.lo:pl.hi][pl.order], wcat, bcat) for g, pl in zip(graphs, plans)]
+        outs = []
+        for g, pl, (b, w) in zip(graphs, plans, stage):   # interior rows before the halo rows exist
+            b[pl.n_local:] = float("nan")
+            out = torch.empty((pl.n_local, 352), device=dev)
+            egc_aggregate_combine(g, conv._spec_coo, b, w, conv.bias, rows=(0, pl.n_interior), out=out)
+            outs.append(out)
+        P.simulate_exchange([b for b, _ in stage], plans)
+        got2 = torch.empty_like(ref)
+        for g, pl, (b, w), out in zip(graphs, plans, stage, outs):
+            egc_aggregate_combine(g, conv._spec_coo, b, w, conv.bias, rows=(pl.n_interior, pl.n_local), out=out)
+            back = torch.empty_like(out)
+            back[pl.order] = out
+            got2[pl.lo:pl.hi] = back
+        got = torch.empty_like(ref)
+        got[order] = got2                               # back to the caller's vertex ids
+    assert bool(torch.isfinite(got).all())
+    assert rel_err(got.cpu().numpy(), ref.cpu().numpy()) <= TOL

@@ -136,3 +136,93 @@ def test_halo_exchange_gloo_world2():
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+def test_cost_balanced_bounds():
+    cost = torch.tensor([10.0, 1, 1, 1, 1, 1, 1, 1, 1, 2])
+    b = P.cost_balanced_bounds(cost, 2)
+    assert b[0] == 0 and b[-1] == 10 and 0 < b[1] < 10
+    assert b == sorted(b)
+    assert P.cost_balanced_bounds(torch.zeros(0), 3) == [0, 0, 0, 0]
+    # one vertex heavier than a whole share: boundaries stay monotone
+    b = P.cost_balanced_bounds(torch.tensor([100.0, 1, 1, 1]), 4)
+    assert b == sorted(b) and b[-1] == 4
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_locality_partition_is_a_valid_balanced_renumbering(world):
+    from egc_amd.workloads import heavy_tailed_graph
+    n = 6000
+    ei = heavy_tailed_graph(n, 45000, seed=5, communities=32, p_in=0.8)
+    order, new_of_old, bounds = P.locality_partition(ei, n, world)
+    assert torch.equal(torch.sort(order).values, torch.arange(n))
+    assert torch.equal(new_of_old[order], torch.arange(n))
+    assert bounds[0] == 0 and bounds[-1] == n and len(bounds) == world + 1 and bounds == sorted(bounds)
+    # deterministic: every rank derives the same partition without communicating
+    o2, n2, b2 = P.locality_partition(ei.clone(), n, world)
+    assert torch.equal(order, o2) and b2 == bounds
+    q_naive = P.partition_quality(ei, P.vertex_ranges(n, world))
+    q = P.partition_quality(new_of_old[ei], bounds)
+    assert sum(q["entries_per_rank"]) == ei.size(1)
+    mean = ei.size(1) / world
+    assert max(q["entries_per_rank"]) <= 1.15 * mean < max(q_naive["entries_per_rank"])   # hubs no longer on one rank
+    assert q["cross_edge_frac"] < 0.6 * q_naive["cross_edge_frac"]                        # planted communities found
+    assert sum(q["halo_rows_per_rank"]) < sum(q_naive["halo_rows_per_rank"])
+
+
+def test_partition_with_explicit_bounds_reproduces_tables():
+    """build_local_simulation with the renumbered graph + cost-balanced bounds: same invariants as the equal split."""
+    from egc_amd.workloads import heavy_tailed_graph
+    n, world = 3000, 4
+    ei = heavy_tailed_graph(n, 20000, seed=6)
+    order, new_of_old, bounds = P.locality_partition(ei, n, world)
+    ei2 = new_of_old[ei]
+    parts = P.build_local_simulation(ei2, n, world, bounds=bounds)
+    table = torch.arange(n * 3, dtype=torch.float32).view(n, 3)
+    tables = []
+    for ei_l, plan in parts:
+        assert (plan.lo, plan.hi) == (bounds[plan.rank], bounds[plan.rank + 1])
+        t = torch.zeros(plan.n_local + plan.n_halo, 3)
+        t[:plan.n_local] = table[plan.lo:plan.hi]
+        tables.append(t)
+    P.simulate_exchange(tables, [p for _, p in parts])
+    for (ei_l, plan), t in zip(parts, tables):
+        ext_ids = torch.cat([torch.arange(plan.lo, plan.hi), plan.halo_global_ids])
+        assert torch.equal(t, table[ext_ids])
+        kept = P.local_edges(ei2, plan.lo, plan.hi)
+        assert torch.equal(ext_ids[ei_l[0]], kept[0]) and torch.equal(ei_l[1] + plan.lo, kept[1])
+
+
+def _worker_bounds(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from egc_amd.workloads import heavy_tailed_graph
+        n = 2000
+        ei = heavy_tailed_graph(n, 14000, seed=8, communities=16, p_in=0.7)
+        order, new_of_old, bounds = P.locality_partition(ei, n, world)      # same on every rank, no communication
+        ei2 = new_of_old[ei]
+        lo, hi = bounds[rank], bounds[rank + 1]
+        owned = P.local_edges(ei2, lo, hi)
+        ei_l, plan = P.build_distributed(owned, n, interior_first=True, bounds=bounds)
+        table = torch.arange(n * 5, dtype=torch.float32).view(n, 5)
+        own = torch.arange(lo, hi)[plan.order]
+        ext = torch.zeros(plan.n_local + plan.n_halo, 5)
+        ext[:plan.n_local] = table[own]
+        plan.exchange(ext)
+        ext_ids = torch.cat([own, plan.halo_global_ids])
+        ok = torch.equal(ext, table[ext_ids]) and torch.equal(ext_ids[ei_l[0]], owned[0])
+        ok = ok and (plan.lo, plan.hi) == (lo, hi) and plan.n_local == hi - lo
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_renumbered_partition_gloo_world2():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_bounds, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
