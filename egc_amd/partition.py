@@ -67,15 +67,30 @@ def _cluster_labels(src, dst, n, cost, max_cost, rounds):
     return lab
 
 
-def _pack_lpt(costs_desc: torch.Tensor, parts: int) -> torch.Tensor:
-    """Longest-processing-time packing of clusters (sorted by decreasing cost) onto `parts` bins."""
+def _pack_lpt(costs_desc: torch.Tensor, parts: int, exact: int = 4096) -> torch.Tensor:
+    """Packing of clusters (sorted by decreasing cost) onto `parts` bins: longest-processing-time first for the
+    `exact` largest (a host loop), the long tail of small clusters dealt out so that every bin ends up with the same
+    total (vectorised: position of the cluster's midpoint in the cumulative cost of the tail, shifted by what the bins
+    already hold)."""
     import heapq
+    m = int(costs_desc.numel())
+    out = torch.empty(m, dtype=torch.int64)
+    loads = [0.0] * parts
     heap = [(0.0, p) for p in range(parts)]
-    out = torch.empty(costs_desc.numel(), dtype=torch.int64)
-    for i, c in enumerate(costs_desc.tolist()):
+    k = min(m, exact)
+    for i, c in enumerate(costs_desc[:k].tolist()):
         load, p = heapq.heappop(heap)
         out[i] = p
+        loads[p] = load + c
         heapq.heappush(heap, (load + c, p))
+    if m > k:
+        tail = costs_desc[k:].double()
+        total = float(tail.sum()) + sum(loads)
+        share = total / parts
+        room = torch.tensor([max(share - l, 0.0) for l in loads], dtype=torch.float64)   # what each bin still takes
+        edges = torch.cumsum(room, 0)
+        mid = torch.cumsum(tail, 0) - tail / 2
+        out[k:] = torch.searchsorted(edges, mid.clamp(max=float(edges[-1]) * (1 - 1e-12))).clamp_(max=parts - 1)
     return out
 
 
