@@ -73,6 +73,12 @@ struct AggArgs {
   int* arg_max;
   int* arg_min;
   int self_pos;              // = n_edges
+  // egc_aggregate_fusedw.hip only: the weightings x @ comb_weight^T + comb_bias are computed inside the launch
+  const float* x;            // [n_nodes, F_in]
+  const float* wfrag;        // comb_weight^T as A fragments of v_mfma_f32_16x16x4_f32: [H][M][64 lanes][4]
+  const float* wbias4;       // comb_bias laid out [H][B = 4][4] (zero beyond A)
+  int F_in, M;               // M = ceil(F_in / 16) k-steps of 16
+  int* queue;                // [FUSEDW_QUEUES + 1] work counters + exit counter (zero on entry, zero on exit)
 };
 
 enum { STAT_SUM = 0, STAT_SQ = 1, STAT_MX = 2, STAT_MN = 3, STAT_WS = 4 };
@@ -157,5 +163,13 @@ __device__ inline __amdgpu_buffer_rsrc_t bases_rsrc(const AggArgs& a) {
 // Returns EGC_OK, an error, or EGC_ERR_UNSUPPORTED when the generic path must be used instead.
 bool fast_path_supported(const AggArgs& a, int layout, int chunks);
 int launch_fast(AggArgs a, int64_t n_nodes, const PlanCaps& caps, hipStream_t stream);
+
+// egc_aggregate_fusedw.hip: the same with the weightings Linear computed inside the launch (a.x, a.wfrag, ...).
+constexpr int FUSEDW_QUEUE_INTS = 16;  // work-queue shards + exit counter (workspace, zero on entry and on exit)
+bool fusedw_supported(const AggArgs& a, int layout);
+size_t fusedw_pack_floats(int H, int f_in);
+int fusedw_pack(const float* wcat, const float* bcat, int f_in, int ldw_cat, int col0, int H, int A, float* packed,
+                hipStream_t stream);
+int launch_fusedw(AggArgs a, const PlanCaps& caps, hipStream_t stream);
 
 }  // namespace egc
