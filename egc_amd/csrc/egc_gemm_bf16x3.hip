@@ -588,7 +588,8 @@ size_t egc_basis_pack_bytes(int32_t f_in, int32_t f_g, int32_t w_cols) {
   const int ldb = (f_g + 3) & ~3;
   const int NV = round_up32(ldb + w_cols);
   const int KS = (f_in + XKT - 1) / XKT;
-  return std::max((size_t)KS * 3 * NV * XKT * sizeof(u16), f16x2_pack_bytes(KS, NV));
+  return std::max(std::max((size_t)KS * 3 * NV * XKT * sizeof(u16), f16x2_pack_bytes(KS, NV)),
+                  f16x2k_pack_bytes(f_in, f_g, ldb, w_cols));
 }
 
 static bool use_f16x2(int f_in, int ldb, int NV) {
@@ -604,6 +605,7 @@ int egc_basis_pack(const float* wcat, int32_t f_in, int32_t f_g, int32_t w_cols,
   const int NV = round_up32(ldb + w_cols);
   const int KS = (f_in + XKT - 1) / XKT;
   if (use_f16x2(f_in, ldb, NV)) return f16x2_pack(wcat, f_in, f_g, w_cols, ldb, NV, KS, packed, stream);
+  if (f16x2k_shape(f_in, f_g, ldb, w_cols)) return f16x2k_pack(wcat, f_in, f_g, ldb, w_cols, packed, stream);
   const int total = KS * NV * XKT;
   pack_bf16x3_kernel<<<(total + 255) / 256, 256, 0, stream>>>(wcat, f_in, f_g, w_cols, ldb, NV, KS, (u16*)packed);
   EGC_LAUNCH_CHECK("pack_bf16x3_kernel");
@@ -621,6 +623,8 @@ int egc_basis_transform_packed(const float* x, const void* packed, const float* 
   const int KS = (f_in + XKT - 1) / XKT;
   if (use_f16x2(f_in, ldb, NV))  // the planes were packed for this kernel: no other form can read them
     return f16x2_launch(x, packed, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, stream);
+  if (f16x2k_shape(f_in, f_g, ldb, w_cols))  // likewise: its planes are in its own fragment order
+    return f16x2k_launch(x, packed, bcat, n_nodes, f_in, f_g, ldb, w_cols, bases, weightings, stream);
   if (f_in <= 128 && NV <= 256 && getenv("EGC_GEMM_NO_WS") == nullptr) {  // weight-stationary form (<= 8 wavefronts)
     const u16* pk = (const u16*)packed;
     int st;

@@ -1,0 +1,421 @@
+// Basis transform + weightings Linear for F_in > 128 on the fp16 matrix cores with fp32-level accuracy (gfx950):
+// the register-stationary fp16x2 scheme of egc_gemm_f16x2.hip carried to long k (128 < F_in <= 384) -- the
+// reference's ogbn-mag layers (352 wide, mag/models.py:23-53) and its other trained nets (136 ... 304 wide).
+//
+//     [bases | weightings] = x[N,F_in] @ [bases_weight | comb.weight^T]  (+ comb.bias)
+//
+// Reference behaviour replaced: torch.matmul(x, bases_weight) (experiments/layers.py:97-101,
+// optimized_layers.py:180) and comb_weights(x) (layers.py:110, optimized_layers.py:182).
+//
+// Numerics: exactly those of egc_gemm_f16x2.hip -- every x row and weight column scaled by a power of two so that
+// its largest magnitude lies in [1, 2), xs = xh + 2^-11 xl in two fp16 planes (same for w), three products
+// (xh wh, xh wl + xl wh) accumulated in fp32, result 2^ex 2^ew (acc0 + 2^-11 acc1): ~2^-22 relative.
+//
+// What changes with long k is WHERE the weights can live.  [F_in x 208 columns] in two fp16 planes is 293 KB at the
+// ogbn-mag shape: no LDS holds it and a 32-column register block (176 registers) leaves no room for anything else,
+// which is why the bf16x3 kernel re-stages the weights from L2 every k-step and ends up LDS-bandwidth bound (1.0 ms
+// against 0.26 ms of HBM or MFMA time).  Here a wavefront owns SIXTEEN columns for the whole k range
+// (v_mfma_f32_16x16x32_f16: 4 registers per plane and k-step of 32 -> 88 registers at F_in = 352) and one workgroup
+// of up to 16 wavefronts covers up to 256 virtual columns: the weights are read from memory ONCE per workgroup.
+// x arrives by LDS-DMA into a ring of two raw fp32 tiles of 16 rows (the row maximum needs the whole row before
+// the first MFMA, so a tile is complete rows), is split into two fp16 planes (double-buffered) half a wavefront
+// per row, and every wavefront multiplies the same 16 x F_in planes by its own weights: per tile and wavefront
+// 3 KS MFMAs of 16 cycles against 2 KS LDS reads of 1 KB.  One barrier per tile: the split of tile t + 1 and
+// the MFMAs of tile t sit between the same two barriers, so the vector work of one wavefront runs beside the matrix
+// work of another.
+#include <stdlib.h>
+
+#include <algorithm>
+#include <cstdio>
+
+#include "egc_common.h"
+#include "egc_gemm_split.h"
+
+namespace egc {
+
+typedef float f32x4k __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8k __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2k __attribute__((ext_vector_type(2)));
+typedef float f32x2k __attribute__((ext_vector_type(2)));
+typedef unsigned short u16;
+typedef unsigned int u32x4k __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2k __attribute__((ext_vector_type(2)));
+
+constexpr int KROWS = 16;  // rows of an x tile = one MFMA row block
+
+__device__ inline void lds_barrier_k() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Virtual column space: column tiles of 16; tiles [0, TB) hold the bases columns (ldb of them, the rest of the last
+// tile is padding that is never stored), tiles [TB, NT) the weightings columns.
+struct KCols {
+  int F_g, ldb, W, TB, NT;
+  __host__ __device__ inline int source(int v) const {  // column of wcat behind virtual column v, or -1
+    const int t = v >> 4;
+    if (t < TB) return v < F_g ? v : -1;
+    const int w = v - 16 * TB;
+    return w < W ? F_g + w : -1;
+  }
+};
+
+// packed: [NT][KS][2 planes][64 lanes][8] fp16 -- the A fragments of v_mfma_f32_16x16x32_f16 in register order
+// (lane (i, kq) holds k = 32 s + 8 kq .. + 7 of column 16 t + i) -- followed by float inv_scale[16 NT].
+// One wavefront per virtual column: lanes stride over k, the column maximum is a wavefront all-reduce.
+__global__ void __launch_bounds__(64) pack_f16x2k_kernel(const float* __restrict__ wcat, int K, KCols c, int KS,
+                                                         u16* __restrict__ packed) {
+  const int v = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int src = c.source(v);
+  const int ldw = c.F_g + c.W;
+  unsigned amax = 0;
+  if (src >= 0)
+    for (int k = lane; k < K; k += 64) amax = max(amax, __float_as_uint(wcat[(int64_t)k * ldw + src]) & 0x7fffffffu);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) amax = max(amax, (unsigned)__shfl_xor((int)amax, d));
+  unsigned be = amax >> 23;
+  be = be > 253u ? 253u : be;
+  const float scale = __uint_as_float((254u - be) << 23), inv = __uint_as_float(be << 23);
+  const int t = v >> 4, i = v & 15;
+  for (int k = lane; k < KS * 32; k += 64) {
+    const float w = (src >= 0 && k < K) ? wcat[(int64_t)k * ldw + src] * scale : 0.f;
+    const _Float16 h = (_Float16)w;
+    const _Float16 l = (_Float16)((w - (float)h) * 2048.f);
+    const int s = k >> 5, kq = (k >> 3) & 3, e = k & 7;
+    const int64_t base = ((((int64_t)t * KS + s) * 2) * 64 + (kq * 16 + i)) * 8 + e;
+    packed[base] = __builtin_bit_cast(u16, h);
+    packed[base + 64 * 8] = __builtin_bit_cast(u16, l);
+  }
+  if (lane == 0) reinterpret_cast<float*>(packed + (int64_t)c.NT * KS * 2 * 64 * 8)[v] = inv;
+}
+
+template <int N>
+__device__ inline void vmwait_k() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// wave-uniform runtime count (DMA wave-instructions per tile depend on F_in and the workgroup size)
+__device__ inline void vmwait_rt(int n) {
+  switch (n) {
+    case 0: vmwait_k<0>(); break;   case 1: vmwait_k<1>(); break;   case 2: vmwait_k<2>(); break;
+    case 3: vmwait_k<3>(); break;   case 4: vmwait_k<4>(); break;   case 5: vmwait_k<5>(); break;
+    case 6: vmwait_k<6>(); break;   case 7: vmwait_k<7>(); break;   case 8: vmwait_k<8>(); break;
+    case 9: vmwait_k<9>(); break;   case 10: vmwait_k<10>(); break; case 11: vmwait_k<11>(); break;
+    case 12: vmwait_k<12>(); break; case 13: vmwait_k<13>(); break; case 14: vmwait_k<14>(); break;
+    case 15: vmwait_k<15>(); break; case 16: vmwait_k<16>(); break; case 17: vmwait_k<17>(); break;
+    case 18: vmwait_k<18>(); break; case 19: vmwait_k<19>(); break; case 20: vmwait_k<20>(); break;
+    default: vmwait_k<0>(); break;
+  }
+}
+
+#ifdef EGC_GEMMK_STAMPS
+__device__ unsigned long long egc_stampk[8];  // diagnostic build only: cycles per phase, summed over wavefronts
+#define KST(k) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); ksum[k] += _t - kt0; kt0 = _t; }
+#else
+#define KST(k)
+#endif
+
+template <int KS, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) basis_gemm_f16x2k_kernel(const float* __restrict__ x, const u16* __restrict__ packed,
+                                                                      const float* __restrict__ bcat, int64_t M, int K,
+                                                                      KCols c, float* __restrict__ bases,
+                                                                      float* __restrict__ weightings, int n_tiles, int LDX,
+                                                                      int R, int slot_bytes) {
+  extern __shared__ __attribute__((aligned(16))) char smem_k[];
+  char* raw = smem_k;                                                    // [2][slot_bytes] raw fp32 tiles (DMA ring)
+  u16* xs = reinterpret_cast<u16*>(smem_k + 2 * slot_bytes);             // [2 buffers][2 planes][KROWS][LDX] fp16
+  float* row_inv = reinterpret_cast<float*>(xs + 4 * KROWS * LDX);       // [2 buffers][KROWS]
+  float* colinfo = row_inv + 2 * KROWS;                                  // [16 NT][2]: inverse column scale, bias
+  const int tid = threadIdx.x;
+  const int nthreads = blockDim.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ct = wave;                                                   // this wavefront's column tile
+  const int j = lane & 15, quad = lane >> 4;
+  const int K4 = K >> 2;                                                 // 16-byte pieces per row
+  constexpr unsigned GOOB = 0xFFFFFFF0u;
+  const u32x4k rx = {(unsigned)(uintptr_t)x, (unsigned)((uintptr_t)x >> 32) & 0xffffu, (unsigned)(M * K * 4), 0x00020000u};
+  const unsigned raw_lds = (unsigned)(uintptr_t)raw;
+  const unsigned magic_K4 = (unsigned)(((uint64_t)1 << 32) / (uint64_t)K4) + 1u;
+
+  // one LDS-DMA wave-instruction: 64 lanes x 16 B from per-lane global offsets to 1 KiB of contiguous LDS
+  auto dma_tile = [&](int tile, int slot) {
+    for (int i = 0; i < R; ++i) {
+      const int pc = tid + nthreads * i;
+      const int row = (int)__umulhi((unsigned)pc, magic_K4);   // pc / K4 for pc < 2^16
+      const int k4 = pc - row * K4;
+      const int64_t gm = (int64_t)tile * KROWS + row;
+      const bool ok = (tile < n_tiles) & (row < KROWS) & (gm < M);
+      const unsigned voff = ok ? (unsigned)((gm * K + 4 * k4) * 4) : GOOB;
+      const unsigned dst = __builtin_amdgcn_readfirstlane(raw_lds + slot * slot_bytes + (wave * 64 + nthreads * i) * 16);
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep)
+                   : "v"(voff), "s"(dst), "s"(rx)
+                   : "memory");
+    }
+  };
+
+  const int stride = gridDim.x;
+  int tile = blockIdx.x;
+  if (tile >= n_tiles) return;
+  dma_tile(tile, 0);
+  dma_tile(tile + stride, 1);
+  // zero the planes once: the k range [K, 32 KS) and the row padding are never written again
+  for (int i = tid; i < 4 * KROWS * LDX / 8; i += nthreads) reinterpret_cast<u32x4k*>(xs)[i] = u32x4k{0, 0, 0, 0};
+
+  // both planes of this wavefront's F_in x 16 weight block, as A operands
+  f16x8k wf[KS][2];
+  {
+    const u16* src = packed + ((int64_t)ct * KS * 2 * 64 + lane) * 8;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      wf[s][0] = *reinterpret_cast<const f16x8k*>(src + (s * 2) * 64 * 8);
+      wf[s][1] = *reinterpret_cast<const f16x8k*>(src + (s * 2 + 1) * 64 * 8);
+    }
+  }
+  // output addressing: lane (j, quad) holds, per row block, row 16 rb + j and virtual columns 16 ct + 4 quad .. + 3
+  const bool to_bases = ct < c.TB;
+  const int out_ld = to_bases ? c.ldb : c.W;
+  const int col0 = to_bases ? 16 * ct + 4 * quad : 16 * (ct - c.TB) + 4 * quad;
+  const int lim = to_bases ? c.ldb : c.W;
+  float* outp = to_bases ? bases : weightings;
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, (unsigned)(M * out_ld * 4), 0x00020000);
+  const float* inv_tab = reinterpret_cast<const float*>(packed + (int64_t)c.NT * KS * 2 * 64 * 8);
+  // inverse column scales and biases live in LDS (8 registers less next to the 8 KS weight registers)
+  for (int v = tid; v < 16 * c.NT; v += nthreads) {
+    const int w = v - 16 * c.TB;
+    colinfo[2 * v] = inv_tab[v];
+    colinfo[2 * v + 1] = (w >= 0 && w < c.W && bcat != nullptr) ? bcat[w] : 0.f;
+  }
+  const bool vec_store = (out_ld & 3) == 0;
+  vmwait_k<0>();
+  // the compiler counts only its own loads: let it retire the weight loads HERE
+#pragma unroll
+  for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(wf[s][0]), "+v"(wf[s][1]));
+  // the first two tiles were requested before the weight loads: both have landed by now (vmcnt(0) above)
+  lds_barrier_k();
+
+  const int hw = tid >> 5;                    // half-wavefront index: one row of the tile per half-wavefront and pass
+  const int hl = tid & 31;
+  const int n_hw = nthreads >> 5;
+  const int n_stores = vec_store ? 1 : 4;     // store instructions per tile and wavefront
+  // raw fp32 rows of ring slot `rslot` -> the two fp16 planes of buffer `pbuf` + row scales
+  auto split = [&](int rslot, int pbuf) {
+    const char* rs = raw + rslot * slot_bytes;
+    u16* xp = xs + pbuf * 2 * KROWS * LDX;
+    for (int row = hw; row < KROWS; row += n_hw) {
+      float m = 0.f;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int k4 = hl + 32 * i;
+        if (k4 < K4) {
+          const float4 v = *reinterpret_cast<const float4*>(rs + ((size_t)row * K4 + k4) * 16);
+          float mi;
+          asm("v_max3_f32 %0, |%1|, |%2|, |%3|\n\tv_max_f32 %0, |%4|, %0" : "=&v"(mi) : "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+          m = fmaxf(m, mi);
+        }
+      }
+      unsigned a = __float_as_uint(m);
+      a = max(a, (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+      a = max(a, (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+      a = max(a, (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0x141, 0xf, 0xf, true));  // row_half_mirror
+      a = max(a, (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0x140, 0xf, 0xf, true));  // row_mirror
+      a = max(a, (unsigned)__builtin_amdgcn_ds_swizzle((int)a, 0x401F));                    // lane ^ 16
+      unsigned e = a & 0x7f800000u;
+      e = min(max(e, 13u << 23), 253u << 23);
+      const float sc = __uint_as_float(0x7f000000u - e);                  // 2^-e
+      const float sc2k = __uint_as_float(0x7f000000u + (11u << 23) - e);  // 2^(11-e)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int k4 = hl + 32 * i;
+        if (k4 < K4) {
+          const float4 v = *reinterpret_cast<const float4*>(rs + ((size_t)row * K4 + k4) * 16);   // second read: 12 registers less
+          const f16x2k h01 = __builtin_convertvector(f32x2k{v.x * sc, v.y * sc}, f16x2k);
+          const f16x2k h23 = __builtin_convertvector(f32x2k{v.z * sc, v.w * sc}, f16x2k);
+          f16x2k l01, l23;
+          l01[0] = (_Float16)__builtin_fmaf((float)h01[0], -2048.f, v.x * sc2k);
+          l01[1] = (_Float16)__builtin_fmaf((float)h01[1], -2048.f, v.y * sc2k);
+          l23[0] = (_Float16)__builtin_fmaf((float)h23[0], -2048.f, v.z * sc2k);
+          l23[1] = (_Float16)__builtin_fmaf((float)h23[1], -2048.f, v.w * sc2k);
+          u16* dst = xp + row * LDX + 4 * k4;
+          *reinterpret_cast<u32x2k*>(dst) = u32x2k{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
+          *reinterpret_cast<u32x2k*>(dst + KROWS * LDX) = u32x2k{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
+        }
+      }
+      if (hl == 0) row_inv[pbuf * KROWS + row] = __uint_as_float(e);  // 2^e
+    }
+  };
+  split(0, 0);
+#ifdef EGC_GEMMK_STAMPS
+  unsigned long long kt0, ksum[6] = {0, 0, 0, 0, 0, 0};
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(kt0) :: "memory");
+#endif
+  // One barrier per tile.  At the top of iteration t (tile t of this workgroup): ring slot (t + 1) % 2 holds the raw
+  // tile t + 1, plane buffer t % 2 the split tile t.  After the barrier the slot t % 2 is free (everybody has split
+  // tile t) and is re-armed with tile t + 2 at once -- a whole iteration of cover for its latency; then the wavefronts
+  // split tile t + 1 into the other plane buffer and multiply tile t, in whatever order they get there: the vector
+  // work of one wavefront runs beside the matrix work of another.
+  int cur = 0;
+  for (bool first = true; tile < n_tiles; tile += stride, first = false) {
+    if (first) vmwait_k<0>(); else vmwait_rt(n_stores);  // own pieces of tile t + 1: only the last tile's stores came after them
+    KST(0)
+    lds_barrier_k();
+    KST(1)
+    split(cur ^ 1, cur ^ 1);
+    KST(3)
+    dma_tile(tile + 2 * stride, cur);
+    KST(2)
+    {
+      f32x4k acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      const u16* xb = xs + cur * 2 * KROWS * LDX + j * LDX + 8 * quad;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const f16x8k xh = *reinterpret_cast<const f16x8k*>(xb + 32 * s);
+        const f16x8k xl = *reinterpret_cast<const f16x8k*>(xb + KROWS * LDX + 32 * s);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[s][0], xh, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[s][0], xl, acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[s][1], xh, acc1, 0, 0, 0);
+      }
+      const float ri = row_inv[cur * KROWS + j];
+      f32x4k cinv, cbias;
+      {
+        const float* ci = colinfo + 2 * (16 * ct + 4 * quad);
+        const f32x4k c01 = *reinterpret_cast<const f32x4k*>(ci), c23 = *reinterpret_cast<const f32x4k*>(ci + 4);
+        cinv = f32x4k{c01[0], c01[2], c23[0], c23[2]};
+        cbias = f32x4k{c01[1], c01[3], c23[1], c23[3]};
+      }
+      const int64_t grow = (int64_t)tile * KROWS + j;
+      f32x4k o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = __builtin_fmaf(__builtin_fmaf(acc1[r], 1.f / 2048.f, acc0[r]), cinv[r] * ri, cbias[r]);
+      // Every store instruction is always issued (masked lanes go out of the buffer's range): the counted wait at
+      // the top of the loop relies on a fixed number of vector-memory operations per tile.
+      const bool row_ok = grow < M;
+      const unsigned off = (unsigned)((grow * out_ld + col0) * 4);
+      if (vec_store) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4k, o), ro, (row_ok && col0 + 3 < lim) ? off : GOOB, 0, 0);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o[r]), ro, (row_ok && col0 + r < lim) ? off + 4u * r : GOOB, 0, 0);
+      }
+    }
+    KST(5)
+    cur ^= 1;
+  }
+  vmwait_k<0>();  // no DMA may still be writing this block's LDS when it is handed to the next block
+#ifdef EGC_GEMMK_STAMPS
+  if (lane == 0)
+    for (int k = 0; k < 6; ++k) atomicAdd(&egc_stampk[k], ksum[k]);
+#endif
+}
+
+bool f16x2k_shape(int f_in, int f_g, int ldb, int w_cols) {
+  if (getenv("EGC_GEMM_NO_F16X2K") != nullptr) return false;
+  if (f_in <= 128 || f_in > 384 || (f_in & 3) != 0) return false;
+  const int NT = (ldb + 15) / 16 + (w_cols + 15) / 16;
+  if ((f_in + 31) / 32 == 12 && NT > 12) return false;  // 96 weight registers do not fit four wavefronts per SIMD
+  return NT >= 1 && NT <= 16;
+}
+
+static KCols kcols(int f_g, int ldb, int w_cols) {
+  KCols c;
+  c.F_g = f_g; c.ldb = ldb; c.W = w_cols;
+  c.TB = (ldb + 15) / 16;
+  c.NT = c.TB + (w_cols + 15) / 16;
+  return c;
+}
+
+size_t f16x2k_pack_bytes(int f_in, int f_g, int ldb, int w_cols) {
+  const KCols c = kcols(f_g, ldb, w_cols);
+  const int KS = (f_in + 31) / 32;
+  return (size_t)c.NT * KS * 2 * 64 * 8 * sizeof(u16) + (size_t)c.NT * 16 * sizeof(float);
+}
+
+int f16x2k_pack(const float* wcat, int f_in, int f_g, int ldb, int w_cols, void* packed, hipStream_t stream) {
+  const KCols c = kcols(f_g, ldb, w_cols);
+  const int KS = (f_in + 31) / 32;
+  pack_f16x2k_kernel<<<c.NT * 16, 64, 0, stream>>>(wcat, f_in, c, KS, (u16*)packed);
+  EGC_LAUNCH_CHECK("pack_f16x2k_kernel");
+  return EGC_OK;
+}
+
+template <int KS, int WAVES>
+static int launch_k(const float* x, const u16* packed, const float* bcat, int64_t M, int K, const KCols& c, float* bases,
+                    float* weightings, hipStream_t stream) {
+  const int threads = c.NT * 64;
+  const int64_t n_tiles64 = ceil_div(M, KROWS);
+  if (n_tiles64 >= ((int64_t)1 << 31)) return EGC_ERR_INVALID;
+  const int n_tiles = (int)n_tiles64;
+  // row stride of the planes in fp16: the B fragments are ds_read_b128 of lanes (row j = lane & 15, k piece lane >> 4);
+  // with 32 KS + 16 every one of the instruction's four 16-lane groups touches 16 distinct 4-bank slots
+  // (32 KS + 8 leaves five 2-way conflicts per group)
+  const int LDX = 32 * KS + 16;
+  const int R = (int)ceil_div((int64_t)KROWS * (K / 4), threads);
+  const int slot_bytes = R * threads * 16;
+  const size_t lds = (size_t)2 * slot_bytes + (size_t)4 * KROWS * LDX * sizeof(u16) + (2 * KROWS + 2 * 16 * c.NT) * sizeof(float);
+  if (lds > 160 * 1024 || R > 16) return EGC_ERR_UNSUPPORTED;
+  auto kern = &basis_gemm_f16x2k_kernel<KS, WAVES>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) { set_last_error("hipFuncSetAttribute(f16x2k)", e); return EGC_ERR_HIP; }
+    attr_set = true;
+  }
+  int grid = 256;  // one workgroup per CU (LDS)
+  if (const char* e = getenv("EGC_GEMM_GRID")) grid = atoi(e);
+  if (grid > n_tiles) grid = n_tiles;
+  kern<<<grid, threads, lds, stream>>>(x, packed, bcat, M, K, c, bases, weightings, n_tiles, LDX, R, slot_bytes);
+  EGC_LAUNCH_CHECK("basis_gemm_f16x2k_kernel");
+#ifdef EGC_GEMMK_STAMPS
+  {
+    static int calls = 0;
+    if (++calls == 10) {
+      hipDeviceSynchronize();
+      unsigned long long h[8];
+      hipMemcpyFromSymbol(h, HIP_SYMBOL(egc_stampk), sizeof(h));
+      const double per = (double)calls * n_tiles * c.NT;
+      fprintf(stderr, "[gemmk stamps] K=%d NT=%d R=%d per tile and wavefront (cycles): dma-wait %.0f barrier %.0f dma-issue %.0f split %.0f mfma+store %.0f\n",
+              K, c.NT, R, h[0] / per, h[1] / per, h[2] / per, h[3] / per, h[5] / per);
+    }
+  }
+#endif
+  return EGC_OK;
+}
+
+template <int KS>
+static int launch_ks(const float* x, const u16* packed, const float* bcat, int64_t M, int K, const KCols& c, float* bases,
+                     float* weightings, hipStream_t stream) {
+  if (c.NT <= 12) return launch_k<KS, 12>(x, packed, bcat, M, K, c, bases, weightings, stream);
+  return launch_k<KS, 16>(x, packed, bcat, M, K, c, bases, weightings, stream);
+}
+
+int f16x2k_launch(const float* x, const void* packed, const float* bcat, int64_t M, int K, int f_g, int ldb, int W,
+                  float* bases, float* weightings, hipStream_t stream) {
+  if ((reinterpret_cast<uintptr_t>(x) & 15) != 0 || (reinterpret_cast<uintptr_t>(bases) & 15) != 0 ||
+      (W > 0 && (W & 3) == 0 && (reinterpret_cast<uintptr_t>(weightings) & 15) != 0))
+    return EGC_ERR_UNSUPPORTED;
+  const KCols c = kcols(f_g, ldb, W);
+  const u16* pk = (const u16*)packed;
+  const int64_t widest = std::max(std::max(K, ldb), W);
+  int64_t max_rows = ((int64_t)0x7FFFFFF0 / (4 * widest)) & ~(int64_t)(KROWS - 1);
+  if (const char* e = getenv("EGC_GEMM_MAX_ROWS")) max_rows = std::max<int64_t>(KROWS, atoll(e) & ~(int64_t)(KROWS - 1));  // tests
+  for (int64_t r0 = 0; r0 < M; r0 += max_rows) {
+    const int64_t rows = std::min(max_rows, M - r0);
+    const float* xr = x + r0 * K;
+    float* br = bases + r0 * ldb;
+    float* wr = weightings != nullptr ? weightings + r0 * W : nullptr;
+    int st;
+    switch ((K + 31) / 32) {
+      case 5: st = launch_ks<5>(xr, pk, bcat, rows, K, c, br, wr, stream); break;
+      case 6: st = launch_ks<6>(xr, pk, bcat, rows, K, c, br, wr, stream); break;
+      case 7: st = launch_ks<7>(xr, pk, bcat, rows, K, c, br, wr, stream); break;
+      case 8: st = launch_ks<8>(xr, pk, bcat, rows, K, c, br, wr, stream); break;
+      case 9: st = launch_ks<9>(xr, pk, bcat, rows, K, c, br, wr, stream); break;
+      case 10: st = launch_ks<10>(xr, pk, bcat, rows, K, c, br, wr, stream); break;
+      case 11: st = launch_ks<11>(xr, pk, bcat, rows, K, c, br, wr, stream); break;
+      case 12: st = launch_ks<12>(xr, pk, bcat, rows, K, c, br, wr, stream); break;
+      default: return EGC_ERR_UNSUPPORTED;
+    }
+    if (st != EGC_OK) return st;
+  }
+  return EGC_OK;
+}
+
+}  // namespace egc

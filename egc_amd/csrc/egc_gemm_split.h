@@ -18,4 +18,11 @@ int f16x2_pack(const float* wcat, int f_in, int f_g, int w_cols, int ldb, int NV
 int f16x2_launch(const float* x, const void* packed, const float* bcat, int64_t M, int K, int W, float* bases, int ldb,
                  float* weightings, int NV, hipStream_t stream);
 
+// Shapes served by the long-k fp16x2 kernel (egc_gemm_f16x2k.hip): 128 < F_in <= 384, at most 16 column tiles of 16.
+bool f16x2k_shape(int f_in, int f_g, int ldb, int w_cols);
+size_t f16x2k_pack_bytes(int f_in, int f_g, int ldb, int w_cols);
+int f16x2k_pack(const float* wcat, int f_in, int f_g, int ldb, int w_cols, void* packed, hipStream_t stream);
+int f16x2k_launch(const float* x, const void* packed, const float* bcat, int64_t M, int K, int f_g, int ldb, int W,
+                  float* bases, float* weightings, hipStream_t stream);
+
 }  // namespace egc

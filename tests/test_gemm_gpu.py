@@ -1,6 +1,7 @@
 """The basis-transform GEMM through the C ABI (egc_basis_pack / egc_basis_transform_packed and the exact
 fp32 form) against float64: fp32-level accuracy on every shape path -- the fp16x2 register-stationary kernel
-(96 < F_in <= 128, F_g % 32 == 0, 192 padded columns), the bf16x3 kernels (everything else) -- including rows
+(96 < F_in <= 128, F_g % 32 == 0, 192 padded columns), its long-k form (128 < F_in <= 384, egc_gemm_f16x2k.hip),
+the bf16x3 kernels (everything else) -- including rows
 and columns of wildly different magnitude, zero rows, ragged sizes and non-finite inputs.
 
 Tolerance: componentwise |got - ref| <= 4e-6 * (|x| @ |w| + |b|), i.e. a few fp32 roundings of the products
@@ -56,7 +57,12 @@ def _check(x, wcat, bcat, f_g, w_cols, bases, wt, tol=4e-6):
     (100, 64, 126),   # fp16x2 kernel, F_in < 128 (zero-filled ring), W not a multiple of 4
     (128, 32, 160),   # fp16x2 kernel, 1 bases tile + 5 weightings tiles
     (124, 124, 48),   # bf16x3 (F_g % 32 != 0)
-    (168, 84, 32),    # bf16x3, LDS-staged general kernel
+    (168, 84, 32),    # long-k fp16x2 kernel (128 < F_in <= 384, <= 16 column tiles of 16)
+    (352, 176, 32),   # long-k fp16x2: the ogbn-mag layer (13 column tiles, 11 k-steps)
+    (224, 224, 48),   # long-k fp16x2: molhiv 224/H4/B4 (17 tiles -> falls back to bf16x3)
+    (384, 64, 128),   # long-k fp16x2: the longest k it takes
+    (132, 20, 7),     # long-k fp16x2: ragged weightings width (dword stores), partial column tiles
+    (300, 300, 48),   # bf16x3, LDS-staged general kernel (too many column tiles for the long-k kernel)
     (7, 5, 3),        # tiny ragged
 ])
 def test_packed_gemm_matches_float64(n, f_in, f_g, w_cols):
@@ -120,6 +126,31 @@ def test_row_ranges_launched_separately(monkeypatch):
     monkeypatch.setenv("EGC_GEMM_MAX_ROWS", "192")
     g = torch.Generator(device="cpu").manual_seed(13)
     n, f_in, f_g, w_cols = 1000, 128, 64, 128
+    x, wcat, bcat = (torch.randn(n, f_in, generator=g).to(DEV), torch.randn(f_in, f_g + w_cols, generator=g).to(DEV),
+                     torch.randn(w_cols, generator=g).to(DEV))
+    _check(x, wcat, bcat, f_g, w_cols, *_transform(x, wcat, bcat, f_g, w_cols))
+
+
+def test_long_k_kernel_rows_of_wildly_different_magnitude():
+    """The per-row power-of-two scaling of the long-k fp16x2 kernel (row maximum over the WHOLE row before the split)."""
+    g = torch.Generator(device="cpu").manual_seed(21)
+    n, f_in, f_g, w_cols = 3001, 352, 176, 32
+    x = torch.randn(n, f_in, generator=g) * torch.exp2(torch.randint(-100, 100, (n, 1), generator=g).float())
+    x[:, ::5] *= 1e-4
+    x[7] = 0.0
+    wcat = torch.randn(f_in, f_g + w_cols, generator=g) * torch.exp2(torch.randint(-20, 20, (1, f_g + w_cols), generator=g).float())
+    wcat[:, 9] = 0.0
+    bcat = torch.randn(w_cols, generator=g)
+    x, wcat, bcat = x.to(DEV), wcat.to(DEV), bcat.to(DEV)
+    bases, wt = _transform(x, wcat, bcat, f_g, w_cols)
+    _check(x, wcat, bcat, f_g, w_cols, bases, wt)
+    assert bool((bases[7] == 0).all()) and bool((bases[:, 9] == 0).all())
+
+
+def test_long_k_kernel_row_ranges_launched_separately(monkeypatch):
+    monkeypatch.setenv("EGC_GEMM_MAX_ROWS", "96")
+    g = torch.Generator(device="cpu").manual_seed(23)
+    n, f_in, f_g, w_cols = 500, 352, 176, 32
     x, wcat, bcat = (torch.randn(n, f_in, generator=g).to(DEV), torch.randn(f_in, f_g + w_cols, generator=g).to(DEV),
                      torch.randn(w_cols, generator=g).to(DEV))
     _check(x, wcat, bcat, f_g, w_cols, *_transform(x, wcat, bcat, f_g, w_cols))
