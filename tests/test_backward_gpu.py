@@ -8,7 +8,13 @@ from oracle import egc_torch_ref as tref
 
 pytestmark = pytest.mark.gpu
 
-GTOL = 2e-4  # fp32 kernels (atomics, re-association) vs a float64 reference, scale-relative
+def gtol(aggrs):
+    """Bound on |HIP gradient - float64 gradient|, scale-relative: north_star's 1e-5 for every layer without std / var.
+    With std / var the gradient carries 1 / (2 std) (158 at zero variance): the REFERENCE's own float32 run is 4.5e-5 to
+    7.6e-5 away from its float64 run on the committed fixtures (tests/golden/MANIFEST_GRAD.json, f32_vs_f64_grad_x),
+    so nothing evaluated in float32 can be held to 1e-5 there (tests/test_backward_golden.py applies a per-fixture
+    bound derived from that distance)."""
+    return 2e-4 if {"std", "var"} & set(aggrs) else 1e-5
 
 
 def _rel(a, b):
@@ -55,9 +61,9 @@ def test_egconv_gradients(aggrs, kw):
                               sigmoid=kw.get("sigmoid", False))
     ref.backward(gout.double().cpu())
     assert _rel(out, ref) <= 1e-5
-    assert _rel(x.grad, x64.grad) <= GTOL
+    assert _rel(x.grad, x64.grad) <= gtol(aggrs)
     for k, v in conv.named_parameters():
-        assert _rel(v.grad, p64[k].grad) <= GTOL, k
+        assert _rel(v.grad, p64[k].grad) <= gtol(aggrs), k
 
 
 @pytest.mark.parametrize("aggrs,kw", [
@@ -91,9 +97,9 @@ def test_efficient_graph_conv_gradients(aggrs, kw):
         add_self_loops=kw.get("add_self_loops", True))
     ref.backward(gout.double().cpu())
     assert _rel(out, ref) <= 1e-5
-    assert _rel(x.grad, x64.grad) <= GTOL
+    assert _rel(x.grad, x64.grad) <= gtol(aggrs)
     for k, v in conv.named_parameters():
-        assert _rel(v.grad, p64[k].grad) <= GTOL, k
+        assert _rel(v.grad, p64[k].grad) <= gtol(aggrs), k
 
 
 def test_max_gradient_goes_to_first_maximal_edge():
@@ -231,6 +237,6 @@ def test_input_gradient_through_the_packed_gemm(fin, aggrs):
                               p64["bias"], H, B, aggrs)
     ref.backward(gout.double().cpu())
     assert _rel(out, ref) <= 1e-5
-    assert _rel(x.grad, x64.grad) <= GTOL
+    assert _rel(x.grad, x64.grad) <= gtol(aggrs)
     for k, v in conv.named_parameters():
-        assert _rel(v.grad, p64[k].grad) <= GTOL, k
+        assert _rel(v.grad, p64[k].grad) <= gtol(aggrs), k
