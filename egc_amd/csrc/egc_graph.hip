@@ -161,6 +161,287 @@ __global__ void __launch_bounds__(256) edge_dis_kernel(int64_t n_edges, const in
   }
 }
 
+
+// =============================================================================================
+// Fast graph build (egc_graph_build): COO -> stable CSR + degree tables + long-row plan + per-entry deg^-1/2 in
+// FIVE launches, no library sort -- per-batch graphs of the reference's batched nets (zinc/models.py:60-74,
+// mol/pna_style_models.py:64-79, cifar/models.py:61-75) pay this conversion every step, and at ~100 k edges the
+// eight-plus launches of the radix-sort pipeline cost more than the layer they feed.
+//   1 hist     in-degree (and non-self in-degree) per destination by atomics; range check of every id
+//   2 sums     per-block sums of the degrees
+//   3 scan     exclusive scan -> rowptr (every block re-adds the few block sums in front of it); deg^-1/2 tables
+//   4 scatter  entry position = rowptr[dst] + a slot drawn from the row's counter (any order inside a row)
+//   5 rows     every row sorted by input position (the order torch_scatter's first-edge arg rule needs): 16 lanes per
+//              short row, the whole block on long rows (LDS bitonic up to 4096 entries, in global memory beyond);
+//              long-row plan; per-entry deg^-1/2
+// Workspace: int32 deg[n + 1] | deg_ns[n] | block sums | counters -- zero on entry, left zero on exit (the scatter
+// counts the degrees back down, the scan clears the rest).
+// =============================================================================================
+constexpr int BUILD_SCAN_ITEMS = 4096;   // elements per scan block (1024 threads x 4)
+constexpr int BUILD_LDS_SORT = 4096;     // longest row sorted in LDS
+
+__global__ void __launch_bounds__(256) build_hist_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
+                                                         int64_t n_edges, int n_nodes, int n_src, int* __restrict__ deg,
+                                                         int* __restrict__ deg_ns, int* __restrict__ maxp1,
+                                                         int* __restrict__ status) {
+  __shared__ int wave_max[4];
+  int m = 0;
+  bool bad = false;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_edges; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t s = src[e], d = dst[e];
+    if (s < 0 || s >= n_src || d < 0 || d >= n_nodes) { bad = true; continue; }   // dropped; reported through *status
+    atomicAdd(&deg[d], 1);
+    if (s != d) atomicAdd(&deg_ns[d], 1);
+    m = max(m, (int)max(s, d) + 1);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+  if (__ballot(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(status, 1);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
+    if (m > 0) atomicMax(maxp1, m);
+  }
+}
+
+__global__ void __launch_bounds__(1024) build_sums_kernel(const int* __restrict__ deg, int n_nodes, int* __restrict__ bsum) {
+  __shared__ int ws[16];
+  const int base = blockIdx.x * BUILD_SCAN_ITEMS + threadIdx.x * 4;
+  int v = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v += (base + k < n_nodes) ? deg[base + k] : 0;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int k = 0; k < 16; ++k) t += ws[k];
+    bsum[blockIdx.x] = t;
+  }
+}
+
+__global__ void __launch_bounds__(1024) build_scan_kernel(const int* __restrict__ deg, int* __restrict__ deg_ns, int n_nodes,
+                                                          int* __restrict__ bsum, int n_blocks, int* __restrict__ rowptr,
+                                                          float* __restrict__ dis_raw, float* __restrict__ dis_looped,
+                                                          int* __restrict__ maxp1, int32_t* __restrict__ max_index) {
+  __shared__ int ws[16];
+  __shared__ int s_prefix;
+  // prefix of the blocks in front of this one: a few hundred values at most, re-added by every block
+  int p = 0;
+  for (int k = threadIdx.x; k < (int)blockIdx.x; k += 1024) p += bsum[k];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) p += __shfl_xor(p, off);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = p;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int k = 0; k < 16; ++k) t += ws[k];
+    s_prefix = t;
+  }
+  __syncthreads();
+  const int base = blockIdx.x * BUILD_SCAN_ITEMS + threadIdx.x * 4;
+  int d[4], dn[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const bool ok = base + k < n_nodes;
+    d[k] = ok ? deg[base + k] : 0;
+    dn[k] = ok ? deg_ns[base + k] : 0;
+  }
+  int mine = d[0] + d[1] + d[2] + d[3];
+  int incl = mine;  // inclusive scan over the wavefront, then over the 16 wavefronts
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off);
+    if ((int)(threadIdx.x & 63) >= off) incl += t;
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 63) ws[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  int wave_off = 0;
+  for (int k = 0; k < (int)(threadIdx.x >> 6); ++k) wave_off += ws[k];
+  int run = s_prefix + wave_off + incl - mine;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (base + k < n_nodes) {
+      rowptr[base + k] = run;
+      if (dis_raw != nullptr) dis_raw[base + k] = d[k] > 0 ? 1.0f / sqrtf((float)d[k]) : 0.0f;
+      if (dis_looped != nullptr) dis_looped[base + k] = 1.0f / sqrtf((float)(dn[k] + 1));
+      deg_ns[base + k] = 0;   // workspace left zero
+    }
+    run += d[k];
+  }
+  if (base <= n_nodes && n_nodes < base + 4) rowptr[n_nodes] = run - 0;   // (run has passed every element < n_nodes of this thread)
+  __syncthreads();
+  if (blockIdx.x == (unsigned)n_blocks - 1 && threadIdx.x == 0) {
+    *max_index = *maxp1 - 1;
+    *maxp1 = 0;
+  }
+}
+
+__global__ void __launch_bounds__(256) build_scatter_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
+                                                            int64_t n_edges, int n_nodes, int n_src, int* __restrict__ deg,
+                                                            const int* __restrict__ rowptr, int* __restrict__ col,
+                                                            int* __restrict__ edge_id, int* __restrict__ bsum, int n_blocks) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_edges; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t s = src[e], d = dst[e];
+    if (s < 0 || s >= n_src || d < 0 || d >= n_nodes) continue;
+    const int slot = atomicSub(&deg[d], 1) - 1;   // counts the degree back down: the counters end at zero
+    const int pos = rowptr[d] + slot;
+    col[pos] = (int)s;
+    edge_id[pos] = (int)e;
+  }
+  if (blockIdx.x == 0)
+    for (int k = threadIdx.x; k < n_blocks; k += blockDim.x) bsum[k] = 0;
+}
+
+// Bitonic sort of np2 (a power of two) (key, value) pairs by one workgroup.  Comparator direction follows the GLOBAL
+// index, so the same routine sorts a whole array (base = 0, np2 = its length) or finishes the small-stride steps of a
+// bigger network inside one LDS-resident chunk (base = the chunk's first index).
+__device__ inline void bitonic_steps(int2* kv, int n, int base, int k, int j_first) {
+  for (int j = j_first; j > 0; j >>= 1) {
+    for (int t = threadIdx.x; t < n; t += blockDim.x) {
+      const int l = t ^ j;
+      if (l > t) {
+        const int2 a = kv[t], b = kv[l];
+        const bool up = ((base + t) & k) == 0;
+        if ((a.x > b.x) == up) { kv[t] = b; kv[l] = a; }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Rows longer than the LDS buffer: chunks of BUILD_LDS_SORT are sorted in LDS, the strides >= BUILD_LDS_SORT of the
+// remaining merge stages run in global memory (one pass each), everything below again chunk by chunk in LDS.
+__device__ inline void bitonic_big(int2* g, int np2, int2* lds) {
+  constexpr int C = BUILD_LDS_SORT;
+  for (int c0 = 0; c0 < np2; c0 += C) {
+    for (int t = threadIdx.x; t < C; t += blockDim.x) lds[t] = g[c0 + t];
+    __syncthreads();
+    for (int k = 2; k <= C; k <<= 1) bitonic_steps(lds, C, c0, k, k >> 1);
+    for (int t = threadIdx.x; t < C; t += blockDim.x) g[c0 + t] = lds[t];
+    __syncthreads();
+  }
+  for (int k = 2 * C; k <= np2; k <<= 1) {
+    for (int j = k >> 1; j >= C; j >>= 1) {
+      for (int i = threadIdx.x; i < np2; i += blockDim.x) {
+        const int l = i ^ j;
+        if (l > i) {
+          const int2 a = g[i], b = g[l];
+          const bool up = (i & k) == 0;
+          if ((a.x > b.x) == up) { g[i] = b; g[l] = a; }
+        }
+      }
+      __syncthreads();
+    }
+    for (int c0 = 0; c0 < np2; c0 += C) {
+      for (int t = threadIdx.x; t < C; t += blockDim.x) lds[t] = g[c0 + t];
+      __syncthreads();
+      bitonic_steps(lds, C, c0, k, C >> 1);
+      for (int t = threadIdx.x; t < C; t += blockDim.x) g[c0 + t] = lds[t];
+      __syncthreads();
+    }
+  }
+}
+
+constexpr int ROWS_PER_BLOCK = 64;
+__global__ void __launch_bounds__(16 * ROWS_PER_BLOCK) build_rows_kernel(int n_nodes, int64_t n_edges, const int* __restrict__ rowptr,
+                                                                         int* __restrict__ col, int* __restrict__ edge_id,
+                                                                         const float* __restrict__ dis_raw,
+                                                                         const float* __restrict__ dis_looped,
+                                                                         float* __restrict__ edis_raw, float* __restrict__ edis_looped,
+                                                                         int32_t* __restrict__ plan, int cap_long, int cap_chunks,
+                                                                         int2* __restrict__ big_scratch) {
+  __shared__ int s_ids[ROWS_PER_BLOCK][EGC_LONG_ROW_THRESHOLD];   // input positions of a short row
+  __shared__ int2 s_sort[BUILD_LDS_SORT];                           // (input position, source) pairs of a long row
+  __shared__ int s_long, s_chunks, s_base_long, s_base_chunk;
+  __shared__ int s_nlong, s_long_row[ROWS_PER_BLOCK];
+  const int sl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int row = blockIdx.x * ROWS_PER_BLOCK + rl;
+  const bool live = row < n_nodes;
+  if (threadIdx.x == 0) { s_long = 0; s_chunks = 0; s_nlong = 0; }
+  __syncthreads();
+  const int start = live ? rowptr[row] : 0, end = live ? rowptr[row + 1] : 0;
+  const int deg = end - start;
+  const bool is_long = live && deg > EGC_LONG_ROW_THRESHOLD;
+  // ---- short rows: rank sort by input position, 16 lanes per row, up to 4 entries per lane ----
+  int my_id[4], my_col[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int p = start + sl + 16 * k;
+    const bool ok = !is_long && p < end;
+    my_id[k] = ok ? edge_id[p] : 0x7fffffff;
+    my_col[k] = ok ? col[p] : 0;
+    if (ok) s_ids[rl][sl + 16 * k] = my_id[k];
+  }
+  // long-row bookkeeping (plan entries as in prepare_kernel)
+  const int nch = is_long ? (deg + EGC_LONG_ROW_CHUNK - 1) / EGC_LONG_ROW_CHUNK : 0;
+  int slot = 0, c0 = 0;
+  if (is_long && sl == 0) {
+    slot = atomicAdd(&s_long, 1);
+    c0 = atomicAdd(&s_chunks, nch);
+    s_long_row[atomicAdd(&s_nlong, 1)] = rl;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && s_long > 0) {
+    s_base_long = atomicAdd(&plan[0], s_long);
+    s_base_chunk = atomicAdd(&plan[1], s_chunks);
+  }
+  if (!is_long) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (sl + 16 * k < deg) {
+        int rank = 0;
+        for (int t = 0; t < deg; ++t) rank += s_ids[rl][t] < my_id[k];
+        const int p = start + rank;
+        col[p] = my_col[k];
+        edge_id[p] = my_id[k];
+        if (edis_raw != nullptr) edis_raw[p] = dis_raw[my_col[k]];
+        if (edis_looped != nullptr) edis_looped[p] = dis_looped[my_col[k]];
+      }
+    }
+  }
+  __syncthreads();
+  if (is_long) {
+    slot = __shfl(slot, threadIdx.x & 48) + s_base_long;
+    c0 = __shfl(c0, threadIdx.x & 48) + s_base_chunk;
+    int32_t* long_row = plan + 4;
+    int32_t* long_chunk0 = long_row + cap_long;
+    int32_t* chunk_slot = long_chunk0 + cap_long;
+    int32_t* chunk_begin = chunk_slot + cap_chunks;
+    if (slot < cap_long && c0 + nch <= cap_chunks) {
+      if (sl == 0) { long_row[slot] = row; long_chunk0[slot] = c0; }
+      for (int k = sl; k < nch; k += 16) { chunk_slot[c0 + k] = slot; chunk_begin[c0 + k] = start + k * EGC_LONG_ROW_CHUNK; }
+    }
+  }
+  // ---- long rows of this block, one at a time, by the whole block ----
+  const int nl = s_nlong;
+  for (int li = 0; li < nl; ++li) {
+    const int r = blockIdx.x * ROWS_PER_BLOCK + s_long_row[li];
+    const int rs = rowptr[r], re = rowptr[r + 1], d = re - rs;
+    int np2 = 1;
+    while (np2 < d) np2 <<= 1;
+    int2* kv = d <= BUILD_LDS_SORT ? s_sort : big_scratch + (int64_t)rs * 2;   // global scratch: 2 x its own range (padding)
+    __syncthreads();
+    for (int i = threadIdx.x; i < np2; i += blockDim.x) kv[i] = i < d ? int2{edge_id[rs + i], col[rs + i]} : int2{0x7fffffff, 0};
+    __syncthreads();
+    if (d <= BUILD_LDS_SORT) {
+      for (int k = 2; k <= np2; k <<= 1) bitonic_steps(kv, np2, 0, k, k >> 1);
+    } else {
+      bitonic_big(kv, np2, s_sort);
+    }
+    for (int i = threadIdx.x; i < d; i += blockDim.x) {
+      const int2 v = kv[i];
+      edge_id[rs + i] = v.x;
+      col[rs + i] = v.y;
+      if (edis_raw != nullptr) edis_raw[rs + i] = dis_raw[v.y];
+      if (edis_looped != nullptr) edis_looped[rs + i] = dis_looped[v.y];
+    }
+  }
+}
+
 __global__ void plan_header_kernel(int32_t* plan, int cap_long, int cap_chunks) {
   plan[0] = 0;
   plan[1] = 0;
@@ -261,6 +542,62 @@ int egc_csr_edge_dis(int64_t n_edges, const int32_t* col, const float* dis_raw, 
   const int blocks = (int)std::min<int64_t>(ceil_div(n_edges, 256), 256 * 8);
   edge_dis_kernel<<<blocks, 256, 0, stream>>>(n_edges, col, dis_raw, dis_looped, edge_dis_raw, edge_dis_looped);
   EGC_LAUNCH_CHECK("edge_dis_kernel");
+  return EGC_OK;
+}
+
+size_t egc_graph_build_workspace_bytes(int64_t n_nodes, int64_t n_edges) {
+  if (n_nodes < 0 || n_edges < 0) return 0;
+  const int64_t nb = ceil_div(n_nodes + 1, (int64_t)BUILD_SCAN_ITEMS);
+  // deg[n + 1] | deg_ns[n] | block sums | max id + 1: zero on entry, ALL of it zero again on exit -- so the next call
+  // may lay a different graph's arrays over the same bytes
+  return align256((size_t)(n_nodes + 1) * 4) + align256((size_t)n_nodes * 4 + 4) + align256((size_t)nb * 4) + 256;
+}
+
+size_t egc_graph_build_scratch_bytes(int64_t n_edges) {
+  if (n_edges < 0) return 0;
+  // sort area of the rows longer than the LDS sort: two (position, source) pairs per entry (power-of-two padding),
+  // indexed by the row's own CSR range; any content on entry, garbage on exit -- hence not part of the workspace
+  return align256((size_t)n_edges * 2 * sizeof(int2)) + 256;
+}
+
+int egc_graph_build(const int64_t* src, const int64_t* dst, int64_t n_edges, int64_t n_nodes, int64_t n_src_rows,
+                    int32_t* rowptr, int32_t* col, int32_t* edge_id, int32_t* max_index, float* dis_raw,
+                    float* dis_looped, float* edge_dis_raw, float* edge_dis_looped, int32_t* plan, int32_t* status,
+                    void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes, egc_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_nodes < 0 || n_edges < 0 || n_nodes >= ((int64_t)1 << 30) || n_edges >= ((int64_t)1 << 30)) return EGC_ERR_INVALID;
+  if (rowptr == nullptr || max_index == nullptr || plan == nullptr || status == nullptr) return EGC_ERR_INVALID;
+  if (n_edges > 0 && (src == nullptr || dst == nullptr || col == nullptr || edge_id == nullptr)) return EGC_ERR_INVALID;
+  if (workspace == nullptr || workspace_bytes < egc_graph_build_workspace_bytes(n_nodes, n_edges)) return EGC_ERR_WORKSPACE;
+  if (scratch == nullptr || scratch_bytes < egc_graph_build_scratch_bytes(n_edges)) return EGC_ERR_WORKSPACE;
+  if (dis_raw == nullptr) edge_dis_raw = nullptr;
+  if (dis_looped == nullptr) edge_dis_looped = nullptr;
+  const int64_t n_src = n_src_rows > 0 ? n_src_rows : n_nodes;
+  const int nb = (int)ceil_div(n_nodes + 1, (int64_t)BUILD_SCAN_ITEMS);
+  char* ws = (char*)workspace;
+  int* deg = (int*)ws;
+  int* deg_ns = (int*)(ws + align256((size_t)(n_nodes + 1) * 4));
+  int* bsum = (int*)((char*)deg_ns + align256((size_t)n_nodes * 4 + 4));
+  int* maxp1 = (int*)((char*)bsum + align256((size_t)nb * 4));
+  int2* big = (int2*)scratch;
+  PlanCaps c = plan_caps(n_nodes, n_edges);
+  plan_header_kernel<<<1, 1, 0, stream>>>(plan, (int)c.cap_long, (int)c.cap_chunks);
+  EGC_LAUNCH_CHECK("plan_header_kernel");
+  const int eblocks = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n_edges, 256), 256 * 8));
+  build_hist_kernel<<<eblocks, 256, 0, stream>>>(src, dst, n_edges, (int)n_nodes, (int)n_src, deg, deg_ns, maxp1, status);
+  EGC_LAUNCH_CHECK("build_hist_kernel");
+  build_sums_kernel<<<nb, 1024, 0, stream>>>(deg, (int)n_nodes, bsum);
+  EGC_LAUNCH_CHECK("build_sums_kernel");
+  build_scan_kernel<<<nb, 1024, 0, stream>>>(deg, deg_ns, (int)n_nodes, bsum, nb, rowptr, dis_raw, dis_looped, maxp1, max_index);
+  EGC_LAUNCH_CHECK("build_scan_kernel");
+  build_scatter_kernel<<<eblocks, 256, 0, stream>>>(src, dst, n_edges, (int)n_nodes, (int)n_src, deg, rowptr, col, edge_id, bsum, nb);
+  EGC_LAUNCH_CHECK("build_scatter_kernel");
+  if (n_nodes > 0) {
+    build_rows_kernel<<<(int)ceil_div(n_nodes, (int64_t)ROWS_PER_BLOCK), 16 * ROWS_PER_BLOCK, 0, stream>>>(
+        (int)n_nodes, n_edges, rowptr, col, edge_id, dis_raw, dis_looped, edge_dis_raw, edge_dis_looped, plan, (int)c.cap_long,
+        (int)c.cap_chunks, big);
+    EGC_LAUNCH_CHECK("build_rows_kernel");
+  }
   return EGC_OK;
 }
 

@@ -81,6 +81,8 @@ class CSRGraph:
         dev = edge_index.device
         ei = edge_index.contiguous()
         n, e = int(num_nodes), int(ei.size(1))
+        if e <= _FAST_BUILD_MAX_EDGES and os.environ.get("EGC_GRAPH_BUILD", "fast") != "sort":
+            return cls._build_fast(ei, n, e, num_src_rows)
         with _device_guard(dev):
             # one int32 slab for everything integer (per-batch graphs: allocator calls and fills cost as much as
             # the kernels): rowptr | col | edge_id | max_index | long-row plan, each piece 16-byte aligned
@@ -99,6 +101,60 @@ class CSRGraph:
                                         edge_id.data_ptr(), max_index.data_ptr(), ws.data_ptr(), ws.numel(),
                                         _stream_ptr(dev)), "egc_coo_to_csr")
             return cls._prepare(n, e, rowptr, col, edge_id, max_index, num_src_rows, plan=plan)
+
+    @classmethod
+    def _build_fast(cls, ei: torch.Tensor, n: int, e: int, num_src_rows) -> "CSRGraph":
+        """egc_graph_build: CSR + degree tables + per-entry deg^-1/2 + long-row plan in ONE library call (five launches,
+        no library sort) -- the per-batch path of the reference's batched nets.  Node ids are range-checked on the
+        device; the flag is read at the graph's next synchronisation point (check_indices)."""
+        lib = _C.load()
+        dev = ei.device
+        ns = n if num_src_rows is None else int(num_src_rows)
+        if ns <= 0 and e > 0:
+            raise RuntimeError("egc_amd: num_src_rows must be positive")
+        square = ns == n
+        with _device_guard(dev):
+            e1 = max(e, 1)
+            plan_ints = int(lib.egc_plan_ints(n, e))
+            sizes = (n + 1, e1, e1, 1, plan_ints, 1)
+            offs, total = [], 0
+            for sz in sizes:
+                offs.append(total)
+                total += (sz + 3) & ~3
+            slab = torch.empty(total, dtype=torch.int32, device=dev)
+            rowptr, col, edge_id, max_index, plan, status = (slab[o:o + sz] for o, sz in zip(offs, sizes))
+            status.zero_()
+            nrow = max(n, ns, 1)
+            nd, ee = (nrow + 3) & ~3, (e1 + 3) & ~3
+            fslab = torch.empty(2 * nd + (2 * ee if square else 0), dtype=torch.float32, device=dev)
+            dis_raw, dis_looped = fslab[:nrow], fslab[nd:nd + nrow]
+            if nrow > n:      # halo entries: filled by their owners later (partition.HaloPlan.exchange)
+                fslab[:2 * nd].zero_()
+            edr = fslab[2 * nd:2 * nd + e1] if square else None
+            edl = fslab[2 * nd + ee:2 * nd + ee + e1] if square else None
+            ws = _build_workspace(dev, int(lib.egc_graph_build_workspace_bytes(n, e)))
+            scratch = torch.empty(int(lib.egc_graph_build_scratch_bytes(e)), dtype=torch.uint8, device=dev)
+            _C.check(lib.egc_graph_build(ei[0].data_ptr(), ei[1].data_ptr(), e, n, ns, rowptr.data_ptr(), col.data_ptr(),
+                                         edge_id.data_ptr(), max_index.data_ptr(), dis_raw.data_ptr(), dis_looped.data_ptr(),
+                                         edr.data_ptr() if edr is not None else None,
+                                         edl.data_ptr() if edl is not None else None, plan.data_ptr(), status.data_ptr(),
+                                         ws.data_ptr(), ws.numel(), scratch.data_ptr(), scratch.numel(), _stream_ptr(dev)),
+                     "egc_graph_build")
+        g = cls(n, e, rowptr, col, edge_id, dis_raw, dis_looped, max_index, plan, ns)
+        g.edge_dis_raw, g.edge_dis_looped = edr, edl
+        g._status = status
+        if os.environ.get("EGC_CHECK_INDICES", "0") not in ("", "0"):
+            g.check_indices()
+        return g
+
+    def check_indices(self) -> "CSRGraph":
+        """Raise if the graph was built from node ids outside [0, N) -- what the reference's PyG path does at
+        ``index_select`` (optimized_layers.py:191-193).  Synchronises; called wherever the graph synchronises anyway
+        (trim_launches: cached layers, adj_t inputs) and on every build under EGC_CHECK_INDICES=1."""
+        st = getattr(self, "_status", None)
+        if st is not None and int(st.item()) != 0:
+            raise RuntimeError("egc_amd: edge_index holds node ids outside [0, num_nodes): index out of range")
+        return self
 
     @classmethod
     def from_partition(cls, edge_index_local: torch.Tensor, plan, global_max_index: int | None = None,
@@ -227,12 +283,28 @@ class CSRGraph:
         many times (``cached=True`` layers, full-graph training); about 4 us per launch at ogbn-arxiv size."""
         if self._n_chunks is None or self._n_chunks < 0:
             self._n_chunks = int(self.plan[1].item())
+            self.check_indices()
         return self
 
     def long_row_stats(self):
         """(n_long_rows, n_chunks) -- synchronises; diagnostics only."""
         h = self.plan[:2].cpu()
         return int(h[0]), int(h[1])
+
+
+_FAST_BUILD_MAX_EDGES = 400_000   # beyond: the radix-sort pipeline (scattered atomics run at ~20 M/s on MI355X: 1.9 M edges took 390 us here against 180 us there)
+_BUILD_WS: "dict[tuple, torch.Tensor]" = {}
+
+
+def _build_workspace(dev, nbytes: int) -> torch.Tensor:
+    """Scratch of egc_graph_build: zero before its first use, left zero by every call -> one buffer per (device,
+    stream), grown (and zeroed again) when a bigger graph comes along."""
+    key = (str(dev), _stream_ptr(dev))
+    ws = _BUILD_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.zeros(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=dev)
+        _BUILD_WS[key] = ws
+    return ws
 
 
 class SparseTensor:

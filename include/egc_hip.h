@@ -112,6 +112,26 @@ int egc_coo_to_csr(const int64_t* src, const int64_t* dst, int64_t n_edges, int6
                    int32_t* rowptr, int32_t* col, int32_t* edge_id, int32_t* max_index,
                    void* workspace, size_t workspace_bytes, egc_stream_t stream);
 
+/* One call for a per-batch graph: COO -> CSR by destination (stable inside a row) + both deg^-1/2 tables + their
+ * per-entry copies + the long-row plan, in five launches and without a library sort -- what egc_coo_to_csr +
+ * egc_csr_prepare + egc_csr_edge_dis produce in a dozen.  Replaces the same reference call sites (per-batch
+ * index handling of MessagePassing.propagate: zinc/models.py:60-74, mol/pna_style_models.py:64-79,
+ * cifar/models.py:61-75; gcn_norm's degree pass).  Node ids are RANGE-CHECKED here: an edge whose source is outside
+ * [0, n_src_rows) or whose destination is outside [0, n_nodes) is dropped and bit 0 of *status (device int32, zeroed
+ * by the caller) is set -- the PyG path behind optimized_layers.py:191-193 raises on such an index; the host side
+ * reads the flag at its next synchronisation point (CSRGraph.check_indices).  rowptr[n_nodes] is then the number
+ * of edges kept.  n_src_rows = 0 means n_nodes.  dis_* / edge_dis_* may be NULL (skipped).
+ * Workspace: egc_graph_build_workspace_bytes() bytes, zero-filled before its FIRST use; every call leaves ALL of it
+ * zero again, so one buffer (of the largest size needed) serves graphs of any size on the same stream.  Scratch:
+ * egc_graph_build_scratch_bytes() bytes, any content (sort area of rows longer than 4096 entries).
+ * Limits: n_nodes, n_edges < 2^30. */
+size_t egc_graph_build_workspace_bytes(int64_t n_nodes, int64_t n_edges);
+size_t egc_graph_build_scratch_bytes(int64_t n_edges);
+int egc_graph_build(const int64_t* src, const int64_t* dst, int64_t n_edges, int64_t n_nodes, int64_t n_src_rows,
+                    int32_t* rowptr, int32_t* col, int32_t* edge_id, int32_t* max_index, float* dis_raw,
+                    float* dis_looped, float* edge_dis_raw, float* edge_dis_looped, int32_t* plan, int32_t* status,
+                    void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes, egc_stream_t stream);
+
 /* Degree statistics + long-row plan for an existing CSR.  Replaces gcn_norm's degree scatter and
  * pow(-0.5) (layers.py:173-178, optimized_layers.py:131-137) -- the per-edge weight
  * dis[src]*dis[dst] is formed inside the aggregate kernel, never materialised.

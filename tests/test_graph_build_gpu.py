@@ -1,0 +1,117 @@
+"""egc_graph_build (five launches, no library sort) against the radix-sort pipeline (egc_coo_to_csr + egc_csr_prepare +
+egc_csr_edge_dis) and the numpy oracle: the CSR must be IDENTICAL -- rowptr, col and edge_id bit for bit (entries of a
+row in input order: torch_scatter's first-edge arg rule depends on it) -- for short rows, rows sorted in LDS, hub rows
+sorted through global memory, duplicates, self loops, empty rows, rectangular source spaces; node ids out of range are
+reported (PyG raises at index_select, optimized_layers.py:191-193)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _both(ei, n, monkeypatch, ns=None):
+    import egc_amd
+    monkeypatch.setenv("EGC_GRAPH_BUILD", "sort")
+    a = egc_amd.CSRGraph.from_edge_index(ei, n, ns)
+    monkeypatch.setenv("EGC_GRAPH_BUILD", "fast")
+    b = egc_amd.CSRGraph.from_edge_index(ei, n, ns)
+    torch.cuda.synchronize()
+    return a, b
+
+
+def _same(a, b, e):
+    assert torch.equal(a.rowptr, b.rowptr)
+    assert torch.equal(a.col[:e], b.col[:e])
+    assert torch.equal(a.edge_id[:e], b.edge_id[:e])
+    assert torch.equal(a.max_index, b.max_index)
+    n = a.n_nodes
+    assert torch.equal(a.dis_raw[:n], b.dis_raw[:n]) and torch.equal(a.dis_looped[:n], b.dis_looped[:n])
+    if a.edge_dis_raw is not None:
+        assert torch.equal(a.edge_dis_raw[:e], b.edge_dis_raw[:e]) and torch.equal(a.edge_dis_looped[:e], b.edge_dis_looped[:e])
+    # the long-row plan: same rows and chunks (slots are handed out by atomics: order may differ)
+    pa, pb = a.plan.cpu().numpy(), b.plan.cpu().numpy()
+    assert list(pa[:4]) == list(pb[:4])
+    nl, nc, cl, cc = (int(v) for v in pa[:4])
+    rows = lambda p: sorted(p[4:4 + nl].tolist())
+    assert rows(pa) == rows(pb)
+    chunks = lambda p: sorted(p[4 + 2 * cl + cc:4 + 2 * cl + cc + nc].tolist())
+    assert chunks(pa) == chunks(pb)
+
+
+@pytest.mark.parametrize("n,e,hubs", [(1, 0, []), (7, 3, []), (300, 2500, []), (2000, 30000, [(5, 700), (17, 100)]),
+                                      (5000, 60000, [(1, 5000), (4000, 9000), (77, 4096), (78, 4097)]),
+                                      (53000, 110000, [])])
+def test_fast_build_is_bit_identical_to_the_sort_pipeline(n, e, hubs, monkeypatch):
+    dev = _dev()
+    rng = np.random.default_rng(n + e)
+    ei = rng.integers(0, n, size=(2, e)).astype(np.int64)
+    at = 0
+    for row, k in hubs:
+        ei[1, at:at + k] = row
+        at += k
+    if e > 100:
+        ei[0, -50:] = ei[1, -50:]                 # self loops
+        ei[:, -100:-50] = ei[:, -150:-100]        # duplicates
+    ei = ei[:, rng.permutation(e)] if e else ei
+    a, b = _both(torch.from_numpy(ei).to(dev), n, monkeypatch)
+    _same(a, b, e)
+    # and the oracle's stable order
+    order = np.argsort(ei[1], kind="stable")
+    assert np.array_equal(b.edge_id[:e].cpu().numpy(), order.astype(np.int32))
+    assert np.array_equal(b.col[:e].cpu().numpy(), ei[0][order].astype(np.int32))
+    b.check_indices()
+
+
+def test_fast_build_twice_on_one_workspace_and_rectangular_sources(monkeypatch):
+    dev = _dev()
+    rng = np.random.default_rng(3)
+    for n, ns, e in [(400, 1000, 5000), (900, 120, 7000), (400, 1000, 5000)]:
+        ei = np.stack([rng.integers(0, ns, size=e), rng.integers(0, n, size=e)]).astype(np.int64)
+        a, b = _both(torch.from_numpy(ei).to(dev), n, monkeypatch, ns)
+        _same(a, b, e)
+
+
+def test_out_of_range_ids_are_reported(monkeypatch):
+    import egc_amd
+    dev = _dev()
+    monkeypatch.setenv("EGC_GRAPH_BUILD", "fast")
+    n = 50
+    ei = torch.randint(0, n, (2, 400), device=dev)
+    good = egc_amd.CSRGraph.from_edge_index(ei, n).check_indices()
+    assert int(good.rowptr[-1]) == 400
+    for bad_row, bad_val in [(0, n), (1, n + 3), (0, -1), (1, -7)]:
+        bad = ei.clone()
+        bad[bad_row, 17] = bad_val
+        g = egc_amd.CSRGraph.from_edge_index(bad, n)
+        with pytest.raises(RuntimeError, match="out of range"):
+            g.check_indices()
+        assert int(g.rowptr[-1]) == 399           # the offending edge is dropped, nothing is read out of bounds
+        with pytest.raises(RuntimeError, match="out of range"):
+            egc_amd.CSRGraph.from_edge_index(bad, n).trim_launches()
+    # the workspace survives a faulty build: the next graph is right
+    again = egc_amd.CSRGraph.from_edge_index(ei, n).check_indices()
+    assert torch.equal(again.rowptr, good.rowptr) and torch.equal(again.col, good.col)
+    monkeypatch.setenv("EGC_CHECK_INDICES", "1")
+    bad = ei.clone()
+    bad[0, 0] = 10 ** 9
+    with pytest.raises(RuntimeError, match="out of range"):
+        egc_amd.CSRGraph.from_edge_index(bad, n)
+
+
+def test_graphs_of_different_sizes_share_one_workspace(monkeypatch):
+    """Regression: the sort area of hub rows is NOT part of the zero-on-exit workspace -- a small graph with a hub row
+    followed by a larger graph (whose degree counters overlay the bytes the first one used) must come out right."""
+    dev = _dev()
+    rng = np.random.default_rng(9)
+    for n, ns, e, hub in [(1200, 14000, 140000, 9000), (14000, 1200, 140000, 0), (300, 300, 60000, 30000), (50000, 50000, 100000, 0)]:
+        ei = np.stack([rng.integers(0, ns, size=e), rng.integers(0, n, size=e)]).astype(np.int64)
+        if hub:
+            ei[1, :hub] = 7
+        a, b = _both(torch.from_numpy(ei).to(dev), n, monkeypatch, ns)
+        _same(a, b, e)
