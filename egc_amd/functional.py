@@ -547,6 +547,9 @@ def egc_aggregate_combine_apply(graph, spec, bases, weightings, bias=None):
 
 
 def egc_layer_apply(graph, spec, x, wcat, bcat, bias, packed=None):
+    from . import ops   # torch.library registration of the same call (egc_amd/ops.py)
+    if ops.use_torch_op():
+        return ops.layer_apply_op(graph, spec, x, wcat, bcat, bias)
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, wcat, bcat, bias)):
         return _EGCLayerFunction.apply(x, wcat, bcat, bias, graph, spec)
     return egc_layer_forward(graph, spec, x, wcat, bcat, bias, packed=packed)
