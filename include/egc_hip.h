@@ -114,11 +114,11 @@ int egc_coo_to_csr(const int64_t* src, const int64_t* dst, int64_t n_edges, int6
 
 /* One call for a per-batch graph: COO -> CSR by destination (stable inside a row) + both deg^-1/2 tables + their
  * per-entry copies + the long-row plan, in five launches and without a library sort -- what egc_coo_to_csr +
- * egc_csr_prepare + egc_csr_edge_dis produce in a dozen.  Replaces the same reference call sites (per-batch
+ * egc_csr_prepare + egc_csr_edge_dis produce in a dozen (five launches: histogram, block sums, scan, scatter, rows).  Replaces the same reference call sites (per-batch
  * index handling of MessagePassing.propagate: zinc/models.py:60-74, mol/pna_style_models.py:64-79,
  * cifar/models.py:61-75; gcn_norm's degree pass).  Node ids are RANGE-CHECKED here: an edge whose source is outside
- * [0, n_src_rows) or whose destination is outside [0, n_nodes) is dropped and bit 0 of *status (device int32, zeroed
- * by the caller) is set -- the PyG path behind optimized_layers.py:191-193 raises on such an index; the host side
+ * [0, n_src_rows) or whose destination is outside [0, n_nodes) is dropped and *status (device int32, written by
+ * every call: 0 or 1) is set -- the PyG path behind optimized_layers.py:191-193 raises on such an index; the host side
  * reads the flag at its next synchronisation point (CSRGraph.check_indices).  rowptr[n_nodes] is then the number
  * of edges kept.  n_src_rows = 0 means n_nodes.  dis_* / edge_dis_* may be NULL (skipped).
  * Workspace: egc_graph_build_workspace_bytes() bytes, zero-filled before its FIRST use; every call leaves ALL of it

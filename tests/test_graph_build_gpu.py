@@ -115,3 +115,22 @@ def test_graphs_of_different_sizes_share_one_workspace(monkeypatch):
             ei[1, :hub] = 7
         a, b = _both(torch.from_numpy(ei).to(dev), n, monkeypatch, ns)
         _same(a, b, e)
+
+
+@pytest.mark.parametrize("kind", ["molecules", "knn", "sorted_by_dst_with_a_hub"])
+def test_fast_build_on_graph_contiguous_batches(kind, monkeypatch):
+    """The LDS-windowed tiles (destinations of 2048 consecutive edges within 2048 rows): batches of small graphs, kNN
+    lists sorted by destination, and a sorted list with a hub row that spans many tiles."""
+    from egc_amd.workloads import knn_superpixel_batch, molecule_batch
+    dev = _dev()
+    if kind == "molecules":
+        ei, n, _ = molecule_batch(600, seed=2)
+    elif kind == "knn":
+        ei, n, _ = knn_superpixel_batch(300, seed=2)
+    else:
+        rng = np.random.default_rng(4)
+        n = 30000
+        dst = np.sort(np.concatenate([rng.integers(0, n, size=150000), np.full(20000, 12345)]))
+        ei = torch.from_numpy(np.stack([rng.integers(0, n, size=dst.size), dst]).astype(np.int64))
+    a, b = _both(ei.to(dev), n, monkeypatch)
+    _same(a, b, int(ei.size(1)))
