@@ -11,6 +11,8 @@ layer = egc_amd.EGConv(128, 128, aggrs=["sum", "mean", "max", "symnorm"]).to(dev
 x = torch.randn(n, 128, device=dev, requires_grad=True)
 go = torch.randn(n, 128, device=dev)
 def fwd_bwd():
+    layer.zero_grad(set_to_none=True)   # as the reference's loops do every step (zinc/configs.py:64-67)
+    x.grad = None
     out = layer(x, g)
     out.backward(go)
 for _ in range(3): fwd_bwd()
