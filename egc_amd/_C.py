@@ -93,6 +93,9 @@ SYMBOLS = {
     "egc_aggregate_combine_strided_f32": (C.c_int, [C.POINTER(EgcGraph), C.POINTER(EgcLayer), C.c_void_p, C.c_int32,
                                                     C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(EgcPost), C.c_void_p,
                                                     C.c_void_p, C.c_size_t, C.c_void_p]),
+    "egc_weight_grad_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
+    "egc_weight_grad_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "egc_column_sums_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "egc_segment_mean_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "egc_train_stats_floats": (C.c_int64, [C.POINTER(EgcLayer)]),

@@ -1,0 +1,309 @@
+// Weight gradient of the layer's two Linear maps: out[F][K] = x^T @ d, with x [N][F] the layer input and
+// d [N][K] = [d_bases | d_weightings] (what autograd computes for the reference's `torch.matmul(x, bases_weight)` and
+// `comb_weights(x)`: experiments/optimized_layers.py:177-178), and in the same pass the column sums of d (the
+// gradient of comb_weights' bias).
+//
+// The reduction runs over the N rows, the output is tiny (128 x 192 at config 2): a split over row ranges.  Every
+// workgroup keeps one whole output tile (up to 128 x 192) in accumulators, streams its row range through a
+// double-buffered LDS tile of 32 rows (global -> registers -> LDS, the loads of two tiles in flight while one is
+// multiplied), and multiplies on v_mfma_f32_16x16x4_f32: exact fp32 products and sums, no operand splitting and --
+// because that form takes ONE element per lane (A[m = lane % 16][k = lane / 16]) -- no transposition of x on the way
+// from its row-major rows.  Partial tiles (and the partial column sums behind them) go to a workspace; a second
+// small launch adds them in a fixed order (deterministic, unlike float atomics).
+//
+// Bound: matrix cores.  2 N F K flops at 64 FLOP/clk/SIMD (MI355X_MICROARCH.md: 157 TFLOP/s fp32 MFMA) = 53 us at
+// config 2 (N = 169,343, F = 128, K = 192); the operands are 217 MB = 27 us of HBM time, so the stream hides behind
+// the MFMAs.  Measured on MI355X: 87 us + 6 us for the reduction (96 TFLOP/s in the main kernel; the same loop on
+// LDS-resident data without loads reaches 122-132, a bare MFMA loop 150), against 85 + 8 + 15 + 8 us for the
+// library's split batched GEMM, its sum, and the separate column-sum pass this call replaces.  Shapes that need
+// several output tiles (F > 128 or K > 192) re-read the operands once per tile; the host routes the large ones to
+// the library GEMM (egc_amd/functional.py).
+#include <stdlib.h>
+
+#include "egc_common.h"
+
+namespace egc {
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int XT_WM = 2;  // wavefronts along the output rows (F) of a block tile
+
+constexpr int xt_pitch(int cols) { return cols + ((cols % 64) == 0 ? 16 : 48); }  // pitch % 64 == 16: the 4 k-rows of a fragment hit 64 distinct banks
+
+// MT x NT: 16 x 16 output tiles per wavefront; XT_WM x WN wavefronts per workgroup (block tile 32 MT rows of F by
+// 16 NT WN columns of K); XT_ROWS rows of the reduction per LDS stage
+template <int MT, int NT, int WN, int XT_ROWS>
+__global__ void __launch_bounds__(64 * XT_WM * WN) xt_gemm_kernel(const float* __restrict__ x, int64_t ldx, int F,
+                                                             const float* __restrict__ d, int64_t ldd, int K,
+                                                             int64_t n_rows, int64_t rows_per_chunk, int n_chunks,
+                                                             int out_m, int out_n,
+                                                             float* __restrict__ partial, int want_sums) {
+  constexpr int XT_THREADS = 64 * XT_WM * WN;
+  constexpr int TM = 16 * XT_WM * MT, TN = 16 * WN * NT, COLS = TM + TN, P = xt_pitch(COLS);
+  extern __shared__ float lds[];  // [2][XT_ROWS][P]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave % XT_WM, wn = wave / XT_WM;
+  const int m = lane & 15, kk = lane >> 4;
+  // workgroup id -> (row range, output tile): the tiles of one row range sit on ONE XCD (ids 8 apart) and are
+  // dispatched together, so the range's rows are fetched from HBM once and re-read from that XCD's L2
+  const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+  const int tile_id = rest % (out_m * out_n), chunk = (rest / (out_m * out_n)) * 8 + xcd;
+  if (chunk >= n_chunks) return;
+  const int m_tile = tile_id % out_m, n_tile = tile_id / out_m;
+  const int m0 = m_tile * TM, n0 = n_tile * TN;
+  const int64_t row_begin = (int64_t)chunk * rows_per_chunk;
+  const int64_t row_end = row_begin + rows_per_chunk < n_rows ? row_begin + rows_per_chunk : n_rows;
+  const int n_tiles = row_end > row_begin ? (int)((row_end - row_begin + XT_ROWS - 1) / XT_ROWS) : 0;
+
+  // what this thread stages per tile: LOADS float4 pieces (row r, column piece c4) of [x tile | d tile], through
+  // buffer loads over the workgroup's row range: rows past the range and masked pieces read as zeros without a
+  // branch, so the loads of two tiles stay in flight behind counted waits
+  const int64_t range_rows = row_end > row_begin ? row_end - row_begin : 0;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(x + row_begin * ldx), 0, (unsigned)(range_rows * ldx * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(d + row_begin * ldd), 0, (unsigned)(range_rows * ldd * 4), 0x00020000);
+  constexpr unsigned XT_OOB = 0xFFFFFFF0u;
+  constexpr int AX4 = TM / 4, BD4 = TN / 4;  // float4 pieces per row of the x tile / the d tile
+  constexpr int LX = (XT_ROWS * AX4 + XT_THREADS - 1) / XT_THREADS, LD = (XT_ROWS * BD4 + XT_THREADS - 1) / XT_THREADS;
+  unsigned off_x[LX], off_d[LD];
+  int lds_x[LX], lds_d[LD];
+#pragma unroll
+  for (int i = 0; i < LX; ++i) {
+    const int idx = t + i * XT_THREADS, r = idx / AX4, c4 = idx - r * AX4;
+    const bool in_tile = idx < XT_ROWS * AX4;
+    off_x[i] = (in_tile && m0 + 4 * c4 < F) ? (unsigned)((r * ldx + m0 + 4 * c4) * 4) : XT_OOB;
+    lds_x[i] = in_tile ? r * P + 4 * c4 : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < LD; ++i) {
+    const int idx = t + i * XT_THREADS, r = idx / BD4, c4 = idx - r * BD4;
+    const bool in_tile = idx < XT_ROWS * BD4;
+    off_d[i] = (in_tile && n0 + 4 * c4 < K) ? (unsigned)((r * ldd + n0 + 4 * c4) * 4) : XT_OOB;
+    lds_d[i] = in_tile ? r * P + TM + 4 * c4 : -1;
+  }
+  const unsigned step_x = (unsigned)(XT_ROWS * ldx * 4), step_d = (unsigned)(XT_ROWS * ldd * 4);
+  // staging registers: two tiles ahead of the one being multiplied (an HBM round trip under load is longer than one
+  // tile's MFMAs).  A masked piece keeps its out-of-range offset; live ones stay below 4 GiB (checked by the host).
+  struct Stage { f4 x[LX]; f4 d[LD]; };
+  Stage st0, st1;
+  auto fetch = [&](int tile, Stage& st) {
+#pragma unroll
+    for (int i = 0; i < LX; ++i) {
+      const unsigned o = off_x[i] == XT_OOB ? XT_OOB : off_x[i] + (unsigned)tile * step_x;
+      st.x[i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, o, 0, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < LD; ++i) {
+      const unsigned o = off_d[i] == XT_OOB ? XT_OOB : off_d[i] + (unsigned)tile * step_d;
+      st.d[i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rd, o, 0, 0));
+    }
+  };
+  auto put = [&](int buf, const Stage& st) {
+    float* base = lds + buf * (XT_ROWS * P);
+#pragma unroll
+    for (int i = 0; i < LX; ++i)
+      if (lds_x[i] >= 0) *reinterpret_cast<f4*>(base + lds_x[i]) = st.x[i];
+#pragma unroll
+    for (int i = 0; i < LD; ++i)
+      if (lds_d[i] >= 0) *reinterpret_cast<f4*>(base + lds_d[i]) = st.d[i];
+  };
+
+  f4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+  float cs[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) cs[j] = 0.f;
+
+  const int a_col = wm * (16 * MT) + m, b_col = TM + wn * (16 * NT) + m;
+  auto multiply = [&](int bufi) {
+    const float* buf = lds + bufi * (XT_ROWS * P) + kk * P;
+#pragma unroll
+    for (int s = 0; s < XT_ROWS / 4; ++s) {
+      float a[MT], b[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a[i] = buf[s * 4 * P + a_col + 16 * i];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) b[j] = buf[s * 4 * P + b_col + 16 * j];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) cs[j] += b[j];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  fetch(0, st0);
+  put(0, st0);
+  fetch(1, st0);
+  fetch(2, st1);
+  __syncthreads();
+  for (int tile = 0; tile < n_tiles; tile += 2) {  // n_tiles is uniform over the workgroup
+    multiply(0);
+    put(1, st0);
+    fetch(tile + 3, st0);
+    __syncthreads();
+    if (tile + 1 < n_tiles) multiply(1);
+    put(0, st1);
+    fetch(tile + 4, st1);
+    __syncthreads();
+  }
+
+  // partial tile: accumulator register r of tile (i, j) is output row 16 i + 4 (lane / 16) + r, column 16 j + lane % 16
+  const int64_t record = (int64_t)F * K + K;  // the chunk's tile, then its column sums
+  float* out = partial + (int64_t)chunk * record;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = n0 + wn * (16 * NT) + 16 * j + m;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * (16 * MT) + 16 * i + 4 * kk + r;
+        if (row < F && col < K) out[(int64_t)row * K + col] = acc[i][j][r];
+      }
+    }
+  if (want_sums && m_tile == 0 && wm == 0) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      float v = cs[j];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      const int col = n0 + wn * (16 * NT) + 16 * j + m;
+      if (kk == 0 && col < K) out[(int64_t)F * K + col] = v;
+    }
+  }
+}
+
+// out[i] = sum over chunks of partial[c][i], four floats per thread, 16 threads per output piece each adding every
+// 16th chunk (all loads of a thread in flight at once), then a tree over the 16.  A chunk's record is the F x K tile
+// followed by the K column sums; pieces past `fk` floats go to `sums`.
+__global__ void __launch_bounds__(256) xt_reduce_kernel(const float* __restrict__ partial, int64_t record, int64_t fk,
+                                                        int chunks, float* __restrict__ out, float* __restrict__ sums) {
+  __shared__ f4 red[256];
+  const int t = threadIdx.x, o = t & 15, g = t >> 4;
+  const int64_t piece = (int64_t)blockIdx.x * 16 + o;
+  const int64_t pieces = (sums != nullptr ? record : fk) / 4, stride = record / 4;
+  f4 s = f4{0.f, 0.f, 0.f, 0.f};
+  if (piece < pieces) {
+    const f4* p = reinterpret_cast<const f4*>(partial) + piece;
+#pragma unroll 8
+    for (int c = g; c < chunks; c += 16) s += p[(int64_t)c * stride];
+  }
+  red[t] = s;
+  __syncthreads();
+#pragma unroll
+  for (int w = 128; w >= 16; w >>= 1) {
+    if (t < w) red[t] += red[t + w];
+    __syncthreads();
+  }
+  if (t < 16 && piece < pieces) {
+    if (piece < fk / 4) reinterpret_cast<f4*>(out)[piece] = red[t];
+    else reinterpret_cast<f4*>(sums)[piece - fk / 4] = red[t];
+  }
+}
+
+struct XtPlan {
+  int mt, nt, m_tiles, n_tiles, chunks;
+  int64_t rows_per_chunk;
+};
+
+constexpr int XT_WN = 4;     // wavefronts along the output columns (K): 8 wavefronts per workgroup, one workgroup per CU
+constexpr int XT_STAGE = 32;  // rows of the reduction per LDS stage
+
+XtPlan xt_plan(int64_t n_rows, int F, int K) {
+  // tile shape: modelled time per row of the reduction = the larger of the MFMA time of the padded tile grid
+  // (157 flop/ps) and the operand bytes every output tile re-reads (6 B/ps), plus a quarter of the smaller
+  static const int mts[] = {1, 2, 4}, nts[] = {1, 2, 3};
+  XtPlan p{};
+  double best = 1e300;
+  for (int mt : mts)
+    for (int nt : nts) {
+      const int64_t mtl = ceil_div(F, 32 * mt), ntl = ceil_div(K, 64 * nt);
+      const double mfma = 2.0 * (double)(mtl * 32 * mt) * (double)(ntl * 64 * nt) / 157.0;
+      const double mem = 4.0 * (double)(mtl * ntl * (32 * mt + 64 * nt)) / 6.0;
+      const double cost = (mfma > mem ? mfma : mem) + 0.25 * (mfma > mem ? mem : mfma);
+      if (cost < best) {
+        best = cost;
+        p.mt = mt;
+        p.nt = nt;
+        p.m_tiles = (int)mtl;
+        p.n_tiles = (int)ntl;
+      }
+    }
+  const int64_t tiles = (int64_t)p.m_tiles * p.n_tiles;
+  int64_t chunks = ceil_div(256, tiles);
+  const int64_t max_chunks = ceil_div(n_rows > 0 ? n_rows : 1, XT_STAGE);
+  if (chunks > max_chunks) chunks = max_chunks;
+  p.rows_per_chunk = ceil_div(ceil_div(n_rows > 0 ? n_rows : 1, chunks), XT_STAGE) * XT_STAGE;
+  p.chunks = (int)ceil_div(n_rows > 0 ? n_rows : 1, p.rows_per_chunk);
+  return p;
+}
+
+template <int MT, int NT, int WN, int ROWS>
+int launch_xt(const XtPlan& p, const float* x, int64_t ldx, int F, const float* d, int64_t ldd, int K, int64_t n_rows,
+              float* partial, int want_sums, hipStream_t stream) {
+  constexpr int lds_bytes = 2 * ROWS * xt_pitch(16 * XT_WM * MT + 16 * WN * NT) * 4;
+  static bool configured = false;
+  if (!configured) {
+    EGC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&xt_gemm_kernel<MT, NT, WN, ROWS>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    configured = true;
+  }
+  const unsigned grid = (unsigned)(ceil_div(p.chunks, 8) * 8 * p.m_tiles * p.n_tiles);
+  xt_gemm_kernel<MT, NT, WN, ROWS><<<grid, 64 * XT_WM * WN, lds_bytes, stream>>>(
+      x, ldx, F, d, ldd, K, n_rows, p.rows_per_chunk, p.chunks, p.m_tiles, p.n_tiles, partial, want_sums);
+  EGC_LAUNCH_CHECK("xt_gemm_kernel");
+  return EGC_OK;
+}
+
+}  // namespace
+}  // namespace egc
+
+extern "C" {
+
+int64_t egc_weight_grad_workspace_bytes(int64_t n_rows, int32_t f_in, int32_t k_cols) {
+  if (n_rows < 0 || f_in <= 0 || k_cols <= 0) return 0;
+  const egc::XtPlan p = egc::xt_plan(n_rows, f_in, k_cols);
+  return (int64_t)p.chunks * ((int64_t)f_in * k_cols + k_cols) * 4;
+}
+
+int egc_weight_grad_f32(const float* x, int64_t ldx, const float* d, int64_t ldd, int64_t n_rows, int32_t f_in,
+                        int32_t k_cols, float* out, float* col_sums, void* workspace, int64_t workspace_bytes,
+                        void* stream_) {
+  using namespace egc;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_rows < 0 || f_in <= 0 || k_cols <= 0 || out == nullptr) return EGC_ERR_INVALID;
+  if ((f_in % 4) || (k_cols % 4) || (ldx % 4) || (ldd % 4) || ((uintptr_t)x % 16) || ((uintptr_t)d % 16) ||
+      ((uintptr_t)out % 16) || ((uintptr_t)col_sums % 16) || ((uintptr_t)workspace % 16))
+    return EGC_ERR_UNSUPPORTED;
+  if (workspace_bytes < egc_weight_grad_workspace_bytes(n_rows, f_in, k_cols) || workspace == nullptr)
+    return EGC_ERR_INVALID;
+  const XtPlan p = xt_plan(n_rows, f_in, k_cols);
+  // 32-bit buffer offsets inside a workgroup's row range (plus the look-ahead past its end)
+  if ((double)(p.rows_per_chunk + 160) * (double)(ldx > ldd ? ldx : ldd) * 4.0 >= 4.0e9) return EGC_ERR_UNSUPPORTED;
+  const int64_t fk = (int64_t)f_in * k_cols;
+  float* partial = static_cast<float*>(workspace);
+  const int want_sums = col_sums != nullptr;
+  int rc = EGC_ERR_UNSUPPORTED;
+#define EGC_XT_CASE(MT, NT) \
+  if (p.mt == MT && p.nt == NT) rc = launch_xt<MT, NT, XT_WN, XT_STAGE>(p, x, ldx, f_in, d, ldd, k_cols, n_rows, partial, want_sums, stream);
+  EGC_XT_CASE(1, 1) EGC_XT_CASE(1, 2) EGC_XT_CASE(1, 3)
+  EGC_XT_CASE(2, 1) EGC_XT_CASE(2, 2) EGC_XT_CASE(2, 3)
+  EGC_XT_CASE(4, 1) EGC_XT_CASE(4, 2) EGC_XT_CASE(4, 3)
+#undef EGC_XT_CASE
+  if (rc != EGC_OK) return rc;
+  const int64_t record = fk + k_cols;
+  xt_reduce_kernel<<<(unsigned)ceil_div((want_sums ? record : fk) / 4, 16), 256, 0, stream>>>(partial, record, fk, p.chunks,
+                                                                                            out, col_sums);
+  EGC_LAUNCH_CHECK("xt_reduce_kernel");
+  return EGC_OK;
+}
+
+}  // extern "C"

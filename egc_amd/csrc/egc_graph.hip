@@ -182,6 +182,8 @@ __global__ void __launch_bounds__(256) edge_dis_kernel(int64_t n_edges, const in
 // =============================================================================================
 constexpr int BUILD_SCAN_ITEMS = 4096;   // elements per scan block (1024 threads x 4)
 constexpr int BUILD_LDS_SORT = 4096;     // longest row sorted in LDS
+constexpr int BUILD_WAVE_ROW = BUILD_LDS_SORT / 16;  // longest row sorted by ONE wavefront (16 per workgroup)
+constexpr int BUILD_RANK_ROW = 1024;     // longest row rank-sorted by the workgroup (one entry per thread)
 
 constexpr int BUILD_TILE = 2048;   // edges per workgroup of the histogram / scatter kernels (256 threads x 8)
 constexpr int BUILD_WIN = 2048;    // destination window a tile may span to be counted in LDS
@@ -228,9 +230,13 @@ __device__ inline TileEdges load_tile(const int64_t* __restrict__ src, const int
 __global__ void __launch_bounds__(256) build_hist_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
                                                          int64_t n_edges, int n_nodes, int n_src, int* __restrict__ deg,
                                                          int* __restrict__ deg_ns, int* __restrict__ maxp1,
-                                                         int* __restrict__ status) {
+                                                         int* __restrict__ status, int32_t* __restrict__ plan,
+                                                         int cap_long, int cap_chunks) {
   __shared__ int s_cnt[BUILD_WIN], s_ns[BUILD_WIN];
   __shared__ int s_min, s_max, s_top;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // header of the long-row plan: the scan kernel registers the long rows
+    plan[0] = 0; plan[1] = 0; plan[2] = cap_long; plan[3] = cap_chunks;
+  }
   const TileEdges t = load_tile(src, dst, n_edges, n_nodes, n_src, &s_min, &s_max);
   if (__ballot(t.bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(status, 1);
   if (t.dmin > t.dmax) return;
@@ -336,6 +342,11 @@ __global__ void __launch_bounds__(1024) build_scan_kernel(const int* __restrict_
       if (dis_raw != nullptr) dis_raw[base + k] = d[k] > 0 ? 1.0f / sqrtf((float)d[k]) : 0.0f;
       if (dis_looped != nullptr) dis_looped[base + k] = 1.0f / sqrtf((float)(dn[k] + 1));
       deg_ns[base + k] = 0;   // workspace left zero
+      if (d[k] > EGC_LONG_ROW_THRESHOLD) {  // long row: a slot of the plan and a run of chunk slots (entries: rows kernel)
+        const int slot = atomicAdd(&plan[0], 1);
+        const int c0 = atomicAdd(&plan[1], (d[k] + EGC_LONG_ROW_CHUNK - 1) / EGC_LONG_ROW_CHUNK);
+        if (slot < cap_long) { plan[4 + slot] = base + k; plan[4 + cap_long + slot] = c0; }
+      }
     }
     run += d[k];
   }
@@ -344,7 +355,6 @@ __global__ void __launch_bounds__(1024) build_scan_kernel(const int* __restrict_
   if (blockIdx.x == (unsigned)n_blocks - 1 && threadIdx.x == 0) {
     *max_index = *maxp1 - 1;
     *maxp1 = 0;
-    plan[0] = 0; plan[1] = 0; plan[2] = cap_long; plan[3] = cap_chunks;   // header of the long-row plan (rows kernel fills it)
   }
 }
 
@@ -443,6 +453,53 @@ __device__ inline void bitonic_big(int2* g, int np2, int2* lds) {
   }
 }
 
+// Rows of BUILD_LDS_SORT < d <= BUILD_MERGE_ROW entries, by one workgroup: chunks of BUILD_LDS_SORT sorted in LDS (no
+// padding of the whole row to a power of two), then every entry's final place = its index in its own chunk + its
+// lower bounds in the other chunks, found by binary search with ONE chunk's keys resident in LDS at a time (keys are
+// input positions: unique).  g: scratch of 2 d int2 (sorted chunks, then d ranks).  Quadratic in the chunk count,
+// hence the cap; longer rows take the bitonic network.
+constexpr int BUILD_MERGE_ROW = 65536;
+__device__ inline void merge_sort_big(int2* g, int d, int2* lds, int* edge_id_row, int* col_row, const float* dis_raw,
+                                      const float* dis_looped, float* edis_raw_row, float* edis_looped_row) {
+  constexpr int C = BUILD_LDS_SORT;
+  int* rank = reinterpret_cast<int*>(g + d);
+  int* keys = reinterpret_cast<int*>(lds);
+  for (int c0 = 0; c0 < d; c0 += C) {
+    const int len = min(C, d - c0);
+    int np2 = 1;
+    while (np2 < len) np2 <<= 1;
+    for (int t = threadIdx.x; t < np2; t += blockDim.x) lds[t] = t < len ? int2{edge_id_row[c0 + t], col_row[c0 + t]} : int2{0x7fffffff, 0};
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1) bitonic_steps(lds, np2, 0, k, k >> 1);
+    for (int t = threadIdx.x; t < len; t += blockDim.x) { g[c0 + t] = lds[t]; rank[c0 + t] = t; }
+    __syncthreads();
+  }
+  for (int c0 = 0; c0 < d; c0 += C) {
+    const int len = min(C, d - c0);
+    for (int t = threadIdx.x; t < len; t += blockDim.x) keys[t] = g[c0 + t].x;
+    __syncthreads();
+    for (int i = threadIdx.x; i < d; i += blockDim.x) {
+      if (i >= c0 && i < c0 + len) continue;
+      const int key = g[i].x;
+      int lo = 0, hi = len;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (keys[mid] < key) lo = mid + 1; else hi = mid;
+      }
+      rank[i] += lo;
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < d; i += blockDim.x) {
+    const int2 v = g[i];
+    const int p = rank[i];
+    edge_id_row[p] = v.x;
+    col_row[p] = v.y;
+    if (edis_raw_row != nullptr) edis_raw_row[p] = dis_raw[v.y];
+    if (edis_looped_row != nullptr) edis_looped_row[p] = dis_looped[v.y];
+  }
+}
+
 constexpr int ROWS_PER_BLOCK = 64;
 __global__ void __launch_bounds__(16 * ROWS_PER_BLOCK) build_rows_kernel(int n_nodes, int64_t n_edges, const int* __restrict__ rowptr,
                                                                          int* __restrict__ col, int* __restrict__ edge_id,
@@ -454,17 +511,13 @@ __global__ void __launch_bounds__(16 * ROWS_PER_BLOCK) build_rows_kernel(int n_n
                                                                          int32_t* __restrict__ status) {
   __shared__ int s_ids[ROWS_PER_BLOCK][EGC_LONG_ROW_THRESHOLD];   // input positions of a short row
   __shared__ int2 s_sort[BUILD_LDS_SORT];                           // (input position, source) pairs of a long row
-  __shared__ int s_long, s_chunks, s_base_long, s_base_chunk;
-  __shared__ int s_nlong, s_long_row[ROWS_PER_BLOCK];
   const int sl = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int row = blockIdx.x * ROWS_PER_BLOCK + rl;
   const bool live = row < n_nodes;
-  if (threadIdx.x == 0) { s_long = 0; s_chunks = 0; s_nlong = 0; }
   if (blockIdx.x == 0 && threadIdx.x == 0) {   // the range-check flag leaves the (zero-on-exit) workspace
     *status = *ws_status;
     *ws_status = 0;
   }
-  __syncthreads();
   const int start = live ? rowptr[row] : 0, end = live ? rowptr[row + 1] : 0;
   const int deg = end - start;
   const bool is_long = live && deg > EGC_LONG_ROW_THRESHOLD;
@@ -478,19 +531,7 @@ __global__ void __launch_bounds__(16 * ROWS_PER_BLOCK) build_rows_kernel(int n_n
     my_col[k] = ok ? col[p] : 0;
     if (ok) s_ids[rl][sl + 16 * k] = my_id[k];
   }
-  // long-row bookkeeping (plan entries as in prepare_kernel)
-  const int nch = is_long ? (deg + EGC_LONG_ROW_CHUNK - 1) / EGC_LONG_ROW_CHUNK : 0;
-  int slot = 0, c0 = 0;
-  if (is_long && sl == 0) {
-    slot = atomicAdd(&s_long, 1);
-    c0 = atomicAdd(&s_chunks, nch);
-    s_long_row[atomicAdd(&s_nlong, 1)] = rl;
-  }
   __syncthreads();
-  if (threadIdx.x == 0 && s_long > 0) {
-    s_base_long = atomicAdd(&plan[0], s_long);
-    s_base_chunk = atomicAdd(&plan[1], s_chunks);
-  }
   if (!is_long) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -505,32 +546,82 @@ __global__ void __launch_bounds__(16 * ROWS_PER_BLOCK) build_rows_kernel(int n_n
       }
     }
   }
-  __syncthreads();
-  if (is_long) {
-    slot = __shfl(slot, threadIdx.x & 48) + s_base_long;
-    c0 = __shfl(c0, threadIdx.x & 48) + s_base_chunk;
-    int32_t* long_row = plan + 4;
-    int32_t* long_chunk0 = long_row + cap_long;
-    int32_t* chunk_slot = long_chunk0 + cap_long;
-    int32_t* chunk_begin = chunk_slot + cap_chunks;
-    if (slot < cap_long && c0 + nch <= cap_chunks) {
-      if (sl == 0) { long_row[slot] = row; long_chunk0[slot] = c0; }
-      for (int k = sl; k < nch; k += 16) { chunk_slot[c0 + k] = slot; chunk_begin[c0 + k] = start + k * EGC_LONG_ROW_CHUNK; }
+  // ---- long rows: registered in the plan by the scan kernel, spread over ALL workgroups by plan slot (hubs often
+  // have consecutive ids: a workgroup that sorted the long rows among its own 64 would own every one of them) ----
+  const int n_long = min(plan[0], cap_long);
+  if (n_long == 0) return;
+  const int32_t* long_row = plan + 4;
+  const int32_t* long_chunk0 = long_row + cap_long;
+  int32_t* chunk_slot = plan + 4 + 2 * cap_long;
+  int32_t* chunk_begin = chunk_slot + cap_chunks;
+  // up to BUILD_WAVE_ROW entries: one wavefront per row, rank sort in its strip of s_sort, no workgroup barrier
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int slot = blockIdx.x * 16 + wave; slot < n_long; slot += gridDim.x * 16) {
+    const int r = long_row[slot];
+    const int rs = rowptr[r], d = rowptr[r + 1] - rs;
+    if (d > BUILD_WAVE_ROW) continue;
+    int2* kv = s_sort + wave * BUILD_WAVE_ROW;
+    int2 mine[BUILD_WAVE_ROW / 64];
+#pragma unroll
+    for (int k = 0; k < BUILD_WAVE_ROW / 64; ++k) {
+      const int i = lane + 64 * k;
+      mine[k] = i < d ? int2{edge_id[rs + i], col[rs + i]} : int2{0x7fffffff, 0};
+      if (i < d) kv[i] = mine[k];
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the strip is read by the other lanes of this wavefront
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < BUILD_WAVE_ROW / 64; ++k) {
+      if (lane + 64 * k < d) {
+        int rank = 0;
+        for (int t = 0; t < d; ++t) rank += kv[t].x < mine[k].x;
+        const int p = rs + rank;
+        edge_id[p] = mine[k].x;
+        col[p] = mine[k].y;
+        if (edis_raw != nullptr) edis_raw[p] = dis_raw[mine[k].y];
+        if (edis_looped != nullptr) edis_looped[p] = dis_looped[mine[k].y];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();   // strip reused by this wavefront's next row
   }
-  // ---- long rows of this block, one at a time, by the whole block ----
-  const int nl = s_nlong;
-  for (int li = 0; li < nl; ++li) {
-    const int r = blockIdx.x * ROWS_PER_BLOCK + s_long_row[li];
+  // longer ones: the whole workgroup, one slot at a time -- rank sort up to BUILD_RANK_ROW entries, bitonic networks
+  // beyond (in LDS up to BUILD_LDS_SORT, through global scratch above that); every slot's chunk entries on the way
+  for (int slot = blockIdx.x; slot < n_long; slot += gridDim.x) {
+    const int r = long_row[slot], c0 = long_chunk0[slot];
     const int rs = rowptr[r], re = rowptr[r + 1], d = re - rs;
+    const int nch = (d + EGC_LONG_ROW_CHUNK - 1) / EGC_LONG_ROW_CHUNK;
+    if (c0 + nch <= cap_chunks)
+      for (int k = threadIdx.x; k < nch; k += blockDim.x) { chunk_slot[c0 + k] = slot; chunk_begin[c0 + k] = rs + k * EGC_LONG_ROW_CHUNK; }
+    if (d <= BUILD_WAVE_ROW) continue;   // uniform over the workgroup
     int np2 = 1;
     while (np2 < d) np2 <<= 1;
     int2* kv = d <= BUILD_LDS_SORT ? s_sort : big_scratch + (int64_t)rs * 2;   // global scratch: 2 x its own range (padding)
     __syncthreads();
-    for (int i = threadIdx.x; i < np2; i += blockDim.x) kv[i] = i < d ? int2{edge_id[rs + i], col[rs + i]} : int2{0x7fffffff, 0};
+    if (d <= BUILD_RANK_ROW) {
+      const int i = threadIdx.x;
+      const int2 v = i < d ? int2{edge_id[rs + i], col[rs + i]} : int2{0x7fffffff, 0};
+      if (i < d) kv[i] = v;
+      __syncthreads();
+      if (i < d) {
+        int rank = 0;
+        for (int t = 0; t < d; ++t) rank += kv[t].x < v.x;
+        const int p = rs + rank;
+        edge_id[p] = v.x;
+        col[p] = v.y;
+        if (edis_raw != nullptr) edis_raw[p] = dis_raw[v.y];
+        if (edis_looped != nullptr) edis_looped[p] = dis_looped[v.y];
+      }
+      continue;
+    }
+    if (d <= BUILD_LDS_SORT || d > BUILD_MERGE_ROW)
+      for (int i = threadIdx.x; i < np2; i += blockDim.x) kv[i] = i < d ? int2{edge_id[rs + i], col[rs + i]} : int2{0x7fffffff, 0};
     __syncthreads();
     if (d <= BUILD_LDS_SORT) {
       for (int k = 2; k <= np2; k <<= 1) bitonic_steps(kv, np2, 0, k, k >> 1);
+    } else if (d <= BUILD_MERGE_ROW) {
+      merge_sort_big(kv, d, s_sort, edge_id + rs, col + rs, dis_raw, dis_looped, edis_raw != nullptr ? edis_raw + rs : nullptr,
+                     edis_looped != nullptr ? edis_looped + rs : nullptr);
+      continue;
     } else {
       bitonic_big(kv, np2, s_sort);
     }
@@ -693,7 +784,8 @@ int egc_graph_build(const int64_t* src, const int64_t* dst, int64_t n_edges, int
     return EGC_OK;
   }
   const int eblocks = (int)std::max<int64_t>(1, ceil_div(n_edges, (int64_t)BUILD_TILE));
-  build_hist_kernel<<<eblocks, 256, 0, stream>>>(src, dst, n_edges, (int)n_nodes, (int)n_src, deg, deg_ns, maxp1, ws_status);
+  build_hist_kernel<<<eblocks, 256, 0, stream>>>(src, dst, n_edges, (int)n_nodes, (int)n_src, deg, deg_ns, maxp1, ws_status, plan,
+                                             (int)c.cap_long, (int)c.cap_chunks);
   EGC_LAUNCH_CHECK("build_hist_kernel");
   build_sums_kernel<<<nb, 1024, 0, stream>>>(deg, (int)n_nodes, bsum);
   EGC_LAUNCH_CHECK("build_sums_kernel");

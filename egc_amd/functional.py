@@ -426,9 +426,36 @@ def egc_aggregate_combine_backward(graph: CSRGraph, spec: LayerSpec, bases, weig
     return d_bases, d_w, d_cat   # d_cat is None unless the joint layout was asked for and applies
 
 
-def _xt_matmul(x: torch.Tensor, d: torch.Tensor) -> torch.Tensor:
-    """x^T @ d for tall x [N, F], d [N, C] (the weight gradient): a reduction over N with a tiny output, which
-    rocBLAS runs as one 128 x 192 tile grid (397 us at N = 169k); as a split-K batched GEMM + sum it takes 96 us."""
+def _weight_grads(x: torch.Tensor, d: torch.Tensor, col_sums: bool = False):
+    """(x^T @ d, d.sum(0) or None) for tall x [N, F], d [N, K]: the gradient of [bases_weight | comb_weights.weight]
+    and of comb_weights.bias (autograd's products behind optimized_layers.py:177-178) in one pass over both
+    operands through egc_weight_grad_f32 -- fp32 matrix-core products over row ranges, added in a fixed order.
+    Shapes outside that entry point's envelope (a dimension not a multiple of 4), and outputs larger than one
+    128 x 192 accumulator tile on long reductions (ogbn-mag widths: the library's split GEMM is faster there), take
+    torch's GEMM on the device."""
+    n, f = x.shape
+    k = d.size(1)
+    big = (f > 128 or k > 192) and n > 65536
+    if (n == 0 or big or f % 4 or k % 4 or not x.is_cuda or x.dtype != torch.float32 or d.dtype != torch.float32
+            or x.stride(1) != 1 or d.stride(1) != 1 or x.stride(0) % 4 or d.stride(0) % 4
+            or x.data_ptr() % 16 or d.data_ptr() % 16):
+        return _xt_library(x, d), (_column_sums(d) if col_sums else None)
+    lib = _C.load()
+    dev = x.device
+    with _device_guard(dev):
+        out = torch.empty((f, k), dtype=torch.float32, device=dev)
+        cs = torch.empty(k, dtype=torch.float32, device=dev) if col_sums else None
+        nbytes = int(lib.egc_weight_grad_workspace_bytes(n, f, k))
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+        _C.check(lib.egc_weight_grad_f32(x.data_ptr(), x.stride(0), d.data_ptr(), d.stride(0), n, f, k, out.data_ptr(),
+                                         cs.data_ptr() if cs is not None else None, ws.data_ptr(), ws.numel(),
+                                         _stream_ptr(dev)), "egc_weight_grad_f32")
+    return out, cs
+
+
+def _xt_library(x: torch.Tensor, d: torch.Tensor) -> torch.Tensor:
+    """x^T @ d on the library GEMM: as one product rocBLAS runs a single tile grid over the tiny output (397 us at
+    N = 169k); split into 64 row ranges + a sum it takes 96 us."""
     n = x.size(0)
     splits = 64
     if n < 64 * splits:
@@ -438,6 +465,10 @@ def _xt_matmul(x: torch.Tensor, d: torch.Tensor) -> torch.Tensor:
     if m < n:
         out = out + x[m:].t() @ d[m:]
     return out
+
+
+def _xt_matmul(x: torch.Tensor, d: torch.Tensor) -> torch.Tensor:
+    return _weight_grads(x, d)[0]
 
 
 def _column_sums(t: torch.Tensor) -> torch.Tensor:
@@ -512,8 +543,13 @@ class _EGCLayerFunction(torch.autograd.Function):
         if d_cat is None:
             d_cat = torch.cat([d_bases[:, :spec.f_g], d_w], dim=1)         # [N, F_g + W]
         dx = _dx_matmul(d_cat, wcat) if ctx.needs_input_grad[0] else None
-        dwcat = _xt_matmul(x, d_cat) if ctx.needs_input_grad[1] else None
-        dbcat = _column_sums(d_w) if (ctx.has_bcat and ctx.needs_input_grad[2]) else None
+        need_bcat = ctx.has_bcat and ctx.needs_input_grad[2]
+        dwcat = dbcat = None
+        if ctx.needs_input_grad[1]:
+            dwcat, sums = _weight_grads(x, d_cat, col_sums=need_bcat)   # column sums of d_w ride along
+            dbcat = sums[d_cat.size(1) - spec.w_cols:] if need_bcat else None
+        elif need_bcat:
+            dbcat = _column_sums(d_w)
         dbias = _column_sums(grad_out) if (ctx.has_bias and ctx.needs_input_grad[3]) else None
         return dx, dwcat, dbcat, dbias, None, None
 

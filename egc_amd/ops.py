@@ -92,7 +92,8 @@ def layer_backward(grad_out: torch.Tensor, x: torch.Tensor, wcat: torch.Tensor, 
     if d_cat is None:
         d_cat = torch.cat([d_bases[:, :spec.f_g], d_w], dim=1)
     empty = x.new_empty((0,))
-    return (F._dx_matmul(d_cat, wcat), F._xt_matmul(x, d_cat), F._column_sums(d_w) if need_bcat else empty,
+    dwcat, sums = F._weight_grads(x, d_cat, col_sums=need_bcat)
+    return (F._dx_matmul(d_cat, wcat), dwcat, sums[d_cat.size(1) - spec.w_cols:] if need_bcat else empty,
             F._column_sums(grad_out) if need_bias else empty)
 
 

@@ -256,6 +256,20 @@ int egc_aggregate_combine_strided_f32(const egc_graph* graph, const egc_layer* l
                                       const float* weightings, int32_t ldw, const float* bias, const egc_post* post,
                                       float* out, void* workspace, size_t workspace_bytes, egc_stream_t stream);
 
+/* Weight gradient of the layer's two Linear maps in one pass: out[f_in][k_cols] = x^T @ d for x [n_rows][f_in]
+ * (row stride ldx) and d [n_rows][k_cols] (row stride ldd; the joint [d_bases | d_weightings] array of
+ * egc_aggregate_combine_backward_f32), and, when col_sums != NULL, col_sums[k_cols] = the column sums of d (the
+ * gradient of the combination Linear's bias).  Replaces what autograd runs for the reference's
+ * `torch.matmul(x, self.bases_weight)` / `self.comb_weights(x)` (experiments/optimized_layers.py:177-178;
+ * experiments/layers.py:110-111): exact fp32 products and sums on the fp32 matrix-core instruction, row ranges
+ * added in a fixed order (deterministic).  f_in, k_cols, ldx, ldd multiples of 4 and 16-byte aligned pointers,
+ * else EGC_ERR_UNSUPPORTED.  workspace: egc_weight_grad_workspace_bytes(n_rows, f_in, k_cols) bytes, contents
+ * irrelevant on entry and on exit. */
+int64_t egc_weight_grad_workspace_bytes(int64_t n_rows, int32_t f_in, int32_t k_cols);
+int egc_weight_grad_f32(const float* x, int64_t ldx, const float* d, int64_t ldd, int64_t n_rows, int32_t f_in,
+                        int32_t k_cols, float* out, float* col_sums, void* workspace, int64_t workspace_bytes,
+                        void* stream);
+
 /* Column sums of a row-major array with row stride ld (floats), as n_partials partial rows:
  * partials[p, c] = sum of x[r, c] over the p-th block of rows, c < cols; the caller adds the few partial rows up.
  * The bias gradients of a training step (grad_out summed over the nodes for `bias`, d_weightings for the

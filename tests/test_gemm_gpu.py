@@ -154,3 +154,60 @@ def test_long_k_kernel_row_ranges_launched_separately(monkeypatch):
     x, wcat, bcat = (torch.randn(n, f_in, generator=g).to(DEV), torch.randn(f_in, f_g + w_cols, generator=g).to(DEV),
                      torch.randn(w_cols, generator=g).to(DEV))
     _check(x, wcat, bcat, f_g, w_cols, *_transform(x, wcat, bcat, f_g, w_cols))
+
+
+# --- weight gradient x^T @ d + column sums (egc_weight_grad_f32, egc_gemm_xt.hip) ---------------------------------
+
+def _weight_grad(x, d, sums=True):
+    from egc_amd import _C
+    lib = _C.load()
+    n, f = x.shape
+    k = d.size(1)
+    out = torch.full((f, k), float("nan"), device=DEV)
+    cs = torch.full((k,), float("nan"), device=DEV) if sums else None
+    nb = int(lib.egc_weight_grad_workspace_bytes(n, f, k))
+    ws = torch.full((max(nb, 16) // 4,), float("nan"), device=DEV)   # contents irrelevant on entry
+    _C.check(lib.egc_weight_grad_f32(x.data_ptr(), x.stride(0), d.data_ptr(), d.stride(0), n, f, k, out.data_ptr(),
+                                     cs.data_ptr() if sums else None, ws.data_ptr(), ws.numel() * 4,
+                                     torch.cuda.current_stream().cuda_stream), "egc_weight_grad_f32")
+    torch.cuda.synchronize()
+    return out, cs
+
+
+@pytest.mark.parametrize("n", [0, 1, 31, 32, 33, 1000, 16391, 70001])
+@pytest.mark.parametrize("f,k", [(128, 192), (100, 132), (4, 4), (32, 64), (64, 128), (352, 208), (36, 260), (132, 68)])
+def test_weight_grad_matches_float64(n, f, k):
+    g = torch.Generator(device="cpu").manual_seed(n * 131 + f * 7 + k)
+    x = torch.randn(n, f, generator=g).to(DEV)
+    d = (torch.randn(n, k, generator=g) * torch.logspace(-6, 2, k)).to(DEV)   # columns of very different size
+    out, cs = _weight_grad(x, d)
+    ref = x.double().t() @ d.double()
+    budget = x.double().abs().t() @ d.double().abs()
+    tiny = torch.finfo(torch.float32).tiny
+    # fp32 products, fp32 running sums over <= a few hundred rows per range, then <= 256 partial sums
+    tol = 2e-6 * max(1.0, (n ** 0.5) / 8)
+    assert float(((out.double() - ref).abs() / (budget + tiny)).max() if n else out.abs().max()) <= tol
+    rs, bs = d.double().sum(0), d.double().abs().sum(0)
+    assert float(((cs.double() - rs).abs() / (bs + tiny)).max() if n else cs.abs().max()) <= tol
+
+
+def test_weight_grad_strided_operands_and_no_sums():
+    g = torch.Generator(device="cpu").manual_seed(9)
+    xs = torch.randn(5000, 160, generator=g).to(DEV)
+    ds = torch.randn(5000, 256, generator=g).to(DEV)
+    x, d = xs[:, 16:144], ds[:, 64:256]            # column blocks: row strides 160 / 256
+    out, cs = _weight_grad(x, d, sums=False)
+    ref = x.double().t() @ d.double()
+    assert cs is None and float((out.double() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+
+
+def test_weight_grad_rejects_unaligned_shapes():
+    from egc_amd import _C
+    lib = _C.load()
+    x = torch.zeros(8, 6, device=DEV)
+    d = torch.zeros(8, 8, device=DEV)
+    o = torch.zeros(6, 8, device=DEV)
+    ws = torch.zeros(1 << 16, device=DEV)
+    rc = lib.egc_weight_grad_f32(x.data_ptr(), 6, d.data_ptr(), 8, 8, 6, 8, o.data_ptr(), None, ws.data_ptr(),
+                                 ws.numel() * 4, torch.cuda.current_stream().cuda_stream)
+    assert rc == 4   # EGC_ERR_UNSUPPORTED
