@@ -217,6 +217,9 @@ struct BwdArgs {
   const int* cnt;            // [N] entries of the row's aggregation set
   const int* arg_max;        // [N, ldb] CSR position / n_edges (self loop) / -1, or nullptr
   const int* arg_min;
+  const int* rowptr;         // destination-side row pointers (arg positions relative to their row)
+  unsigned char* arg8_max;   // [N, ldb] the same positions as one byte each, relative to the row's first entry
+  unsigned char* arg8_min;   //          (ARG8_NONE: self-loop / empty row, ARG8_FAR: >= ARG8_NONE entries into the row)
   float* d_bases;            // [n_src_rows, ld_db >= ldb]  (zero-initialised by the host)
   float* d_weightings;       // [N, ld_dw >= W]
   int ld_db, ld_dw;          // row strides (floats) of the two gradient arrays
@@ -364,6 +367,32 @@ __global__ void __launch_bounds__(256) bwd_dst_kernel(BwdArgs a) {
 // weights sit in per-group LDS strips; a lane forms  d agg_t = sum_h w'[h][b][t] g[h][l..l+3]  and its share of
 // d w'[h][b][t] = sum_l g[h][l] agg_t[b][l]  in one pass over h, the shares meet in an xor butterfly over the P
 // lanes of the basis, and lane l4 stores the heads l4 H/P .. (l4+1) H/P - 1.
+// In-row arg positions in 8 bits.  The source side compares, per transposed entry, the arg positions of the
+// destination row with the entry's own position: gathered as int32 that is a 256-byte row per entry (a third of the
+// kernel's traffic at the north star); relative to the row's first entry a position fits one byte for all but hub
+// rows, and the gathered row shrinks to 64 bytes.  Encoding: 0 .. 253 = position - rowptr[row]; ARG8_NONE = no entry
+// of the row can match (appended self-loop, empty row); ARG8_FAR = position >= rowptr[row] + ARG8_NONE: entries that
+// far into a (hub) row, and only they, still compare against the int32 table.
+constexpr unsigned ARG8_NONE = 254u, ARG8_FAR = 255u;
+__device__ inline unsigned arg8_pack(int4 a, int start, int n_edges) {
+  auto enc = [&](int p) -> unsigned {
+    if (p < 0 || p >= n_edges) return ARG8_NONE;
+    const unsigned rel = (unsigned)(p - start);
+    return rel < ARG8_NONE ? rel : ARG8_FAR;
+  };
+  return enc(a.x) | (enc(a.y) << 8) | (enc(a.z) << 16) | (enc(a.w) << 24);
+}
+__global__ void __launch_bounds__(256) arg8_kernel(const int* __restrict__ arg, const int* __restrict__ rowptr,
+                                                   unsigned* __restrict__ arg8, int64_t quads, int quads_per_row,
+                                                   int n_edges) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread: 4 columns -> one packed dword
+  if (k >= quads) return;
+  const int row = (int)(k / quads_per_row);
+  const int start = rowptr[row];
+  const int4 a = *reinterpret_cast<const int4*>(arg + 4 * k);
+  arg8[k] = arg8_pack(a, start, n_edges);
+}
+
 constexpr int BWD_HMAX = 16;   // heads supported by the register form
 // HT / AT: compile-time head and aggregator counts (the d = 128, H = 8 layers; everything else: bwd_dst_kernel)
 // AGG: the aggregator codes packed 3 bits each (first in the low bits) with bit 31 set, or 0 = read them from
@@ -510,6 +539,13 @@ __global__ void __launch_bounds__(256) bwd_dst_fast_kernel(BwdArgs a) {
       default: d_s += d * f4{dis_i, dis_i, dis_i, dis_i}; break;
     }
   }
+  if (wr && (a.arg8_max != nullptr || a.arg8_min != nullptr)) {  // the arg positions of this row, one byte each (see arg8_pack)
+    const int start = a.rowptr[rr];
+    if (a.arg8_max != nullptr)
+      reinterpret_cast<unsigned*>(a.arg8_max)[o >> 2] = arg8_pack(*reinterpret_cast<const int4*>(a.arg_max + o), start, a.n_edges);
+    if (a.arg8_min != nullptr)
+      reinterpret_cast<unsigned*>(a.arg8_min)[o >> 2] = arg8_pack(*reinterpret_cast<const int4*>(a.arg_min + o), start, a.n_edges);
+  }
   if (wr) {
     const f4 two_dv = d_v * f4{2.f * rcnt, 2.f * rcnt, 2.f * rcnt, 2.f * rcnt};
     if (a.need_t) __builtin_nontemporal_store(d_t - mean * two_dv, reinterpret_cast<f4*>(a.tab_t + o));  // else never read
@@ -569,20 +605,48 @@ struct SrcCfg {
 constexpr int BWD_FU = 4;
 template <int NS, class SC>
 __device__ inline void sum_tables(const BwdArgs& a, const __amdgpu_buffer_rsrc_t (&rt)[3],
-                                  const __amdgpu_buffer_rsrc_t (&rx)[4], int row, int start, int end, int first, int step,
+                                  const __amdgpu_buffer_rsrc_t (&rx)[4], const __amdgpu_buffer_rsrc_t (&r8)[2], int row,
+                                  int start, int end, int first, int step,
                                   int q, int LPR, bool xl, bool yl, f4 (&at)[NS], f4 (&as)[NS], f4 (&av)[NS]) {
+  // Every memory round trip on the critical path of a batch costs as much as the gathers themselves (the kernel is
+  // bound by the batches in flight, and loads return in order): the indices of batch n + 1 are loaded beside the
+  // gathers of batch n, the arg positions are requested BEFORE the table slots so that the dependent gather of the
+  // extremum gradients leaves while the table slots are still in flight.
   const bool ext = SC::has_x(a) || SC::has_n(a);
-  for (int p0 = start + first; p0 < end; p0 += step * BWD_FU) {
-    int dst[BWD_FU], pos[BWD_FU];
+  int dst_n[BWD_FU], pos_n[BWD_FU];
+  auto load_indices = [&](int p0) {
 #pragma unroll
     for (int u = 0; u < BWD_FU; ++u) {
       const int p = p0 + u * step;
-      dst[u] = p < end ? a.t_col[p] : -1;
-      pos[u] = (ext && p < end) ? a.t_edge_id[p] : -2;
+      dst_n[u] = p < end ? a.t_col[p] : -1;
+      pos_n[u] = (ext && p < end) ? a.t_edge_id[p] : -2;
     }
+  };
+  load_indices(start + first);
+  for (int p0 = start + first; p0 < end; p0 += step * BWD_FU) {
+    int dst[BWD_FU], pos[BWD_FU], rp[BWD_FU];
+#pragma unroll
+    for (int u = 0; u < BWD_FU; ++u) { dst[u] = dst_n[u]; pos[u] = pos_n[u]; }
+    load_indices(p0 + step * BWD_FU);
+#pragma unroll
+    for (int u = 0; u < BWD_FU; ++u) rp[u] = (ext && dst[u] >= 0) ? a.rowptr[dst[u]] : 0;   // -> position inside the destination row
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
       const int s = q + k * LPR;
+      // max / min: the whole gradient of (destination, column) goes to the entry its arg position names
+      unsigned a8[2][BWD_FU];
+      if (ext) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          if (!(e == 0 ? SC::has_x(a) : SC::has_n(a))) continue;
+#pragma unroll
+          for (int u = 0; u < BWD_FU; ++u) {
+            const bool lv = dst[u] >= 0 && s < a.slots;
+            const unsigned off = (unsigned)dst[u] * (unsigned)a.ldb + (unsigned)s * 4u;
+            a8[e][u] = __builtin_amdgcn_raw_buffer_load_b32(r8[e], lv ? off : OOB, 0, 0);
+          }
+        }
+      }
       f4 vt[BWD_FU], vs[BWD_FU], vv[BWD_FU];
 #pragma unroll
       for (int u = 0; u < BWD_FU; ++u) {
@@ -593,40 +657,45 @@ __device__ inline void sum_tables(const BwdArgs& a, const __amdgpu_buffer_rsrc_t
         if (SC::has_v(a)) vv[u] = load_slot(rt[2], (live && !(xl && is_self)) ? off : OOB);
         if (SC::has_s(a)) vs[u] = load_slot(rt[1], (live && !(yl && is_self)) ? off : OOB);
       }
+      if (ext) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          if (!(e == 0 ? SC::has_x(a) : SC::has_n(a))) continue;
+          f4 gv[BWD_FU];
+          int4 ar[BWD_FU];
+          bool mx[BWD_FU], my[BWD_FU], mz[BWD_FU], mw[BWD_FU], far[BWD_FU];
+#pragma unroll
+          for (int u = 0; u < BWD_FU; ++u) {
+            // positions up to ARG8_NONE - 1 entries into the destination row compare bytes (an out-of-range load
+            // returns 0 and a byte 0 would match position 0, hence the lv term); further in (hub rows) a byte
+            // ARG8_FAR marks a candidate that the int32 row decides -- requested together with the gradient slot
+            const bool lv = dst[u] >= 0 && s < a.slots;
+            const unsigned rel = min((unsigned)(pos[u] - rp[u]), ARG8_FAR);
+            const unsigned want = rel < ARG8_NONE ? rel : ARG8_FAR;
+            far[u] = rel >= ARG8_NONE;
+            mx[u] = lv && (a8[e][u] & 0xffu) == want;
+            my[u] = lv && ((a8[e][u] >> 8) & 0xffu) == want;
+            mz[u] = lv && ((a8[e][u] >> 16) & 0xffu) == want;
+            mw[u] = lv && (a8[e][u] >> 24) == want;
+            const bool any = mx[u] || my[u] || mz[u] || mw[u];
+            const unsigned off = (unsigned)dst[u] * (unsigned)a.ldb * 4u + (unsigned)s * 16u;
+            gv[u] = load_slot(rx[2 * e + 1], any ? off : OOB);
+            ar[u] = __builtin_bit_cast(int4, load_slot(rx[2 * e], (any && far[u]) ? off : OOB));
+          }
+#pragma unroll
+          for (int u = 0; u < BWD_FU; ++u) {
+            const bool nx = !far[u] || ar[u].x == pos[u], ny = !far[u] || ar[u].y == pos[u];
+            const bool nz = !far[u] || ar[u].z == pos[u], nw = !far[u] || ar[u].w == pos[u];
+            at[k].x += (mx[u] && nx) ? gv[u].x : 0.f; at[k].y += (my[u] && ny) ? gv[u].y : 0.f;
+            at[k].z += (mz[u] && nz) ? gv[u].z : 0.f; at[k].w += (mw[u] && nw) ? gv[u].w : 0.f;
+          }
+        }
+      }
 #pragma unroll
       for (int u = 0; u < BWD_FU; ++u) {
         at[k] += vt[u];
         if (SC::has_v(a)) av[k] += vv[u];
         if (SC::has_s(a)) as[k] += vs[u];
-      }
-      // max / min: the whole gradient of (destination, column) goes to the entry its arg position names.  The arg
-      // rows are gathered first; the gradient slot only where one of the lane's four columns names this entry
-      // (into a hub destination almost none does), through an out-of-range offset otherwise.
-      if (ext) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          if (!(e == 0 ? SC::has_x(a) : SC::has_n(a))) continue;
-          int4 ar[BWD_FU];
-          f4 gv[BWD_FU];
-          bool lv[BWD_FU];
-#pragma unroll
-          for (int u = 0; u < BWD_FU; ++u) {
-            lv[u] = dst[u] >= 0 && s < a.slots;
-            const unsigned off = (unsigned)dst[u] * (unsigned)a.ldb * 4u + (unsigned)s * 16u;
-            ar[u] = __builtin_bit_cast(int4, load_slot(rx[2 * e], lv[u] ? off : OOB));
-          }
-#pragma unroll
-          for (int u = 0; u < BWD_FU; ++u) {
-            const bool hit = lv[u] && (ar[u].x == pos[u] || ar[u].y == pos[u] || ar[u].z == pos[u] || ar[u].w == pos[u]);
-            const unsigned off = (unsigned)dst[u] * (unsigned)a.ldb * 4u + (unsigned)s * 16u;
-            gv[u] = load_slot(rx[2 * e + 1], hit ? off : OOB);
-          }
-#pragma unroll
-          for (int u = 0; u < BWD_FU; ++u) {
-            at[k].x += ar[u].x == pos[u] ? gv[u].x : 0.f; at[k].y += ar[u].y == pos[u] ? gv[u].y : 0.f;
-            at[k].z += ar[u].z == pos[u] ? gv[u].z : 0.f; at[k].w += ar[u].w == pos[u] ? gv[u].w : 0.f;
-          }
-        }
       }
     }
   }
@@ -653,6 +722,9 @@ __global__ void __launch_bounds__(256) bwd_src_kernel(BwdArgs a) {
   rx[1] = __builtin_amdgcn_make_buffer_rsrc((void*)(a.tab_x != nullptr ? a.tab_x : a.tab_t), 0, a.tab_bytes, 0x00020000);
   rx[2] = __builtin_amdgcn_make_buffer_rsrc((void*)(a.arg_min != nullptr ? (const void*)a.arg_min : (const void*)a.tab_t), 0, a.tab_bytes, 0x00020000);
   rx[3] = __builtin_amdgcn_make_buffer_rsrc((void*)(a.tab_n != nullptr ? a.tab_n : a.tab_t), 0, a.tab_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t r8[2];   // the arg positions in 8 bits: a quarter of the bytes of rx[0] / rx[2]
+  r8[0] = __builtin_amdgcn_make_buffer_rsrc((void*)(a.arg8_max != nullptr ? (const void*)a.arg8_max : (const void*)a.tab_t), 0, a.tab_bytes / 4, 0x00020000);
+  r8[1] = __builtin_amdgcn_make_buffer_rsrc((void*)(a.arg8_min != nullptr ? (const void*)a.arg8_min : (const void*)a.tab_t), 0, a.tab_bytes / 4, 0x00020000);
   const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
 
   int row, start, end, first, step;
@@ -682,7 +754,7 @@ __global__ void __launch_bounds__(256) bwd_src_kernel(BwdArgs a) {
   f4 at[NS], as[NS], av[NS];
 #pragma unroll
   for (int k = 0; k < NS; ++k) at[k] = as[k] = av[k] = zero;
-  sum_tables<NS, SC>(a, rt, rx, row, start, end, first, step, q, LPR, xl, yl, at, as, av);
+  sum_tables<NS, SC>(a, rt, rx, r8, row, start, end, first, step, q, LPR, xl, yl, at, as, av);
   if (atomic) {  // merge the G groups of the chunk
     for (int off = LPR; off < 64; off <<= 1) {
 #pragma unroll
@@ -743,7 +815,8 @@ extern "C" {
 size_t egc_backward_workspace_bytes(const egc_layer* layer, int64_t n_nodes) {
   if (layer == nullptr || n_nodes < 0 || layer->num_heads <= 0) return 0;
   const int ldb = egc_bases_ld(layer);
-  return (size_t)5 * (size_t)n_nodes * ldb * sizeof(float) + 256;  // tables T, S, V, X, N
+  // tables T, S, V, X, N; then the 8-bit in-row arg positions of max and min
+  return (size_t)5 * (size_t)n_nodes * ldb * sizeof(float) + (size_t)2 * (size_t)n_nodes * ldb + 256;
 }
 
 int egc_aggregate_combine_backward_f32(const egc_graph* graph, const egc_graph* t_graph, const egc_layer* layer,
@@ -836,6 +909,13 @@ int egc_aggregate_combine_backward_f32(const egc_graph* graph, const egc_graph* 
   a.tab_n = a.stat_slot[STAT_MN] >= 0 ? ws + (size_t)4 * n * ldb : nullptr;
   a.t_edge_id = t_graph->edge_id;
   if ((a.tab_x != nullptr || a.tab_n != nullptr) && a.t_edge_id == nullptr) return EGC_ERR_INVALID;
+  a.rowptr = graph->rowptr;
+  {
+    unsigned char* bytes = reinterpret_cast<unsigned char*>(ws + (size_t)5 * n * ldb);
+    a.arg8_max = a.tab_x != nullptr ? bytes : nullptr;
+    a.arg8_min = a.tab_n != nullptr ? bytes + (size_t)n * ldb : nullptr;
+    if ((a.arg8_max != nullptr || a.arg8_min != nullptr) && a.rowptr == nullptr) return EGC_ERR_INVALID;
+  }
   a.tab_bytes = (unsigned)((uint64_t)n * ldb * 4ull);
   a.lds_floats_per_wave = a.A * ldb + ((a.F_out + 3) & ~3) + 2 * ((a.W + 3) & ~3);
   int wpb = 4;
@@ -872,6 +952,15 @@ int egc_aggregate_combine_backward_f32(const egc_graph* graph, const egc_graph* 
     } else {
       bwd_dst_kernel<<<(unsigned)ceil_div(n, wpb), wpb * 64, lds, stream>>>(a);
       EGC_LAUNCH_CHECK("bwd_dst_kernel");
+      // (the register-resident kernel derives the 8-bit arg positions itself)
+      const int64_t quads = n * (ldb / 4);
+      if (a.arg8_max != nullptr)
+        arg8_kernel<<<(unsigned)ceil_div(quads, 256), 256, 0, stream>>>(arg_max, a.rowptr, reinterpret_cast<unsigned*>(a.arg8_max), quads,
+                                                                       ldb / 4, (int)graph->n_edges);
+      if (a.arg8_min != nullptr)
+        arg8_kernel<<<(unsigned)ceil_div(quads, 256), 256, 0, stream>>>(arg_min, a.rowptr, reinterpret_cast<unsigned*>(a.arg8_min), quads,
+                                                                       ldb / 4, (int)graph->n_edges);
+      EGC_LAUNCH_CHECK("arg8_kernel");
     }
   }
 
