@@ -358,7 +358,13 @@ static int launch_k(const float* x, const u16* packed, const float* bcat, int64_
     if (e != hipSuccess) { set_last_error("hipFuncSetAttribute(f16x2k)", e); return EGC_ERR_HIP; }
     attr_set = true;
   }
-  int grid = 256;  // one workgroup per CU (LDS)
+  // workgroups per CU: as many as the LDS holds, within about five wavefronts per SIMD (the KS <= 9 kernels use up to
+  // 102 registers).  Short k leaves room for two (F_in = 192, 8 column tiles: 59 KB of LDS each), and the second one's
+  // matrix work covers the first one's barrier and split: 66.9 -> 50.1 us for the 192 -> 128 gradient GEMM at
+  // N = 169,343 (a third workgroup that does not fit measured 57 us: uneven CUs).
+  int per_cu = (int)std::min<size_t>((size_t)160 * 1024 / lds, (size_t)(20 / c.NT));
+  if (KS > 9 || per_cu < 1) per_cu = 1;
+  int grid = 256 * per_cu;
   if (const char* e = getenv("EGC_GEMM_GRID")) grid = atoi(e);
   if (grid > n_tiles) grid = n_tiles;
   kern<<<grid, threads, lds, stream>>>(x, packed, bcat, M, K, c, bases, weightings, n_tiles, LDX, R, slot_bytes);
