@@ -554,6 +554,43 @@ class _EGCLayerFunction(torch.autograd.Function):
         return dx, dwcat, dbcat, dbias, None, None
 
 
+class _DenseTransformFunction(torch.autograd.Function):
+    """Autograd around the dense half of a layer alone: (bases [N, ldb], weightings [N, W]) = x @ [B | C] (+ bcat on
+    the weightings block) through egc_basis_transform, with the gradients w.r.t. x / wcat / bcat through the
+    repository's own GEMMs (_dx_matmul, _weight_grads) -- what autograd produces for the reference's
+    ``torch.matmul(x, bases_weight)`` + one ``Linear`` per weightings block (rmag/models.py:113-143), as ONE forward
+    GEMM per node type instead of one per Linear."""
+
+    @staticmethod
+    def forward(ctx, x, wcat, bcat, graph, gspec):
+        bases, weightings = egc_basis_transform(graph, gspec, x, wcat, bcat, None)
+        ctx.save_for_backward(x, wcat)
+        ctx.gspec, ctx.has_bcat = gspec, bcat is not None
+        return bases, weightings
+
+    @staticmethod
+    def backward(ctx, d_bases, d_w):
+        x, wcat = ctx.saved_tensors
+        f_g = ctx.gspec.f_g
+        d_cat = torch.cat([d_bases[:, :f_g], d_w], dim=1)   # pad columns of `bases` carry no gradient
+        dx = _dx_matmul(d_cat, wcat) if ctx.needs_input_grad[0] else None
+        need_bcat = ctx.has_bcat and ctx.needs_input_grad[2]
+        dwcat = dbcat = None
+        if ctx.needs_input_grad[1]:
+            dwcat, sums = _weight_grads(x, d_cat, col_sums=need_bcat)
+            dbcat = sums[f_g:] if need_bcat else None
+        elif need_bcat:
+            dbcat = _column_sums(d_w.contiguous())
+        return dx, dwcat, dbcat, None, None
+
+
+def egc_dense_transform_apply(graph, gspec, x, wcat, bcat):
+    """egc_basis_transform with autograd when any input requires a gradient (``gspec``: f_in, f_g, w_cols, ldb)."""
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, wcat, bcat)):
+        return _DenseTransformFunction.apply(x, wcat, bcat, graph, gspec)
+    return egc_basis_transform(graph, gspec, x, wcat, bcat, None)
+
+
 class _AggregateCombineFunction(torch.autograd.Function):
     """Autograd around the fused aggregate/combine alone: ``bases`` [n_src_rows, ldb] and the pre-activation
     ``weightings`` [N, W] (layout [h][b][a]) come from differentiable torch ops of the caller (relational EGC:

@@ -6,7 +6,8 @@ relation's rectangular adjacency, combined with weightings computed from the TAR
 accumulated into the target type's output.  The sparse part of every term is the fused aggregate/combine
 kernel of this repository (``egc_aggregate_combine_f32`` through the C ABI): the root term runs it on an
 identity adjacency, a relation on its ``[N_target, N_source]`` CSR (``egc_graph.n_src_rows``).  The dense
-Linears are plain GEMMs (torch.matmul -> rocBLAS), as in the reference.
+Linears of one node type are ONE GEMM on this repository's matrix-core kernels, in inference and in training
+(forward and the gradient GEMMs: ``egc_dense_transform_apply``).
 
 Interface = the reference's: ``REGConv(in_channels, out_channels, num_heads, num_bases)``,
 ``forward(x_dict, adj_t_dict)`` with ``adj_t_dict[(src, rel, dst)]`` an ``adj_t`` whose rows are targets
@@ -20,11 +21,10 @@ from types import SimpleNamespace
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import _C
-from .functional import (PostOp, egc_aggregate_combine, egc_aggregate_combine_apply, egc_basis_transform, gemm_exact,
-                         make_spec, pack_weights)
+from .functional import (PostOp, egc_aggregate_combine, egc_aggregate_combine_apply, egc_basis_transform,
+                         egc_dense_transform_apply, gemm_exact, make_spec, pack_weights)
 from .graph import CSRGraph, SparseTensor
 from .layers import glorot_
 
@@ -144,26 +144,29 @@ class REGConv(nn.Module):
         if not needs_grad and (self.num_heads * self.num_bases) % 4 == 0 and \
                 all(tuple(k) in self.edge_types for k in adj_t_dict):
             return self._forward_inference(x_dict, adj_t_dict)
-        ldb = self._spec_root.ldb
-        f_g = self._spec_root.f_g
-        bases, out = {}, {}
+        # training: the same ONE GEMM per node type as in inference ([bases | root weightings | weightings of every
+        # relation into the type], rmag/models.py:113-143), built from the parameters with differentiable ops and
+        # run -- forward and the three gradient GEMMs -- on this repository's kernels (egc_dense_transform_apply)
+        HB = self.num_heads * self.num_bases
+        f_g, ldb = self._spec_root.f_g, self._spec_root.ldb
+        perm = self._hba_rows
+        bases, wt, out, offs = {}, {}, {}, {}
         for key, x in x_dict.items():
-            b = torch.matmul(x, self.bases_weight)                                   # rmag/models.py:113-115
-            bases[key] = b if ldb == f_g else F.pad(b, (0, ldb - f_g))
-            w_root = self.root_combs[key](x)                                         # [N, H*B] = [h][b] (A = 1)
-            out[key] = egc_aggregate_combine_apply(self._identity_graph(x.size(0), x.device), self._spec_root,
-                                                   bases[key].contiguous(), w_root.contiguous())  # :117-129
+            rels = [k for k in self.edge_types if k[2] == key and tuple(k) in {tuple(a) for a in adj_t_dict}]
+            lins = [self.root_combs[key]] + [self.rel_combs[f"{k[0]}_{k[1]}_{k[2]}"] for k in rels]
+            wcat = torch.cat([self.bases_weight, lins[0].weight.t()] + [lin.weight[perm].t() for lin in lins[1:]], dim=1)
+            bcat = torch.cat([lins[0].bias] + [lin.bias[perm] for lin in lins[1:]])
+            gspec = SimpleNamespace(f_in=self.in_channels, f_g=f_g, w_cols=wcat.size(1) - f_g, ldb=ldb)
+            ident = self._identity_graph(x.size(0), x.device)
+            bases[key], wt[key] = egc_dense_transform_apply(ident, gspec, x, wcat, bcat)
+            offs[key] = {tuple(k): HB + 2 * HB * i for i, k in enumerate(rels)}
+            out[key] = egc_aggregate_combine_apply(ident, self._spec_root, bases[key], wt[key][:, :HB].contiguous())  # :117-129
         for key, adj_t in adj_t_dict.items():
             src, _, dst = key
-            lin = self.rel_combs[f"{key[0]}_{key[1]}_{key[2]}"]
-            w_rel = F.linear(x_dict[dst], lin.weight[self._hba_rows], lin.bias[self._hba_rows])   # :141-143
             g = _as_graph(adj_t, x_dict[dst].size(0), x_dict[src].size(0))
-            b_src, w_rel = bases[src].contiguous(), w_rel.contiguous()
-            if torch.is_grad_enabled() and any(t.requires_grad for t in (b_src, w_rel)):
-                out[dst] = out[dst] + egc_aggregate_combine_apply(g, self._spec_rel, b_src, w_rel)    # :131-144
-            else:  # inference: the kernel's store adds the terms accumulated so far (egc_post.residual, in place)
-                egc_aggregate_combine(g, self._spec_rel, b_src, w_rel, None, post=PostOp(residual=out[dst]),
-                                      out=out[dst])
+            o = offs[dst][tuple(key)]
+            out[dst] = out[dst] + egc_aggregate_combine_apply(g, self._spec_rel, bases[src],
+                                                              wt[dst][:, o:o + 2 * HB].contiguous())  # :131-144
         return out
 
     def __repr__(self):
