@@ -96,6 +96,12 @@ SYMBOLS = {
     "egc_weight_grad_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
     "egc_weight_grad_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "egc_column_moments_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,
+                                         C.c_int32, C.c_void_p]),
+    "egc_affine_act_residual_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
+                                              C.c_int32, C.c_void_p, C.c_void_p]),
+    "egc_affine_act_backward_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "egc_column_sums_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "egc_segment_mean_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "egc_train_stats_floats": (C.c_int64, [C.POINTER(EgcLayer)]),

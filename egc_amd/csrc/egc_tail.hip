@@ -1,0 +1,159 @@
+// The caller-side tail of an EGC layer in TRAINING mode: the reference's graph nets run
+//     h = conv(x, edge_index);  h = bn(h);  h = relu(h);  x = x + h
+// every step (zinc/models.py:66-72, mol/pna_style_models.py:71-78, cifar/models.py:67-74).  In eval mode the whole
+// tail folds into the store of the aggregate kernel (egc_post); with batch statistics it cannot -- the statistics
+// need every row of h first -- but it still is two passes instead of PyTorch's five (statistics, normalise, relu,
+// add; and as many again backward):
+//     forward   column_moments  (sum h, sum h^2 per channel, float64 accumulation)         reads h
+//               affine_act_residual   out = act(h * scale + shift) + residual              reads h, residual; writes out
+//     backward  tail_backward_moments (sum g, sum g h per channel; g = dout * [pre-activation > 0])   reads dout, h
+//               tail_backward   dh = A g + B h + C  (the BatchNorm backward with its two sums folded into A, B, C)
+// All four are plain streaming kernels: 16 bytes per lane, channel constants from LDS, HBM-bound.
+#include <algorithm>
+
+#include "egc_common.h"
+
+namespace egc {
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+__device__ inline d4 to_d4(f4 v) { return d4{(double)v.x, (double)v.y, (double)v.z, (double)v.w}; }
+
+// out[block][0][c] = sum over the block's rows of a[r][c] (* mask), out[block][1][c] = sum of a[r][c] * b[r][c]
+// (b == a: the second moment).  MASKED: a is multiplied by [b * scale + shift > 0] first (the ReLU mask recomputed
+// from the saved pre-BatchNorm activations instead of stored).
+template <bool MASKED>
+__global__ void __launch_bounds__(256) column_moments_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             int64_t n_rows, int cols, int rows_per_block,
+                                                             double* __restrict__ out) {
+  __shared__ d4 red[2][256];
+  const int cg = cols >> 2;                 // 16-byte column groups (<= 256)
+  const int rl = 256 / cg;                  // row lanes
+  const int g = threadIdx.x % cg, lane_r = threadIdx.x / cg;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = min(r0 + rows_per_block, n_rows);
+  d4 s1 = d4{0, 0, 0, 0}, s2 = d4{0, 0, 0, 0};
+  f4 sc = f4{0.f, 0.f, 0.f, 0.f}, sh = sc;
+  if (MASKED) { sc = reinterpret_cast<const f4*>(scale)[g]; sh = reinterpret_cast<const f4*>(shift)[g]; }
+  if (lane_r < rl)
+    for (int64_t r = r0 + lane_r; r < r1; r += rl) {
+      f4 va = __builtin_nontemporal_load(reinterpret_cast<const f4*>(a + r * cols) + g);
+      const f4 vb = MASKED ? __builtin_nontemporal_load(reinterpret_cast<const f4*>(b + r * cols) + g) : va;
+      if (MASKED) {
+        const f4 pre = vb * sc + sh;
+        va = f4{pre.x > 0.f ? va.x : 0.f, pre.y > 0.f ? va.y : 0.f, pre.z > 0.f ? va.z : 0.f, pre.w > 0.f ? va.w : 0.f};
+      }
+      const d4 da = to_d4(va);
+      s1 += da;
+      s2 += da * to_d4(vb);
+    }
+  red[0][threadIdx.x] = s1;
+  red[1][threadIdx.x] = s2;
+  __syncthreads();
+  if (lane_r == 0) {
+    for (int k = 1; k < rl; ++k) { s1 += red[0][k * cg + g]; s2 += red[1][k * cg + g]; }
+    double* o = out + (int64_t)blockIdx.x * 2 * cols;
+    reinterpret_cast<d4*>(o)[g] = s1;
+    reinterpret_cast<d4*>(o + cols)[g] = s2;
+  }
+}
+
+// out = act(h * scale + shift) + residual, 16 bytes per thread
+__global__ void __launch_bounds__(256) affine_act_residual_kernel(const float* __restrict__ h, const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift,
+                                                                  const float* __restrict__ residual, int relu,
+                                                                  int64_t quads, int cg, float* __restrict__ out) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= quads) return;
+  const int g = (int)(k % cg);
+  f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4*>(h) + k) * reinterpret_cast<const f4*>(scale)[g] +
+         reinterpret_cast<const f4*>(shift)[g];
+  if (relu) v = f4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+  if (residual != nullptr) v += __builtin_nontemporal_load(reinterpret_cast<const f4*>(residual) + k);
+  __builtin_nontemporal_store(v, reinterpret_cast<f4*>(out) + k);
+}
+
+// dh = A * g + B * h + C with g = dout * [h * scale + shift > 0] (relu) or dout
+__global__ void __launch_bounds__(256) tail_backward_kernel(const float* __restrict__ dout, const float* __restrict__ h,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            int relu, const float* __restrict__ ca, const float* __restrict__ cb,
+                                                            const float* __restrict__ cc, int64_t quads, int cg,
+                                                            float* __restrict__ dh) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= quads) return;
+  const int g = (int)(k % cg);
+  const f4 hv = __builtin_nontemporal_load(reinterpret_cast<const f4*>(h) + k);
+  f4 gv = __builtin_nontemporal_load(reinterpret_cast<const f4*>(dout) + k);
+  if (relu) {
+    const f4 pre = hv * reinterpret_cast<const f4*>(scale)[g] + reinterpret_cast<const f4*>(shift)[g];
+    gv = f4{pre.x > 0.f ? gv.x : 0.f, pre.y > 0.f ? gv.y : 0.f, pre.z > 0.f ? gv.z : 0.f, pre.w > 0.f ? gv.w : 0.f};
+  }
+  const f4 r = reinterpret_cast<const f4*>(ca)[g] * gv + reinterpret_cast<const f4*>(cb)[g] * hv + reinterpret_cast<const f4*>(cc)[g];
+  __builtin_nontemporal_store(r, reinterpret_cast<f4*>(dh) + k);
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+}  // namespace egc
+
+using namespace egc;
+
+extern "C" {
+
+int egc_column_moments_f64(const float* a, const float* b, const float* scale, const float* shift, int64_t n_rows,
+                           int32_t cols, double* partials, int32_t n_partials, egc_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_rows < 0 || cols <= 0 || partials == nullptr || n_partials <= 0) return EGC_ERR_INVALID;
+  if ((cols & 3) != 0 || cols > 1024 || !aligned16(a) || !aligned16(b) || !aligned16(scale) || !aligned16(shift) ||
+      (reinterpret_cast<uintptr_t>(partials) & 31) != 0)
+    return EGC_ERR_UNSUPPORTED;
+  if (n_rows > 0 && a == nullptr) return EGC_ERR_INVALID;
+  const bool masked = b != nullptr;
+  if (masked && (scale == nullptr || shift == nullptr)) return EGC_ERR_INVALID;
+  const int rows_per_block = (int)std::max<int64_t>(ceil_div(n_rows, (int64_t)n_partials), 1);  // empty blocks write zeros
+  if (masked)
+    column_moments_kernel<true><<<(unsigned)n_partials, 256, 0, stream>>>(a, b, scale, shift, n_rows, cols, rows_per_block, partials);
+  else
+    column_moments_kernel<false><<<(unsigned)n_partials, 256, 0, stream>>>(a, nullptr, nullptr, nullptr, n_rows, cols, rows_per_block, partials);
+  EGC_LAUNCH_CHECK("column_moments_kernel");
+  return EGC_OK;
+}
+
+int egc_affine_act_residual_f32(const float* h, const float* scale, const float* shift, const float* residual,
+                                int32_t relu, int64_t n_rows, int32_t cols, float* out, egc_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_rows < 0 || cols <= 0 || scale == nullptr || shift == nullptr) return EGC_ERR_INVALID;
+  if ((cols & 3) != 0 || !aligned16(h) || !aligned16(scale) || !aligned16(shift) || !aligned16(residual) || !aligned16(out))
+    return EGC_ERR_UNSUPPORTED;
+  if (n_rows == 0) return EGC_OK;
+  if (h == nullptr || out == nullptr) return EGC_ERR_INVALID;
+  const int64_t quads = n_rows * (cols / 4);
+  affine_act_residual_kernel<<<(unsigned)ceil_div(quads, 256), 256, 0, stream>>>(h, scale, shift, residual, relu, quads, cols / 4, out);
+  EGC_LAUNCH_CHECK("affine_act_residual_kernel");
+  return EGC_OK;
+}
+
+int egc_affine_act_backward_f32(const float* dout, const float* h, const float* scale, const float* shift, int32_t relu,
+                                const float* coef_g, const float* coef_h, const float* coef_1, int64_t n_rows, int32_t cols,
+                                float* dh, egc_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_rows < 0 || cols <= 0 || scale == nullptr || shift == nullptr || coef_g == nullptr || coef_h == nullptr ||
+      coef_1 == nullptr)
+    return EGC_ERR_INVALID;
+  if ((cols & 3) != 0 || !aligned16(dout) || !aligned16(h) || !aligned16(scale) || !aligned16(shift) || !aligned16(coef_g) ||
+      !aligned16(coef_h) || !aligned16(coef_1) || !aligned16(dh))
+    return EGC_ERR_UNSUPPORTED;
+  if (n_rows == 0) return EGC_OK;
+  if (dout == nullptr || h == nullptr || dh == nullptr) return EGC_ERR_INVALID;
+  const int64_t quads = n_rows * (cols / 4);
+  tail_backward_kernel<<<(unsigned)ceil_div(quads, 256), 256, 0, stream>>>(dout, h, scale, shift, relu, coef_g, coef_h, coef_1, quads,
+                                                                         cols / 4, dh);
+  EGC_LAUNCH_CHECK("tail_backward_kernel");
+  return EGC_OK;
+}
+
+}  // extern "C"

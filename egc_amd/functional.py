@@ -612,6 +612,97 @@ class _AggregateCombineFunction(torch.autograd.Function):
         return d_bases, d_w, dbias, None, None
 
 
+def _column_moments(a: torch.Tensor, b=None, scale=None, shift=None):
+    """(sum_r g, sum_r g * b) per column in float64 through egc_column_moments_f64; b is None: g = a and the second
+    sum is the second moment of a; else g = a * [b * scale + shift > 0]."""
+    lib = _C.load()
+    n, c = a.shape
+    dev = a.device
+    with _device_guard(dev):
+        parts = max(1, min(1024, (n + 127) // 128))
+        out = torch.empty((parts, 2, c), dtype=torch.float64, device=dev)
+        _C.check(lib.egc_column_moments_f64(a.data_ptr(), b.data_ptr() if b is not None else None,
+                                            scale.data_ptr() if scale is not None else None,
+                                            shift.data_ptr() if shift is not None else None, n, c, out.data_ptr(), parts,
+                                            _stream_ptr(dev)), "egc_column_moments_f64")
+    m = out.sum(0)
+    return m[0], m[1]
+
+
+class _BatchNormActResidualFunction(torch.autograd.Function):
+    """out = act(batch_norm(h; batch statistics) * gamma + beta) + residual -- the training-mode tail of the
+    reference's blocks (zinc/models.py:66-72) in two streaming passes each way (egc_tail.hip).  Returns
+    (out, batch mean, biased batch variance); the running statistics are the caller's."""
+
+    @staticmethod
+    def forward(ctx, h, residual, gamma, beta, eps, relu):
+        lib = _C.load()
+        n, c = h.shape
+        dev = h.device
+        h = h.contiguous()
+        s1, s2 = _column_moments(h)
+        mean = s1 / n
+        var = (s2 / n - mean * mean).clamp_(min=0.0)            # biased, float64
+        rstd = torch.rsqrt(var + eps)
+        g64 = gamma.double() if gamma is not None else torch.ones(c, dtype=torch.float64, device=dev)
+        b64 = beta.double() if beta is not None else torch.zeros(c, dtype=torch.float64, device=dev)
+        scale = (g64 * rstd).float()
+        shift = (b64 - mean * g64 * rstd).float()
+        res = residual.contiguous() if residual is not None else None
+        with _device_guard(dev):
+            out = torch.empty_like(h)
+            _C.check(lib.egc_affine_act_residual_f32(h.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                                     res.data_ptr() if res is not None else None, int(relu), n, c,
+                                                     out.data_ptr(), _stream_ptr(dev)), "egc_affine_act_residual_f32")
+        ctx.save_for_backward(h, scale, shift, mean, rstd, gamma)
+        ctx.relu, ctx.has_res, ctx.has_gamma, ctx.has_beta = bool(relu), residual is not None, gamma is not None, beta is not None
+        ctx.mark_non_differentiable(mean, var)
+        return out, mean, var
+
+    @staticmethod
+    def backward(ctx, dout, _dmean, _dvar):
+        lib = _C.load()
+        h, scale, shift, mean, rstd, gamma = ctx.saved_tensors
+        n, c = h.shape
+        dev = h.device
+        dout = dout.contiguous()
+        dh = dgamma = dbeta = None
+        if ctx.needs_input_grad[0] or (ctx.has_gamma and ctx.needs_input_grad[2]) or (ctx.has_beta and ctx.needs_input_grad[3]):
+            if ctx.relu:
+                s1, sgh = _column_moments(dout, h, scale, shift)       # sum g, sum g h   (g = dout * relu mask)
+            else:
+                s1 = _column_sums(dout).double()
+                sgh = (dout.double() * h.double()).sum(0) if n else torch.zeros(c, dtype=torch.float64, device=dev)
+            s2 = (sgh - mean * s1) * rstd                               # sum g * h_hat
+            dgamma = s2.float() if ctx.has_gamma and ctx.needs_input_grad[2] else None
+            dbeta = s1.float() if ctx.has_beta and ctx.needs_input_grad[3] else None
+            if ctx.needs_input_grad[0]:
+                g64 = gamma.double() if gamma is not None else torch.ones(c, dtype=torch.float64, device=dev)
+                a = g64 * rstd                                          # dh = a g - (a / n) (s1 + (h - mean) rstd s2)
+                coef_g = a.float()
+                coef_h = (-(a / n) * rstd * s2).float()
+                coef_1 = (-(a / n) * (s1 - mean * rstd * s2)).float()
+                with _device_guard(dev):
+                    dh = torch.empty_like(h)
+                    _C.check(lib.egc_affine_act_backward_f32(dout.data_ptr(), h.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                                             int(ctx.relu), coef_g.data_ptr(), coef_h.data_ptr(),
+                                                             coef_1.data_ptr(), n, c, dh.data_ptr(), _stream_ptr(dev)),
+                             "egc_affine_act_backward_f32")
+        dres = dout if ctx.has_res and ctx.needs_input_grad[1] else None
+        return dh, dres, dgamma, dbeta, None, None
+
+
+def batch_norm_act_residual_supported(h: torch.Tensor) -> bool:
+    return (h.is_cuda and h.dtype == torch.float32 and h.dim() == 2 and h.size(0) > 1 and h.size(1) % 4 == 0
+            and h.size(1) <= 1024)
+
+
+def batch_norm_act_residual(h, residual, gamma, beta, eps: float, relu: bool):
+    """Training-mode BatchNorm1d (batch statistics) -> optional ReLU -> optional residual add, fused
+    (_BatchNormActResidualFunction): returns (out, batch mean [C] float64, biased batch variance [C] float64)."""
+    return _BatchNormActResidualFunction.apply(h, residual, gamma, beta, float(eps), bool(relu))
+
+
 def egc_aggregate_combine_apply(graph, spec, bases, weightings, bias=None):
     """egc_aggregate_combine with autograd when any input requires a gradient."""
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (bases, weightings, bias)):

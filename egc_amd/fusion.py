@@ -4,15 +4,18 @@ The reference's graph nets wrap every EGC layer the same way (zinc/models.py:66-
 cifar/models.py:67-74):   x = conv(x, edge_index);  x = bn(x);  x = relu(x);  x = x + identity   and finish with
 ``global_mean_pool(x, batch)``.  In eval mode BatchNorm1d is a per-channel affine map, so the whole tail folds into the
 store of the fused aggregate/combine kernel (``egc_aggregate_combine_post_f32``): three elementwise passes over
-[N, F_out] and three launches less per layer.  In training mode the block runs the plain sequence (batch statistics
-need the un-normalised activations anyway).
+[N, F_out] and three launches less per layer.  With batch statistics (training) the statistics need every row of the
+layer's output first, so the tail is its own two streaming passes each way (``batch_norm_act_residual``:
+statistics, then normalise + ReLU + residual in one pass; backward the two BatchNorm sums with the ReLU mask
+recomputed, then one pass for the gradient) instead of PyTorch's pass per operator.
 """
 from __future__ import annotations
 
 import torch
 import torch.nn as nn
 
-from .functional import PostOp, egc_layer_forward, segment_mean
+from .functional import (PostOp, batch_norm_act_residual, batch_norm_act_residual_supported, egc_layer_forward,
+                         segment_mean)
 from .graph import graph_from_input
 
 
@@ -33,11 +36,31 @@ class FusedEGCBlock(nn.Module):
             h = torch.relu(h)
         return x + h if self.residual else h
 
+    def _batch_stats(self, x, edge_index):
+        """conv, then BatchNorm1d on batch statistics -> ReLU -> + input in two passes; the running statistics are
+        updated as nn.BatchNorm1d does (momentum or cumulative average, unbiased variance)."""
+        bn = self.bn
+        h = self.conv(x=x, edge_index=edge_index) if hasattr(self.conv, "aggs") else self.conv(x, edge_index)
+        if not batch_norm_act_residual_supported(h) or (self.residual and x.shape != h.shape):
+            h = bn(h)
+            h = torch.relu(h) if self.relu else h
+            return x + h if self.residual else h
+        out, mean, var = batch_norm_act_residual(h, x if self.residual else None, bn.weight if bn.affine else None,
+                                                 bn.bias if bn.affine else None, bn.eps, self.relu)
+        if bn.training and bn.track_running_stats:
+            with torch.no_grad():
+                n = h.size(0)
+                bn.num_batches_tracked += 1
+                m = 1.0 / float(bn.num_batches_tracked) if bn.momentum is None else bn.momentum
+                bn.running_mean.mul_(1 - m).add_(mean.to(bn.running_mean.dtype), alpha=m)
+                bn.running_var.mul_(1 - m).add_((var * (n / (n - 1))).to(bn.running_var.dtype), alpha=m)
+        return out
+
     def forward(self, x, edge_index):
         bn = self.bn
-        fusable = not (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())))
         if bn is not None and (bn.training or not bn.track_running_stats):
-            fusable = False
+            return self._batch_stats(x, edge_index)      # batch statistics: the tail is its own two passes
+        fusable = not (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())))
         if not fusable:
             return self._plain(x, edge_index)
         conv = self.conv

@@ -270,6 +270,30 @@ int egc_weight_grad_f32(const float* x, int64_t ldx, const float* d, int64_t ldd
                         int32_t k_cols, float* out, float* col_sums, void* workspace, int64_t workspace_bytes,
                         void* stream);
 
+/* The caller-side tail of a layer in TRAINING mode: conv -> BatchNorm1d (batch statistics) -> ReLU -> + input, as the
+ * reference's nets run it every step (zinc/models.py:66-72, mol/pna_style_models.py:71-78, cifar/models.py:67-74).
+ * Two streaming passes forward and two backward instead of one per PyTorch operator; in eval mode the tail needs no
+ * pass at all (egc_post).  h, residual, out, dout, dh are dense [n_rows, cols] float32 arrays, cols a multiple of 4
+ * (<= 1024 for the moments), every pointer 16-byte aligned (EGC_ERR_UNSUPPORTED otherwise).
+ *
+ *   egc_column_moments_f64      partials[p][0][c] = sum over the p-th block of rows of g[r][c],
+ *                               partials[p][1][c] = sum of g[r][c] * b[r][c], accumulated in float64 (the caller adds
+ *                               the n_partials blocks).  b == NULL: g = a, second moment of a itself (forward: batch
+ *                               mean and variance of h).  b != NULL: g = a * [b * scale + shift > 0] (backward: a =
+ *                               dout, b = h; the ReLU mask is recomputed from h, not stored), giving the two sums of
+ *                               the BatchNorm backward.  partials: n_partials * 2 * cols doubles, 32-byte aligned.
+ *   egc_affine_act_residual_f32 out = act(h * scale + shift) + residual   (scale = gamma * rstd, shift = beta - mean *
+ *                               scale; relu != 0: act = max(., 0); residual may be NULL)
+ *   egc_affine_act_backward_f32 dh = coef_g * g + coef_h * h + coef_1 per channel, g as above: the BatchNorm backward
+ *                               with its two sums folded into the three per-channel coefficient vectors. */
+int egc_column_moments_f64(const float* a, const float* b, const float* scale, const float* shift, int64_t n_rows,
+                           int32_t cols, double* partials, int32_t n_partials, egc_stream_t stream);
+int egc_affine_act_residual_f32(const float* h, const float* scale, const float* shift, const float* residual,
+                                int32_t relu, int64_t n_rows, int32_t cols, float* out, egc_stream_t stream);
+int egc_affine_act_backward_f32(const float* dout, const float* h, const float* scale, const float* shift, int32_t relu,
+                                const float* coef_g, const float* coef_h, const float* coef_1, int64_t n_rows, int32_t cols,
+                                float* dh, egc_stream_t stream);
+
 /* Column sums of a row-major array with row stride ld (floats), as n_partials partial rows:
  * partials[p, c] = sum of x[r, c] over the p-th block of rows, c < cols; the caller adds the few partial rows up.
  * The bias gradients of a training step (grad_out summed over the nodes for `bias`, d_weightings for the

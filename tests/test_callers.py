@@ -116,11 +116,58 @@ def test_fused_block_equals_conv_bn_relu_residual(hidden, H, B, aggrs):
             ref = block._plain(x, ei)
         scale = max(1.0, float(ref.abs().max()))
         assert float((got - ref).abs().max()) / scale <= 1e-5, (relu, residual, use_bn)
-    # training mode (or grad needed): the block runs the plain sequence and stays differentiable
+    # training mode: batch statistics (test_fused_block_training_tail_equals_batch_norm_relu_residual); differentiable
     block = egc_amd.FusedEGCBlock(conv, bn).train()
     xg = x.clone().requires_grad_(True)
     block(xg, ei).sum().backward()
     assert xg.grad is not None and bool(torch.isfinite(xg.grad).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hidden,H,B,aggrs", [(128, 8, 4, ["symadd", "max", "mean"]), (168, 8, 4, ["symadd"]),
+                                              (42, 6, 3, ["add", "std"])])   # 42 % 4 != 0: the plain sequence
+@pytest.mark.parametrize("relu,residual,affine,momentum", [(True, True, True, 0.1), (False, True, True, None),
+                                                           (True, False, False, 0.1)])
+def test_fused_block_training_tail_equals_batch_norm_relu_residual(hidden, H, B, aggrs, relu, residual, affine, momentum):
+    """FusedEGCBlock (training): conv -> BatchNorm1d on batch statistics -> ReLU -> + identity in two streaming passes
+    each way (egc_tail.hip) == the reference nets' separate operators (zinc/models.py:66-72): output, gradients
+    w.r.t. the input and every parameter, running statistics."""
+    import copy
+    dev = torch.device("cuda:0")
+    atom, ei, n, batch = zinc_like_batch(64, seed=7)
+    torch.manual_seed(3)
+    conv = egc_amd.EfficientGraphConv(hidden, hidden, num_heads=H, num_bases=B, softmax_weights=False, aggrs=aggrs).to(dev)
+    bn = nn.BatchNorm1d(hidden, affine=affine, momentum=momentum).to(dev)
+    with torch.no_grad():
+        if affine:
+            bn.weight.normal_(); bn.bias.normal_()
+        conv.bias.normal_()
+    conv_r, bn_r = copy.deepcopy(conv), copy.deepcopy(bn)
+    x = torch.randn(n, hidden, device=dev)
+    gout = torch.randn(n, hidden, device=dev)
+    ei = ei.to(dev)
+    block = egc_amd.FusedEGCBlock(conv, bn, relu=relu, residual=residual).train()
+    ref_block = egc_amd.FusedEGCBlock(conv_r, bn_r, relu=relu, residual=residual).train()
+    for step in range(2):                       # two steps: the running statistics move twice
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        got = block(xa, ei)
+        ref = ref_block._plain(xb, ei)
+        (got * gout).sum().backward()
+        (ref * gout).sum().backward()
+        scale = max(1.0, float(ref.detach().abs().max()))
+        assert float((got.detach() - ref.detach()).abs().max()) / scale <= 1e-5, step
+
+        def close(a, b, what, tol=2e-5):
+            assert float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max())), (what, step)
+        close(xa.grad, xb.grad, "x.grad")
+        for (name, pa), (_, pb) in zip(list(conv.named_parameters()) + list(bn.named_parameters()),
+                                       list(conv_r.named_parameters()) + list(bn_r.named_parameters())):
+            # PyTorch's own fp32 BatchNorm backward is the yardstick here: both sides sum 10^3 float32 products
+            close(pa.grad, pb.grad, name, tol=1e-4)
+            pa.grad = None; pb.grad = None
+        close(bn.running_mean, bn_r.running_mean, "running_mean")
+        close(bn.running_var, bn_r.running_var, "running_var")
+        assert int(bn.num_batches_tracked) == int(bn_r.num_batches_tracked) == step + 1
 
 
 @pytest.mark.gpu
