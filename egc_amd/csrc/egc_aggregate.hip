@@ -388,7 +388,9 @@ static WsLayout ws_layout(const egc_layer* L, int64_t n_nodes, int64_t n_edges, 
   w.partial_bytes = align256((size_t)rec_chunks * 7 * rec_lanes * 16);
   w.nself_bytes = align256((size_t)rec_chunks * sizeof(int));
   w.queue_bytes = align256((size_t)FUSEDW_QUEUE_INTS * sizeof(int));  // work queue of the fused-weightings launch
-  w.total = w.counter_bytes + w.partial_bytes + w.nself_bytes + w.queue_bytes;
+  // order: [counters][queue] -- the part that must be zero before the first use, its size a function of (n_nodes,
+  // n_edges) alone -- then [partials][nself], records that are written before they are read
+  w.total = w.counter_bytes + w.queue_bytes + w.partial_bytes + w.nself_bytes;
   return w;
 }
 
@@ -422,6 +424,12 @@ int32_t egc_bases_ld(const egc_layer* layer) {
 size_t egc_aggregate_workspace_bytes_for(const egc_layer* layer, const egc_graph* graph) {
   if (graph == nullptr || validate_layer(layer) != EGC_OK || graph->n_nodes < 0 || graph->n_edges < 0) return 0;
   return ws_layout(layer, graph->n_nodes, graph->n_edges, graph->n_chunks).total;
+}
+
+size_t egc_aggregate_workspace_zero_bytes(const egc_layer* layer, int64_t n_nodes, int64_t n_edges) {
+  if (validate_layer(layer) != EGC_OK || n_nodes < 0 || n_edges < 0) return 0;
+  const WsLayout w = ws_layout(layer, n_nodes, n_edges);
+  return w.counter_bytes + w.queue_bytes;
 }
 
 size_t egc_aggregate_workspace_bytes(const egc_layer* layer, int64_t n_nodes, int64_t n_edges) {
@@ -608,9 +616,9 @@ static int aggregate_combine_impl(const egc_graph* graph, const egc_layer* layer
   WsLayout w = ws_layout(layer, n, e, graph->n_chunks);
   if (workspace == nullptr || workspace_bytes < w.total) return EGC_ERR_WORKSPACE;
   a.counters = (int*)workspace;
-  a.partial = (float*)((char*)workspace + w.counter_bytes);
-  a.partial_nself = (int*)((char*)workspace + w.counter_bytes + w.partial_bytes);
-  a.queue = (int*)((char*)workspace + w.counter_bytes + w.partial_bytes + w.nself_bytes);
+  a.queue = (int*)((char*)workspace + w.counter_bytes);
+  a.partial = (float*)((char*)workspace + w.counter_bytes + w.queue_bytes);
+  a.partial_nself = (int*)((char*)workspace + w.counter_bytes + w.queue_bytes + w.partial_bytes);
   a.x = x_fused;
   a.F_in = layer->in_channels;
   a.M = 0;  // set by launch_fusedw

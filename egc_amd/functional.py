@@ -152,7 +152,8 @@ def egc_aggregate_combine(graph: CSRGraph, spec: LayerSpec, bases: torch.Tensor,
         if out is None:
             out = torch.empty((n, spec.f_out), dtype=torch.float32, device=dev)
         g = graph.c_struct()
-        ws = graph.workspace(lib.egc_aggregate_workspace_bytes_for(C.byref(spec.c), C.byref(g)))
+        ws = graph.workspace(lib.egc_aggregate_workspace_bytes_for(C.byref(spec.c), C.byref(g)),
+                             lib.egc_aggregate_workspace_zero_bytes(C.byref(spec.c), graph.n_nodes, graph.n_edges))
         bias_p = bias.contiguous().data_ptr() if bias is not None else None
         if ldw != spec.w_cols:
             keep = []
@@ -279,7 +280,8 @@ def egc_layer_forward_fused(graph: CSRGraph, spec: LayerSpec, x: torch.Tensor, p
         bases = torch.empty((n, spec.ldb), dtype=torch.float32, device=dev)
         out = torch.empty((n, spec.f_out), dtype=torch.float32, device=dev)
         g = graph.c_struct()
-        ws = graph.workspace(lib.egc_aggregate_workspace_bytes_for(C.byref(spec.c), C.byref(g)))
+        ws = graph.workspace(lib.egc_aggregate_workspace_bytes_for(C.byref(spec.c), C.byref(g)),
+                             lib.egc_aggregate_workspace_zero_bytes(C.byref(spec.c), graph.n_nodes, graph.n_edges))
         bias_p = bias.contiguous().data_ptr() if bias is not None else None
         stream = _stream_ptr(dev)
         if post is None:
@@ -320,7 +322,8 @@ def _layer_forward_one_call(graph: CSRGraph, spec: LayerSpec, x, packed, bcat, b
         weightings = torch.empty((n, spec.w_cols), dtype=torch.float32, device=dev)
         out = torch.empty((n, spec.f_out), dtype=torch.float32, device=dev)
         g = graph.c_struct()
-        ws = graph.workspace(lib.egc_aggregate_workspace_bytes_for(C.byref(spec.c), C.byref(g)))
+        ws = graph.workspace(lib.egc_aggregate_workspace_bytes_for(C.byref(spec.c), C.byref(g)),
+                             lib.egc_aggregate_workspace_zero_bytes(C.byref(spec.c), graph.n_nodes, graph.n_edges))
         _C.check(lib.egc_layer_forward_packed(
             C.byref(g), C.byref(spec.c), x.data_ptr(), packed.data_ptr(),
             bcat.contiguous().data_ptr() if bcat is not None else None,
@@ -380,7 +383,8 @@ def egc_aggregate_combine_train(graph: CSRGraph, spec: LayerSpec, bases: torch.T
         arg_max = torch.empty((n, spec.ldb), dtype=torch.int32, device=dev) if _C.AGGR_MAX in codes else None
         arg_min = torch.empty((n, spec.ldb), dtype=torch.int32, device=dev) if _C.AGGR_MIN in codes else None
         g = graph.c_struct()
-        ws = graph.workspace(lib.egc_aggregate_workspace_bytes_for(C.byref(spec.c), C.byref(g)))
+        ws = graph.workspace(lib.egc_aggregate_workspace_bytes_for(C.byref(spec.c), C.byref(g)),
+                             lib.egc_aggregate_workspace_zero_bytes(C.byref(spec.c), graph.n_nodes, graph.n_edges))
         _C.check(lib.egc_aggregate_combine_train_f32(
             C.byref(g), C.byref(spec.c), bases.data_ptr(), spec.ldb, weightings.data_ptr(),
             bias.contiguous().data_ptr() if bias is not None else None, out.data_ptr(), stats.data_ptr(),

@@ -263,13 +263,20 @@ class CSRGraph:
             self._transposed.trim_launches()
         return self._transposed
 
-    def workspace(self, nbytes: int) -> torch.Tensor:
-        """Scratch for egc_aggregate_combine_f32.  The C ABI wants it zero-filled before its first use
-        and leaves it reusable afterwards, so it is zeroed once and kept per (size, stream)."""
+    def workspace(self, nbytes: int, zero_bytes: int | None = None) -> torch.Tensor:
+        """Scratch for egc_aggregate_combine_f32, kept per (size, stream).  The C ABI wants the first ``zero_bytes``
+        bytes (egc_aggregate_workspace_zero_bytes: the long-row arrival counters) zero before the first use and leaves
+        the buffer reusable afterwards; the rest -- capacity-sized chunk records, 60 MB for a CIFAR batch of 2048
+        graphs -- is written before it is read and is not filled."""
         key = (int(nbytes), _stream_ptr(self.device))
         ws = self._workspaces.get(key)
         if ws is None:
-            ws = torch.zeros(max(int(nbytes), 1), dtype=torch.uint8, device=self.device)
+            n = max(int(nbytes), 1)
+            if zero_bytes is None or zero_bytes >= n:
+                ws = torch.zeros(n, dtype=torch.uint8, device=self.device)
+            else:
+                ws = torch.empty(n, dtype=torch.uint8, device=self.device)
+                ws[:int(zero_bytes)].zero_()
             self._workspaces[key] = ws
         return ws
 

@@ -199,10 +199,14 @@ int egc_basis_transform_packed(const float* x, const void* packed, const float* 
                                float* weightings, egc_stream_t stream);
 
 /* Scratch bytes egc_aggregate_combine_f32 needs for this layer on this graph.
- * CONTRACT: the workspace must be zero-filled before its FIRST use (it holds the long-row arrival
- * counters of the fused kernel); every call leaves it ready for the next call on the same stream.
- * One workspace must not be shared by calls that may run concurrently on different streams. */
+ * CONTRACT: its first egc_aggregate_workspace_zero_bytes() bytes must be zero before its FIRST use (the long-row
+ * arrival counters of the fused kernel: 4 bytes per possible long row); the rest holds chunk records that are written
+ * before they are read and may start with any contents -- a per-batch graph costs an allocation and a memset of a
+ * few KB, not of the whole capacity-sized buffer.  Every call leaves the workspace ready for the next call on the
+ * same stream.  One workspace must not be shared by calls that may run concurrently on different streams, nor
+ * between graphs of different sizes (the zero part of one layout overlaps the records of another). */
 size_t egc_aggregate_workspace_bytes(const egc_layer* layer, int64_t n_nodes, int64_t n_edges);
+size_t egc_aggregate_workspace_zero_bytes(const egc_layer* layer, int64_t n_nodes, int64_t n_edges);
 /* The same for one graph: when egc_graph.n_chunks carries the host copy of the plan's chunk count, the records of
  * chunk slots that do not exist are not allocated (ogbn-mag shape: 0.2 GB instead of 1.5 GB); with n_chunks = -1 it
  * equals egc_aggregate_workspace_bytes.  A workspace of this size serves exactly this graph. */

@@ -465,6 +465,45 @@ def test_layer_forward_is_graph_capturable():
     assert rel_err(out.cpu().numpy(), ref2.cpu().numpy()) <= TOL
 
 
+def test_workspace_needs_only_its_zero_prefix():
+    """egc_aggregate_workspace_zero_bytes: only the arrival counters at the front of the workspace have to be zero
+    before the first use; the chunk records behind them may hold anything (a per-batch graph's workspace is not
+    filled).  Hub rows present: long-row chunks are what the workspace is for."""
+    import ctypes as C
+    import egc_amd
+    from egc_amd import _C
+    from egc_amd import functional as F
+    from egc_amd.workloads import heavy_tailed_graph
+    dev = _dev()
+    lib = _C.load()
+    n = 20000
+    ei = heavy_tailed_graph(n, 200000, seed=11).to(dev)
+    conv = egc_amd.EGConv(128, 128, aggrs=["sum", "mean", "max", "symnorm"]).to(dev).eval()
+    graph = egc_amd.CSRGraph.from_edge_index(ei, n)
+    spec = conv._spec_coo
+    total = int(lib.egc_aggregate_workspace_bytes(C.byref(spec.c), n, ei.size(1)))
+    zero = int(lib.egc_aggregate_workspace_zero_bytes(C.byref(spec.c), n, ei.size(1)))
+    assert 0 < zero < total and zero % 16 == 0
+    with torch.no_grad():
+        wcat, bcat = conv._packed_weights()
+        x = torch.randn(n, 128, device=dev)
+        bases, wt = F.egc_basis_transform(graph, spec, x, wcat, bcat, None)
+        ref = F.egc_aggregate_combine(graph, spec, bases, wt, conv.bias)       # the graph's own (zero-prefixed) workspace
+        g = graph.c_struct()
+        for fill in (0xFF, 0x7F, 0x01):
+            ws = torch.full((total,), fill, dtype=torch.uint8, device=dev)
+            ws[:zero].zero_()
+            out = torch.empty((n, 128), device=dev)
+            for _ in range(2):   # second call: the workspace is left ready by the first
+                _C.check(lib.egc_aggregate_combine_f32(C.byref(g), C.byref(spec.c), bases.data_ptr(), spec.ldb, wt.data_ptr(),
+                                                       conv.bias.data_ptr(), out.data_ptr(), None, None, ws.data_ptr(),
+                                                       ws.numel(), torch.cuda.current_stream().cuda_stream),
+                         "egc_aggregate_combine_f32")
+                torch.cuda.synchronize()
+                assert torch.equal(out, ref), fill
+            assert bool((ws[:zero] == 0).all())
+
+
 def test_arrays_beyond_two_gib_sampled_rows_against_float64():
     """N = 4.3 M nodes: x, weightings and out exceed 2 GiB each (the GEMM runs in row ranges, the aggregate's
     32-bit buffer offsets pass 2^31), a hub row of ~10^5 entries.  Sampled rows -- the first, the last, the hub,
