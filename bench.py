@@ -188,6 +188,22 @@ def other_configs(dev, seed):
     out["config2_training_step"] = {"workload": "config 2, forward + backward of one EGConv layer through autograd (gradients cleared every step)",
                                     "step_ms": ms, "edges_per_s": (int(ei.size(1)) + n) / (ms * 1e-3)}
     log(f"  training step (config 2): {ms:.4f} ms")
+    # the reference nets' block (zinc/models.py:66-72): conv -> BatchNorm1d (batch statistics) -> ReLU -> + input
+    bn = torch.nn.BatchNorm1d(F_OUT).to(dev)
+    block = egc_amd.FusedEGCBlock(layer, bn).train()
+
+    def block_step(fn):
+        block.zero_grad(set_to_none=True)
+        x.grad = None
+        fn(x, g).backward(go)
+    for fn in (block, block._plain):
+        for _ in range(3):
+            block_step(fn)
+    ms_fused = time_region(lambda: block_step(block), 10)
+    ms_torch = time_region(lambda: block_step(block._plain), 10)
+    out["config2_training_block"] = {"workload": "config 2, forward + backward of conv -> BatchNorm1d(train) -> ReLU -> + input",
+                                     "step_ms": ms_fused, "step_ms_with_torch_tail": ms_torch}
+    log(f"  training block (config 2): {ms_fused:.4f} ms (torch tail: {ms_torch:.4f} ms)")
     return out
 
 

@@ -1,0 +1,25 @@
+#!/bin/bash
+# Collects the rocprofv3 summaries kept under profiles/ (run on the GPU box through gpurun from the repository root:
+#   gpurun -- 'bash tools/collect_profiles.sh r02'
+# then `python tools/summarize_profiles.py r02` here copies / condenses them into profiles/).
+# Counters are collected in their own passes (--pmc never combined with tracing), one counter set per pass.
+TAG=${1:-r02}
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+B="python3 $R/bench.py --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats -d $O/kt2 -o kt --output-format csv -- $B --no-other-configs > $O/bench_config2_under_rocprof.json 2> $O/kt2.log
+rocprofv3 --kernel-trace --stats -d $O/kt -o kt --output-format csv -- $B > $O/bench_under_rocprof.json 2> $O/kt.log
+rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o pmc --output-format csv -- $B --no-other-configs --steps 20 --warmup 5 > /dev/null 2> $O/pmc_fetch.log
+rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o pmc --output-format csv -- $B --no-other-configs --steps 20 --warmup 5 > /dev/null 2> $O/pmc_write.log
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_BUSY_CYCLES -d $O/pmc_sq -o pmc --output-format csv -- $B --no-other-configs --steps 20 --warmup 5 > /dev/null 2> $O/pmc_sq.log
+rocprofv3 --kernel-trace --stats -d $O/train -o kt --output-format csv -- python3 $R/tools/training_step_time.py > $O/train.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/block -o kt --output-format csv -- python3 $R/tools/block_step_time.py > $O/block.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/mag -o kt --output-format csv -- python3 $R/bench.py --workload mag --steps 20 --warmup 5 > $O/mag_bench.json 2> $O/mag.log
+cd $R
+python3 bench.py > $O/bench.json 2> $O/bench.err
+tail -3 $O/bench.err
+# the raw per-dispatch traces are large: keep the statistics and the counter collections only
+find $O -name "*kernel_trace.csv" -delete
+du -sh $O
