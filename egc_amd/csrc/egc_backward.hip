@@ -539,13 +539,6 @@ __global__ void __launch_bounds__(256) bwd_dst_fast_kernel(BwdArgs a) {
       default: d_s += d * f4{dis_i, dis_i, dis_i, dis_i}; break;
     }
   }
-  if (wr && (a.arg8_max != nullptr || a.arg8_min != nullptr)) {  // the arg positions of this row, one byte each (see arg8_pack)
-    const int start = a.rowptr[rr];
-    if (a.arg8_max != nullptr)
-      reinterpret_cast<unsigned*>(a.arg8_max)[o >> 2] = arg8_pack(*reinterpret_cast<const int4*>(a.arg_max + o), start, a.n_edges);
-    if (a.arg8_min != nullptr)
-      reinterpret_cast<unsigned*>(a.arg8_min)[o >> 2] = arg8_pack(*reinterpret_cast<const int4*>(a.arg_min + o), start, a.n_edges);
-  }
   if (wr) {
     const f4 two_dv = d_v * f4{2.f * rcnt, 2.f * rcnt, 2.f * rcnt, 2.f * rcnt};
     if (a.need_t) __builtin_nontemporal_store(d_t - mean * two_dv, reinterpret_cast<f4*>(a.tab_t + o));  // else never read
@@ -952,7 +945,8 @@ int egc_aggregate_combine_backward_f32(const egc_graph* graph, const egc_graph* 
     } else {
       bwd_dst_kernel<<<(unsigned)ceil_div(n, wpb), wpb * 64, lds, stream>>>(a);
       EGC_LAUNCH_CHECK("bwd_dst_kernel");
-      // (the register-resident kernel derives the 8-bit arg positions itself)
+    }
+    {  // the arg positions in 8 bits (its own 13 us pass: folded into the destination kernel it cost that kernel 17)
       const int64_t quads = n * (ldb / 4);
       if (a.arg8_max != nullptr)
         arg8_kernel<<<(unsigned)ceil_div(quads, 256), 256, 0, stream>>>(arg_max, a.rowptr, reinterpret_cast<unsigned*>(a.arg8_max), quads,
