@@ -207,6 +207,42 @@ def other_configs(dev, seed):
     return out
 
 
+def bench_rmag(args, world, dev):
+    """The heterogeneous ogbn-mag shape (BASELINE.json's "~21M edges": rmag/models.py:18-26, 1.94 M nodes of 4 types,
+    21.1 M typed edges + reverses / symmetrisation = 42.1 M CSR entries in 7 relations) through one REGConv layer
+    (rmag/models.py:75-148) on ONE GPU; the relational layer has no partitioned form."""
+    import egc_amd
+    from egc_amd import workloads as wl
+    if world > 1:
+        raise SystemExit("bench.py --workload rmag: the relational layer runs on one GPU (no partitioned REGConv)")
+    torch.manual_seed(args.seed)
+    nodes, rel = wl.rmag_like(seed=args.seed)
+    adj = {}
+    for (s, r, d), ei in rel.items():
+        ei = ei.to(dev)
+        adj[(s, r, d)] = egc_amd.SparseTensor(row=ei[1], col=ei[0], sparse_sizes=(nodes[d], nodes[s]))
+    conv = egc_amd.REGConv(F_IN, F_OUT, HEADS, BASES).to(dev).eval()
+    x = {k: torch.randn(n, F_IN, device=dev) for k, n in nodes.items()}
+    entries = sum(int(v.shape[1]) for v in rel.values())
+    with torch.no_grad():
+        for _ in range(max(args.warmup, 3)):
+            conv(x, adj)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            conv(x, adj)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / args.steps * 1e3
+    print(json.dumps({
+        "metric": METRIC, "value": entries / (ms * 1e-3), "unit": "edges/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "gemm": "fp16x2 / bf16x3 split, one GEMM per node type", "data": "synthetic",
+        "config": {"workload": f"ogbn-mag-shaped typed graph ({sum(nodes.values())} nodes of {len(nodes)} types, "
+                               f"{entries} CSR entries in {len(rel)} relations), REGConv {F_IN}->{F_OUT} H={HEADS} B={BASES}",
+                   "layer": "REGConv", "parallelism": "single GPU"},
+        "roofline": None, "cpu_baseline": None}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -214,8 +250,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
-    ap.add_argument("--workload", default=None, choices=[None, "arxiv", "mag", "arxiv-weak"],
-                    help="default: arxiv (config 2) on one GPU, mag (config 5, strong scaling) on several")
+    ap.add_argument("--workload", default=None, choices=[None, "arxiv", "mag", "arxiv-weak", "rmag"],
+                    help="default: arxiv (config 2) on one GPU, mag (config 5, strong scaling) on several; rmag = the "
+                         "21 M-edge typed ogbn-mag graph through REGConv (SURVEY 8f row 4), one GPU only")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
 
@@ -224,6 +261,8 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     workload = args.workload or ("arxiv" if world == 1 else "mag")
+    if workload == "rmag":
+        return bench_rmag(args, world, dev)
     if workload != "arxiv" or world > 1:
         import bench_multi  # the partitioned workloads live in their own file
         return bench_multi.run(args, world, rank, local, workload)

@@ -18,6 +18,7 @@ rocprofv3 --kernel-trace --stats -d $O/train -o kt --output-format csv -- python
 rocprofv3 --kernel-trace --stats -d $O/block -o kt --output-format csv -- python3 $R/tools/block_step_time.py > $O/block.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/mag -o kt --output-format csv -- python3 $R/bench.py --workload mag --steps 20 --warmup 5 > $O/mag_bench.json 2> $O/mag.log
 cd $R
+python3 bench.py --workload rmag --steps 10 --warmup 3 > $O/rmag_bench.json 2> $O/rmag.err
 python3 bench.py > $O/bench.json 2> $O/bench.err
 tail -3 $O/bench.err
 # the raw per-dispatch traces are large: keep the statistics and the counter collections only

@@ -40,6 +40,7 @@ def main():
     cp("mag/kt_kernel_stats.csv", f"{tag}_mag_layer_kernel_stats.csv")
     cp("bench.json", f"{tag}_bench.json")
     cp("mag_bench.json", f"{tag}_mag_bench.json")
+    cp("rmag_bench.json", f"{tag}_rmag_bench.json")
     for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
         out = {"pmc_fetch": "pmc_fetch_size", "pmc_write": "pmc_write_size", "pmc_sq": "pmc_sq_counters"}[name]
         condense(os.path.join(src, name, "pmc_counter_collection.csv"), os.path.join(dst, f"{tag}_{out}.csv"))
