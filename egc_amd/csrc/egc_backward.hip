@@ -220,7 +220,9 @@ struct BwdArgs {
   const int* rowptr;         // destination-side row pointers (arg positions relative to their row)
   unsigned char* arg8_max;   // [N, ldb] the same positions as one byte each, relative to the row's first entry
   unsigned char* arg8_min;   //          (ARG8_NONE: self-loop / empty row, ARG8_FAR: >= ARG8_NONE entries into the row)
-  float* d_bases;            // [n_src_rows, ld_db >= ldb]  (zero-initialised by the host)
+  float* d_bases;            // [n_src_rows, ld_db >= ldb]
+  int overwrite_db;          // square graph: every d_bases row is WRITTEN (long source rows zeroed by the destination
+                             // kernel, short ones stored by the source kernel); else the host zero-fills and rows are added to
   float* d_weightings;       // [N, ld_dw >= W]
   int ld_db, ld_dw;          // row strides (floats) of the two gradient arrays
   float* tab_t;              // [N, ldb]
@@ -248,6 +250,8 @@ __global__ void __launch_bounds__(256) bwd_dst_kernel(BwdArgs a) {
   const int wave = threadIdx.x >> 6;
   const int row = blockIdx.x * (blockDim.x >> 6) + wave;
   if (row >= a.n_nodes) return;
+  if (a.overwrite_db && a.t_rowptr[row + 1] - a.t_rowptr[row] > EGC_LONG_ROW_THRESHOLD)   // its chunks add by atomics
+    for (int c = lane; c < a.ldb; c += 64) a.d_bases[(int64_t)row * a.ld_db + c] = 0.f;
   float* lds_agg = smem + wave * a.lds_floats_per_wave;
   float* lds_g = lds_agg + a.A * a.ldb;
   float* lds_w = lds_g + ((a.F_out + 3) & ~3);
@@ -522,6 +526,8 @@ __global__ void __launch_bounds__(256) bwd_dst_fast_kernel(BwdArgs a) {
   f4 d_t = zero, d_s = zero, d_v = zero;
   const int64_t o = (int64_t)rr * a.ldb + 4 * q;
   const bool wr = row_ok && live;
+  if (a.overwrite_db && wr && a.t_rowptr[rr + 1] - a.t_rowptr[rr] > EGC_LONG_ROW_THRESHOLD)   // its chunks add by atomics
+    *reinterpret_cast<f4*>(a.d_bases + (int64_t)rr * a.ld_db + 4 * q) = zero;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     if (t >= A) break;
@@ -793,8 +799,10 @@ __global__ void __launch_bounds__(256) bwd_src_kernel(BwdArgs a) {
     float* dst = a.d_bases + (int64_t)row * a.ld_db + 4 * s;
     if (atomic) {
       atomicAdd(dst, d.x); atomicAdd(dst + 1, d.y); atomicAdd(dst + 2, d.z); atomicAdd(dst + 3, d.w);
+    } else if (a.overwrite_db) {
+      *reinterpret_cast<f4*>(dst) = d;   // short rows are owned by this lane group: no fill, no read-modify-write
     } else {
-      *reinterpret_cast<f4*>(dst) += d;  // short rows are owned by this lane group; atomics of other kernels are done
+      *reinterpret_cast<f4*>(dst) += d;  // host-zeroed array (rectangular graphs)
     }
   }
 }
@@ -860,6 +868,7 @@ int egc_aggregate_combine_backward_f32(const egc_graph* graph, const egc_graph* 
     return EGC_ERR_INVALID;
   a.n_nodes = (int)n;
   a.n_src_rows = (int)n_src;
+  a.overwrite_db = n_src == n;
   a.n_edges = (int)graph->n_edges;
   a.ldb = ldb;
   a.slots = ldb / 4;

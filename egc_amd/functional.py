@@ -413,10 +413,11 @@ def egc_aggregate_combine_backward(graph: CSRGraph, spec: LayerSpec, bases, weig
         d_cat = None
         if joint and graph.n_src_rows == n and (spec.ldb + spec.w_cols) % 4 == 0:
             d_cat = torch.empty((n, spec.ldb + spec.w_cols), dtype=torch.float32, device=dev)
-            d_bases, d_w = d_cat[:, :spec.ldb], d_cat[:, spec.ldb:]
-            d_bases.zero_()                                                                       # atomics land here
+            d_bases, d_w = d_cat[:, :spec.ldb], d_cat[:, spec.ldb:]     # square graph: every d_bases row is written
         else:
-            d_bases = torch.zeros((graph.n_src_rows, spec.ldb), dtype=torch.float32, device=dev)  # atomics land here
+            # rectangular graphs: hub rows' partial sums arrive by atomics into a zeroed array
+            alloc = torch.empty if graph.n_src_rows == n else torch.zeros
+            d_bases = alloc((graph.n_src_rows, spec.ldb), dtype=torch.float32, device=dev)
             d_w = torch.empty((n, spec.w_cols), dtype=torch.float32, device=dev)
         nbytes = lib.egc_backward_workspace_bytes(C.byref(spec.c), n)
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)

@@ -375,8 +375,9 @@ int egc_layer_forward_fused_f32(const egc_graph* graph, const egc_layer* layer, 
  * aggregators the transposed graph must be built from the edge list in DESTINATION-CSR ORDER (edge k = CSR
  * entry k: source graph.col[k], destination = k's row), so that t_graph.edge_id maps a transposed entry to the
  * CSR position that arg_max / arg_min name.
- * Outputs: d_bases [n_src_rows, ldb] -- MUST be zero-filled by the caller (the partial sums of hub rows
- * arrive by float atomics) -- and d_weightings [n_nodes, H*B*A] (gradient w.r.t. the
+ * Outputs: d_bases [n_src_rows, ldb] -- on a square graph (n_src_rows == n_nodes) every row is written and the
+ * array may hold anything on entry; on a rectangular one it MUST be zero-filled by the caller (the partial sums
+ * of hub rows arrive by float atomics) -- and d_weightings [n_nodes, H*B*A] (gradient w.r.t. the
  * pre-activation weightings).  ld_d_bases / ld_d_weightings are their row strides in floats (0 = dense: ldb
  * and H*B*A; ld_d_bases a multiple of 4, d_bases 16-byte aligned): a caller whose next step is a GEMM with
  * the concatenated weight matrix [bases_weight | comb_weight^T] passes two column blocks of ONE

@@ -240,3 +240,49 @@ def test_input_gradient_through_the_packed_gemm(fin, aggrs):
     assert _rel(x.grad, x64.grad) <= gtol(aggrs)
     for k, v in conv.named_parameters():
         assert _rel(v.grad, p64[k].grad) <= gtol(aggrs), k
+
+
+@pytest.mark.parametrize("generic", [False, True])
+def test_d_bases_needs_no_fill_on_square_graphs(generic, monkeypatch):
+    """egc_aggregate_combine_backward_f32 on a square graph WRITES every row of d_bases (short source rows are stored,
+    hub rows zeroed by the destination kernel before their chunks add): the array is handed over full of NaN here
+    (C ABI directly, joint [d_bases | d_weightings] layout) and must come back equal to the zero-filled run."""
+    import ctypes as C
+    import egc_amd
+    from egc_amd import _C, functional as F
+    from egc_amd.workloads import heavy_tailed_graph
+    if generic:
+        monkeypatch.setenv("EGC_BWD_GENERIC", "1")
+    dev = torch.device("cuda:0")
+    lib = _C.load()
+    n = 12000
+    ei = heavy_tailed_graph(n, 150000, seed=3).to(dev)          # hub rows on both sides of the transposition
+    g = egc_amd.CSRGraph.from_edge_index(ei, n)
+    conv = egc_amd.EGConv(128, 128, aggrs=["sum", "mean", "max", "symnorm"]).to(dev)
+    spec = conv._spec_coo
+    with torch.no_grad():
+        wcat, bcat = conv._packed_weights()
+        x = torch.randn(n, 128, device=dev)
+        go = torch.randn(n, 128, device=dev)
+        bases, wt = F.egc_basis_transform(g, spec, x, wcat, bcat, None)
+        _, (stats, cnt, arg_max, arg_min) = F.egc_aggregate_combine_train(g, spec, bases, wt, conv.bias)
+        tg = g.transposed()
+        cg, ct = g.c_struct(), tg.c_struct()
+        nbytes = lib.egc_backward_workspace_bytes(C.byref(spec.c), n)
+        outs = []
+        for fill in (0.0, float("nan")):
+            d_cat = torch.full((n, spec.ldb + spec.w_cols), fill, device=dev)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            _C.check(lib.egc_aggregate_combine_backward_f32(
+                C.byref(cg), C.byref(ct), C.byref(spec.c), bases.data_ptr(), spec.ldb, wt.data_ptr(), go.data_ptr(),
+                stats.data_ptr(), cnt.data_ptr(), arg_max.data_ptr(), None, d_cat.data_ptr(), d_cat.stride(0),
+                d_cat[:, spec.ldb:].data_ptr(), d_cat.stride(0), ws.data_ptr(), ws.numel(),
+                torch.cuda.current_stream().cuda_stream), "egc_aggregate_combine_backward_f32")
+            torch.cuda.synchronize()
+            outs.append(d_cat)
+    assert bool(torch.isfinite(outs[1]).all())
+    # hub rows: float atomics in arrival order -> equal up to summation order, everything else bit for bit
+    deg_t = torch.bincount(ei[0], minlength=n)
+    short = deg_t <= 64
+    assert torch.equal(outs[0][short], outs[1][short])
+    assert _rel(outs[1], outs[0]) <= 1e-6
