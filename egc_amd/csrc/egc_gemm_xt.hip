@@ -306,4 +306,16 @@ int egc_weight_grad_f32(const float* x, int64_t ldx, const float* d, int64_t ldd
   return EGC_OK;
 }
 
+/* out[c] = sum over p of partials[p][c] (p < n_partials, c < cols): the second step of egc_column_sums_f32 (and of any
+ * other [P][cols] float32 partial layout), in a fixed order. */
+int egc_sum_partials_f32(const float* partials, int32_t n_partials, int32_t cols, float* out, void* stream_) {
+  using namespace egc;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_partials <= 0 || cols <= 0 || partials == nullptr || out == nullptr) return EGC_ERR_INVALID;
+  if ((cols & 3) != 0 || ((uintptr_t)partials & 15) != 0 || ((uintptr_t)out & 15) != 0) return EGC_ERR_UNSUPPORTED;
+  xt_reduce_kernel<<<(unsigned)ceil_div(cols / 4, 16), 256, 0, stream>>>(partials, cols, cols, n_partials, out, nullptr);
+  EGC_LAUNCH_CHECK("xt_reduce_kernel");
+  return EGC_OK;
+}
+
 }  // extern "C"

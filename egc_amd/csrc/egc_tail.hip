@@ -97,6 +97,42 @@ __global__ void __launch_bounds__(256) tail_backward_kernel(const float* __restr
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// The GEMM operand of an EGConv layer from its parameters, and the parameter gradients from the operand's gradient.
+//   wcat [F_in][B Ls + W] = [bases_weight with every basis padded from L to Ls columns | comb_weight^T, rows [h][a][b] ->
+//   columns [h][b][a]],  bcat [W] = comb_bias permuted the same way   (W = H B A).
+// GRAD: the same index map read the other way (wcat / bcat are the gradients, the parameters' gradients are written).
+struct PackDims { int F_in, H, A, B, L, Ls; };
+template <bool GRAD>
+__global__ void __launch_bounds__(256) egconv_pack_kernel(float* __restrict__ bases_w, float* __restrict__ comb_w,
+                                                          float* __restrict__ comb_b, float* __restrict__ wcat,
+                                                          float* __restrict__ bcat, PackDims d) {
+  const int F_g = d.B * d.Ls, W = d.H * d.B * d.A, cols = F_g + W;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx < (int64_t)d.F_in * cols) {
+    const int k = (int)(idx / cols), c = (int)(idx - (int64_t)k * cols);
+    if (c < F_g) {
+      const int b = c / d.Ls, l = c - b * d.Ls;
+      if (l < d.L) {
+        float* p = bases_w + (int64_t)k * d.B * d.L + b * d.L + l;
+        if (GRAD) *p = wcat[idx]; else wcat[idx] = *p;
+      } else if (!GRAD) {
+        wcat[idx] = 0.f;   // padding column of a padded basis
+      }
+    } else {
+      const int j = c - F_g;                       // [h][b][a]
+      const int h = j / (d.B * d.A), r = j - h * d.B * d.A, b = r / d.A, a = r - b * d.A;
+      float* p = comb_w + (int64_t)((h * d.A + a) * d.B + b) * d.F_in + k;
+      if (GRAD) *p = wcat[idx]; else wcat[idx] = *p;
+    }
+  }
+  if (idx < W && bcat != nullptr && comb_b != nullptr) {
+    const int j = (int)idx;
+    const int h = j / (d.B * d.A), r = j - h * d.B * d.A, b = r / d.A, a = r - b * d.A;
+    float* p = comb_b + (h * d.A + a) * d.B + b;
+    if (GRAD) *p = bcat[j]; else bcat[j] = *p;
+  }
+}
+
 }  // namespace
 }  // namespace egc
 
@@ -153,6 +189,25 @@ int egc_affine_act_backward_f32(const float* dout, const float* h, const float* 
   tail_backward_kernel<<<(unsigned)ceil_div(quads, 256), 256, 0, stream>>>(dout, h, scale, shift, relu, coef_g, coef_h, coef_1, quads,
                                                                          cols / 4, dh);
   EGC_LAUNCH_CHECK("tail_backward_kernel");
+  return EGC_OK;
+}
+
+int egc_egconv_pack_f32(const float* bases_weight, const float* comb_weight, const float* comb_bias, int32_t f_in,
+                        int32_t num_heads, int32_t num_aggrs, int32_t num_bases, int32_t basis_len, int32_t basis_stride,
+                        float* wcat, float* bcat, int32_t grad, egc_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (f_in <= 0 || num_heads <= 0 || num_aggrs <= 0 || num_bases <= 0 || basis_len <= 0 || basis_stride < basis_len ||
+      bases_weight == nullptr || comb_weight == nullptr || wcat == nullptr)
+    return EGC_ERR_INVALID;
+  const PackDims d{f_in, num_heads, num_aggrs, num_bases, basis_len, basis_stride};
+  const int64_t total = (int64_t)f_in * (num_bases * basis_stride + num_heads * num_bases * num_aggrs);
+  const unsigned grid = (unsigned)ceil_div(total, 256);
+  float* bw = const_cast<float*>(bases_weight);
+  float* cw = const_cast<float*>(comb_weight);
+  float* cb = const_cast<float*>(comb_bias);
+  if (grad) egconv_pack_kernel<true><<<grid, 256, 0, stream>>>(bw, cw, cb, wcat, bcat, d);
+  else egconv_pack_kernel<false><<<grid, 256, 0, stream>>>(bw, cw, cb, wcat, bcat, d);
+  EGC_LAUNCH_CHECK("egconv_pack_kernel");
   return EGC_OK;
 }
 

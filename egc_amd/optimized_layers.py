@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from . import _C
-from .functional import (egc_layer_apply, gemm_exact, make_spec, pack_weights, pad_bases_columns,
+from .functional import (egc_layer_apply, gemm_exact, make_spec, pack_egconv_weights, pack_weights, pad_bases_columns,
                          padded_basis_stride)
 from .graph import CSRGraph, SparseTensor, graph_from_input
 from .layers import glorot_
@@ -87,6 +87,12 @@ class EGConv(nn.Module):
 
     def _pack(self):
         H, A, B, F = self.num_heads, len(self.aggregators), self.num_bases, self.in_channels
+        sp = self._spec_coo
+        if (torch.is_grad_enabled() and self.bases_weight.is_cuda and self.bases_weight.dtype == torch.float32
+                and self.comb_weight.bias is not None):
+            # training: one launch each way instead of the differentiable torch chain below
+            return pack_egconv_weights(self.bases_weight, self.comb_weight.weight, self.comb_weight.bias, F, H, A, B,
+                                       sp.basis_len, sp.basis_stride)
         w = self.comb_weight.weight.view(H, A, B, F).permute(0, 2, 1, 3).reshape(H * B * A, F)
         b = self.comb_weight.bias.view(H, A, B).permute(0, 2, 1).reshape(H * B * A)
         sp = self._spec_coo

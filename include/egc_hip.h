@@ -298,6 +298,17 @@ int egc_affine_act_backward_f32(const float* dout, const float* h, const float* 
                                 const float* coef_g, const float* coef_h, const float* coef_1, int64_t n_rows, int32_t cols,
                                 float* dh, egc_stream_t stream);
 
+/* The GEMM operand of an EGConv layer from its parameters (grad == 0), or the parameters' gradients from the operand's
+ * gradient (grad != 0: the three parameter arrays are WRITTEN, wcat / bcat read) -- one launch instead of the permute /
+ * pad / transpose / cat chain (and its autograd mirror) around optimized_layers.py:177-182's two weight matrices:
+ *   wcat [f_in][B * basis_stride + H*B*A] = [bases_weight [f_in][B * basis_len], each basis padded to basis_stride columns
+ *                                           | comb_weight^T with the Linear's rows [h][a][b] as columns [h][b][a]],
+ *   bcat [H*B*A] = comb_bias permuted the same way (bcat / comb_bias may be NULL together).
+ * All arrays dense float32. */
+int egc_egconv_pack_f32(const float* bases_weight, const float* comb_weight, const float* comb_bias, int32_t f_in,
+                        int32_t num_heads, int32_t num_aggrs, int32_t num_bases, int32_t basis_len, int32_t basis_stride,
+                        float* wcat, float* bcat, int32_t grad, egc_stream_t stream);
+
 /* Column sums of a row-major array with row stride ld (floats), as n_partials partial rows:
  * partials[p, c] = sum of x[r, c] over the p-th block of rows, c < cols; the caller adds the few partial rows up.
  * The bias gradients of a training step (grad_out summed over the nodes for `bias`, d_weightings for the
@@ -306,6 +317,9 @@ int egc_affine_act_backward_f32(const float* dout, const float* h, const float* 
  * (EGC_ERR_UNSUPPORTED otherwise); deterministic (no atomics). */
 int egc_column_sums_f32(const float* x, int64_t n_rows, int32_t ld, int32_t cols, float* partials, int32_t n_partials,
                         egc_stream_t stream);
+/* out[c] = sum over p of partials[p][c]: adds the partial rows of egc_column_sums_f32 up in a fixed order (cols a
+ * multiple of 4, both pointers 16-byte aligned). */
+int egc_sum_partials_f32(const float* partials, int32_t n_partials, int32_t cols, float* out, egc_stream_t stream);
 
 /* Mean of the rows of x [n_rows, width] over consecutive segments: out[g] = mean(x[seg_ptr[g] : seg_ptr[g+1]])
  * (0 for an empty segment; x may be NULL when every segment is empty).  global_mean_pool over a PyG batch
