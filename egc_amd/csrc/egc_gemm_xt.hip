@@ -27,6 +27,11 @@ namespace {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt: the global loads that are meant
+// to stay in flight across two tiles would be waited for at every barrier (measured: tile period = compute + HBM
+// latency instead of their maximum).
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 constexpr int XT_WM = 2;  // wavefronts along the output rows (F) of a block tile
 
 constexpr int xt_pitch(int cols) { return cols + ((cols % 64) == 0 ? 16 : 48); }  // pitch % 64 == 16: the 4 k-rows of a fragment hit 64 distinct banks
@@ -143,16 +148,16 @@ __global__ void __launch_bounds__(64 * XT_WM * WN) xt_gemm_kernel(const float* _
   put(0, st0);
   fetch(1, st0);
   fetch(2, st1);
-  __syncthreads();
+  lds_barrier();
   for (int tile = 0; tile < n_tiles; tile += 2) {  // n_tiles is uniform over the workgroup
     multiply(0);
     put(1, st0);
     fetch(tile + 3, st0);
-    __syncthreads();
+    lds_barrier();
     if (tile + 1 < n_tiles) multiply(1);
     put(0, st1);
     fetch(tile + 4, st1);
-    __syncthreads();
+    lds_barrier();
   }
 
   // partial tile: accumulator register r of tile (i, j) is output row 16 i + 4 (lane / 16) + r, column 16 j + lane % 16
@@ -178,6 +183,238 @@ __global__ void __launch_bounds__(64 * XT_WM * WN) xt_gemm_kernel(const float* _
       const int col = n0 + wn * (16 * NT) + 16 * j + m;
       if (kk == 0 && col < K) out[(int64_t)F * K + col] = v;
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same reduction on the 16-bit matrix cores, for outputs of up to 128 x 192 (one accumulator tile per workgroup:
+// the north-star layer).  fp32 MFMA caps this GEMM at 53 us (157 TFLOP/s) while its operands are 27 us of HBM; the
+// bf16 pipe is 16 x faster, so the operands are split into three bf16 planes IN REGISTERS on the way from LDS to the
+// MFMA (v = h + m + l, each plane the top 16 bits of what the previous ones left: 24 significant bits, no scaling --
+// bf16 has fp32's exponent range, so gradients of any magnitude survive) and six products are accumulated in fp32
+// (hh, hm, mh, mm, hl, lh: what is dropped is below 2^-24 of a product) -- the scheme of egc_gemm_bf16x3.hip.
+//   * v_mfma_f32_32x32x16_bf16 wants 8 consecutive elements of the REDUCTION index per lane; the reduction runs over
+//     rows, so the tile is transposed on its way through LDS: the thread that splits a value reads 8 consecutive rows
+//     of one column of the row-major fp32 stage (8 ds_read_b32, pitch 324 floats) and writes 16 bytes per plane;
+//   * 8 wavefronts = 4 (rows of the output: 32 columns of x each) x 2 (3 x 32 columns of d each), 18 MFMAs per
+//     wavefront and 16 rows.
+// Measured on MI355X at config 2: 68 us + 6 us for the reduction against 87 + 6 for the fp32-MFMA kernel below (and
+// 85 + 8 + 15 + 8 for the library path).  The matrix work is 20 us and the HBM stream alone 37 us (the kernel with the
+// multiply removed), yet three organisations of the split -- in the consuming wavefronts from the fp32 stage; once per
+// tile behind its own barrier; once per tile inside the MFMA interval (this one) -- all land within 3 us of each
+// other: per 16 rows a CU moves ~180 KB through LDS (stage write, transposing read, plane write, and 96 KB of fragment
+// reads because every B fragment is read by four wavefronts), which is what the three have in common.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+
+struct Planes3 { bf16x8 h, m, l; };
+
+// eight fp32 values -> three bf16x8 planes (element j of a plane <- v[j]; truncation splits: every step exact)
+__device__ inline Planes3 split3(const float (&v)[8]) {
+  u32x4v ph, pm, pl;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned a0 = __float_as_uint(v[2 * i]), a1 = __float_as_uint(v[2 * i + 1]);
+    const float r0 = v[2 * i] - __uint_as_float(a0 & 0xffff0000u), r1 = v[2 * i + 1] - __uint_as_float(a1 & 0xffff0000u);
+    const unsigned b0 = __float_as_uint(r0), b1 = __float_as_uint(r1);
+    const float s0 = r0 - __uint_as_float(b0 & 0xffff0000u), s1 = r1 - __uint_as_float(b1 & 0xffff0000u);
+    ph[i] = __builtin_amdgcn_perm(a1, a0, 0x07060302u);                       // high halves: [v1.hi16 | v0.hi16]
+    pm[i] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+    pl[i] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+  }
+  Planes3 o;
+  o.h = __builtin_bit_cast(bf16x8, ph);
+  o.m = __builtin_bit_cast(bf16x8, pm);
+  o.l = __builtin_bit_cast(bf16x8, pl);
+  return o;
+}
+
+constexpr int X3_ROWS = 16, X3_TM = 128, X3_TN = 192, X3_COLS = X3_TM + X3_TN, X3_P = X3_COLS + 4, X3_THREADS = 512;
+constexpr int X3_RP = X3_ROWS + 8;   // row pitch of the transposed planes, in halves (48 bytes: 16-byte aligned pieces)
+constexpr int X3_STAGE_FLOATS = X3_ROWS * X3_P, X3_PLANE_HALVES = X3_COLS * X3_RP;
+constexpr int X3_LDS_BYTES = 2 * X3_STAGE_FLOATS * 4 + 2 * 3 * X3_PLANE_HALVES * 2;
+constexpr int X3_AHEAD = 4;   // register stages: global loads run this many 16-row sub-tiles ahead of their LDS write
+
+// Pipeline over 16-row sub-tiles s, ONE barrier per sub-tile; between two barriers every wavefront
+//     multiplies sub-tile s        (bf16 planes [s % 2]: 18 MFMAs of 32x32x16, three output tiles, product-major order)
+//     splits     sub-tile s + 1    (fp32 stage [(s+1) % 2] -> planes [(s+1) % 2]: its share of 640 column x 8-row tasks)
+//     stages     sub-tile s + 2    (registers -> fp32 stage [s % 2], row-major as loaded)
+//     requests   sub-tile s + 6    (buffer loads into the register set that was just written out)
+// so the vector work of one wavefront (split) runs beside the matrix work of the other wavefront of its SIMD, and
+// 64 rows (80 KB per CU) are always in flight.  Every value is split ONCE per tile, by the thread that transposes it
+// (8 consecutive rows of one column -> one 16-byte write per plane); an MFMA fragment is one 16-byte read per plane.
+// Splitting in the consuming wavefronts instead costs 4 x the vector work (every B fragment is used by four wavefronts)
+// and a split phase behind its own barrier does not overlap the MFMAs (both forms were built and measured: header).
+__global__ void __launch_bounds__(X3_THREADS) xt_gemm_bf16x3_kernel(const float* __restrict__ x, int64_t ldx, int F,
+                                                                    const float* __restrict__ d, int64_t ldd, int K,
+                                                                    int64_t n_rows, int64_t rows_per_chunk, int n_chunks,
+                                                                    float* __restrict__ partial, int want_sums) {
+  extern __shared__ float lds[];
+  float* stage = lds;                                                                  // [2][X3_ROWS][X3_P] fp32
+  unsigned short* planes = reinterpret_cast<unsigned short*>(lds + 2 * X3_STAGE_FLOATS);  // [2][3][X3_COLS][X3_RP] bf16
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave & 3, wn = wave >> 2;
+  const int c32 = lane & 31, g = lane >> 5;
+  const int chunk = blockIdx.x;
+  if (chunk >= n_chunks) return;
+  const int64_t row_begin = (int64_t)chunk * rows_per_chunk;
+  const int64_t row_end = row_begin + rows_per_chunk < n_rows ? row_begin + rows_per_chunk : n_rows;
+  const int n_sub = row_end > row_begin ? (int)((row_end - row_begin + X3_ROWS - 1) / X3_ROWS) : 0;
+
+  // staging: branch-free buffer loads over the workgroup's row range (rows past it and masked columns read as zeros)
+  const int64_t range_rows = row_end > row_begin ? row_end - row_begin : 0;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(x + row_begin * ldx), 0, (unsigned)(range_rows * ldx * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(d + row_begin * ldd), 0, (unsigned)(range_rows * ldd * 4), 0x00020000);
+  constexpr unsigned XT_OOB = 0xFFFFFFF0u;
+  constexpr int AX4 = X3_TM / 4, BD4 = X3_TN / 4;            // 32, 48 sixteen-byte pieces per row
+  static_assert(X3_ROWS * AX4 == X3_THREADS, "one x piece per thread and sub-tile");
+  constexpr int LD = (X3_ROWS * BD4 + X3_THREADS - 1) / X3_THREADS;   // 2 (the second for half of the threads)
+  unsigned off_x, off_d[LD];
+  int lds_x, lds_d[LD];
+  {
+    const int r = t / AX4, c4 = t - r * AX4;
+    off_x = (4 * c4 < F) ? (unsigned)((r * ldx + 4 * c4) * 4) : XT_OOB;
+    lds_x = r * X3_P + 4 * c4;
+  }
+#pragma unroll
+  for (int i = 0; i < LD; ++i) {
+    const int idx = t + i * X3_THREADS, r = idx / BD4, c4 = idx - r * BD4;
+    const bool in_tile = idx < X3_ROWS * BD4;
+    off_d[i] = (in_tile && 4 * c4 < K) ? (unsigned)((r * ldd + 4 * c4) * 4) : XT_OOB;
+    lds_d[i] = in_tile ? r * X3_P + X3_TM + 4 * c4 : -1;
+  }
+  const unsigned step_x = (unsigned)(X3_ROWS * ldx * 4), step_d = (unsigned)(X3_ROWS * ldd * 4);
+  struct Regs { f4 x; f4 d[LD]; };
+  Regs rg[X3_AHEAD];
+  auto fetch = [&](int sub, Regs& st) {
+    const unsigned ox = off_x == XT_OOB ? XT_OOB : off_x + (unsigned)sub * step_x;
+    st.x = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, ox, 0, 0));
+#pragma unroll
+    for (int i = 0; i < LD; ++i) {
+      const unsigned o = off_d[i] == XT_OOB ? XT_OOB : off_d[i] + (unsigned)sub * step_d;
+      st.d[i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rd, o, 0, 0));
+    }
+  };
+  auto put = [&](int sb, const Regs& st) {
+    float* base = stage + sb * X3_STAGE_FLOATS;
+    *reinterpret_cast<f4*>(base + lds_x) = st.x;
+#pragma unroll
+    for (int i = 0; i < LD; ++i)
+      if (lds_d[i] >= 0) *reinterpret_cast<f4*>(base + lds_d[i]) = st.d[i];
+  };
+  // column sums of d (from the fp32 stage): wavefront w owns d columns 24 w .. 24 w + 23, two lanes (8 rows each) per column
+  const bool sums = want_sums != 0;
+  const int cs_col = wave * 24 + (lane % 24), cs_part = lane / 24;   // lanes 48..63 idle
+  float colsum = 0.f;
+  auto split = [&](int sb) {   // fp32 stage sb -> planes sb (both indexed by the sub-tile's parity)
+    const float* src = stage + sb * X3_STAGE_FLOATS;
+    unsigned short* pl = planes + sb * 3 * X3_PLANE_HALVES;
+    if (sums && cs_part < 2) {
+#pragma unroll
+      for (int j = 0; j < X3_ROWS / 2; ++j) colsum += src[(cs_part * (X3_ROWS / 2) + j) * X3_P + X3_TM + cs_col];
+    }
+    // task = (column c, row group of 8): lanes take consecutive columns (conflict-free fp32 reads at pitch X3_P)
+#pragma unroll
+    for (int it = 0; it < (X3_COLS * (X3_ROWS / 8) + X3_THREADS - 1) / X3_THREADS; ++it) {
+      const int task = t + it * X3_THREADS;
+      if (task < X3_COLS * (X3_ROWS / 8)) {
+        const int rgp = task / X3_COLS, c = task - rgp * X3_COLS;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = src[(8 * rgp + j) * X3_P + c];
+        const Planes3 p = split3(v);
+        unsigned short* dst = pl + c * X3_RP + 8 * rgp;
+        *reinterpret_cast<bf16x8*>(dst) = p.h;
+        *reinterpret_cast<bf16x8*>(dst + X3_PLANE_HALVES) = p.m;
+        *reinterpret_cast<bf16x8*>(dst + 2 * X3_PLANE_HALVES) = p.l;
+      }
+    }
+  };
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  const int a_row = wm * 32 + c32, b_row = X3_TM + wn * 96 + c32;   // "rows" of the transposed planes = tile columns
+  auto multiply = [&](int sb) {
+    const unsigned short* base = planes + sb * 3 * X3_PLANE_HALVES + 8 * g;
+    Planes3 a, b[3];
+    a.h = *reinterpret_cast<const bf16x8*>(base + a_row * X3_RP);
+    a.m = *reinterpret_cast<const bf16x8*>(base + a_row * X3_RP + X3_PLANE_HALVES);
+    a.l = *reinterpret_cast<const bf16x8*>(base + a_row * X3_RP + 2 * X3_PLANE_HALVES);
+#pragma unroll
+    for (int tt = 0; tt < 3; ++tt) {
+      const unsigned short* bp = base + (b_row + 32 * tt) * X3_RP;
+      b[tt].h = *reinterpret_cast<const bf16x8*>(bp);
+      b[tt].m = *reinterpret_cast<const bf16x8*>(bp + X3_PLANE_HALVES);
+      b[tt].l = *reinterpret_cast<const bf16x8*>(bp + 2 * X3_PLANE_HALVES);
+    }
+    // product-major order: consecutive MFMAs go to different accumulators (a chain on one accumulator would issue at
+    // the result latency instead of the pipe rate); small terms first
+#pragma unroll
+    for (int tt = 0; tt < 3; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b[tt].h, acc[tt], 0, 0, 0);
+#pragma unroll
+    for (int tt = 0; tt < 3; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b[tt].l, acc[tt], 0, 0, 0);
+#pragma unroll
+    for (int tt = 0; tt < 3; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b[tt].m, acc[tt], 0, 0, 0);
+#pragma unroll
+    for (int tt = 0; tt < 3; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b[tt].h, acc[tt], 0, 0, 0);
+#pragma unroll
+    for (int tt = 0; tt < 3; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b[tt].m, acc[tt], 0, 0, 0);
+#pragma unroll
+    for (int tt = 0; tt < 3; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b[tt].h, acc[tt], 0, 0, 0);
+  };
+
+  // prologue: sub-tiles 0 and 1 staged, 0 split; register sets hold sub-tiles 2 .. 5 (set = sub-tile % 4)
+  fetch(0, rg[0]);
+  fetch(1, rg[1]);
+  put(0, rg[0]);
+  put(1, rg[1]);
+  fetch(2, rg[2]);
+  fetch(3, rg[3]);
+  fetch(4, rg[0]);
+  fetch(5, rg[1]);
+  lds_barrier();
+  split(0);
+  lds_barrier();
+  // interval s: multiply s | split s + 1 | stage s + 2 | request s + 6        (unrolled by four: register sets are static)
+#define X3_INTERVAL(S, SET)                      \
+  {                                              \
+    if ((S) < n_sub) multiply((S) & 1);          \
+    split(((S) + 1) & 1);                        \
+    put((S) & 1, rg[SET]);                       \
+    fetch((S) + 6, rg[SET]);                     \
+    lds_barrier();                               \
+  }
+  for (int s = 0; s < n_sub; s += 4) {   // n_sub is uniform over the workgroup
+    X3_INTERVAL(s, 2)
+    X3_INTERVAL(s + 1, 3)
+    X3_INTERVAL(s + 2, 0)
+    X3_INTERVAL(s + 3, 1)
+  }
+#undef X3_INTERVAL
+
+  // C/D layout of the 32x32 MFMA: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  const int64_t record = (int64_t)F * K + K;
+  float* out = partial + (int64_t)chunk * record;
+#pragma unroll
+  for (int tt = 0; tt < 3; ++tt) {
+    const int col = wn * 96 + 32 * tt + c32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+      if (row < F && col < K) out[(int64_t)row * K + col] = acc[tt][r];
+    }
+  }
+  if (sums) {   // the two row halves of a column meet through LDS (nothing reads the stage any more)
+    float* red = stage;
+    if (cs_part < 2) red[cs_part * X3_TN + cs_col] = colsum;
+    lds_barrier();
+    if (t < X3_TN && t < K) out[(int64_t)F * K + t] = red[t] + red[X3_TN + t];
   }
 }
 
@@ -223,12 +460,14 @@ XtPlan xt_plan(int64_t n_rows, int F, int K) {
   static const int mts[] = {1, 2, 4}, nts[] = {1, 2, 3};
   XtPlan p{};
   double best = 1e300;
+  const bool one_tile = F <= 128 && K <= 192 && getenv("EGC_XT_FP32") == nullptr;   // xt_gemm_bf16x3_kernel
   for (int mt : mts)
     for (int nt : nts) {
       const int64_t mtl = ceil_div(F, 32 * mt), ntl = ceil_div(K, 64 * nt);
       const double mfma = 2.0 * (double)(mtl * 32 * mt) * (double)(ntl * 64 * nt) / 157.0;
       const double mem = 4.0 * (double)(mtl * ntl * (32 * mt + 64 * nt)) / 6.0;
       const double cost = (mfma > mem ? mfma : mem) + 0.25 * (mfma > mem ? mem : mfma);
+      if (one_tile && (mt != 4 || nt != 3)) continue;
       if (cost < best) {
         best = cost;
         p.mt = mt;
@@ -292,12 +531,27 @@ int egc_weight_grad_f32(const float* x, int64_t ldx, const float* d, int64_t ldd
   float* partial = static_cast<float*>(workspace);
   const int want_sums = col_sums != nullptr;
   int rc = EGC_ERR_UNSUPPORTED;
+  static const bool fp32_only = getenv("EGC_XT_FP32") != nullptr;
+  if (!fp32_only && f_in <= X3_TM && k_cols <= X3_TN) {   // one accumulator tile: the bf16x3 kernel
+    constexpr int lds_bytes = X3_LDS_BYTES;
+    static bool configured = false;
+    if (!configured) {
+      EGC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&xt_gemm_bf16x3_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+      configured = true;
+    }
+    xt_gemm_bf16x3_kernel<<<(unsigned)p.chunks, X3_THREADS, lds_bytes, stream>>>(x, ldx, f_in, d, ldd, k_cols, n_rows,
+                                                                               p.rows_per_chunk, p.chunks, partial, want_sums);
+    EGC_LAUNCH_CHECK("xt_gemm_bf16x3_kernel");
+    rc = EGC_OK;
+  } else {
 #define EGC_XT_CASE(MT, NT) \
   if (p.mt == MT && p.nt == NT) rc = launch_xt<MT, NT, XT_WN, XT_STAGE>(p, x, ldx, f_in, d, ldd, k_cols, n_rows, partial, want_sums, stream);
   EGC_XT_CASE(1, 1) EGC_XT_CASE(1, 2) EGC_XT_CASE(1, 3)
   EGC_XT_CASE(2, 1) EGC_XT_CASE(2, 2) EGC_XT_CASE(2, 3)
   EGC_XT_CASE(4, 1) EGC_XT_CASE(4, 2) EGC_XT_CASE(4, 3)
 #undef EGC_XT_CASE
+  }
   if (rc != EGC_OK) return rc;
   const int64_t record = fk + k_cols;
   xt_reduce_kernel<<<(unsigned)ceil_div((want_sums ? record : fk) / 4, 16), 256, 0, stream>>>(partial, record, fk, p.chunks,
