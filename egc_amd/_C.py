@@ -70,6 +70,8 @@ SYMBOLS = {
                                           C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "egc_basis_pack_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "egc_basis_pack": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "egc_basis_pack_transposed": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t,
+                                            C.c_void_p]),
     "egc_basis_transform_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                              C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "egc_layer_forward_packed": (C.c_int, [C.POINTER(EgcGraph), C.POINTER(EgcLayer), C.c_void_p, C.c_void_p,
@@ -95,6 +97,10 @@ SYMBOLS = {
                                                     C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(EgcPost), C.c_void_p,
                                                     C.c_void_p, C.c_size_t, C.c_void_p]),
     "egc_weight_grad_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
+    "egc_weight_grad_ex_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
+    "egc_weight_grad_ex_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                         C.c_int64, C.c_void_p]),
     "egc_weight_grad_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "egc_column_moments_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,

@@ -82,8 +82,8 @@ __device__ inline void split3(float f, u16& h, u16& m, u16& l) {
 }
 
 // packed[ks][plane][v][32] : plane p of w[k = 32*ks + kk][source column of v]
-__global__ void __launch_bounds__(256) pack_bf16x3_kernel(const float* __restrict__ wcat, int K, int F_g, int W, int ldb,
-                                                          int NV, int KS, u16* __restrict__ packed) {
+__global__ void __launch_bounds__(256) pack_bf16x3_kernel(const float* __restrict__ wcat, int64_t rs, int64_t cs, int K, int F_g,
+                                                          int W, int ldb, int NV, int KS, u16* __restrict__ packed) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (ks, v, kk)
   const int total = KS * NV * XKT;
   if (idx >= total) return;
@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(256) pack_bf16x3_kernel(const float* __restric
   const int ks = idx / (XKT * NV);
   const int k = ks * XKT + kk;
   const int src = (v < F_g) ? v : ((v < ldb || v >= ldb + W) ? -1 : v - ldb + F_g);
-  const float w = (src >= 0 && k < K) ? wcat[(int64_t)k * (F_g + W) + src] : 0.f;
+  const float w = (src >= 0 && k < K) ? wcat[k * rs + src * cs] : 0.f;
   u16 h, m, l;
   split3(w, h, m, l);
   const int64_t base = ((int64_t)ks * 3 * NV + v) * XKT + kk;
@@ -596,20 +596,30 @@ static bool use_f16x2(int f_in, int ldb, int NV) {
   return f16x2_shape(f_in, ldb, NV) && getenv("EGC_GEMM_BF16X3") == nullptr;
 }
 
-int egc_basis_pack(const float* wcat, int32_t f_in, int32_t f_g, int32_t w_cols, void* packed, size_t packed_bytes,
-                   egc_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+static int basis_pack_strided(const float* wcat, int64_t rs, int64_t cs, int32_t f_in, int32_t f_g, int32_t w_cols,
+                              void* packed, size_t packed_bytes, hipStream_t stream) {
   if (wcat == nullptr || packed == nullptr || f_in <= 0 || f_g <= 0 || w_cols < 0) return EGC_ERR_INVALID;
   if (packed_bytes < egc_basis_pack_bytes(f_in, f_g, w_cols)) return EGC_ERR_WORKSPACE;
   const int ldb = (f_g + 3) & ~3;
   const int NV = round_up32(ldb + w_cols);
   const int KS = (f_in + XKT - 1) / XKT;
-  if (use_f16x2(f_in, ldb, NV)) return f16x2_pack(wcat, f_in, f_g, w_cols, ldb, NV, KS, packed, stream);
-  if (f16x2k_shape(f_in, f_g, ldb, w_cols)) return f16x2k_pack(wcat, f_in, f_g, ldb, w_cols, packed, stream);
+  if (use_f16x2(f_in, ldb, NV)) return f16x2_pack(wcat, rs, cs, f_in, f_g, w_cols, ldb, NV, KS, packed, stream);
+  if (f16x2k_shape(f_in, f_g, ldb, w_cols)) return f16x2k_pack(wcat, rs, cs, f_in, f_g, ldb, w_cols, packed, stream);
   const int total = KS * NV * XKT;
-  pack_bf16x3_kernel<<<(total + 255) / 256, 256, 0, stream>>>(wcat, f_in, f_g, w_cols, ldb, NV, KS, (u16*)packed);
+  pack_bf16x3_kernel<<<(total + 255) / 256, 256, 0, stream>>>(wcat, rs, cs, f_in, f_g, w_cols, ldb, NV, KS, (u16*)packed);
   EGC_LAUNCH_CHECK("pack_bf16x3_kernel");
   return EGC_OK;
+}
+
+int egc_basis_pack(const float* wcat, int32_t f_in, int32_t f_g, int32_t w_cols, void* packed, size_t packed_bytes,
+                   egc_stream_t stream_) {
+  return basis_pack_strided(wcat, (int64_t)f_g + w_cols, 1, f_in, f_g, w_cols, packed, packed_bytes, (hipStream_t)stream_);
+}
+
+int egc_basis_pack_transposed(const float* wt, int64_t ld, int32_t f_in, int32_t f_g, int32_t w_cols, void* packed,
+                              size_t packed_bytes, egc_stream_t stream_) {
+  if (ld < f_in) return EGC_ERR_INVALID;
+  return basis_pack_strided(wt, 1, ld, f_in, f_g, w_cols, packed, packed_bytes, (hipStream_t)stream_);
 }
 
 int egc_basis_transform_packed(const float* x, const void* packed, const float* bcat, int64_t n_nodes, int32_t f_in,

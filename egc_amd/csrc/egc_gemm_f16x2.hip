@@ -62,20 +62,20 @@ __device__ inline void split2_pk(f32x2 v, unsigned& h, unsigned& l) {
 // packed[ks][plane][v][32] (fp16 bits) followed by float inv_scale[NV].  One wavefront per virtual column
 // (runs once per parameter update -- every step when training): lanes stride over k, the column maximum is a
 // wavefront all-reduce.
-__global__ void __launch_bounds__(64) pack_f16x2_kernel(const float* __restrict__ wcat, int K, int F_g, int W, int ldb,
-                                                        int NV, int KS, u16* __restrict__ packed) {
+__global__ void __launch_bounds__(64) pack_f16x2_kernel(const float* __restrict__ wcat, int64_t rs, int64_t cs, int K, int F_g,
+                                                        int W, int ldb, int NV, int KS, u16* __restrict__ packed) {
   const int v = blockIdx.x;
   const int lane = threadIdx.x;
   const int src = (v < F_g) ? v : ((v < ldb || v >= ldb + W) ? -1 : v - ldb + F_g);
   unsigned amax = 0;
   if (src >= 0)
-    for (int k = lane; k < K; k += 64) amax = max(amax, __float_as_uint(wcat[(int64_t)k * (F_g + W) + src]) & 0x7fffffffu);
+    for (int k = lane; k < K; k += 64) amax = max(amax, __float_as_uint(wcat[k * rs + src * cs]) & 0x7fffffffu);
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) amax = max(amax, (unsigned)__shfl_xor((int)amax, d));
   float scale, inv;
   scales_of(amax, scale, inv);
   for (int k = lane; k < KS * GEMM_KT; k += 64) {
-    const float w = (src >= 0 && k < K) ? wcat[(int64_t)k * (F_g + W) + src] * scale : 0.f;
+    const float w = (src >= 0 && k < K) ? wcat[k * rs + src * cs] * scale : 0.f;
     const _Float16 h = (_Float16)w;
     const _Float16 l = (_Float16)((w - (float)h) * 2048.f);
     const int64_t base = ((int64_t)(k / GEMM_KT) * 2 * NV + v) * GEMM_KT + (k % GEMM_KT);
@@ -400,8 +400,9 @@ __global__ void __launch_bounds__(F16X2_THREADS) basis_gemm_f16x2_kernel(const f
 
 size_t f16x2_pack_bytes(int KS, int NV) { return (size_t)KS * 2 * NV * GEMM_KT * sizeof(u16) + (size_t)NV * sizeof(float); }
 
-int f16x2_pack(const float* wcat, int f_in, int f_g, int w_cols, int ldb, int NV, int KS, void* packed, hipStream_t stream) {
-  pack_f16x2_kernel<<<NV, 64, 0, stream>>>(wcat, f_in, f_g, w_cols, ldb, NV, KS, (u16*)packed);
+int f16x2_pack(const float* wcat, int64_t rs, int64_t cs, int f_in, int f_g, int w_cols, int ldb, int NV, int KS, void* packed,
+               hipStream_t stream) {
+  pack_f16x2_kernel<<<NV, 64, 0, stream>>>(wcat, rs, cs, f_in, f_g, w_cols, ldb, NV, KS, (u16*)packed);
   EGC_LAUNCH_CHECK("pack_f16x2_kernel");
   return EGC_OK;
 }

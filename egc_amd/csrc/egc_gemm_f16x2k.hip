@@ -60,15 +60,14 @@ struct KCols {
 // packed: [NT][KS][2 planes][64 lanes][8] fp16 -- the A fragments of v_mfma_f32_16x16x32_f16 in register order
 // (lane (i, kq) holds k = 32 s + 8 kq .. + 7 of column 16 t + i) -- followed by float inv_scale[16 NT].
 // One wavefront per virtual column: lanes stride over k, the column maximum is a wavefront all-reduce.
-__global__ void __launch_bounds__(64) pack_f16x2k_kernel(const float* __restrict__ wcat, int K, KCols c, int KS,
-                                                         u16* __restrict__ packed) {
+__global__ void __launch_bounds__(64) pack_f16x2k_kernel(const float* __restrict__ wcat, int64_t rs, int64_t cs, int K,
+                                                         KCols c, int KS, u16* __restrict__ packed) {
   const int v = blockIdx.x;
   const int lane = threadIdx.x;
   const int src = c.source(v);
-  const int ldw = c.F_g + c.W;
   unsigned amax = 0;
   if (src >= 0)
-    for (int k = lane; k < K; k += 64) amax = max(amax, __float_as_uint(wcat[(int64_t)k * ldw + src]) & 0x7fffffffu);
+    for (int k = lane; k < K; k += 64) amax = max(amax, __float_as_uint(wcat[k * rs + src * cs]) & 0x7fffffffu);
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) amax = max(amax, (unsigned)__shfl_xor((int)amax, d));
   unsigned be = amax >> 23;
@@ -76,7 +75,7 @@ __global__ void __launch_bounds__(64) pack_f16x2k_kernel(const float* __restrict
   const float scale = __uint_as_float((254u - be) << 23), inv = __uint_as_float(be << 23);
   const int t = v >> 4, i = v & 15;
   for (int k = lane; k < KS * 32; k += 64) {
-    const float w = (src >= 0 && k < K) ? wcat[(int64_t)k * ldw + src] * scale : 0.f;
+    const float w = (src >= 0 && k < K) ? wcat[k * rs + src * cs] * scale : 0.f;
     const _Float16 h = (_Float16)w;
     const _Float16 l = (_Float16)((w - (float)h) * 2048.f);
     const int s = k >> 5, kq = (k >> 3) & 3, e = k & 7;
@@ -328,10 +327,11 @@ size_t f16x2k_pack_bytes(int f_in, int f_g, int ldb, int w_cols) {
   return (size_t)c.NT * KS * 2 * 64 * 8 * sizeof(u16) + (size_t)c.NT * 16 * sizeof(float);
 }
 
-int f16x2k_pack(const float* wcat, int f_in, int f_g, int ldb, int w_cols, void* packed, hipStream_t stream) {
+int f16x2k_pack(const float* wcat, int64_t rs, int64_t cs, int f_in, int f_g, int ldb, int w_cols, void* packed,
+                hipStream_t stream) {
   const KCols c = kcols(f_g, ldb, w_cols);
   const int KS = (f_in + 31) / 32;
-  pack_f16x2k_kernel<<<c.NT * 16, 64, 0, stream>>>(wcat, f_in, c, KS, (u16*)packed);
+  pack_f16x2k_kernel<<<c.NT * 16, 64, 0, stream>>>(wcat, rs, cs, f_in, c, KS, (u16*)packed);
   EGC_LAUNCH_CHECK("pack_f16x2k_kernel");
   return EGC_OK;
 }

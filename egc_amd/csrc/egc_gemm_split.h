@@ -14,14 +14,18 @@ inline bool f16x2_shape(int f_in, int ldb, int NV) {
 }
 
 size_t f16x2_pack_bytes(int KS, int NV);
-int f16x2_pack(const float* wcat, int f_in, int f_g, int w_cols, int ldb, int NV, int KS, void* packed, hipStream_t stream);
+// (rs, cs): floats between consecutive k / consecutive columns of the source: (f_g + w_cols, 1) for wcat [f_in][f_g + w_cols],
+// (1, ld) for its transpose stored [f_g + w_cols][ld]
+int f16x2_pack(const float* wcat, int64_t rs, int64_t cs, int f_in, int f_g, int w_cols, int ldb, int NV, int KS, void* packed,
+               hipStream_t stream);
 int f16x2_launch(const float* x, const void* packed, const float* bcat, int64_t M, int K, int W, float* bases, int ldb,
                  float* weightings, int NV, hipStream_t stream);
 
 // Shapes served by the long-k fp16x2 kernel (egc_gemm_f16x2k.hip): 128 < F_in <= 384, at most 16 column tiles of 16.
 bool f16x2k_shape(int f_in, int f_g, int ldb, int w_cols);
 size_t f16x2k_pack_bytes(int f_in, int f_g, int ldb, int w_cols);
-int f16x2k_pack(const float* wcat, int f_in, int f_g, int ldb, int w_cols, void* packed, hipStream_t stream);
+int f16x2k_pack(const float* wcat, int64_t rs, int64_t cs, int f_in, int f_g, int ldb, int w_cols, void* packed,
+                hipStream_t stream);
 int f16x2k_launch(const float* x, const void* packed, const float* bcat, int64_t M, int K, int f_g, int ldb, int W,
                   float* bases, float* weightings, hipStream_t stream);
 

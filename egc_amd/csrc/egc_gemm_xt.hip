@@ -20,6 +20,8 @@
 // the library GEMM (egc_amd/functional.py).
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "egc_common.h"
 
 namespace egc {
@@ -249,7 +251,8 @@ constexpr int X3_AHEAD = 4;   // register stages: global loads run this many 16-
 __global__ void __launch_bounds__(X3_THREADS) xt_gemm_bf16x3_kernel(const float* __restrict__ x, int64_t ldx, int F,
                                                                     const float* __restrict__ d, int64_t ldd, int K,
                                                                     int64_t n_rows, int64_t rows_per_chunk, int n_chunks,
-                                                                    float* __restrict__ partial, int want_sums) {
+                                                                    float* __restrict__ partial, int want_sums,
+                                                                    const float* __restrict__ e, int64_t lde, int E) {
   extern __shared__ float lds[];
   float* stage = lds;                                                                  // [2][X3_ROWS][X3_P] fp32
   unsigned short* planes = reinterpret_cast<unsigned short*>(lds + 2 * X3_STAGE_FLOATS);  // [2][3][X3_COLS][X3_RP] bf16
@@ -287,11 +290,21 @@ __global__ void __launch_bounds__(X3_THREADS) xt_gemm_bf16x3_kernel(const float*
     lds_d[i] = in_tile ? r * X3_P + X3_TM + 4 * c4 : -1;
   }
   const unsigned step_x = (unsigned)(X3_ROWS * ldx * 4), step_d = (unsigned)(X3_ROWS * ldd * 4);
-  struct Regs { f4 x; f4 d[LD]; };
+  // optional third array e [n_rows][E <= 128]: only its column sums are wanted (the layer's bias gradient = column sums
+  // of grad_out): one more 16-byte load per thread and sub-tile, added up in registers, never staged
+  const bool has_e = e != nullptr;
+  const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(has_e ? e + row_begin * lde : x), 0, has_e ? (unsigned)(range_rows * lde * 4) : 0u, 0x00020000);
+  const unsigned off_e = (has_e && 4 * (t % AX4) < E) ? (unsigned)(((t / AX4) * lde + 4 * (t % AX4)) * 4) : XT_OOB;
+  const unsigned step_e = (unsigned)(X3_ROWS * lde * 4);
+  f4 esum = f4{0.f, 0.f, 0.f, 0.f};
+  struct Regs { f4 x; f4 d[LD]; f4 e; };
   Regs rg[X3_AHEAD];
   auto fetch = [&](int sub, Regs& st) {
     const unsigned ox = off_x == XT_OOB ? XT_OOB : off_x + (unsigned)sub * step_x;
     st.x = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, ox, 0, 0));
+    if (has_e)   // uniform
+      st.e = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(re, off_e == XT_OOB ? XT_OOB : off_e + (unsigned)sub * step_e, 0, 0));
 #pragma unroll
     for (int i = 0; i < LD; ++i) {
       const unsigned o = off_d[i] == XT_OOB ? XT_OOB : off_d[i] + (unsigned)sub * step_d;
@@ -300,6 +313,7 @@ __global__ void __launch_bounds__(X3_THREADS) xt_gemm_bf16x3_kernel(const float*
   };
   auto put = [&](int sb, const Regs& st) {
     float* base = stage + sb * X3_STAGE_FLOATS;
+    if (has_e) esum += st.e;
     *reinterpret_cast<f4*>(base + lds_x) = st.x;
 #pragma unroll
     for (int i = 0; i < LD; ++i)
@@ -399,7 +413,7 @@ __global__ void __launch_bounds__(X3_THREADS) xt_gemm_bf16x3_kernel(const float*
 #undef X3_INTERVAL
 
   // C/D layout of the 32x32 MFMA: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-  const int64_t record = (int64_t)F * K + K;
+  const int64_t record = (int64_t)F * K + K + E;
   float* out = partial + (int64_t)chunk * record;
 #pragma unroll
   for (int tt = 0; tt < 3; ++tt) {
@@ -416,17 +430,32 @@ __global__ void __launch_bounds__(X3_THREADS) xt_gemm_bf16x3_kernel(const float*
     lds_barrier();
     if (t < X3_TN && t < K) out[(int64_t)F * K + t] = red[t] + red[X3_TN + t];
   }
+  if (has_e) {  // the sixteen row lanes of a 16-byte column piece
+    f4* red4 = reinterpret_cast<f4*>(planes);
+    lds_barrier();
+    red4[t] = esum;
+    lds_barrier();
+    if (t < AX4 && 4 * t < E) {
+      f4 v = red4[t];
+#pragma unroll
+      for (int r = 1; r < X3_ROWS; ++r) v += red4[r * AX4 + t];
+      *reinterpret_cast<f4*>(out + (int64_t)F * K + K + 4 * t) = v;
+    }
+  }
 }
 
 // out[i] = sum over chunks of partial[c][i], four floats per thread, 16 threads per output piece each adding every
 // 16th chunk (all loads of a thread in flight at once), then a tree over the 16.  A chunk's record is the F x K tile
 // followed by the K column sums; pieces past `fk` floats go to `sums`.
 __global__ void __launch_bounds__(256) xt_reduce_kernel(const float* __restrict__ partial, int64_t record, int64_t fk,
-                                                        int chunks, float* __restrict__ out, float* __restrict__ sums) {
+                                                        int chunks, float* __restrict__ out, float* __restrict__ sums,
+                                                        int sums_cols = 0, float* __restrict__ sums2 = nullptr) {
   __shared__ f4 red[256];
   const int t = threadIdx.x, o = t & 15, g = t >> 4;
   const int64_t piece = (int64_t)blockIdx.x * 16 + o;
-  const int64_t pieces = (sums != nullptr ? record : fk) / 4, stride = record / 4;
+  // record = [fk floats -> out][sums_cols floats -> sums][the rest -> sums2]; a null destination ends the record early
+  const int64_t used = sums == nullptr ? fk : (sums2 == nullptr && sums_cols > 0 ? fk + sums_cols : record);
+  const int64_t pieces = used / 4, stride = record / 4;
   f4 s = f4{0.f, 0.f, 0.f, 0.f};
   if (piece < pieces) {
     const f4* p = reinterpret_cast<const f4*>(partial) + piece;
@@ -442,7 +471,8 @@ __global__ void __launch_bounds__(256) xt_reduce_kernel(const float* __restrict_
   }
   if (t < 16 && piece < pieces) {
     if (piece < fk / 4) reinterpret_cast<f4*>(out)[piece] = red[t];
-    else reinterpret_cast<f4*>(sums)[piece - fk / 4] = red[t];
+    else if (sums2 == nullptr || piece < (fk + sums_cols) / 4) reinterpret_cast<f4*>(sums)[piece - fk / 4] = red[t];
+    else reinterpret_cast<f4*>(sums2)[piece - (fk + sums_cols) / 4] = red[t];
   }
 }
 
@@ -507,32 +537,42 @@ int launch_xt(const XtPlan& p, const float* x, int64_t ldx, int F, const float* 
 
 extern "C" {
 
-int64_t egc_weight_grad_workspace_bytes(int64_t n_rows, int32_t f_in, int32_t k_cols) {
-  if (n_rows < 0 || f_in <= 0 || k_cols <= 0) return 0;
+int64_t egc_weight_grad_ex_workspace_bytes(int64_t n_rows, int32_t f_in, int32_t k_cols, int32_t e_cols) {
+  if (n_rows < 0 || f_in <= 0 || k_cols <= 0 || e_cols < 0) return 0;
   const egc::XtPlan p = egc::xt_plan(n_rows, f_in, k_cols);
-  return (int64_t)p.chunks * ((int64_t)f_in * k_cols + k_cols) * 4;
+  return (int64_t)p.chunks * ((int64_t)f_in * k_cols + k_cols + e_cols) * 4;
 }
 
-int egc_weight_grad_f32(const float* x, int64_t ldx, const float* d, int64_t ldd, int64_t n_rows, int32_t f_in,
-                        int32_t k_cols, float* out, float* col_sums, void* workspace, int64_t workspace_bytes,
-                        void* stream_) {
+int64_t egc_weight_grad_workspace_bytes(int64_t n_rows, int32_t f_in, int32_t k_cols) {
+  return egc_weight_grad_ex_workspace_bytes(n_rows, f_in, k_cols, 0);
+}
+
+int egc_weight_grad_ex_f32(const float* x, int64_t ldx, const float* d, int64_t ldd, int64_t n_rows, int32_t f_in,
+                           int32_t k_cols, float* out, float* col_sums, const float* e, int64_t lde, int32_t e_cols,
+                           float* e_sums, void* workspace, int64_t workspace_bytes, void* stream_) {
   using namespace egc;
   hipStream_t stream = (hipStream_t)stream_;
   if (n_rows < 0 || f_in <= 0 || k_cols <= 0 || out == nullptr) return EGC_ERR_INVALID;
+  if (e == nullptr || e_sums == nullptr) { e = nullptr; e_sums = nullptr; e_cols = 0; }
   if ((f_in % 4) || (k_cols % 4) || (ldx % 4) || (ldd % 4) || ((uintptr_t)x % 16) || ((uintptr_t)d % 16) ||
-      ((uintptr_t)out % 16) || ((uintptr_t)col_sums % 16) || ((uintptr_t)workspace % 16))
+      ((uintptr_t)out % 16) || ((uintptr_t)col_sums % 16) || ((uintptr_t)workspace % 16) || (e_cols % 4) || (lde % 4) ||
+      ((uintptr_t)e % 16) || ((uintptr_t)e_sums % 16))
     return EGC_ERR_UNSUPPORTED;
-  if (workspace_bytes < egc_weight_grad_workspace_bytes(n_rows, f_in, k_cols) || workspace == nullptr)
+  static const bool fp32_only = getenv("EGC_XT_FP32") != nullptr;
+  const bool one_tile = !fp32_only && f_in <= X3_TM && k_cols <= X3_TN;
+  // the third array rides along only in the one-tile kernel, next to the column sums of d, 128 columns at most
+  if (e != nullptr && (!one_tile || e_cols > X3_TM || col_sums == nullptr)) return EGC_ERR_UNSUPPORTED;
+  if (workspace_bytes < egc_weight_grad_ex_workspace_bytes(n_rows, f_in, k_cols, e_cols) || workspace == nullptr)
     return EGC_ERR_INVALID;
   const XtPlan p = xt_plan(n_rows, f_in, k_cols);
   // 32-bit buffer offsets inside a workgroup's row range (plus the look-ahead past its end)
-  if ((double)(p.rows_per_chunk + 160) * (double)(ldx > ldd ? ldx : ldd) * 4.0 >= 4.0e9) return EGC_ERR_UNSUPPORTED;
+  const int64_t widest = std::max(std::max(ldx, ldd), e != nullptr ? lde : (int64_t)0);
+  if ((double)(p.rows_per_chunk + 160) * (double)widest * 4.0 >= 4.0e9) return EGC_ERR_UNSUPPORTED;
   const int64_t fk = (int64_t)f_in * k_cols;
   float* partial = static_cast<float*>(workspace);
   const int want_sums = col_sums != nullptr;
   int rc = EGC_ERR_UNSUPPORTED;
-  static const bool fp32_only = getenv("EGC_XT_FP32") != nullptr;
-  if (!fp32_only && f_in <= X3_TM && k_cols <= X3_TN) {   // one accumulator tile: the bf16x3 kernel
+  if (one_tile) {   // one accumulator tile: the bf16x3 kernel
     constexpr int lds_bytes = X3_LDS_BYTES;
     static bool configured = false;
     if (!configured) {
@@ -540,8 +580,8 @@ int egc_weight_grad_f32(const float* x, int64_t ldx, const float* d, int64_t ldd
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
       configured = true;
     }
-    xt_gemm_bf16x3_kernel<<<(unsigned)p.chunks, X3_THREADS, lds_bytes, stream>>>(x, ldx, f_in, d, ldd, k_cols, n_rows,
-                                                                               p.rows_per_chunk, p.chunks, partial, want_sums);
+    xt_gemm_bf16x3_kernel<<<(unsigned)p.chunks, X3_THREADS, lds_bytes, stream>>>(
+        x, ldx, f_in, d, ldd, k_cols, n_rows, p.rows_per_chunk, p.chunks, partial, want_sums, e, lde, e_cols);
     EGC_LAUNCH_CHECK("xt_gemm_bf16x3_kernel");
     rc = EGC_OK;
   } else {
@@ -553,11 +593,19 @@ int egc_weight_grad_f32(const float* x, int64_t ldx, const float* d, int64_t ldd
 #undef EGC_XT_CASE
   }
   if (rc != EGC_OK) return rc;
-  const int64_t record = fk + k_cols;
-  xt_reduce_kernel<<<(unsigned)ceil_div((want_sums ? record : fk) / 4, 16), 256, 0, stream>>>(partial, record, fk, p.chunks,
-                                                                                            out, col_sums);
+  const int64_t record = fk + k_cols + e_cols;
+  const int64_t used = !want_sums ? fk : (e != nullptr ? record : fk + k_cols);
+  xt_reduce_kernel<<<(unsigned)ceil_div(used / 4, 16), 256, 0, stream>>>(partial, record, fk, p.chunks, out, col_sums, k_cols,
+                                                                         e_sums);
   EGC_LAUNCH_CHECK("xt_reduce_kernel");
   return EGC_OK;
+}
+
+int egc_weight_grad_f32(const float* x, int64_t ldx, const float* d, int64_t ldd, int64_t n_rows, int32_t f_in,
+                        int32_t k_cols, float* out, float* col_sums, void* workspace, int64_t workspace_bytes,
+                        void* stream_) {
+  return egc_weight_grad_ex_f32(x, ldx, d, ldd, n_rows, f_in, k_cols, out, col_sums, nullptr, 0, 0, nullptr, workspace,
+                                workspace_bytes, stream_);
 }
 
 /* out[c] = sum over p of partials[p][c] (p < n_partials, c < cols): the second step of egc_column_sums_f32 (and of any

@@ -475,31 +475,45 @@ def egc_aggregate_combine_backward(graph: CSRGraph, spec: LayerSpec, bases, weig
     return d_bases, d_w, d_cat   # d_cat is None unless the joint layout was asked for and applies
 
 
-def _weight_grads(x: torch.Tensor, d: torch.Tensor, col_sums: bool = False):
-    """(x^T @ d, d.sum(0) or None) for tall x [N, F], d [N, K]: the gradient of [bases_weight | comb_weights.weight]
-    and of comb_weights.bias (autograd's products behind optimized_layers.py:177-178) in one pass over both
-    operands through egc_weight_grad_f32 -- fp32 matrix-core products over row ranges, added in a fixed order.
-    Shapes outside that entry point's envelope (a dimension not a multiple of 4), and outputs larger than one
-    128 x 192 accumulator tile on long reductions (ogbn-mag widths: the library's split GEMM is faster there), take
-    torch's GEMM on the device."""
+def _weight_grads(x: torch.Tensor, d: torch.Tensor, col_sums: bool = False, extra: torch.Tensor | None = None):
+    """(x^T @ d, d.sum(0) or None[, extra.sum(0)]) for tall x [N, F], d [N, K]: the gradient of [bases_weight |
+    comb_weights.weight], of comb_weights.bias and -- with ``extra`` = grad_out -- of the layer's bias (autograd's
+    products behind optimized_layers.py:177-178,207-208) in one pass over the operands through egc_weight_grad_ex_f32:
+    split-bf16 matrix-core products with fp32-level accuracy over row ranges, added in a fixed order.  Shapes outside
+    that entry point's envelope (a dimension not a multiple of 4), and outputs larger than one 128 x 192 accumulator
+    tile on long reductions (ogbn-mag widths: the library's split GEMM is faster there), take torch's GEMM on the
+    device.  Returns a pair without ``extra``, a triple with it."""
     n, f = x.shape
     k = d.size(1)
     big = (f > 128 or k > 192) and n > 65536
+
+    def done(w, s, e):
+        return (w, s) if extra is None else (w, s, e)
     if (n == 0 or big or f % 4 or k % 4 or not x.is_cuda or x.dtype != torch.float32 or d.dtype != torch.float32
             or x.stride(1) != 1 or d.stride(1) != 1 or x.stride(0) % 4 or d.stride(0) % 4
             or x.data_ptr() % 16 or d.data_ptr() % 16):
-        return _xt_library(x, d), (_column_sums(d) if col_sums else None)
+        return done(_xt_library(x, d), _column_sums(d) if col_sums else None, _column_sums(extra) if extra is not None else None)
     lib = _C.load()
     dev = x.device
+    ride = (extra is not None and col_sums and f <= 128 and k <= 192 and extra.dim() == 2 and extra.size(0) == n
+            and extra.size(1) % 4 == 0 and extra.size(1) <= 128 and extra.dtype == torch.float32 and extra.stride(1) == 1
+            and extra.stride(0) % 4 == 0 and extra.data_ptr() % 16 == 0 and not gemm_exact()
+            and os.environ.get("EGC_XT_FP32") is None)
     with _device_guard(dev):
         out = torch.empty((f, k), dtype=torch.float32, device=dev)
         cs = torch.empty(k, dtype=torch.float32, device=dev) if col_sums else None
-        nbytes = int(lib.egc_weight_grad_workspace_bytes(n, f, k))
+        e_cols = extra.size(1) if ride else 0
+        es = torch.empty(e_cols, dtype=torch.float32, device=dev) if ride else None
+        nbytes = int(lib.egc_weight_grad_ex_workspace_bytes(n, f, k, e_cols))
         ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
-        _C.check(lib.egc_weight_grad_f32(x.data_ptr(), x.stride(0), d.data_ptr(), d.stride(0), n, f, k, out.data_ptr(),
-                                         cs.data_ptr() if cs is not None else None, ws.data_ptr(), ws.numel(),
-                                         _stream_ptr(dev)), "egc_weight_grad_f32")
-    return out, cs
+        _C.check(lib.egc_weight_grad_ex_f32(x.data_ptr(), x.stride(0), d.data_ptr(), d.stride(0), n, f, k, out.data_ptr(),
+                                            cs.data_ptr() if cs is not None else None,
+                                            extra.data_ptr() if ride else None, extra.stride(0) if ride else 0, e_cols,
+                                            es.data_ptr() if ride else None, ws.data_ptr(), ws.numel(),
+                                            _stream_ptr(dev)), "egc_weight_grad_ex_f32")
+    if extra is not None and not ride:
+        es = _column_sums(extra)
+    return done(out, cs, es)
 
 
 def _xt_library(x: torch.Tensor, d: torch.Tensor) -> torch.Tensor:
@@ -552,12 +566,13 @@ def _dx_matmul(d_cat: torch.Tensor, wcat: torch.Tensor) -> torch.Tensor:
     lib = _C.load()
     dev = d_cat.device
     with _device_guard(dev):
-        wt = wcat.detach().t().contiguous()
+        w = wcat.detach().contiguous()          # [f_in, k]: the transpose of this GEMM's operand, packed where it lies
         nbytes = lib.egc_basis_pack_bytes(k, f_in, 0)
         packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         dx = torch.empty((n, f_in), dtype=torch.float32, device=dev)
         stream = _stream_ptr(dev)
-        _C.check(lib.egc_basis_pack(wt.data_ptr(), k, f_in, 0, packed.data_ptr(), nbytes, stream), "egc_basis_pack")
+        _C.check(lib.egc_basis_pack_transposed(w.data_ptr(), k, k, f_in, 0, packed.data_ptr(), nbytes, stream),
+                 "egc_basis_pack_transposed")
         _C.check(lib.egc_basis_transform_packed(d_cat.data_ptr(), packed.data_ptr(), None, n, k, f_in, 0, dx.data_ptr(),
                                                 f_in, None, stream), "egc_basis_transform_packed")
     return dx
@@ -597,13 +612,19 @@ class _EGCLayerFunction(torch.autograd.Function):
             d_cat = torch.cat([d_bases[:, :spec.f_g], d_w], dim=1)         # [N, F_g + W]
         dx = _dx_matmul(d_cat, wcat) if ctx.needs_input_grad[0] else None
         need_bcat = ctx.has_bcat and ctx.needs_input_grad[2]
-        dwcat = dbcat = None
+        need_bias = ctx.has_bias and ctx.needs_input_grad[3]
+        dwcat = dbcat = dbias = None
         if ctx.needs_input_grad[1]:
-            dwcat, sums = _weight_grads(x, d_cat, col_sums=need_bcat)   # column sums of d_w ride along
+            # the column sums of d_w (comb bias) and of grad_out (the layer's bias) ride along with x^T d_cat
+            if need_bias and need_bcat:
+                dwcat, sums, dbias = _weight_grads(x, d_cat, col_sums=True, extra=grad_out)
+            else:
+                dwcat, sums = _weight_grads(x, d_cat, col_sums=need_bcat)
             dbcat = sums[d_cat.size(1) - spec.w_cols:] if need_bcat else None
         elif need_bcat:
             dbcat = _column_sums(d_w)
-        dbias = _column_sums(grad_out) if (ctx.has_bias and ctx.needs_input_grad[3]) else None
+        if need_bias and dbias is None:
+            dbias = _column_sums(grad_out)
         return dx, dwcat, dbcat, dbias, None, None
 
 

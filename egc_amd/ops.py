@@ -92,9 +92,12 @@ def layer_backward(grad_out: torch.Tensor, x: torch.Tensor, wcat: torch.Tensor, 
     if d_cat is None:
         d_cat = torch.cat([d_bases[:, :spec.f_g], d_w], dim=1)
     empty = x.new_empty((0,))
-    dwcat, sums = F._weight_grads(x, d_cat, col_sums=need_bcat)
-    return (F._dx_matmul(d_cat, wcat), dwcat, sums[d_cat.size(1) - spec.w_cols:] if need_bcat else empty,
-            F._column_sums(grad_out) if need_bias else empty)
+    if need_bcat and need_bias:   # both bias gradients ride along with the weight gradient (egc_weight_grad_ex_f32)
+        dwcat, sums, dbias = F._weight_grads(x, d_cat, col_sums=True, extra=grad_out)
+    else:
+        dwcat, sums = F._weight_grads(x, d_cat, col_sums=need_bcat)
+        dbias = F._column_sums(grad_out) if need_bias else empty
+    return (F._dx_matmul(d_cat, wcat), dwcat, sums[d_cat.size(1) - spec.w_cols:] if need_bcat else empty, dbias)
 
 
 @layer_backward.register_fake

@@ -194,6 +194,11 @@ int egc_basis_transform_f32(const float* x, const float* wcat, const float* bcat
 size_t egc_basis_pack_bytes(int32_t f_in, int32_t f_g, int32_t w_cols);
 int egc_basis_pack(const float* wcat, int32_t f_in, int32_t f_g, int32_t w_cols, void* packed,
                    size_t packed_bytes, egc_stream_t stream);
+/* egc_basis_pack of a matrix given TRANSPOSED: wt [f_g + w_cols][ld >= f_in] row-major holds wcat^T (element (k, c) of
+ * wcat at wt[c * ld + k]).  The gradient w.r.t. x is [d bases | d weightings] @ wcat^T -- a basis transform whose
+ * "wcat" is the transpose of the layer's own operand: this packs it where it lies (no transposed copy per step). */
+int egc_basis_pack_transposed(const float* wt, int64_t ld, int32_t f_in, int32_t f_g, int32_t w_cols, void* packed,
+                              size_t packed_bytes, egc_stream_t stream);
 int egc_basis_transform_packed(const float* x, const void* packed, const float* bcat, int64_t n_nodes,
                                int32_t f_in, int32_t f_g, int32_t w_cols, float* bases, int32_t ldb,
                                float* weightings, egc_stream_t stream);
@@ -270,6 +275,16 @@ int egc_aggregate_combine_strided_f32(const egc_graph* graph, const egc_layer* l
  * else EGC_ERR_UNSUPPORTED.  workspace: egc_weight_grad_workspace_bytes(n_rows, f_in, k_cols) bytes, contents
  * irrelevant on entry and on exit. */
 int64_t egc_weight_grad_workspace_bytes(int64_t n_rows, int32_t f_in, int32_t k_cols);
+/* The same with the column sums of a THIRD array riding along: e [n_rows][e_cols] (row stride lde; e_cols <= 128, a
+ * multiple of 4) -> e_sums[e_cols].  A training step wants three reductions over the nodes -- the weight gradient, the
+ * column sums of d weightings (bias of the combination Linear) and the column sums of grad_out (the layer's bias,
+ * layers.py:137-138 / optimized_layers.py:207-208) -- and this is all three in one pass.  Only where the weight
+ * gradient is one 128 x 192 accumulator tile (f_in <= 128, k_cols <= 192) and col_sums is requested; otherwise
+ * EGC_ERR_UNSUPPORTED (use egc_column_sums_f32 for e).  e == NULL or e_sums == NULL: egc_weight_grad_f32. */
+int64_t egc_weight_grad_ex_workspace_bytes(int64_t n_rows, int32_t f_in, int32_t k_cols, int32_t e_cols);
+int egc_weight_grad_ex_f32(const float* x, int64_t ldx, const float* d, int64_t ldd, int64_t n_rows, int32_t f_in,
+                           int32_t k_cols, float* out, float* col_sums, const float* e, int64_t lde, int32_t e_cols,
+                           float* e_sums, void* workspace, int64_t workspace_bytes, void* stream);
 int egc_weight_grad_f32(const float* x, int64_t ldx, const float* d, int64_t ldd, int64_t n_rows, int32_t f_in,
                         int32_t k_cols, float* out, float* col_sums, void* workspace, int64_t workspace_bytes,
                         void* stream);

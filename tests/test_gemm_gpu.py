@@ -211,3 +211,43 @@ def test_weight_grad_rejects_unaligned_shapes():
     rc = lib.egc_weight_grad_f32(x.data_ptr(), 6, d.data_ptr(), 8, 8, 6, 8, o.data_ptr(), None, ws.data_ptr(),
                                  ws.numel() * 4, torch.cuda.current_stream().cuda_stream)
     assert rc == 4   # EGC_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("n", [0, 5, 1000, 40001])
+@pytest.mark.parametrize("f,k,e", [(128, 192, 128), (100, 132, 36), (32, 64, 4)])
+def test_weight_grad_with_the_column_sums_of_a_third_array(n, f, k, e):
+    """egc_weight_grad_ex_f32: x^T d, the column sums of d and the column sums of a third array (grad_out) in one pass."""
+    from egc_amd import functional as F
+    g = torch.Generator(device="cpu").manual_seed(n + 3 * f + 5 * k + 7 * e)
+    x = torch.randn(n, f, generator=g).to(DEV)
+    d = torch.randn(n, k, generator=g).to(DEV)
+    ex = (torch.randn(n, e, generator=g) * 3 + 0.5).to(DEV)
+    w, cs, es = F._weight_grads(x, d, col_sums=True, extra=ex)
+    tol = 2e-6 * max(1.0, (n ** 0.5) / 8)
+    tiny = torch.finfo(torch.float32).tiny
+    ref, bud = x.double().t() @ d.double(), x.double().abs().t() @ d.double().abs()
+    assert float(((w.double() - ref).abs() / (bud + tiny)).max() if n else w.abs().max()) <= tol
+    for got, src in ((cs, d), (es, ex)):
+        r, b = src.double().sum(0), src.double().abs().sum(0)
+        assert got.shape == r.shape
+        assert float(((got.double() - r).abs() / (b + tiny)).max() if n else got.abs().max()) <= tol
+
+
+@pytest.mark.parametrize("f_in,f_g,w_cols", [(128, 64, 128), (192, 128, 0), (352, 176, 32), (124, 124, 48)])
+def test_pack_transposed_equals_pack(f_in, f_g, w_cols):
+    """egc_basis_pack_transposed(W^T stored row-major) produces the very planes egc_basis_pack(W) does (all three
+    split forms: fp16x2, long-k fp16x2, bf16x3)."""
+    from egc_amd import _C
+    lib = _C.load()
+    g = torch.Generator(device="cpu").manual_seed(f_in + f_g)
+    w = (torch.randn(f_in, f_g + w_cols, generator=g) * torch.logspace(-3, 3, f_g + w_cols)).to(DEV)
+    wt = torch.zeros(f_g + w_cols, f_in + 4, device=DEV)      # row stride > f_in
+    wt[:, :f_in] = w.t()
+    nb = lib.egc_basis_pack_bytes(f_in, f_g, w_cols)
+    a = torch.zeros(nb, dtype=torch.uint8, device=DEV)
+    b = torch.zeros(nb, dtype=torch.uint8, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    _C.check(lib.egc_basis_pack(w.data_ptr(), f_in, f_g, w_cols, a.data_ptr(), nb, st), "pack")
+    _C.check(lib.egc_basis_pack_transposed(wt.data_ptr(), wt.stride(0), f_in, f_g, w_cols, b.data_ptr(), nb, st), "pack_t")
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
