@@ -466,7 +466,20 @@ int egc_segment_mean_f32(const float* x, const int64_t* seg_ptr, int64_t n_segme
 int64_t egc_train_stats_floats(const egc_layer* layer) {
   if (validate_layer(layer) != EGC_OK) return 0;
   int slot[5];
-  return (int64_t)stat_layout(layer->aggrs, layer->num_aggrs, slot) * egc_bases_ld(layer);
+  const int64_t k = stat_layout(layer->aggrs, layer->num_aggrs, slot), ldb = egc_bases_ld(layer);
+  // raw aggregates, then the 8-bit in-row arg positions of max / min (ldb bytes each per row; egc_aggregate_dev.h)
+  return k * ldb + ((slot[STAT_MX] >= 0 ? 1 : 0) + (slot[STAT_MN] >= 0 ? 1 : 0)) * (ldb / 4);
+}
+
+// where the arg8 tables of a training call sit inside its `stats` buffer
+static void arg8_tables(const egc_layer* layer, int64_t n, float* stats, bool want_max, bool want_min, unsigned** a8max,
+                        unsigned** a8min) {
+  int slot[5];
+  const int64_t k = stat_layout(layer->aggrs, layer->num_aggrs, slot), ldb = egc_bases_ld(layer);
+  unsigned char* bytes = reinterpret_cast<unsigned char*>(stats + n * k * ldb);
+  const bool has_max = slot[STAT_MX] >= 0, has_min = slot[STAT_MN] >= 0;
+  *a8max = (has_max && want_max) ? reinterpret_cast<unsigned*>(bytes) : nullptr;
+  *a8min = (has_min && want_min) ? reinterpret_cast<unsigned*>(bytes + (has_max ? n * ldb : 0)) : nullptr;
 }
 
 static int aggregate_combine_impl(const egc_graph* graph, const egc_layer* layer, const float* bases, int32_t ldb,
@@ -518,7 +531,9 @@ int egc_aggregate_combine_train_f32(const egc_graph* graph, const egc_layer* lay
   int st = aggregate_combine_impl(graph, layer, bases, ldb, weightings, bias, nullptr, out, stats, cnt, 0, -1, workspace,
                                   workspace_bytes, stream, arg_max, arg_min, &arg_done);
   if (st != EGC_OK || arg_done) return st;
-  return egc::arg_extrema(graph, layer, bases, ldb, stats, cnt, arg_max, arg_min, (hipStream_t)stream);
+  unsigned *a8max, *a8min;
+  arg8_tables(layer, graph->n_nodes, stats, arg_max != nullptr, arg_min != nullptr, &a8max, &a8min);
+  return egc::arg_extrema(graph, layer, bases, ldb, stats, cnt, arg_max, arg_min, a8max, a8min, (hipStream_t)stream);
 }
 
 static int aggregate_combine_impl(const egc_graph* graph, const egc_layer* layer, const float* bases, int32_t ldb,
@@ -596,6 +611,8 @@ static int aggregate_combine_impl(const egc_graph* graph, const egc_layer* layer
   a.stat_k = stat_layout(a.aggr, a.A, a.stat_slot);
   a.arg_max = a.stat_slot[STAT_MX] >= 0 ? arg_max : nullptr;
   a.arg_min = a.stat_slot[STAT_MN] >= 0 ? arg_min : nullptr;
+  a.arg8_max = a.arg8_min = nullptr;
+  if (stats != nullptr) arg8_tables(layer, n, stats, a.arg_max != nullptr, a.arg_min != nullptr, &a.arg8_max, &a.arg8_min);
   a.self_pos = (int)e;
 
   int chunks = 1;

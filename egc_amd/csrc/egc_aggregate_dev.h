@@ -16,6 +16,24 @@ typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 
 constexpr unsigned OOB = 0xFFFFFFF0u;  // any offset >= num_records makes a buffer load return 0
 
+// In-row arg positions in 8 bits (training forward -> backward).  The backward's source side compares, per transposed
+// entry, the arg positions of the destination row with the entry's own position: as int32 that is a 256-byte row per
+// entry at the north star; relative to the row's first entry a position fits one byte for all but hub rows and the
+// gathered row shrinks to 64 bytes.  Encoding: 0 .. 253 = position - rowptr[row]; ARG8_NONE = no entry of the row
+// can match (appended self-loop, empty row); ARG8_FAR = position >= rowptr[row] + ARG8_NONE: entries that far into a
+// (hub) row, and only they, still compare against the int32 table.  The tables live behind the raw aggregates in
+// the `stats` buffer of egc_aggregate_combine_train_f32: [N][stat_k][ldb] floats, then [N][ldb] bytes for max, then
+// [N][ldb] bytes for min (each only if the layer has that aggregator).
+constexpr unsigned ARG8_NONE = 254u, ARG8_FAR = 255u;
+__device__ inline unsigned arg8_pack(int4 a, int start, int n_edges) {
+  auto enc = [&](int p) -> unsigned {
+    if (p < 0 || p >= n_edges) return ARG8_NONE;
+    const unsigned rel = (unsigned)(p - start);
+    return rel < ARG8_NONE ? rel : ARG8_FAR;
+  };
+  return enc(a.x) | (enc(a.y) << 8) | (enc(a.z) << 16) | (enc(a.w) << 24);
+}
+
 struct AggArgs {
   const int* rowptr;
   const int* col;
@@ -72,6 +90,8 @@ struct AggArgs {
   // row), tracked inside the aggregation.  The generic kernels leave them to arg_extrema().
   int* arg_max;
   int* arg_min;
+  unsigned* arg8_max;      // the same positions as bytes relative to the row's first entry (arg8_pack), or nullptr
+  unsigned* arg8_min;
   int self_pos;              // = n_edges
   // egc_aggregate_fusedw.hip only: the weightings x @ comb_weight^T + comb_bias are computed inside the launch
   const float* x;            // [n_nodes, F_in]

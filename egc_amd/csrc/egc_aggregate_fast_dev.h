@@ -330,12 +330,16 @@ __device__ inline void finish_group(const AggArgs& a, const FastRsrc& R, int lan
         const i4 r = i4{acc.ax.x == ARG_NONE ? none : acc.ax.x, acc.ax.y == ARG_NONE ? none : acc.ax.y,
                         acc.ax.z == ARG_NONE ? none : acc.ax.z, acc.ax.w == ARG_NONE ? none : acc.ax.w};
         __builtin_nontemporal_store(r, reinterpret_cast<i4*>(a.arg_max + ao));
+        if (a.arg8_max != nullptr)
+          __builtin_nontemporal_store(arg8_pack(int4{r.x, r.y, r.z, r.w}, a.rowptr[row], a.self_pos), a.arg8_max + (ao >> 2));
       }
       if constexpr (NEED & NEED_MN)
         if (a.arg_min != nullptr) {
           const i4 r = i4{acc.an.x == ARG_NONE ? none : acc.an.x, acc.an.y == ARG_NONE ? none : acc.an.y,
                           acc.an.z == ARG_NONE ? none : acc.an.z, acc.an.w == ARG_NONE ? none : acc.an.w};
           __builtin_nontemporal_store(r, reinterpret_cast<i4*>(a.arg_min + ao));
+          if (a.arg8_min != nullptr)
+            __builtin_nontemporal_store(arg8_pack(int4{r.x, r.y, r.z, r.w}, a.rowptr[row], a.self_pos), a.arg8_min + (ao >> 2));
         }
     }
   }

@@ -153,8 +153,21 @@ __global__ void __launch_bounds__(256) arg_finalize_kernel(int* arg, const int* 
   if (arg[k] == ARG_INIT) arg[k] = cnt[k / ldb] > 0 ? n_edges : -1;
 }
 
+// arg8 tables (egc_aggregate_dev.h) from int32 arg rows: the generic training forward's last step
+__global__ void __launch_bounds__(256) arg8_kernel(const int* __restrict__ arg, const int* __restrict__ rowptr,
+                                                   unsigned* __restrict__ arg8, int64_t quads, int quads_per_row,
+                                                   int n_edges) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread: 4 columns -> one packed dword
+  if (k >= quads) return;
+  const int row = (int)(k / quads_per_row);
+  const int start = rowptr[row];
+  const int4 a = *reinterpret_cast<const int4*>(arg + 4 * k);
+  arg8[k] = arg8_pack(a, start, n_edges);
+}
+
 int arg_extrema(const egc_graph* graph, const egc_layer* layer, const float* bases, int32_t ldb, const float* stats,
-                const int32_t* cnt, int32_t* arg_max, int32_t* arg_min, hipStream_t stream) {
+                const int32_t* cnt, int32_t* arg_max, int32_t* arg_min, unsigned* arg8_max, unsigned* arg8_min,
+                hipStream_t stream) {
   int slot[5];
   const int k = stat_layout(layer->aggrs, layer->num_aggrs, slot);
   if (slot[STAT_MX] < 0) arg_max = nullptr;
@@ -196,6 +209,12 @@ int arg_extrema(const egc_graph* graph, const egc_layer* layer, const float* bas
   if (arg_max != nullptr) arg_finalize_kernel<<<(unsigned)ceil_div(total, 256), 256, 0, stream>>>(arg_max, cnt, total, ldb, (int)e);
   if (arg_min != nullptr) arg_finalize_kernel<<<(unsigned)ceil_div(total, 256), 256, 0, stream>>>(arg_min, cnt, total, ldb, (int)e);
   EGC_LAUNCH_CHECK("arg_finalize_kernel");
+  const int64_t quads = total / 4;
+  if (arg_max != nullptr && arg8_max != nullptr)
+    arg8_kernel<<<(unsigned)ceil_div(quads, 256), 256, 0, stream>>>(arg_max, graph->rowptr, arg8_max, quads, ldb / 4, (int)e);
+  if (arg_min != nullptr && arg8_min != nullptr)
+    arg8_kernel<<<(unsigned)ceil_div(quads, 256), 256, 0, stream>>>(arg_min, graph->rowptr, arg8_min, quads, ldb / 4, (int)e);
+  EGC_LAUNCH_CHECK("arg8_kernel");
   return EGC_OK;
 }
 
@@ -371,32 +390,6 @@ __global__ void __launch_bounds__(256) bwd_dst_kernel(BwdArgs a) {
 // weights sit in per-group LDS strips; a lane forms  d agg_t = sum_h w'[h][b][t] g[h][l..l+3]  and its share of
 // d w'[h][b][t] = sum_l g[h][l] agg_t[b][l]  in one pass over h, the shares meet in an xor butterfly over the P
 // lanes of the basis, and lane l4 stores the heads l4 H/P .. (l4+1) H/P - 1.
-// In-row arg positions in 8 bits.  The source side compares, per transposed entry, the arg positions of the
-// destination row with the entry's own position: gathered as int32 that is a 256-byte row per entry (a third of the
-// kernel's traffic at the north star); relative to the row's first entry a position fits one byte for all but hub
-// rows, and the gathered row shrinks to 64 bytes.  Encoding: 0 .. 253 = position - rowptr[row]; ARG8_NONE = no entry
-// of the row can match (appended self-loop, empty row); ARG8_FAR = position >= rowptr[row] + ARG8_NONE: entries that
-// far into a (hub) row, and only they, still compare against the int32 table.
-constexpr unsigned ARG8_NONE = 254u, ARG8_FAR = 255u;
-__device__ inline unsigned arg8_pack(int4 a, int start, int n_edges) {
-  auto enc = [&](int p) -> unsigned {
-    if (p < 0 || p >= n_edges) return ARG8_NONE;
-    const unsigned rel = (unsigned)(p - start);
-    return rel < ARG8_NONE ? rel : ARG8_FAR;
-  };
-  return enc(a.x) | (enc(a.y) << 8) | (enc(a.z) << 16) | (enc(a.w) << 24);
-}
-__global__ void __launch_bounds__(256) arg8_kernel(const int* __restrict__ arg, const int* __restrict__ rowptr,
-                                                   unsigned* __restrict__ arg8, int64_t quads, int quads_per_row,
-                                                   int n_edges) {
-  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread: 4 columns -> one packed dword
-  if (k >= quads) return;
-  const int row = (int)(k / quads_per_row);
-  const int start = rowptr[row];
-  const int4 a = *reinterpret_cast<const int4*>(arg + 4 * k);
-  arg8[k] = arg8_pack(a, start, n_edges);
-}
-
 constexpr int BWD_HMAX = 16;   // heads supported by the register form
 // HT / AT: compile-time head and aggregator counts (the d = 128, H = 8 layers; everything else: bwd_dst_kernel)
 // AGG: the aggregator codes packed 3 bits each (first in the low bits) with bit 31 set, or 0 = read them from
@@ -816,8 +809,7 @@ extern "C" {
 size_t egc_backward_workspace_bytes(const egc_layer* layer, int64_t n_nodes) {
   if (layer == nullptr || n_nodes < 0 || layer->num_heads <= 0) return 0;
   const int ldb = egc_bases_ld(layer);
-  // tables T, S, V, X, N; then the 8-bit in-row arg positions of max and min
-  return (size_t)5 * (size_t)n_nodes * ldb * sizeof(float) + (size_t)2 * (size_t)n_nodes * ldb + 256;
+  return (size_t)5 * (size_t)n_nodes * ldb * sizeof(float) + 256;  // tables T, S, V, X, N
 }
 
 int egc_aggregate_combine_backward_f32(const egc_graph* graph, const egc_graph* t_graph, const egc_layer* layer,
@@ -912,10 +904,10 @@ int egc_aggregate_combine_backward_f32(const egc_graph* graph, const egc_graph* 
   a.t_edge_id = t_graph->edge_id;
   if ((a.tab_x != nullptr || a.tab_n != nullptr) && a.t_edge_id == nullptr) return EGC_ERR_INVALID;
   a.rowptr = graph->rowptr;
-  {
-    unsigned char* bytes = reinterpret_cast<unsigned char*>(ws + (size_t)5 * n * ldb);
+  {  // the 8-bit in-row arg positions the training forward left behind the raw aggregates (egc_aggregate_dev.h)
+    unsigned char* bytes = reinterpret_cast<unsigned char*>(const_cast<float*>(stats) + (size_t)n * a.stat_k * ldb);
     a.arg8_max = a.tab_x != nullptr ? bytes : nullptr;
-    a.arg8_min = a.tab_n != nullptr ? bytes + (size_t)n * ldb : nullptr;
+    a.arg8_min = a.tab_n != nullptr ? bytes + (a.tab_x != nullptr ? (size_t)n * ldb : 0) : nullptr;
     if ((a.arg8_max != nullptr || a.arg8_min != nullptr) && a.rowptr == nullptr) return EGC_ERR_INVALID;
   }
   a.tab_bytes = (unsigned)((uint64_t)n * ldb * 4ull);
@@ -954,16 +946,6 @@ int egc_aggregate_combine_backward_f32(const egc_graph* graph, const egc_graph* 
     } else {
       bwd_dst_kernel<<<(unsigned)ceil_div(n, wpb), wpb * 64, lds, stream>>>(a);
       EGC_LAUNCH_CHECK("bwd_dst_kernel");
-    }
-    {  // the arg positions in 8 bits (its own 13 us pass: folded into the destination kernel it cost that kernel 17)
-      const int64_t quads = n * (ldb / 4);
-      if (a.arg8_max != nullptr)
-        arg8_kernel<<<(unsigned)ceil_div(quads, 256), 256, 0, stream>>>(arg_max, a.rowptr, reinterpret_cast<unsigned*>(a.arg8_max), quads,
-                                                                       ldb / 4, (int)graph->n_edges);
-      if (a.arg8_min != nullptr)
-        arg8_kernel<<<(unsigned)ceil_div(quads, 256), 256, 0, stream>>>(arg_min, a.rowptr, reinterpret_cast<unsigned*>(a.arg8_min), quads,
-                                                                       ldb / 4, (int)graph->n_edges);
-      EGC_LAUNCH_CHECK("arg8_kernel");
     }
   }
 

@@ -64,6 +64,7 @@ static inline PlanCaps plan_caps(int64_t n_nodes, int64_t n_edges) {
 
 // egc_backward.hip: CSR positions of the first entries attaining each row's max / min (training forward)
 int arg_extrema(const egc_graph* graph, const egc_layer* layer, const float* bases, int32_t ldb, const float* stats,
-                const int32_t* cnt, int32_t* arg_max, int32_t* arg_min, hipStream_t stream);
+                const int32_t* cnt, int32_t* arg_max, int32_t* arg_min, unsigned* arg8_max, unsigned* arg8_min,
+                hipStream_t stream);
 
 }  // namespace egc
