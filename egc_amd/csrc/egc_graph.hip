@@ -500,7 +500,8 @@ __device__ inline void merge_sort_big(int2* g, int d, int2* lds, int* edge_id_ro
   }
 }
 
-constexpr int ROWS_PER_BLOCK = 64;
+constexpr int ROWS_PER_BLOCK = 64;   // lane groups (of 16) per workgroup
+constexpr int ROWS_PER_GROUP = 2;    // rows per lane group of the short-row pass
 __global__ void __launch_bounds__(16 * ROWS_PER_BLOCK) build_rows_kernel(int n_nodes, int64_t n_edges, const int* __restrict__ rowptr,
                                                                          int* __restrict__ col, int* __restrict__ edge_id,
                                                                          const float* __restrict__ dis_raw,
@@ -512,39 +513,60 @@ __global__ void __launch_bounds__(16 * ROWS_PER_BLOCK) build_rows_kernel(int n_n
   __shared__ int s_ids[ROWS_PER_BLOCK][EGC_LONG_ROW_THRESHOLD];   // input positions of a short row
   __shared__ int2 s_sort[BUILD_LDS_SORT];                           // (input position, source) pairs of a long row
   const int sl = threadIdx.x & 15, rl = threadIdx.x >> 4;
-  const int row = blockIdx.x * ROWS_PER_BLOCK + rl;
-  const bool live = row < n_nodes;
   if (blockIdx.x == 0 && threadIdx.x == 0) {   // the range-check flag leaves the (zero-on-exit) workspace
     *status = *ws_status;
     *ws_status = 0;
   }
-  const int start = live ? rowptr[row] : 0, end = live ? rowptr[row + 1] : 0;
-  const int deg = end - start;
-  const bool is_long = live && deg > EGC_LONG_ROW_THRESHOLD;
-  // ---- short rows: rank sort by input position, 16 lanes per row, up to 4 entries per lane ----
-  int my_id[4], my_col[4];
+  // ---- short rows: rank sort by input position, 16 lanes per row, up to 4 entries per lane; every lane group takes
+  // ROWS_PER_GROUP rows with the loads of all of them issued before the first is ranked (the kernel is a chain of
+  // dependent memory round trips -- row pointers, entries, deg^-1/2 of the sources -- so rows in flight are its speed)
+  int start[ROWS_PER_GROUP], deg[ROWS_PER_GROUP];
+  bool shortrow[ROWS_PER_GROUP];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int p = start + sl + 16 * k;
-    const bool ok = !is_long && p < end;
-    my_id[k] = ok ? edge_id[p] : 0x7fffffff;
-    my_col[k] = ok ? col[p] : 0;
-    if (ok) s_ids[rl][sl + 16 * k] = my_id[k];
+  for (int r = 0; r < ROWS_PER_GROUP; ++r) {
+    const int row = (blockIdx.x * ROWS_PER_BLOCK + rl) * ROWS_PER_GROUP + r;
+    const bool live = row < n_nodes;
+    start[r] = live ? rowptr[row] : 0;
+    deg[r] = (live ? rowptr[row + 1] : 0) - start[r];
+    shortrow[r] = live && deg[r] <= EGC_LONG_ROW_THRESHOLD;
   }
-  __syncthreads();
-  if (!is_long) {
+  int my_id[ROWS_PER_GROUP][4], my_col[ROWS_PER_GROUP][4];
+#pragma unroll
+  for (int r = 0; r < ROWS_PER_GROUP; ++r)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      if (sl + 16 * k < deg) {
-        int rank = 0;
-        for (int t = 0; t < deg; ++t) rank += s_ids[rl][t] < my_id[k];
-        const int p = start + rank;
-        col[p] = my_col[k];
-        edge_id[p] = my_id[k];
-        if (edis_raw != nullptr) edis_raw[p] = dis_raw[my_col[k]];
-        if (edis_looped != nullptr) edis_looped[p] = dis_looped[my_col[k]];
+      const bool ok = shortrow[r] && sl + 16 * k < deg[r];
+      my_id[r][k] = ok ? edge_id[start[r] + sl + 16 * k] : 0x7fffffff;
+      my_col[r][k] = ok ? col[start[r] + sl + 16 * k] : 0;
+    }
+#pragma unroll
+  for (int r = 0; r < ROWS_PER_GROUP; ++r) {
+    if (deg[r] > 16) {   // the row's strip: written and read by the 16 lanes of ONE wavefront, no workgroup barrier
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (shortrow[r] && sl + 16 * k < deg[r]) s_ids[rl][sl + 16 * k] = my_id[r][k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (shortrow[r]) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (sl + 16 * k < deg[r]) {
+          int rank = 0;
+          if (deg[r] <= 16) {   // one entry per lane: compare through the lanes, no LDS round trip
+            for (int t = 0; t < deg[r]; ++t) rank += __shfl(my_id[r][0], (threadIdx.x & 48) + t) < my_id[r][k];
+          } else {
+            for (int t = 0; t < deg[r]; ++t) rank += s_ids[rl][t] < my_id[r][k];
+          }
+          const int p = start[r] + rank;
+          col[p] = my_col[r][k];
+          edge_id[p] = my_id[r][k];
+          if (edis_raw != nullptr) edis_raw[p] = dis_raw[my_col[r][k]];
+          if (edis_looped != nullptr) edis_looped[p] = dis_looped[my_col[r][k]];
+        }
       }
     }
+    __builtin_amdgcn_wave_barrier();   // the strip is reused by the group's next row
   }
   // ---- long rows: registered in the plan by the scan kernel, spread over ALL workgroups by plan slot (hubs often
   // have consecutive ids: a workgroup that sorted the long rows among its own 64 would own every one of them) ----
@@ -794,7 +816,7 @@ int egc_graph_build(const int64_t* src, const int64_t* dst, int64_t n_edges, int
   EGC_LAUNCH_CHECK("build_scan_kernel");
   build_scatter_kernel<<<eblocks, 256, 0, stream>>>(src, dst, n_edges, (int)n_nodes, (int)n_src, deg, rowptr, col, edge_id, bsum, nb);
   EGC_LAUNCH_CHECK("build_scatter_kernel");
-  build_rows_kernel<<<(int)ceil_div(n_nodes, (int64_t)ROWS_PER_BLOCK), 16 * ROWS_PER_BLOCK, 0, stream>>>(
+  build_rows_kernel<<<(int)ceil_div(n_nodes, (int64_t)ROWS_PER_BLOCK * ROWS_PER_GROUP), 16 * ROWS_PER_BLOCK, 0, stream>>>(
       (int)n_nodes, n_edges, rowptr, col, edge_id, dis_raw, dis_looped, edge_dis_raw, edge_dis_looped, plan, (int)c.cap_long,
       (int)c.cap_chunks, big, ws_status, status);
   EGC_LAUNCH_CHECK("build_rows_kernel");
