@@ -97,15 +97,19 @@ __global__ void __launch_bounds__(256) tail_backward_kernel(const float* __restr
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// The GEMM operand of an EGConv layer from its parameters, and the parameter gradients from the operand's gradient.
-//   wcat [F_in][B Ls + W] = [bases_weight with every basis padded from L to Ls columns | comb_weight^T, rows [h][a][b] ->
-//   columns [h][b][a]],  bcat [W] = comb_bias permuted the same way   (W = H B A).
+// The GEMM operand of a layer from its parameters, and the parameter gradients from the operand's gradient.
+//   wcat [F_in][B Ls + W] = [the B basis matrices side by side, each padded from L to Ls columns | comb_weight^T],
+//   bcat [W] = comb_bias   (W = H B A).  The bases come as ONE [F_in][B L] matrix (EGConv.bases_weight) or as B matrices
+//   [F_in][L] (EfficientGraphConv.bases_weight.{0..B-1}); with `permute` the Linear's rows [h][a][b] (EGConv's
+//   comb_weight, optimized_layers.py:195-202) become columns [h][b][a], otherwise the rows are [h][b][a] already.
 // GRAD: the same index map read the other way (wcat / bcat are the gradients, the parameters' gradients are written).
-struct PackDims { int F_in, H, A, B, L, Ls; };
+constexpr int PACK_MAX_PARTS = 32;
+struct PackDims { int F_in, H, A, B, L, Ls, n_parts, permute; };
+struct PackPtrs { float* part[PACK_MAX_PARTS]; };
 template <bool GRAD>
-__global__ void __launch_bounds__(256) egconv_pack_kernel(float* __restrict__ bases_w, float* __restrict__ comb_w,
-                                                          float* __restrict__ comb_b, float* __restrict__ wcat,
-                                                          float* __restrict__ bcat, PackDims d) {
+__global__ void __launch_bounds__(256) weights_pack_kernel(PackPtrs bases, float* __restrict__ comb_w,
+                                                           float* __restrict__ comb_b, float* __restrict__ wcat,
+                                                           float* __restrict__ bcat, PackDims d) {
   const int F_g = d.B * d.Ls, W = d.H * d.B * d.A, cols = F_g + W;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx < (int64_t)d.F_in * cols) {
@@ -113,23 +117,31 @@ __global__ void __launch_bounds__(256) egconv_pack_kernel(float* __restrict__ ba
     if (c < F_g) {
       const int b = c / d.Ls, l = c - b * d.Ls;
       if (l < d.L) {
-        float* p = bases_w + (int64_t)k * d.B * d.L + b * d.L + l;
+        float* p = d.n_parts == 1 ? bases.part[0] + (int64_t)k * d.B * d.L + b * d.L + l
+                                  : bases.part[b] + (int64_t)k * d.L + l;
         if (GRAD) *p = wcat[idx]; else wcat[idx] = *p;
       } else if (!GRAD) {
         wcat[idx] = 0.f;   // padding column of a padded basis
       }
     } else {
       const int j = c - F_g;                       // [h][b][a]
-      const int h = j / (d.B * d.A), r = j - h * d.B * d.A, b = r / d.A, a = r - b * d.A;
-      float* p = comb_w + (int64_t)((h * d.A + a) * d.B + b) * d.F_in + k;
+      int row = j;
+      if (d.permute) {
+        const int h = j / (d.B * d.A), r = j - h * d.B * d.A, b = r / d.A, a = r - b * d.A;
+        row = (h * d.A + a) * d.B + b;
+      }
+      float* p = comb_w + (int64_t)row * d.F_in + k;
       if (GRAD) *p = wcat[idx]; else wcat[idx] = *p;
     }
   }
   if (idx < W && bcat != nullptr && comb_b != nullptr) {
     const int j = (int)idx;
-    const int h = j / (d.B * d.A), r = j - h * d.B * d.A, b = r / d.A, a = r - b * d.A;
-    float* p = comb_b + (h * d.A + a) * d.B + b;
-    if (GRAD) *p = bcat[j]; else bcat[j] = *p;
+    int row = j;
+    if (d.permute) {
+      const int h = j / (d.B * d.A), r = j - h * d.B * d.A, b = r / d.A, a = r - b * d.A;
+      row = (h * d.A + a) * d.B + b;
+    }
+    if (GRAD) comb_b[row] = bcat[j]; else bcat[j] = comb_b[row];
   }
 }
 
@@ -192,22 +204,27 @@ int egc_affine_act_backward_f32(const float* dout, const float* h, const float* 
   return EGC_OK;
 }
 
-int egc_egconv_pack_f32(const float* bases_weight, const float* comb_weight, const float* comb_bias, int32_t f_in,
-                        int32_t num_heads, int32_t num_aggrs, int32_t num_bases, int32_t basis_len, int32_t basis_stride,
-                        float* wcat, float* bcat, int32_t grad, egc_stream_t stream_) {
+int egc_weights_pack_f32(const float* const* bases_parts, int32_t n_parts, const float* comb_weight, const float* comb_bias,
+                         int32_t f_in, int32_t num_heads, int32_t num_aggrs, int32_t num_bases, int32_t basis_len,
+                         int32_t basis_stride, int32_t permute_hab, float* wcat, float* bcat, int32_t grad,
+                         egc_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (f_in <= 0 || num_heads <= 0 || num_aggrs <= 0 || num_bases <= 0 || basis_len <= 0 || basis_stride < basis_len ||
-      bases_weight == nullptr || comb_weight == nullptr || wcat == nullptr)
+      bases_parts == nullptr || comb_weight == nullptr || wcat == nullptr || (n_parts != 1 && n_parts != num_bases))
     return EGC_ERR_INVALID;
-  const PackDims d{f_in, num_heads, num_aggrs, num_bases, basis_len, basis_stride};
+  if (n_parts > PACK_MAX_PARTS) return EGC_ERR_UNSUPPORTED;
+  PackPtrs ptrs;
+  for (int i = 0; i < PACK_MAX_PARTS; ++i) ptrs.part[i] = i < n_parts ? const_cast<float*>(bases_parts[i]) : nullptr;
+  for (int i = 0; i < n_parts; ++i)
+    if (ptrs.part[i] == nullptr) return EGC_ERR_INVALID;
+  const PackDims d{f_in, num_heads, num_aggrs, num_bases, basis_len, basis_stride, n_parts, permute_hab != 0};
   const int64_t total = (int64_t)f_in * (num_bases * basis_stride + num_heads * num_bases * num_aggrs);
   const unsigned grid = (unsigned)ceil_div(total, 256);
-  float* bw = const_cast<float*>(bases_weight);
   float* cw = const_cast<float*>(comb_weight);
   float* cb = const_cast<float*>(comb_bias);
-  if (grad) egconv_pack_kernel<true><<<grid, 256, 0, stream>>>(bw, cw, cb, wcat, bcat, d);
-  else egconv_pack_kernel<false><<<grid, 256, 0, stream>>>(bw, cw, cb, wcat, bcat, d);
-  EGC_LAUNCH_CHECK("egconv_pack_kernel");
+  if (grad) weights_pack_kernel<true><<<grid, 256, 0, stream>>>(ptrs, cw, cb, wcat, bcat, d);
+  else weights_pack_kernel<false><<<grid, 256, 0, stream>>>(ptrs, cw, cb, wcat, bcat, d);
+  EGC_LAUNCH_CHECK("weights_pack_kernel");
   return EGC_OK;
 }
 

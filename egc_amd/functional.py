@@ -51,24 +51,33 @@ def pad_bases_columns(w: torch.Tensor, num_bases: int, basis_len: int, basis_str
     return torch.nn.functional.pad(w.reshape(f_in, num_bases, basis_len), (0, basis_stride - basis_len)).reshape(f_in, -1)
 
 
-class _PackEGConvFunction(torch.autograd.Function):
-    """(wcat, bcat) = the GEMM operand of an EGConv layer from (bases_weight, comb_weight.weight, comb_weight.bias),
-    and the parameters' gradients from (d wcat, d bcat): one launch each way (egc_egconv_pack_f32) instead of the
-    permute / pad / transpose / cat chain and its autograd mirror -- seven launches of 5 us per training step."""
+class _PackWeightsFunction(torch.autograd.Function):
+    """(wcat, bcat) = the GEMM operand of a layer from its parameters, and the parameters' gradients from (d wcat,
+    d bcat): one launch each way (egc_weights_pack_f32) instead of the cat / pad / permute / transpose chain and its
+    autograd mirror -- seven or more launches of 5 us per training step.  Inputs: dims, permute flag, comb weight,
+    comb bias (or None), then the basis matrices (one [F_in, B L] or B of [F_in, L])."""
 
     @staticmethod
-    def forward(ctx, bases_weight, comb_w, comb_b, dims):
+    def forward(ctx, dims, permute, comb_w, comb_b, *bases):
         lib = _C.load()
         f_in, H, A, B, L, Ls = dims
-        dev = bases_weight.device
-        bw, cw, cb = bases_weight.contiguous(), comb_w.contiguous(), comb_b.contiguous()
+        dev = comb_w.device
+        parts = [b.contiguous() for b in bases]
+        cw = comb_w.contiguous()
+        cb = comb_b.contiguous() if comb_b is not None else None
+        ptrs = (C.c_void_p * len(parts))(*[p.data_ptr() for p in parts])
         with _device_guard(dev):
             wcat = torch.empty((f_in, B * Ls + H * B * A), dtype=torch.float32, device=dev)
-            bcat = torch.empty(H * B * A, dtype=torch.float32, device=dev)
-            _C.check(lib.egc_egconv_pack_f32(bw.data_ptr(), cw.data_ptr(), cb.data_ptr(), f_in, H, A, B, L, Ls,
-                                             wcat.data_ptr(), bcat.data_ptr(), 0, _stream_ptr(dev)), "egc_egconv_pack_f32")
-        ctx.dims = dims
-        ctx.shapes = (bases_weight.shape, comb_w.shape, comb_b.shape)
+            bcat = torch.empty(H * B * A, dtype=torch.float32, device=dev) if cb is not None else None
+            _C.check(lib.egc_weights_pack_f32(ptrs, len(parts), cw.data_ptr(), cb.data_ptr() if cb is not None else None,
+                                              f_in, H, A, B, L, Ls, int(permute), wcat.data_ptr(),
+                                              bcat.data_ptr() if bcat is not None else None, 0, _stream_ptr(dev)),
+                     "egc_weights_pack_f32")
+        ctx.dims, ctx.permute, ctx.has_b = dims, permute, cb is not None
+        ctx.shapes = (comb_w.shape, comb_b.shape if comb_b is not None else None, [b.shape for b in bases])
+        if bcat is None:
+            bcat = wcat.new_empty(0)
+            ctx.mark_non_differentiable(bcat)
         return wcat, bcat
 
     @staticmethod
@@ -79,20 +88,32 @@ class _PackEGConvFunction(torch.autograd.Function):
         with _device_guard(dev):
             if dwcat is None:
                 dwcat = torch.zeros((f_in, B * Ls + H * B * A), dtype=torch.float32, device=dev)
-            if dbcat is None:
-                dbcat = torch.zeros(H * B * A, dtype=torch.float32, device=dev)
-            dwcat, dbcat = dwcat.contiguous(), dbcat.contiguous()
-            dbw = torch.empty(ctx.shapes[0], dtype=torch.float32, device=dev)
-            dcw = torch.empty(ctx.shapes[1], dtype=torch.float32, device=dev)
-            dcb = torch.empty(ctx.shapes[2], dtype=torch.float32, device=dev)
-            _C.check(lib.egc_egconv_pack_f32(dbw.data_ptr(), dcw.data_ptr(), dcb.data_ptr(), f_in, H, A, B, L, Ls,
-                                             dwcat.data_ptr(), dbcat.data_ptr(), 1, _stream_ptr(dev)), "egc_egconv_pack_f32")
-        return dbw, dcw, dcb, None
+            dwcat = dwcat.contiguous()
+            dcw = torch.empty(ctx.shapes[0], dtype=torch.float32, device=dev)
+            dcb = dbc = None
+            if ctx.has_b:
+                dbc = (dbcat if dbcat is not None else torch.zeros(H * B * A, dtype=torch.float32, device=dev)).contiguous()
+                dcb = torch.empty(ctx.shapes[1], dtype=torch.float32, device=dev)
+            dparts = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in ctx.shapes[2]]
+            ptrs = (C.c_void_p * len(dparts))(*[p.data_ptr() for p in dparts])
+            _C.check(lib.egc_weights_pack_f32(ptrs, len(dparts), dcw.data_ptr(), dcb.data_ptr() if dcb is not None else None,
+                                              f_in, H, A, B, L, Ls, int(ctx.permute), dwcat.data_ptr(),
+                                              dbc.data_ptr() if dbc is not None else None, 1, _stream_ptr(dev)),
+                     "egc_weights_pack_f32")
+        return (None, None, dcw, dcb, *dparts)
+
+
+def pack_layer_weights(bases, comb_w, comb_b, f_in, H, A, B, L, Ls, permute_hab: bool):
+    """Differentiable (wcat [f_in, B Ls + H B A], bcat [H B A] or None) on the device kernel; ``bases`` is a list of one
+    [f_in, B L] matrix or of B [f_in, L] matrices (float32 CUDA parameters)."""
+    wcat, bcat = _PackWeightsFunction.apply((int(f_in), int(H), int(A), int(B), int(L), int(Ls)), bool(permute_hab),
+                                            comb_w, comb_b, *bases)
+    return wcat, (bcat if comb_b is not None else None)
 
 
 def pack_egconv_weights(bases_weight, comb_w, comb_b, f_in, H, A, B, L, Ls):
-    """Differentiable (wcat [f_in, B Ls + H B A], bcat [H B A]) on the device kernels; float32 CUDA parameters."""
-    return _PackEGConvFunction.apply(bases_weight, comb_w, comb_b, (int(f_in), int(H), int(A), int(B), int(L), int(Ls)))
+    """EGConv: one basis matrix, comb rows [h][a][b] permuted to [h][b][a] (optimized_layers.py:195-202)."""
+    return pack_layer_weights([bases_weight], comb_w, comb_b, f_in, H, A, B, L, Ls, True)
 
 
 def make_spec(in_channels, out_channels, num_heads, num_bases, aggr_codes, agg_set, sym_set, loops_all_nodes,

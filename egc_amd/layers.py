@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import _C
-from .functional import (egc_layer_apply, gemm_exact, make_spec, pack_weights, pad_bases_columns,
+from .functional import (egc_layer_apply, gemm_exact, make_spec, pack_layer_weights, pack_weights, pad_bases_columns,
                          padded_basis_stride)
 from .graph import SparseTensor, graph_from_input
 
@@ -98,6 +98,12 @@ class EfficientGraphConv(nn.Module):
     # [bases_weight.0 | ... | bases_weight.B-1 | comb_weights.weight^T], rebuilt when a parameter changes
     def _cat_weights(self):
         sp = self._spec
+        w = self.comb_weights.weight
+        if torch.is_grad_enabled() and w.is_cuda and w.dtype == torch.float32 and self.num_bases <= 32:
+            # training: one launch each way instead of the differentiable cat / pad / transpose chain below
+            A = w.size(0) // (self.num_heads * self.num_bases)
+            return pack_layer_weights(list(self.bases_weight._parameters.values()), w, None, self.in_channels,
+                                      self.num_heads, A, self.num_bases, sp.basis_len, sp.basis_stride, False)[0]
         bases = pad_bases_columns(torch.cat(list(self.bases_weight), dim=1), self.num_bases, sp.basis_len, sp.basis_stride)
         return torch.cat([bases, self.comb_weights.weight.t()], dim=1)
 

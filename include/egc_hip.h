@@ -313,16 +313,20 @@ int egc_affine_act_backward_f32(const float* dout, const float* h, const float* 
                                 const float* coef_g, const float* coef_h, const float* coef_1, int64_t n_rows, int32_t cols,
                                 float* dh, egc_stream_t stream);
 
-/* The GEMM operand of an EGConv layer from its parameters (grad == 0), or the parameters' gradients from the operand's
- * gradient (grad != 0: the three parameter arrays are WRITTEN, wcat / bcat read) -- one launch instead of the permute /
- * pad / transpose / cat chain (and its autograd mirror) around optimized_layers.py:177-182's two weight matrices:
- *   wcat [f_in][B * basis_stride + H*B*A] = [bases_weight [f_in][B * basis_len], each basis padded to basis_stride columns
- *                                           | comb_weight^T with the Linear's rows [h][a][b] as columns [h][b][a]],
- *   bcat [H*B*A] = comb_bias permuted the same way (bcat / comb_bias may be NULL together).
- * All arrays dense float32. */
-int egc_egconv_pack_f32(const float* bases_weight, const float* comb_weight, const float* comb_bias, int32_t f_in,
-                        int32_t num_heads, int32_t num_aggrs, int32_t num_bases, int32_t basis_len, int32_t basis_stride,
-                        float* wcat, float* bcat, int32_t grad, egc_stream_t stream);
+/* The GEMM operand of a layer from its parameters (grad == 0), or the parameters' gradients from the operand's
+ * gradient (grad != 0: the parameter arrays are WRITTEN, wcat / bcat read) -- one launch instead of the cat / pad /
+ * permute / transpose chain (and its autograd mirror) around the two weight matrices of layers.py:97-111 /
+ * optimized_layers.py:177-182:
+ *   wcat [f_in][B * basis_stride + H*B*A] = [the B basis matrices side by side, each padded from basis_len to basis_stride
+ *                                           columns | comb_weight^T],        bcat [H*B*A] = comb_bias
+ * bases_parts: n_parts = 1 -> one [f_in][B * basis_len] matrix (EGConv.bases_weight); n_parts = B -> B matrices
+ * [f_in][basis_len] (EfficientGraphConv.bases_weight.{0..B-1}); a HOST array of device pointers.  permute_hab != 0: the
+ * Linear's rows are ordered [h][a][b] (EGConv, optimized_layers.py:195-202) and become columns [h][b][a]; 0: they are
+ * [h][b][a] already.  bcat / comb_bias may be NULL together.  All arrays dense float32. */
+int egc_weights_pack_f32(const float* const* bases_parts, int32_t n_parts, const float* comb_weight, const float* comb_bias,
+                         int32_t f_in, int32_t num_heads, int32_t num_aggrs, int32_t num_bases, int32_t basis_len,
+                         int32_t basis_stride, int32_t permute_hab, float* wcat, float* bcat, int32_t grad,
+                         egc_stream_t stream);
 
 /* Column sums of a row-major array with row stride ld (floats), as n_partials partial rows:
  * partials[p, c] = sum of x[r, c] over the p-th block of rows, c < cols; the caller adds the few partial rows up.
