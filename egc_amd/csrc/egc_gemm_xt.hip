@@ -484,13 +484,24 @@ struct XtPlan {
 constexpr int XT_WN = 4;     // wavefronts along the output columns (K): 8 wavefronts per workgroup, one workgroup per CU
 constexpr int XT_STAGE = 32;  // rows of the reduction per LDS stage
 
+// EGC_XT_FP32 (any value) or EGC_GEMM_EXACT=1 (the switch of the forward GEMMs): exact fp32 products on the fp32 MFMA
+// instead of the split-bf16 form
+bool xt_fp32_only() {
+  static const bool v = [] {
+    if (getenv("EGC_XT_FP32") != nullptr) return true;
+    const char* e = getenv("EGC_GEMM_EXACT");
+    return e != nullptr && e[0] != '\0' && !(e[0] == '0' && e[1] == '\0');
+  }();
+  return v;
+}
+
 XtPlan xt_plan(int64_t n_rows, int F, int K) {
   // tile shape: modelled time per row of the reduction = the larger of the MFMA time of the padded tile grid
   // (157 flop/ps) and the operand bytes every output tile re-reads (6 B/ps), plus a quarter of the smaller
   static const int mts[] = {1, 2, 4}, nts[] = {1, 2, 3};
   XtPlan p{};
   double best = 1e300;
-  const bool one_tile = F <= 128 && K <= 192 && getenv("EGC_XT_FP32") == nullptr;   // xt_gemm_bf16x3_kernel
+  const bool one_tile = F <= 128 && K <= 192 && !xt_fp32_only();   // xt_gemm_bf16x3_kernel
   for (int mt : mts)
     for (int nt : nts) {
       const int64_t mtl = ceil_div(F, 32 * mt), ntl = ceil_div(K, 64 * nt);
@@ -558,7 +569,7 @@ int egc_weight_grad_ex_f32(const float* x, int64_t ldx, const float* d, int64_t 
       ((uintptr_t)out % 16) || ((uintptr_t)col_sums % 16) || ((uintptr_t)workspace % 16) || (e_cols % 4) || (lde % 4) ||
       ((uintptr_t)e % 16) || ((uintptr_t)e_sums % 16))
     return EGC_ERR_UNSUPPORTED;
-  static const bool fp32_only = getenv("EGC_XT_FP32") != nullptr;
+  const bool fp32_only = xt_fp32_only();
   const bool one_tile = !fp32_only && f_in <= X3_TM && k_cols <= X3_TN;
   // the third array rides along only in the one-tile kernel, next to the column sums of d, 128 columns at most
   if (e != nullptr && (!one_tile || e_cols > X3_TM || col_sums == nullptr)) return EGC_ERR_UNSUPPORTED;

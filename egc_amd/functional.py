@@ -519,7 +519,7 @@ def _weight_grads(x: torch.Tensor, d: torch.Tensor, col_sums: bool = False, extr
     ride = (extra is not None and col_sums and f <= 128 and k <= 192 and extra.dim() == 2 and extra.size(0) == n
             and extra.size(1) % 4 == 0 and extra.size(1) <= 128 and extra.dtype == torch.float32 and extra.stride(1) == 1
             and extra.stride(0) % 4 == 0 and extra.data_ptr() % 16 == 0 and not gemm_exact()
-            and os.environ.get("EGC_XT_FP32") is None)
+            and os.environ.get("EGC_XT_FP32") is None)   # (the fp32-MFMA form has no third stream)
     with _device_guard(dev):
         out = torch.empty((f, k), dtype=torch.float32, device=dev)
         cs = torch.empty(k, dtype=torch.float32, device=dev) if col_sums else None
