@@ -3,6 +3,10 @@
 // `comb_weights(x)`: experiments/optimized_layers.py:177-178), and in the same pass the column sums of d (the
 // gradient of comb_weights' bias).
 //
+// Two kernels, same decomposition.  Outputs of up to 128 x 192 (the north-star layer): xt_gemm_bf16x3_kernel, split
+// bf16 on the 16-bit matrix cores (further down, with the optional column sums of a third array riding along).  Larger
+// outputs, and EGC_GEMM_EXACT=1 / EGC_XT_FP32: xt_gemm_kernel, exact fp32 on the fp32 matrix cores, described here.
+//
 // The reduction runs over the N rows, the output is tiny (128 x 192 at config 2): a split over row ranges.  Every
 // workgroup keeps one whole output tile (up to 128 x 192) in accumulators, streams its row range through a
 // double-buffered LDS tile of 32 rows (global -> registers -> LDS, the loads of two tiles in flight while one is
