@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(WAVES * 64) basis_gemm_f16x2k_kernel(const flo
                                                                       const float* __restrict__ bcat, int64_t M, int K,
                                                                       KCols c, float* __restrict__ bases,
                                                                       float* __restrict__ weightings, int n_tiles, int LDX,
-                                                                      int R, int slot_bytes) {
+                                                                      int R, int slot_bytes, int tile0) {
   extern __shared__ __attribute__((aligned(16))) char smem_k[];
   char* raw = smem_k;                                                    // [2][slot_bytes] raw fp32 tiles (DMA ring)
   u16* xs = reinterpret_cast<u16*>(smem_k + 2 * slot_bytes);             // [2 buffers][2 planes][KROWS][LDX] fp16
@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(WAVES * 64) basis_gemm_f16x2k_kernel(const flo
   const int nthreads = blockDim.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ct = wave;                                                   // this wavefront's column tile
+  const int ct = tile0 + wave;                                           // this wavefront's column tile (a launch covers tiles tile0 .. tile0 + wavefronts - 1)
   const int j = lane & 15, quad = lane >> 4;
   const int K4 = K >> 2;                                                 // 16-byte pieces per row
   constexpr unsigned GOOB = 0xFFFFFFF0u;
@@ -309,8 +309,9 @@ bool f16x2k_shape(int f_in, int f_g, int ldb, int w_cols) {
   if (getenv("EGC_GEMM_NO_F16X2K") != nullptr) return false;
   if (f_in <= 128 || f_in > 384 || (f_in & 3) != 0) return false;
   const int NT = (ldb + 15) / 16 + (w_cols + 15) / 16;
-  if ((f_in + 31) / 32 == 12 && NT > 12) return false;  // 96 weight registers do not fit four wavefronts per SIMD
-  return NT >= 1 && NT <= 16;
+  const int per_launch = NT <= 16 ? NT : (NT + 1) / 2;   // two launches beyond 16 column tiles
+  if ((f_in + 31) / 32 == 12 && per_launch > 12) return false;  // 96 weight registers do not fit four wavefronts per SIMD
+  return NT >= 1 && NT <= 32;
 }
 
 static KCols kcols(int f_g, int ldb, int w_cols) {
@@ -338,8 +339,8 @@ int f16x2k_pack(const float* wcat, int64_t rs, int64_t cs, int f_in, int f_g, in
 
 template <int KS, int WAVES>
 static int launch_k(const float* x, const u16* packed, const float* bcat, int64_t M, int K, const KCols& c, float* bases,
-                    float* weightings, hipStream_t stream) {
-  const int threads = c.NT * 64;
+                    float* weightings, hipStream_t stream, int tile0, int ntl) {
+  const int threads = ntl * 64;   // this launch: column tiles tile0 .. tile0 + ntl - 1
   const int64_t n_tiles64 = ceil_div(M, KROWS);
   if (n_tiles64 >= ((int64_t)1 << 31)) return EGC_ERR_INVALID;
   const int n_tiles = (int)n_tiles64;
@@ -362,12 +363,12 @@ static int launch_k(const float* x, const u16* packed, const float* bcat, int64_
   // 102 registers).  Short k leaves room for two (F_in = 192, 8 column tiles: 59 KB of LDS each), and the second one's
   // matrix work covers the first one's barrier and split: 66.9 -> 50.1 us for the 192 -> 128 gradient GEMM at
   // N = 169,343 (a third workgroup that does not fit measured 57 us: uneven CUs).
-  int per_cu = (int)std::min<size_t>((size_t)160 * 1024 / lds, (size_t)(20 / c.NT));
+  int per_cu = (int)std::min<size_t>((size_t)160 * 1024 / lds, (size_t)(20 / ntl));
   if (KS > 9 || per_cu < 1) per_cu = 1;
   int grid = 256 * per_cu;
   if (const char* e = getenv("EGC_GEMM_GRID")) grid = atoi(e);
   if (grid > n_tiles) grid = n_tiles;
-  kern<<<grid, threads, lds, stream>>>(x, packed, bcat, M, K, c, bases, weightings, n_tiles, LDX, R, slot_bytes);
+  kern<<<grid, threads, lds, stream>>>(x, packed, bcat, M, K, c, bases, weightings, n_tiles, LDX, R, slot_bytes, tile0);
   EGC_LAUNCH_CHECK("basis_gemm_f16x2k_kernel");
 #ifdef EGC_GEMMK_STAMPS
   {
@@ -388,8 +389,17 @@ static int launch_k(const float* x, const u16* packed, const float* bcat, int64_
 template <int KS>
 static int launch_ks(const float* x, const u16* packed, const float* bcat, int64_t M, int K, const KCols& c, float* bases,
                      float* weightings, hipStream_t stream) {
-  if (c.NT <= 12) return launch_k<KS, 12>(x, packed, bcat, M, K, c, bases, weightings, stream);
-  return launch_k<KS, 16>(x, packed, bcat, M, K, c, bases, weightings, stream);
+  // more than 16 column tiles (e.g. 224/H4/B4 with three aggregators: 14 + 3; 300/H4/B4: 19 + 3; 304/H8/B8: 20 + 4): two
+  // launches over half of the tiles each -- x is read twice, which still beats the LDS-staged bf16x3 kernel 2 x
+  const int launches = c.NT <= 16 ? 1 : 2;
+  for (int l = 0, t0 = 0; l < launches; ++l) {
+    const int ntl = (c.NT - t0 + (launches - l) - 1) / (launches - l);
+    const int st = ntl <= 12 ? launch_k<KS, 12>(x, packed, bcat, M, K, c, bases, weightings, stream, t0, ntl)
+                             : launch_k<KS, 16>(x, packed, bcat, M, K, c, bases, weightings, stream, t0, ntl);
+    if (st != EGC_OK) return st;
+    t0 += ntl;
+  }
+  return EGC_OK;
 }
 
 int f16x2k_launch(const float* x, const void* packed, const float* bcat, int64_t M, int K, int f_g, int ldb, int W,
