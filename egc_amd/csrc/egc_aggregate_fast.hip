@@ -272,6 +272,10 @@ int launch_fast(AggArgs a, int64_t n_nodes, const PlanCaps& caps, hipStream_t st
     EGC_STATIC_CFG(8, 4, 23, 1, agg_pack(Y), EGC_ACT_NONE, false, true, true, 0)            // arxiv EGC-S 184/H8/B4 symadd
     EGC_STATIC_CFG(4, 4, 34, 3, agg_pack(Y, X, M), EGC_ACT_NONE, false, true, true, 0)      // arxiv EGC-M 136/H4/B4
     EGC_STATIC_CFG(8, 4, 21, 1, agg_pack(Y), EGC_ACT_NONE, false, true, true, 0)            // zinc EGC-S 168/H8/B4 symadd
+    EGC_STATIC_CFG(4, 4, 31, 3, agg_pack(S, EGC_AGGR_STD, X), EGC_ACT_NONE, false, true, true, NEED_SQ)  // zinc EGC-M 124/H4/B4 add,std,max
+    EGC_STATIC_CFG(4, 4, 32, 3, agg_pack(Y, EGC_AGGR_STD, X), EGC_ACT_NONE, false, true, true, NEED_SQ)  // cifar EGC-M 128/H4/B4 symadd,std,max
+    EGC_STATIC_CFG(8, 4, 37, 1, agg_pack(Y), EGC_ACT_NONE, false, true, true, 0)            // molhiv EGC-S 296/H8/B4 symadd
+    EGC_STATIC_CFG(4, 4, 56, 3, agg_pack(S, M, X), EGC_ACT_NONE, false, true, true, 0)      // molhiv EGC-M 224/H4/B4 add,mean,max
     // EGConv on ogbn-mag (mag/models.py:24-53; train_main_table.sh:53-54): 352/H8/B4, symnorm or mean
     EGC_STATIC_CFG(8, 4, 44, 1, agg_pack(Y), EGC_ACT_NONE, true, true, true, 0)
     EGC_STATIC_CFG(8, 4, 44, 1, agg_pack(M), EGC_ACT_NONE, true, true, true, 0)
