@@ -582,7 +582,8 @@ def _dx_matmul(d_cat: torch.Tensor, wcat: torch.Tensor) -> torch.Tensor:
     128 us of the fp32 library GEMM at config 2, 44 instead of 79 for an EGC-S layer; same fp32-level accuracy."""
     f_in, k = wcat.size(0), wcat.size(1)
     n = d_cat.size(0)
-    if gemm_exact() or f_in % 4 != 0 or n == 0 or not d_cat.is_cuda or not d_cat.is_contiguous() or d_cat.data_ptr() % 16:
+    if (gemm_exact() or f_in % 4 != 0 or k % 4 != 0 or n == 0 or not d_cat.is_cuda or not d_cat.is_contiguous()
+            or d_cat.data_ptr() % 16):      # (rows of d_cat must be 16-byte aligned for the split-precision kernels)
         return d_cat @ wcat.t()
     lib = _C.load()
     dev = d_cat.device
