@@ -555,7 +555,7 @@ __global__ void __launch_bounds__(256) bwd_dst_fast_kernel(BwdArgs a) {
           if (t < A) dwp[h][t] += __shfl_xor(dwp[h][t], off);
       }
   }
-  const int hpl = H / P;   // heads per lane (host: P divides H)
+  const int hpl = H >= P ? H / P : 1;   // heads per lane (host: P divides H, or H < P: lanes 0 .. H-1 keep one head each)
 #pragma unroll
   for (int h = 0; h < HM; ++h) {
     if (h >= H) break;
@@ -921,9 +921,11 @@ int egc_aggregate_combine_backward_f32(const egc_graph* graph, const egc_graph* 
     const int P = a.Ls / 4;
     const bool fast = getenv("EGC_BWD_GENERIC") == nullptr && (a.Ls & 3) == 0 && a.ldb == a.B * a.Ls && P >= 1 &&
                       (P & (P - 1)) == 0 && (a.B & (a.B - 1)) == 0 && a.slots <= 64 && a.A <= 4 && a.H <= BWD_HMAX &&
-                      a.H % P == 0 && a.act != EGC_ACT_SOFTMAX &&
+                      (a.H % P == 0 || a.H < P) && a.act != EGC_ACT_SOFTMAX &&
                       // only the compiled head / aggregator counts: with run-time counts the LDS kernel is faster
-                      a.slots <= 16 && a.H == 8 && (a.A == 1 || a.A == 3 || a.A == 4);
+                      ((a.slots <= 16 && a.H == 8 && (a.A == 1 || a.A == 3 || a.A == 4)) ||
+                       // zinc EGC-M 124/H4/B4 and CIFAR EGC-M 128/H4/B4: 32 slots, 8 per basis, three aggregators
+                       (a.slots == 32 && a.H == 4 && a.A == 3));
     if (fast) {
       const int lpr = a.slots <= 16 ? 16 : a.slots <= 32 ? 32 : 64;
       const int G = 64 / lpr;
@@ -933,7 +935,8 @@ int egc_aggregate_combine_backward_f32(const egc_graph* graph, const egc_graph* 
       unsigned packed = BWD_STATIC;
       for (int t = 0; t < a.A; ++t) packed |= (unsigned)a.aggr[t] << (3 * t);
       constexpr int S = EGC_AGGR_SUM, M = EGC_AGGR_MEAN, X = EGC_AGGR_MAX, Y = EGC_AGGR_SYMNORM;
-      if (a.A == 4 && a.act == EGC_ACT_NONE && packed == bwd_agg_pack(S, M, X, Y))      // EGConv north star, compiled in
+      if (a.slots == 32) bwd_dst_fast_kernel<5, 4, 3><<<fgrid, 256, flds, stream>>>(a);
+      else if (a.A == 4 && a.act == EGC_ACT_NONE && packed == bwd_agg_pack(S, M, X, Y))      // EGConv north star, compiled in
         bwd_dst_fast_kernel<4, 8, 4, bwd_agg_pack(S, M, X, Y)><<<fgrid, 256, flds, stream>>>(a);
       else if (a.A == 3 && a.act == EGC_ACT_NONE && packed == bwd_agg_pack(Y, X, M))    // EfficientGraphConv EGC-M
         bwd_dst_fast_kernel<4, 8, 3, bwd_agg_pack(Y, X, M)><<<fgrid, 256, flds, stream>>>(a);

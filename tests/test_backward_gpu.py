@@ -286,3 +286,38 @@ def test_d_bases_needs_no_fill_on_square_graphs(generic, monkeypatch):
     short = deg_t <= 64
     assert torch.equal(outs[0][short], outs[1][short])
     assert _rel(outs[1], outs[0]) <= 1e-6
+
+
+@pytest.mark.parametrize("hidden,H,B,aggrs", [
+    (124, 4, 4, ["add", "std", "max"]),        # zinc EGC-M: padded bases (L = 31), 32 slots, H < slots per basis
+    (128, 4, 4, ["symadd", "std", "max"]),     # CIFAR EGC-M
+    (136, 4, 4, ["symadd", "max", "mean"]),    # arxiv EGC-M: 36 slots -> generic destination kernel
+    (168, 8, 4, ["symadd"]),                   # zinc / CIFAR EGC-S
+    (224, 4, 4, ["add", "mean", "max"]),       # molhiv EGC-M
+])
+def test_trained_reference_shapes_gradients(hidden, H, B, aggrs):
+    """Gradients of EfficientGraphConv at the layer shapes of the reference's trained nets (hyperparameters.md) -- the
+    register-resident and the generic backward kernels both occur -- against float64 autograd through the restatement."""
+    import egc_amd
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(hidden)
+    n = 300
+    ei = _graph(rng, n, 2400, hub=170, self_loops=7)
+    torch.manual_seed(hidden)
+    conv = egc_amd.EfficientGraphConv(hidden, hidden, H, B, False, aggrs=aggrs).to(dev)
+    with torch.no_grad():
+        conv.bias.normal_()
+    x = torch.randn(n, hidden, device=dev, requires_grad=True)
+    gout = torch.randn(n, hidden, device=dev)
+    out = conv(x=x, edge_index=torch.from_numpy(ei).to(dev))
+    out.backward(gout)
+    p64 = {k: v.detach().double().cpu().requires_grad_(True) for k, v in conv.named_parameters()}
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    ref = tref.efficient_graph_conv_forward(
+        x64, ei, [p64[f"bases_weight.{b}"] for b in range(B)], p64["comb_weights.weight"], p64["comb_weights.bias"],
+        p64["bias"], H, aggrs)
+    ref.backward(gout.double().cpu())
+    assert _rel(out, ref) <= 1e-5
+    assert _rel(x.grad, x64.grad) <= gtol(aggrs)
+    for k, v in conv.named_parameters():
+        assert _rel(v.grad, p64[k].grad) <= gtol(aggrs), k
