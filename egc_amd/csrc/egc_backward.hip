@@ -433,10 +433,12 @@ __global__ void __launch_bounds__(256) bwd_dst_fast_kernel(BwdArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int g = lane >> LPR_LOG2, q = lane & (LPR - 1);
-  const int P = a.Ls >> 2;                      // lanes per basis (power of two)
+  const int P = a.Ls >> 2;                      // lanes per basis: a power of two (shifts, xor butterfly) or not
+  const bool p2 = (P & (P - 1)) == 0;           // (division, segmented reduction): uniform over the launch
   const int plog = 31 - __builtin_clz(P);
   const bool live = q < a.slots;
-  const int b = min(q >> plog, a.B - 1), l4 = q & (P - 1);
+  const int bq = p2 ? q >> plog : q / P;
+  const int b = min(bq, a.B - 1), l4 = q - bq * P;
   const int row = (blockIdx.x * 4 + wave) * G + g;
   const bool row_ok = row < a.n_nodes;
   const int rr = row_ok ? row : 0;
@@ -448,7 +450,7 @@ __global__ void __launch_bounds__(256) bwd_dst_fast_kernel(BwdArgs a) {
 
   // ---- stage the row's g and w' (LPR lanes, 16 bytes each per step)
   for (int o = 4 * q; o < H * a.Ls; o += 4 * LPR) {
-    const int h = (o >> 2) >> plog, l = o - h * a.Ls;       // 4 consecutive channels of one head (Ls = 4 P)
+    const int h = p2 ? (o >> 2) >> plog : (o >> 2) / P, l = o - h * a.Ls;   // 4 consecutive channels of one head (Ls = 4 P)
     f4 v = f4{0.f, 0.f, 0.f, 0.f};
     const float* gp = a.grad_out + (int64_t)rr * a.F_out + h * a.L + l;
     if (l + 3 < a.L) { v.x = gp[0]; v.y = gp[1]; v.z = gp[2]; v.w = gp[3]; }
@@ -545,21 +547,39 @@ __global__ void __launch_bounds__(256) bwd_dst_fast_kernel(BwdArgs a) {
     if (a.tab_v != nullptr) __builtin_nontemporal_store(two_dv, reinterpret_cast<f4*>(a.tab_v + o));
   }
 
-  // ---- d w': butterfly over the P lanes of a basis, then lane l4 keeps heads [l4 H/P, (l4+1) H/P)
-  for (int off = 1; off < P; off <<= 1) {
+  // ---- d w': sum over the P lanes of a basis.  P a power of two: xor butterfly (every lane ends with the sum), then
+  // lane l4 keeps heads [l4 H/P, (l4+1) H/P); otherwise a segmented shift-down reduction (lane l4 = 0 ends with the
+  // sum) and that lane keeps every head
+  if (p2) {
+    for (int off = 1; off < P; off <<= 1) {
 #pragma unroll
-    for (int h = 0; h < HM; ++h)
-      if (h < H) {
+      for (int h = 0; h < HM; ++h)
+        if (h < H) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-          if (t < A) dwp[h][t] += __shfl_xor(dwp[h][t], off);
-      }
+          for (int t = 0; t < 4; ++t)
+            if (t < A) dwp[h][t] += __shfl_xor(dwp[h][t], off);
+        }
+    }
+  } else {
+    for (int off = 1; off < P; off <<= 1) {
+      const bool take = l4 + off < P;
+#pragma unroll
+      for (int h = 0; h < HM; ++h)
+        if (h < H) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            if (t < A) {
+              const float o = __shfl_down(dwp[h][t], off);
+              dwp[h][t] += take ? o : 0.f;
+            }
+        }
+    }
   }
   const int hpl = H >= P ? H / P : 1;   // heads per lane (host: P divides H, or H < P: lanes 0 .. H-1 keep one head each)
 #pragma unroll
   for (int h = 0; h < HM; ++h) {
     if (h >= H) break;
-    if (!(wr && h / hpl == l4)) continue;
+    if (!(wr && (p2 ? h / hpl == l4 : l4 == 0))) continue;
     const int k0 = (h * a.B + b) * A;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -919,13 +939,17 @@ int egc_aggregate_combine_backward_f32(const egc_graph* graph, const egc_graph* 
   {
     // register-resident form when the layout allows (see bwd_dst_fast_kernel), else the LDS-based kernel
     const int P = a.Ls / 4;
-    const bool fast = getenv("EGC_BWD_GENERIC") == nullptr && (a.Ls & 3) == 0 && a.ldb == a.B * a.Ls && P >= 1 &&
-                      (P & (P - 1)) == 0 && (a.B & (a.B - 1)) == 0 && a.slots <= 64 && a.A <= 4 && a.H <= BWD_HMAX &&
-                      (a.H % P == 0 || a.H < P) && a.act != EGC_ACT_SOFTMAX &&
+    const bool p2 = (P & (P - 1)) == 0;
+    const bool fast = getenv("EGC_BWD_GENERIC") == nullptr && (a.Ls & 3) == 0 && a.ldb == a.B * a.Ls && P >= 1 && P <= 16 &&
+                      (a.B & (a.B - 1)) == 0 && a.slots <= 64 && a.A <= 4 && a.H <= BWD_HMAX &&
+                      (!p2 || a.H % P == 0 || a.H < P) && a.act != EGC_ACT_SOFTMAX &&
                       // only the compiled head / aggregator counts: with run-time counts the LDS kernel is faster
                       ((a.slots <= 16 && a.H == 8 && (a.A == 1 || a.A == 3 || a.A == 4)) ||
-                       // zinc EGC-M 124/H4/B4 and CIFAR EGC-M 128/H4/B4: 32 slots, 8 per basis, three aggregators
-                       (a.slots == 32 && a.H == 4 && a.A == 3));
+                       // the other trained nets of the reference (hyperparameters.md): zinc EGC-M 124/H4/B4, CIFAR EGC-M
+                       // 128/H4/B4 (32 slots); zinc / CIFAR EGC-S 168/H8/B4, arxiv EGC-S 184/H8/B4 (24 slots); arxiv EGC-M
+                       // 136/H4/B4 (36), molhiv EGC-M 224/H4/B4 (56); molhiv EGC-S 296/H8/B4 (40)
+                       (a.slots > 16 && a.slots <= 32 && ((a.H == 4 && a.A == 3) || (a.H == 8 && a.A == 1))) ||
+                       (a.slots > 32 && ((a.H == 4 && a.A == 3) || (a.H == 8 && a.A == 1))));
     if (fast) {
       const int lpr = a.slots <= 16 ? 16 : a.slots <= 32 ? 32 : 64;
       const int G = 64 / lpr;
@@ -935,7 +959,10 @@ int egc_aggregate_combine_backward_f32(const egc_graph* graph, const egc_graph* 
       unsigned packed = BWD_STATIC;
       for (int t = 0; t < a.A; ++t) packed |= (unsigned)a.aggr[t] << (3 * t);
       constexpr int S = EGC_AGGR_SUM, M = EGC_AGGR_MEAN, X = EGC_AGGR_MAX, Y = EGC_AGGR_SYMNORM;
-      if (a.slots == 32) bwd_dst_fast_kernel<5, 4, 3><<<fgrid, 256, flds, stream>>>(a);
+      if (a.slots > 32 && a.H == 4) bwd_dst_fast_kernel<6, 4, 3><<<fgrid, 256, flds, stream>>>(a);
+      else if (a.slots > 32) bwd_dst_fast_kernel<6, 8, 1><<<fgrid, 256, flds, stream>>>(a);
+      else if (a.slots > 16 && a.H == 4) bwd_dst_fast_kernel<5, 4, 3><<<fgrid, 256, flds, stream>>>(a);
+      else if (a.slots > 16) bwd_dst_fast_kernel<5, 8, 1><<<fgrid, 256, flds, stream>>>(a);
       else if (a.A == 4 && a.act == EGC_ACT_NONE && packed == bwd_agg_pack(S, M, X, Y))      // EGConv north star, compiled in
         bwd_dst_fast_kernel<4, 8, 4, bwd_agg_pack(S, M, X, Y)><<<fgrid, 256, flds, stream>>>(a);
       else if (a.A == 3 && a.act == EGC_ACT_NONE && packed == bwd_agg_pack(Y, X, M))    // EfficientGraphConv EGC-M
