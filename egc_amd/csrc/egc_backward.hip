@@ -1003,6 +1003,12 @@ int egc_aggregate_combine_backward_f32(const egc_graph* graph, const egc_graph* 
     bwd_src_kernel<1, SRC_STATIC | SRC_S | SRC_XL | SRC_YL><<<grid, 256, 0, stream>>>(a);
   } else if (ns == 1 && fl == (SRC_STATIC | SRC_T | SRC_X)) {                      // relational EGC: mean+max, raw
     bwd_src_kernel<1, SRC_STATIC | SRC_T | SRC_X><<<grid, 256, 0, stream>>>(a);
+  } else if (ns == 1 && fl == (SRC_STATIC | SRC_T | SRC_V | SRC_X | SRC_YL)) {     // EfficientGraphConv add+std+max (zinc EGC-M)
+    bwd_src_kernel<1, SRC_STATIC | SRC_T | SRC_V | SRC_X | SRC_YL><<<grid, 256, 0, stream>>>(a);
+  } else if (ns == 1 && fl == (SRC_STATIC | SRC_T | SRC_S | SRC_V | SRC_X | SRC_YL)) {  // symadd+std+max (CIFAR EGC-M)
+    bwd_src_kernel<1, SRC_STATIC | SRC_T | SRC_S | SRC_V | SRC_X | SRC_YL><<<grid, 256, 0, stream>>>(a);
+  } else if (ns == 1 && fl == (SRC_STATIC | SRC_T | SRC_X | SRC_YL)) {             // add+mean+max (molhiv EGC-M)
+    bwd_src_kernel<1, SRC_STATIC | SRC_T | SRC_X | SRC_YL><<<grid, 256, 0, stream>>>(a);
   } else
   switch (ns) {
     case 1: bwd_src_kernel<1><<<grid, 256, 0, stream>>>(a); break;
