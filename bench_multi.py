@@ -84,7 +84,8 @@ def run(args, world, rank, local, workload):
             naive_bounds = partition.vertex_ranges(n_global, world)
             q_naive = partition.partition_quality(ei_dev, naive_bounds)
             if reorder:
-                order, new_of_old, bounds = partition.locality_partition(ei_dev, n_global, world)
+                order, new_of_old, bounds = partition.agree_on_partition(
+                    *partition.locality_partition(ei_dev, n_global, world))
                 ei_dev = new_of_old[ei_dev]
                 q = partition.partition_quality(ei_dev, bounds)
             else:
@@ -214,7 +215,8 @@ def run(args, world, rank, local, workload):
     result = {
         "metric": METRIC, "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-        "dtype": "f32", "gemm": "bf16x3-split (6 x v_mfma_f32_32x32x16_bf16 per k-step)" if f_in > 128 else "fp16x2-split",
+        "dtype": "f32", "gemm": ("fp16x2-split, long-k form (egc_gemm_f16x2k.hip; the bf16x3 kernel when an operand leaves fp16's range)"
+                 if f_in > 128 else "fp16x2-split"),
         "data": "synthetic",
         "config": {"workload": desc, "n_nodes_global": n_global, "n_nodes_rank0": n, "e_in_rank0": e_in,
                    "e_eff_total": total_e_eff, "layer": "EGConv",

@@ -165,6 +165,26 @@ def locality_partition(edge_index: torch.Tensor, n_nodes: int, world: int, round
     return order, new_of_old, bounds
 
 
+def agree_on_partition(order: torch.Tensor, new_of_old: torch.Tensor, bounds: List[int], group=None):
+    """Make rank 0's renumbering the one every rank uses (one broadcast of N ids at setup, not on the data path).
+    locality_partition is deterministic for a given input, so this changes nothing when all ranks ran the same
+    software on the same edge list -- it is there because a disagreement would not fail cleanly: ranks with
+    different `bounds` ask each other for rows that do not exist and the all-to-all-v of the layer never matches up."""
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return order, new_of_old, list(bounds)
+    dev = new_of_old.device
+    staged = dev.type == "cuda" and dist.get_backend(group) == "gloo"     # (testing aid, see HaloPlan.exchange_start)
+    noo = new_of_old.cpu() if staged else new_of_old.clone()
+    b = torch.tensor(list(bounds), dtype=torch.int64, device=noo.device)
+    dist.broadcast(noo, src=0, group=group)
+    dist.broadcast(b, src=0, group=group)
+    noo = noo.to(dev)
+    order = torch.empty_like(noo)
+    order[noo] = torch.arange(noo.numel(), device=dev, dtype=noo.dtype)
+    return order, noo, [int(v) for v in b.tolist()]
+
+
 def partition_quality(edge_index: torch.Tensor, bounds: List[int]) -> dict:
     """Halo statistics of a contiguous split with the given boundaries (diagnostics; what bench.py reports)."""
     dev = edge_index.device

@@ -226,3 +226,37 @@ def test_renumbered_partition_gloo_world2():
     ret = mgr.dict()
     mp.spawn(_worker_bounds, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+def _worker_agree(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from egc_amd.workloads import heavy_tailed_graph
+        n = 500
+        ei = heavy_tailed_graph(n, 3000, seed=5, communities=8, p_in=0.7)
+        order, new_of_old, bounds = P.locality_partition(ei, n, world)
+        ref = (order.clone(), new_of_old.clone(), list(bounds))
+        if rank == 1:     # a rank that (for whatever reason) derived something else must end up with rank 0's
+            new_of_old = new_of_old.flip(0).contiguous()
+            order = torch.empty_like(new_of_old)
+            order[new_of_old] = torch.arange(n)
+            bounds = [0, n // 3, n]
+        o2, n2, b2 = P.agree_on_partition(order, new_of_old, bounds)
+        ret[rank] = bool(torch.equal(o2, ref[0]) and torch.equal(n2, ref[1]) and b2 == ref[2])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_ranks_agree_on_rank0s_partition_gloo_world2():
+    """bench.py's multi-GPU setup: whatever a rank computed, the renumbering in use is rank 0's."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_agree, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+    # without a process group it is the identity
+    o, m, b = P.agree_on_partition(torch.arange(4), torch.arange(4), [0, 2, 4])
+    assert b == [0, 2, 4] and torch.equal(o, torch.arange(4))
