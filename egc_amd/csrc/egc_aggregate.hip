@@ -96,15 +96,44 @@ __device__ inline void reduce_groups(const AggArgs& a, Acc<CHUNKS>& acc) {
   }
 }
 
+// Row-only operands of the epilogue, requested BEFORE the row's gather so that their latency (a dependent chain of
+// global loads per one-row wavefront otherwise) hides under it: the row's own basis slots (self-loop term) and its
+// weightings row (W <= 128: two floats per lane; wider rows are read in the epilogue).
+constexpr int ROW_PRE_W = 2;
+template <int CHUNKS>
+struct RowPre {
+  f4 vself[CHUNKS];
+  float w[ROW_PRE_W];
+  bool has_self, has_w;
+};
+template <int CHUNKS>
+__device__ inline void preload_row(const AggArgs& a, __amdgpu_buffer_rsrc_t rsrc, int row, int lane, RowPre<CHUNKS>& pre) {
+  const int q = lane & ((1 << a.lpr_log2) - 1);
+  const int nloop = a.loops_all ? a.n_nodes : (*a.max_index + 1);
+  pre.has_self = row < nloop;
+  const bool want = (a.x_looped || a.y_looped) && pre.has_self;
+#pragma unroll
+  for (int k = 0; k < CHUNKS; ++k) {
+    const int s = k * 64 + q;
+    pre.vself[k] = load_slot(rsrc, (want && s < a.slots) ? (unsigned)row * (unsigned)a.ldb * 4u + (unsigned)s * 16u : OOB);
+  }
+  pre.has_w = a.W <= 64 * ROW_PRE_W;
+  const float* wrow_g = a.weightings + (int64_t)row * a.ldw;
+#pragma unroll
+  for (int i = 0; i < ROW_PRE_W; ++i) {
+    const int k = lane + 64 * i;
+    pre.w[i] = (pre.has_w && k < a.W) ? __builtin_nontemporal_load(wrow_g + k) : 0.f;
+  }
+}
+
 // Self-loop term, aggregator finalisation, weight nonlinearity, combine, bias, store.
 // `acc` must already be merged over lane groups; `deg` / `nself` are the row's entry and self-entry counts.
 template <int CHUNKS>
 __device__ inline void finish_row(const AggArgs& a, __amdgpu_buffer_rsrc_t rsrc, int row, Acc<CHUNKS>& acc, int deg,
-                                  int nself, int lane, float* lds) {
+                                  int nself, int lane, float* lds, const RowPre<CHUNKS>& pre) {
   const int q = lane & ((1 << a.lpr_log2) - 1);
   const int g = lane >> a.lpr_log2;
-  const int nloop = a.loops_all ? a.n_nodes : (*a.max_index + 1);
-  const bool has_self = row < nloop;
+  const bool has_self = pre.has_self;
   int cnt = deg;
   if (a.x_looped) cnt = deg - nself + (has_self ? 1 : 0);
 
@@ -112,11 +141,8 @@ __device__ inline void finish_row(const AggArgs& a, __amdgpu_buffer_rsrc_t rsrc,
     const float dis_i = a.dis != nullptr ? a.dis[row] : 0.f;
     const float wself = dis_i * dis_i;
 #pragma unroll
-    for (int k = 0; k < CHUNKS; ++k) {
-      const int s = k * 64 + q;
-      const f4 v = load_slot(rsrc, s < a.slots ? (unsigned)row * (unsigned)a.ldb * 4u + (unsigned)s * 16u : OOB);
-      fold(acc.sum[k], acc.sq[k], acc.mx[k], acc.mn[k], acc.ws[k], v, a.x_looped != 0, a.y_looped != 0, wself);
-    }
+    for (int k = 0; k < CHUNKS; ++k)
+      fold(acc.sum[k], acc.sq[k], acc.mx[k], acc.mn[k], acc.ws[k], pre.vself[k], a.x_looped != 0, a.y_looped != 0, wself);
   }
 
   float* lds_agg = lds;
@@ -158,12 +184,18 @@ __device__ inline void finish_row(const AggArgs& a, __amdgpu_buffer_rsrc_t rsrc,
     }
   }
   // (2) the node's weightings row, nonlinearity applied, into LDS
-  const float* wrow_g = a.weightings + (int64_t)row * a.ldw;
-  for (int k = lane; k < a.W; k += 64) {
-    float w = wrow_g[k];
+  auto w_act = [&](float w) {
     if (a.act == EGC_ACT_SIGMOID) w = 1.0f / (1.0f + expf(-w));
     else if (a.act == EGC_ACT_HARDTANH) w = fminf(fmaxf(w, -1.0f), 1.0f);
-    lds_w[k] = w;
+    return w;
+  };
+  if (pre.has_w) {
+#pragma unroll
+    for (int i = 0; i < ROW_PRE_W; ++i)
+      if (lane + 64 * i < a.W) lds_w[lane + 64 * i] = w_act(pre.w[i]);
+  } else {
+    const float* wrow_g = a.weightings + (int64_t)row * a.ldw;
+    for (int k = lane; k < a.W; k += 64) lds_w[k] = w_act(wrow_g[k]);
   }
   const int AB = a.A * a.B;
   if (a.act == EGC_ACT_SOFTMAX) {
@@ -186,23 +218,49 @@ __device__ inline void finish_row(const AggArgs& a, __amdgpu_buffer_rsrc_t rsrc,
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
   // (3) combine: out[h*L + l] = sum_{a,b} w[h][a][b] * agg[a][b*L + l] (+ bias)
+  //     Two outputs per lane and four bases per step: sixteen independent LDS reads are in flight before the first
+  //     fmaf needs one (one read per fmaf exposed the LDS latency A * B times per output); every output still adds
+  //     its terms in the order (a, b), so the result does not depend on the grouping.
   float* orow = a.out + (int64_t)row * a.F_out;
-  for (int o = lane; o < a.F_out; o += 64) {
-    const int h = a.L == 1 ? o : (int)__umulhi((unsigned)o, a.magic_L);
-    const int l = o - h * a.L;
-    const float* wh = lds_w + h * AB;
-    const float* ag = lds_agg + l;
-    float z = 0.f;
+  for (int o0 = lane; o0 < a.F_out; o0 += 128) {
+    const bool two = o0 + 64 < a.F_out;
+    const int o1 = two ? o0 + 64 : o0;
+    const int h0 = a.L == 1 ? o0 : (int)__umulhi((unsigned)o0, a.magic_L);
+    const int h1 = a.L == 1 ? o1 : (int)__umulhi((unsigned)o1, a.magic_L);
+    const float* wh0 = lds_w + h0 * AB;
+    const float* wh1 = lds_w + h1 * AB;
+    const float* ag0 = lds_agg + (o0 - h0 * a.L);
+    const float* ag1 = lds_agg + (o1 - h1 * a.L);
+    float z0 = 0.f, z1 = 0.f;
     for (int t = 0; t < a.A; ++t) {
-      const float* agt = ag + t * a.ldb;
-      const float* wt = wh + t * a.sa;
-      for (int b = 0; b < a.B; ++b) z = fmaf(wt[b * a.sb], agt[b * a.Ls], z);
+      const int wo = t * a.sa, ao = t * a.ldb;
+      for (int b0 = 0; b0 < a.B; b0 += 4) {
+        float w0[4], w1[4], v0[4], v1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int b = min(b0 + u, a.B - 1);     // (wave-uniform; the clamped repeats are not added)
+          w0[u] = wh0[wo + b * a.sb];
+          w1[u] = wh1[wo + b * a.sb];
+          v0[u] = ag0[ao + b * a.Ls];
+          v1[u] = ag1[ao + b * a.Ls];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (b0 + u < a.B) {
+            z0 = fmaf(w0[u], v0[u], z0);
+            z1 = fmaf(w1[u], v1[u], z1);
+          }
+      }
     }
-    if (a.bias != nullptr) z += a.bias[o];
-    if (a.post_scale != nullptr) z = fmaf(z, a.post_scale[o], a.post_shift[o]);
-    if (a.post_relu) z = fmaxf(z, 0.f);
-    if (a.residual != nullptr) z += a.residual[(int64_t)row * a.F_out + o];
-    __builtin_nontemporal_store(z, &orow[o]);  // written once, read by a later kernel: keep it out of the L2 write-back at kernel end
+    auto put = [&](int o, float z) {
+      if (a.bias != nullptr) z += a.bias[o];
+      if (a.post_scale != nullptr) z = fmaf(z, a.post_scale[o], a.post_shift[o]);
+      if (a.post_relu) z = fmaxf(z, 0.f);
+      if (a.residual != nullptr) z += a.residual[(int64_t)row * a.F_out + o];
+      __builtin_nontemporal_store(z, &orow[o]);  // written once, read by a later kernel: keep it out of the L2 write-back at kernel end
+    };
+    put(o0, z0);
+    if (two) put(o1, z1);
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
@@ -221,12 +279,14 @@ __global__ void __launch_bounds__(256) agg_rows_kernel(AggArgs a) {
   const int deg = end - start;
   if (deg > EGC_LONG_ROW_THRESHOLD) return;
   const __amdgpu_buffer_rsrc_t rsrc = bases_rsrc(a);
+  RowPre<CHUNKS> pre;
+  preload_row<CHUNKS>(a, rsrc, row, lane, pre);
   Acc<CHUNKS> acc;
   acc.init();
   int nself = 0;
   accumulate_range<CHUNKS, U>(a, rsrc, row, start, end, lane, acc, nself);
   reduce_groups<CHUNKS>(a, acc);
-  finish_row<CHUNKS>(a, rsrc, row, acc, deg, nself, lane, smem + wave * a.lds_floats_per_wave);
+  finish_row<CHUNKS>(a, rsrc, row, acc, deg, nself, lane, smem + wave * a.lds_floats_per_wave, pre);
 }
 
 // One wavefront per long-row chunk -> partial record.
@@ -309,7 +369,9 @@ __global__ void __launch_bounds__(256) agg_merge_kernel(AggArgs a) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) nself += __shfl_xor(nself, off);
   const __amdgpu_buffer_rsrc_t rsrc = bases_rsrc(a);
-  finish_row<CHUNKS>(a, rsrc, row, acc, deg, nself, lane, smem + wave * a.lds_floats_per_wave);
+  RowPre<CHUNKS> pre;
+  preload_row<CHUNKS>(a, rsrc, row, lane, pre);
+  finish_row<CHUNKS>(a, rsrc, row, acc, deg, nself, lane, smem + wave * a.lds_floats_per_wave, pre);
 }
 
 // One wavefront per segment: lanes stride over the columns, rows are summed in order (deterministic).
@@ -397,7 +459,10 @@ static WsLayout ws_layout(const egc_layer* L, int64_t n_nodes, int64_t n_edges, 
 template <int CHUNKS>
 static int launch_all(const AggArgs& a, int64_t n_nodes, const PlanCaps& caps, int wpb, size_t lds_bytes,
                       hipStream_t stream) {
-  constexpr int U = 4;
+  // neighbour rows in flight per lane group.  With two or more slots per lane the staging registers of four rows
+  // cost a wavefront per SIMD (130 VGPRs -> 3 wavefronts; two rows: 4), and these one-row wavefronts are bound by
+  // their chain of dependent memory round trips, i.e. by occupancy: 887 -> 802 us at 300/H4/B4 on the arxiv graph.
+  constexpr int U = CHUNKS == 1 ? 4 : 2;
   const int threads = wpb * 64;
   // long-row chunks first (they are the longest work items), then the per-row kernel, then the merge
   agg_chunks_kernel<CHUNKS, U><<<(unsigned)ceil_div(caps.cap_chunks, 4), 256, 0, stream>>>(a);
