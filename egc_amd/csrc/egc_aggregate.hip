@@ -51,7 +51,8 @@ __device__ inline void accumulate_range(const AggArgs& a, __amdgpu_buffer_rsrc_t
     const int p = base + lane;
     const bool pv = p < end;
     const int jj = pv ? a.col[p] : row;
-    const float dd = a.dis != nullptr ? a.dis[jj] : 0.f;
+    // source-side deg^-1/2: streamed per entry when the graph carries it (one dependent round trip less), else gathered
+    const float dd = a.edis != nullptr ? (pv ? a.edis[p] : 0.f) : (a.dis != nullptr ? a.dis[jj] : 0.f);
     nself += __popcll(__ballot(pv && jj == row));
     const int cnt = min(64, end - base);
     for (int t0 = 0; t0 < cnt; t0 += U * G) {
