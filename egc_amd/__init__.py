@@ -9,6 +9,7 @@ Public surface (mirrors the reference's layer API):
   CSRGraph             device CSR + degree statistics + long-row plan
   egc_layer_forward    operator-level call into libegc_hip.so
   ops                  the same call as torch.library operators (torch.ops.egc_amd.layer_forward / _train / _backward)
+  GraphedStep          a whole training / inference step (graph build included) recorded as one hipGraph
 """
 from .graph import CSRGraph, SparseTensor, GLOBAL_GRAPH_CACHE  # noqa: F401
 from .functional import egc_layer_forward, make_spec, LayerSpec  # noqa: F401
@@ -16,6 +17,7 @@ from .layers import EfficientGraphConv  # noqa: F401
 from .optimized_layers import EGConv  # noqa: F401
 from .relational import REGConv  # noqa: F401
 from .fusion import FusedEGCBlock, global_mean_pool  # noqa: F401
+from .hipgraph import GraphedStep  # noqa: F401
 from . import ops  # noqa: F401  (registers torch.ops.egc_amd.*)
 
 __version__ = "0.1.0"

@@ -255,7 +255,9 @@ class CSRGraph:
             with _device_guard(dev):
                 # destination id of every CSR entry = its row index
                 counts = (self.rowptr[1:] - self.rowptr[:-1]).long()
-                dst = torch.repeat_interleave(torch.arange(n, device=dev), counts)
+                # (output_size: without it repeat_interleave reads the total back to the host -- a synchronisation per
+                #  new graph, and an error inside a hipGraph recording)
+                dst = torch.repeat_interleave(torch.arange(n, device=dev), counts, output_size=e)
                 src = self.col[:e].long()
                 # swap roles: "source" = dst (becomes the entry), "destination" = src (becomes the row)
                 self._transposed = CSRGraph.from_edge_index(torch.stack([dst, src]), ns, max(n, 1))
@@ -365,8 +367,17 @@ class GraphCache:
         self._items: "OrderedDict[tuple, tuple]" = OrderedDict()
 
     def get(self, edge_index: torch.Tensor, num_nodes: int) -> CSRGraph:
+        scope = None
+        if edge_index.is_cuda and torch.cuda.is_current_stream_capturing():
+            # A recording (hipGraph) must CONTAIN the build: a replay reads whatever the edge_index buffer holds then,
+            # so a graph built before the recording would be stale.  Inside egc_amd.GraphedStep the layers of the step
+            # share one recorded build (entries keyed by the recording); a recording made any other way gets a build
+            # per layer call -- slower, never stale.
+            scope = _RECORDING[0]
+            if scope is None:
+                return CSRGraph.from_edge_index(edge_index, num_nodes)
         key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), int(num_nodes),
-               edge_index.device)
+               edge_index.device, scope)
         hit = self._items.get(key)
         if hit is not None and hit[0] is edge_index:
             self._items.move_to_end(key)
@@ -380,8 +391,28 @@ class GraphCache:
     def clear(self):
         self._items.clear()
 
+    def drop_recording(self, scope):
+        """Forget the graphs built inside a finished recording (their buffers belong to its memory pool)."""
+        for key in [k for k in self._items if k[-1] is scope]:
+            del self._items[key]
 
+
+_RECORDING = [None]     # the recording in progress (egc_amd.hipgraph.GraphedStep), or None
 GLOBAL_GRAPH_CACHE = GraphCache()
+
+
+class recording_scope:
+    """Marks the hipGraph recording in progress for the graph cache (used by egc_amd.hipgraph.GraphedStep)."""
+
+    def __enter__(self):
+        self._token = object()
+        self._outer, _RECORDING[0] = _RECORDING[0], self._token
+        return self
+
+    def __exit__(self, *exc):
+        _RECORDING[0] = self._outer
+        GLOBAL_GRAPH_CACHE.drop_recording(self._token)
+        return False
 
 
 def graph_from_input(edge_index, num_nodes: int) -> CSRGraph:

@@ -1,0 +1,134 @@
+"""A training step of a stack of EGC blocks recorded as one hipGraph (egc_amd.GraphedStep) reproduces the eager step:
+nothing on the library's training path allocates outside torch's allocator, reads back to the host or depends on
+state a replay would not restore (workspaces are zero on exit; the per-batch graph build is stream-ordered)."""
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+
+def _blocks(dev, kind, n_blocks=2, hidden=64):
+    import egc_amd
+    from egc_amd.fusion import FusedEGCBlock
+    torch.manual_seed(0)
+    def conv():
+        if kind == "opt":
+            return egc_amd.EGConv(hidden, hidden, aggrs=["sum", "max", "symnorm"], num_heads=4, num_bases=4)
+        return egc_amd.EfficientGraphConv(hidden, hidden, 4, 4, False, aggrs=["add", "std", "max"])
+    return nn.ModuleList([FusedEGCBlock(conv(), nn.BatchNorm1d(hidden)) for _ in range(n_blocks)]).to(dev).train()
+
+
+def _grads(params):
+    return [p.grad.detach().clone() for p in params]
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("kind", ["opt", "lay"])
+def test_recorded_training_step_equals_the_eager_step(kind):
+    import egc_amd
+    from egc_amd import workloads as wl
+    dev = torch.device("cuda:0")
+    _, ei, n, _ = wl.zinc_like_batch(64, seed=3)
+    ei = ei.to(dev)
+    blocks = _blocks(dev, kind)
+    params = list(blocks.parameters())
+    graph = egc_amd.CSRGraph.from_edge_index(ei, n).trim_launches()
+    x = torch.randn(n, 64, device=dev)
+    gout = torch.randn(n, 64, device=dev)
+    stats0 = [b.bn.running_mean.clone() for b in blocks]
+
+    def step():
+        h = x
+        for b in blocks:
+            h = b(h, graph)
+        h.backward(gout)
+
+    def eager():
+        for p in params:
+            p.grad = None
+        step()
+        return _grads(params)
+
+    graphed = egc_amd.GraphedStep(step, params=params)
+    for trial in range(3):
+        x.copy_(torch.randn(n, 64, device=dev))          # new contents of the static buffers
+        gout.copy_(torch.randn(n, 64, device=dev))
+        graphed()
+        got = _grads(params)
+        held = [p.grad for p in params]
+        ref = eager()
+        for p, h in zip(params, held):                    # give the recording its gradient buffers back
+            p.grad = h
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b), (kind, trial, _rel(a, b))
+    # the recorded BatchNorm updated its running statistics at every replay, as the eager module does
+    assert all(not torch.equal(b.bn.running_mean, s) for b, s in zip(blocks, stats0))
+
+
+@pytest.mark.parametrize("helper", [True, False])
+def test_per_batch_graph_build_inside_the_recording(helper):
+    """COO in: the CSR build (egc_graph_build) is part of the recorded step, so a replay rebuilds the graph from whatever
+    the static edge_index buffer holds -- batches of the same padded size go through one recording.  The graph cache
+    must not hand a recording a graph built before it (stale at the first replay): inside GraphedStep the layers share
+    one recorded build, a plain torch.cuda.graph recording gets one build per layer call."""
+    import egc_amd
+    from egc_amd import workloads as wl
+    dev = torch.device("cuda:0")
+    batches = []
+    for seed in range(3):
+        _, ei, n, _ = wl.zinc_like_batch(48, seed=seed)
+        batches.append((ei, n))
+    n_pad = max(n for _, n in batches) + 1
+    e_pad = max(ei.size(1) for ei, _ in batches)
+
+    def padded(ei):     # pad with self-loops on a spare last node (isolated from every real graph)
+        extra = e_pad - ei.size(1)
+        return torch.cat([ei, torch.full((2, extra), n_pad - 1, dtype=ei.dtype)], dim=1).to(dev)
+
+    blocks = _blocks(dev, "opt")
+    params = list(blocks.parameters())
+    edge_index = padded(batches[0][0]).clone()
+    x = torch.randn(n_pad, 64, device=dev)
+    gout = torch.randn(n_pad, 64, device=dev)
+
+    def step():
+        h = x
+        for b in blocks:
+            h = b(h, edge_index)
+        h.backward(gout)
+
+    if helper:
+        graphed = egc_amd.GraphedStep(step, params=params)
+    else:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                for p in params:
+                    p.grad = None
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        for p in params:
+            p.grad = None
+        cg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(cg):
+            step()
+        graphed = cg.replay
+    for ei, _ in batches[1:] + batches[:1]:
+        edge_index.copy_(padded(ei))
+        x.copy_(torch.randn(n_pad, 64, device=dev))
+        graphed()
+        got = _grads(params)
+        held = [p.grad for p in params]
+        for p in params:
+            p.grad = None
+        step()
+        ref = _grads(params)
+        for p, h in zip(params, held):
+            p.grad = h
+        for a, b in zip(got, ref):
+            assert _rel(a, b) <= 1e-6
