@@ -61,6 +61,77 @@ __global__ void __launch_bounds__(256) column_moments_kernel(const float* __rest
   }
 }
 
+// Column totals of the partial moments: 16 columns x 16 partial lanes per workgroup, each lane adding its partials in
+// index order, the 16 lanes of a column then added in lane order (a fixed order: the result does not depend on timing).
+__device__ inline void moment_totals(const double* __restrict__ partials, int n_partials, int cols, int col, int pl,
+                                     double (&red)[2][16][17], double& t1, double& t2) {
+  double s1 = 0.0, s2 = 0.0;
+  if (col < cols)
+    for (int p = pl; p < n_partials; p += 16) {
+      s1 += partials[(int64_t)p * 2 * cols + col];
+      s2 += partials[(int64_t)p * 2 * cols + cols + col];
+    }
+  red[0][threadIdx.x & 15][pl] = s1;
+  red[1][threadIdx.x & 15][pl] = s2;
+  __syncthreads();
+  t1 = t2 = 0.0;
+  if (pl == 0)
+    for (int k = 0; k < 16; ++k) { t1 += red[0][threadIdx.x & 15][k]; t2 += red[1][threadIdx.x & 15][k]; }
+}
+
+// Everything between the statistics pass and the elementwise pass of the training-mode BatchNorm tail, per column:
+// batch mean / biased variance / 1/std (float64), the affine pair the elementwise kernel applies, and the running
+// statistics of the module (nn.BatchNorm1d: unbiased variance, momentum or -- momentum < 0 -- the cumulative average
+// 1 / *n_tracked, the count already incremented by the caller).  Was ~20 five-microsecond torch kernels per layer.
+__global__ void __launch_bounds__(256) bn_forward_finalize_kernel(const double* __restrict__ partials, int n_partials, int cols,
+                                                                  double n_rows, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, double eps,
+                                                                  double* __restrict__ stats, float* __restrict__ affine,
+                                                                  float* __restrict__ running_mean,
+                                                                  float* __restrict__ running_var, double momentum,
+                                                                  const int64_t* __restrict__ n_tracked) {
+  __shared__ double red[2][16][17];
+  const int col = blockIdx.x * 16 + (threadIdx.x & 15), pl = threadIdx.x >> 4;
+  double s1, s2;
+  moment_totals(partials, n_partials, cols, col, pl, red, s1, s2);
+  if (pl != 0 || col >= cols) return;
+  const double mean = s1 / n_rows;
+  double var = s2 / n_rows - mean * mean;
+  var = var > 0.0 ? var : 0.0;
+  const double rstd = 1.0 / sqrt(var + eps);
+  const double g = gamma != nullptr ? (double)gamma[col] : 1.0, b = beta != nullptr ? (double)beta[col] : 0.0;
+  stats[col] = mean;
+  stats[cols + col] = var;
+  stats[2 * cols + col] = rstd;
+  affine[col] = (float)(g * rstd);
+  affine[cols + col] = (float)(b - mean * g * rstd);
+  if (running_mean != nullptr) {
+    const double m = momentum >= 0.0 ? momentum : 1.0 / (double)(*n_tracked);
+    running_mean[col] = (float)((1.0 - m) * (double)running_mean[col] + m * mean);
+    running_var[col] = (float)((1.0 - m) * (double)running_var[col] + m * var * (n_rows / (n_rows - 1.0)));
+  }
+}
+
+// Backward counterpart: from the partial sums (sum g, sum g h) of the masked upstream gradient, the gradients of the
+// affine parameters and the three per-column coefficients of dh = c_g g + c_h h + c_1.
+__global__ void __launch_bounds__(256) bn_backward_finalize_kernel(const double* __restrict__ partials, int n_partials, int cols,
+                                                                   double n_rows, const double* __restrict__ stats,
+                                                                   const float* __restrict__ gamma, float* __restrict__ outv) {
+  __shared__ double red[2][16][17];
+  const int col = blockIdx.x * 16 + (threadIdx.x & 15), pl = threadIdx.x >> 4;
+  double s1, sgh;
+  moment_totals(partials, n_partials, cols, col, pl, red, s1, sgh);
+  if (pl != 0 || col >= cols) return;
+  const double mean = stats[col], rstd = stats[2 * cols + col];
+  const double s2 = (sgh - mean * s1) * rstd;                 // sum g * h_hat
+  const double a = (gamma != nullptr ? (double)gamma[col] : 1.0) * rstd;
+  outv[col] = (float)s2;                                      // d gamma
+  outv[cols + col] = (float)s1;                               // d beta
+  outv[2 * cols + col] = (float)a;                            // dh = a g - (a / n) (s1 + (h - mean) rstd s2)
+  outv[3 * cols + col] = (float)(-(a / n_rows) * rstd * s2);
+  outv[4 * cols + col] = (float)(-(a / n_rows) * (s1 - mean * rstd * s2));
+}
+
 // out = act(h * scale + shift) + residual, 16 bytes per thread
 __global__ void __launch_bounds__(256) affine_act_residual_kernel(const float* __restrict__ h, const float* __restrict__ scale,
                                                                   const float* __restrict__ shift,
@@ -168,6 +239,33 @@ int egc_column_moments_f64(const float* a, const float* b, const float* scale, c
   else
     column_moments_kernel<false><<<(unsigned)n_partials, 256, 0, stream>>>(a, nullptr, nullptr, nullptr, n_rows, cols, rows_per_block, partials);
   EGC_LAUNCH_CHECK("column_moments_kernel");
+  return EGC_OK;
+}
+
+int egc_bn_forward_finalize(const double* partials, int32_t n_partials, int32_t cols, int64_t n_rows, const float* gamma,
+                            const float* beta, double eps, double* stats, float* affine, float* running_mean,
+                            float* running_var, double momentum, const int64_t* n_tracked, egc_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (partials == nullptr || n_partials <= 0 || cols <= 0 || n_rows <= 0 || stats == nullptr || affine == nullptr)
+    return EGC_ERR_INVALID;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return EGC_ERR_INVALID;
+  if (running_mean != nullptr && momentum < 0.0 && n_tracked == nullptr) return EGC_ERR_INVALID;
+  if (running_mean != nullptr && n_rows < 2) return EGC_ERR_INVALID;   // (nn.BatchNorm1d raises on one row in training mode)
+  bn_forward_finalize_kernel<<<(unsigned)ceil_div(cols, 16), 256, 0, stream>>>(partials, n_partials, cols, (double)n_rows, gamma,
+                                                                             beta, eps, stats, affine, running_mean,
+                                                                             running_var, momentum, n_tracked);
+  EGC_LAUNCH_CHECK("bn_forward_finalize_kernel");
+  return EGC_OK;
+}
+
+int egc_bn_backward_finalize(const double* partials, int32_t n_partials, int32_t cols, int64_t n_rows, const double* stats,
+                             const float* gamma, float* out5, egc_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (partials == nullptr || n_partials <= 0 || cols <= 0 || n_rows <= 0 || stats == nullptr || out5 == nullptr)
+    return EGC_ERR_INVALID;
+  bn_backward_finalize_kernel<<<(unsigned)ceil_div(cols, 16), 256, 0, stream>>>(partials, n_partials, cols, (double)n_rows, stats,
+                                                                              gamma, out5);
+  EGC_LAUNCH_CHECK("bn_backward_finalize_kernel");
   return EGC_OK;
 }
 

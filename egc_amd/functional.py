@@ -708,9 +708,10 @@ class _AggregateCombineFunction(torch.autograd.Function):
         return d_bases, d_w, dbias, None, None
 
 
-def _column_moments(a: torch.Tensor, b=None, scale=None, shift=None):
-    """(sum_r g, sum_r g * b) per column in float64 through egc_column_moments_f64; b is None: g = a and the second
-    sum is the second moment of a; else g = a * [b * scale + shift > 0]."""
+def _moment_partials(a: torch.Tensor, b=None, scale=None, shift=None) -> torch.Tensor:
+    """[parts][2][C] float64 partial sums (sum_r g, sum_r g * b) over row blocks through egc_column_moments_f64; b is None:
+    g = a and the second sum is the second moment of a; else g = a * [b * scale + shift > 0].  The blocks are added by
+    the finalize kernels (egc_bn_forward_finalize / egc_bn_backward_finalize)."""
     lib = _C.load()
     n, c = a.shape
     dev = a.device
@@ -721,71 +722,82 @@ def _column_moments(a: torch.Tensor, b=None, scale=None, shift=None):
                                             scale.data_ptr() if scale is not None else None,
                                             shift.data_ptr() if shift is not None else None, n, c, out.data_ptr(), parts,
                                             _stream_ptr(dev)), "egc_column_moments_f64")
-    m = out.sum(0)
-    return m[0], m[1]
+    return out
+
+
+def _f32_vec(t, c):
+    """A [C] parameter / buffer the finalize kernels may read in place (float32, dense), else None."""
+    return t is not None and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == c
 
 
 class _BatchNormActResidualFunction(torch.autograd.Function):
     """out = act(batch_norm(h; batch statistics) * gamma + beta) + residual -- the training-mode tail of the
-    reference's blocks (zinc/models.py:66-72) in two streaming passes each way (egc_tail.hip).  Returns
-    (out, batch mean, biased batch variance); the running statistics are the caller's."""
+    reference's blocks (zinc/models.py:66-72) in two streaming passes each way plus ONE per-channel launch between them
+    (egc_tail.hip), which also updates the module's running statistics when they are passed.  Returns
+    (out, batch mean, biased batch variance), both float64."""
 
     @staticmethod
-    def forward(ctx, h, residual, gamma, beta, eps, relu):
+    def forward(ctx, h, residual, gamma, beta, eps, relu, running_mean, running_var, momentum, n_tracked):
         lib = _C.load()
         n, c = h.shape
         dev = h.device
         h = h.contiguous()
-        s1, s2 = _column_moments(h)
-        mean = s1 / n
-        var = (s2 / n - mean * mean).clamp_(min=0.0)            # biased, float64
-        rstd = torch.rsqrt(var + eps)
-        g64 = gamma.double() if gamma is not None else torch.ones(c, dtype=torch.float64, device=dev)
-        b64 = beta.double() if beta is not None else torch.zeros(c, dtype=torch.float64, device=dev)
-        scale = (g64 * rstd).float()
-        shift = (b64 - mean * g64 * rstd).float()
+        gamma_c = gamma.detach().contiguous().float() if gamma is not None else None
+        beta_c = beta.detach().contiguous().float() if beta is not None else None
+        parts = _moment_partials(h)
         res = residual.contiguous() if residual is not None else None
         with _device_guard(dev):
+            stats = torch.empty((3, c), dtype=torch.float64, device=dev)     # mean | biased variance | 1 / std
+            affine = torch.empty((2, c), dtype=torch.float32, device=dev)    # scale | shift
             out = torch.empty_like(h)
-            _C.check(lib.egc_affine_act_residual_f32(h.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+            stream = _stream_ptr(dev)
+            _C.check(lib.egc_bn_forward_finalize(
+                parts.data_ptr(), parts.size(0), c, n, gamma_c.data_ptr() if gamma_c is not None else None,
+                beta_c.data_ptr() if beta_c is not None else None, float(eps), stats.data_ptr(), affine.data_ptr(),
+                running_mean.data_ptr() if running_mean is not None else None,
+                running_var.data_ptr() if running_var is not None else None,
+                -1.0 if momentum is None else float(momentum),
+                n_tracked.data_ptr() if n_tracked is not None else None, stream), "egc_bn_forward_finalize")
+            _C.check(lib.egc_affine_act_residual_f32(h.data_ptr(), affine[0].data_ptr(), affine[1].data_ptr(),
                                                      res.data_ptr() if res is not None else None, int(relu), n, c,
-                                                     out.data_ptr(), _stream_ptr(dev)), "egc_affine_act_residual_f32")
-        ctx.save_for_backward(h, scale, shift, mean, rstd, gamma)
+                                                     out.data_ptr(), stream), "egc_affine_act_residual_f32")
+        ctx.save_for_backward(h, affine, stats, gamma_c)
         ctx.relu, ctx.has_res, ctx.has_gamma, ctx.has_beta = bool(relu), residual is not None, gamma is not None, beta is not None
+        mean, var = stats[0], stats[1]
         ctx.mark_non_differentiable(mean, var)
         return out, mean, var
 
     @staticmethod
     def backward(ctx, dout, _dmean, _dvar):
         lib = _C.load()
-        h, scale, shift, mean, rstd, gamma = ctx.saved_tensors
+        h, affine, stats, gamma_c = ctx.saved_tensors
         n, c = h.shape
         dev = h.device
         dout = dout.contiguous()
         dh = dgamma = dbeta = None
         if ctx.needs_input_grad[0] or (ctx.has_gamma and ctx.needs_input_grad[2]) or (ctx.has_beta and ctx.needs_input_grad[3]):
             if ctx.relu:
-                s1, sgh = _column_moments(dout, h, scale, shift)       # sum g, sum g h   (g = dout * relu mask)
+                parts = _moment_partials(dout, h, affine[0], affine[1])  # sum g, sum g h   (g = dout * relu mask)
             else:
                 s1 = _column_sums(dout).double()
                 sgh = (dout.double() * h.double()).sum(0) if n else torch.zeros(c, dtype=torch.float64, device=dev)
-            s2 = (sgh - mean * s1) * rstd                               # sum g * h_hat
-            dgamma = s2.float() if ctx.has_gamma and ctx.needs_input_grad[2] else None
-            dbeta = s1.float() if ctx.has_beta and ctx.needs_input_grad[3] else None
-            if ctx.needs_input_grad[0]:
-                g64 = gamma.double() if gamma is not None else torch.ones(c, dtype=torch.float64, device=dev)
-                a = g64 * rstd                                          # dh = a g - (a / n) (s1 + (h - mean) rstd s2)
-                coef_g = a.float()
-                coef_h = (-(a / n) * rstd * s2).float()
-                coef_1 = (-(a / n) * (s1 - mean * rstd * s2)).float()
-                with _device_guard(dev):
+                parts = torch.stack([s1, sgh]).unsqueeze(0).contiguous()
+            with _device_guard(dev):
+                out5 = torch.empty((5, c), dtype=torch.float32, device=dev)   # d gamma | d beta | coef_g | coef_h | coef_1
+                stream = _stream_ptr(dev)
+                _C.check(lib.egc_bn_backward_finalize(parts.data_ptr(), parts.size(0), c, n, stats.data_ptr(),
+                                                      gamma_c.data_ptr() if gamma_c is not None else None, out5.data_ptr(),
+                                                      stream), "egc_bn_backward_finalize")
+                dgamma = out5[0] if ctx.has_gamma and ctx.needs_input_grad[2] else None
+                dbeta = out5[1] if ctx.has_beta and ctx.needs_input_grad[3] else None
+                if ctx.needs_input_grad[0]:
                     dh = torch.empty_like(h)
-                    _C.check(lib.egc_affine_act_backward_f32(dout.data_ptr(), h.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                                                             int(ctx.relu), coef_g.data_ptr(), coef_h.data_ptr(),
-                                                             coef_1.data_ptr(), n, c, dh.data_ptr(), _stream_ptr(dev)),
-                             "egc_affine_act_backward_f32")
+                    _C.check(lib.egc_affine_act_backward_f32(dout.data_ptr(), h.data_ptr(), affine[0].data_ptr(),
+                                                             affine[1].data_ptr(), int(ctx.relu), out5[2].data_ptr(),
+                                                             out5[3].data_ptr(), out5[4].data_ptr(), n, c, dh.data_ptr(),
+                                                             stream), "egc_affine_act_backward_f32")
         dres = dout if ctx.has_res and ctx.needs_input_grad[1] else None
-        return dh, dres, dgamma, dbeta, None, None
+        return dh, dres, dgamma, dbeta, None, None, None, None, None, None
 
 
 def batch_norm_act_residual_supported(h: torch.Tensor) -> bool:
@@ -793,10 +805,19 @@ def batch_norm_act_residual_supported(h: torch.Tensor) -> bool:
             and h.size(1) <= 1024)
 
 
-def batch_norm_act_residual(h, residual, gamma, beta, eps: float, relu: bool):
+def batch_norm_act_residual(h, residual, gamma, beta, eps: float, relu: bool, running_mean=None, running_var=None,
+                            momentum=None, num_batches_tracked=None):
     """Training-mode BatchNorm1d (batch statistics) -> optional ReLU -> optional residual add, fused
-    (_BatchNormActResidualFunction): returns (out, batch mean [C] float64, biased batch variance [C] float64)."""
-    return _BatchNormActResidualFunction.apply(h, residual, gamma, beta, float(eps), bool(relu))
+    (_BatchNormActResidualFunction): returns (out, batch mean [C] float64, biased batch variance [C] float64).
+    With ``running_mean`` / ``running_var`` (float32 [C], dense) the running statistics are updated in the same launch
+    that finishes the batch statistics, as nn.BatchNorm1d does: unbiased variance, ``momentum``, or -- momentum None --
+    the cumulative average over ``num_batches_tracked`` (a device int64 scalar the CALLER has already incremented)."""
+    c = h.size(1)
+    if running_mean is not None and not (_f32_vec(running_mean, c) and _f32_vec(running_var, c)
+                                         and (momentum is not None or num_batches_tracked is not None)):
+        raise RuntimeError("egc_amd: running statistics must be dense float32 [C] tensors")
+    return _BatchNormActResidualFunction.apply(h, residual, gamma, beta, float(eps), bool(relu), running_mean, running_var,
+                                               momentum, num_batches_tracked)
 
 
 def egc_aggregate_combine_apply(graph, spec, bases, weightings, bias=None):

@@ -45,12 +45,19 @@ class FusedEGCBlock(nn.Module):
             h = bn(h)
             h = torch.relu(h) if self.relu else h
             return x + h if self.residual else h
-        out, mean, var = batch_norm_act_residual(h, x if self.residual else None, bn.weight if bn.affine else None,
-                                                 bn.bias if bn.affine else None, bn.eps, self.relu)
-        if bn.training and bn.track_running_stats:
+        track = bn.training and bn.track_running_stats
+        in_place = (track and bn.running_mean.dtype == torch.float32 and bn.running_mean.is_contiguous()
+                    and bn.running_var.dtype == torch.float32 and bn.running_var.is_contiguous())
+        if track:
+            with torch.no_grad():
+                bn.num_batches_tracked += 1      # (a device scalar: the kernel reads it, nothing comes back to the host)
+        out, mean, var = batch_norm_act_residual(
+            h, x if self.residual else None, bn.weight if bn.affine else None, bn.bias if bn.affine else None, bn.eps,
+            self.relu, bn.running_mean if in_place else None, bn.running_var if in_place else None, bn.momentum,
+            bn.num_batches_tracked if in_place else None)
+        if track and not in_place:               # running statistics kept in another dtype: torch's arithmetic
             with torch.no_grad():
                 n = h.size(0)
-                bn.num_batches_tracked += 1
                 m = 1.0 / float(bn.num_batches_tracked) if bn.momentum is None else bn.momentum
                 bn.running_mean.mul_(1 - m).add_(mean.to(bn.running_mean.dtype), alpha=m)
                 bn.running_var.mul_(1 - m).add_((var * (n / (n - 1))).to(bn.running_var.dtype), alpha=m)

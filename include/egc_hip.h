@@ -301,12 +301,25 @@ int egc_weight_grad_f32(const float* x, int64_t ldx, const float* d, int64_t ldd
  *                               mean and variance of h).  b != NULL: g = a * [b * scale + shift > 0] (backward: a =
  *                               dout, b = h; the ReLU mask is recomputed from h, not stored), giving the two sums of
  *                               the BatchNorm backward.  partials: n_partials * 2 * cols doubles, 32-byte aligned.
+ *   egc_bn_forward_finalize     everything per channel between the two forward passes, in one launch: the partials
+ *                               added in a fixed order, stats = [mean | biased variance | 1/sqrt(var + eps)] (3 * cols
+ *                               doubles), affine = [scale | shift] (2 * cols floats) for the elementwise pass, and --
+ *                               running_mean != NULL -- the module's running statistics as nn.BatchNorm1d updates them
+ *                               (unbiased variance; momentum >= 0, or momentum < 0: the cumulative average 1 /
+ *                               *n_tracked with the count already incremented by the caller).  gamma / beta may be NULL.
+ *   egc_bn_backward_finalize    the same between the two backward passes: out5 = [d gamma | d beta | coef_g | coef_h |
+ *                               coef_1] (5 * cols floats) from the partial sums of the masked gradient and `stats`.
  *   egc_affine_act_residual_f32 out = act(h * scale + shift) + residual   (scale = gamma * rstd, shift = beta - mean *
  *                               scale; relu != 0: act = max(., 0); residual may be NULL)
  *   egc_affine_act_backward_f32 dh = coef_g * g + coef_h * h + coef_1 per channel, g as above: the BatchNorm backward
  *                               with its two sums folded into the three per-channel coefficient vectors. */
 int egc_column_moments_f64(const float* a, const float* b, const float* scale, const float* shift, int64_t n_rows,
                            int32_t cols, double* partials, int32_t n_partials, egc_stream_t stream);
+int egc_bn_forward_finalize(const double* partials, int32_t n_partials, int32_t cols, int64_t n_rows, const float* gamma,
+                            const float* beta, double eps, double* stats, float* affine, float* running_mean,
+                            float* running_var, double momentum, const int64_t* n_tracked, egc_stream_t stream);
+int egc_bn_backward_finalize(const double* partials, int32_t n_partials, int32_t cols, int64_t n_rows, const double* stats,
+                             const float* gamma, float* out5, egc_stream_t stream);
 int egc_affine_act_residual_f32(const float* h, const float* scale, const float* shift, const float* residual,
                                 int32_t relu, int64_t n_rows, int32_t cols, float* out, egc_stream_t stream);
 int egc_affine_act_backward_f32(const float* dout, const float* h, const float* scale, const float* shift, int32_t relu,
