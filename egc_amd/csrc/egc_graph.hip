@@ -161,6 +161,25 @@ __global__ void __launch_bounds__(256) edge_dis_kernel(int64_t n_edges, const in
   }
 }
 
+// The CSR back as a COO list with the roles swapped -- entry p of row i (source j = col[p]) becomes the edge
+// (source i, destination j) -- i.e. the input of the TRANSPOSED graph's build (the backward's source-side pass).
+// One launch (a binary search of the row pointers per entry) instead of the half-dozen torch kernels of
+// diff / repeat_interleave / cast / stack, and no read-back of the entry count.
+__global__ void __launch_bounds__(256) csr_transposed_coo_kernel(int n_nodes, int64_t n_edges, const int32_t* __restrict__ rowptr,
+                                                                 const int32_t* __restrict__ col, int64_t* __restrict__ out_src,
+                                                                 int64_t* __restrict__ out_dst) {
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; p < n_edges; p += (int64_t)gridDim.x * blockDim.x) {
+    int lo = 0, hi = n_nodes;                  // largest row with rowptr[row] <= p
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if ((int64_t)rowptr[mid] <= p) lo = mid; else hi = mid;
+    }
+    out_src[p] = lo;
+    out_dst[p] = col[p];
+  }
+}
+
 
 // =============================================================================================
 // Fast graph build (egc_graph_build): COO -> stable CSR + degree tables + long-row plan + per-entry deg^-1/2 in
@@ -757,6 +776,18 @@ int egc_csr_edge_dis(int64_t n_edges, const int32_t* col, const float* dis_raw, 
   const int blocks = (int)std::min<int64_t>(ceil_div(n_edges, 256), 256 * 8);
   edge_dis_kernel<<<blocks, 256, 0, stream>>>(n_edges, col, dis_raw, dis_looped, edge_dis_raw, edge_dis_looped);
   EGC_LAUNCH_CHECK("edge_dis_kernel");
+  return EGC_OK;
+}
+
+int egc_csr_transposed_coo(int64_t n_nodes, int64_t n_edges, const int32_t* rowptr, const int32_t* col, int64_t* out_src,
+                           int64_t* out_dst, egc_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_nodes < 0 || n_edges < 0 || n_nodes >= (1ll << 31) || n_edges >= (1ll << 31)) return EGC_ERR_INVALID;
+  if (n_edges == 0) return EGC_OK;
+  if (n_nodes == 0 || rowptr == nullptr || col == nullptr || out_src == nullptr || out_dst == nullptr) return EGC_ERR_INVALID;
+  const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(n_edges, (int64_t)256), 8192);
+  csr_transposed_coo_kernel<<<blocks, 256, 0, stream>>>((int)n_nodes, n_edges, rowptr, col, out_src, out_dst);
+  EGC_LAUNCH_CHECK("csr_transposed_coo_kernel");
   return EGC_OK;
 }
 

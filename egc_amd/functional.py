@@ -762,6 +762,7 @@ class _BatchNormActResidualFunction(torch.autograd.Function):
                                                      res.data_ptr() if res is not None else None, int(relu), n, c,
                                                      out.data_ptr(), stream), "egc_affine_act_residual_f32")
         ctx.save_for_backward(h, affine, stats, gamma_c)
+        ctx.set_materialize_grads(False)     # (mean / var carry no gradient: no zero-filled stand-ins per backward)
         ctx.relu, ctx.has_res, ctx.has_gamma, ctx.has_beta = bool(relu), residual is not None, gamma is not None, beta is not None
         mean, var = stats[0], stats[1]
         ctx.mark_non_differentiable(mean, var)
@@ -773,6 +774,8 @@ class _BatchNormActResidualFunction(torch.autograd.Function):
         h, affine, stats, gamma_c = ctx.saved_tensors
         n, c = h.shape
         dev = h.device
+        if dout is None:
+            return (None,) * 10
         dout = dout.contiguous()
         dh = dgamma = dbeta = None
         if ctx.needs_input_grad[0] or (ctx.has_gamma and ctx.needs_input_grad[2]) or (ctx.has_beta and ctx.needs_input_grad[3]):

@@ -253,14 +253,13 @@ class CSRGraph:
             dev = self.device
             n, e, ns = self.n_nodes, self.n_edges, self.n_src_rows
             with _device_guard(dev):
-                # destination id of every CSR entry = its row index
-                counts = (self.rowptr[1:] - self.rowptr[:-1]).long()
-                # (output_size: without it repeat_interleave reads the total back to the host -- a synchronisation per
-                #  new graph, and an error inside a hipGraph recording)
-                dst = torch.repeat_interleave(torch.arange(n, device=dev), counts, output_size=e)
-                src = self.col[:e].long()
-                # swap roles: "source" = dst (becomes the entry), "destination" = src (becomes the row)
-                self._transposed = CSRGraph.from_edge_index(torch.stack([dst, src]), ns, max(n, 1))
+                # swap roles: "source" = the entry's row (becomes the entry), "destination" = its column (becomes the
+                # row); one launch, no read-back (a per-batch graph pays this in every training step)
+                coo = torch.empty((2, e), dtype=torch.int64, device=dev)
+                _C.check(_C.load().egc_csr_transposed_coo(n, e, self.rowptr.data_ptr(), self.col.data_ptr(),
+                                                          coo[0].data_ptr(), coo[1].data_ptr() if e else None,
+                                                          _stream_ptr(dev)), "egc_csr_transposed_coo")
+                self._transposed = CSRGraph.from_edge_index(coo, ns, max(n, 1))
         if self._n_chunks is not None and self._n_chunks >= 0:   # a static graph: its transpose is one too
             self._transposed.trim_launches()
         return self._transposed

@@ -139,6 +139,13 @@ int egc_graph_build(const int64_t* src, const int64_t* dst, int64_t n_edges, int
 int egc_csr_prepare(int64_t n_nodes, int64_t n_edges, const int32_t* rowptr, const int32_t* col,
                     float* dis_raw, float* dis_looped, int32_t* plan, egc_stream_t stream);
 
+/* The CSR as the COO input of its TRANSPOSE's build: out_src[p] = the row that holds entry p, out_dst[p] = col[p]
+ * (int64, as egc_graph_build / egc_coo_to_csr take them).  The backward's source-side pass walks the transposed graph
+ * (autograd of the gather behind MessagePassing.propagate, optimized_layers.py:191-193); entry order is kept, so
+ * the transposed graph's edge_id is the CSR position the arg comparisons need. */
+int egc_csr_transposed_coo(int64_t n_nodes, int64_t n_edges, const int32_t* rowptr, const int32_t* col, int64_t* out_src,
+                           int64_t* out_dst, egc_stream_t stream);
+
 /* Per-entry copies of the source-side deg^-1/2 (egc_graph.edge_dis_*): out[p] = dis[col[p]].  Call after the
  * dis_* arrays are final (on a vertex partition: after their halo entries have arrived).  Either pair may be NULL. */
 int egc_csr_edge_dis(int64_t n_edges, const int32_t* col, const float* dis_raw, const float* dis_looped,
