@@ -38,6 +38,9 @@ def main():
     cp("train/kt_kernel_stats.csv", f"{tag}_training_step_kernel_stats.csv")
     cp("block/kt_kernel_stats.csv", f"{tag}_training_block_kernel_stats.csv")
     cp("mag/kt_kernel_stats.csv", f"{tag}_mag_layer_kernel_stats.csv")
+    if os.path.exists(os.path.join(src, "small/kt_kernel_stats.csv")):
+        cp("small/kt_kernel_stats.csv", f"{tag}_small_batch_step_kernel_stats.csv")
+        cp("small.log", f"{tag}_small_batch_step.log")
     cp("bench.json", f"{tag}_bench.json")
     cp("mag_bench.json", f"{tag}_mag_bench.json")
     cp("rmag_bench.json", f"{tag}_rmag_bench.json")
