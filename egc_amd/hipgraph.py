@@ -6,7 +6,8 @@ launches them (Python, the autograd engine, ~25 launches per layer and direction
 the training path is stream-ordered device work with host-known sizes -- no allocation outside torch's caching
 allocator, no host read-back (the index check of a fresh graph is deferred, graph.check_indices) -- so the step can
 be recorded once and replayed: 4 x [EGConv -> BatchNorm1d(train) -> ReLU -> + x], forward + backward on a 128-molecule
-batch, 2.40 ms eager -> 0.73 ms replayed on MI355X, gradients bit-identical.
+batch (graph build included), 1.1-1.7 ms eager -> 0.41-0.48 ms replayed on MI355X, gradients bit-identical (DESIGN.md
+section 5).
 
 Usage (static shapes: the tensors the step reads and writes are the SAME objects at every replay; a batch with fewer
 nodes / edges is padded by the caller, e.g. with isolated nodes and self-loops on the last of them)::
