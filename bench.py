@@ -211,6 +211,17 @@ def other_configs(dev, seed):
     out["config2_training_block"] = {"workload": "config 2, forward + backward of conv -> BatchNorm1d(train) -> ReLU -> + input",
                                      "step_ms": ms_fused, "step_ms_with_torch_tail": ms_torch}
     log(f"  training block (config 2): {ms_fused:.4f} ms (torch tail: {ms_torch:.4f} ms)")
+    # the ogbn-arxiv net's own block has a dropout in front of the residual add (arxiv/norm_models.py:34-40, p = 0.2)
+    block = egc_amd.FusedEGCBlock(layer, bn, dropout=0.2).train()
+    for fn in (block, block._plain):
+        for _ in range(3):
+            block_step(fn)
+    ms_fused = time_region_median(lambda: block_step(block), 10, 3)
+    ms_torch = time_region_median(lambda: block_step(block._plain), 10, 3)
+    out["config2_training_block_arxiv_net"] = {
+        "workload": "config 2, forward + backward of conv -> BatchNorm1d(train) -> ReLU -> dropout(0.2) -> + input",
+        "step_ms": ms_fused, "step_ms_with_torch_tail": ms_torch}
+    log(f"  arxiv-net training block (config 2, dropout 0.2): {ms_fused:.4f} ms (torch tail: {ms_torch:.4f} ms)")
     del block, layer, x, go, g
     # the batch sizes the reference actually trains at (zinc/configs.py: 128 graphs per batch): a few thousand nodes,
     # where the step is bound by what launches the kernels -- eager against the whole step replayed as one hipGraph

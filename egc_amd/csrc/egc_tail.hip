@@ -24,11 +24,19 @@ __device__ inline d4 to_d4(f4 v) { return d4{(double)v.x, (double)v.y, (double)v
 // out[block][0][c] = sum over the block's rows of a[r][c] (* mask), out[block][1][c] = sum of a[r][c] * b[r][c]
 // (b == a: the second moment).  MASKED: a is multiplied by [b * scale + shift > 0] first (the ReLU mask recomputed
 // from the saved pre-BatchNorm activations instead of stored).
+// dropout: keep[r][c] (one byte per element, 0 = dropped), survivors scaled by keep_scale = 1 / (1 - p)
+__device__ inline f4 keep4(const unsigned char* __restrict__ keep, int64_t quad, float keep_scale) {
+  const unsigned m = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(keep) + quad);
+  return f4{(m & 0xffu) ? keep_scale : 0.f, (m & 0xff00u) ? keep_scale : 0.f, (m & 0xff0000u) ? keep_scale : 0.f,
+            (m & 0xff000000u) ? keep_scale : 0.f};
+}
+
 template <bool MASKED>
 __global__ void __launch_bounds__(256) column_moments_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
                                                              int64_t n_rows, int cols, int rows_per_block,
-                                                             double* __restrict__ out) {
+                                                             double* __restrict__ out, int relu,
+                                                             const unsigned char* __restrict__ keep, float keep_scale) {
   __shared__ d4 red[2][256];
   const int cg = cols >> 2;                 // 16-byte column groups (<= 256)
   const int rl = 256 / cg;                  // row lanes
@@ -37,14 +45,17 @@ __global__ void __launch_bounds__(256) column_moments_kernel(const float* __rest
   const int64_t r1 = min(r0 + rows_per_block, n_rows);
   d4 s1 = d4{0, 0, 0, 0}, s2 = d4{0, 0, 0, 0};
   f4 sc = f4{0.f, 0.f, 0.f, 0.f}, sh = sc;
-  if (MASKED) { sc = reinterpret_cast<const f4*>(scale)[g]; sh = reinterpret_cast<const f4*>(shift)[g]; }
+  if (MASKED && relu) { sc = reinterpret_cast<const f4*>(scale)[g]; sh = reinterpret_cast<const f4*>(shift)[g]; }
   if (lane_r < rl)
     for (int64_t r = r0 + lane_r; r < r1; r += rl) {
       f4 va = __builtin_nontemporal_load(reinterpret_cast<const f4*>(a + r * cols) + g);
       const f4 vb = MASKED ? __builtin_nontemporal_load(reinterpret_cast<const f4*>(b + r * cols) + g) : va;
       if (MASKED) {
-        const f4 pre = vb * sc + sh;
-        va = f4{pre.x > 0.f ? va.x : 0.f, pre.y > 0.f ? va.y : 0.f, pre.z > 0.f ? va.z : 0.f, pre.w > 0.f ? va.w : 0.f};
+        if (keep != nullptr) va = va * keep4(keep, r * cg + g, keep_scale);
+        if (relu) {
+          const f4 pre = vb * sc + sh;
+          va = f4{pre.x > 0.f ? va.x : 0.f, pre.y > 0.f ? va.y : 0.f, pre.z > 0.f ? va.z : 0.f, pre.w > 0.f ? va.w : 0.f};
+        }
       }
       const d4 da = to_d4(va);
       s1 += da;
@@ -136,13 +147,15 @@ __global__ void __launch_bounds__(256) bn_backward_finalize_kernel(const double*
 __global__ void __launch_bounds__(256) affine_act_residual_kernel(const float* __restrict__ h, const float* __restrict__ scale,
                                                                   const float* __restrict__ shift,
                                                                   const float* __restrict__ residual, int relu,
-                                                                  int64_t quads, int cg, float* __restrict__ out) {
+                                                                  int64_t quads, int cg, float* __restrict__ out,
+                                                                  const unsigned char* __restrict__ keep, float keep_scale) {
   const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (k >= quads) return;
   const int g = (int)(k % cg);
   f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4*>(h) + k) * reinterpret_cast<const f4*>(scale)[g] +
          reinterpret_cast<const f4*>(shift)[g];
   if (relu) v = f4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+  if (keep != nullptr) v = v * keep4(keep, k, keep_scale);
   if (residual != nullptr) v += __builtin_nontemporal_load(reinterpret_cast<const f4*>(residual) + k);
   __builtin_nontemporal_store(v, reinterpret_cast<f4*>(out) + k);
 }
@@ -152,12 +165,14 @@ __global__ void __launch_bounds__(256) tail_backward_kernel(const float* __restr
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             int relu, const float* __restrict__ ca, const float* __restrict__ cb,
                                                             const float* __restrict__ cc, int64_t quads, int cg,
-                                                            float* __restrict__ dh) {
+                                                            float* __restrict__ dh, const unsigned char* __restrict__ keep,
+                                                            float keep_scale) {
   const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (k >= quads) return;
   const int g = (int)(k % cg);
   const f4 hv = __builtin_nontemporal_load(reinterpret_cast<const f4*>(h) + k);
   f4 gv = __builtin_nontemporal_load(reinterpret_cast<const f4*>(dout) + k);
+  if (keep != nullptr) gv = gv * keep4(keep, k, keep_scale);
   if (relu) {
     const f4 pre = hv * reinterpret_cast<const f4*>(scale)[g] + reinterpret_cast<const f4*>(shift)[g];
     gv = f4{pre.x > 0.f ? gv.x : 0.f, pre.y > 0.f ? gv.y : 0.f, pre.z > 0.f ? gv.z : 0.f, pre.w > 0.f ? gv.w : 0.f};
@@ -223,8 +238,9 @@ using namespace egc;
 
 extern "C" {
 
-int egc_column_moments_f64(const float* a, const float* b, const float* scale, const float* shift, int64_t n_rows,
-                           int32_t cols, double* partials, int32_t n_partials, egc_stream_t stream_) {
+int egc_column_moments_f64(const float* a, const float* b, const float* scale, const float* shift, int32_t relu,
+                           const uint8_t* keep, float keep_scale, int64_t n_rows, int32_t cols, double* partials,
+                           int32_t n_partials, egc_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (n_rows < 0 || cols <= 0 || partials == nullptr || n_partials <= 0) return EGC_ERR_INVALID;
   if ((cols & 3) != 0 || cols > 1024 || !aligned16(a) || !aligned16(b) || !aligned16(scale) || !aligned16(shift) ||
@@ -232,12 +248,15 @@ int egc_column_moments_f64(const float* a, const float* b, const float* scale, c
     return EGC_ERR_UNSUPPORTED;
   if (n_rows > 0 && a == nullptr) return EGC_ERR_INVALID;
   const bool masked = b != nullptr;
-  if (masked && (scale == nullptr || shift == nullptr)) return EGC_ERR_INVALID;
+  if (masked && relu && (scale == nullptr || shift == nullptr)) return EGC_ERR_INVALID;
+  if (keep != nullptr && (!masked || (reinterpret_cast<uintptr_t>(keep) & 3) != 0)) return EGC_ERR_INVALID;
   const int rows_per_block = (int)std::max<int64_t>(ceil_div(n_rows, (int64_t)n_partials), 1);  // empty blocks write zeros
   if (masked)
-    column_moments_kernel<true><<<(unsigned)n_partials, 256, 0, stream>>>(a, b, scale, shift, n_rows, cols, rows_per_block, partials);
+    column_moments_kernel<true><<<(unsigned)n_partials, 256, 0, stream>>>(a, b, scale, shift, n_rows, cols,
+                                                                          rows_per_block, partials, relu, keep, keep_scale);
   else
-    column_moments_kernel<false><<<(unsigned)n_partials, 256, 0, stream>>>(a, nullptr, nullptr, nullptr, n_rows, cols, rows_per_block, partials);
+    column_moments_kernel<false><<<(unsigned)n_partials, 256, 0, stream>>>(a, nullptr, nullptr, nullptr, n_rows, cols, rows_per_block,
+                                                                           partials, 0, nullptr, 1.f);
   EGC_LAUNCH_CHECK("column_moments_kernel");
   return EGC_OK;
 }
@@ -270,7 +289,8 @@ int egc_bn_backward_finalize(const double* partials, int32_t n_partials, int32_t
 }
 
 int egc_affine_act_residual_f32(const float* h, const float* scale, const float* shift, const float* residual,
-                                int32_t relu, int64_t n_rows, int32_t cols, float* out, egc_stream_t stream_) {
+                                int32_t relu, const uint8_t* keep, float keep_scale, int64_t n_rows, int32_t cols,
+                                float* out, egc_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (n_rows < 0 || cols <= 0 || scale == nullptr || shift == nullptr) return EGC_ERR_INVALID;
   if ((cols & 3) != 0 || !aligned16(h) || !aligned16(scale) || !aligned16(shift) || !aligned16(residual) || !aligned16(out))
@@ -278,14 +298,16 @@ int egc_affine_act_residual_f32(const float* h, const float* scale, const float*
   if (n_rows == 0) return EGC_OK;
   if (h == nullptr || out == nullptr) return EGC_ERR_INVALID;
   const int64_t quads = n_rows * (cols / 4);
-  affine_act_residual_kernel<<<(unsigned)ceil_div(quads, 256), 256, 0, stream>>>(h, scale, shift, residual, relu, quads, cols / 4, out);
+  if ((reinterpret_cast<uintptr_t>(keep) & 3) != 0) return EGC_ERR_UNSUPPORTED;
+  affine_act_residual_kernel<<<(unsigned)ceil_div(quads, 256), 256, 0, stream>>>(h, scale, shift, residual, relu, quads, cols / 4, out,
+                                                                               keep, keep_scale);
   EGC_LAUNCH_CHECK("affine_act_residual_kernel");
   return EGC_OK;
 }
 
 int egc_affine_act_backward_f32(const float* dout, const float* h, const float* scale, const float* shift, int32_t relu,
-                                const float* coef_g, const float* coef_h, const float* coef_1, int64_t n_rows, int32_t cols,
-                                float* dh, egc_stream_t stream_) {
+                                const uint8_t* keep, float keep_scale, const float* coef_g, const float* coef_h,
+                                const float* coef_1, int64_t n_rows, int32_t cols, float* dh, egc_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (n_rows < 0 || cols <= 0 || scale == nullptr || shift == nullptr || coef_g == nullptr || coef_h == nullptr ||
       coef_1 == nullptr)
@@ -296,8 +318,9 @@ int egc_affine_act_backward_f32(const float* dout, const float* h, const float* 
   if (n_rows == 0) return EGC_OK;
   if (dout == nullptr || h == nullptr || dh == nullptr) return EGC_ERR_INVALID;
   const int64_t quads = n_rows * (cols / 4);
+  if ((reinterpret_cast<uintptr_t>(keep) & 3) != 0) return EGC_ERR_UNSUPPORTED;
   tail_backward_kernel<<<(unsigned)ceil_div(quads, 256), 256, 0, stream>>>(dout, h, scale, shift, relu, coef_g, coef_h, coef_1, quads,
-                                                                         cols / 4, dh);
+                                                                         cols / 4, dh, keep, keep_scale);
   EGC_LAUNCH_CHECK("tail_backward_kernel");
   return EGC_OK;
 }

@@ -708,10 +708,11 @@ class _AggregateCombineFunction(torch.autograd.Function):
         return d_bases, d_w, dbias, None, None
 
 
-def _moment_partials(a: torch.Tensor, b=None, scale=None, shift=None) -> torch.Tensor:
+def _moment_partials(a: torch.Tensor, b=None, scale=None, shift=None, relu=True, keep=None, keep_scale=1.0) -> torch.Tensor:
     """[parts][2][C] float64 partial sums (sum_r g, sum_r g * b) over row blocks through egc_column_moments_f64; b is None:
-    g = a and the second sum is the second moment of a; else g = a * [b * scale + shift > 0].  The blocks are added by
-    the finalize kernels (egc_bn_forward_finalize / egc_bn_backward_finalize)."""
+    g = a and the second sum is the second moment of a; else g = a * keep * keep_scale * [b * scale + shift > 0] (dropout
+    mask if given, ReLU mask if ``relu``).  The blocks are added by the finalize kernels (egc_bn_forward_finalize /
+    egc_bn_backward_finalize)."""
     lib = _C.load()
     n, c = a.shape
     dev = a.device
@@ -720,8 +721,9 @@ def _moment_partials(a: torch.Tensor, b=None, scale=None, shift=None) -> torch.T
         out = torch.empty((parts, 2, c), dtype=torch.float64, device=dev)
         _C.check(lib.egc_column_moments_f64(a.data_ptr(), b.data_ptr() if b is not None else None,
                                             scale.data_ptr() if scale is not None else None,
-                                            shift.data_ptr() if shift is not None else None, n, c, out.data_ptr(), parts,
-                                            _stream_ptr(dev)), "egc_column_moments_f64")
+                                            shift.data_ptr() if shift is not None else None, int(bool(relu)),
+                                            keep.data_ptr() if keep is not None else None, float(keep_scale), n, c,
+                                            out.data_ptr(), parts, _stream_ptr(dev)), "egc_column_moments_f64")
     return out
 
 
@@ -733,11 +735,12 @@ def _f32_vec(t, c):
 class _BatchNormActResidualFunction(torch.autograd.Function):
     """out = act(batch_norm(h; batch statistics) * gamma + beta) + residual -- the training-mode tail of the
     reference's blocks (zinc/models.py:66-72) in two streaming passes each way plus ONE per-channel launch between them
-    (egc_tail.hip), which also updates the module's running statistics when they are passed.  Returns
-    (out, batch mean, biased batch variance), both float64."""
+    (egc_tail.hip), which also updates the module's running statistics when they are passed.  ``keep`` ([N, C] uint8,
+    0 = dropped) with ``keep_scale`` = 1 / (1 - p) puts a dropout between the activation and the residual add, as the
+    ogbn-arxiv net has it (arxiv/norm_models.py:34-40).  Returns (out, batch mean, biased batch variance), both float64."""
 
     @staticmethod
-    def forward(ctx, h, residual, gamma, beta, eps, relu, running_mean, running_var, momentum, n_tracked):
+    def forward(ctx, h, residual, gamma, beta, eps, relu, running_mean, running_var, momentum, n_tracked, keep, keep_scale):
         lib = _C.load()
         n, c = h.shape
         dev = h.device
@@ -759,9 +762,11 @@ class _BatchNormActResidualFunction(torch.autograd.Function):
                 -1.0 if momentum is None else float(momentum),
                 n_tracked.data_ptr() if n_tracked is not None else None, stream), "egc_bn_forward_finalize")
             _C.check(lib.egc_affine_act_residual_f32(h.data_ptr(), affine[0].data_ptr(), affine[1].data_ptr(),
-                                                     res.data_ptr() if res is not None else None, int(relu), n, c,
-                                                     out.data_ptr(), stream), "egc_affine_act_residual_f32")
-        ctx.save_for_backward(h, affine, stats, gamma_c)
+                                                     res.data_ptr() if res is not None else None, int(relu),
+                                                     keep.data_ptr() if keep is not None else None, float(keep_scale),
+                                                     n, c, out.data_ptr(), stream), "egc_affine_act_residual_f32")
+        ctx.save_for_backward(h, affine, stats, gamma_c, keep)
+        ctx.keep_scale = float(keep_scale)
         ctx.set_materialize_grads(False)     # (mean / var carry no gradient: no zero-filled stand-ins per backward)
         ctx.relu, ctx.has_res, ctx.has_gamma, ctx.has_beta = bool(relu), residual is not None, gamma is not None, beta is not None
         mean, var = stats[0], stats[1]
@@ -771,16 +776,16 @@ class _BatchNormActResidualFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, _dmean, _dvar):
         lib = _C.load()
-        h, affine, stats, gamma_c = ctx.saved_tensors
+        h, affine, stats, gamma_c, keep = ctx.saved_tensors
         n, c = h.shape
         dev = h.device
         if dout is None:
-            return (None,) * 10
+            return (None,) * 12
         dout = dout.contiguous()
         dh = dgamma = dbeta = None
         if ctx.needs_input_grad[0] or (ctx.has_gamma and ctx.needs_input_grad[2]) or (ctx.has_beta and ctx.needs_input_grad[3]):
-            if ctx.relu:
-                parts = _moment_partials(dout, h, affine[0], affine[1])  # sum g, sum g h   (g = dout * relu mask)
+            if ctx.relu or keep is not None:    # sum g, sum g h   (g = dout * dropout mask * relu mask)
+                parts = _moment_partials(dout, h, affine[0], affine[1], ctx.relu, keep, ctx.keep_scale)
             else:
                 s1 = _column_sums(dout).double()
                 sgh = (dout.double() * h.double()).sum(0) if n else torch.zeros(c, dtype=torch.float64, device=dev)
@@ -796,11 +801,12 @@ class _BatchNormActResidualFunction(torch.autograd.Function):
                 if ctx.needs_input_grad[0]:
                     dh = torch.empty_like(h)
                     _C.check(lib.egc_affine_act_backward_f32(dout.data_ptr(), h.data_ptr(), affine[0].data_ptr(),
-                                                             affine[1].data_ptr(), int(ctx.relu), out5[2].data_ptr(),
-                                                             out5[3].data_ptr(), out5[4].data_ptr(), n, c, dh.data_ptr(),
-                                                             stream), "egc_affine_act_backward_f32")
+                                                             affine[1].data_ptr(), int(ctx.relu),
+                                                             keep.data_ptr() if keep is not None else None, ctx.keep_scale,
+                                                             out5[2].data_ptr(), out5[3].data_ptr(), out5[4].data_ptr(), n, c,
+                                                             dh.data_ptr(), stream), "egc_affine_act_backward_f32")
         dres = dout if ctx.has_res and ctx.needs_input_grad[1] else None
-        return dh, dres, dgamma, dbeta, None, None, None, None, None, None
+        return dh, dres, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 def batch_norm_act_residual_supported(h: torch.Tensor) -> bool:
@@ -809,18 +815,22 @@ def batch_norm_act_residual_supported(h: torch.Tensor) -> bool:
 
 
 def batch_norm_act_residual(h, residual, gamma, beta, eps: float, relu: bool, running_mean=None, running_var=None,
-                            momentum=None, num_batches_tracked=None):
+                            momentum=None, num_batches_tracked=None, keep=None, keep_scale: float = 1.0):
     """Training-mode BatchNorm1d (batch statistics) -> optional ReLU -> optional residual add, fused
     (_BatchNormActResidualFunction): returns (out, batch mean [C] float64, biased batch variance [C] float64).
     With ``running_mean`` / ``running_var`` (float32 [C], dense) the running statistics are updated in the same launch
     that finishes the batch statistics, as nn.BatchNorm1d does: unbiased variance, ``momentum``, or -- momentum None --
-    the cumulative average over ``num_batches_tracked`` (a device int64 scalar the CALLER has already incremented)."""
+    the cumulative average over ``num_batches_tracked`` (a device int64 scalar the CALLER has already incremented).
+    ``keep`` / ``keep_scale``: dropout between the activation and the residual add (see the Function)."""
     c = h.size(1)
     if running_mean is not None and not (_f32_vec(running_mean, c) and _f32_vec(running_var, c)
                                          and (momentum is not None or num_batches_tracked is not None)):
         raise RuntimeError("egc_amd: running statistics must be dense float32 [C] tensors")
+    if keep is not None and (keep.dtype != torch.uint8 or keep.shape != h.shape or not keep.is_contiguous()
+                             or keep.device != h.device):
+        raise RuntimeError("egc_amd: the dropout mask must be a dense uint8 tensor of the shape of h")
     return _BatchNormActResidualFunction.apply(h, residual, gamma, beta, float(eps), bool(relu), running_mean, running_var,
-                                               momentum, num_batches_tracked)
+                                               momentum, num_batches_tracked, keep, float(keep_scale))
 
 
 def egc_aggregate_combine_apply(graph, spec, bases, weightings, bias=None):

@@ -2,7 +2,8 @@
 
 The reference's graph nets wrap every EGC layer the same way (zinc/models.py:66-72, mol/pna_style_models.py:71-78,
 cifar/models.py:67-74):   x = conv(x, edge_index);  x = bn(x);  x = relu(x);  x = x + identity   and finish with
-``global_mean_pool(x, batch)``.  In eval mode BatchNorm1d is a per-channel affine map, so the whole tail folds into the
+``global_mean_pool(x, batch)``; the ogbn-arxiv net puts ``F.dropout`` between the ReLU and the residual add
+(arxiv/norm_models.py:34-40).  In eval mode BatchNorm1d is a per-channel affine map, so the whole tail folds into the
 store of the fused aggregate/combine kernel (``egc_aggregate_combine_post_f32``): three elementwise passes over
 [N, F_out] and three launches less per layer.  With batch statistics (training) the statistics need every row of the
 layer's output first, so the tail is its own two streaming passes each way (``batch_norm_act_residual``:
@@ -20,13 +21,23 @@ from .graph import graph_from_input
 
 
 class FusedEGCBlock(nn.Module):
-    """conv -> BatchNorm1d -> ReLU (-> + input) as one module; ``conv`` is an ``egc_amd.EfficientGraphConv`` or
-    ``egc_amd.EGConv``, ``bn`` the ``nn.BatchNorm1d`` that follows it in the reference nets (shared, not copied:
-    state dicts keep their keys)."""
+    """conv -> BatchNorm1d -> ReLU (-> dropout) (-> + input) as one module; ``conv`` is an ``egc_amd.EfficientGraphConv``
+    or ``egc_amd.EGConv``, ``bn`` the ``nn.BatchNorm1d`` that follows it in the reference nets (shared, not copied:
+    state dicts keep their keys), ``dropout`` the probability of the arxiv net's ``F.dropout(x, p, self.training)``
+    (0 for the other nets).  The dropout mask is drawn from torch's generator on the input's device (one byte per
+    element), so ``torch.manual_seed`` reproduces a run; the mask of the last training forward stays in
+    ``last_keep_mask`` for inspection."""
 
-    def __init__(self, conv: nn.Module, bn: nn.BatchNorm1d | None = None, relu: bool = True, residual: bool = True):
+    def __init__(self, conv: nn.Module, bn: nn.BatchNorm1d | None = None, relu: bool = True, residual: bool = True,
+                 dropout: float = 0.0):
         super().__init__()
-        self.conv, self.bn, self.relu, self.residual = conv, bn, relu, residual
+        if not 0.0 <= float(dropout) < 1.0:
+            raise ValueError(f"dropout probability has to be in [0, 1), got {dropout}")
+        self.conv, self.bn, self.relu, self.residual, self.dropout = conv, bn, relu, residual, float(dropout)
+        self.last_keep_mask = None
+
+    def _dropping(self):
+        return self.dropout > 0.0 and self.training
 
     def _plain(self, x, edge_index):
         h = self.conv(x=x, edge_index=edge_index) if hasattr(self.conv, "aggs") else self.conv(x, edge_index)
@@ -34,6 +45,8 @@ class FusedEGCBlock(nn.Module):
             h = self.bn(h)
         if self.relu:
             h = torch.relu(h)
+        if self._dropping():
+            h = torch.nn.functional.dropout(h, self.dropout, True)
         return x + h if self.residual else h
 
     def _batch_stats(self, x, edge_index):
@@ -44,7 +57,13 @@ class FusedEGCBlock(nn.Module):
         if not batch_norm_act_residual_supported(h) or (self.residual and x.shape != h.shape):
             h = bn(h)
             h = torch.relu(h) if self.relu else h
+            if self._dropping():
+                h = torch.nn.functional.dropout(h, self.dropout, True)
             return x + h if self.residual else h
+        keep = None
+        if self._dropping():
+            keep = torch.empty(h.shape, dtype=torch.uint8, device=h.device).bernoulli_(1.0 - self.dropout)
+            self.last_keep_mask = keep
         track = bn.training and bn.track_running_stats
         in_place = (track and bn.running_mean.dtype == torch.float32 and bn.running_mean.is_contiguous()
                     and bn.running_var.dtype == torch.float32 and bn.running_var.is_contiguous())
@@ -54,7 +73,7 @@ class FusedEGCBlock(nn.Module):
         out, mean, var = batch_norm_act_residual(
             h, x if self.residual else None, bn.weight if bn.affine else None, bn.bias if bn.affine else None, bn.eps,
             self.relu, bn.running_mean if in_place else None, bn.running_var if in_place else None, bn.momentum,
-            bn.num_batches_tracked if in_place else None)
+            bn.num_batches_tracked if in_place else None, keep, 1.0 / (1.0 - self.dropout))
         if track and not in_place:               # running statistics kept in another dtype: torch's arithmetic
             with torch.no_grad():
                 n = h.size(0)
@@ -67,6 +86,8 @@ class FusedEGCBlock(nn.Module):
         bn = self.bn
         if bn is not None and (bn.training or not bn.track_running_stats):
             return self._batch_stats(x, edge_index)      # batch statistics: the tail is its own two passes
+        if self._dropping():                              # (dropout without batch statistics: torch's operators)
+            return self._plain(x, edge_index)
         fusable = not (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())))
         if not fusable:
             return self._plain(x, edge_index)

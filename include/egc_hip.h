@@ -302,10 +302,16 @@ int egc_weight_grad_f32(const float* x, int64_t ldx, const float* d, int64_t ldd
  * pass at all (egc_post).  h, residual, out, dout, dh are dense [n_rows, cols] float32 arrays, cols a multiple of 4
  * (<= 1024 for the moments), every pointer 16-byte aligned (EGC_ERR_UNSUPPORTED otherwise).
  *
+ * The ogbn-arxiv net puts a dropout between the ReLU and the residual add (arxiv/norm_models.py:34-40): `keep`
+ * ([n_rows, cols] bytes, 0 = dropped, 4-byte aligned; NULL = no dropout) and keep_scale = 1 / (1 - p) carry it through
+ * all three passes -- out = act(.) * keep * keep_scale + residual forward, g = dout * keep * keep_scale * [pre > 0]
+ * backward.  The mask itself is the caller's (torch's generator on the Python side).
+ *
  *   egc_column_moments_f64      partials[p][0][c] = sum over the p-th block of rows of g[r][c],
  *                               partials[p][1][c] = sum of g[r][c] * b[r][c], accumulated in float64 (the caller adds
  *                               the n_partials blocks).  b == NULL: g = a, second moment of a itself (forward: batch
- *                               mean and variance of h).  b != NULL: g = a * [b * scale + shift > 0] (backward: a =
+ *                               mean and variance of h).  b != NULL: g = a * keep * keep_scale * [b * scale + shift > 0]
+ *                               (the last factor only with relu != 0; backward: a =
  *                               dout, b = h; the ReLU mask is recomputed from h, not stored), giving the two sums of
  *                               the BatchNorm backward.  partials: n_partials * 2 * cols doubles, 32-byte aligned.
  *   egc_bn_forward_finalize     everything per channel between the two forward passes, in one launch: the partials
@@ -320,18 +326,20 @@ int egc_weight_grad_f32(const float* x, int64_t ldx, const float* d, int64_t ldd
  *                               scale; relu != 0: act = max(., 0); residual may be NULL)
  *   egc_affine_act_backward_f32 dh = coef_g * g + coef_h * h + coef_1 per channel, g as above: the BatchNorm backward
  *                               with its two sums folded into the three per-channel coefficient vectors. */
-int egc_column_moments_f64(const float* a, const float* b, const float* scale, const float* shift, int64_t n_rows,
-                           int32_t cols, double* partials, int32_t n_partials, egc_stream_t stream);
+int egc_column_moments_f64(const float* a, const float* b, const float* scale, const float* shift, int32_t relu,
+                           const uint8_t* keep, float keep_scale, int64_t n_rows, int32_t cols, double* partials,
+                           int32_t n_partials, egc_stream_t stream);
 int egc_bn_forward_finalize(const double* partials, int32_t n_partials, int32_t cols, int64_t n_rows, const float* gamma,
                             const float* beta, double eps, double* stats, float* affine, float* running_mean,
                             float* running_var, double momentum, const int64_t* n_tracked, egc_stream_t stream);
 int egc_bn_backward_finalize(const double* partials, int32_t n_partials, int32_t cols, int64_t n_rows, const double* stats,
                              const float* gamma, float* out5, egc_stream_t stream);
 int egc_affine_act_residual_f32(const float* h, const float* scale, const float* shift, const float* residual,
-                                int32_t relu, int64_t n_rows, int32_t cols, float* out, egc_stream_t stream);
+                                int32_t relu, const uint8_t* keep, float keep_scale, int64_t n_rows, int32_t cols,
+                                float* out, egc_stream_t stream);
 int egc_affine_act_backward_f32(const float* dout, const float* h, const float* scale, const float* shift, int32_t relu,
-                                const float* coef_g, const float* coef_h, const float* coef_1, int64_t n_rows, int32_t cols,
-                                float* dh, egc_stream_t stream);
+                                const uint8_t* keep, float keep_scale, const float* coef_g, const float* coef_h,
+                                const float* coef_1, int64_t n_rows, int32_t cols, float* dh, egc_stream_t stream);
 
 /* The GEMM operand of a layer from its parameters (grad == 0), or the parameters' gradients from the operand's
  * gradient (grad != 0: the parameter arrays are WRITTEN, wcat / bcat read) -- one launch instead of the cat / pad /

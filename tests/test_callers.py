@@ -171,6 +171,62 @@ def test_fused_block_training_tail_equals_batch_norm_relu_residual(hidden, H, B,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("relu,p", [(True, 0.2), (False, 0.5)])
+def test_fused_block_training_tail_with_the_arxiv_nets_dropout(relu, p):
+    """The ogbn-arxiv net's block (arxiv/norm_models.py:34-40): conv -> bn -> relu -> F.dropout -> + identity.  The fused
+    tail carries the dropout mask through its three passes; against torch's operators applied with the SAME mask
+    (FusedEGCBlock.last_keep_mask): output, input and parameter gradients.  Eval mode: dropout is the identity."""
+    import copy
+    dev = torch.device("cuda:0")
+    atom, ei, n, batch = zinc_like_batch(64, seed=9)
+    torch.manual_seed(5)
+    hidden = 128
+    conv = egc_amd.EGConv(hidden, hidden, aggrs=["sum", "mean", "max", "symnorm"], num_heads=8, num_bases=4).to(dev)
+    bn = nn.BatchNorm1d(hidden).to(dev)
+    with torch.no_grad():
+        bn.weight.normal_(); bn.bias.normal_(); conv.bias.normal_()
+    conv_r, bn_r = copy.deepcopy(conv), copy.deepcopy(bn)
+    x = torch.randn(n, hidden, device=dev)
+    gout = torch.randn(n, hidden, device=dev)
+    ei = ei.to(dev)
+    block = egc_amd.FusedEGCBlock(conv, bn, relu=relu, residual=True, dropout=p).train()
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    got = block(xa, ei)
+    keep = block.last_keep_mask
+    assert keep is not None and keep.dtype == torch.uint8 and keep.shape == got.shape
+    frac = float(keep.float().mean())
+    assert abs(frac - (1.0 - p)) < 0.02, frac
+    h = bn_r(conv_r(xb, ei))
+    h = torch.relu(h) if relu else h
+    ref = h * keep.float() / (1.0 - p) + xb
+    (got * gout).sum().backward()
+    (ref * gout).sum().backward()
+    scale = max(1.0, float(ref.detach().abs().max()))
+    assert float((got.detach() - ref.detach()).abs().max()) / scale <= 1e-5
+
+    def close(a, b, what, tol):
+        assert float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max())), what
+    close(xa.grad, xb.grad, "x.grad", 2e-5)
+    for (name, pa), (_, pb) in zip(list(conv.named_parameters()) + list(bn.named_parameters()),
+                                   list(conv_r.named_parameters()) + list(bn_r.named_parameters())):
+        close(pa.grad, pb.grad, name, 1e-4)
+    close(bn.running_mean, bn_r.running_mean, "running_mean", 2e-5)
+    # a second forward draws a new mask; the same seed reproduces it
+    torch.manual_seed(11); block(x, ei); k1 = block.last_keep_mask.clone()
+    torch.manual_seed(11); block(x, ei); k2 = block.last_keep_mask
+    assert torch.equal(k1, k2) and not torch.equal(k1, keep)
+    block.eval(); bn_r.eval()
+    with torch.no_grad():
+        e_got = block(x, ei)
+        e_ref = x + (torch.relu(bn_r(conv_r(x, ei))) if relu else bn_r(conv_r(x, ei)))
+    # (the two BatchNorms saw a different number of training batches above: compare with the block's own statistics)
+    bn_r.load_state_dict(bn.state_dict())
+    with torch.no_grad():
+        e_ref = x + (torch.relu(bn_r(conv_r(x, ei))) if relu else bn_r(conv_r(x, ei)))
+    assert float((e_got - e_ref).abs().max()) <= 1e-5 * max(1.0, float(e_ref.abs().max()))
+
+
+@pytest.mark.gpu
 def test_global_mean_pool_matches_index_add():
     dev = torch.device("cuda:0")
     _, _, n, batch = zinc_like_batch(200, seed=2)

@@ -28,3 +28,7 @@ print("block training step, fused tail   ms %.3f" % ev(block))
 print("block training step, torch tail   ms %.3f" % ev(block._plain))
 def conv_only(x, g): return conv(x, g)
 print("conv alone (no tail)              ms %.3f" % ev(conv_only))
+# the ogbn-arxiv net's own block (arxiv/norm_models.py:34-40): ... -> ReLU -> F.dropout(p = 0.2) -> + input
+block = egc_amd.FusedEGCBlock(conv, bn, dropout=0.2).train()
+print("arxiv block (dropout 0.2), fused   ms %.3f" % ev(block))
+print("arxiv block (dropout 0.2), torch   ms %.3f" % ev(block._plain))
