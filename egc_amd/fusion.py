@@ -39,7 +39,8 @@ class FusedEGCBlock(nn.Module):
     def _dropping(self):
         return self.dropout > 0.0 and self.training
 
-    def _plain(self, x, edge_index):
+    def _plain(self, x, edge_index, identity=None):
+        identity = x if identity is None else identity
         h = self.conv(x=x, edge_index=edge_index) if hasattr(self.conv, "aggs") else self.conv(x, edge_index)
         if self.bn is not None:
             h = self.bn(h)
@@ -47,19 +48,20 @@ class FusedEGCBlock(nn.Module):
             h = torch.relu(h)
         if self._dropping():
             h = torch.nn.functional.dropout(h, self.dropout, True)
-        return x + h if self.residual else h
+        return identity + h if self.residual else h
 
-    def _batch_stats(self, x, edge_index):
+    def _batch_stats(self, x, edge_index, identity=None):
         """conv, then BatchNorm1d on batch statistics -> ReLU -> + input in two passes; the running statistics are
         updated as nn.BatchNorm1d does (momentum or cumulative average, unbiased variance)."""
         bn = self.bn
+        identity = x if identity is None else identity
         h = self.conv(x=x, edge_index=edge_index) if hasattr(self.conv, "aggs") else self.conv(x, edge_index)
-        if not batch_norm_act_residual_supported(h) or (self.residual and x.shape != h.shape):
+        if not batch_norm_act_residual_supported(h) or (self.residual and identity.shape != h.shape):
             h = bn(h)
             h = torch.relu(h) if self.relu else h
             if self._dropping():
                 h = torch.nn.functional.dropout(h, self.dropout, True)
-            return x + h if self.residual else h
+            return identity + h if self.residual else h
         keep = None
         if self._dropping():
             keep = torch.empty(h.shape, dtype=torch.uint8, device=h.device).bernoulli_(1.0 - self.dropout)
@@ -71,7 +73,7 @@ class FusedEGCBlock(nn.Module):
             with torch.no_grad():
                 bn.num_batches_tracked += 1      # (a device scalar: the kernel reads it, nothing comes back to the host)
         out, mean, var = batch_norm_act_residual(
-            h, x if self.residual else None, bn.weight if bn.affine else None, bn.bias if bn.affine else None, bn.eps,
+            h, identity if self.residual else None, bn.weight if bn.affine else None, bn.bias if bn.affine else None, bn.eps,
             self.relu, bn.running_mean if in_place else None, bn.running_var if in_place else None, bn.momentum,
             bn.num_batches_tracked if in_place else None, keep, 1.0 / (1.0 - self.dropout))
         if track and not in_place:               # running statistics kept in another dtype: torch's arithmetic
@@ -82,22 +84,26 @@ class FusedEGCBlock(nn.Module):
                 bn.running_var.mul_(1 - m).add_((var * (n / (n - 1))).to(bn.running_var.dtype), alpha=m)
         return out
 
-    def forward(self, x, edge_index):
+    def forward(self, x, edge_index, identity=None):
+        """``identity``: what the residual adds when it is not the layer's input itself -- the CIFAR net drops out the
+        layer's input but adds the undropped activations back (cifar/models.py:64-71): ``block(drop(x), ei, identity=x)``."""
         bn = self.bn
         if bn is not None and (bn.training or not bn.track_running_stats):
-            return self._batch_stats(x, edge_index)      # batch statistics: the tail is its own two passes
+            return self._batch_stats(x, edge_index, identity)   # batch statistics: the tail is its own two passes
         if self._dropping():                              # (dropout without batch statistics: torch's operators)
-            return self._plain(x, edge_index)
-        fusable = not (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())))
+            return self._plain(x, edge_index, identity)
+        fusable = not (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())
+                                                    or (identity is not None and identity.requires_grad)))
         if not fusable:
-            return self._plain(x, edge_index)
+            return self._plain(x, edge_index, identity)
+        identity = x if identity is None else identity
         conv = self.conv
         scale = shift = None
         if bn is not None:
             inv = torch.rsqrt(bn.running_var + bn.eps)
             scale = inv * bn.weight if bn.affine else inv
             shift = (bn.bias if bn.affine else 0) - bn.running_mean * scale
-        post = PostOp(scale, shift, x if self.residual else None, self.relu)
+        post = PostOp(scale, shift, identity if self.residual else None, self.relu)
         graph = graph_from_input(edge_index, x.size(0))
         if hasattr(conv, "aggs"):      # EfficientGraphConv
             wcat = conv._packed_weights()

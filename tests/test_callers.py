@@ -227,6 +227,38 @@ def test_fused_block_training_tail_with_the_arxiv_nets_dropout(relu, p):
 
 
 @pytest.mark.gpu
+def test_fused_block_with_a_separate_identity_as_in_the_cifar_net():
+    """cifar/models.py:64-71 drops out the layer's INPUT and adds the undropped activations back:
+    block(drop(x), edge_index, identity=x) in training (two-pass tail) and in eval mode (tail in the kernel's store)."""
+    import copy
+    dev = torch.device("cuda:0")
+    atom, ei, n, batch = zinc_like_batch(48, seed=4)
+    torch.manual_seed(2)
+    hidden = 64
+    conv = egc_amd.EfficientGraphConv(hidden, hidden, num_heads=4, num_bases=4, softmax_weights=False, aggrs=["symadd", "max"]).to(dev)
+    bn = nn.BatchNorm1d(hidden).to(dev)
+    conv_r, bn_r = copy.deepcopy(conv), copy.deepcopy(bn)
+    ei = ei.to(dev)
+    x = torch.randn(n, hidden, device=dev)
+    xd = torch.nn.functional.dropout(x, 0.3, True)
+    gout = torch.randn(n, hidden, device=dev)
+    block = egc_amd.FusedEGCBlock(conv, bn).train()
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    mask = (xd != 0).float() / 0.7
+    got = block(xa * mask, ei, identity=xa)
+    ref = torch.relu(bn_r(conv_r(x=xb * mask, edge_index=ei))) + xb
+    (got * gout).sum().backward(); (ref * gout).sum().backward()
+    tol = lambda b: 2e-5 * max(1.0, float(b.abs().max()))
+    assert float((got.detach() - ref.detach()).abs().max()) <= tol(ref.detach())
+    assert float((xa.grad - xb.grad).abs().max()) <= tol(xb.grad)
+    block.eval(); bn_r.eval()
+    with torch.no_grad():
+        got = block(xd, ei, identity=x)
+        ref = torch.relu(bn_r(conv_r(x=xd, edge_index=ei))) + x
+    assert float((got - ref).abs().max()) <= tol(ref)
+
+
+@pytest.mark.gpu
 def test_global_mean_pool_matches_index_add():
     dev = torch.device("cuda:0")
     _, _, n, batch = zinc_like_batch(200, seed=2)
