@@ -176,3 +176,26 @@ def test_rmag_like_workload_has_the_reference_relations():
     c = rel[("paper", "cites", "paper")]
     key = c[0] * nodes["paper"] + c[1]
     assert torch.equal(torch.sort(key).values, torch.sort(c[1] * nodes["paper"] + c[0]).values)   # symmetric
+
+
+def test_graphed_step_and_fused_block_host_logic():
+    """No GPU: GraphedStep refuses loudly (there is nothing to record on); FusedEGCBlock validates its dropout
+    probability; the graph cache's recording scope nests and clears what it built."""
+    import egc_amd
+    from egc_amd import graph as G
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            egc_amd.GraphedStep(lambda: None)
+    conv = egc_amd.EGConv(16, 16, aggrs=["sum"], num_heads=4, num_bases=2)
+    with pytest.raises(ValueError):
+        egc_amd.FusedEGCBlock(conv, torch.nn.BatchNorm1d(16), dropout=1.0)
+    blk = egc_amd.FusedEGCBlock(conv, torch.nn.BatchNorm1d(16), dropout=0.25)
+    assert blk.dropout == 0.25 and blk._dropping() and not blk.eval()._dropping()
+    assert G._RECORDING[0] is None
+    with G.recording_scope() as outer:
+        tok = G._RECORDING[0]
+        assert tok is not None
+        with G.recording_scope():
+            assert G._RECORDING[0] is not tok
+        assert G._RECORDING[0] is tok
+    assert G._RECORDING[0] is None
