@@ -260,6 +260,28 @@ def other_configs(dev, seed):
         out[key] = {"workload": f"{label} (N={n}, E={int(ei.size(1))}): graph build + 4 x [EGConv -> BatchNorm1d(train) -> ReLU -> + x], "
                                 "forward + backward", "eager_step_ms": ms_eager, "hipgraph_replay_ms": ms_graph}
         log(f"  {key}: eager {ms_eager:.4f} ms, one hipGraph {ms_graph:.4f} ms")
+        del graphed
+        # the same net serving: eval mode (BatchNorm / ReLU / residual in the aggregate kernel's store), graph build included
+        blocks.eval()
+        outs = []
+
+        def infer():
+            with torch.no_grad():
+                h = xs
+                for b in blocks:
+                    h = b(h, ei)
+            outs[:] = [h]
+
+        def eager_infer():
+            ei.add_(0)
+            infer()
+        ms_eager = wall(eager_infer)
+        graphed = egc_amd.GraphedStep(infer)
+        ms_graph = wall(graphed)
+        out[key.replace("training_step", "inference")] = {
+            "workload": f"{label}: graph build + 4 fused blocks, eval-mode forward", "eager_ms": ms_eager,
+            "hipgraph_replay_ms": ms_graph}
+        log(f"  {key.replace('training_step', 'inference')}: eager {ms_eager:.4f} ms, one hipGraph {ms_graph:.4f} ms")
         del graphed, blocks, params
     return out
 

@@ -35,6 +35,7 @@ class FusedEGCBlock(nn.Module):
             raise ValueError(f"dropout probability has to be in [0, 1), got {dropout}")
         self.conv, self.bn, self.relu, self.residual, self.dropout = conv, bn, relu, residual, float(dropout)
         self.last_keep_mask = None
+        self._affine, self._affine_key = None, None
 
     def _dropping(self):
         return self.dropout > 0.0 and self.training
@@ -100,9 +101,17 @@ class FusedEGCBlock(nn.Module):
         conv = self.conv
         scale = shift = None
         if bn is not None:
-            inv = torch.rsqrt(bn.running_var + bn.eps)
-            scale = inv * bn.weight if bn.affine else inv
-            shift = (bn.bias if bn.affine else 0) - bn.running_mean * scale
+            # eval-mode BatchNorm is a per-channel affine map: computed once per state of the module (five tiny torch
+            # kernels per call otherwise -- most of a small batch's forward)
+            srcs = [bn.running_mean, bn.running_var] + ([bn.weight, bn.bias] if bn.affine else [])
+            key = tuple((t.data_ptr(), t._version) for t in srcs) + (bn.eps,)
+            if self._affine_key != key:
+                with torch.no_grad():
+                    inv = torch.rsqrt(bn.running_var + bn.eps)
+                    sc = inv * bn.weight if bn.affine else inv
+                    sh = (bn.bias if bn.affine else 0) - bn.running_mean * sc
+                self._affine, self._affine_key = (sc.contiguous(), sh.contiguous()), key
+            scale, shift = self._affine
         post = PostOp(scale, shift, identity if self.residual else None, self.relu)
         graph = graph_from_input(edge_index, x.size(0))
         if hasattr(conv, "aggs"):      # EfficientGraphConv

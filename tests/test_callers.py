@@ -259,6 +259,29 @@ def test_fused_block_with_a_separate_identity_as_in_the_cifar_net():
 
 
 @pytest.mark.gpu
+def test_fused_block_eval_affine_follows_the_batch_norm_state():
+    """The eval-mode affine pair is cached per state of the BatchNorm module: in-place updates of its buffers or
+    parameters (a training step in between, load_state_dict) must show in the next eval forward."""
+    dev = torch.device("cuda:0")
+    atom, ei, n, batch = zinc_like_batch(16, seed=1)
+    torch.manual_seed(0)
+    conv = egc_amd.EGConv(32, 32, aggrs=["sum", "max"], num_heads=4, num_bases=2).to(dev)
+    bn = nn.BatchNorm1d(32).to(dev)
+    block = egc_amd.FusedEGCBlock(conv, bn).eval()
+    x, ei = torch.randn(n, 32, device=dev), ei.to(dev)
+
+    def ref():
+        with torch.no_grad():
+            return x + torch.relu(bn(conv(x, ei)))
+    with torch.no_grad():
+        for change in (lambda: None, lambda: bn.running_mean.normal_(), lambda: bn.weight.data.mul_(1.7),
+                       lambda: bn.load_state_dict({k: v + 0.25 if v.dtype.is_floating_point else v for k, v in bn.state_dict().items()})):
+            change()
+            got, want = block(x, ei), ref()
+            assert float((got - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.gpu
 def test_global_mean_pool_matches_index_add():
     dev = torch.device("cuda:0")
     _, _, n, batch = zinc_like_batch(200, seed=2)
