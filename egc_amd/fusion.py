@@ -102,7 +102,8 @@ class FusedEGCBlock(nn.Module):
         scale = shift = None
         if bn is not None:
             # eval-mode BatchNorm is a per-channel affine map: computed once per state of the module (five tiny torch
-            # kernels per call otherwise -- most of a small batch's forward)
+            # kernels per call otherwise -- most of a small batch's forward); keyed on the version counters, as the layers'
+            # packed weights are: in-place updates (optimizer steps, load_state_dict) are seen, writes through .data are not
             srcs = [bn.running_mean, bn.running_var] + ([bn.weight, bn.bias] if bn.affine else [])
             key = tuple((t.data_ptr(), t._version) for t in srcs) + (bn.eps,)
             if self._affine_key != key:

@@ -261,7 +261,8 @@ def test_fused_block_with_a_separate_identity_as_in_the_cifar_net():
 @pytest.mark.gpu
 def test_fused_block_eval_affine_follows_the_batch_norm_state():
     """The eval-mode affine pair is cached per state of the BatchNorm module: in-place updates of its buffers or
-    parameters (a training step in between, load_state_dict) must show in the next eval forward."""
+    parameters (a training step in between, load_state_dict) must show in the next eval forward.  (Keyed on the tensors'
+    version counters, like the layers' packed weights: writes through ``.data`` bypass those by design.)"""
     dev = torch.device("cuda:0")
     atom, ei, n, batch = zinc_like_batch(16, seed=1)
     torch.manual_seed(0)
@@ -274,7 +275,7 @@ def test_fused_block_eval_affine_follows_the_batch_norm_state():
         with torch.no_grad():
             return x + torch.relu(bn(conv(x, ei)))
     with torch.no_grad():
-        for change in (lambda: None, lambda: bn.running_mean.normal_(), lambda: bn.weight.data.mul_(1.7),
+        for change in (lambda: None, lambda: bn.running_mean.normal_(), lambda: bn.weight.mul_(1.7),
                        lambda: bn.load_state_dict({k: v + 0.25 if v.dtype.is_floating_point else v for k, v in bn.state_dict().items()})):
             change()
             got, want = block(x, ei), ref()
