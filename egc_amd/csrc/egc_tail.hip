@@ -36,8 +36,11 @@ __global__ void __launch_bounds__(256) column_moments_kernel(const float* __rest
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
                                                              int64_t n_rows, int cols, int rows_per_block,
                                                              double* __restrict__ out, int relu,
-                                                             const unsigned char* __restrict__ keep, float keep_scale) {
+                                                             const unsigned char* __restrict__ keep, float keep_scale,
+                                                             int64_t* __restrict__ count_inc) {
   __shared__ d4 red[2][256];
+  // BatchNorm's num_batches_tracked: bumped here, one launch BEFORE the finalize kernel reads it
+  if (count_inc != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *count_inc += 1;
   const int cg = cols >> 2;                 // 16-byte column groups (<= 256)
   const int rl = 256 / cg;                  // row lanes
   const int g = threadIdx.x % cg, lane_r = threadIdx.x / cg;
@@ -240,7 +243,7 @@ extern "C" {
 
 int egc_column_moments_f64(const float* a, const float* b, const float* scale, const float* shift, int32_t relu,
                            const uint8_t* keep, float keep_scale, int64_t n_rows, int32_t cols, double* partials,
-                           int32_t n_partials, egc_stream_t stream_) {
+                           int32_t n_partials, int64_t* count_inc, egc_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (n_rows < 0 || cols <= 0 || partials == nullptr || n_partials <= 0) return EGC_ERR_INVALID;
   if ((cols & 3) != 0 || cols > 1024 || !aligned16(a) || !aligned16(b) || !aligned16(scale) || !aligned16(shift) ||
@@ -253,10 +256,10 @@ int egc_column_moments_f64(const float* a, const float* b, const float* scale, c
   const int rows_per_block = (int)std::max<int64_t>(ceil_div(n_rows, (int64_t)n_partials), 1);  // empty blocks write zeros
   if (masked)
     column_moments_kernel<true><<<(unsigned)n_partials, 256, 0, stream>>>(a, b, scale, shift, n_rows, cols,
-                                                                          rows_per_block, partials, relu, keep, keep_scale);
+                                                                          rows_per_block, partials, relu, keep, keep_scale, count_inc);
   else
     column_moments_kernel<false><<<(unsigned)n_partials, 256, 0, stream>>>(a, nullptr, nullptr, nullptr, n_rows, cols, rows_per_block,
-                                                                           partials, 0, nullptr, 1.f);
+                                                                           partials, 0, nullptr, 1.f, count_inc);
   EGC_LAUNCH_CHECK("column_moments_kernel");
   return EGC_OK;
 }

@@ -708,7 +708,8 @@ class _AggregateCombineFunction(torch.autograd.Function):
         return d_bases, d_w, dbias, None, None
 
 
-def _moment_partials(a: torch.Tensor, b=None, scale=None, shift=None, relu=True, keep=None, keep_scale=1.0) -> torch.Tensor:
+def _moment_partials(a: torch.Tensor, b=None, scale=None, shift=None, relu=True, keep=None, keep_scale=1.0,
+                     count_inc=None) -> torch.Tensor:
     """[parts][2][C] float64 partial sums (sum_r g, sum_r g * b) over row blocks through egc_column_moments_f64; b is None:
     g = a and the second sum is the second moment of a; else g = a * keep * keep_scale * [b * scale + shift > 0] (dropout
     mask if given, ReLU mask if ``relu``).  The blocks are added by the finalize kernels (egc_bn_forward_finalize /
@@ -723,7 +724,8 @@ def _moment_partials(a: torch.Tensor, b=None, scale=None, shift=None, relu=True,
                                             scale.data_ptr() if scale is not None else None,
                                             shift.data_ptr() if shift is not None else None, int(bool(relu)),
                                             keep.data_ptr() if keep is not None else None, float(keep_scale), n, c,
-                                            out.data_ptr(), parts, _stream_ptr(dev)), "egc_column_moments_f64")
+                                            out.data_ptr(), parts, count_inc.data_ptr() if count_inc is not None else None,
+                                            _stream_ptr(dev)), "egc_column_moments_f64")
     return out
 
 
@@ -747,7 +749,8 @@ class _BatchNormActResidualFunction(torch.autograd.Function):
         h = h.contiguous()
         gamma_c = gamma.detach().contiguous().float() if gamma is not None else None
         beta_c = beta.detach().contiguous().float() if beta is not None else None
-        parts = _moment_partials(h)
+        # (the statistics pass also bumps num_batches_tracked, one launch before the finalize kernel reads it)
+        parts = _moment_partials(h, count_inc=n_tracked if running_mean is not None else None)
         res = residual.contiguous() if residual is not None else None
         with _device_guard(dev):
             stats = torch.empty((3, c), dtype=torch.float64, device=dev)     # mean | biased variance | 1 / std
@@ -820,12 +823,15 @@ def batch_norm_act_residual(h, residual, gamma, beta, eps: float, relu: bool, ru
     (_BatchNormActResidualFunction): returns (out, batch mean [C] float64, biased batch variance [C] float64).
     With ``running_mean`` / ``running_var`` (float32 [C], dense) the running statistics are updated in the same launch
     that finishes the batch statistics, as nn.BatchNorm1d does: unbiased variance, ``momentum``, or -- momentum None --
-    the cumulative average over ``num_batches_tracked`` (a device int64 scalar the CALLER has already incremented).
+    the cumulative average over ``num_batches_tracked`` (a device int64 scalar, INCREMENTED here when given).
     ``keep`` / ``keep_scale``: dropout between the activation and the residual add (see the Function)."""
     c = h.size(1)
     if running_mean is not None and not (_f32_vec(running_mean, c) and _f32_vec(running_var, c)
                                          and (momentum is not None or num_batches_tracked is not None)):
         raise RuntimeError("egc_amd: running statistics must be dense float32 [C] tensors")
+    if num_batches_tracked is not None and (num_batches_tracked.dtype != torch.int64 or num_batches_tracked.numel() != 1
+                                            or num_batches_tracked.device != h.device):
+        raise RuntimeError("egc_amd: num_batches_tracked must be an int64 scalar on the device of h")
     if keep is not None and (keep.dtype != torch.uint8 or keep.shape != h.shape or not keep.is_contiguous()
                              or keep.device != h.device):
         raise RuntimeError("egc_amd: the dropout mask must be a dense uint8 tensor of the shape of h")

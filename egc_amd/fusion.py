@@ -70,13 +70,14 @@ class FusedEGCBlock(nn.Module):
         track = bn.training and bn.track_running_stats
         in_place = (track and bn.running_mean.dtype == torch.float32 and bn.running_mean.is_contiguous()
                     and bn.running_var.dtype == torch.float32 and bn.running_var.is_contiguous())
-        if track:
+        counted = in_place and bn.num_batches_tracked is not None and bn.num_batches_tracked.dtype == torch.int64
+        if track and not counted:
             with torch.no_grad():
-                bn.num_batches_tracked += 1      # (a device scalar: the kernel reads it, nothing comes back to the host)
+                bn.num_batches_tracked += 1      # (else: bumped by the statistics pass, on the device)
         out, mean, var = batch_norm_act_residual(
             h, identity if self.residual else None, bn.weight if bn.affine else None, bn.bias if bn.affine else None, bn.eps,
             self.relu, bn.running_mean if in_place else None, bn.running_var if in_place else None, bn.momentum,
-            bn.num_batches_tracked if in_place else None, keep, 1.0 / (1.0 - self.dropout))
+            bn.num_batches_tracked if counted else None, keep, 1.0 / (1.0 - self.dropout))
         if track and not in_place:               # running statistics kept in another dtype: torch's arithmetic
             with torch.no_grad():
                 n = h.size(0)

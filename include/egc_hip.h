@@ -314,6 +314,8 @@ int egc_weight_grad_f32(const float* x, int64_t ldx, const float* d, int64_t ldd
  *                               (the last factor only with relu != 0; backward: a =
  *                               dout, b = h; the ReLU mask is recomputed from h, not stored), giving the two sums of
  *                               the BatchNorm backward.  partials: n_partials * 2 * cols doubles, 32-byte aligned.
+ *                               count_inc (device int64, may be NULL) is incremented by one: nn.BatchNorm1d's
+ *                               num_batches_tracked, bumped one launch before egc_bn_forward_finalize reads it.
  *   egc_bn_forward_finalize     everything per channel between the two forward passes, in one launch: the partials
  *                               added in a fixed order, stats = [mean | biased variance | 1/sqrt(var + eps)] (3 * cols
  *                               doubles), affine = [scale | shift] (2 * cols floats) for the elementwise pass, and --
@@ -328,7 +330,7 @@ int egc_weight_grad_f32(const float* x, int64_t ldx, const float* d, int64_t ldd
  *                               with its two sums folded into the three per-channel coefficient vectors. */
 int egc_column_moments_f64(const float* a, const float* b, const float* scale, const float* shift, int32_t relu,
                            const uint8_t* keep, float keep_scale, int64_t n_rows, int32_t cols, double* partials,
-                           int32_t n_partials, egc_stream_t stream);
+                           int32_t n_partials, int64_t* count_inc, egc_stream_t stream);
 int egc_bn_forward_finalize(const double* partials, int32_t n_partials, int32_t cols, int64_t n_rows, const float* gamma,
                             const float* beta, double eps, double* stats, float* affine, float* running_mean,
                             float* running_var, double momentum, const int64_t* n_tracked, egc_stream_t stream);
