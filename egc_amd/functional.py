@@ -51,6 +51,49 @@ def pad_bases_columns(w: torch.Tensor, num_bases: int, basis_len: int, basis_str
     return torch.nn.functional.pad(w.reshape(f_in, num_bases, basis_len), (0, basis_stride - basis_len)).reshape(f_in, -1)
 
 
+def _pack_params(dims, permute, comb_w, comb_b, bases):
+    """(wcat [f_in, B Ls + H B A], bcat [H B A] or None) from the parameters: one launch (egc_weights_pack_f32)."""
+    lib = _C.load()
+    f_in, H, A, B, L, Ls = dims
+    dev = comb_w.device
+    parts = [b.contiguous() for b in bases]
+    cw = comb_w.contiguous()
+    cb = comb_b.contiguous() if comb_b is not None else None
+    ptrs = (C.c_void_p * len(parts))(*[p.data_ptr() for p in parts])
+    with _device_guard(dev):
+        wcat = torch.empty((f_in, B * Ls + H * B * A), dtype=torch.float32, device=dev)
+        bcat = torch.empty(H * B * A, dtype=torch.float32, device=dev) if cb is not None else None
+        _C.check(lib.egc_weights_pack_f32(ptrs, len(parts), cw.data_ptr(), cb.data_ptr() if cb is not None else None,
+                                          f_in, H, A, B, L, Ls, int(permute), wcat.data_ptr(),
+                                          bcat.data_ptr() if bcat is not None else None, 0, _stream_ptr(dev)),
+                 "egc_weights_pack_f32")
+    return wcat, bcat
+
+
+def _unpack_param_grads(dims, permute, shapes, has_b, dwcat, dbcat):
+    """The parameters' gradients (d comb_w, d comb_b or None, [d basis matrices]) from (d wcat, d bcat): the same index
+    map read the other way, one launch."""
+    lib = _C.load()
+    f_in, H, A, B, L, Ls = dims
+    dev = dwcat.device if dwcat is not None else dbcat.device
+    with _device_guard(dev):
+        if dwcat is None:
+            dwcat = torch.zeros((f_in, B * Ls + H * B * A), dtype=torch.float32, device=dev)
+        dwcat = dwcat.contiguous()
+        dcw = torch.empty(shapes[0], dtype=torch.float32, device=dev)
+        dcb = dbc = None
+        if has_b:
+            dbc = (dbcat if dbcat is not None else torch.zeros(H * B * A, dtype=torch.float32, device=dev)).contiguous()
+            dcb = torch.empty(shapes[1], dtype=torch.float32, device=dev)
+        dparts = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in shapes[2]]
+        ptrs = (C.c_void_p * len(dparts))(*[p.data_ptr() for p in dparts])
+        _C.check(lib.egc_weights_pack_f32(ptrs, len(dparts), dcw.data_ptr(), dcb.data_ptr() if dcb is not None else None,
+                                          f_in, H, A, B, L, Ls, int(permute), dwcat.data_ptr(),
+                                          dbc.data_ptr() if dbc is not None else None, 1, _stream_ptr(dev)),
+                 "egc_weights_pack_f32")
+    return dcw, dcb, dparts
+
+
 class _PackWeightsFunction(torch.autograd.Function):
     """(wcat, bcat) = the GEMM operand of a layer from its parameters, and the parameters' gradients from (d wcat,
     d bcat): one launch each way (egc_weights_pack_f32) instead of the cat / pad / permute / transpose chain and its
@@ -59,21 +102,8 @@ class _PackWeightsFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, dims, permute, comb_w, comb_b, *bases):
-        lib = _C.load()
-        f_in, H, A, B, L, Ls = dims
-        dev = comb_w.device
-        parts = [b.contiguous() for b in bases]
-        cw = comb_w.contiguous()
-        cb = comb_b.contiguous() if comb_b is not None else None
-        ptrs = (C.c_void_p * len(parts))(*[p.data_ptr() for p in parts])
-        with _device_guard(dev):
-            wcat = torch.empty((f_in, B * Ls + H * B * A), dtype=torch.float32, device=dev)
-            bcat = torch.empty(H * B * A, dtype=torch.float32, device=dev) if cb is not None else None
-            _C.check(lib.egc_weights_pack_f32(ptrs, len(parts), cw.data_ptr(), cb.data_ptr() if cb is not None else None,
-                                              f_in, H, A, B, L, Ls, int(permute), wcat.data_ptr(),
-                                              bcat.data_ptr() if bcat is not None else None, 0, _stream_ptr(dev)),
-                     "egc_weights_pack_f32")
-        ctx.dims, ctx.permute, ctx.has_b = dims, permute, cb is not None
+        wcat, bcat = _pack_params(dims, permute, comb_w, comb_b, bases)
+        ctx.dims, ctx.permute, ctx.has_b = dims, permute, comb_b is not None
         ctx.shapes = (comb_w.shape, comb_b.shape if comb_b is not None else None, [b.shape for b in bases])
         if bcat is None:
             bcat = wcat.new_empty(0)
@@ -82,24 +112,7 @@ class _PackWeightsFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dwcat, dbcat):
-        lib = _C.load()
-        f_in, H, A, B, L, Ls = ctx.dims
-        dev = dwcat.device if dwcat is not None else dbcat.device
-        with _device_guard(dev):
-            if dwcat is None:
-                dwcat = torch.zeros((f_in, B * Ls + H * B * A), dtype=torch.float32, device=dev)
-            dwcat = dwcat.contiguous()
-            dcw = torch.empty(ctx.shapes[0], dtype=torch.float32, device=dev)
-            dcb = dbc = None
-            if ctx.has_b:
-                dbc = (dbcat if dbcat is not None else torch.zeros(H * B * A, dtype=torch.float32, device=dev)).contiguous()
-                dcb = torch.empty(ctx.shapes[1], dtype=torch.float32, device=dev)
-            dparts = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in ctx.shapes[2]]
-            ptrs = (C.c_void_p * len(dparts))(*[p.data_ptr() for p in dparts])
-            _C.check(lib.egc_weights_pack_f32(ptrs, len(dparts), dcw.data_ptr(), dcb.data_ptr() if dcb is not None else None,
-                                              f_in, H, A, B, L, Ls, int(ctx.permute), dwcat.data_ptr(),
-                                              dbc.data_ptr() if dbc is not None else None, 1, _stream_ptr(dev)),
-                     "egc_weights_pack_f32")
+        dcw, dcb, dparts = _unpack_param_grads(ctx.dims, ctx.permute, ctx.shapes, ctx.has_b, dwcat, dbcat)
         return (None, None, dcw, dcb, *dparts)
 
 
@@ -609,45 +622,83 @@ class _EGCLayerFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, wcat, bcat, bias, graph, spec):
-        bases, weightings = egc_basis_transform(graph, spec, x, wcat, bcat, None)
-        if graph.halo is not None and graph.n_src_rows > graph.n_nodes:
-            graph.halo.exchange(bases)   # vertex partition: halo rows of `bases` from their owners
-        out, saved = egc_aggregate_combine_train(graph, spec, bases, weightings, bias)
-        ctx.save_for_backward(x, wcat, bases, weightings)
-        ctx.graph, ctx.spec, ctx.saved = graph, spec, saved
-        ctx.has_bcat, ctx.has_bias = bcat is not None, bias is not None
-        return out
+        return _layer_train_forward(ctx, x, wcat, bcat, bias, graph, spec)
 
     @staticmethod
     def backward(ctx, grad_out):
-        x, wcat, bases, weightings = ctx.saved_tensors
-        spec = ctx.spec
-        grad_out = grad_out.contiguous()
-        d_bases, d_w, d_cat = egc_aggregate_combine_backward(ctx.graph, spec, bases, weightings, grad_out, ctx.saved,
-                                                             joint=spec.ldb == spec.f_g)
-        halo = ctx.graph.halo
-        if halo is not None and ctx.graph.n_src_rows > ctx.graph.n_nodes:
-            # gradients collected for other ranks' vertices go home (reverse all-to-all-v) and are added there
-            back = halo.exchange_reverse(d_bases)
-            d_bases = d_bases[:ctx.graph.n_nodes].index_add(0, halo.send_idx, back)
-        if d_cat is None:
-            d_cat = torch.cat([d_bases[:, :spec.f_g], d_w], dim=1)         # [N, F_g + W]
-        dx = _dx_matmul(d_cat, wcat) if ctx.needs_input_grad[0] else None
-        need_bcat = ctx.has_bcat and ctx.needs_input_grad[2]
-        need_bias = ctx.has_bias and ctx.needs_input_grad[3]
-        dwcat = dbcat = dbias = None
-        if ctx.needs_input_grad[1]:
-            # the column sums of d_w (comb bias) and of grad_out (the layer's bias) ride along with x^T d_cat
-            if need_bias and need_bcat:
-                dwcat, sums, dbias = _weight_grads(x, d_cat, col_sums=True, extra=grad_out)
-            else:
-                dwcat, sums = _weight_grads(x, d_cat, col_sums=need_bcat)
-            dbcat = sums[d_cat.size(1) - spec.w_cols:] if need_bcat else None
-        elif need_bcat:
-            dbcat = _column_sums(d_w)
-        if need_bias and dbias is None:
-            dbias = _column_sums(grad_out)
+        need = ctx.needs_input_grad
+        dx, dwcat, dbcat, dbias = _layer_train_backward(ctx, grad_out, need[0], need[1], ctx.has_bcat and need[2],
+                                                        ctx.has_bias and need[3])
         return dx, dwcat, dbcat, dbias, None, None
+
+
+def _layer_train_forward(ctx, x, wcat, bcat, bias, graph, spec):
+    bases, weightings = egc_basis_transform(graph, spec, x, wcat, bcat, None)
+    if graph.halo is not None and graph.n_src_rows > graph.n_nodes:
+        graph.halo.exchange(bases)   # vertex partition: halo rows of `bases` from their owners
+    out, saved = egc_aggregate_combine_train(graph, spec, bases, weightings, bias)
+    ctx.save_for_backward(x, wcat, bases, weightings)
+    ctx.graph, ctx.spec, ctx.saved = graph, spec, saved
+    ctx.has_bcat, ctx.has_bias = bcat is not None, bias is not None
+    return out
+
+
+def _layer_train_backward(ctx, grad_out, need_x, need_wcat, need_bcat, need_bias):
+    """(dx, d wcat, d bcat, d bias) of the fused layer; what is not needed is None."""
+    x, wcat, bases, weightings = ctx.saved_tensors
+    spec = ctx.spec
+    grad_out = grad_out.contiguous()
+    d_bases, d_w, d_cat = egc_aggregate_combine_backward(ctx.graph, spec, bases, weightings, grad_out, ctx.saved,
+                                                         joint=spec.ldb == spec.f_g)
+    halo = ctx.graph.halo
+    if halo is not None and ctx.graph.n_src_rows > ctx.graph.n_nodes:
+        # gradients collected for other ranks' vertices go home (reverse all-to-all-v) and are added there
+        back = halo.exchange_reverse(d_bases)
+        d_bases = d_bases[:ctx.graph.n_nodes].index_add(0, halo.send_idx, back)
+    if d_cat is None:
+        d_cat = torch.cat([d_bases[:, :spec.f_g], d_w], dim=1)         # [N, F_g + W]
+    dx = _dx_matmul(d_cat, wcat) if need_x else None
+    dwcat = dbcat = dbias = None
+    if need_wcat:
+        # the column sums of d_w (comb bias) and of grad_out (the layer's bias) ride along with x^T d_cat
+        if need_bias and need_bcat:
+            dwcat, sums, dbias = _weight_grads(x, d_cat, col_sums=True, extra=grad_out)
+        else:
+            dwcat, sums = _weight_grads(x, d_cat, col_sums=need_bcat)
+        dbcat = sums[d_cat.size(1) - spec.w_cols:] if need_bcat else None
+    elif need_bcat:
+        dbcat = _column_sums(d_w)
+    if need_bias and dbias is None:
+        dbias = _column_sums(grad_out)
+    return dx, dwcat, dbcat, dbias
+
+
+class _EGCLayerParamsFunction(torch.autograd.Function):
+    """_PackWeightsFunction and _EGCLayerFunction as ONE autograd node: the layer straight from the module's parameters
+    (comb weight, comb bias, basis matrices), their gradients straight back -- one ``apply`` and one backward node per
+    layer instead of two (a small batch's training step is bound by exactly that).
+    ``comb_b`` goes through the pack (EGConv: rows permuted with the weight's); ``bcat_direct`` is a combination bias
+    already in the operand's order (EfficientGraphConv), used and differentiated as it is."""
+
+    @staticmethod
+    def forward(ctx, x, bias, comb_w, comb_b, bcat_direct, graph, spec, dims, permute, *bases):
+        wcat, bcat = _pack_params(dims, permute, comb_w, comb_b, bases)
+        ctx.dims, ctx.permute, ctx.packed_b = dims, permute, comb_b is not None
+        ctx.shapes = (comb_w.shape, comb_b.shape if comb_b is not None else None, [b.shape for b in bases])
+        return _layer_train_forward(ctx, x, wcat, bcat if comb_b is not None else bcat_direct, bias, graph, spec)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        need = ctx.needs_input_grad
+        need_w = need[2] or any(need[9:])
+        need_b = ctx.has_bcat and (need[3] if ctx.packed_b else need[4])
+        dx, dwcat, dbcat, dbias = _layer_train_backward(ctx, grad_out, need[0], need_w, need_b, ctx.has_bias and need[1])
+        dcw = dcb = None
+        dparts = [None] * len(ctx.shapes[2])
+        if need_w or (need_b and ctx.packed_b):
+            dcw, dcb, dparts = _unpack_param_grads(ctx.dims, ctx.permute, ctx.shapes, ctx.packed_b, dwcat,
+                                                   dbcat if ctx.packed_b else None)
+        return (dx, dbias, dcw, dcb, None if ctx.packed_b else dbcat, None, None, None, None, *dparts)
 
 
 class _DenseTransformFunction(torch.autograd.Function):
@@ -844,6 +895,14 @@ def egc_aggregate_combine_apply(graph, spec, bases, weightings, bias=None):
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (bases, weightings, bias)):
         return _AggregateCombineFunction.apply(bases, weightings, bias, graph, spec)
     return egc_aggregate_combine(graph, spec, bases, weightings, bias)
+
+
+def egc_layer_apply_params(graph, spec, x, bias, comb_w, comb_b, bcat_direct, bases, f_in, H, A, B, L, Ls, permute_hab):
+    """The training-path layer call from the module parameters (one autograd node: _EGCLayerParamsFunction).  ``bases``:
+    one [f_in, B L] matrix or B [f_in, L] matrices; ``comb_b`` a combination bias to permute with the weight's rows,
+    ``bcat_direct`` one already in the operand's order (pass exactly one of the two, or neither)."""
+    return _EGCLayerParamsFunction.apply(x, bias, comb_w, comb_b, bcat_direct, graph, spec,
+                                         (int(f_in), int(H), int(A), int(B), int(L), int(Ls)), bool(permute_hab), *bases)
 
 
 def egc_layer_apply(graph, spec, x, wcat, bcat, bias, packed=None):

@@ -19,8 +19,9 @@ import torch
 import torch.nn as nn
 
 from . import _C
-from .functional import (egc_layer_apply, gemm_exact, make_spec, pack_layer_weights, pack_weights, pad_bases_columns,
-                         padded_basis_stride)
+from . import ops
+from .functional import (egc_layer_apply, egc_layer_apply_params, gemm_exact, make_spec, pack_layer_weights, pack_weights,
+                         pad_bases_columns, padded_basis_stride)
 from .graph import SparseTensor, graph_from_input
 
 _AGGR_CODE = {"add": _C.AGGR_SUM, "mean": _C.AGGR_MEAN, "max": _C.AGGR_MAX, "min": _C.AGGR_MIN,
@@ -136,6 +137,16 @@ class EfficientGraphConv(nn.Module):
             graph = graph_from_input(edge_index, x.size(0))
             if self.cache:
                 self._cached_graph = graph.trim_launches()
+        w = self.comb_weights.weight
+        params = list(self.bases_weight._parameters.values())
+        if (torch.is_grad_enabled() and w.is_cuda and w.dtype == torch.float32 and self.num_bases <= 32
+                and x.is_cuda and (w.requires_grad or any(p.requires_grad for p in params)) and not ops.use_torch_op()):
+            # training: parameters in, parameter gradients out, one autograd node (pack + layer + unpack)
+            sp = self._spec
+            A = w.size(0) // (self.num_heads * self.num_bases)
+            return egc_layer_apply_params(graph, sp, x, self.bias, w, None, self.comb_weights.bias, params,
+                                          self.in_channels, self.num_heads, A, self.num_bases, sp.basis_len,
+                                          sp.basis_stride, False)
         wcat = self._packed_weights()
         return egc_layer_apply(graph, self._spec, x, wcat, self.comb_weights.bias, self.bias,
                                packed=self._weight_planes(wcat))

@@ -22,8 +22,9 @@ import torch
 import torch.nn as nn
 
 from . import _C
-from .functional import (egc_layer_apply, gemm_exact, make_spec, pack_egconv_weights, pack_weights, pad_bases_columns,
-                         padded_basis_stride)
+from . import ops
+from .functional import (egc_layer_apply, egc_layer_apply_params, gemm_exact, make_spec, pack_egconv_weights, pack_weights,
+                         pad_bases_columns, padded_basis_stride)
 from .graph import CSRGraph, SparseTensor, graph_from_input
 from .layers import glorot_
 
@@ -130,6 +131,12 @@ class EGConv(nn.Module):
             spec = self._spec_coo if is_coo else self._spec_adj
             if self.cached:
                 self._cached_graph = (graph.trim_launches(), spec)
+        bw, cw, cb = self.bases_weight, self.comb_weight.weight, self.comb_weight.bias
+        if (torch.is_grad_enabled() and bw.is_cuda and bw.dtype == torch.float32 and cb is not None and x.is_cuda
+                and (bw.requires_grad or cw.requires_grad or cb.requires_grad) and not ops.use_torch_op()):
+            # training: parameters in, parameter gradients out, one autograd node (pack + layer + unpack)
+            return egc_layer_apply_params(graph, spec, x, self.bias, cw, cb, None, [bw], self.in_channels, self.num_heads,
+                                          len(self.aggregators), self.num_bases, spec.basis_len, spec.basis_stride, True)
         wcat, bcat = self._packed_weights()
         return egc_layer_apply(graph, spec, x, wcat, bcat, self.bias, packed=self._weight_planes(spec, wcat))
 
