@@ -321,3 +321,37 @@ def test_trained_reference_shapes_gradients(hidden, H, B, aggrs):
     assert _rel(x.grad, x64.grad) <= gtol(aggrs)
     for k, v in conv.named_parameters():
         assert _rel(v.grad, p64[k].grad) <= gtol(aggrs), k
+
+
+@pytest.mark.parametrize("kind", ["opt", "lay"])
+def test_frozen_parameters_take_the_operand_level_node_and_agree(kind):
+    """With trainable parameters the modules run pack + layer + unpack as one autograd node (_EGCLayerParamsFunction);
+    with frozen parameters (fine-tuning a head, saliency maps) the cached operand goes through _EGCLayerFunction.
+    Same d out / d x either way; the frozen layer produces no parameter gradients."""
+    import egc_amd
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    n, hidden = 700, 64
+    ei = torch.from_numpy(rng.integers(0, n, size=(2, 6000))).to(dev)
+    torch.manual_seed(1)
+    if kind == "opt":
+        layer = egc_amd.EGConv(hidden, hidden, aggrs=["sum", "max", "symnorm"], num_heads=4, num_bases=4).to(dev)
+    else:
+        layer = egc_amd.EfficientGraphConv(hidden, hidden, 4, 4, False, aggrs=["add", "max", "symadd"]).to(dev)
+    x = torch.randn(n, hidden, device=dev)
+    gout = torch.randn(n, hidden, device=dev)
+    call = (lambda t: layer(t, ei)) if kind == "opt" else (lambda t: layer(x=t, edge_index=ei))
+    xa = x.clone().requires_grad_(True)
+    out_a = call(xa)
+    out_a.backward(gout)
+    assert all(p.grad is not None for p in layer.parameters())
+    for p in layer.parameters():
+        p.requires_grad_(False)
+        p.grad = None
+    xb = x.clone().requires_grad_(True)
+    out_b = call(xb)
+    out_b.backward(gout)
+    assert all(p.grad is None for p in layer.parameters())
+    assert torch.equal(out_a.detach(), out_b.detach())
+    scale = max(1.0, float(xa.grad.abs().max()))
+    assert float((xa.grad - xb.grad).abs().max()) <= 1e-6 * scale
