@@ -47,7 +47,10 @@ class GraphedStep:
     Do not set these ``.grad`` to None between replays (``zero_grad(set_to_none=False)`` or nothing at all).
 
     ``warmup`` eager runs on a side stream come first (torch's recipe): one-time work -- kernel attribute calls,
-    workspaces cached on graph objects, the allocator's pools -- must not land in the recording."""
+    workspaces cached on graph objects, the allocator's pools -- must not land in the recording.  They are real calls
+    of ``fn``: a step that also runs the optimizer (``torch.optim.Adam(..., capturable=True)`` followed by
+    ``zero_grad(set_to_none=False)`` -- the whole iteration is then one replay, parameters bit-identical to the eager
+    loop's, tests/test_hipgraph_gpu.py) has trained ``warmup + 1`` iterations when the constructor returns."""
 
     def __init__(self, fn: Callable[[], None], params: Optional[Iterable[torch.nn.Parameter]] = None, warmup: int = 3,
                  pool=None):

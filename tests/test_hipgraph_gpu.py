@@ -132,3 +132,52 @@ def test_per_batch_graph_build_inside_the_recording(helper):
             p.grad = h
         for a, b in zip(got, ref):
             assert _rel(a, b) <= 1e-6
+
+
+def test_whole_iteration_with_the_optimizer_in_the_recording():
+    """forward + loss + backward + Adam (capturable) + zero_grad as ONE recording: after k replays the parameters equal
+    those of k eager iterations from the same start, bit for bit.  (GraphedStep's warm-up runs are real calls of the
+    step: here the start state is restored after the recording to compare like with like.)"""
+    import copy
+    import egc_amd
+    from egc_amd import workloads as wl
+    dev = torch.device("cuda:0")
+    _, ei, n, _ = wl.zinc_like_batch(32, seed=2)
+    ei = ei.to(dev)
+    x = torch.randn(n, 64, device=dev)
+    tgt = torch.randn(n, 64, device=dev)
+
+    def run(recorded, k=6):
+        blocks = _blocks(dev, "opt")
+        params = list(blocks.parameters())
+        opt = torch.optim.Adam(params, lr=1e-2, capturable=True, foreach=True)
+        start = copy.deepcopy(blocks.state_dict())
+
+        def step():
+            h = x
+            for b in blocks:
+                h = b(h, ei)
+            ((h - tgt) ** 2).mean().backward()
+            opt.step()
+            opt.zero_grad(set_to_none=False)
+        if not recorded:
+            for p in params:
+                p.grad = torch.zeros_like(p)
+            for _ in range(k):
+                step()
+        else:
+            g = egc_amd.GraphedStep(step, params=params, warmup=2)
+            blocks.load_state_dict(start)
+            for st in opt.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+            for p in params:
+                p.grad.zero_()
+            for _ in range(k):
+                g()
+        torch.cuda.synchronize()
+        return [p.detach().clone() for p in params] + [b.bn.running_var.clone() for b in blocks]
+
+    for a, b in zip(run(True), run(False)):
+        assert torch.equal(a, b)
