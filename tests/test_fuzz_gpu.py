@@ -4,8 +4,12 @@ self-loops, duplicate edges, isolated nodes, exact ties, empty edge lists), HIP 
 for a quarter of the cases, every gradient against float64 autograd through the torch restatement.
 
 Tolerance: 1e-5 (north_star) scale-relative for the forward; 1e-4 where the layer has `std` / `var`, whose
-`sqrt(relu(E[x^2] - E[x]^2) + 1e-5)` amplifies last-bit differences of `bases` between two correct GEMMs by up to
-158x on (nearly) constant neighbourhoods; 5e-4 for gradients (fp32 atomics vs float64)."""
+`sqrt(relu(E[x^2] - E[x]^2) + 1e-5)` amplifies last-bit differences between two correct fp32 evaluations (and the
+2^-22 operand rounding of the split-precision GEMM) by up to 158x on (nearly) constant neighbourhoods (DESIGN.md
+section 1).  Cases beyond 1e-4 -- seeds 101 / 109 / 118, kept from a longer sweep: a one-node graph with a dozen
+self-loops under `std`, 1e-4 .. 2.4e-4 -- must meet the criterion that does not depend on the evaluation order: against
+the same layer in float64, no further off than the fp32 restatement of the reference (x2, + 1e-5).  5e-4 for gradients
+(fp32 atomics vs float64)."""
 import numpy as np
 import pytest
 import torch
@@ -17,7 +21,22 @@ from oracle import egc_torch_ref as tref
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed,generic", [(11, False), (12, False), (13, False), (14, True), (15, True)])
+def _truth64(tref, kind, layer, x, ei, H, B, names, flags, asl):
+    """The layer in float64 through the torch restatement (parameters and input promoted)."""
+    p64 = {k: v.detach().double().cpu() for k, v in layer.named_parameters()}
+    x64 = torch.from_numpy(x).double()
+    with torch.no_grad():
+        if kind == "opt":
+            return tref.egconv_forward(x64, ei, p64["bases_weight"], p64["comb_weight.weight"], p64["comb_weight.bias"], p64["bias"],
+                                       H, B, names, add_self_loops=asl, sigmoid=flags.get("sigmoid", False))
+        return tref.efficient_graph_conv_forward(x64, ei, [p64[f"bases_weight.{b}"] for b in range(B)], p64["comb_weights.weight"],
+                                                 p64["comb_weights.bias"], p64["bias"], H, names, softmax=flags.get("softmax", False),
+                                                 hardtanh=flags.get("hardtanh", False), sigmoid=flags.get("sigmoid", False),
+                                                 add_self_loops=asl)
+
+
+@pytest.mark.parametrize("seed,generic", [(11, False), (12, False), (13, False), (14, True), (15, True), (101, False), (109, False),
+                                          (118, False)])
 def test_random_layers_and_graphs_match_the_oracles(seed, generic, monkeypatch):
     import egc_amd
     if generic:   # the generic forward kernels + separate arg pass, and the run-time forms of the backward kernels
@@ -87,8 +106,18 @@ def test_random_layers_and_graphs_match_the_oracles(seed, generic, monkeypatch):
                 out = layer(xt, arg) if kind == "opt" else layer(x=xt, edge_index=arg)
             if out is not None:
                 err = rel_err(out.cpu().numpy(), ref); worst = max(worst, err)
-                tol = 1e-4 if any(a in ('std', 'var') for a in names) else 1e-5
-                if not err <= tol: fails.append(("fwd", case, kind, H, B, L, fin, names, n, e, flags, asl, err))
+                stdvar = any(a in ('std', 'var') for a in names)
+                ok = err <= (1e-4 if stdvar else 1e-5)
+                if not ok and stdvar:
+                    # two correct fp32 evaluations of sqrt(relu(E[x^2] - E[x]^2) + 1e-5) may be 1e-3 apart on (nearly)
+                    # constant neighbourhoods -- e.g. one node with a dozen self-loops; beyond 1e-4 the criterion is
+                    # the one that does not depend on the evaluation order: against the same layer in float64 the HIP
+                    # result is no further off than the fp32 restatement of the reference's arithmetic (x2, + 1e-5)
+                    truth = _truth64(tref, kind, layer, x, ei, H, B, names, flags, asl).numpy()
+                    e_hip, e_ref = rel_err(out.cpu().numpy(), truth), rel_err(ref, truth)
+                    ok = e_hip <= 2.0 * e_ref + 1e-5
+                    err = (err, e_hip, e_ref)
+                if not ok: fails.append(("fwd", case, kind, H, B, L, fin, names, n, e, flags, asl, err))
             # gradients for a subset (float64 torch reference); skip std/var/max/min kinks at exact ties
             if case % 4 == 0 and n <= 900 and not any(a in ("std", "var") for a in names):
                 xg = torch.from_numpy(x).to(dev).requires_grad_(True)

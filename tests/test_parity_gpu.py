@@ -594,9 +594,11 @@ def test_multi_chunk_hub_rows_with_few_slots_on_small_graphs(hidden, H, B, kind,
 def test_std_var_layers_are_as_accurate_as_the_fp32_restatement(kind, aggrs, near_constant):
     """Where the parity tests allow 1e-4 for `std` / `var` layers (sqrt(relu(E[x^2] - E[x]^2) + 1e-5) amplifies last-bit
     differences between two correct fp32 evaluations), this pins the HIP path the other way round: against the SAME layer
-    evaluated in float64, its error is no larger than that of the fp32 restatement of the reference's arithmetic
-    (oracle/egc_oracle.py; x2 + the 1e-5 of north_star as slack) -- on random inputs and on nearly constant
-    neighbourhoods, the worst case of the cancellation."""
+    evaluated in float64, its error on these inputs is no larger than that of the fp32 restatement of the reference's
+    arithmetic (oracle/egc_oracle.py; x2 + the 1e-5 of north_star as slack) -- on random inputs and on nearly constant
+    neighbourhoods, the worst case of the cancellation.  Not a universal bound: the randomised sweep finds small
+    graphs where the split-precision GEMM's 2^-22 operand rounding, amplified the same way, leaves the HIP result a few
+    times further from float64 than the restatement (7e-5 against 2e-5); those stay inside the 1e-4 of the sweep."""
     import egc_amd
     from oracle import egc_torch_ref as tref
     dev = _dev()
