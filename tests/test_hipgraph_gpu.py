@@ -181,3 +181,42 @@ def test_whole_iteration_with_the_optimizer_in_the_recording():
 
     for a, b in zip(run(True), run(False)):
         assert torch.equal(a, b)
+
+
+def test_recorded_step_on_a_graph_with_hub_rows():
+    """Hub rows go through the long-row chunk role: arrival counters in the workspace (zero on entry, zero on exit),
+    partial records, float atomics in the backward's hub rows.  Replays of one recording must keep giving the eager
+    step's result (to rounding: the hub rows' backward sums are order-dependent)."""
+    import egc_amd
+    from egc_amd.workloads import heavy_tailed_graph
+    dev = torch.device("cuda:0")
+    n = 20000
+    ei = heavy_tailed_graph(n, 160000, seed=4).to(dev)
+    deg = torch.bincount(ei[1], minlength=n)
+    assert int(deg.max()) > 2000                     # rows well above the long-row threshold
+    blocks = _blocks(dev, "opt")
+    params = list(blocks.parameters())
+    graph = egc_amd.CSRGraph.from_edge_index(ei, n)          # capacity-sized launches: nothing read back
+    x = torch.randn(n, 64, device=dev)
+    gout = torch.randn(n, 64, device=dev)
+
+    def step():
+        h = x
+        for b in blocks:
+            h = b(h, graph)
+        h.backward(gout)
+
+    graphed = egc_amd.GraphedStep(step, params=params)
+    for trial in range(4):
+        x.copy_(torch.randn(n, 64, device=dev))
+        graphed()
+        got = _grads(params)
+        held = [p.grad for p in params]
+        for p in params:
+            p.grad = None
+        step()
+        ref = _grads(params)
+        for p, h in zip(params, held):
+            p.grad = h
+        for a, b in zip(got, ref):      # (a conv bias in front of a BatchNorm has a zero gradient: absolute floor)
+            assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max())), trial
