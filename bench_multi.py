@@ -16,7 +16,6 @@ from __future__ import annotations
 import ctypes as C
 import json
 import os
-import sys
 import time
 
 import torch

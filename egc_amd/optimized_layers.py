@@ -25,7 +25,7 @@ from . import _C
 from . import ops
 from .functional import (egc_layer_apply, egc_layer_apply_params, gemm_exact, make_spec, pack_egconv_weights, pack_weights,
                          pad_bases_columns, padded_basis_stride)
-from .graph import CSRGraph, SparseTensor, graph_from_input
+from .graph import graph_from_input
 from .layers import glorot_
 
 _AGGR_CODE = {"sum": _C.AGGR_SUM, "mean": _C.AGGR_MEAN, "symnorm": _C.AGGR_SYMNORM, "min": _C.AGGR_MIN,
