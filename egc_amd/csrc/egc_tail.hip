@@ -37,8 +37,11 @@ __global__ void __launch_bounds__(256) column_moments_kernel(const float* __rest
                                                              int64_t n_rows, int cols, int rows_per_block,
                                                              double* __restrict__ out, int relu,
                                                              const unsigned char* __restrict__ keep, float keep_scale,
-                                                             int64_t* __restrict__ count_inc) {
+                                                             int64_t* __restrict__ count_inc,
+                                                             const int64_t* __restrict__ n_valid) {
   __shared__ d4 red[2][256];
+  // rows [*n_valid, n_rows) are padding (a batch padded to the static shape of a hipGraph recording): not counted
+  if (n_valid != nullptr) n_rows = min(n_rows, max(*n_valid, (int64_t)0));
   // BatchNorm's num_batches_tracked: bumped here, one launch BEFORE the finalize kernel reads it
   if (count_inc != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *count_inc += 1;
   const int cg = cols >> 2;                 // 16-byte column groups (<= 256)
@@ -103,8 +106,10 @@ __global__ void __launch_bounds__(256) bn_forward_finalize_kernel(const double* 
                                                                   double* __restrict__ stats, float* __restrict__ affine,
                                                                   float* __restrict__ running_mean,
                                                                   float* __restrict__ running_var, double momentum,
-                                                                  const int64_t* __restrict__ n_tracked) {
+                                                                  const int64_t* __restrict__ n_tracked,
+                                                                  const int64_t* __restrict__ n_valid) {
   __shared__ double red[2][16][17];
+  if (n_valid != nullptr) n_rows = fmax(fmin(n_rows, (double)*n_valid), 1.0);
   const int col = blockIdx.x * 16 + (threadIdx.x & 15), pl = threadIdx.x >> 4;
   double s1, s2;
   moment_totals(partials, n_partials, cols, col, pl, red, s1, s2);
@@ -122,7 +127,7 @@ __global__ void __launch_bounds__(256) bn_forward_finalize_kernel(const double* 
   if (running_mean != nullptr) {
     const double m = momentum >= 0.0 ? momentum : 1.0 / (double)(*n_tracked);
     running_mean[col] = (float)((1.0 - m) * (double)running_mean[col] + m * mean);
-    running_var[col] = (float)((1.0 - m) * (double)running_var[col] + m * var * (n_rows / (n_rows - 1.0)));
+    running_var[col] = (float)((1.0 - m) * (double)running_var[col] + m * var * (n_rows > 1.0 ? n_rows / (n_rows - 1.0) : 1.0));
   }
 }
 
@@ -130,8 +135,10 @@ __global__ void __launch_bounds__(256) bn_forward_finalize_kernel(const double* 
 // affine parameters and the three per-column coefficients of dh = c_g g + c_h h + c_1.
 __global__ void __launch_bounds__(256) bn_backward_finalize_kernel(const double* __restrict__ partials, int n_partials, int cols,
                                                                    double n_rows, const double* __restrict__ stats,
-                                                                   const float* __restrict__ gamma, float* __restrict__ outv) {
+                                                                   const float* __restrict__ gamma, float* __restrict__ outv,
+                                                                   const int64_t* __restrict__ n_valid) {
   __shared__ double red[2][16][17];
+  if (n_valid != nullptr) n_rows = fmax(fmin(n_rows, (double)*n_valid), 1.0);
   const int col = blockIdx.x * 16 + (threadIdx.x & 15), pl = threadIdx.x >> 4;
   double s1, sgh;
   moment_totals(partials, n_partials, cols, col, pl, red, s1, sgh);
@@ -151,10 +158,15 @@ __global__ void __launch_bounds__(256) affine_act_residual_kernel(const float* _
                                                                   const float* __restrict__ shift,
                                                                   const float* __restrict__ residual, int relu,
                                                                   int64_t quads, int cg, float* __restrict__ out,
-                                                                  const unsigned char* __restrict__ keep, float keep_scale) {
+                                                                  const unsigned char* __restrict__ keep, float keep_scale,
+                                                                  const int64_t* __restrict__ n_valid) {
   const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (k >= quads) return;
   const int g = (int)(k % cg);
+  if (n_valid != nullptr && k / cg >= *n_valid) {      // padding rows stay zero
+    __builtin_nontemporal_store(f4{0.f, 0.f, 0.f, 0.f}, reinterpret_cast<f4*>(out) + k);
+    return;
+  }
   f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4*>(h) + k) * reinterpret_cast<const f4*>(scale)[g] +
          reinterpret_cast<const f4*>(shift)[g];
   if (relu) v = f4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
@@ -169,10 +181,14 @@ __global__ void __launch_bounds__(256) tail_backward_kernel(const float* __restr
                                                             int relu, const float* __restrict__ ca, const float* __restrict__ cb,
                                                             const float* __restrict__ cc, int64_t quads, int cg,
                                                             float* __restrict__ dh, const unsigned char* __restrict__ keep,
-                                                            float keep_scale) {
+                                                            float keep_scale, const int64_t* __restrict__ n_valid) {
   const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (k >= quads) return;
   const int g = (int)(k % cg);
+  if (n_valid != nullptr && k / cg >= *n_valid) {      // padding rows carry no gradient (the per-channel constant
+    __builtin_nontemporal_store(f4{0.f, 0.f, 0.f, 0.f}, reinterpret_cast<f4*>(dh) + k);   // term would otherwise reach
+    return;                                             // the layer's bias and weight gradients)
+  }
   const f4 hv = __builtin_nontemporal_load(reinterpret_cast<const f4*>(h) + k);
   f4 gv = __builtin_nontemporal_load(reinterpret_cast<const f4*>(dout) + k);
   if (keep != nullptr) gv = gv * keep4(keep, k, keep_scale);
@@ -243,7 +259,7 @@ extern "C" {
 
 int egc_column_moments_f64(const float* a, const float* b, const float* scale, const float* shift, int32_t relu,
                            const uint8_t* keep, float keep_scale, int64_t n_rows, int32_t cols, double* partials,
-                           int32_t n_partials, int64_t* count_inc, egc_stream_t stream_) {
+                           int32_t n_partials, int64_t* count_inc, const int64_t* n_valid, egc_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (n_rows < 0 || cols <= 0 || partials == nullptr || n_partials <= 0) return EGC_ERR_INVALID;
   if ((cols & 3) != 0 || cols > 1024 || !aligned16(a) || !aligned16(b) || !aligned16(scale) || !aligned16(shift) ||
@@ -256,44 +272,46 @@ int egc_column_moments_f64(const float* a, const float* b, const float* scale, c
   const int rows_per_block = (int)std::max<int64_t>(ceil_div(n_rows, (int64_t)n_partials), 1);  // empty blocks write zeros
   if (masked)
     column_moments_kernel<true><<<(unsigned)n_partials, 256, 0, stream>>>(a, b, scale, shift, n_rows, cols,
-                                                                          rows_per_block, partials, relu, keep, keep_scale, count_inc);
+                                                                          rows_per_block, partials, relu, keep, keep_scale, count_inc, n_valid);
   else
     column_moments_kernel<false><<<(unsigned)n_partials, 256, 0, stream>>>(a, nullptr, nullptr, nullptr, n_rows, cols, rows_per_block,
-                                                                           partials, 0, nullptr, 1.f, count_inc);
+                                                                           partials, 0, nullptr, 1.f, count_inc, n_valid);
   EGC_LAUNCH_CHECK("column_moments_kernel");
   return EGC_OK;
 }
 
 int egc_bn_forward_finalize(const double* partials, int32_t n_partials, int32_t cols, int64_t n_rows, const float* gamma,
                             const float* beta, double eps, double* stats, float* affine, float* running_mean,
-                            float* running_var, double momentum, const int64_t* n_tracked, egc_stream_t stream_) {
+                            float* running_var, double momentum, const int64_t* n_tracked, const int64_t* n_valid,
+                            egc_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (partials == nullptr || n_partials <= 0 || cols <= 0 || n_rows <= 0 || stats == nullptr || affine == nullptr)
     return EGC_ERR_INVALID;
   if ((running_mean == nullptr) != (running_var == nullptr)) return EGC_ERR_INVALID;
   if (running_mean != nullptr && momentum < 0.0 && n_tracked == nullptr) return EGC_ERR_INVALID;
   if (running_mean != nullptr && n_rows < 2) return EGC_ERR_INVALID;   // (nn.BatchNorm1d raises on one row in training mode)
+  // (with a device-side row count the check is the caller's: a count below 2 leaves the variance term unscaled)
   bn_forward_finalize_kernel<<<(unsigned)ceil_div(cols, 16), 256, 0, stream>>>(partials, n_partials, cols, (double)n_rows, gamma,
                                                                              beta, eps, stats, affine, running_mean,
-                                                                             running_var, momentum, n_tracked);
+                                                                             running_var, momentum, n_tracked, n_valid);
   EGC_LAUNCH_CHECK("bn_forward_finalize_kernel");
   return EGC_OK;
 }
 
 int egc_bn_backward_finalize(const double* partials, int32_t n_partials, int32_t cols, int64_t n_rows, const double* stats,
-                             const float* gamma, float* out5, egc_stream_t stream_) {
+                             const float* gamma, float* out5, const int64_t* n_valid, egc_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (partials == nullptr || n_partials <= 0 || cols <= 0 || n_rows <= 0 || stats == nullptr || out5 == nullptr)
     return EGC_ERR_INVALID;
   bn_backward_finalize_kernel<<<(unsigned)ceil_div(cols, 16), 256, 0, stream>>>(partials, n_partials, cols, (double)n_rows, stats,
-                                                                              gamma, out5);
+                                                                              gamma, out5, n_valid);
   EGC_LAUNCH_CHECK("bn_backward_finalize_kernel");
   return EGC_OK;
 }
 
 int egc_affine_act_residual_f32(const float* h, const float* scale, const float* shift, const float* residual,
                                 int32_t relu, const uint8_t* keep, float keep_scale, int64_t n_rows, int32_t cols,
-                                float* out, egc_stream_t stream_) {
+                                float* out, const int64_t* n_valid, egc_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (n_rows < 0 || cols <= 0 || scale == nullptr || shift == nullptr) return EGC_ERR_INVALID;
   if ((cols & 3) != 0 || !aligned16(h) || !aligned16(scale) || !aligned16(shift) || !aligned16(residual) || !aligned16(out))
@@ -303,14 +321,15 @@ int egc_affine_act_residual_f32(const float* h, const float* scale, const float*
   const int64_t quads = n_rows * (cols / 4);
   if ((reinterpret_cast<uintptr_t>(keep) & 3) != 0) return EGC_ERR_UNSUPPORTED;
   affine_act_residual_kernel<<<(unsigned)ceil_div(quads, 256), 256, 0, stream>>>(h, scale, shift, residual, relu, quads, cols / 4, out,
-                                                                               keep, keep_scale);
+                                                                               keep, keep_scale, n_valid);
   EGC_LAUNCH_CHECK("affine_act_residual_kernel");
   return EGC_OK;
 }
 
 int egc_affine_act_backward_f32(const float* dout, const float* h, const float* scale, const float* shift, int32_t relu,
                                 const uint8_t* keep, float keep_scale, const float* coef_g, const float* coef_h,
-                                const float* coef_1, int64_t n_rows, int32_t cols, float* dh, egc_stream_t stream_) {
+                                const float* coef_1, int64_t n_rows, int32_t cols, float* dh, const int64_t* n_valid,
+                                egc_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (n_rows < 0 || cols <= 0 || scale == nullptr || shift == nullptr || coef_g == nullptr || coef_h == nullptr ||
       coef_1 == nullptr)
@@ -323,7 +342,7 @@ int egc_affine_act_backward_f32(const float* dout, const float* h, const float* 
   const int64_t quads = n_rows * (cols / 4);
   if ((reinterpret_cast<uintptr_t>(keep) & 3) != 0) return EGC_ERR_UNSUPPORTED;
   tail_backward_kernel<<<(unsigned)ceil_div(quads, 256), 256, 0, stream>>>(dout, h, scale, shift, relu, coef_g, coef_h, coef_1, quads,
-                                                                         cols / 4, dh, keep, keep_scale);
+                                                                         cols / 4, dh, keep, keep_scale, n_valid);
   EGC_LAUNCH_CHECK("tail_backward_kernel");
   return EGC_OK;
 }

@@ -760,7 +760,7 @@ class _AggregateCombineFunction(torch.autograd.Function):
 
 
 def _moment_partials(a: torch.Tensor, b=None, scale=None, shift=None, relu=True, keep=None, keep_scale=1.0,
-                     count_inc=None) -> torch.Tensor:
+                     count_inc=None, n_valid=None) -> torch.Tensor:
     """[parts][2][C] float64 partial sums (sum_r g, sum_r g * b) over row blocks through egc_column_moments_f64; b is None:
     g = a and the second sum is the second moment of a; else g = a * keep * keep_scale * [b * scale + shift > 0] (dropout
     mask if given, ReLU mask if ``relu``).  The blocks are added by the finalize kernels (egc_bn_forward_finalize /
@@ -776,6 +776,7 @@ def _moment_partials(a: torch.Tensor, b=None, scale=None, shift=None, relu=True,
                                             shift.data_ptr() if shift is not None else None, int(bool(relu)),
                                             keep.data_ptr() if keep is not None else None, float(keep_scale), n, c,
                                             out.data_ptr(), parts, count_inc.data_ptr() if count_inc is not None else None,
+                                            n_valid.data_ptr() if n_valid is not None else None,
                                             _stream_ptr(dev)), "egc_column_moments_f64")
     return out
 
@@ -793,7 +794,8 @@ class _BatchNormActResidualFunction(torch.autograd.Function):
     ogbn-arxiv net has it (arxiv/norm_models.py:34-40).  Returns (out, batch mean, biased batch variance), both float64."""
 
     @staticmethod
-    def forward(ctx, h, residual, gamma, beta, eps, relu, running_mean, running_var, momentum, n_tracked, keep, keep_scale):
+    def forward(ctx, h, residual, gamma, beta, eps, relu, running_mean, running_var, momentum, n_tracked, keep, keep_scale,
+                n_valid):
         lib = _C.load()
         n, c = h.shape
         dev = h.device
@@ -801,7 +803,7 @@ class _BatchNormActResidualFunction(torch.autograd.Function):
         gamma_c = gamma.detach().contiguous().float() if gamma is not None else None
         beta_c = beta.detach().contiguous().float() if beta is not None else None
         # (the statistics pass also bumps num_batches_tracked, one launch before the finalize kernel reads it)
-        parts = _moment_partials(h, count_inc=n_tracked if running_mean is not None else None)
+        parts = _moment_partials(h, count_inc=n_tracked if running_mean is not None else None, n_valid=n_valid)
         res = residual.contiguous() if residual is not None else None
         with _device_guard(dev):
             stats = torch.empty((3, c), dtype=torch.float64, device=dev)     # mean | biased variance | 1 / std
@@ -814,12 +816,15 @@ class _BatchNormActResidualFunction(torch.autograd.Function):
                 running_mean.data_ptr() if running_mean is not None else None,
                 running_var.data_ptr() if running_var is not None else None,
                 -1.0 if momentum is None else float(momentum),
-                n_tracked.data_ptr() if n_tracked is not None else None, stream), "egc_bn_forward_finalize")
+                n_tracked.data_ptr() if n_tracked is not None else None,
+                n_valid.data_ptr() if n_valid is not None else None, stream), "egc_bn_forward_finalize")
             _C.check(lib.egc_affine_act_residual_f32(h.data_ptr(), affine[0].data_ptr(), affine[1].data_ptr(),
                                                      res.data_ptr() if res is not None else None, int(relu),
                                                      keep.data_ptr() if keep is not None else None, float(keep_scale),
-                                                     n, c, out.data_ptr(), stream), "egc_affine_act_residual_f32")
-        ctx.save_for_backward(h, affine, stats, gamma_c, keep)
+                                                     n, c, out.data_ptr(),
+                                                     n_valid.data_ptr() if n_valid is not None else None, stream),
+                     "egc_affine_act_residual_f32")
+        ctx.save_for_backward(h, affine, stats, gamma_c, keep, n_valid)
         ctx.keep_scale = float(keep_scale)
         ctx.set_materialize_grads(False)     # (mean / var carry no gradient: no zero-filled stand-ins per backward)
         ctx.relu, ctx.has_res, ctx.has_gamma, ctx.has_beta = bool(relu), residual is not None, gamma is not None, beta is not None
@@ -830,16 +835,16 @@ class _BatchNormActResidualFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, _dmean, _dvar):
         lib = _C.load()
-        h, affine, stats, gamma_c, keep = ctx.saved_tensors
+        h, affine, stats, gamma_c, keep, n_valid = ctx.saved_tensors
         n, c = h.shape
         dev = h.device
         if dout is None:
-            return (None,) * 12
+            return (None,) * 13
         dout = dout.contiguous()
         dh = dgamma = dbeta = None
         if ctx.needs_input_grad[0] or (ctx.has_gamma and ctx.needs_input_grad[2]) or (ctx.has_beta and ctx.needs_input_grad[3]):
-            if ctx.relu or keep is not None:    # sum g, sum g h   (g = dout * dropout mask * relu mask)
-                parts = _moment_partials(dout, h, affine[0], affine[1], ctx.relu, keep, ctx.keep_scale)
+            if ctx.relu or keep is not None or n_valid is not None:    # sum g, sum g h   (g = dout * dropout mask * relu mask)
+                parts = _moment_partials(dout, h, affine[0], affine[1], ctx.relu, keep, ctx.keep_scale, n_valid=n_valid)
             else:
                 s1 = _column_sums(dout).double()
                 sgh = (dout.double() * h.double()).sum(0) if n else torch.zeros(c, dtype=torch.float64, device=dev)
@@ -849,7 +854,8 @@ class _BatchNormActResidualFunction(torch.autograd.Function):
                 stream = _stream_ptr(dev)
                 _C.check(lib.egc_bn_backward_finalize(parts.data_ptr(), parts.size(0), c, n, stats.data_ptr(),
                                                       gamma_c.data_ptr() if gamma_c is not None else None, out5.data_ptr(),
-                                                      stream), "egc_bn_backward_finalize")
+                                                      n_valid.data_ptr() if n_valid is not None else None, stream),
+                         "egc_bn_backward_finalize")
                 dgamma = out5[0] if ctx.has_gamma and ctx.needs_input_grad[2] else None
                 dbeta = out5[1] if ctx.has_beta and ctx.needs_input_grad[3] else None
                 if ctx.needs_input_grad[0]:
@@ -858,9 +864,10 @@ class _BatchNormActResidualFunction(torch.autograd.Function):
                                                              affine[1].data_ptr(), int(ctx.relu),
                                                              keep.data_ptr() if keep is not None else None, ctx.keep_scale,
                                                              out5[2].data_ptr(), out5[3].data_ptr(), out5[4].data_ptr(), n, c,
-                                                             dh.data_ptr(), stream), "egc_affine_act_backward_f32")
+                                                             dh.data_ptr(), n_valid.data_ptr() if n_valid is not None else None,
+                                                             stream), "egc_affine_act_backward_f32")
         dres = dout if ctx.has_res and ctx.needs_input_grad[1] else None
-        return dh, dres, dgamma, dbeta, None, None, None, None, None, None, None, None
+        return dh, dres, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
 def batch_norm_act_residual_supported(h: torch.Tensor) -> bool:
@@ -869,13 +876,15 @@ def batch_norm_act_residual_supported(h: torch.Tensor) -> bool:
 
 
 def batch_norm_act_residual(h, residual, gamma, beta, eps: float, relu: bool, running_mean=None, running_var=None,
-                            momentum=None, num_batches_tracked=None, keep=None, keep_scale: float = 1.0):
+                            momentum=None, num_batches_tracked=None, keep=None, keep_scale: float = 1.0, n_valid=None):
     """Training-mode BatchNorm1d (batch statistics) -> optional ReLU -> optional residual add, fused
     (_BatchNormActResidualFunction): returns (out, batch mean [C] float64, biased batch variance [C] float64).
     With ``running_mean`` / ``running_var`` (float32 [C], dense) the running statistics are updated in the same launch
     that finishes the batch statistics, as nn.BatchNorm1d does: unbiased variance, ``momentum``, or -- momentum None --
     the cumulative average over ``num_batches_tracked`` (a device int64 scalar, INCREMENTED here when given).
-    ``keep`` / ``keep_scale``: dropout between the activation and the residual add (see the Function)."""
+    ``keep`` / ``keep_scale``: dropout between the activation and the residual add (see the Function).
+    ``n_valid`` (device int64 scalar): only the first n_valid rows are real -- the rest is the padding of a batch brought
+    to a recording's static shape; statistics and gradients are those of nn.BatchNorm1d on the real rows."""
     c = h.size(1)
     if running_mean is not None and not (_f32_vec(running_mean, c) and _f32_vec(running_var, c)
                                          and (momentum is not None or num_batches_tracked is not None)):
@@ -886,8 +895,10 @@ def batch_norm_act_residual(h, residual, gamma, beta, eps: float, relu: bool, ru
     if keep is not None and (keep.dtype != torch.uint8 or keep.shape != h.shape or not keep.is_contiguous()
                              or keep.device != h.device):
         raise RuntimeError("egc_amd: the dropout mask must be a dense uint8 tensor of the shape of h")
+    if n_valid is not None and (n_valid.dtype != torch.int64 or n_valid.numel() != 1 or n_valid.device != h.device):
+        raise RuntimeError("egc_amd: n_valid must be an int64 scalar on the device of h")
     return _BatchNormActResidualFunction.apply(h, residual, gamma, beta, float(eps), bool(relu), running_mean, running_var,
-                                               momentum, num_batches_tracked, keep, float(keep_scale))
+                                               momentum, num_batches_tracked, keep, float(keep_scale), n_valid)
 
 
 def egc_aggregate_combine_apply(graph, spec, bases, weightings, bias=None):

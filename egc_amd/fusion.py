@@ -51,13 +51,15 @@ class FusedEGCBlock(nn.Module):
             h = torch.nn.functional.dropout(h, self.dropout, True)
         return identity + h if self.residual else h
 
-    def _batch_stats(self, x, edge_index, identity=None):
+    def _batch_stats(self, x, edge_index, identity=None, n_valid=None):
         """conv, then BatchNorm1d on batch statistics -> ReLU -> + input in two passes; the running statistics are
         updated as nn.BatchNorm1d does (momentum or cumulative average, unbiased variance)."""
         bn = self.bn
         identity = x if identity is None else identity
         h = self.conv(x=x, edge_index=edge_index) if hasattr(self.conv, "aggs") else self.conv(x, edge_index)
         if not batch_norm_act_residual_supported(h) or (self.residual and identity.shape != h.shape):
+            if n_valid is not None:
+                raise RuntimeError("egc_amd: n_valid needs the fused training tail (float32 CUDA activations, channels % 4 == 0)")
             h = bn(h)
             h = torch.relu(h) if self.relu else h
             if self._dropping():
@@ -77,7 +79,7 @@ class FusedEGCBlock(nn.Module):
         out, mean, var = batch_norm_act_residual(
             h, identity if self.residual else None, bn.weight if bn.affine else None, bn.bias if bn.affine else None, bn.eps,
             self.relu, bn.running_mean if in_place else None, bn.running_var if in_place else None, bn.momentum,
-            bn.num_batches_tracked if counted else None, keep, 1.0 / (1.0 - self.dropout))
+            bn.num_batches_tracked if counted else None, keep, 1.0 / (1.0 - self.dropout), n_valid)
         if track and not in_place:               # running statistics kept in another dtype: torch's arithmetic
             with torch.no_grad():
                 n = h.size(0)
@@ -86,12 +88,15 @@ class FusedEGCBlock(nn.Module):
                 bn.running_var.mul_(1 - m).add_((var * (n / (n - 1))).to(bn.running_var.dtype), alpha=m)
         return out
 
-    def forward(self, x, edge_index, identity=None):
+    def forward(self, x, edge_index, identity=None, n_valid=None):
         """``identity``: what the residual adds when it is not the layer's input itself -- the CIFAR net drops out the
-        layer's input but adds the undropped activations back (cifar/models.py:64-71): ``block(drop(x), ei, identity=x)``."""
+        layer's input but adds the undropped activations back (cifar/models.py:64-71): ``block(drop(x), ei, identity=x)``.
+        ``n_valid`` (device int64 scalar): the batch occupies the first n_valid rows, the rest is padding up to the
+        static shape of a hipGraph recording (egc_amd.GraphedStep); BatchNorm's batch statistics then count the real
+        rows only, so one recording serves batches of every size up to the padded one with unchanged numerics."""
         bn = self.bn
         if bn is not None and (bn.training or not bn.track_running_stats):
-            return self._batch_stats(x, edge_index, identity)   # batch statistics: the tail is its own two passes
+            return self._batch_stats(x, edge_index, identity, n_valid)   # batch statistics: the tail is its own two passes
         if self._dropping():                              # (dropout without batch statistics: torch's operators)
             return self._plain(x, edge_index, identity)
         fusable = not (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())

@@ -10,10 +10,12 @@ batch (graph build included), 1.1-1.7 ms eager -> 0.41-0.48 ms replayed on MI355
 section 5).
 
 Usage (static shapes: the tensors the step reads and writes are the SAME objects at every replay; a batch with fewer
-nodes / edges is padded by the caller, e.g. with isolated nodes and self-loops on the last of them -- the EGC layers
-keep padded rows to themselves, but anything that reduces over ALL rows sees them: BatchNorm's batch statistics, a
-mean-pool without its ``batch`` vector.  Nets with such layers record one step per distinct (N, E), or bucket their
-batches to exact sizes, if the reference's numerics are to be kept)::
+nodes / edges is padded by the caller, e.g. with isolated nodes behind the real ones and self-loops on the last of
+them -- the EGC layers keep padded rows to themselves, but anything that reduces over ALL rows sees them.  For
+BatchNorm's batch statistics ``FusedEGCBlock(...)(x, edge_index, n_valid=t)`` takes the number of real rows as a device
+scalar ``t``: statistics, running statistics and gradients are then nn.BatchNorm1d's on the real rows, and ONE
+recording serves every batch up to the padded size (tests/test_hipgraph_gpu.py).  A readout must likewise use its
+``batch`` vector, with the padding in a spare graph)::
 
     x, edge_index = static input buffers
     def step():

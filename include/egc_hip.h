@@ -307,6 +307,13 @@ int egc_weight_grad_f32(const float* x, int64_t ldx, const float* d, int64_t ldd
  * all three passes -- out = act(.) * keep * keep_scale + residual forward, g = dout * keep * keep_scale * [pre > 0]
  * backward.  The mask itself is the caller's (torch's generator on the Python side).
  *
+ * n_valid (device int64, may be NULL): the number of leading rows that are real; rows [*n_valid, n_rows) are the
+ * padding of a batch brought to the static shape of a hipGraph recording -- the statistics passes skip them and the
+ * per-channel launches divide by *n_valid, so one recording serves batches of any size up to (n_rows, E) with
+ * nn.BatchNorm1d's numerics on the real rows.  The elementwise passes write zeros to the padding rows (forward: they
+ * stay clean for the next layer; backward: the per-channel constant of the BatchNorm gradient must not reach the
+ * layer's bias and weight gradients through them).
+ *
  *   egc_column_moments_f64      partials[p][0][c] = sum over the p-th block of rows of g[r][c],
  *                               partials[p][1][c] = sum of g[r][c] * b[r][c], accumulated in float64 (the caller adds
  *                               the n_partials blocks).  b == NULL: g = a, second moment of a itself (forward: batch
@@ -330,18 +337,20 @@ int egc_weight_grad_f32(const float* x, int64_t ldx, const float* d, int64_t ldd
  *                               with its two sums folded into the three per-channel coefficient vectors. */
 int egc_column_moments_f64(const float* a, const float* b, const float* scale, const float* shift, int32_t relu,
                            const uint8_t* keep, float keep_scale, int64_t n_rows, int32_t cols, double* partials,
-                           int32_t n_partials, int64_t* count_inc, egc_stream_t stream);
+                           int32_t n_partials, int64_t* count_inc, const int64_t* n_valid, egc_stream_t stream);
 int egc_bn_forward_finalize(const double* partials, int32_t n_partials, int32_t cols, int64_t n_rows, const float* gamma,
                             const float* beta, double eps, double* stats, float* affine, float* running_mean,
-                            float* running_var, double momentum, const int64_t* n_tracked, egc_stream_t stream);
+                            float* running_var, double momentum, const int64_t* n_tracked, const int64_t* n_valid,
+                            egc_stream_t stream);
 int egc_bn_backward_finalize(const double* partials, int32_t n_partials, int32_t cols, int64_t n_rows, const double* stats,
-                             const float* gamma, float* out5, egc_stream_t stream);
+                             const float* gamma, float* out5, const int64_t* n_valid, egc_stream_t stream);
 int egc_affine_act_residual_f32(const float* h, const float* scale, const float* shift, const float* residual,
                                 int32_t relu, const uint8_t* keep, float keep_scale, int64_t n_rows, int32_t cols,
-                                float* out, egc_stream_t stream);
+                                float* out, const int64_t* n_valid, egc_stream_t stream);
 int egc_affine_act_backward_f32(const float* dout, const float* h, const float* scale, const float* shift, int32_t relu,
                                 const uint8_t* keep, float keep_scale, const float* coef_g, const float* coef_h,
-                                const float* coef_1, int64_t n_rows, int32_t cols, float* dh, egc_stream_t stream);
+                                const float* coef_1, int64_t n_rows, int32_t cols, float* dh, const int64_t* n_valid,
+                                egc_stream_t stream);
 
 /* The GEMM operand of a layer from its parameters (grad == 0), or the parameters' gradients from the operand's
  * gradient (grad != 0: the parameter arrays are WRITTEN, wcat / bcat read) -- one launch instead of the cat / pad /

@@ -220,3 +220,57 @@ def test_recorded_step_on_a_graph_with_hub_rows():
             p.grad = h
         for a, b in zip(got, ref):      # (a conv bias in front of a BatchNorm has a zero gradient: absolute floor)
             assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max())), trial
+
+
+def test_one_recording_serves_batches_of_different_size_with_batch_norm():
+    """Batches padded to one static (N, E) -- isolated nodes behind the real ones, self-loops on the last of them -- go
+    through ONE recording; with the number of real rows in a device scalar (n_valid) BatchNorm's batch statistics count
+    the real rows only, so gradients and running statistics equal those of the eager step on the UNPADDED batch."""
+    import egc_amd
+    from egc_amd import workloads as wl
+    dev = torch.device("cuda:0")
+    batches = []
+    for k, seed in ((40, 1), (56, 2), (33, 3)):
+        _, ei, n, _ = wl.zinc_like_batch(k, seed=seed)
+        batches.append((ei.to(dev), n, torch.randn(n, 64, device=dev), torch.randn(n, 64, device=dev)))
+    n_pad = max(b[1] for b in batches) + 8
+    e_pad = max(b[0].size(1) for b in batches) + 16
+    blocks = _blocks(dev, "opt")
+    params = list(blocks.parameters())
+    # static buffers of the recording
+    x = torch.zeros(n_pad, 64, device=dev)
+    gout = torch.zeros(n_pad, 64, device=dev)          # zero on the padding rows: they do not reach the loss
+    edge_index = torch.full((2, e_pad), n_pad - 1, dtype=torch.int64, device=dev)
+    n_valid = torch.zeros((), dtype=torch.int64, device=dev)
+
+    def load(ei, n, xb, gb):
+        x.zero_(); gout.zero_()
+        x[:n] = xb; gout[:n] = gb
+        edge_index.fill_(n_pad - 1)
+        edge_index[:, :ei.size(1)] = ei
+        n_valid.fill_(n)
+
+    def step():
+        h = x
+        for b in blocks:
+            h = b(h, edge_index, n_valid=n_valid)
+        h.backward(gout)
+
+    load(*batches[0])
+    graphed = egc_amd.GraphedStep(step, params=params)
+    import copy
+    for ei, n, xb, gb in batches[1:] + batches[:1]:
+        ref_blocks = copy.deepcopy(blocks)
+        for p in ref_blocks.parameters():
+            p.grad = None
+        load(ei, n, xb, gb)
+        graphed()
+        got = _grads(params) + [b.bn.running_mean.clone() for b in blocks] + [b.bn.running_var.clone() for b in blocks]
+        h = xb
+        for b in ref_blocks:                            # the eager step on the unpadded batch
+            h = b(h, ei)
+        h.backward(gb)
+        ref = [p.grad for p in ref_blocks.parameters()] + [b.bn.running_mean for b in ref_blocks] + \
+              [b.bn.running_var for b in ref_blocks]
+        for a, b in zip(got, ref):
+            assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
