@@ -274,3 +274,85 @@ def test_one_recording_serves_batches_of_different_size_with_batch_norm():
               [b.bn.running_var for b in ref_blocks]
         for a, b in zip(got, ref):
             assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
+
+
+def test_small_net_trained_on_padded_batches_through_one_recording():
+    """The reference's small-batch loop end to end (zinc/main.py shape: embedding -> blocks -> mean pool -> head -> loss
+    -> optimizer step): random-size batches copied into static padded buffers, ONE recording replayed per batch,
+    against the eager loop on the unpadded batches -- same parameters after six steps."""
+    import copy
+    import egc_amd
+    from egc_amd import workloads as wl
+    dev = torch.device("cuda:0")
+    hidden, n_types = 64, 28
+    torch.manual_seed(0)
+    emb = nn.Embedding(n_types, hidden).to(dev)
+    blocks = _blocks(dev, "opt", n_blocks=2, hidden=hidden)
+    head = nn.Linear(hidden, 1).to(dev)
+    net = nn.ModuleList([emb, blocks, head])
+    ref_net = copy.deepcopy(net)
+    data = []
+    for k, seed in ((24, 1), (40, 2), (31, 3), (40, 4), (17, 5), (36, 6)):
+        atom, ei, n, batch = wl.zinc_like_batch(k, seed=seed)
+        data.append((atom.to(dev), ei.to(dev), n, batch.to(dev), k, torch.randn(k, 1, device=dev)))
+    n_pad = max(d[2] for d in data) + 4
+    e_pad = max(d[1].size(1) for d in data) + 8
+    g_pad = max(d[4] for d in data) + 1                   # + a spare graph that owns the padding rows
+
+    def forward(net_, atom, ei, batch, n_graphs, counts, n_valid=None):
+        emb_, blocks_, head_ = net_
+        h = emb_(atom)
+        for b in blocks_:
+            h = b(h, ei, n_valid=n_valid)
+        pooled = torch.zeros(n_graphs, hidden, device=dev).index_add_(0, batch, h) / counts
+        return head_(pooled)
+
+    # static buffers
+    s_atom = torch.zeros(n_pad, dtype=torch.int64, device=dev)
+    s_ei = torch.full((2, e_pad), n_pad - 1, dtype=torch.int64, device=dev)
+    s_batch = torch.full((n_pad,), g_pad - 1, dtype=torch.int64, device=dev)
+    s_counts = torch.ones(g_pad, 1, device=dev)
+    s_target = torch.zeros(g_pad, 1, device=dev)
+    s_gmask = torch.zeros(g_pad, 1, device=dev)
+    s_inv_g = torch.ones((), device=dev)
+    s_nvalid = torch.zeros((), dtype=torch.int64, device=dev)
+    params = list(net.parameters())
+    opt = torch.optim.SGD(params, lr=0.05, foreach=True)
+    ref_opt = torch.optim.SGD(list(ref_net.parameters()), lr=0.05, foreach=True)
+
+    def load(atom, ei, n, batch, k, target):
+        s_atom.zero_(); s_atom[:n] = atom
+        s_ei.fill_(n_pad - 1); s_ei[:, :ei.size(1)] = ei
+        s_batch.fill_(g_pad - 1); s_batch[:n] = batch
+        s_counts.fill_(1.0); s_counts[:k, 0] = torch.bincount(batch, minlength=k).float()
+        s_target.zero_(); s_target[:k] = target
+        s_gmask.zero_(); s_gmask[:k] = 1.0
+        s_inv_g.fill_(1.0 / k)
+        s_nvalid.fill_(n)
+
+    def step():
+        out = forward(net, s_atom, s_ei, s_batch, g_pad, s_counts, s_nvalid)
+        (((out - s_target) ** 2 * s_gmask).sum() * s_inv_g).backward()     # mean over the real graphs
+        opt.step()
+        opt.zero_grad(set_to_none=False)
+
+    load(*data[0])
+    start = copy.deepcopy(net.state_dict())
+    graphed = egc_amd.GraphedStep(step, params=params, warmup=2)
+    net.load_state_dict(start)                             # (the warm-up runs were real steps)
+    for p in params:
+        p.grad.zero_()
+    for atom, ei, n, batch, k, target in data:
+        load(atom, ei, n, batch, k, target)
+        graphed()
+        ref_opt.zero_grad(set_to_none=True)
+        counts = torch.bincount(batch, minlength=k).float()[:, None]
+        out = forward(ref_net, atom, ei, batch, k, counts)
+        ((out - target) ** 2).mean().backward()
+        ref_opt.step()
+    torch.cuda.synchronize()
+    for (name, a), (_, b) in zip(net.state_dict().items(), ref_net.state_dict().items()):
+        if a.dtype.is_floating_point:
+            assert float((a - b).abs().max()) <= 1e-4 * max(1.0, float(b.abs().max())), name
+        else:
+            assert torch.equal(a, b), name
