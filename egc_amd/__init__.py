@@ -4,7 +4,8 @@ Public surface (mirrors the reference's layer API):
   EfficientGraphConv   drop-in for experiments/layers.py:EfficientGraphConv
   EGConv               drop-in for experiments/optimized_layers.py:EGConv
   REGConv              drop-in for experiments/rmag/models.py:REGConv (relational EGC)
-  FusedEGCBlock        conv -> BatchNorm1d(eval) -> ReLU -> + identity in the kernel's store; global_mean_pool
+  FusedEGCBlock        conv -> BatchNorm1d -> ReLU (-> dropout) -> + identity: eval mode in the kernel's store, training
+                       mode in two passes each way; global_mean_pool (differentiable segmented mean)
   SparseTensor         minimal adj_t container (torch_sparse is not required)
   CSRGraph             device CSR + degree statistics + long-row plan
   egc_layer_forward    operator-level call into libegc_hip.so

@@ -130,9 +130,28 @@ class FusedEGCBlock(nn.Module):
         return egc_layer_forward(graph, spec, x, wcat, bcat, conv.bias, packed=conv._weight_planes(spec, wcat), post=post)
 
 
+class _SegmentMeanFunction(torch.autograd.Function):
+    """out[g] = mean of the rows of graph g (a sorted batch vector's segments); d x[r] = d out[batch[r]] / count."""
+
+    @staticmethod
+    def forward(ctx, x, seg, batch):
+        ctx.save_for_backward(seg, batch)
+        return segment_mean(x, seg)
+
+    @staticmethod
+    def backward(ctx, dout):
+        seg, batch = ctx.saved_tensors
+        counts = (seg[1:] - seg[:-1]).clamp_(min=1).to(dout.dtype)
+        return (dout / counts[:, None]).index_select(0, batch), None, None
+
+
 def global_mean_pool(x: torch.Tensor, batch: torch.Tensor, size: int | None = None) -> torch.Tensor:
-    """torch_geometric.nn.global_mean_pool for a SORTED batch vector (graphs are contiguous in a PyG batch):
-    a segmented mean on the device (``egc_segment_mean_f32``); differentiable callers should use torch ops."""
+    """torch_geometric.nn.global_mean_pool for a SORTED batch vector (graphs are contiguous in a PyG batch; the
+    readout of the reference's batched nets, zinc/models.py:73): a segmented mean on the device
+    (``egc_segment_mean_f32``), differentiable.  Pass ``size`` (the number of graphs) where nothing may be read back
+    to the host -- inside a hipGraph recording; without it the number of graphs comes from ``batch.max()``."""
     n_graphs = int(batch.max()) + 1 if size is None else int(size)
     seg = torch.searchsorted(batch, torch.arange(n_graphs + 1, device=batch.device, dtype=batch.dtype))
+    if torch.is_grad_enabled() and x.requires_grad:
+        return _SegmentMeanFunction.apply(x, seg, batch)
     return segment_mean(x, seg)

@@ -295,3 +295,11 @@ def test_global_mean_pool_matches_index_add():
     assert egc_amd.global_mean_pool(x, batch, size=n_graphs + 3).shape == (n_graphs + 3, 77)   # trailing empty graphs -> 0
     empty = egc_amd.global_mean_pool(x[:0], batch[:0], size=2)                                 # no nodes at all
     assert empty.shape == (2, 77) and not empty.any()
+    # differentiable: d x[r] = d out[batch[r]] / count of its graph (trailing empty graphs contribute nothing)
+    xg = x.clone().requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    go = torch.randn(n_graphs + 3, 77, device=dev)
+    egc_amd.global_mean_pool(xg, batch, size=n_graphs + 3).backward(go)
+    cnt = torch.bincount(batch, minlength=n_graphs + 3).clamp(min=1).view(-1, 1)
+    (torch.zeros(n_graphs + 3, 77, device=dev).index_add(0, batch, xr) / cnt).backward(go)
+    assert float((xg.grad - xr.grad).abs().max()) <= 1e-6
