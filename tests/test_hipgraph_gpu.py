@@ -304,7 +304,10 @@ def test_small_net_trained_on_padded_batches_through_one_recording():
         h = emb_(atom)
         for b in blocks_:
             h = b(h, ei, n_valid=n_valid)
-        pooled = torch.zeros(n_graphs, hidden, device=dev).index_add_(0, batch, h) / counts
+        if n_valid is not None:      # the recorded side: the library's readout (size given: nothing read back)
+            pooled = egc_amd.global_mean_pool(h, batch, size=n_graphs)
+        else:
+            pooled = torch.zeros(n_graphs, hidden, device=dev).index_add_(0, batch, h) / counts
         return head_(pooled)
 
     # static buffers
