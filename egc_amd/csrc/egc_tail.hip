@@ -52,21 +52,37 @@ __global__ void __launch_bounds__(256) column_moments_kernel(const float* __rest
   d4 s1 = d4{0, 0, 0, 0}, s2 = d4{0, 0, 0, 0};
   f4 sc = f4{0.f, 0.f, 0.f, 0.f}, sh = sc;
   if (MASKED && relu) { sc = reinterpret_cast<const f4*>(scale)[g]; sh = reinterpret_cast<const f4*>(shift)[g]; }
-  if (lane_r < rl)
-    for (int64_t r = r0 + lane_r; r < r1; r += rl) {
-      f4 va = __builtin_nontemporal_load(reinterpret_cast<const f4*>(a + r * cols) + g);
-      const f4 vb = MASKED ? __builtin_nontemporal_load(reinterpret_cast<const f4*>(b + r * cols) + g) : va;
-      if (MASKED) {
-        if (keep != nullptr) va = va * keep4(keep, r * cg + g, keep_scale);
-        if (relu) {
-          const f4 pre = vb * sc + sh;
-          va = f4{pre.x > 0.f ? va.x : 0.f, pre.y > 0.f ? va.y : 0.f, pre.z > 0.f ? va.z : 0.f, pre.w > 0.f ? va.w : 0.f};
-        }
+  auto fold = [&](f4 va, f4 vb, int64_t r) {
+    if (MASKED) {
+      if (keep != nullptr) va = va * keep4(keep, r * cg + g, keep_scale);
+      if (relu) {
+        const f4 pre = vb * sc + sh;
+        va = f4{pre.x > 0.f ? va.x : 0.f, pre.y > 0.f ? va.y : 0.f, pre.z > 0.f ? va.z : 0.f, pre.w > 0.f ? va.w : 0.f};
       }
-      const d4 da = to_d4(va);
-      s1 += da;
-      s2 += da * to_d4(vb);
     }
+    const d4 da = to_d4(va);
+    s1 += da;
+    s2 += da * to_d4(vb);
+  };
+  if (lane_r < rl) {
+    // four rows of loads in flight per thread (the float64 adds are a dependent chain; the loads need not wait for it)
+    int64_t r = r0 + lane_r;
+    for (; r + 3 * (int64_t)rl < r1; r += 4 * (int64_t)rl) {
+      f4 va[4], vb[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        va[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(a + (r + u * (int64_t)rl) * cols) + g);
+        vb[u] = MASKED ? __builtin_nontemporal_load(reinterpret_cast<const f4*>(b + (r + u * (int64_t)rl) * cols) + g) : va[u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) fold(va[u], vb[u], r + u * (int64_t)rl);
+    }
+    for (; r < r1; r += rl) {
+      const f4 va = __builtin_nontemporal_load(reinterpret_cast<const f4*>(a + r * cols) + g);
+      const f4 vb = MASKED ? __builtin_nontemporal_load(reinterpret_cast<const f4*>(b + r * cols) + g) : va;
+      fold(va, vb, r);
+    }
+  }
   red[0][threadIdx.x] = s1;
   red[1][threadIdx.x] = s2;
   __syncthreads();
@@ -186,8 +202,9 @@ __global__ void __launch_bounds__(256) affine_act_residual_kernel(const float* _
                                                                   const int64_t* __restrict__ n_valid) {
   const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (k >= quads) return;
-  const int g = (int)(k % cg);
-  if (n_valid != nullptr && k / cg >= *n_valid) {      // padding rows stay zero
+  const bool p2 = (cg & (cg - 1)) == 0;              // (a 64-bit modulo per 16 bytes is most of this kernel's arithmetic)
+  const int g = p2 ? (int)(k & (cg - 1)) : (int)(k % cg);
+  if (n_valid != nullptr && (p2 ? k >> __builtin_ctz(cg) : k / cg) >= *n_valid) {      // padding rows stay zero
     __builtin_nontemporal_store(f4{0.f, 0.f, 0.f, 0.f}, reinterpret_cast<f4*>(out) + k);
     return;
   }
@@ -208,8 +225,9 @@ __global__ void __launch_bounds__(256) tail_backward_kernel(const float* __restr
                                                             float keep_scale, const int64_t* __restrict__ n_valid) {
   const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (k >= quads) return;
-  const int g = (int)(k % cg);
-  if (n_valid != nullptr && k / cg >= *n_valid) {      // padding rows carry no gradient (the per-channel constant
+  const bool p2 = (cg & (cg - 1)) == 0;
+  const int g = p2 ? (int)(k & (cg - 1)) : (int)(k % cg);
+  if (n_valid != nullptr && (p2 ? k >> __builtin_ctz(cg) : k / cg) >= *n_valid) {      // padding rows carry no gradient (the per-channel constant
     __builtin_nontemporal_store(f4{0.f, 0.f, 0.f, 0.f}, reinterpret_cast<f4*>(dh) + k);   // term would otherwise reach
     return;                                             // the layer's bias and weight gradients)
   }
