@@ -15,6 +15,8 @@ rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o pmc --output-format csv -- $B --no
 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o pmc --output-format csv -- $B --no-other-configs --steps 20 --warmup 5 > /dev/null 2> $O/pmc_write.log
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_BUSY_CYCLES -d $O/pmc_sq -o pmc --output-format csv -- $B --no-other-configs --steps 20 --warmup 5 > /dev/null 2> $O/pmc_sq.log
 rocprofv3 --kernel-trace --stats -d $O/train -o kt --output-format csv -- python3 $R/tools/training_step_time.py > $O/train.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $O/pmc_train_fetch -o pmc --output-format csv -- python3 $R/tools/training_step_time.py > /dev/null 2> $O/pmc_train_fetch.log
+rocprofv3 --pmc WRITE_SIZE -d $O/pmc_train_write -o pmc --output-format csv -- python3 $R/tools/training_step_time.py > /dev/null 2> $O/pmc_train_write.log
 rocprofv3 --kernel-trace --stats -d $O/block -o kt --output-format csv -- python3 $R/tools/block_step_time.py > $O/block.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/small -o kt --output-format csv -- python3 $R/tools/small_batch_step_time.py > $O/small.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/mag -o kt --output-format csv -- python3 $R/bench.py --workload mag --steps 20 --warmup 5 > $O/mag_bench.json 2> $O/mag.log

@@ -47,6 +47,10 @@ def main():
     for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
         out = {"pmc_fetch": "pmc_fetch_size", "pmc_write": "pmc_write_size", "pmc_sq": "pmc_sq_counters"}[name]
         condense(os.path.join(src, name, "pmc_counter_collection.csv"), os.path.join(dst, f"{tag}_{out}.csv"))
+    for name, out in (("pmc_train_fetch", "pmc_training_step_fetch_size"), ("pmc_train_write", "pmc_training_step_write_size")):
+        f = os.path.join(src, name, "pmc_counter_collection.csv")
+        if os.path.exists(f):
+            condense(f, os.path.join(dst, f"{tag}_{out}.csv"))
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"),
                            os.path.join(src, "pmc_fetch", "pmc_counter_collection.csv"),
                            os.path.join(src, "pmc_write", "pmc_counter_collection.csv"),
