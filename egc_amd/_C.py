@@ -57,11 +57,13 @@ SYMBOLS = {
     "egc_coo_to_csr_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "egc_coo_to_csr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "egc_coo_to_csr_checked": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "egc_graph_build_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "egc_graph_build_scratch_bytes": (C.c_size_t, [C.c_int64]),
     "egc_graph_build": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                  C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
+                                  C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
     "egc_csr_edge_dis": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "egc_csr_prepare": (C.c_int, [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p]),

@@ -490,13 +490,12 @@ constexpr int XT_STAGE = 32;  // rows of the reduction per LDS stage
 
 // EGC_XT_FP32 (any value) or EGC_GEMM_EXACT=1 (the switch of the forward GEMMs): exact fp32 products on the fp32 MFMA
 // instead of the split-bf16 form
+// Read per call (a getenv is nothing next to a launch): the host side decides from the same variables at every call
+// (functional._weight_grads), and a value cached here at first use would disagree with it once the environment changes.
 bool xt_fp32_only() {
-  static const bool v = [] {
-    if (getenv("EGC_XT_FP32") != nullptr) return true;
-    const char* e = getenv("EGC_GEMM_EXACT");
-    return e != nullptr && e[0] != '\0' && !(e[0] == '0' && e[1] == '\0');
-  }();
-  return v;
+  if (getenv("EGC_XT_FP32") != nullptr) return true;
+  const char* e = getenv("EGC_GEMM_EXACT");
+  return e != nullptr && e[0] != '\0' && !(e[0] == '0' && e[1] == '\0');
 }
 
 XtPlan xt_plan(int64_t n_rows, int F, int K) {

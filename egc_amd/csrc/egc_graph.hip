@@ -29,16 +29,32 @@ void set_last_error(const char* what, hipError_t err) {
 
 // keys[e] = dst[e] as u32; running max of every node id seen (src and dst) -> *max_index.
 // One atomic per BLOCK (the launch caps the grid): thousands of same-address atomics cost more than the read.
+// With `status` (range-checked form): an edge whose source is outside [0, n_src) or whose destination is outside
+// [0, n_nodes) gets the key n_nodes -- it sorts behind every row, rowptr[n_nodes] then counts the edges kept -- and the
+// flags are raised (what the reference's PyG path answers with an exception at index_select, optimized_layers.py:191-193).
 __global__ void __launch_bounds__(256) coo_keys_kernel(const int64_t* __restrict__ src,
                                                        const int64_t* __restrict__ dst, int64_t n_edges,
-                                                       uint32_t* __restrict__ keys, int32_t* __restrict__ max_index) {
+                                                       uint32_t* __restrict__ keys, int32_t* __restrict__ max_index,
+                                                       int64_t n_nodes, int64_t n_src, int32_t* __restrict__ status,
+                                                       int32_t* __restrict__ host_flag) {
   __shared__ int wave_max[4];
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int m = -1;
+  bool bad = false;
   for (; e < n_edges; e += (int64_t)gridDim.x * blockDim.x) {
-    int s = (int)src[e], d = (int)dst[e];
+    const int64_t s64 = src[e], d64 = dst[e];
+    if (status != nullptr && (s64 < 0 || s64 >= n_src || d64 < 0 || d64 >= n_nodes)) {
+      keys[e] = (uint32_t)n_nodes;
+      bad = true;
+      continue;
+    }
+    int s = (int)s64, d = (int)d64;
     keys[e] = (uint32_t)d;
     m = max(m, max(s, d));
+  }
+  if (__ballot(bad) != 0 && (threadIdx.x & 63) == 0) {
+    atomicOr(status, 1);
+    if (host_flag != nullptr) *(volatile int32_t*)host_flag = 1;
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
@@ -51,11 +67,13 @@ __global__ void __launch_bounds__(256) coo_keys_kernel(const int64_t* __restrict
 }
 
 // col[p] = src[edge_id[p]]
+// col[p] = src[edge_id[p]]; positions behind the kept entries (dropped edges of the range-checked form) get a harmless 0
 __global__ void __launch_bounds__(256) gather_col_kernel(const int64_t* __restrict__ src,
                                                          const uint32_t* __restrict__ edge_id, int64_t n_edges,
-                                                         int32_t* __restrict__ col) {
+                                                         int32_t* __restrict__ col, const int32_t* __restrict__ n_kept) {
   int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  for (; p < n_edges; p += (int64_t)gridDim.x * blockDim.x) col[p] = (int32_t)src[edge_id[p]];
+  const int64_t kept = n_kept != nullptr ? (int64_t)*n_kept : n_edges;
+  for (; p < n_edges; p += (int64_t)gridDim.x * blockDim.x) col[p] = p < kept ? (int32_t)src[edge_id[p]] : 0;
 }
 
 // rowptr[i] = first position p with sorted_dst[p] >= i  (i in [0, n_nodes])
@@ -169,7 +187,13 @@ __global__ void __launch_bounds__(256) csr_transposed_coo_kernel(int n_nodes, in
                                                                  const int32_t* __restrict__ col, int64_t* __restrict__ out_src,
                                                                  int64_t* __restrict__ out_dst) {
   int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t kept = rowptr[n_nodes];        // < n_edges when a range-checked build dropped edges
   for (; p < n_edges; p += (int64_t)gridDim.x * blockDim.x) {
+    if (p >= kept) {                           // no entry here: an id the transposed graph's build drops again
+      out_src[p] = -1;
+      out_dst[p] = -1;
+      continue;
+    }
     int lo = 0, hi = n_nodes;                  // largest row with rowptr[row] <= p
     while (hi - lo > 1) {
       const int mid = (lo + hi) >> 1;
@@ -250,14 +274,17 @@ __global__ void __launch_bounds__(256) build_hist_kernel(const int64_t* __restri
                                                          int64_t n_edges, int n_nodes, int n_src, int* __restrict__ deg,
                                                          int* __restrict__ deg_ns, int* __restrict__ maxp1,
                                                          int* __restrict__ status, int32_t* __restrict__ plan,
-                                                         int cap_long, int cap_chunks) {
+                                                         int cap_long, int cap_chunks, int32_t* __restrict__ host_flag) {
   __shared__ int s_cnt[BUILD_WIN], s_ns[BUILD_WIN];
   __shared__ int s_min, s_max, s_top;
   if (blockIdx.x == 0 && threadIdx.x == 0) {  // header of the long-row plan: the scan kernel registers the long rows
     plan[0] = 0; plan[1] = 0; plan[2] = cap_long; plan[3] = cap_chunks;
   }
   const TileEdges t = load_tile(src, dst, n_edges, n_nodes, n_src, &s_min, &s_max);
-  if (__ballot(t.bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(status, 1);
+  if (__ballot(t.bad) != 0 && (threadIdx.x & 63) == 0) {
+    atomicOr(status, 1);
+    if (host_flag != nullptr) *(volatile int32_t*)host_flag = 1;   // sticky, host-visible: read without a synchronisation
+  }
   if (t.dmin > t.dmax) return;
   int m = 0;
 #pragma unroll
@@ -536,6 +563,14 @@ __global__ void __launch_bounds__(16 * ROWS_PER_BLOCK) build_rows_kernel(int n_n
     *status = *ws_status;
     *ws_status = 0;
   }
+  if (blockIdx.x == gridDim.x - 1) {           // dropped edges leave positions behind the last row: defined, harmless
+    for (int64_t p = (int64_t)rowptr[n_nodes] + threadIdx.x; p < n_edges; p += blockDim.x) {
+      col[p] = 0;
+      edge_id[p] = 0x7fffffff;
+      if (edis_raw != nullptr) edis_raw[p] = 0.0f;
+      if (edis_looped != nullptr) edis_looped[p] = 0.0f;
+    }
+  }
   // ---- short rows: rank sort by input position, 16 lanes per row, up to 4 entries per lane; every lane group takes
   // ROWS_PER_GROUP rows with the loads of all of them issued before the first is ranked (the kernel is a chain of
   // dependent memory round trips -- row pointers, entries, deg^-1/2 of the sources -- so rows in flight are its speed)
@@ -709,7 +744,7 @@ extern "C" {
 
 const char* egc_last_error(void) { return g_last_error.c_str(); }
 
-const char* egc_version(void) { return "egc_hip 0.1.0 gfx950"; }
+const char* egc_version(void) { return "egc_hip 0.3.0 gfx950"; }
 
 int64_t egc_plan_ints(int64_t n_nodes, int64_t n_edges) {
   if (n_nodes < 0 || n_edges < 0) return -1;
@@ -720,7 +755,7 @@ int64_t egc_plan_ints(int64_t n_nodes, int64_t n_edges) {
 size_t egc_coo_to_csr_workspace_bytes(int64_t n_nodes, int64_t n_edges) {
   if (n_nodes < 0 || n_edges < 0) return 0;
   size_t temp = 0;
-  if (sort_temp_bytes(n_nodes, n_edges, &temp) != hipSuccess) return 0;
+  if (sort_temp_bytes(n_nodes + 1, n_edges, &temp) != hipSuccess) return 0;   // (+1: the checked form's key for dropped edges)
   // keys_in + keys_out + rocprim temp
   return 2 * align256((size_t)n_edges * sizeof(uint32_t)) + align256(temp) + 256;
 }
@@ -728,6 +763,13 @@ size_t egc_coo_to_csr_workspace_bytes(int64_t n_nodes, int64_t n_edges) {
 int egc_coo_to_csr(const int64_t* src, const int64_t* dst, int64_t n_edges, int64_t n_nodes, int32_t* rowptr,
                    int32_t* col, int32_t* edge_id, int32_t* max_index, void* workspace, size_t workspace_bytes,
                    egc_stream_t stream_) {
+  return egc_coo_to_csr_checked(src, dst, n_edges, n_nodes, 0, rowptr, col, edge_id, max_index, nullptr, nullptr, workspace,
+                                workspace_bytes, stream_);
+}
+
+int egc_coo_to_csr_checked(const int64_t* src, const int64_t* dst, int64_t n_edges, int64_t n_nodes, int64_t n_src_rows,
+                           int32_t* rowptr, int32_t* col, int32_t* edge_id, int32_t* max_index, int32_t* status,
+                           int32_t* host_flag, void* workspace, size_t workspace_bytes, egc_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (n_nodes < 0 || n_edges < 0 || n_nodes >= ((int64_t)1 << 31) - 1 || n_edges >= ((int64_t)1 << 31) - 1)
     return EGC_ERR_INVALID;
@@ -736,12 +778,18 @@ int egc_coo_to_csr(const int64_t* src, const int64_t* dst, int64_t n_edges, int6
 
   init_scalar_kernel<<<1, 1, 0, stream>>>(max_index, -1);
   EGC_LAUNCH_CHECK("init_scalar_kernel");
+  if (status != nullptr) {
+    init_scalar_kernel<<<1, 1, 0, stream>>>(status, 0);
+    EGC_LAUNCH_CHECK("init_scalar_kernel");
+  }
   if (n_edges == 0) {
     EGC_HIP_TRY(hipMemsetAsync(rowptr, 0, (size_t)(n_nodes + 1) * sizeof(int32_t), stream));
     return EGC_OK;
   }
+  const int64_t n_src = n_src_rows > 0 ? n_src_rows : n_nodes;
+  const int64_t n_keys = status != nullptr ? n_nodes + 1 : n_nodes;   // the checked form sorts dropped edges under key n_nodes
   size_t temp = 0;
-  EGC_HIP_TRY(sort_temp_bytes(n_nodes, n_edges, &temp));
+  EGC_HIP_TRY(sort_temp_bytes(n_keys, n_edges, &temp));
   const size_t kbytes = align256((size_t)n_edges * sizeof(uint32_t));
   if (workspace == nullptr || workspace_bytes < 2 * kbytes + align256(temp)) return EGC_ERR_WORKSPACE;
   char* ws = (char*)workspace;
@@ -752,16 +800,17 @@ int egc_coo_to_csr(const int64_t* src, const int64_t* dst, int64_t n_edges, int6
   const int threads = 256;
   const int blocks = (int)std::min<int64_t>(ceil_div(n_edges, threads), 256 * 8);
   const int key_blocks = std::min(blocks, 512);
-  coo_keys_kernel<<<key_blocks, threads, 0, stream>>>(src, dst, n_edges, keys_in, max_index);
+  coo_keys_kernel<<<key_blocks, threads, 0, stream>>>(src, dst, n_edges, keys_in, max_index, n_nodes, n_src, status, host_flag);
   EGC_LAUNCH_CHECK("coo_keys_kernel");
   // Stable LSD radix sort of (dst, input position): the value array IS edge_id.
   EGC_HIP_TRY(rocprim::radix_sort_pairs(sort_temp, temp, (const uint32_t*)keys_in, keys_out,
                                         rocprim::counting_iterator<uint32_t>(0), (uint32_t*)edge_id,
-                                        (size_t)n_edges, 0u, key_bits(n_nodes), stream));
-  gather_col_kernel<<<blocks, threads, 0, stream>>>(src, (const uint32_t*)edge_id, n_edges, col);
-  EGC_LAUNCH_CHECK("gather_col_kernel");
+                                        (size_t)n_edges, 0u, key_bits(n_keys), stream));
   rowptr_kernel<<<(int)ceil_div(n_nodes + 1, threads), threads, 0, stream>>>(keys_out, n_edges, n_nodes, rowptr);
   EGC_LAUNCH_CHECK("rowptr_kernel");
+  gather_col_kernel<<<blocks, threads, 0, stream>>>(src, (const uint32_t*)edge_id, n_edges, col,
+                                                    status != nullptr ? rowptr + n_nodes : nullptr);
+  EGC_LAUNCH_CHECK("gather_col_kernel");
   return EGC_OK;
 }
 
@@ -809,7 +858,8 @@ size_t egc_graph_build_scratch_bytes(int64_t n_edges) {
 int egc_graph_build(const int64_t* src, const int64_t* dst, int64_t n_edges, int64_t n_nodes, int64_t n_src_rows,
                     int32_t* rowptr, int32_t* col, int32_t* edge_id, int32_t* max_index, float* dis_raw,
                     float* dis_looped, float* edge_dis_raw, float* edge_dis_looped, int32_t* plan, int32_t* status,
-                    void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes, egc_stream_t stream_) {
+                    int32_t* host_flag, void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes,
+                    egc_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (n_nodes < 0 || n_edges < 0 || n_nodes >= ((int64_t)1 << 30) || n_edges >= ((int64_t)1 << 30)) return EGC_ERR_INVALID;
   if (rowptr == nullptr || max_index == nullptr || plan == nullptr || status == nullptr) return EGC_ERR_INVALID;
@@ -831,6 +881,7 @@ int egc_graph_build(const int64_t* src, const int64_t* dst, int64_t n_edges, int
   if (n_nodes == 0) {  // nothing to build: header and flag only (every edge is out of range)
     plan_header_kernel<<<1, 1, 0, stream>>>(plan, (int)c.cap_long, (int)c.cap_chunks);
     init_scalar_kernel<<<1, 1, 0, stream>>>(status, n_edges > 0 ? 1 : 0);
+    if (n_edges > 0 && host_flag != nullptr) init_scalar_kernel<<<1, 1, 0, stream>>>(host_flag, 1);
     init_scalar_kernel<<<1, 1, 0, stream>>>(max_index, -1);
     EGC_HIP_TRY(hipMemsetAsync(rowptr, 0, sizeof(int32_t), stream));
     EGC_LAUNCH_CHECK("egc_graph_build(empty)");
@@ -838,7 +889,7 @@ int egc_graph_build(const int64_t* src, const int64_t* dst, int64_t n_edges, int
   }
   const int eblocks = (int)std::max<int64_t>(1, ceil_div(n_edges, (int64_t)BUILD_TILE));
   build_hist_kernel<<<eblocks, 256, 0, stream>>>(src, dst, n_edges, (int)n_nodes, (int)n_src, deg, deg_ns, maxp1, ws_status, plan,
-                                             (int)c.cap_long, (int)c.cap_chunks);
+                                             (int)c.cap_long, (int)c.cap_chunks, host_flag);
   EGC_LAUNCH_CHECK("build_hist_kernel");
   build_sums_kernel<<<nb, 1024, 0, stream>>>(deg, (int)n_nodes, bsum);
   EGC_LAUNCH_CHECK("build_sums_kernel");

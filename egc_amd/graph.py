@@ -46,6 +46,31 @@ def _device_guard(device):
     return torch.cuda.device(device)
 
 
+class _IndexFlag:
+    """The sticky out-of-range word of the graph builds (include/egc_hip.h: ``host_flag``): one int32 in pinned host
+    memory per process.  A build that meets a node id outside its range drops the edge and stores 1 here from the
+    device; the host reads the word -- a plain memory read, no synchronisation -- at the start of every later graph
+    build and layer call and raises.  The reference's PyG path raises at ``index_select`` (optimized_layers.py:191-193)
+    in the call itself; here the error surfaces at the next call into the package at the latest (like an
+    asynchronous device error), never not at all."""
+    _word = None
+    _view = None
+
+    @classmethod
+    def ptr(cls) -> int:
+        if cls._word is None:
+            cls._word = torch.zeros(1, dtype=torch.int32).pin_memory()
+            cls._view = C.c_int32.from_address(cls._word.data_ptr())
+        return cls._word.data_ptr()
+
+    @classmethod
+    def poll(cls):
+        if cls._view is not None and cls._view.value != 0:
+            cls._view.value = 0
+            raise RuntimeError("egc_amd: an edge_index handed to an earlier graph build holds node ids outside "
+                               "[0, num_nodes): index out of range (those edges were dropped)")
+
+
 def _require_cuda(t: torch.Tensor, what: str):
     if not t.is_cuda:
         raise RuntimeError(
@@ -71,7 +96,7 @@ class CSRGraph:
     # -- construction ---------------------------------------------------------------------
     @classmethod
     def from_edge_index(cls, edge_index: torch.Tensor, num_nodes: int, num_src_rows: int | None = None,
-                        build: str = "auto") -> "CSRGraph":
+                        build: str = "auto", _poll: bool = True) -> "CSRGraph":
         """COO ``edge_index`` (int64 [2, E], row 0 = source, row 1 = destination) -> CSRGraph.
         ``num_src_rows`` (>= num_nodes) is the size of the source index space when it is larger than the
         set of rows (owned + halo vertices of a partition).
@@ -86,6 +111,8 @@ class CSRGraph:
         _require_cuda(edge_index, "edge_index")
         if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.size(0) != 2:
             raise RuntimeError("egc_amd: edge_index must be an int64 tensor of shape [2, E]")
+        if _poll:
+            _IndexFlag.poll()
         lib = _C.load()
         dev = edge_index.device
         ei = edge_index.contiguous()
@@ -102,19 +129,25 @@ class CSRGraph:
             # the kernels): rowptr | col | edge_id | max_index | long-row plan, each piece 16-byte aligned
             e1 = max(e, 1)
             plan_ints = int(lib.egc_plan_ints(n, e))
-            sizes = (n + 1, e1, e1, 1, plan_ints)
+            sizes = (n + 1, e1, e1, 1, plan_ints, 1)
             offs, total = [], 0
             for sz in sizes:
                 offs.append(total)
                 total += (sz + 3) & ~3
             slab = torch.empty(total, dtype=torch.int32, device=dev)
-            rowptr, col, edge_id, max_index, plan = (slab[o:o + sz] for o, sz in zip(offs, sizes))
+            rowptr, col, edge_id, max_index, plan, status = (slab[o:o + sz] for o, sz in zip(offs, sizes))
             ws_bytes = lib.egc_coo_to_csr_workspace_bytes(n, e)
             ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
-            _C.check(lib.egc_coo_to_csr(ei[0].data_ptr(), ei[1].data_ptr(), e, n, rowptr.data_ptr(), col.data_ptr(),
-                                        edge_id.data_ptr(), max_index.data_ptr(), ws.data_ptr(), ws.numel(),
-                                        _stream_ptr(dev)), "egc_coo_to_csr")
-            return cls._prepare(n, e, rowptr, col, edge_id, max_index, num_src_rows, plan=plan)
+            _C.check(lib.egc_coo_to_csr_checked(ei[0].data_ptr(), ei[1].data_ptr(), e, n,
+                                                int(num_src_rows) if num_src_rows is not None else 0, rowptr.data_ptr(),
+                                                col.data_ptr(), edge_id.data_ptr(), max_index.data_ptr(), status.data_ptr(),
+                                                _IndexFlag.ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(dev)),
+                     "egc_coo_to_csr_checked")
+            g = cls._prepare(n, e, rowptr, col, edge_id, max_index, num_src_rows, plan=plan)
+            g._status = status
+            if os.environ.get("EGC_CHECK_INDICES", "0") not in ("", "0"):
+                g.check_indices()
+            return g
 
     @classmethod
     def _build_fast(cls, ei: torch.Tensor, n: int, e: int, num_src_rows) -> "CSRGraph":
@@ -151,7 +184,8 @@ class CSRGraph:
                                          edge_id.data_ptr(), max_index.data_ptr(), dis_raw.data_ptr(), dis_looped.data_ptr(),
                                          edr.data_ptr() if edr is not None else None,
                                          edl.data_ptr() if edl is not None else None, plan.data_ptr(), status.data_ptr(),
-                                         ws.data_ptr(), ws.numel(), scratch.data_ptr(), scratch.numel(), _stream_ptr(dev)),
+                                         _IndexFlag.ptr(), ws.data_ptr(), ws.numel(), scratch.data_ptr(), scratch.numel(),
+                                         _stream_ptr(dev)),
                      "egc_graph_build")
         g = cls(n, e, rowptr, col, edge_id, dis_raw, dis_looped, max_index, plan, ns)
         g.edge_dis_raw, g.edge_dis_looped = edr, edl
@@ -163,9 +197,13 @@ class CSRGraph:
     def check_indices(self) -> "CSRGraph":
         """Raise if the graph was built from node ids outside [0, N) -- what the reference's PyG path does at
         ``index_select`` (optimized_layers.py:191-193).  Synchronises; called wherever the graph synchronises anyway
-        (trim_launches: cached layers, adj_t inputs) and on every build under EGC_CHECK_INDICES=1."""
+        (trim_launches: cached layers, adj_t inputs) and on every build under EGC_CHECK_INDICES=1.  Paths that never
+        synchronise (per-batch graphs, recorded steps) are covered by the sticky host-visible flag (_IndexFlag), polled
+        at every later build and layer call."""
         st = getattr(self, "_status", None)
         if st is not None and int(st.item()) != 0:
+            if _IndexFlag._view is not None:
+                _IndexFlag._view.value = 0      # reported here
             raise RuntimeError("egc_amd: edge_index holds node ids outside [0, num_nodes): index out of range")
         return self
 
@@ -259,7 +297,7 @@ class CSRGraph:
                 _C.check(_C.load().egc_csr_transposed_coo(n, e, self.rowptr.data_ptr(), self.col.data_ptr(),
                                                           coo[0].data_ptr(), coo[1].data_ptr() if e else None,
                                                           _stream_ptr(dev)), "egc_csr_transposed_coo")
-                self._transposed = CSRGraph.from_edge_index(coo, ns, max(n, 1))
+                self._transposed = CSRGraph.from_edge_index(coo, ns, max(n, 1), _poll=False)   # (derived, not user input)
         if self._n_chunks is not None and self._n_chunks >= 0:   # a static graph: its transpose is one too
             self._transposed.trim_launches()
         return self._transposed
@@ -283,6 +321,7 @@ class CSRGraph:
 
     # -- C view -----------------------------------------------------------------------------
     def c_struct(self) -> _C.EgcGraph:
+        _IndexFlag.poll()      # every layer call passes here: a bad edge_index of an earlier build surfaces now
         if self._n_chunks is None:
             # A host copy of the chunk count would trim the launch to the chunks that exist, at the price of one
             # synchronisation per graph.  Measured (ogbn-mag shape: 208 k chunk slots, 52 k idle workgroups per
@@ -320,13 +359,25 @@ _BUILD_WS: "dict[tuple, torch.Tensor]" = {}
 
 def _build_workspace(dev, nbytes: int) -> torch.Tensor:
     """Scratch of egc_graph_build: zero before its first use, left zero by every call -> one buffer per (device,
-    stream), grown (and zeroed again) when a bigger graph comes along."""
+    stream), grown (and zeroed again) when a bigger graph comes along.  While a hipGraph is being recorded the buffer
+    and its zero-fill belong to THAT recording (capture-pool memory and a memset node of the graph being captured):
+    it is allocated and zeroed inside the recording and never enters the process-wide cache -- a later recording
+    must not inherit a buffer whose zero-fill exists only as a node of an earlier graph."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.zeros(max(int(nbytes), 1 << 12), dtype=torch.uint8, device=dev)
     key = (str(dev), _stream_ptr(dev))
     ws = _BUILD_WS.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.zeros(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=dev)
         _BUILD_WS[key] = ws
     return ws
+
+
+def drop_stream_workspaces(stream) -> None:
+    """Forget the build scratch cached for `stream` (a torch.cuda.Stream about to go away)."""
+    raw = stream.cuda_stream
+    for key in [k for k in _BUILD_WS if k[1] == raw]:
+        del _BUILD_WS[key]
 
 
 class SparseTensor:
@@ -365,7 +416,11 @@ class GraphCache:
         self.capacity = capacity
         self._items: "OrderedDict[tuple, tuple]" = OrderedDict()
 
-    def get(self, edge_index: torch.Tensor, num_nodes: int) -> CSRGraph:
+    def get(self, edge_index: torch.Tensor, num_nodes: int, static: bool = False) -> CSRGraph:
+        # a STATIC graph (cached=True / cache=True layers: one full graph, built once) beyond the small sizes takes the
+        # sort pipeline whatever its density: its edges come in arbitrary order and its hubs are long, which is where the
+        # tile-based build degrades (1.4 ms against 240 us at the ogbn-arxiv shape); per-batch graphs keep "auto"
+        build = "sort" if (static and int(edge_index.size(1)) > _FAST_BUILD_SMALL) else "auto"
         scope = None
         if edge_index.is_cuda and torch.cuda.is_current_stream_capturing():
             # A recording (hipGraph) must CONTAIN the build: a replay reads whatever the edge_index buffer holds then,
@@ -374,14 +429,14 @@ class GraphCache:
             # per layer call -- slower, never stale.
             scope = _RECORDING[0]
             if scope is None:
-                return CSRGraph.from_edge_index(edge_index, num_nodes)
+                return CSRGraph.from_edge_index(edge_index, num_nodes, build=build)
         key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), int(num_nodes),
                edge_index.device, scope)
         hit = self._items.get(key)
         if hit is not None and hit[0] is edge_index:
             self._items.move_to_end(key)
             return hit[1]
-        g = CSRGraph.from_edge_index(edge_index, num_nodes)
+        g = CSRGraph.from_edge_index(edge_index, num_nodes, build=build)
         self._items[key] = (edge_index, g)
         while len(self._items) > self.capacity:
             self._items.popitem(last=False)
@@ -414,8 +469,9 @@ class recording_scope:
         return False
 
 
-def graph_from_input(edge_index, num_nodes: int) -> CSRGraph:
-    """Dispatch on the two input forms of the reference layers (Tensor COO or SparseTensor adj_t)."""
+def graph_from_input(edge_index, num_nodes: int, static: bool = False) -> CSRGraph:
+    """Dispatch on the two input forms of the reference layers (Tensor COO or SparseTensor adj_t).  ``static``: the
+    caller keeps the graph (cached layers)."""
     if isinstance(edge_index, CSRGraph):
         return edge_index
     if isinstance(edge_index, SparseTensor):
@@ -423,5 +479,5 @@ def graph_from_input(edge_index, num_nodes: int) -> CSRGraph:
     if isinstance(edge_index, torch.Tensor):
         if edge_index.layout == torch.sparse_csr:
             return CSRGraph.from_csr(edge_index.crow_indices(), edge_index.col_indices(), num_nodes)
-        return GLOBAL_GRAPH_CACHE.get(edge_index, num_nodes)
+        return GLOBAL_GRAPH_CACHE.get(edge_index, num_nodes, static)
     raise RuntimeError(f"egc_amd: unsupported edge_index type {type(edge_index)}")

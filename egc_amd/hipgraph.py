@@ -67,6 +67,8 @@ class GraphedStep:
                 self._clear_grads()
                 fn()
         torch.cuda.current_stream().wait_stream(side)
+        from . import graph as _graph
+        _graph.drop_stream_workspaces(side)     # the warm-up stream is gone after this: so is its build scratch
         self._clear_grads()
         self.graph = torch.cuda.CUDAGraph()
         with recording_scope(), torch.cuda.graph(self.graph, pool=pool):

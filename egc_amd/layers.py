@@ -134,7 +134,7 @@ class EfficientGraphConv(nn.Module):
         if self.cache and self._cached_graph is not None:
             graph = self._cached_graph
         else:
-            graph = graph_from_input(edge_index, x.size(0))
+            graph = graph_from_input(edge_index, x.size(0), static=bool(self.cache))
             if self.cache:
                 self._cached_graph = graph.trim_launches()
         w = self.comb_weights.weight

@@ -18,20 +18,32 @@ graphs of ~50 k nodes would feel); set EGC_USE_TORCH_OP=1, or run under torch.co
 """
 from __future__ import annotations
 
+import ctypes as C
+import itertools
 import os
 import weakref
 
 import torch
 
+from . import _C
 from . import functional as F
 
 _REGISTRY: "weakref.WeakValueDictionary[int, object]" = weakref.WeakValueDictionary()
+_NEXT_HANDLE = itertools.count(1)     # handles are never reused: a freed object's handle stays stale for good
 
 
 def handle_of(obj) -> int:
-    """Integer handle of a CSRGraph / LayerSpec for the operator schema; valid while `obj` is alive."""
-    h = id(obj)
-    _REGISTRY[h] = obj
+    """Integer handle of a CSRGraph / LayerSpec for the operator schema; valid while `obj` is alive.  One handle per
+    object, drawn from a counter (``id(obj)`` can be handed to a NEW object once the old one is freed, and a stale
+    handle would then resolve to it)."""
+    h = getattr(obj, "_egc_handle", None)
+    if h is None or _REGISTRY.get(h) is not obj:
+        h = next(_NEXT_HANDLE)
+        try:
+            obj._egc_handle = h
+        except AttributeError:     # objects without a __dict__: a fresh handle per call, still unique
+            pass
+        _REGISTRY[h] = obj
     return h
 
 
@@ -68,11 +80,18 @@ def layer_forward_train(x: torch.Tensor, wcat: torch.Tensor, bcat: torch.Tensor 
 
 @layer_forward_train.register_fake
 def _(x, wcat, bcat, bias, graph_handle, spec_handle):
+    # shapes from the same sources as the real operator (egc_aggregate_combine_train): the statistics width is the
+    # library's (it includes the 8-bit arg tables), arg_max / arg_min exist only for layers with max / min
     graph, spec = _get(graph_handle), _get(spec_handle)
     n = x.shape[0]
     i32 = dict(dtype=torch.int32)
+    codes = [spec.c.aggrs[t] for t in range(spec.c.num_aggrs)]
+    stats_w = max(int(_C.load().egc_train_stats_floats(C.byref(spec.c))), 1)
+
+    def arg(code):
+        return x.new_empty((n, spec.ldb), **i32) if code in codes else x.new_empty((0,), **i32)
     return (x.new_empty((n, spec.f_out)), x.new_empty((graph.n_src_rows, spec.ldb)), x.new_empty((n, spec.w_cols)),
-            x.new_empty((n, 1)), x.new_empty((max(n, 1),), **i32), x.new_empty((n, spec.ldb), **i32), x.new_empty((n, spec.ldb), **i32))
+            x.new_empty((n, stats_w)), x.new_empty((max(n, 1),), **i32), arg(_C.AGGR_MAX), arg(_C.AGGR_MIN))
 
 
 @torch.library.custom_op("egc_amd::layer_backward", mutates_args=(), device_types="cuda")

@@ -126,7 +126,7 @@ class EGConv(nn.Module):
         if self.cached and self._cached_graph is not None:
             graph, spec = self._cached_graph
         else:
-            graph = graph_from_input(edge_index, x.size(self.node_dim))
+            graph = graph_from_input(edge_index, x.size(self.node_dim), static=bool(self.cached))
             is_coo = isinstance(edge_index, torch.Tensor) and edge_index.layout == torch.strided
             spec = self._spec_coo if is_coo else self._spec_adj
             if self.cached:

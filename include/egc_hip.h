@@ -107,10 +107,22 @@ size_t egc_coo_to_csr_workspace_bytes(int64_t n_nodes, int64_t n_edges);
  * index_select/scatter index handling of MessagePassing.propagate (layers.py:191-193,
  * optimized_layers.py:191-193) and ToSparseTensor (experiments/utils.py:95-113).
  * Writes rowptr[n_nodes+1], col[n_edges], edge_id[n_edges], max_index[1].
- * Returns EGC_ERR_INVALID if n_nodes or n_edges >= 2^31.  Out-of-range node ids are NOT detected. */
+ * Returns EGC_ERR_INVALID if n_nodes or n_edges >= 2^31.  Out-of-range node ids are NOT detected by this entry
+ * (egc_coo_to_csr_checked is the one the host side of this repository calls). */
 int egc_coo_to_csr(const int64_t* src, const int64_t* dst, int64_t n_edges, int64_t n_nodes,
                    int32_t* rowptr, int32_t* col, int32_t* edge_id, int32_t* max_index,
                    void* workspace, size_t workspace_bytes, egc_stream_t stream);
+
+/* The same conversion with every node id RANGE-CHECKED, as egc_graph_build does it: an edge whose source is outside
+ * [0, n_src_rows) (0 = n_nodes) or whose destination is outside [0, n_nodes) is dropped -- it sorts behind the last row,
+ * rowptr[n_nodes] is the number of edges kept, col / edge_id behind it are defined (0 / undefined order) and never
+ * referenced by a row -- and two flags are raised: *status (device int32, written by every call: 0 or 1) and, when
+ * given, *host_flag = 1 (a STICKY word in host-visible memory, e.g. hipHostMalloc'ed: never cleared by the library, so
+ * the host can poll it without synchronising the stream and report the error at its next call -- the reference's PyG
+ * path raises at index_select, optimized_layers.py:191-193).  Same workspace as egc_coo_to_csr. */
+int egc_coo_to_csr_checked(const int64_t* src, const int64_t* dst, int64_t n_edges, int64_t n_nodes, int64_t n_src_rows,
+                           int32_t* rowptr, int32_t* col, int32_t* edge_id, int32_t* max_index, int32_t* status,
+                           int32_t* host_flag, void* workspace, size_t workspace_bytes, egc_stream_t stream);
 
 /* One call for a per-batch graph: COO -> CSR by destination (stable inside a row) + both deg^-1/2 tables + their
  * per-entry copies + the long-row plan, in five launches and without a library sort -- what egc_coo_to_csr +
@@ -119,8 +131,11 @@ int egc_coo_to_csr(const int64_t* src, const int64_t* dst, int64_t n_edges, int6
  * cifar/models.py:61-75; gcn_norm's degree pass).  Node ids are RANGE-CHECKED here: an edge whose source is outside
  * [0, n_src_rows) or whose destination is outside [0, n_nodes) is dropped and *status (device int32, written by
  * every call: 0 or 1) is set -- the PyG path behind optimized_layers.py:191-193 raises on such an index; the host side
- * reads the flag at its next synchronisation point (CSRGraph.check_indices).  rowptr[n_nodes] is then the number
- * of edges kept.  n_src_rows = 0 means n_nodes.  dis_* / edge_dis_* may be NULL (skipped).
+ * reads the flag at its next synchronisation point (CSRGraph.check_indices); host_flag (may be NULL) is the sticky
+ * host-visible word of egc_coo_to_csr_checked, polled without a synchronisation.  rowptr[n_nodes] is then the number
+ * of edges kept; col / edge_id / edge_dis_* behind it are written with harmless values (0 / INT32_MAX / 0), and
+ * egc_csr_transposed_coo emits (-1, -1) for those positions, which the transposed graph's build drops again.
+ * n_src_rows = 0 means n_nodes.  dis_* / edge_dis_* may be NULL (skipped).
  * Workspace: egc_graph_build_workspace_bytes() bytes, zero-filled before its FIRST use; every call leaves ALL of it
  * zero again, so one buffer (of the largest size needed) serves graphs of any size on the same stream.  Scratch:
  * egc_graph_build_scratch_bytes() bytes, any content (sort area of rows longer than 4096 entries).
@@ -130,7 +145,8 @@ size_t egc_graph_build_scratch_bytes(int64_t n_edges);
 int egc_graph_build(const int64_t* src, const int64_t* dst, int64_t n_edges, int64_t n_nodes, int64_t n_src_rows,
                     int32_t* rowptr, int32_t* col, int32_t* edge_id, int32_t* max_index, float* dis_raw,
                     float* dis_looped, float* edge_dis_raw, float* edge_dis_looped, int32_t* plan, int32_t* status,
-                    void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes, egc_stream_t stream);
+                    int32_t* host_flag, void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes,
+                    egc_stream_t stream);
 
 /* Degree statistics + long-row plan for an existing CSR.  Replaces gcn_norm's degree scatter and
  * pow(-0.5) (layers.py:173-178, optimized_layers.py:131-137) -- the per-edge weight

@@ -62,3 +62,17 @@ def rel_err(a, b):
     if a.size == 0:
         return 0.0
     return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
+
+
+def elementwise_excess(a, b, tol=1e-5):
+    """Element-wise companion of rel_err (VERDICT r2 next #4c): the largest |a - b| / (tol |b| + tol s_row), with
+    s_row = max(1, max_j |b[row, j]|) the scale of the element's OWN output row -- rel_err alone measures every element
+    against the largest output of the whole array and says nothing about small rows next to large ones.  <= 1 passes."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    if a.size == 0:
+        return 0.0
+    b2 = b.reshape(b.shape[0], -1) if b.ndim > 1 else b.reshape(1, -1)
+    a2 = a.reshape(b2.shape)
+    s_row = np.maximum(1.0, np.abs(b2).max(axis=1, keepdims=True))
+    return float((np.abs(a2 - b2) / (tol * np.abs(b2) + tol * s_row)).max())

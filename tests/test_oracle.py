@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import golden_names, load_golden, oracle_forward, rel_err
+from golden_util import elementwise_excess, golden_names, load_golden, oracle_forward, rel_err
 from oracle import egc_oracle as orc
 
 
@@ -16,6 +16,7 @@ def test_oracle_reproduces_golden(name):
     assert out.shape == g["out"].shape and out.dtype == np.float32
     # differences come only from numpy-vs-torch fp32 GEMM summation order
     assert rel_err(out, g["out"]) <= 2e-6, rel_err(out, g["out"])
+    assert elementwise_excess(out, g["out"], 1e-5) <= 1.0     # element-wise, against each element's own row scale
 
 
 def test_golden_set_covers_the_survey_list():

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import golden_names, load_golden, oracle_forward, rel_err
+from golden_util import elementwise_excess, golden_names, load_golden, oracle_forward, rel_err
 from oracle import egc_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -61,6 +61,10 @@ def test_golden(name):
     out = run_layer(layer, g, dev)
     assert out.shape == g["out"].shape
     assert rel_err(out, g["out"]) <= TOL, f"{name}: rel err {rel_err(out, g['out']):.3e}"
+    # element by element against the element's own row scale (small rows next to large ones); layers with std / var
+    # amplify the last bits of `bases` 158x on (nearly) constant neighbourhoods: 1e-4 there
+    etol = 1e-4 if any(a in ("std", "var") for a in g["meta"]["aggrs"]) else TOL
+    assert elementwise_excess(out, g["out"], etol) <= 1.0, f"{name}: element-wise excess {elementwise_excess(out, g['out'], etol):.3f}"
     # and against the oracle (pins the oracle and the HIP path to each other as well)
     assert rel_err(out, oracle_forward(g, orc)) <= TOL
 
