@@ -8,8 +8,9 @@ aggregators sum+mean+max+symnorm, fp32).
 A "step" is one full layer forward through the C ABI (basis GEMM + fused aggregate/combine) with every input
 already resident in HBM and the CSR pre-built (static graph, the reference's ``cached=True``).  Rank 0 prints
 ONE JSON line.  For N > 1 the driver launches this file under torch.distributed.run (one rank per GPU, RCCL)
-and the workload is BASELINE config 5: ONE ogbn-mag-shaped graph, vertex-partitioned over the ranks (strong
-scaling; ``--workload arxiv-weak`` keeps round 1's weak-scaling synthetic).
+and the line is STRONG scaling of the same config-2 graph, vertex-partitioned over the ranks (so the N = 1 point of
+the curve is this file's N = 1 line), with BASELINE config 5 -- the homogeneous ogbn-mag shape and the ~21 M-edge
+typed graph through a partitioned REGConv -- nested under ``strong_scaling`` (bench_multi.py).
 
 Extra objects on the JSON line:
   roofline      -- the dominant kernel (fused aggregate+combine launch): SURVEY.md 8(d) algorithmic bytes of
@@ -52,7 +53,8 @@ def dist_setup(n_gpus):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    force = os.environ.get("EGC_BENCH_FORCE_PARTITION", "0") not in ("", "0") and "RANK" in os.environ
+    if world > 1 or force:   # (force: the partitioned code path with RCCL at world size 1, tests/test_bench_multi_gpu.py)
         import torch.distributed as dist
         backend = os.environ.get("EGC_BENCH_BACKEND", "nccl")  # "gloo": functional smoke test on a shared GPU
         local = local % max(torch.cuda.device_count(), 1)
@@ -327,7 +329,7 @@ def bench_rmag(args, world, dev):
     import egc_amd
     from egc_amd import workloads as wl
     if world > 1:
-        raise SystemExit("bench.py --workload rmag: the relational layer runs on one GPU (no partitioned REGConv)")
+        raise SystemExit("bench_rmag is the one-GPU form; N > 1 goes through bench_multi.strong_typed")
     torch.manual_seed(args.seed)
     nodes, rel = wl.rmag_like(seed=args.seed)
     adj = {}
@@ -348,7 +350,7 @@ def bench_rmag(args, world, dev):
         ms = (time.perf_counter() - t0) / args.steps * 1e3
     print(json.dumps({
         "metric": METRIC, "value": entries / (ms * 1e-3), "unit": "edges/s", "n_gpus": 1, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": None, "vs_baseline": None,
         "dtype": "f32", "gemm": "fp16x2 / bf16x3 split, one GEMM per node type", "data": "synthetic",
         "config": {"workload": f"ogbn-mag-shaped typed graph ({sum(nodes.values())} nodes of {len(nodes)} types, "
                                f"{entries} CSR entries in {len(rel)} relations), REGConv {F_IN}->{F_OUT} H={HEADS} B={BASES}",
@@ -363,9 +365,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
-    ap.add_argument("--workload", default=None, choices=[None, "arxiv", "mag", "arxiv-weak", "rmag"],
-                    help="default: arxiv (config 2) on one GPU, mag (config 5, strong scaling) on several; rmag = the "
-                         "21 M-edge typed ogbn-mag graph through REGConv (SURVEY 8f row 4), one GPU only")
+    ap.add_argument("--workload", default=None, choices=[None, "all", "arxiv", "mag", "arxiv-weak", "rmag"],
+                    help="default: arxiv (config 2) on one GPU; on several GPUs `all` = config 2 strong scaling as the "
+                         "headline with config 5 (homogeneous mag, typed rmag through a partitioned REGConv) nested; "
+                         "arxiv / mag / rmag run one of them alone")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
 
@@ -373,10 +376,13 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    workload = args.workload or ("arxiv" if world == 1 else "mag")
-    if workload == "rmag":
+    workload = args.workload or ("arxiv" if world == 1 else "all")
+    if workload == "rmag" and world == 1:
         return bench_rmag(args, world, dev)
-    if workload != "arxiv" or world > 1:
+    forced = os.environ.get("EGC_BENCH_FORCE_PARTITION", "0") not in ("", "0") and "RANK" in os.environ
+    if forced and args.workload is None:
+        workload = "all"
+    if workload != "arxiv" or world > 1 or forced:
         import bench_multi  # the partitioned workloads live in their own file
         return bench_multi.run(args, world, rank, local, workload)
 
@@ -477,7 +483,8 @@ def main():
     result = {
         "metric": METRIC,
         "value": value, "unit": "edges/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": None,   # one GPU: neither weak nor strong
+        "vs_baseline": None,
         "dtype": "f32", "gemm": "exact fp32 MFMA" if gemm_exact() else
                  "fp16x2-split (3 x v_mfma_f32_32x32x16_f16 per k-step, fp32 accumulate, 22-bit operands)",
         "data": "synthetic",
@@ -543,7 +550,8 @@ def main():
             err = float((out_main.cpu() - ref_out).abs().max() / max(1.0, float(ref_out.abs().max())))
             log(f"cpu port: {cpu_s * 1e3:.1f} ms/forward on {threads} threads; HIP vs CPU port rel err {err:.2e}")
             result["cpu_baseline"] = {
-                "value": e_eff / cpu_s, "unit": "edges/s", "cores": threads, "kind": "port",
+                "value": e_eff / cpu_s, "unit": "edges/s", "cores": threads, "threads": threads,
+                "host_cores": os.cpu_count(), "kind": "port",   # `cores` = the threads actually used (the contract's field)
                 "sample": f"full config-2 layer forward (E_eff={e_cached}), gcn_norm cached; best of 8/16/32/64 "
                           f"torch threads, median of 5 runs each after a warm-up; {cpu_s * 1e3:.1f} ms per forward "
                           f"on a {os.cpu_count()}-core host",

@@ -128,6 +128,11 @@ SYMBOLS = {
     "egc_aggregate_combine_train_f32": (C.c_int, [C.POINTER(EgcGraph), C.POINTER(EgcLayer), C.c_void_p, C.c_int32,
                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "egc_aggregate_combine_train_rows_f32": (C.c_int, [C.POINTER(EgcGraph), C.POINTER(EgcLayer), C.c_void_p, C.c_int32,
+                                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                       C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t,
+                                                       C.c_void_p]),
+    "egc_gather_rows_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "egc_aggregate_combine_backward_f32": (C.c_int, [C.POINTER(EgcGraph), C.POINTER(EgcGraph), C.POINTER(EgcLayer),
                                                      C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,

@@ -602,6 +602,22 @@ int egc_aggregate_combine_train_f32(const egc_graph* graph, const egc_layer* lay
   return egc::arg_extrema(graph, layer, bases, ldb, stats, cnt, arg_max, arg_min, a8max, a8min, (hipStream_t)stream);
 }
 
+int egc_aggregate_combine_train_rows_f32(const egc_graph* graph, const egc_layer* layer, const float* bases, int32_t ldb,
+                                         const float* weightings, const float* bias, float* out, float* stats,
+                                         int32_t* cnt, int32_t* arg_max, int32_t* arg_min, int64_t row_begin,
+                                         int64_t row_end, void* workspace, size_t workspace_bytes, egc_stream_t stream) {
+  if (graph == nullptr || layer == nullptr || stats == nullptr || cnt == nullptr || row_end < 0) return EGC_ERR_INVALID;
+  bool arg_done = false;
+  int st = aggregate_combine_impl(graph, layer, bases, ldb, weightings, bias, nullptr, out, stats, cnt, row_begin, row_end,
+                                  workspace, workspace_bytes, stream, arg_max, arg_min, &arg_done);
+  // kernels that do not track the arg positions themselves leave them to one pass over ALL rows: it runs with the range
+  // that ends at the last row (the ranges of a split call are issued in ascending order)
+  if (st != EGC_OK || arg_done || row_end < graph->n_nodes) return st;
+  unsigned *a8max, *a8min;
+  arg8_tables(layer, graph->n_nodes, stats, arg_max != nullptr, arg_min != nullptr, &a8max, &a8min);
+  return egc::arg_extrema(graph, layer, bases, ldb, stats, cnt, arg_max, arg_min, a8max, a8min, (hipStream_t)stream);
+}
+
 static int aggregate_combine_impl(const egc_graph* graph, const egc_layer* layer, const float* bases, int32_t ldb,
                                   const float* weightings, const float* bias, const egc_post* post, float* out,
                                   float* stats, int32_t* cnt_out, int64_t row_begin, int64_t row_end, void* workspace,

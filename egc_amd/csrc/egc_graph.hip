@@ -711,6 +711,18 @@ __global__ void __launch_bounds__(16 * ROWS_PER_BLOCK) build_rows_kernel(int n_n
   }
 }
 
+// out[k][:] = table[idx[k]][:] for rows of w4 16-byte pieces (the send pack of the halo exchange): one piece per lane,
+// consecutive lanes on consecutive pieces of a row -- whole rows are read and written as contiguous runs
+__global__ void __launch_bounds__(256) gather_rows_kernel(const float4* __restrict__ table, const int64_t* __restrict__ idx,
+                                                          int64_t n_pieces, int w4, int64_t ld4, float4* __restrict__ out) {
+  int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; g < n_pieces; g += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t k = g / w4;
+    const int c = (int)(g - k * w4);
+    out[g] = table[idx[k] * ld4 + c];
+  }
+}
+
 __global__ void plan_header_kernel(int32_t* plan, int cap_long, int cap_chunks) {
   plan[0] = 0;
   plan[1] = 0;
@@ -837,6 +849,20 @@ int egc_csr_transposed_coo(int64_t n_nodes, int64_t n_edges, const int32_t* rowp
   const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(n_edges, (int64_t)256), 8192);
   csr_transposed_coo_kernel<<<blocks, 256, 0, stream>>>((int)n_nodes, n_edges, rowptr, col, out_src, out_dst);
   EGC_LAUNCH_CHECK("csr_transposed_coo_kernel");
+  return EGC_OK;
+}
+
+int egc_gather_rows_f32(const float* table, int64_t ld, const int64_t* idx, int64_t n_rows, int32_t width, float* out,
+                        egc_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_rows < 0 || width <= 0 || (width & 3) != 0 || (ld & 3) != 0 || ld < width) return EGC_ERR_INVALID;
+  if (n_rows == 0) return EGC_OK;
+  if (table == nullptr || idx == nullptr || out == nullptr) return EGC_ERR_INVALID;
+  if (((uintptr_t)table & 15) != 0 || ((uintptr_t)out & 15) != 0) return EGC_ERR_INVALID;
+  const int64_t pieces = n_rows * (width / 4);
+  const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(pieces, (int64_t)256), 256 * 16);
+  gather_rows_kernel<<<blocks, 256, 0, stream>>>((const float4*)table, idx, pieces, width / 4, ld / 4, (float4*)out);
+  EGC_LAUNCH_CHECK("gather_rows_kernel");
   return EGC_OK;
 }
 

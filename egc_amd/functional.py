@@ -167,9 +167,12 @@ def gemm_exact() -> bool:
 
 
 def egc_basis_transform(graph: CSRGraph, spec: LayerSpec, x: torch.Tensor, wcat: torch.Tensor,
-                        bcat: torch.Tensor | None, packed: torch.Tensor | None = None):
+                        bcat: torch.Tensor | None, packed: torch.Tensor | None = None,
+                        bases_out: torch.Tensor | None = None):
     """Step 1 (egc_basis_transform_packed / _f32): returns (bases [n_src_rows, ldb], weightings [N, W]).
-    Only the first N rows of bases are written; halo rows are the caller's (partitioned runs)."""
+    Only the first N rows of bases are written; halo rows are the caller's (partitioned runs).  ``bases_out``: a dense
+    float32 [>= N, ldb] block to write the basis rows into instead of a fresh array (a row range of a table shared by
+    several node types: relational EGC on a vertex partition); it is returned as ``bases``."""
     lib = _C.load()
     n = graph.n_nodes
     _check_f32(x, "x", (n, spec.f_in))
@@ -182,7 +185,13 @@ def egc_basis_transform(graph: CSRGraph, spec: LayerSpec, x: torch.Tensor, wcat:
     x = x.contiguous()
     wcat = wcat.contiguous()
     with _device_guard(dev):
-        bases = torch.empty((graph.n_src_rows, spec.ldb), dtype=torch.float32, device=dev)  # owned | halo rows
+        if bases_out is not None:
+            if (bases_out.dtype != torch.float32 or bases_out.dim() != 2 or bases_out.size(0) < n or bases_out.size(1) != spec.ldb
+                    or not bases_out.is_contiguous() or bases_out.device != dev or bases_out.data_ptr() % 16):
+                raise RuntimeError("egc_amd: bases_out must be a dense, 16-byte aligned float32 [>= N, ldb] block on x's device")
+            bases = bases_out
+        else:
+            bases = torch.empty((graph.n_src_rows, spec.ldb), dtype=torch.float32, device=dev)  # owned | halo rows
         weightings = torch.empty((n, spec.w_cols), dtype=torch.float32, device=dev)
         bcat_p = bcat.contiguous().data_ptr() if bcat is not None else None
         if gemm_exact():
@@ -443,9 +452,11 @@ def egc_layer_forward(graph: CSRGraph, spec: LayerSpec, x: torch.Tensor, wcat: t
 
 
 def egc_aggregate_combine_train(graph: CSRGraph, spec: LayerSpec, bases: torch.Tensor, weightings: torch.Tensor,
-                                bias: torch.Tensor | None):
+                                bias: torch.Tensor | None, between_ranges=None, split_at: int | None = None):
     """Training form of egc_aggregate_combine (egc_aggregate_combine_train_f32): returns
-    (out, saved) where ``saved`` = (stats, cnt, arg_max, arg_min) is what the backward consumes."""
+    (out, saved) where ``saved`` = (stats, cnt, arg_max, arg_min) is what the backward consumes.
+    ``split_at`` / ``between_ranges``: finish rows [0, split_at) first, call ``between_ranges()`` (e.g. wait for the halo
+    rows of ``bases``), then the rest (egc_aggregate_combine_train_rows_f32)."""
     lib = _C.load()
     n = graph.n_nodes
     _check_f32(bases, "bases", (graph.n_src_rows, spec.ldb))
@@ -463,12 +474,22 @@ def egc_aggregate_combine_train(graph: CSRGraph, spec: LayerSpec, bases: torch.T
         g = graph.c_struct()
         ws = graph.workspace(lib.egc_aggregate_workspace_bytes_for(C.byref(spec.c), C.byref(g)),
                              lib.egc_aggregate_workspace_zero_bytes(C.byref(spec.c), graph.n_nodes, graph.n_edges))
-        _C.check(lib.egc_aggregate_combine_train_f32(
-            C.byref(g), C.byref(spec.c), bases.data_ptr(), spec.ldb, weightings.data_ptr(),
-            bias.contiguous().data_ptr() if bias is not None else None, out.data_ptr(), stats.data_ptr(),
-            cnt.data_ptr(), arg_max.data_ptr() if arg_max is not None else None,
-            arg_min.data_ptr() if arg_min is not None else None, ws.data_ptr(), ws.numel(), _stream_ptr(dev)),
-            "egc_aggregate_combine_train_f32")
+        bias_p = bias.contiguous().data_ptr() if bias is not None else None
+        amax_p = arg_max.data_ptr() if arg_max is not None else None
+        amin_p = arg_min.data_ptr() if arg_min is not None else None
+        if split_at is None:
+            _C.check(lib.egc_aggregate_combine_train_f32(
+                C.byref(g), C.byref(spec.c), bases.data_ptr(), spec.ldb, weightings.data_ptr(), bias_p, out.data_ptr(),
+                stats.data_ptr(), cnt.data_ptr(), amax_p, amin_p, ws.data_ptr(), ws.numel(), _stream_ptr(dev)),
+                "egc_aggregate_combine_train_f32")
+        else:
+            for lo, hi in ((0, int(split_at)), (int(split_at), n)):
+                if lo > 0 and between_ranges is not None:
+                    between_ranges()
+                _C.check(lib.egc_aggregate_combine_train_rows_f32(
+                    C.byref(g), C.byref(spec.c), bases.data_ptr(), spec.ldb, weightings.data_ptr(), bias_p, out.data_ptr(),
+                    stats.data_ptr(), cnt.data_ptr(), amax_p, amin_p, lo, hi, ws.data_ptr(), ws.numel(), _stream_ptr(dev)),
+                    "egc_aggregate_combine_train_rows_f32")
     return out, (stats, cnt, arg_max, arg_min)
 
 
@@ -632,11 +653,25 @@ class _EGCLayerFunction(torch.autograd.Function):
         return dx, dwcat, dbcat, dbias, None, None
 
 
-def _layer_train_forward(ctx, x, wcat, bcat, bias, graph, spec):
+def train_forward_core(graph, spec, x, wcat, bcat, bias):
+    """(out, bases, weightings, saved) of the training forward, halo exchange included (shared with egc_amd/ops.py)."""
     bases, weightings = egc_basis_transform(graph, spec, x, wcat, bcat, None)
-    if graph.halo is not None and graph.n_src_rows > graph.n_nodes:
-        graph.halo.exchange(bases)   # vertex partition: halo rows of `bases` from their owners
-    out, saved = egc_aggregate_combine_train(graph, spec, bases, weightings, bias)
+    halo = graph.halo if (graph.halo is not None and graph.n_src_rows > graph.n_nodes) else None
+    if halo is not None and halo.n_interior is not None:
+        # vertex partition, interior rows first: they are finished while the halo rows of `bases` travel (the overlapped
+        # form of the inference path, egc_layer_forward)
+        handle = halo.exchange_start(bases)
+        out, saved = egc_aggregate_combine_train(graph, spec, bases, weightings, bias, split_at=halo.n_interior,
+                                                 between_ranges=lambda: halo.exchange_finish(handle))
+    else:
+        if halo is not None:
+            halo.exchange(bases)   # vertex partition: halo rows of `bases` from their owners
+        out, saved = egc_aggregate_combine_train(graph, spec, bases, weightings, bias)
+    return out, bases, weightings, saved
+
+
+def _layer_train_forward(ctx, x, wcat, bcat, bias, graph, spec):
+    out, bases, weightings, saved = train_forward_core(graph, spec, x, wcat, bcat, bias)
     ctx.save_for_backward(x, wcat, bases, weightings)
     ctx.graph, ctx.spec, ctx.saved = graph, spec, saved
     ctx.has_bcat, ctx.has_bias = bcat is not None, bias is not None

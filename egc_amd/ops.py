@@ -70,10 +70,7 @@ def layer_forward_train(x: torch.Tensor, wcat: torch.Tensor, bcat: torch.Tensor 
                         graph_handle: int, spec_handle: int
                         ) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     graph, spec = _get(graph_handle), _get(spec_handle)
-    bases, weightings = F.egc_basis_transform(graph, spec, x, wcat, bcat, None)
-    if graph.halo is not None and graph.n_src_rows > graph.n_nodes:
-        graph.halo.exchange(bases)
-    out, (stats, cnt, arg_max, arg_min) = F.egc_aggregate_combine_train(graph, spec, bases, weightings, bias)
+    out, bases, weightings, (stats, cnt, arg_max, arg_min) = F.train_forward_core(graph, spec, x, wcat, bcat, bias)
     none = x.new_empty((0,), dtype=torch.int32)
     return out, bases, weightings, stats, cnt, arg_max if arg_max is not None else none, arg_min if arg_min is not None else none
 
@@ -116,7 +113,8 @@ def layer_backward(grad_out: torch.Tensor, x: torch.Tensor, wcat: torch.Tensor, 
     else:
         dwcat, sums = F._weight_grads(x, d_cat, col_sums=need_bcat)
         dbias = F._column_sums(grad_out) if need_bias else empty
-    return (F._dx_matmul(d_cat, wcat), dwcat, sums[d_cat.size(1) - spec.w_cols:] if need_bcat else empty, dbias)
+    # (outputs own their storage: an operator must not hand out a view into a larger internal array)
+    return (F._dx_matmul(d_cat, wcat), dwcat, sums[d_cat.size(1) - spec.w_cols:].clone() if need_bcat else empty, dbias)
 
 
 @layer_backward.register_fake

@@ -233,6 +233,7 @@ class HaloPlan:
     order: Optional[torch.Tensor] = None       # [n_local] old local id at each new position
     new_of_old: Optional[torch.Tensor] = None  # [n_local] inverse
     n_interior: Optional[int] = None           # rows [0, n_interior) read no halo row
+    live: bool = False                         # built by build_distributed: the exchange calls go to the process group
 
     @property
     def n_local(self) -> int:
@@ -249,7 +250,7 @@ class HaloPlan:
         runs concurrently with the transfer and must not touch the halo rows."""
         import torch.distributed as dist
         n = self.n_local
-        send = table[:n].index_select(0, self.send_idx).contiguous()
+        send = self.pack_send(table)
         recv = table[n:n + self.n_halo]
         width = 1 if table.dim() == 1 else table.size(1)
         out_splits = [r * width for r in self.recv_splits]
@@ -263,6 +264,31 @@ class HaloPlan:
         work = dist.all_to_all_single(recv.view(-1), send.view(-1), out_splits, in_splits, group=self.group,
                                       async_op=True)
         return work, send  # `send` must stay alive until the transfer has completed
+
+    def pack_send(self, table: torch.Tensor) -> torch.Tensor:
+        """The send buffer of the exchange: the owned rows other ranks read, grouped by destination rank.  On the GPU
+        one launch of the library's own gather (egc_gather_rows_f32: whole rows as 16-byte pieces); CPU tensors (the
+        gloo tests) take torch's index_select."""
+        n = self.n_local
+        if (table.is_cuda and table.dim() == 2 and table.dtype == torch.float32 and table.size(1) % 4 == 0
+                and table.stride(1) == 1 and table.stride(0) % 4 == 0 and table.data_ptr() % 16 == 0
+                and self.send_idx.dtype == torch.int64 and self.send_idx.is_cuda):
+            from . import _C
+            from .graph import _stream_ptr
+            k = int(self.send_idx.numel())
+            send = torch.empty((k, table.size(1)), dtype=torch.float32, device=table.device)
+            if k:
+                _C.check(_C.load().egc_gather_rows_f32(table.data_ptr(), int(table.stride(0)), self.send_idx.data_ptr(), k,
+                                                       int(table.size(1)), send.data_ptr(), _stream_ptr(table.device)),
+                         "egc_gather_rows_f32")
+            return send
+        return table[:n].index_select(0, self.send_idx.to(table.device)).contiguous()
+
+    def predicted_exchange_ms(self, row_bytes: int, link_gbs: float = 153.0) -> float:
+        """xGMI model of SURVEY.md 8(e): every peer pair has its own link (7 x ~153 GB/s per GPU), so one all-to-all-v
+        takes about the LARGEST single peer message (sent or received) / link bandwidth."""
+        peer = max(max(self.recv_splits, default=0), max(self.send_splits, default=0))
+        return peer * row_bytes / (link_gbs * 1e9) * 1e3
 
     @staticmethod
     def exchange_finish(handle):
@@ -360,8 +386,10 @@ def build_distributed(edge_index_owned: torch.Tensor, n_global: int, group=None,
     dist.all_to_all_single(req, halo.contiguous().to(cdev), send_splits, recv_splits, group=group)
     req = req.to(dev)
     plan = HaloPlan(rank, world, lo, hi, n_global, halo, recv_splits, (req - lo).contiguous(), send_splits, group)
+    plan.live = True
     plan.stats = dict(n_local=hi - lo, n_halo=int(halo.numel()), n_send=int(req.numel()),
-                      max_peer_rows=max(recv_splits) if recv_splits else 0)
+                      max_peer_rows=max(recv_splits) if recv_splits else 0,
+                      max_peer_rows_sent=max(send_splits) if send_splits else 0)
     src = remap_sources(edge_index_owned[0], lo, hi, halo)
     ei_local = torch.stack([src, edge_index_owned[1] - lo])
     return (_interior_first(ei_local, plan) if interior_first else ei_local), plan
@@ -396,3 +424,136 @@ def simulate_exchange(tables: List[torch.Tensor], plans: List[HaloPlan]):
                     rows = other.new_of_old.to(rows.device)[rows]
                 t[n:n + plan.n_halo][sel] = tables[q][:other.n_local].index_select(0, rows)
     return tables
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Typed (heterogeneous) graphs: relational EGC on a vertex partition (rmag/models.py:18-26,75-148 distributed)
+# ---------------------------------------------------------------------------------------------------------------
+@dataclass
+class TypedLayout:
+    """Every node type is cut into `world` contiguous ranges of its own ids; rank p owns range p of EVERY type.  The
+    ranks' owned sets are laid end to end in one COMBINED id space (rank-major, then type in `node_types` order), so
+    that the machinery of the homogeneous partition applies unchanged: one table of basis rows per rank,
+    [owned rows of all types | halo rows of all types], ONE all-to-all-v per layer whatever the number of types."""
+    node_types: List[str]
+    counts: dict                       # type -> number of nodes
+    type_bounds: dict                  # type -> [b_0 .. b_world]
+    world: int
+    rank_bounds: List[int] = field(default_factory=list)   # combined space: rank p owns [rank_bounds[p], rank_bounds[p+1])
+    type_off: dict = field(default_factory=dict)           # type -> [world] offset of the type's block inside rank p's rows
+
+    def __post_init__(self):
+        self.rank_bounds, self.type_off = [0], {t: [] for t in self.node_types}
+        for p in range(self.world):
+            off = 0
+            for t in self.node_types:
+                self.type_off[t].append(off)
+                off += self.type_bounds[t][p + 1] - self.type_bounds[t][p]
+            self.rank_bounds.append(self.rank_bounds[-1] + off)
+
+    @property
+    def n_total(self) -> int:
+        return self.rank_bounds[-1]
+
+    def owned(self, t: str, rank: int):
+        return self.type_bounds[t][rank], self.type_bounds[t][rank + 1]
+
+    def combined_ids(self, t: str, ids: torch.Tensor) -> torch.Tensor:
+        """Combined-space id of the type-`t` nodes `ids`."""
+        b = torch.tensor(self.type_bounds[t], dtype=ids.dtype, device=ids.device)
+        q = torch.bucketize(ids, b[1:-1], right=True)
+        base = torch.tensor([self.rank_bounds[p] + self.type_off[t][p] - self.type_bounds[t][p] for p in range(self.world)],
+                            dtype=ids.dtype, device=ids.device)
+        return ids + base[q]
+
+
+def typed_layout(counts: dict, relations: dict, world: int, node_types: Optional[List[str]] = None,
+                 row_cost: float = 4.0) -> TypedLayout:
+    """Cost-balanced cuts per node type: cost(v) = in-degree of v over every relation that targets its type +
+    `row_cost` (what the rank's aggregate launches and GEMM scale with).  Deterministic from the edge lists, so every
+    rank derives the same layout without communication.  No locality renumbering here (the homogeneous path has
+    locality_partition): the typed synthetic has no community structure to find."""
+    node_types = sorted(counts) if node_types is None else list(node_types)
+    bounds = {}
+    for t in node_types:
+        dev = next((ei.device for (s, r, d), ei in relations.items() if d == t), torch.device("cpu"))
+        cost = torch.full((counts[t],), float(row_cost), dtype=torch.float32, device=dev)
+        for (s, r, d), ei in relations.items():
+            if d == t and ei.numel():
+                cost.index_add_(0, ei[1], torch.ones(ei.size(1), dtype=torch.float32, device=dev))
+        bounds[t] = cost_balanced_bounds(cost, world)
+    return TypedLayout(node_types, dict(counts), bounds, world)
+
+
+@dataclass
+class TypedPartition:
+    """One rank's share of a typed graph: the halo plan over the combined id space and, per relation, the edge list
+    with LOCAL target rows (position inside the rank's range of the target type) and source ids that index the
+    rank's basis table [owned rows of all types | halo rows]."""
+    layout: TypedLayout
+    rank: int
+    plan: HaloPlan
+    rel_edges: dict                    # (src type, name, dst type) -> int64 [2, E_p]: table row of the source, local target row
+
+    @property
+    def n_table(self) -> int:
+        return self.plan.n_local + self.plan.n_halo
+
+    def n_owned(self, t: str) -> int:
+        lo, hi = self.layout.owned(t, self.rank)
+        return hi - lo
+
+    def table_rows(self, t: str):
+        """Row range of type `t`'s owned block inside the rank's table."""
+        o = self.layout.type_off[t][self.rank]
+        return o, o + self.n_owned(t)
+
+
+def _typed_owned_edges(relations: dict, layout: TypedLayout, rank: int):
+    """The rank's edges of every relation (target owned), in combined ids, concatenated; with the segment sizes."""
+    keys, segs, parts = [], [], []
+    for key, ei in relations.items():
+        s, _, d = key
+        lo, hi = layout.owned(d, rank)
+        own = local_edges(ei, lo, hi)
+        keys.append(key)
+        segs.append(int(own.size(1)))
+        parts.append(torch.stack([layout.combined_ids(s, own[0]), layout.combined_ids(d, own[1])]))
+    dev = parts[0].device if parts else torch.device("cpu")
+    return keys, segs, (torch.cat(parts, dim=1) if parts else torch.empty((2, 0), dtype=torch.int64, device=dev))
+
+
+def _typed_split(keys, segs, ei_local, layout: TypedLayout, rank: int) -> dict:
+    out, at = {}, 0
+    for key, sz in zip(keys, segs):
+        e = ei_local[:, at:at + sz]
+        at += sz
+        out[key] = torch.stack([e[0], e[1] - layout.type_off[key[2]][rank]])   # target row inside its type's block
+    return out
+
+
+def build_typed_distributed(relations: dict, layout: TypedLayout, group=None) -> TypedPartition:
+    """Collective setup of the typed partition (two small all-to-alls, as build_distributed).  `relations`:
+    {(src type, name, dst type): int64 [2, E] (source ids, target ids of the types' own id spaces)} -- the whole
+    graph on every rank, or at least this rank's edges."""
+    import torch.distributed as dist
+    rank = dist.get_rank(group)
+    keys, segs, combined = _typed_owned_edges(relations, layout, rank)
+    ei_local, plan = build_distributed(combined, layout.n_total, group, interior_first=False, bounds=layout.rank_bounds)
+    return TypedPartition(layout, rank, plan, _typed_split(keys, segs, ei_local, layout, rank))
+
+
+def build_typed_local_simulation(relations: dict, layout: TypedLayout) -> List[TypedPartition]:
+    """All ranks' typed partitions inside one process (tests, one-GPU validation); exchange with simulate_exchange
+    over [p.plan for p in parts]."""
+    parts = []
+    for p in range(layout.world):
+        keys, segs, combined = _typed_owned_edges(relations, layout, p)
+        lo, hi = layout.rank_bounds[p], layout.rank_bounds[p + 1]
+        halo, recv_splits = _halo_ids(combined, lo, hi, layout.rank_bounds)
+        plan = HaloPlan(p, layout.world, lo, hi, layout.n_total, halo, recv_splits, torch.empty(0, dtype=torch.int64),
+                        [0] * layout.world)
+        plan.stats = dict(n_local=hi - lo, n_halo=int(halo.numel()), max_peer_rows=max(recv_splits) if recv_splits else 0)
+        ei_local = torch.stack([remap_sources(combined[0], lo, hi, halo), combined[1] - lo])
+        parts.append(TypedPartition(layout, p, plan, _typed_split(keys, segs, ei_local, layout, p)))
+    return parts

@@ -138,6 +138,66 @@ class REGConv(nn.Module):
                                   post=PostOp(residual=out[dst]), out=out[dst])
         return out
 
+    # -- vertex-partitioned form (SURVEY.md 8e / BASELINE config 5: the ~21 M-edge typed ogbn-mag graph over 2/4/8 GPUs) --
+    def partition_graphs(self, part, device=None):
+        """The per-relation CSRs of one rank's TypedPartition (egc_amd.partition): rows = the rank's nodes of the target
+        type, columns = rows of the rank's basis table [owned rows of all types | halo rows].  Built once per graph."""
+        graphs = {}
+        for key, e in part.rel_edges.items():
+            e = e if device is None else e.to(device)
+            graphs[tuple(key)] = CSRGraph.from_edge_index(e.contiguous(), part.n_owned(key[2]), max(part.n_table, 1)).trim_launches()
+        return graphs
+
+    def forward_partitioned(self, x_dict, part, graphs, table=None, exchange=None):
+        """Inference forward of this rank's share: ``x_dict[type]`` = the rank's OWNED rows of each type (in the order of
+        its range), ``graphs`` = partition_graphs(part).  Returns {type: out rows of the owned nodes}.
+
+        One GEMM per node type writes the type's basis rows into its block of the rank's table; ONE all-to-all-v
+        (part.plan, all types at once -- the basis matrix is shared, every row has the same width) brings the halo
+        rows; the root terms (identity adjacency: no halo row) run while the rows travel; the relation terms follow.
+        ``exchange``: replaces part.plan.exchange_start/finish (tests: a simulated exchange); called with the table."""
+        HB = self.num_heads * self.num_bases
+        ldb = self._spec_root.ldb
+        dev = next(iter(x_dict.values())).device
+        if table is None:
+            table = torch.empty((max(part.n_table, 1), ldb), dtype=torch.float32, device=dev)
+        wt, out, offs = {}, {}, {}
+        for t in self.node_types:
+            x = x_dict[t]
+            lo, hi = part.table_rows(t)
+            if x.size(0) != hi - lo:
+                raise RuntimeError(f"egc_amd.REGConv: {t}: {x.size(0)} rows given, the rank owns {hi - lo}")
+            wcat, bcat, planes, gspec, rels = self._type_weights(t)
+            offs[t] = {k: HB + 2 * HB * i for i, k in enumerate(rels)}
+            if hi > lo:
+                ident = self._identity_graph(hi - lo, dev)
+                _, wt[t] = egc_basis_transform(ident, gspec, x, wcat, bcat, planes, bases_out=table[lo:hi])
+            else:
+                wt[t] = torch.empty((0, wcat.size(1) - gspec.f_g), dtype=torch.float32, device=dev)
+        handle = None
+        if exchange is None:
+            if part.plan.live:          # (a plan of build_typed_local_simulation has no process group behind it)
+                handle = part.plan.exchange_start(table)
+        for t in self.node_types:                      # root terms: the rows' own bases, nothing remote
+            lo, hi = part.table_rows(t)
+            if hi > lo:
+                ident = self._identity_graph(hi - lo, dev)
+                out[t] = egc_aggregate_combine(ident, self._spec_root, table[lo:hi], wt[t][:, :HB], None)
+            else:
+                out[t] = torch.empty((0, self.out_channels), dtype=torch.float32, device=dev)
+        if exchange is not None:
+            exchange(table)
+        elif handle is not None:
+            part.plan.exchange_finish(handle)
+        for key, g in graphs.items():
+            src, _, dst = key
+            if g.n_nodes == 0:
+                continue
+            o = offs[dst][tuple(key)]
+            egc_aggregate_combine(g, self._spec_rel, table, wt[dst][:, o:o + 2 * HB], None,
+                                  post=PostOp(residual=out[dst]), out=out[dst])
+        return out
+
     def forward(self, x_dict, adj_t_dict):
         needs_grad = torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters()) or
                                                   any(x.requires_grad for x in x_dict.values()))

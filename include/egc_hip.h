@@ -167,6 +167,13 @@ int egc_csr_transposed_coo(int64_t n_nodes, int64_t n_edges, const int32_t* rowp
 int egc_csr_edge_dis(int64_t n_edges, const int32_t* col, const float* dis_raw, const float* dis_looped,
                      float* edge_dis_raw, float* edge_dis_looped, egc_stream_t stream);
 
+/* Vertex-partitioned runs (the reference is single-device, so there is no call site to cite beyond the
+ * gather of MessagePassing.propagate this distributes): out[k][0..width) = table[idx[k]][0..width) -- the SEND PACK of
+ * the halo all-to-all-v (the rows of `bases` other ranks read, grouped by destination rank), one launch.  width and ld
+ * (row stride of table, floats) multiples of 4; table and out 16-byte aligned; idx int64 row ids. */
+int egc_gather_rows_f32(const float* table, int64_t ld, const int64_t* idx, int64_t n_rows, int32_t width, float* out,
+                        egc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Layer description (the arguments of EfficientGraphConv.__init__ layers.py:13-27 /
  * EGConv.__init__ optimized_layers.py:74-86 that shape the computation).
@@ -418,6 +425,13 @@ int egc_aggregate_combine_train_f32(const egc_graph* graph, const egc_layer* lay
                                     const float* weightings, const float* bias, float* out, float* stats,
                                     int32_t* cnt, int32_t* arg_max, int32_t* arg_min, void* workspace,
                                     size_t workspace_bytes, egc_stream_t stream);
+/* The same over rows [row_begin, row_end) only, all arrays full-size (the training counterpart of
+ * egc_aggregate_combine_rows_f32: on a vertex partition the interior rows are finished while the halo rows of `bases`
+ * travel).  The ranges of one forward are issued in ascending order and the last one ends at n_nodes. */
+int egc_aggregate_combine_train_rows_f32(const egc_graph* graph, const egc_layer* layer, const float* bases, int32_t ldb,
+                                         const float* weightings, const float* bias, float* out, float* stats,
+                                         int32_t* cnt, int32_t* arg_max, int32_t* arg_min, int64_t row_begin,
+                                         int64_t row_end, void* workspace, size_t workspace_bytes, egc_stream_t stream);
 
 /* Whole layer forward = egc_basis_transform_f32 + egc_aggregate_combine_f32
  * (EfficientGraphConv.forward layers.py:89-140 / EGConv.forward optimized_layers.py:177-210

@@ -378,4 +378,4 @@ def regconv_forward(x_dict, adj_dict, bases_weight, rel_combs, root_combs, num_h
         w, b = rel_combs[f"{key[0]}_{key[1]}_{key[2]}"]
         weightings = (x_dict[dst].astype(f32) @ w.astype(f32).T + b.astype(f32)).reshape(-1, H, 2 * B)
         out[dst] = out[dst] + np.matmul(weightings, aggregated)
-    return {k: v.reshape(v.shape[0], -1).astype(f32) for k, v in out.items()}                       # :146-148
+    return {k: v.reshape(v.shape[0], H * L).astype(f32) for k, v in out.items()}                    # :146-148 (H * L: empty types too)

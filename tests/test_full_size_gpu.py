@@ -216,3 +216,127 @@ def test_config5_partitioned_at_mag_size_equals_single_gpu(world):
         got[order] = got2                               # back to the caller's vertex ids
     assert bool(torch.isfinite(got).all())
     assert rel_err(got.cpu().numpy(), ref.cpu().numpy()) <= TOL
+    # ... and against FLOAT64 recomputations of sampled rows (hubs, the last row, rows on both sides of every cut, random
+    # ones) from the caller's un-renumbered graph: the partitioned path is held to the reference's arithmetic, not to
+    # the single-GPU HIP result
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(3)
+        cuts = torch.tensor([b for b in bounds[1:-1]] + [b - 1 for b in bounds[1:-1]])
+        rows = torch.cat([torch.tensor([0, 1, 2, n - 1]), order.cpu()[cuts.clamp(0, n - 1)],
+                          torch.randint(0, n, (120,), generator=g)]).to(dev)
+        nonself = torch.bincount(ei_d[1][ei_d[0] != ei_d[1]], minlength=n).double() + 1
+        dis = nonself.pow(-0.5)
+        sel = torch.isin(ei_d[1], rows) & (ei_d[0] != ei_d[1])
+        s_sel, d_sel = ei_d[0][sel], ei_d[1][sel]
+        Wb = conv.bases_weight.double()
+        H, B, L = 8, 4, 44
+        worst = 0.0
+        for r in rows.tolist():
+            nb = torch.cat([s_sel[d_sel == r], torch.tensor([r], device=dev)])
+            agg = ((x[nb].double() @ Wb) * (dis[nb] * dis[r])[:, None]).sum(0)
+            wt = (x[r].double() @ conv.comb_weight.weight.double().t() + conv.comb_weight.bias.double()).view(H, 1, B)
+            want = torch.einsum("hab,abl->hl", wt, agg.view(1, B, L)).reshape(-1) + conv.bias.double()
+            worst = max(worst, float((got[r].double() - want).abs().max() / want.abs().max().clamp(min=1)))
+    assert worst <= TOL, worst
+
+
+def _regconv_partitioned(conv, x, nodes, rel, world, dev):
+    """REGConv on `world` simulated ranks, one after the other on this GPU (typed partition, simulated all-to-all-v);
+    returns {type: rows of all ranks concatenated} -- the ranks own consecutive ranges of every type."""
+    from egc_amd import partition as P
+    layout = P.typed_layout(nodes, rel, world, node_types=list(conv.node_types))
+    parts = P.build_typed_local_simulation(rel, layout)
+    ldb = conv._spec_root.ldb
+    tables = [torch.full((max(p.n_table, 1), ldb), float("nan"), device=dev) for p in parts]
+    graphs = [conv.partition_graphs(p, dev) for p in parts]
+    xs = [{t: x[t][layout.owned(t, p.rank)[0]:layout.owned(t, p.rank)[1]].contiguous() for t in conv.node_types} for p in parts]
+    # pass 1 on every rank: GEMMs + root terms (what runs before the halo rows have arrived); then the exchange; then
+    # the relation terms.  forward_partitioned does all three per call, so it is called with an exchange hook that
+    # (on the LAST rank's call of pass 1) has every table's owned rows ready
+    outs = [None] * world
+    for i, part in enumerate(parts):      # fill every rank's owned rows first
+        conv.forward_partitioned(xs[i], part, {}, table=tables[i], exchange=lambda t: None)
+    P.simulate_exchange(tables, [p.plan for p in parts])
+    for i, part in enumerate(parts):
+        halo = tables[i][part.plan.n_local:part.plan.n_local + part.plan.n_halo].clone()
+
+        def put_back(t, halo=halo, part=part):
+            t[part.plan.n_local:part.plan.n_local + part.plan.n_halo] = halo
+        outs[i] = conv.forward_partitioned(xs[i], part, graphs[i], table=tables[i], exchange=put_back)
+    return {t: torch.cat([o[t] for o in outs]) for t in conv.node_types}, layout, parts
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_regconv_partitioned_equals_unpartitioned_and_oracle_scaled(world):
+    """The vertex-partitioned REGConv (egc_amd.partition.TypedLayout: every node type cut into per-rank ranges, one
+    table of basis rows per rank, ONE exchange for all types) on a 2 % scale model of the typed ogbn-mag graph: the
+    ranks' rows concatenated == the numpy oracle of rmag/models.py:112-148 on the whole graph."""
+    import egc_amd
+    from egc_amd.workloads import rmag_like
+    dev = _dev()
+    nodes, rel = rmag_like(seed=4, scale=0.02)
+    torch.manual_seed(5)
+    conv = egc_amd.REGConv(128, 64, 4, 4)
+    x = {k: torch.randn(n, 128) for k, n in nodes.items()}
+    sd = {k: v.detach().numpy() for k, v in conv.state_dict().items()}
+    ref = orc.regconv_forward(
+        {k: v.numpy() for k, v in x.items()}, {k: v.numpy() for k, v in rel.items()}, sd["bases_weight"],
+        {f"{k[0]}_{k[1]}_{k[2]}": (sd[f"rel_combs.{k[0]}_{k[1]}_{k[2]}.weight"], sd[f"rel_combs.{k[0]}_{k[1]}_{k[2]}.bias"])
+         for k in rel},
+        {k: (sd[f"root_combs.{k}.weight"], sd[f"root_combs.{k}.bias"]) for k in nodes}, 4, 4)
+    conv = conv.to(dev).eval()
+    xd = {k: v.to(dev) for k, v in x.items()}
+    with torch.no_grad():
+        got, layout, parts = _regconv_partitioned(conv, xd, nodes, {k: v.to(dev) for k, v in rel.items()}, world, dev)
+        whole = conv(xd, _rel_adj(rel, nodes, dev))
+    for k in nodes:
+        assert got[k].shape == whole[k].shape and bool(torch.isfinite(got[k]).all())
+        assert rel_err(got[k].cpu().numpy(), ref[k]) <= TOL, (k, rel_err(got[k].cpu().numpy(), ref[k]))
+        assert rel_err(got[k].cpu().numpy(), whole[k].cpu().numpy()) <= TOL
+    assert sum(p.plan.n_local for p in parts) == sum(nodes.values())
+
+
+def test_regconv_partitioned_at_full_typed_mag_size_sampled_rows_float64():
+    """BASELINE config 5's ~21 M-edge typed graph as bench.py --gpus N runs it (workloads.rmag_like at full size, 4
+    simulated ranks): sampled `paper`, `author` and `field_of_study` rows -- the heaviest hubs, rows at the cuts, random
+    ones -- recomputed in float64 from the un-partitioned typed graph."""
+    import egc_amd
+    from egc_amd.workloads import rmag_like
+    dev = _dev()
+    world = 4
+    nodes, rel = rmag_like(seed=0)
+    rel = {k: v.to(dev) for k, v in rel.items()}
+    torch.manual_seed(6)
+    H, B, L = 8, 4, 16
+    conv = egc_amd.REGConv(128, H * L, H, B).to(dev).eval()
+    x = {k: torch.randn(n, 128, device=dev) for k, n in nodes.items()}
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        out, layout, parts = _regconv_partitioned(conv, x, nodes, rel, world, dev)
+        Wb = conv.bases_weight.double()
+        worst = 0.0
+        for t in ("paper", "author", "field_of_study"):
+            cuts = [b for b in layout.type_bounds[t][1:-1]] + [b - 1 for b in layout.type_bounds[t][1:-1]]
+            rows = torch.cat([torch.tensor([0, 1, nodes[t] - 1] + [min(max(c, 0), nodes[t] - 1) for c in cuts]),
+                              torch.randint(0, nodes[t], (30,), generator=g)]).tolist()
+            for r in rows:
+                xr = x[t][r].double()
+                lin = conv.root_combs[t]
+                ref = torch.einsum("hb,bl->hl", (xr @ lin.weight.double().t() + lin.bias.double()).view(H, B),
+                                   (xr @ Wb).view(B, L))
+                for key, ei in rel.items():
+                    if key[2] != t:
+                        continue
+                    nb = ei[0][ei[1] == r]
+                    if nb.numel() == 0:
+                        continue            # empty neighbourhood: mean and max are both 0
+                    bj = x[key[0]][nb].double() @ Wb
+                    agg = torch.stack([bj.mean(0), bj.max(0).values]).view(2 * B, L)
+                    lin = conv.rel_combs[f"{key[0]}_{key[1]}_{key[2]}"]
+                    w = (xr @ lin.weight.double().t() + lin.bias.double()).view(H, 2 * B)
+                    ref = ref + w @ agg
+                ref = ref.reshape(-1)
+                worst = max(worst, float((out[t][r].double() - ref).abs().max() / ref.abs().max().clamp(min=1)))
+    assert worst <= TOL, worst
+    # one exchange per layer whatever the number of types: a rank's table holds owned + halo rows of ALL types
+    assert all(p.n_table == p.plan.n_local + p.plan.n_halo for p in parts)
