@@ -71,8 +71,9 @@ def layer_forward_train(x: torch.Tensor, wcat: torch.Tensor, bcat: torch.Tensor 
                         ) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     graph, spec = _get(graph_handle), _get(spec_handle)
     out, bases, weightings, (stats, cnt, arg_max, arg_min) = F.train_forward_core(graph, spec, x, wcat, bcat, bias)
-    none = x.new_empty((0,), dtype=torch.int32)
-    return out, bases, weightings, stats, cnt, arg_max if arg_max is not None else none, arg_min if arg_min is not None else none
+    def none():     # (a fresh tensor per output: an operator's returns may not alias each other)
+        return x.new_empty((0,), dtype=torch.int32)
+    return out, bases, weightings, stats, cnt, arg_max if arg_max is not None else none(), arg_min if arg_min is not None else none()
 
 
 @layer_forward_train.register_fake

@@ -36,3 +36,73 @@ class ZincStyleNet(nn.Module):
             h = torch.relu(bn(conv(x=x, edge_index=edge_index)))
             x = x + h if self.residual else h
         return self.readout(mean_pool(x, batch, n_graphs))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Counterparts of the reference's nets with the reference's OWN module names, so that a state dict captured from the
+# reference's classes (tests/golden/net_*.npz, make_golden_nets.py) loads with strict=True: what a user does who swaps
+# the layer class under released checkpoints.  `conv_fn(conv, x, edge_index)` decides what runs the
+# layer (the module itself on the GPU; the CPU restatement wearing the module's parameters in the CPU tests);
+# `fuse(conv, bn)` may return a block that runs conv -> bn -> relu (-> + x) in one go (egc_amd.FusedEGCBlock).
+# ---------------------------------------------------------------------------------------------------------------
+def _default_conv(conv, x, edge_index):
+    return conv(x=x, edge_index=edge_index) if hasattr(conv, "aggs") else conv(x, edge_index)
+
+
+class ZincNetLike(nn.Module):
+    """zinc/models.py:17-74: embedding -> L x [conv, BatchNorm1d, ReLU (+ identity)] -> mean pool -> mlp."""
+
+    def __init__(self, hidden, n_layers, make_layer, residual=True):
+        super().__init__()
+        self.embedding = nn.Embedding(28, hidden)
+        self.graph_layers = nn.ModuleList([nn.ModuleList([make_layer(hidden), nn.BatchNorm1d(hidden), nn.ReLU()])
+                                           for _ in range(n_layers)])
+        self.mlp = head_mlp([hidden, hidden // 2, hidden // 4, 1])
+        self.residual = residual
+
+    def forward(self, atom, edge_index, batch, n_graphs, conv_fn=_default_conv, fuse=None, pool=mean_pool):
+        x = self.embedding(atom.view(-1))
+        for conv, bn, act in self.graph_layers:
+            if fuse is not None:
+                x = fuse(conv, bn, self.residual)(x, edge_index)
+            else:
+                h = act(bn(conv_fn(conv, x, edge_index)))
+                x = x + h if self.residual else h
+        return self.mlp(pool(x, batch, n_graphs))
+
+
+class ArxivNetLike(nn.Module):
+    """arxiv/norm_models.py:13-43 with dropout 0: Linear -> L x [conv, bn, relu, + identity] -> Linear -> log_softmax."""
+
+    def __init__(self, hidden, n_layers, make_layer, residual=True, n_features=128, n_classes=40):
+        super().__init__()
+        self.embed = nn.Sequential(nn.Linear(n_features, hidden))        # utils.mlp([128, hidden]) is one Linear
+        self.convs = nn.ModuleList([make_layer(hidden) for _ in range(n_layers)])
+        self.bns = nn.ModuleList([nn.BatchNorm1d(hidden) for _ in range(n_layers)])
+        self.out = nn.Linear(hidden, n_classes)
+        self.residual = residual
+
+    def forward(self, x, edge_index, conv_fn=_default_conv, fuse=None):
+        x = self.embed(x)
+        for conv, bn in zip(self.convs, self.bns):
+            if fuse is not None:
+                x = fuse(conv, bn, self.residual)(x, edge_index)
+            else:
+                h = torch.relu(bn(conv_fn(conv, x, edge_index)))
+                x = x + h if self.residual else h
+        return self.out(x).log_softmax(dim=-1)
+
+
+class MagNetLike(nn.Module):
+    """mag/models.py:16-69 with dropout 0: EGConv(128 -> h) -> relu -> ... -> EGConv(h -> 352)[:, :349] -> log_softmax."""
+
+    def __init__(self, hidden, n_layers, make_layer, in_features=128, out_rounded=352, out_true=349):
+        super().__init__()
+        dims = [in_features] + [hidden] * (n_layers - 1) + [out_rounded]
+        self.convs = nn.ModuleList([make_layer(a, b) for a, b in zip(dims[:-1], dims[1:])])
+        self.out_true = out_true
+
+    def forward(self, x, adj_t, conv_fn=_default_conv):
+        for conv in self.convs[:-1]:
+            x = torch.relu(conv_fn(conv, x, adj_t))
+        return conv_fn(self.convs[-1], x, adj_t)[:, :self.out_true].log_softmax(dim=-1)
