@@ -72,6 +72,10 @@ SYMBOLS = {
                                           C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "egc_basis_pack_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "egc_basis_pack": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "egc_layer_gemm_flags": (C.c_int32, [C.POINTER(EgcLayer)]),
+    "egc_basis_pack_ex": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "egc_basis_transform_packed_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                                C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "egc_basis_pack_transposed": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t,
                                             C.c_void_p]),
     "egc_basis_transform_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,

@@ -824,11 +824,20 @@ int egc_layer_forward_packed(const egc_graph* graph, const egc_layer* layer, con
   if (st != EGC_OK) return st;
   const int fg = layer->num_bases * layer_basis_stride(layer);  // padded bases are GEMM columns too (zero weights)
   const int w = layer->num_heads * layer->num_bases * layer->num_aggrs;
-  st = egc_basis_transform_packed(x, packed, bcat, graph->n_nodes, layer->in_channels, fg, w, bases, ldb, weightings,
-                                  stream);
+  st = egc_basis_transform_packed_ex(x, packed, bcat, graph->n_nodes, layer->in_channels, fg, w, egc_layer_gemm_flags(layer),
+                                     bases, ldb, weightings, stream);
   if (st != EGC_OK) return st;
   return egc_aggregate_combine_f32(graph, layer, bases, ldb, weightings, bias, out, nullptr, nullptr, workspace,
                                    workspace_bytes, stream);
+}
+
+int32_t egc_layer_gemm_flags(const egc_layer* layer) {
+  if (layer == nullptr) return 0;
+  if (const char* e = getenv("EGC_GEMM_FAST"))   // keep the 22-bit form for std / var layers too (measurements)
+    if (e[0] != '\0' && !(e[0] == '0' && e[1] == '\0')) return 0;
+  for (int t = 0; t < layer->num_aggrs && t < EGC_MAX_AGGRS; ++t)
+    if (layer->aggrs[t] == EGC_AGGR_VAR || layer->aggrs[t] == EGC_AGGR_STD) return EGC_GEMM_24BIT;
+  return 0;
 }
 
 }  // extern "C"

@@ -592,19 +592,24 @@ size_t egc_basis_pack_bytes(int32_t f_in, int32_t f_g, int32_t w_cols) {
                   f16x2k_pack_bytes(f_in, f_g, ldb, w_cols));
 }
 
-static bool use_f16x2(int f_in, int ldb, int NV) {
-  return f16x2_shape(f_in, ldb, NV) && getenv("EGC_GEMM_BF16X3") == nullptr;
+// flags & EGC_GEMM_24BIT: operands split into THREE bf16 planes (24 significand bits: nothing of an fp32 operand is
+// dropped) whatever the shape -- the fp16x2 forms keep 22 bits, which layers with std / var amplify (egc_hip.h)
+static bool use_f16x2(int f_in, int ldb, int NV, int flags) {
+  return (flags & EGC_GEMM_24BIT) == 0 && f16x2_shape(f_in, ldb, NV) && getenv("EGC_GEMM_BF16X3") == nullptr;
+}
+static bool use_f16x2k(int f_in, int f_g, int ldb, int w_cols, int flags) {
+  return (flags & EGC_GEMM_24BIT) == 0 && f16x2k_shape(f_in, f_g, ldb, w_cols);
 }
 
 static int basis_pack_strided(const float* wcat, int64_t rs, int64_t cs, int32_t f_in, int32_t f_g, int32_t w_cols,
-                              void* packed, size_t packed_bytes, hipStream_t stream) {
+                              void* packed, size_t packed_bytes, hipStream_t stream, int flags = 0) {
   if (wcat == nullptr || packed == nullptr || f_in <= 0 || f_g <= 0 || w_cols < 0) return EGC_ERR_INVALID;
   if (packed_bytes < egc_basis_pack_bytes(f_in, f_g, w_cols)) return EGC_ERR_WORKSPACE;
   const int ldb = (f_g + 3) & ~3;
   const int NV = round_up32(ldb + w_cols);
   const int KS = (f_in + XKT - 1) / XKT;
-  if (use_f16x2(f_in, ldb, NV)) return f16x2_pack(wcat, rs, cs, f_in, f_g, w_cols, ldb, NV, KS, packed, stream);
-  if (f16x2k_shape(f_in, f_g, ldb, w_cols)) return f16x2k_pack(wcat, rs, cs, f_in, f_g, ldb, w_cols, packed, stream);
+  if (use_f16x2(f_in, ldb, NV, flags)) return f16x2_pack(wcat, rs, cs, f_in, f_g, w_cols, ldb, NV, KS, packed, stream);
+  if (use_f16x2k(f_in, f_g, ldb, w_cols, flags)) return f16x2k_pack(wcat, rs, cs, f_in, f_g, ldb, w_cols, packed, stream);
   const int total = KS * NV * XKT;
   pack_bf16x3_kernel<<<(total + 255) / 256, 256, 0, stream>>>(wcat, rs, cs, f_in, f_g, w_cols, ldb, NV, KS, (u16*)packed);
   EGC_LAUNCH_CHECK("pack_bf16x3_kernel");
@@ -616,6 +621,11 @@ int egc_basis_pack(const float* wcat, int32_t f_in, int32_t f_g, int32_t w_cols,
   return basis_pack_strided(wcat, (int64_t)f_g + w_cols, 1, f_in, f_g, w_cols, packed, packed_bytes, (hipStream_t)stream_);
 }
 
+int egc_basis_pack_ex(const float* wcat, int32_t f_in, int32_t f_g, int32_t w_cols, int32_t flags, void* packed,
+                      size_t packed_bytes, egc_stream_t stream_) {
+  return basis_pack_strided(wcat, (int64_t)f_g + w_cols, 1, f_in, f_g, w_cols, packed, packed_bytes, (hipStream_t)stream_, flags);
+}
+
 int egc_basis_pack_transposed(const float* wt, int64_t ld, int32_t f_in, int32_t f_g, int32_t w_cols, void* packed,
                               size_t packed_bytes, egc_stream_t stream_) {
   if (ld < f_in) return EGC_ERR_INVALID;
@@ -625,15 +635,21 @@ int egc_basis_pack_transposed(const float* wt, int64_t ld, int32_t f_in, int32_t
 int egc_basis_transform_packed(const float* x, const void* packed, const float* bcat, int64_t n_nodes, int32_t f_in,
                                int32_t f_g, int32_t w_cols, float* bases, int32_t ldb, float* weightings,
                                egc_stream_t stream_) {
+  return egc_basis_transform_packed_ex(x, packed, bcat, n_nodes, f_in, f_g, w_cols, 0, bases, ldb, weightings, stream_);
+}
+
+int egc_basis_transform_packed_ex(const float* x, const void* packed, const float* bcat, int64_t n_nodes, int32_t f_in,
+                                  int32_t f_g, int32_t w_cols, int32_t flags, float* bases, int32_t ldb, float* weightings,
+                                  egc_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (n_nodes < 0 || f_in <= 0 || f_g <= 0 || w_cols < 0 || ldb != ((f_g + 3) & ~3)) return EGC_ERR_INVALID;
   if (n_nodes == 0) return EGC_OK;
   if (x == nullptr || packed == nullptr || bases == nullptr || (w_cols > 0 && weightings == nullptr)) return EGC_ERR_INVALID;
   const int NV = round_up32(ldb + w_cols);
   const int KS = (f_in + XKT - 1) / XKT;
-  if (use_f16x2(f_in, ldb, NV))  // the planes were packed for this kernel: no other form can read them
+  if (use_f16x2(f_in, ldb, NV, flags))  // the planes were packed for this kernel: no other form can read them
     return f16x2_launch(x, packed, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, stream);
-  if (f16x2k_shape(f_in, f_g, ldb, w_cols))  // likewise: its planes are in its own fragment order
+  if (use_f16x2k(f_in, f_g, ldb, w_cols, flags))  // likewise: its planes are in its own fragment order
     return f16x2k_launch(x, packed, bcat, n_nodes, f_in, f_g, ldb, w_cols, bases, weightings, stream);
   if (f_in <= 128 && NV <= 256 && getenv("EGC_GEMM_NO_WS") == nullptr) {  // weight-stationary form (<= 8 wavefronts)
     const u16* pk = (const u16*)packed;

@@ -32,6 +32,12 @@ class LayerSpec:
     def ldb(self) -> int:
         return (self.f_g + 3) & ~3
 
+    @property
+    def gemm_flags(self) -> int:
+        """Operand precision of the layer's split GEMM (egc_layer_gemm_flags): EGC_GEMM_24BIT for layers with std / var,
+        whose cancellation amplifies what a 22-bit operand split drops; EGC_GEMM_FAST=1 keeps the fast form for them too."""
+        return int(_C.load().egc_layer_gemm_flags(C.byref(self.c)))     # (decided in ONE place: the library)
+
 
 def padded_basis_stride(out_channels: int, num_heads: int, num_bases: int) -> int:
     """Basis stride the layers use: L itself when it is a multiple of 4; otherwise L rounded up to 4 -- each
@@ -156,8 +162,8 @@ def pack_weights(spec: LayerSpec, wcat: torch.Tensor) -> torch.Tensor:
     with _device_guard(dev):
         nbytes = lib.egc_basis_pack_bytes(spec.f_in, spec.f_g, spec.w_cols)
         packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        _C.check(lib.egc_basis_pack(wcat.data_ptr(), spec.f_in, spec.f_g, spec.w_cols, packed.data_ptr(),
-                                    nbytes, _stream_ptr(dev)), "egc_basis_pack")
+        _C.check(lib.egc_basis_pack_ex(wcat.data_ptr(), spec.f_in, spec.f_g, spec.w_cols, getattr(spec, "gemm_flags", 0),
+                                       packed.data_ptr(), nbytes, _stream_ptr(dev)), "egc_basis_pack_ex")
     return packed
 
 
@@ -201,9 +207,10 @@ def egc_basis_transform(graph: CSRGraph, spec: LayerSpec, x: torch.Tensor, wcat:
         else:
             if packed is None:
                 packed = pack_weights(spec, wcat)
-            _C.check(lib.egc_basis_transform_packed(x.data_ptr(), packed.data_ptr(), bcat_p, n, spec.f_in, spec.f_g,
-                                                    spec.w_cols, bases.data_ptr(), spec.ldb, weightings.data_ptr(),
-                                                    _stream_ptr(dev)), "egc_basis_transform_packed")
+            _C.check(lib.egc_basis_transform_packed_ex(x.data_ptr(), packed.data_ptr(), bcat_p, n, spec.f_in, spec.f_g,
+                                                       spec.w_cols, getattr(spec, "gemm_flags", 0), bases.data_ptr(),
+                                                       spec.ldb, weightings.data_ptr(), _stream_ptr(dev)),
+                     "egc_basis_transform_packed_ex")
     return bases, weightings
 
 

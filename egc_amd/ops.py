@@ -48,6 +48,7 @@ def handle_of(obj) -> int:
 
 
 def _get(h: int):
+    h = int(h)      # (under torch.compile a handle may arrive as a SymInt: specialise on it, it names one object)
     obj = _REGISTRY.get(h)
     if obj is None:
         raise RuntimeError("egc_amd: stale graph / layer handle (the object behind it has been freed)")

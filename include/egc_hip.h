@@ -224,6 +224,22 @@ int egc_basis_transform_f32(const float* x, const float* wcat, const float* bcat
 size_t egc_basis_pack_bytes(int32_t f_in, int32_t f_g, int32_t w_cols);
 int egc_basis_pack(const float* wcat, int32_t f_in, int32_t f_g, int32_t w_cols, void* packed,
                    size_t packed_bytes, egc_stream_t stream);
+/* Operand precision of the split GEMM.  flags = 0: as above (fp16x2, 22 significand bits, where the shape has that
+ * kernel).  EGC_GEMM_24BIT: three bf16 planes per operand for EVERY shape -- all 24 bits of an fp32 operand survive.
+ * Layers with `std` / `var` want it: var = E[x^2] - E[x]^2 cancels on (nearly) constant neighbourhoods and
+ * std = sqrt(relu(var) + 1e-5) (layers.py:203-216) then amplifies what the GEMM dropped from `bases` 158x; with 22-bit
+ * operands such a layer lands a few times further from the float64 value than the reference's own float32 does
+ * (measured 7e-5 against 2e-5 of the output scale), with 24-bit operands it does not.  egc_layer_gemm_flags(layer) =
+ * EGC_GEMM_24BIT exactly for those layers: pass it to BOTH calls of a layer (pack and transform must agree);
+ * egc_layer_forward_packed applies it by itself, so its `packed` must come from egc_basis_pack_ex with the same flags.
+ * Cost at the 128-wide shapes: 63-70 us instead of 40 us per GEMM at ogbn-arxiv size. */
+#define EGC_GEMM_24BIT 1
+int32_t egc_layer_gemm_flags(const egc_layer* layer);
+int egc_basis_pack_ex(const float* wcat, int32_t f_in, int32_t f_g, int32_t w_cols, int32_t flags, void* packed,
+                      size_t packed_bytes, egc_stream_t stream);
+int egc_basis_transform_packed_ex(const float* x, const void* packed, const float* bcat, int64_t n_nodes, int32_t f_in,
+                                  int32_t f_g, int32_t w_cols, int32_t flags, float* bases, int32_t ldb,
+                                  float* weightings, egc_stream_t stream);
 /* egc_basis_pack of a matrix given TRANSPOSED: wt [f_g + w_cols][ld >= f_in] row-major holds wcat^T (element (k, c) of
  * wcat at wt[c * ld + k]).  The gradient w.r.t. x is [d bases | d weightings] @ wcat^T -- a basis transform whose
  * "wcat" is the transpose of the layer's own operand: this packs it where it lies (no transposed copy per step). */

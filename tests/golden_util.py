@@ -13,7 +13,8 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 def golden_names():
     """Single-layer fixtures (make_golden.py); the relational ones (make_golden_rel.py) are rel_*."""
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-    return [n for n in names if not n.startswith(("rel_", "grad_"))]   # grad_*: make_golden_grad.py (test_backward_golden.py)
+    # grad_*: make_golden_grad.py (test_backward_golden.py); net_* / relgrad_*: make_golden_nets.py (test_nets_golden.py)
+    return [n for n in names if not n.startswith(("rel_", "grad_", "net_", "relgrad_"))]
 
 
 def rel_golden_names():

@@ -20,6 +20,12 @@ from oracle import egc_torch_ref as tref
 
 pytestmark = pytest.mark.gpu
 
+# std / var layers: HIP vs float64 <= max(1e-5, STDVAR_K x the fp32 restatement's own error vs float64).  Measured over these
+# seeds (gpurun_out/r3_fuzz24.log, r3_fuzz22.log -> profiles/r03_stdvar_gemm_precision.md): with the 24-bit-operand GEMM
+# such layers run by default the worst ratio is 6.0 (two fp32 summation orders of E[x^2] - E[x]^2, amplified 158x: single
+# draws of the same rounding noise); with the 22-bit fp16x2 GEMM (EGC_GEMM_FAST=1) one case of seed 118 sits at 28x.
+STDVAR_K = 8.0
+
 
 def _truth64(tref, kind, layer, x, ei, H, B, names, flags, asl):
     """The layer in float64 through the torch restatement (parameters and input promoted)."""
@@ -48,6 +54,7 @@ def test_random_layers_and_graphs_match_the_oracles(seed, generic, monkeypatch):
     worst = 0.0
     worst_g = 0.0
     fails = []
+    stdvar_stats = []
 
     LAY = ["add", "mean", "max", "min", "symadd", "var", "std"]
     OPT = ["sum", "mean", "max", "min", "symnorm", "var", "std"]
@@ -107,18 +114,20 @@ def test_random_layers_and_graphs_match_the_oracles(seed, generic, monkeypatch):
             if out is not None:
                 err = rel_err(out.cpu().numpy(), ref); worst = max(worst, err)
                 stdvar = any(a in ('std', 'var') for a in names)
-                ok = err <= (1e-4 if stdvar else 1e-5)
+                ok = err <= 1e-5
                 if not ok and stdvar:
                     # two correct fp32 evaluations of sqrt(relu(E[x^2] - E[x]^2) + 1e-5) may be 1e-3 apart on (nearly)
-                    # constant neighbourhoods -- e.g. one node with a dozen self-loops; beyond 1e-4 the criterion is
-                    # the one that does not depend on the evaluation order: against the same layer in float64 the HIP
-                    # result is of the order of the fp32 restatement's own error (x8, + 1e-5: at the one element of
-                    # a layer where mean^2 / var is largest both errors are single draws of the same amplified
-                    # rounding noise -- seed 202 has 1.2e-4 against 2.4e-5, with either GEMM form)
+                    # constant neighbourhoods -- e.g. one node with a dozen self-loops -- so beyond 1e-5 the criterion is
+                    # the one that does not depend on the evaluation order: against the same layer in FLOAT64 the HIP
+                    # result holds 1e-5 wherever the reference's own float32 arithmetic (the restatement) does, and
+                    # is otherwise of the order of the restatement's own error (STDVAR_K x; at the one element of a
+                    # layer where mean^2 / var is largest both errors are single draws of the same amplified rounding
+                    # noise).  Layers with std / var run the 24-bit-operand GEMM (egc_layer_gemm_flags) for this.
                     truth = _truth64(tref, kind, layer, x, ei, H, B, names, flags, asl).numpy()
                     e_hip, e_ref = rel_err(out.cpu().numpy(), truth), rel_err(ref, truth)
-                    ok = e_hip <= 8.0 * e_ref + 1e-5
+                    ok = e_hip <= max(1e-5, STDVAR_K * e_ref)
                     err = (err, e_hip, e_ref)
+                    stdvar_stats.append((e_hip, e_ref, case))
                 if not ok: fails.append(("fwd", case, kind, H, B, L, fin, names, n, e, flags, asl, err))
             # gradients for a subset (float64 torch reference); skip std/var/max/min kinks at exact ties
             if case % 4 == 0 and n <= 900 and not any(a in ("std", "var") for a in names):
@@ -144,4 +153,8 @@ def test_random_layers_and_graphs_match_the_oracles(seed, generic, monkeypatch):
                 if not ge <= 5e-4: fails.append(("grad", case, kind, H, B, L, fin, names, n, e, flags, asl, ge))
         except Exception as ex:
             fails.append(("exc", case, kind, H, B, L, fin, names, n, e, flags, asl, repr(ex)[:200]))
+    if stdvar_stats:
+        print(f"[fuzz seed {seed}] std/var cases beyond 1e-5 of the fp32 restatement: {len(stdvar_stats)}; vs float64: "
+              f"worst HIP {max(s[0] for s in stdvar_stats):.2e}, worst restatement {max(s[1] for s in stdvar_stats):.2e}, "
+              f"worst HIP / restatement {max(s[0] / max(s[1], 1e-30) for s in stdvar_stats):.2f}")
     assert not fails, fails[:5]
