@@ -831,6 +831,89 @@ int egc_layer_forward_packed(const egc_graph* graph, const egc_layer* layer, con
                                    workspace_bytes, stream);
 }
 
+// ---- batches of small graphs: tiles of whole graphs (egc_aggregate_tile.hip) ----
+static int tile_layer_args(const egc_layer* layer, AggArgs& a) {
+  int st = validate_layer(layer);
+  if (st != EGC_OK) return st;
+  a = AggArgs{};
+  a.ldb = egc_bases_ld(layer);
+  a.slots = a.ldb / 4;
+  a.F_out = layer->out_channels;
+  a.H = layer->num_heads;
+  a.B = layer->num_bases;
+  a.A = layer->num_aggrs;
+  a.L = layer->out_channels / layer->num_heads;
+  a.Ls = layer_basis_stride(layer);
+  a.W = a.H * a.B * a.A;
+  a.ldw = a.W;
+  for (int t = 0; t < EGC_MAX_AGGRS; ++t) a.aggr[t] = t < a.A ? layer->aggrs[t] : 0;
+  a.x_looped = layer->agg_set == EGC_SET_LOOPED;
+  a.y_looped = layer->sym_set == EGC_SET_LOOPED;
+  a.loops_all = layer->loops_all_nodes != 0;
+  if (layer->weight_layout == EGC_LAYOUT_HAB) { a.sa = a.B; a.sb = 1; } else { a.sa = 1; a.sb = a.A; }
+  a.act = layer->weight_act;
+  a.lpr_log2 = 4;
+  int chunks = a.slots <= 64 ? 1 : (a.slots + 63) / 64;
+  if (!fast_path_supported(a, layer->weight_layout, chunks)) return EGC_ERR_UNSUPPORTED;
+  return EGC_OK;
+}
+
+int32_t egc_batch_tile_nodes(const egc_layer* layer, int32_t edges_per_node, int32_t with_post) {
+  AggArgs a;
+  if (tile_layer_args(layer, a) != EGC_OK || edges_per_node < 1) return 0;
+  const int lpr = a.slots <= 16 ? 16 : a.slots <= 32 ? 32 : 64;
+  a.w_lds_stride = (a.W + 3) & ~3;
+  a.bias_lds_floats = (a.H * a.Ls + 3) & ~3;
+  a.lds_floats_per_wave = (with_post ? 2 : 1) * a.bias_lds_floats + (64 / lpr) * a.w_lds_stride;
+  return tile_capacity(a, edges_per_node);
+}
+
+int egc_batch_plan(const int64_t* graph_ptr, int64_t n_graphs, const int64_t* dst, int64_t n_edges, int64_t n_nodes,
+                   int32_t slot, int32_t* tiles, int32_t n_tiles, egc_stream_t stream) {
+  if (graph_ptr == nullptr || tiles == nullptr || n_graphs < 0 || n_edges < 0 || n_nodes < 0 || slot <= 0) return EGC_ERR_INVALID;
+  if (n_nodes >= ((int64_t)1 << 31) - 1 || n_edges >= ((int64_t)1 << 31) - 1) return EGC_ERR_INVALID;
+  if (n_tiles != (int32_t)((n_nodes + slot - 1) / slot)) return EGC_ERR_INVALID;
+  if (n_edges > 0 && dst == nullptr) return EGC_ERR_INVALID;
+  if (n_tiles == 0) return EGC_OK;
+  return launch_tile_plan(graph_ptr, n_graphs, dst, n_edges, n_nodes, slot, n_tiles, reinterpret_cast<int4*>(tiles),
+                          (hipStream_t)stream);
+}
+
+int egc_aggregate_combine_batch_f32(const int32_t* tiles, int32_t n_tiles, int32_t tile_nodes, int32_t tile_edges,
+                                    const int64_t* src, const int64_t* dst, int64_t n_nodes, const int32_t* max_index,
+                                    const egc_layer* layer, const float* bases, int32_t ldb, const float* weightings,
+                                    int32_t ldw, const float* bias, const egc_post* post, float* out, int32_t* status,
+                                    int32_t* host_flag, egc_stream_t stream) {
+  AggArgs a;
+  int st = tile_layer_args(layer, a);
+  if (st != EGC_OK) return st;
+  if (n_nodes < 0 || n_tiles < 0 || n_nodes >= ((int64_t)1 << 31) - 1) return EGC_ERR_INVALID;
+  if (n_nodes == 0 || n_tiles == 0) return EGC_OK;
+  if (tiles == nullptr || bases == nullptr || weightings == nullptr || out == nullptr || status == nullptr) return EGC_ERR_INVALID;
+  if (ldb != a.ldb || (reinterpret_cast<uintptr_t>(bases) & 15) != 0) return EGC_ERR_INVALID;
+  if (post != nullptr && ((post->scale == nullptr) != (post->shift == nullptr))) return EGC_ERR_INVALID;
+  if (!a.loops_all && max_index == nullptr) return EGC_ERR_INVALID;
+  if ((uint64_t)n_nodes * (uint64_t)ldb * 4ull > (uint64_t)OOB) return EGC_ERR_UNSUPPORTED;
+  a.ldw = ldw > 0 ? ldw : a.W;
+  if (a.ldw != a.W && (a.ldw < a.W || (a.ldw & 3) != 0 || (reinterpret_cast<uintptr_t>(weightings) & 15) != 0)) return EGC_ERR_INVALID;
+  a.n_nodes = (int)n_nodes;
+  a.row_begin = 0;
+  a.row_end = (int)n_nodes;
+  a.bases = bases;
+  a.weightings = weightings;
+  a.bias = bias;
+  a.out = out;
+  a.dis = layer_uses_symnorm(layer) ? bases : nullptr;   // (a flag here: the deg^-1/2 tables are built per tile, in LDS)
+  a.bases_bytes = (unsigned)((uint64_t)n_nodes * ldb * 4ull);
+  a.post_scale = post != nullptr ? post->scale : nullptr;
+  a.post_shift = post != nullptr ? post->shift : nullptr;
+  a.residual = post != nullptr ? post->residual : nullptr;
+  a.post_relu = post != nullptr && post->relu != 0;
+  a.self_pos = 0;
+  return launch_tile_simple(a, reinterpret_cast<const int4*>(tiles), n_tiles, tile_nodes, tile_edges, src, dst, max_index,
+                            status, host_flag, (hipStream_t)stream);
+}
+
 int32_t egc_layer_gemm_flags(const egc_layer* layer) {
   if (layer == nullptr) return 0;
   if (const char* e = getenv("EGC_GEMM_FAST"))   // keep the 22-bit form for std / var layers too (measurements)

@@ -1,0 +1,450 @@
+// Batches of small graphs (BASELINE configs 3 / 4: molecules, superpixel graphs): the aggregate+combine launch on TILES
+// OF WHOLE GRAPHS, with the graph preparation inside it.
+//
+// The reference's batched nets (zinc/models.py:60-74, mol/pna_style_models.py:64-79, cifar/models.py:61-75) call the layer
+// with a PyG batch: the disjoint union of a few hundred to a few thousand small graphs, nodes numbered graph by graph,
+// the edges of one graph contiguous in `edge_index`.  On such a batch the adjacency is block diagonal, so a workgroup
+// that takes a run of consecutive graphs needs nothing from outside its own rows:
+//
+//   plan    (tile_plan_kernel, once per batch, shared by the layers of a net): the node range [0, N) is cut into slots of
+//           S nodes; tile k = the graphs whose first node lies in slot k -> node range [n0, n1), edge range [e0, e1)
+//           (wave-wide 64-ary searches in the graph offsets and in the destination row of edge_index);
+//   layer   (agg_tile_kernel, one workgroup per tile): the tile's rows of `bases` are copied into LDS once (each row
+//           is then gathered from LDS by every in-neighbour instead of from L2 / HBM: at 8 in-neighbours per node the
+//           CIFAR batch reads 62 MB of basis rows instead of 556 MB of gathered ones); the tile's edges are turned into
+//           a CSR in LDS (degree count by LDS atomics, wave scan, scatter) together with both deg^-1/2 tables --
+//           the five launches of egc_graph_build per batch disappear; the lane groups then aggregate their rows
+//           from LDS and run the register epilogue of the fast kernel family (egc_aggregate_fast_dev.h: finish_group),
+//           weightings rows prefetched one pass ahead.
+//
+// Replaces, for such batches, the same reference call sites as egc_graph_build + egc_aggregate_combine_post_f32
+// (MessagePassing.propagate's index handling and gather, torch_scatter's reductions, the combine and the caller's
+// BatchNorm(eval) / ReLU / residual tail).  Inference form (no arg positions / statistics for a backward).
+// Every edge is range-checked against ITS TILE: an edge that leaves its graph's tile (an edge list that is not grouped by
+// graph, an id outside [0, N)), a tile with more nodes or edges than the LDS areas hold -> *status and the sticky
+// host flag are raised (codes below) and the tile's rows are left unwritten.
+// The order of a row's entries inside the LDS CSR follows the LDS atomics (not the input order): sums may differ in the
+// last bits from run to run (as the reference's own GPU scatter does); max / min are exact.
+#include <algorithm>
+
+#include "egc_aggregate_fast_dev.h"
+
+namespace egc {
+
+constexpr int TILE_THREADS = 512;
+constexpr int TILE_WAVES = TILE_THREADS / 64;
+constexpr int TILE_MAX_NODES = 1024;    // hard cap (u16 ids would allow more; LDS does not)
+constexpr int TILE_EDGE_REGS = 12;      // edges per thread held in registers between the two CSR passes
+
+struct TileArgs {
+  const int4* tiles;       // (n0, n1, e0, e1) per tile
+  const int64_t* src;      // edge_index[0]
+  const int64_t* dst;      // edge_index[1]
+  const int* max_index;    // device scalar (layers with loops_all == 0), or nullptr
+  int32_t* status;
+  int32_t* host_flag;
+  int tmax, emax;          // capacity of the LDS areas: nodes / edges per tile
+  // byte offsets of the tile areas inside dynamic LDS (behind the per-wavefront epilogue strips)
+  int off_bases, off_col, off_rowptr, off_cnt, off_ns, off_dis_raw, off_dis_looped;
+};
+
+// first index i in [0, n) with arr[i] >= key (n if none), by one wavefront: 64-ary narrowing, then one probe per lane.
+// On an array that is not sorted the result is still a deterministic function of (arr, key) -- the tiles' edge ranges
+// therefore always partition [0, E), and the tile kernel's per-edge range check reports what the search got wrong.
+__device__ inline int64_t wave_lower_bound(const int64_t* __restrict__ arr, int64_t n, int64_t key, int lane) {
+  int64_t lo = 0, hi = n;   // answer in [lo, hi]; everything before lo is < key, arr[hi] (if hi < n) is >= key
+  while (hi - lo > 64) {
+    const int64_t step = (hi - lo + 63) / 64;
+    const int64_t i = lo + (int64_t)lane * step;
+    const bool ge = i < hi ? arr[i] >= key : true;
+    const unsigned long long m = __ballot(ge);
+    const int f = __ffsll((long long)m) - 1;            // first probe that is >= key
+    if (f < 0) { lo = lo + 63 * step + 1; if (lo > hi) lo = hi; continue; }   // all 64 probes < key: the answer lies behind the last one
+    const int64_t nhi = lo + (int64_t)f * step;
+    const int64_t nlo = f > 0 ? lo + (int64_t)(f - 1) * step + 1 : lo;
+    lo = nlo;
+    hi = nhi < hi ? nhi : hi;
+  }
+  const int64_t i = lo + lane;
+  const bool ge = i < hi ? arr[i] >= key : true;
+  const unsigned long long m = __ballot(ge);
+  const int f = __ffsll((long long)m) - 1;
+  return f < 0 ? hi : (lo + f < hi ? lo + f : hi);
+}
+
+__global__ void __launch_bounds__(256) tile_plan_kernel(const int64_t* __restrict__ ptr, int64_t n_graphs,
+                                                        const int64_t* __restrict__ dst, int64_t n_edges, int64_t n_nodes,
+                                                        int slot, int n_tiles, int4* __restrict__ tiles) {
+  const int lane = threadIdx.x & 63;
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (k >= n_tiles) return;
+  // graphs whose first node lies in [k S, (k + 1) S)
+  const int64_t g0 = wave_lower_bound(ptr, n_graphs + 1, (int64_t)k * slot, lane);
+  const int64_t g1 = wave_lower_bound(ptr, n_graphs + 1, (int64_t)(k + 1) * slot, lane);
+  int64_t n0 = g0 <= n_graphs ? ptr[g0] : n_nodes;
+  int64_t n1 = g1 <= n_graphs ? ptr[g1] : n_nodes;
+  if (k == n_tiles - 1) n1 = n_nodes;         // (ptr[G] == N for a well-formed batch; nodes behind it stay with the last tile)
+  if (k == 0) n0 = 0;
+  n0 = n0 < 0 ? 0 : (n0 > n_nodes ? n_nodes : n0);
+  n1 = n1 < n0 ? n0 : (n1 > n_nodes ? n_nodes : n1);
+  const int64_t e0 = n0 <= 0 ? 0 : wave_lower_bound(dst, n_edges, n0, lane);
+  const int64_t e1 = n1 >= n_nodes ? n_edges : wave_lower_bound(dst, n_edges, n1, lane);
+  if (lane == 0) tiles[k] = int4{(int)n0, (int)n1, (int)e0, (int)(e1 < e0 ? e0 : e1)};
+}
+
+// entry u of a batch: source row j from the staged lane, its slot from LDS
+template <int NEED, class C>
+__device__ inline void gather_batch_lds(const AggArgs& a, FAcc<NEED>& acc, const f4* __restrict__ lds_bases4, int ldb4, int q,
+                                        int addr0, int row, int jj, float dd, float dis_i, int n_valid, int first, int pos_base) {
+  f4 v[FU];
+  float w[FU];
+  bool in_x[FU];
+#pragma unroll
+  for (int u = 0; u < FU; ++u) {
+    const int addr = addr0 + u * 4;
+    const int j = bperm(addr, jj);
+    const bool is_self = j == row;
+    in_x[u] = (first + u < n_valid) && !(C::xl(a) && is_self);
+    v[u] = in_x[u] ? lds_bases4[j * ldb4 + q] : f4{0.f, 0.f, 0.f, 0.f};
+    w[u] = bperm(addr, dd) * dis_i;
+    if (C::yl(a) && !C::xl(a)) w[u] = is_self ? 0.f : w[u];
+  }
+#pragma unroll
+  for (int u = 0; u < FU; ++u) fold<NEED>(acc, v[u], w[u], in_x[u], pos_base + first + u);
+}
+
+template <int LPR_LOG2, class C>
+__device__ inline void load_weightings_row(const AggArgs& a, int q, int row, bool row_ok, f4 (&wpre)[2]) {
+  constexpr int LPR = 1 << LPR_LOG2;
+  const int W = C::W(a);
+  const float* wrow = a.weightings + (int64_t)(row_ok ? row : 0) * a.ldw;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int c0 = (q + k * LPR) * 4;
+    wpre[k] = f4{0.f, 0.f, 0.f, 0.f};
+    if (row_ok && c0 + 3 < W) wpre[k] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(wrow + c0));
+    else if (row_ok && c0 < W) {
+      wpre[k].x = wrow[c0];
+      if (c0 + 1 < W) wpre[k].y = wrow[c0 + 1];
+      if (c0 + 2 < W) wpre[k].z = wrow[c0 + 2];
+    }
+  }
+}
+
+__device__ inline void tile_error(const TileArgs& t, int code) {
+  atomicOr(t.status, code);
+  if (t.host_flag != nullptr) *(volatile int32_t*)t.host_flag = 1;
+}
+
+template <int LPR_LOG2, int HPB, int NEED, class C>
+__global__ void __launch_bounds__(TILE_THREADS) agg_tile_kernel(AggArgs a, TileArgs t) {
+  constexpr int LPR = 1 << LPR_LOG2, G = 64 / LPR;
+  extern __shared__ float smem[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int g = lane >> LPR_LOG2;
+  const int q = lane & (LPR - 1);
+  const int F_out = C::F_out(a);
+
+  const int4 tl = t.tiles[blockIdx.x];
+  const int n0 = tl.x, T = tl.y - tl.x, e0 = tl.z, Et = tl.w - tl.z;
+  if (T <= 0) {
+    if (Et > 0 && tid == 0) tile_error(t, 1);   // edges without rows: not a graph-grouped list
+    return;
+  }
+  if (T > t.tmax || Et > t.emax) {               // does not fit the LDS areas: report, leave the rows unwritten
+    if (tid == 0) tile_error(t, 2);
+    return;
+  }
+
+  // ---- per-wavefront epilogue strips: [bias (x scale + shift)][scale][G weight strips], as agg_fast_kernel ----
+  float* lds_bias = smem + wave * a.lds_floats_per_wave;
+  const bool post = a.post_scale != nullptr;
+  float* lds_scale = lds_bias + a.bias_lds_floats;
+  float* lds_w = lds_bias + (post ? 2 : 1) * a.bias_lds_floats;
+  for (int o = lane; o < C::H(a) * C::Ls(a); o += 64) {
+    const int h = o / C::Ls(a), l = o - h * C::Ls(a);
+    const int c = h * C::L(a) + l;
+    const bool real = l < C::L(a);
+    float bv = (a.bias != nullptr && real) ? a.bias[c] : 0.f;
+    if (post) {
+      const float sc = real ? a.post_scale[c] : 0.f;
+      bv = fmaf(bv, sc, real ? a.post_shift[c] : 0.f);
+      lds_scale[o] = sc;
+    }
+    lds_bias[o] = bv;
+  }
+  char* base = reinterpret_cast<char*>(smem);
+  f4* lds_bases4 = reinterpret_cast<f4*>(base + t.off_bases);
+  unsigned short* lds_col = reinterpret_cast<unsigned short*>(base + t.off_col);
+  int* lds_rowptr = reinterpret_cast<int*>(base + t.off_rowptr);
+  int* lds_cnt = reinterpret_cast<int*>(base + t.off_cnt);       // in-degree, then the scatter cursor
+  int* lds_ns = reinterpret_cast<int*>(base + t.off_ns);         // non-self in-degree
+  float* lds_dis_raw = reinterpret_cast<float*>(base + t.off_dis_raw);
+  float* lds_dis_looped = reinterpret_cast<float*>(base + t.off_dis_looped);
+  const int ldb4 = a.ldb >> 2;
+
+  // ---- (A) requests: the tile's edges (critical path of the CSR), then its basis rows (one flat copy) ----
+  int es[TILE_EDGE_REGS], ed[TILE_EDGE_REGS];
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < TILE_EDGE_REGS; ++k) {
+    const int i = tid + k * TILE_THREADS;
+    es[k] = ed[k] = -1;
+    if (i < Et) {
+      const int64_t s = t.src[(int64_t)e0 + i] - n0, d = t.dst[(int64_t)e0 + i] - n0;
+      if (s < 0 || s >= T || d < 0 || d >= T) bad = true;
+      else { es[k] = (int)s; ed[k] = (int)d; }
+    }
+  }
+  for (int i = tid; i < T; i += TILE_THREADS) { lds_cnt[i] = 0; lds_ns[i] = 0; }
+  const int n4 = T * ldb4;
+  const f4* gb4 = reinterpret_cast<const f4*>(a.bases) + (int64_t)n0 * ldb4;
+#pragma unroll 4
+  for (int i = tid; i < n4; i += TILE_THREADS) lds_bases4[i] = gb4[i];
+  if (__ballot(bad) != 0 && lane == 0) tile_error(t, 1);
+  __syncthreads();
+
+  // ---- (B) in-degrees ----
+#pragma unroll
+  for (int k = 0; k < TILE_EDGE_REGS; ++k)
+    if (ed[k] >= 0) {
+      atomicAdd(&lds_cnt[ed[k]], 1);
+      if (es[k] != ed[k]) atomicAdd(&lds_ns[ed[k]], 1);
+    }
+  __syncthreads();
+
+  // ---- (C) exclusive scan -> rowptr, deg^-1/2 tables (wavefront 0; T <= 1024: up to 16 entries per lane) ----
+  if (wave == 0) {
+    const int per = (T + 63) >> 6;
+    const int b0 = lane * per;
+    int mine = 0;
+    for (int k = 0; k < per; ++k) mine += (b0 + k < T) ? lds_cnt[b0 + k] : 0;
+    int incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int v = __shfl_up(incl, off);
+      if (lane >= off) incl += v;
+    }
+    int run = incl - mine;
+    for (int k = 0; k < per; ++k) {
+      const int i = b0 + k;
+      if (i < T) {
+        const int c = lds_cnt[i];
+        lds_rowptr[i] = run;
+        lds_dis_raw[i] = c > 0 ? 1.0f / sqrtf((float)c) : 0.0f;          // as prepare_kernel / build_scan_kernel
+        lds_dis_looped[i] = 1.0f / sqrtf((float)(lds_ns[i] + 1));
+        lds_cnt[i] = 0;                                                   // becomes the cursor
+        run += c;
+      }
+    }
+    if (lane == 63) lds_rowptr[T] = incl;
+  }
+  __syncthreads();
+
+  // ---- (D) scatter ----
+#pragma unroll
+  for (int k = 0; k < TILE_EDGE_REGS; ++k)
+    if (ed[k] >= 0) {
+      const int pos = lds_rowptr[ed[k]] + atomicAdd(&lds_cnt[ed[k]], 1);
+      lds_col[pos] = (unsigned short)es[k];
+    }
+  __syncthreads();
+
+  // ---- (E) rows: one lane group per row, G rows per wavefront and pass; weightings of the next pass in flight ----
+  FastRsrc R;
+  R.bases = bases_rsrc(a);
+  R.out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (unsigned)a.n_nodes * (unsigned)F_out * 4u, 0x00020000);
+  R.res = __builtin_amdgcn_make_buffer_rsrc((void*)(a.residual != nullptr ? a.residual : a.out), 0,
+                                            (unsigned)a.n_nodes * (unsigned)F_out * 4u, 0x00020000);
+  const bool looped_any = C::xl(a) || C::yl(a);
+  const float* lds_dis = C::yl(a) ? lds_dis_looped : lds_dis_raw;
+  const bool want_dis = a.dis != nullptr;       // (set by the host when the layer has a symnorm aggregator)
+  const int max_index = (!C::loops_all(a) && t.max_index != nullptr) ? *t.max_index : 0x7fffffff;
+  constexpr int RPP = TILE_WAVES * G;           // rows per pass
+  const int grp_addr = (g << LPR_LOG2) << 2;
+  f4 wnext[2];
+  {
+    const int r = wave * G + g;
+    load_weightings_row<LPR_LOG2, C>(a, q, n0 + r, r < T, wnext);
+  }
+  for (int r0 = 0; r0 < T; r0 += RPP) {
+    const int r = r0 + wave * G + g;             // local row of this lane group
+    const bool row_ok = r < T;
+    const int row = n0 + (row_ok ? r : 0);
+    f4 wpre[2] = {wnext[0], wnext[1]};
+    if (r0 + RPP < T) load_weightings_row<LPR_LOG2, C>(a, q, n0 + r + RPP, r + RPP < T, wnext);
+    const int start = row_ok ? lds_rowptr[r] : 0;
+    const int nd = row_ok ? lds_rowptr[r + 1] - start : 0;
+    int maxd = nd;
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) maxd = max(maxd, bperm((lane ^ off) << 2, maxd));
+    maxd = __builtin_amdgcn_readfirstlane(maxd);
+    const float dis_i = (want_dis && row_ok) ? lds_dis[r] : 0.f;
+    const bool has_self = row_ok && (C::loops_all(a) || row <= max_index);
+    const bool want_self = looped_any && has_self;
+    const f4 vself = (want_self && q < C::slots(a)) ? lds_bases4[r * ldb4 + q] : f4{0.f, 0.f, 0.f, 0.f};
+
+    FAcc<NEED> acc;
+    acc.init();
+    int nself = 0;
+    for (int ts = 0; ts < maxd; ts += LPR) {
+      const bool pv = ts + q < nd;
+      const int jj = pv ? (int)lds_col[start + ts + q] : 0;
+      const float dd = (pv && want_dis) ? lds_dis[jj] : 0.f;
+      if (looped_any) {
+        const unsigned long long sb = __ballot(pv && jj == r);
+        nself += __popcll((sb >> (g << LPR_LOG2)) & ((LPR == 64) ? ~0ull : ((1ull << LPR) - 1ull)));
+      }
+      const int cnt = min(LPR, maxd - ts);
+      for (int t0 = 0; t0 < cnt; t0 += FU)
+        gather_batch_lds<NEED, C>(a, acc, lds_bases4, ldb4, q, grp_addr + (t0 << 2), r, jj, dd, dis_i,
+                                  q < C::slots(a) ? nd : 0, ts + t0, start);
+    }
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    finish_group<LPR_LOG2, HPB, NEED, C>(a, R, ln, row, row_ok, acc, nd, nself, dis_i, vself, has_self, wpre, true, lds_w,
+                                         lds_bias, lds_scale);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+struct TileLds {
+  size_t strips, total;
+  int off_bases, off_col, off_rowptr, off_cnt, off_ns, off_dis_raw, off_dis_looped;
+};
+
+static TileLds tile_lds(const AggArgs& a, int tmax, int emax) {
+  TileLds L;
+  auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+  size_t at = up16((size_t)TILE_WAVES * a.lds_floats_per_wave * sizeof(float));
+  L.strips = at;
+  L.off_bases = (int)at; at += up16((size_t)tmax * a.ldb * 4);
+  L.off_col = (int)at; at += up16((size_t)emax * 2);
+  L.off_rowptr = (int)at; at += up16((size_t)(tmax + 1) * 4);
+  L.off_cnt = (int)at; at += up16((size_t)tmax * 4);
+  L.off_ns = (int)at; at += up16((size_t)tmax * 4);
+  L.off_dis_raw = (int)at; at += up16((size_t)tmax * 4);
+  L.off_dis_looped = (int)at; at += up16((size_t)tmax * 4);
+  L.total = at;
+  return L;
+}
+
+constexpr size_t TILE_LDS_BUDGET = 160 * 1024;
+
+template <int LPR_LOG2, int HPB, int NEED, class C>
+static int launch_tile_one(const AggArgs& a, const TileArgs& t, unsigned grid, size_t lds, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&agg_tile_kernel<LPR_LOG2, HPB, NEED, C>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)TILE_LDS_BUDGET);
+    if (e != hipSuccess) { set_last_error("hipFuncSetAttribute(agg_tile_kernel)", e); return EGC_ERR_HIP; }
+    attr_set = true;
+  }
+  agg_tile_kernel<LPR_LOG2, HPB, NEED, C><<<grid, TILE_THREADS, lds, stream>>>(a, t);
+  EGC_LAUNCH_CHECK("agg_tile_kernel");
+  return EGC_OK;
+}
+
+template <int LPR_LOG2>
+static int launch_tile_rt(const AggArgs& a, const TileArgs& t, int need, unsigned grid, size_t lds, hipStream_t stream) {
+  const int hpb = (a.H + a.B - 1) / a.B;
+  if (need == 0) {
+    if (hpb <= 1) return launch_tile_one<LPR_LOG2, 1, 0, RtCfg>(a, t, grid, lds, stream);
+    if (hpb <= 2) return launch_tile_one<LPR_LOG2, 2, 0, RtCfg>(a, t, grid, lds, stream);
+    return launch_tile_one<LPR_LOG2, 4, 0, RtCfg>(a, t, grid, lds, stream);
+  }
+  if (hpb <= 1) return launch_tile_one<LPR_LOG2, 1, NEED_SQ | NEED_MN, RtCfg>(a, t, grid, lds, stream);
+  if (hpb <= 2) return launch_tile_one<LPR_LOG2, 2, NEED_SQ | NEED_MN, RtCfg>(a, t, grid, lds, stream);
+  return launch_tile_one<LPR_LOG2, 4, NEED_SQ | NEED_MN, RtCfg>(a, t, grid, lds, stream);
+}
+
+// the layer configurations with their constants compiled in (the same idea as EGC_STATIC_CFG of the fast kernel)
+template <class C, int LPR_LOG2, int HPB, int NEED>
+static bool try_tile_static(const AggArgs& a, const TileArgs& t, int h, int b, int l, int na, unsigned agg, bool xl, bool yl,
+                            bool loops_all, unsigned grid, size_t lds, hipStream_t stream, int* status) {
+  unsigned packed = 0;
+  for (int k = 0; k < a.A; ++k) packed |= (unsigned)a.aggr[k] << (3 * k);
+  if (a.H != h || a.B != b || a.L != l || a.Ls != l || a.A != na || packed != agg || a.act != EGC_ACT_NONE ||
+      (a.x_looped != 0) != xl || (a.y_looped != 0) != yl || (a.loops_all != 0) != loops_all)
+    return false;
+  *status = launch_tile_one<LPR_LOG2, HPB, NEED, C>(a, t, grid, lds, stream);
+  return true;
+}
+
+// largest node count whose LDS areas fit (edges: emax = edges_per_node x nodes)
+int tile_capacity(const AggArgs& a_in, int edges_per_node) {
+  AggArgs a = a_in;
+  int best = 0;
+  for (int tmax = 32; tmax <= TILE_MAX_NODES; tmax += 32) {
+    const int emax = std::min(tmax * edges_per_node, TILE_THREADS * TILE_EDGE_REGS);
+    if (tile_lds(a, tmax, emax).total <= TILE_LDS_BUDGET) best = tmax; else break;
+  }
+  return best;
+}
+
+int launch_tile(AggArgs a, TileArgs t, int n_tiles, hipStream_t stream) {
+  const int lpr = a.slots <= 16 ? 16 : a.slots <= 32 ? 32 : 64;
+  const int G = 64 / lpr;
+  a.lanes_pb = a.Ls / 4;
+  a.magic_P = (unsigned)(((uint64_t)1 << 32) / (uint64_t)a.lanes_pb) + 1u;
+  if ((a.lanes_pb & (a.lanes_pb - 1)) == 0) {
+    int lg = 0;
+    while ((4 << lg) < a.Ls) ++lg;
+    a.lpb_log2 = lg;
+  } else {
+    a.lpb_log2 = -1;
+  }
+  a.need_mean = a.need_var = 0;
+  int need = 0;
+  for (int k = 0; k < a.A; ++k) {
+    if (a.aggr[k] == EGC_AGGR_MEAN || a.aggr[k] == EGC_AGGR_VAR || a.aggr[k] == EGC_AGGR_STD) a.need_mean = 1;
+    if (a.aggr[k] == EGC_AGGR_VAR || a.aggr[k] == EGC_AGGR_STD) { a.need_var = 1; need |= NEED_SQ; }
+    if (a.aggr[k] == EGC_AGGR_MIN) need |= NEED_MN;
+  }
+  a.w_lds_stride = (a.W + 3) & ~3;
+  a.bias_lds_floats = (a.H * a.Ls + 3) & ~3;
+  a.lds_floats_per_wave = (a.post_scale != nullptr ? 2 : 1) * a.bias_lds_floats + G * a.w_lds_stride;
+  const TileLds L = tile_lds(a, t.tmax, t.emax);
+  if (L.total > TILE_LDS_BUDGET || t.tmax > TILE_MAX_NODES || t.emax > TILE_THREADS * TILE_EDGE_REGS) return EGC_ERR_UNSUPPORTED;
+  t.off_bases = L.off_bases; t.off_col = L.off_col; t.off_rowptr = L.off_rowptr; t.off_cnt = L.off_cnt; t.off_ns = L.off_ns;
+  t.off_dis_raw = L.off_dis_raw; t.off_dis_looped = L.off_dis_looped;
+  const unsigned grid = (unsigned)n_tiles;
+  if (getenv("EGC_NO_STATIC_CFG") == nullptr) {
+    int status = EGC_OK;
+    constexpr int S = EGC_AGGR_SUM, M = EGC_AGGR_MEAN, X = EGC_AGGR_MAX, Y = EGC_AGGR_SYMNORM;
+    // EGConv EGC-M north star (configs 3 / 4 of BASELINE.json): d=128, H=8, B=4, sum+mean+max+symnorm, loops on every node
+    if (try_tile_static<StCfg<8, 4, 16, 4, agg_pack(S, M, X, Y), EGC_ACT_NONE, true, true, true>, 4, 2, 0>(
+            a, t, 8, 4, 16, 4, agg_pack(S, M, X, Y), true, true, true, grid, L.total, stream, &status)) return status;
+    // EfficientGraphConv EGC-M / EGC-S at d=128 (symadd looped, the others raw)
+    if (try_tile_static<StCfg<8, 4, 16, 3, agg_pack(Y, X, M), EGC_ACT_NONE, false, true, true>, 4, 2, 0>(
+            a, t, 8, 4, 16, 3, agg_pack(Y, X, M), false, true, true, grid, L.total, stream, &status)) return status;
+    if (try_tile_static<StCfg<8, 4, 16, 1, agg_pack(Y), EGC_ACT_NONE, false, true, true>, 4, 2, 0>(
+            a, t, 8, 4, 16, 1, agg_pack(Y), false, true, true, grid, L.total, stream, &status)) return status;
+  }
+  switch (lpr) {
+    case 16: return launch_tile_rt<4>(a, t, need, grid, L.total, stream);
+    case 32: return launch_tile_rt<5>(a, t, need, grid, L.total, stream);
+    default: return launch_tile_rt<6>(a, t, need, grid, L.total, stream);
+  }
+}
+
+int launch_tile_simple(AggArgs a, const int4* tiles, int n_tiles, int tmax, int emax, const int64_t* src, const int64_t* dst,
+                       const int* max_index, int32_t* status, int32_t* host_flag, hipStream_t stream) {
+  TileArgs t = {};
+  t.tiles = tiles; t.src = src; t.dst = dst; t.max_index = max_index; t.status = status; t.host_flag = host_flag;
+  t.tmax = tmax; t.emax = emax;
+  return launch_tile(a, t, n_tiles, stream);
+}
+
+int launch_tile_plan(const int64_t* ptr, int64_t n_graphs, const int64_t* dst, int64_t n_edges, int64_t n_nodes, int slot,
+                     int n_tiles, int4* tiles, hipStream_t stream) {
+  tile_plan_kernel<<<(unsigned)((n_tiles + 3) / 4), 256, 0, stream>>>(ptr, n_graphs, dst, n_edges, n_nodes, slot, n_tiles, tiles);
+  EGC_LAUNCH_CHECK("tile_plan_kernel");
+  return EGC_OK;
+}
+
+}  // namespace egc

@@ -14,7 +14,7 @@ from dataclasses import dataclass
 import torch
 
 from . import _C
-from .graph import CSRGraph, _require_cuda, _stream_ptr, _device_guard
+from .graph import CSRGraph, GraphBatch, _IndexFlag, _require_cuda, _stream_ptr, _device_guard
 
 
 @dataclass
@@ -296,6 +296,60 @@ def egc_aggregate_combine(graph: CSRGraph, spec: LayerSpec, bases: torch.Tensor,
     return out
 
 
+def _batch_tile_setup(gb: GraphBatch, spec: LayerSpec, post):
+    """(tiles, n_tiles, tile_nodes, tile_edges) when the tile kernels serve this layer on this batch, else None."""
+    if os.environ.get("EGC_NO_TILE", "0") not in ("", "0"):
+        return None
+    lib = _C.load()
+    cap = int(lib.egc_batch_tile_nodes(C.byref(spec.c), gb.edges_per_node, 1 if (post is not None and post.scale is not None) else 0))
+    if cap <= 0:
+        return None
+    plan = gb.plan(cap)
+    if plan is None:
+        return None
+    tiles, n_tiles, _ = plan
+    return tiles, n_tiles, cap, min(cap * gb.edges_per_node, 512 * 12)
+
+
+def egc_aggregate_combine_batch(gb: GraphBatch, spec: LayerSpec, bases, weightings, bias, post, tiled):
+    """Steps 2 + 3 on tiles of whole graphs (egc_aggregate_combine_batch_f32): the CSR of each tile is built in LDS by the
+    workgroup that aggregates it."""
+    lib = _C.load()
+    _IndexFlag.poll()
+    n = gb.n_nodes
+    tiles, n_tiles, tile_nodes, tile_edges = tiled
+    _check_f32(bases, "bases", (n, spec.ldb))
+    _check_f32(weightings, "weightings", (n, spec.w_cols))
+    dev = bases.device
+    ldw = 0
+    if n > 1 and weightings.stride(1) == 1 and weightings.stride(0) != spec.w_cols:
+        ldw = int(weightings.stride(0))
+    elif not weightings.is_contiguous():
+        weightings = weightings.contiguous()
+    with _device_guard(dev):
+        out = torch.empty((n, spec.f_out), dtype=torch.float32, device=dev)
+        keep = []
+        p = None
+        if post is not None:
+            def sptr(t, shape, name):
+                if t is None:
+                    return None
+                _check_f32(t, name, shape)
+                keep.append(t.contiguous())
+                return keep[-1].data_ptr()
+            p = _C.EgcPost(sptr(post.scale, (spec.f_out,), "post.scale"), sptr(post.shift, (spec.f_out,), "post.shift"),
+                           sptr(post.residual, (n, spec.f_out), "post.residual"), int(bool(post.relu)))
+        ei = gb.edge_index
+        needs_max = not bool(spec.c.loops_all_nodes)
+        _C.check(lib.egc_aggregate_combine_batch_f32(
+            tiles.data_ptr(), n_tiles, tile_nodes, tile_edges, ei[0].data_ptr(), ei[1].data_ptr(), n,
+            gb.max_index().data_ptr() if needs_max else None, C.byref(spec.c), bases.data_ptr(), spec.ldb,
+            weightings.data_ptr(), ldw, bias.contiguous().data_ptr() if bias is not None else None,
+            C.byref(p) if p is not None else None, out.data_ptr(), gb.status().data_ptr(), _IndexFlag.ptr(),
+            _stream_ptr(dev)), "egc_aggregate_combine_batch_f32")
+    return out
+
+
 def segment_mean(x: torch.Tensor, seg_ptr: torch.Tensor) -> torch.Tensor:
     """Mean of consecutive row segments of x [N, C]: out[g] = mean(x[seg_ptr[g]:seg_ptr[g+1]]) (egc_segment_mean_f32)."""
     lib = _C.load()
@@ -434,6 +488,13 @@ def egc_layer_forward(graph: CSRGraph, spec: LayerSpec, x: torch.Tensor, wcat: t
     bcat = comb.bias ([W]) or None, bias = layer bias ([F_out]) or None; ``packed`` = pack_weights(wcat)
     if the caller keeps one (otherwise it is produced here).  On a vertex-partitioned graph the halo rows
     of ``bases`` are exchanged (one all-to-all-v) between the two steps."""
+    if isinstance(graph, GraphBatch):
+        tiled = None if return_intermediates else _batch_tile_setup(graph, spec, post)
+        if tiled is None:
+            graph = graph.csr()          # outside the tile kernels' envelope: the ordinary path on the same edges
+        else:
+            bases, weightings = egc_basis_transform(graph, spec, x, wcat, bcat, packed)
+            return egc_aggregate_combine_batch(graph, spec, bases, weightings, bias, post, tiled)
     halo = graph.halo if graph.n_src_rows > graph.n_nodes else None
     if (halo is None and not return_intermediates and graph.n_src_rows == graph.n_nodes and fused_enabled()
             and not gemm_exact() and fused_supported(spec)):
@@ -950,18 +1011,22 @@ def egc_aggregate_combine_apply(graph, spec, bases, weightings, bias=None):
     return egc_aggregate_combine(graph, spec, bases, weightings, bias)
 
 
+def _as_csr(graph):
+    return graph.csr() if isinstance(graph, GraphBatch) else graph
+
+
 def egc_layer_apply_params(graph, spec, x, bias, comb_w, comb_b, bcat_direct, bases, f_in, H, A, B, L, Ls, permute_hab):
     """The training-path layer call from the module parameters (one autograd node: _EGCLayerParamsFunction).  ``bases``:
     one [f_in, B L] matrix or B [f_in, L] matrices; ``comb_b`` a combination bias to permute with the weight's rows,
     ``bcat_direct`` one already in the operand's order (pass exactly one of the two, or neither)."""
-    return _EGCLayerParamsFunction.apply(x, bias, comb_w, comb_b, bcat_direct, graph, spec,
+    return _EGCLayerParamsFunction.apply(x, bias, comb_w, comb_b, bcat_direct, _as_csr(graph), spec,
                                          (int(f_in), int(H), int(A), int(B), int(L), int(Ls)), bool(permute_hab), *bases)
 
 
 def egc_layer_apply(graph, spec, x, wcat, bcat, bias, packed=None):
     from . import ops   # torch.library registration of the same call (egc_amd/ops.py)
     if ops.use_torch_op():
-        return ops.layer_apply_op(graph, spec, x, wcat, bcat, bias)
+        return ops.layer_apply_op(_as_csr(graph), spec, x, wcat, bcat, bias)
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, wcat, bcat, bias)):
-        return _EGCLayerFunction.apply(x, wcat, bcat, bias, graph, spec)
+        return _EGCLayerFunction.apply(x, wcat, bcat, bias, _as_csr(graph), spec)
     return egc_layer_forward(graph, spec, x, wcat, bcat, bias, packed=packed)

@@ -17,7 +17,7 @@ import torch.nn as nn
 
 from .functional import (PostOp, batch_norm_act_residual, batch_norm_act_residual_supported, egc_layer_forward,
                          segment_mean)
-from .graph import graph_from_input
+from .graph import GraphBatch, graph_from_input
 
 
 class FusedEGCBlock(nn.Module):
@@ -126,7 +126,8 @@ class FusedEGCBlock(nn.Module):
             return egc_layer_forward(graph, conv._spec, x, wcat, conv.comb_weights.bias, conv.bias,
                                      packed=conv._weight_planes(wcat), post=post)
         wcat, bcat = conv._packed_weights()   # EGConv
-        spec = conv._spec_coo if isinstance(edge_index, torch.Tensor) and edge_index.layout == torch.strided else conv._spec_adj
+        spec = conv._spec_coo if ((isinstance(edge_index, torch.Tensor) and edge_index.layout == torch.strided)
+                                  or isinstance(edge_index, GraphBatch)) else conv._spec_adj
         return egc_layer_forward(graph, spec, x, wcat, bcat, conv.bias, packed=conv._weight_planes(spec, wcat), post=post)
 
 

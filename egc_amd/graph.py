@@ -407,6 +407,106 @@ class SparseTensor:
         return self._sizes[dim]
 
 
+class GraphBatch:
+    """A PyG-style BATCH of small graphs as the ``edge_index`` argument of the layers (``conv(x, GraphBatch(...))``),
+    for the kernels that work on tiles of whole graphs (egc_aggregate_combine_batch_f32): no CSR is built per batch --
+    each workgroup builds its tile's in LDS -- and a tile's basis rows are gathered from LDS.
+
+    What the reference's batched nets hand to the layer is ``batch.edge_index`` of a PyG ``Batch``
+    (zinc/models.py:60-74, mol/pna_style_models.py:64-79, cifar/models.py:61-75); the same ``Batch`` carries the graphs'
+    node offsets (``batch.ptr``) -- pass them here:
+
+        gb = egc_amd.GraphBatch(batch.edge_index, ptr=batch.ptr, max_nodes=max graph size)    # or batch=batch.batch,
+        x = conv(x, gb)                                                                         # num_graphs=batch.num_graphs
+
+    Requirements (checked on the device, reported like an out-of-range index -- a RuntimeError at the next call into the
+    package at the latest): graphs are numbered one after the other and the edges of one graph are contiguous in
+    ``edge_index`` (PyG's collation); a tile (a run of graphs of about ``slot`` nodes + one graph) fits the LDS areas.
+    ``max_nodes``: an upper bound of the largest graph's node count (default 128) -- it sets the slot so that no tile
+    overflows.  Layers outside the tile kernels' envelope, and every call that needs gradients, use the CSR of the same
+    edge list instead (built on first need, ``csr()``): results are the same, the speed is the ordinary path's."""
+
+    def __init__(self, edge_index: torch.Tensor, ptr: torch.Tensor | None = None, batch: torch.Tensor | None = None,
+                 num_graphs: int | None = None, num_nodes: int | None = None, max_nodes: int = 128, edges_per_node: int = 16):
+        _require_cuda(edge_index, "edge_index")
+        if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.size(0) != 2:
+            raise RuntimeError("egc_amd: edge_index must be an int64 tensor of shape [2, E]")
+        self.edge_index = edge_index.contiguous()
+        self.device = edge_index.device
+        if ptr is None:
+            if batch is None or num_graphs is None:
+                raise RuntimeError("egc_amd.GraphBatch: pass ptr (node offsets of the graphs, int64 [G + 1]) or batch "
+                                   "together with num_graphs")
+            b = batch.to(self.device)
+            ptr = torch.searchsorted(b, torch.arange(int(num_graphs) + 1, device=self.device, dtype=b.dtype))
+            if num_nodes is None:
+                num_nodes = int(batch.numel())
+        self.ptr = ptr.to(device=self.device, dtype=torch.int64).contiguous()
+        self.n_graphs = int(self.ptr.numel()) - 1
+        self.n_nodes = None if num_nodes is None else int(num_nodes)     # else: the row count of the first x seen
+        self.max_nodes, self.edges_per_node = int(max_nodes), int(edges_per_node)
+        self.n_edges = int(edge_index.size(1))
+        self.halo = None
+        self._plans = {}
+        self._csr = None
+        self._status = None
+        self._max_index = None
+
+    @property
+    def n_src_rows(self):
+        return self.n_nodes
+
+    def trim_launches(self) -> "GraphBatch":
+        return self
+
+    def csr(self) -> "CSRGraph":
+        """The ordinary CSR of the same edge list (training, layers outside the tile kernels' envelope)."""
+        if self._csr is None:
+            self._csr = CSRGraph.from_edge_index(self.edge_index, self.n_nodes)
+        return self._csr
+
+    def max_index(self) -> torch.Tensor:
+        if self._max_index is None:
+            self._max_index = (self.edge_index.max().to(torch.int32).reshape(1) if self.n_edges
+                               else torch.full((1,), -1, dtype=torch.int32, device=self.device))
+        return self._max_index
+
+    def status(self) -> torch.Tensor:
+        if self._status is None:
+            self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        return self._status
+
+    def check(self) -> "GraphBatch":
+        """Raise if a tile kernel has found the batch malformed (synchronises)."""
+        if self._status is not None and int(self._status.item()) != 0:
+            code = int(self._status.item())
+            self._status.zero_()
+            if _IndexFlag._view is not None:
+                _IndexFlag._view.value = 0
+            raise RuntimeError("egc_amd.GraphBatch: " + ("a tile exceeds the LDS areas (raise max_nodes / edges_per_node, or "
+                               "pass the plain edge_index)" if code & 2 else "edge_index is not grouped by graph, or holds "
+                               "node ids outside its graph: index out of range"))
+        return self
+
+    def plan(self, tile_nodes: int):
+        """(tiles int32 [n_tiles, 4], n_tiles, slot) for tiles of at most `tile_nodes` nodes; built once per capacity."""
+        hit = self._plans.get(tile_nodes)
+        if hit is None:
+            lib = _C.load()
+            slot = tile_nodes - self.max_nodes + 1
+            if slot < 8:
+                return None
+            n = self.n_nodes
+            n_tiles = (n + slot - 1) // slot
+            with _device_guard(self.device):
+                tiles = torch.empty((max(n_tiles, 1), 4), dtype=torch.int32, device=self.device)
+                _C.check(lib.egc_batch_plan(self.ptr.data_ptr(), self.n_graphs, self.edge_index[1].data_ptr(), self.n_edges, n,
+                                            slot, tiles.data_ptr(), n_tiles, _stream_ptr(self.device)), "egc_batch_plan")
+            hit = (tiles, n_tiles, slot)
+            self._plans[tile_nodes] = hit
+        return hit
+
+
 class GraphCache:
     """Small LRU of CSRGraphs keyed by the identity of the ``edge_index`` tensor, so that the
     layers of one network share one COO->CSR conversion per batch (SURVEY.md call stack d).
@@ -473,6 +573,12 @@ def graph_from_input(edge_index, num_nodes: int, static: bool = False) -> CSRGra
     """Dispatch on the two input forms of the reference layers (Tensor COO or SparseTensor adj_t).  ``static``: the
     caller keeps the graph (cached layers)."""
     if isinstance(edge_index, CSRGraph):
+        return edge_index
+    if isinstance(edge_index, GraphBatch):
+        if edge_index.n_nodes is None:
+            edge_index.n_nodes = int(num_nodes)
+        elif edge_index.n_nodes != int(num_nodes):
+            raise RuntimeError(f"egc_amd.GraphBatch: built for {edge_index.n_nodes} nodes, x has {int(num_nodes)} rows")
         return edge_index
     if isinstance(edge_index, SparseTensor):
         return edge_index.graph

@@ -25,7 +25,7 @@ from . import _C
 from . import ops
 from .functional import (egc_layer_apply, egc_layer_apply_params, gemm_exact, make_spec, pack_egconv_weights, pack_weights,
                          pad_bases_columns, padded_basis_stride)
-from .graph import graph_from_input
+from .graph import GraphBatch, graph_from_input
 from .layers import glorot_
 
 _AGGR_CODE = {"sum": _C.AGGR_SUM, "mean": _C.AGGR_MEAN, "symnorm": _C.AGGR_SYMNORM, "min": _C.AGGR_MIN,
@@ -127,7 +127,7 @@ class EGConv(nn.Module):
             graph, spec = self._cached_graph
         else:
             graph = graph_from_input(edge_index, x.size(self.node_dim), static=bool(self.cached))
-            is_coo = isinstance(edge_index, torch.Tensor) and edge_index.layout == torch.strided
+            is_coo = (isinstance(edge_index, torch.Tensor) and edge_index.layout == torch.strided) or isinstance(edge_index, GraphBatch)
             spec = self._spec_coo if is_coo else self._spec_adj
             if self.cached:
                 self._cached_graph = (graph.trim_launches(), spec)
