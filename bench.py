@@ -126,7 +126,10 @@ def roofline_terms(n, e_eff, f_in, f_g, f_out, w_cols, symnorm):
 # -------------------------------------------------------------------------------------------------
 # other configs (N = 1): measured in the same run, module-level calls (what a caller of the layer pays)
 # -------------------------------------------------------------------------------------------------
-def measure_layer_config(name, ei_cpu, n, conv, f_in, dev, per_batch_csr, iters=30):
+def measure_layer_config(name, ei_cpu, n, conv, f_in, dev, per_batch_csr, iters=30, batch=None, max_nodes=None):
+    """`batch` (+ `max_nodes`): the workload is a PyG-style batch of small graphs -- measured on the ordinary path (per-batch
+    egc_graph_build + GEMM + aggregate) AND on the tile path (egc_amd.GraphBatch: one plan launch per batch; GEMM; one
+    launch that builds each tile's CSR in LDS and aggregates from LDS); the record's headline fields are the faster one's."""
     import egc_amd
     ei = ei_cpu.to(dev)
     x = torch.randn(n, f_in, device=dev)
@@ -155,6 +158,38 @@ def measure_layer_config(name, ei_cpu, n, conv, f_in, dev, per_batch_csr, iters=
         tot = rec["layer_ms"] + rec["csr_build_ms"]
         rec["edges_per_s_incl_csr"] = e_eff / (tot * 1e-3)
         rec["frac_incl_csr"] = t["layer"] / (tot * 1e-3) / 1e9 / HBM_PEAK_GBS
+        rec["path"] = "csr: egc_graph_build (5 launches) + GEMM + agg_fast_kernel"
+    if batch is not None:
+        g_count = int(batch.max()) + 1
+        ptr = torch.searchsorted(batch.to(dev), torch.arange(g_count + 1, device=dev))
+        with torch.no_grad():
+            def make():
+                return egc_amd.GraphBatch(ei, ptr=ptr, num_nodes=n, max_nodes=max_nodes or 256)
+            gb = make()
+            ref = conv(x, egc_amd.CSRGraph.from_edge_index(ei, n))
+            out = conv(x, gb)
+            gb.check()
+            err = float((out - ref).abs().max() / ref.abs().max().clamp(min=1))
+            setup = next(iter(gb._setups.values()))
+
+            def plan_only():
+                make().plan(setup[0])
+            plan_ms = time_region_median(plan_only, 10)
+            tile_ms = time_region_median(lambda: conv(x, gb), iters, 3)
+
+            def one_go():
+                conv(x, make())
+            both_ms = time_region_median(one_go, iters, 3)
+        tile = {"path": "tile: egc_batch_plan (1 launch) + GEMM + agg_tile_kernel (CSR built in LDS per tile of whole graphs)",
+                "plan_ms": plan_ms, "layer_ms": tile_ms, "plan_plus_layer_ms": both_ms, "slot": setup[0], "lds_nodes": setup[1],
+                "edges_per_s_incl_plan": e_eff / (both_ms * 1e-3),
+                "frac_incl_plan": t["layer"] / (both_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "layer_frac": t["layer"] / (tile_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "rel_err_vs_csr_path": err}
+        rec["csr_path"] = {k: rec[k] for k in ("csr_build_ms", "layer_ms", "edges_per_s_incl_csr", "frac_incl_csr", "layer_frac", "path")}
+        rec["tile_path"] = tile
+        if both_ms < rec["layer_ms"] + rec["csr_build_ms"]:      # headline fields: the faster path
+            rec.update(csr_build_ms=plan_ms, layer_ms=tile_ms, edges_per_s=e_eff / (tile_ms * 1e-3), layer_frac=tile["layer_frac"],
+                       edges_per_s_incl_csr=tile["edges_per_s_incl_plan"], frac_incl_csr=tile["frac_incl_plan"], path=tile["path"])
     log(f"  {name}: " + ", ".join(f"{k}={v:.4g}" if isinstance(v, float) else f"{k}={v}" for k, v in rec.items()
                                   if k != "workload"))
     del g, x, ei
@@ -191,13 +226,14 @@ def _oc_layer_configs(out, dev, seed):
     from egc_amd import workloads as wl
     torch.manual_seed(seed)
     ns = _north_star_layer
-    ei, n, _ = wl.molecule_batch(2048, seed=seed)
+    ei, n, batch = wl.molecule_batch(2048, seed=seed)
     out["config3_molhiv_b2048"] = measure_layer_config(
-        "ogbg-molhiv-shaped batch of 2048 graphs, EGC-M d=128 H=8 B=4 sum+mean+max+symnorm", ei, n, ns(), F_IN, dev, True)
-    ei, n, _ = wl.knn_superpixel_batch(2048, seed=seed)
+        "ogbg-molhiv-shaped batch of 2048 graphs, EGC-M d=128 H=8 B=4 sum+mean+max+symnorm", ei, n, ns(), F_IN, dev, True,
+        batch=batch, max_nodes=222)
+    ei, n, batch = wl.knn_superpixel_batch(2048, seed=seed)
     out["config4_cifar_b2048"] = measure_layer_config(
         "CIFAR10-superpixel-shaped batch of 2048 8-NN graphs, EGC-M d=128 H=8 B=4 sum+mean+max+symnorm", ei, n, ns(),
-        F_IN, dev, True)
+        F_IN, dev, True, batch=batch, max_nodes=150)
     ei, n = wl.mag_like(seed=seed)
     out["config5_mag_homogeneous_1gpu"] = measure_layer_config(
         "ogbn-mag-shaped homogeneous graph (mag/configs.py:73-88), EGConv 352->352 H=8 B=4 symnorm (mag/models.py:23-53)",

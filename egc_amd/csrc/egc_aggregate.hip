@@ -858,38 +858,40 @@ static int tile_layer_args(const egc_layer* layer, AggArgs& a) {
   return EGC_OK;
 }
 
-int32_t egc_batch_tile_nodes(const egc_layer* layer, int32_t edges_per_node, int32_t with_post) {
+int32_t egc_batch_tile_nodes(const egc_layer* layer, int32_t max_tile_nodes, int32_t max_tile_edges, int32_t with_post) {
   AggArgs a;
-  if (tile_layer_args(layer, a) != EGC_OK || edges_per_node < 1) return 0;
+  if (tile_layer_args(layer, a) != EGC_OK || max_tile_nodes < 1 || max_tile_edges < 0) return 0;
   const int lpr = a.slots <= 16 ? 16 : a.slots <= 32 ? 32 : 64;
   a.w_lds_stride = (a.W + 3) & ~3;
   a.bias_lds_floats = (a.H * a.Ls + 3) & ~3;
   a.lds_floats_per_wave = (with_post ? 2 : 1) * a.bias_lds_floats + (64 / lpr) * a.w_lds_stride;
-  return tile_capacity(a, edges_per_node);
+  return tile_capacity(a, max_tile_nodes, max_tile_edges);
 }
 
 int egc_batch_plan(const int64_t* graph_ptr, int64_t n_graphs, const int64_t* dst, int64_t n_edges, int64_t n_nodes,
-                   int32_t slot, int32_t* tiles, int32_t n_tiles, egc_stream_t stream) {
-  if (graph_ptr == nullptr || tiles == nullptr || n_graphs < 0 || n_edges < 0 || n_nodes < 0 || slot <= 0) return EGC_ERR_INVALID;
+                   int32_t slot, int32_t* tiles, int32_t n_slots, int32_t* n_tiles, egc_stream_t stream) {
+  if (graph_ptr == nullptr || tiles == nullptr || n_tiles == nullptr || n_graphs < 0 || n_edges < 0 || n_nodes < 0 || slot <= 0)
+    return EGC_ERR_INVALID;
   if (n_nodes >= ((int64_t)1 << 31) - 1 || n_edges >= ((int64_t)1 << 31) - 1) return EGC_ERR_INVALID;
-  if (n_tiles != (int32_t)((n_nodes + slot - 1) / slot)) return EGC_ERR_INVALID;
+  if (n_slots != (int32_t)((n_nodes + slot - 1) / slot)) return EGC_ERR_INVALID;
   if (n_edges > 0 && dst == nullptr) return EGC_ERR_INVALID;
-  if (n_tiles == 0) return EGC_OK;
-  return launch_tile_plan(graph_ptr, n_graphs, dst, n_edges, n_nodes, slot, n_tiles, reinterpret_cast<int4*>(tiles),
+  if (n_slots == 0) return hipMemsetAsync(n_tiles, 0, sizeof(int32_t), (hipStream_t)stream) == hipSuccess ? EGC_OK : EGC_ERR_HIP;
+  return launch_tile_plan(graph_ptr, n_graphs, dst, n_edges, n_nodes, slot, n_slots, reinterpret_cast<int4*>(tiles), n_tiles,
                           (hipStream_t)stream);
 }
 
-int egc_aggregate_combine_batch_f32(const int32_t* tiles, int32_t n_tiles, int32_t tile_nodes, int32_t tile_edges,
-                                    const int64_t* src, const int64_t* dst, int64_t n_nodes, const int32_t* max_index,
-                                    const egc_layer* layer, const float* bases, int32_t ldb, const float* weightings,
-                                    int32_t ldw, const float* bias, const egc_post* post, float* out, int32_t* status,
-                                    int32_t* host_flag, egc_stream_t stream) {
+int egc_aggregate_combine_batch_f32(const int32_t* tiles, const int32_t* n_tiles, int32_t n_tiles_bound, int32_t lds_nodes,
+                                    int32_t max_tile_nodes, int32_t max_tile_edges, const int64_t* src, const int64_t* dst,
+                                    int64_t n_nodes, const int32_t* max_index, const egc_layer* layer, const float* bases,
+                                    int32_t ldb, const float* weightings, int32_t ldw, const float* bias, const egc_post* post,
+                                    float* out, int32_t* status, int32_t* host_flag, egc_stream_t stream) {
   AggArgs a;
   int st = tile_layer_args(layer, a);
   if (st != EGC_OK) return st;
-  if (n_nodes < 0 || n_tiles < 0 || n_nodes >= ((int64_t)1 << 31) - 1) return EGC_ERR_INVALID;
-  if (n_nodes == 0 || n_tiles == 0) return EGC_OK;
-  if (tiles == nullptr || bases == nullptr || weightings == nullptr || out == nullptr || status == nullptr) return EGC_ERR_INVALID;
+  if (n_nodes < 0 || n_tiles_bound < 0 || n_nodes >= ((int64_t)1 << 31) - 1) return EGC_ERR_INVALID;
+  if (n_nodes == 0 || n_tiles_bound == 0) return EGC_OK;
+  if (tiles == nullptr || n_tiles == nullptr || bases == nullptr || weightings == nullptr || out == nullptr || status == nullptr)
+    return EGC_ERR_INVALID;
   if (ldb != a.ldb || (reinterpret_cast<uintptr_t>(bases) & 15) != 0) return EGC_ERR_INVALID;
   if (post != nullptr && ((post->scale == nullptr) != (post->shift == nullptr))) return EGC_ERR_INVALID;
   if (!a.loops_all && max_index == nullptr) return EGC_ERR_INVALID;
@@ -910,8 +912,8 @@ int egc_aggregate_combine_batch_f32(const int32_t* tiles, int32_t n_tiles, int32
   a.residual = post != nullptr ? post->residual : nullptr;
   a.post_relu = post != nullptr && post->relu != 0;
   a.self_pos = 0;
-  return launch_tile_simple(a, reinterpret_cast<const int4*>(tiles), n_tiles, tile_nodes, tile_edges, src, dst, max_index,
-                            status, host_flag, (hipStream_t)stream);
+  return launch_tile_simple(a, reinterpret_cast<const int4*>(tiles), n_tiles, n_tiles_bound, lds_nodes, max_tile_nodes,
+                            max_tile_edges, src, dst, max_index, status, host_flag, (hipStream_t)stream);
 }
 
 int32_t egc_layer_gemm_flags(const egc_layer* layer) {

@@ -193,11 +193,11 @@ int fusedw_pack(const float* wcat, const float* bcat, int f_in, int ldw_cat, int
 int launch_fusedw(AggArgs a, const PlanCaps& caps, hipStream_t stream);
 
 // egc_aggregate_tile.hip: batches of small graphs, tiles of whole graphs with the CSR built in LDS
-struct TileArgs;
-int tile_capacity(const AggArgs& a, int edges_per_node);
+int tile_capacity(const AggArgs& a, int tmax, int emax);
 int launch_tile_plan(const int64_t* ptr, int64_t n_graphs, const int64_t* dst, int64_t n_edges, int64_t n_nodes, int slot,
-                     int n_tiles, int4* tiles, hipStream_t stream);
-int launch_tile_simple(AggArgs a, const int4* tiles, int n_tiles, int tmax, int emax, const int64_t* src, const int64_t* dst,
-                       const int* max_index, int32_t* status, int32_t* host_flag, hipStream_t stream);
+                     int n_slots, int4* tiles, int* count, hipStream_t stream);
+int launch_tile_simple(AggArgs a, const int4* tiles, const int* n_tiles_dev, int n_tiles_bound, int tlds, int tmax, int emax,
+                       const int64_t* src, const int64_t* dst, const int* max_index, int32_t* status, int32_t* host_flag,
+                       hipStream_t stream);
 
 }  // namespace egc

@@ -33,84 +33,72 @@ namespace egc {
 
 constexpr int TILE_THREADS = 512;
 constexpr int TILE_WAVES = TILE_THREADS / 64;
-constexpr int TILE_MAX_NODES = 1024;    // hard cap (u16 ids would allow more; LDS does not)
-constexpr int TILE_EDGE_REGS = 12;      // edges per thread held in registers between the two CSR passes
+constexpr int TILE_MAX_NODES = 2048;    // cap of the per-tile CSR areas (local ids are 16-bit)
+constexpr int TILE_WGS_PER_CU = 2;      // what the LDS areas are sized for (tile_capacity)
 
 struct TileArgs {
-  const int4* tiles;       // (n0, n1, e0, e1) per tile
+  const int4* tiles;       // (n0, n1, e0, e1) per non-empty tile, compacted (any order)
+  const int* n_tiles;      // device scalar: how many
   const int64_t* src;      // edge_index[0]
   const int64_t* dst;      // edge_index[1]
   const int* max_index;    // device scalar (layers with loops_all == 0), or nullptr
   int32_t* status;
   int32_t* host_flag;
-  int tmax, emax;          // capacity of the LDS areas: nodes / edges per tile
+  int tlds;                // nodes whose basis rows fit the LDS area: larger tiles gather from memory instead
+  int tmax, emax;          // capacity of the per-tile CSR areas: nodes / edges
   // byte offsets of the tile areas inside dynamic LDS (behind the per-wavefront epilogue strips)
   int off_bases, off_col, off_rowptr, off_cnt, off_ns, off_dis_raw, off_dis_looped;
 };
 
-// first index i in [0, n) with arr[i] >= key (n if none), by one wavefront: 64-ary narrowing, then one probe per lane.
-// On an array that is not sorted the result is still a deterministic function of (arr, key) -- the tiles' edge ranges
-// therefore always partition [0, E), and the tile kernel's per-edge range check reports what the search got wrong.
-__device__ inline int64_t wave_lower_bound(const int64_t* __restrict__ arr, int64_t n, int64_t key, int lane) {
+// first index i in [0, n) with arr[i] >= key (n if none), by HALF a wavefront (lanes [32 h, 32 h + 32) share `key`): 32-ary
+// narrowing, then one probe per lane -- the two halves of a wavefront run two searches side by side.  On an array that
+// is not sorted the result is still a deterministic function of (arr, key): the tiles' edge ranges therefore always
+// partition [0, E), and the tile kernel's per-edge range check reports what the search got wrong.
+__device__ inline int64_t half_wave_lower_bound(const int64_t* __restrict__ arr, int64_t n, int64_t key, int lane) {
+  const int l32 = lane & 31, sh = lane & 32;
   int64_t lo = 0, hi = n;   // answer in [lo, hi]; everything before lo is < key, arr[hi] (if hi < n) is >= key
-  while (hi - lo > 64) {
-    const int64_t step = (hi - lo + 63) / 64;
-    const int64_t i = lo + (int64_t)lane * step;
-    const bool ge = i < hi ? arr[i] >= key : true;
-    const unsigned long long m = __ballot(ge);
-    const int f = __ffsll((long long)m) - 1;            // first probe that is >= key
-    if (f < 0) { lo = lo + 63 * step + 1; if (lo > hi) lo = hi; continue; }   // all 64 probes < key: the answer lies behind the last one
+  while (__ballot(hi - lo > 32) != 0) {            // (the other half may still be narrowing: keep probing in step)
+    const bool live = hi - lo > 32;
+    const int64_t step = live ? (hi - lo + 31) / 32 : 1;
+    const int64_t i = lo + (int64_t)l32 * step;
+    const bool ge = (live && i < hi) ? arr[i] >= key : true;
+    const unsigned m = (unsigned)(__ballot(ge) >> sh);
+    if (!live) continue;
+    const int f = __ffs((int)m) - 1;               // first probe that is >= key
+    if (f < 0) { lo = lo + 31 * step + 1; if (lo > hi) lo = hi; continue; }   // all probes < key: the answer lies behind the last
     const int64_t nhi = lo + (int64_t)f * step;
-    const int64_t nlo = f > 0 ? lo + (int64_t)(f - 1) * step + 1 : lo;
-    lo = nlo;
+    lo = f > 0 ? lo + (int64_t)(f - 1) * step + 1 : lo;
     hi = nhi < hi ? nhi : hi;
   }
-  const int64_t i = lo + lane;
+  const int64_t i = lo + l32;
   const bool ge = i < hi ? arr[i] >= key : true;
-  const unsigned long long m = __ballot(ge);
-  const int f = __ffsll((long long)m) - 1;
+  const unsigned m = (unsigned)(__ballot(ge) >> sh);
+  const int f = __ffs((int)m) - 1;
   return f < 0 ? hi : (lo + f < hi ? lo + f : hi);
 }
 
+// One wavefront per slot k: lanes 0-31 find where the slot's first graph starts (node n0, edge e0), lanes 32-63 the same
+// for slot k + 1 (n1, e1); a non-empty tile [n0, n1) x [e0, e1) takes the next place of the compacted list.
 __global__ void __launch_bounds__(256) tile_plan_kernel(const int64_t* __restrict__ ptr, int64_t n_graphs,
                                                         const int64_t* __restrict__ dst, int64_t n_edges, int64_t n_nodes,
-                                                        int slot, int n_tiles, int4* __restrict__ tiles) {
+                                                        int slot, int n_slots, int4* __restrict__ tiles, int* __restrict__ count) {
   const int lane = threadIdx.x & 63;
   const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (k >= n_tiles) return;
-  // graphs whose first node lies in [k S, (k + 1) S)
-  const int64_t g0 = wave_lower_bound(ptr, n_graphs + 1, (int64_t)k * slot, lane);
-  const int64_t g1 = wave_lower_bound(ptr, n_graphs + 1, (int64_t)(k + 1) * slot, lane);
-  int64_t n0 = g0 <= n_graphs ? ptr[g0] : n_nodes;
-  int64_t n1 = g1 <= n_graphs ? ptr[g1] : n_nodes;
-  if (k == n_tiles - 1) n1 = n_nodes;         // (ptr[G] == N for a well-formed batch; nodes behind it stay with the last tile)
-  if (k == 0) n0 = 0;
-  n0 = n0 < 0 ? 0 : (n0 > n_nodes ? n_nodes : n0);
-  n1 = n1 < n0 ? n0 : (n1 > n_nodes ? n_nodes : n1);
-  const int64_t e0 = n0 <= 0 ? 0 : wave_lower_bound(dst, n_edges, n0, lane);
-  const int64_t e1 = n1 >= n_nodes ? n_edges : wave_lower_bound(dst, n_edges, n1, lane);
-  if (lane == 0) tiles[k] = int4{(int)n0, (int)n1, (int)e0, (int)(e1 < e0 ? e0 : e1)};
-}
-
-// entry u of a batch: source row j from the staged lane, its slot from LDS
-template <int NEED, class C>
-__device__ inline void gather_batch_lds(const AggArgs& a, FAcc<NEED>& acc, const f4* __restrict__ lds_bases4, int ldb4, int q,
-                                        int addr0, int row, int jj, float dd, float dis_i, int n_valid, int first, int pos_base) {
-  f4 v[FU];
-  float w[FU];
-  bool in_x[FU];
-#pragma unroll
-  for (int u = 0; u < FU; ++u) {
-    const int addr = addr0 + u * 4;
-    const int j = bperm(addr, jj);
-    const bool is_self = j == row;
-    in_x[u] = (first + u < n_valid) && !(C::xl(a) && is_self);
-    v[u] = in_x[u] ? lds_bases4[j * ldb4 + q] : f4{0.f, 0.f, 0.f, 0.f};
-    w[u] = bperm(addr, dd) * dis_i;
-    if (C::yl(a) && !C::xl(a)) w[u] = is_self ? 0.f : w[u];
-  }
-#pragma unroll
-  for (int u = 0; u < FU; ++u) fold<NEED>(acc, v[u], w[u], in_x[u], pos_base + first + u);
+  if (k >= n_slots) return;
+  const int kb = k + (lane >> 5);                  // the boundary this half works on
+  const int64_t g = half_wave_lower_bound(ptr, n_graphs + 1, (int64_t)kb * slot, lane);
+  int64_t nd = g <= n_graphs ? ptr[g] : n_nodes;
+  nd = nd < 0 ? 0 : (nd > n_nodes ? n_nodes : nd);
+  if (kb == 0) nd = 0;
+  if (kb >= n_slots) nd = n_nodes;                 // (ptr[G] == N for a well-formed batch; stragglers stay with the last tile)
+  int64_t ed = half_wave_lower_bound(dst, n_edges, nd, lane);
+  if (nd <= 0) ed = 0;
+  if (nd >= n_nodes) ed = n_edges;
+  const int n0 = (int)__shfl(nd, 0), e0 = (int)__shfl(ed, 0);
+  int n1 = (int)__shfl(nd, 32), e1 = (int)__shfl(ed, 32);
+  n1 = n1 < n0 ? n0 : n1;
+  e1 = e1 < e0 ? e0 : e1;
+  if (lane == 0 && (n1 > n0 || e1 > e0)) tiles[atomicAdd(count, 1)] = int4{n0, n1, e0, e1};
 }
 
 template <int LPR_LOG2, class C>
@@ -136,6 +124,7 @@ __device__ inline void tile_error(const TileArgs& t, int code) {
   if (t.host_flag != nullptr) *(volatile int32_t*)t.host_flag = 1;
 }
 
+// Persistent: the workgroups (TILE_WGS_PER_CU per CU, sized by their LDS) take tiles k = blockIdx.x, + gridDim.x, ...
 template <int LPR_LOG2, int HPB, int NEED, class C>
 __global__ void __launch_bounds__(TILE_THREADS) agg_tile_kernel(AggArgs a, TileArgs t) {
   constexpr int LPR = 1 << LPR_LOG2, G = 64 / LPR;
@@ -146,17 +135,10 @@ __global__ void __launch_bounds__(TILE_THREADS) agg_tile_kernel(AggArgs a, TileA
   const int g = lane >> LPR_LOG2;
   const int q = lane & (LPR - 1);
   const int F_out = C::F_out(a);
-
-  const int4 tl = t.tiles[blockIdx.x];
-  const int n0 = tl.x, T = tl.y - tl.x, e0 = tl.z, Et = tl.w - tl.z;
-  if (T <= 0) {
-    if (Et > 0 && tid == 0) tile_error(t, 1);   // edges without rows: not a graph-grouped list
-    return;
-  }
-  if (T > t.tmax || Et > t.emax) {               // does not fit the LDS areas: report, leave the rows unwritten
-    if (tid == 0) tile_error(t, 2);
-    return;
-  }
+  const int n_tiles = *t.n_tiles;
+  int k = blockIdx.x;
+  if (k >= n_tiles) return;
+  int4 tl = t.tiles[k];
 
   // ---- per-wavefront epilogue strips: [bias (x scale + shift)][scale][G weight strips], as agg_fast_kernel ----
   float* lds_bias = smem + wave * a.lds_floats_per_wave;
@@ -184,75 +166,8 @@ __global__ void __launch_bounds__(TILE_THREADS) agg_tile_kernel(AggArgs a, TileA
   float* lds_dis_raw = reinterpret_cast<float*>(base + t.off_dis_raw);
   float* lds_dis_looped = reinterpret_cast<float*>(base + t.off_dis_looped);
   const int ldb4 = a.ldb >> 2;
-
-  // ---- (A) requests: the tile's edges (critical path of the CSR), then its basis rows (one flat copy) ----
-  int es[TILE_EDGE_REGS], ed[TILE_EDGE_REGS];
-  bool bad = false;
-#pragma unroll
-  for (int k = 0; k < TILE_EDGE_REGS; ++k) {
-    const int i = tid + k * TILE_THREADS;
-    es[k] = ed[k] = -1;
-    if (i < Et) {
-      const int64_t s = t.src[(int64_t)e0 + i] - n0, d = t.dst[(int64_t)e0 + i] - n0;
-      if (s < 0 || s >= T || d < 0 || d >= T) bad = true;
-      else { es[k] = (int)s; ed[k] = (int)d; }
-    }
-  }
-  for (int i = tid; i < T; i += TILE_THREADS) { lds_cnt[i] = 0; lds_ns[i] = 0; }
-  const int n4 = T * ldb4;
-  const f4* gb4 = reinterpret_cast<const f4*>(a.bases) + (int64_t)n0 * ldb4;
-#pragma unroll 4
-  for (int i = tid; i < n4; i += TILE_THREADS) lds_bases4[i] = gb4[i];
-  if (__ballot(bad) != 0 && lane == 0) tile_error(t, 1);
-  __syncthreads();
-
-  // ---- (B) in-degrees ----
-#pragma unroll
-  for (int k = 0; k < TILE_EDGE_REGS; ++k)
-    if (ed[k] >= 0) {
-      atomicAdd(&lds_cnt[ed[k]], 1);
-      if (es[k] != ed[k]) atomicAdd(&lds_ns[ed[k]], 1);
-    }
-  __syncthreads();
-
-  // ---- (C) exclusive scan -> rowptr, deg^-1/2 tables (wavefront 0; T <= 1024: up to 16 entries per lane) ----
-  if (wave == 0) {
-    const int per = (T + 63) >> 6;
-    const int b0 = lane * per;
-    int mine = 0;
-    for (int k = 0; k < per; ++k) mine += (b0 + k < T) ? lds_cnt[b0 + k] : 0;
-    int incl = mine;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const int v = __shfl_up(incl, off);
-      if (lane >= off) incl += v;
-    }
-    int run = incl - mine;
-    for (int k = 0; k < per; ++k) {
-      const int i = b0 + k;
-      if (i < T) {
-        const int c = lds_cnt[i];
-        lds_rowptr[i] = run;
-        lds_dis_raw[i] = c > 0 ? 1.0f / sqrtf((float)c) : 0.0f;          // as prepare_kernel / build_scan_kernel
-        lds_dis_looped[i] = 1.0f / sqrtf((float)(lds_ns[i] + 1));
-        lds_cnt[i] = 0;                                                   // becomes the cursor
-        run += c;
-      }
-    }
-    if (lane == 63) lds_rowptr[T] = incl;
-  }
-  __syncthreads();
-
-  // ---- (D) scatter ----
-#pragma unroll
-  for (int k = 0; k < TILE_EDGE_REGS; ++k)
-    if (ed[k] >= 0) {
-      const int pos = lds_rowptr[ed[k]] + atomicAdd(&lds_cnt[ed[k]], 1);
-      lds_col[pos] = (unsigned short)es[k];
-    }
-  __syncthreads();
-
-  // ---- (E) rows: one lane group per row, G rows per wavefront and pass; weightings of the next pass in flight ----
+  const unsigned row_bytes = (unsigned)a.ldb * 4u;
+  const unsigned slot_off = (unsigned)q * 16u;
   FastRsrc R;
   R.bases = bases_rsrc(a);
   R.out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (unsigned)a.n_nodes * (unsigned)F_out * 4u, 0x00020000);
@@ -264,48 +179,140 @@ __global__ void __launch_bounds__(TILE_THREADS) agg_tile_kernel(AggArgs a, TileA
   const int max_index = (!C::loops_all(a) && t.max_index != nullptr) ? *t.max_index : 0x7fffffff;
   constexpr int RPP = TILE_WAVES * G;           // rows per pass
   const int grp_addr = (g << LPR_LOG2) << 2;
-  f4 wnext[2];
-  {
-    const int r = wave * G + g;
-    load_weightings_row<LPR_LOG2, C>(a, q, n0 + r, r < T, wnext);
-  }
-  for (int r0 = 0; r0 < T; r0 += RPP) {
-    const int r = r0 + wave * G + g;             // local row of this lane group
-    const bool row_ok = r < T;
-    const int row = n0 + (row_ok ? r : 0);
-    f4 wpre[2] = {wnext[0], wnext[1]};
-    if (r0 + RPP < T) load_weightings_row<LPR_LOG2, C>(a, q, n0 + r + RPP, r + RPP < T, wnext);
-    const int start = row_ok ? lds_rowptr[r] : 0;
-    const int nd = row_ok ? lds_rowptr[r + 1] - start : 0;
-    int maxd = nd;
-#pragma unroll
-    for (int off = LPR; off < 64; off <<= 1) maxd = max(maxd, bperm((lane ^ off) << 2, maxd));
-    maxd = __builtin_amdgcn_readfirstlane(maxd);
-    const float dis_i = (want_dis && row_ok) ? lds_dis[r] : 0.f;
-    const bool has_self = row_ok && (C::loops_all(a) || row <= max_index);
-    const bool want_self = looped_any && has_self;
-    const f4 vself = (want_self && q < C::slots(a)) ? lds_bases4[r * ldb4 + q] : f4{0.f, 0.f, 0.f, 0.f};
 
-    FAcc<NEED> acc;
-    acc.init();
-    int nself = 0;
-    for (int ts = 0; ts < maxd; ts += LPR) {
-      const bool pv = ts + q < nd;
-      const int jj = pv ? (int)lds_col[start + ts + q] : 0;
-      const float dd = (pv && want_dis) ? lds_dis[jj] : 0.f;
-      if (looped_any) {
-        const unsigned long long sb = __ballot(pv && jj == r);
-        nself += __popcll((sb >> (g << LPR_LOG2)) & ((LPR == 64) ? ~0ull : ((1ull << LPR) - 1ull)));
-      }
-      const int cnt = min(LPR, maxd - ts);
-      for (int t0 = 0; t0 < cnt; t0 += FU)
-        gather_batch_lds<NEED, C>(a, acc, lds_bases4, ldb4, q, grp_addr + (t0 << 2), r, jj, dd, dis_i,
-                                  q < C::slots(a) ? nd : 0, ts + t0, start);
+  for (; k < n_tiles; k += gridDim.x) {
+    const int n0 = tl.x, T = tl.y - tl.x, e0 = tl.z, Et = tl.w - tl.z;
+    if (k + (int)gridDim.x < n_tiles) tl = t.tiles[k + gridDim.x];   // the next tile's record, long before it is needed
+    if (T <= 0 || T > t.tmax || Et > t.emax) {   // edges without rows / beyond the CSR areas: report, leave the rows unwritten
+      if (tid == 0) tile_error(t, T <= 0 ? 1 : 2);
+      continue;
     }
-    int ln = lane;
-    asm volatile("" : "+v"(ln));
-    finish_group<LPR_LOG2, HPB, NEED, C>(a, R, ln, row, row_ok, acc, nd, nself, dis_i, vself, has_self, wpre, true, lds_w,
-                                         lds_bias, lds_scale);
+    const bool in_lds = T <= t.tlds;             // the tile's basis rows fit LDS (else: gathered from memory)
+
+    // ---- (A) requests: first rows' weightings, the tile's basis rows by LDS-DMA (one flat copy), counters zeroed ----
+    f4 wnext[2];
+    {
+      const int r = wave * G + g;
+      load_weightings_row<LPR_LOG2, C>(a, q, n0 + r, r < T, wnext);
+    }
+    if (in_lds) {
+      const int n4 = T * ldb4;
+      const f4* gb4 = reinterpret_cast<const f4*>(a.bases) + (int64_t)n0 * ldb4;
+      for (int i = tid; i < n4; i += TILE_THREADS)    // LDS destination = wave-uniform base + lane * 16: a flat copy qualifies
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb4 + i),
+                                         (__attribute__((address_space(3))) void*)(lds_bases4 + i), 16, 0, 0);
+    }
+    for (int i = tid; i < T; i += TILE_THREADS) { lds_cnt[i] = 0; lds_ns[i] = 0; }
+    __syncthreads();
+
+    // ---- (B) in-degrees; every edge checked against the tile ----
+    bool bad = false;
+#pragma unroll 4
+    for (int i = tid; i < Et; i += TILE_THREADS) {
+      const int64_t s = t.src[(int64_t)e0 + i] - n0, d = t.dst[(int64_t)e0 + i] - n0;
+      if (s < 0 || s >= T || d < 0 || d >= T) { bad = true; continue; }
+      atomicAdd(&lds_cnt[(int)d], 1);
+      if (s != d) atomicAdd(&lds_ns[(int)d], 1);
+    }
+    if (__ballot(bad) != 0 && lane == 0) tile_error(t, 1);
+    __syncthreads();
+
+    // ---- (C) exclusive scan -> rowptr, deg^-1/2 tables (wavefront 0) ----
+    if (wave == 0) {
+      const int per = (T + 63) >> 6;
+      const int b0 = lane * per;
+      int mine = 0;
+      for (int j = 0; j < per; ++j) mine += (b0 + j < T) ? lds_cnt[b0 + j] : 0;
+      int incl = mine;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
+      }
+      int run = incl - mine;
+      for (int j = 0; j < per; ++j) {
+        const int i = b0 + j;
+        if (i < T) {
+          const int c = lds_cnt[i];
+          lds_rowptr[i] = run;
+          lds_dis_raw[i] = c > 0 ? 1.0f / sqrtf((float)c) : 0.0f;          // as prepare_kernel / build_scan_kernel
+          lds_dis_looped[i] = 1.0f / sqrtf((float)(lds_ns[i] + 1));
+          lds_cnt[i] = 0;                                                   // becomes the cursor
+          run += c;
+        }
+      }
+      if (lane == 63) lds_rowptr[T] = incl;
+    }
+    __syncthreads();
+
+    // ---- (D) scatter (the edges again: L2-resident by now) ----
+#pragma unroll 4
+    for (int i = tid; i < Et; i += TILE_THREADS) {
+      const int64_t s = t.src[(int64_t)e0 + i] - n0, d = t.dst[(int64_t)e0 + i] - n0;
+      if (s < 0 || s >= T || d < 0 || d >= T) continue;
+      const int pos = lds_rowptr[(int)d] + atomicAdd(&lds_cnt[(int)d], 1);
+      lds_col[pos] = (unsigned short)s;
+    }
+    __syncthreads();
+
+    // ---- (E) rows: one lane group per row, G rows per wavefront and pass; weightings of the next pass in flight ----
+    for (int r0 = 0; r0 < T; r0 += RPP) {
+      const int r = r0 + wave * G + g;             // local row of this lane group
+      const bool row_ok = r < T;
+      const int row = n0 + (row_ok ? r : 0);
+      f4 wpre[2] = {wnext[0], wnext[1]};
+      if (r0 + RPP < T) load_weightings_row<LPR_LOG2, C>(a, q, n0 + r + RPP, r + RPP < T, wnext);
+      const int start = row_ok ? lds_rowptr[r] : 0;
+      const int nd = row_ok ? lds_rowptr[r + 1] - start : 0;
+      int maxd = nd;
+#pragma unroll
+      for (int off = LPR; off < 64; off <<= 1) maxd = max(maxd, bperm((lane ^ off) << 2, maxd));
+      maxd = __builtin_amdgcn_readfirstlane(maxd);
+      const float dis_i = (want_dis && row_ok) ? lds_dis[r] : 0.f;
+      const bool has_self = row_ok && (C::loops_all(a) || row <= max_index);
+      const bool want_self = looped_any && has_self && q < C::slots(a);
+      f4 vself = f4{0.f, 0.f, 0.f, 0.f};
+      if (in_lds) { if (want_self) vself = lds_bases4[r * ldb4 + q]; }
+      else vself = load_slot(R.bases, want_self ? (unsigned)row * row_bytes + slot_off : OOB);
+
+      FAcc<NEED> acc;
+      acc.init();
+      int nself = 0;
+      const int n_valid = q < C::slots(a) ? nd : 0;
+      for (int ts = 0; ts < maxd; ts += LPR) {
+        const bool pv = ts + q < nd;
+        const int jj = pv ? (int)lds_col[start + ts + q] : 0;
+        const float dd = (pv && want_dis) ? lds_dis[jj] : 0.f;
+        if (looped_any) {
+          const unsigned long long sb = __ballot(pv && jj == r);
+          nself += __popcll((sb >> (g << LPR_LOG2)) & ((LPR == 64) ? ~0ull : ((1ull << LPR) - 1ull)));
+        }
+        const int cnt = min(LPR, maxd - ts);
+        for (int t0 = 0; t0 < cnt; t0 += FU) {
+          f4 v[FU];
+          float w[FU];
+          bool in_x[FU];
+#pragma unroll
+          for (int u = 0; u < FU; ++u) {
+            const int addr = grp_addr + ((t0 + u) << 2);
+            const int j = bperm(addr, jj);
+            const bool is_self = j == r;
+            in_x[u] = (ts + t0 + u < n_valid) && !(C::xl(a) && is_self);
+            if (in_lds) v[u] = in_x[u] ? lds_bases4[j * ldb4 + q] : f4{0.f, 0.f, 0.f, 0.f};
+            else v[u] = load_slot(R.bases, in_x[u] ? (unsigned)(n0 + j) * row_bytes + slot_off : OOB);
+            w[u] = bperm(addr, dd) * dis_i;
+            if (C::yl(a) && !C::xl(a)) w[u] = is_self ? 0.f : w[u];
+          }
+#pragma unroll
+          for (int u = 0; u < FU; ++u) fold<NEED>(acc, v[u], w[u], in_x[u], start + ts + t0 + u);
+        }
+      }
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      finish_group<LPR_LOG2, HPB, NEED, C>(a, R, ln, row, row_ok, acc, nd, nself, dis_i, vself, has_self, wpre, true, lds_w,
+                                           lds_bias, lds_scale);
+    }
+    __syncthreads();   // every wavefront is done with the tile's LDS areas
   }
 }
 
@@ -317,12 +324,12 @@ struct TileLds {
   int off_bases, off_col, off_rowptr, off_cnt, off_ns, off_dis_raw, off_dis_looped;
 };
 
-static TileLds tile_lds(const AggArgs& a, int tmax, int emax) {
+static TileLds tile_lds(const AggArgs& a, int tlds, int tmax, int emax) {
   TileLds L;
   auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
   size_t at = up16((size_t)TILE_WAVES * a.lds_floats_per_wave * sizeof(float));
   L.strips = at;
-  L.off_bases = (int)at; at += up16((size_t)tmax * a.ldb * 4);
+  L.off_bases = (int)at; at += up16((size_t)tlds * a.ldb * 4);
   L.off_col = (int)at; at += up16((size_t)emax * 2);
   L.off_rowptr = (int)at; at += up16((size_t)(tmax + 1) * 4);
   L.off_cnt = (int)at; at += up16((size_t)tmax * 4);
@@ -333,7 +340,7 @@ static TileLds tile_lds(const AggArgs& a, int tmax, int emax) {
   return L;
 }
 
-constexpr size_t TILE_LDS_BUDGET = 160 * 1024;
+constexpr size_t TILE_LDS_BUDGET = (160 * 1024) / TILE_WGS_PER_CU - 512;   // per workgroup (two per CU)
 
 template <int LPR_LOG2, int HPB, int NEED, class C>
 static int launch_tile_one(const AggArgs& a, const TileArgs& t, unsigned grid, size_t lds, hipStream_t stream) {
@@ -375,13 +382,12 @@ static bool try_tile_static(const AggArgs& a, const TileArgs& t, int h, int b, i
   return true;
 }
 
-// largest node count whose LDS areas fit (edges: emax = edges_per_node x nodes)
-int tile_capacity(const AggArgs& a_in, int edges_per_node) {
+// nodes whose basis rows fit the LDS area of one workgroup, next to CSR areas for (tmax nodes, emax edges)
+int tile_capacity(const AggArgs& a_in, int tmax, int emax) {
   AggArgs a = a_in;
   int best = 0;
-  for (int tmax = 32; tmax <= TILE_MAX_NODES; tmax += 32) {
-    const int emax = std::min(tmax * edges_per_node, TILE_THREADS * TILE_EDGE_REGS);
-    if (tile_lds(a, tmax, emax).total <= TILE_LDS_BUDGET) best = tmax; else break;
+  for (int tlds = 16; tlds <= tmax; tlds += 16) {
+    if (tile_lds(a, tlds, tmax, emax).total <= TILE_LDS_BUDGET) best = tlds; else break;
   }
   return best;
 }
@@ -408,11 +414,11 @@ int launch_tile(AggArgs a, TileArgs t, int n_tiles, hipStream_t stream) {
   a.w_lds_stride = (a.W + 3) & ~3;
   a.bias_lds_floats = (a.H * a.Ls + 3) & ~3;
   a.lds_floats_per_wave = (a.post_scale != nullptr ? 2 : 1) * a.bias_lds_floats + G * a.w_lds_stride;
-  const TileLds L = tile_lds(a, t.tmax, t.emax);
-  if (L.total > TILE_LDS_BUDGET || t.tmax > TILE_MAX_NODES || t.emax > TILE_THREADS * TILE_EDGE_REGS) return EGC_ERR_UNSUPPORTED;
+  const TileLds L = tile_lds(a, t.tlds, t.tmax, t.emax);
+  if (L.total > TILE_LDS_BUDGET || t.tmax > TILE_MAX_NODES || t.tlds > t.tmax || t.tlds < 1) return EGC_ERR_UNSUPPORTED;
   t.off_bases = L.off_bases; t.off_col = L.off_col; t.off_rowptr = L.off_rowptr; t.off_cnt = L.off_cnt; t.off_ns = L.off_ns;
   t.off_dis_raw = L.off_dis_raw; t.off_dis_looped = L.off_dis_looped;
-  const unsigned grid = (unsigned)n_tiles;
+  const unsigned grid = (unsigned)std::min(n_tiles, 256 * TILE_WGS_PER_CU);   // persistent: n_tiles = upper bound of the tile count
   if (getenv("EGC_NO_STATIC_CFG") == nullptr) {
     int status = EGC_OK;
     constexpr int S = EGC_AGGR_SUM, M = EGC_AGGR_MEAN, X = EGC_AGGR_MAX, Y = EGC_AGGR_SYMNORM;
@@ -432,17 +438,20 @@ int launch_tile(AggArgs a, TileArgs t, int n_tiles, hipStream_t stream) {
   }
 }
 
-int launch_tile_simple(AggArgs a, const int4* tiles, int n_tiles, int tmax, int emax, const int64_t* src, const int64_t* dst,
-                       const int* max_index, int32_t* status, int32_t* host_flag, hipStream_t stream) {
+int launch_tile_simple(AggArgs a, const int4* tiles, const int* n_tiles_dev, int n_tiles_bound, int tlds, int tmax, int emax,
+                       const int64_t* src, const int64_t* dst, const int* max_index, int32_t* status, int32_t* host_flag,
+                       hipStream_t stream) {
   TileArgs t = {};
-  t.tiles = tiles; t.src = src; t.dst = dst; t.max_index = max_index; t.status = status; t.host_flag = host_flag;
-  t.tmax = tmax; t.emax = emax;
-  return launch_tile(a, t, n_tiles, stream);
+  t.tiles = tiles; t.n_tiles = n_tiles_dev; t.src = src; t.dst = dst; t.max_index = max_index; t.status = status;
+  t.host_flag = host_flag;
+  t.tlds = tlds; t.tmax = tmax; t.emax = emax;
+  return launch_tile(a, t, n_tiles_bound, stream);
 }
 
 int launch_tile_plan(const int64_t* ptr, int64_t n_graphs, const int64_t* dst, int64_t n_edges, int64_t n_nodes, int slot,
-                     int n_tiles, int4* tiles, hipStream_t stream) {
-  tile_plan_kernel<<<(unsigned)((n_tiles + 3) / 4), 256, 0, stream>>>(ptr, n_graphs, dst, n_edges, n_nodes, slot, n_tiles, tiles);
+                     int n_slots, int4* tiles, int* count, hipStream_t stream) {
+  EGC_HIP_TRY(hipMemsetAsync(count, 0, sizeof(int), stream));
+  tile_plan_kernel<<<(unsigned)((n_slots + 3) / 4), 256, 0, stream>>>(ptr, n_graphs, dst, n_edges, n_nodes, slot, n_slots, tiles, count);
   EGC_LAUNCH_CHECK("tile_plan_kernel");
   return EGC_OK;
 }

@@ -297,18 +297,10 @@ def egc_aggregate_combine(graph: CSRGraph, spec: LayerSpec, bases: torch.Tensor,
 
 
 def _batch_tile_setup(gb: GraphBatch, spec: LayerSpec, post):
-    """(tiles, n_tiles, tile_nodes, tile_edges) when the tile kernels serve this layer on this batch, else None."""
+    """What the tile kernels need for this layer on this batch (GraphBatch.tile_setup), or None."""
     if os.environ.get("EGC_NO_TILE", "0") not in ("", "0"):
         return None
-    lib = _C.load()
-    cap = int(lib.egc_batch_tile_nodes(C.byref(spec.c), gb.edges_per_node, 1 if (post is not None and post.scale is not None) else 0))
-    if cap <= 0:
-        return None
-    plan = gb.plan(cap)
-    if plan is None:
-        return None
-    tiles, n_tiles, _ = plan
-    return tiles, n_tiles, cap, min(cap * gb.edges_per_node, 512 * 12)
+    return gb.tile_setup(spec.c, post is not None and post.scale is not None)
 
 
 def egc_aggregate_combine_batch(gb: GraphBatch, spec: LayerSpec, bases, weightings, bias, post, tiled):
@@ -317,7 +309,7 @@ def egc_aggregate_combine_batch(gb: GraphBatch, spec: LayerSpec, bases, weightin
     lib = _C.load()
     _IndexFlag.poll()
     n = gb.n_nodes
-    tiles, n_tiles, tile_nodes, tile_edges = tiled
+    tiles, n_tiles_dev, n_slots, lds_nodes, tmax, emax = tiled
     _check_f32(bases, "bases", (n, spec.ldb))
     _check_f32(weightings, "weightings", (n, spec.w_cols))
     dev = bases.device
@@ -342,7 +334,7 @@ def egc_aggregate_combine_batch(gb: GraphBatch, spec: LayerSpec, bases, weightin
         ei = gb.edge_index
         needs_max = not bool(spec.c.loops_all_nodes)
         _C.check(lib.egc_aggregate_combine_batch_f32(
-            tiles.data_ptr(), n_tiles, tile_nodes, tile_edges, ei[0].data_ptr(), ei[1].data_ptr(), n,
+            tiles.data_ptr(), n_tiles_dev.data_ptr(), n_slots, lds_nodes, tmax, emax, ei[0].data_ptr(), ei[1].data_ptr(), n,
             gb.max_index().data_ptr() if needs_max else None, C.byref(spec.c), bases.data_ptr(), spec.ldb,
             weightings.data_ptr(), ldw, bias.contiguous().data_ptr() if bias is not None else None,
             C.byref(p) if p is not None else None, out.data_ptr(), gb.status().data_ptr(), _IndexFlag.ptr(),

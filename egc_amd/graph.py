@@ -422,12 +422,13 @@ class GraphBatch:
     Requirements (checked on the device, reported like an out-of-range index -- a RuntimeError at the next call into the
     package at the latest): graphs are numbered one after the other and the edges of one graph are contiguous in
     ``edge_index`` (PyG's collation); a tile (a run of graphs of about ``slot`` nodes + one graph) fits the LDS areas.
-    ``max_nodes``: an upper bound of the largest graph's node count (default 128) -- it sets the slot so that no tile
-    overflows.  Layers outside the tile kernels' envelope, and every call that needs gradients, use the CSR of the same
+    ``max_nodes``: an upper bound of the largest graph's node count (default 256) -- it sizes the per-tile CSR areas;
+    tiles whose basis rows exceed the LDS area (a run of unusually large graphs) gather from memory instead, tiles beyond
+    slot + max_nodes nodes or edges_per_node x that many edges are reported.  Layers outside the tile kernels' envelope, and every call that needs gradients, use the CSR of the same
     edge list instead (built on first need, ``csr()``): results are the same, the speed is the ordinary path's."""
 
     def __init__(self, edge_index: torch.Tensor, ptr: torch.Tensor | None = None, batch: torch.Tensor | None = None,
-                 num_graphs: int | None = None, num_nodes: int | None = None, max_nodes: int = 128, edges_per_node: int = 16):
+                 num_graphs: int | None = None, num_nodes: int | None = None, max_nodes: int = 256, edges_per_node: int = 16):
         _require_cuda(edge_index, "edge_index")
         if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.size(0) != 2:
             raise RuntimeError("egc_amd: edge_index must be an int64 tensor of shape [2, E]")
@@ -448,6 +449,7 @@ class GraphBatch:
         self.n_edges = int(edge_index.size(1))
         self.halo = None
         self._plans = {}
+        self._setups = {}
         self._csr = None
         self._status = None
         self._max_index = None
@@ -488,22 +490,52 @@ class GraphBatch:
                                "node ids outside its graph: index out of range"))
         return self
 
-    def plan(self, tile_nodes: int):
-        """(tiles int32 [n_tiles, 4], n_tiles, slot) for tiles of at most `tile_nodes` nodes; built once per capacity."""
-        hit = self._plans.get(tile_nodes)
+    def tile_setup(self, spec_c, with_post: bool):
+        """Everything egc_aggregate_combine_batch_f32 needs for a layer on this batch, or None when the layer is outside the
+        tile kernels' envelope: (tiles, n_tiles (device), n_slots, lds_nodes, max_tile_nodes, max_tile_edges)."""
+        key = (C.string_at(C.addressof(spec_c), C.sizeof(spec_c)), bool(with_post))
+        hit = self._setups.get(key)
         if hit is None:
             lib = _C.load()
-            slot = tile_nodes - self.max_nodes + 1
-            if slot < 8:
-                return None
+            n, gcount = self.n_nodes, max(self.n_graphs, 1)
+            typical = min(self.max_nodes, max(2 * -(-n // gcount), 8))
+            epn = self.edges_per_node
+
+            def areas(slot):
+                tmax = min(2048, slot + self.max_nodes - 1)
+                return tmax, min(tmax * epn, 16384)
+            tmax, emax = areas(64)
+            lds = int(lib.egc_batch_tile_nodes(C.byref(spec_c), tmax, emax, int(with_post)))
+            if lds <= 0:
+                hit = False
+            else:
+                # a slot + one typical graph fills the LDS area; enough slots to occupy the chip twice over when the batch allows
+                slot = max(8, min(lds - typical + 1, -(-n // 1024)) if n >= 8 * 1024 else lds - typical + 1)
+                tmax, emax = areas(slot)
+                lds = int(lib.egc_batch_tile_nodes(C.byref(spec_c), tmax, emax, int(with_post)))
+                hit = (slot, lds, tmax, emax) if lds > 0 else False
+            self._setups[key] = hit
+        if hit is False:
+            return None
+        slot, lds, tmax, emax = hit
+        tiles, count, n_slots = self.plan(slot)
+        return tiles, count, n_slots, lds, tmax, emax
+
+    def plan(self, slot: int):
+        """(tiles int32 [n_slots, 4], n_tiles device scalar, n_slots) for slots of `slot` nodes; one launch, built once."""
+        hit = self._plans.get(slot)
+        if hit is None:
+            lib = _C.load()
             n = self.n_nodes
-            n_tiles = (n + slot - 1) // slot
+            n_slots = (n + slot - 1) // slot
             with _device_guard(self.device):
-                tiles = torch.empty((max(n_tiles, 1), 4), dtype=torch.int32, device=self.device)
+                buf = torch.empty(4 * max(n_slots, 1) + 4, dtype=torch.int32, device=self.device)
+                tiles, count = buf[:4 * max(n_slots, 1)].view(-1, 4), buf[4 * max(n_slots, 1):]
                 _C.check(lib.egc_batch_plan(self.ptr.data_ptr(), self.n_graphs, self.edge_index[1].data_ptr(), self.n_edges, n,
-                                            slot, tiles.data_ptr(), n_tiles, _stream_ptr(self.device)), "egc_batch_plan")
-            hit = (tiles, n_tiles, slot)
-            self._plans[tile_nodes] = hit
+                                            slot, tiles.data_ptr(), n_slots, count.data_ptr(), _stream_ptr(self.device)),
+                         "egc_batch_plan")
+            hit = (tiles, count, n_slots)
+            self._plans[slot] = hit
         return hit
 
 

@@ -454,32 +454,34 @@ int egc_aggregate_combine_train_rows_f32(const egc_graph* graph, const egc_layer
  * graph preparation inside it (egc_aggregate_tile.hip).  The reference's batched nets call the layer with a PyG batch
  * (zinc/models.py:60-74, mol/pna_style_models.py:64-79, cifar/models.py:61-75): graphs numbered one after the other
  * (`batch.ptr` = their node offsets), the edges of one graph contiguous in `edge_index` -- a block-diagonal adjacency.
- *   egc_batch_tile_nodes   how many nodes (with edges_per_node x that many edges) one tile may hold for this layer:
- *                          the tile's rows of `bases` (ldb floats each), its CSR and both deg^-1/2 tables live in the
- *                          160 KB of LDS of one workgroup; 0 = the layer does not qualify (envelope of the
- *                          register-resident kernels: <= 64 slots per row, A <= 4, B a power of two, no softmax).
- *   egc_batch_plan         once per batch: cuts [0, n_nodes) into slots of `slot` nodes; tile k = the graphs whose first
- *                          node lies in slot k, as (n0, n1, e0, e1) -- node range and edge range -- in tiles[4 k ..];
- *                          n_tiles = ceil(n_nodes / slot).  A tile then holds < slot + (largest graph) nodes: choose
- *                          slot <= egc_batch_tile_nodes - largest graph + 1.  graph_ptr: int64 [n_graphs + 1].
+ *   egc_batch_tile_nodes   lds_nodes: how many nodes' basis rows (ldb floats each) fit the LDS of one workgroup (two per
+ *                          CU) next to the per-tile CSR areas for (max_tile_nodes, max_tile_edges); 0 = the layer does not
+ *                          qualify (envelope of the register-resident kernels: <= 64 slots per row, A <= 4, B a power
+ *                          of two, no softmax).  A tile of at most lds_nodes nodes gathers its basis rows from LDS, a
+ *                          larger one (up to max_tile_nodes) from memory like the ordinary kernels.
+ *   egc_batch_plan         once per batch, one launch: cuts [0, n_nodes) into n_slots = ceil(n_nodes / slot) slots; the
+ *                          graphs whose first node lies in slot k form one tile (n0, n1, e0, e1) -- node range and edge
+ *                          range; the non-empty tiles are written to tiles[4 i ..] in any order and counted in *n_tiles
+ *                          (device).  A tile holds < slot + (largest graph) nodes.  graph_ptr: int64 [n_graphs + 1].
  *   egc_aggregate_combine_batch_f32
  *                          contract of egc_aggregate_combine_post_f32 (same reference call sites; plus those of
  *                          egc_graph_build: no CSR is built beforehand) for the rows of every tile, straight from the
- *                          COO lists src / dst.  ldw = row stride of weightings (0 = dense).  max_index: device scalar,
- *                          needed only by layers with loops_all_nodes = 0.  Inference form.
+ *                          COO lists src / dst; n_tiles_bound = n_slots (sizes the persistent launch).  ldw = row stride of
+ *                          weightings (0 = dense).  max_index: device scalar, needed only by layers with
+ *                          loops_all_nodes = 0.  Inference form.
  * Every edge is checked against its tile: an edge that leaves the tile (list not grouped by graph, id out of range) or a
- * tile beyond tile_nodes / tile_edges raises *status (bit 0 / bit 1; zero it before the call) and the sticky *host_flag
- * (see egc_coo_to_csr_checked) and leaves the tile's rows unwritten.  A row's entries are summed in the order of the LDS
- * atomics that built the CSR: sums are reproducible to rounding, max / min exactly.
+ * tile beyond max_tile_nodes / max_tile_edges raises *status (bit 0 / bit 1; zero it before the call) and the sticky
+ * *host_flag (see egc_coo_to_csr_checked) and leaves the tile's rows unwritten.  A row's entries are summed in the order of
+ * the LDS atomics that built the CSR: sums are reproducible to rounding, max / min exactly.
  * ------------------------------------------------------------------------------------------ */
-int32_t egc_batch_tile_nodes(const egc_layer* layer, int32_t edges_per_node, int32_t with_post);
+int32_t egc_batch_tile_nodes(const egc_layer* layer, int32_t max_tile_nodes, int32_t max_tile_edges, int32_t with_post);
 int egc_batch_plan(const int64_t* graph_ptr, int64_t n_graphs, const int64_t* dst, int64_t n_edges, int64_t n_nodes,
-                   int32_t slot, int32_t* tiles, int32_t n_tiles, egc_stream_t stream);
-int egc_aggregate_combine_batch_f32(const int32_t* tiles, int32_t n_tiles, int32_t tile_nodes, int32_t tile_edges,
-                                    const int64_t* src, const int64_t* dst, int64_t n_nodes, const int32_t* max_index,
-                                    const egc_layer* layer, const float* bases, int32_t ldb, const float* weightings,
-                                    int32_t ldw, const float* bias, const egc_post* post, float* out, int32_t* status,
-                                    int32_t* host_flag, egc_stream_t stream);
+                   int32_t slot, int32_t* tiles, int32_t n_slots, int32_t* n_tiles, egc_stream_t stream);
+int egc_aggregate_combine_batch_f32(const int32_t* tiles, const int32_t* n_tiles, int32_t n_tiles_bound, int32_t lds_nodes,
+                                    int32_t max_tile_nodes, int32_t max_tile_edges, const int64_t* src, const int64_t* dst,
+                                    int64_t n_nodes, const int32_t* max_index, const egc_layer* layer, const float* bases,
+                                    int32_t ldb, const float* weightings, int32_t ldw, const float* bias, const egc_post* post,
+                                    float* out, int32_t* status, int32_t* host_flag, egc_stream_t stream);
 
 /* Whole layer forward = egc_basis_transform_f32 + egc_aggregate_combine_f32
  * (EfficientGraphConv.forward layers.py:89-140 / EGConv.forward optimized_layers.py:177-210

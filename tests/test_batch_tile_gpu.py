@@ -143,6 +143,36 @@ def test_fused_block_tail_on_the_tile_path():
     assert float((got - ref).abs().max()) / max(1.0, float(ref.abs().max())) <= 1e-5
 
 
+def test_tiles_larger_than_the_lds_area_gather_from_memory():
+    """A batch whose graphs are much larger than its average promises (one 900-node graph among small ones): its tile does
+    not fit the LDS area and takes the memory-gather form of the same kernel -- same results."""
+    import egc_amd
+    dev = _dev()
+    rng = np.random.default_rng(21)
+    sizes = np.array([20] * 150 + [900] + [20] * 150)
+    ptr = np.concatenate([[0], np.cumsum(sizes)])
+    srcs, dsts = [], []
+    for g, n in enumerate(sizes):
+        e = 5 * n
+        srcs.append(rng.integers(0, n, size=e) + ptr[g])
+        dsts.append(rng.integers(0, n, size=e) + ptr[g])
+    ei = torch.from_numpy(np.stack([np.concatenate(srcs), np.concatenate(dsts)]).astype(np.int64))
+    n = int(ptr[-1])
+    aggrs = ["sum", "mean", "max", "symnorm"]
+    torch.manual_seed(8)
+    conv = _layer("opt", 128, 8, 4, aggrs)
+    x = torch.randn(n, 128)
+    ref = _oracle(conv, "opt", x, ei, 8, 4, aggrs)
+    conv = conv.to(dev).eval()
+    gb = egc_amd.GraphBatch(ei.to(dev), ptr=torch.from_numpy(ptr.astype(np.int64)).to(dev), max_nodes=900)
+    with torch.no_grad():
+        out = conv(x.to(dev), gb)
+    gb.check()
+    lds_nodes = next(iter(gb._setups.values()))[1]
+    assert lds_nodes < 900
+    assert rel_err(out.cpu().numpy(), ref) <= TOL
+
+
 def test_training_through_a_graph_batch_uses_the_csr_path():
     import egc_amd
     dev = _dev()
@@ -181,12 +211,12 @@ def test_malformed_batches_are_reported():
         conv(x, gb)
     with pytest.raises(RuntimeError, match="not grouped by graph"):
         gb.check()
-    # (3) a graph larger than max_nodes promises -> a tile beyond the LDS areas
+    # (3) a graph larger than max_nodes promises -> a tile beyond the per-tile CSR areas
     big_ptr = torch.tensor([0, n])
     gb = egc_amd.GraphBatch(ei.to(dev), ptr=big_ptr.to(dev), max_nodes=16)
     with torch.no_grad():
         conv(x, gb)
-    with pytest.raises(RuntimeError, match="exceeds the LDS"):
+    with pytest.raises(RuntimeError, match="exceeds the"):
         gb.check()
     # (4) without an explicit check the error surfaces at the next call into the package
     gb = egc_amd.GraphBatch(bad.to(dev), ptr=ptr.to(dev), max_nodes=90)

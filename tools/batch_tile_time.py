@@ -45,15 +45,18 @@ def main():
             err = float((out - ref).abs().max() / ref.abs().max().clamp(min=1))
             t_build = med(lambda: egc_amd.CSRGraph.from_edge_index(ei, n))
             t_layer = med(lambda: conv(x, g))
-            t_plan = med(lambda: egc_amd.GraphBatch(ei, ptr=ptr, max_nodes=mx, num_nodes=n).plan(next(iter(gb._plans))))
+            slot = next(iter(gb._plans))
+            t_plan = med(lambda: egc_amd.GraphBatch(ei, ptr=ptr, max_nodes=mx, num_nodes=n).plan(slot))
             t_tile = med(lambda: conv(x, gb))
             def both():
                 conv(x, egc_amd.GraphBatch(ei, ptr=ptr, max_nodes=mx, num_nodes=n))
             t_both = med(both)
         tiles = next(iter(gb._plans.values()))
+        setup = next(iter(gb._setups.values()))
         print(f"{name}: N={n} E={ei.size(1)}  ordinary: build {t_build * 1e3:.1f} us + layer {t_layer * 1e3:.1f} us = "
               f"{(t_build + t_layer) * 1e3:.1f} us | tile path: plan {t_plan * 1e3:.1f} us + layer {t_tile * 1e3:.1f} us, "
-              f"plan+layer in one go {t_both * 1e3:.1f} us  ({tiles[1]} tiles, slot {tiles[2]})  rel err vs ordinary {err:.1e}")
+              f"plan+layer in one go {t_both * 1e3:.1f} us  ({int(tiles[1][0])} tiles of {tiles[2]} slots, slot {setup[0]}, "
+              f"lds nodes {setup[1]}, tmax {setup[2]}, emax {setup[3]})  rel err vs ordinary {err:.1e}")
 
 
 if __name__ == "__main__":
