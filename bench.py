@@ -162,9 +162,11 @@ def measure_layer_config(name, ei_cpu, n, conv, f_in, dev, per_batch_csr, iters=
     if batch is not None:
         g_count = int(batch.max()) + 1
         ptr = torch.searchsorted(batch.to(dev), torch.arange(g_count + 1, device=dev))
+        # the graphs' node and edge offsets: what a PyG batch carries from its collation (batch.ptr, the edge_index slices)
+        eptr = torch.searchsorted(batch.to(dev)[ei[1]], torch.arange(g_count + 1, device=dev))
         with torch.no_grad():
             def make():
-                return egc_amd.GraphBatch(ei, ptr=ptr, num_nodes=n, max_nodes=max_nodes or 256)
+                return egc_amd.GraphBatch(ei, ptr=ptr, num_nodes=n, max_nodes=max_nodes or 256, edge_ptr=eptr)
             gb = make()
             ref = conv(x, egc_amd.CSRGraph.from_edge_index(ei, n))
             out = conv(x, gb)

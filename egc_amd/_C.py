@@ -137,8 +137,8 @@ SYMBOLS = {
                                                        C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t,
                                                        C.c_void_p]),
     "egc_batch_tile_nodes": (C.c_int32, [C.POINTER(EgcLayer), C.c_int32, C.c_int32, C.c_int32]),
-    "egc_batch_plan": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_int32,
-                                 C.c_void_p, C.c_void_p]),
+    "egc_batch_plan": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p,
+                                 C.c_int32, C.c_void_p, C.c_void_p]),
     "egc_aggregate_combine_batch_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                                   C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(EgcLayer), C.c_void_p, C.c_int32,
                                                   C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(EgcPost), C.c_void_p, C.c_void_p,

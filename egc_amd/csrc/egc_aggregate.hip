@@ -868,8 +868,8 @@ int32_t egc_batch_tile_nodes(const egc_layer* layer, int32_t max_tile_nodes, int
   return tile_capacity(a, max_tile_nodes, max_tile_edges);
 }
 
-int egc_batch_plan(const int64_t* graph_ptr, int64_t n_graphs, const int64_t* dst, int64_t n_edges, int64_t n_nodes,
-                   int32_t slot, int32_t* tiles, int32_t n_slots, int32_t* n_tiles, egc_stream_t stream) {
+int egc_batch_plan(const int64_t* graph_ptr, const int64_t* edge_ptr, int64_t n_graphs, const int64_t* dst, int64_t n_edges,
+                   int64_t n_nodes, int32_t slot, int32_t* tiles, int32_t n_slots, int32_t* n_tiles, egc_stream_t stream) {
   if (graph_ptr == nullptr || tiles == nullptr || n_tiles == nullptr || n_graphs < 0 || n_edges < 0 || n_nodes < 0 || slot <= 0)
     return EGC_ERR_INVALID;
   if (n_nodes >= ((int64_t)1 << 31) - 1 || n_edges >= ((int64_t)1 << 31) - 1) return EGC_ERR_INVALID;
@@ -877,7 +877,7 @@ int egc_batch_plan(const int64_t* graph_ptr, int64_t n_graphs, const int64_t* ds
   if (n_edges > 0 && dst == nullptr) return EGC_ERR_INVALID;
   if (n_slots == 0) return hipMemsetAsync(n_tiles, 0, sizeof(int32_t), (hipStream_t)stream) == hipSuccess ? EGC_OK : EGC_ERR_HIP;
   return launch_tile_plan(graph_ptr, n_graphs, dst, n_edges, n_nodes, slot, n_slots, reinterpret_cast<int4*>(tiles), n_tiles,
-                          (hipStream_t)stream);
+                          edge_ptr, (hipStream_t)stream);
 }
 
 int egc_aggregate_combine_batch_f32(const int32_t* tiles, const int32_t* n_tiles, int32_t n_tiles_bound, int32_t lds_nodes,

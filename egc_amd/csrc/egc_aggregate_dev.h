@@ -195,7 +195,7 @@ int launch_fusedw(AggArgs a, const PlanCaps& caps, hipStream_t stream);
 // egc_aggregate_tile.hip: batches of small graphs, tiles of whole graphs with the CSR built in LDS
 int tile_capacity(const AggArgs& a, int tmax, int emax);
 int launch_tile_plan(const int64_t* ptr, int64_t n_graphs, const int64_t* dst, int64_t n_edges, int64_t n_nodes, int slot,
-                     int n_slots, int4* tiles, int* count, hipStream_t stream);
+                     int n_slots, int4* tiles, int* count, const int64_t* edge_ptr, hipStream_t stream);
 int launch_tile_simple(AggArgs a, const int4* tiles, const int* n_tiles_dev, int n_tiles_bound, int tlds, int tmax, int emax,
                        const int64_t* src, const int64_t* dst, const int* max_index, int32_t* status, int32_t* host_flag,
                        hipStream_t stream);

@@ -35,6 +35,7 @@ constexpr int TILE_THREADS = 512;
 constexpr int TILE_WAVES = TILE_THREADS / 64;
 constexpr int TILE_MAX_NODES = 2048;    // cap of the per-tile CSR areas (local ids are 16-bit)
 constexpr int TILE_WGS_PER_CU = 2;      // what the LDS areas are sized for (tile_capacity)
+constexpr int TILE_EDGE_REGS = 6;       // edges per thread kept in registers between the two CSR passes (3072 per tile)
 
 struct TileArgs {
   const int4* tiles;       // (n0, n1, e0, e1) per non-empty tile, compacted (any order)
@@ -81,7 +82,8 @@ __device__ inline int64_t half_wave_lower_bound(const int64_t* __restrict__ arr,
 // for slot k + 1 (n1, e1); a non-empty tile [n0, n1) x [e0, e1) takes the next place of the compacted list.
 __global__ void __launch_bounds__(256) tile_plan_kernel(const int64_t* __restrict__ ptr, int64_t n_graphs,
                                                         const int64_t* __restrict__ dst, int64_t n_edges, int64_t n_nodes,
-                                                        int slot, int n_slots, int4* __restrict__ tiles, int* __restrict__ count) {
+                                                        int slot, int n_slots, int4* __restrict__ tiles, int* __restrict__ count,
+                                                        const int64_t* __restrict__ edge_ptr) {
   const int lane = threadIdx.x & 63;
   const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (k >= n_slots) return;
@@ -91,7 +93,10 @@ __global__ void __launch_bounds__(256) tile_plan_kernel(const int64_t* __restric
   nd = nd < 0 ? 0 : (nd > n_nodes ? n_nodes : nd);
   if (kb == 0) nd = 0;
   if (kb >= n_slots) nd = n_nodes;                 // (ptr[G] == N for a well-formed batch; stragglers stay with the last tile)
-  int64_t ed = half_wave_lower_bound(dst, n_edges, nd, lane);
+  // the graph's first edge: given by the caller (PyG keeps the per-graph edge offsets of a collated batch), else found
+  // in the destination row of edge_index (edges grouped by graph)
+  int64_t ed = edge_ptr != nullptr ? (g <= n_graphs ? edge_ptr[g] : n_edges) : half_wave_lower_bound(dst, n_edges, nd, lane);
+  ed = ed < 0 ? 0 : (ed > n_edges ? n_edges : ed);
   if (nd <= 0) ed = 0;
   if (nd >= n_nodes) ed = n_edges;
   const int n0 = (int)__shfl(nd, 0), e0 = (int)__shfl(ed, 0);
@@ -99,6 +104,41 @@ __global__ void __launch_bounds__(256) tile_plan_kernel(const int64_t* __restric
   n1 = n1 < n0 ? n0 : n1;
   e1 = e1 < e0 ? e0 : e1;
   if (lane == 0 && (n1 > n0 || e1 > e0)) tiles[atomicAdd(count, 1)] = int4{n0, n1, e0, e1};
+}
+
+// The same tiles from the GRAPH side, when the caller supplies the graphs' edge offsets: one thread per graph; a graph
+// whose first node lies in another slot than its predecessor's heads a tile, which runs to the next head.  No search:
+// one round of loads (against the eight dependent probes of the search form).
+__global__ void __launch_bounds__(256) tile_plan_graphs_kernel(const int64_t* __restrict__ ptr, const int64_t* __restrict__ edge_ptr,
+                                                               int64_t n_graphs, int64_t n_edges, int64_t n_nodes, int slot,
+                                                               int4* __restrict__ tiles, int* __restrict__ count) {
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= n_graphs) return;
+  const int64_t p0 = ptr[g];
+  const int64_t sg = p0 / slot;
+  if (g > 0 && ptr[g - 1] / slot == sg) return;     // not a head
+  int64_t end = g + 1;
+  for (bool found = false; !found && end < n_graphs;) {
+    int64_t v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = end + j < n_graphs ? ptr[end + j] : (int64_t)-1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (!found) {
+        if (end + j >= n_graphs || v[j] / slot != sg) { found = true; end += j; }
+      }
+    if (!found) end += 8;
+  }
+  if (end > n_graphs) end = n_graphs;
+  auto clampn = [&](int64_t v) { return v < 0 ? (int64_t)0 : (v > n_nodes ? n_nodes : v); };
+  auto clampe = [&](int64_t v) { return v < 0 ? (int64_t)0 : (v > n_edges ? n_edges : v); };
+  const int64_t n0 = g == 0 ? 0 : clampn(p0);
+  int64_t n1 = end >= n_graphs ? n_nodes : clampn(ptr[end]);
+  const int64_t e0 = g == 0 ? 0 : clampe(edge_ptr[g]);
+  int64_t e1 = end >= n_graphs ? n_edges : clampe(edge_ptr[end]);
+  n1 = n1 < n0 ? n0 : n1;
+  e1 = e1 < e0 ? e0 : e1;
+  if (n1 > n0 || e1 > e0) tiles[atomicAdd(count, 1)] = int4{(int)n0, (int)n1, (int)e0, (int)e1};
 }
 
 template <int LPR_LOG2, class C>
@@ -125,8 +165,9 @@ __device__ inline void tile_error(const TileArgs& t, int code) {
 }
 
 // Persistent: the workgroups (TILE_WGS_PER_CU per CU, sized by their LDS) take tiles k = blockIdx.x, + gridDim.x, ...
+// (two 8-wavefront workgroups per CU = 4 wavefronts per SIMD: 128 VGPRs each)
 template <int LPR_LOG2, int HPB, int NEED, class C>
-__global__ void __launch_bounds__(TILE_THREADS) agg_tile_kernel(AggArgs a, TileArgs t) {
+__global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) agg_tile_kernel(AggArgs a, TileArgs t) {
   constexpr int LPR = 1 << LPR_LOG2, G = 64 / LPR;
   extern __shared__ float smem[];
   const int tid = threadIdx.x;
@@ -189,11 +230,28 @@ __global__ void __launch_bounds__(TILE_THREADS) agg_tile_kernel(AggArgs a, TileA
     }
     const bool in_lds = T <= t.tlds;             // the tile's basis rows fit LDS (else: gathered from memory)
 
-    // ---- (A) requests: first rows' weightings, the tile's basis rows by LDS-DMA (one flat copy), counters zeroed ----
-    f4 wnext[2];
+    // ---- (A) every request of the tile at once: the weightings of the first two passes, the edges (registers), the
+    //      basis rows by LDS-DMA (one flat copy); counters zeroed.  ONE memory latency, paid at the barrier below. ----
+    f4 wn0[2], wn1[2];
     {
       const int r = wave * G + g;
-      load_weightings_row<LPR_LOG2, C>(a, q, n0 + r, r < T, wnext);
+      load_weightings_row<LPR_LOG2, C>(a, q, n0 + r, r < T, wn0);
+      load_weightings_row<LPR_LOG2, C>(a, q, n0 + r + RPP, r + RPP < T, wn1);
+    }
+    const bool in_regs = Et <= TILE_THREADS * TILE_EDGE_REGS;   // else: both CSR passes stream the edges from memory
+    int es[TILE_EDGE_REGS], ed[TILE_EDGE_REGS];
+    bool bad = false;
+    if (in_regs) {
+#pragma unroll
+      for (int j = 0; j < TILE_EDGE_REGS; ++j) {
+        const int i = tid + j * TILE_THREADS;
+        es[j] = ed[j] = -1;
+        if (i < Et) {
+          const int64_t s = t.src[(int64_t)e0 + i] - n0, d = t.dst[(int64_t)e0 + i] - n0;
+          if (s < 0 || s >= T || d < 0 || d >= T) bad = true;
+          else { es[j] = (int)s; ed[j] = (int)d; }
+        }
+      }
     }
     if (in_lds) {
       const int n4 = T * ldb4;
@@ -206,13 +264,21 @@ __global__ void __launch_bounds__(TILE_THREADS) agg_tile_kernel(AggArgs a, TileA
     __syncthreads();
 
     // ---- (B) in-degrees; every edge checked against the tile ----
-    bool bad = false;
+    if (in_regs) {
+#pragma unroll
+      for (int j = 0; j < TILE_EDGE_REGS; ++j)
+        if (ed[j] >= 0) {
+          atomicAdd(&lds_cnt[ed[j]], 1);
+          if (es[j] != ed[j]) atomicAdd(&lds_ns[ed[j]], 1);
+        }
+    } else {
 #pragma unroll 4
-    for (int i = tid; i < Et; i += TILE_THREADS) {
-      const int64_t s = t.src[(int64_t)e0 + i] - n0, d = t.dst[(int64_t)e0 + i] - n0;
-      if (s < 0 || s >= T || d < 0 || d >= T) { bad = true; continue; }
-      atomicAdd(&lds_cnt[(int)d], 1);
-      if (s != d) atomicAdd(&lds_ns[(int)d], 1);
+      for (int i = tid; i < Et; i += TILE_THREADS) {
+        const int64_t s = t.src[(int64_t)e0 + i] - n0, d = t.dst[(int64_t)e0 + i] - n0;
+        if (s < 0 || s >= T || d < 0 || d >= T) { bad = true; continue; }
+        atomicAdd(&lds_cnt[(int)d], 1);
+        if (s != d) atomicAdd(&lds_ns[(int)d], 1);
+      }
     }
     if (__ballot(bad) != 0 && lane == 0) tile_error(t, 1);
     __syncthreads();
@@ -245,23 +311,29 @@ __global__ void __launch_bounds__(TILE_THREADS) agg_tile_kernel(AggArgs a, TileA
     }
     __syncthreads();
 
-    // ---- (D) scatter (the edges again: L2-resident by now) ----
+    // ---- (D) scatter ----
+    if (in_regs) {
+#pragma unroll
+      for (int j = 0; j < TILE_EDGE_REGS; ++j)
+        if (ed[j] >= 0) lds_col[lds_rowptr[ed[j]] + atomicAdd(&lds_cnt[ed[j]], 1)] = (unsigned short)es[j];
+    } else {
 #pragma unroll 4
-    for (int i = tid; i < Et; i += TILE_THREADS) {
-      const int64_t s = t.src[(int64_t)e0 + i] - n0, d = t.dst[(int64_t)e0 + i] - n0;
-      if (s < 0 || s >= T || d < 0 || d >= T) continue;
-      const int pos = lds_rowptr[(int)d] + atomicAdd(&lds_cnt[(int)d], 1);
-      lds_col[pos] = (unsigned short)s;
+      for (int i = tid; i < Et; i += TILE_THREADS) {
+        const int64_t s = t.src[(int64_t)e0 + i] - n0, d = t.dst[(int64_t)e0 + i] - n0;
+        if (s < 0 || s >= T || d < 0 || d >= T) continue;
+        lds_col[lds_rowptr[(int)d] + atomicAdd(&lds_cnt[(int)d], 1)] = (unsigned short)s;
+      }
     }
     __syncthreads();
 
-    // ---- (E) rows: one lane group per row, G rows per wavefront and pass; weightings of the next pass in flight ----
+    // ---- (E) rows: one lane group per row, G rows per wavefront and pass; weightings two passes ahead ----
     for (int r0 = 0; r0 < T; r0 += RPP) {
       const int r = r0 + wave * G + g;             // local row of this lane group
       const bool row_ok = r < T;
       const int row = n0 + (row_ok ? r : 0);
-      f4 wpre[2] = {wnext[0], wnext[1]};
-      if (r0 + RPP < T) load_weightings_row<LPR_LOG2, C>(a, q, n0 + r + RPP, r + RPP < T, wnext);
+      f4 wpre[2] = {wn0[0], wn0[1]};
+      wn0[0] = wn1[0]; wn0[1] = wn1[1];
+      if (r0 + 2 * RPP < T) load_weightings_row<LPR_LOG2, C>(a, q, n0 + r + 2 * RPP, r + 2 * RPP < T, wn1);
       const int start = row_ok ? lds_rowptr[r] : 0;
       const int nd = row_ok ? lds_rowptr[r + 1] - start : 0;
       int maxd = nd;
@@ -449,9 +521,16 @@ int launch_tile_simple(AggArgs a, const int4* tiles, const int* n_tiles_dev, int
 }
 
 int launch_tile_plan(const int64_t* ptr, int64_t n_graphs, const int64_t* dst, int64_t n_edges, int64_t n_nodes, int slot,
-                     int n_slots, int4* tiles, int* count, hipStream_t stream) {
+                     int n_slots, int4* tiles, int* count, const int64_t* edge_ptr, hipStream_t stream) {
   EGC_HIP_TRY(hipMemsetAsync(count, 0, sizeof(int), stream));
-  tile_plan_kernel<<<(unsigned)((n_slots + 3) / 4), 256, 0, stream>>>(ptr, n_graphs, dst, n_edges, n_nodes, slot, n_slots, tiles, count);
+  if (edge_ptr != nullptr && n_graphs > 0) {
+    tile_plan_graphs_kernel<<<(unsigned)((n_graphs + 255) / 256), 256, 0, stream>>>(ptr, edge_ptr, n_graphs, n_edges, n_nodes, slot,
+                                                                                tiles, count);
+    EGC_LAUNCH_CHECK("tile_plan_graphs_kernel");
+    return EGC_OK;
+  }
+  tile_plan_kernel<<<(unsigned)((n_slots + 3) / 4), 256, 0, stream>>>(ptr, n_graphs, dst, n_edges, n_nodes, slot, n_slots, tiles, count,
+                                                                      edge_ptr);
   EGC_LAUNCH_CHECK("tile_plan_kernel");
   return EGC_OK;
 }

@@ -428,7 +428,8 @@ class GraphBatch:
     edge list instead (built on first need, ``csr()``): results are the same, the speed is the ordinary path's."""
 
     def __init__(self, edge_index: torch.Tensor, ptr: torch.Tensor | None = None, batch: torch.Tensor | None = None,
-                 num_graphs: int | None = None, num_nodes: int | None = None, max_nodes: int = 256, edges_per_node: int = 16):
+                 num_graphs: int | None = None, num_nodes: int | None = None, max_nodes: int = 256, edges_per_node: int = 16,
+                 edge_ptr: torch.Tensor | None = None):
         _require_cuda(edge_index, "edge_index")
         if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.size(0) != 2:
             raise RuntimeError("egc_amd: edge_index must be an int64 tensor of shape [2, E]")
@@ -444,6 +445,11 @@ class GraphBatch:
                 num_nodes = int(batch.numel())
         self.ptr = ptr.to(device=self.device, dtype=torch.int64).contiguous()
         self.n_graphs = int(self.ptr.numel()) - 1
+        # the graphs' edge offsets, when the caller has them (PyG's collation keeps them: batch._slice_dict["edge_index"]);
+        # without them the plan finds each tile's first edge by searching the destination row
+        self.edge_ptr = None if edge_ptr is None else edge_ptr.to(device=self.device, dtype=torch.int64).contiguous()
+        if self.edge_ptr is not None and self.edge_ptr.numel() != self.ptr.numel():
+            raise RuntimeError("egc_amd.GraphBatch: edge_ptr must have one entry per graph + 1, like ptr")
         self.n_nodes = None if num_nodes is None else int(num_nodes)     # else: the row count of the first x seen
         self.max_nodes, self.edges_per_node = int(max_nodes), int(edges_per_node)
         self.n_edges = int(edge_index.size(1))
@@ -485,9 +491,9 @@ class GraphBatch:
             self._status.zero_()
             if _IndexFlag._view is not None:
                 _IndexFlag._view.value = 0
-            raise RuntimeError("egc_amd.GraphBatch: " + ("a tile exceeds the LDS areas (raise max_nodes / edges_per_node, or "
-                               "pass the plain edge_index)" if code & 2 else "edge_index is not grouped by graph, or holds "
-                               "node ids outside its graph: index out of range"))
+            raise RuntimeError("egc_amd.GraphBatch: " + ("edge_index is not grouped by graph, or holds node ids outside its "
+                               "graph: index out of range" if code & 1 else "a tile exceeds the per-tile areas (raise "
+                               "max_nodes / edges_per_node, or pass the plain edge_index)"))
         return self
 
     def tile_setup(self, spec_c, with_post: bool):
@@ -509,8 +515,10 @@ class GraphBatch:
             if lds <= 0:
                 hit = False
             else:
-                # a slot + one typical graph fills the LDS area; enough slots to occupy the chip twice over when the batch allows
-                slot = max(8, min(lds - typical + 1, -(-n // 1024)) if n >= 8 * 1024 else lds - typical + 1)
+                # a slot + one typical graph fills the LDS area: tiles as large as LDS allows (every tile pays a fixed
+                # latency chain -- requests, three LDS passes of the CSR build -- whatever its size); smaller only when the
+                # batch would otherwise leave CUs without a tile
+                slot = max(8, min(lds - typical + 1, max(16, -(-n // 256))))
                 tmax, emax = areas(slot)
                 lds = int(lib.egc_batch_tile_nodes(C.byref(spec_c), tmax, emax, int(with_post)))
                 hit = (slot, lds, tmax, emax) if lds > 0 else False
@@ -531,8 +539,9 @@ class GraphBatch:
             with _device_guard(self.device):
                 buf = torch.empty(4 * max(n_slots, 1) + 4, dtype=torch.int32, device=self.device)
                 tiles, count = buf[:4 * max(n_slots, 1)].view(-1, 4), buf[4 * max(n_slots, 1):]
-                _C.check(lib.egc_batch_plan(self.ptr.data_ptr(), self.n_graphs, self.edge_index[1].data_ptr(), self.n_edges, n,
-                                            slot, tiles.data_ptr(), n_slots, count.data_ptr(), _stream_ptr(self.device)),
+                _C.check(lib.egc_batch_plan(self.ptr.data_ptr(), self.edge_ptr.data_ptr() if self.edge_ptr is not None else None,
+                                            self.n_graphs, self.edge_index[1].data_ptr(), self.n_edges, n, slot,
+                                            tiles.data_ptr(), n_slots, count.data_ptr(), _stream_ptr(self.device)),
                          "egc_batch_plan")
             hit = (tiles, count, n_slots)
             self._plans[slot] = hit

@@ -462,7 +462,9 @@ int egc_aggregate_combine_train_rows_f32(const egc_graph* graph, const egc_layer
  *   egc_batch_plan         once per batch, one launch: cuts [0, n_nodes) into n_slots = ceil(n_nodes / slot) slots; the
  *                          graphs whose first node lies in slot k form one tile (n0, n1, e0, e1) -- node range and edge
  *                          range; the non-empty tiles are written to tiles[4 i ..] in any order and counted in *n_tiles
- *                          (device).  A tile holds < slot + (largest graph) nodes.  graph_ptr: int64 [n_graphs + 1].
+ *                          (device).  A tile holds < slot + (largest graph) nodes.  graph_ptr: int64 [n_graphs + 1];
+ *                          edge_ptr: the graphs' edge offsets, int64 [n_graphs + 1] (PyG keeps them for a collated batch),
+ *                          or NULL: found by searching the destination row of edge_index.
  *   egc_aggregate_combine_batch_f32
  *                          contract of egc_aggregate_combine_post_f32 (same reference call sites; plus those of
  *                          egc_graph_build: no CSR is built beforehand) for the rows of every tile, straight from the
@@ -475,8 +477,8 @@ int egc_aggregate_combine_train_rows_f32(const egc_graph* graph, const egc_layer
  * the LDS atomics that built the CSR: sums are reproducible to rounding, max / min exactly.
  * ------------------------------------------------------------------------------------------ */
 int32_t egc_batch_tile_nodes(const egc_layer* layer, int32_t max_tile_nodes, int32_t max_tile_edges, int32_t with_post);
-int egc_batch_plan(const int64_t* graph_ptr, int64_t n_graphs, const int64_t* dst, int64_t n_edges, int64_t n_nodes,
-                   int32_t slot, int32_t* tiles, int32_t n_slots, int32_t* n_tiles, egc_stream_t stream);
+int egc_batch_plan(const int64_t* graph_ptr, const int64_t* edge_ptr, int64_t n_graphs, const int64_t* dst, int64_t n_edges,
+                   int64_t n_nodes, int32_t slot, int32_t* tiles, int32_t n_slots, int32_t* n_tiles, egc_stream_t stream);
 int egc_aggregate_combine_batch_f32(const int32_t* tiles, const int32_t* n_tiles, int32_t n_tiles_bound, int32_t lds_nodes,
                                     int32_t max_tile_nodes, int32_t max_tile_edges, const int64_t* src, const int64_t* dst,
                                     int64_t n_nodes, const int32_t* max_index, const egc_layer* layer, const float* bases,

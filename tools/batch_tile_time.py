@@ -30,15 +30,20 @@ def main():
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     conv = egc_amd.EGConv(128, 128, aggrs=["sum", "mean", "max", "symnorm"], num_heads=8, num_bases=4).to(dev).eval()
-    for name, (ei, n, batch), G, mx in (("molhiv b2048", wl.molecule_batch(2048, seed=0), 2048, 222),
-                                         ("cifar b2048", wl.knn_superpixel_batch(2048, seed=0), 2048, 150),
-                                         ("zinc b128", wl.zinc_like_batch(128, seed=0)[1:], 128, 37)):
+    only = os.environ.get("EGC_TILE_ONLY", "")
+    for name, gen, G, mx in (("molhiv b2048", lambda: wl.molecule_batch(2048, seed=0), 2048, 222),
+                             ("cifar b2048", lambda: wl.knn_superpixel_batch(2048, seed=0), 2048, 150),
+                             ("zinc b128", lambda: wl.zinc_like_batch(128, seed=0)[1:], 128, 37)):
+        if only and not name.startswith(only):
+            continue
+        ei, n, batch = gen()
         ei, batch = ei.to(dev), batch.to(dev)
         ptr = torch.searchsorted(batch, torch.arange(G + 1, device=dev))
+        eptr = torch.searchsorted(batch[ei[1]], torch.arange(G + 1, device=dev))   # a PyG batch carries these (collation's slices)
         x = torch.randn(n, 128, device=dev)
         with torch.no_grad():
             g = egc_amd.CSRGraph.from_edge_index(ei, n)
-            gb = egc_amd.GraphBatch(ei, ptr=ptr, max_nodes=mx, num_nodes=n)
+            gb = egc_amd.GraphBatch(ei, ptr=ptr, max_nodes=mx, num_nodes=n, edge_ptr=eptr)
             ref = conv(x, g)
             out = conv(x, gb)
             gb.check()
@@ -46,10 +51,10 @@ def main():
             t_build = med(lambda: egc_amd.CSRGraph.from_edge_index(ei, n))
             t_layer = med(lambda: conv(x, g))
             slot = next(iter(gb._plans))
-            t_plan = med(lambda: egc_amd.GraphBatch(ei, ptr=ptr, max_nodes=mx, num_nodes=n).plan(slot))
+            t_plan = med(lambda: egc_amd.GraphBatch(ei, ptr=ptr, max_nodes=mx, num_nodes=n, edge_ptr=eptr).plan(slot))
             t_tile = med(lambda: conv(x, gb))
             def both():
-                conv(x, egc_amd.GraphBatch(ei, ptr=ptr, max_nodes=mx, num_nodes=n))
+                conv(x, egc_amd.GraphBatch(ei, ptr=ptr, max_nodes=mx, num_nodes=n, edge_ptr=eptr))
             t_both = med(both)
         tiles = next(iter(gb._plans.values()))
         setup = next(iter(gb._setups.values()))
