@@ -464,7 +464,9 @@ __device__ inline void load_row_operands(const AggArgs& a, const FastRsrc& R, in
     wpre[0] = wpre[1] = f4{0.f, 0.f, 0.f, 0.f};
     return;
   }
-  const float* wrow = a.weightings + (int64_t)(row_ok ? row : 0) * a.ldw;
+  // (a masked lane group reads the first row of the launch's own range: a caller that finishes rows [b, e) only needs
+  // the weightings of those rows to exist)
+  const float* wrow = a.weightings + (int64_t)(row_ok ? row : a.row_begin) * a.ldw;
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int c0 = (q + k * LPR) * 4;
