@@ -33,6 +33,14 @@ class LayerSpec:
         return (self.f_g + 3) & ~3
 
     @property
+    def c_addr(self) -> int:
+        """Address of the C struct (stable: the spec owns it)."""
+        a = self.__dict__.get("_c_addr")
+        if a is None:
+            a = self.__dict__["_c_addr"] = C.addressof(self.c)
+        return a
+
+    @property
     def gemm_flags(self) -> int:
         """Operand precision of the layer's split GEMM (egc_layer_gemm_flags): EGC_GEMM_24BIT for layers with std / var,
         whose cancellation amplifies what a 22-bit operand split drops; EGC_GEMM_FAST=1 keeps the fast form for them too."""
@@ -447,9 +455,26 @@ def egc_layer_forward_fused(graph: CSRGraph, spec: LayerSpec, x: torch.Tensor, p
     return (out, bases) if return_bases else out
 
 
+def _native_ops(dev):
+    """The compiled binding (egc_amd/_native.py) when it is built and `dev` is the current device."""
+    from . import _native
+    nat = _native.ops()
+    if nat is None or dev.index != torch.cuda.current_device():
+        return None
+    return nat
+
+
 def _layer_forward_one_call(graph: CSRGraph, spec: LayerSpec, x, packed, bcat, bias):
     """The common inference case (one GPU, packed weights at hand, no fused tail) as ONE library call
-    (egc_layer_forward_packed: both launches from C) -- small batched graphs are bound by the host side."""
+    (egc_layer_forward_packed: both launches from C) -- small batched graphs are bound by the host side.  Through the
+    compiled TORCH_LIBRARY binding when it is built (one dispatcher call: allocations + both launches in C++)."""
+    nat = _native_ops(x.device) if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2) else None
+    if nat is not None and x.device == graph.device and tuple(x.shape) == (graph.n_nodes, spec.f_in):
+        return nat.layer_forward(x if x.is_contiguous() else x.contiguous(), packed,
+                                 bcat if (bcat is None or bcat.is_contiguous()) else bcat.contiguous(),
+                                 bias if (bias is None or bias.is_contiguous()) else bias.contiguous(),
+                                 graph.c_addr(), spec.c_addr, graph.workspace_for(spec), _stream_ptr(x.device), spec.ldb,
+                                 spec.w_cols, spec.f_out)
     lib = _C.load()
     n = graph.n_nodes
     _check_f32(x, "x", (n, spec.f_in))
@@ -495,6 +520,16 @@ def egc_layer_forward(graph: CSRGraph, spec: LayerSpec, x: torch.Tensor, wcat: t
     if (halo is None and post is None and packed is not None and not return_intermediates and not gemm_exact()
             and graph.n_src_rows == graph.n_nodes):
         return _layer_forward_one_call(graph, spec, x, packed, bcat, bias)
+    if (halo is None and post is not None and packed is not None and not return_intermediates and not gemm_exact()
+            and graph.n_src_rows == graph.n_nodes and x.is_cuda and x.dtype == torch.float32):
+        nat = _native_ops(x.device)
+        if nat is not None and x.device == graph.device and tuple(x.shape) == (graph.n_nodes, spec.f_in):
+            def dense(t):
+                return t if (t is None or t.is_contiguous()) else t.contiguous()
+            return nat.layer_forward_post(dense(x), packed, dense(bcat), dense(bias), graph.c_addr(), spec.c_addr,
+                                          graph.workspace_for(spec), _stream_ptr(x.device), spec.ldb, spec.w_cols, spec.f_out,
+                                          spec.gemm_flags, dense(post.scale), dense(post.shift), dense(post.residual),
+                                          bool(post.relu))
     bases, weightings = egc_basis_transform(graph, spec, x, wcat, bcat, packed)
     if halo is not None and halo.n_interior is not None and post is None:
         # interior rows (no halo source) are finished while the halo rows of `bases` travel

@@ -337,6 +337,34 @@ class CSRGraph:
                            self.edge_dis_raw.data_ptr() if self.edge_dis_raw is not None else None,
                            self.edge_dis_looped.data_ptr() if self.edge_dis_looped is not None else None)
 
+    def c_addr(self) -> int:
+        """Address of a C view of this graph that stays valid (and current) while the graph lives: what the compiled
+        binding takes (egc_amd/_native.py).  Rebuilt when something the struct carries has changed."""
+        key = (self._n_chunks, 0 if self.edge_dis_raw is None else self.edge_dis_raw.data_ptr(),
+               0 if self.edge_dis_looped is None else self.edge_dis_looped.data_ptr())
+        hit = getattr(self, "_c_cached", None)
+        if hit is None or hit[0] != key or self._n_chunks is None:
+            st = self.c_struct()           # (polls the index flag, settles _n_chunks)
+            key = (self._n_chunks, key[1], key[2])
+            hit = self._c_cached = (key, st, C.addressof(st))
+        else:
+            _IndexFlag.poll()
+        return hit[2]
+
+    def workspace_for(self, spec) -> torch.Tensor:
+        """The aggregate workspace of (this graph, this layer), sized once."""
+        cache = self.__dict__.setdefault("_ws_for", {})
+        key = (id(spec), _stream_ptr(self.device), self._n_chunks)
+        ws = cache.get(key)
+        if ws is None:
+            lib = _C.load()
+            g = self.c_struct()
+            ws = self.workspace(lib.egc_aggregate_workspace_bytes_for(C.byref(spec.c), C.byref(g)),
+                                lib.egc_aggregate_workspace_zero_bytes(C.byref(spec.c), self.n_nodes, self.n_edges))
+            cache[(id(spec), _stream_ptr(self.device), self._n_chunks)] = ws
+            cache.setdefault("_keep", []).append(spec)      # id(spec) stays unique while the entry lives
+        return ws
+
     def trim_launches(self) -> "CSRGraph":
         """Read the long-row chunk count back to the host (ONE synchronisation) so that later launches carry only
         the chunk workgroups that exist instead of the plan's capacity -- for a graph that is built once and used
