@@ -47,6 +47,19 @@ class EgcLayer(C.Structure):
     ]
 
 
+_ENV_DATA = getattr(os.environ, "_data", None)     # CPython on POSIX: the bytes dict behind os.environ
+
+
+def env_flag(name: str) -> bool:
+    """True when the environment variable is set to something other than "" / "0" -- read on every call (tests and
+    notebooks flip these), but through the bytes dict behind os.environ where CPython has one: os.environ.get costs
+    1.5 us per lookup (key encoding + value decoding), four of them were a quarter of an eval-mode layer call."""
+    if _ENV_DATA is not None:
+        v = _ENV_DATA.get(name.encode())
+        return v is not None and v not in (b"", b"0")
+    return os.environ.get(name, "0") not in ("", "0")
+
+
 class EgcPost(C.Structure):
     _fields_ = [("scale", C.c_void_p), ("shift", C.c_void_p), ("residual", C.c_void_p), ("relu", C.c_int32)]
 

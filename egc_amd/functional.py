@@ -177,7 +177,7 @@ def pack_weights(spec: LayerSpec, wcat: torch.Tensor) -> torch.Tensor:
 
 def gemm_exact() -> bool:
     """EGC_GEMM_EXACT=1 selects the plain fp32-MFMA GEMM instead of the split-precision matrix-core form."""
-    return os.environ.get("EGC_GEMM_EXACT", "0") not in ("", "0")
+    return _C.env_flag("EGC_GEMM_EXACT")
 
 
 def egc_basis_transform(graph: CSRGraph, spec: LayerSpec, x: torch.Tensor, wcat: torch.Tensor,
@@ -306,7 +306,7 @@ def egc_aggregate_combine(graph: CSRGraph, spec: LayerSpec, bases: torch.Tensor,
 
 def _batch_tile_setup(gb: GraphBatch, spec: LayerSpec, post):
     """What the tile kernels need for this layer on this batch (GraphBatch.tile_setup), or None."""
-    if os.environ.get("EGC_NO_TILE", "0") not in ("", "0"):
+    if _C.env_flag("EGC_NO_TILE"):
         return None
     return gb.tile_setup(spec.c, post is not None and post.scale is not None)
 
@@ -372,7 +372,7 @@ def fused_supported(spec: LayerSpec) -> bool:
 def fused_enabled() -> bool:
     """EGC_FUSEDW=1 routes qualifying inference calls through the fused-weightings launch.  Off by default: on
     MI355X it is slower than the two-launch path."""
-    return os.environ.get("EGC_FUSEDW", "0") not in ("", "0")
+    return _C.env_flag("EGC_FUSEDW")
 
 
 _FUSED_PACKS: "dict[tuple, tuple]" = {}

@@ -145,7 +145,7 @@ layer_forward_train.register_autograd(_backward, setup_context=_setup_context)
 
 
 def use_torch_op() -> bool:
-    return os.environ.get("EGC_USE_TORCH_OP", "0") not in ("", "0") or torch.compiler.is_compiling()
+    return _C.env_flag("EGC_USE_TORCH_OP") or torch.compiler.is_compiling()
 
 
 def layer_apply_op(graph, spec, x, wcat, bcat, bias):

@@ -12,16 +12,21 @@ import egc_amd  # noqa: E402
 from egc_amd import _native  # noqa: E402
 
 
-def wall(fn, iters=2000):
+def wall(fn, iters=150, reps=15):
+    """Host time per call: bursts of `iters` calls into an EMPTY queue (a burst short enough that the launches never
+    wait for the GPU -- the kernels of one call take ~15 us of GPU time, a call less than that of host time otherwise
+    shows up as the GPU's), median over the bursts."""
     for _ in range(200):
         fn()
+    out = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        out.append((time.perf_counter() - t0) / iters * 1e6)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        fn()
-    t = (time.perf_counter() - t0) / iters
-    torch.cuda.synchronize()
-    return t * 1e6
+    return sorted(out)[reps // 2]
 
 
 def main():
