@@ -117,6 +117,13 @@ __device__ inline f4 f4_sqr_rn(f4 v) {
   return f4{__fmul_rn(v.x, v.x), __fmul_rn(v.y, v.y), __fmul_rn(v.z, v.z), __fmul_rn(v.w, v.w)};
 }
 __device__ inline f4 splat(float w) { return f4{w, w, w, w}; }
+__device__ inline constexpr bool getenv_scatter4() {
+#ifdef EGC_NO_SCATTER4
+  return false;
+#else
+  return true;
+#endif
+}
 
 __device__ inline float bperm(int byte_addr, float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_addr, __builtin_bit_cast(int, v)));
@@ -147,6 +154,32 @@ __device__ inline void dpp_sum_over_4_bases(f4& v) {
       "v_add_f32_dpp %2, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
       "v_add_f32_dpp %3, %3, %3 row_ror:4 row_mask:0xf bank_mask:0xf"
       : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+}
+
+// Reduce-scatter over the 4 bases of a 16-lane row (lanes q = 4 b + l4): `p[j]` is the lane's share of head (b + j) mod 4;
+// afterwards the lane holds the complete sum of ITS head (bb == b): r = p[0] + ror4(p[1]) + ror8(p[2]) + ror12(p[3]) -- lane
+// i of a DPP row receives lane (i - n) mod 16 under row_ror:n, i.e. basis b receives basis b - n / 4, which holds head b at
+// j = n / 4.  Three DPP additions per component instead of the two-step all-reduce of every head followed by a select
+// (8 additions + 4 selects per head: 48 instructions for four heads against 12 here).
+__device__ inline f4 dpp_reduce_scatter_4_bases(f4 p0, f4 p1, f4 p2, f4 p3) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %4, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %5, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %6, %2 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %7, %3 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %8, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %9, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %10, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %11, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %12, %0 row_ror:12 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %13, %1 row_ror:12 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %14, %2 row_ror:12 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %15, %3 row_ror:12 row_mask:0xf bank_mask:0xf"
+      : "+v"(p0.x), "+v"(p0.y), "+v"(p0.z), "+v"(p0.w)
+      : "v"(p1.x), "v"(p1.y), "v"(p1.z), "v"(p1.w), "v"(p2.x), "v"(p2.y), "v"(p2.z), "v"(p2.w), "v"(p3.x), "v"(p3.y), "v"(p3.z),
+        "v"(p3.w));
+  return p0;
 }
 
 template <int NEED>
@@ -376,6 +409,34 @@ __device__ inline void finish_group(const AggArgs& a, const FastRsrc& R, int lan
   // (3) combine: for head h = hb*B + bb every lane forms its (b, l..l+3) share, the butterfly sums over
   //     b, and the lane with b == bb keeps the head's 4 channels
   f4 o[HPB];
+  // B = 4 bases x 4 slots in one 16-lane DPP row (every d = 128 / H = 8 / B = 4 layer): each lane forms the shares of the
+  // four heads of a block in ITS OWN order -- head (b + j) mod 4 at step j, the weights come from a lane-dependent LDS
+  // address -- and one reduce-scatter leaves every lane with the complete sum of the head it stores
+  const bool scatter4 = C::pow2(a) && LPR == 16 && C::lpb_log2(a) == 2 && C::slots(a) == 16 && B == 4 && (H & 3) == 0 &&
+                        getenv_scatter4();
+  if (scatter4) {
+#pragma unroll
+    for (int hb = 0; hb < HPB; ++hb) {
+      f4 p[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int h = hb * 4 + ((b + j) & 3);
+        const float* wp = wl + (min(h, H - 1) * 4 + b) * AW;
+        if (A == 4) {  // wave-uniform
+          const f4 wv = *reinterpret_cast<const f4*>(wp);
+          p[j] = val[0] * splat(wv.x);
+          p[j] = f4_fma(splat(wv.y), val[1], p[j]);
+          p[j] = f4_fma(splat(wv.z), val[2], p[j]);
+          p[j] = f4_fma(splat(wv.w), val[3], p[j]);
+        } else {
+          p[j] = val[0] * splat(wp[0]);
+          if (A > 1) p[j] = f4_fma(splat(wp[1]), val[1], p[j]);
+          if (A > 2) p[j] = f4_fma(splat(wp[2]), val[2], p[j]);
+        }
+      }
+      o[hb] = dpp_reduce_scatter_4_bases(p[0], p[1], p[2], p[3]);
+    }
+  } else
 #pragma unroll
   for (int hb = 0; hb < HPB; ++hb) {
     o[hb] = zero;

@@ -153,7 +153,11 @@ def test_nets_on_the_hip_layers_match_the_reference_float64(name, fused):
     for k, p in net.named_parameters():
         want = torch.from_numpy(z[f"grad64:{k}"]).double()
         bound = max(1e-5, 5.0 * meta["f32_vs_f64_grad"][k])
-        err = float((p.grad.cpu().double() - want).abs().max() / max(1e-2 * gscale, float(want.abs().max())))
+        wmax = float(want.abs().max())
+        # a bias in front of a BatchNorm on batch statistics has an analytically ZERO gradient (1e-17 in float64): what any
+        # float32 evaluation leaves there is cancellation noise of terms of the net's gradient scale -- held to that scale
+        denom = gscale if wmax < 1e-6 * gscale else max(1e-2 * gscale, wmax)
+        err = float((p.grad.cpu().double() - want).abs().max() / denom)
         assert err <= bound, (k, err, bound)
     if leaf is not None:
         assert rel(leaf.grad, z["grad_x64"]) <= max(1e-5, 5.0 * meta["f32_vs_f64_grad_max"])
