@@ -47,6 +47,28 @@ def _mix32(v: torch.Tensor, salt: int) -> torch.Tensor:
     return h ^ (h >> 13)
 
 
+def _label_sums(lab: torch.Tensor, cost64: torch.Tensor, n: int) -> torch.Tensor:
+    """[n] float64: total cost of every label value.  Sort + running sum instead of index_add: once labels have merged
+    into clusters of 10^5 vertices, float64 atomics onto a handful of addresses take seconds per call on the GPU (the
+    setup of the ogbn-mag-sized partition spent 9 of its 14 s there at two ranks)."""
+    order = torch.argsort(lab)
+    ls = lab[order]
+    cs = torch.cumsum(cost64[order], 0)
+    u, counts = torch.unique_consecutive(ls, return_counts=True)
+    ends = torch.cumsum(counts, 0) - 1
+    upto = cs[ends]
+    tot = upto.clone()
+    tot[1:] -= upto[:-1]
+    out = torch.zeros(n, dtype=torch.float64, device=lab.device)
+    out[u] = tot
+    return out
+
+
+def _part_loads(part: torch.Tensor, cost64: torch.Tensor, parts: int) -> torch.Tensor:
+    """[parts] float64 total cost per part: one masked reduction per part (never atomics onto `parts` addresses)."""
+    return torch.stack([(cost64 * (part == p)).sum() for p in range(parts)])
+
+
 def _cluster_labels(src, dst, n, cost, max_cost, rounds):
     """Size-capped label propagation: every vertex starts as its own cluster; per round a hashed half of the
     vertices adopts the most frequent label among its in-neighbours (ties by a hash), clusters whose cost has
@@ -54,10 +76,11 @@ def _cluster_labels(src, dst, n, cost, max_cost, rounds):
     dev = src.device
     ids = torch.arange(n, device=dev)
     lab = ids.clone()
+    cost64 = cost.double()
     for r in range(rounds):
         uk, cnt = torch.unique(dst * n + lab[src], return_counts=True)
         d, l = uk // n, uk % n
-        ccost = torch.zeros(n, dtype=torch.float64, device=dev).index_add_(0, lab, cost.double())
+        ccost = _label_sums(lab, cost64, n)
         closed = (ccost[l] >= max_cost) & (l != lab[d])
         score = cnt.double() + (_mix32(l, r).double() / 4294967296.0)
         score = torch.where(closed, torch.full_like(score, -1.0), score)
@@ -124,7 +147,7 @@ def locality_partition(edge_index: torch.Tensor, n_nodes: int, world: int, round
         #     labels), (2) packed into the parts largest-first onto the least loaded part
         lab = _cluster_labels(src, dst, n, cost, float(cost.sum()) / (8.0 * P), cluster_rounds)
         cl, inv = torch.unique(lab, return_inverse=True)
-        ccost = torch.zeros(cl.numel(), dtype=torch.float64, device=dev).index_add_(0, inv, cost.double())
+        ccost = _label_sums(lab, cost.double(), n)[cl]
         o = torch.argsort(ccost, descending=True, stable=True)
         bins = _pack_lpt(ccost[o].cpu(), P)
         part_of_cluster = torch.empty(cl.numel(), dtype=torch.int64, device=dev)
@@ -136,7 +159,7 @@ def locality_partition(edge_index: torch.Tensor, n_nodes: int, world: int, round
     cap = float(cost.sum()) / P * slack
     for r in range(rounds if P > 1 else 0):
         hist = torch.zeros(n * P, dtype=torch.float32, device=dev).index_add_(0, dst * P + part[src], ones).view(n, P)
-        load = torch.zeros(P, dtype=torch.float64, device=dev).index_add_(0, part, cost.double())
+        load = _part_loads(part, cost.double(), P)
         open_ = (load < cap).to(hist.dtype)                                  # full parts take no newcomers
         own = hist.gather(1, part[:, None]).squeeze(1)
         score = hist * open_[None, :]
