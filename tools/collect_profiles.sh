@@ -20,7 +20,14 @@ rocprofv3 --pmc WRITE_SIZE -d $O/pmc_train_write -o pmc --output-format csv -- p
 rocprofv3 --kernel-trace --stats -d $O/block -o kt --output-format csv -- python3 $R/tools/block_step_time.py > $O/block.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/small -o kt --output-format csv -- python3 $R/tools/small_batch_step_time.py > $O/small.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/mag -o kt --output-format csv -- python3 $R/bench.py --workload mag --steps 20 --warmup 5 > $O/mag_bench.json 2> $O/mag.log
+# round 3: the tile path of configs 3 / 4 (egc_amd.GraphBatch) beside the ordinary per-batch build, per workload
+for w in molhiv cifar; do
+  EGC_TILE_ONLY=$w rocprofv3 --kernel-trace --stats -d $O/tile_$w -o kt --output-format csv -- python3 $R/tools/batch_tile_time.py > $O/tile_$w.log 2>&1
+done
+EGC_TILE_ONLY=cifar rocprofv3 --pmc FETCH_SIZE -d $O/pmc_tile_fetch -o pmc --output-format csv -- python3 $R/tools/batch_tile_time.py > /dev/null 2> $O/pmc_tile_fetch.log
+EGC_TILE_ONLY=cifar rocprofv3 --pmc WRITE_SIZE -d $O/pmc_tile_write -o pmc --output-format csv -- python3 $R/tools/batch_tile_time.py > /dev/null 2> $O/pmc_tile_write.log
 cd $R
+python3 tools/host_overhead_time.py > $O/host_overhead.log 2>&1
 python3 bench.py --workload rmag --steps 10 --warmup 3 > $O/rmag_bench.json 2> $O/rmag.err
 python3 bench.py > $O/bench.json 2> $O/bench.err
 tail -3 $O/bench.err

@@ -44,6 +44,16 @@ def main():
     cp("bench.json", f"{tag}_bench.json")
     cp("mag_bench.json", f"{tag}_mag_bench.json")
     cp("rmag_bench.json", f"{tag}_rmag_bench.json")
+    for w in ("molhiv", "cifar"):
+        if os.path.exists(os.path.join(src, f"tile_{w}/kt_kernel_stats.csv")):
+            cp(f"tile_{w}/kt_kernel_stats.csv", f"{tag}_tile_path_{w}_kernel_stats.csv")
+            cp(f"tile_{w}.log", f"{tag}_tile_path_{w}.log")
+    for name, out in (("pmc_tile_fetch", "pmc_tile_path_cifar_fetch_size"), ("pmc_tile_write", "pmc_tile_path_cifar_write_size")):
+        f = os.path.join(src, name, "pmc_counter_collection.csv")
+        if os.path.exists(f):
+            condense(f, os.path.join(dst, f"{tag}_{out}.csv"))
+    if os.path.exists(os.path.join(src, "host_overhead.log")):
+        cp("host_overhead.log", f"{tag}_host_overhead.log")
     for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
         out = {"pmc_fetch": "pmc_fetch_size", "pmc_write": "pmc_write_size", "pmc_sq": "pmc_sq_counters"}[name]
         condense(os.path.join(src, name, "pmc_counter_collection.csv"), os.path.join(dst, f"{tag}_{out}.csv"))
