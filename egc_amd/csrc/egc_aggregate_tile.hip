@@ -221,47 +221,52 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
   constexpr int RPP = TILE_WAVES * G;           // rows per pass
   const int grp_addr = (g << LPR_LOG2) << 2;
 
+  // LDS-only barrier: __syncthreads() would also drain the LDS-DMA in flight (hipcc emits vmcnt(0) in front of it)
+  auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  // the edges of a tile, TILE_EDGE_REGS per thread, checked against the tile (-1 = absent or outside: reported)
+  int es[TILE_EDGE_REGS], ed[TILE_EDGE_REGS];
+  bool bad = false;
+  int edges_of = -1;            // the tile whose edges es / ed hold (requested one tile ahead, during the rows phase)
+  auto request_edges = [&](const int4 rec, int which) {
+    const int tn0 = rec.x, tT = rec.y - rec.x, te0 = rec.z, tE = rec.w - rec.z;
+    bad = false;
+    edges_of = which;
+    if (tT <= 0 || tE > TILE_THREADS * TILE_EDGE_REGS) return;
+#pragma unroll
+    for (int j = 0; j < TILE_EDGE_REGS; ++j) {
+      const int i = tid + j * TILE_THREADS;
+      es[j] = ed[j] = -1;
+      if (i < tE) {
+        const int64_t s = t.src[(int64_t)te0 + i] - tn0, d = t.dst[(int64_t)te0 + i] - tn0;
+        if (s < 0 || s >= tT || d < 0 || d >= tT) bad = true;
+        else { es[j] = (int)s; ed[j] = (int)d; }
+      }
+    }
+  };
+
   for (; k < n_tiles; k += gridDim.x) {
+    const int4 cur = tl;
     const int n0 = tl.x, T = tl.y - tl.x, e0 = tl.z, Et = tl.w - tl.z;
-    if (k + (int)gridDim.x < n_tiles) tl = t.tiles[k + gridDim.x];   // the next tile's record, long before it is needed
+    const bool has_next = k + (int)gridDim.x < n_tiles;
+    if (has_next) tl = t.tiles[k + gridDim.x];   // the next tile's record, long before it is needed
     if (T <= 0 || T > t.tmax || Et > t.emax) {   // edges without rows / beyond the CSR areas: report, leave the rows unwritten
       if (tid == 0) tile_error(t, T <= 0 ? 1 : 2);
       continue;
     }
     const bool in_lds = T <= t.tlds;             // the tile's basis rows fit LDS (else: gathered from memory)
+    const bool in_regs = Et <= TILE_THREADS * TILE_EDGE_REGS;   // else: both CSR passes stream the edges from memory
 
-    // ---- (A) every request of the tile at once: the weightings of the first two passes, the edges (registers), the
-    //      basis rows by LDS-DMA (one flat copy); counters zeroed.  ONE memory latency, paid at the barrier below. ----
+    // ---- (A) the weightings of the first two passes; the edges unless they were requested during the previous tile's
+    //      rows; counters zeroed ----
     f4 wn0[2], wn1[2];
     {
       const int r = wave * G + g;
       load_weightings_row<LPR_LOG2, C>(a, q, n0 + r, r < T, wn0);
       load_weightings_row<LPR_LOG2, C>(a, q, n0 + r + RPP, r + RPP < T, wn1);
     }
-    const bool in_regs = Et <= TILE_THREADS * TILE_EDGE_REGS;   // else: both CSR passes stream the edges from memory
-    int es[TILE_EDGE_REGS], ed[TILE_EDGE_REGS];
-    bool bad = false;
-    if (in_regs) {
-#pragma unroll
-      for (int j = 0; j < TILE_EDGE_REGS; ++j) {
-        const int i = tid + j * TILE_THREADS;
-        es[j] = ed[j] = -1;
-        if (i < Et) {
-          const int64_t s = t.src[(int64_t)e0 + i] - n0, d = t.dst[(int64_t)e0 + i] - n0;
-          if (s < 0 || s >= T || d < 0 || d >= T) bad = true;
-          else { es[j] = (int)s; ed[j] = (int)d; }
-        }
-      }
-    }
-    if (in_lds) {
-      const int n4 = T * ldb4;
-      const f4* gb4 = reinterpret_cast<const f4*>(a.bases) + (int64_t)n0 * ldb4;
-      for (int i = tid; i < n4; i += TILE_THREADS)    // LDS destination = wave-uniform base + lane * 16: a flat copy qualifies
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb4 + i),
-                                         (__attribute__((address_space(3))) void*)(lds_bases4 + i), 16, 0, 0);
-    }
+    if (in_regs && edges_of != k) request_edges(cur, k);
     for (int i = tid; i < T; i += TILE_THREADS) { lds_cnt[i] = 0; lds_ns[i] = 0; }
-    __syncthreads();
+    lds_barrier();
 
     // ---- (B) in-degrees; every edge checked against the tile ----
     if (in_regs) {
@@ -272,6 +277,7 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
           if (es[j] != ed[j]) atomicAdd(&lds_ns[ed[j]], 1);
         }
     } else {
+      bad = false;
 #pragma unroll 4
       for (int i = tid; i < Et; i += TILE_THREADS) {
         const int64_t s = t.src[(int64_t)e0 + i] - n0, d = t.dst[(int64_t)e0 + i] - n0;
@@ -281,7 +287,17 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
       }
     }
     if (__ballot(bad) != 0 && lane == 0) tile_error(t, 1);
-    __syncthreads();
+    // the tile's basis rows by LDS-DMA (one flat copy), issued AFTER the edges have been consumed (the compiler drains
+    // every outstanding load at the first use of an ordinary one) and waited for only in front of the rows phase: the
+    // copy runs beside the scan and the scatter
+    if (in_lds) {
+      const int n4 = T * ldb4;
+      const f4* gb4 = reinterpret_cast<const f4*>(a.bases) + (int64_t)n0 * ldb4;
+      for (int i = tid; i < n4; i += TILE_THREADS)    // LDS destination = wave-uniform base + lane * 16: a flat copy qualifies
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb4 + i),
+                                         (__attribute__((address_space(3))) void*)(lds_bases4 + i), 16, 0, 0);
+    }
+    lds_barrier();
 
     // ---- (C) exclusive scan -> rowptr, deg^-1/2 tables (wavefront 0) ----
     if (wave == 0) {
@@ -309,7 +325,7 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
       }
       if (lane == 63) lds_rowptr[T] = incl;
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- (D) scatter ----
     if (in_regs) {
@@ -324,7 +340,9 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
         lds_col[lds_rowptr[(int)d] + atomicAdd(&lds_cnt[(int)d], 1)] = (unsigned short)s;
       }
     }
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's pieces of the basis rows have landed ...
+    lds_barrier();                                       // ... and so have everybody else's
+    if (has_next) request_edges(tl, k + (int)gridDim.x); // the next tile's edges travel during this tile's rows
 
     // ---- (E) rows: one lane group per row, G rows per wavefront and pass; weightings two passes ahead ----
     for (int r0 = 0; r0 < T; r0 += RPP) {
@@ -384,7 +402,7 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
       finish_group<LPR_LOG2, HPB, NEED, C>(a, R, ln, row, row_ok, acc, nd, nself, dis_i, vself, has_self, wpre, true, lds_w,
                                            lds_bias, lds_scale);
     }
-    __syncthreads();   // every wavefront is done with the tile's LDS areas
+    lds_barrier();   // every wavefront is done with the tile's LDS areas
   }
 }
 

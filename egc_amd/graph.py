@@ -435,6 +435,9 @@ class SparseTensor:
         return self._sizes[dim]
 
 
+_TILE_SETUPS: "dict[tuple, object]" = {}     # (layer, batch shape) -> (slot, lds_nodes, tmax, emax) | False
+
+
 class GraphBatch:
     """A PyG-style BATCH of small graphs as the ``edge_index`` argument of the layers (``conv(x, GraphBatch(...))``),
     for the kernels that work on tiles of whole graphs (egc_aggregate_combine_batch_f32): no CSR is built per batch --
@@ -530,6 +533,12 @@ class GraphBatch:
         key = (C.string_at(C.addressof(spec_c), C.sizeof(spec_c)), bool(with_post))
         hit = self._setups.get(key)
         if hit is None:
+            # the sizing depends on the layer and on the batch's SHAPE only: batches of one loader share it
+            gkey = key + (self.n_nodes, self.n_graphs, self.max_nodes, self.edges_per_node)
+            hit = _TILE_SETUPS.get(gkey)
+            if hit is not None:
+                self._setups[key] = hit
+        if hit is None:
             lib = _C.load()
             n, gcount = self.n_nodes, max(self.n_graphs, 1)
             typical = min(self.max_nodes, max(2 * -(-n // gcount), 8))
@@ -551,6 +560,9 @@ class GraphBatch:
                 lds = int(lib.egc_batch_tile_nodes(C.byref(spec_c), tmax, emax, int(with_post)))
                 hit = (slot, lds, tmax, emax) if lds > 0 else False
             self._setups[key] = hit
+            if len(_TILE_SETUPS) > 256:
+                _TILE_SETUPS.clear()
+            _TILE_SETUPS[key + (self.n_nodes, self.n_graphs, self.max_nodes, self.edges_per_node)] = hit
         if hit is False:
             return None
         slot, lds, tmax, emax = hit
