@@ -75,7 +75,7 @@ def main():
     errs = {"out": rel(out_nat, ref.detach()[lo:hi]), "dx": rel(gx_nat, xr.grad[lo:hi])}
     for k, p in conv.named_parameters():
         errs[k] = rel(grads[k], p.grad.detach().cpu())
-    bad = {k: v for k, v in errs.items() if v > 2e-4}
+    bad = {k: v for k, v in errs.items() if v > 2e-5}   # two fp32 evaluations of the same sums (float atomics in the source kernel)
     print(f"rank {rank}: halo {plan.n_halo} rows, errors {errs}", flush=True)
     dist.barrier()
     dist.destroy_process_group()

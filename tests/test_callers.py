@@ -77,7 +77,7 @@ def test_zinc_net_forward_and_gradients_match_cpu_restatement(hidden, H, B, aggr
         return float((a.detach().cpu().double() - b.detach().double()).abs().max()) / max(1e-6, float(b.abs().max()))
 
     scale = max(1.0, float(out_ref.detach().abs().max()))
-    assert float((out.detach().cpu().double() - out_ref.detach()).abs().max()) / scale <= 2e-4
+    assert float((out.detach().cpu().double() - out_ref.detach()).abs().max()) / scale <= 5e-5
     for got, want, cal in [
         (net.embedding.weight.grad, ref.embedding.weight.grad, ref32.embedding.weight.grad),
         (net.convs[0].comb_weights.weight.grad, ref.convs[0].layer.comb_weights.weight.grad,
@@ -89,7 +89,7 @@ def test_zinc_net_forward_and_gradients_match_cpu_restatement(hidden, H, B, aggr
         # Atoms of one type share an embedding row, so neighbourhoods hold exact duplicates: relu(var) sits
         # at its kink and max has near-ties, and WHICH side fp32 rounding lands on differs between any two
         # fp32 evaluations (the fp32 CPU restatement itself is 2.4e-2 from float64 on a single such layer)
-        floor = 1e-2 if set(aggrs) & {"std", "max", "min"} else 2e-3
+        floor = 2e-3 if set(aggrs) & {"std", "max", "min"} else 2e-4   # (fixture-calibrated bounds: tests/test_nets_golden.py)
         assert rel(got, want) <= max(floor, 4.0 * rel(cal, want)), (rel(got, want), rel(cal, want))
 
 

@@ -102,7 +102,9 @@ def test_hip_regconv_gradients_match_float64_restatement():
 
     def close(a, b, what):
         err = float((a.detach().cpu().double() - b).abs().max()) / max(1e-12, float(b.abs().max()))
-        assert err <= 2e-4, (what, err)
+        # (the reference-derived float64 fixtures of tests/test_nets_golden.py hold REGConv's backward to
+        # max(1e-5, 5 x the reference's own fp32-vs-fp64 distance); this float64 restatement on random inputs to 2e-5)
+        assert err <= 2e-5, (what, err)
 
     for k in x:
         close(x[k].grad, x64[k].grad, f"x[{k}]")
