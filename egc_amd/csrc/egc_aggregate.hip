@@ -459,7 +459,7 @@ static WsLayout ws_layout(const egc_layer* L, int64_t n_nodes, int64_t n_edges, 
 
 template <int CHUNKS>
 static int launch_all(const AggArgs& a, int64_t n_nodes, const PlanCaps& caps, int wpb, size_t lds_bytes,
-                      hipStream_t stream) {
+                      hipStream_t stream, bool wide_rows = false) {
   // neighbour rows in flight per lane group.  With two or more slots per lane the staging registers of four rows
   // cost a wavefront per SIMD (130 VGPRs -> 3 wavefronts; two rows: 4), and these one-row wavefronts are bound by
   // their chain of dependent memory round trips, i.e. by occupancy: 887 -> 802 us at 300/H4/B4 on the arxiv graph.
@@ -468,8 +468,13 @@ static int launch_all(const AggArgs& a, int64_t n_nodes, const PlanCaps& caps, i
   // long-row chunks first (they are the longest work items), then the per-row kernel, then the merge
   agg_chunks_kernel<CHUNKS, U><<<(unsigned)ceil_div(caps.cap_chunks, 4), 256, 0, stream>>>(a);
   EGC_LAUNCH_CHECK("agg_chunks_kernel");
-  agg_rows_kernel<CHUNKS, U><<<(unsigned)ceil_div(a.row_end - a.row_begin, wpb), threads, lds_bytes, stream>>>(a);
-  EGC_LAUNCH_CHECK("agg_rows_kernel");
+  if (wide_rows) {   // 65..128 slots per row: the short rows on the two-slots-per-lane register kernel (egc_aggregate_fast.hip)
+    const int st = launch_wide_rows(a, stream);
+    if (st != EGC_OK) return st;
+  } else {
+    agg_rows_kernel<CHUNKS, U><<<(unsigned)ceil_div(a.row_end - a.row_begin, wpb), threads, lds_bytes, stream>>>(a);
+    EGC_LAUNCH_CHECK("agg_rows_kernel");
+  }
   agg_merge_kernel<CHUNKS><<<(unsigned)ceil_div(caps.cap_long, wpb), threads, lds_bytes, stream>>>(a);
   EGC_LAUNCH_CHECK("agg_merge_kernel");
   return EGC_OK;
@@ -661,6 +666,8 @@ static int aggregate_combine_impl(const egc_graph* graph, const egc_layer* layer
   a.bias = bias;
   a.out = out;
   a.n_nodes = (int)n;
+  a.l4_off = 0;
+  a.wide_p0 = a.wide_p1 = 0;
   a.row_begin = (int)row_begin;
   a.row_end = row_end < 0 ? (int)n : (int)row_end;
   if (a.row_begin < 0 || a.row_end > (int)n) return EGC_ERR_INVALID;
@@ -742,7 +749,8 @@ static int aggregate_combine_impl(const egc_graph* graph, const egc_layer* layer
 
   switch (chunks) {
     case 1: return launch_all<1>(a, n, caps, wpb, lds_bytes, stream);
-    case 2: return launch_all<2>(a, n, caps, wpb, lds_bytes, stream);
+    case 2: return launch_all<2>(a, n, caps, wpb, lds_bytes, stream,
+                                 !force_generic && getenv("EGC_NO_WIDE") == nullptr && wide_path_supported(a, layer->weight_layout));
     case 3: return launch_all<3>(a, n, caps, wpb, lds_bytes, stream);
     case 4: return launch_all<4>(a, n, caps, wpb, lds_bytes, stream);
     default: return EGC_ERR_UNSUPPORTED;

@@ -71,6 +71,8 @@ struct AggArgs {
   int chunk_blocks;        // leading blocks of the grid that take long-row chunks
   int need_mean, need_var;
   int n_chunks_hint;       // host-known number of long-row chunks, or -1 (launch for the capacity)
+  int l4_off;              // two-slots-per-lane kernel: first slot (inside a basis) of the set being finished (else 0)
+  int wide_p0, wide_p1;    // two-slots-per-lane kernel: slots per basis of the lane's first / second set (P0 + P1 = Ls / 4)
   int w_lds_stride;        // floats between the per-group weight strips in LDS
   int bias_lds_floats;     // floats of the per-wavefront bias strip in LDS
   // training forward only (egc_aggregate_combine_train_f32): the row's raw running aggregates, after the
@@ -183,6 +185,9 @@ __device__ inline __amdgpu_buffer_rsrc_t bases_rsrc(const AggArgs& a) {
 // Returns EGC_OK, an error, or EGC_ERR_UNSUPPORTED when the generic path must be used instead.
 bool fast_path_supported(const AggArgs& a, int layout, int chunks);
 int launch_fast(AggArgs a, int64_t n_nodes, const PlanCaps& caps, hipStream_t stream);
+// rows of 65..128 slots (the two ogbg-code nets): two slots per lane, short rows only (egc_aggregate_fast.hip)
+bool wide_path_supported(const AggArgs& a, int layout);
+int launch_wide_rows(AggArgs a, hipStream_t stream);
 
 // egc_aggregate_fusedw.hip: the same with the weightings Linear computed inside the launch (a.x, a.wfrag, ...).
 constexpr int FUSEDW_QUEUE_INTS = 16;  // work-queue shards + exit counter (workspace, zero on entry and on exit)

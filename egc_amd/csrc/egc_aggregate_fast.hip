@@ -158,6 +158,181 @@ agg_fast_kernel(AggArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Rows of 65 .. 128 slots (the reference's two ogbg-code nets: 300/H4/B4 -> 76 slots, 304/H8/B8 -> 80 slots with padded
+// bases; run_pretrained.sh:47-48, code/models.py:226-234): one row per wavefront, TWO slots per lane.  The slots of every
+// basis are cut into a first set of P0 and a second set of P1 = P - P0: lane q holds slot (b = q / P0, l4 = q % P0) of
+// the first set and slot (b = q / P1, P0 + q % P1) of the second.  Each set is a complete sub-layer over its own
+// channels (every basis present, <= 64 lanes), so the register epilogue of the fast kernels runs once per set, unchanged
+// but for the channel offset (l4_off); a neighbour row is gathered whole, as two 16-byte loads per lane.  Short rows only:
+// long rows keep the chunk + merge kernels of egc_aggregate.hip.  Inference form.
+// ---------------------------------------------------------------------------------------------
+constexpr int WFU = 2;   // neighbour rows in flight per wavefront (two slots each)
+
+template <int HPB, int NEED>
+__global__ void __launch_bounds__(256) agg_wide_kernel(AggArgs a) {
+  using C = RtCfg;
+  extern __shared__ float smem[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const unsigned row_bytes = (unsigned)a.ldb * 4u;
+  const int F_out = a.F_out;
+  float* lds_bias = smem + wave * a.lds_floats_per_wave;
+  const bool post = a.post_scale != nullptr;
+  float* lds_scale = lds_bias + a.bias_lds_floats;
+  float* lds_w = lds_bias + (post ? 2 : 1) * a.bias_lds_floats;
+  for (int o = lane; o < a.H * a.Ls; o += 64) {
+    const int h = o / a.Ls, l = o - h * a.Ls;
+    const int c = h * a.L + l;
+    const bool real = l < a.L;
+    float bv = (a.bias != nullptr && real) ? a.bias[c] : 0.f;
+    if (post) {
+      const float sc = real ? a.post_scale[c] : 0.f;
+      bv = fmaf(bv, sc, real ? a.post_shift[c] : 0.f);
+      lds_scale[o] = sc;
+    }
+    lds_bias[o] = bv;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  FastRsrc R;
+  R.bases = bases_rsrc(a);
+  R.out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (unsigned)a.n_nodes * (unsigned)F_out * 4u, 0x00020000);
+  R.res = __builtin_amdgcn_make_buffer_rsrc((void*)(a.residual != nullptr ? a.residual : a.out), 0,
+                                            (unsigned)a.n_nodes * (unsigned)F_out * 4u, 0x00020000);
+  const bool looped_any = a.x_looped || a.y_looped;
+  // the two per-set views of the layer: lanes per basis, live lanes, channel offset
+  AggArgs a0 = a, a1 = a;
+  const int P = a.Ls >> 2, P0 = a.wide_p0, P1 = a.wide_p1;
+  a0.lanes_pb = P0; a0.slots = a.B * P0; a0.l4_off = 0;
+  a1.lanes_pb = P1; a1.slots = a.B * P1; a1.l4_off = P0;
+  a0.magic_P = (unsigned)(((uint64_t)1 << 32) / (uint64_t)P0) + 1u;
+  a1.magic_P = (unsigned)(((uint64_t)1 << 32) / (uint64_t)P1) + 1u;
+  a0.lpb_log2 = a1.lpb_log2 = -1;    // division + rotation butterfly (P0, P1 are rarely powers of two)
+  const int b0 = min((int)__umulhi((unsigned)lane, a0.magic_P), a.B - 1), b1 = min((int)__umulhi((unsigned)lane, a1.magic_P), a.B - 1);
+  const bool live0 = lane < a0.slots, live1 = lane < a1.slots;
+  const unsigned so0 = (unsigned)(b0 * P + (lane - b0 * P0)) * 16u;            // byte offset of the lane's two slots in a row
+  const unsigned so1 = (unsigned)(b1 * P + P0 + (lane - b1 * P1)) * 16u;
+
+  const int Q = a.rows_per_wave;
+  const int gw = (int)blockIdx.x * 4 + wave;
+  const int r0 = __builtin_amdgcn_readfirstlane(a.row_begin + gw * Q);
+  const int n_end = a.row_end;
+  if (r0 >= n_end) return;
+  const int rp = a.rowptr[min(r0 + lane, a.n_nodes)];
+  for (int k = 0; k < Q; ++k) {
+    const int row = r0 + k;
+    if (row >= n_end) break;
+    const int start = __builtin_amdgcn_readfirstlane(bperm(k << 2, rp));
+    const int deg = __builtin_amdgcn_readfirstlane(bperm((k + 1) << 2, rp)) - start;
+    if (deg > EGC_LONG_ROW_THRESHOLD) continue;     // chunk + merge kernels
+    const int nd = deg;
+    const bool pv = lane < nd;
+    const int jj = pv ? a.col[start + lane] : 0;
+    const float dd = !pv ? 0.f : a.edis != nullptr ? a.edis[start + lane] : a.dis != nullptr ? a.dis[jj] : 0.f;
+    const float dis_i = a.dis != nullptr ? a.dis[row] : 0.f;
+    // row-only operands
+    f4 wpre[2], vself0, vself1;
+    const bool has_self = a.loops_all || row <= *a.max_index;
+    const bool want_self = looped_any && has_self;
+    vself0 = load_slot(R.bases, (want_self && live0) ? (unsigned)row * row_bytes + so0 : OOB);
+    vself1 = load_slot(R.bases, (want_self && live1) ? (unsigned)row * row_bytes + so1 : OOB);
+    {
+      const float* wrow = a.weightings + (int64_t)row * a.ldw;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int c0 = (lane + kk * 64) * 4;
+        wpre[kk] = f4{0.f, 0.f, 0.f, 0.f};
+        if (c0 + 3 < a.W) wpre[kk] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(wrow + c0));
+        else if (c0 < a.W) {
+          wpre[kk].x = wrow[c0];
+          if (c0 + 1 < a.W) wpre[kk].y = wrow[c0 + 1];
+          if (c0 + 2 < a.W) wpre[kk].z = wrow[c0 + 2];
+        }
+      }
+    }
+    int nself = 0;
+    if (looped_any) nself = __popcll(__ballot(pv && jj == row));
+    FAcc<NEED> acc0, acc1;
+    acc0.init();
+    acc1.init();
+    for (int t0 = 0; t0 < nd; t0 += WFU) {
+      f4 v0[WFU], v1[WFU];
+      float w[WFU];
+      bool in_x[WFU];
+#pragma unroll
+      for (int u = 0; u < WFU; ++u) {
+        const int addr = (t0 + u) << 2;
+        const int j = bperm(addr, jj);
+        const bool is_self = j == row;
+        in_x[u] = (t0 + u < nd) && !(a.x_looped && is_self);
+        const unsigned base = (unsigned)j * row_bytes;
+        v0[u] = load_slot(R.bases, (in_x[u] && live0) ? base + so0 : OOB);
+        v1[u] = load_slot(R.bases, (in_x[u] && live1) ? base + so1 : OOB);
+        w[u] = bperm(addr, dd) * dis_i;
+        if (a.y_looped && !a.x_looped) w[u] = is_self ? 0.f : w[u];
+      }
+#pragma unroll
+      for (int u = 0; u < WFU; ++u) {
+        fold<NEED>(acc0, v0[u], w[u], in_x[u] && live0, start + t0 + u);
+        fold<NEED>(acc1, v1[u], w[u], in_x[u] && live1, start + t0 + u);
+      }
+    }
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    finish_group<6, HPB, NEED, C>(a0, R, ln, row, true, acc0, nd, nself, dis_i, vself0, has_self, wpre, true, lds_w, lds_bias, lds_scale);
+    finish_group<6, HPB, NEED, C>(a1, R, ln, row, true, acc1, nd, nself, dis_i, vself1, has_self, wpre, true, lds_w, lds_bias, lds_scale);
+  }
+}
+
+bool wide_path_supported(const AggArgs& a, int layout) {
+  if (layout != EGC_LAYOUT_HBA || a.act == EGC_ACT_SOFTMAX) return false;
+  if (a.x_looped && !a.y_looped) return false;
+  if (a.slots <= 64 || a.slots > 128) return false;
+  if ((a.Ls & 3) != 0 || a.ldb != a.B * a.Ls) return false;          // every 16-byte slot belongs to one basis (padded bases)
+  if ((a.B & (a.B - 1)) != 0) return false;
+  if (a.A < 1 || a.A > AMAX) return false;
+  if ((a.H + a.B - 1) / a.B > HPB_MAX) return false;
+  if (a.W > 512) return false;                                        // weightings row: 2 x 16 bytes per lane
+  const int P = a.Ls / 4, P0 = (P + 1) / 2;
+  if (a.B * P0 > 64) return false;
+  if (a.stats != nullptr || a.arg_max != nullptr || a.arg_min != nullptr) return false;   // inference form
+  if ((uint64_t)a.n_nodes * (uint64_t)a.F_out * 4ull > (uint64_t)OOB) return false;
+  return true;
+}
+
+template <int HPB>
+static int launch_wide_need(const AggArgs& a, int need, unsigned grid, size_t lds, hipStream_t stream) {
+  if (need == 0) agg_wide_kernel<HPB, 0><<<grid, 256, lds, stream>>>(a);
+  else agg_wide_kernel<HPB, NEED_SQ | NEED_MN><<<grid, 256, lds, stream>>>(a);
+  EGC_LAUNCH_CHECK("agg_wide_kernel");
+  return EGC_OK;
+}
+
+int launch_wide_rows(AggArgs a, hipStream_t stream) {
+  const int P = a.Ls / 4;
+  a.wide_p0 = (P + 1) / 2;
+  a.wide_p1 = P - a.wide_p0;
+  a.l4_off = 0;
+  a.rows_per_wave = 8;
+  a.need_mean = a.need_var = 0;
+  int need = 0;
+  for (int t = 0; t < a.A; ++t) {
+    if (a.aggr[t] == EGC_AGGR_MEAN || a.aggr[t] == EGC_AGGR_VAR || a.aggr[t] == EGC_AGGR_STD) a.need_mean = 1;
+    if (a.aggr[t] == EGC_AGGR_VAR || a.aggr[t] == EGC_AGGR_STD) { a.need_var = 1; need |= NEED_SQ; }
+    if (a.aggr[t] == EGC_AGGR_MIN) need |= NEED_MN;
+  }
+  a.w_lds_stride = (a.W + 3) & ~3;
+  a.bias_lds_floats = (a.H * a.Ls + 3) & ~3;
+  a.lds_floats_per_wave = (a.post_scale != nullptr ? 2 : 1) * a.bias_lds_floats + a.w_lds_stride;   // G = 1
+  const size_t lds = (size_t)4 * a.lds_floats_per_wave * sizeof(float);
+  if (lds > 64 * 1024) return EGC_ERR_UNSUPPORTED;
+  const unsigned grid = (unsigned)ceil_div((int64_t)a.row_end - a.row_begin, (int64_t)4 * a.rows_per_wave);
+  const int hpb = (a.H + a.B - 1) / a.B;
+  if (hpb <= 1) return launch_wide_need<1>(a, need, grid, lds, stream);
+  if (hpb <= 2) return launch_wide_need<2>(a, need, grid, lds, stream);
+  return launch_wide_need<4>(a, need, grid, lds, stream);
+}
+
 bool fast_path_supported(const AggArgs& a, int layout, int chunks) {
   if (chunks != 1 || layout != EGC_LAYOUT_HBA || a.act == EGC_ACT_SOFTMAX) return false;
   if (a.x_looped && !a.y_looped) return false;  // never produced by either layer class

@@ -50,6 +50,7 @@ struct RtCfg {
   static __device__ inline bool loops_all(const AggArgs& a) { return a.loops_all != 0; }
   static __device__ inline bool need_mean(const AggArgs& a) { return a.need_mean != 0; }
   static __device__ inline int aggr(const AggArgs& a, int t) { return a.aggr[t]; }
+  static __device__ inline int l4_off(const AggArgs& a) { return a.l4_off; }
 };
 
 constexpr int ilog2(int x) { return x <= 1 ? 0 : 1 + ilog2(x >> 1); }
@@ -92,6 +93,7 @@ struct StCfg {
     return has(EGC_AGGR_MEAN) || has(EGC_AGGR_VAR) || has(EGC_AGGR_STD);
   }
   static __device__ inline constexpr int aggr(const AggArgs&, int t) { return agg_at(t); }
+  static __device__ inline constexpr int l4_off(const AggArgs&) { return 0; }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -473,7 +475,9 @@ __device__ inline void finish_group(const AggArgs& a, const FastRsrc& R, int lan
       if (b == bb) o[hb] = part;
     }
   }
-  // (4) bias + store: lane (b, l4) owns out[row, (hb*B + b)*L + 4*l4 ..+3]
+  // (4) bias + store: lane (b, l4) owns out[row, (hb*B + b)*L + 4*l4 ..+3]  (two-slots-per-lane kernel: the second set of
+  // a lane's slots starts l4_off slots into every basis)
+  l4 += C::l4_off(a);
   const unsigned orow = (unsigned)row * (unsigned)C::F_out(a) * 4u;
 #pragma unroll
   for (int hb = 0; hb < HPB; ++hb) {

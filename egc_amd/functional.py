@@ -50,10 +50,11 @@ class LayerSpec:
 def padded_basis_stride(out_channels: int, num_heads: int, num_bases: int) -> int:
     """Basis stride the layers use: L itself when it is a multiple of 4; otherwise L rounded up to 4 -- each
     basis then owns whole 16-byte slots and the register-resident kernels apply -- as long as the padded row
-    still fits their 64 slots (beyond that the LDS-based kernels run either way and padding buys nothing)."""
+    still fits their 128 slots (64: one slot per lane; 65-128, the two ogbg-code nets: two slots per lane, round 3;
+    beyond that the LDS-based kernels run either way and padding buys nothing)."""
     L = out_channels // num_heads
     Lp = (L + 3) & ~3
-    return Lp if (Lp != L and num_bases * Lp <= 256) else L
+    return Lp if (Lp != L and num_bases * Lp <= 512) else L
 
 
 def pad_bases_columns(w: torch.Tensor, num_bases: int, basis_len: int, basis_stride: int) -> torch.Tensor:
