@@ -445,7 +445,8 @@ static WsLayout ws_layout(const egc_layer* L, int64_t n_nodes, int64_t n_edges, 
   // publishes it.  The register-resident kernels lay a record out by their lane-group size (16 / 32 / 64 lanes),
   // which exceeds the row's slot count whenever that is not 16, 32 or 64 -- size the buffer by the larger of the two.
   const int slots = ldb / 4;
-  const int rec_lanes = slots <= 16 ? 16 : slots <= 32 ? 32 : slots <= 64 ? 64 : slots;
+  // (65..128 slots: the two-slots-per-lane kernel publishes 5 aggregates x 2 sets x 64 lanes = 640 slots-of-16-bytes per chunk)
+  const int rec_lanes = slots <= 16 ? 16 : slots <= 32 ? 32 : slots <= 64 ? 64 : slots <= 128 ? 128 : slots;
   // chunk slots that can be written: the plan's capacity, or the host-known chunk count of this graph
   const int64_t rec_chunks = (n_chunks >= 0 && n_chunks <= c.cap_chunks) ? n_chunks : c.cap_chunks;
   w.partial_bytes = align256((size_t)rec_chunks * 7 * rec_lanes * 16);
@@ -465,16 +466,13 @@ static int launch_all(const AggArgs& a, int64_t n_nodes, const PlanCaps& caps, i
   // their chain of dependent memory round trips, i.e. by occupancy: 887 -> 802 us at 300/H4/B4 on the arxiv graph.
   constexpr int U = CHUNKS == 1 ? 4 : 2;
   const int threads = wpb * 64;
+  if (wide_rows)   // 65..128 slots per row: the two-slots-per-lane register kernel, long-row chunks included (egc_aggregate_fast.hip)
+    return launch_wide_rows(a, caps, stream);
   // long-row chunks first (they are the longest work items), then the per-row kernel, then the merge
   agg_chunks_kernel<CHUNKS, U><<<(unsigned)ceil_div(caps.cap_chunks, 4), 256, 0, stream>>>(a);
   EGC_LAUNCH_CHECK("agg_chunks_kernel");
-  if (wide_rows) {   // 65..128 slots per row: the short rows on the two-slots-per-lane register kernel (egc_aggregate_fast.hip)
-    const int st = launch_wide_rows(a, stream);
-    if (st != EGC_OK) return st;
-  } else {
-    agg_rows_kernel<CHUNKS, U><<<(unsigned)ceil_div(a.row_end - a.row_begin, wpb), threads, lds_bytes, stream>>>(a);
-    EGC_LAUNCH_CHECK("agg_rows_kernel");
-  }
+  agg_rows_kernel<CHUNKS, U><<<(unsigned)ceil_div(a.row_end - a.row_begin, wpb), threads, lds_bytes, stream>>>(a);
+  EGC_LAUNCH_CHECK("agg_rows_kernel");
   agg_merge_kernel<CHUNKS><<<(unsigned)ceil_div(caps.cap_long, wpb), threads, lds_bytes, stream>>>(a);
   EGC_LAUNCH_CHECK("agg_merge_kernel");
   return EGC_OK;

@@ -66,6 +66,7 @@ struct AggArgs {
   int lpb_log2;            // log2(lanes per basis block) = log2(L / 4), or -1: not a power-of-two layout
   int lanes_pb;            // L / 4
   unsigned magic_P;        // floor(2^32 / lanes_pb) + 1
+  unsigned magic_P1;       // two-slots-per-lane kernel: the same for the second set (wide_p1)
   int hpg;                 // heads per lane group = ceil(H / G)
   int rows_per_wave;
   int chunk_blocks;        // leading blocks of the grid that take long-row chunks
@@ -187,7 +188,7 @@ bool fast_path_supported(const AggArgs& a, int layout, int chunks);
 int launch_fast(AggArgs a, int64_t n_nodes, const PlanCaps& caps, hipStream_t stream);
 // rows of 65..128 slots (the two ogbg-code nets): two slots per lane, short rows only (egc_aggregate_fast.hip)
 bool wide_path_supported(const AggArgs& a, int layout);
-int launch_wide_rows(AggArgs a, hipStream_t stream);
+int launch_wide_rows(AggArgs a, const PlanCaps& caps, hipStream_t stream);   // short rows AND long-row chunks: one launch
 
 // egc_aggregate_fusedw.hip: the same with the weightings Linear computed inside the launch (a.x, a.wfrag, ...).
 constexpr int FUSEDW_QUEUE_INTS = 16;  // work-queue shards + exit counter (workspace, zero on entry and on exit)

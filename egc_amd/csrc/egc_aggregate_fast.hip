@@ -169,22 +169,196 @@ agg_fast_kernel(AggArgs a) {
 // ---------------------------------------------------------------------------------------------
 constexpr int WFU = 2;   // neighbour rows in flight per wavefront (two slots each)
 
-template <int HPB, int NEED>
+// The per-set views of a layer description: the set's lanes per basis and its first slot inside a basis.  Over a
+// compile-time configuration (StCfg) both are constants; over RtCfg they come from the kernel arguments
+// (wide_p0 / wide_p1), selected by SET.
+template <class Base, int SET, int PS = 0, int OFF = 0>
+struct WideSet : Base {
+  static constexpr bool stat = PS > 0;
+  static __device__ inline int lanes_pb(const AggArgs& a) { return stat ? PS : (SET == 0 ? a.wide_p0 : a.wide_p1); }
+  static __device__ inline int slots(const AggArgs& a) { return Base::B(a) * lanes_pb(a); }
+  static __device__ inline bool pow2(const AggArgs& a) { return stat ? ((PS & (PS - 1)) == 0 && (Base::B(a) & (Base::B(a) - 1)) == 0) : false; }
+  static __device__ inline int lpb_log2(const AggArgs&) { return stat ? ilog2(PS > 0 ? PS : 1) : -1; }
+  static __device__ inline int basis_of(const AggArgs& a, int q) {
+    return stat ? q / (PS > 0 ? PS : 1) : (int)__umulhi((unsigned)q, SET == 0 ? a.magic_P : a.magic_P1);
+  }
+  static __device__ inline int l4_off(const AggArgs& a) { return stat ? OFF : (SET == 0 ? 0 : a.wide_p0); }
+};
+
+struct WideLane {   // what a lane needs to address its two slots
+  bool live0, live1;
+  unsigned so0, so1;
+};
+
+template <class C0, class C1>
+__device__ inline WideLane wide_lane(const AggArgs& a, int lane) {
+  WideLane w;
+  const int P = a.Ls >> 2, B = C0::B(a);
+  const int b0 = min(C0::basis_of(a, lane), B - 1), b1 = min(C1::basis_of(a, lane), B - 1);
+  w.live0 = lane < C0::slots(a);
+  w.live1 = lane < C1::slots(a);
+  w.so0 = (unsigned)(b0 * P + (lane - b0 * C0::lanes_pb(a))) * 16u;
+  w.so1 = (unsigned)(b1 * P + C1::l4_off(a) + (lane - b1 * C1::lanes_pb(a))) * 16u;
+  return w;
+}
+
+// 64 staged entries (jj, dd in the lanes; `cnt` of them valid) folded into the two sets
+template <int NEED, class C0>
+__device__ inline void wide_gather(const AggArgs& a, const FastRsrc& R, const WideLane& wl_, FAcc<NEED>& acc0, FAcc<NEED>& acc1,
+                                   int row, int jj, float dd, float dis_i, int cnt, unsigned row_bytes, int pos_base) {
+  for (int t0 = 0; t0 < cnt; t0 += WFU) {
+    f4 v0[WFU], v1[WFU];
+    float w[WFU];
+    bool in_x[WFU];
+#pragma unroll
+    for (int u = 0; u < WFU; ++u) {
+      const int addr = (t0 + u) << 2;
+      const int j = bperm(addr, jj);
+      const bool is_self = j == row;
+      in_x[u] = (t0 + u < cnt) && !(C0::xl(a) && is_self);
+      const unsigned base = (unsigned)j * row_bytes;
+      v0[u] = load_slot(R.bases, (in_x[u] && wl_.live0) ? base + wl_.so0 : OOB);
+      v1[u] = load_slot(R.bases, (in_x[u] && wl_.live1) ? base + wl_.so1 : OOB);
+      w[u] = bperm(addr, dd) * dis_i;
+      if (C0::yl(a) && !C0::xl(a)) w[u] = is_self ? 0.f : w[u];
+    }
+#pragma unroll
+    for (int u = 0; u < WFU; ++u) {
+      fold<NEED>(acc0, v0[u], w[u], in_x[u] && wl_.live0, pos_base + t0 + u);
+      fold<NEED>(acc1, v1[u], w[u], in_x[u] && wl_.live1, pos_base + t0 + u);
+    }
+  }
+}
+
+// row-only operands + the two epilogues
+template <int HPB, int NEED, class C0, class C1>
+__device__ inline void wide_finish(const AggArgs& a, const FastRsrc& R, const WideLane& wl_, int lane, int row, FAcc<NEED>& acc0,
+                                   FAcc<NEED>& acc1, int deg, int nself, float dis_i, unsigned row_bytes, float* lds_w,
+                                   const float* lds_bias, const float* lds_scale) {
+  const bool looped_any = C0::xl(a) || C0::yl(a);
+  const bool has_self = C0::loops_all(a) || row <= *a.max_index;
+  const bool want_self = looped_any && has_self;
+  const f4 vself0 = load_slot(R.bases, (want_self && wl_.live0) ? (unsigned)row * row_bytes + wl_.so0 : OOB);
+  const f4 vself1 = load_slot(R.bases, (want_self && wl_.live1) ? (unsigned)row * row_bytes + wl_.so1 : OOB);
+  f4 wpre[2];
+  const float* wrow = a.weightings + (int64_t)row * a.ldw;
+  const int W = C0::W(a);
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const int c0 = (lane + kk * 64) * 4;
+    wpre[kk] = f4{0.f, 0.f, 0.f, 0.f};
+    if (c0 + 3 < W) wpre[kk] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(wrow + c0));
+    else if (c0 < W) {
+      wpre[kk].x = wrow[c0];
+      if (c0 + 1 < W) wpre[kk].y = wrow[c0 + 1];
+      if (c0 + 2 < W) wpre[kk].z = wrow[c0 + 2];
+    }
+  }
+  int ln = lane;
+  asm volatile("" : "+v"(ln));
+  finish_group<6, HPB, NEED, C0>(a, R, ln, row, true, acc0, deg, nself, dis_i, vself0, has_self, wpre, true, lds_w, lds_bias, lds_scale);
+  finish_group<6, HPB, NEED, C1>(a, R, ln, row, true, acc1, deg, nself, dis_i, vself1, has_self, wpre, true, lds_w, lds_bias, lds_scale);
+}
+
+// chunk record of the two-slots-per-lane kernel: [5 aggregates][2 sets][64 lanes] float4 (the workspace holds 7 x 128)
+constexpr int WREC = 5 * 2 * 64;
+
+template <int HPB, int NEED, class C0, class C1>
+__device__ inline void wide_long_row_chunk(const AggArgs& a, const FastRsrc& R, const WideLane& wl_, int c, int lane,
+                                           unsigned row_bytes, float* lds_w, const float* lds_bias, const float* lds_scale) {
+  if (c >= a.plan[1]) return;
+  const int cap_long = a.plan[2], cap_chunks = a.plan[3];
+  const int* long_row = a.plan + 4;
+  const int* long_chunk0 = long_row + cap_long;
+  const int* chunk_slot = long_chunk0 + cap_long;
+  const int* chunk_begin = chunk_slot + cap_chunks;
+  const int slot = __builtin_amdgcn_readfirstlane(chunk_slot[c]);
+  const int row = __builtin_amdgcn_readfirstlane(long_row[slot]);
+  if (row < a.row_begin || row >= a.row_end) return;
+  const int start = __builtin_amdgcn_readfirstlane(chunk_begin[c]);
+  const int row_start = __builtin_amdgcn_readfirstlane(a.rowptr[row]);
+  const int row_end = __builtin_amdgcn_readfirstlane(a.rowptr[row + 1]);
+  const int end = min(start + EGC_LONG_ROW_CHUNK, row_end);
+  const int deg = row_end - row_start;
+  const int nch = (deg + EGC_LONG_ROW_CHUNK - 1) / EGC_LONG_ROW_CHUNK;
+  const float dis_i = a.dis != nullptr ? a.dis[row] : 0.f;
+  const bool looped_any = C0::xl(a) || C0::yl(a);
+  FAcc<NEED> acc0, acc1;
+  acc0.init();
+  acc1.init();
+  int nself = 0;
+  for (int base = start; base < end; base += 64) {
+    const int p = base + lane;
+    const bool pv = p < end;
+    const int jj = pv ? a.col[p] : row;
+    const float dd = a.edis != nullptr ? (pv ? a.edis[p] : 0.f) : (a.dis != nullptr ? a.dis[jj] : 0.f);
+    if (looped_any) nself += __popcll(__ballot(pv && jj == row));
+    wide_gather<NEED, C0>(a, R, wl_, acc0, acc1, row, jj, dd, dis_i, min(64, end - base), row_bytes, base);
+  }
+  if (nch > 1) {
+    // publication as in long_row_chunk (egc_aggregate_fast_dev.h): write-through stores, drained, then the counter
+    constexpr int WT = 0x11;
+    const __amdgpu_buffer_rsrc_t pw = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(reinterpret_cast<f4*>(a.partial) + (int64_t)c * WREC), 0, (unsigned)WREC * 16u, 0x00020000);
+    const unsigned po = (unsigned)lane * 16u;
+    auto put = [&](int k, f4 v0, f4 v1) {
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v0), pw, po, (k * 2 + 0) * 64 * 16, WT);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v1), pw, po, (k * 2 + 1) * 64 * 16, WT);
+    };
+    put(0, acc0.sum, acc1.sum);
+    put(2, acc0.mx, acc1.mx);
+    put(4, acc0.ws, acc1.ws);
+    if constexpr (NEED & NEED_SQ) put(1, acc0.sq, acc1.sq);
+    if constexpr (NEED & NEED_MN) put(3, acc0.mn, acc1.mn);
+    const __amdgpu_buffer_rsrc_t pn = __builtin_amdgcn_make_buffer_rsrc((void*)(a.partial_nself + c), 0, 4u, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b32(nself, pn, lane == 0 ? 0u : OOB, 0, WT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int arrived = 0;
+    if (lane == 0) arrived = __hip_atomic_fetch_add(&a.counters[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    arrived = __builtin_amdgcn_readfirstlane(arrived);
+    if (arrived != nch - 1) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(&a.counters[slot], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int c0 = __builtin_amdgcn_readfirstlane(long_chunk0[slot]);
+    acc0.init();
+    acc1.init();
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(reinterpret_cast<const f4*>(a.partial) + (int64_t)c0 * WREC), 0, (unsigned)nch * (unsigned)WREC * 16u, 0x00020000);
+    for (int kk = 0; kk < nch; ++kk) {   // chunk order: deterministic
+      const unsigned off = ((unsigned)kk * WREC + (unsigned)lane) * 16u;
+      auto get = [&](int k, int s_) { return load_slot_wt(prs, off + (unsigned)((k * 2 + s_) * 64 * 16)); };
+      acc0.sum += get(0, 0); acc1.sum += get(0, 1);
+      acc0.ws += get(4, 0); acc1.ws += get(4, 1);
+      acc0.mx = f4_vmax(acc0.mx, get(2, 0)); acc1.mx = f4_vmax(acc1.mx, get(2, 1));
+      if constexpr (NEED & NEED_SQ) { acc0.sq += get(1, 0); acc1.sq += get(1, 1); }
+      if constexpr (NEED & NEED_MN) { acc0.mn = f4_vmin(acc0.mn, get(3, 0)); acc1.mn = f4_vmin(acc1.mn, get(3, 1)); }
+    }
+    nself = 0;
+    for (int k = lane; k < nch; k += 64)
+      nself += __hip_atomic_load(&a.partial_nself[c0 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nself += bperm((lane ^ off) << 2, nself);
+  }
+  wide_finish<HPB, NEED, C0, C1>(a, R, wl_, lane, row, acc0, acc1, deg, nself, dis_i, row_bytes, lds_w, lds_bias, lds_scale);
+}
+
+template <int HPB, int NEED, class C0, class C1>
 __global__ void __launch_bounds__(256) agg_wide_kernel(AggArgs a) {
-  using C = RtCfg;
   extern __shared__ float smem[];
+  if ((int)blockIdx.x < a.chunk_blocks && (int)blockIdx.x * 4 >= a.plan[1]) return;  // unused chunk slots
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const unsigned row_bytes = (unsigned)a.ldb * 4u;
-  const int F_out = a.F_out;
+  const int F_out = C0::F_out(a);
   float* lds_bias = smem + wave * a.lds_floats_per_wave;
   const bool post = a.post_scale != nullptr;
   float* lds_scale = lds_bias + a.bias_lds_floats;
   float* lds_w = lds_bias + (post ? 2 : 1) * a.bias_lds_floats;
-  for (int o = lane; o < a.H * a.Ls; o += 64) {
-    const int h = o / a.Ls, l = o - h * a.Ls;
-    const int c = h * a.L + l;
-    const bool real = l < a.L;
+  for (int o = lane; o < C0::H(a) * C0::Ls(a); o += 64) {
+    const int h = o / C0::Ls(a), l = o - h * C0::Ls(a);
+    const int c = h * C0::L(a) + l;
+    const bool real = l < C0::L(a);
     float bv = (a.bias != nullptr && real) ? a.bias[c] : 0.f;
     if (post) {
       const float sc = real ? a.post_scale[c] : 0.f;
@@ -199,22 +373,16 @@ __global__ void __launch_bounds__(256) agg_wide_kernel(AggArgs a) {
   R.out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (unsigned)a.n_nodes * (unsigned)F_out * 4u, 0x00020000);
   R.res = __builtin_amdgcn_make_buffer_rsrc((void*)(a.residual != nullptr ? a.residual : a.out), 0,
                                             (unsigned)a.n_nodes * (unsigned)F_out * 4u, 0x00020000);
-  const bool looped_any = a.x_looped || a.y_looped;
-  // the two per-set views of the layer: lanes per basis, live lanes, channel offset
-  AggArgs a0 = a, a1 = a;
-  const int P = a.Ls >> 2, P0 = a.wide_p0, P1 = a.wide_p1;
-  a0.lanes_pb = P0; a0.slots = a.B * P0; a0.l4_off = 0;
-  a1.lanes_pb = P1; a1.slots = a.B * P1; a1.l4_off = P0;
-  a0.magic_P = (unsigned)(((uint64_t)1 << 32) / (uint64_t)P0) + 1u;
-  a1.magic_P = (unsigned)(((uint64_t)1 << 32) / (uint64_t)P1) + 1u;
-  a0.lpb_log2 = a1.lpb_log2 = -1;    // division + rotation butterfly (P0, P1 are rarely powers of two)
-  const int b0 = min((int)__umulhi((unsigned)lane, a0.magic_P), a.B - 1), b1 = min((int)__umulhi((unsigned)lane, a1.magic_P), a.B - 1);
-  const bool live0 = lane < a0.slots, live1 = lane < a1.slots;
-  const unsigned so0 = (unsigned)(b0 * P + (lane - b0 * P0)) * 16u;            // byte offset of the lane's two slots in a row
-  const unsigned so1 = (unsigned)(b1 * P + P0 + (lane - b1 * P1)) * 16u;
+  const WideLane wl_ = wide_lane<C0, C1>(a, lane);
 
+  if ((int)blockIdx.x < a.chunk_blocks) {   // long-row chunk role
+    const int c = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+    wide_long_row_chunk<HPB, NEED, C0, C1>(a, R, wl_, c, lane, row_bytes, lds_w, lds_bias, lds_scale);
+    return;
+  }
+  const bool looped_any = C0::xl(a) || C0::yl(a);
   const int Q = a.rows_per_wave;
-  const int gw = (int)blockIdx.x * 4 + wave;
+  const int gw = ((int)blockIdx.x - a.chunk_blocks) * 4 + wave;
   const int r0 = __builtin_amdgcn_readfirstlane(a.row_begin + gw * Q);
   const int n_end = a.row_end;
   if (r0 >= n_end) return;
@@ -224,63 +392,17 @@ __global__ void __launch_bounds__(256) agg_wide_kernel(AggArgs a) {
     if (row >= n_end) break;
     const int start = __builtin_amdgcn_readfirstlane(bperm(k << 2, rp));
     const int deg = __builtin_amdgcn_readfirstlane(bperm((k + 1) << 2, rp)) - start;
-    if (deg > EGC_LONG_ROW_THRESHOLD) continue;     // chunk + merge kernels
-    const int nd = deg;
-    const bool pv = lane < nd;
+    if (deg > EGC_LONG_ROW_THRESHOLD) continue;     // chunk role
+    const bool pv = lane < deg;
     const int jj = pv ? a.col[start + lane] : 0;
     const float dd = !pv ? 0.f : a.edis != nullptr ? a.edis[start + lane] : a.dis != nullptr ? a.dis[jj] : 0.f;
     const float dis_i = a.dis != nullptr ? a.dis[row] : 0.f;
-    // row-only operands
-    f4 wpre[2], vself0, vself1;
-    const bool has_self = a.loops_all || row <= *a.max_index;
-    const bool want_self = looped_any && has_self;
-    vself0 = load_slot(R.bases, (want_self && live0) ? (unsigned)row * row_bytes + so0 : OOB);
-    vself1 = load_slot(R.bases, (want_self && live1) ? (unsigned)row * row_bytes + so1 : OOB);
-    {
-      const float* wrow = a.weightings + (int64_t)row * a.ldw;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const int c0 = (lane + kk * 64) * 4;
-        wpre[kk] = f4{0.f, 0.f, 0.f, 0.f};
-        if (c0 + 3 < a.W) wpre[kk] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(wrow + c0));
-        else if (c0 < a.W) {
-          wpre[kk].x = wrow[c0];
-          if (c0 + 1 < a.W) wpre[kk].y = wrow[c0 + 1];
-          if (c0 + 2 < a.W) wpre[kk].z = wrow[c0 + 2];
-        }
-      }
-    }
-    int nself = 0;
-    if (looped_any) nself = __popcll(__ballot(pv && jj == row));
+    const int nself = looped_any ? __popcll(__ballot(pv && jj == row)) : 0;
     FAcc<NEED> acc0, acc1;
     acc0.init();
     acc1.init();
-    for (int t0 = 0; t0 < nd; t0 += WFU) {
-      f4 v0[WFU], v1[WFU];
-      float w[WFU];
-      bool in_x[WFU];
-#pragma unroll
-      for (int u = 0; u < WFU; ++u) {
-        const int addr = (t0 + u) << 2;
-        const int j = bperm(addr, jj);
-        const bool is_self = j == row;
-        in_x[u] = (t0 + u < nd) && !(a.x_looped && is_self);
-        const unsigned base = (unsigned)j * row_bytes;
-        v0[u] = load_slot(R.bases, (in_x[u] && live0) ? base + so0 : OOB);
-        v1[u] = load_slot(R.bases, (in_x[u] && live1) ? base + so1 : OOB);
-        w[u] = bperm(addr, dd) * dis_i;
-        if (a.y_looped && !a.x_looped) w[u] = is_self ? 0.f : w[u];
-      }
-#pragma unroll
-      for (int u = 0; u < WFU; ++u) {
-        fold<NEED>(acc0, v0[u], w[u], in_x[u] && live0, start + t0 + u);
-        fold<NEED>(acc1, v1[u], w[u], in_x[u] && live1, start + t0 + u);
-      }
-    }
-    int ln = lane;
-    asm volatile("" : "+v"(ln));
-    finish_group<6, HPB, NEED, C>(a0, R, ln, row, true, acc0, nd, nself, dis_i, vself0, has_self, wpre, true, lds_w, lds_bias, lds_scale);
-    finish_group<6, HPB, NEED, C>(a1, R, ln, row, true, acc1, nd, nself, dis_i, vself1, has_self, wpre, true, lds_w, lds_bias, lds_scale);
+    wide_gather<NEED, C0>(a, R, wl_, acc0, acc1, row, jj, dd, dis_i, deg, row_bytes, start);
+    wide_finish<HPB, NEED, C0, C1>(a, R, wl_, lane, row, acc0, acc1, deg, nself, dis_i, row_bytes, lds_w, lds_bias, lds_scale);
   }
 }
 
@@ -300,33 +422,59 @@ bool wide_path_supported(const AggArgs& a, int layout) {
   return true;
 }
 
-template <int HPB>
-static int launch_wide_need(const AggArgs& a, int need, unsigned grid, size_t lds, hipStream_t stream) {
-  if (need == 0) agg_wide_kernel<HPB, 0><<<grid, 256, lds, stream>>>(a);
-  else agg_wide_kernel<HPB, NEED_SQ | NEED_MN><<<grid, 256, lds, stream>>>(a);
+template <int HPB, int NEED, class C0, class C1>
+static int launch_wide_one(const AggArgs& a, unsigned grid, size_t lds, hipStream_t stream) {
+  agg_wide_kernel<HPB, NEED, C0, C1><<<grid, 256, lds, stream>>>(a);
   EGC_LAUNCH_CHECK("agg_wide_kernel");
   return EGC_OK;
 }
 
-int launch_wide_rows(AggArgs a, hipStream_t stream) {
+template <int HPB>
+static int launch_wide_need(const AggArgs& a, int need, unsigned grid, size_t lds, hipStream_t stream) {
+  using R0 = WideSet<RtCfg, 0>;
+  using R1 = WideSet<RtCfg, 1>;
+  if (need == 0) return launch_wide_one<HPB, 0, R0, R1>(a, grid, lds, stream);
+  return launch_wide_one<HPB, NEED_SQ | NEED_MN, R0, R1>(a, grid, lds, stream);
+}
+
+int launch_wide_rows(AggArgs a, const PlanCaps& caps, hipStream_t stream) {
   const int P = a.Ls / 4;
   a.wide_p0 = (P + 1) / 2;
   a.wide_p1 = P - a.wide_p0;
+  a.magic_P = (unsigned)(((uint64_t)1 << 32) / (uint64_t)a.wide_p0) + 1u;
+  a.magic_P1 = (unsigned)(((uint64_t)1 << 32) / (uint64_t)a.wide_p1) + 1u;
+  a.lanes_pb = a.wide_p0;
+  a.lpb_log2 = -1;
   a.l4_off = 0;
   a.rows_per_wave = 8;
+  a.chunk_blocks = (int)ceil_div(a.n_chunks_hint >= 0 ? a.n_chunks_hint : caps.cap_chunks, 4);
   a.need_mean = a.need_var = 0;
   int need = 0;
+  unsigned packed = 0;
   for (int t = 0; t < a.A; ++t) {
     if (a.aggr[t] == EGC_AGGR_MEAN || a.aggr[t] == EGC_AGGR_VAR || a.aggr[t] == EGC_AGGR_STD) a.need_mean = 1;
     if (a.aggr[t] == EGC_AGGR_VAR || a.aggr[t] == EGC_AGGR_STD) { a.need_var = 1; need |= NEED_SQ; }
     if (a.aggr[t] == EGC_AGGR_MIN) need |= NEED_MN;
+    packed |= (unsigned)a.aggr[t] << (3 * t);
   }
   a.w_lds_stride = (a.W + 3) & ~3;
   a.bias_lds_floats = (a.H * a.Ls + 3) & ~3;
   a.lds_floats_per_wave = (a.post_scale != nullptr ? 2 : 1) * a.bias_lds_floats + a.w_lds_stride;   // G = 1
   const size_t lds = (size_t)4 * a.lds_floats_per_wave * sizeof(float);
   if (lds > 64 * 1024) return EGC_ERR_UNSUPPORTED;
-  const unsigned grid = (unsigned)ceil_div((int64_t)a.row_end - a.row_begin, (int64_t)4 * a.rows_per_wave);
+  const unsigned grid = (unsigned)(a.chunk_blocks + ceil_div((int64_t)a.row_end - a.row_begin, (int64_t)4 * a.rows_per_wave));
+  if (getenv("EGC_NO_STATIC_CFG") == nullptr && a.act == EGC_ACT_NONE && !a.x_looped && a.y_looped && a.loops_all) {
+    constexpr int X = EGC_AGGR_MAX, N = EGC_AGGR_MIN, Y = EGC_AGGR_SYMNORM;
+    // the reference's ogbg-code nets (run_pretrained.sh:47-48): EGC-M 300/H4/B4 symadd,min,max and EGC-S 304/H8/B8 symadd
+    if (a.H == 4 && a.B == 4 && a.L == 75 && a.Ls == 76 && a.A == 3 && packed == agg_pack(Y, N, X)) {
+      using St = StCfg<4, 4, 75, 3, agg_pack(Y, N, X), EGC_ACT_NONE, false, true, true, 76>;
+      return launch_wide_one<1, NEED_MN, WideSet<St, 0, 10, 0>, WideSet<St, 1, 9, 10>>(a, grid, lds, stream);
+    }
+    if (a.H == 8 && a.B == 8 && a.L == 38 && a.Ls == 40 && a.A == 1 && packed == agg_pack(Y)) {
+      using St = StCfg<8, 8, 38, 1, agg_pack(Y), EGC_ACT_NONE, false, true, true, 40>;
+      return launch_wide_one<1, 0, WideSet<St, 0, 5, 0>, WideSet<St, 1, 5, 5>>(a, grid, lds, stream);
+    }
+  }
   const int hpb = (a.H + a.B - 1) / a.B;
   if (hpb <= 1) return launch_wide_need<1>(a, need, grid, lds, stream);
   if (hpb <= 2) return launch_wide_need<2>(a, need, grid, lds, stream);

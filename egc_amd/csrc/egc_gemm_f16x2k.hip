@@ -311,7 +311,15 @@ bool f16x2k_shape(int f_in, int f_g, int ldb, int w_cols) {
   const int NT = (ldb + 15) / 16 + (w_cols + 15) / 16;
   const int per_launch = NT <= 16 ? NT : (NT + 1) / 2;   // two launches beyond 16 column tiles
   if ((f_in + 31) / 32 == 12 && per_launch > 12) return false;  // 96 weight registers do not fit four wavefronts per SIMD
-  return NT >= 1 && NT <= 32;
+  if (NT < 1 || NT > 32) return false;
+  // launch_k's staging limits, on the narrower launch: a thread stages at most 16 pieces of 16 bytes of the x tile,
+  // and the tile, its planes and the bias rows fit the LDS (a narrow GEMM over a long k -- the dx GEMM of a layer with
+  // few input features -- has too few wavefronts to stage its tile: bf16x3 kernels then)
+  const int narrow = NT <= 16 ? NT : NT / 2;
+  const int KS = (f_in + 31) / 32, threads = narrow * 64;
+  const int R = (KROWS * (f_in / 4) + threads - 1) / threads;
+  const size_t lds = (size_t)2 * R * threads * 16 + (size_t)4 * KROWS * (32 * KS + 16) * sizeof(u16) + (2 * KROWS + 2 * 16 * NT) * sizeof(float);
+  return R <= 16 && lds <= 160 * 1024;
 }
 
 static KCols kcols(int f_g, int ldb, int w_cols) {

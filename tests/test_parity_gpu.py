@@ -205,6 +205,41 @@ def test_register_kernels_on_non_power_of_two_rows(hidden, H, B, kind, aggrs):
     assert rel_err(out, out_g) <= 2e-6
 
 
+@pytest.mark.parametrize("hidden,H,B,aggrs", [(300, 4, 4, ["symadd", "min", "max"]), (304, 8, 8, ["symadd"]),   # compile-time forms
+                                             (300, 4, 4, ["add", "std", "max"]), (304, 8, 8, ["mean", "var", "min", "symadd"]),
+                                             (260, 4, 4, ["symadd", "max"]), (400, 4, 4, ["symadd", "mean"]), (1000, 8, 4, ["max"]),
+                                             (600, 4, 2, ["symadd", "min", "max"]), (272, 2, 2, ["add"]),
+                                             (1056, 8, 2, ["symadd", "max"])])
+def test_two_slots_per_lane_kernel(hidden, H, B, aggrs):
+    """Rows of 65..128 16-byte slots (the ogbg-code nets of run_pretrained.sh:47-48: 300/H4/B4 symadd,min,max and
+    304/H8/B8 symadd, and other widths) on agg_wide_kernel: two slots per lane, both sets' epilogues, short rows and
+    hub rows cut into chunks (boundaries of the threshold and the chunk length) in ONE launch; against the numpy oracle,
+    and against the LDS-based kernels and the run-time-configured form of the same kernel."""
+    import os
+    from egc_amd import _C
+    dev = _dev()
+    T, K = _C.LONG_ROW_THRESHOLD, _C.LONG_ROW_CHUNK
+    n = 1200
+    hubs = [(0, 3 * K + 7), (17, K + 1), (18, K), (19, T), (20, T + 1), (21, 2 * K), (n - 1, 2 * K + 1), (400, 63), (401, 64), (402, 65)]
+
+    def run():
+        rng = np.random.default_rng(hidden * 7 + len(aggrs))
+        ei = _hub_graph(rng, n, 7000, hubs)
+        return _oracle_case("lay", rng, n, ei, 48, hidden, H, B, aggrs, dev)
+
+    out, ref = run()
+    assert rel_err(out, ref) <= TOL
+    for flag in ("EGC_NO_WIDE", "EGC_NO_STATIC_CFG"):
+        os.environ[flag] = "1"
+        try:
+            other, _ = run()
+        finally:
+            del os.environ[flag]
+        assert rel_err(out, other) <= 2e-6, flag
+    out2, _ = run()
+    assert np.array_equal(out, out2)       # chunk-order merge: run-to-run identical
+
+
 def test_fin_not_multiple_of_4_and_fin_ne_fout():
     dev = _dev()
     rng = np.random.default_rng(3)
