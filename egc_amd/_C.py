@@ -106,6 +106,7 @@ SYMBOLS = {
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_size_t, C.c_void_p]),
     "egc_backward_workspace_bytes": (C.c_size_t, [C.POINTER(EgcLayer), C.c_int64]),
+    "egc_backward_workspace_bytes_for": (C.c_size_t, [C.POINTER(EgcLayer), C.POINTER(EgcGraph)]),
     "egc_aggregate_combine_rows_f32": (C.c_int, [C.POINTER(EgcGraph), C.POINTER(EgcLayer), C.c_void_p, C.c_int32,
                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                                  C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -251,6 +251,11 @@ struct BwdArgs {
   float* tab_x;              // [N, ldb] d agg_max, or nullptr
   float* tab_n;              // [N, ldb] d agg_min, or nullptr
   const int* t_edge_id;      // transposed entry -> position of the same edge in the destination-side CSR
+  const unsigned* rec_x;     // [n_edges][16] extremum-gradient records per destination-CSR entry (bwd_records_kernel), or nullptr
+  const unsigned* rec_n;
+  unsigned rec_bytes;
+  int dst_group_floats;      // bwd_dst_fast_kernel: LDS floats per lane group
+  int rec_fused;             // bwd_dst_fast_kernel writes the records of its short rows (the chunk blocks of bwd_records_kernel: the long rows)
   int n_nodes, n_src_rows, n_edges;
   int ldb, slots, F_g, F_out, W, H, B, A, L, Ls;  // F_g = B * Ls: bases columns incl. per-basis padding
   int aggr[EGC_MAX_AGGRS];
@@ -383,6 +388,163 @@ __global__ void __launch_bounds__(256) bwd_dst_kernel(BwdArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// extremum-gradient records
+// ---------------------------------------------------------------------------------------------
+// The gradient of max / min goes, per (destination row, column), to ONE entry of the row: the one its arg position names.
+// Seen from a transposed entry, that is a handful of the destination row's columns (F_g / degree on average) -- fetched
+// as arg bytes plus 16-byte pieces of the X row it costs ~260 bytes of sectors per entry for ~17 bytes of payload.
+// bwd_records_kernel turns the (arg, X) rows into one 64-byte record per destination-CSR entry: the (value, column) pairs
+// that entry receives.  The source kernel then reads ONE 64-byte line per entry, with no dependent loads before it
+// (the arg-byte path needs rowptr[dst] -> arg bytes -> X pieces), and adds the values into a per-lane-group LDS row.
+// Entries that receive more than REC_ITEMS columns (rows of a few entries) are marked REC_OVERFLOW; the source kernel
+// compares the int32 arg row for them.
+#ifndef EGC_REC_LOAD_AUX
+#define EGC_REC_LOAD_AUX 0
+#endif
+constexpr int REC_ITEMS = 12;             // (value, column) pairs per record
+constexpr unsigned REC_OVERFLOW = 0xffu;  // dword 15: count, or this
+// record = 16 dwords: [0..11] values, [12..14] their columns (one byte each: ldb <= 256), [15] count
+
+struct RecArgs {
+  const int* rowptr;
+  const int* plan;     // long-row plan of the destination-side graph
+  const int* arg;      // [N, ldb] CSR position / n_edges / -1
+  const float* x;      // [N, ldb] d agg_max (d agg_min)
+  unsigned* rec;       // [n_edges][16]
+  int n_nodes, ldb, slots, chunk_blocks, group_u32;
+  int short_rows;      // 0: the destination kernel writes the short rows' records itself (bwd_dst_fast_kernel)
+};
+
+// One lane group (GS lanes, NS slots of four columns per lane: slot q + k GS) builds the records of n_entries <= TS
+// consecutive entries of a destination row; rel[k][c] = the entry (relative to the first of them) that column
+// 4 (q + k GS) + c names, or anything outside [0, n_entries).  Counting sort of the columns by entry in LDS
+// (lds: count [TS] | offset [TS] | items [ldb] x (value, column)), then one 64-byte store sequence per entry.
+template <int GS_LOG2, int NS, int TS>
+__device__ inline void records_from_columns(unsigned* lds, int ldb, unsigned* rec0, int n_entries, int (&rel)[NS][4],
+                                            const float (&xv)[NS][4], int lane) {
+  constexpr int GS = 1 << GS_LOG2, CPL = TS / GS;   // counters per lane
+  static_assert(CPL == 1 || CPL == 2 || CPL == 4, "table size");
+  const int q = lane & (GS - 1);
+  unsigned* cnt = lds;
+  unsigned* off = lds + TS;
+  unsigned* vals = lds + 2 * TS;                                       // [ldb] values, sorted by entry
+  unsigned char* cols = reinterpret_cast<unsigned char*>(vals + ldb);  // [ldb] their columns
+#pragma unroll
+  for (int i = 0; i < CPL; ++i) cnt[CPL * q + i] = 0u;
+  unsigned rank[NS][4];
+#pragma unroll
+  for (int k = 0; k < NS; ++k)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const bool ok = (unsigned)rel[k][c] < (unsigned)n_entries;
+      if (!ok) rel[k][c] = -1;
+      rank[k][c] = ok ? __hip_atomic_fetch_add(&cnt[rel[k][c]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+    }
+  // exclusive prefix of the counts (LDS operations of one wavefront execute in order: no barrier)
+  unsigned cl[CPL], t = 0;
+#pragma unroll
+  for (int i = 0; i < CPL; ++i) { cl[i] = cnt[CPL * q + i]; t += cl[i]; }
+  unsigned incl = t;
+#pragma unroll
+  for (int d = 1; d < GS; d <<= 1) {
+    const unsigned o = __shfl(incl, max(lane - d, 0));
+    if (q >= d) incl += o;
+  }
+  unsigned run = incl - t;
+#pragma unroll
+  for (int i = 0; i < CPL; ++i) { off[CPL * q + i] = run; run += cl[i]; }
+#pragma unroll
+  for (int k = 0; k < NS; ++k)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (rel[k][c] >= 0) {
+        const unsigned p = off[rel[k][c]] + rank[k][c];
+        vals[p] = __float_as_uint(xv[k][c]);
+        cols[p] = (unsigned char)(4 * (q + k * GS) + c);
+      }
+  // Four lanes per entry, 16 bytes of its record each: a store instruction writes whole 64-byte lines (a lane per
+  // record would touch 64 lines per instruction).  Parts 0..2: values o + 4 v .. + 3; part 3: the column bytes
+  // o .. o + 11 (three dwords cut out of four aligned ones) and the count.
+  const int v = q & 3;
+  for (int e = q >> 2; e < n_entries; e += GS / 4) {
+    const unsigned cn = cnt[e], o = off[e];
+    const unsigned m = min(cn, (unsigned)REC_ITEMS);
+    const unsigned* src = v < 3 ? vals + o + 4 * v : reinterpret_cast<const unsigned*>(cols) + (o >> 2);
+    const unsigned d0 = src[0], d1 = src[1], d2 = src[2], d3 = src[3];
+    uint4 w;
+    if (v < 3) {
+      const unsigned i0 = 4 * v;
+      w = uint4{i0 < m ? d0 : 0u, i0 + 1 < m ? d1 : 0u, i0 + 2 < m ? d2 : 0u, i0 + 3 < m ? d3 : 0u};
+    } else {
+      const unsigned sh = o & 3u;
+      auto keep = [&](unsigned first) -> unsigned {   // bytes first .. first + 3 of the list that exist
+        return m >= first + 4 ? 0xffffffffu : m > first ? (1u << (8 * (m - first))) - 1u : 0u;
+      };
+      w = uint4{__builtin_amdgcn_alignbyte(d1, d0, sh) & keep(0), __builtin_amdgcn_alignbyte(d2, d1, sh) & keep(4),
+                __builtin_amdgcn_alignbyte(d3, d2, sh) & keep(8), cn <= (unsigned)REC_ITEMS ? cn : REC_OVERFLOW};
+    }
+#ifdef EGC_REC_NT_STORE
+    __builtin_nontemporal_store(w, reinterpret_cast<uint4*>(rec0 + (int64_t)e * 16) + v);
+#else
+    reinterpret_cast<uint4*>(rec0 + (int64_t)e * 16)[v] = w;
+#endif
+  }
+}
+
+// the same from the (arg, X) rows in memory
+template <int GS_LOG2, int NS>
+__device__ inline void build_records(const RecArgs& a, unsigned* lds, int row, int begin, int n_entries, bool valid, int lane) {
+  constexpr int GS = 1 << GS_LOG2;
+  const int q = lane & (GS - 1);
+  int rel[NS][4];
+  float xv[NS][4];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const int s = q + k * GS;
+    const bool live = valid && s < a.slots;
+    const int64_t o = (int64_t)row * a.ldb + 4 * s;
+    const int4 ar = live ? *reinterpret_cast<const int4*>(a.arg + o) : int4{-1, -1, -1, -1};
+    const f4 x = live ? *reinterpret_cast<const f4*>(a.x + o) : f4{0.f, 0.f, 0.f, 0.f};
+    // (arg < begin, self loop = n_edges, -1: not an entry of this range)
+    rel[k][0] = ar.x - begin; rel[k][1] = ar.y - begin; rel[k][2] = ar.z - begin; rel[k][3] = ar.w - begin;
+    xv[k][0] = x.x; xv[k][1] = x.y; xv[k][2] = x.z; xv[k][3] = x.w;
+    if (!live) rel[k][0] = rel[k][1] = rel[k][2] = rel[k][3] = -1;
+  }
+  records_from_columns<GS_LOG2, NS, 4 * GS>(lds, a.ldb, a.rec + (int64_t)begin * 16, valid ? n_entries : 0, rel, xv, lane);
+}
+
+// Leading blocks: one wavefront per EGC_LONG_ROW_CHUNK-entry chunk of a long destination row (the row's columns over
+// the 64 lanes); the other blocks: 16 lanes per short row, 16 rows per workgroup.  Every entry's record is written.
+template <int NS>
+__global__ void __launch_bounds__(256) bwd_records_kernel(RecArgs a) {
+  extern __shared__ unsigned rec_lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  unsigned* wl = rec_lds + wave * 4 * a.group_u32;
+  if ((int)blockIdx.x < a.chunk_blocks) {
+    const int c = blockIdx.x * 4 + wave;
+    if (c >= a.plan[1]) return;
+    const int cap_long = a.plan[2], cap_chunks = a.plan[3];
+    const int* long_row = a.plan + 4;
+    const int* chunk_slot = long_row + 2 * cap_long;
+    const int* chunk_begin = chunk_slot + cap_chunks;
+    const int row = long_row[chunk_slot[c]];
+    const int begin = chunk_begin[c];
+    const int n_entries = min(EGC_LONG_ROW_CHUNK, a.rowptr[row + 1] - begin);
+    build_records<6, 1>(a, wl, row, begin, n_entries, true, lane);
+    return;
+  }
+  if (!a.short_rows) return;
+  const int g = lane >> 4;
+  const int row = (((int)blockIdx.x - a.chunk_blocks) * 4 + wave) * 4 + g;
+  bool valid = row < a.n_nodes;
+  const int begin = valid ? a.rowptr[row] : 0;
+  int n_entries = valid ? a.rowptr[row + 1] - begin : 0;
+  if (n_entries > EGC_LONG_ROW_THRESHOLD) { valid = false; n_entries = 0; }   // the chunk blocks own this row
+  build_records<4, NS>(a, wl + g * a.group_u32, valid ? row : 0, begin, n_entries, valid, lane);
+}
+
 // Register-resident form of bwd_dst_kernel for the layouts the forward's register kernels serve with shifts:
 // every basis spans a power-of-two number P of 16-byte slots (L or the padded stride a multiple of 4), B a power
 // of two, S = B P <= 64 slots, and P divides H.  One LANE GROUP per destination row (G = 64 / LPR rows per wavefront,
@@ -443,7 +605,7 @@ __global__ void __launch_bounds__(256) bwd_dst_fast_kernel(BwdArgs a) {
   const bool row_ok = row < a.n_nodes;
   const int rr = row_ok ? row : 0;
   const int gpad = (a.H * a.Ls + 3) & ~3, wpad = (a.W + 3) & ~3;
-  float* lds_g = smem + (wave * G + g) * (gpad + wpad);    // g in the padded head layout [h][Ls]
+  float* lds_g = smem + (wave * G + g) * a.dst_group_floats;  // g in the padded head layout [h][Ls]
   float* lds_w = lds_g + gpad;                              // activated weights [h][b][a]
   const int A = AT > 0 ? AT : a.A, H = HT > 0 ? HT : a.H;
   constexpr int HM = HT > 0 ? HT : BWD_HMAX;
@@ -518,9 +680,15 @@ __global__ void __launch_bounds__(256) bwd_dst_fast_kernel(BwdArgs a) {
   }
 
   // ---- tables for the source side
-  f4 d_t = zero, d_s = zero, d_v = zero;
+  f4 d_t = zero, d_s = zero, d_v = zero, d_x = zero, d_n = zero;
   const int64_t o = (int64_t)rr * a.ldb + 4 * q;
   const bool wr = row_ok && live;
+  // the row's arg positions as bytes relative to its first entry (egc_aggregate_dev.h): requested here, used last
+  unsigned a8x = 0xffffffffu, a8n = 0xffffffffu;
+  if (a.rec_fused && wr) {
+    if (a.rec_x != nullptr) a8x = reinterpret_cast<const unsigned*>(a.arg8_max)[o >> 2];
+    if (a.rec_n != nullptr) a8n = reinterpret_cast<const unsigned*>(a.arg8_min)[o >> 2];
+  }
   if (a.overwrite_db && wr && a.t_rowptr[rr + 1] - a.t_rowptr[rr] > EGC_LONG_ROW_THRESHOLD)   // its chunks add by atomics
     *reinterpret_cast<f4*>(a.d_bases + (int64_t)rr * a.ld_db + 4 * q) = zero;
 #pragma unroll
@@ -530,8 +698,8 @@ __global__ void __launch_bounds__(256) bwd_dst_fast_kernel(BwdArgs a) {
     switch (AG::aggr(a, t)) {
       case EGC_AGGR_SUM: d_t += d; break;
       case EGC_AGGR_MEAN: d_t += d * f4{rcnt, rcnt, rcnt, rcnt}; break;
-      case EGC_AGGR_MAX: if (wr) __builtin_nontemporal_store(cnt > 0 ? d : zero, reinterpret_cast<f4*>(a.tab_x + o)); break;
-      case EGC_AGGR_MIN: if (wr) __builtin_nontemporal_store(cnt > 0 ? d : zero, reinterpret_cast<f4*>(a.tab_n + o)); break;
+      case EGC_AGGR_MAX: d_x = cnt > 0 ? d : zero; if (wr) __builtin_nontemporal_store(d_x, reinterpret_cast<f4*>(a.tab_x + o)); break;
+      case EGC_AGGR_MIN: d_n = cnt > 0 ? d : zero; if (wr) __builtin_nontemporal_store(d_n, reinterpret_cast<f4*>(a.tab_n + o)); break;
       case EGC_AGGR_VAR: d_v += d; break;
       case EGC_AGGR_STD:
         d_v += f4{var.x > 0.f ? d.x / (2.0f * sd.x) : 0.f, var.y > 0.f ? d.y / (2.0f * sd.y) : 0.f,
@@ -594,6 +762,24 @@ __global__ void __launch_bounds__(256) bwd_dst_fast_kernel(BwdArgs a) {
       __builtin_nontemporal_store(d, &a.d_weightings[(int64_t)row * a.ld_dw + k0 + t]);
     }
   }
+
+  // ---- the records of the row's entries (short rows; the strips of g and w' are no longer needed: LDS reused)
+  if (a.rec_fused) {
+    const int begin = row_ok ? a.rowptr[rr] : 0;
+    int n_entries = row_ok ? a.rowptr[rr + 1] - begin : 0;
+    if (n_entries > EGC_LONG_ROW_THRESHOLD) n_entries = 0;   // bwd_records_kernel's chunk blocks
+    unsigned* rl = reinterpret_cast<unsigned*>(lds_g);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const unsigned* rec = e == 0 ? a.rec_x : a.rec_n;
+      if (rec == nullptr) continue;
+      const unsigned a8 = e == 0 ? a8x : a8n;
+      const f4 d = e == 0 ? d_x : d_n;
+      int rel[1][4] = {{(int)(a8 & 0xffu), (int)((a8 >> 8) & 0xffu), (int)((a8 >> 16) & 0xffu), (int)(a8 >> 24)}};   // ARG8_NONE / ARG8_FAR >= 64
+      const float xv[1][4] = {{d.x, d.y, d.z, d.w}};
+      records_from_columns<LPR_LOG2, 1, 64>(rl, a.ldb, const_cast<unsigned*>(rec) + (int64_t)begin * 16, n_entries, rel, xv, lane);
+    }
+  }
 }
 
 // Sum of the destination tables over one source row's out-entries [start, end), entries t, t + step, ...:
@@ -601,7 +787,8 @@ __global__ void __launch_bounds__(256) bwd_dst_fast_kernel(BwdArgs a) {
 // FL: which tables exist and which edge sets are LOOPED, compiled in (bit 0 set) or read from the arguments (0).
 // The run-time form makes the compiler clone the gather loop per flag combination (9,000 lines of ISA, SGPR
 // spills); the shipped layer kinds get a lean kernel each.
-constexpr unsigned SRC_STATIC = 1u, SRC_S = 2u, SRC_V = 4u, SRC_X = 8u, SRC_N = 16u, SRC_XL = 32u, SRC_YL = 64u, SRC_T = 128u;
+constexpr unsigned SRC_STATIC = 1u, SRC_S = 2u, SRC_V = 4u, SRC_X = 8u, SRC_N = 16u, SRC_XL = 32u, SRC_YL = 64u, SRC_T = 128u,
+                   SRC_REC = 256u;   // max / min gradients arrive as per-entry records (REC_*) instead of arg bytes + X sectors
 template <unsigned FL>
 struct SrcCfg {
   static constexpr bool fixed = (FL & SRC_STATIC) != 0;
@@ -612,26 +799,34 @@ struct SrcCfg {
   static __device__ inline bool has_n(const BwdArgs& a) { return fixed ? (FL & SRC_N) != 0 : a.tab_n != nullptr; }
   static __device__ inline bool xl(const BwdArgs& a) { return fixed ? (FL & SRC_XL) != 0 : a.x_looped != 0; }
   static __device__ inline bool yl(const BwdArgs& a) { return fixed ? (FL & SRC_YL) != 0 : a.y_looped != 0; }
+  static __device__ inline bool rec(const BwdArgs& a) { return fixed ? (FL & SRC_REC) != 0 : (a.rec_x != nullptr || a.rec_n != nullptr); }
 };
 
-constexpr int BWD_FU = 4;
+#ifndef EGC_BWD_FU
+#define EGC_BWD_FU 4
+#endif
+constexpr int BWD_FU = EGC_BWD_FU;
 template <int NS, class SC>
 __device__ inline void sum_tables(const BwdArgs& a, const __amdgpu_buffer_rsrc_t (&rt)[3],
-                                  const __amdgpu_buffer_rsrc_t (&rx)[4], const __amdgpu_buffer_rsrc_t (&r8)[2], int row,
+                                  const __amdgpu_buffer_rsrc_t (&rx)[4], const __amdgpu_buffer_rsrc_t (&r8)[2],
+                                  const __amdgpu_buffer_rsrc_t (&rr)[2], float* acc, int row,
                                   int start, int end, int first, int step,
                                   int q, int LPR, bool xl, bool yl, f4 (&at)[NS], f4 (&as)[NS], f4 (&av)[NS]) {
   // Every memory round trip on the critical path of a batch costs as much as the gathers themselves (the kernel is
   // bound by the batches in flight, and loads return in order): the indices of batch n + 1 are loaded beside the
   // gathers of batch n, the arg positions are requested BEFORE the table slots so that the dependent gather of the
   // extremum gradients leaves while the table slots are still in flight.
-  const bool ext = SC::has_x(a) || SC::has_n(a);
+  const bool ext_any = SC::has_x(a) || SC::has_n(a);
+  const bool rec = ext_any && SC::rec(a);   // records: one 64-byte line per entry, no dependent loads
+  const bool ext = ext_any && !rec;         // arg bytes, then pieces of the X rows
+  const int lane = threadIdx.x & 63;
   int dst_n[BWD_FU], pos_n[BWD_FU];
   auto load_indices = [&](int p0) {
 #pragma unroll
     for (int u = 0; u < BWD_FU; ++u) {
       const int p = p0 + u * step;
       dst_n[u] = p < end ? a.t_col[p] : -1;
-      pos_n[u] = (ext && p < end) ? a.t_edge_id[p] : -2;
+      pos_n[u] = (ext_any && p < end) ? a.t_edge_id[p] : -2;
     }
   };
   load_indices(start + first);
@@ -642,6 +837,16 @@ __device__ inline void sum_tables(const BwdArgs& a, const __amdgpu_buffer_rsrc_t
     load_indices(p0 + step * BWD_FU);
 #pragma unroll
     for (int u = 0; u < BWD_FU; ++u) rp[u] = (ext && dst[u] >= 0) ? a.rowptr[dst[u]] : 0;   // -> position inside the destination row
+    unsigned rw[2][BWD_FU];
+    if (rec) {   // dword q of the entry's record: the group's first 16 lanes fetch the 64-byte line
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        if (!(e == 0 ? SC::has_x(a) : SC::has_n(a))) continue;
+#pragma unroll
+        for (int u = 0; u < BWD_FU; ++u)
+          rw[e][u] = __builtin_amdgcn_raw_buffer_load_b32(rr[e], (dst[u] >= 0 && q < 16) ? (unsigned)pos[u] * 64u + (unsigned)q * 4u : OOB, 0, EGC_REC_LOAD_AUX);
+      }
+    }
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
       const int s = q + k * LPR;
@@ -710,13 +915,55 @@ __device__ inline void sum_tables(const BwdArgs& a, const __amdgpu_buffer_rsrc_t
         if (SC::has_s(a)) as[k] += vs[u];
       }
     }
+    if (rec) {
+      const int gl = lane & ~(LPR - 1);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        if (!(e == 0 ? SC::has_x(a) : SC::has_n(a))) continue;
+        bool ovf[BWD_FU], any_ovf = false;
+#pragma unroll
+        for (int u = 0; u < BWD_FU; ++u) {
+          const unsigned cn = __shfl(rw[e][u], gl + 15) & 0xffu;              // (a dead entry loaded zeros: count 0)
+          const unsigned colw = __shfl(rw[e][u], gl + 12 + ((q & 15) >> 2));
+          const unsigned col = (colw >> ((q & 3) * 8)) & 0xffu;
+          ovf[u] = cn == REC_OVERFLOW;
+          any_ovf = any_ovf || ovf[u];
+          if (q < REC_ITEMS && (unsigned)q < cn && !ovf[u])
+            __hip_atomic_fetch_add(&acc[col], __uint_as_float(rw[e][u]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (__ballot(any_ovf) != 0ull) {   // entries that receive more than REC_ITEMS columns: the int32 arg row decides
+#pragma unroll
+          for (int k = 0; k < NS; ++k) {
+            const int s = q + k * LPR;
+            f4 gv[BWD_FU];
+            int4 ar[BWD_FU];
+#pragma unroll
+            for (int u = 0; u < BWD_FU; ++u) {
+              const bool lv = ovf[u] && dst[u] >= 0 && s < a.slots;
+              const unsigned off = (unsigned)dst[u] * (unsigned)a.ldb * 4u + (unsigned)s * 16u;
+              gv[u] = load_slot(rx[2 * e + 1], lv ? off : OOB);
+              ar[u] = __builtin_bit_cast(int4, load_slot(rx[2 * e], lv ? off : OOB));
+            }
+#pragma unroll
+            for (int u = 0; u < BWD_FU; ++u) {
+              const bool lv = ovf[u] && dst[u] >= 0 && s < a.slots;
+              at[k].x += (lv && ar[u].x == pos[u]) ? gv[u].x : 0.f; at[k].y += (lv && ar[u].y == pos[u]) ? gv[u].y : 0.f;
+              at[k].z += (lv && ar[u].z == pos[u]) ? gv[u].z : 0.f; at[k].w += (lv && ar[u].w == pos[u]) ? gv[u].w : 0.f;
+            }
+          }
+        }
+      }
+    }
   }
 }
 
 // d bases[j] += sum over out-neighbours of the tables (+ self-loop terms).  Leading blocks: one wavefront per
 // EGC_LONG_ROW_CHUNK-entry chunk of a long row, partial sums by float atomics; the other blocks: one lane group per short row.
+#ifndef EGC_SRC_WAVES
+#define EGC_SRC_WAVES 1
+#endif
 template <int NS, unsigned FL = 0>
-__global__ void __launch_bounds__(256) bwd_src_kernel(BwdArgs a) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NS == 1 ? EGC_SRC_WAVES : 1, 8))) bwd_src_kernel(BwdArgs a) {
   using SC = SrcCfg<FL>;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -737,6 +984,14 @@ __global__ void __launch_bounds__(256) bwd_src_kernel(BwdArgs a) {
   __amdgpu_buffer_rsrc_t r8[2];   // the arg positions in 8 bits: a quarter of the bytes of rx[0] / rx[2]
   r8[0] = __builtin_amdgcn_make_buffer_rsrc((void*)(a.arg8_max != nullptr ? (const void*)a.arg8_max : (const void*)a.tab_t), 0, a.tab_bytes / 4, 0x00020000);
   r8[1] = __builtin_amdgcn_make_buffer_rsrc((void*)(a.arg8_min != nullptr ? (const void*)a.arg8_min : (const void*)a.tab_t), 0, a.tab_bytes / 4, 0x00020000);
+  __amdgpu_buffer_rsrc_t rr[2];   // the per-entry records of max / min
+  rr[0] = __builtin_amdgcn_make_buffer_rsrc((void*)(a.rec_x != nullptr ? (const void*)a.rec_x : (const void*)a.tab_t), 0, a.rec_x != nullptr ? a.rec_bytes : 0u, 0x00020000);
+  rr[1] = __builtin_amdgcn_make_buffer_rsrc((void*)(a.rec_n != nullptr ? (const void*)a.rec_n : (const void*)a.tab_t), 0, a.rec_n != nullptr ? a.rec_bytes : 0u, 0x00020000);
+  // records path: a row of F_g sums per lane group, filled by LDS float adds (G * ldb <= 256 floats per wavefront)
+  __shared__ float src_acc[4 * 256];
+  float* acc = src_acc + wave * 256 + g * a.ldb;
+  const bool use_rec = (SC::has_x(a) || SC::has_n(a)) && SC::rec(a);
+  if (use_rec) *reinterpret_cast<f4*>(src_acc + wave * 256 + lane * 4) = f4{0.f, 0.f, 0.f, 0.f};
   const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
 
   int row, start, end, first, step;
@@ -766,7 +1021,14 @@ __global__ void __launch_bounds__(256) bwd_src_kernel(BwdArgs a) {
   f4 at[NS], as[NS], av[NS];
 #pragma unroll
   for (int k = 0; k < NS; ++k) at[k] = as[k] = av[k] = zero;
-  sum_tables<NS, SC>(a, rt, rx, r8, row, start, end, first, step, q, LPR, xl, yl, at, as, av);
+  sum_tables<NS, SC>(a, rt, rx, r8, rr, acc, row, start, end, first, step, q, LPR, xl, yl, at, as, av);
+  if (use_rec) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      const int s = q + k * LPR;
+      if (s < a.slots) at[k] += *reinterpret_cast<const f4*>(acc + 4 * s);   // (LDS operations of a wavefront are in order)
+    }
+  }
   if (atomic) {  // merge the G groups of the chunk
     for (int off = LPR; off < 64; off <<= 1) {
 #pragma unroll
@@ -829,7 +1091,30 @@ extern "C" {
 size_t egc_backward_workspace_bytes(const egc_layer* layer, int64_t n_nodes) {
   if (layer == nullptr || n_nodes < 0 || layer->num_heads <= 0) return 0;
   const int ldb = egc_bases_ld(layer);
-  return (size_t)5 * (size_t)n_nodes * ldb * sizeof(float) + 256;  // tables T, S, V, X, N
+  return (((size_t)5 * (size_t)n_nodes * ldb * sizeof(float) + 255) & ~(size_t)255) + 256;  // tables T, S, V, X, N
+}
+
+static int layer_extrema(const egc_layer* layer) {
+  int mx = 0, mn = 0;
+  for (int t = 0; t < layer->num_aggrs && t < EGC_MAX_AGGRS; ++t) {
+    if (layer->aggrs[t] == EGC_AGGR_MAX) mx = 1;
+    if (layer->aggrs[t] == EGC_AGGR_MIN) mn = 1;
+  }
+  return mx + mn;
+}
+
+// records of the extremum gradients (bwd_records_kernel): one 64-byte line per entry and extremum, behind the tables
+static bool records_apply(const egc_layer* layer, int64_t n_edges) {
+  const int ldb = egc_bases_ld(layer);
+  return layer_extrema(layer) > 0 && n_edges > 0 && ldb <= 256 && (uint64_t)n_edges * 64ull < (uint64_t)OOB &&
+         getenv("EGC_BWD_NO_REC") == nullptr;
+}
+
+size_t egc_backward_workspace_bytes_for(const egc_layer* layer, const egc_graph* graph) {
+  if (layer == nullptr || graph == nullptr || graph->n_nodes < 0 || graph->n_edges < 0) return 0;
+  const size_t base = egc_backward_workspace_bytes(layer, graph->n_nodes);
+  if (base == 0 || !records_apply(layer, graph->n_edges)) return base;
+  return base + (size_t)layer_extrema(layer) * (size_t)graph->n_edges * 64;
 }
 
 int egc_aggregate_combine_backward_f32(const egc_graph* graph, const egc_graph* t_graph, const egc_layer* layer,
@@ -931,6 +1216,18 @@ int egc_aggregate_combine_backward_f32(const egc_graph* graph, const egc_graph* 
     if ((a.arg8_max != nullptr || a.arg8_min != nullptr) && a.rowptr == nullptr) return EGC_ERR_INVALID;
   }
   a.tab_bytes = (unsigned)((uint64_t)n * ldb * 4ull);
+  // per-entry records when the caller's workspace holds them (egc_backward_workspace_bytes_for)
+  a.rec_x = a.rec_n = nullptr;
+  a.rec_bytes = 0;
+  const size_t tables_bytes = egc_backward_workspace_bytes(layer, n);   // (a multiple of 256: 64-byte aligned records)
+  if ((a.tab_x != nullptr || a.tab_n != nullptr) && records_apply(layer, graph->n_edges) && graph->plan != nullptr &&
+      workspace_bytes >= tables_bytes + (size_t)layer_extrema(layer) * (size_t)graph->n_edges * 64) {
+    unsigned char* r = reinterpret_cast<unsigned char*>(workspace) + tables_bytes;
+    if (a.tab_x != nullptr) { a.rec_x = reinterpret_cast<const unsigned*>(r); r += (size_t)graph->n_edges * 64; }
+    if (a.tab_n != nullptr) a.rec_n = reinterpret_cast<const unsigned*>(r);
+    a.rec_bytes = (unsigned)((uint64_t)graph->n_edges * 64ull);
+  }
+  a.rec_fused = 0;
   a.lds_floats_per_wave = a.A * ldb + ((a.F_out + 3) & ~3) + 2 * ((a.W + 3) & ~3);
   int wpb = 4;
   if ((size_t)wpb * a.lds_floats_per_wave * sizeof(float) > 48 * 1024) wpb = 1;
@@ -953,7 +1250,10 @@ int egc_aggregate_combine_backward_f32(const egc_graph* graph, const egc_graph* 
     if (fast) {
       const int lpr = a.slots <= 16 ? 16 : a.slots <= 32 ? 32 : 64;
       const int G = 64 / lpr;
-      const size_t flds = (size_t)4 * G * (((a.H * a.Ls + 3) & ~3) + ((a.W + 3) & ~3)) * sizeof(float);
+      a.rec_fused = a.rec_bytes != 0 && getenv("EGC_BWD_REC_SEPARATE") == nullptr;
+      // per lane group: the strips of g and w'; afterwards the record builder's count | offset | values | column bytes
+      a.dst_group_floats = std::max(((a.H * a.Ls + 3) & ~3) + ((a.W + 3) & ~3), a.rec_fused ? 128 + a.ldb + a.ldb / 4 + 4 : 0);
+      const size_t flds = (size_t)4 * G * a.dst_group_floats * sizeof(float);
       const unsigned fgrid = (unsigned)ceil_div(n, (int64_t)4 * G);
       if (flds > 64 * 1024) return EGC_ERR_UNSUPPORTED;
       unsigned packed = BWD_STATIC;
@@ -979,6 +1279,32 @@ int egc_aggregate_combine_backward_f32(const egc_graph* graph, const egc_graph* 
     }
   }
 
+  if (a.rec_bytes != 0) {   // (arg, X) rows -> per-entry records
+    RecArgs r;
+    r.rowptr = graph->rowptr; r.plan = graph->plan;
+    r.n_nodes = (int)n; r.ldb = ldb; r.slots = a.slots;
+    r.group_u32 = 128 + ldb + ldb / 4 + 4;   // count | offset | values | column bytes (+ the over-read of the last list)
+    const PlanCaps dcaps = plan_caps(n, graph->n_edges);
+    const int64_t dchunks = (graph->n_chunks >= 0 && graph->n_chunks <= dcaps.cap_chunks) ? graph->n_chunks : dcaps.cap_chunks;
+    r.chunk_blocks = (int)ceil_div(dchunks, 4);
+    r.short_rows = a.rec_fused ? 0 : 1;
+    const unsigned rgrid = (unsigned)(r.chunk_blocks + (r.short_rows ? ceil_div(n, (int64_t)16) : 0));
+    const size_t rlds = (size_t)16 * r.group_u32 * sizeof(unsigned);
+    for (int e = 0; e < 2; ++e) {
+      r.arg = e == 0 ? a.arg_max : a.arg_min;
+      r.x = e == 0 ? a.tab_x : a.tab_n;
+      r.rec = const_cast<unsigned*>(e == 0 ? a.rec_x : a.rec_n);
+      if (r.rec == nullptr || rgrid == 0) continue;
+      switch ((a.slots + 15) / 16) {
+        case 1: bwd_records_kernel<1><<<rgrid, 256, rlds, stream>>>(r); break;
+        case 2: bwd_records_kernel<2><<<rgrid, 256, rlds, stream>>>(r); break;
+        case 3: bwd_records_kernel<3><<<rgrid, 256, rlds, stream>>>(r); break;
+        default: bwd_records_kernel<4><<<rgrid, 256, rlds, stream>>>(r); break;
+      }
+      EGC_LAUNCH_CHECK("bwd_records_kernel");
+    }
+  }
+
   int lg = 0;
   while ((1 << lg) < a.slots && lg < 6) ++lg;
   if (lg < 4) lg = 4;
@@ -991,24 +1317,24 @@ int egc_aggregate_combine_backward_f32(const egc_graph* graph, const egc_graph* 
   const unsigned grid = (unsigned)(a.chunk_blocks + ceil_div(n_src, (int64_t)4 * G));
   unsigned fl = SRC_STATIC | (a.need_t ? SRC_T : 0u) | (a.tab_s != nullptr ? SRC_S : 0u) | (a.tab_v != nullptr ? SRC_V : 0u) |
                 (a.tab_x != nullptr ? SRC_X : 0u) | (a.tab_n != nullptr ? SRC_N : 0u) | (a.x_looped ? SRC_XL : 0u) |
-                (a.y_looped ? SRC_YL : 0u);
+                (a.y_looped ? SRC_YL : 0u) | (a.rec_bytes != 0 ? SRC_REC : 0u);
   if (getenv("EGC_BWD_GENERIC") != nullptr) fl = 0;
-  if (ns == 1 && fl == (SRC_STATIC | SRC_T | SRC_S | SRC_X | SRC_XL | SRC_YL)) {  // EGConv sum+mean+max+symnorm (north star)
-    bwd_src_kernel<1, SRC_STATIC | SRC_T | SRC_S | SRC_X | SRC_XL | SRC_YL><<<grid, 256, 0, stream>>>(a);
-  } else if (ns == 1 && fl == (SRC_STATIC | SRC_T | SRC_S | SRC_X | SRC_YL)) {     // EfficientGraphConv symadd+max+mean
-    bwd_src_kernel<1, SRC_STATIC | SRC_T | SRC_S | SRC_X | SRC_YL><<<grid, 256, 0, stream>>>(a);
+  if (ns == 1 && fl == (SRC_STATIC | SRC_T | SRC_S | SRC_X | SRC_XL | SRC_YL | SRC_REC)) {  // EGConv sum+mean+max+symnorm (north star)
+    bwd_src_kernel<1, SRC_STATIC | SRC_T | SRC_S | SRC_X | SRC_XL | SRC_YL | SRC_REC><<<grid, 256, 0, stream>>>(a);
+  } else if (ns == 1 && fl == (SRC_STATIC | SRC_T | SRC_S | SRC_X | SRC_YL | SRC_REC)) {     // EfficientGraphConv symadd+max+mean
+    bwd_src_kernel<1, SRC_STATIC | SRC_T | SRC_S | SRC_X | SRC_YL | SRC_REC><<<grid, 256, 0, stream>>>(a);
   } else if (ns == 1 && fl == (SRC_STATIC | SRC_S | SRC_YL)) {                     // EfficientGraphConv symadd (EGC-S)
     bwd_src_kernel<1, SRC_STATIC | SRC_S | SRC_YL><<<grid, 256, 0, stream>>>(a);
   } else if (ns == 1 && fl == (SRC_STATIC | SRC_S | SRC_XL | SRC_YL)) {            // EGConv symnorm
     bwd_src_kernel<1, SRC_STATIC | SRC_S | SRC_XL | SRC_YL><<<grid, 256, 0, stream>>>(a);
-  } else if (ns == 1 && fl == (SRC_STATIC | SRC_T | SRC_X)) {                      // relational EGC: mean+max, raw
-    bwd_src_kernel<1, SRC_STATIC | SRC_T | SRC_X><<<grid, 256, 0, stream>>>(a);
-  } else if (ns == 1 && fl == (SRC_STATIC | SRC_T | SRC_V | SRC_X | SRC_YL)) {     // EfficientGraphConv add+std+max (zinc EGC-M)
-    bwd_src_kernel<1, SRC_STATIC | SRC_T | SRC_V | SRC_X | SRC_YL><<<grid, 256, 0, stream>>>(a);
-  } else if (ns == 1 && fl == (SRC_STATIC | SRC_T | SRC_S | SRC_V | SRC_X | SRC_YL)) {  // symadd+std+max (CIFAR EGC-M)
-    bwd_src_kernel<1, SRC_STATIC | SRC_T | SRC_S | SRC_V | SRC_X | SRC_YL><<<grid, 256, 0, stream>>>(a);
-  } else if (ns == 1 && fl == (SRC_STATIC | SRC_T | SRC_X | SRC_YL)) {             // add+mean+max (molhiv EGC-M)
-    bwd_src_kernel<1, SRC_STATIC | SRC_T | SRC_X | SRC_YL><<<grid, 256, 0, stream>>>(a);
+  } else if (ns == 1 && fl == (SRC_STATIC | SRC_T | SRC_X | SRC_REC)) {                      // relational EGC: mean+max, raw
+    bwd_src_kernel<1, SRC_STATIC | SRC_T | SRC_X | SRC_REC><<<grid, 256, 0, stream>>>(a);
+  } else if (ns == 1 && fl == (SRC_STATIC | SRC_T | SRC_V | SRC_X | SRC_YL | SRC_REC)) {     // EfficientGraphConv add+std+max (zinc EGC-M)
+    bwd_src_kernel<1, SRC_STATIC | SRC_T | SRC_V | SRC_X | SRC_YL | SRC_REC><<<grid, 256, 0, stream>>>(a);
+  } else if (ns == 1 && fl == (SRC_STATIC | SRC_T | SRC_S | SRC_V | SRC_X | SRC_YL | SRC_REC)) {  // symadd+std+max (CIFAR EGC-M)
+    bwd_src_kernel<1, SRC_STATIC | SRC_T | SRC_S | SRC_V | SRC_X | SRC_YL | SRC_REC><<<grid, 256, 0, stream>>>(a);
+  } else if (ns == 1 && fl == (SRC_STATIC | SRC_T | SRC_X | SRC_YL | SRC_REC)) {             // add+mean+max (molhiv EGC-M)
+    bwd_src_kernel<1, SRC_STATIC | SRC_T | SRC_X | SRC_YL | SRC_REC><<<grid, 256, 0, stream>>>(a);
   } else
   switch (ns) {
     case 1: bwd_src_kernel<1><<<grid, 256, 0, stream>>>(a); break;

@@ -614,9 +614,9 @@ def egc_aggregate_combine_backward(graph: CSRGraph, spec: LayerSpec, bases, weig
             alloc = torch.empty if graph.n_src_rows == n else torch.zeros
             d_bases = alloc((graph.n_src_rows, spec.ldb), dtype=torch.float32, device=dev)
             d_w = torch.empty((n, spec.w_cols), dtype=torch.float32, device=dev)
-        nbytes = lib.egc_backward_workspace_bytes(C.byref(spec.c), n)
-        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
         g, t = graph.c_struct(), tg.c_struct()
+        nbytes = lib.egc_backward_workspace_bytes_for(C.byref(spec.c), C.byref(g))   # tables + per-entry max / min records
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
         _C.check(lib.egc_aggregate_combine_backward_f32(
             C.byref(g), C.byref(t), C.byref(spec.c), bases.data_ptr(), spec.ldb, weightings.data_ptr(),
             grad_out.contiguous().data_ptr(), stats.data_ptr(), cnt.data_ptr(),

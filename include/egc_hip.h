@@ -538,8 +538,13 @@ int egc_layer_forward_fused_f32(const egc_graph* graph, const egc_layer* layer, 
  * and H*B*A; ld_d_bases a multiple of 4, d_bases 16-byte aligned): a caller whose next step is a GEMM with
  * the concatenated weight matrix [bases_weight | comb_weight^T] passes two column blocks of ONE
  * [n_nodes, ldb + H*B*A] array and saves the concatenation.  The dense gradients (x, bases_weight, comb
- * weight/bias, bias) are plain GEMMs / column sums left to the caller. */
+ * weight/bias, bias) are plain GEMMs / column sums left to the caller.
+ * Workspace: egc_backward_workspace_bytes(layer, n_nodes) holds the per-destination tables; with
+ * egc_backward_workspace_bytes_for(layer, graph) bytes (64 more per entry and max / min aggregator) the gradients of
+ * max / min travel as one 64-byte record per entry instead of arg bytes + pieces of the X rows (round 3: the source
+ * kernel then fetches payload, not sectors).  Either size is accepted; the results are the same. */
 size_t egc_backward_workspace_bytes(const egc_layer* layer, int64_t n_nodes);
+size_t egc_backward_workspace_bytes_for(const egc_layer* layer, const egc_graph* graph);
 int egc_aggregate_combine_backward_f32(const egc_graph* graph, const egc_graph* t_graph, const egc_layer* layer,
                                        const float* bases, int32_t ldb, const float* weightings,
                                        const float* grad_out, const float* stats, const int32_t* cnt,

@@ -355,3 +355,80 @@ def test_frozen_parameters_take_the_operand_level_node_and_agree(kind):
     assert torch.equal(out_a.detach(), out_b.detach())
     scale = max(1.0, float(xa.grad.abs().max()))
     assert float((xa.grad - xb.grad).abs().max()) <= 1e-6 * scale
+
+
+@pytest.mark.parametrize("kind,hidden,H,B,aggrs", [
+    ("opt", 64, 8, 4, ["sum", "mean", "max", "symnorm"]),      # north star: records built inside bwd_dst_fast_kernel
+    ("opt", 64, 8, 4, ["min", "max"]),
+    ("lay", 128, 4, 4, ["symadd", "std", "max"]),              # 32 slots
+    ("lay", 224, 4, 4, ["add", "mean", "max"]),                # 56 slots (64-lane groups)
+    ("lay", 136, 4, 4, ["symadd", "max", "min"]),              # 36 slots, two record arrays
+    ("opt", 42, 6, 3, ["max", "min", "mean"]),                 # LDS-based destination kernel -> bwd_records_kernel's short rows
+    ("lay", 256, 4, 4, ["max"]),                               # 64 slots
+])
+def test_extremum_gradient_records_equal_the_arg_byte_path(kind, hidden, H, B, aggrs, monkeypatch):
+    """The gradients of max / min reach the source kernel as one 64-byte record per entry (egc_backward.hip,
+    bwd_records_kernel / the fused builder): same gradients as the arg-byte path (EGC_BWD_NO_REC=1) up to the order of
+    float additions, on a graph with rows of 0..5 entries (records overflow: more than 12 columns go to one entry), hub
+    rows cut into chunks (both sides), exact ties between sources, explicit self loops; float64 autograd bounds both."""
+    import egc_amd
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(hidden + len(aggrs))
+    n = 1500
+    parts = [rng.integers(0, n, size=(2, 9000))]
+    for node, deg in [(0, 2100), (1, 300), (77, 65), (78, 64), (400, 257)]:          # destination hubs
+        parts.append(np.stack([rng.integers(0, n, size=deg), np.full(deg, node)]))
+    for node, deg in [(5, 1500), (6, 70)]:                                            # source hubs (long transposed rows)
+        parts.append(np.stack([np.full(deg, node), rng.integers(0, n, size=deg)]))
+    s = rng.integers(0, n, size=40)
+    parts.append(np.stack([s, s]))
+    ei = np.concatenate(parts, axis=1)
+    ei = ei[:, (ei[1] < n - 300) | (rng.random(ei.shape[1]) < 0.15)]                  # the last rows: 0..5 entries each
+    ei = torch.from_numpy(ei[:, rng.permutation(ei.shape[1])].astype(np.int64)).to(dev)
+    torch.manual_seed(3)
+    if kind == "opt":
+        conv = egc_amd.EGConv(48, hidden, aggrs=aggrs, num_heads=H, num_bases=B).to(dev)
+    else:
+        conv = egc_amd.EfficientGraphConv(48, hidden, H, B, False, aggrs=aggrs).to(dev)
+    x0 = torch.randn(n, 48, device=dev)
+    x0[torch.from_numpy(rng.integers(12, n, size=200)).to(dev)] = x0[11].clone()   # exact ties
+    gout = torch.randn(n, hidden, device=dev)
+
+    def grads():
+        x = x0.clone().requires_grad_(True)
+        conv.zero_grad()
+        out = conv(x, ei) if kind == "opt" else conv(x=x, edge_index=ei)
+        out.backward(gout)
+        return [x.grad.clone()] + [p.grad.clone() for p in conv.parameters()]
+
+    rec = grads()
+    monkeypatch.setenv("EGC_BWD_NO_REC", "1")
+    ref = grads()
+    monkeypatch.delenv("EGC_BWD_NO_REC")
+    monkeypatch.setenv("EGC_BWD_REC_SEPARATE", "1")       # every record by bwd_records_kernel
+    sep = grads()
+    for a, b, c in zip(rec, ref, sep):
+        assert _rel(a, b) <= 2e-6 and _rel(c, b) <= 2e-6
+    assert float(rec[0].abs().max()) > 0
+
+
+def test_backward_workspace_sizes():
+    """egc_backward_workspace_bytes_for = the tables + 64 bytes per entry and max / min aggregator; the smaller size of
+    egc_backward_workspace_bytes is still accepted (arg-byte path)."""
+    import ctypes as C
+    from egc_amd import _C
+    from egc_amd import functional as F
+    import egc_amd
+    dev = torch.device("cuda:0")
+    lib = _C.load()
+    rng = np.random.default_rng(0)
+    n = 500
+    ei = torch.from_numpy(_graph(rng, n, 4000, hub=100)).to(dev)
+    g = egc_amd.CSRGraph.from_edge_index(ei, n)
+    for aggrs, extrema in [(["sum", "max"], 1), (["min", "max", "mean"], 2), (["symnorm"], 0)]:
+        conv = egc_amd.EGConv(16, 64, aggrs=aggrs, num_heads=8, num_bases=4)
+        spec = conv._spec_coo
+        gs = g.c_struct()
+        small = lib.egc_backward_workspace_bytes(C.byref(spec.c), n)
+        big = lib.egc_backward_workspace_bytes_for(C.byref(spec.c), C.byref(gs))
+        assert big == small + extrema * g.n_edges * 64 and small % 256 == 0
