@@ -43,6 +43,8 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ inline void lds_barrier2() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+constexpr int F16X2_KP = 128;          // k extent of the register-resident weight block (F_in <= 128, zero beyond F_in)
+
 // biased exponent of the scale group's largest magnitude -> (scale, inverse scale), both exact powers of two
 __device__ inline void scales_of(unsigned amax_bits, float& scale, float& inv) {
   unsigned be = amax_bits >> 23;        // sign already cleared
@@ -59,7 +61,7 @@ __device__ inline void split2_pk(f32x2 v, unsigned& h, unsigned& l) {
   l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
 }
 
-// packed[ks][plane][v][32] (fp16 bits) followed by float inv_scale[NV].  One wavefront per virtual column
+// packed[column tile][k-step][plane][lane][8] (fp16 bits, the MFMA B fragments as they are loaded) followed by float inv_scale[NV].  One wavefront per virtual column
 // (runs once per parameter update -- every step when training): lanes stride over k, the column maximum is a
 // wavefront all-reduce.
 __global__ void __launch_bounds__(64) pack_f16x2_kernel(const float* __restrict__ wcat, int64_t rs, int64_t cs, int K, int F_g,
@@ -78,9 +80,13 @@ __global__ void __launch_bounds__(64) pack_f16x2_kernel(const float* __restrict_
     const float w = (src >= 0 && k < K) ? wcat[k * rs + src * cs] * scale : 0.f;
     const _Float16 h = (_Float16)w;
     const _Float16 l = (_Float16)((w - (float)h) * 2048.f);
-    const int64_t base = ((int64_t)(k / GEMM_KT) * 2 * NV + v) * GEMM_KT + (k % GEMM_KT);
+    // fragment order: the B operand of k-step s (16 k), plane p, column tile ct is 64 lanes x 8 halves, lane
+    // 32 (k % 16 / 8) + column % 32 -- a wavefront of the GEMM fetches it as ONE contiguous KiB (with the planes laid
+    // out [k-slab][plane][column][32 k] every lane's 16 bytes sat in a line of their own, and the 196 KB of weight
+    // loads of a block took ~3 us of its prologue)
+    const int64_t base = ((((int64_t)(v >> 5) * (F16X2_KP / 16) + (k >> 4)) * 2) * 64 + 32 * ((k & 15) >> 3) + (v & 31)) * 8 + (k & 7);
     packed[base] = __builtin_bit_cast(u16, h);
-    packed[base + (int64_t)NV * GEMM_KT] = __builtin_bit_cast(u16, l);
+    packed[base + 64 * 8] = __builtin_bit_cast(u16, l);
   }
   if (lane == 0) reinterpret_cast<float*>(packed + (int64_t)KS * 2 * NV * GEMM_KT)[v] = inv;
 }
@@ -109,7 +115,6 @@ __device__ unsigned long long* egc_stamp_buf2 = nullptr;  // diagnostic build on
 // and the wavefront immediately re-arms the slot with the tile three ahead: 64 KB per CU always in flight.
 constexpr int F16X2_THREADS = 768;      // 6 column tiles x 2 row halves
 constexpr int F16X2_ROWS = 64;
-constexpr int F16X2_KP = 128;
 constexpr int F16X2_LDX = F16X2_KP + 8;
 constexpr int F16X2_RAW_BYTES = F16X2_ROWS * F16X2_KP * 4;                  // one raw fp32 tile
 constexpr int F16X2_PLANE_BYTES = 2 * 2 * F16X2_ROWS * F16X2_LDX * 2;       // two buffers x two planes
@@ -122,7 +127,7 @@ __global__ void __launch_bounds__(F16X2_THREADS) basis_gemm_f16x2_kernel(const f
                                                                           const float* __restrict__ bcat, int64_t M, int K,
                                                                           int W, float* __restrict__ bases, int ldb,
                                                                           float* __restrict__ weightings, int NV,
-                                                                          int n_tiles) {
+                                                                          int rows_per_block) {
   constexpr int KP = F16X2_KP;
   constexpr int KSUB = KP / 16;         // 16-k MFMA steps
   constexpr int LDX = F16X2_LDX;
@@ -145,6 +150,12 @@ __global__ void __launch_bounds__(F16X2_THREADS) basis_gemm_f16x2_kernel(const f
 #endif
   const int l31 = lane & 31, hh = lane >> 5;
   const int cb = 32 * ct;
+  // A block owns a CONTIGUOUS row range of M / gridDim rows (its last tile is partial: the DMA and the stores of the
+  // rows beyond the range are dropped by range checks, and the loop is bound by those bytes): every block moves the
+  // same bytes.  (Whole 64-row tiles dealt round-robin left 86 of 256 blocks with an 11th tile at config 2.)
+  const int64_t row_lo = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t row_hi = row_lo + rows_per_block < M ? row_lo + rows_per_block : M;
+  const int n_tiles = (int)((row_hi - row_lo + F16X2_ROWS - 1) / F16X2_ROWS);
 
   f16x8 wf[KSUB][2];
   float col_inv, col_bias;
@@ -156,8 +167,8 @@ __global__ void __launch_bounds__(F16X2_THREADS) basis_gemm_f16x2_kernel(const f
   // this wavefront's 32 columns lie either in `bases` or in `weightings` (host: ldb % 32 == 0)
   const bool to_bases = cb < ldb;
   const __amdgpu_buffer_rsrc_t ro =
-      to_bases ? __builtin_amdgcn_make_buffer_rsrc((void*)bases, 0, (unsigned)(M * ldb * 4), 0x00020000)
-               : __builtin_amdgcn_make_buffer_rsrc((void*)weightings, 0, (unsigned)(M * (int64_t)W * 4), 0x00020000);
+      to_bases ? __builtin_amdgcn_make_buffer_rsrc((void*)bases, 0, (unsigned)(row_hi * ldb * 4), 0x00020000)
+               : __builtin_amdgcn_make_buffer_rsrc((void*)weightings, 0, (unsigned)(row_hi * (int64_t)W * 4), 0x00020000);
   const int out_ld = to_bases ? ldb : W;
   const int out_col = (to_bases ? cb : cb - ldb) + l31;
   const bool col_ok = out_col < (to_bases ? ldb : W);
@@ -169,8 +180,8 @@ __global__ void __launch_bounds__(F16X2_THREADS) basis_gemm_f16x2_kernel(const f
     const int pc = tid + nthreads * i;
     const int row = pc >> 5;
     const int k4 = (pc & 31) * 4;
-    const int64_t gm = (int64_t)tile * ROWS + row;
-    const bool ok = (tile < n_tiles) & (gm < M) & (k4 < K);
+    const int64_t gm = row_lo + (int64_t)tile * ROWS + row;
+    const bool ok = (tile < n_tiles) & (gm < row_hi) & (k4 < K);
     const unsigned voff = ok ? (unsigned)((gm * K + k4) * 4) : GOOB;
     const unsigned dst =
         __builtin_amdgcn_readfirstlane(raw_lds + slot * F16X2_RAW_BYTES + (wave * 64 + nthreads * i) * 16);  // wave-uniform
@@ -260,13 +271,13 @@ __global__ void __launch_bounds__(F16X2_THREADS) basis_gemm_f16x2_kernel(const f
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v3), ro, voff, so + 3 * out_ld * 4, 0);
   };
   auto out_offset = [&](int tile, bool valid) -> unsigned {
-    return (valid & col_ok) ? (unsigned)((((int64_t)tile * ROWS + 32 * rt + 4 * hh) * out_ld + out_col) * 4) : SOOB;
+    return (valid & col_ok) ? (unsigned)(((row_lo + (int64_t)tile * ROWS + 32 * rt + 4 * hh) * out_ld + out_col) * 4) : SOOB;
   };
 #define EGC_PIN __builtin_amdgcn_sched_barrier(0)
 
-  const int stride = gridDim.x;
-  int tile = blockIdx.x;
-  if (tile >= n_tiles) return;
+  constexpr int stride = 1;   // (tiles of this block's own range, in order)
+  int tile = 0;
+  if (n_tiles <= 0) return;
   if (K < KP) {  // columns k >= K of a tile are out of range for the DMA and must read as 0
     for (int i = tid; i < 2 * F16X2_RAW_BYTES / 16; i += nthreads) reinterpret_cast<u32x4*>(raw)[i] = u32x4{0, 0, 0, 0};
     lds_barrier2();
@@ -284,8 +295,7 @@ __global__ void __launch_bounds__(F16X2_THREADS) basis_gemm_f16x2_kernel(const f
   for (int s = 0; s < KSUB; ++s)
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-      const u16* src = packed + ((((int64_t)(s >> 1) * 2 + p) * NV + cb + l31) * GEMM_KT + 16 * (s & 1) + 8 * hh);
-      wf[s][p] = *reinterpret_cast<const f16x8*>(src);
+      wf[s][p] = *reinterpret_cast<const f16x8*>(packed + ((((int64_t)ct * KSUB + s) * 2 + p) * 64 + lane) * 8);   // one KiB per wavefront
     }
   // every output element of a lane belongs to ONE column (cb + l31): its inverse scale and bias stay in registers
   col_inv = reinterpret_cast<const float*>(packed + (int64_t)(KP / GEMM_KT) * 2 * NV * GEMM_KT)[cb + l31];
@@ -425,6 +435,7 @@ static int f16x2_launch_rows(const float* x, const void* packed, const float* bc
   int grid = 256;  // one 12-wavefront block per CU (registers: 3 wavefronts per SIMD)
   if (const char* e = getenv("EGC_GEMM_GRID")) grid = atoi(e);
   if (grid > n_tiles) grid = n_tiles;
+  const int rows_per_block = (int)((M + grid - 1) / grid);   // contiguous, equal row ranges
 #ifdef EGC_GEMM_STAMPS
   static unsigned long long* dbuf = nullptr;
   if (dbuf == nullptr) {
@@ -434,7 +445,7 @@ static int f16x2_launch_rows(const float* x, const void* packed, const float* bc
   hipMemset(dbuf, 0, 1024 * 16 * 8 * 8);
 #endif
   basis_gemm_f16x2_kernel<<<grid, threads, lds, stream>>>(x, (const u16*)packed, bcat, M, K, W, bases, ldb, weightings,
-                                                               NV, n_tiles);
+                                                               NV, rows_per_block);
   EGC_LAUNCH_CHECK("basis_gemm_f16x2_kernel");
 #ifdef EGC_GEMM_STAMPS
   {
