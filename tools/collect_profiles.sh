@@ -28,6 +28,8 @@ EGC_TILE_ONLY=cifar rocprofv3 --pmc FETCH_SIZE -d $O/pmc_tile_fetch -o pmc --out
 EGC_TILE_ONLY=cifar rocprofv3 --pmc WRITE_SIZE -d $O/pmc_tile_write -o pmc --output-format csv -- python3 $R/tools/batch_tile_time.py > /dev/null 2> $O/pmc_tile_write.log
 cd $R
 python3 tools/host_overhead_time.py > $O/host_overhead.log 2>&1
+python3 tools/reference_shapes_time.py > $O/reference_shapes.log 2>&1   # every trained layer shape of the reference, arxiv-shaped graph
+python3 tools/gemm_time.py > $O/gemm_time.log 2>&1
 python3 bench.py --workload rmag --steps 10 --warmup 3 > $O/rmag_bench.json 2> $O/rmag.err
 python3 bench.py > $O/bench.json 2> $O/bench.err
 tail -3 $O/bench.err

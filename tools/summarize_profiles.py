@@ -54,6 +54,9 @@ def main():
             condense(f, os.path.join(dst, f"{tag}_{out}.csv"))
     if os.path.exists(os.path.join(src, "host_overhead.log")):
         cp("host_overhead.log", f"{tag}_host_overhead.log")
+    for name in ("reference_shapes", "gemm_time"):
+        if os.path.exists(os.path.join(src, name + ".log")):
+            cp(name + ".log", f"{tag}_{name}.log")
     for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
         out = {"pmc_fetch": "pmc_fetch_size", "pmc_write": "pmc_write_size", "pmc_sq": "pmc_sq_counters"}[name]
         condense(os.path.join(src, name, "pmc_counter_collection.csv"), os.path.join(dst, f"{tag}_{out}.csv"))
