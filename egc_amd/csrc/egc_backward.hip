@@ -604,7 +604,7 @@ __global__ void __launch_bounds__(256) bwd_dst_fast_kernel(BwdArgs a) {
   const int row = (blockIdx.x * 4 + wave) * G + g;
   const bool row_ok = row < a.n_nodes;
   const int rr = row_ok ? row : 0;
-  const int gpad = (a.H * a.Ls + 3) & ~3, wpad = (a.W + 3) & ~3;
+  const int gpad = (a.H * a.Ls + 3) & ~3;
   float* lds_g = smem + (wave * G + g) * a.dst_group_floats;  // g in the padded head layout [h][Ls]
   float* lds_w = lds_g + gpad;                              // activated weights [h][b][a]
   const int A = AT > 0 ? AT : a.A, H = HT > 0 ? HT : a.H;
