@@ -106,3 +106,56 @@ class MagNetLike(nn.Module):
         for conv in self.convs[:-1]:
             x = torch.relu(conv_fn(conv, x, adj_t))
         return conv_fn(self.convs[-1], x, adj_t)[:, :self.out_true].log_softmax(dim=-1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The training loop of the batched nets (zinc/configs.py): this repository's counterpart of train / evaluate and of the
+# optimizer / scheduler wiring around them, pinned by tests/golden/train_*.npz (the reference's own loop run under shims).
+# ---------------------------------------------------------------------------------------------------------------------
+def zinc_loss(out, y):
+    """zinc/configs.py:48-50: L1 between the net's [n_graphs, 1] output and y viewed alike."""
+    return torch.nn.functional.l1_loss(out, y.view_as(out))
+
+
+def train_epoch(forward, modules, optimizer, batches):
+    """zinc/configs.py:53-72: one pass over the training batches -- zero_grad, forward, L1 loss, backward, step; returns
+    the mean of the per-batch losses.  ``forward(batch)`` runs the net on one batch (a dict of tensors)."""
+    for m in modules:
+        m.train()
+    total, count = 0.0, 0
+    for batch in batches:
+        optimizer.zero_grad()
+        loss = zinc_loss(forward(batch), batch["y"])
+        loss.backward()
+        optimizer.step()
+        total += loss.item()
+        count += 1
+    return total / count
+
+
+@torch.no_grad()
+def evaluate(forward, modules, batches):
+    """zinc/configs.py:75-90: eval mode, mean of the per-batch L1 losses."""
+    for m in modules:
+        m.eval()
+    total, count = 0.0, 0
+    for batch in batches:
+        total += zinc_loss(forward(batch), batch["y"]).item()
+        count += 1
+    return total / count
+
+
+def fit_zinc(forward, modules, params, data, lr, wd, iterations):
+    """The per-iteration schedule of zinc/configs.py:128-154: Adam(lr, weight_decay=wd); ReduceLROnPlateau(mode 'min',
+    factor 0.5, patience 10, min_lr 1e-5) stepped with the validation loss after every training pass; test loss at the
+    end.  Returns (train losses, validation losses, learning rates, test loss)."""
+    opt = torch.optim.Adam(params, lr=lr, weight_decay=wd)
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, "min", factor=0.5, patience=10, min_lr=1e-5)
+    tr, va, lrs = [], [], []
+    for _ in range(iterations):
+        tr.append(train_epoch(forward, modules, opt, data["train"]))
+        v = evaluate(forward, modules, data["val"])
+        sched.step(v)
+        va.append(v)
+        lrs.append(opt.param_groups[0]["lr"])
+    return tr, va, lrs, evaluate(forward, modules, data["test"])
