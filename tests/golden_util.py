@@ -13,8 +13,9 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 def golden_names():
     """Single-layer fixtures (make_golden.py); the relational ones (make_golden_rel.py) are rel_*."""
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-    # grad_*: make_golden_grad.py (test_backward_golden.py); net_* / relgrad_*: make_golden_nets.py (test_nets_golden.py)
-    return [n for n in names if not n.startswith(("rel_", "grad_", "net_", "relgrad_"))]
+    # grad_*: make_golden_grad.py (test_backward_golden.py); net_* / relgrad_*: make_golden_nets.py (test_nets_golden.py);
+    # train_*: make_golden_train.py (test_train_golden.py)
+    return [n for n in names if not n.startswith(("rel_", "grad_", "net_", "relgrad_", "train_"))]
 
 
 def rel_golden_names():
