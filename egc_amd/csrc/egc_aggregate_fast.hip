@@ -419,6 +419,9 @@ bool wide_path_supported(const AggArgs& a, int layout) {
   if (a.B * P0 > 64) return false;
   if (a.stats != nullptr || a.arg_max != nullptr || a.arg_min != nullptr) return false;   // inference form
   if ((uint64_t)a.n_nodes * (uint64_t)a.F_out * 4ull > (uint64_t)OOB) return false;
+  // LDS of launch_wide_rows (bias strip [+ scale strip] + one weightings row per wavefront, four wavefronts)
+  const size_t strips = (size_t)(a.post_scale != nullptr ? 2 : 1) * ((a.H * a.Ls + 3) & ~3) + ((a.W + 3) & ~3);
+  if (4 * strips * sizeof(float) > 64 * 1024) return false;
   return true;
 }
 

@@ -1054,18 +1054,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NS == 
       if (SC::has_v(a)) vv += *reinterpret_cast<const f4*>(a.tab_v + o);
     }
     if (yl && has_self && SC::has_s(a)) sv += *reinterpret_cast<const f4*>(a.tab_s + o);
-    if (xl && has_self) {  // the appended self-loop attained the extremum: arg == n_edges
-      if (SC::has_x(a)) {
-        const int4 ar = *reinterpret_cast<const int4*>(a.arg_max + o);
-        const f4 gx = *reinterpret_cast<const f4*>(a.tab_x + o);
-        t.x += ar.x == a.n_edges ? gx.x : 0.f; t.y += ar.y == a.n_edges ? gx.y : 0.f;
-        t.z += ar.z == a.n_edges ? gx.z : 0.f; t.w += ar.w == a.n_edges ? gx.w : 0.f;
-      }
-      if (SC::has_n(a)) {
-        const int4 ar = *reinterpret_cast<const int4*>(a.arg_min + o);
-        const f4 gn = *reinterpret_cast<const f4*>(a.tab_n + o);
-        t.x += ar.x == a.n_edges ? gn.x : 0.f; t.y += ar.y == a.n_edges ? gn.y : 0.f;
-        t.z += ar.z == a.n_edges ? gn.z : 0.f; t.w += ar.w == a.n_edges ? gn.w : 0.f;
+    if (xl && has_self) {
+      // the appended self-loop attained the extremum: arg == n_edges, i.e. byte ARG8_NONE in the 8-bit table (an empty
+      // row has it too, with a zero gradient) -- 4 bytes instead of 16 per slot, and the gradient slot only where some
+      // column of it goes to the loop (about one slot in four at config 2)
+      const unsigned off = (unsigned)row * (unsigned)a.ldb * 4u + (unsigned)s * 16u;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        if (!(e == 0 ? SC::has_x(a) : SC::has_n(a))) continue;
+        const unsigned b8 = __builtin_amdgcn_raw_buffer_load_b32(r8[e], off >> 2, 0, 0);
+        const bool sx = (b8 & 0xffu) == ARG8_NONE, sy = ((b8 >> 8) & 0xffu) == ARG8_NONE;
+        const bool sz = ((b8 >> 16) & 0xffu) == ARG8_NONE, sw = (b8 >> 24) == ARG8_NONE;
+        const f4 gx = load_slot(rx[2 * e + 1], (sx || sy || sz || sw) ? off : OOB);
+        t.x += sx ? gx.x : 0.f; t.y += sy ? gx.y : 0.f; t.z += sz ? gx.z : 0.f; t.w += sw ? gx.w : 0.f;
       }
     }
     f4 d = t;
