@@ -251,11 +251,13 @@ struct BwdArgs {
   float* tab_x;              // [N, ldb] d agg_max, or nullptr
   float* tab_n;              // [N, ldb] d agg_min, or nullptr
   const int* t_edge_id;      // transposed entry -> position of the same edge in the destination-side CSR
-  const unsigned* rec_x;     // [n_edges][16] extremum-gradient records per destination-CSR entry (bwd_records_kernel), or nullptr
+  const unsigned* rec_x;     // [n_edges][16] extremum-gradient records per destination-CSR entry (records_from_columns), or nullptr
   const unsigned* rec_n;
   unsigned rec_bytes;
   int dst_group_floats;      // bwd_dst_fast_kernel: LDS floats per lane group
-  int rec_fused;             // bwd_dst_fast_kernel writes the records of its short rows (the chunk blocks of bwd_records_kernel: the long rows)
+  const int* d_plan;         // long-row plan of the destination-side graph (records of hub rows)
+  int dst_row_blocks;        // bwd_dst_fast_kernel: blocks of the row role; the blocks behind them build the records of hub-row chunks
+  int rec_fused;             // bwd_dst_fast_kernel builds every record itself (row role: short rows; trailing blocks: hub-row chunks)
   int n_nodes, n_src_rows, n_edges;
   int ldb, slots, F_g, F_out, W, H, B, A, L, Ls;  // F_g = B * Ls: bases columns incl. per-basis padding
   int aggr[EGC_MAX_AGGRS];
@@ -394,7 +396,8 @@ __global__ void __launch_bounds__(256) bwd_dst_kernel(BwdArgs a) {
 // The gradient of max / min goes, per (destination row, column), to ONE entry of the row: the one its arg position names.
 // Seen from a transposed entry, that is a handful of the destination row's columns (F_g / degree on average) -- fetched
 // as arg bytes plus 16-byte pieces of the X row it costs ~260 bytes of sectors per entry for ~17 bytes of payload.
-// bwd_records_kernel turns the (arg, X) rows into one 64-byte record per destination-CSR entry: the (value, column) pairs
+// The destination side (inside bwd_dst_fast_kernel; bwd_records_kernel behind the LDS-based destination kernel) turns the
+// (arg, X) rows into one 64-byte record per destination-CSR entry: the (value, column) pairs
 // that entry receives.  The source kernel then reads ONE 64-byte line per entry, with no dependent loads before it
 // (the arg-byte path needs rowptr[dst] -> arg bytes -> X pieces), and adds the values into a per-lane-group LDS row.
 // Entries that receive more than REC_ITEMS columns (rows of a few entries) are marked REC_OVERFLOW; the source kernel
@@ -601,13 +604,64 @@ __global__ void __launch_bounds__(256) bwd_dst_fast_kernel(BwdArgs a) {
   const bool live = q < a.slots;
   const int bq = p2 ? q >> plog : q / P;
   const int b = min(bq, a.B - 1), l4 = q - bq * P;
+  const int A = AT > 0 ? AT : a.A, H = HT > 0 ? HT : a.H;
+  if (a.rec_fused && (int)blockIdx.x >= a.dst_row_blocks) {
+    // ---- trailing blocks: the records of one 256-entry chunk of a hub row per wavefront (lane = slot of the row).  The
+    // row's d agg_max / d agg_min are formed here again from g and w' (H fused multiply-adds per column, in the row role's
+    // order: the same bits) instead of waiting for the row role's X table -- no second launch for the hub rows.
+    const int c = ((int)blockIdx.x - a.dst_row_blocks) * 4 + wave;
+    if (c >= a.d_plan[1]) return;
+    const int cap_long = a.d_plan[2], cap_chunks = a.d_plan[3];
+    const int* long_row = a.d_plan + 4;
+    const int* chunk_slot = long_row + 2 * cap_long;
+    const int* chunk_begin = chunk_slot + cap_chunks;
+    const int crow = long_row[chunk_slot[c]];
+    const int begin = chunk_begin[c];
+    const int n_entries = min(EGC_LONG_ROW_CHUNK, a.rowptr[crow + 1] - begin);
+    const bool clive = lane < a.slots;
+    const int cbq = p2 ? lane >> plog : lane / P;
+    const int cb = min(cbq, a.B - 1), cl = 4 * (lane - cbq * P);
+    unsigned* wl = reinterpret_cast<unsigned*>(smem + wave * G * a.dst_group_floats);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const unsigned* rec = e == 0 ? a.rec_x : a.rec_n;
+      if (rec == nullptr) continue;
+      int ta = 0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (t < A && AG::aggr(a, t) == (e == 0 ? (int)EGC_AGGR_MAX : (int)EGC_AGGR_MIN)) ta = t;
+      f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int h = 0; h < (HT > 0 ? HT : BWD_HMAX); ++h) {
+        if (h >= H) break;
+        float w = clive ? a.weightings[(int64_t)crow * a.W + (h * a.B + cb) * A + ta] : 0.f;
+        if (AG::act(a) == EGC_ACT_SIGMOID) w = 1.0f / (1.0f + expf(-w));
+        else if (AG::act(a) == EGC_ACT_HARDTANH) w = fminf(fmaxf(w, -1.0f), 1.0f);
+        const float* gp = a.grad_out + (int64_t)crow * a.F_out + h * a.L + cl;
+        f4 gv = f4{0.f, 0.f, 0.f, 0.f};
+        if (clive) {
+          if (cl < a.L) gv.x = gp[0];
+          if (cl + 1 < a.L) gv.y = gp[1];
+          if (cl + 2 < a.L) gv.z = gp[2];
+          if (cl + 3 < a.L) gv.w = gp[3];
+        }
+        acc = f4_fma(f4{w, w, w, w}, gv, acc);
+      }
+      const int* argp = e == 0 ? a.arg_max : a.arg_min;
+      const int4 ar = clive ? *reinterpret_cast<const int4*>(argp + (int64_t)crow * a.ldb + 4 * lane) : int4{-1, -1, -1, -1};
+      int rel[1][4] = {{ar.x - begin, ar.y - begin, ar.z - begin, ar.w - begin}};
+      if (!clive) rel[0][0] = rel[0][1] = rel[0][2] = rel[0][3] = -1;
+      const float xv[1][4] = {{acc.x, acc.y, acc.z, acc.w}};
+      records_from_columns<6, 1, 4 * 64>(wl, a.ldb, const_cast<unsigned*>(rec) + (int64_t)begin * 16, n_entries, rel, xv, lane);
+    }
+    return;
+  }
   const int row = (blockIdx.x * 4 + wave) * G + g;
   const bool row_ok = row < a.n_nodes;
   const int rr = row_ok ? row : 0;
   const int gpad = (a.H * a.Ls + 3) & ~3;
   float* lds_g = smem + (wave * G + g) * a.dst_group_floats;  // g in the padded head layout [h][Ls]
   float* lds_w = lds_g + gpad;                              // activated weights [h][b][a]
-  const int A = AT > 0 ? AT : a.A, H = HT > 0 ? HT : a.H;
   constexpr int HM = HT > 0 ? HT : BWD_HMAX;
 
   // ---- stage the row's g and w' (LPR lanes, 16 bytes each per step)
@@ -767,7 +821,7 @@ __global__ void __launch_bounds__(256) bwd_dst_fast_kernel(BwdArgs a) {
   if (a.rec_fused) {
     const int begin = row_ok ? a.rowptr[rr] : 0;
     int n_entries = row_ok ? a.rowptr[rr + 1] - begin : 0;
-    if (n_entries > EGC_LONG_ROW_THRESHOLD) n_entries = 0;   // bwd_records_kernel's chunk blocks
+    if (n_entries > EGC_LONG_ROW_THRESHOLD) n_entries = 0;   // the trailing blocks' chunk role
     unsigned* rl = reinterpret_cast<unsigned*>(lds_g);
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -1229,6 +1283,8 @@ int egc_aggregate_combine_backward_f32(const egc_graph* graph, const egc_graph* 
     a.rec_bytes = (unsigned)((uint64_t)graph->n_edges * 64ull);
   }
   a.rec_fused = 0;
+  a.d_plan = graph->plan;
+  a.dst_row_blocks = 0;
   a.lds_floats_per_wave = a.A * ldb + ((a.F_out + 3) & ~3) + 2 * ((a.W + 3) & ~3);
   int wpb = 4;
   if ((size_t)wpb * a.lds_floats_per_wave * sizeof(float) > 48 * 1024) wpb = 1;
@@ -1253,9 +1309,18 @@ int egc_aggregate_combine_backward_f32(const egc_graph* graph, const egc_graph* 
       const int G = 64 / lpr;
       a.rec_fused = a.rec_bytes != 0 && getenv("EGC_BWD_REC_SEPARATE") == nullptr;
       // per lane group: the strips of g and w'; afterwards the record builder's count | offset | values | column bytes
-      a.dst_group_floats = std::max(((a.H * a.Ls + 3) & ~3) + ((a.W + 3) & ~3), a.rec_fused ? 128 + a.ldb + a.ldb / 4 + 4 : 0);
+      // (64 entries per group in the row role; 256 per WAVEFRONT in the hub-chunk role of the trailing blocks)
+      a.dst_group_floats = std::max(((a.H * a.Ls + 3) & ~3) + ((a.W + 3) & ~3),
+                                    a.rec_fused ? std::max(128 + a.ldb + a.ldb / 4 + 4, (512 + a.ldb + a.ldb / 4 + 4 + G - 1) / G) : 0);
       const size_t flds = (size_t)4 * G * a.dst_group_floats * sizeof(float);
-      const unsigned fgrid = (unsigned)ceil_div(n, (int64_t)4 * G);
+      a.dst_row_blocks = (int)ceil_div(n, (int64_t)4 * G);
+      a.d_plan = graph->plan;
+      int rec_chunk_blocks = 0;
+      if (a.rec_fused) {
+        const PlanCaps dc = plan_caps(n, graph->n_edges);
+        rec_chunk_blocks = (int)ceil_div((graph->n_chunks >= 0 && graph->n_chunks <= dc.cap_chunks) ? graph->n_chunks : dc.cap_chunks, 4);
+      }
+      const unsigned fgrid = (unsigned)(a.dst_row_blocks + rec_chunk_blocks);
       if (flds > 64 * 1024) return EGC_ERR_UNSUPPORTED;
       unsigned packed = BWD_STATIC;
       for (int t = 0; t < a.A; ++t) packed |= (unsigned)a.aggr[t] << (3 * t);
@@ -1289,7 +1354,8 @@ int egc_aggregate_combine_backward_f32(const egc_graph* graph, const egc_graph* 
     const int64_t dchunks = (graph->n_chunks >= 0 && graph->n_chunks <= dcaps.cap_chunks) ? graph->n_chunks : dcaps.cap_chunks;
     r.chunk_blocks = (int)ceil_div(dchunks, 4);
     r.short_rows = a.rec_fused ? 0 : 1;
-    const unsigned rgrid = (unsigned)(r.chunk_blocks + (r.short_rows ? ceil_div(n, (int64_t)16) : 0));
+    // (with the records built inside bwd_dst_fast_kernel -- rows AND hub chunks -- there is nothing left to launch)
+    const unsigned rgrid = a.rec_fused ? 0u : (unsigned)(r.chunk_blocks + ceil_div(n, (int64_t)16));
     const size_t rlds = (size_t)16 * r.group_u32 * sizeof(unsigned);
     for (int e = 0; e < 2; ++e) {
       r.arg = e == 0 ? a.arg_max : a.arg_min;
