@@ -12,10 +12,16 @@ dev = torch.device("cuda:0")
 shapes = [(169343, 128, 128, 8, 4, 4), (52771, 128, 128, 8, 4, 4), (240730, 128, 128, 8, 4, 4)]
 if "--mag" in sys.argv:
     shapes = [(736389, 352, 352, 8, 4, 1)]
+if "--wide" in sys.argv:     # F_in > 128 layer shapes of the reference's nets on the arxiv-sized graph (hidden, H, B, A)
+    shapes = [(169343, h, h, H, B, A) for h, H, B, A in ((136, 4, 4, 3), (184, 8, 4, 1), (224, 4, 4, 3), (296, 8, 4, 1), (300, 4, 4, 3), (304, 8, 8, 1))]
 for n, fin, fout, H, B, A in shapes:
     aggrs = ["sum", "mean", "max", "symnorm"][:A] if A > 1 else ["symnorm"]
-    conv = egc_amd.EGConv(fin, fout, aggrs=aggrs, num_heads=H, num_bases=B).to(dev).eval()
-    spec = conv._spec_coo
+    if "--wide" in sys.argv:
+        conv = egc_amd.EfficientGraphConv(fin, fout, H, B, False, aggrs=["symadd", "max", "mean"][:A]).to(dev).eval()
+        spec = conv._spec
+    else:
+        conv = egc_amd.EGConv(fin, fout, aggrs=aggrs, num_heads=H, num_bases=B).to(dev).eval()
+        spec = conv._spec_coo
     x = torch.randn(n, fin, device=dev)
     g = egc_amd.CSRGraph.from_edge_index(torch.zeros((2, 1), dtype=torch.long, device=dev), n)
     with torch.no_grad():
