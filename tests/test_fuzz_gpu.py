@@ -16,7 +16,12 @@ backward in the default path): 38 seeds clean; seed 303 (kept) has a case withou
 which is the oracle's own error -- it adds the 1,500 entries of a hub row one after the other (1.44e-5 from float64; HIP
 3.2e-7) -- hence the float64 criterion for such cases too (HIP within 1e-5 of float64, no allowance); seed 337 (not kept: it
 fails the x8 rule at 9.5) has ONE element of one std layer at 1.27e-5 from float64, a row of six tied neighbours whose
-E[x^2] - E[x]^2 the restatement happens to cancel exactly (every other element of that layer: <= 2.6e-7).
+E[x^2] - E[x]^2 the restatement happens to cancel exactly (every other element of that layer: <= 2.6e-7).  Seeds 340-399:
+59 clean; seed 377 (not kept) is the same thing at its plainest -- two rows whose three neighbours are IDENTICAL (true
+variance 0): float32 leaves E[x^2] - E[x]^2 = +3 / +1 / 0 ulp(x^2) here and -1 / 0 / 0 in the restatement (the bits of the
+GEMM's outputs decide), relu() hides the negative draws and sqrt(. + 1e-5) turns the positive ones into 1.1e-4 of std:
+3.1e-5 of the output against the restatement's 3.1e-7.  Nothing evaluated in float32 can promise the sign of that
+residue; what is promised is the formula of layers.py:203-216 with separately rounded squares, products and differences.
 EGC_FUZZ_DUMP=<dir> saves the inputs of failing cases."""
 import numpy as np
 import pytest
