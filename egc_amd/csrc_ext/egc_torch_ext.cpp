@@ -12,6 +12,9 @@
 #include <ATen/ATen.h>
 #include <torch/library.h>
 
+#include <algorithm>
+#include <vector>
+
 #include "egc_hip.h"
 
 namespace {
@@ -73,6 +76,136 @@ at::Tensor layer_forward_post(const at::Tensor& x, const at::Tensor& packed, con
   return out;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Training (round 3): forward and backward of the layer FROM THE MODULE'S PARAMETERS, one dispatcher call each -- what
+// egc_amd/functional.py's _EGCLayerParamsFunction does through ten Python helpers and as many ctypes calls (the eager
+// small-batch training step is bound by exactly that host time: DESIGN.md section 5).  Same library entry points, same
+// order, same buffers; square graphs without a halo, the dense-gradient shapes of egc_weight_grad_ex_f32 -- everything
+// else stays on the Python path (egc_amd/functional.py decides).
+// ---------------------------------------------------------------------------------------------------------------------
+// -> [out, wcat, bcat (or empty), bases, weightings, stats, cnt, arg_max (or empty), arg_min (or empty)]
+std::vector<at::Tensor> train_forward(const at::Tensor& x, const at::Tensor& comb_w, const c10::optional<at::Tensor>& comb_b,
+                                      const c10::optional<at::Tensor>& bcat_direct, at::TensorList basis_parts,
+                                      const c10::optional<at::Tensor>& bias, int64_t graph, int64_t layer,
+                                      const at::Tensor& workspace, int64_t stream, int64_t H, int64_t A, int64_t B, int64_t L,
+                                      int64_t Ls, bool permute_hab, int64_t gemm_flags) {
+  check_f32(x, "x");
+  check_f32(comb_w, "comb weight");
+  const auto* g = reinterpret_cast<const egc_graph*>(graph);
+  const auto* l = reinterpret_cast<const egc_layer*>(layer);
+  auto st = reinterpret_cast<egc_stream_t>(stream);
+  const int64_t n = x.size(0), f_in = x.size(1);
+  TORCH_CHECK(x.dim() == 2 && n == g->n_nodes && f_in == l->in_channels, "egc_amd: x has the wrong shape");
+  TORCH_CHECK(g->n_src_rows == 0 || g->n_src_rows == n, "egc_amd: the compiled training path takes square graphs");
+  const auto opts = x.options();
+  const int64_t f_g = B * Ls, W = H * B * A, ldb = egc_bases_ld(l), f_out = l->out_channels;
+  // (1) the GEMM operand from the parameters
+  at::Tensor wcat = at::empty({f_in, f_g + W}, opts);
+  at::Tensor bcat = comb_b.has_value() ? at::empty({W}, opts) : at::empty({0}, opts);
+  std::vector<const float*> parts;
+  for (const auto& t : basis_parts) { check_f32(t, "basis matrix"); parts.push_back(t.data_ptr<float>()); }
+  if (comb_b.has_value()) check_f32(*comb_b, "comb bias");
+  check_status(egc_weights_pack_f32(parts.data(), (int32_t)parts.size(), comb_w.data_ptr<float>(), fptr(comb_b), (int32_t)f_in,
+                                    (int32_t)H, (int32_t)A, (int32_t)B, (int32_t)L, (int32_t)Ls, permute_hab ? 1 : 0,
+                                    wcat.data_ptr<float>(), comb_b.has_value() ? bcat.data_ptr<float>() : nullptr, 0, st),
+               "egc_weights_pack_f32");
+  // (2) its split-precision planes, (3) the GEMM
+  const size_t pbytes = egc_basis_pack_bytes((int32_t)f_in, (int32_t)f_g, (int32_t)W);
+  at::Tensor planes = at::empty({(int64_t)pbytes}, opts.dtype(at::kByte));
+  check_status(egc_basis_pack_ex(wcat.data_ptr<float>(), (int32_t)f_in, (int32_t)f_g, (int32_t)W, (int32_t)gemm_flags,
+                                 planes.data_ptr(), pbytes, st), "egc_basis_pack_ex");
+  const float* bc = comb_b.has_value() ? bcat.data_ptr<float>() : fptr(bcat_direct);
+  if (bcat_direct.has_value()) check_f32(*bcat_direct, "comb bias");
+  at::Tensor bases = at::empty({n, ldb}, opts), weightings = at::empty({n, W}, opts);
+  check_status(egc_basis_transform_packed_ex(x.data_ptr<float>(), planes.data_ptr(), bc, n, (int32_t)f_in, (int32_t)f_g,
+                                             (int32_t)W, (int32_t)gemm_flags, bases.data_ptr<float>(), (int32_t)ldb,
+                                             weightings.data_ptr<float>(), st), "egc_basis_transform_packed_ex");
+  // (4) the training aggregate: output + what the backward consumes
+  bool has_max = false, has_min = false;
+  for (int t = 0; t < l->num_aggrs; ++t) {
+    has_max = has_max || l->aggrs[t] == EGC_AGGR_MAX;
+    has_min = has_min || l->aggrs[t] == EGC_AGGR_MIN;
+  }
+  at::Tensor out = at::empty({n, f_out}, opts);
+  at::Tensor stats = at::empty({n, std::max<int64_t>(egc_train_stats_floats(l), 1)}, opts);
+  at::Tensor cnt = at::empty({std::max<int64_t>(n, 1)}, opts.dtype(at::kInt));
+  at::Tensor arg_max = has_max ? at::empty({n, ldb}, opts.dtype(at::kInt)) : at::empty({0}, opts.dtype(at::kInt));
+  at::Tensor arg_min = has_min ? at::empty({n, ldb}, opts.dtype(at::kInt)) : at::empty({0}, opts.dtype(at::kInt));
+  if (bias.has_value()) check_f32(*bias, "bias");
+  check_status(egc_aggregate_combine_train_f32(g, l, bases.data_ptr<float>(), (int32_t)ldb, weightings.data_ptr<float>(), fptr(bias),
+                                               out.data_ptr<float>(), stats.data_ptr<float>(), cnt.data_ptr<int32_t>(),
+                                               has_max ? arg_max.data_ptr<int32_t>() : nullptr,
+                                               has_min ? arg_min.data_ptr<int32_t>() : nullptr, workspace.data_ptr(),
+                                               (size_t)workspace.numel(), st), "egc_aggregate_combine_train_f32");
+  return {out, wcat, bcat, bases, weightings, stats, cnt, arg_max, arg_min};
+}
+
+// -> [dx (or empty), d comb_w, d comb_b or d bcat_direct (or empty), d bias (or empty), d basis matrices ...]
+// Requires (checked by the caller): ldb == B Ls, (ldb + W) % 4 == 0, f_in % 4 == 0, f_in <= 128, ldb + W <= 192,
+// f_out % 4 == 0, f_out <= 128 -- the one-pass dense-gradient kernel's envelope; a bias and a combination bias present.
+std::vector<at::Tensor> train_backward(const at::Tensor& grad_out, const at::Tensor& x, const at::Tensor& wcat,
+                                       const at::Tensor& bases, const at::Tensor& weightings, const at::Tensor& stats,
+                                       const at::Tensor& cnt, const at::Tensor& arg_max, const at::Tensor& arg_min, int64_t graph,
+                                       int64_t t_graph, int64_t layer, int64_t stream, int64_t H, int64_t A, int64_t B, int64_t L,
+                                       int64_t Ls, bool permute_hab, bool packed_bias, bool need_x, at::IntArrayRef comb_w_shape,
+                                       at::IntArrayRef comb_b_shape, int64_t n_parts, at::IntArrayRef part_shape) {
+  const auto* g = reinterpret_cast<const egc_graph*>(graph);
+  const auto* tg = reinterpret_cast<const egc_graph*>(t_graph);
+  const auto* l = reinterpret_cast<const egc_layer*>(layer);
+  auto st = reinterpret_cast<egc_stream_t>(stream);
+  at::Tensor go = grad_out.contiguous();
+  check_f32(go, "grad_out");
+  const int64_t n = x.size(0), f_in = x.size(1);
+  const int64_t W = H * B * A, ldb = egc_bases_ld(l), k = ldb + W, f_out = l->out_channels;
+  const auto opts = x.options();
+  // (1) sparse backward into the column blocks of ONE [N, ldb + W] array: the left operand of both dense gradients
+  at::Tensor d_cat = at::empty({n, k}, opts);
+  const size_t wbytes = egc_backward_workspace_bytes_for(l, g);
+  at::Tensor ws = at::empty({(int64_t)std::max<size_t>(wbytes, 1)}, opts.dtype(at::kByte));
+  check_status(egc_aggregate_combine_backward_f32(g, tg, l, bases.data_ptr<float>(), (int32_t)ldb, weightings.data_ptr<float>(),
+                                                  go.data_ptr<float>(), stats.data_ptr<float>(), cnt.data_ptr<int32_t>(),
+                                                  arg_max.numel() ? arg_max.data_ptr<int32_t>() : nullptr,
+                                                  arg_min.numel() ? arg_min.data_ptr<int32_t>() : nullptr, d_cat.data_ptr<float>(),
+                                                  (int32_t)k, d_cat.data_ptr<float>() + ldb, (int32_t)k, ws.data_ptr(), wbytes, st),
+               "egc_aggregate_combine_backward_f32");
+  // (2) dx = d_cat wcat^T on the split-precision GEMM (wcat packed where it lies)
+  at::Tensor dx = at::empty({0}, opts);
+  if (need_x) {
+    const size_t pb = egc_basis_pack_bytes((int32_t)k, (int32_t)f_in, 0);
+    at::Tensor packed = at::empty({(int64_t)pb}, opts.dtype(at::kByte));
+    dx = at::empty({n, f_in}, opts);
+    check_status(egc_basis_pack_transposed(wcat.data_ptr<float>(), k, (int32_t)k, (int32_t)f_in, 0, packed.data_ptr(), pb, st),
+                 "egc_basis_pack_transposed");
+    check_status(egc_basis_transform_packed(d_cat.data_ptr<float>(), packed.data_ptr(), nullptr, n, (int32_t)k, (int32_t)f_in, 0,
+                                            dx.data_ptr<float>(), (int32_t)f_in, nullptr, st), "egc_basis_transform_packed");
+  }
+  // (3) d wcat = x^T d_cat with the column sums of d_cat (combination bias) and of grad_out (the layer's bias) in the same pass
+  at::Tensor dwcat = at::empty({f_in, k}, opts), cs = at::empty({k}, opts), es = at::empty({f_out}, opts);
+  const int64_t gbytes = (int64_t)egc_weight_grad_ex_workspace_bytes(n, (int32_t)f_in, (int32_t)k, (int32_t)f_out);
+  at::Tensor gws = at::empty({std::max<int64_t>(gbytes, 16)}, opts.dtype(at::kByte));
+  check_status(egc_weight_grad_ex_f32(x.data_ptr<float>(), f_in, d_cat.data_ptr<float>(), k, n, (int32_t)f_in, (int32_t)k,
+                                      dwcat.data_ptr<float>(), cs.data_ptr<float>(), go.data_ptr<float>(), f_out, (int32_t)f_out,
+                                      es.data_ptr<float>(), gws.data_ptr(), gws.numel(), st), "egc_weight_grad_ex_f32");
+  // (4) the parameters' gradients from (d wcat, d bcat): the pack's index map read the other way
+  at::Tensor dbcat = cs.slice(0, k - W, k).contiguous();
+  at::Tensor dcw = at::empty(comb_w_shape, opts);
+  at::Tensor dcb = packed_bias ? at::empty(comb_b_shape, opts) : dbcat;
+  std::vector<at::Tensor> dparts;
+  std::vector<const float*> ptrs;
+  for (int64_t i = 0; i < n_parts; ++i) {
+    dparts.push_back(at::empty(part_shape, opts));
+    ptrs.push_back(dparts.back().data_ptr<float>());
+  }
+  check_status(egc_weights_pack_f32(ptrs.data(), (int32_t)n_parts, dcw.data_ptr<float>(), packed_bias ? dcb.data_ptr<float>() : nullptr,
+                                    (int32_t)f_in, (int32_t)H, (int32_t)A, (int32_t)B, (int32_t)L, (int32_t)Ls, permute_hab ? 1 : 0,
+                                    dwcat.data_ptr<float>(), packed_bias ? dbcat.data_ptr<float>() : nullptr, 1, st),
+               "egc_weights_pack_f32 (gradients)");
+  std::vector<at::Tensor> out{dx, dcw, dcb, es};
+  out.insert(out.end(), dparts.begin(), dparts.end());
+  return out;
+}
+
 }  // namespace
 
 TORCH_LIBRARY(egc_amd_native, m) {
@@ -81,10 +214,18 @@ TORCH_LIBRARY(egc_amd_native, m) {
   m.def("layer_forward_post(Tensor x, Tensor packed, Tensor? bcat, Tensor? bias, int graph, int layer, Tensor workspace, "
         "int stream, int ldb, int w_cols, int f_out, int gemm_flags, Tensor? scale, Tensor? shift, Tensor? residual, bool relu) "
         "-> Tensor");
+  m.def("train_forward(Tensor x, Tensor comb_w, Tensor? comb_b, Tensor? bcat_direct, Tensor[] basis_parts, Tensor? bias, int graph, "
+        "int layer, Tensor workspace, int stream, int H, int A, int B, int L, int Ls, bool permute_hab, int gemm_flags) -> Tensor[]");
+  m.def("train_backward(Tensor grad_out, Tensor x, Tensor wcat, Tensor bases, Tensor weightings, Tensor stats, Tensor cnt, "
+        "Tensor arg_max, Tensor arg_min, int graph, int t_graph, int layer, int stream, int H, int A, int B, int L, int Ls, "
+        "bool permute_hab, bool packed_bias, bool need_x, int[] comb_w_shape, int[] comb_b_shape, int n_parts, int[] part_shape) "
+        "-> Tensor[]");
 }
 
 // HIP devices only (PyTorch-ROCm dispatches them under the CUDA key): a CPU tensor finds no kernel and the dispatcher raises
 TORCH_LIBRARY_IMPL(egc_amd_native, CUDA, m) {
   m.impl("layer_forward", &layer_forward);
   m.impl("layer_forward_post", &layer_forward_post);
+  m.impl("train_forward", &train_forward);
+  m.impl("train_backward", &train_backward);
 }

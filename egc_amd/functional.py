@@ -465,6 +465,33 @@ def _native_ops(dev):
     return nat
 
 
+def _native_train_ops(graph, spec, x, bias, comb_w, comb_b, bcat_direct, bases):
+    """The compiled binding for the training call (train_forward / train_backward of egc_amd/csrc_ext), or None: one GPU,
+    a square graph without a halo, dense float32 operands, a bias and a combination bias, and the shape envelope in which
+    the backward's dense gradients are one-pass kernels (egc_weight_grad_ex_f32 with both column-sum streams riding along,
+    the packed d x GEMM, the joint [N, ldb + W] gradient array).  Everything else: the Python path below, same kernels."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous() and x.size(0) > 0):
+        return None
+    nat = _native_ops(x.device)
+    if nat is None or not hasattr(nat, "train_forward") or _C.env_flag("EGC_NO_NATIVE_TRAIN"):
+        return None
+    if graph.halo is not None or graph.n_src_rows != graph.n_nodes or gemm_exact() or os.environ.get("EGC_XT_FP32") is not None:
+        return None
+    cb = comb_b if comb_b is not None else bcat_direct
+    if bias is None or cb is None or (comb_b is not None and bcat_direct is not None):
+        return None
+    k = spec.ldb + spec.w_cols
+    if not (spec.ldb == spec.f_g and k % 4 == 0 and k <= 192 and spec.f_in % 4 == 0 and spec.f_in <= 128
+            and spec.f_out % 4 == 0 and spec.f_out <= 128):
+        return None
+    for t in (bias, comb_w, cb, *bases):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            return None
+    if len({tuple(b.shape) for b in bases}) != 1:
+        return None
+    return nat
+
+
 def _layer_forward_one_call(graph: CSRGraph, spec: LayerSpec, x, packed, bcat, bias):
     """The common inference case (one GPU, packed weights at hand, no fused tail) as ONE library call
     (egc_layer_forward_packed: both launches from C) -- small batched graphs are bound by the host side.  Through the
@@ -813,14 +840,38 @@ class _EGCLayerParamsFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, bias, comb_w, comb_b, bcat_direct, graph, spec, dims, permute, *bases):
-        wcat, bcat = _pack_params(dims, permute, comb_w, comb_b, bases)
         ctx.dims, ctx.permute, ctx.packed_b = dims, permute, comb_b is not None
         ctx.shapes = (comb_w.shape, comb_b.shape if comb_b is not None else None, [b.shape for b in bases])
+        nat = _native_train_ops(graph, spec, x, bias, comb_w, comb_b, bcat_direct, bases)
+        ctx.native = nat is not None
+        if nat is not None:
+            # pack + planes + GEMM + training aggregate as ONE compiled call (egc_amd/csrc_ext: train_forward)
+            f_in, H, A, B, L, Ls = dims
+            out, wcat, _, bases_t, weightings, stats, cnt, arg_max, arg_min = nat.train_forward(
+                x, comb_w, comb_b, bcat_direct, list(bases), bias, graph.c_addr(), spec.c_addr, graph.workspace_for(spec),
+                _stream_ptr(x.device), H, A, B, L, Ls, bool(permute), spec.gemm_flags)
+            ctx.save_for_backward(x, wcat, bases_t, weightings, stats, cnt, arg_max, arg_min)
+            ctx.graph, ctx.spec = graph, spec
+            ctx.has_bcat, ctx.has_bias = True, True
+            return out
+        wcat, bcat = _pack_params(dims, permute, comb_w, comb_b, bases)
         return _layer_train_forward(ctx, x, wcat, bcat if comb_b is not None else bcat_direct, bias, graph, spec)
 
     @staticmethod
     def backward(ctx, grad_out):
         need = ctx.needs_input_grad
+        if ctx.native:
+            x, wcat, bases_t, weightings, stats, cnt, arg_max, arg_min = ctx.saved_tensors
+            f_in, H, A, B, L, Ls = ctx.dims
+            nat = _native_ops(x.device)
+            shapes = ctx.shapes
+            res = nat.train_backward(grad_out, x, wcat, bases_t, weightings, stats, cnt, arg_max, arg_min, ctx.graph.c_addr(),
+                                     ctx.graph.transposed().c_addr(), ctx.spec.c_addr, _stream_ptr(x.device), H, A, B, L, Ls,
+                                     bool(ctx.permute), bool(ctx.packed_b), bool(need[0]), list(shapes[0]),
+                                     list(shapes[1]) if shapes[1] is not None else [0], len(shapes[2]), list(shapes[2][0]))
+            dx, dcw, dcb_or_bcat, dbias = res[0] if need[0] else None, res[1], res[2], res[3]
+            return (dx, dbias, dcw, dcb_or_bcat if ctx.packed_b else None, None if ctx.packed_b else dcb_or_bcat,
+                    None, None, None, None, *res[4:])
         need_w = need[2] or any(need[9:])
         need_b = ctx.has_bcat and (need[3] if ctx.packed_b else need[4])
         dx, dwcat, dbcat, dbias = _layer_train_backward(ctx, grad_out, need[0], need_w, need_b, ctx.has_bias and need[1])
