@@ -31,19 +31,50 @@ __device__ inline f4 keep4(const unsigned char* __restrict__ keep, int64_t quad,
             (m & 0xff000000u) ? keep_scale : 0.f};
 }
 
-template <bool MASKED>
+// Small inputs (few partial blocks): the per-column step between the statistics pass and the elementwise pass rides in
+// the SAME launch -- the block that arrives last (agent-scope counter; the partials travel as agent-scope stores and
+// loads: no cache write-back fence) adds the partials in the finalize kernels' fixed order and finishes every column.
+// A training step of the reference's batched nets is bound by its launches: one launch less per
+// block and direction.
+struct FinArgs {
+  int* sync;                    // arrival counter: zero on entry, zero again on exit
+  double eps, momentum;
+  const float* gamma;
+  const float* beta;
+  double* stats;                // forward: written [3][cols]
+  float* affine;
+  float* running_mean;
+  float* running_var;
+  const int64_t* n_tracked;
+  const double* bstats;         // backward: the forward's stats
+  float* outv;                  // backward: [5][cols]
+};
+
+template <bool COHERENT>
+__device__ inline void moment_totals(const double* __restrict__ partials, int n_partials, int cols, int col, int pl,
+                                     double (&red)[2][4][64 + 1], double& t1, double& t2);
+__device__ inline void bn_forward_column(double s1, double s2, int col, int cols, double n_rows, const float* gamma, const float* beta,
+                                         double eps, double* stats, float* affine, float* running_mean, float* running_var,
+                                         double momentum, double n_tracked);
+__device__ inline void bn_backward_column(double s1, double sgh, int col, int cols, double n_rows, const double* stats,
+                                          const float* gamma, float* outv);
+
+template <bool MASKED, int FIN = 0>   // FIN: 0 partials only, 1 + forward finalize, 2 + backward finalize
 __global__ void __launch_bounds__(256) column_moments_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
                                                              int64_t n_rows, int cols, int rows_per_block,
                                                              double* __restrict__ out, int relu,
                                                              const unsigned char* __restrict__ keep, float keep_scale,
                                                              int64_t* __restrict__ count_inc,
-                                                             const int64_t* __restrict__ n_valid) {
+                                                             const int64_t* __restrict__ n_valid, FinArgs fin = FinArgs()) {
   __shared__ d4 red[2][256];
   // rows [*n_valid, n_rows) are padding (a batch padded to the static shape of a hipGraph recording): not counted
   if (n_valid != nullptr) n_rows = min(n_rows, max(*n_valid, (int64_t)0));
   // BatchNorm's num_batches_tracked: bumped here, one launch BEFORE the finalize kernel reads it
-  if (count_inc != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *count_inc += 1;
+  if (count_inc != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (FIN != 0) __hip_atomic_fetch_add(count_inc, (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // read by the last block
+    else *count_inc += 1;
+  }
   const int cg = cols >> 2;                 // 16-byte column groups (<= 256)
   const int rl = 256 / cg;                  // row lanes
   const int g = threadIdx.x % cg, lane_r = threadIdx.x / cg;
@@ -89,8 +120,57 @@ __global__ void __launch_bounds__(256) column_moments_kernel(const float* __rest
   if (lane_r == 0) {
     for (int k = 1; k < rl; ++k) { s1 += red[0][k * cg + g]; s2 += red[1][k * cg + g]; }
     double* o = out + (int64_t)blockIdx.x * 2 * cols;
-    reinterpret_cast<d4*>(o)[g] = s1;
-    reinterpret_cast<d4*>(o + cols)[g] = s2;
+    if (FIN != 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __hip_atomic_store(o + 4 * g + i, s1[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(o + cols + 4 * g + i, s2[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {
+      reinterpret_cast<d4*>(o)[g] = s1;
+      reinterpret_cast<d4*>(o + cols)[g] = s2;
+    }
+  }
+  if constexpr (FIN != 0) {
+    __shared__ int last_block;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this block's partials have left
+    __syncthreads();
+    if (threadIdx.x == 0)
+      last_block = __hip_atomic_fetch_add(fin.sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!last_block) return;
+    if (threadIdx.x == 0) __hip_atomic_store(fin.sync, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const double nr = fmax((double)n_rows, 1.0);
+    // One thread per column; at most 64 partial blocks (host), added in the finalize kernels' order -- eight runs of eight
+    // partials, then the eight run totals: the same bits as the two-launch form.  All loads of a column are independent.
+    const int np = (int)gridDim.x;
+    for (int col = threadIdx.x; col < cols; col += 256) {
+      double v1[64], v2[64];
+#pragma unroll
+      for (int p = 0; p < 64; ++p) {
+        const bool ok = p < np;
+        v1[p] = ok ? __hip_atomic_load(out + (int64_t)p * 2 * cols + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        v2[p] = ok ? __hip_atomic_load(out + (int64_t)p * 2 * cols + cols + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      }
+      double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        double u1 = 0.0, u2 = 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { u1 += v1[8 * k + j]; u2 += v2[8 * k + j]; }
+        t1 += u1; t2 += u2;
+      }
+      if (FIN == 1) {
+        double tracked = 1.0;
+        if (fin.momentum < 0.0 && fin.running_mean != nullptr)
+          tracked = (double)__hip_atomic_load(fin.n_tracked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bn_forward_column(t1, t2, col, cols, nr, fin.gamma, fin.beta, fin.eps, fin.stats, fin.affine, fin.running_mean,
+                          fin.running_var, fin.momentum, tracked);
+      } else {
+        bn_backward_column(t1, t2, col, cols, nr, fin.bstats, fin.gamma, fin.outv);
+      }
+    }
   }
 }
 
@@ -99,8 +179,12 @@ __global__ void __launch_bounds__(256) column_moments_kernel(const float* __rest
 // 23 us for 1,024 partials), the lanes of a column are then added eight at a time in lane order -- a fixed order: the
 // result does not depend on timing.
 constexpr int FIN_COLS = 4, FIN_LANES = 64;
+template <bool COHERENT>
 __device__ inline void moment_totals(const double* __restrict__ partials, int n_partials, int cols, int col, int pl,
                                      double (&red)[2][FIN_COLS][FIN_LANES + 1], double& t1, double& t2) {
+  auto ld = [&](int64_t i) -> double {      // partials of the same launch come through agent-scope loads
+    return COHERENT ? __hip_atomic_load(partials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : partials[i];
+  };
   const int cl = threadIdx.x % FIN_COLS;
   double s1 = 0.0, s2 = 0.0;
   if (col < cols) {
@@ -109,15 +193,15 @@ __device__ inline void moment_totals(const double* __restrict__ partials, int n_
       double a[4], b[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        a[u] = partials[(int64_t)(p + u * FIN_LANES) * 2 * cols + col];
-        b[u] = partials[(int64_t)(p + u * FIN_LANES) * 2 * cols + cols + col];
+        a[u] = ld((int64_t)(p + u * FIN_LANES) * 2 * cols + col);
+        b[u] = ld((int64_t)(p + u * FIN_LANES) * 2 * cols + cols + col);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) { s1 += a[u]; s2 += b[u]; }
     }
     for (; p < n_partials; p += FIN_LANES) {
-      s1 += partials[(int64_t)p * 2 * cols + col];
-      s2 += partials[(int64_t)p * 2 * cols + cols + col];
+      s1 += ld((int64_t)p * 2 * cols + col);
+      s2 += ld((int64_t)p * 2 * cols + cols + col);
     }
   }
   red[0][cl][pl] = s1;
@@ -136,6 +220,38 @@ __device__ inline void moment_totals(const double* __restrict__ partials, int n_
     for (int k = 0; k < 8; ++k) { t1 += red[0][cl][k]; t2 += red[1][cl][k]; }
 }
 
+__device__ inline void bn_forward_column(double s1, double s2, int col, int cols, double n_rows, const float* gamma, const float* beta,
+                                         double eps, double* stats, float* affine, float* running_mean, float* running_var,
+                                         double momentum, double n_tracked) {
+  const double mean = s1 / n_rows;
+  double var = s2 / n_rows - mean * mean;
+  var = var > 0.0 ? var : 0.0;
+  const double rstd = 1.0 / sqrt(var + eps);
+  const double g = gamma != nullptr ? (double)gamma[col] : 1.0, b = beta != nullptr ? (double)beta[col] : 0.0;
+  stats[col] = mean;
+  stats[cols + col] = var;
+  stats[2 * cols + col] = rstd;
+  affine[col] = (float)(g * rstd);
+  affine[cols + col] = (float)(b - mean * g * rstd);
+  if (running_mean != nullptr) {
+    const double m = momentum >= 0.0 ? momentum : 1.0 / n_tracked;
+    running_mean[col] = (float)((1.0 - m) * (double)running_mean[col] + m * mean);
+    running_var[col] = (float)((1.0 - m) * (double)running_var[col] + m * var * (n_rows > 1.0 ? n_rows / (n_rows - 1.0) : 1.0));
+  }
+}
+
+__device__ inline void bn_backward_column(double s1, double sgh, int col, int cols, double n_rows, const double* stats,
+                                          const float* gamma, float* outv) {
+  const double mean = stats[col], rstd = stats[2 * cols + col];
+  const double s2 = (sgh - mean * s1) * rstd;                 // sum g * h_hat
+  const double a = (gamma != nullptr ? (double)gamma[col] : 1.0) * rstd;
+  outv[col] = (float)s2;                                      // d gamma
+  outv[cols + col] = (float)s1;                               // d beta
+  outv[2 * cols + col] = (float)a;                            // dh = a g - (a / n) (s1 + (h - mean) rstd s2)
+  outv[3 * cols + col] = (float)(-(a / n_rows) * rstd * s2);
+  outv[4 * cols + col] = (float)(-(a / n_rows) * (s1 - mean * rstd * s2));
+}
+
 // Everything between the statistics pass and the elementwise pass of the training-mode BatchNorm tail, per column:
 // batch mean / biased variance / 1/std (float64), the affine pair the elementwise kernel applies, and the running
 // statistics of the module (nn.BatchNorm1d: unbiased variance, momentum or -- momentum < 0 -- the cumulative average
@@ -152,23 +268,10 @@ __global__ void __launch_bounds__(256) bn_forward_finalize_kernel(const double* 
   if (n_valid != nullptr) n_rows = fmax(fmin(n_rows, (double)*n_valid), 1.0);
   const int col = blockIdx.x * FIN_COLS + threadIdx.x % FIN_COLS, pl = threadIdx.x / FIN_COLS;
   double s1, s2;
-  moment_totals(partials, n_partials, cols, col, pl, red, s1, s2);
+  moment_totals<false>(partials, n_partials, cols, col, pl, red, s1, s2);
   if (pl != 0 || col >= cols) return;
-  const double mean = s1 / n_rows;
-  double var = s2 / n_rows - mean * mean;
-  var = var > 0.0 ? var : 0.0;
-  const double rstd = 1.0 / sqrt(var + eps);
-  const double g = gamma != nullptr ? (double)gamma[col] : 1.0, b = beta != nullptr ? (double)beta[col] : 0.0;
-  stats[col] = mean;
-  stats[cols + col] = var;
-  stats[2 * cols + col] = rstd;
-  affine[col] = (float)(g * rstd);
-  affine[cols + col] = (float)(b - mean * g * rstd);
-  if (running_mean != nullptr) {
-    const double m = momentum >= 0.0 ? momentum : 1.0 / (double)(*n_tracked);
-    running_mean[col] = (float)((1.0 - m) * (double)running_mean[col] + m * mean);
-    running_var[col] = (float)((1.0 - m) * (double)running_var[col] + m * var * (n_rows > 1.0 ? n_rows / (n_rows - 1.0) : 1.0));
-  }
+  bn_forward_column(s1, s2, col, cols, n_rows, gamma, beta, eps, stats, affine, running_mean, running_var, momentum,
+                    (momentum < 0.0 && running_mean != nullptr) ? (double)(*n_tracked) : 1.0);
 }
 
 // Backward counterpart: from the partial sums (sum g, sum g h) of the masked upstream gradient, the gradients of the
@@ -181,16 +284,9 @@ __global__ void __launch_bounds__(256) bn_backward_finalize_kernel(const double*
   if (n_valid != nullptr) n_rows = fmax(fmin(n_rows, (double)*n_valid), 1.0);
   const int col = blockIdx.x * FIN_COLS + threadIdx.x % FIN_COLS, pl = threadIdx.x / FIN_COLS;
   double s1, sgh;
-  moment_totals(partials, n_partials, cols, col, pl, red, s1, sgh);
+  moment_totals<false>(partials, n_partials, cols, col, pl, red, s1, sgh);
   if (pl != 0 || col >= cols) return;
-  const double mean = stats[col], rstd = stats[2 * cols + col];
-  const double s2 = (sgh - mean * s1) * rstd;                 // sum g * h_hat
-  const double a = (gamma != nullptr ? (double)gamma[col] : 1.0) * rstd;
-  outv[col] = (float)s2;                                      // d gamma
-  outv[cols + col] = (float)s1;                               // d beta
-  outv[2 * cols + col] = (float)a;                            // dh = a g - (a / n) (s1 + (h - mean) rstd s2)
-  outv[3 * cols + col] = (float)(-(a / n_rows) * rstd * s2);
-  outv[4 * cols + col] = (float)(-(a / n_rows) * (s1 - mean * rstd * s2));
+  bn_backward_column(s1, sgh, col, cols, n_rows, stats, gamma, outv);
 }
 
 // out = act(h * scale + shift) + residual, 16 bytes per thread
@@ -319,6 +415,64 @@ int egc_column_moments_f64(const float* a, const float* b, const float* scale, c
     column_moments_kernel<false><<<(unsigned)n_partials, 256, 0, stream>>>(a, nullptr, nullptr, nullptr, n_rows, cols, rows_per_block,
                                                                            partials, 0, nullptr, 1.f, count_inc, n_valid);
   EGC_LAUNCH_CHECK("column_moments_kernel");
+  return EGC_OK;
+}
+
+constexpr int BN_FUSE_MAX_PARTIALS = 64;   // beyond: the finalize as its own launch (many blocks share the column totals)
+
+int egc_bn_forward_stats_f32(const float* h, int64_t n_rows, int32_t cols, double* partials, int32_t n_partials,
+                             int64_t* count_inc, const int64_t* n_valid, const float* gamma, const float* beta, double eps,
+                             double* stats, float* affine, float* running_mean, float* running_var, double momentum,
+                             const int64_t* n_tracked, int32_t* sync, egc_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (sync == nullptr || n_partials > BN_FUSE_MAX_PARTIALS) {
+    const int st = egc_column_moments_f64(h, nullptr, nullptr, nullptr, 0, nullptr, 1.f, n_rows, cols, partials, n_partials, count_inc,
+                                          n_valid, stream_);
+    if (st != EGC_OK) return st;
+    return egc_bn_forward_finalize(partials, n_partials, cols, n_rows, gamma, beta, eps, stats, affine, running_mean, running_var,
+                                   momentum, n_tracked, n_valid, stream_);
+  }
+  if (n_rows <= 0 || cols <= 0 || partials == nullptr || n_partials <= 0 || h == nullptr || stats == nullptr || affine == nullptr)
+    return EGC_ERR_INVALID;
+  if ((cols & 3) != 0 || cols > 1024 || !aligned16(h) || (reinterpret_cast<uintptr_t>(partials) & 31) != 0) return EGC_ERR_UNSUPPORTED;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return EGC_ERR_INVALID;
+  if (running_mean != nullptr && momentum < 0.0 && n_tracked == nullptr) return EGC_ERR_INVALID;
+  if (running_mean != nullptr && n_rows < 2) return EGC_ERR_INVALID;
+  FinArgs f = FinArgs();
+  f.sync = sync; f.eps = eps; f.momentum = momentum; f.gamma = gamma; f.beta = beta; f.stats = stats; f.affine = affine;
+  f.running_mean = running_mean; f.running_var = running_var; f.n_tracked = n_tracked;
+  const int rows_per_block = (int)std::max<int64_t>(ceil_div(n_rows, (int64_t)n_partials), 1);
+  column_moments_kernel<false, 1><<<(unsigned)n_partials, 256, 0, stream>>>(h, nullptr, nullptr, nullptr, n_rows, cols, rows_per_block,
+                                                                              partials, 0, nullptr, 1.f, count_inc, n_valid, f);
+  EGC_LAUNCH_CHECK("column_moments_kernel (with the forward finalize)");
+  return EGC_OK;
+}
+
+int egc_bn_backward_stats_f32(const float* dout, const float* h, const float* scale, const float* shift, int32_t relu,
+                              const uint8_t* keep, float keep_scale, int64_t n_rows, int32_t cols, double* partials,
+                              int32_t n_partials, const int64_t* n_valid, const double* stats, const float* gamma, float* out5,
+                              int32_t* sync, egc_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (sync == nullptr || n_partials > BN_FUSE_MAX_PARTIALS) {
+    const int st = egc_column_moments_f64(dout, h, scale, shift, relu, keep, keep_scale, n_rows, cols, partials, n_partials, nullptr,
+                                          n_valid, stream_);
+    if (st != EGC_OK) return st;
+    return egc_bn_backward_finalize(partials, n_partials, cols, n_rows, stats, gamma, out5, n_valid, stream_);
+  }
+  if (n_rows <= 0 || cols <= 0 || partials == nullptr || n_partials <= 0 || dout == nullptr || h == nullptr || stats == nullptr ||
+      out5 == nullptr)
+    return EGC_ERR_INVALID;
+  if ((cols & 3) != 0 || cols > 1024 || !aligned16(dout) || !aligned16(h) || !aligned16(scale) || !aligned16(shift) ||
+      (reinterpret_cast<uintptr_t>(partials) & 31) != 0)
+    return EGC_ERR_UNSUPPORTED;
+  if (relu && (scale == nullptr || shift == nullptr)) return EGC_ERR_INVALID;
+  if (keep != nullptr && (reinterpret_cast<uintptr_t>(keep) & 3) != 0) return EGC_ERR_INVALID;
+  FinArgs f = FinArgs();
+  f.sync = sync; f.gamma = gamma; f.bstats = stats; f.outv = out5;
+  const int rows_per_block = (int)std::max<int64_t>(ceil_div(n_rows, (int64_t)n_partials), 1);
+  column_moments_kernel<true, 2><<<(unsigned)n_partials, 256, 0, stream>>>(dout, h, scale, shift, n_rows, cols, rows_per_block, partials,
+                                                                             relu, keep, keep_scale, nullptr, n_valid, f);
+  EGC_LAUNCH_CHECK("column_moments_kernel (with the backward finalize)");
   return EGC_OK;
 }
 

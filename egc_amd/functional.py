@@ -977,29 +977,35 @@ class _BatchNormActResidualFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, residual, gamma, beta, eps, relu, running_mean, running_var, momentum, n_tracked, keep, keep_scale,
-                n_valid):
+                n_valid, sync=None):
         lib = _C.load()
         n, c = h.shape
         dev = h.device
         h = h.contiguous()
         gamma_c = gamma.detach().contiguous().float() if gamma is not None else None
         beta_c = beta.detach().contiguous().float() if beta is not None else None
-        # (the statistics pass also bumps num_batches_tracked, one launch before the finalize kernel reads it)
-        parts = _moment_partials(h, count_inc=n_tracked if running_mean is not None else None, n_valid=n_valid)
         res = residual.contiguous() if residual is not None else None
+        ctx.sync = sync
         with _device_guard(dev):
+            n_parts = max(1, min(1024, (n + 127) // 128))
+            parts = torch.empty((n_parts, 2, c), dtype=torch.float64, device=dev)
             stats = torch.empty((3, c), dtype=torch.float64, device=dev)     # mean | biased variance | 1 / std
             affine = torch.empty((2, c), dtype=torch.float32, device=dev)    # scale | shift
             out = torch.empty_like(h)
             stream = _stream_ptr(dev)
-            _C.check(lib.egc_bn_forward_finalize(
-                parts.data_ptr(), parts.size(0), c, n, gamma_c.data_ptr() if gamma_c is not None else None,
+            # statistics pass (which also bumps num_batches_tracked) + the per-channel step: one call, and with a sync word
+            # and few partial blocks one launch (egc_bn_forward_stats_f32)
+            _C.check(lib.egc_bn_forward_stats_f32(
+                h.data_ptr(), n, c, parts.data_ptr(), n_parts,
+                n_tracked.data_ptr() if (n_tracked is not None and running_mean is not None) else None,
+                n_valid.data_ptr() if n_valid is not None else None,
+                gamma_c.data_ptr() if gamma_c is not None else None,
                 beta_c.data_ptr() if beta_c is not None else None, float(eps), stats.data_ptr(), affine.data_ptr(),
                 running_mean.data_ptr() if running_mean is not None else None,
                 running_var.data_ptr() if running_var is not None else None,
                 -1.0 if momentum is None else float(momentum),
                 n_tracked.data_ptr() if n_tracked is not None else None,
-                n_valid.data_ptr() if n_valid is not None else None, stream), "egc_bn_forward_finalize")
+                sync.data_ptr() if sync is not None else None, stream), "egc_bn_forward_stats_f32")
             _C.check(lib.egc_affine_act_residual_f32(h.data_ptr(), affine[0].data_ptr(), affine[1].data_ptr(),
                                                      res.data_ptr() if res is not None else None, int(relu),
                                                      keep.data_ptr() if keep is not None else None, float(keep_scale),
@@ -1021,23 +1027,33 @@ class _BatchNormActResidualFunction(torch.autograd.Function):
         n, c = h.shape
         dev = h.device
         if dout is None:
-            return (None,) * 13
+            return (None,) * 14
         dout = dout.contiguous()
         dh = dgamma = dbeta = None
         if ctx.needs_input_grad[0] or (ctx.has_gamma and ctx.needs_input_grad[2]) or (ctx.has_beta and ctx.needs_input_grad[3]):
-            if ctx.relu or keep is not None or n_valid is not None:    # sum g, sum g h   (g = dout * dropout mask * relu mask)
-                parts = _moment_partials(dout, h, affine[0], affine[1], ctx.relu, keep, ctx.keep_scale, n_valid=n_valid)
-            else:
+            masked = ctx.relu or keep is not None or n_valid is not None
+            if not masked:
                 s1 = _column_sums(dout).double()
                 sgh = (dout.double() * h.double()).sum(0) if n else torch.zeros(c, dtype=torch.float64, device=dev)
                 parts = torch.stack([s1, sgh]).unsqueeze(0).contiguous()
             with _device_guard(dev):
                 out5 = torch.empty((5, c), dtype=torch.float32, device=dev)   # d gamma | d beta | coef_g | coef_h | coef_1
                 stream = _stream_ptr(dev)
-                _C.check(lib.egc_bn_backward_finalize(parts.data_ptr(), parts.size(0), c, n, stats.data_ptr(),
-                                                      gamma_c.data_ptr() if gamma_c is not None else None, out5.data_ptr(),
-                                                      n_valid.data_ptr() if n_valid is not None else None, stream),
-                         "egc_bn_backward_finalize")
+                if masked:      # sum g, sum g h (g = dout * dropout mask * relu mask) + the per-channel step: one call
+                    n_parts = max(1, min(1024, (n + 127) // 128))
+                    parts = torch.empty((n_parts, 2, c), dtype=torch.float64, device=dev)
+                    sync = ctx.sync
+                    _C.check(lib.egc_bn_backward_stats_f32(
+                        dout.data_ptr(), h.data_ptr(), affine[0].data_ptr(), affine[1].data_ptr(), int(ctx.relu),
+                        keep.data_ptr() if keep is not None else None, ctx.keep_scale, n, c, parts.data_ptr(), n_parts,
+                        n_valid.data_ptr() if n_valid is not None else None, stats.data_ptr(),
+                        gamma_c.data_ptr() if gamma_c is not None else None, out5.data_ptr(),
+                        sync.data_ptr() if sync is not None else None, stream), "egc_bn_backward_stats_f32")
+                else:
+                    _C.check(lib.egc_bn_backward_finalize(parts.data_ptr(), parts.size(0), c, n, stats.data_ptr(),
+                                                          gamma_c.data_ptr() if gamma_c is not None else None, out5.data_ptr(),
+                                                          n_valid.data_ptr() if n_valid is not None else None, stream),
+                             "egc_bn_backward_finalize")
                 dgamma = out5[0] if ctx.has_gamma and ctx.needs_input_grad[2] else None
                 dbeta = out5[1] if ctx.has_beta and ctx.needs_input_grad[3] else None
                 if ctx.needs_input_grad[0]:
@@ -1049,7 +1065,7 @@ class _BatchNormActResidualFunction(torch.autograd.Function):
                                                              dh.data_ptr(), n_valid.data_ptr() if n_valid is not None else None,
                                                              stream), "egc_affine_act_backward_f32")
         dres = dout if ctx.has_res and ctx.needs_input_grad[1] else None
-        return dh, dres, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+        return dh, dres, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
 
 def batch_norm_act_residual_supported(h: torch.Tensor) -> bool:
@@ -1058,7 +1074,8 @@ def batch_norm_act_residual_supported(h: torch.Tensor) -> bool:
 
 
 def batch_norm_act_residual(h, residual, gamma, beta, eps: float, relu: bool, running_mean=None, running_var=None,
-                            momentum=None, num_batches_tracked=None, keep=None, keep_scale: float = 1.0, n_valid=None):
+                            momentum=None, num_batches_tracked=None, keep=None, keep_scale: float = 1.0, n_valid=None,
+                            sync=None):
     """Training-mode BatchNorm1d (batch statistics) -> optional ReLU -> optional residual add, fused
     (_BatchNormActResidualFunction): returns (out, batch mean [C] float64, biased batch variance [C] float64).
     With ``running_mean`` / ``running_var`` (float32 [C], dense) the running statistics are updated in the same launch
@@ -1066,7 +1083,9 @@ def batch_norm_act_residual(h, residual, gamma, beta, eps: float, relu: bool, ru
     the cumulative average over ``num_batches_tracked`` (a device int64 scalar, INCREMENTED here when given).
     ``keep`` / ``keep_scale``: dropout between the activation and the residual add (see the Function).
     ``n_valid`` (device int64 scalar): only the first n_valid rows are real -- the rest is the padding of a batch brought
-    to a recording's static shape; statistics and gradients are those of nn.BatchNorm1d on the real rows."""
+    to a recording's static shape; statistics and gradients are those of nn.BatchNorm1d on the real rows.
+    ``sync`` (device int32 scalar, zero; the caller's for the lifetime of its module): lets the statistics pass and the
+    per-channel step of small inputs be ONE launch each way (egc_bn_forward_stats_f32)."""
     c = h.size(1)
     if running_mean is not None and not (_f32_vec(running_mean, c) and _f32_vec(running_var, c)
                                          and (momentum is not None or num_batches_tracked is not None)):
@@ -1080,7 +1099,7 @@ def batch_norm_act_residual(h, residual, gamma, beta, eps: float, relu: bool, ru
     if n_valid is not None and (n_valid.dtype != torch.int64 or n_valid.numel() != 1 or n_valid.device != h.device):
         raise RuntimeError("egc_amd: n_valid must be an int64 scalar on the device of h")
     return _BatchNormActResidualFunction.apply(h, residual, gamma, beta, float(eps), bool(relu), running_mean, running_var,
-                                               momentum, num_batches_tracked, keep, float(keep_scale), n_valid)
+                                               momentum, num_batches_tracked, keep, float(keep_scale), n_valid, sync)
 
 
 def egc_aggregate_combine_apply(graph, spec, bases, weightings, bias=None):

@@ -36,6 +36,8 @@ class FusedEGCBlock(nn.Module):
         self.conv, self.bn, self.relu, self.residual, self.dropout = conv, bn, relu, residual, float(dropout)
         self.last_keep_mask = None
         self._affine, self._affine_key = None, None
+        # arrival counter of the fused statistics launches (egc_bn_forward_stats_f32: zero between launches); not state
+        self.register_buffer("_bn_sync", torch.zeros(1, dtype=torch.int32), persistent=False)
 
     def _dropping(self):
         return self.dropout > 0.0 and self.training
@@ -79,7 +81,8 @@ class FusedEGCBlock(nn.Module):
         out, mean, var = batch_norm_act_residual(
             h, identity if self.residual else None, bn.weight if bn.affine else None, bn.bias if bn.affine else None, bn.eps,
             self.relu, bn.running_mean if in_place else None, bn.running_var if in_place else None, bn.momentum,
-            bn.num_batches_tracked if counted else None, keep, 1.0 / (1.0 - self.dropout), n_valid)
+            bn.num_batches_tracked if counted else None, keep, 1.0 / (1.0 - self.dropout), n_valid,
+            sync=self._bn_sync if self._bn_sync.device == h.device else None)
         if track and not in_place:               # running statistics kept in another dtype: torch's arithmetic
             with torch.no_grad():
                 n = h.size(0)

@@ -377,6 +377,20 @@ int egc_weight_grad_f32(const float* x, int64_t ldx, const float* d, int64_t ldd
 int egc_column_moments_f64(const float* a, const float* b, const float* scale, const float* shift, int32_t relu,
                            const uint8_t* keep, float keep_scale, int64_t n_rows, int32_t cols, double* partials,
                            int32_t n_partials, int64_t* count_inc, const int64_t* n_valid, egc_stream_t stream);
+/* Statistics pass + per-channel step as ONE call (round 3): egc_column_moments_f64 followed by egc_bn_forward_finalize /
+ * egc_bn_backward_finalize with the same arguments.  With `sync` (a device int32 that is zero on entry; it is zero again
+ * on exit, so one word serves a module for ever) and at most 64 partial blocks it is also ONE LAUNCH: the block that
+ * finishes last adds the partials (in the finalize kernels' order: same bits) and writes the per-channel results -- the
+ * batched nets' training step (zinc/models.py:66-72 at 128 graphs per step) is bound by its launches.  sync == NULL or
+ * more partial blocks: the two launches. */
+int egc_bn_forward_stats_f32(const float* h, int64_t n_rows, int32_t cols, double* partials, int32_t n_partials,
+                             int64_t* count_inc, const int64_t* n_valid, const float* gamma, const float* beta, double eps,
+                             double* stats, float* affine, float* running_mean, float* running_var, double momentum,
+                             const int64_t* n_tracked, int32_t* sync, egc_stream_t stream);
+int egc_bn_backward_stats_f32(const float* dout, const float* h, const float* scale, const float* shift, int32_t relu,
+                              const uint8_t* keep, float keep_scale, int64_t n_rows, int32_t cols, double* partials,
+                              int32_t n_partials, const int64_t* n_valid, const double* stats, const float* gamma, float* out5,
+                              int32_t* sync, egc_stream_t stream);
 int egc_bn_forward_finalize(const double* partials, int32_t n_partials, int32_t cols, int64_t n_rows, const float* gamma,
                             const float* beta, double eps, double* stats, float* affine, float* running_mean,
                             float* running_var, double momentum, const int64_t* n_tracked, const int64_t* n_valid,

@@ -105,6 +105,10 @@ def test_hip_layers_follow_the_reference_trajectory(name, fused):
     # (validation runs on BatchNorm's RUNNING statistics, which integrate the differences of every preceding step, and the
     # std net is the sensitive one -- DESIGN.md 3.2: measured 4.1e-5 against the reference's own 8.1e-6, run to run 3.5-4.2e-5)
     tol_va = max(1e-5, 10 * float(r_va[head].max()))
+    if {"std", "var"} & set(meta["aggrs"]):
+        # the std net's validation loss moves with the ORDER of the float atomics on hub rows (3.5e-5 ... 9e-5 run to run on
+        # the same binary): the bound tests/test_backward_gpu.py gives std / var layers (gtol)
+        tol_va = max(tol_va, 2e-4)
     assert d_tr[head].max() <= tol_tr, (d_tr, tol_tr)
     assert d_va[head].max() <= tol_va, (d_va, tol_va)
     assert d_tr.max() <= max(2e-3, 5 * man["f32_vs_f64_train_loss"]) and d_va.max() <= max(2e-3, 5 * man["f32_vs_f64_val_loss"])
