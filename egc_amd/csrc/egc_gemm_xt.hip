@@ -27,6 +27,7 @@
 #include <algorithm>
 
 #include "egc_common.h"
+#include "egc_pack_map.h"
 
 namespace egc {
 namespace {
@@ -451,14 +452,28 @@ __global__ void __launch_bounds__(X3_THREADS) xt_gemm_bf16x3_kernel(const float*
 // out[i] = sum over chunks of partial[c][i], four floats per thread, 16 threads per output piece each adding every
 // 16th chunk (all loads of a thread in flight at once), then a tree over the 16.  A chunk's record is the F x K tile
 // followed by the K column sums; pieces past `fk` floats go to `sums`.
+// SCATTER: the F x K tile is the gradient of a layer's GEMM operand [bases | comb_weight^T] and `sums` that of its bias: they
+// are written straight into the PARAMETERS' gradients through the pack's index map (egc_pack_map.h) -- no d wcat array, no
+// unpack launch (a training step of the batched nets is bound by its launches).
+struct XtScatter {
+  PackPtrs bases;      // gradients of the basis matrices
+  float* comb_w;       // gradient of the combination Linear's weight
+  float* comb_b;       // gradient of its bias (rows permuted with the weight's), or nullptr
+  float* bcat;         // ... or the bias gradient in the operand's order, or nullptr
+  PackDims d;
+  int k_cols;          // columns of the tile = B Ls + W
+};
+template <bool SCATTER = false>
 __global__ void __launch_bounds__(256) xt_reduce_kernel(const float* __restrict__ partial, int64_t record, int64_t fk,
                                                         int chunks, float* __restrict__ out, float* __restrict__ sums,
-                                                        int sums_cols = 0, float* __restrict__ sums2 = nullptr) {
+                                                        int sums_cols = 0, float* __restrict__ sums2 = nullptr,
+                                                        XtScatter sc = XtScatter()) {
   __shared__ f4 red[256];
   const int t = threadIdx.x, o = t & 15, g = t >> 4;
   const int64_t piece = (int64_t)blockIdx.x * 16 + o;
   // record = [fk floats -> out][sums_cols floats -> sums][the rest -> sums2]; a null destination ends the record early
-  const int64_t used = sums == nullptr ? fk : (sums2 == nullptr && sums_cols > 0 ? fk + sums_cols : record);
+  const bool has_sums = SCATTER || sums != nullptr;      // (scatter mode: the column sums go to the bias gradient)
+  const int64_t used = !has_sums ? fk : (sums2 == nullptr && sums_cols > 0 ? fk + sums_cols : record);
   const int64_t pieces = used / 4, stride = record / 4;
   f4 s = f4{0.f, 0.f, 0.f, 0.f};
   if (piece < pieces) {
@@ -474,7 +489,28 @@ __global__ void __launch_bounds__(256) xt_reduce_kernel(const float* __restrict_
     __syncthreads();
   }
   if (t < 16 && piece < pieces) {
-    if (piece < fk / 4) reinterpret_cast<f4*>(out)[piece] = red[t];
+    if (SCATTER && piece < (fk + sums_cols) / 4) {
+      const f4 v = red[t];
+      const float vv[4] = {v.x, v.y, v.z, v.w};
+      if (piece < fk / 4) {
+        const int64_t idx = 4 * piece;
+        const int k = (int)(idx / sc.k_cols), c0 = (int)(idx - (int64_t)k * sc.k_cols);   // (k_cols % 4 == 0: one row per piece)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float* p = pack_param_ptr(sc.bases, sc.comb_w, sc.d, k, c0 + i);
+          if (p != nullptr) *p = vv[i];
+        }
+      } else {
+        const int F_g = sc.d.B * sc.d.Ls;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int j = (int)(4 * (piece - fk / 4)) + i - F_g;    // column of the weightings block
+          if (j < 0) continue;                                      // column sums of d bases: nobody's gradient
+          if (sc.comb_b != nullptr) sc.comb_b[pack_comb_row(sc.d, j)] = vv[i];
+          else if (sc.bcat != nullptr) sc.bcat[j] = vv[i];
+        }
+      }
+    } else if (piece < fk / 4) reinterpret_cast<f4*>(out)[piece] = red[t];
     else if (sums2 == nullptr || piece < (fk + sums_cols) / 4) reinterpret_cast<f4*>(sums)[piece - fk / 4] = red[t];
     else reinterpret_cast<f4*>(sums2)[piece - (fk + sums_cols) / 4] = red[t];
   }
@@ -561,12 +597,12 @@ int64_t egc_weight_grad_workspace_bytes(int64_t n_rows, int32_t f_in, int32_t k_
   return egc_weight_grad_ex_workspace_bytes(n_rows, f_in, k_cols, 0);
 }
 
-int egc_weight_grad_ex_f32(const float* x, int64_t ldx, const float* d, int64_t ldd, int64_t n_rows, int32_t f_in,
-                           int32_t k_cols, float* out, float* col_sums, const float* e, int64_t lde, int32_t e_cols,
-                           float* e_sums, void* workspace, int64_t workspace_bytes, void* stream_) {
+static int weight_grad_impl(const float* x, int64_t ldx, const float* d, int64_t ldd, int64_t n_rows, int32_t f_in,
+                            int32_t k_cols, float* out, float* col_sums, const float* e, int64_t lde, int32_t e_cols,
+                            float* e_sums, void* workspace, int64_t workspace_bytes, void* stream_, const egc::XtScatter* sc) {
   using namespace egc;
   hipStream_t stream = (hipStream_t)stream_;
-  if (n_rows < 0 || f_in <= 0 || k_cols <= 0 || out == nullptr) return EGC_ERR_INVALID;
+  if (n_rows < 0 || f_in <= 0 || k_cols <= 0 || (out == nullptr && sc == nullptr)) return EGC_ERR_INVALID;
   if (e == nullptr || e_sums == nullptr) { e = nullptr; e_sums = nullptr; e_cols = 0; }
   if ((f_in % 4) || (k_cols % 4) || (ldx % 4) || (ldd % 4) || ((uintptr_t)x % 16) || ((uintptr_t)d % 16) ||
       ((uintptr_t)out % 16) || ((uintptr_t)col_sums % 16) || ((uintptr_t)workspace % 16) || (e_cols % 4) || (lde % 4) ||
@@ -575,7 +611,8 @@ int egc_weight_grad_ex_f32(const float* x, int64_t ldx, const float* d, int64_t 
   const bool fp32_only = xt_fp32_only();
   const bool one_tile = !fp32_only && f_in <= X3_TM && k_cols <= X3_TN;
   // the third array rides along only in the one-tile kernel, next to the column sums of d, 128 columns at most
-  if (e != nullptr && (!one_tile || e_cols > X3_TM || col_sums == nullptr)) return EGC_ERR_UNSUPPORTED;
+  const int want_sums = (col_sums != nullptr || sc != nullptr) ? 1 : 0;   // scatter mode: the sums are the bias gradient
+  if (e != nullptr && (!one_tile || e_cols > X3_TM || !want_sums)) return EGC_ERR_UNSUPPORTED;
   if (workspace_bytes < egc_weight_grad_ex_workspace_bytes(n_rows, f_in, k_cols, e_cols) || workspace == nullptr)
     return EGC_ERR_INVALID;
   const XtPlan p = xt_plan(n_rows, f_in, k_cols);
@@ -584,7 +621,6 @@ int egc_weight_grad_ex_f32(const float* x, int64_t ldx, const float* d, int64_t 
   if ((double)(p.rows_per_chunk + 160) * (double)widest * 4.0 >= 4.0e9) return EGC_ERR_UNSUPPORTED;
   const int64_t fk = (int64_t)f_in * k_cols;
   float* partial = static_cast<float*>(workspace);
-  const int want_sums = col_sums != nullptr;
   int rc = EGC_ERR_UNSUPPORTED;
   if (one_tile) {   // one accumulator tile: the bf16x3 kernel
     constexpr int lds_bytes = X3_LDS_BYTES;
@@ -609,10 +645,45 @@ int egc_weight_grad_ex_f32(const float* x, int64_t ldx, const float* d, int64_t 
   if (rc != EGC_OK) return rc;
   const int64_t record = fk + k_cols + e_cols;
   const int64_t used = !want_sums ? fk : (e != nullptr ? record : fk + k_cols);
-  xt_reduce_kernel<<<(unsigned)ceil_div(used / 4, 16), 256, 0, stream>>>(partial, record, fk, p.chunks, out, col_sums, k_cols,
-                                                                         e_sums);
+  if (sc != nullptr)
+    xt_reduce_kernel<true><<<(unsigned)ceil_div(used / 4, 16), 256, 0, stream>>>(partial, record, fk, p.chunks, out, col_sums, k_cols,
+                                                                                 e_sums, *sc);
+  else
+    xt_reduce_kernel<false><<<(unsigned)ceil_div(used / 4, 16), 256, 0, stream>>>(partial, record, fk, p.chunks, out, col_sums, k_cols,
+                                                                                  e_sums);
   EGC_LAUNCH_CHECK("xt_reduce_kernel");
   return EGC_OK;
+}
+
+int egc_weight_grad_ex_f32(const float* x, int64_t ldx, const float* d, int64_t ldd, int64_t n_rows, int32_t f_in,
+                           int32_t k_cols, float* out, float* col_sums, const float* e, int64_t lde, int32_t e_cols,
+                           float* e_sums, void* workspace, int64_t workspace_bytes, void* stream_) {
+  return weight_grad_impl(x, ldx, d, ldd, n_rows, f_in, k_cols, out, col_sums, e, lde, e_cols, e_sums, workspace, workspace_bytes,
+                          stream_, nullptr);
+}
+
+int egc_weight_grad_params_f32(const float* x, int64_t ldx, const float* d, int64_t ldd, int64_t n_rows, int32_t f_in,
+                               int32_t num_heads, int32_t num_aggrs, int32_t num_bases, int32_t basis_len, int32_t basis_stride,
+                               int32_t permute_hab, float* const* d_bases_parts, int32_t n_parts, float* d_comb_weight,
+                               float* d_comb_bias, float* d_bcat, const float* e, int64_t lde, int32_t e_cols, float* e_sums,
+                               void* workspace, int64_t workspace_bytes, void* stream_) {
+  using namespace egc;
+  if (f_in <= 0 || num_heads <= 0 || num_aggrs <= 0 || num_bases <= 0 || basis_len <= 0 || basis_stride < basis_len ||
+      d_bases_parts == nullptr || d_comb_weight == nullptr || (n_parts != 1 && n_parts != num_bases))
+    return EGC_ERR_INVALID;
+  if (n_parts > PACK_MAX_PARTS) return EGC_ERR_UNSUPPORTED;
+  XtScatter sc;
+  for (int i = 0; i < PACK_MAX_PARTS; ++i) sc.bases.part[i] = i < n_parts ? d_bases_parts[i] : nullptr;
+  for (int i = 0; i < n_parts; ++i)
+    if (sc.bases.part[i] == nullptr) return EGC_ERR_INVALID;
+  sc.comb_w = d_comb_weight;
+  sc.comb_b = d_comb_bias;
+  sc.bcat = d_bcat;
+  sc.d = PackDims{f_in, num_heads, num_aggrs, num_bases, basis_len, basis_stride, n_parts, permute_hab != 0};
+  sc.k_cols = num_bases * basis_stride + num_heads * num_bases * num_aggrs;
+  // the column sums are always formed (the bias gradient rides on them); they land in the parameters, not in an array
+  return weight_grad_impl(x, ldx, d, ldd, n_rows, f_in, sc.k_cols, nullptr, nullptr, e, lde, e_cols, e_sums, workspace,
+                          workspace_bytes, stream_, &sc);
 }
 
 int egc_weight_grad_f32(const float* x, int64_t ldx, const float* d, int64_t ldd, int64_t n_rows, int32_t f_in,

@@ -12,6 +12,7 @@
 #include <algorithm>
 
 #include "egc_common.h"
+#include "egc_pack_map.h"
 
 namespace egc {
 namespace {
@@ -346,9 +347,6 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 //   [F_in][L] (EfficientGraphConv.bases_weight.{0..B-1}); with `permute` the Linear's rows [h][a][b] (EGConv's
 //   comb_weight, optimized_layers.py:195-202) become columns [h][b][a], otherwise the rows are [h][b][a] already.
 // GRAD: the same index map read the other way (wcat / bcat are the gradients, the parameters' gradients are written).
-constexpr int PACK_MAX_PARTS = 32;
-struct PackDims { int F_in, H, A, B, L, Ls, n_parts, permute; };
-struct PackPtrs { float* part[PACK_MAX_PARTS]; };
 template <bool GRAD>
 __global__ void __launch_bounds__(256) weights_pack_kernel(PackPtrs bases, float* __restrict__ comb_w,
                                                            float* __restrict__ comb_b, float* __restrict__ wcat,
@@ -357,34 +355,16 @@ __global__ void __launch_bounds__(256) weights_pack_kernel(PackPtrs bases, float
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx < (int64_t)d.F_in * cols) {
     const int k = (int)(idx / cols), c = (int)(idx - (int64_t)k * cols);
-    if (c < F_g) {
-      const int b = c / d.Ls, l = c - b * d.Ls;
-      if (l < d.L) {
-        float* p = d.n_parts == 1 ? bases.part[0] + (int64_t)k * d.B * d.L + b * d.L + l
-                                  : bases.part[b] + (int64_t)k * d.L + l;
-        if (GRAD) *p = wcat[idx]; else wcat[idx] = *p;
-      } else if (!GRAD) {
-        wcat[idx] = 0.f;   // padding column of a padded basis
-      }
-    } else {
-      const int j = c - F_g;                       // [h][b][a]
-      int row = j;
-      if (d.permute) {
-        const int h = j / (d.B * d.A), r = j - h * d.B * d.A, b = r / d.A, a = r - b * d.A;
-        row = (h * d.A + a) * d.B + b;
-      }
-      float* p = comb_w + (int64_t)row * d.F_in + k;
+    float* p = pack_param_ptr(bases, comb_w, d, k, c);
+    if (p != nullptr) {
       if (GRAD) *p = wcat[idx]; else wcat[idx] = *p;
+    } else if (!GRAD) {
+      wcat[idx] = 0.f;   // padding column of a padded basis
     }
   }
   if (idx < W && bcat != nullptr && comb_b != nullptr) {
     const int j = (int)idx;
-    int row = j;
-    if (d.permute) {
-      const int h = j / (d.B * d.A), r = j - h * d.B * d.A, b = r / d.A, a = r - b * d.A;
-      row = (h * d.A + a) * d.B + b;
-    }
-    if (GRAD) comb_b[row] = bcat[j]; else bcat[j] = comb_b[row];
+    if (GRAD) comb_b[pack_comb_row(d, j)] = bcat[j]; else bcat[j] = comb_b[pack_comb_row(d, j)];
   }
 }
 

@@ -180,27 +180,25 @@ std::vector<at::Tensor> train_backward(const at::Tensor& grad_out, const at::Ten
     check_status(egc_basis_transform_packed(d_cat.data_ptr<float>(), packed.data_ptr(), nullptr, n, (int32_t)k, (int32_t)f_in, 0,
                                             dx.data_ptr<float>(), (int32_t)f_in, nullptr, st), "egc_basis_transform_packed");
   }
-  // (3) d wcat = x^T d_cat with the column sums of d_cat (combination bias) and of grad_out (the layer's bias) in the same pass
-  at::Tensor dwcat = at::empty({f_in, k}, opts), cs = at::empty({k}, opts), es = at::empty({f_out}, opts);
-  const int64_t gbytes = (int64_t)egc_weight_grad_ex_workspace_bytes(n, (int32_t)f_in, (int32_t)k, (int32_t)f_out);
-  at::Tensor gws = at::empty({std::max<int64_t>(gbytes, 16)}, opts.dtype(at::kByte));
-  check_status(egc_weight_grad_ex_f32(x.data_ptr<float>(), f_in, d_cat.data_ptr<float>(), k, n, (int32_t)f_in, (int32_t)k,
-                                      dwcat.data_ptr<float>(), cs.data_ptr<float>(), go.data_ptr<float>(), f_out, (int32_t)f_out,
-                                      es.data_ptr<float>(), gws.data_ptr(), gws.numel(), st), "egc_weight_grad_ex_f32");
-  // (4) the parameters' gradients from (d wcat, d bcat): the pack's index map read the other way
-  at::Tensor dbcat = cs.slice(0, k - W, k).contiguous();
+  // (3) x^T d_cat with the column sums of d_cat (combination bias) and of grad_out (the layer's bias) in one pass, written
+  // straight into the parameters' gradients through the pack's index map (egc_weight_grad_params_f32): no d wcat, no unpack
+  at::Tensor es = at::empty({f_out}, opts);
   at::Tensor dcw = at::empty(comb_w_shape, opts);
-  at::Tensor dcb = packed_bias ? at::empty(comb_b_shape, opts) : dbcat;
+  at::Tensor dcb = packed_bias ? at::empty(comb_b_shape, opts) : at::empty({W}, opts);
   std::vector<at::Tensor> dparts;
-  std::vector<const float*> ptrs;
+  std::vector<float*> ptrs;
   for (int64_t i = 0; i < n_parts; ++i) {
+    // (padding columns of a padded basis have no parameter behind them: every element of a part is written)
     dparts.push_back(at::empty(part_shape, opts));
     ptrs.push_back(dparts.back().data_ptr<float>());
   }
-  check_status(egc_weights_pack_f32(ptrs.data(), (int32_t)n_parts, dcw.data_ptr<float>(), packed_bias ? dcb.data_ptr<float>() : nullptr,
-                                    (int32_t)f_in, (int32_t)H, (int32_t)A, (int32_t)B, (int32_t)L, (int32_t)Ls, permute_hab ? 1 : 0,
-                                    dwcat.data_ptr<float>(), packed_bias ? dbcat.data_ptr<float>() : nullptr, 1, st),
-               "egc_weights_pack_f32 (gradients)");
+  const int64_t gbytes = (int64_t)egc_weight_grad_ex_workspace_bytes(n, (int32_t)f_in, (int32_t)k, (int32_t)f_out);
+  at::Tensor gws = at::empty({std::max<int64_t>(gbytes, 16)}, opts.dtype(at::kByte));
+  check_status(egc_weight_grad_params_f32(x.data_ptr<float>(), f_in, d_cat.data_ptr<float>(), k, n, (int32_t)f_in, (int32_t)H,
+                                          (int32_t)A, (int32_t)B, (int32_t)L, (int32_t)Ls, permute_hab ? 1 : 0, ptrs.data(),
+                                          (int32_t)n_parts, dcw.data_ptr<float>(), packed_bias ? dcb.data_ptr<float>() : nullptr,
+                                          packed_bias ? nullptr : dcb.data_ptr<float>(), go.data_ptr<float>(), f_out, (int32_t)f_out,
+                                          es.data_ptr<float>(), gws.data_ptr(), gws.numel(), st), "egc_weight_grad_params_f32");
   std::vector<at::Tensor> out{dx, dcw, dcb, es};
   out.insert(out.end(), dparts.begin(), dparts.end());
   return out;

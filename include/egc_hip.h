@@ -331,6 +331,17 @@ int64_t egc_weight_grad_ex_workspace_bytes(int64_t n_rows, int32_t f_in, int32_t
 int egc_weight_grad_ex_f32(const float* x, int64_t ldx, const float* d, int64_t ldd, int64_t n_rows, int32_t f_in,
                            int32_t k_cols, float* out, float* col_sums, const float* e, int64_t lde, int32_t e_cols,
                            float* e_sums, void* workspace, int64_t workspace_bytes, void* stream);
+/* egc_weight_grad_ex_f32 for a layer's OWN parameters (round 3): d = [d bases | d weightings] is the gradient of the GEMM
+ * operand egc_weights_pack_f32 builds, and the reduction writes x^T d and the column sums of d straight into the gradients of
+ * the basis matrices (one [f_in, B L] or B of [f_in, L]), of the combination Linear's weight and of its bias (d_comb_bias:
+ * rows permuted with the weight's; or d_bcat: in the operand's order; either may be NULL) through the pack's index map -- no
+ * d wcat array and no unpack launch.  e / e_sums as in egc_weight_grad_ex_f32 (the layer's bias gradient = column sums of
+ * grad_out).  Workspace: egc_weight_grad_ex_workspace_bytes(n_rows, f_in, B Ls + H B A, e_cols). */
+int egc_weight_grad_params_f32(const float* x, int64_t ldx, const float* d, int64_t ldd, int64_t n_rows, int32_t f_in,
+                               int32_t num_heads, int32_t num_aggrs, int32_t num_bases, int32_t basis_len, int32_t basis_stride,
+                               int32_t permute_hab, float* const* d_bases_parts, int32_t n_parts, float* d_comb_weight,
+                               float* d_comb_bias, float* d_bcat, const float* e, int64_t lde, int32_t e_cols, float* e_sums,
+                               void* workspace, int64_t workspace_bytes, void* stream);
 int egc_weight_grad_f32(const float* x, int64_t ldx, const float* d, int64_t ldd, int64_t n_rows, int32_t f_in,
                         int32_t k_cols, float* out, float* col_sums, void* workspace, int64_t workspace_bytes,
                         void* stream);
