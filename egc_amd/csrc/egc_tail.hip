@@ -35,8 +35,9 @@ __device__ inline f4 keep4(const unsigned char* __restrict__ keep, int64_t quad,
 // Small inputs (few partial blocks): the per-column step between the statistics pass and the elementwise pass rides in
 // the SAME launch -- the block that arrives last (agent-scope counter; the partials travel as agent-scope stores and
 // loads: no cache write-back fence) adds the partials in the finalize kernels' fixed order and finishes every column.
-// A training step of the reference's batched nets is bound by its launches: one launch less per
-// block and direction.
+// One launch less per block and direction -- and NOT faster where it was meant to be: the chain write-through partials ->
+// arrival atomic -> last block's reads costs 17-18 us per launch against ~6 + ~4.5 us for the two kernels, and a replayed
+// ZINC-shaped step takes 426-429 us with it against 372-373 us without (include/egc_hip.h); opt-in.
 struct FinArgs {
   int* sync;                    // arrival counter: zero on entry, zero again on exit
   double eps, momentum;
@@ -141,7 +142,9 @@ __global__ void __launch_bounds__(256) column_moments_kernel(const float* __rest
     __syncthreads();
     if (!last_block) return;
     if (threadIdx.x == 0) __hip_atomic_store(fin.sync, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifndef EGC_BN_NO_ACQ
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
     const double nr = fmax((double)n_rows, 1.0);
     // One thread per column; at most 64 partial blocks (host), added in the finalize kernels' order -- eight runs of eight
     // partials, then the eight run totals: the same bits as the two-launch form.  All loads of a column are independent.
@@ -151,8 +154,9 @@ __global__ void __launch_bounds__(256) column_moments_kernel(const float* __rest
 #pragma unroll
       for (int p = 0; p < 64; ++p) {
         const bool ok = p < np;
-        v1[p] = ok ? __hip_atomic_load(out + (int64_t)p * 2 * cols + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-        v2[p] = ok ? __hip_atomic_load(out + (int64_t)p * 2 * cols + cols + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        // (plain loads: the acquire fence above dropped this XCD's stale lines, the writers' stores were write-through)
+        v1[p] = ok ? out[(int64_t)p * 2 * cols + col] : 0.0;
+        v2[p] = ok ? out[(int64_t)p * 2 * cols + cols + col] : 0.0;
       }
       double t1 = 0.0, t2 = 0.0;
 #pragma unroll

@@ -13,6 +13,8 @@ recomputed, then one pass for the gradient) instead of PyTorch's pass per operat
 from __future__ import annotations
 
 import torch
+
+from . import _C
 import torch.nn as nn
 
 from .functional import (PostOp, batch_norm_act_residual, batch_norm_act_residual_supported, egc_layer_forward,
@@ -36,7 +38,8 @@ class FusedEGCBlock(nn.Module):
         self.conv, self.bn, self.relu, self.residual, self.dropout = conv, bn, relu, residual, float(dropout)
         self.last_keep_mask = None
         self._affine, self._affine_key = None, None
-        # arrival counter of the fused statistics launches (egc_bn_forward_stats_f32: zero between launches); not state
+        # arrival counter of the one-launch form of the statistics step (egc_bn_forward_stats_f32; opt-in, EGC_BN_ONE_LAUNCH=1:
+        # measured slower than the two launches when the step is replayed as a hipGraph); not state
         self.register_buffer("_bn_sync", torch.zeros(1, dtype=torch.int32), persistent=False)
 
     def _dropping(self):
@@ -82,7 +85,7 @@ class FusedEGCBlock(nn.Module):
             h, identity if self.residual else None, bn.weight if bn.affine else None, bn.bias if bn.affine else None, bn.eps,
             self.relu, bn.running_mean if in_place else None, bn.running_var if in_place else None, bn.momentum,
             bn.num_batches_tracked if counted else None, keep, 1.0 / (1.0 - self.dropout), n_valid,
-            sync=self._bn_sync if self._bn_sync.device == h.device else None)
+            sync=self._bn_sync if (self._bn_sync.device == h.device and _C.env_flag("EGC_BN_ONE_LAUNCH")) else None)
         if track and not in_place:               # running statistics kept in another dtype: torch's arithmetic
             with torch.no_grad():
                 n = h.size(0)

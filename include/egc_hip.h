@@ -393,7 +393,11 @@ int egc_column_moments_f64(const float* a, const float* b, const float* scale, c
  * on exit, so one word serves a module for ever) and at most 64 partial blocks it is also ONE LAUNCH: the block that
  * finishes last adds the partials (in the finalize kernels' order: same bits) and writes the per-channel results -- the
  * batched nets' training step (zinc/models.py:66-72 at 128 graphs per step) is bound by its launches.  sync == NULL or
- * more partial blocks: the two launches. */
+ * more partial blocks: the two launches.  MEASURED (ZINC-shaped batch of 128, 4 blocks forward + backward, same box): the one
+ * launch is 17-18 us per call against ~6 + ~4.5 for the two kernels (a chain of cross-XCD round trips: write-through
+ * partials, the arrival atomic, the last block's reads), 426-429 us per replayed step against 372-373 with two launches;
+ * eager 0.98-1.18 ms against 1.03-1.23.  The host side (egc_amd.FusedEGCBlock) therefore passes sync only on request
+ * (EGC_BN_ONE_LAUNCH=1). */
 int egc_bn_forward_stats_f32(const float* h, int64_t n_rows, int32_t cols, double* partials, int32_t n_partials,
                              int64_t* count_inc, const int64_t* n_valid, const float* gamma, const float* beta, double eps,
                              double* stats, float* affine, float* running_mean, float* running_var, double momentum,

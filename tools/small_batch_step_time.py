@@ -6,7 +6,10 @@ import egc_amd
 from egc_amd import workloads as wl
 from egc_amd.fusion import FusedEGCBlock
 dev = torch.device("cuda:0")
+only = os.environ.get("EGC_SMALL_ONLY", "")     # "zinc" / "molhiv": one workload (kernel statistics per size)
 for name, (ei, n, batch) in (("zinc-like batch 128", wl.zinc_like_batch()[1:]), ("molhiv batch 2048", wl.molecule_batch())):
+    if only and only not in name:
+        continue
     ei = ei.to(dev)
     torch.manual_seed(0)
     blocks = nn.ModuleList([FusedEGCBlock(egc_amd.EGConv(128, 128, aggrs=["sum", "mean", "max", "symnorm"], num_heads=8, num_bases=4),
