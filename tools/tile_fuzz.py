@@ -1,0 +1,67 @@
+"""A hunt, not a test: random PyG-shaped batches (graph counts, size distributions incl. graphs larger than a tile's LDS
+area, degrees, hubs, self loops, empty graphs; with and without edge offsets; several max_nodes / edges_per_node hints)
+through the tile path (egc_amd.GraphBatch) against the ordinary CSR path of the same layer.  Prints every case whose
+outputs differ by more than 5e-6 (scale-relative) or that raises.  usage: python tools/tile_fuzz.py [n_cases] [seed]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import egc_amd
+
+dev = torch.device("cuda:0")
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+LAYERS = [("opt", 128, 8, 4, ["sum", "mean", "max", "symnorm"]), ("lay", 128, 8, 4, ["symadd", "max", "mean"]), ("lay", 128, 8, 4, ["symadd"]),
+          ("opt", 64, 4, 4, ["min", "std", "var"]), ("opt", 96, 4, 2, ["sum", "max"]), ("lay", 168, 8, 4, ["symadd"]),
+          ("lay", 124, 4, 4, ["add", "std", "max"]), ("opt", 32, 2, 2, ["mean"]), ("lay", 224, 4, 4, ["add", "mean", "max"])]
+bad = refused = 0
+for case in range(n_cases):
+    kind, hidden, H, B, aggrs = LAYERS[int(rng.integers(len(LAYERS)))]
+    asl = bool(rng.random() < 0.8)
+    n_graphs = int(rng.choice([1, 2, 7, 60, 400, 2500]))
+    hi = int(rng.choice([2, 12, 40, 150, 600]))
+    sizes = rng.integers(1, hi + 1, size=n_graphs)
+    if rng.random() < 0.3: sizes[rng.integers(0, n_graphs, size=max(1, n_graphs // 10))] = 1
+    ptr = np.concatenate([[0], np.cumsum(sizes)])
+    srcs, dsts, eptr = [], [], [0]
+    dens = float(rng.choice([0.0, 1.0, 2.2, 8.0, 20.0]))
+    for g in range(n_graphs):
+        n, o = int(sizes[g]), int(ptr[g])
+        e = int(rng.poisson(dens * n)) if dens > 0 else 0
+        if rng.random() < 0.05: e = 0
+        s, d = rng.integers(0, n, size=e), rng.integers(0, n, size=e)
+        if e > 6 and rng.random() < 0.15: d[: e // 2] = int(rng.integers(0, n))      # hub row
+        if e > 4 and rng.random() < 0.3: s[-2:] = d[-2:]                              # self loops
+        srcs.append(s + o); dsts.append(d + o); eptr.append(eptr[-1] + e)
+    ei = torch.from_numpy(np.stack([np.concatenate(srcs), np.concatenate(dsts)]).astype(np.int64)).to(dev)
+    N = int(ptr[-1])
+    torch.manual_seed(case)
+    if kind == "opt":
+        conv = egc_amd.EGConv(hidden, hidden, aggrs=aggrs, num_heads=H, num_bases=B, add_self_loops=asl).to(dev).eval()
+    else:
+        conv = egc_amd.EfficientGraphConv(hidden, hidden, H, B, False, aggrs=aggrs, add_self_loops=asl).to(dev).eval()
+    with torch.no_grad(): conv.bias.normal_()
+    x = torch.randn(N, hidden, device=dev)
+    kw = {}
+    if rng.random() < 0.5: kw["edge_ptr"] = torch.tensor(eptr, dtype=torch.int64, device=dev)
+    if rng.random() < 0.5: kw["max_nodes"] = int(rng.choice([16, 64, 256, 1024]))
+    if rng.random() < 0.3: kw["edges_per_node"] = int(rng.choice([4, 16, 64]))
+    desc = (case, kind, hidden, H, B, aggrs, asl, n_graphs, hi, dens, N, int(ei.size(1)), {k: (v if not torch.is_tensor(v) else "given") for k, v in kw.items()})
+    try:
+        with torch.no_grad():
+            ref = conv(x, ei) if kind == "opt" else conv(x=x, edge_index=ei)
+            gb = egc_amd.GraphBatch(ei, ptr=torch.from_numpy(ptr.astype(np.int64)).to(dev), **kw)
+            out = conv(x, gb) if kind == "opt" else conv(x=x, edge_index=gb)
+            gb.check()
+        torch.cuda.synchronize()
+        err = float((out - ref).abs().max() / max(1.0, float(ref.abs().max()))) if N else 0.0
+        if not err <= 5e-6:      # (two float32 summation orders: up to ~3e-6 on rows of 20-40 entries)
+            bad += 1
+            print("MISMATCH", err, desc, flush=True)
+    except Exception as ex:
+        msg = repr(ex)[:160]
+        if "exceeds the per-tile areas" in msg:      # a legitimate refusal (a graph beyond the tile areas): counted, not a bug
+            refused += 1
+            continue
+        bad += 1
+        print("EXC", msg, desc, flush=True)
+print(f"{n_cases} cases, {bad} bad, {refused} refused (a graph beyond the per-tile areas)")
