@@ -281,3 +281,55 @@ def test_thirty_two_column_long_k_kernel(n, f_in, f_g, w_cols, monkeypatch):
         monkeypatch.setenv("EGC_GEMM_MAX_ROWS", "4096")
         b2, w2 = _transform(x, wcat, bcat, f_g, w_cols)
         assert torch.equal(bases, b2) and torch.equal(wt, w2)
+
+
+@pytest.mark.parametrize("n", [5, 1000, 40001])
+@pytest.mark.parametrize("f_in,H,A,B,L,Ls,permute,n_parts", [
+    (128, 8, 4, 4, 16, 16, True, 1),      # EGConv north star: one [F_in, B L] basis matrix, Linear rows [h][a][b]
+    (48, 4, 3, 4, 8, 8, False, 4),        # EfficientGraphConv: B basis matrices, rows [h][b][a]
+    (64, 2, 1, 2, 21, 24, False, 2),      # padded bases (L = 21 -> Ls = 24): padding columns have no parameter behind them
+])
+def test_weight_grad_params_equals_the_two_step_form(n, f_in, H, A, B, L, Ls, permute, n_parts):
+    """egc_weight_grad_params_f32 (x^T d and the column sums written straight into the parameters' gradients through the
+    pack's index map) == egc_weight_grad_ex_f32 followed by the gradient unpack of egc_weights_pack_f32, bit for bit: same
+    partial products, same reduction order, one launch less."""
+    import ctypes as C
+    from egc_amd import _C
+    lib = _C.load()
+    torch.manual_seed(n + f_in)
+    W, f_g = H * B * A, B * Ls
+    k, f_out = f_g + W, H * L
+    e_cols = (f_out + 3) // 4 * 4
+    x = torch.randn(n, f_in, device=DEV)
+    d = torch.randn(n, k, device=DEV)
+    e = torch.randn(n, e_cols, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    nb = lib.egc_weight_grad_ex_workspace_bytes(n, f_in, k, e_cols)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=DEV)
+    part_shape = (f_in, B * L) if n_parts == 1 else (f_in, L)
+
+    def fresh():
+        return ([torch.full(part_shape, float("nan"), device=DEV) for _ in range(n_parts)],
+                torch.full((W, f_in), float("nan"), device=DEV), torch.full((W,), float("nan"), device=DEV))
+    # two steps
+    dwcat, cs, es = torch.empty(f_in, k, device=DEV), torch.empty(k, device=DEV), torch.empty(e_cols, device=DEV)
+    _C.check(lib.egc_weight_grad_ex_f32(x.data_ptr(), f_in, d.data_ptr(), k, n, f_in, k, dwcat.data_ptr(), cs.data_ptr(), e.data_ptr(),
+                                        e_cols, e_cols, es.data_ptr(), ws.data_ptr(), ws.numel(), st), "ex")
+    parts_a, cw_a, cb_a = fresh()
+    ptrs = (C.c_void_p * n_parts)(*[p.data_ptr() for p in parts_a])
+    dbcat = cs[f_g:].contiguous()
+    _C.check(lib.egc_weights_pack_f32(ptrs, n_parts, cw_a.data_ptr(), cb_a.data_ptr(), f_in, H, A, B, L, Ls, int(permute),
+                                      dwcat.data_ptr(), dbcat.data_ptr(), 1, st), "unpack")
+    # one step
+    parts_b, cw_b, cb_b = fresh()
+    es_b = torch.empty(e_cols, device=DEV)
+    ptrs_b = (C.c_void_p * n_parts)(*[p.data_ptr() for p in parts_b])
+    _C.check(lib.egc_weight_grad_params_f32(x.data_ptr(), f_in, d.data_ptr(), k, n, f_in, H, A, B, L, Ls, int(permute), ptrs_b, n_parts,
+                                            cw_b.data_ptr(), cb_b.data_ptr(), None, e.data_ptr(), e_cols, e_cols, es_b.data_ptr(),
+                                            ws.data_ptr(), ws.numel(), st), "params")
+    torch.cuda.synchronize()
+    for a, b in zip(parts_a + [cw_a, cb_a, es], parts_b + [cw_b, cb_b, es_b]):
+        assert torch.equal(a, b) and not torch.isnan(b).any()
+    # and against float64
+    ref = x.double().t() @ d.double()
+    assert float((dwcat.double() - ref).abs().max() / ref.abs().max()) <= 1e-5
