@@ -303,3 +303,43 @@ def test_global_mean_pool_matches_index_add():
     cnt = torch.bincount(batch, minlength=n_graphs + 3).clamp(min=1).view(-1, 1)
     (torch.zeros(n_graphs + 3, 77, device=dev).index_add(0, batch, xr) / cnt).backward(go)
     assert float((xg.grad - xr.grad).abs().max()) <= 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("momentum", [0.1, None])
+@pytest.mark.parametrize("n", [300, 4000])        # 3 and 32 partial blocks: both inside the one-launch form's 64
+def test_batch_norm_statistics_in_one_launch_equal_the_two_launches(n, momentum, monkeypatch):
+    """The opt-in one-launch form of the BatchNorm statistics step (egc_bn_forward_stats_f32 / egc_bn_backward_stats_f32 with a
+    sync word: the last block adds the partials in the finalize kernels' order) gives the SAME BITS as the two launches --
+    outputs, every gradient, running statistics, num_batches_tracked -- over several steps (the sync word returns to zero)."""
+    import copy
+    import egc_amd
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(n)
+    ei = torch.from_numpy(rng.integers(0, n, size=(2, 6 * n))).to(dev)
+    torch.manual_seed(0)
+    conv = egc_amd.EGConv(64, 64, aggrs=["sum", "max", "symnorm"], num_heads=4, num_bases=4)
+    bn = torch.nn.BatchNorm1d(64, momentum=momentum)
+    blk_a = egc_amd.FusedEGCBlock(conv, bn).to(dev).train()
+    blk_b = copy.deepcopy(blk_a)
+    x = torch.randn(n, 64, device=dev)
+    gout = torch.randn(n, 64, device=dev)
+
+    def steps(blk):
+        outs = []
+        for _ in range(3):
+            xi = x.clone().requires_grad_(True)
+            blk.zero_grad()
+            out = blk(xi, ei)
+            out.backward(gout)
+            outs.append([out.detach().clone(), xi.grad.clone()] + [p.grad.clone() for p in blk.parameters()])
+        return outs, [blk.bn.running_mean.clone(), blk.bn.running_var.clone(), blk.bn.num_batches_tracked.clone()]
+    two = steps(blk_a)
+    monkeypatch.setenv("EGC_BN_ONE_LAUNCH", "1")
+    one = steps(blk_b)
+    for sa, sb in zip(two[0], one[0]):
+        for a, b in zip(sa, sb):
+            assert torch.equal(a, b)
+    for a, b in zip(two[1], one[1]):
+        assert torch.equal(a, b)
+    assert int(blk_b._bn_sync.item()) == 0
