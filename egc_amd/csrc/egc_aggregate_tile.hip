@@ -31,10 +31,16 @@
 
 namespace egc {
 
-constexpr int TILE_THREADS = 512;
+#ifndef EGC_TILE_THREADS
+#define EGC_TILE_THREADS 512
+#endif
+#ifndef EGC_TILE_WGS
+#define EGC_TILE_WGS 2
+#endif
+constexpr int TILE_THREADS = EGC_TILE_THREADS;
 constexpr int TILE_WAVES = TILE_THREADS / 64;
 constexpr int TILE_MAX_NODES = 2048;    // cap of the per-tile CSR areas (local ids are 16-bit)
-constexpr int TILE_WGS_PER_CU = 2;      // what the LDS areas are sized for (tile_capacity)
+constexpr int TILE_WGS_PER_CU = EGC_TILE_WGS;      // what the LDS areas are sized for (tile_capacity)
 constexpr int TILE_EDGE_REGS = 6;       // edges per thread kept in registers between the two CSR passes (3072 per tile)
 
 struct TileArgs {
