@@ -22,6 +22,9 @@ variance 0): float32 leaves E[x^2] - E[x]^2 = +3 / +1 / 0 ulp(x^2) here and -1 /
 GEMM's outputs decide), relu() hides the negative draws and sqrt(. + 1e-5) turns the positive ones into 1.1e-4 of std:
 3.1e-5 of the output against the restatement's 3.1e-7.  Nothing evaluated in float32 can promise the sign of that
 residue; what is promised is the formula of layers.py:203-216 with separately rounded squares, products and differences.
+Seeds 400-449 (final binary of the round): 47 clean; 405 and 410 are two more std layers over tied neighbours (2e-5); 413
+(kept) is a GRADIENT 9.8e-4 from float64 that the float32 restatement shares to 4e-7 -- a near-tie of max / min that float32
+and float64 resolve differently -- hence the float32 yardstick for such cases.
 EGC_FUZZ_DUMP=<dir> saves the inputs of failing cases."""
 import numpy as np
 import pytest
@@ -66,7 +69,7 @@ def _extra_seeds():
 
 
 @pytest.mark.parametrize("seed,generic", [(11, False), (12, False), (13, False), (14, True), (15, True), (101, False), (109, False),
-                                          (118, False), (202, False), (303, False)] + _extra_seeds())
+                                          (118, False), (202, False), (303, False), (413, False)] + _extra_seeds())
 def test_random_layers_and_graphs_match_the_oracles(seed, generic, monkeypatch):
     import egc_amd
     if generic:   # the generic forward kernels + separate arg pass, and the run-time forms of the backward kernels
@@ -187,8 +190,32 @@ def test_random_layers_and_graphs_match_the_oracles(seed, generic, monkeypatch):
                     if a is None: a = torch.zeros_like(b)
                     return float((a.detach().double().cpu() - b).abs().max() / max(1.0, float(b.abs().max())))
                 ge = max([rel(xg.grad, x64.grad)] + [rel(v.grad, p64[k].grad) for k, v in layer.named_parameters()])
+                if not ge <= 5e-4 and any(a in ("max", "min") for a in names):
+                    # a NEAR-tie of max / min: float32 and float64 pick different neighbours and a whole gradient entry moves
+                    # (seed 413, case 68: the float32 restatement is 9.8e-4 from float64 too, HIP 4.7e-7 from the float32
+                    # restatement) -- then the float32 evaluation of the same formula is the yardstick
+                    p32 = {k: v.detach().float().cpu().requires_grad_(True) for k, v in layer.named_parameters()}
+                    x32 = torch.from_numpy(x).float().requires_grad_(True)
+                    if kind == "opt":
+                        r32 = tref.egconv_forward(x32, ei, p32["bases_weight"], p32["comb_weight.weight"], p32["comb_weight.bias"], p32["bias"], H, B,
+                                                  names, add_self_loops=asl, sigmoid=flags.get("sigmoid", False))
+                    else:
+                        r32 = tref.efficient_graph_conv_forward(x32, ei, [p32[f"bases_weight.{b}"] for b in range(B)], p32["comb_weights.weight"],
+                                                                p32["comb_weights.bias"], p32["bias"], H, names, softmax=flags.get("softmax", False),
+                                                                hardtanh=flags.get("hardtanh", False), sigmoid=flags.get("sigmoid", False),
+                                                                add_self_loops=asl)
+                    r32.backward(gout.cpu())
+                    g32 = max([rel(xg.grad, x32.grad.double())] + [rel(v.grad, p32[k].grad.double()) for k, v in layer.named_parameters()])
+                    if g32 <= 2e-5:
+                        ge = g32
                 worst_g = max(worst_g, ge)
-                if not ge <= 5e-4: fails.append(("grad", case, kind, H, B, L, fin, names, n, e, flags, asl, ge))
+                if not ge <= 5e-4:
+                    fails.append(("grad", case, kind, H, B, L, fin, names, n, e, flags, asl, ge))
+                    import os
+                    if os.environ.get("EGC_FUZZ_DUMP"):
+                        np.savez(os.path.join(os.environ["EGC_FUZZ_DUMP"], f"fuzzgrad_{seed}_{case}.npz"), x=x, ei=ei, gout=gout.cpu().numpy(),
+                                 gx=xg.grad.cpu().numpy(), meta=np.frombuffer(repr(dict(meta, aggrs=[str(a) for a in names])).encode(), dtype=np.uint8),
+                                 **{f"p:{k}": v for k, v in sd.items()}, **{f"g:{k}": v.grad.cpu().numpy() for k, v in layer.named_parameters()})
         except Exception as ex:
             fails.append(("exc", case, kind, H, B, L, fin, names, n, e, flags, asl, repr(ex)[:200]))
     if stdvar_stats:
