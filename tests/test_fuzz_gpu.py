@@ -22,6 +22,9 @@ variance 0): float32 leaves E[x^2] - E[x]^2 = +3 / +1 / 0 ulp(x^2) here and -1 /
 GEMM's outputs decide), relu() hides the negative draws and sqrt(. + 1e-5) turns the positive ones into 1.1e-4 of std:
 3.1e-5 of the output against the restatement's 3.1e-7.  Nothing evaluated in float32 can promise the sign of that
 residue; what is promised is the formula of layers.py:203-216 with separately rounded squares, products and differences.
+These draws are what the ELEMENT-WISE criterion is for (_stdvar_allowance): beyond 1e-5 and beyond 8 x the restatement, a std /
+var layer must lie within 1e-5 + the spread that (4 + sqrt(deg)) ulp of E[x^2] in the variance produces in its own output,
+computed in float64 from the layer's formula -- seeds 337 and 377 are kept under it.
 Seeds 400-449 (final binary of the round): 47 clean; 405 and 410 are two more std layers over tied neighbours (2e-5); 413
 (kept) is a GRADIENT 9.8e-4 from float64 that the float32 restatement shares to 4e-7 -- a near-tie of max / min that float32
 and float64 resolve differently -- hence the float32 yardstick for such cases.
@@ -68,8 +71,51 @@ def _extra_seeds():
     return out
 
 
+def _stdvar_allowance(kind, layer, x, ei, H, B, names, flags, asl):
+    """What float32 itself leaves in a std / var layer's output, element by element [N, F_out] (float64): the formula
+    var = E[x^2] - E[x]^2 (layers.py:203-216) evaluated in float32 has a residue of a few ulp OF E[x^2] whatever the
+    variance is -- sums of deg terms, two divisions, a square, a difference: (4 + sqrt(deg)) ulp is a generous envelope;
+    measured on identical neighbours: 0 ... +-3 ulp, either sign with equal probability -- and std = sqrt(relu(var) + 1e-5)
+    passes it on with slope 1 / (2 std) <= 158.  The allowance is that spread, through the combination's |weights|."""
+    p = {k: v.detach().double().cpu() for k, v in layer.named_parameters()}
+    x64 = torch.from_numpy(x).double()
+    n = x64.size(0)
+    with torch.no_grad():
+        if kind == "opt":
+            e2, _ = orc.egconv_edge_set(np.asarray(ei), n, list(names), asl)
+            bases = x64 @ p["bases_weight"]
+            w = x64 @ p["comb_weight.weight"].t() + p["comb_weight.bias"]
+            if flags.get("sigmoid", False): w = torch.sigmoid(w)
+            w = w.view(n, H, len(names), B).abs()                               # [n, h, a, b]
+        else:
+            e2 = np.asarray(ei)                                                  # std / var see the raw edges (layers.py:166-193)
+            bases = torch.cat([x64 @ p[f"bases_weight.{b}"] for b in range(B)], dim=1)
+            w = x64 @ p["comb_weights.weight"].t() + p["comb_weights.bias"]
+            if flags.get("softmax", False): w = w.view(n, H, B * len(names)).softmax(dim=-1)
+            elif flags.get("sigmoid", False): w = torch.sigmoid(w)
+            elif flags.get("hardtanh", False): w = torch.nn.functional.hardtanh(w)
+            w = w.view(n, H, B, len(names)).abs().permute(0, 1, 3, 2)            # -> [n, h, a, b]
+        src, dst = torch.from_numpy(e2[0]).long(), torch.from_numpy(e2[1]).long()
+        xj = bases[src]
+        deg = torch.zeros(n, dtype=torch.float64).index_add(0, dst, torch.ones(dst.numel(), dtype=torch.float64))
+        dn = deg.clamp(min=1).view(-1, 1)
+        mean = torch.zeros_like(bases).index_add(0, dst, xj) / dn
+        m2 = torch.zeros_like(bases).index_add(0, dst, xj * xj) / dn
+        var = m2 - mean * mean
+        delta = (4.0 + deg.sqrt()).view(-1, 1) * 2.0 ** -23 * (m2 + mean * mean)
+        spread_std = torch.sqrt(torch.relu(var + delta) + 1e-5) - torch.sqrt(torch.relu(var - delta) + 1e-5)
+        L = bases.size(1) // B
+        allow = torch.zeros(n, H, L, dtype=torch.float64)
+        for a, name in enumerate(names):
+            if name in ("std", "var"):
+                sp = (spread_std if name == "std" else 2.0 * delta).view(n, B, L)
+                allow += torch.einsum("nhb,nbl->nhl", w[:, :, a, :], sp)
+    return allow.reshape(n, H * L).numpy()
+
+
 @pytest.mark.parametrize("seed,generic", [(11, False), (12, False), (13, False), (14, True), (15, True), (101, False), (109, False),
-                                          (118, False), (202, False), (303, False), (413, False)] + _extra_seeds())
+                                          (118, False), (202, False), (303, False), (337, False), (377, False), (413, False)]
+                         + _extra_seeds())
 def test_random_layers_and_graphs_match_the_oracles(seed, generic, monkeypatch):
     import egc_amd
     if generic:   # the generic forward kernels + separate arg pass, and the run-time forms of the backward kernels
@@ -161,6 +207,13 @@ def test_random_layers_and_graphs_match_the_oracles(seed, generic, monkeypatch):
                     truth = _truth64(tref, kind, layer, x, ei, H, B, names, flags, asl).numpy()
                     e_hip, e_ref = rel_err(out.cpu().numpy(), truth), rel_err(ref, truth)
                     ok = e_hip <= max(1e-5, STDVAR_K * e_ref)
+                    if not ok:
+                        # ... or, element by element, within what float32 leaves in E[x^2] - E[x]^2 (its residue has either
+                        # sign with equal probability, relu() hides the negative draws: the restatement's own error on one
+                        # layer is a sample of the same noise, not a bound for it)
+                        allow = _stdvar_allowance(kind, layer, x, ei, H, B, names, flags, asl)
+                        scale = max(1.0, float(np.abs(truth).max()))
+                        ok = bool((np.abs(out.cpu().numpy().astype(np.float64) - truth) <= 1e-5 * scale + allow).all())
                     err = (err, e_hip, e_ref)
                     stdvar_stats.append((e_hip, e_ref, case))
                 if not ok:
