@@ -28,6 +28,7 @@ computed in float64 from the layer's formula -- seeds 337 and 377 are kept under
 Seeds 400-449 (final binary of the round): 47 clean; 405 and 410 are two more std layers over tied neighbours (2e-5); 413
 (kept) is a GRADIENT 9.8e-4 from float64 that the float32 restatement shares to 4e-7 -- a near-tie of max / min that float32
 and float64 resolve differently -- hence the float32 yardstick for such cases.
+Under these criteria seeds 300-749 (450 seeds, 54,000 configurations) all pass on the final binary of the round.
 EGC_FUZZ_DUMP=<dir> saves the inputs of failing cases."""
 import numpy as np
 import pytest
