@@ -6,6 +6,7 @@
 // Layer: EGConv(128, 128, aggrs = sum, mean, max, symnorm, H = 8, B = 4) semantics, i.e. the gcn_norm edge set
 // (self-loops replaced by one per node) for every aggregator (reference optimized_layers.py:127-208), in both
 // weight layouts (HBA -> register-resident kernels, HAB -> generic kernels) and both GEMM forms (fp32, packed).
+// Round 3: also the training forward and the sparse backward, with both workspace sizes (record path / arg-byte path).
 // Exit code 0 and "c_abi_check: OK" on success.
 #include <hip/hip_runtime.h>
 
@@ -194,6 +195,81 @@ int main() {
     HIP_OK(hipFree(d_wcat)); HIP_OK(hipFree(d_bcat)); HIP_OK(hipFree(d_bases)); HIP_OK(hipFree(d_wt));
     HIP_OK(hipFree(d_out)); HIP_OK(hipFree(d_ws)); HIP_OK(hipFree(d_packed));
   }
-  std::printf("%s %s\n", egc_version(), worst <= 1e-5 ? "c_abi_check: OK" : "c_abi_check: FAILED");
-  return (runs == 4 && worst <= 1e-5) ? 0 : 1;
+  // ---- training forward + sparse backward through the C ABI (round 3), twice: with the workspace of
+  // egc_backward_workspace_bytes (arg-byte path) and of egc_backward_workspace_bytes_for (one 64-byte record per entry for the
+  // max gradients) -- the two must agree up to the order of float additions
+  double bwd_diff = 0.0;
+  {
+    egc_layer layer = {};
+    layer.in_channels = F_in; layer.out_channels = F_out; layer.num_heads = H; layer.num_bases = B; layer.num_aggrs = A;
+    for (int a = 0; a < A; ++a) layer.aggrs[a] = aggrs[a];
+    layer.agg_set = EGC_SET_LOOPED; layer.sym_set = EGC_SET_LOOPED; layer.loops_all_nodes = 1;
+    layer.weight_layout = EGC_LAYOUT_HBA; layer.weight_act = EGC_ACT_NONE; layer.basis_stride = 0;
+    const int ldb = egc_bases_ld(&layer);
+    std::vector<float> wcat((size_t)F_in * (F_g + W)), bcat(W), gout((size_t)n * F_out);
+    for (int k = 0; k < F_in; ++k)
+      for (int c = 0; c < F_g; ++c) wcat[(size_t)k * (F_g + W) + c] = wb[(size_t)k * F_g + c];
+    for (int h = 0; h < H; ++h)
+      for (int a = 0; a < A; ++a)
+        for (int b = 0; b < B; ++b) {
+          const int r_ref = h * A * B + a * B + b, r = h * B * A + b * A + a;
+          bcat[r] = bc[r_ref];
+          for (int k = 0; k < F_in; ++k) wcat[(size_t)k * (F_g + W) + F_g + r] = wc[(size_t)r_ref * F_in + k];
+        }
+    for (auto& v : gout) v = next_unit();
+    float *d_wcat = to_device(wcat), *d_bcat = to_device(bcat), *d_gout = to_device(gout);
+    float* d_bases = device_zeros<float>((size_t)n * ldb);
+    float* d_wt = device_zeros<float>((size_t)n * W);
+    float* d_out = device_zeros<float>((size_t)n * F_out);
+    const size_t ws_bytes = egc_aggregate_workspace_bytes(&layer, n, e);
+    char* d_ws = device_zeros<char>(ws_bytes);
+    const size_t pk_bytes = egc_basis_pack_bytes(F_in, F_g, W);
+    char* d_packed = device_zeros<char>(pk_bytes);
+    EGC_CHECK(egc_basis_pack(d_wcat, F_in, F_g, W, d_packed, pk_bytes, stream));
+    EGC_CHECK(egc_basis_transform_packed(d_x, d_packed, d_bcat, n, F_in, F_g, W, d_bases, ldb, d_wt, stream));
+    float* d_stats = device_zeros<float>((size_t)n * (size_t)egc_train_stats_floats(&layer));
+    int32_t* d_cnt = device_zeros<int32_t>(n);
+    int32_t* d_argmax = device_zeros<int32_t>((size_t)n * ldb);
+    EGC_CHECK(egc_aggregate_combine_train_f32(&g, &layer, d_bases, ldb, d_wt, d_bias, d_out, d_stats, d_cnt, d_argmax, nullptr, d_ws,
+                                              ws_bytes, stream));
+    // the transposed graph, from the edge list in destination-CSR order (its edge_id then names CSR positions)
+    int64_t *d_tsrc = device_zeros<int64_t>(e), *d_tdst = device_zeros<int64_t>(e);
+    EGC_CHECK(egc_csr_transposed_coo(n, e, d_rowptr, d_col, d_tsrc, d_tdst, stream));
+    int32_t* d_trowptr = device_zeros<int32_t>(n + 1);
+    int32_t *d_tcol = device_zeros<int32_t>(e), *d_teid = device_zeros<int32_t>(e), *d_tmax = device_zeros<int32_t>(1);
+    HIP_OK(hipMemsetAsync(d_csr_ws, 0, csr_ws_bytes, stream));
+    EGC_CHECK(egc_coo_to_csr(d_tsrc, d_tdst, e, n, d_trowptr, d_tcol, d_teid, d_tmax, d_csr_ws, csr_ws_bytes, stream));
+    float *d_tdr = device_zeros<float>(n), *d_tdl = device_zeros<float>(n);
+    int32_t* d_tplan = device_zeros<int32_t>((size_t)egc_plan_ints(n, e));
+    EGC_CHECK(egc_csr_prepare(n, e, d_trowptr, d_tcol, d_tdr, d_tdl, d_tplan, stream));
+    egc_graph tg = {};
+    tg.n_nodes = n; tg.n_edges = e; tg.rowptr = d_trowptr; tg.col = d_tcol; tg.edge_id = d_teid; tg.dis_raw = d_tdr;
+    tg.dis_looped = d_tdl; tg.max_index = d_tmax; tg.plan = d_tplan; tg.n_chunks = -1; tg.n_src_rows = 0;
+    std::vector<float> res[2];
+    const size_t sizes[2] = {egc_backward_workspace_bytes(&layer, n), egc_backward_workspace_bytes_for(&layer, &g)};
+    if (sizes[1] != sizes[0] + (size_t)e * 64) { std::fprintf(stderr, "workspace sizes: %zu %zu\n", sizes[0], sizes[1]); return 4; }
+    for (int v = 0; v < 2; ++v) {
+      char* d_bws = device_zeros<char>(sizes[v]);
+      float* d_db = device_zeros<float>((size_t)n * ldb);
+      float* d_dw = device_zeros<float>((size_t)n * W);
+      HIP_OK(hipMemsetAsync(d_db, 0xff, (size_t)n * ldb * sizeof(float), stream));   // square graph: every row is written
+      EGC_CHECK(egc_aggregate_combine_backward_f32(&g, &tg, &layer, d_bases, ldb, d_wt, d_gout, d_stats, d_cnt, d_argmax, nullptr, d_db, 0,
+                                                   d_dw, 0, d_bws, sizes[v], stream));
+      res[v].resize((size_t)n * (ldb + W));
+      HIP_OK(hipMemcpyAsync(res[v].data(), d_db, (size_t)n * ldb * sizeof(float), hipMemcpyDeviceToHost, stream));
+      HIP_OK(hipMemcpyAsync(res[v].data() + (size_t)n * ldb, d_dw, (size_t)n * W * sizeof(float), hipMemcpyDeviceToHost, stream));
+      HIP_OK(hipStreamSynchronize(stream));
+      HIP_OK(hipFree(d_bws)); HIP_OK(hipFree(d_db)); HIP_OK(hipFree(d_dw));
+    }
+    double scale = 1.0;
+    for (float v : res[0]) scale = std::max(scale, (double)std::fabs(v));
+    for (size_t k = 0; k < res[0].size(); ++k) {
+      const double d = std::fabs((double)res[0][k] - (double)res[1][k]);
+      bwd_diff = std::isnan(d) ? INFINITY : std::max(bwd_diff, d / scale);
+    }
+    std::printf("sparse backward, record path vs arg-byte path: max |diff| / scale = %.3e\n", bwd_diff);
+  }
+  const bool ok = runs == 4 && worst <= 1e-5 && bwd_diff <= 3e-6;
+  std::printf("%s %s\n", egc_version(), ok ? "c_abi_check: OK" : "c_abi_check: FAILED");
+  return ok ? 0 : 1;
 }
