@@ -63,9 +63,40 @@ def dist_setup(n_gpus):
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
-    elif n_gpus > 1:
-        raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     return world, rank, local
+
+
+def spawn_ranks(n_gpus, argv):
+    """``python bench.py --gpus N`` with N > 1 and no RANK in the environment: start the N ranks ourselves, as children
+    (``python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>``), relay rank 0's ONE JSON line and
+    exit with the launcher's code.  Called before anything in this process has touched the GPU (no torch.cuda call has
+    run yet); this process never initialises it -- it only waits for the child."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", str(port)),
+           os.path.abspath(__file__)] + list(argv)
+    log("bench.py: starting", n_gpus, "ranks:", " ".join(cmd))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, cwd=ROOT, text=True)
+    lines = []
+    for ln in proc.stdout:            # ranks other than 0 print nothing on stdout; stderr goes straight through
+        if ln.startswith("{"):
+            lines.append(ln.rstrip("\n"))
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    for ln in lines:
+        print(ln, flush=True)
+    if rc == 0 and len(lines) != 1:
+        log(f"bench.py: expected ONE JSON line from rank 0, got {len(lines)}")
+        rc = 1
+    raise SystemExit(rc)
 
 
 def time_region(fn, iters, sync=None):
@@ -410,6 +441,8 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        spawn_ranks(args.gpus, sys.argv[1:])     # does not return
     world, rank, local = dist_setup(args.gpus)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     dev = torch.device("cuda", local)

@@ -58,3 +58,18 @@ def test_all_three_workloads_two_gloo_ranks_on_one_gpu():
 def test_all_three_workloads_rccl_world_size_one():
     line = _run(1, 29553, {"EGC_BENCH_FORCE_PARTITION": "1"})
     _check_line(line, 1, True)
+
+
+def test_bench_starts_its_own_ranks_when_given_gpus_without_a_launcher():
+    """`python bench.py --gpus 2` with no RANK in the environment (the form the N = 1 driver command has): bench.py spawns
+    the two ranks itself as children of a process that never touched the GPU, and relays rank 0's one line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(EGC_BENCH_SCALE="0.05", EGC_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    _check_line(line, 2, True)
+    assert line["scaling"] == "strong" and line["n_gpus"] == 2
