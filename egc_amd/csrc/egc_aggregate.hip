@@ -922,6 +922,64 @@ int egc_aggregate_combine_batch_f32(const int32_t* tiles, const int32_t* n_tiles
                             max_tile_edges, src, dst, max_index, status, host_flag, (hipStream_t)stream);
 }
 
+// ---- batches of small graphs, the whole layer in one launch (egc_fused_tile.hip) ----
+int32_t egc_batch_fused_tile_nodes(const egc_layer* layer, int32_t max_tile_edges, int32_t with_post) {
+  AggArgs a;
+  if (tile_layer_args(layer, a) != EGC_OK) return 0;
+  return fused_tile_capacity(a, layer->in_channels, max_tile_edges, with_post != 0);
+}
+
+int64_t egc_batch_fused_pack_bytes(const egc_layer* layer) {
+  AggArgs a;
+  if (tile_layer_args(layer, a) != EGC_OK || !fused_tile_shape(a, layer->in_channels)) return 0;
+  return (int64_t)fused_tile_pack_bytes();
+}
+
+int egc_batch_fused_pack(const egc_layer* layer, const float* wcat, const float* bcat, void* packed, int64_t packed_bytes,
+                         egc_stream_t stream) {
+  AggArgs a;
+  int st = tile_layer_args(layer, a);
+  if (st != EGC_OK) return st;
+  if (!fused_tile_shape(a, layer->in_channels)) return EGC_ERR_UNSUPPORTED;
+  if (wcat == nullptr || packed == nullptr || packed_bytes < (int64_t)fused_tile_pack_bytes()) return EGC_ERR_INVALID;
+  return fused_tile_pack(wcat, bcat, layer->in_channels, a.B * a.Ls, a.W, a.ldb, packed, (hipStream_t)stream);
+}
+
+int egc_layer_forward_batch_fused_f32(const int64_t* graph_ptr, const int64_t* edge_ptr, int64_t n_graphs, const int64_t* src,
+                                      const int64_t* dst, int64_t n_edges, int64_t n_nodes, const int32_t* max_index,
+                                      const egc_layer* layer, const float* x, const void* packed, const float* bias,
+                                      const egc_post* post, float* out, int32_t tile_nodes, int32_t max_tile_edges,
+                                      int32_t* status, int32_t* host_flag, egc_stream_t stream) {
+  AggArgs a;
+  int st = tile_layer_args(layer, a);
+  if (st != EGC_OK) return st;
+  if (n_nodes < 0 || n_graphs < 0 || n_edges < 0 || n_nodes >= ((int64_t)1 << 31) - 1 || n_edges >= ((int64_t)1 << 31) - 1)
+    return EGC_ERR_INVALID;
+  if (n_nodes == 0 || n_graphs == 0) return EGC_OK;
+  if (graph_ptr == nullptr || x == nullptr || packed == nullptr || out == nullptr || status == nullptr) return EGC_ERR_INVALID;
+  if (n_edges > 0 && (src == nullptr || dst == nullptr)) return EGC_ERR_INVALID;
+  if ((reinterpret_cast<uintptr_t>(x) & 15) != 0 || (reinterpret_cast<uintptr_t>(packed) & 15) != 0) return EGC_ERR_INVALID;
+  if (post != nullptr && ((post->scale == nullptr) != (post->shift == nullptr))) return EGC_ERR_INVALID;
+  if (!a.loops_all && max_index == nullptr) return EGC_ERR_INVALID;
+  if ((uint64_t)n_nodes * (uint64_t)a.F_out * 4ull > (uint64_t)OOB) return EGC_ERR_UNSUPPORTED;
+  a.n_nodes = (int)n_nodes;
+  a.row_begin = 0;
+  a.row_end = (int)n_nodes;
+  a.bases = nullptr;          // never in memory
+  a.weightings = nullptr;
+  a.bases_bytes = 0;
+  a.bias = bias;
+  a.out = out;
+  a.dis = layer_uses_symnorm(layer) ? x : nullptr;   // (a flag: the deg^-1/2 tables are built per tile, in LDS)
+  a.post_scale = post != nullptr ? post->scale : nullptr;
+  a.post_shift = post != nullptr ? post->shift : nullptr;
+  a.residual = post != nullptr ? post->residual : nullptr;
+  a.post_relu = post != nullptr && post->relu != 0;
+  a.self_pos = 0;
+  return launch_fused_tile(a, graph_ptr, edge_ptr, n_graphs, src, dst, n_edges, max_index, x, layer->in_channels, packed,
+                           tile_nodes, max_tile_edges, status, host_flag, (hipStream_t)stream);
+}
+
 int32_t egc_layer_gemm_flags(const egc_layer* layer) {
   if (layer == nullptr) return 0;
   if (const char* e = getenv("EGC_GEMM_FAST"))   // keep the 22-bit form for std / var layers too (measurements)

@@ -206,4 +206,13 @@ int launch_tile_simple(AggArgs a, const int4* tiles, const int* n_tiles_dev, int
                        const int64_t* src, const int64_t* dst, const int* max_index, int32_t* status, int32_t* host_flag,
                        hipStream_t stream);
 
+// egc_fused_tile.hip: the whole layer on tiles of whole graphs in ONE launch (plan + GEMM + CSR + aggregate + combine)
+bool fused_tile_shape(const AggArgs& a, int f_in);
+int fused_tile_capacity(const AggArgs& a, int f_in, int max_tile_edges, bool with_post);
+size_t fused_tile_pack_bytes();
+int fused_tile_pack(const float* wcat, const float* bcat, int f_in, int f_g, int w_cols, int ldb, void* packed, hipStream_t stream);
+int launch_fused_tile(AggArgs a, const int64_t* ptr, const int64_t* edge_ptr, int64_t n_graphs, const int64_t* src,
+                      const int64_t* dst, int64_t n_edges, const int* max_index, const float* x, int f_in, const void* packed,
+                      int tcap, int emax, int32_t* status, int32_t* host_flag, hipStream_t stream);
+
 }  // namespace egc

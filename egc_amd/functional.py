@@ -351,6 +351,81 @@ def egc_aggregate_combine_batch(gb: GraphBatch, spec: LayerSpec, bases, weightin
     return out
 
 
+_BATCH_FUSED_PACKS: "dict[tuple, tuple]" = {}
+
+
+def _batch_fused_pack(spec: LayerSpec, wcat: torch.Tensor, bcat):
+    """The weight planes of egc_layer_forward_batch_fused_f32 (egc_batch_fused_pack), cached on the identity / version of
+    the concatenated weights (rebuilt only when a parameter changes)."""
+    key = (wcat.data_ptr(), wcat._version, bcat.data_ptr() if bcat is not None else 0,
+           bcat._version if bcat is not None else 0, spec.f_in, spec.f_out, spec.w_cols, str(wcat.device))
+    hit = _BATCH_FUSED_PACKS.get(key)
+    if hit is None:
+        lib = _C.load()
+        _check_f32(wcat, "wcat", (spec.f_in, spec.f_g + spec.w_cols))
+        dev = wcat.device
+        wc = wcat.contiguous()
+        with _device_guard(dev):
+            nbytes = int(lib.egc_batch_fused_pack_bytes(C.byref(spec.c)))
+            if nbytes <= 0:
+                raise RuntimeError("egc_amd: layer outside the envelope of the one-launch batch kernel")
+            packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            _C.check(lib.egc_batch_fused_pack(C.byref(spec.c), wc.data_ptr(), bcat.contiguous().data_ptr() if bcat is not None else None,
+                                              packed.data_ptr(), nbytes, _stream_ptr(dev)), "egc_batch_fused_pack")
+        if len(_BATCH_FUSED_PACKS) >= 32:
+            _BATCH_FUSED_PACKS.clear()
+        hit = (wcat, bcat, packed)       # keep the keyed tensors alive: their addresses are the key
+        _BATCH_FUSED_PACKS[key] = hit
+    return hit[2]
+
+
+def _batch_fused_setup(gb: GraphBatch, spec: LayerSpec, post, wcat):
+    """(tile_nodes, max_tile_edges) when this layer call can run as ONE launch on the batch, else None.  Layers with std / var
+    keep the 24-bit-operand GEMM of the two-launch path (egc_layer_gemm_flags); EGC_NO_FUSED_TILE=1 switches the path off."""
+    if _C.env_flag("EGC_NO_FUSED_TILE") or _C.env_flag("EGC_NO_TILE") or gemm_exact() or wcat.requires_grad:
+        return None
+    if spec.gemm_flags != 0 and not _C.env_flag("EGC_GEMM_FAST"):
+        return None
+    return gb.fused_setup(spec.c, post is not None and post.scale is not None)
+
+
+def egc_layer_forward_batch_fused(gb: GraphBatch, spec: LayerSpec, x, wcat, bcat, bias, post, setup):
+    """The whole layer on a batch of whole graphs in ONE launch (egc_layer_forward_batch_fused_f32): plan, basis transform +
+    weightings on the matrix cores, the tiles' CSR, aggregation and combine -- x and the edge list in, out out."""
+    lib = _C.load()
+    _IndexFlag.poll()
+    n = gb.n_nodes
+    tile_nodes, emax = setup
+    _check_f32(x, "x", (n, spec.f_in))
+    dev = x.device
+    if dev != gb.device:
+        raise RuntimeError(f"egc_amd: x is on {dev} but the batch is on {gb.device}")
+    x = x.contiguous()
+    packed = _batch_fused_pack(spec, wcat, bcat)
+    with _device_guard(dev):
+        out = torch.empty((n, spec.f_out), dtype=torch.float32, device=dev)
+        keep = []
+        p = None
+        if post is not None:
+            def sptr(t, shape, name):
+                if t is None:
+                    return None
+                _check_f32(t, name, shape)
+                keep.append(t.contiguous())
+                return keep[-1].data_ptr()
+            p = _C.EgcPost(sptr(post.scale, (spec.f_out,), "post.scale"), sptr(post.shift, (spec.f_out,), "post.shift"),
+                           sptr(post.residual, (n, spec.f_out), "post.residual"), int(bool(post.relu)))
+        ei = gb.edge_index
+        needs_max = not bool(spec.c.loops_all_nodes)
+        _C.check(lib.egc_layer_forward_batch_fused_f32(
+            gb.ptr.data_ptr(), gb.edge_ptr.data_ptr() if gb.edge_ptr is not None else None, gb.n_graphs, ei[0].data_ptr(),
+            ei[1].data_ptr(), gb.n_edges, n, gb.max_index().data_ptr() if needs_max else None, C.byref(spec.c), x.data_ptr(),
+            packed.data_ptr(), bias.contiguous().data_ptr() if bias is not None else None, C.byref(p) if p is not None else None,
+            out.data_ptr(), tile_nodes, emax, gb.status().data_ptr(), _IndexFlag.ptr(), _stream_ptr(dev)),
+            "egc_layer_forward_batch_fused_f32")
+    return out
+
+
 def segment_mean(x: torch.Tensor, seg_ptr: torch.Tensor) -> torch.Tensor:
     """Mean of consecutive row segments of x [N, C]: out[g] = mean(x[seg_ptr[g]:seg_ptr[g+1]]) (egc_segment_mean_f32)."""
     lib = _C.load()
@@ -534,6 +609,9 @@ def egc_layer_forward(graph: CSRGraph, spec: LayerSpec, x: torch.Tensor, wcat: t
     if the caller keeps one (otherwise it is produced here).  On a vertex-partitioned graph the halo rows
     of ``bases`` are exchanged (one all-to-all-v) between the two steps."""
     if isinstance(graph, GraphBatch):
+        fsetup = None if return_intermediates else _batch_fused_setup(graph, spec, post, wcat)
+        if fsetup is not None:
+            return egc_layer_forward_batch_fused(graph, spec, x, wcat, bcat, bias, post, fsetup)
         tiled = None if return_intermediates else _batch_tile_setup(graph, spec, post)
         if tiled is None:
             graph = graph.csr()          # outside the tile kernels' envelope: the ordinary path on the same edges

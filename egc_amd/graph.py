@@ -569,6 +569,30 @@ class GraphBatch:
         tiles, count, n_slots = self.plan(slot)
         return tiles, count, n_slots, lds, tmax, emax
 
+    def fused_setup(self, spec_c, with_post: bool):
+        """(tile_nodes, max_tile_edges) for egc_layer_forward_batch_fused_f32 -- the whole layer in one launch, no `bases` /
+        `weightings` in memory, no plan launch -- or None when the layer is outside that kernel's envelope or the declared
+        largest graph (``max_nodes``) does not fit the LDS image of a tile (the two-launch tile path or the CSR path then)."""
+        key = (C.string_at(C.addressof(spec_c), C.sizeof(spec_c)), bool(with_post), "fused")
+        hit = self._setups.get(key)
+        if hit is None:
+            gkey = key + (self.max_nodes, self.edges_per_node)
+            hit = _TILE_SETUPS.get(gkey)
+            if hit is None:
+                lib = _C.load()
+                emax, cap = 4096, 0
+                for _ in range(3):
+                    cap = int(lib.egc_batch_fused_tile_nodes(C.byref(spec_c), emax, int(with_post)))
+                    if cap <= 0 or cap * self.edges_per_node <= emax:
+                        break
+                    emax = min(16384, -(-cap * self.edges_per_node // 1024) * 1024)
+                hit = (cap, emax) if (cap >= self.max_nodes and cap > 0 and cap * self.edges_per_node <= emax) else False
+                if len(_TILE_SETUPS) > 256:
+                    _TILE_SETUPS.clear()
+                _TILE_SETUPS[gkey] = hit
+            self._setups[key] = hit
+        return hit or None
+
     def plan(self, slot: int):
         """(tiles int32 [n_slots, 4], n_tiles device scalar, n_slots) for slots of `slot` nodes; one launch, built once."""
         hit = self._plans.get(slot)

@@ -514,6 +514,42 @@ int egc_aggregate_combine_batch_f32(const int32_t* tiles, const int32_t* n_tiles
                                     int32_t ldb, const float* weightings, int32_t ldw, const float* bias, const egc_post* post,
                                     float* out, int32_t* status, int32_t* host_flag, egc_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Batches of small graphs, the WHOLE layer in ONE launch (egc_fused_tile.hip): per tile of whole graphs
+ *   x rows -> basis transform + weightings Linear on the matrix cores -> LDS -> CSR of the tile's edges in LDS ->
+ *   multi-aggregator reduction -> combine (+ bias, egc_post tail) -> out.
+ * Neither `bases` nor `weightings` exist in memory and there is no plan launch: every workgroup finds its own tiles from
+ * graph_ptr (and edge_ptr, or by searching the destination row of edge_index when it is NULL).
+ * Replaces, for such batches, ALL the reference call sites of egc_basis_transform_packed + egc_graph_build +
+ * egc_aggregate_combine_post_f32: torch.matmul(x, bases_weight), comb_weight(x) (experiments/layers.py:97-101,110;
+ * optimized_layers.py:180-182), gcn_norm / add_remaining_self_loops (optimized_layers.py:127-175; layers.py:172-188),
+ * MessagePassing.propagate + scatter per aggregator (optimized_layers.py:186-249; layers.py:191-219), the combine and bias
+ * (optimized_layers.py:195-208; layers.py:127-138), and the caller's bn(eval) -> relu -> + identity (zinc/models.py:66-73,
+ * cifar/models.py:64-71, mol/pna_style_models.py:70-78).
+ *   egc_batch_fused_tile_nodes  rows of a tile whose image (bases + weightings rows, CSR areas for max_tile_edges entries)
+ *                               fits the LDS of one CU; 0 = the layer is outside this kernel's envelope (F_in <= 128 and a
+ *                               multiple of 4, ldb + H B A <= 192, the register-resident kernels' envelope).  A batch whose
+ *                               largest graph has more nodes than this must take egc_aggregate_combine_batch_f32 or the CSR path.
+ *   egc_batch_fused_pack_bytes / egc_batch_fused_pack
+ *                               wcat [F_in, F_g + W] (+ bcat [W] or NULL) -> the two fp16 weight planes in MFMA fragment
+ *                               order + column scales + comb bias; once per parameter update.
+ *   egc_layer_forward_batch_fused_f32
+ *                               the launch.  tile_nodes: a multiple of 16, <= egc_batch_fused_tile_nodes(...); status /
+ *                               host_flag as egc_aggregate_combine_batch_f32 (bit 0: an edge leaves its tile or the graph
+ *                               offsets do not cover [0, n_nodes); bit 1: a tile beyond tile_nodes / max_tile_edges; the
+ *                               rows of such a tile are left unwritten).  Inference form, fp16x2-split GEMM (22-bit operands,
+ *                               fp32 accumulate: the arithmetic of egc_basis_transform_packed at the north-star shape).
+ * ------------------------------------------------------------------------------------------ */
+int32_t egc_batch_fused_tile_nodes(const egc_layer* layer, int32_t max_tile_edges, int32_t with_post);
+int64_t egc_batch_fused_pack_bytes(const egc_layer* layer);
+int egc_batch_fused_pack(const egc_layer* layer, const float* wcat, const float* bcat, void* packed, int64_t packed_bytes,
+                         egc_stream_t stream);
+int egc_layer_forward_batch_fused_f32(const int64_t* graph_ptr, const int64_t* edge_ptr, int64_t n_graphs, const int64_t* src,
+                                      const int64_t* dst, int64_t n_edges, int64_t n_nodes, const int32_t* max_index,
+                                      const egc_layer* layer, const float* x, const void* packed, const float* bias,
+                                      const egc_post* post, float* out, int32_t tile_nodes, int32_t max_tile_edges,
+                                      int32_t* status, int32_t* host_flag, egc_stream_t stream);
+
 /* Whole layer forward = egc_basis_transform_f32 + egc_aggregate_combine_f32
  * (EfficientGraphConv.forward layers.py:89-140 / EGConv.forward optimized_layers.py:177-210
  * after graph preparation).  bases [N,ldb] and weightings [N,W] are caller-provided intermediates. */

@@ -15,6 +15,13 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5
 
 
+@pytest.fixture(autouse=True)
+def _two_launch_tile_path(monkeypatch):
+    """This file pins the TWO-launch tile path (GEMM + agg_tile_kernel); batches that qualify take the one-launch kernel of
+    egc_fused_tile.hip by default (tests/test_fused_tile_gpu.py)."""
+    monkeypatch.setenv("EGC_NO_FUSED_TILE", "1")
+
+
 def _dev():
     assert torch.cuda.is_available(), "these tests need the MI355X"
     return torch.device("cuda:0")

@@ -1,0 +1,252 @@
+"""Batches of whole graphs, the layer in ONE launch (egc_fused_tile.hip; egc_layer_forward_batch_fused_f32): plan, basis
+transform + weightings on the matrix cores, per-tile CSR, aggregation and combine inside one kernel -- no `bases` /
+`weightings` in memory.  Against the numpy oracle of the reference's layers (layers.py:89-225, optimized_layers.py:124-278)
+on PyG-shaped batches (molecules, superpixel k-NN graphs, hub rows, isolated nodes, self loops, duplicate edges, empty
+graphs), both layers' edge-set conventions, the fused BatchNorm(eval) / ReLU / residual tail, the full size of BASELINE
+configs 1 / 3 / 4, with and without the graphs' edge offsets; its envelope and its error reporting."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import elementwise_excess, rel_err
+from test_batch_tile_gpu import _layer, _messy_batch, _oracle
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _ran_fused(gb):
+    return any(k[-1] == "fused" and v for k, v in gb._setups.items() if isinstance(k, tuple))
+
+
+def _edge_ptr(ei, ptr):
+    """The graphs' edge offsets as PyG's collation keeps them (edges grouped by graph)."""
+    d = ei[1].numpy()
+    return torch.from_numpy(np.searchsorted(d, ptr.numpy(), side="left").astype(np.int64)) if np.all(np.diff(d) >= 0) else None
+
+
+@pytest.mark.parametrize("kind,hidden,H,B,aggrs,asl", [
+    ("opt", 128, 8, 4, ["sum", "mean", "max", "symnorm"], True),       # north star (static configuration)
+    ("lay", 128, 8, 4, ["symadd", "max", "mean"], True),               # EfficientGraphConv EGC-M (static)
+    ("lay", 128, 8, 4, ["symadd"], True),                              # EGC-S: A = 1 (weightings rows padded to [h][b][4])
+    ("opt", 128, 1, 1, ["sum"], True),                                 # BASELINE config 1's plumbing shape: ldb = 128, W = 1
+    ("opt", 64, 4, 4, ["min", "max", "mean"], True),                   # run-time configuration, NEED_MN, F_in = 64
+    ("opt", 96, 4, 2, ["sum", "max"], True),                           # no symnorm: loops from add_remaining_self_loops
+    ("opt", 128, 8, 4, ["symnorm", "mean"], False),                    # RAW sets
+    ("lay", 124, 4, 4, ["add", "mean", "max"], True),                  # L = 31: padded bases, 32 slots
+    ("opt", 128, 8, 2, ["sum", "symnorm", "max"], True),               # 8 lanes per basis, A = 3
+])
+@pytest.mark.parametrize("with_edge_ptr", [False, True])
+def test_one_launch_layer_matches_the_oracle_on_a_messy_batch(kind, hidden, H, B, aggrs, asl, with_edge_ptr):
+    import egc_amd
+    dev = _dev()
+    ei, n, ptr = _messy_batch(hidden + len(aggrs))
+    torch.manual_seed(1)
+    conv = _layer(kind, hidden, H, B, aggrs, asl)
+    x = torch.randn(n, hidden)
+    ref = _oracle(conv, kind, x, ei, H, B, aggrs, asl)
+    conv = conv.to(dev).eval()
+    # the messy batch's edges are grouped by graph but not sorted by destination: offsets from the generator's own layout
+    eptr = None
+    if with_edge_ptr:
+        g_of_edge = np.searchsorted(ptr.numpy(), ei[1].numpy(), side="right") - 1
+        assert np.all(np.diff(g_of_edge) >= 0)
+        eptr = torch.from_numpy(np.searchsorted(g_of_edge, np.arange(ptr.numel()), side="left").astype(np.int64)).to(dev)
+    gb = egc_amd.GraphBatch(ei.to(dev), ptr=ptr.to(dev), max_nodes=90, edge_ptr=eptr)
+    with torch.no_grad():
+        out = conv(x.to(dev), gb) if kind == "opt" else conv(x=x.to(dev), edge_index=gb)
+    gb.check()
+    assert _ran_fused(gb) and not gb._plans, "the one-launch path did not run"
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert rel_err(got, ref) <= TOL, rel_err(got, ref)
+    assert elementwise_excess(got, ref, TOL) <= 1.0
+
+
+def test_without_edge_offsets_the_edges_must_be_sorted_by_graph_not_by_destination():
+    """edge_ptr = None: the tile's edge range is found by searching the destination row for the tile's first node, which only
+    needs the edges GROUPED by graph in graph order (PyG's collation) -- the messy batch's rows are unsorted inside a graph."""
+    import egc_amd
+    dev = _dev()
+    ei, n, ptr = _messy_batch(3, n_graphs=120)
+    aggrs = ["sum", "mean", "max", "symnorm"]
+    torch.manual_seed(5)
+    conv = _layer("opt", 128, 8, 4, aggrs)
+    x = torch.randn(n, 128)
+    ref = _oracle(conv, "opt", x, ei, 8, 4, aggrs)
+    conv = conv.to(dev).eval()
+    gb = egc_amd.GraphBatch(ei.to(dev), ptr=ptr.to(dev), max_nodes=90)
+    with torch.no_grad():
+        out = conv(x.to(dev), gb)
+    gb.check()
+    assert _ran_fused(gb)
+    assert rel_err(out.cpu().numpy(), ref) <= TOL
+
+
+@pytest.mark.parametrize("workload", ["molhiv", "cifar", "zinc"])
+@pytest.mark.parametrize("with_edge_ptr", [False, True])
+def test_one_launch_layer_at_full_batch_sizes(workload, with_edge_ptr):
+    """BASELINE configs 3 / 4 (2048 molecules; 2048 superpixel 8-NN graphs, 1.93 M edges) and a ZINC batch of 128 (config 1's
+    batch), north-star layer through EGConv; whole output against the oracle, scale-relative AND element-wise."""
+    import egc_amd
+    from egc_amd.workloads import knn_superpixel_batch, molecule_batch, zinc_like_batch
+    dev = _dev()
+    if workload == "molhiv":
+        ei, n, batch = molecule_batch(2048, seed=0); G = 2048
+    elif workload == "cifar":
+        ei, n, batch = knn_superpixel_batch(2048, seed=0); G = 2048
+    else:
+        _, ei, n, batch = zinc_like_batch(128, seed=0); G = 128
+    sizes = torch.bincount(batch, minlength=G)
+    mx = int(sizes.max())
+    ptr = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(sizes, 0)])
+    eptr = None
+    if with_edge_ptr:
+        eptr = torch.searchsorted(batch[ei[1]].contiguous(), torch.arange(G + 1)).to(dev)
+    torch.manual_seed(3)
+    aggrs = ["sum", "mean", "max", "symnorm"]
+    conv = _layer("opt", 128, 8, 4, aggrs)
+    x = torch.randn(n, 128)
+    ref = _oracle(conv, "opt", x, ei, 8, 4, aggrs)
+    conv = conv.to(dev).eval()
+    gb = egc_amd.GraphBatch(ei.to(dev), ptr=ptr.to(dev), max_nodes=mx, edge_ptr=eptr)
+    with torch.no_grad():
+        out = conv(x.to(dev), gb)
+    gb.check()
+    assert _ran_fused(gb) and not gb._plans
+    got = out.cpu().numpy()
+    assert rel_err(got, ref) <= TOL, rel_err(got, ref)
+    assert elementwise_excess(got, ref, TOL) <= 1.0
+    # and the two-launch tile path on the same batch: same results up to summation order
+    import os
+    os.environ["EGC_NO_FUSED_TILE"] = "1"
+    try:
+        gb2 = egc_amd.GraphBatch(ei.to(dev), ptr=ptr.to(dev), max_nodes=mx, edge_ptr=eptr)
+        with torch.no_grad():
+            out2 = conv(x.to(dev), gb2)
+        gb2.check()
+    finally:
+        del os.environ["EGC_NO_FUSED_TILE"]
+    assert rel_err(got, out2.cpu().numpy()) <= TOL
+
+
+def test_fused_block_tail_in_the_one_launch_kernel():
+    """FusedEGCBlock (eval): BatchNorm affine + ReLU + residual in the kernel's store == the plain composition."""
+    import egc_amd
+    dev = _dev()
+    ei, n, ptr = _messy_batch(5)
+    torch.manual_seed(2)
+    conv = _layer("lay", 128, 8, 4, ["symadd", "max", "mean"]).to(dev)
+    bn = torch.nn.BatchNorm1d(128).to(dev)
+    with torch.no_grad():
+        bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0); bn.weight.normal_(); bn.bias.normal_()
+    x = torch.randn(n, 128, device=dev)
+    gb = egc_amd.GraphBatch(ei.to(dev), ptr=ptr.to(dev), max_nodes=90)
+    block = egc_amd.FusedEGCBlock(conv, bn).eval()
+    with torch.no_grad():
+        got = block(x, gb)
+        ref = block._plain(x, ei.to(dev))
+    gb.check()
+    assert _ran_fused(gb)
+    assert float((got - ref).abs().max()) / max(1.0, float(ref.abs().max())) <= 1e-5
+
+
+def test_weight_nonlinearities_in_the_gemm_epilogue():
+    """sigmoid / hardtanh on the weightings (layers.py:123-125) are applied where the GEMM writes them to the LDS image."""
+    import egc_amd
+    dev = _dev()
+    ei, n, ptr = _messy_batch(17, n_graphs=80)
+    for kw in ({"sigmoid_weights": True}, {"hardtanh_weights": True}):
+        torch.manual_seed(6)
+        conv = egc_amd.EfficientGraphConv(128, 128, 8, 4, False, aggrs=["symadd", "max", "mean"], **kw)
+        with torch.no_grad():
+            conv.bias.normal_()
+        conv = conv.to(dev).eval()
+        x = torch.randn(n, 128, device=dev)
+        gb = egc_amd.GraphBatch(ei.to(dev), ptr=ptr.to(dev), max_nodes=90)
+        with torch.no_grad():
+            got = conv(x=x, edge_index=gb)
+            ref = conv(x=x, edge_index=ei.to(dev))
+        gb.check()
+        assert _ran_fused(gb)
+        assert float((got - ref).abs().max()) / max(1.0, float(ref.abs().max())) <= 1e-5
+
+
+def test_envelope_and_fallbacks():
+    """Outside the envelope the batch takes the two-launch tile path / the CSR path with the same results: a declared graph
+    size beyond the LDS image, F_in > 128, std / var layers (24-bit-operand GEMM), training."""
+    import egc_amd
+    dev = _dev()
+    ei, n, ptr = _messy_batch(23, n_graphs=100)
+    aggrs = ["sum", "mean", "max", "symnorm"]
+    torch.manual_seed(7)
+    conv = _layer("opt", 128, 8, 4, aggrs).to(dev).eval()
+    x = torch.randn(n, 128, device=dev)
+    with torch.no_grad():
+        ref = conv(x, ei.to(dev))
+        gb = egc_amd.GraphBatch(ei.to(dev), ptr=ptr.to(dev), max_nodes=1000)     # beyond the image: two-launch tile path
+        out = conv(x, gb)
+        gb.check()
+        assert not _ran_fused(gb) and gb._plans
+        assert float((out - ref).abs().max()) / max(1.0, float(ref.abs().max())) <= 1e-5
+        sv = _layer("opt", 128, 8, 4, ["sum", "std", "max"]).to(dev).eval()     # std: the 24-bit GEMM of the two-launch path
+        gb = egc_amd.GraphBatch(ei.to(dev), ptr=ptr.to(dev), max_nodes=90)
+        sv(x, gb)
+        gb.check()
+        assert not _ran_fused(gb)
+        wide = _layer("opt", 256, 8, 4, aggrs).to(dev).eval()                   # F_in = 256
+        gb = egc_amd.GraphBatch(ei.to(dev), ptr=ptr.to(dev), max_nodes=90)
+        wide(torch.randn(n, 256, device=dev), gb)
+        gb.check()
+        assert not _ran_fused(gb)
+
+
+def test_malformed_batches_are_reported_by_the_one_launch_kernel():
+    import egc_amd
+    dev = _dev()
+    ei, n, ptr = _messy_batch(12, n_graphs=60)
+    conv = _layer("opt", 128, 8, 4, ["sum", "mean", "max", "symnorm"]).to(dev).eval()
+    x = torch.randn(n, 128, device=dev)
+    # (1) an edge between two graphs of different tiles
+    bad = ei.clone()
+    bad[0, 5] = n - 1
+    gb = egc_amd.GraphBatch(bad.to(dev), ptr=ptr.to(dev), max_nodes=90)
+    with torch.no_grad():
+        conv(x, gb)
+    assert _ran_fused(gb)
+    with pytest.raises(RuntimeError, match="not grouped by graph"):
+        gb.check()
+    # (2) edge list shuffled across graphs
+    perm = torch.randperm(ei.size(1))
+    gb = egc_amd.GraphBatch(ei[:, perm].to(dev), ptr=ptr.to(dev), max_nodes=90)
+    with torch.no_grad():
+        conv(x, gb)
+    with pytest.raises(RuntimeError, match="not grouped by graph"):
+        gb.check()
+    # (3) a graph larger than max_nodes promises -> a tile beyond the LDS image
+    big_ptr = torch.tensor([0, n])
+    gb = egc_amd.GraphBatch(ei.to(dev), ptr=big_ptr.to(dev), max_nodes=16)
+    with torch.no_grad():
+        conv(x, gb)
+    with pytest.raises(RuntimeError, match="exceeds the"):
+        gb.check()
+    # (4) graph offsets that are not monotone (such a ptr made the plan launch write out of bounds; this kernel
+    # keeps no tile list): reported, nothing outside `out` is written -- a guard array behind `out` stays intact
+    ptr_bad = ptr.clone()
+    ptr_bad[1::2] = ptr[-1]
+    ptr_bad[2::2] = 0
+    ptr_bad[-1] = n
+    eptr = torch.zeros_like(ptr_bad)
+    gb = egc_amd.GraphBatch(ei.to(dev), ptr=ptr_bad.to(dev), max_nodes=90, edge_ptr=eptr.to(dev))
+    with torch.no_grad():
+        conv(x, gb)
+    with pytest.raises(RuntimeError):
+        gb.check()
+    with torch.no_grad():
+        ok = conv(x, ei.to(dev))      # the device is still healthy
+    assert torch.isfinite(ok).all()
