@@ -30,6 +30,7 @@
 // their tile raise *status and the sticky host flag; the host routes batches whose declared largest graph exceeds the
 // capacity to the two-launch path.
 #include <algorithm>
+#include <cstdio>
 
 #include "egc_aggregate_fast_dev.h"
 
@@ -48,15 +49,20 @@ constexpr int FT_FIRST_HELPER = 12;     // wavefronts 12-15: x rows -> planes
 constexpr int FT_HELPER_THREADS = (FT_WAVES - FT_FIRST_HELPER) * 64;
 constexpr int FT_KP = 128;              // k extent of the register-resident weight tiles (F_in <= 128, zero beyond)
 constexpr int FT_CHUNK = 16;            // rows per GEMM step (one MFMA tile)
-#ifndef EGC_FT_DEPTH
-#define EGC_FT_DEPTH 4
-#endif
-constexpr int FT_DEPTH = EGC_FT_DEPTH;  // x chunks in flight
-constexpr int FT_EDGE_REGS = 3;         // edges per thread kept in registers (16:16 packed local ids)
+constexpr int FT_WORKER_THREADS = FT_FIRST_HELPER * 64;
+constexpr int FT_EDGE_REGS = 4;         // edges per worker thread kept in registers (16:16 packed local ids)
+constexpr int FT_RING = 10;             // 16-row chunks of x a tile may have: the helpers hold them all in registers (80 VGPRs)
 constexpr int FT_MAX_NODES = 2048;      // local ids are 16-bit, the scan is one wavefront
 constexpr int FT_NV = FT_MFMA_WAVES * 16;
 constexpr int FT_PLANE_BYTES = FT_CHUNK * FT_KP * 2;     // one plane of one chunk
 constexpr int FT_PLANES_BYTES = 2 * 2 * FT_PLANE_BYTES;  // [2 buffers][2 planes]
+
+#ifdef EGC_FT_STAMPS
+__device__ unsigned long long* egc_ft_stamp_buf = nullptr;   // diagnostic build only: [grid][8] accumulated cycles per phase
+#define FT_STAMP(k) { if (tid == 0) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); ft_acc[k] += _t - ft_t0; ft_t0 = _t; } }
+#else
+#define FT_STAMP(k)
+#endif
 
 struct FusedTileArgs {
   const int64_t* ptr;        // node offsets of the graphs [G + 1]
@@ -74,6 +80,7 @@ struct FusedTileArgs {
   int n_ct;                  // column tiles in use = ceil((ldb + W) / 16)
   int tcap, emax;            // LDS image: rows of bases / weightings, entries of the CSR
   int wl_floats;             // floats per weightings row in LDS: H * B * 4
+  int dbg;                   // diagnostic build (EGC_FT_STAMPS) only: bit 0 no split, bit 1 no MFMA, bit 2 no rows
   int off_rec, off_planes, off_rowinv, off_bases, off_wt, off_col, off_rowptr, off_cnt, off_ns, off_dis_raw, off_dis_looped;
 };
 
@@ -121,23 +128,24 @@ int fused_tile_pack(const float* wcat, const float* bcat, int f_in, int f_g, int
 
 // first index i in [0, n) with arr[i] >= key (n if none), by HALF a wavefront (lanes [32 h, 32 h + 32) share `key`), as
 // egc_aggregate_tile.hip: the two halves of a wavefront run two searches side by side; deterministic on unsorted input.
-__device__ inline int64_t ft_half_wave_lower_bound(const int64_t* __restrict__ arr, int64_t n, int64_t key, int lane) {
+// 32-bit indices (n < 2^31): this runs in the wavefronts whose registers carry a tile of x.
+__device__ inline int ft_half_wave_lower_bound(const int64_t* __restrict__ arr, int n, int64_t key, int lane) {
   const int l32 = lane & 31, sh = lane & 32;
-  int64_t lo = 0, hi = n;
+  int lo = 0, hi = n;
   while (__ballot(hi - lo > 32) != 0) {
     const bool live = hi - lo > 32;
-    const int64_t step = live ? (hi - lo + 31) / 32 : 1;
-    const int64_t i = lo + (int64_t)l32 * step;
+    const int step = live ? (hi - lo + 31) / 32 : 1;
+    const int i = lo + l32 * step;
     const bool ge = (live && i < hi) ? arr[i] >= key : true;
     const unsigned m = (unsigned)(__ballot(ge) >> sh);
     if (!live) continue;
     const int f = __ffs((int)m) - 1;
     if (f < 0) { lo = lo + 31 * step + 1; if (lo > hi) lo = hi; continue; }
-    const int64_t nhi = lo + (int64_t)f * step;
-    lo = f > 0 ? lo + (int64_t)(f - 1) * step + 1 : lo;
+    const int nhi = lo + f * step;
+    lo = f > 0 ? lo + (f - 1) * step + 1 : lo;
     hi = nhi < hi ? nhi : hi;
   }
-  const int64_t i = lo + l32;
+  const int i = lo + l32;
   const bool ge = i < hi ? arr[i] >= key : true;
   const unsigned m = (unsigned)(__ballot(ge) >> sh);
   const int f = __ffs((int)m) - 1;
@@ -168,28 +176,17 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
-  const int g = lane >> LPR_LOG2;
-  const int q = lane & (LPR - 1);
-  const int F_out = C::F_out(a);
   const bool is_helper = wave >= FT_FIRST_HELPER;
-  const bool is_mfma = wave < t.n_ct;
 
   // ---- LDS image ----
   char* base = reinterpret_cast<char*>(smem);
   float* lds_bias = smem;                                   // [bias (x scale + shift)][scale]: one copy for the workgroup
   const bool post = a.post_scale != nullptr;
   float* lds_scale = lds_bias + a.bias_lds_floats;
-  int* lds_rec = reinterpret_cast<int*>(base + t.off_rec);  // [2][8]: n0, n1, e0, e1 of the current / next tile
+  int* lds_rec = reinterpret_cast<int*>(base + t.off_rec);  // [3][8]: (n0, n1, e0, e1, valid) of tiles it, it + 1, it + 2; [24]: row counter
+  int* lds_rowctr = lds_rec + 24;
   char* lds_planes = base + t.off_planes;                   // [2 buffers][2 planes][16 rows][128 fp16], 16-byte pieces swizzled
   float* lds_rowinv = reinterpret_cast<float*>(base + t.off_rowinv);   // [2][16]
-  f4* lds_bases4 = reinterpret_cast<f4*>(base + t.off_bases);
-  float* lds_wt = reinterpret_cast<float*>(base + t.off_wt);
-  unsigned short* lds_col = reinterpret_cast<unsigned short*>(base + t.off_col);
-  int* lds_rowptr = reinterpret_cast<int*>(base + t.off_rowptr);
-  int* lds_cnt = reinterpret_cast<int*>(base + t.off_cnt);
-  int* lds_ns = reinterpret_cast<int*>(base + t.off_ns);
-  float* lds_dis_raw = reinterpret_cast<float*>(base + t.off_dis_raw);
-  float* lds_dis_looped = reinterpret_cast<float*>(base + t.off_dis_looped);
   auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
   for (int o = tid; o < C::H(a) * C::Ls(a); o += FT_THREADS) {
@@ -205,15 +202,208 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
     lds_bias[o] = bv;
   }
 
-  // ---- this wavefront's 16-column tile of the packed weights: its column's inverse scale and bias, and where its column
-  //      goes in the LDS image.  The tile itself (both planes of 128 x 16 as B operands: lane -> column 16 wave + lane % 16,
-  //      k = 32 s + 8 (lane / 16) ..+7) is fetched again for every tile of graphs, from L2: kept across the rows phase its 32
-  //      registers push that phase's working set out of the register file (measured at compile time: 129 spilled VGPRs) ----
-  // ONE register array serves both roles (the allocator cannot overlay two arrays whose live ranges only differ by the
-  // wavefront's role): wavefronts 0-11 hold their weight tile in it during the GEMM phase -- u[2 s + p] = k-step s, plane p --
-  // wavefronts 12-15 the x chunks in flight -- u[2 d + i] = piece i of the chunk in register set d
-  static_assert(FT_DEPTH == 4, "the x prefetch shares the 8 x 16-byte registers of a weight tile");
-  f4 u[8];
+#ifdef EGC_FT_STAMPS
+  unsigned long long ft_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ft_t0;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ft_t0) :: "memory");
+  const unsigned long long ft_start = ft_t0;
+#endif
+
+  // A tile's record -> (n0, T, e0, Et, rows of x to multiply); every wavefront derives the same values from the same record
+  struct Tile { int n0, T, e0, Et, nch; bool valid, ok; };
+  auto read_tile = [&](int slot) -> Tile {
+    Tile r;
+    r.valid = __builtin_amdgcn_readfirstlane(lds_rec[slot * 8 + 4]) != 0;
+    r.n0 = __builtin_amdgcn_readfirstlane(lds_rec[slot * 8 + 0]);
+    r.T = __builtin_amdgcn_readfirstlane(lds_rec[slot * 8 + 1]) - r.n0;
+    r.e0 = __builtin_amdgcn_readfirstlane(lds_rec[slot * 8 + 2]);
+    r.Et = __builtin_amdgcn_readfirstlane(lds_rec[slot * 8 + 3]) - r.e0;
+    r.ok = r.valid && r.T > 0 && r.T <= t.tcap && r.Et <= t.emax;
+    r.nch = r.ok ? (r.T + FT_CHUNK - 1) / FT_CHUNK : 0;
+    return r;
+  };
+
+  if (is_helper) {
+    // =====================================================================================================================
+    // wavefronts 12-15: the x stream.  A tile's rows sit in registers one whole tile ahead -- chunk c (16 rows) in xr[2 c],
+    // xr[2 c + 1]; the NEXT tile's rows are requested into the same registers as soon as this tile's last chunk has been
+    // split into the LDS planes (they travel during the rows phase of tile it and the CSR build of tile it + 1: a tile of
+    // x per CU in flight, with no LDS staging) -- and wavefront 15 plans two tiles ahead.
+    // The barrier sequence is the workers': 4 + nch + 1 per tile (nch = 0 for a tile that is skipped).
+    // =====================================================================================================================
+    const int ht = tid - FT_FIRST_HELPER * 64;
+    f4 xr[2 * FT_RING];
+    const int Gn = (int)t.n_graphs;          // (host: n_graphs, n_nodes, n_edges < 2^31)
+    const int Nn = a.n_nodes, En = (int)t.n_edges;
+    int cur_g = 0, g_hi = 0;                 // (meaningful in wavefront 15 only; wave-uniform)
+    auto clampi = [](int64_t v, int hi) -> int { return v < 0 ? 0 : (v > hi ? hi : (int)v); };
+    // next tile of this workgroup -> lds_rec[slot] (wavefront 15, all lanes): graphs [cur_g, next_g) with at most tcap nodes.
+    // Everything in 32 bits and wave-uniform values in scalar registers: this code runs with a tile of x in the vector registers.
+    auto plan_tile = [&](int slot) {
+      int n0 = 0, n1 = 0, e0 = 0, e1 = 0, valid = 0;
+      if (cur_g < g_hi) {
+        const int p0 = clampi(t.ptr[cur_g], Nn);
+        const int gi = cur_g + 1 + lane;
+        const int pv = clampi(t.ptr[gi <= g_hi ? gi : g_hi], Nn);
+        const bool ok = gi <= g_hi && pv - p0 <= t.tcap && pv >= p0;
+        const unsigned long long m = __ballot(ok);
+        int n_ok = m == ~0ull ? 64 : __ffsll((long long)~m) - 1;     // graphs that fit (a prefix: ptr is non-decreasing)
+        n_ok = n_ok < 1 ? 1 : n_ok;                                   // a single graph beyond the capacity: reported by the tile
+        // offsets that decrease inside the run: reported (the node ranges of the tiles then no longer partition [0, N))
+        const int pprev = __shfl_up(pv, 1);
+        const bool dec = gi <= g_hi && lane < n_ok && pv < (lane == 0 ? p0 : pprev);
+        if (__ballot(dec) != 0 && lane == 0) ft_error(t, 1);
+        const int next_g = cur_g + n_ok;
+        const int pn = __builtin_amdgcn_readfirstlane(__shfl(pv, n_ok - 1));
+        n0 = p0;
+        n1 = pn < p0 ? p0 : pn;
+        if (t.edge_ptr != nullptr) {
+          const int64_t b0 = t.edge_ptr[cur_g], b1 = t.edge_ptr[next_g];
+          if (b1 < b0 && lane == 0) ft_error(t, 1);
+          e0 = clampi(b0, En);
+          e1 = clampi(b1, En);
+        } else {   // the two ends side by side in the two halves of the wavefront
+          const int r = ft_half_wave_lower_bound(t.dst, En, lane < 32 ? n0 : n1, lane);
+          e0 = __builtin_amdgcn_readfirstlane(__shfl(r, 0));
+          e1 = __builtin_amdgcn_readfirstlane(__shfl(r, 32));
+        }
+        if (cur_g == 0) e0 = 0;
+        if (next_g >= Gn) e1 = En;
+        e1 = e1 < e0 ? e0 : e1;
+        cur_g = next_g;
+        valid = 1;
+      }
+      if (lane == 0) {
+        lds_rec[slot * 8 + 0] = n0; lds_rec[slot * 8 + 1] = n1; lds_rec[slot * 8 + 2] = e0; lds_rec[slot * 8 + 3] = e1;
+        lds_rec[slot * 8 + 4] = valid;
+      }
+    };
+    if (wave == FT_WAVES - 1) {
+      // the workgroup's graphs: [g_lo, g_hi) = those whose first node lies in its share of [0, N)
+      const int64_t nb = gridDim.x, b = blockIdx.x;
+      const int64_t k_lo = b * Nn / nb, k_hi = (b + 1) * Nn / nb;
+      const int r = ft_half_wave_lower_bound(t.ptr, Gn + 1, lane < 32 ? k_lo : k_hi, lane);
+      int lo = __builtin_amdgcn_readfirstlane(__shfl(r, 0)), hi = __builtin_amdgcn_readfirstlane(__shfl(r, 32));
+      if (b == 0) lo = 0;
+      if (b == nb - 1) hi = Gn;
+      lo = lo > Gn ? Gn : lo;
+      hi = hi > Gn ? Gn : hi;
+      cur_g = lo;
+      g_hi = hi < lo ? lo : hi;
+      if (b == 0 && lane == 0 && Gn > 0 && (t.ptr[0] != 0 || t.ptr[Gn] != Nn)) ft_error(t, 1);   // offsets that do not cover [0, N)
+      plan_tile(0);
+      plan_tile(1);
+    }
+    lds_barrier();
+
+    // 16-byte pieces p = ht + 256 i (i = 0, 1) of a 16-row chunk <-> (row p / 32, k 4 (p % 32)).  Per thread: the two byte
+    // offsets inside a chunk (rows beyond the tile fall outside the tile's descriptor and read as 0; the chunk is a SCALAR
+    // offset of the load) and the two destinations inside a plane buffer -- a few registers next to the 80 that carry x.
+    // (Address arithmetic per use, in ten unrolled bodies, is hoisted out of the tile loop by the compiler and spills.)
+    constexpr unsigned XOOB = 0x80000000u;     // out of range for any tile, also with the scalar chunk offset added
+    unsigned xoff[2];
+    int pdst[2], prow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int p = ht + FT_HELPER_THREADS * i;
+      const int row = p >> 5, k4 = (p & 31) * 4;
+      xoff[i] = k4 < t.F_in ? (unsigned)(row * t.F_in + k4) * 4u : XOOB;
+      pdst[i] = row * (FT_KP * 2) + ((((k4 >> 3) ^ row) & 15) << 4) + (k4 & 7) * 2;
+      prow[i] = row;
+    }
+    auto x_load = [&](f4& d0, f4& d1, const __amdgpu_buffer_rsrc_t rs, int c) {
+      const int so = c * FT_CHUNK * t.F_in * 4;
+      d0 = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, xoff[0], so, 0));
+      d1 = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, xoff[1], so, 0));
+    };
+    auto split = [&](const f4 v0, const f4 v1, int buf) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const f4 v = i == 0 ? v0 : v1;
+        unsigned e = ft_row_amax(v) & 0x7f800000u;
+        e = min(max(e, 13u << 23), 253u << 23);
+        const float sc = __uint_as_float(0x7f000000u - e);                  // 2^-e
+        const float sc2k = __uint_as_float(0x7f000000u + (11u << 23) - e);  // 2^(11-e)
+        const ft_h2 h01 = __builtin_convertvector(ft_f2{v.x * sc, v.y * sc}, ft_h2);
+        const ft_h2 h23 = __builtin_convertvector(ft_f2{v.z * sc, v.w * sc}, ft_h2);
+        ft_h2 l01, l23;
+        l01[0] = (_Float16)__builtin_fmaf((float)h01[0], -2048.f, v.x * sc2k);
+        l01[1] = (_Float16)__builtin_fmaf((float)h01[1], -2048.f, v.y * sc2k);
+        l23[0] = (_Float16)__builtin_fmaf((float)h23[0], -2048.f, v.z * sc2k);
+        l23[1] = (_Float16)__builtin_fmaf((float)h23[1], -2048.f, v.w * sc2k);
+        char* dstp = lds_planes + buf * (2 * FT_PLANE_BYTES) + pdst[i];
+        *reinterpret_cast<ft_u2*>(dstp) = ft_u2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
+        *reinterpret_cast<ft_u2*>(dstp + FT_PLANE_BYTES) = ft_u2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
+        lds_rowinv[buf * FT_CHUNK + prow[i]] = __uint_as_float(e);          // 2^e (the 32 lanes of a row write the same word)
+      }
+    };
+    // a tile's rows of x through a descriptor of their own (no 4 GiB limit on x; rows beyond the tile read as 0)
+    auto x_rsrc_of = [&](const Tile& r) {
+      return __builtin_amdgcn_make_buffer_rsrc((void*)(t.x + (int64_t)r.n0 * t.F_in), 0,
+                                               (unsigned)(r.ok ? r.T : 0) * (unsigned)t.F_in * 4u, 0x00020000);
+    };
+    {
+      const Tile first = read_tile(0);
+      const __amdgpu_buffer_rsrc_t rs = x_rsrc_of(first);
+#pragma unroll
+      for (int c = 0; c < FT_RING; ++c)
+        if (c < first.nch) x_load(xr[2 * c], xr[2 * c + 1], rs, c);
+    }
+    for (int it = 0;; ++it) {
+      const Tile cur = read_tile(it % 3);
+      if (!cur.valid) break;
+      const Tile nxt = read_tile((it + 1) % 3);
+      const __amdgpu_buffer_rsrc_t rsn = x_rsrc_of(nxt);
+      if (wave == FT_WAVES - 1) plan_tile((it + 2) % 3);
+      lds_barrier();                                   // (A)
+      lds_barrier();                                   // (B)
+      lds_barrier();                                   // (C)
+      // (the only wait for memory in this loop: the tile's rows were requested a whole tile ago)
+#ifdef EGC_FT_STAMPS
+      if (!(t.dbg & 1))
+#endif
+      if (0 < cur.nch) split(xr[0], xr[1], 0);         // (a tile that is skipped has no chunks: only the barriers remain)
+      lds_barrier();                                   // (D)
+#pragma unroll
+      for (int c = 0; c < FT_RING; ++c) {
+        if (c < cur.nch) {   // workgroup-uniform
+#ifdef EGC_FT_STAMPS
+          if (!(t.dbg & 1))
+#endif
+          if (c + 1 < FT_RING && c + 1 < cur.nch) split(xr[2 * (c + 1)], xr[2 * (c + 1) + 1], (c + 1) & 1);
+          lds_barrier();
+        }
+      }
+      // the next tile's rows, all of them at once: they travel during this tile's rows phase and the next tile's CSR build.
+      // (Requested chunk by chunk inside the loop above, the compiler's conservative vmcnt(0) in front of every split made
+      // each step wait for the request it had just issued.)
+#pragma unroll
+      for (int c = 0; c < FT_RING; ++c)
+        if (c < nxt.nch) x_load(xr[2 * c], xr[2 * c + 1], rsn, c);
+      lds_barrier();                                   // (end of tile)
+    }
+    return;
+  }
+
+  // =======================================================================================================================
+  // wavefronts 0-11: CSR of the tile in LDS, the matrix-core step of every chunk the helpers stage, the rows
+  // =======================================================================================================================
+  const int g = lane >> LPR_LOG2;
+  const int q = lane & (LPR - 1);
+  const int F_out = C::F_out(a);
+  const bool is_mfma = wave < t.n_ct;
+  f4* lds_bases4 = reinterpret_cast<f4*>(base + t.off_bases);
+  float* lds_wt = reinterpret_cast<float*>(base + t.off_wt);
+  unsigned short* lds_col = reinterpret_cast<unsigned short*>(base + t.off_col);
+  int* lds_rowptr = reinterpret_cast<int*>(base + t.off_rowptr);
+  int* lds_cnt = reinterpret_cast<int*>(base + t.off_cnt);
+  int* lds_ns = reinterpret_cast<int*>(base + t.off_ns);
+  float* lds_dis_raw = reinterpret_cast<float*>(base + t.off_dis_raw);
+  float* lds_dis_looped = reinterpret_cast<float*>(base + t.off_dis_looped);
+
+  // this wavefront's 16-column tile of the packed weights: its column's inverse scale and bias, and where its column goes in
+  // the LDS image.  The tile itself (both planes of 128 x 16 as B operands: lane -> column 16 wave + lane % 16, k = 32 s +
+  // 8 (lane / 16) ..+7) is fetched again for every tile of graphs, from L2: kept across the rows phase its 32 registers
+  // push that phase's working set out of the register file.
   float col_inv = 0.f, col_bias = 0.f;
   int dst_off = -1, dst_stride = 0;        // byte offset inside a row of the image area / bytes between its rows
   bool dst_act = false;
@@ -233,10 +423,6 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       dst_act = true;
     }
   }
-
-  // ---- the workgroup's graphs: [g_lo, g_hi) = those whose first node lies in its share of [0, N) ----
-  const int64_t Gn = t.n_graphs;
-  int64_t cur_g = 0, g_hi = 0;             // (meaningful in wavefront 15 only)
   const int ldb4 = a.ldb >> 2;
   FastRsrc R;
   R.bases = bases_rsrc(a);
@@ -247,175 +433,61 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
   const float* lds_dis = C::yl(a) ? lds_dis_looped : lds_dis_raw;
   const bool want_dis = a.dis != nullptr;
   const int max_index = (!C::loops_all(a) && t.max_index != nullptr) ? *t.max_index : 0x7fffffff;
-  constexpr int RPP = FT_WAVES * G;
   const int grp_addr = (g << LPR_LOG2) << 2;
-
-  // next tile of this workgroup -> lds_rec[slot] (wavefront 15, all lanes): graphs [cur_g, next_g) with at most tcap nodes
-  auto plan_tile = [&](int slot) {
-    int n0 = 0, n1 = 0, e0 = 0, e1 = 0;
-    if (cur_g < g_hi) {
-      const int64_t p0 = t.ptr[cur_g];
-      const int64_t gi = cur_g + 1 + lane;
-      const int64_t pv = t.ptr[gi <= g_hi ? gi : g_hi];
-      const bool ok = gi <= g_hi && pv - p0 <= (int64_t)t.tcap && pv >= p0;
-      const unsigned long long m = __ballot(ok);
-      int n_ok = m == ~0ull ? 64 : __ffsll((long long)~m) - 1;     // graphs that fit (a prefix: ptr is non-decreasing)
-      n_ok = n_ok < 1 ? 1 : n_ok;                                   // a single graph beyond the capacity: reported by the tile
-      // offsets that decrease inside the run: reported (the node ranges of the tiles then no longer partition [0, N))
-      const int64_t pprev = __shfl_up(pv, 1);
-      const bool dec = gi <= g_hi && lane < n_ok && pv < (lane == 0 ? p0 : pprev);
-      if (__ballot(dec) != 0 && lane == 0) ft_error(t, 1);
-      const int64_t next_g = cur_g + n_ok;
-      int64_t pn = __shfl(pv, n_ok - 1);
-      int64_t a0 = p0, a1 = pn;
-      a0 = a0 < 0 ? 0 : (a0 > a.n_nodes ? a.n_nodes : a0);
-      a1 = a1 < a0 ? a0 : (a1 > a.n_nodes ? a.n_nodes : a1);
-      int64_t b0, b1;
-      if (t.edge_ptr != nullptr) {
-        b0 = t.edge_ptr[cur_g];
-        b1 = t.edge_ptr[next_g];
-        if (b1 < b0 && lane == 0) ft_error(t, 1);
-      } else {   // the two ends side by side in the two halves of the wavefront
-        const int64_t r = ft_half_wave_lower_bound(t.dst, t.n_edges, lane < 32 ? a0 : a1, lane);
-        b0 = __shfl(r, 0);
-        b1 = __shfl(r, 32);
-      }
-      if (cur_g == 0) b0 = 0;
-      if (next_g >= Gn) b1 = t.n_edges;
-      b0 = b0 < 0 ? 0 : (b0 > t.n_edges ? t.n_edges : b0);
-      b1 = b1 < b0 ? b0 : (b1 > t.n_edges ? t.n_edges : b1);
-      n0 = (int)a0; n1 = (int)a1; e0 = (int)b0; e1 = (int)b1;
-      cur_g = next_g;
-      if (lane == 0) { lds_rec[slot * 8 + 4] = 1; }
-    } else if (lane == 0) {
-      lds_rec[slot * 8 + 4] = 0;           // no further tile
-    }
-    if (lane == 0) {
-      lds_rec[slot * 8 + 0] = n0; lds_rec[slot * 8 + 1] = n1; lds_rec[slot * 8 + 2] = e0; lds_rec[slot * 8 + 3] = e1;
-    }
-  };
-
-  if (wave == FT_WAVES - 1) {
-    const int64_t N = a.n_nodes;
-    const int64_t nb = gridDim.x, b = blockIdx.x;
-    const int64_t k_lo = b * N / nb, k_hi = (b + 1) * N / nb;
-    const int64_t r = ft_half_wave_lower_bound(t.ptr, Gn + 1, lane < 32 ? k_lo : k_hi, lane);
-    int64_t lo = __shfl(r, 0), hi = __shfl(r, 32);
-    if (b == 0) lo = 0;
-    if (b == nb - 1) hi = Gn;
-    lo = lo > Gn ? Gn : lo;
-    hi = hi > Gn ? Gn : hi;
-    cur_g = lo;
-    g_hi = hi < lo ? lo : hi;
-    if (b == 0 && lane == 0 && Gn > 0 && (t.ptr[0] != 0 || t.ptr[Gn] != N)) ft_error(t, 1);   // offsets that do not cover [0, N)
-    plan_tile(0);
-  }
-  lds_barrier();
+  lds_barrier();       // bias strips, the first two tile records
 
   // ---- edges of a tile: FT_EDGE_REGS per thread, local ids packed 16:16, -1 = absent / outside the tile (reported) ----
   int epk[FT_EDGE_REGS];
   bool bad = false;
   int edges_of = -1;
-  auto request_edges = [&](int rn0, int rn1, int re0, int re1, int which) {
-    const int tT = rn1 - rn0, tE = re1 - re0;
+  auto request_edges = [&](const Tile& r, int which) {
     bad = false;
     edges_of = which;
 #pragma unroll
     for (int j = 0; j < FT_EDGE_REGS; ++j) epk[j] = -1;
-    if (tT <= 0 || tT > t.tcap || tE > FT_THREADS * FT_EDGE_REGS) return;
+    if (!r.ok || r.Et > FT_WORKER_THREADS * FT_EDGE_REGS) return;
 #pragma unroll
     for (int j = 0; j < FT_EDGE_REGS; ++j) {
-      const int i = tid + j * FT_THREADS;
-      if (i < tE) {
-        const int64_t s = t.src[(int64_t)re0 + i] - rn0, d = t.dst[(int64_t)re0 + i] - rn0;
-        if (s < 0 || s >= tT || d < 0 || d >= tT) bad = true;
+      const int i = tid + j * FT_WORKER_THREADS;
+      if (i < r.Et) {
+        const int64_t s = t.src[(int64_t)r.e0 + i] - r.n0, d = t.dst[(int64_t)r.e0 + i] - r.n0;
+        if (s < 0 || s >= r.T || d < 0 || d >= r.T) bad = true;
         else epk[j] = (int)((s << 16) | d);
       }
     }
   };
 
-  // helper wavefronts: 16-byte pieces p = ht + 256 i (i = 0, 1) of a 16-row chunk <-> (row p / 32, k 4 (p % 32))
-  const int ht = tid - FT_FIRST_HELPER * 64;
-
   for (int it = 0;; ++it) {
-    const int slot = it & 1;
-    if (__builtin_amdgcn_readfirstlane(lds_rec[slot * 8 + 4]) == 0) break;
-    const int n0 = __builtin_amdgcn_readfirstlane(lds_rec[slot * 8 + 0]);
-    const int T = __builtin_amdgcn_readfirstlane(lds_rec[slot * 8 + 1]) - n0;
-    const int e0 = __builtin_amdgcn_readfirstlane(lds_rec[slot * 8 + 2]);
-    const int Et = __builtin_amdgcn_readfirstlane(lds_rec[slot * 8 + 3]) - e0;
-    const bool tile_ok = T > 0 && T <= t.tcap && Et <= t.emax;
-    if (!tile_ok && (T > 0 || Et > 0) && tid == 0) ft_error(t, T <= 0 ? 1 : 2);
-    const bool in_regs = Et <= FT_THREADS * FT_EDGE_REGS;
-    const int nch = tile_ok ? (T + FT_CHUNK - 1) / FT_CHUNK : 0;
-    // the tile's rows of x through a descriptor of their own (no 4 GiB limit on x; rows beyond the tile read as 0)
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(t.x + (int64_t)n0 * t.F_in), 0, (unsigned)(tile_ok ? T : 0) * (unsigned)t.F_in * 4u, 0x00020000);
-    // (`hv`: the helper thread's index through an opaque copy per use -- otherwise every unrolled body's address arithmetic
-    // is hoisted out of the tile loop and lives in registers across the rows phase: 129 spilled VGPRs)
-    auto x_load = [&](f4& d0, f4& d1, int c, int hv) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int p = hv + FT_HELPER_THREADS * i;
-        const int row = FT_CHUNK * c + (p >> 5), k4 = (p & 31) * 4;
-        const bool ok = row < T && k4 < t.F_in;
-        (i == 0 ? d0 : d1) = load_slot(xrs, ok ? (unsigned)(row * t.F_in + k4) * 4u : OOB);
-      }
-    };
-    auto split = [&](const f4 v0, const f4 v1, int buf, int hv) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const f4 v = i == 0 ? v0 : v1;
-        const int p = hv + FT_HELPER_THREADS * i;
-        const int row = p >> 5, k4 = (p & 31) * 4;
-        unsigned e = ft_row_amax(v) & 0x7f800000u;
-        e = min(max(e, 13u << 23), 253u << 23);
-        const float sc = __uint_as_float(0x7f000000u - e);                  // 2^-e
-        const float sc2k = __uint_as_float(0x7f000000u + (11u << 23) - e);  // 2^(11-e)
-        const ft_h2 h01 = __builtin_convertvector(ft_f2{v.x * sc, v.y * sc}, ft_h2);
-        const ft_h2 h23 = __builtin_convertvector(ft_f2{v.z * sc, v.w * sc}, ft_h2);
-        ft_h2 l01, l23;
-        l01[0] = (_Float16)__builtin_fmaf((float)h01[0], -2048.f, v.x * sc2k);
-        l01[1] = (_Float16)__builtin_fmaf((float)h01[1], -2048.f, v.y * sc2k);
-        l23[0] = (_Float16)__builtin_fmaf((float)h23[0], -2048.f, v.z * sc2k);
-        l23[1] = (_Float16)__builtin_fmaf((float)h23[1], -2048.f, v.w * sc2k);
-        char* dstp = lds_planes + buf * (2 * FT_PLANE_BYTES) + row * (FT_KP * 2) + ((((k4 >> 3) ^ row) & 15) << 4) + (k4 & 7) * 2;
-        *reinterpret_cast<ft_u2*>(dstp) = ft_u2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
-        *reinterpret_cast<ft_u2*>(dstp + FT_PLANE_BYTES) = ft_u2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
-        lds_rowinv[buf * FT_CHUNK + row] = __uint_as_float(e);              // 2^e (the 32 lanes of a row write the same word)
-      }
-    };
+    const Tile cur = read_tile(it % 3);
+    if (!cur.valid) break;
+    const Tile nxt = read_tile((it + 1) % 3);
+    const int n0 = cur.n0, T = cur.T, e0 = cur.e0, Et = cur.Et, nch = cur.nch;
+    if (!cur.ok && (T > 0 || Et > 0) && tid == 0) ft_error(t, T <= 0 ? 1 : 2);
+    const bool in_regs = Et <= FT_WORKER_THREADS * FT_EDGE_REGS;
 
-    // ---- (A) requests: edges (unless they came during the previous tile's rows), the first x chunks; counters zeroed;
-    //      wavefront 15 plans the next tile ----
-    if (in_regs && edges_of != it) request_edges(n0, n0 + T, e0, e0 + Et, it);
-    if (is_mfma && tile_ok) {
+    // ---- (A) requests: the edges (unless they came during the previous tile), this wavefront's weight tile; counters zeroed ----
+    if (cur.ok && in_regs && edges_of != it) request_edges(cur, it);
+    f4 u[8];     // u[2 s + p] = k-step s, plane p of the weight tile
+    if (is_mfma && cur.ok) {
       int lv = lane;
       asm volatile("" : "+v"(lv));
       const f4* wsrc = reinterpret_cast<const f4*>(t.packed) + (int64_t)wave * 8 * 64;   // wave-uniform base + lane
 #pragma unroll
       for (int s = 0; s < 8; ++s) u[s] = wsrc[s * 64 + lv];
-    } else if (!is_helper) {
+    } else {
 #pragma unroll
       for (int s = 0; s < 8; ++s) u[s] = f4{0.f, 0.f, 0.f, 0.f};
     }
-    if (is_helper && tile_ok) {
-      int hv = ht;
-      asm volatile("" : "+v"(hv));
-#pragma unroll
-      for (int d = 0; d < FT_DEPTH; ++d)
-        if (d < nch) x_load(u[2 * d], u[2 * d + 1], d, hv);
-    }
-    if (tile_ok)
-      for (int i = tid; i < T; i += FT_THREADS) { lds_cnt[i] = 0; lds_ns[i] = 0; }
-    if (wave == FT_WAVES - 1) plan_tile(slot ^ 1);
+    if (cur.ok)
+      for (int i = tid; i < T; i += FT_WORKER_THREADS) { lds_cnt[i] = 0; lds_ns[i] = 0; }
+    if (tid == 0) *lds_rowctr = 0;
     lds_barrier();
-    const int nn0 = __builtin_amdgcn_readfirstlane(lds_rec[(slot ^ 1) * 8 + 0]);
-    const int nn1 = __builtin_amdgcn_readfirstlane(lds_rec[(slot ^ 1) * 8 + 1]);
-    const int ne0 = __builtin_amdgcn_readfirstlane(lds_rec[(slot ^ 1) * 8 + 2]);
-    const int ne1 = __builtin_amdgcn_readfirstlane(lds_rec[(slot ^ 1) * 8 + 3]);
-    const bool has_next = __builtin_amdgcn_readfirstlane(lds_rec[(slot ^ 1) * 8 + 4]) != 0;
-    if (!tile_ok) { lds_barrier(); continue; }   // (the barrier: nobody rewrites this record slot before all have read it)
+    if (!cur.ok) {   // reported above; the helpers' barrier sequence of a tile without chunks
+      lds_barrier(); lds_barrier(); lds_barrier(); lds_barrier();
+      if (nxt.valid) request_edges(nxt, it + 1);
+      continue;
+    }
+    FT_STAMP(0)
 
     // ---- (B) in-degrees ----
     if (in_regs) {
@@ -429,7 +501,7 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
     } else {
       bad = false;
 #pragma unroll 4
-      for (int i = tid; i < Et; i += FT_THREADS) {
+      for (int i = tid; i < Et; i += FT_WORKER_THREADS) {
         const int64_t s = t.src[(int64_t)e0 + i] - n0, d = t.dst[(int64_t)e0 + i] - n0;
         if (s < 0 || s >= T || d < 0 || d >= T) { bad = true; continue; }
         atomicAdd(&lds_cnt[(int)d], 1);
@@ -438,8 +510,9 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
     }
     if (__ballot(bad) != 0 && lane == 0) ft_error(t, 1);
     lds_barrier();
+    FT_STAMP(1)
 
-    // ---- (C) exclusive scan -> rowptr, deg^-1/2 tables (wavefront 0) ----
+    // ---- (C) exclusive scan of the in-degrees -> rowptr (wavefront 0); the deg^-1/2 tables by everybody else ----
     if (wave == 0) {
       const int per = (T + 63) >> 6;
       const int b0 = lane * per;
@@ -455,98 +528,95 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       for (int j = 0; j < per; ++j) {
         const int i = b0 + j;
         if (i < T) {
-          const int c = lds_cnt[i];
           lds_rowptr[i] = run;
-          lds_dis_raw[i] = c > 0 ? 1.0f / sqrtf((float)c) : 0.0f;
-          lds_dis_looped[i] = 1.0f / sqrtf((float)(lds_ns[i] + 1));
-          lds_cnt[i] = 0;
-          run += c;
+          run += lds_cnt[i];
         }
       }
       if (lane == 63) lds_rowptr[T] = incl;
+    } else {
+      for (int i = tid - 64; i < T; i += FT_WORKER_THREADS - 64) {
+        const int c = lds_cnt[i];
+        lds_dis_raw[i] = c > 0 ? 1.0f / sqrtf((float)c) : 0.0f;          // as prepare_kernel / build_scan_kernel
+        lds_dis_looped[i] = 1.0f / sqrtf((float)(lds_ns[i] + 1));
+      }
     }
     lds_barrier();
+    FT_STAMP(2)
 
-    // ---- (D) scatter; the helpers stage chunk 0 ----
+    // ---- (D) scatter (the cursor of row d counts DOWN from its in-degree: lds_cnt is not zeroed in between) ----
     if (in_regs) {
 #pragma unroll
       for (int j = 0; j < FT_EDGE_REGS; ++j)
         if (epk[j] >= 0) {
           const int s = epk[j] >> 16, d = epk[j] & 0xffff;
-          lds_col[lds_rowptr[d] + atomicAdd(&lds_cnt[d], 1)] = (unsigned short)s;
+          lds_col[lds_rowptr[d] + atomicSub(&lds_cnt[d], 1) - 1] = (unsigned short)s;
         }
     } else {
 #pragma unroll 4
-      for (int i = tid; i < Et; i += FT_THREADS) {
+      for (int i = tid; i < Et; i += FT_WORKER_THREADS) {
         const int64_t s = t.src[(int64_t)e0 + i] - n0, d = t.dst[(int64_t)e0 + i] - n0;
         if (s < 0 || s >= T || d < 0 || d >= T) continue;
-        lds_col[lds_rowptr[(int)d] + atomicAdd(&lds_cnt[(int)d], 1)] = (unsigned short)s;
+        lds_col[lds_rowptr[(int)d] + atomicSub(&lds_cnt[(int)d], 1) - 1] = (unsigned short)s;
       }
-    }
-    if (is_helper) {
-      int hv = ht;
-      asm volatile("" : "+v"(hv));
-      split(u[0], u[1], 0, hv);
-      if (FT_DEPTH < nch) x_load(u[0], u[1], FT_DEPTH, hv);
     }
     lds_barrier();
+    FT_STAMP(3)
     // the next tile's edges travel during this tile's GEMM and rows
-    if (has_next) request_edges(nn0, nn1, ne0, ne1, it + 1);
+    if (nxt.valid) request_edges(nxt, it + 1);
 
     // ---- (G) [bases | weightings] of the tile, 16 rows per step ----
-    for (int c0 = 0; c0 < nch; c0 += FT_DEPTH) {
+    for (int c = 0; c < nch; ++c) {
+      const int buf = c & 1;
+#ifdef EGC_FT_STAMPS
+      if (!(t.dbg & 2))
+#endif
+      if (is_mfma) {
+        int lv = lane;
+        asm volatile("" : "+v"(lv));
+        const int m = lv & 15, qd = lv >> 4;
+        const char* pa = lds_planes + buf * (2 * FT_PLANE_BYTES) + m * (FT_KP * 2);
+        f4 acc0 = f4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0;
 #pragma unroll
-      for (int d = 0; d < FT_DEPTH; ++d) {
-        const int c = c0 + d;
-        if (c < nch) {   // workgroup-uniform
-          const int buf = c & 1;
-          if (is_helper) {
-            if (c + 1 < nch) {      // chunk c + 1 sits in register set (c + 1) % FT_DEPTH = (d + 1) % FT_DEPTH
-              int hv = ht;
-              asm volatile("" : "+v"(hv));
-              split(u[2 * ((d + 1) % FT_DEPTH)], u[2 * ((d + 1) % FT_DEPTH) + 1], buf ^ 1, hv);
-              if (c + 1 + FT_DEPTH < nch) x_load(u[2 * ((d + 1) % FT_DEPTH)], u[2 * ((d + 1) % FT_DEPTH) + 1], c + 1 + FT_DEPTH, hv);
-            }
-          } else if (is_mfma) {
-            int lv = lane;
-            asm volatile("" : "+v"(lv));
-            const int m = lv & 15, qd = lv >> 4;
-            const char* pa = lds_planes + buf * (2 * FT_PLANE_BYTES) + m * (FT_KP * 2);
-            f4 acc0 = f4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-              const int piece = (((4 * s + qd) ^ m) & 15) << 4;
-              const ft_h8 xh = *reinterpret_cast<const ft_h8*>(pa + piece);
-              const ft_h8 xl = *reinterpret_cast<const ft_h8*>(pa + FT_PLANE_BYTES + piece);
-              const ft_h8 wh = __builtin_bit_cast(ft_h8, u[2 * s]), wl = __builtin_bit_cast(ft_h8, u[2 * s + 1]);
-              acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wh, acc0, 0, 0, 0);
-              acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, wh, acc1, 0, 0, 0);
-              acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wl, acc2, 0, 0, 0);
-            }
-            // D: lane -> column lane % 16, rows 4 (lane / 16) + i.  2^ex 2^ew (acc0 + 2^-11 (acc1 + acc2)) + bias
-            const f4 ri = *reinterpret_cast<const f4*>(lds_rowinv + buf * FT_CHUNK + 4 * qd);
-            f4 o;
-            o.x = __builtin_fmaf(__builtin_fmaf(acc1.x + acc2.x, 1.f / 2048.f, acc0.x), col_inv * ri.x, col_bias);
-            o.y = __builtin_fmaf(__builtin_fmaf(acc1.y + acc2.y, 1.f / 2048.f, acc0.y), col_inv * ri.y, col_bias);
-            o.z = __builtin_fmaf(__builtin_fmaf(acc1.z + acc2.z, 1.f / 2048.f, acc0.z), col_inv * ri.z, col_bias);
-            o.w = __builtin_fmaf(__builtin_fmaf(acc1.w + acc2.w, 1.f / 2048.f, acc0.w), col_inv * ri.w, col_bias);
-            if (dst_act) o = w_act<C>(a, o);
-            if (dst_off >= 0) {
-              char* po = base + dst_off + (FT_CHUNK * c + 4 * qd) * dst_stride;
-              *reinterpret_cast<float*>(po) = o.x;
-              *reinterpret_cast<float*>(po + dst_stride) = o.y;
-              *reinterpret_cast<float*>(po + 2 * dst_stride) = o.z;
-              *reinterpret_cast<float*>(po + 3 * dst_stride) = o.w;
-            }
-          }
-          lds_barrier();
+        for (int s = 0; s < 4; ++s) {
+          const int piece = (((4 * s + qd) ^ m) & 15) << 4;
+          const ft_h8 xh = *reinterpret_cast<const ft_h8*>(pa + piece);
+          const ft_h8 xl = *reinterpret_cast<const ft_h8*>(pa + FT_PLANE_BYTES + piece);
+          const ft_h8 wh = __builtin_bit_cast(ft_h8, u[2 * s]), wl = __builtin_bit_cast(ft_h8, u[2 * s + 1]);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wh, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, wh, acc1, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wl, acc2, 0, 0, 0);
+        }
+        // D: lane -> column lane % 16, rows 4 (lane / 16) + i.  2^ex 2^ew (acc0 + 2^-11 (acc1 + acc2)) + bias
+        const f4 ri = *reinterpret_cast<const f4*>(lds_rowinv + buf * FT_CHUNK + 4 * qd);
+        f4 o;
+        o.x = __builtin_fmaf(__builtin_fmaf(acc1.x + acc2.x, 1.f / 2048.f, acc0.x), col_inv * ri.x, col_bias);
+        o.y = __builtin_fmaf(__builtin_fmaf(acc1.y + acc2.y, 1.f / 2048.f, acc0.y), col_inv * ri.y, col_bias);
+        o.z = __builtin_fmaf(__builtin_fmaf(acc1.z + acc2.z, 1.f / 2048.f, acc0.z), col_inv * ri.z, col_bias);
+        o.w = __builtin_fmaf(__builtin_fmaf(acc1.w + acc2.w, 1.f / 2048.f, acc0.w), col_inv * ri.w, col_bias);
+        if (dst_act) o = w_act<C>(a, o);
+        if (dst_off >= 0) {
+          char* po = base + dst_off + (FT_CHUNK * c + 4 * qd) * dst_stride;
+          *reinterpret_cast<float*>(po) = o.x;
+          *reinterpret_cast<float*>(po + dst_stride) = o.y;
+          *reinterpret_cast<float*>(po + 2 * dst_stride) = o.z;
+          *reinterpret_cast<float*>(po + 3 * dst_stride) = o.w;
         }
       }
+      lds_barrier();
     }
+    FT_STAMP(4)
 
-    // ---- (E) rows: one lane group per row, G rows per wavefront and pass, everything from LDS ----
-    for (int r0 = 0; r0 < T; r0 += RPP) {
-      const int r = r0 + wave * G + g;
+    // ---- (E) rows: one lane group per row, G rows per wavefront and turn (turns handed out by an LDS counter: a wavefront
+    //      whose rows are short takes the next ones), everything from LDS ----
+#ifdef EGC_FT_STAMPS
+    if (!(t.dbg & 4))
+#endif
+    for (;;) {
+      int r0 = 0;
+      if (lane == 0) r0 = atomicAdd(lds_rowctr, G);
+      r0 = __builtin_amdgcn_readfirstlane(r0);
+      if (r0 >= T) break;
+      const int r = r0 + g;
       const bool row_ok = r < T;
       const int row = n0 + (row_ok ? r : 0);
       const int start = row_ok ? lds_rowptr[r] : 0;
@@ -579,17 +649,17 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
           float w[FU];
           bool in_x[FU];
 #pragma unroll
-          for (int u = 0; u < FU; ++u) {
-            const int addr = grp_addr + ((t0 + u) << 2);
+          for (int uu = 0; uu < FU; ++uu) {
+            const int addr = grp_addr + ((t0 + uu) << 2);
             const int j = bperm(addr, jj);
             const bool is_self = j == r;
-            in_x[u] = (ts + t0 + u < n_valid) && !(C::xl(a) && is_self);
-            v[u] = in_x[u] ? lds_bases4[j * ldb4 + q] : f4{0.f, 0.f, 0.f, 0.f};
-            w[u] = bperm(addr, dd) * dis_i;
-            if (C::yl(a) && !C::xl(a)) w[u] = is_self ? 0.f : w[u];
+            in_x[uu] = (ts + t0 + uu < n_valid) && !(C::xl(a) && is_self);
+            v[uu] = in_x[uu] ? lds_bases4[j * ldb4 + q] : f4{0.f, 0.f, 0.f, 0.f};
+            w[uu] = bperm(addr, dd) * dis_i;
+            if (C::yl(a) && !C::xl(a)) w[uu] = is_self ? 0.f : w[uu];
           }
 #pragma unroll
-          for (int u = 0; u < FU; ++u) fold<NEED>(acc, v[u], w[u], in_x[u], start + ts + t0 + u);
+          for (int uu = 0; uu < FU; ++uu) fold<NEED>(acc, v[uu], w[uu], in_x[uu], start + ts + t0 + uu);
         }
       }
       int ln = lane;
@@ -599,8 +669,18 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       finish_group<LPR_LOG2, HPB, NEED, C, true>(a, R, ln, row, row_ok, acc, nd, nself, dis_i, vself, has_self, wdummy, true,
                                                  lds_wt + (row_ok ? r : 0) * t.wl_floats, lds_bias, lds_scale);
     }
+    FT_STAMP(5)
     lds_barrier();   // every wavefront is done with the tile's LDS image
+    FT_STAMP(6)
   }
+#ifdef EGC_FT_STAMPS
+  if (tid == 0 && egc_ft_stamp_buf != nullptr) {
+    unsigned long long tend;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tend) :: "memory");
+    ft_acc[7] = tend - ft_start;
+    for (int k = 0; k < 8; ++k) egc_ft_stamp_buf[blockIdx.x * 8 + k] = ft_acc[k];
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -618,7 +698,7 @@ static FtLds ft_lds(const AggArgs& a, int wl_floats, int tcap, int emax, bool wi
   auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
   const int bias_floats = (a.H * a.Ls + 3) & ~3;
   size_t at = up16((size_t)(with_post ? 2 : 1) * bias_floats * sizeof(float));
-  L.off_rec = (int)at; at += 64;
+  L.off_rec = (int)at; at += 128;
   L.off_planes = (int)at; at += FT_PLANES_BYTES;
   L.off_rowinv = (int)at; at += up16(2 * FT_CHUNK * sizeof(float));
   L.off_bases = (int)at; at += up16((size_t)tcap * a.ldb * 4);
@@ -642,7 +722,7 @@ int fused_tile_capacity(const AggArgs& a, int f_in, int max_tile_edges, bool wit
   if (!fused_tile_shape(a, f_in) || max_tile_edges < 0) return 0;
   const int wl = a.H * a.B * 4;
   int best = 0;
-  for (int tcap = FT_CHUNK; tcap <= FT_MAX_NODES; tcap += FT_CHUNK) {
+  for (int tcap = FT_CHUNK; tcap <= FT_CHUNK * FT_RING; tcap += FT_CHUNK) {
     if (ft_lds(a, wl, tcap, max_tile_edges, with_post).total <= FT_LDS_BUDGET) best = tcap; else break;
   }
   return best;
@@ -657,8 +737,34 @@ static int launch_ft_one(const AggArgs& a, const FusedTileArgs& t, unsigned grid
     if (e != hipSuccess) { set_last_error("hipFuncSetAttribute(fused_tile_kernel)", e); return EGC_ERR_HIP; }
     attr_set = true;
   }
+#ifdef EGC_FT_STAMPS
+  static unsigned long long* dbuf = nullptr;
+  if (dbuf == nullptr) {
+    hipMalloc(&dbuf, 256 * 8 * 8);
+    hipMemcpyToSymbol(HIP_SYMBOL(egc_ft_stamp_buf), &dbuf, sizeof(dbuf));
+  }
+  hipMemset(dbuf, 0, 256 * 8 * 8);
+#endif
   fused_tile_kernel<LPR_LOG2, HPB, NEED, C><<<grid, FT_THREADS, lds, stream>>>(a, t);
   EGC_LAUNCH_CHECK("fused_tile_kernel");
+#ifdef EGC_FT_STAMPS
+  {
+    hipDeviceSynchronize();
+    static int calls = 0;
+    if ((++calls % 40) == 0) {
+      unsigned long long h[256 * 8];
+      hipMemcpy(h, dbuf, sizeof(h), hipMemcpyDeviceToHost);
+      double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tmax = 0;
+      for (unsigned b = 0; b < grid; ++b) {
+        for (int k = 0; k < 8; ++k) sum[k] += (double)h[b * 8 + k];
+        tmax = std::max(tmax, (double)h[b * 8 + 7]);
+      }
+      fprintf(stderr, "[ft stamps] grid %u, n_nodes %d: per workgroup (shader cycles): requests %.0f  degrees %.0f  scan %.0f  "
+              "scatter+split0 %.0f  GEMM %.0f  rows %.0f  end barrier %.0f | total avg %.0f max %.0f\n", grid, a.n_nodes,
+              sum[0] / grid, sum[1] / grid, sum[2] / grid, sum[3] / grid, sum[4] / grid, sum[5] / grid, sum[6] / grid, sum[7] / grid, tmax);
+    }
+  }
+#endif
   return EGC_OK;
 }
 
@@ -706,7 +812,10 @@ int launch_fused_tile(AggArgs a, const int64_t* ptr, const int64_t* edge_ptr, in
   t.n_ct = (a.ldb + a.W + 15) / 16;
   t.tcap = tcap; t.emax = emax;
   t.wl_floats = a.H * a.B * 4;
-  if (tcap < FT_CHUNK || tcap > FT_MAX_NODES || (tcap % FT_CHUNK) != 0 || emax < 0) return EGC_ERR_INVALID;
+#ifdef EGC_FT_STAMPS
+  if (const char* e = getenv("EGC_FT_DBG")) t.dbg = atoi(e);
+#endif
+  if (tcap < FT_CHUNK || tcap > FT_CHUNK * FT_RING || (tcap % FT_CHUNK) != 0 || emax < 0) return EGC_ERR_INVALID;
   const FtLds L = ft_lds(a, t.wl_floats, tcap, emax, a.post_scale != nullptr);
   if (L.total > FT_LDS_BUDGET) return EGC_ERR_UNSUPPORTED;
   t.off_rec = L.off_rec; t.off_planes = L.off_planes; t.off_rowinv = L.off_rowinv; t.off_bases = L.off_bases; t.off_wt = L.off_wt;
