@@ -353,7 +353,6 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       if (!cur.valid) break;
       const Tile nxt = read_tile((it + 1) % 3);
       const __amdgpu_buffer_rsrc_t rsn = x_rsrc_of(nxt);
-      if (wave == FT_WAVES - 1) plan_tile((it + 2) % 3);
       lds_barrier();                                   // (A)
       lds_barrier();                                   // (B)
       lds_barrier();                                   // (C)
@@ -373,6 +372,10 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
           lds_barrier();
         }
       }
+      // the tile after the next, while the workers are in their rows phase (its dependent loads -- graph offsets, then edge
+      // offsets or the search -- take two to five memory round trips: in front of barrier (A) they were 15 % of the kernel).
+      // The record's slot was last read during tile it - 1.
+      if (wave == FT_WAVES - 1) plan_tile((it + 2) % 3);
       // the next tile's rows, all of them at once: they travel during this tile's rows phase and the next tile's CSR build.
       // (Requested chunk by chunk inside the loop above, the compiler's conservative vmcnt(0) in front of every split made
       // each step wait for the request it had just issued.)
@@ -436,24 +439,30 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
   const int grp_addr = (g << LPR_LOG2) << 2;
   lds_barrier();       // bias strips, the first two tile records
 
-  // ---- edges of a tile: FT_EDGE_REGS per thread, local ids packed 16:16, -1 = absent / outside the tile (reported) ----
+  // ---- edges of a tile: FT_EDGE_REGS per thread.  REQUESTED one tile ahead as raw 64-bit ids (loads only: nothing here
+  //      may consume them, or the wavefront waits out the memory latency on the spot -- the first form of this function
+  //      compared each id as it came and serialised eight round trips in front of the GEMM loop), turned into local ids
+  //      packed 16:16 and range-checked in phase (B) of their own tile (-1 = absent / outside the tile: reported).
+  //      Unconditional loads through descriptors of the tile's own edge range -- entries beyond it read as 0 without memory
+  //      traffic, a tile that is skipped or streams its edges gets an empty range: no branch, so no register copy of a
+  //      value that is still in flight ----
+  long long raw_s[FT_EDGE_REGS], raw_d[FT_EDGE_REGS];
   int epk[FT_EDGE_REGS];
   bool bad = false;
   int edges_of = -1;
-  auto request_edges = [&](const Tile& r, int which) {
-    bad = false;
-    edges_of = which;
 #pragma unroll
-    for (int j = 0; j < FT_EDGE_REGS; ++j) epk[j] = -1;
-    if (!r.ok || r.Et > FT_WORKER_THREADS * FT_EDGE_REGS) return;
+  for (int j = 0; j < FT_EDGE_REGS; ++j) raw_s[j] = raw_d[j] = -1;
+  auto request_edges = [&](const Tile& r, int which) {
+    edges_of = which;
+    const bool use = r.ok && r.Et <= FT_WORKER_THREADS * FT_EDGE_REGS;
+    const unsigned bytes = use ? (unsigned)r.Et * 8u : 0u;
+    const __amdgpu_buffer_rsrc_t es = __builtin_amdgcn_make_buffer_rsrc((void*)(t.src + r.e0), 0, bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ed = __builtin_amdgcn_make_buffer_rsrc((void*)(t.dst + r.e0), 0, bytes, 0x00020000);
 #pragma unroll
     for (int j = 0; j < FT_EDGE_REGS; ++j) {
-      const int i = tid + j * FT_WORKER_THREADS;
-      if (i < r.Et) {
-        const int64_t s = t.src[(int64_t)r.e0 + i] - r.n0, d = t.dst[(int64_t)r.e0 + i] - r.n0;
-        if (s < 0 || s >= r.T || d < 0 || d >= r.T) bad = true;
-        else epk[j] = (int)((s << 16) | d);
-      }
+      const unsigned off = (unsigned)(tid + j * FT_WORKER_THREADS) * 8u;
+      raw_s[j] = __builtin_bit_cast(long long, __builtin_amdgcn_raw_buffer_load_b64(es, off, 0, 0));
+      raw_d[j] = __builtin_bit_cast(long long, __builtin_amdgcn_raw_buffer_load_b64(ed, off, 0, 0));
     }
   };
 
@@ -491,13 +500,20 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
 
     // ---- (B) in-degrees ----
     if (in_regs) {
+      bad = false;
 #pragma unroll
-      for (int j = 0; j < FT_EDGE_REGS; ++j)
-        if (epk[j] >= 0) {
-          const int s = epk[j] >> 16, d = epk[j] & 0xffff;
-          atomicAdd(&lds_cnt[d], 1);
-          if (s != d) atomicAdd(&lds_ns[d], 1);
+      for (int j = 0; j < FT_EDGE_REGS; ++j) {
+        epk[j] = -1;
+        if (tid + j * FT_WORKER_THREADS < Et) {
+          const long long s = raw_s[j] - n0, d = raw_d[j] - n0;
+          if (s < 0 || s >= T || d < 0 || d >= T) bad = true;
+          else {
+            epk[j] = (int)((s << 16) | d);
+            atomicAdd(&lds_cnt[(int)d], 1);
+            if (s != d) atomicAdd(&lds_ns[(int)d], 1);
+          }
         }
+      }
     } else {
       bad = false;
 #pragma unroll 4
@@ -561,6 +577,9 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
     }
     lds_barrier();
     FT_STAMP(3)
+    // the weight tile has landed HERE as far as the compiler is concerned: otherwise it waits for it (vmcnt(0)) inside the
+    // GEMM loop, which then also waits for the next tile's edges requested just below
+    asm volatile("" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]), "+v"(u[6]), "+v"(u[7]));
     // the next tile's edges travel during this tile's GEMM and rows
     if (nxt.valid) request_edges(nxt, it + 1);
 
@@ -613,7 +632,9 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
 #endif
     for (;;) {
       int r0 = 0;
-      if (lane == 0) r0 = atomicAdd(lds_rowctr, G);
+      // (workgroup scope, relaxed: the plain atomicAdd drains the vector-memory counter first, i.e. waits for the `out`
+      // stores of the wavefront's previous turn)
+      if (lane == 0) r0 = __hip_atomic_fetch_add(lds_rowctr, G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       r0 = __builtin_amdgcn_readfirstlane(r0);
       if (r0 >= T) break;
       const int r = r0 + g;
