@@ -59,7 +59,7 @@ constexpr int FT_PLANES_BYTES = 2 * 2 * FT_PLANE_BYTES;  // [2 buffers][2 planes
 
 #ifdef EGC_FT_STAMPS
 __device__ unsigned long long* egc_ft_stamp_buf = nullptr;   // diagnostic build only: [grid][8] accumulated cycles per phase
-#define FT_STAMP(k) { if (tid == 0) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); ft_acc[k] += _t - ft_t0; ft_t0 = _t; } }
+#define FT_STAMP(k) { if (tid == 0) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); ft_acc[k] += _t - ft_t0; if (blockIdx.x == 7 && it < 12 && egc_ft_stamp_buf != nullptr) egc_ft_stamp_buf[256 * 9 + it * 8 + k] = _t - ft_t0; ft_t0 = _t; } }
 #else
 #define FT_STAMP(k)
 #endif
@@ -150,6 +150,30 @@ __device__ inline int ft_half_wave_lower_bound(const int64_t* __restrict__ arr, 
   const unsigned m = (unsigned)(__ballot(ge) >> sh);
   const int f = __ffs((int)m) - 1;
   return f < 0 ? hi : (lo + f < hi ? lo + f : hi);
+}
+
+// The same lower bound with ONE round of loads when the array is close to linear (graph offsets of a batch of similar
+// graphs, the destination row of their edges): each half looks at the 64 entries around guess = key n / top first and
+// falls back to the full search when the answer is not strictly inside that window.  Same result as the full search on
+// sorted input, a deterministic function of (arr, key) on any input (two workgroups that share a key get the same index).
+__device__ inline int ft_guess_lower_bound(const int64_t* __restrict__ arr, int n, int64_t key, int64_t top, int lane) {
+  const int l32 = lane & 31, sh = lane & 32;
+  int64_t g64 = top > 0 ? key * (int64_t)n / top : 0;
+  int w0 = (int)(g64 < 31 ? 0 : g64 - 31);
+  w0 = w0 > n - 64 ? n - 64 : w0;
+  w0 = w0 < 0 ? 0 : w0;
+  const int i0 = w0 + l32, i1 = w0 + 32 + l32;
+  const int64_t v0 = i0 < n ? arr[i0] : key, v1 = i1 < n ? arr[i1] : key;     // beyond the array: counts as >= key
+  const unsigned m0 = (unsigned)(__ballot(v0 >= key) >> sh), m1 = (unsigned)(__ballot(v1 >= key) >> sh);
+  const int first = m0 != 0 ? __ffs((int)m0) - 1 : (m1 != 0 ? 32 + __ffs((int)m1) - 1 : 64);
+  int r = w0 + first;
+  r = r > n ? n : r;
+  const bool sure = (first > 0 || w0 == 0) && (first < 64 || w0 + 64 >= n);
+  if (__ballot(!sure) != 0) {       // (both halves take part in the full search; each keeps its window result if it was sure)
+    const int full = ft_half_wave_lower_bound(arr, n, key, lane);
+    r = sure ? r : full;
+  }
+  return r;
 }
 
 __device__ inline void ft_error(const FusedTileArgs& t, int code) {
@@ -281,7 +305,7 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       // the workgroup's graphs: [g_lo, g_hi) = those whose first node lies in its share of [0, N)
       const int64_t nb = gridDim.x, b = blockIdx.x;
       const int64_t k_lo = b * Nn / nb, k_hi = (b + 1) * Nn / nb;
-      const int r = ft_half_wave_lower_bound(t.ptr, Gn + 1, lane < 32 ? k_lo : k_hi, lane);
+      const int r = ft_guess_lower_bound(t.ptr, Gn + 1, lane < 32 ? k_lo : k_hi, Nn, lane);
       int lo = __builtin_amdgcn_readfirstlane(__shfl(r, 0)), hi = __builtin_amdgcn_readfirstlane(__shfl(r, 32));
       if (b == 0) lo = 0;
       if (b == nb - 1) hi = Gn;
@@ -290,8 +314,58 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       cur_g = lo;
       g_hi = hi < lo ? lo : hi;
       if (b == 0 && lane == 0 && Gn > 0 && (t.ptr[0] != 0 || t.ptr[Gn] != Nn)) ft_error(t, 1);   // offsets that do not cover [0, N)
-      plan_tile(0);
-      plan_tile(1);
+      // The first TWO tiles from one window of 64 graph offsets and one round of edge offsets (plan_tile twice is four
+      // dependent rounds in front of the first barrier: with the search above, 10,000 cycles of a 65,000-cycle launch).
+      bool both = false;
+      if (cur_g < g_hi) {
+        const int p0 = clampi(t.ptr[cur_g], Nn);
+        const int gi = cur_g + 1 + lane;
+        const int pv = clampi(t.ptr[gi <= g_hi ? gi : g_hi], Nn);
+        const bool ok0 = gi <= g_hi && pv - p0 <= t.tcap && pv >= p0;
+        const unsigned long long m0 = __ballot(ok0);
+        const int n0k = m0 == ~0ull ? 64 : __ffsll((long long)~m0) - 1;
+        if (n0k >= 1 && n0k < 63) {
+          const int p1 = __builtin_amdgcn_readfirstlane(__shfl(pv, n0k - 1));
+          const bool ok1 = lane >= n0k && gi <= g_hi && pv - p1 <= t.tcap && pv >= p1;
+          const unsigned long long m1 = __ballot(ok1) >> n0k;
+          const int n1k = m1 == 0 ? 0 : (__ffsll((long long)~m1) - 1);
+          const int g1 = cur_g + n0k, g2 = g1 + n1k;
+          const bool mono = !(gi <= g_hi && lane < n0k + n1k && pv < (lane == 0 ? p0 : __shfl_up(pv, 1)));
+          // (a second tile that would hold no graph although graphs remain, or a window that ends inside it: the general path)
+          if ((n1k >= 1 || g1 >= g_hi) && n0k + n1k < 64 && __ballot(!mono) == 0) {
+            const int p2 = n1k >= 1 ? __builtin_amdgcn_readfirstlane(__shfl(pv, n0k + n1k - 1)) : p1;
+            int e0, e1, e2;
+            if (t.edge_ptr != nullptr) {
+              const int gsel = lane == 0 ? cur_g : (lane == 1 ? g1 : g2);
+              const int64_t ev = lane < 3 ? t.edge_ptr[gsel] : 0;
+              const int64_t b0 = __shfl(ev, 0), b1 = __shfl(ev, 1), b2 = __shfl(ev, 2);
+              if ((b1 < b0 || b2 < b1) && lane == 0) ft_error(t, 1);
+              e0 = clampi(b0, En); e1 = clampi(b1, En); e2 = clampi(b2, En);
+            } else {
+              const int ra = ft_guess_lower_bound(t.dst, En, lane < 32 ? p0 : p1, Nn, lane);
+              e0 = __builtin_amdgcn_readfirstlane(__shfl(ra, 0));
+              e1 = __builtin_amdgcn_readfirstlane(__shfl(ra, 32));
+              const int rb = ft_guess_lower_bound(t.dst, En, p2, Nn, lane);
+              e2 = __builtin_amdgcn_readfirstlane(__shfl(rb, 0));
+            }
+            if (cur_g == 0) e0 = 0;
+            if (g1 >= Gn) e1 = En;
+            if (g2 >= Gn) e2 = En;
+            e1 = e1 < e0 ? e0 : e1;
+            e2 = e2 < e1 ? e1 : e2;
+            if (lane == 0) {
+              lds_rec[0] = p0; lds_rec[1] = p1; lds_rec[2] = e0; lds_rec[3] = e1; lds_rec[4] = 1;
+              lds_rec[8] = p1; lds_rec[9] = p2; lds_rec[10] = e1; lds_rec[11] = e2; lds_rec[12] = n1k >= 1 ? 1 : 0;
+            }
+            cur_g = g2;
+            both = true;
+          }
+        }
+      }
+      if (!both) {
+        plan_tile(0);
+        plan_tile(1);
+      }
     }
     lds_barrier();
 
@@ -438,6 +512,10 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
   const int max_index = (!C::loops_all(a) && t.max_index != nullptr) ? *t.max_index : 0x7fffffff;
   const int grp_addr = (g << LPR_LOG2) << 2;
   lds_barrier();       // bias strips, the first two tile records
+#ifdef EGC_FT_STAMPS
+  unsigned long long ft_pro = 0;
+  if (tid == 0) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); ft_pro = _t - ft_t0; ft_t0 = _t; }
+#endif
 
   // ---- edges of a tile: FT_EDGE_REGS per thread.  REQUESTED one tile ahead as raw 64-bit ids (loads only: nothing here
   //      may consume them, or the wavefront waits out the memory latency on the spot -- the first form of this function
@@ -490,6 +568,9 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
     if (cur.ok)
       for (int i = tid; i < T; i += FT_WORKER_THREADS) { lds_cnt[i] = 0; lds_ns[i] = 0; }
     if (tid == 0) *lds_rowctr = 0;
+#ifdef EGC_FT_STAMPS
+    if (tid == 0) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); if (blockIdx.x == 7 && it < 12 && egc_ft_stamp_buf != nullptr) egc_ft_stamp_buf[256 * 9 + it * 8 + 7] = _t - ft_t0; }
+#endif
     lds_barrier();
     if (!cur.ok) {   // reported above; the helpers' barrier sequence of a tile without chunks
       lds_barrier(); lds_barrier(); lds_barrier(); lds_barrier();
@@ -534,12 +615,15 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       const int b0 = lane * per;
       int mine = 0;
       for (int j = 0; j < per; ++j) mine += (b0 + j < T) ? lds_cnt[b0 + j] : 0;
+      // inclusive scan over the wavefront on the DPP network (row shifts inside the rows of 16, then the two row
+      // broadcasts): six vector instructions instead of six round trips through the LDS crossbar
       int incl = mine;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const int v = __shfl_up(incl, off);
-        if (lane >= off) incl += v;
-      }
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);   // row_shr:1
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);   // row_shr:2
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);   // row_shr:4
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);   // row_shr:8
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, true);   // row_bcast:15 -> rows 1 and 3
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, true);   // row_bcast:31 -> rows 2 and 3
       int run = incl - mine;
       for (int j = 0; j < per; ++j) {
         const int i = b0 + j;
@@ -700,6 +784,7 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tend) :: "memory");
     ft_acc[7] = tend - ft_start;
     for (int k = 0; k < 8; ++k) egc_ft_stamp_buf[blockIdx.x * 8 + k] = ft_acc[k];
+    egc_ft_stamp_buf[256 * 8 + blockIdx.x] = ft_pro;
   }
 #endif
 }
@@ -761,10 +846,10 @@ static int launch_ft_one(const AggArgs& a, const FusedTileArgs& t, unsigned grid
 #ifdef EGC_FT_STAMPS
   static unsigned long long* dbuf = nullptr;
   if (dbuf == nullptr) {
-    hipMalloc(&dbuf, 256 * 8 * 8);
+    hipMalloc(&dbuf, (256 * 9 + 96) * 8);
     hipMemcpyToSymbol(HIP_SYMBOL(egc_ft_stamp_buf), &dbuf, sizeof(dbuf));
   }
-  hipMemset(dbuf, 0, 256 * 8 * 8);
+  hipMemset(dbuf, 0, (256 * 9 + 96) * 8);
 #endif
   fused_tile_kernel<LPR_LOG2, HPB, NEED, C><<<grid, FT_THREADS, lds, stream>>>(a, t);
   EGC_LAUNCH_CHECK("fused_tile_kernel");
@@ -773,13 +858,19 @@ static int launch_ft_one(const AggArgs& a, const FusedTileArgs& t, unsigned grid
     hipDeviceSynchronize();
     static int calls = 0;
     if ((++calls % 40) == 0) {
-      unsigned long long h[256 * 8];
+      unsigned long long h[256 * 9 + 96];
       hipMemcpy(h, dbuf, sizeof(h), hipMemcpyDeviceToHost);
       double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tmax = 0;
       for (unsigned b = 0; b < grid; ++b) {
         for (int k = 0; k < 8; ++k) sum[k] += (double)h[b * 8 + k];
         tmax = std::max(tmax, (double)h[b * 8 + 7]);
       }
+      for (int i = 0; i < 10; ++i)
+        fprintf(stderr, "[ft tile %d of block 7] requests %llu (before the barrier %llu) degrees %llu scan %llu scatter %llu GEMM %llu rows %llu end %llu\n", i, h[256 * 9 + i * 8], h[256 * 9 + i * 8 + 7],
+                h[256 * 9 + i * 8 + 1], h[256 * 9 + i * 8 + 2], h[256 * 9 + i * 8 + 3], h[256 * 9 + i * 8 + 4], h[256 * 9 + i * 8 + 5], h[256 * 9 + i * 8 + 6]);
+      double pro = 0;
+      for (unsigned b = 0; b < grid; ++b) pro += (double)h[256 * 8 + b];
+      fprintf(stderr, "[ft stamps] prologue %.0f; ", pro / grid);
       fprintf(stderr, "[ft stamps] grid %u, n_nodes %d: per workgroup (shader cycles): requests %.0f  degrees %.0f  scan %.0f  "
               "scatter+split0 %.0f  GEMM %.0f  rows %.0f  end barrier %.0f | total avg %.0f max %.0f\n", grid, a.n_nodes,
               sum[0] / grid, sum[1] / grid, sum[2] / grid, sum[3] / grid, sum[4] / grid, sum[5] / grid, sum[6] / grid, sum[7] / grid, tmax);
