@@ -51,6 +51,7 @@ constexpr int FT_KP = 128;              // k extent of the register-resident wei
 constexpr int FT_CHUNK = 16;            // rows per GEMM step (one MFMA tile)
 constexpr int FT_WORKER_THREADS = FT_FIRST_HELPER * 64;
 constexpr int FT_EDGE_REGS = 4;         // edges per worker thread kept in registers (16:16 packed local ids)
+constexpr int FT_CSR_WAVES = 3;         // helper wavefronts 12-14 build the tiles' CSR (15 plans the tiles)
 constexpr int FT_RING = 10;             // 16-row chunks of x a tile may have: the helpers hold them all in registers (80 VGPRs)
 constexpr int FT_MAX_NODES = 2048;      // local ids are 16-bit, the scan is one wavefront
 constexpr int FT_NV = FT_MFMA_WAVES * 16;
@@ -81,7 +82,9 @@ struct FusedTileArgs {
   int tcap, emax;            // LDS image: rows of bases / weightings, entries of the CSR
   int wl_floats;             // floats per weightings row in LDS: H * B * 4
   int dbg;                   // diagnostic build (EGC_FT_STAMPS) only: bit 0 no split, bit 1 no MFMA, bit 2 no rows
-  int off_rec, off_planes, off_rowinv, off_bases, off_wt, off_col, off_rowptr, off_cnt, off_ns, off_dis_raw, off_dis_looped;
+  int off_rec, off_planes, off_rowinv, off_bases, off_wt;
+  int off_col, off_rowptr, off_cnt, off_dis;   // the CSR areas of an even tile; csr_stride bytes further: those of an odd tile
+  int csr_stride;
 };
 
 // packed[column tile][k-step of 32][plane][lane][8]: lane 16 (k % 32 / 8) + column % 16 holds k = 32 s + 8 (lane / 16) ..+7 of
@@ -252,9 +255,10 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
     // xr[2 c + 1]; the NEXT tile's rows are requested into the same registers as soon as this tile's last chunk has been
     // split into the LDS planes (they travel during the rows phase of tile it and the CSR build of tile it + 1: a tile of
     // x per CU in flight, with no LDS staging) -- and wavefront 15 plans two tiles ahead.
-    // The barrier sequence is the workers': 4 + nch + 1 per tile (nch = 0 for a tile that is skipped).
+    // The barrier sequence is the workers': 1 + nch + 1 per tile (nch = 0 for a tile that is skipped).
     // =====================================================================================================================
     const int ht = tid - FT_FIRST_HELPER * 64;
+    if (ht == 0) lds_rec[25] = 0;            // the CSR builders' synchronisation counter (first used behind the barrier below)
     f4 xr[2 * FT_RING];
     const int Gn = (int)t.n_graphs;          // (host: n_graphs, n_nodes, n_edges < 2^31)
     const int Nn = a.n_nodes, En = (int)t.n_edges;
@@ -415,27 +419,132 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       return __builtin_amdgcn_make_buffer_rsrc((void*)(t.x + (int64_t)r.n0 * t.F_in), 0,
                                                (unsigned)(r.ok ? r.T : 0) * (unsigned)t.F_in * 4u, 0x00020000);
     };
+    // ---- the CSR of a tile, by wavefronts 12-14 (15 plans tiles meanwhile), synchronised among themselves through an LDS
+    //      counter (the workgroup barrier belongs to the workers' schedule): in-degrees (in-degree | non-self in-degree << 16,
+    //      one LDS atomic per edge) | wavefront scan -> rowptr and the layer's deg^-1/2 table (wavefront 12) | scatter through
+    //      the counts counted back down -- which leaves them zero for the next tile that uses this set.  The edges are
+    //      streamed from memory twice (second pass: L2), four per lane in flight; every edge is checked against its tile.
+    //      Built into set (tile & 1) while the workers read the other set in their rows phase. ----
+    int* lds_hsync = lds_rec + 25;
+    int hs_target = 0;
+    auto csr_sync = [&]() {
+      hs_target += FT_CSR_WAVES;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_fetch_add(lds_hsync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      int spins = 0;
+      while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(lds_hsync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < hs_target) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1 << 22)) { if (lane == 0) ft_error(t, 4); break; }     // (a bounded spin cannot hang the GPU)
+      }
+      asm volatile("" ::: "memory");
+    };
+    auto build_csr = [&](const Tile& r, int set) {      // wavefronts 12-14, all of them, for every tile (also a skipped one)
+      char* cb = base + set * t.csr_stride;
+      unsigned short* col = reinterpret_cast<unsigned short*>(cb + t.off_col);
+      int* rowptr = reinterpret_cast<int*>(cb + t.off_rowptr);
+      int* cnt = reinterpret_cast<int*>(cb + t.off_cnt);
+      float* dis = reinterpret_cast<float*>(cb + t.off_dis);
+      const int T = r.ok ? r.T : 0, Et = r.ok ? r.Et : 0;
+      const unsigned ebytes = (unsigned)Et * 8u;
+      const __amdgpu_buffer_rsrc_t es = __builtin_amdgcn_make_buffer_rsrc((void*)(t.src + r.e0), 0, ebytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t ed = __builtin_amdgcn_make_buffer_rsrc((void*)(t.dst + r.e0), 0, ebytes, 0x00020000);
+      constexpr int CT = FT_CSR_WAVES * 64;
+      bool bad = false;
+      for (int i0 = 0; i0 < Et; i0 += 4 * CT) {
+        long long sv[4], dv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {       // (entries beyond the tile's range read as 0 and are skipped below)
+          const unsigned off = (unsigned)(i0 + j * CT + ht) * 8u;
+          sv[j] = __builtin_bit_cast(long long, __builtin_amdgcn_raw_buffer_load_b64(es, off, 0, 0));
+          dv[j] = __builtin_bit_cast(long long, __builtin_amdgcn_raw_buffer_load_b64(ed, off, 0, 0));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (i0 + j * CT + ht < Et) {
+            const long long sl = sv[j] - r.n0, dl = dv[j] - r.n0;
+            if (sl < 0 || sl >= T || dl < 0 || dl >= T) bad = true;
+            else atomicAdd(&cnt[(int)dl], sl != dl ? 0x10001 : 1);
+          }
+        }
+      }
+      if (__ballot(bad) != 0 && lane == 0) ft_error(t, 1);
+      csr_sync();
+      if (wave == FT_FIRST_HELPER) {
+        const int per = (T + 63) >> 6;
+        const int b0 = lane * per;
+        int mine = 0;
+        for (int j = 0; j < per; ++j) mine += (b0 + j < T) ? (cnt[b0 + j] & 0xffff) : 0;
+        // inclusive scan over the wavefront on the DPP network (row shifts inside the rows of 16, then the two row broadcasts)
+        int incl = mine;
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);   // row_shr:1
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);   // row_shr:2
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);   // row_shr:4
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);   // row_shr:8
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, true);   // row_bcast:15 -> rows 1 and 3
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, true);   // row_bcast:31 -> rows 2 and 3
+        int run = incl - mine;
+        for (int j = 0; j < per; ++j) {
+          const int i = b0 + j;
+          if (i < T) {
+            const int cv = cnt[i];
+            const int c = cv & 0xffff, ns = cv >> 16;
+            rowptr[i] = run;
+            run += c;
+            cnt[i] = c;                                                          // the scatter's cursor
+            // deg^-1/2 of the layer's symnorm edge set, as prepare_kernel / build_scan_kernel (egc_graph.hip)
+            dis[i] = C::yl(a) ? 1.0f / sqrtf((float)(ns + 1)) : (c > 0 ? 1.0f / sqrtf((float)c) : 0.0f);
+          }
+        }
+        if (lane == 63) rowptr[T] = incl;
+      }
+      csr_sync();
+      for (int i0 = 0; i0 < Et; i0 += 4 * CT) {
+        long long sv[4], dv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const unsigned off = (unsigned)(i0 + j * CT + ht) * 8u;
+          sv[j] = __builtin_bit_cast(long long, __builtin_amdgcn_raw_buffer_load_b64(es, off, 0, 0));
+          dv[j] = __builtin_bit_cast(long long, __builtin_amdgcn_raw_buffer_load_b64(ed, off, 0, 0));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (i0 + j * CT + ht < Et) {
+            const long long sl = sv[j] - r.n0, dl = dv[j] - r.n0;
+            if (!(sl < 0 || sl >= T || dl < 0 || dl >= T))
+              col[rowptr[(int)dl] + atomicSub(&cnt[(int)dl], 1) - 1] = (unsigned short)sl;
+          }
+        }
+      }
+    };
+    // both sets of counts start at zero (afterwards every build leaves its set zero)
+    if (wave < FT_FIRST_HELPER + FT_CSR_WAVES) {
+      for (int i = ht; i < t.tcap; i += FT_CSR_WAVES * 64) {
+        reinterpret_cast<int*>(base + t.off_cnt)[i] = 0;
+        reinterpret_cast<int*>(base + t.csr_stride + t.off_cnt)[i] = 0;
+      }
+      csr_sync();
+    }
+
+    const Tile first = read_tile(0);
     {
-      const Tile first = read_tile(0);
       const __amdgpu_buffer_rsrc_t rs = x_rsrc_of(first);
 #pragma unroll
       for (int c = 0; c < FT_RING; ++c)
         if (c < first.nch) x_load(xr[2 * c], xr[2 * c + 1], rs, c);
     }
+    // the first tile's CSR while its rows travel (every later one is built during the rows phase of the tile before)
+    if (wave < FT_FIRST_HELPER + FT_CSR_WAVES) build_csr(first, 0);
     for (int it = 0;; ++it) {
       const Tile cur = read_tile(it % 3);
       if (!cur.valid) break;
       const Tile nxt = read_tile((it + 1) % 3);
       const __amdgpu_buffer_rsrc_t rsn = x_rsrc_of(nxt);
-      lds_barrier();                                   // (A)
-      lds_barrier();                                   // (B)
-      lds_barrier();                                   // (C)
-      // (the only wait for memory in this loop: the tile's rows were requested a whole tile ago)
+      // (the only wait for memory in the GEMM phase: the tile's rows were requested a whole tile ago)
 #ifdef EGC_FT_STAMPS
       if (!(t.dbg & 1))
 #endif
       if (0 < cur.nch) split(xr[0], xr[1], 0);         // (a tile that is skipped has no chunks: only the barriers remain)
-      lds_barrier();                                   // (D)
+      lds_barrier();                                   // (chunk 0 staged; the CSR of this tile complete)
 #pragma unroll
       for (int c = 0; c < FT_RING; ++c) {
         if (c < cur.nch) {   // workgroup-uniform
@@ -447,15 +556,17 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
         }
       }
       // the tile after the next, while the workers are in their rows phase (its dependent loads -- graph offsets, then edge
-      // offsets or the search -- take two to five memory round trips: in front of barrier (A) they were 15 % of the kernel).
+      // offsets or the search -- take two to five memory round trips: in front of a barrier they were 15 % of the kernel).
       // The record's slot was last read during tile it - 1.
       if (wave == FT_WAVES - 1) plan_tile((it + 2) % 3);
-      // the next tile's rows, all of them at once: they travel during this tile's rows phase and the next tile's CSR build.
+      // the next tile's rows, all of them at once: they travel during this tile's rows phase and the next tile's first steps.
       // (Requested chunk by chunk inside the loop above, the compiler's conservative vmcnt(0) in front of every split made
       // each step wait for the request it had just issued.)
 #pragma unroll
       for (int c = 0; c < FT_RING; ++c)
         if (c < nxt.nch) x_load(xr[2 * c], xr[2 * c + 1], rsn, c);
+      // and its CSR, into the other set of areas
+      if (wave < FT_FIRST_HELPER + FT_CSR_WAVES) build_csr(nxt, (it + 1) & 1);
       lds_barrier();                                   // (end of tile)
     }
     return;
@@ -470,12 +581,6 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
   const bool is_mfma = wave < t.n_ct;
   f4* lds_bases4 = reinterpret_cast<f4*>(base + t.off_bases);
   float* lds_wt = reinterpret_cast<float*>(base + t.off_wt);
-  unsigned short* lds_col = reinterpret_cast<unsigned short*>(base + t.off_col);
-  int* lds_rowptr = reinterpret_cast<int*>(base + t.off_rowptr);
-  int* lds_cnt = reinterpret_cast<int*>(base + t.off_cnt);
-  int* lds_ns = reinterpret_cast<int*>(base + t.off_ns);
-  float* lds_dis_raw = reinterpret_cast<float*>(base + t.off_dis_raw);
-  float* lds_dis_looped = reinterpret_cast<float*>(base + t.off_dis_looped);
 
   // this wavefront's 16-column tile of the packed weights: its column's inverse scale and bias, and where its column goes in
   // the LDS image.  The tile itself (both planes of 128 x 16 as B operands: lane -> column 16 wave + lane % 16, k = 32 s +
@@ -507,7 +612,6 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
   R.res = __builtin_amdgcn_make_buffer_rsrc((void*)(a.residual != nullptr ? a.residual : a.out), 0,
                                             (unsigned)a.n_nodes * (unsigned)F_out * 4u, 0x00020000);
   const bool looped_any = C::xl(a) || C::yl(a);
-  const float* lds_dis = C::yl(a) ? lds_dis_looped : lds_dis_raw;
   const bool want_dis = a.dis != nullptr;
   const int max_index = (!C::loops_all(a) && t.max_index != nullptr) ? *t.max_index : 0x7fffffff;
   const int grp_addr = (g << LPR_LOG2) << 2;
@@ -517,43 +621,18 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
   if (tid == 0) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); ft_pro = _t - ft_t0; ft_t0 = _t; }
 #endif
 
-  // ---- edges of a tile: FT_EDGE_REGS per thread.  REQUESTED one tile ahead as raw 64-bit ids (loads only: nothing here
-  //      may consume them, or the wavefront waits out the memory latency on the spot -- the first form of this function
-  //      compared each id as it came and serialised eight round trips in front of the GEMM loop), turned into local ids
-  //      packed 16:16 and range-checked in phase (B) of their own tile (-1 = absent / outside the tile: reported).
-  //      Unconditional loads through descriptors of the tile's own edge range -- entries beyond it read as 0 without memory
-  //      traffic, a tile that is skipped or streams its edges gets an empty range: no branch, so no register copy of a
-  //      value that is still in flight ----
-  long long raw_s[FT_EDGE_REGS], raw_d[FT_EDGE_REGS];
-  int epk[FT_EDGE_REGS];
-  bool bad = false;
-  int edges_of = -1;
-#pragma unroll
-  for (int j = 0; j < FT_EDGE_REGS; ++j) raw_s[j] = raw_d[j] = -1;
-  auto request_edges = [&](const Tile& r, int which) {
-    edges_of = which;
-    const bool use = r.ok && r.Et <= FT_WORKER_THREADS * FT_EDGE_REGS;
-    const unsigned bytes = use ? (unsigned)r.Et * 8u : 0u;
-    const __amdgpu_buffer_rsrc_t es = __builtin_amdgcn_make_buffer_rsrc((void*)(t.src + r.e0), 0, bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ed = __builtin_amdgcn_make_buffer_rsrc((void*)(t.dst + r.e0), 0, bytes, 0x00020000);
-#pragma unroll
-    for (int j = 0; j < FT_EDGE_REGS; ++j) {
-      const unsigned off = (unsigned)(tid + j * FT_WORKER_THREADS) * 8u;
-      raw_s[j] = __builtin_bit_cast(long long, __builtin_amdgcn_raw_buffer_load_b64(es, off, 0, 0));
-      raw_d[j] = __builtin_bit_cast(long long, __builtin_amdgcn_raw_buffer_load_b64(ed, off, 0, 0));
-    }
-  };
-
   for (int it = 0;; ++it) {
     const Tile cur = read_tile(it % 3);
     if (!cur.valid) break;
-    const Tile nxt = read_tile((it + 1) % 3);
-    const int n0 = cur.n0, T = cur.T, e0 = cur.e0, Et = cur.Et, nch = cur.nch;
-    if (!cur.ok && (T > 0 || Et > 0) && tid == 0) ft_error(t, T <= 0 ? 1 : 2);
-    const bool in_regs = Et <= FT_WORKER_THREADS * FT_EDGE_REGS;
+    const int n0 = cur.n0, T = cur.T, nch = cur.nch;
+    if (!cur.ok && (T > 0 || cur.Et > 0) && tid == 0) ft_error(t, T <= 0 ? 1 : 2);
+    // this tile's CSR (built by wavefront 14 during the previous tile's rows phase)
+    char* cb = base + (it & 1) * t.csr_stride;
+    const unsigned short* lds_col = reinterpret_cast<const unsigned short*>(cb + t.off_col);
+    const int* lds_rowptr = reinterpret_cast<const int*>(cb + t.off_rowptr);
+    const float* lds_dis = reinterpret_cast<const float*>(cb + t.off_dis);
 
-    // ---- (A) requests: the edges (unless they came during the previous tile), this wavefront's weight tile; counters zeroed ----
-    if (cur.ok && in_regs && edges_of != it) request_edges(cur, it);
+    // ---- this wavefront's weight tile (L2); the row counter ----
     f4 u[8];     // u[2 s + p] = k-step s, plane p of the weight tile
     if (is_mfma && cur.ok) {
       int lv = lane;
@@ -565,107 +644,11 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
 #pragma unroll
       for (int s = 0; s < 8; ++s) u[s] = f4{0.f, 0.f, 0.f, 0.f};
     }
-    if (cur.ok)
-      for (int i = tid; i < T; i += FT_WORKER_THREADS) { lds_cnt[i] = 0; lds_ns[i] = 0; }
     if (tid == 0) *lds_rowctr = 0;
-#ifdef EGC_FT_STAMPS
-    if (tid == 0) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); if (blockIdx.x == 7 && it < 12 && egc_ft_stamp_buf != nullptr) egc_ft_stamp_buf[256 * 9 + it * 8 + 7] = _t - ft_t0; }
-#endif
-    lds_barrier();
-    if (!cur.ok) {   // reported above; the helpers' barrier sequence of a tile without chunks
-      lds_barrier(); lds_barrier(); lds_barrier(); lds_barrier();
-      if (nxt.valid) request_edges(nxt, it + 1);
-      continue;
-    }
-    FT_STAMP(0)
-
-    // ---- (B) in-degrees ----
-    if (in_regs) {
-      bad = false;
-#pragma unroll
-      for (int j = 0; j < FT_EDGE_REGS; ++j) {
-        epk[j] = -1;
-        if (tid + j * FT_WORKER_THREADS < Et) {
-          const long long s = raw_s[j] - n0, d = raw_d[j] - n0;
-          if (s < 0 || s >= T || d < 0 || d >= T) bad = true;
-          else {
-            epk[j] = (int)((s << 16) | d);
-            atomicAdd(&lds_cnt[(int)d], 1);
-            if (s != d) atomicAdd(&lds_ns[(int)d], 1);
-          }
-        }
-      }
-    } else {
-      bad = false;
-#pragma unroll 4
-      for (int i = tid; i < Et; i += FT_WORKER_THREADS) {
-        const int64_t s = t.src[(int64_t)e0 + i] - n0, d = t.dst[(int64_t)e0 + i] - n0;
-        if (s < 0 || s >= T || d < 0 || d >= T) { bad = true; continue; }
-        atomicAdd(&lds_cnt[(int)d], 1);
-        if (s != d) atomicAdd(&lds_ns[(int)d], 1);
-      }
-    }
-    if (__ballot(bad) != 0 && lane == 0) ft_error(t, 1);
-    lds_barrier();
-    FT_STAMP(1)
-
-    // ---- (C) exclusive scan of the in-degrees -> rowptr (wavefront 0); the deg^-1/2 tables by everybody else ----
-    if (wave == 0) {
-      const int per = (T + 63) >> 6;
-      const int b0 = lane * per;
-      int mine = 0;
-      for (int j = 0; j < per; ++j) mine += (b0 + j < T) ? lds_cnt[b0 + j] : 0;
-      // inclusive scan over the wavefront on the DPP network (row shifts inside the rows of 16, then the two row
-      // broadcasts): six vector instructions instead of six round trips through the LDS crossbar
-      int incl = mine;
-      incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);   // row_shr:1
-      incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);   // row_shr:2
-      incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);   // row_shr:4
-      incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);   // row_shr:8
-      incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, true);   // row_bcast:15 -> rows 1 and 3
-      incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, true);   // row_bcast:31 -> rows 2 and 3
-      int run = incl - mine;
-      for (int j = 0; j < per; ++j) {
-        const int i = b0 + j;
-        if (i < T) {
-          lds_rowptr[i] = run;
-          run += lds_cnt[i];
-        }
-      }
-      if (lane == 63) lds_rowptr[T] = incl;
-    } else {
-      for (int i = tid - 64; i < T; i += FT_WORKER_THREADS - 64) {
-        const int c = lds_cnt[i];
-        lds_dis_raw[i] = c > 0 ? 1.0f / sqrtf((float)c) : 0.0f;          // as prepare_kernel / build_scan_kernel
-        lds_dis_looped[i] = 1.0f / sqrtf((float)(lds_ns[i] + 1));
-      }
-    }
-    lds_barrier();
-    FT_STAMP(2)
-
-    // ---- (D) scatter (the cursor of row d counts DOWN from its in-degree: lds_cnt is not zeroed in between) ----
-    if (in_regs) {
-#pragma unroll
-      for (int j = 0; j < FT_EDGE_REGS; ++j)
-        if (epk[j] >= 0) {
-          const int s = epk[j] >> 16, d = epk[j] & 0xffff;
-          lds_col[lds_rowptr[d] + atomicSub(&lds_cnt[d], 1) - 1] = (unsigned short)s;
-        }
-    } else {
-#pragma unroll 4
-      for (int i = tid; i < Et; i += FT_WORKER_THREADS) {
-        const int64_t s = t.src[(int64_t)e0 + i] - n0, d = t.dst[(int64_t)e0 + i] - n0;
-        if (s < 0 || s >= T || d < 0 || d >= T) continue;
-        lds_col[lds_rowptr[(int)d] + atomicSub(&lds_cnt[(int)d], 1) - 1] = (unsigned short)s;
-      }
-    }
-    lds_barrier();
-    FT_STAMP(3)
-    // the weight tile has landed HERE as far as the compiler is concerned: otherwise it waits for it (vmcnt(0)) inside the
-    // GEMM loop, which then also waits for the next tile's edges requested just below
+    // the weight tile has landed HERE as far as the compiler is concerned (else it waits for it inside the GEMM loop)
     asm volatile("" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]), "+v"(u[6]), "+v"(u[7]));
-    // the next tile's edges travel during this tile's GEMM and rows
-    if (nxt.valid) request_edges(nxt, it + 1);
+    lds_barrier();       // chunk 0 is staged, the tile's CSR complete, the row counter zero
+    FT_STAMP(0)
 
     // ---- (G) [bases | weightings] of the tile, 16 rows per step ----
     for (int c = 0; c < nch; ++c) {
@@ -714,7 +697,7 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
 #ifdef EGC_FT_STAMPS
     if (!(t.dbg & 4))
 #endif
-    for (;;) {
+    for (; cur.ok;) {
       int r0 = 0;
       // (workgroup scope, relaxed: the plain atomicAdd drains the vector-memory counter first, i.e. waits for the `out`
       // stores of the wavefront's previous turn)
@@ -796,7 +779,9 @@ constexpr size_t FT_LDS_BUDGET = 160 * 1024 - 256;
 
 struct FtLds {
   size_t total;
-  int off_rec, off_planes, off_rowinv, off_bases, off_wt, off_col, off_rowptr, off_cnt, off_ns, off_dis_raw, off_dis_looped;
+  int off_rec, off_planes, off_rowinv, off_bases, off_wt;
+  int off_col, off_rowptr, off_cnt, off_dis;   // the CSR areas of an even tile; csr_stride bytes further: those of an odd tile
+  int csr_stride;
 };
 
 static FtLds ft_lds(const AggArgs& a, int wl_floats, int tcap, int emax, bool with_post) {
@@ -809,12 +794,13 @@ static FtLds ft_lds(const AggArgs& a, int wl_floats, int tcap, int emax, bool wi
   L.off_rowinv = (int)at; at += up16(2 * FT_CHUNK * sizeof(float));
   L.off_bases = (int)at; at += up16((size_t)tcap * a.ldb * 4);
   L.off_wt = (int)at; at += up16((size_t)tcap * wl_floats * 4);
+  const size_t csr0 = at;
   L.off_col = (int)at; at += up16((size_t)emax * 2);
   L.off_rowptr = (int)at; at += up16((size_t)(tcap + 1) * 4);
   L.off_cnt = (int)at; at += up16((size_t)tcap * 4);
-  L.off_ns = (int)at; at += up16((size_t)tcap * 4);
-  L.off_dis_raw = (int)at; at += up16((size_t)tcap * 4);
-  L.off_dis_looped = (int)at; at += up16((size_t)tcap * 4);
+  L.off_dis = (int)at; at += up16((size_t)tcap * 4);
+  L.csr_stride = (int)(at - csr0);
+  at += L.csr_stride;       // the second set: tile it + 1's CSR is built while tile it's is being read
   L.total = at;
   return L;
 }
@@ -871,8 +857,8 @@ static int launch_ft_one(const AggArgs& a, const FusedTileArgs& t, unsigned grid
       double pro = 0;
       for (unsigned b = 0; b < grid; ++b) pro += (double)h[256 * 8 + b];
       fprintf(stderr, "[ft stamps] prologue %.0f; ", pro / grid);
-      fprintf(stderr, "[ft stamps] grid %u, n_nodes %d: per workgroup (shader cycles): requests %.0f  degrees %.0f  scan %.0f  "
-              "scatter+split0 %.0f  GEMM %.0f  rows %.0f  end barrier %.0f | total avg %.0f max %.0f\n", grid, a.n_nodes,
+      fprintf(stderr, "[ft stamps] grid %u, n_nodes %d: per workgroup (shader cycles): start %.0f  (-) %.0f  (-) %.0f  "
+              "(-) %.0f  GEMM %.0f  rows %.0f  end barrier %.0f | total avg %.0f max %.0f\n", grid, a.n_nodes,
               sum[0] / grid, sum[1] / grid, sum[2] / grid, sum[3] / grid, sum[4] / grid, sum[5] / grid, sum[6] / grid, sum[7] / grid, tmax);
     }
   }
@@ -931,8 +917,7 @@ int launch_fused_tile(AggArgs a, const int64_t* ptr, const int64_t* edge_ptr, in
   const FtLds L = ft_lds(a, t.wl_floats, tcap, emax, a.post_scale != nullptr);
   if (L.total > FT_LDS_BUDGET) return EGC_ERR_UNSUPPORTED;
   t.off_rec = L.off_rec; t.off_planes = L.off_planes; t.off_rowinv = L.off_rowinv; t.off_bases = L.off_bases; t.off_wt = L.off_wt;
-  t.off_col = L.off_col; t.off_rowptr = L.off_rowptr; t.off_cnt = L.off_cnt; t.off_ns = L.off_ns; t.off_dis_raw = L.off_dis_raw;
-  t.off_dis_looped = L.off_dis_looped;
+  t.off_col = L.off_col; t.off_rowptr = L.off_rowptr; t.off_cnt = L.off_cnt; t.off_dis = L.off_dis; t.csr_stride = L.csr_stride;
   // one workgroup per CU at most; fewer when the batch is small (a workgroup's share: at least ~16 nodes, at least one graph)
   int64_t grid = 256;
   if (const char* e = getenv("EGC_FT_GRID")) grid = std::max(1, atoi(e));
