@@ -559,14 +559,15 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       // offsets or the search -- take two to five memory round trips: in front of a barrier they were 15 % of the kernel).
       // The record's slot was last read during tile it - 1.
       if (wave == FT_WAVES - 1) plan_tile((it + 2) % 3);
+      // the next tile's CSR, into the other set of areas -- BEFORE its rows are requested: the vector-memory counter is in
+      // order, so behind twenty row requests every wait for an edge would also wait for the rows
+      if (wave < FT_FIRST_HELPER + FT_CSR_WAVES) build_csr(nxt, (it + 1) & 1);
       // the next tile's rows, all of them at once: they travel during this tile's rows phase and the next tile's first steps.
       // (Requested chunk by chunk inside the loop above, the compiler's conservative vmcnt(0) in front of every split made
       // each step wait for the request it had just issued.)
 #pragma unroll
       for (int c = 0; c < FT_RING; ++c)
         if (c < nxt.nch) x_load(xr[2 * c], xr[2 * c + 1], rsn, c);
-      // and its CSR, into the other set of areas
-      if (wave < FT_FIRST_HELPER + FT_CSR_WAVES) build_csr(nxt, (it + 1) & 1);
       lds_barrier();                                   // (end of tile)
     }
     return;
