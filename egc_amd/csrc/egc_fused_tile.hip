@@ -157,11 +157,11 @@ __device__ inline int ft_half_wave_lower_bound(const int64_t* __restrict__ arr, 
 
 // The same lower bound with ONE round of loads when the array is close to linear (graph offsets of a batch of similar
 // graphs, the destination row of their edges): each half looks at the 64 entries around guess = key n / top first and
-// falls back to the full search when the answer is not strictly inside that window.  Same result as the full search on
+// falls back to the full search when the answer is not strictly inside that window (guess: the caller's, e.g. key n / top).  Same result as the full search on
 // sorted input, a deterministic function of (arr, key) on any input (two workgroups that share a key get the same index).
-__device__ inline int ft_guess_lower_bound(const int64_t* __restrict__ arr, int n, int64_t key, int64_t top, int lane) {
+__device__ inline int ft_guess_lower_bound(const int64_t* __restrict__ arr, int n, int64_t key, int64_t g64, int lane) {
   const int l32 = lane & 31, sh = lane & 32;
-  int64_t g64 = top > 0 ? key * (int64_t)n / top : 0;
+  g64 = g64 > n ? n : g64;
   int w0 = (int)(g64 < 31 ? 0 : g64 - 31);
   w0 = w0 > n - 64 ? n - 64 : w0;
   w0 = w0 < 0 ? 0 : w0;
@@ -263,6 +263,7 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
     const int Gn = (int)t.n_graphs;          // (host: n_graphs, n_nodes, n_edges < 2^31)
     const int Nn = a.n_nodes, En = (int)t.n_edges;
     int cur_g = 0, g_hi = 0;                 // (meaningful in wavefront 15 only; wave-uniform)
+    int last_n = 0, last_e = 0;              // where the last planned tile ended (node, edge): the next search starts its guess there
     auto clampi = [](int64_t v, int hi) -> int { return v < 0 ? 0 : (v > hi ? hi : (int)v); };
     // next tile of this workgroup -> lds_rec[slot] (wavefront 15, all lanes): graphs [cur_g, next_g) with at most tcap nodes.
     // Everything in 32 bits and wave-uniform values in scalar registers: this code runs with a tile of x in the vector registers.
@@ -289,8 +290,11 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
           if (b1 < b0 && lane == 0) ft_error(t, 1);
           e0 = clampi(b0, En);
           e1 = clampi(b1, En);
-        } else {   // the two ends side by side in the two halves of the wavefront
-          const int r = ft_half_wave_lower_bound(t.dst, En, lane < 32 ? n0 : n1, lane);
+        } else {   // the two ends side by side in the two halves of the wavefront, each around its own guess: the edge list is
+                   // close to linear in the node id, locally (one tile further) even more so
+          const int64_t den = Nn > 0 ? Nn : 1;
+          const int64_t ga = (int64_t)last_e + (int64_t)(n0 - last_n) * En / den, gb = ga + (int64_t)(n1 - n0) * En / den;
+          const int r = ft_guess_lower_bound(t.dst, En, lane < 32 ? n0 : n1, lane < 32 ? ga : gb, lane);
           e0 = __builtin_amdgcn_readfirstlane(__shfl(r, 0));
           e1 = __builtin_amdgcn_readfirstlane(__shfl(r, 32));
         }
@@ -299,6 +303,8 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
         e1 = e1 < e0 ? e0 : e1;
         cur_g = next_g;
         valid = 1;
+        last_n = n1;
+        last_e = e1;
       }
       if (lane == 0) {
         lds_rec[slot * 8 + 0] = n0; lds_rec[slot * 8 + 1] = n1; lds_rec[slot * 8 + 2] = e0; lds_rec[slot * 8 + 3] = e1;
@@ -309,7 +315,7 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       // the workgroup's graphs: [g_lo, g_hi) = those whose first node lies in its share of [0, N)
       const int64_t nb = gridDim.x, b = blockIdx.x;
       const int64_t k_lo = b * Nn / nb, k_hi = (b + 1) * Nn / nb;
-      const int r = ft_guess_lower_bound(t.ptr, Gn + 1, lane < 32 ? k_lo : k_hi, Nn, lane);
+      const int r = ft_guess_lower_bound(t.ptr, Gn + 1, lane < 32 ? k_lo : k_hi, (lane < 32 ? k_lo : k_hi) * (Gn + 1) / (Nn > 0 ? Nn : 1), lane);
       int lo = __builtin_amdgcn_readfirstlane(__shfl(r, 0)), hi = __builtin_amdgcn_readfirstlane(__shfl(r, 32));
       if (b == 0) lo = 0;
       if (b == nb - 1) hi = Gn;
@@ -346,10 +352,10 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
               if ((b1 < b0 || b2 < b1) && lane == 0) ft_error(t, 1);
               e0 = clampi(b0, En); e1 = clampi(b1, En); e2 = clampi(b2, En);
             } else {
-              const int ra = ft_guess_lower_bound(t.dst, En, lane < 32 ? p0 : p1, Nn, lane);
+              const int ra = ft_guess_lower_bound(t.dst, En, lane < 32 ? p0 : p1, (int64_t)(lane < 32 ? p0 : p1) * En / (Nn > 0 ? Nn : 1), lane);
               e0 = __builtin_amdgcn_readfirstlane(__shfl(ra, 0));
               e1 = __builtin_amdgcn_readfirstlane(__shfl(ra, 32));
-              const int rb = ft_guess_lower_bound(t.dst, En, p2, Nn, lane);
+              const int rb = ft_guess_lower_bound(t.dst, En, p2, (int64_t)e1 + (int64_t)(p2 - p1) * En / (Nn > 0 ? Nn : 1), lane);
               e2 = __builtin_amdgcn_readfirstlane(__shfl(rb, 0));
             }
             if (cur_g == 0) e0 = 0;
@@ -362,6 +368,8 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
               lds_rec[8] = p1; lds_rec[9] = p2; lds_rec[10] = e1; lds_rec[11] = e2; lds_rec[12] = n1k >= 1 ? 1 : 0;
             }
             cur_g = g2;
+            last_n = p2;
+            last_e = e2;
             both = true;
           }
         }
