@@ -98,6 +98,10 @@ __device__ inline void vmwait_rt(int n) {
     case 12: vmwait_k<12>(); break; case 13: vmwait_k<13>(); break; case 14: vmwait_k<14>(); break;
     case 15: vmwait_k<15>(); break; case 16: vmwait_k<16>(); break; case 17: vmwait_k<17>(); break;
     case 18: vmwait_k<18>(); break; case 19: vmwait_k<19>(); break; case 20: vmwait_k<20>(); break;
+    case 21: vmwait_k<21>(); break; case 22: vmwait_k<22>(); break; case 23: vmwait_k<23>(); break;
+    case 24: vmwait_k<24>(); break; case 25: vmwait_k<25>(); break; case 26: vmwait_k<26>(); break;
+    case 27: vmwait_k<27>(); break; case 28: vmwait_k<28>(); break; case 29: vmwait_k<29>(); break;
+    case 30: vmwait_k<30>(); break; case 31: vmwait_k<31>(); break; case 32: vmwait_k<32>(); break;
     default: vmwait_k<0>(); break;
   }
 }
@@ -114,10 +118,10 @@ __global__ void __launch_bounds__(WAVES * 64) basis_gemm_f16x2k_kernel(const flo
                                                                       const float* __restrict__ bcat, int64_t M, int K,
                                                                       KCols c, float* __restrict__ bases,
                                                                       float* __restrict__ weightings, int n_tiles, int LDX,
-                                                                      int R, int slot_bytes, int tile0) {
+                                                                      int R, int slot_bytes, int tile0, int ring) {
   extern __shared__ __attribute__((aligned(16))) char smem_k[];
-  char* raw = smem_k;                                                    // [2][slot_bytes] raw fp32 tiles (DMA ring)
-  u16* xs = reinterpret_cast<u16*>(smem_k + 2 * slot_bytes);             // [2 buffers][2 planes][KROWS][LDX] fp16
+  char* raw = smem_k;                                                    // [ring][slot_bytes] raw fp32 tiles (DMA ring)
+  u16* xs = reinterpret_cast<u16*>(smem_k + ring * slot_bytes);          // [2 buffers][2 planes][KROWS][LDX] fp16
   float* row_inv = reinterpret_cast<float*>(xs + 4 * KROWS * LDX);       // [2 buffers][KROWS]
   float* colinfo = row_inv + 2 * KROWS;                                  // [16 NT][2]: inverse column scale, bias
   const int tid = threadIdx.x;
@@ -153,8 +157,7 @@ __global__ void __launch_bounds__(WAVES * 64) basis_gemm_f16x2k_kernel(const flo
   const int stride = gridDim.x;
   int tile = blockIdx.x;
   if (tile >= n_tiles) return;
-  dma_tile(tile, 0);
-  dma_tile(tile + stride, 1);
+  for (int r = 0; r < ring; ++r) dma_tile(tile + r * stride, r);    // `ring` tiles of x per CU in flight (two left HBM latency exposed: 3.8 TB/s)
   // zero the planes once: the k range [K, 32 KS) and the row padding are never written again
   for (int i = tid; i < 4 * KROWS * LDX / 8; i += nthreads) reinterpret_cast<u32x4k*>(xs)[i] = u32x4k{0, 0, 0, 0};
 
@@ -187,7 +190,7 @@ __global__ void __launch_bounds__(WAVES * 64) basis_gemm_f16x2k_kernel(const flo
   // the compiler counts only its own loads: let it retire the weight loads HERE
 #pragma unroll
   for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(wf[s][0]), "+v"(wf[s][1]));
-  // the first two tiles were requested before the weight loads: both have landed by now (vmcnt(0) above)
+  // the first tiles were requested before the weight loads: all have landed by now (vmcnt(0) above)
   lds_barrier_k();
 
   const int hw = tid >> 5;                    // half-wavefront index: one row of the tile per half-wavefront and pass
@@ -245,20 +248,24 @@ __global__ void __launch_bounds__(WAVES * 64) basis_gemm_f16x2k_kernel(const flo
   unsigned long long kt0, ksum[6] = {0, 0, 0, 0, 0, 0};
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(kt0) :: "memory");
 #endif
-  // One barrier per tile.  At the top of iteration t (tile t of this workgroup): ring slot (t + 1) % 2 holds the raw
-  // tile t + 1, plane buffer t % 2 the split tile t.  After the barrier the slot t % 2 is free (everybody has split
-  // tile t) and is re-armed with tile t + 2 at once -- a whole iteration of cover for its latency; then the wavefronts
-  // split tile t + 1 into the other plane buffer and multiply tile t, in whatever order they get there: the vector
-  // work of one wavefront runs beside the matrix work of another.
-  int cur = 0;
+  // One barrier per tile.  At the top of iteration t (tile t of this workgroup): ring slots (t + 1) % ring ... hold or await
+  // the raw tiles t + 1 ... t + ring - 1, plane buffer t % 2 the split tile t.  After the barrier the slot t % ring is free
+  // (everybody has split tile t) and is re-armed with tile t + ring at once; then the wavefronts split tile t + 1 into the
+  // other plane buffer and multiply tile t, in whatever order they get there: the vector work of one wavefront runs beside
+  // the matrix work of another.  The wait at the top is for this wavefront's own pieces of tile t + 1: behind them in the
+  // (in-order) counter are the pieces of tiles t + 2 ... t + ring - 1 and the last tile's stores.
+  int cur = 0, slot = 0;
+  const int behind = (ring - 2) * R + n_stores;
   for (bool first = true; tile < n_tiles; tile += stride, first = false) {
-    if (first) vmwait_k<0>(); else vmwait_rt(n_stores);  // own pieces of tile t + 1: only the last tile's stores came after them
+    if (first) vmwait_k<0>(); else vmwait_rt(behind);
     KST(0)
     lds_barrier_k();
     KST(1)
-    split(cur ^ 1, cur ^ 1);
+    const int nslot = slot + 1 == ring ? 0 : slot + 1;
+    split(nslot, cur ^ 1);
     KST(3)
-    dma_tile(tile + 2 * stride, cur);
+    dma_tile(tile + ring * stride, slot);
+    slot = nslot;
     KST(2)
     {
       f32x4k acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -358,7 +365,8 @@ static int launch_k(const float* x, const u16* packed, const float* bcat, int64_
   const int LDX = 32 * KS + 16;
   const int R = (int)ceil_div((int64_t)KROWS * (K / 4), threads);
   const int slot_bytes = R * threads * 16;
-  const size_t lds = (size_t)2 * slot_bytes + (size_t)4 * KROWS * LDX * sizeof(u16) + (2 * KROWS + 2 * 16 * c.NT) * sizeof(float);
+  const size_t fixed = (size_t)4 * KROWS * LDX * sizeof(u16) + (2 * KROWS + 2 * 16 * c.NT) * sizeof(float);
+  size_t lds = (size_t)2 * slot_bytes + fixed;
   if (lds > 160 * 1024 || R > 16) return EGC_ERR_UNSUPPORTED;
   auto kern = &basis_gemm_f16x2k_kernel<KS, WAVES>;
   static bool attr_set = false;
@@ -376,7 +384,17 @@ static int launch_k(const float* x, const u16* packed, const float* bcat, int64_
   int grid = 256 * per_cu;
   if (const char* e = getenv("EGC_GEMM_GRID")) grid = atoi(e);
   if (grid > n_tiles) grid = n_tiles;
-  kern<<<grid, threads, lds, stream>>>(x, packed, bcat, M, K, c, bases, weightings, n_tiles, LDX, R, slot_bytes, tile0);
+  // depth of the raw-tile ring: what the LDS share of a workgroup holds next to the planes, at most 4 (and within the
+  // counted wait's range); a workgroup that shares its CU keeps 2
+  int ring = 2;
+  if (per_cu == 1) {
+    ring = (int)std::min<size_t>(4, ((size_t)160 * 1024 - fixed) / (size_t)slot_bytes);
+    if (const char* e = getenv("EGC_GEMMK_RING")) ring = atoi(e);
+    while (ring > 2 && ((ring - 2) * R + 4 > 32 || (size_t)ring * slot_bytes + fixed > (size_t)160 * 1024)) --ring;
+    if (ring < 2) ring = 2;
+    lds = (size_t)ring * slot_bytes + fixed;
+  }
+  kern<<<grid, threads, lds, stream>>>(x, packed, bcat, M, K, c, bases, weightings, n_tiles, LDX, R, slot_bytes, tile0, ring);
   EGC_LAUNCH_CHECK("basis_gemm_f16x2k_kernel");
 #ifdef EGC_GEMMK_STAMPS
   {
