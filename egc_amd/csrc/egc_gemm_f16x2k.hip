@@ -312,6 +312,280 @@ __global__ void __launch_bounds__(WAVES * 64) basis_gemm_f16x2k_kernel(const flo
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same GEMM with the wavefronts' ROLES separated (round 4; the form the ogbn-mag layer runs on).  In the kernel above
+// every wavefront requests its pieces of x, splits a row and multiplies: next to the 8 KS registers of its weight tile there
+// is no register left to request the next k-step's operands ahead, so every k-step pays the LDS latency (98 cycles per MFMA
+// measured at 352 -> 176 + 32, against 16 of matrix pipe), and the split, the DMA issue and the products of a wavefront are
+// serial (6,400 cycles per 16-row tile and wavefront: 3,200 products, 1,050 split, 570 DMA issue, 1,100 barrier).  Here
+// wavefronts [0, nmf) only multiply -- the operands of k-step s + 1 in flight during the products of k-step s -- and
+// `nh` further wavefronts only move x: LDS-DMA requests `ring` tiles ahead, the fp16x2 split of tile t + 1 while tile t is
+// being multiplied (their registers are free: each row's pieces are read once and kept).  Same numerics, same packed weights.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int KS, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) basis_gemm_f16x2k_spec_kernel(const float* __restrict__ x, const u16* __restrict__ packed,
+                                                                           const float* __restrict__ bcat, int64_t M, int K,
+                                                                           KCols c, float* __restrict__ bases,
+                                                                           float* __restrict__ weightings, int n_tiles, int LDX,
+                                                                           int R, int slot_bytes, int tile0, int ring, int nmf) {
+  extern __shared__ __attribute__((aligned(16))) char smem_k[];
+  char* raw = smem_k;                                                    // [ring][slot_bytes] raw fp32 tiles (DMA ring)
+  u16* xs = reinterpret_cast<u16*>(smem_k + ring * slot_bytes);          // [2 buffers][2 planes][KROWS][LDX] fp16
+  float* row_inv = reinterpret_cast<float*>(xs + 4 * KROWS * LDX);       // [2 buffers][KROWS]
+  float* colinfo = row_inv + 2 * KROWS;                                  // [16 NT][2]: inverse column scale, bias
+  const int tid = threadIdx.x;
+  const int nthreads = blockDim.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool is_helper = wave >= nmf;
+  const int K4 = K >> 2;                                                 // 16-byte pieces per row
+  const int stride = gridDim.x;
+  int tile = blockIdx.x;
+  if (tile >= n_tiles) return;
+  // zero the planes once: the k range [K, 32 KS) and the row padding are never written again
+  for (int i = tid; i < 4 * KROWS * LDX / 8; i += nthreads) reinterpret_cast<u32x4k*>(xs)[i] = u32x4k{0, 0, 0, 0};
+  {
+    const float* inv_tab = reinterpret_cast<const float*>(packed + (int64_t)c.NT * KS * 2 * 64 * 8);
+    for (int v = tid; v < 16 * c.NT; v += nthreads) {
+      const int w = v - 16 * c.TB;
+      colinfo[2 * v] = inv_tab[v];
+      colinfo[2 * v + 1] = (w >= 0 && w < c.W && bcat != nullptr) ? bcat[w] : 0.f;
+    }
+  }
+
+  if (is_helper) {
+    // ================= the x movers =================
+    const int ht = tid - nmf * 64;                 // thread index among the helpers
+    const int hthreads = nthreads - nmf * 64;
+    const int hwave = wave - nmf;
+    constexpr unsigned GOOB = 0xFFFFFFF0u;
+    const u32x4k rx = {(unsigned)(uintptr_t)x, (unsigned)((uintptr_t)x >> 32) & 0xffffu, (unsigned)(M * K * 4), 0x00020000u};
+    const unsigned raw_lds = (unsigned)(uintptr_t)raw;
+    const unsigned magic_K4 = (unsigned)(((uint64_t)1 << 32) / (uint64_t)K4) + 1u;
+    // this thread's (up to 16) pieces of a tile: byte offset inside the tile, or out of range -- computed once (per tile and
+    // piece the index arithmetic was a third of the helpers' time)
+    unsigned poff[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int pc = ht + hthreads * i;
+      const int row = (int)__umulhi((unsigned)pc, magic_K4);   // pc / K4 for pc < 2^16
+      const int k4 = pc - row * K4;
+      poff[i] = (i < R && row < KROWS) ? (unsigned)((row * K + 4 * k4) * 4) : GOOB;
+    }
+    const int64_t tile_bytes = (int64_t)KROWS * K * 4;
+    auto dma_tile = [&](int tl, int slot) {
+      // rows beyond M fall outside the buffer (its range check drops them); a tile beyond the last one is not requested
+      const bool tile_ok = tl < n_tiles;
+      const unsigned tbase = (unsigned)((int64_t)tl * tile_bytes);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (i < R) {     // wave-uniform
+          const unsigned voff = (tile_ok && poff[i] != GOOB) ? tbase + poff[i] : GOOB;
+          const unsigned dst = __builtin_amdgcn_readfirstlane(raw_lds + slot * slot_bytes + (hwave * 64 + hthreads * i) * 16);
+          unsigned keep;
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                       : "=&s"(keep)
+                       : "v"(voff), "s"(dst), "s"(rx)
+                       : "memory");
+        }
+      }
+    };
+    const int hw = ht >> 5, hl = ht & 31, n_hw = hthreads >> 5;
+    // raw fp32 rows of ring slot `rslot` -> the two fp16 planes of buffer `pbuf` + row scales; a half-wavefront per row,
+    // the lane's (up to) three 16-byte pieces read once, together, and kept
+    // (the rows of a half-wavefront -- up to four -- are processed TOGETHER: one row at a time is a chain of ~60 dependent
+    // instructions on a wavefront that has its SIMD's vector unit almost to itself: 1,300 cycles per row measured)
+    auto split = [&](int rslot, int pbuf) {
+      const char* rs = raw + rslot * slot_bytes;
+      u16* xp = xs + pbuf * 2 * KROWS * LDX;
+      constexpr int RPH = 4;
+      float4 v[RPH][3];
+#pragma unroll
+      for (int r = 0; r < RPH; ++r) {
+        const int row = hw + r * n_hw;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const int k4 = hl + 32 * i;
+          // (unconditional reads of clamped addresses: a conditional LDS read becomes a branch with its own wait, and the
+          // first form of this function spent its time in 112 branches; a clamped piece repeats one the maximum already holds)
+          v[r][i] = *reinterpret_cast<const float4*>(rs + ((size_t)(row < KROWS ? row : KROWS - 1) * K4 + (k4 < K4 ? k4 : K4 - 1)) * 16);
+        }
+      }
+      unsigned a[RPH];
+#pragma unroll
+      for (int r = 0; r < RPH; ++r) {
+        float m = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          float mi;
+          asm("v_max3_f32 %0, |%1|, |%2|, |%3|\n\tv_max_f32 %0, |%4|, %0" : "=&v"(mi) : "v"(v[r][i].x), "v"(v[r][i].y), "v"(v[r][i].z), "v"(v[r][i].w));
+          m = fmaxf(m, mi);
+        }
+        a[r] = __float_as_uint(m);
+      }
+#pragma unroll
+      for (int r = 0; r < RPH; ++r) a[r] = max(a[r], (unsigned)__builtin_amdgcn_update_dpp(0, (int)a[r], 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+#pragma unroll
+      for (int r = 0; r < RPH; ++r) a[r] = max(a[r], (unsigned)__builtin_amdgcn_update_dpp(0, (int)a[r], 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+#pragma unroll
+      for (int r = 0; r < RPH; ++r) a[r] = max(a[r], (unsigned)__builtin_amdgcn_update_dpp(0, (int)a[r], 0x141, 0xf, 0xf, true));  // row_half_mirror
+#pragma unroll
+      for (int r = 0; r < RPH; ++r) a[r] = max(a[r], (unsigned)__builtin_amdgcn_update_dpp(0, (int)a[r], 0x140, 0xf, 0xf, true));  // row_mirror
+#pragma unroll
+      for (int r = 0; r < RPH; ++r) a[r] = max(a[r], (unsigned)__builtin_amdgcn_ds_swizzle((int)a[r], 0x401F));                    // lane ^ 16
+#pragma unroll
+      for (int r = 0; r < RPH; ++r) {
+        const int row = hw + r * n_hw;
+        if (row < KROWS) {     // uniform in the half-wavefront
+          unsigned e = a[r] & 0x7f800000u;
+          e = min(max(e, 13u << 23), 253u << 23);
+          const float sc = __uint_as_float(0x7f000000u - e);                  // 2^-e
+          const float sc2k = __uint_as_float(0x7f000000u + (11u << 23) - e);  // 2^(11-e)
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const int k4 = hl + 32 * i;
+            if (k4 < K4) {
+              const float4 w = v[r][i];
+              const f16x2k h01 = __builtin_convertvector(f32x2k{w.x * sc, w.y * sc}, f16x2k);
+              const f16x2k h23 = __builtin_convertvector(f32x2k{w.z * sc, w.w * sc}, f16x2k);
+              f16x2k l01, l23;
+              l01[0] = (_Float16)__builtin_fmaf((float)h01[0], -2048.f, w.x * sc2k);
+              l01[1] = (_Float16)__builtin_fmaf((float)h01[1], -2048.f, w.y * sc2k);
+              l23[0] = (_Float16)__builtin_fmaf((float)h23[0], -2048.f, w.z * sc2k);
+              l23[1] = (_Float16)__builtin_fmaf((float)h23[1], -2048.f, w.w * sc2k);
+              u16* dst = xp + row * LDX + 4 * k4;
+              *reinterpret_cast<u32x2k*>(dst) = u32x2k{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
+              *reinterpret_cast<u32x2k*>(dst + KROWS * LDX) = u32x2k{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
+            }
+          }
+          if (hl == 0) row_inv[pbuf * KROWS + row] = __uint_as_float(e);  // 2^e
+        }
+      }
+    };
+    for (int r = 0; r < ring; ++r) dma_tile(tile + r * stride, r);
+    vmwait_k<0>();
+    lds_barrier_k();           // every helper's pieces of the first tiles have landed; the planes are zeroed, colinfo written
+    split(0, 0);
+    // At the top of iteration t: this wavefront's pieces of tile t + 1 must have landed; behind them in the (in-order)
+    // counter are only the pieces of tiles t + 2 ... t + ring - 1.
+    int cur = 0, slot = 0;
+    const int behind = (ring - 2) * R;
+#ifdef EGC_GEMMK_STAMPS
+    unsigned long long kt0, ksum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(kt0) :: "memory");
+#endif
+    for (; tile < n_tiles; tile += stride) {
+      vmwait_rt(behind);
+      KST(0)
+      lds_barrier_k();         // tile t split (all helpers), tile t + 1 landed, the workers done with plane buffer cur ^ 1
+      KST(1)
+      const int nslot = slot + 1 == ring ? 0 : slot + 1;
+      split(nslot, cur ^ 1);
+      KST(2)
+      dma_tile(tile + ring * stride, slot);     // (slot held tile t: split in the previous iteration, before this barrier)
+      KST(3)
+      slot = nslot;
+      cur ^= 1;
+    }
+    vmwait_k<0>();  // no DMA may still be writing this block's LDS when it is handed to the next block
+#ifdef EGC_GEMMK_STAMPS
+    if (tid == nmf * 64) for (int k = 0; k < 4; ++k) atomicAdd(&egc_stampk[k], ksum[k]);
+#endif
+    return;
+  }
+
+  // ================= the multipliers =================
+  const int ct = tile0 + wave;
+  const int j = lane & 15, quad = lane >> 4;
+  f16x8k wf[KS][2];
+  {
+    const u16* src = packed + ((int64_t)ct * KS * 2 * 64 + lane) * 8;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      wf[s][0] = *reinterpret_cast<const f16x8k*>(src + (s * 2) * 64 * 8);
+      wf[s][1] = *reinterpret_cast<const f16x8k*>(src + (s * 2 + 1) * 64 * 8);
+    }
+  }
+  constexpr unsigned GOOB = 0xFFFFFFF0u;
+  const bool to_bases = ct < c.TB;
+  const int out_ld = to_bases ? c.ldb : c.W;
+  const int col0 = to_bases ? 16 * ct + 4 * quad : 16 * (ct - c.TB) + 4 * quad;
+  const int lim = to_bases ? c.ldb : c.W;
+  float* outp = to_bases ? bases : weightings;
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, (unsigned)(M * out_ld * 4), 0x00020000);
+  const bool vec_store = (out_ld & 3) == 0;
+  vmwait_k<0>();
+#pragma unroll
+  for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(wf[s][0]), "+v"(wf[s][1]));
+  lds_barrier_k();
+  int cur = 0;
+#ifdef EGC_GEMMK_STAMPS
+  unsigned long long kt0, ksum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rt0, rt1, ct0;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(kt0) :: "memory");
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0) :: "memory");
+  ct0 = kt0;
+#endif
+  for (; tile < n_tiles; tile += stride) {
+    lds_barrier_k();
+    KST(4)
+    f32x4k acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const u16* xb = xs + cur * 2 * KROWS * LDX + j * LDX + 8 * quad;
+    // PF operand sets in rotation: the operands of k-step s + PF - 1 are requested before the products of k-step s, and the
+    // order is pinned (left alone the scheduler folds the sets back into one and waits for a read two MFMAs after issuing it)
+    constexpr int PF = 3;
+    f16x8k xh[PF], xl[PF];
+#pragma unroll
+    for (int p = 0; p < PF - 1; ++p)
+      if (p < KS) {
+        xh[p] = *reinterpret_cast<const f16x8k*>(xb + 32 * p);
+        xl[p] = *reinterpret_cast<const f16x8k*>(xb + KROWS * LDX + 32 * p);
+      }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      if (s + PF - 1 < KS) {
+        xh[(s + PF - 1) % PF] = *reinterpret_cast<const f16x8k*>(xb + 32 * (s + PF - 1));
+        xl[(s + PF - 1) % PF] = *reinterpret_cast<const f16x8k*>(xb + KROWS * LDX + 32 * (s + PF - 1));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[s][0], xh[s % PF], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[s][0], xl[s % PF], acc1, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[s][1], xh[s % PF], acc1, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    KST(5)
+    const float ri = row_inv[cur * KROWS + j];
+    f32x4k cinv, cbias;
+    {
+      const float* ci = colinfo + 2 * (16 * ct + 4 * quad);
+      const f32x4k c01 = *reinterpret_cast<const f32x4k*>(ci), c23 = *reinterpret_cast<const f32x4k*>(ci + 4);
+      cinv = f32x4k{c01[0], c01[2], c23[0], c23[2]};
+      cbias = f32x4k{c01[1], c01[3], c23[1], c23[3]};
+    }
+    const int64_t grow = (int64_t)tile * KROWS + j;
+    f32x4k o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = __builtin_fmaf(__builtin_fmaf(acc1[r], 1.f / 2048.f, acc0[r]), cinv[r] * ri, cbias[r]);
+    const bool row_ok = grow < M;
+    const unsigned off = (unsigned)((grow * out_ld + col0) * 4);
+    if (vec_store) {
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4k, o), ro, (row_ok && col0 + 3 < lim) ? off : GOOB, 0, 0);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o[r]), ro, (row_ok && col0 + r < lim) ? off + 4u * r : GOOB, 0, 0);
+    }
+    KST(6)
+    cur ^= 1;
+  }
+#ifdef EGC_GEMMK_STAMPS
+  if (tid == 0) for (int k = 4; k < 7; ++k) atomicAdd(&egc_stampk[k], ksum[k]);
+  if (tid == 0 && blockIdx.x == 0) {
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1) :: "memory");
+    egc_stampk[7] = ((kt0 - ct0) << 24) | ((rt1 - rt0) & 0xffffff);     // loop cycles | 100 MHz ticks of block 0
+  }
+#endif
+}
+
 bool f16x2k_shape(int f_in, int f_g, int ldb, int w_cols) {
   if (getenv("EGC_GEMM_NO_F16X2K") != nullptr) return false;
   if (f_in <= 128 || f_in > 384 || (f_in & 3) != 0) return false;
@@ -355,7 +629,6 @@ int f16x2k_pack(const float* wcat, int64_t rs, int64_t cs, int f_in, int f_g, in
 template <int KS, int WAVES>
 static int launch_k(const float* x, const u16* packed, const float* bcat, int64_t M, int K, const KCols& c, float* bases,
                     float* weightings, hipStream_t stream, int tile0, int ntl) {
-  const int threads = ntl * 64;   // this launch: column tiles tile0 .. tile0 + ntl - 1
   const int64_t n_tiles64 = ceil_div(M, KROWS);
   if (n_tiles64 >= ((int64_t)1 << 31)) return EGC_ERR_INVALID;
   const int n_tiles = (int)n_tiles64;
@@ -363,9 +636,61 @@ static int launch_k(const float* x, const u16* packed, const float* bcat, int64_
   // with 32 KS + 16 every one of the instruction's four 16-lane groups touches 16 distinct 4-bank slots
   // (32 KS + 8 leaves five 2-way conflicts per group)
   const int LDX = 32 * KS + 16;
+  const size_t fixed = (size_t)4 * KROWS * LDX * sizeof(u16) + (2 * KROWS + 2 * 16 * c.NT) * sizeof(float);
+  // ---- separated roles: `nh` helper wavefronts next to the ntl multipliers (this launch: column tiles tile0 .. tile0 + ntl - 1)
+  const int nh = std::min(WAVES - ntl, 4);
+  // (where two workgroups of the everything-in-every-wavefront kernel share a CU -- short k, few column tiles -- that form
+  // stays: 52.7 against 62.3 us at 184 -> 96 + 32, N = 169,343)
+  bool two_per_cu = false;
+  {
+    const int threads = ntl * 64;
+    const int R0 = (int)ceil_div((int64_t)KROWS * (K / 4), threads);
+    const size_t lds0 = (size_t)2 * R0 * threads * 16 + fixed;
+    two_per_cu = KS <= 9 && std::min<size_t>((size_t)160 * 1024 / lds0, (size_t)(20 / ntl)) >= 2;
+  }
+  if (nh >= 2 && !two_per_cu && getenv("EGC_GEMMK_LEGACY") == nullptr) {
+    const int hthreads = nh * 64;
+    const int R = (int)ceil_div((int64_t)KROWS * (K / 4), hthreads);
+    const int slot_bytes = R * hthreads * 16;
+    int ring = (int)std::min<size_t>(4, ((size_t)160 * 1024 - fixed) / (size_t)slot_bytes);
+    if (const char* e = getenv("EGC_GEMMK_RING")) ring = std::min(ring, atoi(e));
+    while (ring > 2 && (ring - 2) * R > 32) --ring;
+    if (ring >= 2 && R <= 16) {
+      const size_t lds = (size_t)ring * slot_bytes + fixed;
+      auto kern = &basis_gemm_f16x2k_spec_kernel<KS, WAVES>;
+      static bool attr_set = false;
+      if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { set_last_error("hipFuncSetAttribute(f16x2k spec)", e); return EGC_ERR_HIP; }
+        attr_set = true;
+      }
+      int grid = 256;
+      if (const char* e = getenv("EGC_GEMM_GRID")) grid = atoi(e);
+      if (grid > n_tiles) grid = n_tiles;
+      kern<<<grid, (ntl + nh) * 64, lds, stream>>>(x, packed, bcat, M, K, c, bases, weightings, n_tiles, LDX, R, slot_bytes, tile0, ring,
+                                                   ntl);
+      EGC_LAUNCH_CHECK("basis_gemm_f16x2k_spec_kernel");
+#ifdef EGC_GEMMK_STAMPS
+      {
+        static int calls = 0;
+        if (++calls == 10) {
+          hipDeviceSynchronize();
+          unsigned long long h[8];
+          hipMemcpyFromSymbol(h, HIP_SYMBOL(egc_stampk), sizeof(h));
+          const double per = (double)calls * n_tiles;   // one helper wavefront and one multiplier per workgroup report
+          fprintf(stderr, "[gemmk spec stamps] K=%d ntl=%d nh=%d R=%d ring=%d per tile (cycles): helper: dma-wait %.0f barrier %.0f split %.0f dma-issue %.0f | multiplier: barrier %.0f products %.0f scale+store %.0f\n",
+                  K, ntl, nh, R, ring, h[0] / per, h[1] / per, h[2] / per, h[3] / per, h[4] / per, h[5] / per, h[6] / per);
+          fprintf(stderr, "[gemmk spec stamps] block 0 loop: %llu shader cycles in %.1f us (s_memrealtime) => %.2f GHz\n", h[7] >> 24, (h[7] & 0xffffff) * 0.01,
+                  (double)(h[7] >> 24) / ((h[7] & 0xffffff) * 10.0));
+        }
+      }
+#endif
+      return EGC_OK;
+    }
+  }
+  const int threads = ntl * 64;
   const int R = (int)ceil_div((int64_t)KROWS * (K / 4), threads);
   const int slot_bytes = R * threads * 16;
-  const size_t fixed = (size_t)4 * KROWS * LDX * sizeof(u16) + (2 * KROWS + 2 * 16 * c.NT) * sizeof(float);
   size_t lds = (size_t)2 * slot_bytes + fixed;
   if (lds > 160 * 1024 || R > 16) return EGC_ERR_UNSUPPORTED;
   auto kern = &basis_gemm_f16x2k_kernel<KS, WAVES>;
@@ -396,19 +721,6 @@ static int launch_k(const float* x, const u16* packed, const float* bcat, int64_
   }
   kern<<<grid, threads, lds, stream>>>(x, packed, bcat, M, K, c, bases, weightings, n_tiles, LDX, R, slot_bytes, tile0, ring);
   EGC_LAUNCH_CHECK("basis_gemm_f16x2k_kernel");
-#ifdef EGC_GEMMK_STAMPS
-  {
-    static int calls = 0;
-    if (++calls == 10) {
-      hipDeviceSynchronize();
-      unsigned long long h[8];
-      hipMemcpyFromSymbol(h, HIP_SYMBOL(egc_stampk), sizeof(h));
-      const double per = (double)calls * n_tiles * c.NT;
-      fprintf(stderr, "[gemmk stamps] K=%d NT=%d R=%d per tile and wavefront (cycles): dma-wait %.0f barrier %.0f dma-issue %.0f split %.0f mfma+store %.0f\n",
-              K, c.NT, R, h[0] / per, h[1] / per, h[2] / per, h[3] / per, h[5] / per);
-    }
-  }
-#endif
   return EGC_OK;
 }
 
@@ -420,8 +732,10 @@ static int launch_ks(const float* x, const u16* packed, const float* bcat, int64
   const int launches = c.NT <= 16 ? 1 : 2;
   for (int l = 0, t0 = 0; l < launches; ++l) {
     const int ntl = (c.NT - t0 + (launches - l) - 1) / (launches - l);
-    const int st = ntl <= 12 ? launch_k<KS, 12>(x, packed, bcat, M, K, c, bases, weightings, stream, t0, ntl)
-                             : launch_k<KS, 16>(x, packed, bcat, M, K, c, bases, weightings, stream, t0, ntl);
+    // up to 9 column tiles: 12 wavefronts (168 registers), 3-4 of them helpers; more: 16 wavefronts (128 registers) with
+    // 16 - ntl helpers (none at 16 tiles: the kernel in which every wavefront does everything)
+    const int st = ntl <= 9 ? launch_k<KS, 12>(x, packed, bcat, M, K, c, bases, weightings, stream, t0, ntl)
+                            : launch_k<KS, 16>(x, packed, bcat, M, K, c, bases, weightings, stream, t0, ntl);
     if (st != EGC_OK) return st;
     t0 += ntl;
   }

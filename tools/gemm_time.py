@@ -31,7 +31,7 @@ for n, fin, fout, H, B, A in shapes:
     for _ in range(5):
         F.egc_basis_transform(g, spec, x, wcat, bcat, planes)
     torch.cuda.synchronize()
-    reps = 40
+    reps = int(os.environ.get("EGC_REPS", "40"))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
