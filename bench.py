@@ -145,6 +145,29 @@ def cpu_baseline(ei, n, x, conv_state, runs=5):
     return out, best[0], best[1], int(cached[0].size(1))
 
 
+def cpu_leg(conv_cpu_state, x_cpu, ei_cpu, H, B, aggrs, e_eff, budget_s=12.0, max_runs=5):
+    """The CPU port on one of the side configs (same inputs as the GPU run): median of up to `max_runs` forwards within about
+    `budget_s` seconds, at the thread count the headline's baseline settled on (8: torch's scatter kernels do not scale
+    further).  Returns the cpu_baseline object and the port's output."""
+    from oracle.egc_cpu_port import egconv_forward_cpu
+    st = conv_cpu_state
+    threads = min(8, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    args = (x_cpu, ei_cpu, st["bases_weight"], st["comb_weight.weight"], st["comb_weight.bias"], st["bias"], H, B, aggrs)
+    t0 = time.perf_counter()
+    out, cached = egconv_forward_cpu(*args)                  # warm-up; builds the cached gcn_norm edge set
+    first = time.perf_counter() - t0
+    times = []
+    while len(times) < max_runs and (not times or sum(times) + first < budget_s):
+        t0 = time.perf_counter()
+        out, _ = egconv_forward_cpu(*args, cached=cached)
+        times.append(time.perf_counter() - t0)
+    med = statistics.median(times)
+    return {"value": e_eff / med, "unit": "edges/s", "cores": threads, "host_cores": os.cpu_count(), "kind": "port",
+            "sample": f"the full workload of this record, gcn_norm cached; median of {len(times)} forwards of {med * 1e3:.1f} ms on "
+                      f"{threads} torch threads"}, out
+
+
 def roofline_terms(n, e_eff, f_in, f_g, f_out, w_cols, symnorm):
     """SURVEY.md 8(d) bytes.  `aggregate_launch` = what the fused aggregate+combine launch must move by that
     model (weightings are "counted as fused (not materialised)"); `layer` = the survey's whole-layer figure."""
@@ -163,7 +186,9 @@ def measure_layer_config(name, ei_cpu, n, conv, f_in, dev, per_batch_csr, iters=
     launch that builds each tile's CSR in LDS and aggregates from LDS); the record's headline fields are the faster one's."""
     import egc_amd
     ei = ei_cpu.to(dev)
-    x = torch.randn(n, f_in, device=dev)
+    x_cpu = torch.randn(n, f_in)
+    x = x_cpu.to(dev)
+    state_cpu = {k: v.detach().clone() for k, v in conv.state_dict().items()}
     conv = conv.to(dev).eval()
     spec = conv._spec_coo
     e_in = int(ei.size(1))
@@ -242,11 +267,63 @@ def measure_layer_config(name, ei_cpu, n, conv, f_in, dev, per_batch_csr, iters=
                        layer_frac=pb["frac_survey_bytes"], edges_per_s_incl_csr=pb["edges_per_s"],
                        frac_incl_csr=pb["frac_survey_bytes"], frac_compulsory_bytes=pb["frac_compulsory_bytes"],
                        path=best + ": " + pb["path"])
+    # ---- the dominant kernel of this config against its own bytes, and the CPU port timed beside it ----
+    try:
+        with torch.no_grad():
+            if batch is not None and "fused" in rec and rec.get("path", "").startswith("fused"):
+                # the whole layer IS one kernel: its frac on SURVEY's bytes (a gather per edge credited) and on what it moves
+                key = rec["path"].split(":")[0]
+                ms_k = rec[key]["same_batch_ms"]
+                rec["roofline"] = {"bound": "hbm", "kernel": "egc::fused_tile_kernel (plan + GEMM + CSR + aggregate + combine)",
+                                   "achieved": t["layer"] / (ms_k * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": t["layer"] / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "frac_compulsory_bytes": rec["compulsory_bytes"] / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "launch_ms": ms_k, "traffic": None,
+                                   "note": "launch_ms includes the host's call (HIP events around module calls on one batch)"}
+                ref_out = conv(x, egc_amd.GraphBatch(ei, ptr=ptr, num_nodes=n, max_nodes=mx))
+            else:
+                from egc_amd import functional as Fn
+                wcat, bcat = conv._packed_weights()
+                planes = conv._weight_planes(spec, wcat)
+                bases, wts = Fn.egc_basis_transform(g, spec, x, wcat, bcat, planes)
+                agg_ms = time_region_median(lambda: Fn.egc_aggregate_combine(g, spec, bases, wts, conv.bias), iters, 3)
+                gemm_ms = time_region_median(lambda: Fn.egc_basis_transform(g, spec, x, wcat, bcat, planes), iters, 3)
+                agg_bytes = t["gather"] + t["col"] + t["rowptr"] + t["deg"] + t["out"]
+                rec["kernels_ms"] = {"basis_gemm": gemm_ms, "aggregate_combine": agg_ms}
+                rec["roofline"] = {"bound": "hbm", "kernel": "egc::agg_fast_kernel (fused aggregate+combine)",
+                                   "achieved": agg_bytes / (agg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": agg_bytes / (agg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "launch_ms": agg_ms, "traffic": None,
+                                   "gemm_frac": (n * 4 * (f_in + spec.ldb + spec.w_cols)) / (gemm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                ref_out = conv(x, g)
+        if not getattr(measure_layer_config, "no_cpu", False):
+            cb, cpu_out = cpu_leg(state_cpu, x_cpu, ei_cpu, conv.num_heads, conv.num_bases, list(conv.aggregators), e_eff)
+            cb["hip_vs_port_rel_err"] = float((ref_out.cpu() - cpu_out).abs().max() / max(1.0, float(cpu_out.abs().max())))
+            rec["cpu_baseline"] = cb
+    except Exception as ex:   # noqa: BLE001 -- a side figure never takes the record down
+        rec["roofline_error"] = repr(ex)[:300]
     log(f"  {name}: " + ", ".join(f"{k}={v:.4g}" if isinstance(v, float) else f"{k}={v}" for k, v in rec.items()
                                   if k != "workload"))
     del g, x, ei
     torch.cuda.empty_cache()
     return rec
+
+
+def training_step_bytes(n, e_eff, f_in=F_IN, f_out=F_OUT, ldb=64, w_cols=128, stat_k=3):
+    """What one training step of the north-star layer (forward + backward, config 2) has to move, pass by pass -- the
+    backward's counterpart of SURVEY.md 8(d)'s forward figure.  Per CSR entry the forward gathers one
+    basis row (ldb floats + a 4-byte index); the backward's source pass gathers, per transposed entry, the destination's two
+    gradient rows (sum-like and max-routed: 2 x ldb floats) and one 64-byte record (arg positions as bytes), plus its index."""
+    row = ldb * 4
+    t = {
+        "fwd_gemm": n * 4 * (f_in + ldb + w_cols),
+        "fwd_aggregate_train": e_eff * (row + 4) + n * 8 + n * 4 * (f_out + w_cols) + n * stat_k * row + n * (ldb + 4),
+        "bwd_destination": n * 4 * (f_out + w_cols + w_cols) + n * stat_k * row + n * 2 * row + e_eff * 64,
+        "bwd_source": e_eff * (2 * row + 64 + 4) + n * 8 + n * row,
+        "weight_gradient": n * 4 * (f_in + ldb + w_cols),
+        "dx_gemm": n * 4 * (ldb + w_cols + f_in),
+    }
+    t["total"] = sum(t.values())
+    return t
 
 
 def _north_star_layer():
@@ -319,8 +396,12 @@ def _oc_config2_training(out, dev, seed):
     for _ in range(3):
         fwd_bwd()
     ms = time_region_median(fwd_bwd, 10, 3)
+    tb = training_step_bytes(n, int(ei.size(1)) + n)
     out["config2_training_step"] = {"workload": "config 2, forward + backward of one EGConv layer through autograd (gradients cleared every step)",
-                                    "step_ms": ms, "edges_per_s": (int(ei.size(1)) + n) / (ms * 1e-3)}
+                                    "step_ms": ms, "edges_per_s": (int(ei.size(1)) + n) / (ms * 1e-3),
+                                    "algorithmic_bytes": tb, "step_frac": tb["total"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "note": "byte model of DESIGN.md section 5 (what each pass has to move; per-kernel times: "
+                                            "profiles/r04_training_step_kernel_stats.csv)"}
     log(f"  training step (config 2): {ms:.4f} ms")
     # the reference nets' block (zinc/models.py:66-72): conv -> BatchNorm1d (batch statistics) -> ReLU -> + input
     bn = torch.nn.BatchNorm1d(F_OUT).to(dev)
@@ -526,6 +607,14 @@ def main():
                                              spec.w_cols, bases.data_ptr(), ldb, weightings.data_ptr(), stream),
                  "egc_basis_transform_f32")
 
+    nb24 = lib.egc_basis_pack_bytes(F_IN, spec.f_g, spec.w_cols)
+    planes24 = torch.empty(nb24, dtype=torch.uint8, device=dev)
+    _C.check(lib.egc_basis_pack_ex(wcat.data_ptr(), F_IN, spec.f_g, spec.w_cols, 1, planes24.data_ptr(), nb24, stream), "egc_basis_pack_ex")
+
+    def gemm_24bit_only():   # the 24-bit-operand form (EGC_GEMM_24BIT: three bf16 planes per operand), for the side field
+        _C.check(lib.egc_basis_transform_packed_ex(x.data_ptr(), planes24.data_ptr(), bcat.data_ptr(), n, F_IN, spec.f_g, spec.w_cols, 1,
+                                                   bases.data_ptr(), ldb, weightings.data_ptr(), stream), "egc_basis_transform_packed_ex")
+
     def agg_only():
         _C.check(lib.egc_aggregate_combine_f32(C.byref(g), C.byref(spec.c), bases.data_ptr(), ldb,
                                                weightings.data_ptr(), bias.data_ptr(), out.data_ptr(), None, None,
@@ -549,6 +638,7 @@ def main():
     agg_ms = time_region(agg_only, reps)
     gemm_ms = time_region(gemm_only, reps)
     gemm_exact_ms = time_region(gemm_exact_only, 20)
+    gemm_24bit_ms = time_region(gemm_24bit_only, 20)
     gemm_only()  # leave the split-precision intermediates in place
     step_ms_events = time_region(step, reps)
 
@@ -563,6 +653,15 @@ def main():
     elapsed = time.perf_counter() - t0
     ms_per_step = elapsed / args.steps * 1e3
     value = float(e_eff) / (elapsed / args.steps)
+    # robustness of the headline (not part of its definition): four more regions of the same length, the median of the five
+    regions = [ms_per_step]
+    for _ in range(4):
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync_all()
+        regions.append((time.perf_counter() - t0) / args.steps * 1e3)
 
     terms = roofline_terms(n, e_eff, F_IN, spec.f_g, F_OUT, spec.w_cols, symnorm=True)
     agg_bytes = terms["aggregate_launch"]
@@ -598,10 +697,18 @@ def main():
                      "note": "SURVEY.md 8(d): gather + col + rowptr + deg + out of the launch; the materialised "
                              "weightings it also reads are waste, not algorithmic bytes"},
         "kernels_ms": {"basis_gemm": gemm_ms, "aggregate_combine": agg_ms, "layer_forward": step_ms_events,
-                       "basis_gemm_exact_fp32": gemm_exact_ms, "layer_forward_gemm_exact_fp32": gemm_exact_ms + agg_ms},
+                       "basis_gemm_exact_fp32": gemm_exact_ms, "layer_forward_gemm_exact_fp32": gemm_exact_ms + agg_ms,
+                       "basis_gemm_24bit": gemm_24bit_ms, "layer_forward_gemm_24bit": gemm_24bit_ms + agg_ms},
         "layer_algorithmic_bytes": terms["layer"],
         "layer_achieved_gbs": terms["layer"] / (step_ms_events * 1e-3) / 1e9,
         "layer_frac": terms["layer"] / (step_ms_events * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        # the precision / speed trade of the GEMM, on the line: the default (fp16x2: 22-bit operands, componentwise error 1.3e-7
+        # against float64 -- below the fp32-MFMA kernel's 3.2e-7, tests/test_gemm_gpu.py), the 24-bit-operand form that std / var
+        # layers take (bf16x3), the plain fp32-MFMA kernel
+        "layer_frac_by_gemm": {"fp16x2_default": terms["layer"] / (step_ms_events * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "bf16x3_24bit": terms["layer"] / ((gemm_24bit_ms + agg_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "exact_fp32_mfma": terms["layer"] / ((gemm_exact_ms + agg_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        "ms_per_step_regions": regions, "ms_per_step_median_of_5_regions": sorted(regions)[2],
     }
 
     # ---- the fused-weightings launch (opt-in, see egc_aggregate_fusedw.hip): measured here so
@@ -638,6 +745,7 @@ def main():
         log(f"  {k:18s} {v / 1e6:10.2f} MB")
     log(f"kernel ms: gemm {gemm_ms:.4f} (exact fp32: {gemm_exact_ms:.4f})  aggregate+combine {agg_ms:.4f}  layer {step_ms_events:.4f}")
     out_main = out.clone()
+    measure_layer_config.no_cpu = bool(args.no_cpu_baseline)
     if not args.no_other_configs:
         log("other configs:")
         result["other_configs"] = other_configs(dev, args.seed)

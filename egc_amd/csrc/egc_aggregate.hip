@@ -902,6 +902,7 @@ int egc_aggregate_combine_batch_f32(const int32_t* tiles, const int32_t* n_tiles
   if (post != nullptr && ((post->scale == nullptr) != (post->shift == nullptr))) return EGC_ERR_INVALID;
   if (!a.loops_all && max_index == nullptr) return EGC_ERR_INVALID;
   if ((uint64_t)n_nodes * (uint64_t)ldb * 4ull > (uint64_t)OOB) return EGC_ERR_UNSUPPORTED;
+  if ((uint64_t)n_nodes * (uint64_t)a.F_out * 4ull > (uint64_t)OOB) return EGC_ERR_UNSUPPORTED;   // out / residual descriptors
   a.ldw = ldw > 0 ? ldw : a.W;
   if (a.ldw != a.W && (a.ldw < a.W || (a.ldw & 3) != 0 || (reinterpret_cast<uintptr_t>(weightings) & 15) != 0)) return EGC_ERR_INVALID;
   a.n_nodes = (int)n_nodes;

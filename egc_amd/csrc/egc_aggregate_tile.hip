@@ -46,6 +46,7 @@ constexpr int TILE_EDGE_REGS = 6;       // edges per thread kept in registers be
 struct TileArgs {
   const int4* tiles;       // (n0, n1, e0, e1) per non-empty tile, compacted (any order)
   const int* n_tiles;      // device scalar: how many
+  int n_tiles_cap;         // records the list holds (a plan of malformed offsets counts more: reported, the excess ignored)
   const int64_t* src;      // edge_index[0]
   const int64_t* dst;      // edge_index[1]
   const int* max_index;    // device scalar (layers with loops_all == 0), or nullptr
@@ -109,7 +110,10 @@ __global__ void __launch_bounds__(256) tile_plan_kernel(const int64_t* __restric
   int n1 = (int)__shfl(nd, 32), e1 = (int)__shfl(ed, 32);
   n1 = n1 < n0 ? n0 : n1;
   e1 = e1 < e0 ? e0 : e1;
-  if (lane == 0 && (n1 > n0 || e1 > e0)) tiles[atomicAdd(count, 1)] = int4{n0, n1, e0, e1};
+  if (lane == 0 && (n1 > n0 || e1 > e0)) {
+    const int i = atomicAdd(count, 1);
+    if (i < n_slots) tiles[i] = int4{n0, n1, e0, e1};
+  }
 }
 
 // The same tiles from the GRAPH side, when the caller supplies the graphs' edge offsets: one thread per graph; a graph
@@ -117,7 +121,7 @@ __global__ void __launch_bounds__(256) tile_plan_kernel(const int64_t* __restric
 // one round of loads (against the eight dependent probes of the search form).
 __global__ void __launch_bounds__(256) tile_plan_graphs_kernel(const int64_t* __restrict__ ptr, const int64_t* __restrict__ edge_ptr,
                                                                int64_t n_graphs, int64_t n_edges, int64_t n_nodes, int slot,
-                                                               int4* __restrict__ tiles, int* __restrict__ count) {
+                                                               int4* __restrict__ tiles, int* __restrict__ count, int n_slots) {
   const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (g >= n_graphs) return;
   const int64_t p0 = ptr[g];
@@ -144,7 +148,12 @@ __global__ void __launch_bounds__(256) tile_plan_graphs_kernel(const int64_t* __
   int64_t e1 = end >= n_graphs ? n_edges : clampe(edge_ptr[end]);
   n1 = n1 < n0 ? n0 : n1;
   e1 = e1 < e0 ? e0 : e1;
-  if (n1 > n0 || e1 > e0) tiles[atomicAdd(count, 1)] = int4{(int)n0, (int)n1, (int)e0, (int)e1};
+  // A well-formed (non-decreasing) ptr yields at most one head per slot; offsets that jump back and forth make almost
+  // every graph a head: the list holds n_slots records and no more (the tile kernel reports the batch: *count > n_slots).
+  if (n1 > n0 || e1 > e0) {
+    const int i = atomicAdd(count, 1);
+    if (i < n_slots) tiles[i] = int4{(int)n0, (int)n1, (int)e0, (int)e1};
+  }
 }
 
 template <int LPR_LOG2, class C>
@@ -182,7 +191,11 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
   const int g = lane >> LPR_LOG2;
   const int q = lane & (LPR - 1);
   const int F_out = C::F_out(a);
-  const int n_tiles = *t.n_tiles;
+  int n_tiles = *t.n_tiles;
+  if (n_tiles > t.n_tiles_cap) {       // graph offsets that are not non-decreasing (egc_batch_plan): code 1, like a bad edge
+    if (tid == 0 && blockIdx.x == 0) { atomicOr(t.status, 1); if (t.host_flag != nullptr) *(volatile int32_t*)t.host_flag = 1; }
+    n_tiles = t.n_tiles_cap;
+  }
   int k = blockIdx.x;
   if (k >= n_tiles) return;
   int4 tl = t.tiles[k];
@@ -255,8 +268,12 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
     const int n0 = tl.x, T = tl.y - tl.x, e0 = tl.z, Et = tl.w - tl.z;
     const bool has_next = k + (int)gridDim.x < n_tiles;
     if (has_next) tl = t.tiles[k + gridDim.x];   // the next tile's record, long before it is needed
-    if (T <= 0 || T > t.tmax || Et > t.emax) {   // edges without rows / beyond the CSR areas: report, leave the rows unwritten
-      if (tid == 0) tile_error(t, T <= 0 ? 1 : 2);
+    if (T <= 0 || T > t.tmax || Et > t.emax) {   // edges without rows / beyond the CSR areas: report; the rows become zeros, not
+      if (tid == 0) tile_error(t, T <= 0 ? 1 : 2);   // whatever the allocation held (the caller may read `out` before it checks)
+      if (T > 0) {
+        const int64_t lo = (int64_t)n0 * F_out, hi = (int64_t)(n0 + T > a.n_nodes ? a.n_nodes : n0 + T) * F_out;
+        for (int64_t i = lo + tid; i < hi; i += TILE_THREADS) a.out[i] = 0.f;
+      }
       continue;
     }
     const bool in_lds = T <= t.tlds;             // the tile's basis rows fit LDS (else: gathered from memory)
@@ -538,7 +555,7 @@ int launch_tile_simple(AggArgs a, const int4* tiles, const int* n_tiles_dev, int
                        const int64_t* src, const int64_t* dst, const int* max_index, int32_t* status, int32_t* host_flag,
                        hipStream_t stream) {
   TileArgs t = {};
-  t.tiles = tiles; t.n_tiles = n_tiles_dev; t.src = src; t.dst = dst; t.max_index = max_index; t.status = status;
+  t.tiles = tiles; t.n_tiles = n_tiles_dev; t.n_tiles_cap = n_tiles_bound; t.src = src; t.dst = dst; t.max_index = max_index; t.status = status;
   t.host_flag = host_flag;
   t.tlds = tlds; t.tmax = tmax; t.emax = emax;
   return launch_tile(a, t, n_tiles_bound, stream);
@@ -549,7 +566,7 @@ int launch_tile_plan(const int64_t* ptr, int64_t n_graphs, const int64_t* dst, i
   EGC_HIP_TRY(hipMemsetAsync(count, 0, sizeof(int), stream));
   if (edge_ptr != nullptr && n_graphs > 0) {
     tile_plan_graphs_kernel<<<(unsigned)((n_graphs + 255) / 256), 256, 0, stream>>>(ptr, edge_ptr, n_graphs, n_edges, n_nodes, slot,
-                                                                                tiles, count);
+                                                                                tiles, count, n_slots);
     EGC_LAUNCH_CHECK("tile_plan_graphs_kernel");
     return EGC_OK;
   }

@@ -634,7 +634,15 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
     const Tile cur = read_tile(it % 3);
     if (!cur.valid) break;
     const int n0 = cur.n0, T = cur.T, nch = cur.nch;
-    if (!cur.ok && (T > 0 || cur.Et > 0) && tid == 0) ft_error(t, T <= 0 ? 1 : 2);
+    if (!cur.ok && (T > 0 || cur.Et > 0)) {
+      if (tid == 0) ft_error(t, T <= 0 ? 1 : 2);
+      // a tile beyond the LDS image is reported and its rows become zeros, not whatever the allocation held (the caller may
+      // read `out` before it checks the status)
+      if (T > 0) {
+        const int64_t lo = (int64_t)n0 * F_out, hi = (int64_t)(n0 + T > a.n_nodes ? a.n_nodes : n0 + T) * F_out;
+        for (int64_t i = lo + tid; i < hi; i += FT_WORKER_THREADS) a.out[i] = 0.f;
+      }
+    }
     // this tile's CSR (built by wavefront 14 during the previous tile's rows phase)
     char* cb = base + (it & 1) * t.csr_stride;
     const unsigned short* lds_col = reinterpret_cast<const unsigned short*>(cb + t.off_col);

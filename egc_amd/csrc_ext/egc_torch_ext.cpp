@@ -10,6 +10,7 @@
 // owners (CSRGraph.c_struct(), LayerSpec.c); they travel as integer addresses, the stream as the raw hipStream_t the
 // ctypes path uses as well (torch._C._cuda_getCurrentRawStream).
 #include <ATen/ATen.h>
+#include <c10/core/DeviceGuard.h>
 #include <torch/library.h>
 
 #include <algorithm>
@@ -30,6 +31,24 @@ void check_status(int st, const char* what) {
   TORCH_CHECK(st == EGC_OK, "egc_amd: ", what, " failed with status ", st, " (", egc_last_error(), ")");
 }
 
+// Shapes of the optional operands and the workspace (the ctypes path checks them in Python; here a wrong-sized scale or
+// residual would be read out of bounds on the device), and the device the pointers live on.
+static void check_vec(const c10::optional<at::Tensor>& t, int64_t n, const char* what, const at::Tensor& x) {
+  if (!t.has_value()) return;
+  check_f32(*t, what);
+  TORCH_CHECK(t->numel() == n && t->device() == x.device(), "egc_amd: ", what, " must hold ", n, " floats on x's device");
+}
+static void check_layer_operands(const at::Tensor& x, const egc_graph* g, const egc_layer* l, const at::Tensor& packed,
+                                 const c10::optional<at::Tensor>& bcat, const c10::optional<at::Tensor>& bias,
+                                 const at::Tensor& workspace, int64_t ldb, int64_t w_cols, int64_t f_out) {
+  TORCH_CHECK(f_out == l->out_channels && ldb == egc_bases_ld(l) && w_cols == (int64_t)l->num_heads * l->num_bases * l->num_aggrs,
+              "egc_amd: ldb / w_cols / f_out do not belong to this layer");
+  check_vec(bcat, w_cols, "bcat", x);
+  check_vec(bias, f_out, "bias", x);
+  TORCH_CHECK(packed.device() == x.device() && workspace.device() == x.device(), "egc_amd: packed weights / workspace on another device");
+  TORCH_CHECK((size_t)workspace.numel() >= egc_aggregate_workspace_bytes_for(l, g), "egc_amd: workspace too small for this graph and layer");
+}
+
 // out = layer(x) -- basis GEMM (split-precision planes `packed`) + fused aggregate/combine, two launches, one call
 at::Tensor layer_forward(const at::Tensor& x, const at::Tensor& packed, const c10::optional<at::Tensor>& bcat,
                          const c10::optional<at::Tensor>& bias, int64_t graph, int64_t layer, const at::Tensor& workspace,
@@ -38,6 +57,8 @@ at::Tensor layer_forward(const at::Tensor& x, const at::Tensor& packed, const c1
   const auto* g = reinterpret_cast<const egc_graph*>(graph);
   const auto* l = reinterpret_cast<const egc_layer*>(layer);
   TORCH_CHECK(x.dim() == 2 && x.size(0) == g->n_nodes && x.size(1) == l->in_channels, "egc_amd: x has the wrong shape");
+  check_layer_operands(x, g, l, packed, bcat, bias, workspace, ldb, w_cols, f_out);
+  const c10::OptionalDeviceGuard device_guard(x.device());   // (allocations below on x's device whatever the current one is)
   const int64_t n = x.size(0);
   const auto opts = x.options();
   at::Tensor bases = at::empty({n, ldb}, opts), weightings = at::empty({n, w_cols}, opts), out = at::empty({n, f_out}, opts);
@@ -59,7 +80,12 @@ at::Tensor layer_forward_post(const at::Tensor& x, const at::Tensor& packed, con
   const auto* g = reinterpret_cast<const egc_graph*>(graph);
   const auto* l = reinterpret_cast<const egc_layer*>(layer);
   TORCH_CHECK(x.dim() == 2 && x.size(0) == g->n_nodes && x.size(1) == l->in_channels, "egc_amd: x has the wrong shape");
-  if (residual.has_value()) check_f32(*residual, "post.residual");
+  check_layer_operands(x, g, l, packed, bcat, bias, workspace, ldb, w_cols, f_out);
+  check_vec(scale, f_out, "post.scale", x);
+  check_vec(shift, f_out, "post.shift", x);
+  check_vec(residual, x.size(0) * f_out, "post.residual", x);
+  TORCH_CHECK(scale.has_value() == shift.has_value(), "egc_amd: post.scale and post.shift come together");
+  const c10::OptionalDeviceGuard device_guard(x.device());   // (allocations below on x's device whatever the current one is)
   const int64_t n = x.size(0);
   const auto opts = x.options();
   at::Tensor bases = at::empty({n, ldb}, opts), weightings = at::empty({n, w_cols}, opts), out = at::empty({n, f_out}, opts);

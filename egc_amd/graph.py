@@ -67,8 +67,10 @@ class _IndexFlag:
     def poll(cls):
         if cls._view is not None and cls._view.value != 0:
             cls._view.value = 0
-            raise RuntimeError("egc_amd: an edge_index handed to an earlier graph build holds node ids outside "
-                               "[0, num_nodes): index out of range (those edges were dropped)")
+            raise RuntimeError("egc_amd: an earlier call reported malformed graph input: an edge_index with node ids outside "
+                               "[0, num_nodes): index out of range (those edges were dropped) -- or, for a GraphBatch, edges that "
+                               "leave their graph / a graph larger than max_nodes (its rows were written as zeros; "
+                               "GraphBatch.check() tells which)")
 
 
 def _require_cuda(t: torch.Tensor, what: str):
@@ -451,7 +453,8 @@ class GraphBatch:
         x = conv(x, gb)                                                                         # num_graphs=batch.num_graphs
 
     Requirements (checked on the device, reported like an out-of-range index -- a RuntimeError at the next call into the
-    package at the latest): graphs are numbered one after the other and the edges of one graph are contiguous in
+    package at the latest; call ``gb.check()`` after the last layer of a batch to get it at once, with the cause; the rows
+    of a tile that is reported are written as ZEROS, never left uninitialised): graphs are numbered one after the other and the edges of one graph are contiguous in
     ``edge_index`` (PyG's collation); a tile (a run of graphs of about ``slot`` nodes + one graph) fits the LDS areas.
     ``max_nodes``: an upper bound of the largest graph's node count (default 256) -- it sizes the per-tile CSR areas;
     tiles whose basis rows exceed the LDS area (a run of unusually large graphs) gather from memory instead, tiles beyond

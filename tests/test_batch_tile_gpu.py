@@ -234,3 +234,60 @@ def test_malformed_batches_are_reported():
         conv(x, ei.to(dev))
     with torch.no_grad():
         conv(x, ei.to(dev))
+
+
+def test_non_monotone_graph_offsets_cannot_overrun_the_tile_list():
+    """with edge_ptr the plan writes one record per tile HEAD; graph offsets that jump back and forth make nearly
+    every graph a head -- more heads than the list has records.  The plan stops at the list's capacity, the tile kernel
+    reports the batch, and nothing outside the list is written (a canary behind it stays intact)."""
+    import ctypes as C
+    import egc_amd
+    from egc_amd import _C
+    dev = _dev()
+    lib = _C.load()
+    n, n_graphs, slot = 4000, 200, 100
+    ptr = torch.zeros(n_graphs + 1, dtype=torch.int64)
+    ptr[1::2] = 3000                                      # 0, 3000, 0, 3000, ...: every graph starts in another slot than its predecessor
+    ptr[-1] = n
+    eptr = torch.zeros(n_graphs + 1, dtype=torch.int64)
+    n_slots = (n + slot - 1) // slot
+    buf = torch.full((4 * n_slots + 4 + 64,), -7, dtype=torch.int32, device=dev)
+    tiles, count, canary = buf[:4 * n_slots], buf[4 * n_slots:4 * n_slots + 4], buf[4 * n_slots + 4:]
+    dst = torch.zeros(1, dtype=torch.int64, device=dev)
+    _C.check(lib.egc_batch_plan(ptr.to(dev).data_ptr(), eptr.to(dev).data_ptr(), n_graphs, dst.data_ptr(), 0, n, slot,
+                                tiles.data_ptr(), n_slots, count.data_ptr(), torch.cuda.current_stream().cuda_stream), "egc_batch_plan")
+    torch.cuda.synchronize()
+    assert int(count[0]) > n_slots                         # more heads than records ...
+    assert bool((canary == -7).all()) and bool((count[1:] == -7).all())   # ... and none written past the list
+    # through the layer: reported, not silently wrong
+    ei, _, _ = _messy_batch(12, n_graphs=60)
+    gb = egc_amd.GraphBatch(torch.zeros((2, 0), dtype=torch.int64, device=dev), ptr=ptr.to(dev), num_nodes=n, max_nodes=90,
+                            edge_ptr=eptr.to(dev))
+    conv = _layer("opt", 128, 8, 4, ["sum", "mean", "max", "symnorm"]).to(dev).eval()
+    with torch.no_grad():
+        conv(torch.randn(n, 128, device=dev), gb)
+    with pytest.raises(RuntimeError):
+        gb.check()
+
+
+def test_rows_of_a_reported_tile_are_zero_not_garbage():
+    import egc_amd
+    dev = _dev()
+    ei, n, ptr = _messy_batch(12, n_graphs=60)
+    conv = _layer("opt", 128, 8, 4, ["sum", "mean", "max", "symnorm"]).to(dev).eval()
+    x = torch.randn(n, 128, device=dev)
+    big_ptr = torch.tensor([0, n])                          # one "graph" far beyond max_nodes
+    for env in ("0", "1"):
+        import os
+        os.environ["EGC_NO_FUSED_TILE"] = env
+        try:
+            gb = egc_amd.GraphBatch(ei.to(dev), ptr=big_ptr.to(dev), max_nodes=16)
+            junk = torch.full((n, 128), float("nan"), device=dev)       # make sure the allocator hands out non-zero memory
+            del junk
+            with torch.no_grad():
+                out = conv(x, gb)
+            with pytest.raises(RuntimeError, match="exceeds the"):
+                gb.check()
+            assert bool((out == 0).all())
+        finally:
+            os.environ.pop("EGC_NO_FUSED_TILE", None)
