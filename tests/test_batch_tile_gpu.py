@@ -254,7 +254,8 @@ def test_non_monotone_graph_offsets_cannot_overrun_the_tile_list():
     buf = torch.full((4 * n_slots + 4 + 64,), -7, dtype=torch.int32, device=dev)
     tiles, count, canary = buf[:4 * n_slots], buf[4 * n_slots:4 * n_slots + 4], buf[4 * n_slots + 4:]
     dst = torch.zeros(1, dtype=torch.int64, device=dev)
-    _C.check(lib.egc_batch_plan(ptr.to(dev).data_ptr(), eptr.to(dev).data_ptr(), n_graphs, dst.data_ptr(), 0, n, slot,
+    ptr_d, eptr_d = ptr.to(dev), eptr.to(dev)              # (kept alive across the call: the C ABI takes raw pointers)
+    _C.check(lib.egc_batch_plan(ptr_d.data_ptr(), eptr_d.data_ptr(), n_graphs, dst.data_ptr(), 0, n, slot,
                                 tiles.data_ptr(), n_slots, count.data_ptr(), torch.cuda.current_stream().cuda_stream), "egc_batch_plan")
     torch.cuda.synchronize()
     assert int(count[0]) > n_slots                         # more heads than records ...
