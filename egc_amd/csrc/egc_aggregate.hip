@@ -478,6 +478,17 @@ static int launch_all(const AggArgs& a, int64_t n_nodes, const PlanCaps& caps, i
   return EGC_OK;
 }
 
+#ifndef EGC_WITH_FUSEDW
+// The launch with the weightings Linear inside (egc_aggregate_fusedw.hip, SURVEY.md 8f rank 3 on the FULL graph) measured
+// 1.56 x slower than the two-launch path on MI355X (round 3: 218 against 140 us) and is not part of the default library:
+// build with EGC_WITH_FUSEDW=1 (egc_amd/csrc/build.sh) to get it.  Without it the entry points report "unsupported"
+// (egc_fused_supported() == 0).  For batches of whole graphs the fusion IS the default: egc_fused_tile.hip.
+bool fusedw_supported(const AggArgs&, int) { return false; }
+size_t fusedw_pack_floats(int, int) { return 0; }
+int fusedw_pack(const float*, const float*, int, int, int, int, int, float*, hipStream_t) { return EGC_ERR_UNSUPPORTED; }
+int launch_fusedw(AggArgs, const PlanCaps&, hipStream_t) { return EGC_ERR_UNSUPPORTED; }
+#endif
+
 }  // namespace egc
 
 using namespace egc;

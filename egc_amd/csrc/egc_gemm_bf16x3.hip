@@ -588,17 +588,14 @@ size_t egc_basis_pack_bytes(int32_t f_in, int32_t f_g, int32_t w_cols) {
   const int ldb = (f_g + 3) & ~3;
   const int NV = round_up32(ldb + w_cols);
   const int KS = (f_in + XKT - 1) / XKT;
-  return std::max(std::max(std::max((size_t)KS * 3 * NV * XKT * sizeof(u16), f16x2_pack_bytes(KS, NV)),
-                           f16x2k_pack_bytes(f_in, f_g, ldb, w_cols)), f16x2w_pack_bytes(f_in, f_g, ldb, w_cols));
+  return std::max(std::max((size_t)KS * 3 * NV * XKT * sizeof(u16), f16x2_pack_bytes(KS, NV)),
+                  f16x2k_pack_bytes(f_in, f_g, ldb, w_cols));
 }
 
 // flags & EGC_GEMM_24BIT: operands split into THREE bf16 planes (24 significand bits: nothing of an fp32 operand is
 // dropped) whatever the shape -- the fp16x2 forms keep 22 bits, which layers with std / var amplify (egc_hip.h)
 static bool use_f16x2(int f_in, int ldb, int NV, int flags) {
   return (flags & EGC_GEMM_24BIT) == 0 && f16x2_shape(f_in, ldb, NV) && getenv("EGC_GEMM_BF16X3") == nullptr;
-}
-static bool use_f16x2w(int f_in, int f_g, int ldb, int w_cols, int flags) {
-  return (flags & EGC_GEMM_24BIT) == 0 && f16x2w_shape(f_in, f_g, ldb, w_cols);
 }
 static bool use_f16x2k(int f_in, int f_g, int ldb, int w_cols, int flags) {
   return (flags & EGC_GEMM_24BIT) == 0 && f16x2k_shape(f_in, f_g, ldb, w_cols);
@@ -612,7 +609,6 @@ static int basis_pack_strided(const float* wcat, int64_t rs, int64_t cs, int32_t
   const int NV = round_up32(ldb + w_cols);
   const int KS = (f_in + XKT - 1) / XKT;
   if (use_f16x2(f_in, ldb, NV, flags)) return f16x2_pack(wcat, rs, cs, f_in, f_g, w_cols, ldb, NV, KS, packed, stream);
-  if (use_f16x2w(f_in, f_g, ldb, w_cols, flags)) return f16x2w_pack(wcat, rs, cs, f_in, f_g, ldb, w_cols, packed, stream);
   if (use_f16x2k(f_in, f_g, ldb, w_cols, flags)) return f16x2k_pack(wcat, rs, cs, f_in, f_g, ldb, w_cols, packed, stream);
   const int total = KS * NV * XKT;
   pack_bf16x3_kernel<<<(total + 255) / 256, 256, 0, stream>>>(wcat, rs, cs, f_in, f_g, w_cols, ldb, NV, KS, (u16*)packed);
@@ -653,8 +649,6 @@ int egc_basis_transform_packed_ex(const float* x, const void* packed, const floa
   const int KS = (f_in + XKT - 1) / XKT;
   if (use_f16x2(f_in, ldb, NV, flags))  // the planes were packed for this kernel: no other form can read them
     return f16x2_launch(x, packed, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, stream);
-  if (use_f16x2w(f_in, f_g, ldb, w_cols, flags))  // likewise (32 columns per wavefront)
-    return f16x2w_launch(x, packed, bcat, n_nodes, f_in, f_g, ldb, w_cols, bases, weightings, stream);
   if (use_f16x2k(f_in, f_g, ldb, w_cols, flags))  // likewise: its planes are in its own fragment order
     return f16x2k_launch(x, packed, bcat, n_nodes, f_in, f_g, ldb, w_cols, bases, weightings, stream);
   if (f_in <= 128 && NV <= 256 && getenv("EGC_GEMM_NO_WS") == nullptr) {  // weight-stationary form (<= 8 wavefronts)

@@ -29,13 +29,4 @@ int f16x2k_pack(const float* wcat, int64_t rs, int64_t cs, int f_in, int f_g, in
 int f16x2k_launch(const float* x, const void* packed, const float* bcat, int64_t M, int K, int f_g, int ldb, int W,
                   float* bases, float* weightings, hipStream_t stream);
 
-// Shapes served by the 32-columns-per-wavefront fp16x2 kernel (egc_gemm_f16x2w.hip, round 3): 128 < F_in <= 352, at most
-// 16 column tiles of 32; preferred over the 16-column kernel where both apply.
-bool f16x2w_shape(int f_in, int f_g, int ldb, int w_cols);
-size_t f16x2w_pack_bytes(int f_in, int f_g, int ldb, int w_cols);
-int f16x2w_pack(const float* wcat, int64_t rs, int64_t cs, int f_in, int f_g, int ldb, int w_cols, void* packed,
-                hipStream_t stream);
-int f16x2w_launch(const float* x, const void* packed, const float* bcat, int64_t M, int K, int f_g, int ldb, int W,
-                  float* bases, float* weightings, hipStream_t stream);
-
 }  // namespace egc

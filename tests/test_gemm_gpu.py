@@ -276,36 +276,6 @@ def test_pack_transposed_equals_pack(f_in, f_g, w_cols):
     assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("n", [1, 31, 32, 33, 1000, 16391])
-@pytest.mark.parametrize("f_in,f_g,w_cols", [
-    (352, 176, 32),   # ogbn-mag layer: 7 column tiles of 32 (the last bases tile half used), KS16 = 22
-    (300, 300, 48),   # ogbg-code EGC-M: 12 tiles = two launches of 6; F_in % 16 != 0 (zero pieces behind the row)
-    (136, 136, 48),   # arxiv EGC-M; F_in % 8 == 0 (row padded to an odd number of pieces)
-    (192, 124, 0),    # d x GEMM of a training step (no weightings block), two workgroups per CU
-    (148, 33, 7),     # ragged everything
-])
-def test_thirty_two_column_long_k_kernel(n, f_in, f_g, w_cols, monkeypatch):
-    """egc_gemm_f16x2w.hip (32 columns per wavefront, in-place split; opt-in: not faster than the 16-column kernel,
-    DESIGN.md 3.2b) keeps the numerics of the other fp16x2 kernels: same componentwise bound against float64, rows of
-    wildly different magnitude, row ranges launched separately."""
-    monkeypatch.setenv("EGC_GEMM_F16X2W", "1")
-    torch.manual_seed(n + f_in)
-    x = torch.randn(n, f_in, device=DEV)
-    if n > 40:
-        x[3] *= 1e-30
-        x[7] *= 1e25
-        x[11] = 0
-    wcat = torch.randn(f_in, f_g + w_cols, device=DEV)
-    wcat[:, 1] *= 1e-20
-    bcat = torch.randn(max(w_cols, 1), device=DEV)[:w_cols]
-    bases, wt = _transform(x, wcat, bcat, f_g, w_cols)
-    _check(x, wcat, bcat, f_g, w_cols, bases, wt)
-    if n == 16391:
-        monkeypatch.setenv("EGC_GEMM_MAX_ROWS", "4096")
-        b2, w2 = _transform(x, wcat, bcat, f_g, w_cols)
-        assert torch.equal(bases, b2) and torch.equal(wt, w2)
-
-
 @pytest.mark.parametrize("n", [5, 1000, 40001])
 @pytest.mark.parametrize("f_in,H,A,B,L,Ls,permute,n_parts", [
     (128, 8, 4, 4, 16, 16, True, 1),      # EGConv north star: one [F_in, B L] basis matrix, Linear rows [h][a][b]

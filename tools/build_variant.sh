@@ -8,7 +8,7 @@ H=$ROOT/egc_amd/csrc
 N=$1; S=$2; F=${3:-}
 mkdir -p $H/obj/var_$N
 extra=""
-{ [ "$S" = egc_gemm_f16x2 ] || [ "$S" = egc_gemm_f16x2k ] || [ "$S" = egc_gemm_f16x2w ]; } && extra="-fno-slp-vectorize"
+{ [ "$S" = egc_gemm_f16x2 ] || [ "$S" = egc_gemm_f16x2k ]; } && extra="-fno-slp-vectorize"
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -ffp-contract=off -I$ROOT/include -I$H -Wall -Wno-unused-function -Wno-pass-failed $extra $F -c $H/$S.hip -o $H/obj/var_$N/$S.o
 objs=""
 for o in $H/obj/*.o; do b=$(basename $o .o); if [ "$b" = "$S" ]; then objs="$objs $H/obj/var_$N/$S.o"; else objs="$objs $o"; fi; done
