@@ -52,6 +52,22 @@ def main():
         f = os.path.join(src, name, "pmc_counter_collection.csv")
         if os.path.exists(f):
             condense(f, os.path.join(dst, f"{tag}_{out}.csv"))
+    # round 4: the one-launch batch layer and the long-k GEMM
+    for w in ("molhiv", "cifar", "zinc"):
+        if os.path.exists(os.path.join(src, f"fused_{w}/kt_kernel_stats.csv")):
+            cp(f"fused_{w}/kt_kernel_stats.csv", f"{tag}_fused_tile_{w}_kernel_stats.csv")
+            cp(f"fused_{w}.log", f"{tag}_fused_tile_{w}.log")
+    for name in ("pmc_fused_molhiv_fetch", "pmc_fused_molhiv_write", "pmc_fused_cifar_fetch", "pmc_fused_cifar_write", "pmc_fused_sq",
+                 "pmc_fused_lds", "pmc_magk_fetch", "pmc_magk_write", "pmc_magk_sq"):
+        f = os.path.join(src, name, "pmc_counter_collection.csv")
+        if os.path.exists(f):
+            condense(f, os.path.join(dst, f"{tag}_{name}.csv"))
+    if os.path.exists(os.path.join(src, "magk/kt_kernel_stats.csv")):
+        cp("magk/kt_kernel_stats.csv", f"{tag}_mag_gemm_kernel_stats.csv")
+        cp("magk.log", f"{tag}_mag_gemm.log")
+    for name in ("gemm_error", "gemm_time_wide"):
+        if os.path.exists(os.path.join(src, name + ".log")):
+            cp(name + ".log", f"{tag}_{name}.log")
     if os.path.exists(os.path.join(src, "host_overhead.log")):
         cp("host_overhead.log", f"{tag}_host_overhead.log")
     for name in ("reference_shapes", "gemm_time"):
