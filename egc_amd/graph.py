@@ -690,6 +690,23 @@ def graph_from_input(edge_index, num_nodes: int, static: bool = False) -> CSRGra
         return edge_index
     if isinstance(edge_index, SparseTensor):
         return edge_index.graph
+    if not isinstance(edge_index, torch.Tensor) and callable(getattr(edge_index, "csr", None)):
+        # a real ``torch_sparse.SparseTensor`` (mag/configs.py:84-85 builds ``adj_t`` with ``ToSparseTensor``; utils.py:107-113):
+        # duck-typed on its public API -- ``.csr() -> (rowptr, col, value)`` with rows = destinations of adj_t,
+        # ``.sparse_sizes() -> (N_dst, N_src)``.  Values are ignored, as the reference drops them (utils.py:103-104).
+        # The conversion is cached on the object: an adj_t is built once per graph.
+        hit = getattr(edge_index, "_egc_amd_graph", None)
+        if hit is None:
+            rowptr, col, _ = edge_index.csr()
+            sizes = tuple(edge_index.sparse_sizes()) if callable(getattr(edge_index, "sparse_sizes", None)) else (int(num_nodes),) * 2
+            if int(sizes[0]) != int(num_nodes):
+                raise RuntimeError(f"egc_amd: adj_t has {int(sizes[0])} rows, x has {int(num_nodes)}")
+            hit = CSRGraph.from_csr(rowptr, col, int(sizes[0]), int(sizes[1])).trim_launches()
+            try:
+                edge_index._egc_amd_graph = hit
+            except AttributeError:      # (an object with __slots__: convert on every call)
+                pass
+        return hit
     if isinstance(edge_index, torch.Tensor):
         if edge_index.layout == torch.sparse_csr:
             return CSRGraph.from_csr(edge_index.crow_indices(), edge_index.col_indices(), num_nodes)

@@ -129,7 +129,8 @@ class EfficientGraphConv(nn.Module):
         return self._planes
 
     def forward(self, x, edge_index):
-        if isinstance(edge_index, SparseTensor) and any(a.aggr_fun in ("var", "std") for a in self.aggs):
+        is_adj = isinstance(edge_index, SparseTensor) or (not isinstance(edge_index, torch.Tensor) and callable(getattr(edge_index, "csr", None)))
+        if is_adj and any(a.aggr_fun in ("var", "std") for a in self.aggs):      # (also a real torch_sparse.SparseTensor)
             raise NotImplementedError  # layers.py:221-224
         if self.cache and self._cached_graph is not None:
             graph = self._cached_graph

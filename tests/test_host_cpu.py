@@ -199,3 +199,48 @@ def test_graphed_step_and_fused_block_host_logic():
             assert G._RECORDING[0] is not tok
         assert G._RECORDING[0] is tok
     assert G._RECORDING[0] is None
+
+
+class _TorchSparseLikeAdjT:
+    """The public API of ``torch_sparse.SparseTensor`` the layers touch, as mag/configs.py:84-85 produces it (``ToSparseTensor``:
+    adj_t with rows = destinations): ``csr()``, ``sparse_sizes()``, ``storage`` -- no egc_amd type involved."""
+
+    def __init__(self, rowptr, col, n_dst, n_src):
+        self._rowptr, self._col, self._sizes = rowptr, col, (n_dst, n_src)
+        self.storage = self
+
+    def csr(self):
+        return self._rowptr, self._col, None
+
+    def sparse_sizes(self):
+        return self._sizes
+
+    def set_value(self, value, layout=None):
+        return self
+
+
+def test_a_foreign_sparse_tensor_is_recognised_by_its_csr_method(monkeypatch):
+    """VERDICT r3 missing #6: `graph_from_input` has only ever met egc_amd.SparseTensor.  A stand-in with torch_sparse's API
+    (`.csr()` / `.sparse_sizes()`) must take the adj_t route: CSRGraph.from_csr on its arrays, the `_spec_adj` of EGConv,
+    NotImplementedError for var / std in EfficientGraphConv (layers.py:221-224)."""
+    import egc_amd.graph as G
+    seen = {}
+
+    class _FakeGraph:
+        def trim_launches(self):
+            return self
+
+    def fake_from_csr(rowptr, col, num_nodes=None, num_src_rows=None):
+        seen["args"] = (rowptr, col, num_nodes, num_src_rows)
+        return _FakeGraph()
+    monkeypatch.setattr(G.CSRGraph, "from_csr", staticmethod(fake_from_csr))
+    rowptr, col = torch.tensor([0, 1, 3]), torch.tensor([1, 0, 1])
+    adj = _TorchSparseLikeAdjT(rowptr, col, 2, 2)
+    g = G.graph_from_input(adj, 2)
+    assert isinstance(g, _FakeGraph) and seen["args"][0] is rowptr and seen["args"][2:] == (2, 2)
+    assert G.graph_from_input(adj, 2) is g                      # converted once, cached on the object
+    with pytest.raises(RuntimeError, match="rows"):
+        G.graph_from_input(_TorchSparseLikeAdjT(rowptr, col, 2, 2), 3)
+    lay = egc_amd.EfficientGraphConv(8, 8, 2, 2, False, aggrs=["add", "std"])
+    with pytest.raises(NotImplementedError):
+        lay(torch.randn(2, 8), adj)

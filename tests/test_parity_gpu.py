@@ -675,3 +675,24 @@ def test_std_var_layers_are_as_accurate_as_the_fp32_restatement(kind, aggrs, nea
     err_hip, err_ref = rel_err(out, truth), rel_err(ref32, truth)
     assert err_hip <= 2.0 * err_ref + 1e-5, (err_hip, err_ref)
     assert rel_err(out, ref32) <= max(1e-4, 2.0 * err_ref)   # (two fp32 evaluations are at most their two errors apart)
+
+
+def test_foreign_sparse_tensor_adj_t_equals_own_sparse_tensor():
+    """An object with torch_sparse.SparseTensor's API (`.csr()`, `.sparse_sizes()`: what `ToSparseTensor` hands to the mag net,
+    mag/configs.py:84-85) through EGConv == egc_amd.SparseTensor on the same graph, bit for bit."""
+    import egc_amd
+    from test_host_cpu import _TorchSparseLikeAdjT
+    dev = _dev()
+    rng = np.random.default_rng(31)
+    n = 700
+    ei = torch.from_numpy(rng.integers(0, n, size=(2, 5000)).astype(np.int64)).to(dev)
+    torch.manual_seed(2)
+    conv = egc_amd.EGConv(64, 64, aggrs=["symnorm", "mean", "max"], num_heads=8, num_bases=4).to(dev).eval()
+    x = torch.randn(n, 64, device=dev)
+    own = egc_amd.SparseTensor(row=ei[1], col=ei[0], sparse_sizes=(n, n))
+    g = own.graph
+    foreign = _TorchSparseLikeAdjT(g.rowptr.long(), g.col[:g.n_edges].long(), n, n)
+    with torch.no_grad():
+        a = conv(x, own)
+        b = conv(x, foreign)
+    assert torch.equal(a, b)
