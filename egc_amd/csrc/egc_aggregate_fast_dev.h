@@ -115,10 +115,65 @@ __device__ inline f4 f4_vmax(f4 a, f4 b) {
 __device__ inline f4 f4_vmin(f4 a, f4 b) {
   return f4{vmin_raw(a.x, b.x), vmin_raw(a.y, b.y), vmin_raw(a.z, b.z), vmin_raw(a.w, b.w)};
 }
+// max / min of three: two entries folded into a running extremum by one instruction
+__device__ inline float vmax3_raw(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ inline float vmin3_raw(float a, float b, float c) {
+  float r;
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ inline f4 f4_vmax3(f4 a, f4 b, f4 c) {
+  return f4{vmax3_raw(a.x, b.x, c.x), vmax3_raw(a.y, b.y, c.y), vmax3_raw(a.z, b.z, c.z), vmax3_raw(a.w, b.w, c.w)};
+}
+__device__ inline f4 f4_vmin3(f4 a, f4 b, f4 c) {
+  return f4{vmin3_raw(a.x, b.x, c.x), vmin3_raw(a.y, b.y, c.y), vmin3_raw(a.z, b.z, c.z), vmin3_raw(a.w, b.w, c.w)};
+}
 __device__ inline f4 f4_sqr_rn(f4 v) {
   return f4{__fmul_rn(v.x, v.x), __fmul_rn(v.y, v.y), __fmul_rn(v.z, v.z), __fmul_rn(v.w, v.w)};
 }
 __device__ inline f4 splat(float w) { return f4{w, w, w, w}; }
+
+// The combine's products on the packed fp32 pipe: one instruction forms two IEEE multiplies / fused multiply-adds, the weight
+// broadcast from EITHER half of the register pair it was read into (op_sel).  Written out because the compiler packs only
+// the broadcast from a pair's low half and leaves the other three quarters of the combine as scalar v_fmac_f32 -- 112
+// instructions per row group where 64 do; every result is bit-identical to the scalar form (same multiply, same fma).
+typedef float f2 __attribute__((ext_vector_type(2)));
+template <bool HI>
+__device__ inline f2 pk_mul_b(f2 v, f2 w) {        // v * w[HI], both components
+  f2 r;
+  if (HI) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(v), "v"(w));
+  else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(r) : "v"(v), "v"(w));
+  return r;
+}
+template <bool HI>
+__device__ inline f2 pk_fma_b(f2 v, f2 w, f2 acc) {  // v * w[HI] + acc, both components
+  if (HI) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(v), "v"(w));
+  else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(v), "v"(w));
+  return acc;
+}
+// sum over t < A of val[t] * wv[t]  (A = 1 .. 4, wave-uniform; the order of the scalar form: a multiply, then fmas)
+__device__ inline f4 combine_share(const f4 (&val)[4], f4 wv, int A) {
+  const f2 w01 = __builtin_shufflevector(wv, wv, 0, 1), w23 = __builtin_shufflevector(wv, wv, 2, 3);
+  f2 lo = pk_mul_b<false>(__builtin_shufflevector(val[0], val[0], 0, 1), w01);
+  f2 hi = pk_mul_b<false>(__builtin_shufflevector(val[0], val[0], 2, 3), w01);
+  if (A > 1) {
+    lo = pk_fma_b<true>(__builtin_shufflevector(val[1], val[1], 0, 1), w01, lo);
+    hi = pk_fma_b<true>(__builtin_shufflevector(val[1], val[1], 2, 3), w01, hi);
+  }
+  if (A > 2) {
+    lo = pk_fma_b<false>(__builtin_shufflevector(val[2], val[2], 0, 1), w23, lo);
+    hi = pk_fma_b<false>(__builtin_shufflevector(val[2], val[2], 2, 3), w23, hi);
+  }
+  if (A > 3) {
+    lo = pk_fma_b<true>(__builtin_shufflevector(val[3], val[3], 0, 1), w23, lo);
+    hi = pk_fma_b<true>(__builtin_shufflevector(val[3], val[3], 2, 3), w23, hi);
+  }
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
 __device__ inline constexpr bool getenv_scatter4() {
 #ifdef EGC_NO_SCATTER4
   return false;
@@ -424,12 +479,8 @@ __device__ inline void finish_group(const AggArgs& a, const FastRsrc& R, int lan
       for (int j = 0; j < 4; ++j) {
         const int h = hb * 4 + ((b + j) & 3);
         const float* wp = wl + (min(h, H - 1) * 4 + b) * AW;
-        if (A == 4) {  // wave-uniform
-          const f4 wv = *reinterpret_cast<const f4*>(wp);
-          p[j] = val[0] * splat(wv.x);
-          p[j] = f4_fma(splat(wv.y), val[1], p[j]);
-          p[j] = f4_fma(splat(wv.z), val[2], p[j]);
-          p[j] = f4_fma(splat(wv.w), val[3], p[j]);
+        if (A == 4 || W_READY) {  // wave-uniform (the LDS image of W_READY keeps four floats per (h, b) for every A)
+          p[j] = combine_share(val, *reinterpret_cast<const f4*>(wp), A);
         } else {
           p[j] = val[0] * splat(wp[0]);
           if (A > 1) p[j] = f4_fma(splat(wp[1]), val[1], p[j]);
@@ -448,12 +499,8 @@ __device__ inline void finish_group(const AggArgs& a, const FastRsrc& R, int lan
       if (h >= H) break;  // wave-uniform
       const float* wp = wl + (h * B + b) * AW;
       f4 part;
-      if (A == 4) {  // wave-uniform
-        const f4 wv = *reinterpret_cast<const f4*>(wp);
-        part = val[0] * splat(wv.x);
-        part = f4_fma(splat(wv.y), val[1], part);
-        part = f4_fma(splat(wv.z), val[2], part);
-        part = f4_fma(splat(wv.w), val[3], part);
+      if (A == 4 || W_READY) {  // wave-uniform
+        part = combine_share(val, *reinterpret_cast<const f4*>(wp), A);
       } else {
         part = val[0] * splat(wp[0]);
         if (A > 1) part = f4_fma(splat(wp[1]), val[1], part);

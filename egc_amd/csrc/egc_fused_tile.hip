@@ -446,36 +446,65 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       }
       asm volatile("" ::: "memory");
     };
-    auto build_csr = [&](const Tile& r, int set) {      // wavefronts 12-14, all of them, for every tile (also a skipped one)
-      char* cb = base + set * t.csr_stride;
-      unsigned short* col = reinterpret_cast<unsigned short*>(cb + t.off_col);
-      int* rowptr = reinterpret_cast<int*>(cb + t.off_rowptr);
-      int* cnt = reinterpret_cast<int*>(cb + t.off_cnt);
-      float* dis = reinterpret_cast<float*>(cb + t.off_dis);
+    // Two halves with the requests for the tile's rows of x between them: csr_count (in-degrees; needs the edges from
+    // memory) | the caller's row requests | csr_finish (scan and scatter; the first 8 edges of every lane are kept in
+    // registers as packed local ids, so that tiles of up to 8 x 192 edges -- all of configs 3 and 4 -- read their edges once
+    // and never wait behind the row requests of the in-order vector-memory counter).
+    constexpr int CT = FT_CSR_WAVES * 64;
+    constexpr int KEEP = 8;                                  // edges per lane kept between the halves
+    constexpr unsigned NO_EDGE = 0xffffffffu;
+    auto csr_count = [&](const Tile& r, int set, unsigned (&epk)[KEEP]) {
+      int* cnt = reinterpret_cast<int*>(base + set * t.csr_stride + t.off_cnt);
       const int T = r.ok ? r.T : 0, Et = r.ok ? r.Et : 0;
       const unsigned ebytes = (unsigned)Et * 8u;
       const __amdgpu_buffer_rsrc_t es = __builtin_amdgcn_make_buffer_rsrc((void*)(t.src + r.e0), 0, ebytes, 0x00020000);
       const __amdgpu_buffer_rsrc_t ed = __builtin_amdgcn_make_buffer_rsrc((void*)(t.dst + r.e0), 0, ebytes, 0x00020000);
-      constexpr int CT = FT_CSR_WAVES * 64;
       bool bad = false;
-      for (int i0 = 0; i0 < Et; i0 += 4 * CT) {
-        long long sv[4], dv[4];
+      long long sv[KEEP], dv[KEEP];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {       // (entries beyond the tile's range read as 0 and are skipped below)
-          const unsigned off = (unsigned)(i0 + j * CT + ht) * 8u;
-          sv[j] = __builtin_bit_cast(long long, __builtin_amdgcn_raw_buffer_load_b64(es, off, 0, 0));
-          dv[j] = __builtin_bit_cast(long long, __builtin_amdgcn_raw_buffer_load_b64(ed, off, 0, 0));
+      for (int j = 0; j < KEEP; ++j) {         // (entries beyond the tile's range read as 0 and are skipped below; the
+        // batch is a SCALAR offset -- it takes part in the range check -- so that one register addresses all of them)
+        sv[j] = __builtin_bit_cast(long long, __builtin_amdgcn_raw_buffer_load_b64(es, (unsigned)ht * 8u, j * CT * 8, 0));
+        dv[j] = __builtin_bit_cast(long long, __builtin_amdgcn_raw_buffer_load_b64(ed, (unsigned)ht * 8u, j * CT * 8, 0));
+      }
+#pragma unroll
+      for (int j = 0; j < KEEP; ++j) {
+        unsigned pk = NO_EDGE;
+        if (j * CT + ht < Et) {
+          const long long sl = sv[j] - r.n0, dl = dv[j] - r.n0;
+          if (sl < 0 || sl >= T || dl < 0 || dl >= T) bad = true;
+          else {
+            atomicAdd(&cnt[(int)dl], sl != dl ? 0x10001 : 1);
+            pk = (unsigned)sl | ((unsigned)dl << 16);
+          }
+        }
+        epk[j] = pk;
+      }
+      for (int i0 = KEEP * CT; i0 < Et; i0 += 4 * CT) {
+        long long s4[4], d4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          s4[j] = __builtin_bit_cast(long long, __builtin_amdgcn_raw_buffer_load_b64(es, (unsigned)ht * 8u, (i0 + j * CT) * 8, 0));
+          d4[j] = __builtin_bit_cast(long long, __builtin_amdgcn_raw_buffer_load_b64(ed, (unsigned)ht * 8u, (i0 + j * CT) * 8, 0));
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if (i0 + j * CT + ht < Et) {
-            const long long sl = sv[j] - r.n0, dl = dv[j] - r.n0;
+            const long long sl = s4[j] - r.n0, dl = d4[j] - r.n0;
             if (sl < 0 || sl >= T || dl < 0 || dl >= T) bad = true;
             else atomicAdd(&cnt[(int)dl], sl != dl ? 0x10001 : 1);
           }
         }
       }
       if (__ballot(bad) != 0 && lane == 0) ft_error(t, 1);
+    };
+    auto csr_finish = [&](const Tile& r, int set, const unsigned (&epk)[KEEP]) {
+      char* cb = base + set * t.csr_stride;
+      unsigned short* col = reinterpret_cast<unsigned short*>(cb + t.off_col);
+      int* rowptr = reinterpret_cast<int*>(cb + t.off_rowptr);
+      int* cnt = reinterpret_cast<int*>(cb + t.off_cnt);
+      float* dis = reinterpret_cast<float*>(cb + t.off_dis);
+      const int T = r.ok ? r.T : 0, Et = r.ok ? r.Et : 0;
       csr_sync();
       if (wave == FT_FIRST_HELPER) {
         const int per = (T + 63) >> 6;
@@ -506,20 +535,31 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
         if (lane == 63) rowptr[T] = incl;
       }
       csr_sync();
-      for (int i0 = 0; i0 < Et; i0 += 4 * CT) {
-        long long sv[4], dv[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const unsigned off = (unsigned)(i0 + j * CT + ht) * 8u;
-          sv[j] = __builtin_bit_cast(long long, __builtin_amdgcn_raw_buffer_load_b64(es, off, 0, 0));
-          dv[j] = __builtin_bit_cast(long long, __builtin_amdgcn_raw_buffer_load_b64(ed, off, 0, 0));
+      for (int j = 0; j < KEEP; ++j) {
+        if (epk[j] != NO_EDGE) {
+          const int dl = (int)(epk[j] >> 16);
+          col[rowptr[dl] + atomicSub(&cnt[dl], 1) - 1] = (unsigned short)(epk[j] & 0xffffu);
         }
+      }
+      if (Et > KEEP * CT) {      // (larger tiles: the rest of their edges a second time, from L2)
+        const unsigned ebytes = (unsigned)Et * 8u;
+        const __amdgpu_buffer_rsrc_t es = __builtin_amdgcn_make_buffer_rsrc((void*)(t.src + r.e0), 0, ebytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ed = __builtin_amdgcn_make_buffer_rsrc((void*)(t.dst + r.e0), 0, ebytes, 0x00020000);
+        for (int i0 = KEEP * CT; i0 < Et; i0 += 4 * CT) {
+          long long s4[4], d4[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (i0 + j * CT + ht < Et) {
-            const long long sl = sv[j] - r.n0, dl = dv[j] - r.n0;
-            if (!(sl < 0 || sl >= T || dl < 0 || dl >= T))
-              col[rowptr[(int)dl] + atomicSub(&cnt[(int)dl], 1) - 1] = (unsigned short)sl;
+          for (int j = 0; j < 4; ++j) {
+            s4[j] = __builtin_bit_cast(long long, __builtin_amdgcn_raw_buffer_load_b64(es, (unsigned)ht * 8u, (i0 + j * CT) * 8, 0));
+            d4[j] = __builtin_bit_cast(long long, __builtin_amdgcn_raw_buffer_load_b64(ed, (unsigned)ht * 8u, (i0 + j * CT) * 8, 0));
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (i0 + j * CT + ht < Et) {
+              const long long sl = s4[j] - r.n0, dl = d4[j] - r.n0;
+              if (!(sl < 0 || sl >= T || dl < 0 || dl >= T))
+                col[rowptr[(int)dl] + atomicSub(&cnt[(int)dl], 1) - 1] = (unsigned short)sl;
+            }
           }
         }
       }
@@ -533,15 +573,17 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       csr_sync();
     }
 
+    const bool csr_wave = wave < FT_FIRST_HELPER + FT_CSR_WAVES;
+    unsigned epk[KEEP];
     const Tile first = read_tile(0);
+    // the first tile's CSR while its rows travel (every later one is built during the rows phase of the tile before)
+    if (csr_wave) csr_count(first, 0, epk);
     {
       const __amdgpu_buffer_rsrc_t rs = x_rsrc_of(first);
 #pragma unroll
-      for (int c = 0; c < FT_RING; ++c)
-        if (c < first.nch) x_load(xr[2 * c], xr[2 * c + 1], rs, c);
+      for (int c = 0; c < FT_RING; ++c) x_load(xr[2 * c], xr[2 * c + 1], rs, c);   // (chunks beyond the tile read as 0)
     }
-    // the first tile's CSR while its rows travel (every later one is built during the rows phase of the tile before)
-    if (wave < FT_FIRST_HELPER + FT_CSR_WAVES) build_csr(first, 0);
+    if (csr_wave) csr_finish(first, 0, epk);
     for (int it = 0;; ++it) {
       const Tile cur = read_tile(it % 3);
       if (!cur.valid) break;
@@ -567,15 +609,17 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       // offsets or the search -- take two to five memory round trips: in front of a barrier they were 15 % of the kernel).
       // The record's slot was last read during tile it - 1.
       if (wave == FT_WAVES - 1) plan_tile((it + 2) % 3);
-      // the next tile's CSR, into the other set of areas -- BEFORE its rows are requested: the vector-memory counter is in
-      // order, so behind twenty row requests every wait for an edge would also wait for the rows
-      if (wave < FT_FIRST_HELPER + FT_CSR_WAVES) build_csr(nxt, (it + 1) & 1);
-      // the next tile's rows, all of them at once: they travel during this tile's rows phase and the next tile's first steps.
-      // (Requested chunk by chunk inside the loop above, the compiler's conservative vmcnt(0) in front of every split made
-      // each step wait for the request it had just issued.)
+      // the next tile's CSR, into the other set of areas, with the requests for its rows between the two halves: the
+      // vector-memory counter is in order, so the edges are read BEFORE the twenty row requests (behind them every wait
+      // for an edge would also wait for the rows), and the rows are requested before the scan and the scatter, which need no
+      // memory: they travel during this tile's rows phase.  All ten chunks are requested, unconditionally (the ones beyond
+      // the tile lie outside its descriptor and cost no traffic): the compiler can then count the requests in flight.
+      // (Requested chunk by chunk inside the loop above, its conservative vmcnt(0) in front of every split made each step
+      // wait for the request it had just issued.)
+      if (csr_wave) csr_count(nxt, (it + 1) & 1, epk);
 #pragma unroll
-      for (int c = 0; c < FT_RING; ++c)
-        if (c < nxt.nch) x_load(xr[2 * c], xr[2 * c + 1], rsn, c);
+      for (int c = 0; c < FT_RING; ++c) x_load(xr[2 * c], xr[2 * c + 1], rsn, c);
+      if (csr_wave) csr_finish(nxt, (it + 1) & 1, epk);
       lds_barrier();                                   // (end of tile)
     }
     return;
@@ -615,6 +659,9 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
     }
   }
   const int ldb4 = a.ldb >> 2;
+  const unsigned ldb_bytes = (unsigned)a.ldb * 4u;
+  const int zrow = t.tcap;                     // the row behind the image's last one: zeros (written once, below)
+  const char* bases_q = base + t.off_bases + (q < C::slots(a) ? q : 0) * 16;
   FastRsrc R;
   R.bases = bases_rsrc(a);
   R.out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (unsigned)a.n_nodes * (unsigned)F_out * 4u, 0x00020000);
@@ -624,6 +671,7 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
   const bool want_dis = a.dis != nullptr;
   const int max_index = (!C::loops_all(a) && t.max_index != nullptr) ? *t.max_index : 0x7fffffff;
   const int grp_addr = (g << LPR_LOG2) << 2;
+  for (int i = tid; i < ldb4; i += FT_WORKER_THREADS) lds_bases4[zrow * ldb4 + i] = f4{0.f, 0.f, 0.f, 0.f};
   lds_barrier();       // bias strips, the first two tile records
 #ifdef EGC_FT_STAMPS
   unsigned long long ft_pro = 0;
@@ -739,15 +787,20 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       FAcc<NEED> acc;
       acc.init();
       int nself = 0;
-      const int n_valid = q < C::slots(a) ? nd : 0;
       for (int ts = 0; ts < maxd; ts += LPR) {
+        // lane q of the group stages entry ts + q of the row: its source row (the image's all-zero row when the entry is
+        // absent, or a self-entry the layer's x-part excludes: one 24-bit multiply-add then addresses every entry, and an
+        // entry takes part in the extrema iff its row is not that one) and its symnorm weight, whole
         const bool pv = ts + q < nd;
         const int jj = pv ? (int)lds_col[start + ts + q] : 0;
-        const float dd = (pv && want_dis) ? lds_dis[jj] : 0.f;
+        const bool self_e = pv && jj == r;
+        float dd = (pv && want_dis) ? lds_dis[jj] * dis_i : 0.f;
+        if (C::yl(a) && !C::xl(a)) dd = self_e ? 0.f : dd;     // mixed sets: the self-entry counts for sum / max only
         if (looped_any) {
-          const unsigned long long sb = __ballot(pv && jj == r);
+          const unsigned long long sb = __ballot(self_e);
           nself += __popcll((sb >> (g << LPR_LOG2)) & ((LPR == 64) ? ~0ull : ((1ull << LPR) - 1ull)));
         }
+        const int jx = (pv && !(C::xl(a) && self_e)) ? jj : zrow;
         const int cnt = min(LPR, maxd - ts);
         for (int t0 = 0; t0 < cnt; t0 += FU) {
           f4 v[FU];
@@ -756,12 +809,25 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
 #pragma unroll
           for (int uu = 0; uu < FU; ++uu) {
             const int addr = grp_addr + ((t0 + uu) << 2);
-            const int j = bperm(addr, jj);
-            const bool is_self = j == r;
-            in_x[uu] = (ts + t0 + uu < n_valid) && !(C::xl(a) && is_self);
-            v[uu] = in_x[uu] ? lds_bases4[j * ldb4 + q] : f4{0.f, 0.f, 0.f, 0.f};
-            w[uu] = bperm(addr, dd) * dis_i;
-            if (C::yl(a) && !C::xl(a)) w[uu] = is_self ? 0.f : w[uu];
+            const int j = bperm(addr, jx);
+            in_x[uu] = j != zrow;
+            v[uu] = *reinterpret_cast<const f4*>(bases_q + __umul24((unsigned)j, ldb_bytes));
+            w[uu] = bperm(addr, dd);
+          }
+          if constexpr (!(NEED & NEED_ARG) && FU == 4) {
+            // every lane's four entries present (wavefront-uniform; the common case of a regular graph): the sums as in fold,
+            // in the same order, and the extrema two entries at a time -- no lane masks
+            if (__ballot(!(in_x[0] && in_x[1] && in_x[2] && in_x[3])) == 0) {
+#pragma unroll
+              for (int uu = 0; uu < FU; ++uu) {
+                acc.sum += v[uu];
+                acc.ws = f4_fma(splat(w[uu]), v[uu], acc.ws);
+                if constexpr (NEED & NEED_SQ) acc.sq += f4_sqr_rn(v[uu]);
+              }
+              acc.mx = f4_vmax3(f4_vmax3(acc.mx, v[0], v[1]), v[2], v[3]);
+              if constexpr (NEED & NEED_MN) acc.mn = f4_vmin3(f4_vmin3(acc.mn, v[0], v[1]), v[2], v[3]);
+              continue;
+            }
           }
 #pragma unroll
           for (int uu = 0; uu < FU; ++uu) fold<NEED>(acc, v[uu], w[uu], in_x[uu], start + ts + t0 + uu);
@@ -809,7 +875,7 @@ static FtLds ft_lds(const AggArgs& a, int wl_floats, int tcap, int emax, bool wi
   L.off_rec = (int)at; at += 128;
   L.off_planes = (int)at; at += FT_PLANES_BYTES;
   L.off_rowinv = (int)at; at += up16(2 * FT_CHUNK * sizeof(float));
-  L.off_bases = (int)at; at += up16((size_t)tcap * a.ldb * 4);
+  L.off_bases = (int)at; at += up16((size_t)(tcap + 1) * a.ldb * 4);   // (+ the all-zero row absent entries read)
   L.off_wt = (int)at; at += up16((size_t)tcap * wl_floats * 4);
   const size_t csr0 = at;
   L.off_col = (int)at; at += up16((size_t)emax * 2);

@@ -22,10 +22,21 @@ from . import _C
 from . import ops
 from .functional import (egc_layer_apply, egc_layer_apply_params, gemm_exact, make_spec, pack_layer_weights, pack_weights,
                          pad_bases_columns, padded_basis_stride)
-from .graph import SparseTensor, graph_from_input
+from .graph import CSRGraph, GraphBatch, SparseTensor, graph_from_input
 
 _AGGR_CODE = {"add": _C.AGGR_SUM, "mean": _C.AGGR_MEAN, "max": _C.AGGR_MAX, "min": _C.AGGR_MIN,
               "symadd": _C.AGGR_SYMNORM, "var": _C.AGGR_VAR, "std": _C.AGGR_STD}
+
+
+def _is_adj_t(edge_index) -> bool:
+    """an adjacency object in the reference's sense (layers.py:221: `isinstance(edge_index, SparseTensor)`): this package's
+    SparseTensor or a foreign one with torch_sparse's csr() -- NOT this package's own CSRGraph / GraphBatch, which also have a
+    csr() and take every aggregator."""
+    if isinstance(edge_index, SparseTensor):
+        return True
+    if isinstance(edge_index, (torch.Tensor, CSRGraph, GraphBatch)):
+        return False
+    return callable(getattr(edge_index, "csr", None))
 
 
 def glorot_(t: torch.Tensor):
@@ -129,8 +140,7 @@ class EfficientGraphConv(nn.Module):
         return self._planes
 
     def forward(self, x, edge_index):
-        is_adj = isinstance(edge_index, SparseTensor) or (not isinstance(edge_index, torch.Tensor) and callable(getattr(edge_index, "csr", None)))
-        if is_adj and any(a.aggr_fun in ("var", "std") for a in self.aggs):      # (also a real torch_sparse.SparseTensor)
+        if _is_adj_t(edge_index) and any(a.aggr_fun in ("var", "std") for a in self.aggs):      # (also a real torch_sparse.SparseTensor)
             raise NotImplementedError  # layers.py:221-224
         if self.cache and self._cached_graph is not None:
             graph = self._cached_graph

@@ -244,3 +244,14 @@ def test_a_foreign_sparse_tensor_is_recognised_by_its_csr_method(monkeypatch):
     lay = egc_amd.EfficientGraphConv(8, 8, 2, 2, False, aggrs=["add", "std"])
     with pytest.raises(NotImplementedError):
         lay(torch.randn(2, 8), adj)
+
+
+def test_own_graph_objects_are_not_taken_for_an_adj_t():
+    """CSRGraph and GraphBatch also have a csr(): they are this package's graphs and take var / std (only an adjacency object in
+    the reference's sense raises NotImplementedError there, layers.py:221-224)."""
+    from egc_amd.layers import _is_adj_t
+    import egc_amd.graph as G
+    assert _is_adj_t(_TorchSparseLikeAdjT(torch.tensor([0, 1]), torch.tensor([0]), 1, 1))
+    assert not _is_adj_t(torch.zeros(2, 3, dtype=torch.long))
+    assert not _is_adj_t(object.__new__(G.GraphBatch)) and not _is_adj_t(object.__new__(G.CSRGraph))
+    assert _is_adj_t(object.__new__(G.SparseTensor))
