@@ -52,7 +52,9 @@ constexpr int FT_CHUNK = 16;            // rows per GEMM step (one MFMA tile)
 constexpr int FT_WORKER_THREADS = FT_FIRST_HELPER * 64;
 constexpr int FT_EDGE_REGS = 4;         // edges per worker thread kept in registers (16:16 packed local ids)
 constexpr int FT_CSR_WAVES = 3;         // helper wavefronts 12-14 build the tiles' CSR (15 plans the tiles)
+constexpr int FT_PER = 3;               // rows per lane of the one-wavefront scan: 3 x 64 >= 16 FT_RING
 constexpr int FT_RING = 10;             // 16-row chunks of x a tile may have: the helpers hold them all in registers (80 VGPRs)
+static_assert(FT_PER * 64 >= FT_CHUNK * FT_RING, "the scan covers a whole tile");
 constexpr int FT_MAX_NODES = 2048;      // local ids are 16-bit, the scan is one wavefront
 constexpr int FT_NV = FT_MFMA_WAVES * 16;
 constexpr int FT_PLANE_BYTES = FT_CHUNK * FT_KP * 2;     // one plane of one chunk
@@ -60,6 +62,7 @@ constexpr int FT_PLANES_BYTES = 2 * 2 * FT_PLANE_BYTES;  // [2 buffers][2 planes
 
 #ifdef EGC_FT_STAMPS
 __device__ unsigned long long* egc_ft_stamp_buf = nullptr;   // diagnostic build only: [grid][8] accumulated cycles per phase
+#define FT_HSTAMP(k, cond) { if ((cond) && lane == 0 && blockIdx.x == 7 && it < 12 && egc_ft_stamp_buf != nullptr) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); egc_ft_stamp_buf[256 * 9 + it * 8 + k] = _t - ft_h0; } }
 #define FT_STAMP(k) { if (tid == 0) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); ft_acc[k] += _t - ft_t0; if (blockIdx.x == 7 && it < 12 && egc_ft_stamp_buf != nullptr) egc_ft_stamp_buf[256 * 9 + it * 8 + k] = _t - ft_t0; ft_t0 = _t; } }
 #else
 #define FT_STAMP(k)
@@ -311,6 +314,30 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
         lds_rec[slot * 8 + 4] = valid;
       }
     };
+    // Wavefront 15, behind a plan: touch the planned tile's edges -- one dword per 64 bytes and lane, 4 KiB per request -- so
+    // that they sit in the XCD's L2 when wavefronts 12-14 request them a tile later (from HBM, under the load of 256
+    // workgroups, the wait for them was 5,000 cycles of the 12,500 the CSR build takes behind the GEMM phase).
+    // All requests return into ONE register (written out: the compiler would give each its own, next to the tile of x this
+    // wavefront also carries); touch_done waits for them before that register can be anything else.
+    constexpr int PF = 3;                      // requests per array: 12 KiB = the 1536 edges the build keeps in registers
+    typedef unsigned ft_u4 __attribute__((ext_vector_type(4)));
+    auto touch_edges = [&](int slot, unsigned& sink) {
+      const int e0 = __builtin_amdgcn_readfirstlane(lds_rec[slot * 8 + 2]), e1 = __builtin_amdgcn_readfirstlane(lds_rec[slot * 8 + 3]);
+      const int ok = __builtin_amdgcn_readfirstlane(lds_rec[slot * 8 + 4]);
+      const unsigned bytes = ok != 0 && e1 > e0 ? (unsigned)(e1 - e0) * 8u : 0u;
+      const unsigned voff = (unsigned)lane * 64u;
+#pragma unroll
+      for (int arr = 0; arr < 2; ++arr) {
+        const uint64_t ad = (uint64_t)((arr == 0 ? t.src : t.dst) + e0);
+        const ft_u4 rs = ft_u4{(unsigned)ad, (unsigned)(ad >> 32) & 0xffffu, bytes, 0x00020000u};   // raw buffer, range-checked
+#pragma unroll
+        for (int k = 0; k < PF; ++k)
+          asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "+v"(sink) : "v"(voff), "s"(rs), "s"(k * 4096) : "memory");
+      }
+    };
+    auto touch_done = [&](unsigned& sink) {
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) :: "memory");
+    };
     if (wave == FT_WAVES - 1) {
       // the workgroup's graphs: [g_lo, g_hi) = those whose first node lies in its share of [0, N)
       const int64_t nb = gridDim.x, b = blockIdx.x;
@@ -378,6 +405,9 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
         plan_tile(0);
         plan_tile(1);
       }
+      unsigned sink = 0;
+      touch_edges(1, sink);
+      touch_done(sink);
     }
     lds_barrier();
 
@@ -446,40 +476,68 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       }
       asm volatile("" ::: "memory");
     };
-    // Two halves with the requests for the tile's rows of x between them: csr_count (in-degrees; needs the edges from
-    // memory) | the caller's row requests | csr_finish (scan and scatter; the first 8 edges of every lane are kept in
-    // registers as packed local ids, so that tiles of up to 8 x 192 edges -- all of configs 3 and 4 -- read their edges once
-    // and never wait behind the row requests of the in-order vector-memory counter).
+    // Four stages -- S0 request the edges, S1 in-degrees, S2 scan (wavefront 12), S3 scatter -- with a synchronisation of the
+    // three wavefronts in front of S2 and S3; the caller interleaves them with the requests for the tile's rows.  The first 8
+    // edges of every lane stay in registers between S1 and S3 as packed local ids (tiles of up to 8 x 192 edges -- all of
+    // configs 3 and 4 -- read their edges once).
     constexpr int CT = FT_CSR_WAVES * 64;
-    constexpr int KEEP = 8;                                  // edges per lane kept between the halves
+    constexpr int KEEP = 8;                                  // edges per lane kept between the stages
     constexpr unsigned NO_EDGE = 0xffffffffu;
-    auto csr_count = [&](const Tile& r, int set, unsigned (&epk)[KEEP]) {
+    auto edge_rsrc = [&](const Tile& r, const int64_t* p) {
+      return __builtin_amdgcn_make_buffer_rsrc((void*)(p + r.e0), 0, (unsigned)(r.ok ? r.Et : 0) * 8u, 0x00020000);
+    };
+    // S0: the first KEEP edges of every lane, two consecutive ones per 16-byte request (edges 2 ht, 2 ht + 1 of batch j of
+    // 2 x 192), INTO THE REGISTERS OF THE ROW CHUNKS 5-8 (e = xr + 10: eight 16-byte values -- four of sources, four of
+    // destinations): those chunks were split long ago, their requests for the next tile follow S1, and so the edges in
+    // flight cost no register next to the tile of x.  (Entries beyond the tile's range read as 0 and are skipped below; the
+    // batch is a SCALAR offset -- it takes part in the range check -- so that one register addresses all of them.)
+    auto csr_s0 = [&](const Tile& r, f4* e) {
+      const __amdgpu_buffer_rsrc_t es = edge_rsrc(r, t.src), ed = edge_rsrc(r, t.dst);
+#pragma unroll
+      for (int j = 0; j < KEEP / 2; ++j) {
+        e[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(es, (unsigned)ht * 16u, j * 2 * CT * 8, 0));
+        e[KEEP / 2 + j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(ed, (unsigned)ht * 16u, j * 2 * CT * 8, 0));
+      }
+    };
+    // an edge's ends as tile-local ids, or false: 64-bit ids whose upper halves are not zero lie outside every tile
+    // (n_nodes < 2^31), the lower halves are compared without sign
+    auto local_ids = [&](long long s64, long long d64, int n0, int T, unsigned& sl, unsigned& dl) -> bool {
+      const unsigned hi = (unsigned)((unsigned long long)s64 >> 32) | (unsigned)((unsigned long long)d64 >> 32);
+      sl = (unsigned)s64 - (unsigned)n0;
+      dl = (unsigned)d64 - (unsigned)n0;
+      return hi == 0u && sl < (unsigned)T && dl < (unsigned)T;
+    };
+    typedef long long ft_l2 __attribute__((ext_vector_type(2)));
+    auto csr_s1 = [&](const Tile& r, int set, const f4* e, unsigned (&epk)[KEEP]) {
       int* cnt = reinterpret_cast<int*>(base + set * t.csr_stride + t.off_cnt);
       const int T = r.ok ? r.T : 0, Et = r.ok ? r.Et : 0;
-      const unsigned ebytes = (unsigned)Et * 8u;
-      const __amdgpu_buffer_rsrc_t es = __builtin_amdgcn_make_buffer_rsrc((void*)(t.src + r.e0), 0, ebytes, 0x00020000);
-      const __amdgpu_buffer_rsrc_t ed = __builtin_amdgcn_make_buffer_rsrc((void*)(t.dst + r.e0), 0, ebytes, 0x00020000);
       bool bad = false;
-      long long sv[KEEP], dv[KEEP];
 #pragma unroll
-      for (int j = 0; j < KEEP; ++j) {         // (entries beyond the tile's range read as 0 and are skipped below; the
-        // batch is a SCALAR offset -- it takes part in the range check -- so that one register addresses all of them)
-        sv[j] = __builtin_bit_cast(long long, __builtin_amdgcn_raw_buffer_load_b64(es, (unsigned)ht * 8u, j * CT * 8, 0));
-        dv[j] = __builtin_bit_cast(long long, __builtin_amdgcn_raw_buffer_load_b64(ed, (unsigned)ht * 8u, j * CT * 8, 0));
-      }
+      for (int j = 0; j < KEEP / 2; ++j) {
+        const ft_l2 s2 = __builtin_bit_cast(ft_l2, e[j]), d2 = __builtin_bit_cast(ft_l2, e[KEEP / 2 + j]);
 #pragma unroll
-      for (int j = 0; j < KEEP; ++j) {
-        unsigned pk = NO_EDGE;
-        if (j * CT + ht < Et) {
-          const long long sl = sv[j] - r.n0, dl = dv[j] - r.n0;
-          if (sl < 0 || sl >= T || dl < 0 || dl >= T) bad = true;
-          else {
-            atomicAdd(&cnt[(int)dl], sl != dl ? 0x10001 : 1);
-            pk = (unsigned)sl | ((unsigned)dl << 16);
+        for (int k = 0; k < 2; ++k) {
+          unsigned pk = NO_EDGE;
+          if (j * 2 * CT + 2 * ht + k < Et) {
+            unsigned sl, dl;
+            if (!local_ids(s2[k], d2[k], r.n0, T, sl, dl)) bad = true;
+            else {
+              atomicAdd(&cnt[dl], sl != dl ? 0x10001 : 1);
+              pk = sl | (dl << 16);
+            }
           }
+          epk[2 * j + k] = pk;
         }
-        epk[j] = pk;
       }
+      if (__ballot(bad) != 0 && lane == 0) ft_error(t, 1);
+    };
+    // the edges beyond the first KEEP of every lane (tiles of more than 8 x 192 edges): requested and counted in one go
+    auto csr_s1_rest = [&](const Tile& r, int set) {
+      int* cnt = reinterpret_cast<int*>(base + set * t.csr_stride + t.off_cnt);
+      const int T = r.ok ? r.T : 0, Et = r.ok ? r.Et : 0;
+      if (Et <= KEEP * CT) return;
+      bool bad = false;
+      const __amdgpu_buffer_rsrc_t es = edge_rsrc(r, t.src), ed = edge_rsrc(r, t.dst);
       for (int i0 = KEEP * CT; i0 < Et; i0 += 4 * CT) {
         long long s4[4], d4[4];
 #pragma unroll
@@ -490,62 +548,75 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if (i0 + j * CT + ht < Et) {
-            const long long sl = s4[j] - r.n0, dl = d4[j] - r.n0;
-            if (sl < 0 || sl >= T || dl < 0 || dl >= T) bad = true;
-            else atomicAdd(&cnt[(int)dl], sl != dl ? 0x10001 : 1);
+            unsigned sl, dl;
+            if (!local_ids(s4[j], d4[j], r.n0, T, sl, dl)) bad = true;
+            else atomicAdd(&cnt[dl], sl != dl ? 0x10001 : 1);
           }
         }
       }
       if (__ballot(bad) != 0 && lane == 0) ft_error(t, 1);
     };
-    auto csr_finish = [&](const Tile& r, int set, const unsigned (&epk)[KEEP]) {
+    auto csr_s2 = [&](const Tile& r, int set) {
+      if (wave != FT_FIRST_HELPER) return;
       char* cb = base + set * t.csr_stride;
-      unsigned short* col = reinterpret_cast<unsigned short*>(cb + t.off_col);
       int* rowptr = reinterpret_cast<int*>(cb + t.off_rowptr);
       int* cnt = reinterpret_cast<int*>(cb + t.off_cnt);
       float* dis = reinterpret_cast<float*>(cb + t.off_dis);
-      const int T = r.ok ? r.T : 0, Et = r.ok ? r.Et : 0;
-      csr_sync();
-      if (wave == FT_FIRST_HELPER) {
-        const int per = (T + 63) >> 6;
-        const int b0 = lane * per;
-        int mine = 0;
-        for (int j = 0; j < per; ++j) mine += (b0 + j < T) ? (cnt[b0 + j] & 0xffff) : 0;
-        // inclusive scan over the wavefront on the DPP network (row shifts inside the rows of 16, then the two row broadcasts)
-        int incl = mine;
-        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);   // row_shr:1
-        incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);   // row_shr:2
-        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);   // row_shr:4
-        incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);   // row_shr:8
-        incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, true);   // row_bcast:15 -> rows 1 and 3
-        incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, true);   // row_bcast:31 -> rows 2 and 3
-        int run = incl - mine;
-        for (int j = 0; j < per; ++j) {
-          const int i = b0 + j;
-          if (i < T) {
-            const int cv = cnt[i];
-            const int c = cv & 0xffff, ns = cv >> 16;
-            rowptr[i] = run;
-            run += c;
-            cnt[i] = c;                                                          // the scatter's cursor
-            // deg^-1/2 of the layer's symnorm edge set, as prepare_kernel / build_scan_kernel (egc_graph.hip)
-            dis[i] = C::yl(a) ? 1.0f / sqrtf((float)(ns + 1)) : (c > 0 ? 1.0f / sqrtf((float)c) : 0.0f);
-          }
+      const int T = r.ok ? r.T : 0;
+      // (while the workers' rows phase keeps the LDS pipeline full every dependent LDS round trip of this build costs
+      // hundreds of cycles: all reads of a stage are issued before the first is used)
+      const int per = (T + 63) >> 6;           // <= 3: T <= 160
+      const int b0 = lane * per;
+      int cv[FT_PER];
+#pragma unroll
+      for (int j = 0; j < FT_PER; ++j) cv[j] = cnt[min(b0 + j, t.tcap - 1)];
+      int mine = 0;
+#pragma unroll
+      for (int j = 0; j < FT_PER; ++j) { cv[j] = (j < per && b0 + j < T) ? cv[j] : 0; mine += cv[j] & 0xffff; }
+      // inclusive scan over the wavefront on the DPP network (row shifts inside the rows of 16, then the two row broadcasts)
+      int incl = mine;
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);   // row_shr:1
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);   // row_shr:2
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);   // row_shr:4
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);   // row_shr:8
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, true);   // row_bcast:15 -> rows 1 and 3
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, true);   // row_bcast:31 -> rows 2 and 3
+      int run = incl - mine;
+#pragma unroll
+      for (int j = 0; j < FT_PER; ++j) {
+        const int i = b0 + j;
+        if (j < per && i < T) {
+          const int c = cv[j] & 0xffff, ns = cv[j] >> 16;
+          rowptr[i] = run;
+          run += c;
+          cnt[i] = c;                                                          // the scatter's cursor
+          // deg^-1/2 of the layer's symnorm edge set, as prepare_kernel / build_scan_kernel (egc_graph.hip)
+          dis[i] = C::yl(a) ? 1.0f / sqrtf((float)(ns + 1)) : (c > 0 ? 1.0f / sqrtf((float)c) : 0.0f);
         }
-        if (lane == 63) rowptr[T] = incl;
       }
-      csr_sync();
+      if (lane == 63) rowptr[T] = incl;
+    };
+    auto csr_s3 = [&](const Tile& r, int set, const unsigned (&epk)[KEEP]) {
+      char* cb = base + set * t.csr_stride;
+      unsigned short* col = reinterpret_cast<unsigned short*>(cb + t.off_col);
+      const int* rowptr = reinterpret_cast<const int*>(cb + t.off_rowptr);
+      int* cnt = reinterpret_cast<int*>(cb + t.off_cnt);
+      const int T = r.ok ? r.T : 0, Et = r.ok ? r.Et : 0;
+      int pos[KEEP], old[KEEP];
 #pragma unroll
       for (int j = 0; j < KEEP; ++j) {
+        pos[j] = 0; old[j] = 0;
         if (epk[j] != NO_EDGE) {
           const int dl = (int)(epk[j] >> 16);
-          col[rowptr[dl] + atomicSub(&cnt[dl], 1) - 1] = (unsigned short)(epk[j] & 0xffffu);
+          pos[j] = rowptr[dl];
+          old[j] = __hip_atomic_fetch_add(&cnt[dl], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       }
+#pragma unroll
+      for (int j = 0; j < KEEP; ++j)
+        if (epk[j] != NO_EDGE) col[pos[j] + old[j] - 1] = (unsigned short)(epk[j] & 0xffffu);
       if (Et > KEEP * CT) {      // (larger tiles: the rest of their edges a second time, from L2)
-        const unsigned ebytes = (unsigned)Et * 8u;
-        const __amdgpu_buffer_rsrc_t es = __builtin_amdgcn_make_buffer_rsrc((void*)(t.src + r.e0), 0, ebytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t ed = __builtin_amdgcn_make_buffer_rsrc((void*)(t.dst + r.e0), 0, ebytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t es = edge_rsrc(r, t.src), ed = edge_rsrc(r, t.dst);
         for (int i0 = KEEP * CT; i0 < Et; i0 += 4 * CT) {
           long long s4[4], d4[4];
 #pragma unroll
@@ -556,9 +627,9 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             if (i0 + j * CT + ht < Et) {
-              const long long sl = s4[j] - r.n0, dl = d4[j] - r.n0;
-              if (!(sl < 0 || sl >= T || dl < 0 || dl >= T))
-                col[rowptr[(int)dl] + atomicSub(&cnt[(int)dl], 1) - 1] = (unsigned short)sl;
+              unsigned sl, dl;
+              if (local_ids(s4[j], d4[j], r.n0, T, sl, dl))
+                col[rowptr[dl] + atomicSub(&cnt[dl], 1) - 1] = (unsigned short)sl;
             }
           }
         }
@@ -574,16 +645,28 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
     }
 
     const bool csr_wave = wave < FT_FIRST_HELPER + FT_CSR_WAVES;
-    unsigned epk[KEEP];
     const Tile first = read_tile(0);
-    // the first tile's CSR while its rows travel (every later one is built during the rows phase of the tile before)
-    if (csr_wave) csr_count(first, 0, epk);
+    // the first tile's CSR while its rows travel (every later one is built during the GEMM steps of the tile before)
+    unsigned epk0[KEEP];
     {
       const __amdgpu_buffer_rsrc_t rs = x_rsrc_of(first);
+      if (csr_wave) csr_s0(first, xr + FT_RING);
 #pragma unroll
-      for (int c = 0; c < FT_RING; ++c) x_load(xr[2 * c], xr[2 * c + 1], rs, c);   // (chunks beyond the tile read as 0)
+      for (int c = 0; c < FT_RING / 2; ++c) x_load(xr[2 * c], xr[2 * c + 1], rs, c);   // (chunks beyond the tile read as 0)
+      if (csr_wave) {
+        csr_s1(first, 0, xr + FT_RING, epk0);
+        csr_s1_rest(first, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = FT_RING / 2; c < FT_RING; ++c) x_load(xr[2 * c], xr[2 * c + 1], rs, c);
     }
-    if (csr_wave) csr_finish(first, 0, epk);
+    if (csr_wave) {
+      csr_sync();
+      csr_s2(first, 0);
+      csr_sync();
+      csr_s3(first, 0, epk0);
+    }
     for (int it = 0;; ++it) {
       const Tile cur = read_tile(it % 3);
       if (!cur.valid) break;
@@ -595,6 +678,8 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
 #endif
       if (0 < cur.nch) split(xr[0], xr[1], 0);         // (a tile that is skipped has no chunks: only the barriers remain)
       lds_barrier();                                   // (chunk 0 staged; the CSR of this tile complete)
+      unsigned epk[KEEP];                      // (declared per tile: nothing of the build is carried over)
+      const int nset = (it + 1) & 1;
 #pragma unroll
       for (int c = 0; c < FT_RING; ++c) {
         if (c < cur.nch) {   // workgroup-uniform
@@ -605,21 +690,56 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
           lds_barrier();
         }
       }
+#ifdef EGC_FT_STAMPS
+      unsigned long long ft_h0;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ft_h0) :: "memory");
+#endif
       // the tile after the next, while the workers are in their rows phase (its dependent loads -- graph offsets, then edge
       // offsets or the search -- take two to five memory round trips: in front of a barrier they were 15 % of the kernel).
       // The record's slot was last read during tile it - 1.
-      if (wave == FT_WAVES - 1) plan_tile((it + 2) % 3);
-      // the next tile's CSR, into the other set of areas, with the requests for its rows between the two halves: the
-      // vector-memory counter is in order, so the edges are read BEFORE the twenty row requests (behind them every wait
-      // for an edge would also wait for the rows), and the rows are requested before the scan and the scatter, which need no
-      // memory: they travel during this tile's rows phase.  All ten chunks are requested, unconditionally (the ones beyond
-      // the tile lie outside its descriptor and cost no traffic): the compiler can then count the requests in flight.
-      // (Requested chunk by chunk inside the loop above, its conservative vmcnt(0) in front of every split made each step
-      // wait for the request it had just issued.)
-      if (csr_wave) csr_count(nxt, (it + 1) & 1, epk);
+      unsigned sink = 0;
+      if (wave == FT_WAVES - 1) {
+        plan_tile((it + 2) % 3);
+        touch_edges((it + 2) % 3, sink);
+      }
+#ifdef EGC_FT_STAMPS
+      FT_HSTAMP(7, wave == FT_WAVES - 1)
+#endif
+      // the next tile's CSR, into the other set of areas (last read during the rows of tile it - 1), interleaved with the
+      // requests for its rows: edges | rows of chunks 0-4 | in-degrees | scan | scatter | rows of chunks 5-9.  The
+      // vector-memory counter is in order: the edges are requested first, so the wait for them leaves the ten row requests
+      // behind them in flight; they travel in the registers of the second half of the rows (csr_s0).  All ten chunks are
+      // requested, unconditionally (the ones beyond the tile lie outside its descriptor and cost no traffic): the compiler can
+      // then count the requests in flight.  (Requested chunk by chunk inside the loop above, its conservative vmcnt(0) in
+      // front of every split made each step wait for the request it had just issued.)
+      if (csr_wave) csr_s0(nxt, xr + FT_RING);
 #pragma unroll
-      for (int c = 0; c < FT_RING; ++c) x_load(xr[2 * c], xr[2 * c + 1], rsn, c);
-      if (csr_wave) csr_finish(nxt, (it + 1) & 1, epk);
+      for (int c = 0; c < FT_RING / 2; ++c) x_load(xr[2 * c], xr[2 * c + 1], rsn, c);
+      if (csr_wave) {
+        csr_s1(nxt, nset, xr + FT_RING, epk);
+        csr_s1_rest(nxt, nset);
+      }
+      __builtin_amdgcn_sched_barrier(0);       // (the second half of the rows into the registers the edges have left)
+#ifdef EGC_FT_STAMPS
+      FT_HSTAMP(1, wave == FT_FIRST_HELPER)
+#endif
+      if (csr_wave) {
+        csr_sync();
+        csr_s2(nxt, nset);
+        csr_sync();
+        csr_s3(nxt, nset, epk);
+      }
+#ifdef EGC_FT_STAMPS
+      FT_HSTAMP(3, wave == FT_FIRST_HELPER)
+#endif
+      // (chunks 5-9 are not split before the next tile's fifth step: their requests -- 1,300 cycles of the CU's one
+      // vector-memory pipeline -- need not stand between the in-degrees and the scan)
+#pragma unroll
+      for (int c = FT_RING / 2; c < FT_RING; ++c) x_load(xr[2 * c], xr[2 * c + 1], rsn, c);
+#ifdef EGC_FT_STAMPS
+      FT_HSTAMP(2, wave == FT_FIRST_HELPER)
+#endif
+      if (wave == FT_WAVES - 1) touch_done(sink);      // (its own row requests are long in flight; the rows phase is longer)
       lds_barrier();                                   // (end of tile)
     }
     return;
@@ -935,7 +1055,7 @@ static int launch_ft_one(const AggArgs& a, const FusedTileArgs& t, unsigned grid
         tmax = std::max(tmax, (double)h[b * 8 + 7]);
       }
       for (int i = 0; i < 10; ++i)
-        fprintf(stderr, "[ft tile %d of block 7] requests %llu (before the barrier %llu) degrees %llu scan %llu scatter %llu GEMM %llu rows %llu end %llu\n", i, h[256 * 9 + i * 8], h[256 * 9 + i * 8 + 7],
+        fprintf(stderr, "[ft tile %d of block 7] start %llu | helpers after the GEMM: plan (wavefront 15) %llu, counts %llu, rows requested %llu, CSR done %llu | GEMM %llu rows %llu end %llu\n", i, h[256 * 9 + i * 8], h[256 * 9 + i * 8 + 7],
                 h[256 * 9 + i * 8 + 1], h[256 * 9 + i * 8 + 2], h[256 * 9 + i * 8 + 3], h[256 * 9 + i * 8 + 4], h[256 * 9 + i * 8 + 5], h[256 * 9 + i * 8 + 6]);
       double pro = 0;
       for (unsigned b = 0; b < grid; ++b) pro += (double)h[256 * 8 + b];
