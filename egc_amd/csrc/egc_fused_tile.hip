@@ -58,7 +58,8 @@ static_assert(FT_PER * 64 >= FT_CHUNK * FT_RING, "the scan covers a whole tile")
 constexpr int FT_MAX_NODES = 2048;      // local ids are 16-bit, the scan is one wavefront
 constexpr int FT_NV = FT_MFMA_WAVES * 16;
 constexpr int FT_PLANE_BYTES = FT_CHUNK * FT_KP * 2;     // one plane of one chunk
-constexpr int FT_PLANES_BYTES = 2 * 2 * FT_PLANE_BYTES;  // [2 buffers][2 planes]
+constexpr int FT_PBUF = 3;                                // chunk buffers: the helpers stage two chunks ahead of the workers' MFMAs
+constexpr int FT_PLANES_BYTES = FT_PBUF * 2 * FT_PLANE_BYTES;  // [3 buffers][2 planes]
 
 #ifdef EGC_FT_STAMPS
 __device__ unsigned long long* egc_ft_stamp_buf = nullptr;   // diagnostic build only: [grid][8] accumulated cycles per phase
@@ -216,7 +217,7 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
   int* lds_rec = reinterpret_cast<int*>(base + t.off_rec);  // [3][8]: (n0, n1, e0, e1, valid) of tiles it, it + 1, it + 2; [24]: row counter
   int* lds_rowctr = lds_rec + 24;
   char* lds_planes = base + t.off_planes;                   // [2 buffers][2 planes][16 rows][128 fp16], 16-byte pieces swizzled
-  float* lds_rowinv = reinterpret_cast<float*>(base + t.off_rowinv);   // [2][16]
+  float* lds_rowinv = reinterpret_cast<float*>(base + t.off_rowinv);   // [3][16]
   auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
   for (int o = tid; o < C::H(a) * C::Ls(a); o += FT_THREADS) {
@@ -677,7 +678,11 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       if (!(t.dbg & 1))
 #endif
       if (0 < cur.nch) split(xr[0], xr[1], 0);         // (a tile that is skipped has no chunks: only the barriers remain)
-      lds_barrier();                                   // (chunk 0 staged; the CSR of this tile complete)
+#ifdef EGC_FT_STAMPS
+      if (!(t.dbg & 1))
+#endif
+      if (1 < cur.nch) split(xr[2], xr[3], 1);
+      lds_barrier();                                   // (chunks 0 and 1 staged; the CSR of this tile complete)
       unsigned epk[KEEP];                      // (declared per tile: nothing of the build is carried over)
       const int nset = (it + 1) & 1;
 #pragma unroll
@@ -686,7 +691,9 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
 #ifdef EGC_FT_STAMPS
           if (!(t.dbg & 1))
 #endif
-          if (c + 1 < FT_RING && c + 1 < cur.nch) split(xr[2 * (c + 1)], xr[2 * (c + 1) + 1], (c + 1) & 1);
+          // two chunks ahead: the workers take the first half of chunk c + 1 while they are in step c, and chunk c - 1, whose
+          // buffer this is, was read in step c - 1 at the latest
+          if (c + 2 < FT_RING && c + 2 < cur.nch) split(xr[2 * (c + 2)], xr[2 * (c + 2) + 1], (c + 2) % FT_PBUF);
           lds_barrier();
         }
       }
@@ -835,27 +842,67 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
     lds_barrier();       // chunk 0 is staged, the tile's CSR complete, the row counter zero
     FT_STAMP(0)
 
-    // ---- (G) [bases | weightings] of the tile, 16 rows per step ----
+    // ---- (G) [bases | weightings] of the tile, 16 rows per step.  The A fragments of a chunk are read in two halves: k-steps
+    //      2, 3 at the start of its step (the MFMAs of k-steps 0, 1 run meanwhile), k-steps 0, 1 at the END OF THE STEP BEFORE
+    //      (behind its last MFMA: their LDS latency passes during the epilogue and the barrier) -- the helpers stage two
+    //      chunks ahead for that.  (In lock step -- barrier, eight reads, twelve MFMAs, epilogue -- the matrix pipe of a SIMD
+    //      was busy 576 of a step's 1,100 cycles.) ----
+    int lvm = lane;
+    asm volatile("" : "+v"(lvm));
+    const int m = lvm & 15, qd = lvm >> 4;
+    auto a_read = [&](int buf, int s, ft_h8& xh, ft_h8& xl) {
+      const char* pa = lds_planes + buf * (2 * FT_PLANE_BYTES) + m * (FT_KP * 2) + ((((4 * s + qd) ^ m) & 15) << 4);
+      xh = *reinterpret_cast<const ft_h8*>(pa);
+      xl = *reinterpret_cast<const ft_h8*>(pa + FT_PLANE_BYTES);
+    };
+    // (the same two reads, written out: the compiler then does not know of them and puts no wait for them in front of the
+    // step's first MFMA -- which would also wait for the step's own four reads, LDS returning in order.  The barrier that
+    // always stands between such a request and its use waits for the LDS counter itself.)
+    static_assert(FT_PLANE_BYTES == 4096, "offset of the low plane in a_prefetch");
+    auto a_prefetch = [&](int buf, int s, ft_h8& xh, ft_h8& xl) {
+      const char* pa = lds_planes + buf * (2 * FT_PLANE_BYTES) + m * (FT_KP * 2) + ((((4 * s + qd) ^ m) & 15) << 4);
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:4096"
+                   : "=&v"(xh), "=&v"(xl) : "v"((unsigned)(uintptr_t)pa) : "memory");
+    };
+    ft_h8 ah[2], al[2];        // k-steps 0, 1 of the chunk of the coming step
+    ah[0] = al[0] = ah[1] = al[1] = ft_h8{0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef EGC_FT_STAMPS
+    if (!(t.dbg & 2))
+#endif
+    if (is_mfma && nch > 0) {
+      a_prefetch(0, 0, ah[0], al[0]);
+      a_prefetch(0, 1, ah[1], al[1]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the one time a tile that no barrier follows the request)
+    }
+    int buf = 0;
     for (int c = 0; c < nch; ++c) {
-      const int buf = c & 1;
 #ifdef EGC_FT_STAMPS
       if (!(t.dbg & 2))
 #endif
       if (is_mfma) {
-        int lv = lane;
-        asm volatile("" : "+v"(lv));
-        const int m = lv & 15, qd = lv >> 4;
-        const char* pa = lds_planes + buf * (2 * FT_PLANE_BYTES) + m * (FT_KP * 2);
+        ft_h8 bh[2], bl[2];
+        a_read(buf, 2, bh[0], bl[0]);
+        a_read(buf, 3, bh[1], bl[1]);
+        __builtin_amdgcn_sched_barrier(0);
         f4 acc0 = f4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const int piece = (((4 * s + qd) ^ m) & 15) << 4;
-          const ft_h8 xh = *reinterpret_cast<const ft_h8*>(pa + piece);
-          const ft_h8 xl = *reinterpret_cast<const ft_h8*>(pa + FT_PLANE_BYTES + piece);
+        for (int s = 0; s < 2; ++s) {
           const ft_h8 wh = __builtin_bit_cast(ft_h8, u[2 * s]), wl = __builtin_bit_cast(ft_h8, u[2 * s + 1]);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wh, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, wh, acc1, 0, 0, 0);
-          acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wl, acc2, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s], wh, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s], wh, acc1, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s], wl, acc2, 0, 0, 0);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const ft_h8 wh = __builtin_bit_cast(ft_h8, u[4 + 2 * s]), wl = __builtin_bit_cast(ft_h8, u[4 + 2 * s + 1]);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[s], wh, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[s], wh, acc1, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[s], wl, acc2, 0, 0, 0);
+        }
+        const int nbuf = buf + 1 == FT_PBUF ? 0 : buf + 1;
+        if (c + 1 < nch) {
+          a_prefetch(nbuf, 0, ah[0], al[0]);
+          a_prefetch(nbuf, 1, ah[1], al[1]);
         }
         // D: lane -> column lane % 16, rows 4 (lane / 16) + i.  2^ex 2^ew (acc0 + 2^-11 (acc1 + acc2)) + bias
         const f4 ri = *reinterpret_cast<const f4*>(lds_rowinv + buf * FT_CHUNK + 4 * qd);
@@ -873,6 +920,7 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
           *reinterpret_cast<float*>(po + 3 * dst_stride) = o.w;
         }
       }
+      buf = buf + 1 == FT_PBUF ? 0 : buf + 1;
       lds_barrier();
     }
     FT_STAMP(4)
@@ -994,7 +1042,7 @@ static FtLds ft_lds(const AggArgs& a, int wl_floats, int tcap, int emax, bool wi
   size_t at = up16((size_t)(with_post ? 2 : 1) * bias_floats * sizeof(float));
   L.off_rec = (int)at; at += 128;
   L.off_planes = (int)at; at += FT_PLANES_BYTES;
-  L.off_rowinv = (int)at; at += up16(2 * FT_CHUNK * sizeof(float));
+  L.off_rowinv = (int)at; at += up16(FT_PBUF * FT_CHUNK * sizeof(float));
   L.off_bases = (int)at; at += up16((size_t)(tcap + 1) * a.ldb * 4);   // (+ the all-zero row absent entries read)
   L.off_wt = (int)at; at += up16((size_t)tcap * wl_floats * 4);
   const size_t csr0 = at;
