@@ -453,6 +453,15 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
         lds_rowinv[buf * FT_CHUNK + prow[i]] = __uint_as_float(e);          // 2^e (the 32 lanes of a row write the same word)
       }
     };
+    // chunks 0 and 1 of a tile -> plane buffers 0 and 1: in front of the tile's first barrier, i.e. at the end of the tile
+    // before (the buffers are free from the last GEMM step on, the rows arrived during the CSR build)
+    auto stage01 = [&](const Tile& r) {
+#ifdef EGC_FT_STAMPS
+      if (t.dbg & 1) return;
+#endif
+      if (0 < r.nch) split(xr[0], xr[1], 0);           // (a tile that is skipped has no chunks: only the barriers remain)
+      if (1 < r.nch) split(xr[2], xr[3], 1);
+    };
     // a tile's rows of x through a descriptor of their own (no 4 GiB limit on x; rows beyond the tile read as 0)
     auto x_rsrc_of = [&](const Tile& r) {
       return __builtin_amdgcn_make_buffer_rsrc((void*)(t.x + (int64_t)r.n0 * t.F_in), 0,
@@ -668,20 +677,13 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       csr_sync();
       csr_s3(first, 0, epk0);
     }
+    stage01(first);
     for (int it = 0;; ++it) {
       const Tile cur = read_tile(it % 3);
       if (!cur.valid) break;
       const Tile nxt = read_tile((it + 1) % 3);
       const __amdgpu_buffer_rsrc_t rsn = x_rsrc_of(nxt);
-      // (the only wait for memory in the GEMM phase: the tile's rows were requested a whole tile ago)
-#ifdef EGC_FT_STAMPS
-      if (!(t.dbg & 1))
-#endif
-      if (0 < cur.nch) split(xr[0], xr[1], 0);         // (a tile that is skipped has no chunks: only the barriers remain)
-#ifdef EGC_FT_STAMPS
-      if (!(t.dbg & 1))
-#endif
-      if (1 < cur.nch) split(xr[2], xr[3], 1);
+      // (chunks 0 and 1 were staged at the end of the tile before / in front of the loop)
       lds_barrier();                                   // (chunks 0 and 1 staged; the CSR of this tile complete)
       unsigned epk[KEEP];                      // (declared per tile: nothing of the build is carried over)
       const int nset = (it + 1) & 1;
@@ -704,6 +706,9 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       // the tile after the next, while the workers are in their rows phase (its dependent loads -- graph offsets, then edge
       // offsets or the search -- take two to five memory round trips: in front of a barrier they were 15 % of the kernel).
       // The record's slot was last read during tile it - 1.
+      // (the helpers' few instructions go first from here to the end of the tile: behind the twelve workers' streams of LDS
+      // reads every dependent step of the CSR build waited its turn at the issue arbiter)
+      __builtin_amdgcn_s_setprio(3);
       unsigned sink = 0;
       if (wave == FT_WAVES - 1) {
         plan_tile((it + 2) % 3);
@@ -746,7 +751,9 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
 #ifdef EGC_FT_STAMPS
       FT_HSTAMP(2, wave == FT_FIRST_HELPER)
 #endif
+      stage01(nxt);
       if (wave == FT_WAVES - 1) touch_done(sink);      // (its own row requests are long in flight; the rows phase is longer)
+      __builtin_amdgcn_s_setprio(0);
       lds_barrier();                                   // (end of tile)
     }
     return;
@@ -805,6 +812,23 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
   if (tid == 0) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); ft_pro = _t - ft_t0; ft_t0 = _t; }
 #endif
 
+  // this wavefront's 16-column tile of the packed weights, from L2, once per tile of graphs (kept across the rows phase its 32
+  // registers push that phase's working set out of the register file): requested when the wavefront has left the rows of the
+  // tile before, so that it travels while the others finish theirs and the helpers stage the first chunks
+  f4 u[8];     // u[2 s + p] = k-step s, plane p of the weight tile
+  auto request_weights = [&]() {
+    if (is_mfma) {
+      int lv = lane;
+      asm volatile("" : "+v"(lv));
+      const f4* wsrc = reinterpret_cast<const f4*>(t.packed) + (int64_t)wave * 8 * 64;   // wave-uniform base + lane
+#pragma unroll
+      for (int s = 0; s < 8; ++s) u[s] = wsrc[s * 64 + lv];
+    } else {
+#pragma unroll
+      for (int s = 0; s < 8; ++s) u[s] = f4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  request_weights();
   for (int it = 0;; ++it) {
     const Tile cur = read_tile(it % 3);
     if (!cur.valid) break;
@@ -824,18 +848,7 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
     const int* lds_rowptr = reinterpret_cast<const int*>(cb + t.off_rowptr);
     const float* lds_dis = reinterpret_cast<const float*>(cb + t.off_dis);
 
-    // ---- this wavefront's weight tile (L2); the row counter ----
-    f4 u[8];     // u[2 s + p] = k-step s, plane p of the weight tile
-    if (is_mfma && cur.ok) {
-      int lv = lane;
-      asm volatile("" : "+v"(lv));
-      const f4* wsrc = reinterpret_cast<const f4*>(t.packed) + (int64_t)wave * 8 * 64;   // wave-uniform base + lane
-#pragma unroll
-      for (int s = 0; s < 8; ++s) u[s] = wsrc[s * 64 + lv];
-    } else {
-#pragma unroll
-      for (int s = 0; s < 8; ++s) u[s] = f4{0.f, 0.f, 0.f, 0.f};
-    }
+    // ---- this wavefront's weight tile: requested when the wavefront left the rows of the tile before (below); the row counter ----
     if (tid == 0) *lds_rowctr = 0;
     // the weight tile has landed HERE as far as the compiler is concerned (else it waits for it inside the GEMM loop)
     asm volatile("" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]), "+v"(u[6]), "+v"(u[7]));
@@ -1009,6 +1022,7 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
                                                  lds_wt + (row_ok ? r : 0) * t.wl_floats, lds_bias, lds_scale);
     }
     FT_STAMP(5)
+    request_weights();
     lds_barrier();   // every wavefront is done with the tile's LDS image
     FT_STAMP(6)
   }
