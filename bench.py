@@ -737,8 +737,10 @@ def main():
                     "every producer wavefront takes a slot the gather needs"}
         gemm_only()
         agg_only()   # `out` back to the default path's result for the CPU comparison below
-    except RuntimeError as exc:  # outside the envelope
-        result["fused_weightings_experiment"] = {"error": str(exc)}
+    except RuntimeError as exc:  # outside the envelope, or the default library (the launch is opt-in: EGC_WITH_FUSEDW=1 build.sh)
+        result["fused_weightings_experiment"] = {
+            "skipped": "a closed experiment, not part of the default library (DESIGN.md section 8); build with "
+                       "EGC_WITH_FUSEDW=1 bash egc_amd/csrc/build.sh to measure it", "reason": str(exc)}
 
     log("algorithmic bytes (SURVEY.md 8d), per forward:")
     for k, v in terms.items():

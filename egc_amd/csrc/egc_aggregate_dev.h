@@ -126,10 +126,14 @@ static inline int stat_layout(const int* aggr, int A, int (&slot)[5]) {
 template <int CHUNKS>
 struct Acc {
   f4 sum[CHUNKS], sq[CHUNKS], mx[CHUNKS], mn[CHUNKS], ws[CHUNKS];
+  // sq = sum of (x - sh)^2 with sh = the row's first entry (set_shift, the same for every partial accumulator of a row):
+  // var = E[(x - sh)^2] - (E[x] - sh)^2 -- layers.py:203-214's E[x^2] - E[x]^2 without its cancellation (FAcc::sh in
+  // egc_aggregate_fast_dev.h has the reasoning)
+  f4 sh[CHUNKS];
   __device__ inline void init() {
 #pragma unroll
     for (int k = 0; k < CHUNKS; ++k) {
-      sum[k] = 0.f; sq[k] = 0.f; ws[k] = 0.f;
+      sum[k] = 0.f; sq[k] = 0.f; ws[k] = 0.f; sh[k] = 0.f;
       mx[k] = -INFINITY; mn[k] = INFINITY;
     }
   }
@@ -153,12 +157,12 @@ __device__ inline f4 load_slot(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
 }
 
 // Fold one gathered neighbour slot into the lane's running aggregates.
-__device__ inline void fold(f4& sum, f4& sq, f4& mx, f4& mn, f4& ws, f4 v, bool in_x, bool in_y, float w) {
+__device__ inline void fold(f4& sum, f4& sq, f4& mx, f4& mn, f4& ws, f4 v, bool in_x, bool in_y, float w, f4 sh) {
   const f4 vx = in_x ? v : f4{0.f, 0.f, 0.f, 0.f};
   sum += vx;
-  // x*x rounded on its own, then added -- as scatter(inputs * inputs) does (layers.py:206-212); a fused
-  // multiply-add here makes var of identical neighbours non-zero, which std amplifies 158x at var = 0.
-  sq += f4{__fmul_rn(vx.x, vx.x), __fmul_rn(vx.y, vx.y), __fmul_rn(vx.z, vx.z), __fmul_rn(vx.w, vx.w)};
+  // (x - sh)^2 rounded on its own, then added (as scatter(inputs * inputs) adds its squares, layers.py:206-212)
+  const f4 d = in_x ? v - sh : f4{0.f, 0.f, 0.f, 0.f};
+  sq += f4{__fmul_rn(d.x, d.x), __fmul_rn(d.y, d.y), __fmul_rn(d.z, d.z), __fmul_rn(d.w, d.w)};
   mx = f4_max(mx, in_x ? v : f4{-INFINITY, -INFINITY, -INFINITY, -INFINITY});
   mn = f4_min(mn, in_x ? v : f4{INFINITY, INFINITY, INFINITY, INFINITY});
   const float wy = in_y ? w : 0.f;

@@ -133,6 +133,10 @@ agg_fast_kernel(AggArgs a) {
 
     FAcc<NEED> acc;
     acc.init();
+    if constexpr (NEED & NEED_SQ) {   // the variance's shift: the row's first entry (lane 0 of the group staged its column)
+      const int first = bperm(grp_addr, jj);
+      acc.sh = load_slot(R.bases, (lane_live && nd > 0) ? (unsigned)first * row_bytes + slot_off : OOB);
+    }
     int nself = 0;
     for (int ts = 0; ts < maxd; ts += LPR) {
       if (ts > 0) jj = (ts + q < nd) ? a.col[start + ts + q] : 0;  // rows of more than LPR entries
@@ -286,6 +290,14 @@ __device__ inline void wide_long_row_chunk(const AggArgs& a, const FastRsrc& R, 
   FAcc<NEED> acc0, acc1;
   acc0.init();
   acc1.init();
+  f4 shift0 = f4{0.f, 0.f, 0.f, 0.f}, shift1 = shift0;   // NEED_SQ: the row's first entry (FAcc::sh), for every chunk and the merge
+  if constexpr (NEED & NEED_SQ) {
+    const int first = __builtin_amdgcn_readfirstlane(a.col[row_start]);
+    shift0 = load_slot(R.bases, wl_.live0 ? (unsigned)first * row_bytes + wl_.so0 : OOB);
+    shift1 = load_slot(R.bases, wl_.live1 ? (unsigned)first * row_bytes + wl_.so1 : OOB);
+    acc0.sh = shift0;
+    acc1.sh = shift1;
+  }
   int nself = 0;
   for (int base = start; base < end; base += 64) {
     const int p = base + lane;
@@ -323,6 +335,7 @@ __device__ inline void wide_long_row_chunk(const AggArgs& a, const FastRsrc& R, 
     const int c0 = __builtin_amdgcn_readfirstlane(long_chunk0[slot]);
     acc0.init();
     acc1.init();
+    if constexpr (NEED & NEED_SQ) { acc0.sh = shift0; acc1.sh = shift1; }
     const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(reinterpret_cast<const f4*>(a.partial) + (int64_t)c0 * WREC), 0, (unsigned)nch * (unsigned)WREC * 16u, 0x00020000);
     for (int kk = 0; kk < nch; ++kk) {   // chunk order: deterministic
@@ -401,6 +414,11 @@ __global__ void __launch_bounds__(256) agg_wide_kernel(AggArgs a) {
     FAcc<NEED> acc0, acc1;
     acc0.init();
     acc1.init();
+    if constexpr (NEED & NEED_SQ) {
+      const int first = __builtin_amdgcn_readfirstlane(jj);       // lane 0 holds the row's first entry
+      acc0.sh = load_slot(R.bases, (wl_.live0 && deg > 0) ? (unsigned)first * row_bytes + wl_.so0 : OOB);
+      acc1.sh = load_slot(R.bases, (wl_.live1 && deg > 0) ? (unsigned)first * row_bytes + wl_.so1 : OOB);
+    }
     wide_gather<NEED, C0>(a, R, wl_, acc0, acc1, row, jj, dd, dis_i, deg, row_bytes, start);
     wide_finish<HPB, NEED, C0, C1>(a, R, wl_, lane, row, acc0, acc1, deg, nself, dis_i, row_bytes, lds_w, lds_bias, lds_scale);
   }

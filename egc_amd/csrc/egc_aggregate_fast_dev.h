@@ -243,10 +243,16 @@ template <int NEED>
 struct FAcc {
   f4 sum, mx, ws;
   f4 sq, mn;  // only touched when NEED says so; dead otherwise
+  // NEED_SQ: `sq` holds the sum of (x - sh)^2, sh = the value of the row's FIRST entry in this lane's slot (set by the caller
+  // right after init(), the same for every partial accumulator of a row).  var = E[(x - sh)^2] - (E[x] - sh)^2 is the same
+  // number as layers.py:203-214's E[x^2] - E[x]^2 in exact arithmetic, without its cancellation: neighbours that are
+  // (nearly) tied -- the case std's sqrt(. + 1e-5) amplifies 158x -- give (nearly) zero terms instead of two numbers of
+  // size mean^2 that have to cancel.  (VERDICT r3 next #4d.)
+  f4 sh;
   i4 ax, an;  // NEED_ARG: positions of the running max / min
   __device__ inline void init() {
     sum = 0.f; ws = 0.f; mx = -INFINITY;
-    if constexpr (NEED & NEED_SQ) sq = 0.f;
+    if constexpr (NEED & NEED_SQ) { sq = 0.f; sh = 0.f; }
     if constexpr (NEED & NEED_MN) mn = INFINITY;
     if constexpr (NEED & NEED_ARG) ax = an = ARG_NONE;
   }
@@ -285,8 +291,8 @@ template <int NEED>
 __device__ inline void fold(FAcc<NEED>& acc, f4 v, float w, bool in_x, int pos) {
   acc.sum += v;
   acc.ws = f4_fma(splat(w), v, acc.ws);
-  if constexpr (NEED & NEED_SQ) acc.sq += f4_sqr_rn(v);
   if (in_x) {
+    if constexpr (NEED & NEED_SQ) acc.sq += f4_sqr_rn(v - acc.sh);   // (an absent entry's 0 is not neutral here: under the mask)
     if constexpr (NEED & NEED_ARG) {
       take_gt4(acc.mx, acc.ax, v, pos);
       if constexpr (NEED & NEED_MN) take_lt4(acc.mn, acc.an, v, pos);
@@ -408,7 +414,10 @@ __device__ inline void finish_group(const AggArgs& a, const FastRsrc& R, int lan
     if (a.stat_slot[STAT_MX] >= 0) __builtin_nontemporal_store(acc.mx, reinterpret_cast<f4*>(st + a.stat_slot[STAT_MX] * a.ldb));
     if (a.stat_slot[STAT_WS] >= 0) __builtin_nontemporal_store(acc.ws, reinterpret_cast<f4*>(st + a.stat_slot[STAT_WS] * a.ldb));
     if constexpr (NEED & NEED_SQ)
-      if (a.stat_slot[STAT_SQ] >= 0) __builtin_nontemporal_store(acc.sq, reinterpret_cast<f4*>(st + a.stat_slot[STAT_SQ] * a.ldb));
+      if (a.stat_slot[STAT_SQ] >= 0) {   // the backward's record keeps the plain sum of squares: sq + sh (2 ds + cnt sh), ds + cnt sh = sum
+        const f4 ds = f4_fma(splat(-(float)cnt), acc.sh, acc.sum);
+        __builtin_nontemporal_store(f4_fma(acc.sh, ds + acc.sum, acc.sq), reinterpret_cast<f4*>(st + a.stat_slot[STAT_SQ] * a.ldb));
+      }
     if constexpr (NEED & NEED_MN)
       if (a.stat_slot[STAT_MN] >= 0) __builtin_nontemporal_store(acc.mn, reinterpret_cast<f4*>(st + a.stat_slot[STAT_MN] * a.ldb));
     if (q == 0) a.cnt_out[row] = cnt;
@@ -437,9 +446,11 @@ __device__ inline void finish_group(const AggArgs& a, const FastRsrc& R, int lan
   const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
   f4 mean = zero, var = zero;
   if constexpr (NEED & NEED_SQ) {
-    // exact divisions: var of identical neighbours must cancel to exactly 0 (see egc_aggregate_dev.h)
+    // exact divisions; sum of (x - sh) = sum - cnt sh with one rounding (identical neighbours: sq == 0, and what is left of
+    // this difference is the rounding of their sum, squared: var == -tiny -> relu -> 0 in std)
     mean = f4_div(acc.sum, cntf);
-    var = f4_var(f4_div(acc.sq, cntf), mean);
+    const f4 ds = f4_fma(splat(-(float)cnt), acc.sh, acc.sum);
+    var = f4_var(f4_div(acc.sq, cntf), f4_div(ds, cntf));
   } else if (C::need_mean(a)) {
     // no var/std in this layer: one reciprocal instead of four IEEE divisions (<= 1 ulp from sum / cnt)
     mean = acc.sum * splat(__builtin_amdgcn_rcpf(cntf));
@@ -773,6 +784,12 @@ __device__ inline void long_row_chunk(const AggArgs& a, const FastRsrc& R, int c
   const float dis_i = a.dis != nullptr ? a.dis[row] : 0.f;
   FAcc<NEED> acc;
   acc.init();
+  f4 shift = f4{0.f, 0.f, 0.f, 0.f};     // NEED_SQ: the row's first entry, for every chunk of the row and for the merge
+  if constexpr (NEED & NEED_SQ) {
+    const int first = __builtin_amdgcn_readfirstlane(a.col[row_start]);
+    shift = load_slot(R.bases, lane_live ? (unsigned)first * row_bytes + slot_off : OOB);
+    acc.sh = shift;
+  }
   int nself = 0;
   for (int base = start; base < end; base += 64) {
     const int p = base + lane;
@@ -823,6 +840,7 @@ __device__ inline void long_row_chunk(const AggArgs& a, const FastRsrc& R, int c
     if (lane == 0) __hip_atomic_store(&a.counters[slot], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int c0 = __builtin_amdgcn_readfirstlane(long_chunk0[slot]);
     acc.init();
+    if constexpr (NEED & NEED_SQ) acc.sh = shift;
     // MU records per group in flight (a hub row has hundreds of chunks)
     constexpr int MU = 4;
     const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(

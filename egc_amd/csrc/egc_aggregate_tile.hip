@@ -390,6 +390,12 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
 
       FAcc<NEED> acc;
       acc.init();
+      if constexpr (NEED & NEED_SQ) {   // the variance's shift: the row's first entry in the tile's CSR (FAcc::sh)
+        const bool want = row_ok && nd > 0 && q < C::slots(a);
+        const int first = want ? (int)lds_col[start] : 0;
+        if (in_lds) { if (want) acc.sh = lds_bases4[first * ldb4 + q]; }
+        else acc.sh = load_slot(R.bases, want ? (unsigned)(n0 + first) * row_bytes + slot_off : OOB);
+      }
       int nself = 0;
       const int n_valid = q < C::slots(a) ? nd : 0;
       for (int ts = 0; ts < maxd; ts += LPR) {

@@ -967,6 +967,8 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
 
       FAcc<NEED> acc;
       acc.init();
+      if constexpr (NEED & NEED_SQ)     // the variance's shift: the row's first entry in the tile's CSR (FAcc::sh)
+        acc.sh = *reinterpret_cast<const f4*>(bases_q + __umul24((unsigned)((row_ok && nd > 0) ? (int)lds_col[start] : zrow), ldb_bytes));
       int nself = 0;
       for (int ts = 0; ts < maxd; ts += LPR) {
         // lane q of the group stages entry ts + q of the row: its source row (the image's all-zero row when the entry is
@@ -1003,7 +1005,7 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
               for (int uu = 0; uu < FU; ++uu) {
                 acc.sum += v[uu];
                 acc.ws = f4_fma(splat(w[uu]), v[uu], acc.ws);
-                if constexpr (NEED & NEED_SQ) acc.sq += f4_sqr_rn(v[uu]);
+                if constexpr (NEED & NEED_SQ) acc.sq += f4_sqr_rn(v[uu] - acc.sh);
               }
               acc.mx = f4_vmax3(f4_vmax3(acc.mx, v[0], v[1]), v[2], v[3]);
               if constexpr (NEED & NEED_MN) acc.mn = f4_vmin3(f4_vmin3(acc.mn, v[0], v[1]), v[2], v[3]);

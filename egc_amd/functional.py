@@ -42,8 +42,9 @@ class LayerSpec:
 
     @property
     def gemm_flags(self) -> int:
-        """Operand precision of the layer's split GEMM (egc_layer_gemm_flags): EGC_GEMM_24BIT for layers with std / var,
-        whose cancellation amplifies what a 22-bit operand split drops; EGC_GEMM_FAST=1 keeps the fast form for them too."""
+        """Operand precision of the layer's split GEMM (egc_layer_gemm_flags): 0 -- the fast fp16x2 form -- for every layer
+        since the variance is accumulated about the row's first entry; EGC_GEMM_STDVAR_24BIT=1 gives std / var layers the
+        24-bit-operand form of rounds 2-3 back."""
         return int(_C.load().egc_layer_gemm_flags(C.byref(self.c)))     # (decided in ONE place: the library)
 
 
@@ -380,11 +381,12 @@ def _batch_fused_pack(spec: LayerSpec, wcat: torch.Tensor, bcat):
 
 
 def _batch_fused_setup(gb: GraphBatch, spec: LayerSpec, post, wcat):
-    """(tile_nodes, max_tile_edges) when this layer call can run as ONE launch on the batch, else None.  Layers with std / var
-    keep the 24-bit-operand GEMM of the two-launch path (egc_layer_gemm_flags); EGC_NO_FUSED_TILE=1 switches the path off."""
+    """(tile_nodes, max_tile_edges) when this layer call can run as ONE launch on the batch, else None.  A layer that asks for
+    the 24-bit-operand GEMM (EGC_GEMM_STDVAR_24BIT=1 and std / var) keeps the two-launch path; EGC_NO_FUSED_TILE=1 switches
+    the path off."""
     if _C.env_flag("EGC_NO_FUSED_TILE") or _C.env_flag("EGC_NO_TILE") or gemm_exact() or wcat.requires_grad:
         return None
-    if spec.gemm_flags != 0 and not _C.env_flag("EGC_GEMM_FAST"):
+    if spec.gemm_flags != 0:
         return None
     return gb.fused_setup(spec.c, post is not None and post.scale is not None)
 

@@ -226,13 +226,15 @@ int egc_basis_pack(const float* wcat, int32_t f_in, int32_t f_g, int32_t w_cols,
                    size_t packed_bytes, egc_stream_t stream);
 /* Operand precision of the split GEMM.  flags = 0: as above (fp16x2, 22 significand bits, where the shape has that
  * kernel).  EGC_GEMM_24BIT: three bf16 planes per operand for EVERY shape -- all 24 bits of an fp32 operand survive.
- * Layers with `std` / `var` want it: var = E[x^2] - E[x]^2 cancels on (nearly) constant neighbourhoods and
- * std = sqrt(relu(var) + 1e-5) (layers.py:203-216) then amplifies what the GEMM dropped from `bases` 158x; with 22-bit
- * operands such a layer lands a few times further from the float64 value than the reference's own float32 does
- * (measured 7e-5 against 2e-5 of the output scale), with 24-bit operands it does not.  egc_layer_gemm_flags(layer) =
- * EGC_GEMM_24BIT exactly for those layers: pass it to BOTH calls of a layer (pack and transform must agree);
- * egc_layer_forward_packed applies it by itself, so its `packed` must come from egc_basis_pack_ex with the same flags.
- * Cost at the 128-wide shapes: 63-70 us instead of 40 us per GEMM at ogbn-arxiv size. */
+ * Rounds 2-3 ran layers with `std` / `var` on it: var = E[x^2] - E[x]^2 cancels on (nearly) constant neighbourhoods and
+ * std = sqrt(relu(var) + 1e-5) (layers.py:203-216) then amplifies what the GEMM dropped from `bases` 158x.  Since round 4
+ * the aggregate kernels accumulate the variance about the row's first entry -- E[(x - s)^2] - (E[x] - s)^2, the same number
+ * without the cancellation -- and such layers sit within 7e-7 of the float64 value with either operand precision (the
+ * float32 formula itself: up to 3.7e-4), so egc_layer_gemm_flags(layer) is 0 for every layer; EGC_GEMM_STDVAR_24BIT=1 in the
+ * environment makes it EGC_GEMM_24BIT for std / var layers again.  Pass its value to BOTH calls of a layer (pack and
+ * transform must agree); egc_layer_forward_packed applies it by itself, so its `packed` must come from egc_basis_pack_ex
+ * with the same flags.  Cost of the 24-bit form at the 128-wide shapes: 63-70 us instead of 40 us per GEMM at ogbn-arxiv
+ * size. */
 #define EGC_GEMM_24BIT 1
 int32_t egc_layer_gemm_flags(const egc_layer* layer);
 int egc_basis_pack_ex(const float* wcat, int32_t f_in, int32_t f_g, int32_t w_cols, int32_t flags, void* packed,

@@ -44,7 +44,14 @@ pytestmark = pytest.mark.gpu
 # seeds (gpurun_out/r3_fuzz24.log, r3_fuzz22.log -> profiles/r03_stdvar_gemm_precision.md): with the 24-bit-operand GEMM
 # such layers run by default the worst ratio is 6.0 (two fp32 summation orders of E[x^2] - E[x]^2, amplified 158x: single
 # draws of the same rounding noise); with the 22-bit fp16x2 GEMM (EGC_GEMM_FAST=1) one case of seed 118 sits at 28x.
-STDVAR_K = 8.0
+# Round 4: the kernels accumulate the variance about the row's first entry (FAcc::sh, egc_aggregate_fast_dev.h) -- the same
+# number without the cancellation -- and such layers run the default fp16x2 GEMM.  Over the committed seeds and 300-330 (44
+# seeds, 5,280 configurations) every std / var layer is within 7e-7 of float64 where the float32 restatement is 1e-5 ... 3.7e-4
+# off (HIP / restatement <= 0.05): the criterion is now HIP <= max(1e-5, 1 x the restatement's own error), and the element-wise
+# allowance for float32's residue is only consulted with EGC_FUZZ_ALLOWANCE=1 (the 24-bit-GEMM / unshifted history above).
+import os as _os
+STDVAR_K = float(_os.environ.get("EGC_FUZZ_STDVAR_K", "1.0"))
+STDVAR_ALLOWANCE = _os.environ.get("EGC_FUZZ_ALLOWANCE", "0") not in ("", "0")
 
 
 def _truth64(tref, kind, layer, x, ei, H, B, names, flags, asl):
@@ -208,7 +215,7 @@ def test_random_layers_and_graphs_match_the_oracles(seed, generic, monkeypatch):
                     truth = _truth64(tref, kind, layer, x, ei, H, B, names, flags, asl).numpy()
                     e_hip, e_ref = rel_err(out.cpu().numpy(), truth), rel_err(ref, truth)
                     ok = e_hip <= max(1e-5, STDVAR_K * e_ref)
-                    if not ok:
+                    if not ok and STDVAR_ALLOWANCE:
                         # ... or, element by element, within what float32 leaves in E[x^2] - E[x]^2 (its residue has either
                         # sign with equal probability, relu() hides the negative draws: the restatement's own error on one
                         # layer is a sample of the same noise, not a bound for it)
