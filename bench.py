@@ -703,13 +703,33 @@ def main():
         "layer_achieved_gbs": terms["layer"] / (step_ms_events * 1e-3) / 1e9,
         "layer_frac": terms["layer"] / (step_ms_events * 1e-3) / 1e9 / HBM_PEAK_GBS,
         # the precision / speed trade of the GEMM, on the line: the default (fp16x2: 22-bit operands, componentwise error 1.3e-7
-        # against float64 -- below the fp32-MFMA kernel's 3.2e-7, tests/test_gemm_gpu.py), the 24-bit-operand form that std / var
-        # layers take (bf16x3), the plain fp32-MFMA kernel
+        # against float64 -- below the fp32-MFMA kernel's 3.2e-7, tests/test_gemm_gpu.py), the 24-bit-operand form (bf16x3: what
+        # std / var layers ran in rounds 2-3, on request since), the plain fp32-MFMA kernel
         "layer_frac_by_gemm": {"fp16x2_default": terms["layer"] / (step_ms_events * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                "bf16x3_24bit": terms["layer"] / ((gemm_24bit_ms + agg_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                "exact_fp32_mfma": terms["layer"] / ((gemm_exact_ms + agg_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS},
         "ms_per_step_regions": regions, "ms_per_step_median_of_5_regions": sorted(regions)[2],
     }
+
+    # ---- a std layer at this size (VERDICT r3 #4c): the same layer with `mean` replaced by `std` -- the same algorithmic bytes.
+    # Since round 4 such layers run the default GEMM (the variance is accumulated about the row's first entry: no cancellation
+    # left to amplify the 22-bit operand split, profiles/r04_stdvar_shift.md); timed through the module on the cached graph.
+    try:
+        torch.manual_seed(args.seed + 7)
+        conv_std = egc_amd.EGConv(F_IN, F_OUT, aggrs=["sum", "std", "max", "symnorm"], num_heads=HEADS, num_bases=BASES,
+                                  cached=True).to(dev).eval()
+
+        def std_step():
+            with torch.no_grad():
+                conv_std(x, graph)
+        for _ in range(20):
+            std_step()
+        std_ms = time_region(std_step, reps)
+        result["std_layer"] = {"aggregators": "sum+std+max+symnorm", "gemm_flags": int(conv_std._spec_coo.gemm_flags),
+                               "layer_ms": std_ms, "layer_frac": terms["layer"] / (std_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "note": "module call (EGConv.forward) on the cached CSR graph; same byte model as the headline layer"}
+    except Exception as exc:   # (a side field must not take the line down)
+        result["std_layer"] = {"error": repr(exc)}
 
     # ---- the fused-weightings launch (opt-in, see egc_aggregate_fusedw.hip): measured here so
     # that the statement "slower than the two-launch path" stays a number of this run
