@@ -315,30 +315,6 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
         lds_rec[slot * 8 + 4] = valid;
       }
     };
-    // Wavefront 15, behind a plan: touch the planned tile's edges -- one dword per 64 bytes and lane, 4 KiB per request -- so
-    // that they sit in the XCD's L2 when wavefronts 12-14 request them a tile later (from HBM, under the load of 256
-    // workgroups, the wait for them was 5,000 cycles of the 12,500 the CSR build takes behind the GEMM phase).
-    // All requests return into ONE register (written out: the compiler would give each its own, next to the tile of x this
-    // wavefront also carries); touch_done waits for them before that register can be anything else.
-    constexpr int PF = 3;                      // requests per array: 12 KiB = the 1536 edges the build keeps in registers
-    typedef unsigned ft_u4 __attribute__((ext_vector_type(4)));
-    auto touch_edges = [&](int slot, unsigned& sink) {
-      const int e0 = __builtin_amdgcn_readfirstlane(lds_rec[slot * 8 + 2]), e1 = __builtin_amdgcn_readfirstlane(lds_rec[slot * 8 + 3]);
-      const int ok = __builtin_amdgcn_readfirstlane(lds_rec[slot * 8 + 4]);
-      const unsigned bytes = ok != 0 && e1 > e0 ? (unsigned)(e1 - e0) * 8u : 0u;
-      const unsigned voff = (unsigned)lane * 64u;
-#pragma unroll
-      for (int arr = 0; arr < 2; ++arr) {
-        const uint64_t ad = (uint64_t)((arr == 0 ? t.src : t.dst) + e0);
-        const ft_u4 rs = ft_u4{(unsigned)ad, (unsigned)(ad >> 32) & 0xffffu, bytes, 0x00020000u};   // raw buffer, range-checked
-#pragma unroll
-        for (int k = 0; k < PF; ++k)
-          asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "+v"(sink) : "v"(voff), "s"(rs), "s"(k * 4096) : "memory");
-      }
-    };
-    auto touch_done = [&](unsigned& sink) {
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) :: "memory");
-    };
     if (wave == FT_WAVES - 1) {
       // the workgroup's graphs: [g_lo, g_hi) = those whose first node lies in its share of [0, N)
       const int64_t nb = gridDim.x, b = blockIdx.x;
@@ -406,9 +382,6 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
         plan_tile(0);
         plan_tile(1);
       }
-      unsigned sink = 0;
-      touch_edges(1, sink);
-      touch_done(sink);
     }
     lds_barrier();
 
@@ -709,11 +682,7 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       // (the helpers' few instructions go first from here to the end of the tile: behind the twelve workers' streams of LDS
       // reads every dependent step of the CSR build waited its turn at the issue arbiter)
       __builtin_amdgcn_s_setprio(3);
-      unsigned sink = 0;
-      if (wave == FT_WAVES - 1) {
-        plan_tile((it + 2) % 3);
-        touch_edges((it + 2) % 3, sink);
-      }
+      if (wave == FT_WAVES - 1) plan_tile((it + 2) % 3);
 #ifdef EGC_FT_STAMPS
       FT_HSTAMP(7, wave == FT_WAVES - 1)
 #endif
@@ -752,7 +721,6 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       FT_HSTAMP(2, wave == FT_FIRST_HELPER)
 #endif
       stage01(nxt);
-      if (wave == FT_WAVES - 1) touch_done(sink);      // (its own row requests are long in flight; the rows phase is longer)
       __builtin_amdgcn_s_setprio(0);
       lds_barrier();                                   // (end of tile)
     }
