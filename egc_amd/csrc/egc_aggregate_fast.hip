@@ -45,7 +45,7 @@ namespace egc {
 template <int LPR_LOG2, int HPB, int NEED, class C>
 // Inference variants (NEED == 0) fit 80 VGPRs without spilling when asked to, which buys the sixth wavefront per
 // SIMD; the variants carrying more running aggregates are left to the register allocator.
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NEED == 0 ? EGC_AGG_WAVES : ((NEED & NEED_ARG) && (NEED & NEED_SQ)) ? 2 : 4)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NEED == 0 ? EGC_AGG_WAVES : ((NEED & NEED_ARG) && (NEED & NEED_SQ)) ? 2 : (NEED == NEED_SQ || NEED == NEED_MN) ? 5 : 4)))
 agg_fast_kernel(AggArgs a) {
   constexpr int LPR = 1 << LPR_LOG2, G = 64 / LPR;
   extern __shared__ float smem[];
@@ -133,10 +133,6 @@ agg_fast_kernel(AggArgs a) {
 
     FAcc<NEED> acc;
     acc.init();
-    if constexpr (NEED & NEED_SQ) {   // the variance's shift: the row's first entry (lane 0 of the group staged its column)
-      const int first = bperm(grp_addr, jj);
-      acc.sh = load_slot(R.bases, (lane_live && nd > 0) ? (unsigned)first * row_bytes + slot_off : OOB);
-    }
     int nself = 0;
     for (int ts = 0; ts < maxd; ts += LPR) {
       if (ts > 0) jj = (ts + q < nd) ? a.col[start + ts + q] : 0;  // rows of more than LPR entries
@@ -147,6 +143,13 @@ agg_fast_kernel(AggArgs a) {
         nself += __popcll((sb >> (g << LPR_LOG2)) & ((LPR == 64) ? ~0ull : ((1ull << LPR) - 1ull)));
       }
       const int cnt = min(LPR, maxd - ts);  // wave-uniform
+      if constexpr (NEED & NEED_SQ) {   // (the row's first batch carries the variance's shift: FAcc::sh)
+        if (ts == 0)
+          gather_batch<NEED, C, true>(a, R, acc, grp_addr, 4, row, jj, dd, dis_i, lane_live ? nd : 0, 0, 1, row_bytes, slot_off, start);
+        for (int t0 = ts == 0 ? FU : 0; t0 < cnt; t0 += FU)
+          gather_batch<NEED, C>(a, R, acc, grp_addr + (t0 << 2), 4, row, jj, dd, dis_i, lane_live ? nd : 0, ts + t0, 1, row_bytes,
+                                slot_off, start);
+      } else
       for (int t0 = 0; t0 < cnt; t0 += FU)
         gather_batch<NEED, C>(a, R, acc, grp_addr + (t0 << 2), 4, row, jj, dd, dis_i, lane_live ? nd : 0, ts + t0, 1, row_bytes,
                               slot_off, start);
@@ -530,6 +533,10 @@ static int launch_need(const AggArgs& a, int need, unsigned grid, size_t lds, hi
     return launch_one<LPR_LOG2, HPB, NEED_SQ | NEED_MN | NEED_ARG, RtCfg>(a, grid, lds, stream);
   }
   if (need == 0) return launch_one<LPR_LOG2, HPB, 0, RtCfg>(a, grid, lds, stream);
+  // (squares without min and min without squares are kernels of their own: either accumulator alone leaves room for a fifth
+  // wavefront per SIMD -- a std layer's aggregate at ogbn-arxiv size 137 -> see DESIGN.md 3.1)
+  if (need == NEED_SQ) return launch_one<LPR_LOG2, HPB, NEED_SQ, RtCfg>(a, grid, lds, stream);
+  if (need == NEED_MN) return launch_one<LPR_LOG2, HPB, NEED_MN, RtCfg>(a, grid, lds, stream);
   return launch_one<LPR_LOG2, HPB, NEED_SQ | NEED_MN, RtCfg>(a, grid, lds, stream);
 }
 
