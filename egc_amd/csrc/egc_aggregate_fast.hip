@@ -133,6 +133,12 @@ agg_fast_kernel(AggArgs a) {
 
     FAcc<NEED> acc;
     acc.init();
+    if constexpr (NEED & NEED_SQ) {   // the variance's shift: the row's first entry (lane 0 of the group staged its column), also
+      // when the layer's x-part excludes that entry (a self-entry under add_self_loops: its value is as good a shift, and 0 --
+      // what the masked gather returns for it -- is none: tiny graphs full of self-entries, tools/tile_fuzz.py seed 77)
+      const int first = bperm(grp_addr, jj);
+      acc.sh = load_slot(R.bases, (lane_live && nd > 0) ? (unsigned)first * row_bytes + slot_off : OOB);
+    }
     int nself = 0;
     for (int ts = 0; ts < maxd; ts += LPR) {
       if (ts > 0) jj = (ts + q < nd) ? a.col[start + ts + q] : 0;  // rows of more than LPR entries
@@ -143,13 +149,6 @@ agg_fast_kernel(AggArgs a) {
         nself += __popcll((sb >> (g << LPR_LOG2)) & ((LPR == 64) ? ~0ull : ((1ull << LPR) - 1ull)));
       }
       const int cnt = min(LPR, maxd - ts);  // wave-uniform
-      if constexpr (NEED & NEED_SQ) {   // (the row's first batch carries the variance's shift: FAcc::sh)
-        if (ts == 0)
-          gather_batch<NEED, C, true>(a, R, acc, grp_addr, 4, row, jj, dd, dis_i, lane_live ? nd : 0, 0, 1, row_bytes, slot_off, start);
-        for (int t0 = ts == 0 ? FU : 0; t0 < cnt; t0 += FU)
-          gather_batch<NEED, C>(a, R, acc, grp_addr + (t0 << 2), 4, row, jj, dd, dis_i, lane_live ? nd : 0, ts + t0, 1, row_bytes,
-                                slot_off, start);
-      } else
       for (int t0 = 0; t0 < cnt; t0 += FU)
         gather_batch<NEED, C>(a, R, acc, grp_addr + (t0 << 2), 4, row, jj, dd, dis_i, lane_live ? nd : 0, ts + t0, 1, row_bytes,
                               slot_off, start);

@@ -335,9 +335,7 @@ struct FastRsrc {
 // holding this lane's first entry of the batch, `step` the byte distance to the next one; entry u of
 // the batch is valid iff first + u * vstep < n_valid (lane-dependent), and its CSR position is
 // pos_base + first + u * vstep; jj / dd are the staged source ids / deg^-1/2.
-// TAKE_SHIFT (NEED_SQ, one accumulator per row): the batch holds the row's first entry -- its value becomes the variance's
-// shift (FAcc::sh) as it arrives, without a request of its own (0 when that entry is absent or excluded: as good a shift).
-template <int NEED, class C, bool TAKE_SHIFT = false>
+template <int NEED, class C>
 __device__ inline void gather_batch(const AggArgs& a, const FastRsrc& R, FAcc<NEED>& acc, int addr0, int step, int row,
                                     int jj, float dd, float dis_i, int n_valid, int first, int vstep,
                                     unsigned row_bytes, unsigned slot_off, int pos_base) {
@@ -354,7 +352,6 @@ __device__ inline void gather_batch(const AggArgs& a, const FastRsrc& R, FAcc<NE
     w[u] = bperm(addr, dd) * dis_i;
     if (C::yl(a) && !C::xl(a)) w[u] = is_self ? 0.f : w[u];  // mixed sets: self-entry counts for sum/max only
   }
-  if constexpr (TAKE_SHIFT && (NEED & NEED_SQ)) acc.sh = v[0];
 #pragma unroll
   for (int u = 0; u < FU; ++u) fold<NEED>(acc, v[u], w[u], in_x[u], pos_base + first + u * vstep);
 }

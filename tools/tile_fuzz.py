@@ -13,7 +13,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 LAYERS = [("opt", 128, 8, 4, ["sum", "mean", "max", "symnorm"]), ("lay", 128, 8, 4, ["symadd", "max", "mean"]), ("lay", 128, 8, 4, ["symadd"]),
           ("opt", 64, 4, 4, ["min", "std", "var"]), ("opt", 96, 4, 2, ["sum", "max"]), ("lay", 168, 8, 4, ["symadd"]),
           ("lay", 124, 4, 4, ["add", "std", "max"]), ("opt", 32, 2, 2, ["mean"]), ("lay", 224, 4, 4, ["add", "mean", "max"])]
-bad = refused = 0
+bad = refused = fused = 0
 for case in range(n_cases):
     kind, hidden, H, B, aggrs = LAYERS[int(rng.integers(len(LAYERS)))]
     asl = bool(rng.random() < 0.8)
@@ -43,7 +43,9 @@ for case in range(n_cases):
     x = torch.randn(N, hidden, device=dev)
     kw = {}
     if rng.random() < 0.5: kw["edge_ptr"] = torch.tensor(eptr, dtype=torch.int64, device=dev)
-    if rng.random() < 0.5: kw["max_nodes"] = int(rng.choice([16, 64, 256, 1024]))
+    r_mx = rng.random()
+    if r_mx < 0.4: kw["max_nodes"] = int(sizes.max())          # the loader's true bound: the one-launch kernel when it is <= its tile
+    elif r_mx < 0.7: kw["max_nodes"] = int(rng.choice([16, 64, 256, 1024]))
     if rng.random() < 0.3: kw["edges_per_node"] = int(rng.choice([4, 16, 64]))
     desc = (case, kind, hidden, H, B, aggrs, asl, n_graphs, hi, dens, N, int(ei.size(1)), {k: (v if not torch.is_tensor(v) else "given") for k, v in kw.items()})
     try:
@@ -52,9 +54,10 @@ for case in range(n_cases):
             gb = egc_amd.GraphBatch(ei, ptr=torch.from_numpy(ptr.astype(np.int64)).to(dev), **kw)
             out = conv(x, gb) if kind == "opt" else conv(x=x, edge_index=gb)
             gb.check()
+            fused += any(isinstance(k, tuple) and k[-1] == "fused" and v for k, v in gb._setups.items())
         torch.cuda.synchronize()
         err = float((out - ref).abs().max() / max(1.0, float(ref.abs().max()))) if N else 0.0
-        if not err <= 5e-6:      # (two float32 summation orders: up to ~3e-6 on rows of 20-40 entries)
+        if not err <= (1e-5 if any(a in ("std", "var") for a in aggrs) else 5e-6):      # (two float32 summation orders: up to ~3e-6 on rows of 20-40 entries; `var` itself, unscaled, 5.3e-6 seen)
             bad += 1
             print("MISMATCH", err, desc, flush=True)
     except Exception as ex:
@@ -64,4 +67,4 @@ for case in range(n_cases):
             continue
         bad += 1
         print("EXC", msg, desc, flush=True)
-print(f"{n_cases} cases, {bad} bad, {refused} refused (a graph beyond the per-tile areas)")
+print(f"{n_cases} cases, {bad} bad, {refused} refused (a graph beyond the per-tile areas), {fused} through the one-launch kernel")
