@@ -864,6 +864,7 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
         ft_h8 bh[2], bl[2];
         a_read(buf, 2, bh[0], bl[0]);
         a_read(buf, 3, bh[1], bl[1]);
+        const f4 ri = *reinterpret_cast<const f4*>(lds_rowinv + buf * FT_CHUNK + 4 * qd);   // (the rows' scales, for the epilogue)
         __builtin_amdgcn_sched_barrier(0);
         f4 acc0 = f4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0;
 #pragma unroll
@@ -886,12 +887,17 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
           a_prefetch(nbuf, 1, ah[1], al[1]);
         }
         // D: lane -> column lane % 16, rows 4 (lane / 16) + i.  2^ex 2^ew (acc0 + 2^-11 (acc1 + acc2)) + bias
-        const f4 ri = *reinterpret_cast<const f4*>(lds_rowinv + buf * FT_CHUNK + 4 * qd);
-        f4 o;
-        o.x = __builtin_fmaf(__builtin_fmaf(acc1.x + acc2.x, 1.f / 2048.f, acc0.x), col_inv * ri.x, col_bias);
-        o.y = __builtin_fmaf(__builtin_fmaf(acc1.y + acc2.y, 1.f / 2048.f, acc0.y), col_inv * ri.y, col_bias);
-        o.z = __builtin_fmaf(__builtin_fmaf(acc1.z + acc2.z, 1.f / 2048.f, acc0.z), col_inv * ri.z, col_bias);
-        o.w = __builtin_fmaf(__builtin_fmaf(acc1.w + acc2.w, 1.f / 2048.f, acc0.w), col_inv * ri.w, col_bias);
+        // (on the packed fp32 pipe: the GEMM phase is bound by the SIMD's vector ISSUE -- 36 MFMAs hold it 288 of a step's
+        // cycles, the helpers' split 340, this epilogue and the LDS instructions the rest -- so eight instructions instead of
+        // sixteen are time; the same operations per component, the same bits)
+        const ft_f2 k2 = ft_f2{1.f / 2048.f, 1.f / 2048.f}, ci2 = ft_f2{col_inv, col_inv}, cb2 = ft_f2{col_bias, col_bias};
+        const ft_f2 a0l = __builtin_shufflevector(acc0, acc0, 0, 1), a0h = __builtin_shufflevector(acc0, acc0, 2, 3);
+        const ft_f2 tl = __builtin_shufflevector(acc1, acc1, 0, 1) + __builtin_shufflevector(acc2, acc2, 0, 1);
+        const ft_f2 th = __builtin_shufflevector(acc1, acc1, 2, 3) + __builtin_shufflevector(acc2, acc2, 2, 3);
+        const ft_f2 ul = __builtin_elementwise_fma(tl, k2, a0l), uh = __builtin_elementwise_fma(th, k2, a0h);
+        const ft_f2 sl = ci2 * __builtin_shufflevector(ri, ri, 0, 1), sh2 = ci2 * __builtin_shufflevector(ri, ri, 2, 3);
+        const ft_f2 ol = __builtin_elementwise_fma(ul, sl, cb2), oh = __builtin_elementwise_fma(uh, sh2, cb2);
+        f4 o = __builtin_shufflevector(ol, oh, 0, 1, 2, 3);
         if (dst_act) o = w_act<C>(a, o);
         if (dst_off >= 0) {
           char* po = base + dst_off + (FT_CHUNK * c + 4 * qd) * dst_stride;
