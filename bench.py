@@ -793,7 +793,8 @@ def main():
                 "host_cores": os.cpu_count(), "kind": "port",   # `cores` = the threads actually used (the contract's field)
                 "sample": f"full config-2 layer forward (E_eff={e_cached}), gcn_norm cached; best of 8/16/32/64 "
                           f"torch threads, median of 5 runs each after a warm-up; {cpu_s * 1e3:.1f} ms per forward "
-                          f"on a {os.cpu_count()}-core host",
+                          f"on a {os.cpu_count()}-core host (torch's scatter / index kernels stop scaling at 8-32 threads: in "
+                          f"plain words, the host is used as an {threads}-core machine)",
                 "hip_vs_port_rel_err": err}
         except Exception as ex:   # noqa: BLE001 -- the measured line is printed either way, with the failure in it
             log(f"cpu baseline failed: {ex!r}")
