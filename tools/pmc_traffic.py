@@ -41,6 +41,10 @@ def main():
     if "aggregate" in out["kernels"]:
         out["aggregate_kernel_hbm_bytes_per_launch"] = out["kernels"]["aggregate"]["hbm_bytes_per_launch"]
     dst = sys.argv[3] if len(sys.argv) > 3 else "profiles/pmc_traffic.json"
+    try:       # the side configs' entries (bench.py: side_traffic) come from their own passes: kept across a refresh of the headline's
+        out["side_configs"] = json.load(open(dst)).get("side_configs", {})
+    except Exception:   # noqa: BLE001
+        pass
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps(out, indent=1))
 
