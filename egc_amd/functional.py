@@ -359,7 +359,8 @@ def _batch_fused_pack(spec: LayerSpec, wcat: torch.Tensor, bcat):
     """The weight planes of egc_layer_forward_batch_fused_f32 (egc_batch_fused_pack), cached on the identity / version of
     the concatenated weights (rebuilt only when a parameter changes)."""
     key = (wcat.data_ptr(), wcat._version, bcat.data_ptr() if bcat is not None else 0,
-           bcat._version if bcat is not None else 0, spec.f_in, spec.f_out, spec.w_cols, str(wcat.device))
+           bcat._version if bcat is not None else 0, spec.f_in, spec.f_out, spec.w_cols, spec.ldb,
+           C.string_at(C.addressof(spec.c), C.sizeof(spec.c)), str(wcat.device), int(_stream_ptr(wcat.device) or 0))
     hit = _BATCH_FUSED_PACKS.get(key)
     if hit is None:
         lib = _C.load()
@@ -380,7 +381,7 @@ def _batch_fused_pack(spec: LayerSpec, wcat: torch.Tensor, bcat):
     return hit[2]
 
 
-def _batch_fused_setup(gb: GraphBatch, spec: LayerSpec, post, wcat):
+def _batch_fused_setup(gb: GraphBatch, spec: LayerSpec, post, wcat, x=None):
     """(tile_nodes, max_tile_edges) when this layer call can run as ONE launch on the batch, else None.  A layer that asks for
     the 24-bit-operand GEMM (EGC_GEMM_STDVAR_24BIT=1 and std / var) keeps the two-launch path; EGC_NO_FUSED_TILE=1 switches
     the path off."""
@@ -388,6 +389,8 @@ def _batch_fused_setup(gb: GraphBatch, spec: LayerSpec, post, wcat):
         return None
     if spec.gemm_flags != 0:
         return None
+    if x is not None and (not x.is_contiguous() or x.data_ptr() % 16 != 0):
+        return None          # (a view at a 4-byte offset of a flat buffer: the CSR / tile paths serve it, this launch reads 16-byte pieces)
     return gb.fused_setup(spec.c, post is not None and post.scale is not None)
 
 
@@ -611,7 +614,7 @@ def egc_layer_forward(graph: CSRGraph, spec: LayerSpec, x: torch.Tensor, wcat: t
     if the caller keeps one (otherwise it is produced here).  On a vertex-partitioned graph the halo rows
     of ``bases`` are exchanged (one all-to-all-v) between the two steps."""
     if isinstance(graph, GraphBatch):
-        fsetup = None if return_intermediates else _batch_fused_setup(graph, spec, post, wcat)
+        fsetup = None if return_intermediates else _batch_fused_setup(graph, spec, post, wcat, x)
         if fsetup is not None:
             return egc_layer_forward_batch_fused(graph, spec, x, wcat, bcat, bias, post, fsetup)
         tiled = None if return_intermediates else _batch_tile_setup(graph, spec, post)

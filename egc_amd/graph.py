@@ -544,7 +544,8 @@ class GraphBatch:
                 _IndexFlag._view.value = 0
             raise RuntimeError("egc_amd.GraphBatch: " + ("edge_index is not grouped by graph, or holds node ids outside its "
                                "graph: index out of range" if code & 1 else "a tile exceeds the per-tile areas (raise "
-                               "max_nodes / edges_per_node, or pass the plain edge_index)"))
+                               "max_nodes / edges_per_node, or pass the plain edge_index)" if code & 2 else
+                               "the one-launch kernel's internal hand-over timed out (status bit 2): its output is undefined"))
         return self
 
     def tile_setup(self, spec_c, with_post: bool):

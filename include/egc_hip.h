@@ -504,7 +504,7 @@ int egc_aggregate_combine_train_rows_f32(const egc_graph* graph, const egc_layer
  *                          loops_all_nodes = 0.  Inference form.
  * Every edge is checked against its tile: an edge that leaves the tile (list not grouped by graph, id out of range) or a
  * tile beyond max_tile_nodes / max_tile_edges raises *status (bit 0 / bit 1; zero it before the call) and the sticky
- * *host_flag (see egc_coo_to_csr_checked) and leaves the tile's rows unwritten.  A row's entries are summed in the order of
+ * *host_flag (see egc_coo_to_csr_checked); the rows of such a tile are written as zeros.  A row's entries are summed in the order of
  * the LDS atomics that built the CSR: sums are reproducible to rounding, max / min exactly.
  * ------------------------------------------------------------------------------------------ */
 int32_t egc_batch_tile_nodes(const egc_layer* layer, int32_t max_tile_nodes, int32_t max_tile_edges, int32_t with_post);
@@ -538,8 +538,10 @@ int egc_aggregate_combine_batch_f32(const int32_t* tiles, const int32_t* n_tiles
  *   egc_layer_forward_batch_fused_f32
  *                               the launch.  tile_nodes: a multiple of 16, <= egc_batch_fused_tile_nodes(...); status /
  *                               host_flag as egc_aggregate_combine_batch_f32 (bit 0: an edge leaves its tile or the graph
- *                               offsets do not cover [0, n_nodes); bit 1: a tile beyond tile_nodes / max_tile_edges; the
- *                               rows of such a tile are left unwritten).  Inference form, fp16x2-split GEMM (22-bit operands,
+ *                               offsets do not cover [0, n_nodes); bit 1: a tile beyond tile_nodes / max_tile_edges -- the
+ *                               rows of such a tile are written as zeros; bit 2: the workgroup-internal hand-over between
+ *                               the wavefronts that build a tile's CSR timed out -- a bounded spin, never a hang; the
+ *                               launch's output is then undefined).  Inference form, fp16x2-split GEMM (22-bit operands,
  *                               fp32 accumulate: the arithmetic of egc_basis_transform_packed at the north-star shape).
  * ------------------------------------------------------------------------------------------ */
 int32_t egc_batch_fused_tile_nodes(const egc_layer* layer, int32_t max_tile_edges, int32_t with_post);

@@ -43,7 +43,7 @@ pytestmark = pytest.mark.gpu
 # std / var layers: HIP vs float64 <= max(1e-5, STDVAR_K x the fp32 restatement's own error vs float64).  Measured over these
 # seeds (gpurun_out/r3_fuzz24.log, r3_fuzz22.log -> profiles/r03_stdvar_gemm_precision.md): with the 24-bit-operand GEMM
 # such layers run by default the worst ratio is 6.0 (two fp32 summation orders of E[x^2] - E[x]^2, amplified 158x: single
-# draws of the same rounding noise); with the 22-bit fp16x2 GEMM (EGC_GEMM_FAST=1) one case of seed 118 sits at 28x.
+# draws of the same rounding noise); with the 22-bit fp16x2 GEMM (the default since round 4; EGC_GEMM_STDVAR_24BIT=1 restores the 24-bit form) one case of seed 118 sits at 28x.
 # Round 4: the kernels accumulate the variance about the row's first entry (FAcc::sh, egc_aggregate_fast_dev.h) -- the same
 # number without the cancellation -- and such layers run the default fp16x2 GEMM.  Over the committed seeds and 300-330 (44
 # seeds, 5,280 configurations) every std / var layer is within 7e-7 of float64 where the float32 restatement is 1e-5 ... 3.7e-4
