@@ -770,37 +770,6 @@ def main():
     except Exception as exc:   # (a side field must not take the line down)
         result["std_layer"] = {"error": repr(exc)}
 
-    # ---- the fused-weightings launch (opt-in, see egc_aggregate_fusedw.hip): measured here so
-    # that the statement "slower than the two-launch path" stays a number of this run
-    try:
-        from egc_amd.functional import pack_fused
-        fplanes, fpack = pack_fused(spec, wcat, bcat)
-
-        def fused_gemm():
-            _C.check(lib.egc_basis_transform_packed(x.data_ptr(), fplanes.data_ptr(), None, n, F_IN, spec.f_g, 0,
-                                                    bases.data_ptr(), ldb, None, stream), "egc_basis_transform_packed")
-
-        def fused_agg():
-            _C.check(lib.egc_aggregate_combine_fused_f32(C.byref(g), C.byref(spec.c), x.data_ptr(), fpack.data_ptr(),
-                                                         bases.data_ptr(), ldb, bias.data_ptr(), None, out.data_ptr(),
-                                                         ws.data_ptr(), ws.numel(), stream), "egc_aggregate_combine_fused_f32")
-        ref_out = out.clone()
-        fused_gemm()
-        fg_ms = time_region(fused_gemm, 50)
-        fa_ms = time_region(fused_agg, 50)
-        ferr = float((out - ref_out).abs().max() / max(1.0, float(ref_out.abs().max())))
-        result["fused_weightings_experiment"] = {
-            "bases_only_gemm_ms": fg_ms, "aggregate_with_in_launch_weightings_ms": fa_ms, "layer_ms": fg_ms + fa_ms,
-            "rel_err_vs_two_launch_path": ferr, "default": False,
-            "note": "weightings Linear on fp32 MFMA inside the aggregate launch (no weightings array in memory); "
-                    "every producer wavefront takes a slot the gather needs"}
-        gemm_only()
-        agg_only()   # `out` back to the default path's result for the CPU comparison below
-    except RuntimeError as exc:  # outside the envelope, or the default library (the launch is opt-in: EGC_WITH_FUSEDW=1 build.sh)
-        result["fused_weightings_experiment"] = {
-            "skipped": "a closed experiment, not part of the default library (DESIGN.md section 8); build with "
-                       "EGC_WITH_FUSEDW=1 bash egc_amd/csrc/build.sh to measure it", "reason": str(exc)}
-
     log("algorithmic bytes (SURVEY.md 8d), per forward:")
     for k, v in terms.items():
         log(f"  {k:18s} {v / 1e6:10.2f} MB")

@@ -179,15 +179,6 @@ SYMBOLS = {
                                                      C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                                      C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
-    "egc_fused_supported": (C.c_int, [C.POINTER(EgcLayer)]),
-    "egc_fused_pack_bytes": (C.c_size_t, [C.POINTER(EgcLayer)]),
-    "egc_fused_pack": (C.c_int, [C.POINTER(EgcLayer), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
-    "egc_aggregate_combine_fused_f32": (C.c_int, [C.POINTER(EgcGraph), C.POINTER(EgcLayer), C.c_void_p, C.c_void_p,
-                                                  C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(EgcPost), C.c_void_p,
-                                                  C.c_void_p, C.c_size_t, C.c_void_p]),
-    "egc_layer_forward_fused_f32": (C.c_int, [C.POINTER(EgcGraph), C.POINTER(EgcLayer), C.c_void_p, C.c_void_p,
-                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
-                                              C.c_void_p, C.c_size_t, C.c_void_p]),
     "egc_last_error": (C.c_char_p, []),
     "egc_version": (C.c_char_p, []),
 }

@@ -477,7 +477,7 @@ static WsLayout ws_layout(const egc_layer* L, int64_t n_nodes, int64_t n_edges, 
   const int64_t rec_chunks = (n_chunks >= 0 && n_chunks <= c.cap_chunks) ? n_chunks : c.cap_chunks;
   w.partial_bytes = align256((size_t)rec_chunks * 7 * rec_lanes * 16);
   w.nself_bytes = align256((size_t)rec_chunks * sizeof(int));
-  w.queue_bytes = align256((size_t)FUSEDW_QUEUE_INTS * sizeof(int));  // work queue of the fused-weightings launch
+  w.queue_bytes = align256((size_t)FUSEDW_QUEUE_INTS * sizeof(int));  // (reserved: keeps the workspace layout of rounds 2-4)
   // order: [counters][queue] -- the part that must be zero before the first use, its size a function of (n_nodes,
   // n_edges) alone -- then [partials][nself], records that are written before they are read
   w.total = w.counter_bytes + w.queue_bytes + w.partial_bytes + w.nself_bytes;
@@ -504,16 +504,6 @@ static int launch_all(const AggArgs& a, int64_t n_nodes, const PlanCaps& caps, i
   return EGC_OK;
 }
 
-#ifndef EGC_WITH_FUSEDW
-// The launch with the weightings Linear inside (egc_aggregate_fusedw.hip, SURVEY.md 8f rank 3 on the FULL graph) measured
-// 1.56 x slower than the two-launch path on MI355X (round 3: 218 against 140 us) and is not part of the default library:
-// build with EGC_WITH_FUSEDW=1 (egc_amd/csrc/build.sh) to get it.  Without it the entry points report "unsupported"
-// (egc_fused_supported() == 0).  For batches of whole graphs the fusion IS the default: egc_fused_tile.hip.
-bool fusedw_supported(const AggArgs&, int) { return false; }
-size_t fusedw_pack_floats(int, int) { return 0; }
-int fusedw_pack(const float*, const float*, int, int, int, int, int, float*, hipStream_t) { return EGC_ERR_UNSUPPORTED; }
-int launch_fusedw(AggArgs, const PlanCaps&, hipStream_t) { return EGC_ERR_UNSUPPORTED; }
-#endif
 
 }  // namespace egc
 
@@ -592,8 +582,7 @@ static int aggregate_combine_impl(const egc_graph* graph, const egc_layer* layer
                                   const float* weightings, const float* bias, const egc_post* post, float* out,
                                   float* stats, int32_t* cnt_out, int64_t row_begin, int64_t row_end, void* workspace,
                                   size_t workspace_bytes, egc_stream_t stream_, int32_t* arg_max = nullptr,
-                                  int32_t* arg_min = nullptr, bool* arg_done = nullptr, int32_t ldw = 0,
-                                  const float* x_fused = nullptr, const void* fused_packed = nullptr);
+                                  int32_t* arg_min = nullptr, bool* arg_done = nullptr, int32_t ldw = 0);
 
 int egc_aggregate_combine_f32(const egc_graph* graph, const egc_layer* layer, const float* bases, int32_t ldb,
                               const float* weightings, const float* bias, float* out, int32_t* arg_max,
@@ -662,7 +651,7 @@ static int aggregate_combine_impl(const egc_graph* graph, const egc_layer* layer
                                   const float* weightings, const float* bias, const egc_post* post, float* out,
                                   float* stats, int32_t* cnt_out, int64_t row_begin, int64_t row_end, void* workspace,
                                   size_t workspace_bytes, egc_stream_t stream_, int32_t* arg_max, int32_t* arg_min,
-                                  bool* arg_done, int32_t ldw, const float* x_fused, const void* fused_packed) {
+                                  bool* arg_done, int32_t ldw) {
   hipStream_t stream = (hipStream_t)stream_;
   if (graph == nullptr) return EGC_ERR_INVALID;
   int st = validate_layer(layer);
@@ -671,9 +660,7 @@ static int aggregate_combine_impl(const egc_graph* graph, const egc_layer* layer
   if (n < 0 || e < 0 || n >= ((int64_t)1 << 31) - 1 || e >= ((int64_t)1 << 31) - 1) return EGC_ERR_INVALID;
   if (n == 0) return EGC_OK;
   if (graph->rowptr == nullptr || graph->plan == nullptr || (e > 0 && graph->col == nullptr)) return EGC_ERR_INVALID;
-  const bool fused = x_fused != nullptr;  // weightings computed inside the launch: no array to read
-  if (bases == nullptr || (weightings == nullptr && !fused) || out == nullptr) return EGC_ERR_INVALID;
-  if (fused && fused_packed == nullptr) return EGC_ERR_INVALID;
+  if (bases == nullptr || weightings == nullptr || out == nullptr) return EGC_ERR_INVALID;
   if (ldb != egc_bases_ld(layer)) return EGC_ERR_INVALID;
   if ((reinterpret_cast<uintptr_t>(bases) & 15) != 0) return EGC_ERR_INVALID;
   const int64_t n_src = graph->n_src_rows > 0 ? graph->n_src_rows : n;  // owned rows + halo rows
@@ -717,7 +704,7 @@ static int aggregate_combine_impl(const egc_graph* graph, const egc_layer* layer
   a.Ls = layer_basis_stride(layer);
   a.W = a.H * a.B * a.A;
   a.ldw = ldw > 0 ? ldw : a.W;  // row stride of `weightings` (a column block of a wider array when > W)
-  if (!fused && a.ldw != a.W && (a.ldw < a.W || (a.ldw & 3) != 0 || (reinterpret_cast<uintptr_t>(weightings) & 15) != 0))
+  if (a.ldw != a.W && (a.ldw < a.W || (a.ldw & 3) != 0 || (reinterpret_cast<uintptr_t>(weightings) & 15) != 0))
     return EGC_ERR_INVALID;
   for (int t = 0; t < EGC_MAX_AGGRS; ++t) a.aggr[t] = t < a.A ? layer->aggrs[t] : 0;
   a.x_looped = layer->agg_set == EGC_SET_LOOPED;
@@ -760,22 +747,15 @@ static int aggregate_combine_impl(const egc_graph* graph, const egc_layer* layer
   a.queue = (int*)((char*)workspace + w.counter_bytes);
   a.partial = (float*)((char*)workspace + w.counter_bytes + w.queue_bytes);
   a.partial_nself = (int*)((char*)workspace + w.counter_bytes + w.queue_bytes + w.partial_bytes);
-  a.x = x_fused;
+  a.x = nullptr;
   a.F_in = layer->in_channels;
-  a.M = 0;  // set by launch_fusedw
-  a.wfrag = (const float*)fused_packed;
-  a.wbias4 = fused ? (const float*)fused_packed + (fusedw_pack_floats(a.H, a.F_in) - (size_t)a.H * 16) : nullptr;
+  a.M = 0;
+  a.wfrag = nullptr;
+  a.wbias4 = nullptr;
   PlanCaps caps = plan_caps(n, e);
   a.rows_per_wave = 0;
   a.n_chunks_hint = (graph->n_chunks >= 0 && graph->n_chunks <= caps.cap_chunks) ? (int)graph->n_chunks : -1;
   if (const char* env = getenv("EGC_ROWS_PER_WAVE")) a.rows_per_wave = atoi(env);
-  if (fused) {
-    a.lpr_log2 = 4;
-    if ((reinterpret_cast<uintptr_t>(x_fused) & 15) != 0 || (reinterpret_cast<uintptr_t>(fused_packed) & 15) != 0)
-      return EGC_ERR_INVALID;
-    if (!fusedw_supported(a, layer->weight_layout)) return EGC_ERR_UNSUPPORTED;
-    return launch_fusedw(a, caps, stream);
-  }
   const bool force_generic = getenv("EGC_FORCE_GENERIC") != nullptr;
   if (!force_generic && fast_path_supported(a, layer->weight_layout, chunks)) {
     if (arg_done != nullptr) *arg_done = true;  // the register-resident kernels track the arg positions themselves
@@ -790,59 +770,6 @@ static int aggregate_combine_impl(const egc_graph* graph, const egc_layer* layer
     case 4: return launch_all<4>(a, n, caps, wpb, lds_bytes, stream);
     default: return EGC_ERR_UNSUPPORTED;
   }
-}
-
-int egc_fused_supported(const egc_layer* layer) {
-  if (validate_layer(layer) != EGC_OK) return 0;
-  AggArgs a = {};
-  a.H = layer->num_heads; a.B = layer->num_bases; a.A = layer->num_aggrs;
-  a.L = layer->out_channels / layer->num_heads; a.Ls = layer_basis_stride(layer);
-  a.ldb = egc_bases_ld(layer); a.slots = a.ldb / 4; a.W = a.H * a.B * a.A; a.F_out = layer->out_channels;
-  a.F_in = layer->in_channels; a.n_nodes = 1; a.act = layer->weight_act;
-  a.x_looped = layer->agg_set == EGC_SET_LOOPED; a.y_looped = layer->sym_set == EGC_SET_LOOPED;
-  for (int t = 0; t < a.A && t < EGC_MAX_AGGRS; ++t) a.aggr[t] = layer->aggrs[t];
-  return fusedw_supported(a, layer->weight_layout) ? 1 : 0;
-}
-
-size_t egc_fused_pack_bytes(const egc_layer* layer) {
-  if (validate_layer(layer) != EGC_OK) return 0;
-  return fusedw_pack_floats(layer->num_heads, layer->in_channels) * sizeof(float);
-}
-
-int egc_fused_pack(const egc_layer* layer, const float* wcat, const float* bcat, void* packed, size_t packed_bytes,
-                   egc_stream_t stream) {
-  int st = validate_layer(layer);
-  if (st != EGC_OK) return st;
-  if (wcat == nullptr || packed == nullptr) return EGC_ERR_INVALID;
-  if (!egc_fused_supported(layer)) return EGC_ERR_UNSUPPORTED;
-  if (packed_bytes < egc_fused_pack_bytes(layer)) return EGC_ERR_WORKSPACE;
-  const int fg = layer->num_bases * layer_basis_stride(layer);
-  const int w = layer->num_heads * layer->num_bases * layer->num_aggrs;
-  return fusedw_pack(wcat, bcat, layer->in_channels, fg + w, fg, layer->num_heads, layer->num_aggrs, (float*)packed,
-                     (hipStream_t)stream);
-}
-
-int egc_aggregate_combine_fused_f32(const egc_graph* graph, const egc_layer* layer, const float* x, const void* fused_packed,
-                                    const float* bases, int32_t ldb, const float* bias, const egc_post* post, float* out,
-                                    void* workspace, size_t workspace_bytes, egc_stream_t stream) {
-  if (x == nullptr || fused_packed == nullptr) return EGC_ERR_INVALID;
-  if (post != nullptr && ((post->scale == nullptr) != (post->shift == nullptr))) return EGC_ERR_INVALID;
-  return aggregate_combine_impl(graph, layer, bases, ldb, nullptr, bias, post, out, nullptr, nullptr, 0, -1, workspace,
-                                workspace_bytes, stream, nullptr, nullptr, nullptr, 0, x, fused_packed);
-}
-
-int egc_layer_forward_fused_f32(const egc_graph* graph, const egc_layer* layer, const float* x, const void* bases_packed,
-                                const void* fused_packed, const float* bias, float* bases, int32_t ldb, float* out,
-                                void* workspace, size_t workspace_bytes, egc_stream_t stream) {
-  if (graph == nullptr) return EGC_ERR_INVALID;
-  int st = validate_layer(layer);
-  if (st != EGC_OK) return st;
-  const int fg = layer->num_bases * layer_basis_stride(layer);
-  st = egc_basis_transform_packed(x, bases_packed, nullptr, graph->n_nodes, layer->in_channels, fg, 0, bases, ldb, nullptr,
-                                  stream);
-  if (st != EGC_OK) return st;
-  return egc_aggregate_combine_fused_f32(graph, layer, x, fused_packed, bases, ldb, bias, nullptr, out, workspace,
-                                         workspace_bytes, stream);
 }
 
 int egc_layer_forward_f32(const egc_graph* graph, const egc_layer* layer, const float* x, const float* wcat,

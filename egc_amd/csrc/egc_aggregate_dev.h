@@ -194,13 +194,7 @@ int launch_fast(AggArgs a, int64_t n_nodes, const PlanCaps& caps, hipStream_t st
 bool wide_path_supported(const AggArgs& a, int layout);
 int launch_wide_rows(AggArgs a, const PlanCaps& caps, hipStream_t stream);   // short rows AND long-row chunks: one launch
 
-// egc_aggregate_fusedw.hip: the same with the weightings Linear computed inside the launch (a.x, a.wfrag, ...).
-constexpr int FUSEDW_QUEUE_INTS = 16;  // work-queue shards + exit counter (workspace, zero on entry and on exit)
-bool fusedw_supported(const AggArgs& a, int layout);
-size_t fusedw_pack_floats(int H, int f_in);
-int fusedw_pack(const float* wcat, const float* bcat, int f_in, int ldw_cat, int col0, int H, int A, float* packed,
-                hipStream_t stream);
-int launch_fusedw(AggArgs a, const PlanCaps& caps, hipStream_t stream);
+constexpr int FUSEDW_QUEUE_INTS = 16;  // (reserved words of the aggregate workspace: layout of rounds 2-4)
 
 // egc_aggregate_tile.hip: batches of small graphs, tiles of whole graphs with the CSR built in LDS
 int tile_capacity(const AggArgs& a, int tmax, int emax);

@@ -87,7 +87,7 @@ agg_fast_kernel(AggArgs a) {
   if ((int)blockIdx.x < a.chunk_blocks) {
     // ---------------- long-row chunk role: the G groups split one chunk's entries ----------------
     const int c = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
-    long_row_chunk<LPR_LOG2, HPB, NEED, C, false>(a, R, c, lane, lds_w, lds_bias, lds_scale);
+    long_row_chunk<LPR_LOG2, HPB, NEED, C>(a, R, c, lane, lds_w, lds_bias, lds_scale);
     return;
   }
 

@@ -1,6 +1,5 @@
 // Device-side building blocks of the register-resident EGC aggregate+combine kernels (gfx950), shared by
-// egc_aggregate_fast.hip (weightings read from memory) and egc_aggregate_fusedw.hip (weightings computed in the
-// launch).  See egc_aggregate_fast.hip for the description of the scheme.
+// egc_aggregate_fast.hip (weightings read from memory) and egc_fused_tile.hip (weightings computed in the launch).  See egc_aggregate_fast.hip for the description of the scheme.
 #pragma once
 #include <stdlib.h>
 
@@ -361,7 +360,7 @@ __device__ inline void gather_batch(const AggArgs& a, const FastRsrc& R, FAcc<NE
 // merged aggregates, its entry count `deg` and self-entry count `nself`; `store` masks the output.
 // ---------------------------------------------------------------------------------------------
 // W_READY: the row's weightings already sit in LDS at lds_w + g * w_lds_stride as [h][b][4] with the
-// nonlinearity applied (egc_aggregate_fusedw.hip: computed in the launch); `wpre` is then unused.
+// nonlinearity applied (egc_fused_tile.hip: computed in the launch); `wpre` is then unused.
 template <int LPR_LOG2, int HPB, int NEED, class C, bool W_READY = false>
 __device__ inline void finish_group(const AggArgs& a, const FastRsrc& R, int lane, int row, bool row_ok, FAcc<NEED>& acc,
                                     int deg, int nself, float dis_i, f4 vself, bool has_self, const f4 (&wpre)[2],
@@ -589,7 +588,12 @@ __device__ inline void load_row_operands(const AggArgs& a, const FastRsrc& R, in
   }
   // (a masked lane group reads the first row of the launch's own range: a caller that finishes rows [b, e) only needs
   // the weightings of those rows to exist)
+#ifdef EGC_DIAG_W_ROW0     // diagnostic build (tools/f3_roundtrip_cost.py): every row reads the SAME weightings row -- the launch with
+                           // the instruction stream unchanged and the weightings' HBM traffic gone (results are wrong, times are not)
+  const float* wrow = a.weightings + (int64_t)a.row_begin * a.ldw;
+#else
   const float* wrow = a.weightings + (int64_t)(row_ok ? row : a.row_begin) * a.ldw;
+#endif
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int c0 = (q + k * LPR) * 4;
@@ -605,22 +609,7 @@ __device__ inline void load_row_operands(const AggArgs& a, const FastRsrc& R, in
 
 
 
-// ---------------------------------------------------------------------------------------------
-// Weightings inside the launch (egc_aggregate_fusedw.hip): w[row] = x[row] @ comb_weight^T + comb_bias on
-// v_mfma_f32_16x16x4_f32 -- exact fp32 (a k-ordered fmaf chain), no operand splitting.  A tile is 16 rows; the
-// MFMA runs with the weights as the A operand (16 weight columns = one head: [b = 4][a = 4]) and x^T as B, so that
-// lane (j = lane & 15, quad = lane >> 4) ends up with w[row j][head][b = quad][a = 0..3] in one accumulator: the
-// combine's unit.  k is consumed in the order 16 m + 4 (lane >> 4) + t, which makes both operands 16-byte loads:
-// x[row][16 m + 4 quad ..+3] and the pre-arranged fragment a.wfrag[((m * H + head) * 64 + lane)].
-// ---------------------------------------------------------------------------------------------
-__device__ inline f4 mfma4(f4 av, f4 xv, f4 acc) {
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, xv.x, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, xv.y, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, xv.z, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, xv.w, acc, 0, 0, 0);
-  return acc;
-}
-
+// the weight nonlinearity on four weightings (egc_fused_tile.hip applies it where the D tile leaves the matrix cores)
 template <class C>
 __device__ inline f4 w_act(const AggArgs& a, f4 t) {
   if (C::act(a) == EGC_ACT_SIGMOID)
@@ -630,133 +619,11 @@ __device__ inline f4 w_act(const AggArgs& a, f4 t) {
   return t;
 }
 
-__device__ inline __amdgpu_buffer_rsrc_t x_rsrc(const AggArgs& a) {
-  return __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (unsigned)a.n_nodes * (unsigned)a.F_in * 4u, 0x00020000);
-}
-
-// A tile's weightings for heads h0 .. h0 + NH - 1 (of HT): acc[hh] of lane (j = lane & 15, quad = lane >> 4) =
-// w[row of lane j][head h0 + hh][b = quad][a = 0..3]; every lane passes the row its j stands for.
-//
-// The fragment stream is software-pipelined by hand: the loads are inline assembly (the compiler otherwise sinks
-// them to their uses and exposes the L2 latency twice per k-step: measured 65 k cycles per tile against 8 k of
-// MFMA) and the waits are counted.  Invariant at the top of k-step m: outstanding, oldest first, are x_m and the NH
-// fragments of step m.  Each pair of heads waits for exactly its two fragments, runs its 8 MFMAs and immediately
-// requests the same two fragments of step m + 1 into the registers it has just read -- every load has a whole
-// k-step (4 NH MFMAs) to arrive and only NH fragment registers are needed.
-template <int N>
-__device__ inline void vm_wait2(f4& p, f4& q) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(p), "+v"(q) : "n"(N)); }
-template <int N>
-__device__ inline void vm_wait3(f4& p, f4& q, f4& r) { asm volatile("s_waitcnt vmcnt(%3)" : "+v"(p), "+v"(q), "+v"(r) : "n"(N)); }
-__device__ inline f4 frag_load(unsigned lane_off, const f4* base) {
-  f4 v;
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(lane_off), "s"(base) : "memory");
-  return v;
-}
-__device__ inline f4 x_load(__amdgpu_buffer_rsrc_t xr, unsigned off) {
-  f4 v;
-  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v) : "v"(off), "s"(xr) : "memory");
-  return v;
-}
-__device__ inline void mfma_pair(f4& c0, f4& c1, const f4 a0, const f4 a1, const f4 x) {
-  c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, x.x, c0, 0, 0, 0);
-  c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, x.x, c1, 0, 0, 0);
-  c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, x.y, c0, 0, 0, 0);
-  c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, x.y, c1, 0, 0, 0);
-  c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, x.z, c0, 0, 0, 0);
-  c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, x.z, c1, 0, 0, 0);
-  c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, x.w, c0, 0, 0, 0);
-  c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, x.w, c1, 0, 0, 0);
-}
-
-template <int NH>
-__device__ inline void w_tile(const AggArgs& a, __amdgpu_buffer_rsrc_t xr, int lane, int row, bool row_ok, int h0, int HT,
-                              f4 (&acc)[NH]) {
-  static_assert(NH == 4 || NH == 8, "pairs of heads, counted waits");
-  const int quad = lane >> 4;
-  const unsigned lane_off = (unsigned)lane * 16u;
-  // wave-uniform base of the fragments of (k-step m, head h0): fragment order [m][h][lane]
-  const f4* frag = reinterpret_cast<const f4*>(a.wfrag) + h0 * 64;
-  const f4* b4 = reinterpret_cast<const f4*>(a.wbias4) + h0 * 4;
-  const unsigned xrow = row_ok ? (unsigned)row * (unsigned)a.F_in * 4u : OOB;
-  auto xoff = [&](int m) -> unsigned {
-    const int k0 = 16 * m + 4 * quad;
-    return (xrow != OOB && k0 < a.F_in) ? xrow + (unsigned)k0 * 4u : OOB;
-  };
-#pragma unroll
-  for (int hh = 0; hh < NH; ++hh) acc[hh] = b4[hh * 4 + quad];
-  // the compiler retires ITS loads here (it cannot see the hand-issued ones below and would otherwise drain the
-  // whole queue inside the loop); the counted waits then start from an empty queue
-#pragma unroll
-  for (int hh = 0; hh < NH; ++hh) asm volatile("" : "+v"(acc[hh]));
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  const int M = a.M;
-  const int64_t kstep = (int64_t)HT * 64;           // f4 elements between consecutive k-steps
-  f4 buf[NH];
-  // x lives in two register sets used alternately: a copy `xc = xn` would read xn before its load has landed
-  // (the compiler cannot see that the register is still in flight)
-  f4 xa = x_load(xr, xoff(0)), xb;
-#pragma unroll
-  for (int hh = 0; hh < NH; ++hh) buf[hh] = frag_load(lane_off, frag + hh * 64);
-  auto step = [&](f4& xcur, f4& xnext, int m) {     // k-step m, not the last one
-    const f4* fn = frag + (int64_t)(m + 1) * kstep;
-    vm_wait3<NH - 2>(xcur, buf[0], buf[1]);
-    xnext = x_load(xr, xoff(m + 1));
-#pragma unroll
-    for (int hp = 0; hp < NH; hp += 2) {
-      if (hp > 0) vm_wait2<NH - 1>(buf[hp], buf[hp + 1]);
-      mfma_pair(acc[hp], acc[hp + 1], buf[hp], buf[hp + 1], xcur);
-      buf[hp] = frag_load(lane_off, fn + hp * 64);
-      buf[hp + 1] = frag_load(lane_off, fn + (hp + 1) * 64);
-    }
-  };
-  auto last = [&](f4& xcur) {                       // nothing is requested any more
-    vm_wait3<NH - 2>(xcur, buf[0], buf[1]);
-    mfma_pair(acc[0], acc[1], buf[0], buf[1], xcur);
-    vm_wait2<NH - 4>(buf[2], buf[3]);
-    mfma_pair(acc[2], acc[3], buf[2], buf[3], xcur);
-    if constexpr (NH == 8) {
-      vm_wait2<2>(buf[4], buf[5]);
-      mfma_pair(acc[4], acc[5], buf[4], buf[5], xcur);
-      vm_wait2<0>(buf[6], buf[7]);
-      mfma_pair(acc[6], acc[7], buf[6], buf[7], xcur);
-    }
-  };
-  // M is even (the pack pads an odd number of k-steps with a zero step): ONE tail, no merge of two register
-  // assignments in front of a wait (a merged path would copy the x register that is still in flight)
-  int m = 0;
-  for (; m + 2 < M; m += 2) {
-    step(xa, xb, m);
-    step(xb, xa, m + 1);
-  }
-  step(xa, xb, m);
-  last(xb);
-}
-
-// One long row, by the wavefront that finishes it: all 16 MFMA columns carry the same row, heads four at a time
-// (16 accumulator + 16 fragment registers next to the merged aggregates); lanes (j < G, quad) then write strip j,
-// so that every lane group finds the row's weightings ([h][b][4], nonlinearity applied) in its own strip.
-template <class C>
-__device__ inline void w_row_to_strips(const AggArgs& a, int lane, int row, float* lds_w) {
-  const int quad = lane >> 4, j = lane & 15;
-  const __amdgpu_buffer_rsrc_t xr = x_rsrc(a);
-  for (int h0 = 0; h0 < C::H(a); h0 += 4) {
-    f4 acc[4];
-    w_tile<4>(a, xr, lane, row, true, h0, C::H(a), acc);
-    if (j < 4) {
-      float* wl = lds_w + j * a.w_lds_stride + (h0 * 4 + quad) * 4;
-#pragma unroll
-      for (int hh = 0; hh < 4; ++hh) *reinterpret_cast<f4*>(wl + hh * 16) = w_act<C>(a, acc[hh]);
-    }
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-}
-
 // ---------------------------------------------------------------------------------------------
 // Long-row chunk role: the G lane groups of one wavefront split the entries of chunk `c`; the wavefront that
-// completes a row's last chunk merges the partial records and finishes the row.  FUSEDW: the finishing wavefront
-// computes the row's weightings itself (w_row_to_strips) instead of reading them from memory.
+// completes a row's last chunk merges the partial records and finishes the row.
 // ---------------------------------------------------------------------------------------------
-template <int LPR_LOG2, int HPB, int NEED, class C, bool FUSEDW>
+template <int LPR_LOG2, int HPB, int NEED, class C>
 __device__ inline void long_row_chunk(const AggArgs& a, const FastRsrc& R, int c, int lane, float* lds_w,
                                       const float* lds_bias, const float* lds_scale) {
   constexpr int LPR = 1 << LPR_LOG2, G = 64 / LPR;
@@ -888,16 +755,9 @@ __device__ inline void long_row_chunk(const AggArgs& a, const FastRsrc& R, int c
   // every group now holds the whole row: all run the epilogue, group 0 stores
   f4 wpre[2], vself;
   bool has_self;
-  if constexpr (FUSEDW) {
-    w_row_to_strips<C>(a, lane, row, lds_w);
-    load_row_operands<LPR_LOG2, C, true>(a, R, lane, row, true, wpre, vself, has_self);
-    finish_group<LPR_LOG2, HPB, NEED, C, true>(a, R, lane, row, true, acc, deg, nself, dis_i, vself, has_self, wpre, g == 0,
-                                               lds_w, lds_bias, lds_scale);
-  } else {
-    load_row_operands<LPR_LOG2, C>(a, R, lane, row, true, wpre, vself, has_self);
-    finish_group<LPR_LOG2, HPB, NEED, C>(a, R, lane, row, true, acc, deg, nself, dis_i, vself, has_self, wpre, g == 0,
-                                         lds_w, lds_bias, lds_scale);
-  }
+  load_row_operands<LPR_LOG2, C>(a, R, lane, row, true, wpre, vself, has_self);
+  finish_group<LPR_LOG2, HPB, NEED, C>(a, R, lane, row, true, acc, deg, nself, dis_i, vself, has_self, wpre, g == 0,
+                                       lds_w, lds_bias, lds_scale);
 }
 
 }  // namespace egc

@@ -171,7 +171,11 @@ __global__ void __launch_bounds__(F16X2_THREADS) basis_gemm_f16x2_kernel(const f
                : __builtin_amdgcn_make_buffer_rsrc((void*)weightings, 0, (unsigned)(row_hi * (int64_t)W * 4), 0x00020000);
   const int out_ld = to_bases ? ldb : W;
   const int out_col = (to_bases ? cb : cb - ldb) + l31;
+#if defined(EGC_DIAG_GEMM_NO_W_STORE) || defined(EGC_DIAG_GEMM_NO_W)   // diagnostic builds (tools/f3_roundtrip_cost.py): the weightings are
+  const bool col_ok = to_bases && out_col < ldb;                        // not written / not computed at all (wrong results, honest times)
+#else
   const bool col_ok = out_col < (to_bases ? ldb : W);
+#endif
   const unsigned raw_lds = (unsigned)(uintptr_t)raw;  // LDS byte address of the ring
   const bool third = wave < 8;
 
@@ -249,6 +253,9 @@ __global__ void __launch_bounds__(F16X2_THREADS) basis_gemm_f16x2_kernel(const f
   };
   f32x16 acc0, acc1, t;   // t: previous tile's acc0 + 2^-11 acc1, waiting for its scales
   auto mfma_step = [&](int s, const f16x8 xh, const f16x8 xl) {
+#ifdef EGC_DIAG_GEMM_NO_W
+    if (!to_bases) return;
+#endif
     acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wf[s][0], acc0, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, wf[s][0], acc1, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wf[s][1], acc1, 0, 0, 0);

@@ -445,97 +445,6 @@ def segment_mean(x: torch.Tensor, seg_ptr: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def fused_supported(spec: LayerSpec) -> bool:
-    """True when the layer qualifies for the launch that computes the weightings itself (egc_fused_supported)."""
-    return bool(_C.load().egc_fused_supported(C.byref(spec.c)))
-
-
-def fused_enabled() -> bool:
-    """EGC_FUSEDW=1 routes qualifying inference calls through the fused-weightings launch.  Off by default: on
-    MI355X it is slower than the two-launch path."""
-    return _C.env_flag("EGC_FUSEDW")
-
-
-_FUSED_PACKS: "dict[tuple, tuple]" = {}
-
-
-def _fused_packs(spec: LayerSpec, wcat: torch.Tensor, bcat):
-    """pack_fused with a small cache keyed on the identity/version of the concatenated weights."""
-    key = (wcat.data_ptr(), wcat._version, bcat.data_ptr() if bcat is not None else 0,
-           bcat._version if bcat is not None else 0, spec.f_in, spec.f_out, spec.w_cols, str(wcat.device))
-    hit = _FUSED_PACKS.get(key)
-    if hit is None:
-        if len(_FUSED_PACKS) >= 16:
-            _FUSED_PACKS.clear()
-        hit = (wcat, bcat) + pack_fused(spec, wcat, bcat)   # keep the keyed tensors alive: their addresses are the key
-        _FUSED_PACKS[key] = hit
-    return hit[2], hit[3]
-
-
-def pack_fused(spec: LayerSpec, wcat: torch.Tensor, bcat: torch.Tensor | None):
-    """(planes of the basis weights alone, fused pack of the combination Linear) for egc_layer_forward_fused: the
-    GEMM then writes only `bases`; the weightings never exist in memory (egc_fused_pack, egc_basis_pack w_cols = 0)."""
-    lib = _C.load()
-    _check_f32(wcat, "wcat", (spec.f_in, spec.f_g + spec.w_cols))
-    dev = wcat.device
-    wcat = wcat.contiguous()
-    with _device_guard(dev):
-        wb = wcat[:, :spec.f_g].contiguous()
-        nb = lib.egc_basis_pack_bytes(spec.f_in, spec.f_g, 0)
-        planes = torch.empty(nb, dtype=torch.uint8, device=dev)
-        _C.check(lib.egc_basis_pack(wb.data_ptr(), spec.f_in, spec.f_g, 0, planes.data_ptr(), nb, _stream_ptr(dev)),
-                 "egc_basis_pack")
-        nf = lib.egc_fused_pack_bytes(C.byref(spec.c))
-        fused = torch.empty(nf, dtype=torch.uint8, device=dev)
-        _C.check(lib.egc_fused_pack(C.byref(spec.c), wcat.data_ptr(), bcat.contiguous().data_ptr() if bcat is not None else None,
-                                    fused.data_ptr(), nf, _stream_ptr(dev)), "egc_fused_pack")
-    return planes, fused
-
-
-def egc_layer_forward_fused(graph: CSRGraph, spec: LayerSpec, x: torch.Tensor, planes: torch.Tensor, fused: torch.Tensor,
-                            bias: torch.Tensor | None, post: PostOp | None = None, return_bases: bool = False):
-    """One layer forward with the weightings computed inside the aggregate launch (egc_layer_forward_fused_f32 /
-    egc_basis_transform_packed + egc_aggregate_combine_fused_f32): two launches, no `weightings` array."""
-    lib = _C.load()
-    n = graph.n_nodes
-    _check_f32(x, "x", (n, spec.f_in))
-    if x.device != graph.device:
-        raise RuntimeError(f"egc_amd: x is on {x.device} but the graph is on {graph.device}")
-    if graph.n_src_rows != n:
-        raise RuntimeError("egc_amd: the fused form runs on un-partitioned graphs")
-    dev = x.device
-    x = x.contiguous()
-    with _device_guard(dev):
-        bases = torch.empty((n, spec.ldb), dtype=torch.float32, device=dev)
-        out = torch.empty((n, spec.f_out), dtype=torch.float32, device=dev)
-        g = graph.c_struct()
-        ws = graph.workspace(lib.egc_aggregate_workspace_bytes_for(C.byref(spec.c), C.byref(g)),
-                             lib.egc_aggregate_workspace_zero_bytes(C.byref(spec.c), graph.n_nodes, graph.n_edges))
-        bias_p = bias.contiguous().data_ptr() if bias is not None else None
-        stream = _stream_ptr(dev)
-        if post is None:
-            _C.check(lib.egc_layer_forward_fused_f32(C.byref(g), C.byref(spec.c), x.data_ptr(), planes.data_ptr(),
-                                                     fused.data_ptr(), bias_p, bases.data_ptr(), spec.ldb, out.data_ptr(),
-                                                     ws.data_ptr(), ws.numel(), stream), "egc_layer_forward_fused_f32")
-        else:
-            keep = []
-
-            def ptr(t, shape, name):
-                if t is None:
-                    return None
-                _check_f32(t, name, shape)
-                keep.append(t.contiguous())
-                return keep[-1].data_ptr()
-            p = _C.EgcPost(ptr(post.scale, (spec.f_out,), "post.scale"), ptr(post.shift, (spec.f_out,), "post.shift"),
-                           ptr(post.residual, (n, spec.f_out), "post.residual"), int(bool(post.relu)))
-            _C.check(lib.egc_basis_transform_packed(x.data_ptr(), planes.data_ptr(), None, n, spec.f_in, spec.f_g, 0,
-                                                    bases.data_ptr(), spec.ldb, None, stream), "egc_basis_transform_packed")
-            _C.check(lib.egc_aggregate_combine_fused_f32(C.byref(g), C.byref(spec.c), x.data_ptr(), fused.data_ptr(),
-                                                         bases.data_ptr(), spec.ldb, bias_p, C.byref(p), out.data_ptr(),
-                                                         ws.data_ptr(), ws.numel(), stream), "egc_aggregate_combine_fused_f32")
-    return (out, bases) if return_bases else out
-
-
 def _native_ops(dev):
     """The compiled binding (egc_amd/_native.py) when it is built and `dev` is the current device."""
     from . import _native
@@ -624,10 +533,6 @@ def egc_layer_forward(graph: CSRGraph, spec: LayerSpec, x: torch.Tensor, wcat: t
             bases, weightings = egc_basis_transform(graph, spec, x, wcat, bcat, packed)
             return egc_aggregate_combine_batch(graph, spec, bases, weightings, bias, post, tiled)
     halo = graph.halo if graph.n_src_rows > graph.n_nodes else None
-    if (halo is None and not return_intermediates and graph.n_src_rows == graph.n_nodes and fused_enabled()
-            and not gemm_exact() and fused_supported(spec)):
-        planes, fused = _fused_packs(spec, wcat, bcat)
-        return egc_layer_forward_fused(graph, spec, x, planes, fused, bias, post)
     if (halo is None and post is None and packed is not None and not return_intermediates and not gemm_exact()
             and graph.n_src_rows == graph.n_nodes):
         return _layer_forward_one_call(graph, spec, x, packed, bcat, bias)

@@ -566,32 +566,6 @@ int egc_layer_forward_packed(const egc_graph* graph, const egc_layer* layer, con
                              const float* bcat, const float* bias, float* bases, int32_t ldb, float* weightings,
                              float* out, void* workspace, size_t workspace_bytes, egc_stream_t stream);
 
-/* ------------------------------------------------------------------------------------------
- * Steps 1b + 2 + 3 in ONE launch -- the weightings Linear computed inside the fused aggregate/combine kernel
- * (SURVEY.md 8f rank 3): the [N, H*B*A] `weightings` intermediate of comb_weights(x) (layers.py:110) /
- * comb_weight(x) (optimized_layers.py:182) is never written to or read from memory; each row's weightings are
- * produced on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 arithmetic) by a producer wavefront of the
- * workgroup that aggregates the row and handed over through LDS (egc_aggregate_fusedw.hip).
- * Envelope (egc_fused_supported): inference form; B = 4, F_out / H = 16 contiguous (d = 128 / H = 8, d = 64 / H = 4),
- * A <= 4 of sum / mean / max / symnorm, weight layout HBA, nonlinearity none / sigmoid / hardtanh, F_in % 4 == 0.
- *   egc_fused_pack: comb weights (the W columns of wcat, as in egc_basis_transform_f32) + bcat -> an opaque buffer of
- *                   egc_fused_pack_bytes() bytes, rebuilt when the parameters change;
- *   egc_aggregate_combine_fused_f32: contract of egc_aggregate_combine_post_f32 with (x, fused_packed) in place of
- *                   `weightings` (x is [n_nodes, in_channels], 16-byte aligned; post may be NULL);
- *   egc_layer_forward_fused_f32: basis transform alone (egc_basis_transform_packed with w_cols = 0; bases_packed from
- *                   egc_basis_pack(wcat = bases_weight, w_cols = 0)) + the fused launch.
- * Workspace: as egc_aggregate_combine_f32 (egc_aggregate_workspace_bytes*; zero before first use). */
-int egc_fused_supported(const egc_layer* layer);
-size_t egc_fused_pack_bytes(const egc_layer* layer);
-int egc_fused_pack(const egc_layer* layer, const float* wcat, const float* bcat, void* packed, size_t packed_bytes,
-                   egc_stream_t stream);
-int egc_aggregate_combine_fused_f32(const egc_graph* graph, const egc_layer* layer, const float* x, const void* fused_packed,
-                                    const float* bases, int32_t ldb, const float* bias, const egc_post* post, float* out,
-                                    void* workspace, size_t workspace_bytes, egc_stream_t stream);
-int egc_layer_forward_fused_f32(const egc_graph* graph, const egc_layer* layer, const float* x, const void* bases_packed,
-                                const void* fused_packed, const float* bias, float* bases, int32_t ldb, float* out,
-                                void* workspace, size_t workspace_bytes, egc_stream_t stream);
-
 /* Backward of egc_aggregate_combine_train_f32 (in the reference PyTorch autograd derives
  * it through layers.py:103-138 / optimized_layers.py:186-208).  Inputs: the forward's `bases`, PRE-activation
  * `weightings` (layout HBA), `stats`, `cnt`, `arg_max` / `arg_min`; grad_out = dL/d out [n_nodes, out_channels];

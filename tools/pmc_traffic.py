@@ -30,7 +30,7 @@ def main():
                      "FETCH_SIZE doubled (gfx950 counts 128-B requests at 64 B)", "kernels": {}}
     for name in fetch:
         short = "aggregate" if "agg_fast_kernel" in name or "agg_rows_kernel" in name else \
-            "aggregate_fused_weightings" if "agg_fusedw" in name else "gemm" if "basis_gemm_f16x2_kernel" in name else \
+            "gemm" if "basis_gemm_f16x2_kernel" in name else \
             "gemm_bases_only_of_the_fused_experiment" if "basis_gemm" in name else None
         if short is None:
             continue
