@@ -168,6 +168,7 @@ SYMBOLS = {
                                                   C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(EgcPost), C.c_void_p, C.c_void_p,
                                                   C.c_void_p, C.c_void_p]),
     "egc_batch_fused_tile_nodes": (C.c_int32, [C.POINTER(EgcLayer), C.c_int32, C.c_int32]),
+    "egc_batch_fused_tile_quantum": (C.c_int32, [C.POINTER(EgcLayer)]),
     "egc_batch_fused_pack_bytes": (C.c_int64, [C.POINTER(EgcLayer)]),
     "egc_batch_fused_pack": (C.c_int, [C.POINTER(EgcLayer), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "egc_layer_forward_batch_fused_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,

@@ -894,10 +894,16 @@ int32_t egc_batch_fused_tile_nodes(const egc_layer* layer, int32_t max_tile_edge
   return fused_tile_capacity(a, layer->in_channels, max_tile_edges, with_post != 0);
 }
 
+int32_t egc_batch_fused_tile_quantum(const egc_layer* layer) {
+  AggArgs a;
+  if (tile_layer_args(layer, a) != EGC_OK) return 0;
+  return fused_tile_quantum(a, layer->in_channels);
+}
+
 int64_t egc_batch_fused_pack_bytes(const egc_layer* layer) {
   AggArgs a;
   if (tile_layer_args(layer, a) != EGC_OK || !fused_tile_shape(a, layer->in_channels)) return 0;
-  return (int64_t)fused_tile_pack_bytes();
+  return (int64_t)fused_tile_pack_bytes(a, layer->in_channels);
 }
 
 int egc_batch_fused_pack(const egc_layer* layer, const float* wcat, const float* bcat, void* packed, int64_t packed_bytes,
@@ -906,8 +912,8 @@ int egc_batch_fused_pack(const egc_layer* layer, const float* wcat, const float*
   int st = tile_layer_args(layer, a);
   if (st != EGC_OK) return st;
   if (!fused_tile_shape(a, layer->in_channels)) return EGC_ERR_UNSUPPORTED;
-  if (wcat == nullptr || packed == nullptr || packed_bytes < (int64_t)fused_tile_pack_bytes()) return EGC_ERR_INVALID;
-  return fused_tile_pack(wcat, bcat, layer->in_channels, a.B * a.Ls, a.W, a.ldb, packed, (hipStream_t)stream);
+  if (wcat == nullptr || packed == nullptr || packed_bytes < (int64_t)fused_tile_pack_bytes(a, layer->in_channels)) return EGC_ERR_INVALID;
+  return fused_tile_pack(a, wcat, bcat, layer->in_channels, a.B * a.Ls, a.W, a.ldb, packed, (hipStream_t)stream);
 }
 
 int egc_layer_forward_batch_fused_f32(const int64_t* graph_ptr, const int64_t* edge_ptr, int64_t n_graphs, const int64_t* src,

@@ -96,7 +96,8 @@ struct AggArgs {
   unsigned* arg8_max;      // the same positions as bytes relative to the row's first entry (arg8_pack), or nullptr
   unsigned* arg8_min;
   int self_pos;              // = n_edges
-  // egc_aggregate_fusedw.hip only: the weightings x @ comb_weight^T + comb_bias are computed inside the launch
+  int w_aw;                  // egc_fused_tile_wide.hip: floats per (h, b) block of the weightings row it keeps in LDS (4, or A when A < 3)
+  // (fields of the deleted fused-weightings launch of rounds 2-4; kept so that the aggregate workspace layout is unchanged)
   const float* x;            // [n_nodes, F_in]
   const float* wfrag;        // comb_weight^T as A fragments of v_mfma_f32_16x16x4_f32: [H][M][64 lanes][4]
   const float* wbias4;       // comb_bias laid out [H][B = 4][4] (zero beyond A)
@@ -207,8 +208,10 @@ int launch_tile_simple(AggArgs a, const int4* tiles, const int* n_tiles_dev, int
 // egc_fused_tile.hip: the whole layer on tiles of whole graphs in ONE launch (plan + GEMM + CSR + aggregate + combine)
 bool fused_tile_shape(const AggArgs& a, int f_in);
 int fused_tile_capacity(const AggArgs& a, int f_in, int max_tile_edges, bool with_post);
-size_t fused_tile_pack_bytes();
-int fused_tile_pack(const float* wcat, const float* bcat, int f_in, int f_g, int w_cols, int ldb, void* packed, hipStream_t stream);
+int fused_tile_quantum(const AggArgs& a, int f_in);      // rows per GEMM chunk: tile_nodes is a multiple of it (16 / 32; 0 = outside)
+size_t fused_tile_pack_bytes(const AggArgs& a, int f_in);
+int fused_tile_pack(const AggArgs& a, const float* wcat, const float* bcat, int f_in, int f_g, int w_cols, int ldb, void* packed,
+                    hipStream_t stream);
 int launch_fused_tile(AggArgs a, const int64_t* ptr, const int64_t* edge_ptr, int64_t n_graphs, const int64_t* src,
                       const int64_t* dst, int64_t n_edges, const int* max_index, const float* x, int f_in, const void* packed,
                       int tcap, int emax, int32_t* status, int32_t* host_flag, hipStream_t stream);

@@ -361,7 +361,9 @@ __device__ inline void gather_batch(const AggArgs& a, const FastRsrc& R, FAcc<NE
 // ---------------------------------------------------------------------------------------------
 // W_READY: the row's weightings already sit in LDS at lds_w + g * w_lds_stride as [h][b][4] with the
 // nonlinearity applied (egc_fused_tile.hip: computed in the launch); `wpre` is then unused.
-template <int LPR_LOG2, int HPB, int NEED, class C, bool W_READY = false>
+// W_AW (W_READY only): floats per (h, b) block of that LDS row -- 4 (the narrow one-launch kernel: compile time), or 0 = a.w_aw
+// (the wide one: 4 for A >= 3, else A -- a 304 / H8 / B8 row with one aggregator then takes 256 bytes, not 1024).
+template <int LPR_LOG2, int HPB, int NEED, class C, bool W_READY = false, int W_AW = 4>
 __device__ inline void finish_group(const AggArgs& a, const FastRsrc& R, int lane, int row, bool row_ok, FAcc<NEED>& acc,
                                     int deg, int nself, float dis_i, f4 vself, bool has_self, const f4 (&wpre)[2],
                                     bool store, float* lds_w, const float* lds_bias, const float* lds_scale) {
@@ -382,7 +384,7 @@ __device__ inline void finish_group(const AggArgs& a, const FastRsrc& R, int lan
 
   // (1) the row's weightings (nonlinearity applied) -> this group's LDS strip, 32 bytes per lane
   float* wl = lds_w + g * a.w_lds_stride;
-  const int AW = W_READY ? 4 : A;  // floats between consecutive (h, b) blocks of the strip
+  const int AW = W_READY ? (W_AW > 0 ? W_AW : a.w_aw) : A;  // floats between consecutive (h, b) blocks of the strip
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int c0 = (q + k * LPR) * 4;
@@ -489,7 +491,7 @@ __device__ inline void finish_group(const AggArgs& a, const FastRsrc& R, int lan
       for (int j = 0; j < 4; ++j) {
         const int h = hb * 4 + ((b + j) & 3);
         const float* wp = wl + (min(h, H - 1) * 4 + b) * AW;
-        if (A == 4 || W_READY) {  // wave-uniform (the LDS image of W_READY keeps four floats per (h, b) for every A)
+        if (A == 4 || (W_READY && AW == 4)) {  // wave-uniform (the LDS image of W_READY keeps four floats per (h, b) for every A)
           p[j] = combine_share(val, *reinterpret_cast<const f4*>(wp), A);
         } else {
           p[j] = val[0] * splat(wp[0]);
@@ -509,7 +511,7 @@ __device__ inline void finish_group(const AggArgs& a, const FastRsrc& R, int lan
       if (h >= H) break;  // wave-uniform
       const float* wp = wl + (h * B + b) * AW;
       f4 part;
-      if (A == 4 || W_READY) {  // wave-uniform
+      if (A == 4 || (W_READY && AW == 4)) {  // wave-uniform
         part = combine_share(val, *reinterpret_cast<const f4*>(wp), A);
       } else {
         part = val[0] * splat(wp[0]);

@@ -610,7 +610,8 @@ class GraphBatch:
                 hit = (cap, emax) if (cap >= self.max_nodes and cap > 0 and cap * self.edges_per_node <= emax) else False
                 if hit is False and cap > 0:
                     # the generous edge areas cost rows: the tightest areas that hold the declared largest graph
-                    need = -(-self.max_nodes // 16) * 16
+                    quantum = max(16, int(lib.egc_batch_fused_tile_quantum(C.byref(spec_c))))
+                    need = -(-self.max_nodes // quantum) * quantum
                     emax = max(64, -(-need * self.edges_per_node // 64) * 64)
                     cap = int(lib.egc_batch_fused_tile_nodes(C.byref(spec_c), emax, int(with_post))) if emax <= 16384 else 0
                     if cap >= need:

@@ -529,14 +529,21 @@ int egc_aggregate_combine_batch_f32(const int32_t* tiles, const int32_t* n_tiles
  * (optimized_layers.py:195-208; layers.py:127-138), and the caller's bn(eval) -> relu -> + identity (zinc/models.py:66-73,
  * cifar/models.py:64-71, mol/pna_style_models.py:70-78).
  *   egc_batch_fused_tile_nodes  rows of a tile whose image (bases + weightings rows, CSR areas for max_tile_edges entries)
- *                               fits the LDS of one CU; 0 = the layer is outside this kernel's envelope (F_in <= 128 and a
- *                               multiple of 4, ldb + H B A <= 192, the register-resident kernels' envelope).  A batch whose
- *                               largest graph has more nodes than this must take egc_aggregate_combine_batch_f32 or the CSR path.
+ *                               fits the LDS of one CU; 0 = the layer is outside this kernel's envelope.  Two forms share the
+ *                               entry points: the register-stationary one (F_in <= 128, ldb + H B A <= 192: the d = 128
+ *                               layers) and, since round 5, the WIDE one for the reference's own wider batched nets
+ *                               (run_pretrained.sh:7,12,23,24 -- 168 / H8 / B4, 296 / H8 / B4, 224 / H4 / B4): F_in <= 320,
+ *                               round32(ldb) + H B A <= 384, weight fragments streamed from L2; both need F_in % 4 == 0 and
+ *                               the register-resident aggregate kernels' envelope (ldb <= 256, B a power of two, A <= 4).
+ *                               A batch whose largest graph has more nodes than this must take
+ *                               egc_aggregate_combine_batch_f32 or the CSR path.
+ *   egc_batch_fused_tile_quantum  rows per matrix-core step of the form that serves the layer (16 / 32; 0 = outside):
+ *                               tile_nodes must be a multiple of it.
  *   egc_batch_fused_pack_bytes / egc_batch_fused_pack
  *                               wcat [F_in, F_g + W] (+ bcat [W] or NULL) -> the two fp16 weight planes in MFMA fragment
  *                               order + column scales + comb bias; once per parameter update.
  *   egc_layer_forward_batch_fused_f32
- *                               the launch.  tile_nodes: a multiple of 16, <= egc_batch_fused_tile_nodes(...); status /
+ *                               the launch.  tile_nodes: a multiple of egc_batch_fused_tile_quantum, <= egc_batch_fused_tile_nodes(...); status /
  *                               host_flag as egc_aggregate_combine_batch_f32 (bit 0: an edge leaves its tile or the graph
  *                               offsets do not cover [0, n_nodes); bit 1: a tile beyond tile_nodes / max_tile_edges -- the
  *                               rows of such a tile are written as zeros; bit 2: the workgroup-internal hand-over between
@@ -545,6 +552,7 @@ int egc_aggregate_combine_batch_f32(const int32_t* tiles, const int32_t* n_tiles
  *                               fp32 accumulate: the arithmetic of egc_basis_transform_packed at the north-star shape).
  * ------------------------------------------------------------------------------------------ */
 int32_t egc_batch_fused_tile_nodes(const egc_layer* layer, int32_t max_tile_edges, int32_t with_post);
+int32_t egc_batch_fused_tile_quantum(const egc_layer* layer);
 int64_t egc_batch_fused_pack_bytes(const egc_layer* layer);
 int egc_batch_fused_pack(const egc_layer* layer, const float* wcat, const float* bcat, void* packed, int64_t packed_bytes,
                          egc_stream_t stream);

@@ -43,6 +43,15 @@ def _edge_ptr(ei, ptr):
     ("lay", 124, 4, 4, ["add", "std", "max"], True),                   # the reference's ZINC EGC-M layer (std: shifted variance)
     ("lay", 128, 4, 4, ["symadd", "std", "max"], True),                # the reference's CIFAR EGC-M layer
     ("opt", 128, 8, 4, ["sum", "var", "min"], True),                   # var + min
+    # ---- the WIDE form (round 5): the reference's own batched layer shapes (run_pretrained.sh:7,12,23,24) and their neighbours ----
+    ("lay", 168, 8, 4, ["symadd"], True),                              # zinc / cifar EGC-S: L = 21 padded to 24, 24 slots, two k-slabs
+    ("lay", 296, 8, 4, ["symadd"], True),                              # molhiv EGC-S: L = 37 padded to 40, 40 slots, three k-slabs
+    ("lay", 224, 4, 4, ["add", "mean", "max"], True),                  # molhiv EGC-M: 56 slots, 224 + 48 columns (9 tiles of 32)
+    ("opt", 256, 8, 4, ["sum", "mean", "max", "symnorm"], True),       # F_in a multiple of 128, 32 slots, A = 4
+    ("lay", 136, 4, 4, ["symadd", "max", "mean"], True),               # arxiv EGC-M's width: a partial second slab of 8 columns
+    ("lay", 184, 8, 4, ["symadd", "std", "max"], True),                # std in the wide form (NEED_SQ), L = 23 padded to 24
+    ("opt", 200, 4, 2, ["min", "max"], False),                         # RAW sets, min, B = 2, no symnorm, F_in % 32 != 0
+    ("opt", 160, 16, 4, ["sum", "symnorm"], True),                     # H / B = 4 heads per basis, A = 2 (two floats per (h, b) block)
 ])
 @pytest.mark.parametrize("with_edge_ptr", [False, True])
 def test_one_launch_layer_matches_the_oracle_on_a_messy_batch(kind, hidden, H, B, aggrs, asl, with_edge_ptr):
@@ -162,6 +171,44 @@ def test_one_launch_layer_at_full_batch_sizes(workload, with_edge_ptr):
     assert rel_err(got, out2.cpu().numpy()) <= TOL
 
 
+@pytest.mark.parametrize("workload,hidden,H,B,aggrs", [
+    ("zinc", 168, 8, 4, ["symadd"]),                 # run_pretrained.sh:7   zinc EGC-S
+    ("cifar", 168, 8, 4, ["symadd"]),                # run_pretrained.sh:12  cifar EGC-S (graphs of up to 150 nodes: 160-row tiles)
+    ("molhiv", 296, 8, 4, ["symadd"]),               # run_pretrained.sh:23  molhiv EGC-S
+    ("molhiv", 224, 4, 4, ["add", "mean", "max"]),   # run_pretrained.sh:24  molhiv EGC-M (BASELINE config 3's own net)
+])
+def test_wide_one_launch_layer_at_full_batch_sizes(workload, hidden, H, B, aggrs):
+    """The reference's own batched nets at the full batch of their dataset's shape through the WIDE one-launch form
+    (EfficientGraphConv, layers.py:89-140): whole output against the oracle, scale-relative AND element-wise, and against the CSR path."""
+    import egc_amd
+    from egc_amd.workloads import knn_superpixel_batch, molecule_batch, zinc_like_batch
+    dev = _dev()
+    if workload == "molhiv":
+        ei, n, batch = molecule_batch(2048, seed=0); G = 2048
+    elif workload == "cifar":
+        ei, n, batch = knn_superpixel_batch(512, seed=0); G = 512        # (512 graphs: the float32 oracle of 2048 takes minutes)
+    else:
+        _, ei, n, batch = zinc_like_batch(128, seed=0); G = 128
+    sizes = torch.bincount(batch, minlength=G)
+    mx = int(sizes.max())
+    ptr = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(sizes, 0)])
+    torch.manual_seed(3)
+    conv = _layer("lay", hidden, H, B, aggrs)
+    x = torch.randn(n, hidden)
+    ref = _oracle(conv, "lay", x, ei, H, B, aggrs)
+    conv = conv.to(dev).eval()
+    gb = egc_amd.GraphBatch(ei.to(dev), ptr=ptr.to(dev), max_nodes=mx)
+    with torch.no_grad():
+        out = conv(x=x.to(dev), edge_index=gb)
+        csr = conv(x=x.to(dev), edge_index=ei.to(dev))
+    gb.check()
+    assert _ran_fused(gb) and not gb._plans, "the one-launch path did not run"
+    got = out.cpu().numpy()
+    assert rel_err(got, ref) <= TOL, rel_err(got, ref)
+    assert elementwise_excess(got, ref, TOL) <= 1.0
+    assert rel_err(got, csr.cpu().numpy()) <= TOL
+
+
 def test_fused_block_tail_in_the_one_launch_kernel():
     """FusedEGCBlock (eval): BatchNorm affine + ReLU + residual in the kernel's store == the plain composition."""
     import egc_amd
@@ -233,11 +280,14 @@ def test_envelope_and_fallbacks(monkeypatch):
         gb.check()
         assert not _ran_fused(gb)
         monkeypatch.delenv("EGC_GEMM_STDVAR_24BIT")
-        wide = _layer("opt", 256, 8, 4, aggrs).to(dev).eval()                   # F_in = 256
+        wide = _layer("opt", 352, 8, 4, ["symnorm"]).to(dev).eval()             # F_in = 352 (the ogbn-mag layer): beyond the wide form's 320
         gb = egc_amd.GraphBatch(ei.to(dev), ptr=ptr.to(dev), max_nodes=90)
-        wide(torch.randn(n, 256, device=dev), gb)
+        xw = torch.randn(n, 352, device=dev)
+        outw = wide(xw, gb)
         gb.check()
         assert not _ran_fused(gb)
+        refw = wide(xw, ei.to(dev))
+        assert float((outw - refw).abs().max()) / max(1.0, float(refw.abs().max())) <= 1e-5
 
 
 def test_malformed_batches_are_reported_by_the_one_launch_kernel():
