@@ -145,7 +145,7 @@ def cpu_baseline(ei, n, x, conv_state, runs=5):
     return out, best[0], best[1], int(cached[0].size(1))
 
 
-def cpu_leg(conv_cpu_state, x_cpu, ei_cpu, H, B, aggrs, e_eff, budget_s=12.0, max_runs=5):
+def cpu_leg(conv_cpu_state, x_cpu, ei_cpu, H, B, aggrs, e_eff, budget_s=12.0, max_runs=5, add_self_loops=True):
     """The CPU port on one of the side configs (same inputs as the GPU run): median of up to `max_runs` forwards within about
     `budget_s` seconds, at the thread count the headline's baseline settled on (8: torch's scatter kernels do not scale
     further).  Returns the cpu_baseline object and the port's output."""
@@ -153,7 +153,7 @@ def cpu_leg(conv_cpu_state, x_cpu, ei_cpu, H, B, aggrs, e_eff, budget_s=12.0, ma
     st = conv_cpu_state
     threads = min(8, os.cpu_count() or 1)
     torch.set_num_threads(threads)
-    args = (x_cpu, ei_cpu, st["bases_weight"], st["comb_weight.weight"], st["comb_weight.bias"], st["bias"], H, B, aggrs)
+    args = (x_cpu, ei_cpu, st["bases_weight"], st["comb_weight.weight"], st["comb_weight.bias"], st["bias"], H, B, aggrs, add_self_loops)
     t0 = time.perf_counter()
     out, cached = egconv_forward_cpu(*args)                  # warm-up; builds the cached gcn_norm edge set
     first = time.perf_counter() - t0
@@ -193,7 +193,8 @@ def roofline_terms(n, e_eff, f_in, f_g, f_out, w_cols, symnorm):
 # -------------------------------------------------------------------------------------------------
 # other configs (N = 1): measured in the same run, module-level calls (what a caller of the layer pays)
 # -------------------------------------------------------------------------------------------------
-def measure_layer_config(name, ei_cpu, n, conv, f_in, dev, per_batch_csr, iters=30, batch=None, max_nodes=None, traffic_key=None):
+def measure_layer_config(name, ei_cpu, n, conv, f_in, dev, per_batch_csr, iters=30, batch=None, max_nodes=None, traffic_key=None,
+                         self_loops=True):
     """`batch` (+ `max_nodes`): the workload is a PyG-style batch of small graphs -- measured on the ordinary path (per-batch
     egc_graph_build + GEMM + aggregate) AND on the tile path (egc_amd.GraphBatch: one plan launch per batch; GEMM; one
     launch that builds each tile's CSR in LDS and aggregates from LDS); the record's headline fields are the faster one's."""
@@ -205,7 +206,9 @@ def measure_layer_config(name, ei_cpu, n, conv, f_in, dev, per_batch_csr, iters=
     conv = conv.to(dev).eval()
     spec = conv._spec_coo
     e_in = int(ei.size(1))
-    e_eff = e_in + n   # EGConv convention (optimized_layers.py:127-175): every aggregator traverses one self loop per node
+    # EGConv convention (optimized_layers.py:127-175): every aggregator traverses one self loop per node -- unless the layer is built
+    # with add_self_loops=False and without symnorm (the edge sets of EfficientGraphConv's add / mean / max, layers.py:166-193)
+    e_eff = e_in + (n if self_loops else 0)
     rec = {"workload": name, "n_nodes": n, "e_in": e_in, "e_eff": e_eff}
     with torch.no_grad():
         if per_batch_csr:
@@ -320,7 +323,8 @@ def measure_layer_config(name, ei_cpu, n, conv, f_in, dev, per_batch_csr, iters=
                                    "gemm_frac": (n * 4 * (f_in + spec.ldb + spec.w_cols)) / (gemm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
                 ref_out = conv(x, g)
         if not getattr(measure_layer_config, "no_cpu", False):
-            cb, cpu_out = cpu_leg(state_cpu, x_cpu, ei_cpu, conv.num_heads, conv.num_bases, list(conv.aggregators), e_eff)
+            cb, cpu_out = cpu_leg(state_cpu, x_cpu, ei_cpu, conv.num_heads, conv.num_bases, list(conv.aggregators), e_eff,
+                                  add_self_loops=self_loops)
             cb["hip_vs_port_rel_err"] = float((ref_out.cpu() - cpu_out).abs().max() / max(1.0, float(cpu_out.abs().max())))
             rec["cpu_baseline"] = cb
     except Exception as ex:   # noqa: BLE001 -- a side figure never takes the record down
@@ -390,6 +394,13 @@ def _oc_layer_configs(out, dev, seed):
     out["config3_molhiv_b2048"] = measure_layer_config(
         "ogbg-molhiv-shaped batch of 2048 graphs, EGC-M d=128 H=8 B=4 sum+mean+max+symnorm", ei, n, ns(), F_IN, dev, True,
         batch=batch, max_nodes=222, traffic_key="config3_molhiv_b2048")
+    # config 3 at the reference's OWN molhiv net (run_pretrained.sh:24, hyperparameters.md: hidden 224, H 4, B 4, add + mean + max on
+    # the raw edges -- EfficientGraphConv's edge sets, expressed through EGConv(add_self_loops=False)): the WIDE one-launch form
+    # (egc_fused_tile_wide*.hip) against plan + GEMM + agg_tile_kernel and the CSR path, all timed in this record
+    out["config3_molhiv_b2048_ref224"] = measure_layer_config(
+        "ogbg-molhiv-shaped batch of 2048 graphs, the reference's molhiv EGC-M layer d=224 H=4 B=4 add+mean+max (raw edges)", ei, n,
+        egc_amd.EGConv(224, 224, aggrs=["sum", "mean", "max"], num_heads=4, num_bases=4, add_self_loops=False), 224, dev, True,
+        batch=batch, max_nodes=222, traffic_key="config3_molhiv_b2048_ref224", self_loops=False)
     ei, n, batch = wl.knn_superpixel_batch(2048, seed=seed)
     out["config4_cifar_b2048"] = measure_layer_config(
         "CIFAR10-superpixel-shaped batch of 2048 8-NN graphs, EGC-M d=128 H=8 B=4 sum+mean+max+symnorm", ei, n, ns(),

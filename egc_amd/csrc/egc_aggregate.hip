@@ -802,7 +802,7 @@ int egc_layer_forward_packed(const egc_graph* graph, const egc_layer* layer, con
 }
 
 // ---- batches of small graphs: tiles of whole graphs (egc_aggregate_tile.hip) ----
-static int tile_layer_args(const egc_layer* layer, AggArgs& a) {
+static int tile_layer_args(const egc_layer* layer, AggArgs& a, bool two_sets_ok = false) {
   int st = validate_layer(layer);
   if (st != EGC_OK) return st;
   a = AggArgs{};
@@ -824,7 +824,9 @@ static int tile_layer_args(const egc_layer* layer, AggArgs& a) {
   a.act = layer->weight_act;
   a.lpr_log2 = 4;
   int chunks = a.slots <= 64 ? 1 : (a.slots + 63) / 64;
-  if (!fast_path_supported(a, layer->weight_layout, chunks)) return EGC_ERR_UNSUPPORTED;
+  a.n_nodes = 1;
+  if (!fast_path_supported(a, layer->weight_layout, chunks) && !(two_sets_ok && wide_path_supported(a, layer->weight_layout)))
+    return EGC_ERR_UNSUPPORTED;      // (65 .. 128 slots: the one-launch kernel finishes such rows in two passes, egc_fused_tile_dev.h)
   return EGC_OK;
 }
 
@@ -890,26 +892,26 @@ int egc_aggregate_combine_batch_f32(const int32_t* tiles, const int32_t* n_tiles
 // ---- batches of small graphs, the whole layer in one launch (egc_fused_tile.hip) ----
 int32_t egc_batch_fused_tile_nodes(const egc_layer* layer, int32_t max_tile_edges, int32_t with_post) {
   AggArgs a;
-  if (tile_layer_args(layer, a) != EGC_OK) return 0;
+  if (tile_layer_args(layer, a, true) != EGC_OK) return 0;
   return fused_tile_capacity(a, layer->in_channels, max_tile_edges, with_post != 0);
 }
 
 int32_t egc_batch_fused_tile_quantum(const egc_layer* layer) {
   AggArgs a;
-  if (tile_layer_args(layer, a) != EGC_OK) return 0;
+  if (tile_layer_args(layer, a, true) != EGC_OK) return 0;
   return fused_tile_quantum(a, layer->in_channels);
 }
 
 int64_t egc_batch_fused_pack_bytes(const egc_layer* layer) {
   AggArgs a;
-  if (tile_layer_args(layer, a) != EGC_OK || !fused_tile_shape(a, layer->in_channels)) return 0;
+  if (tile_layer_args(layer, a, true) != EGC_OK || !fused_tile_shape(a, layer->in_channels)) return 0;
   return (int64_t)fused_tile_pack_bytes(a, layer->in_channels);
 }
 
 int egc_batch_fused_pack(const egc_layer* layer, const float* wcat, const float* bcat, void* packed, int64_t packed_bytes,
                          egc_stream_t stream) {
   AggArgs a;
-  int st = tile_layer_args(layer, a);
+  int st = tile_layer_args(layer, a, true);
   if (st != EGC_OK) return st;
   if (!fused_tile_shape(a, layer->in_channels)) return EGC_ERR_UNSUPPORTED;
   if (wcat == nullptr || packed == nullptr || packed_bytes < (int64_t)fused_tile_pack_bytes(a, layer->in_channels)) return EGC_ERR_INVALID;
@@ -922,7 +924,7 @@ int egc_layer_forward_batch_fused_f32(const int64_t* graph_ptr, const int64_t* e
                                       const egc_post* post, float* out, int32_t tile_nodes, int32_t max_tile_edges,
                                       int32_t* status, int32_t* host_flag, egc_stream_t stream) {
   AggArgs a;
-  int st = tile_layer_args(layer, a);
+  int st = tile_layer_args(layer, a, true);
   if (st != EGC_OK) return st;
   if (n_nodes < 0 || n_graphs < 0 || n_edges < 0 || n_nodes >= ((int64_t)1 << 31) - 1 || n_edges >= ((int64_t)1 << 31) - 1)
     return EGC_ERR_INVALID;

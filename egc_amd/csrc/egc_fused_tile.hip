@@ -109,10 +109,10 @@ static bool ft_narrow_shape(const AggArgs& a, int f_in) {
 // the WIDE form's envelope: F_in <= 320, at most 12 column tiles of 32 (bases padded to a multiple of 32, then the weightings)
 static bool ft_wide_shape(const AggArgs& a, int f_in) {
   static const bool off = getenv("EGC_NO_FUSED_WIDE") != nullptr;
-  return !off && f_in >= 4 && f_in <= FTW_MAX_FIN && (f_in & 3) == 0 && ((a.ldb + 31) & ~31) + a.W <= FTW_MAX_CT * 32 &&
-         a.slots <= 64 && a.A <= AMAX;
+  if (a.slots > 64 && (a.slots > 128 || a.B * (((a.Ls >> 2) + 1) / 2) > 64)) return false;    // two passes of at most 64 lanes
+  return !off && f_in >= 4 && f_in <= FTW_MAX_FIN && (f_in & 3) == 0 && ((a.ldb + 31) & ~31) + a.W <= FTW_MAX_CT * 32 && a.A <= AMAX;
 }
-static inline int ftw_k16(int f_in) { return (f_in + 15) / 16; }
+static inline int ftw_k16(int f_in) { return (((f_in + 15) / 16) + 3) & ~3; }   // k-steps of 16, padded (zero fragments) to the kernel's ring of four
 static inline int ftw_n_ct(const AggArgs& a) { return (((a.ldb + 31) & ~31) + a.W + 31) / 32; }
 
 size_t fused_tile_pack_bytes(const AggArgs& a, int f_in) {
@@ -257,6 +257,7 @@ int launch_fused_tile(AggArgs a, const int64_t* ptr, const int64_t* edge_ptr, in
                       int tcap, int emax, int32_t* status, int32_t* host_flag, hipStream_t stream) {
   if (!fused_tile_shape(a, f_in)) return EGC_ERR_UNSUPPORTED;
   const int lpr = a.slots <= 16 ? 16 : a.slots <= 32 ? 32 : 64;
+  const bool two_sets = a.slots > 64;
   a.lanes_pb = a.Ls / 4;
   a.magic_P = (unsigned)(((uint64_t)1 << 32) / (uint64_t)a.lanes_pb) + 1u;
   if ((a.lanes_pb & (a.lanes_pb - 1)) == 0) {
@@ -289,6 +290,10 @@ int launch_fused_tile(AggArgs a, const int64_t* ptr, const int64_t* edge_ptr, in
   t.n_slabs = (f_in + FTW_SLAB - 1) / FTW_SLAB;
   t.k16 = ftw_k16(f_in);
   t.ldbp = (a.ldb + 31) & ~31;
+  t.nsets = two_sets ? 2 : 1;
+  t.p0 = ((a.Ls >> 2) + 1) / 2;
+  t.magic0 = (unsigned)(((uint64_t)1 << 32) / (uint64_t)t.p0) + 1u;
+  t.magic1 = (unsigned)(((uint64_t)1 << 32) / (uint64_t)std::max(1, (a.Ls >> 2) - t.p0)) + 1u;
 #ifdef EGC_FT_STAMPS
   if (const char* e = getenv("EGC_FT_DBG")) t.dbg = atoi(e);
 #endif

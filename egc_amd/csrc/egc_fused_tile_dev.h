@@ -78,9 +78,11 @@ struct FusedTileArgs {
   int csr_stride;
   // WIDE form only
   int n_slabs;               // ceil(F_in / 128)
-  int k16;                   // ceil(F_in / 16): k-steps of the streamed weight fragments
+  int k16;                   // k-steps of 16 of the streamed weight fragments: ceil(F_in / 16) rounded up to a multiple of 4 (zero steps)
   int ldbp;                  // ldb rounded up to 32: first virtual column of the weightings
   int w_aw;                  // floats per (h, b) block of a weightings row in LDS: 4 for A >= 3, else A
+  int nsets, p0;             // rows of more than 64 slots: two passes, the first over p0 = ceil(P / 2) slots of every basis
+  unsigned magic0, magic1;   // floor(2^32 / p0) + 1, floor(2^32 / (P - p0)) + 1
 };
 
 // first index i in [0, n) with arr[i] >= key (n if none), by HALF a wavefront (lanes [32 h, 32 h + 32) share `key`), as
@@ -1058,61 +1060,86 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
     // ---- (G, WIDE) 32 rows per chunk, one 32-column tile per wavefront on v_mfma_f32_32x32x16_f16 (x as the A operand: lane ->
     //      row lane % 32, k = 16 s + 8 (lane / 32) ..+7; the weights as B: lane -> column 32 wave + lane % 32, same k); per
     //      k-step of 16 both planes of the weight fragment come from L2 (packed[tile][k-step][plane][lane][8]: one KiB per
-    //      request), requested one k-step ahead; three products, acc0 = xh wh, acc1 = xl wh + xh wl.  One barrier per k-slab
-    //      of 128 the helpers stage; the D tile leaves in the chunk's last slab step. ----
+    //      request), requested FOUR k-steps ahead into a ring of four (with one step ahead and a register copy at the end of
+    //      the step every k-step paid the whole L2 latency: 22,000 cycles per chunk against 1,300 of matrix work); three
+    //      products, acc0 = xh wh, acc1 = xl wh + xh wl.  One barrier per k-slab of 128 the helpers stage; the D tile leaves
+    //      behind the chunk's last k-step. ----
     typedef float ft_f16v __attribute__((ext_vector_type(16)));
     int lvm = lane;
     asm volatile("" : "+v"(lvm));
     const int l31 = lvm & 31, hh = lvm >> 5;
-    const ft_h8* bsrc = reinterpret_cast<const ft_h8*>(t.packed) + (int64_t)wave * t.k16 * 128 + lvm;   // [tile][k16][plane][64 lanes]
     constexpr int NS = WIDE;
-    ft_h8 wh = ft_h8{0, 0, 0, 0, 0, 0, 0, 0}, wl = wh;
-    if (is_mfma && nch > 0) { wh = bsrc[0]; wl = bsrc[64]; }
-    int qb = 0;                         // plane buffer of the running step
+    constexpr int BD = 4;                 // weight fragments in flight per wavefront (k-steps); t.k16 is a multiple of it (zero k-steps)
+    const ft_h8* bsrc = reinterpret_cast<const ft_h8*>(t.packed) + (int64_t)wave * t.k16 * 128 + lvm;   // [tile][k16][plane][64 lanes]
+    const int NG = t.k16 / BD;            // groups of BD k-steps per chunk
+    // ring of BD fragments, slot = k-step % BD; a k-step's fragment is requested BD steps ahead (the chunk's last BD steps request
+    // the next chunk's first), always, so that the compiler counts the requests exactly; every request is 1 KiB per plane
+    ft_h8 wh[BD], wl[BD];
+#pragma unroll
+    for (int j = 0; j < BD; ++j) { wh[j] = ft_h8{0, 0, 0, 0, 0, 0, 0, 0}; wl[j] = wh[j]; }
+    if (is_mfma && nch > 0) {
+#pragma unroll
+      for (int j = 0; j < BD; ++j) { wh[j] = bsrc[j * 128]; wl[j] = bsrc[j * 128 + 64]; }
+    }
+    int qb = 0;                         // plane buffer of the running slab step
     for (int c = 0; c < nch; ++c) {
       ft_f16v acc0, acc1;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-      int kk = 0;
-      for (int sl = 0; sl < NS; ++sl) {
-        if (is_mfma) {
-          const int n16 = (min(t.F_in - FTW_SLAB * sl, FTW_SLAB) + 15) >> 4;
-          const char* pa = lds_planes + qb * FTW_PBUF_BYTES + l31 * (FTW_LDX * 2) + hh * 16;
-          for (int s = 0; s < n16; ++s) {
-            const ft_h8 xh = *reinterpret_cast<const ft_h8*>(pa + s * 32);
-            const ft_h8 xl = *reinterpret_cast<const ft_h8*>(pa + s * 32 + FTW_PLANE_BYTES);
-            const int kn = kk + 1 == t.k16 ? 0 : kk + 1;          // (the chunk's last k-step requests the next chunk's first)
-            const ft_h8 nwh = bsrc[(int64_t)kn * 128], nwl = bsrc[(int64_t)kn * 128 + 64];
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wh, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, wh, acc1, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wl, acc1, 0, 0, 0);
-            wh = nwh; wl = nwl;
-            ++kk;
-          }
-          if (sl + 1 == NS) {
-            // D: lane -> column 32 wave + lane % 32, rows 8 j + 4 (lane / 32) + i.  2^ex 2^ew (acc0 + 2^-11 acc1) + bias
-            const float* rinv = lds_rowinv + (c & 1) * FTW_CH + 4 * hh;
+      if (is_mfma) {
+        const char* pa = lds_planes + qb * FTW_PBUF_BYTES + l31 * (FTW_LDX * 2) + hh * 16;
+        for (int g = 0; g < NG; ++g) {
+          const ft_h8* bnext = g + 1 < NG ? bsrc + (int64_t)(g + 1) * (BD * 128) : bsrc;
+          // the A fragments of the group's four k-steps: requested together (their LDS latency passes once per group)
+          ft_h8 xh[BD], xl[BD];
+          const char* pg = pa + (g & 1) * (BD * 32);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const f4 ri = *reinterpret_cast<const f4*>(rinv + 8 * j);
-              f4 o;
-              o.x = __builtin_fmaf(__builtin_fmaf(acc1[4 * j], 1.f / 2048.f, acc0[4 * j]), col_inv * ri.x, col_bias);
-              o.y = __builtin_fmaf(__builtin_fmaf(acc1[4 * j + 1], 1.f / 2048.f, acc0[4 * j + 1]), col_inv * ri.y, col_bias);
-              o.z = __builtin_fmaf(__builtin_fmaf(acc1[4 * j + 2], 1.f / 2048.f, acc0[4 * j + 2]), col_inv * ri.z, col_bias);
-              o.w = __builtin_fmaf(__builtin_fmaf(acc1[4 * j + 3], 1.f / 2048.f, acc0[4 * j + 3]), col_inv * ri.w, col_bias);
-              if (dst_act) o = w_act<C>(a, o);
-              if (dst_off >= 0) {
-                char* po = base + dst_off + (FTW_CH * c + 8 * j + 4 * hh) * dst_stride;
-                *reinterpret_cast<float*>(po) = o.x;
-                *reinterpret_cast<float*>(po + dst_stride) = o.y;
-                *reinterpret_cast<float*>(po + 2 * dst_stride) = o.z;
-                *reinterpret_cast<float*>(po + 3 * dst_stride) = o.w;
-              }
+          for (int j = 0; j < BD; ++j) {
+            xh[j] = *reinterpret_cast<const ft_h8*>(pg + j * 32);
+            xl[j] = *reinterpret_cast<const ft_h8*>(pg + j * 32 + FTW_PLANE_BYTES);
+          }
+#pragma unroll
+          for (int j = 0; j < BD; ++j) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[j], wh[j], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[j], wh[j], acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[j], wl[j], acc1, 0, 0, 0);
+            wh[j] = bnext[j * 128];
+            wl[j] = bnext[j * 128 + 64];
+          }
+          if ((g & 1) && g + 1 < NG) {     // a k-slab of 128 (two groups) is done and another follows: the helpers have staged it
+            qb ^= 1;
+            lds_barrier();
+            pa = lds_planes + qb * FTW_PBUF_BYTES + l31 * (FTW_LDX * 2) + hh * 16;
+          }
+        }
+        {
+          // D: lane -> column 32 wave + lane % 32, rows 8 j + 4 (lane / 32) + i.  2^ex 2^ew (acc0 + 2^-11 acc1) + bias
+          const float* rinv = lds_rowinv + (c & 1) * FTW_CH + 4 * hh;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f4 ri = *reinterpret_cast<const f4*>(rinv + 8 * j);
+            f4 o;
+            o.x = __builtin_fmaf(__builtin_fmaf(acc1[4 * j], 1.f / 2048.f, acc0[4 * j]), col_inv * ri.x, col_bias);
+            o.y = __builtin_fmaf(__builtin_fmaf(acc1[4 * j + 1], 1.f / 2048.f, acc0[4 * j + 1]), col_inv * ri.y, col_bias);
+            o.z = __builtin_fmaf(__builtin_fmaf(acc1[4 * j + 2], 1.f / 2048.f, acc0[4 * j + 2]), col_inv * ri.z, col_bias);
+            o.w = __builtin_fmaf(__builtin_fmaf(acc1[4 * j + 3], 1.f / 2048.f, acc0[4 * j + 3]), col_inv * ri.w, col_bias);
+            if (dst_act) o = w_act<C>(a, o);
+            if (dst_off >= 0) {
+              char* po = base + dst_off + (FTW_CH * c + 8 * j + 4 * hh) * dst_stride;
+              *reinterpret_cast<float*>(po) = o.x;
+              *reinterpret_cast<float*>(po + dst_stride) = o.y;
+              *reinterpret_cast<float*>(po + 2 * dst_stride) = o.z;
+              *reinterpret_cast<float*>(po + 3 * dst_stride) = o.w;
             }
           }
         }
         qb ^= 1;
         lds_barrier();
+      } else {
+        // a wavefront without a column tile keeps the barrier sequence: one per k-slab
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) lds_barrier();
+        qb ^= NS & 1;
       }
     }
     }
@@ -1141,67 +1168,93 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       maxd = __builtin_amdgcn_readfirstlane(maxd);
       const float dis_i = (want_dis && row_ok) ? lds_dis[r] : 0.f;
       const bool has_self = row_ok && (C::loops_all(a) || row <= max_index);
-      const bool want_self = looped_any && has_self && q < C::slots(a);
-      f4 vself = f4{0.f, 0.f, 0.f, 0.f};
-      if (want_self) vself = lds_bases4[r * ldb4 + q];
+      // Rows of 65 .. 128 slots (the reference's ogbg-code nets: 300 / H4 / B4 -> 76, 304 / H8 / B8 -> 80; run_pretrained.sh:47-48)
+      // are finished in TWO passes of at most 64 lanes, as in agg_wide_kernel (egc_aggregate_fast.hip): the P = Ls / 4 slots of
+      // every basis are cut into a first set of P0 and a second of P - P0, each set a complete sub-layer over its own channels
+      // (lane q <-> basis q / Ps, slot q % Ps of the set), the epilogue unchanged but for the channel offset.
+      constexpr bool TWO = WIDE != 0 && LPR_LOG2 == 6 && __is_same(C, RtCfg);
+      const int nsets = TWO ? t.nsets : 1;
+      for (int set = 0; set < nsets; ++set) {
+        AggArgs as_store;
+        int qslot = q;
+        const char* bq = bases_q;
+        if constexpr (TWO) {
+          as_store = a;
+          if (nsets == 2) {
+            const int P = a.Ls >> 2, Ps = set == 0 ? t.p0 : P - t.p0;
+            as_store.lanes_pb = Ps;
+            as_store.slots = a.B * Ps;
+            as_store.magic_P = set == 0 ? t.magic0 : t.magic1;
+            as_store.lpb_log2 = -1;
+            as_store.l4_off = set == 0 ? 0 : t.p0;
+            const int bb = min((int)__umulhi((unsigned)q, as_store.magic_P), a.B - 1);
+            qslot = bb * P + as_store.l4_off + (q - bb * Ps);
+            bq = base + t.off_bases + (q < as_store.slots ? qslot : 0) * 16;
+          }
+        }
+        const AggArgs& as = TWO ? as_store : a;
+        const bool want_self = looped_any && has_self && q < C::slots(as);
+        f4 vself = f4{0.f, 0.f, 0.f, 0.f};
+        if (want_self) vself = lds_bases4[r * ldb4 + qslot];
 
-      FAcc<NEED> acc;
-      acc.init();
-      if constexpr (NEED & NEED_SQ)     // the variance's shift: the row's first entry in the tile's CSR (FAcc::sh)
-        acc.sh = *reinterpret_cast<const f4*>(bases_q + __umul24((unsigned)((row_ok && nd > 0) ? (int)lds_col[start] : zrow), ldb_bytes));
-      int nself = 0;
-      for (int ts = 0; ts < maxd; ts += LPR) {
-        // lane q of the group stages entry ts + q of the row: its source row (the image's all-zero row when the entry is
-        // absent, or a self-entry the layer's x-part excludes: one 24-bit multiply-add then addresses every entry, and an
-        // entry takes part in the extrema iff its row is not that one) and its symnorm weight, whole
-        const bool pv = ts + q < nd;
-        const int jj = pv ? (int)lds_col[start + ts + q] : 0;
-        const bool self_e = pv && jj == r;
-        float dd = (pv && want_dis) ? lds_dis[jj] * dis_i : 0.f;
-        if (C::yl(a) && !C::xl(a)) dd = self_e ? 0.f : dd;     // mixed sets: the self-entry counts for sum / max only
-        if (looped_any) {
-          const unsigned long long sb = __ballot(self_e);
-          nself += __popcll((sb >> (g << LPR_LOG2)) & ((LPR == 64) ? ~0ull : ((1ull << LPR) - 1ull)));
-        }
-        const int jx = (pv && !(C::xl(a) && self_e)) ? jj : zrow;
-        const int cnt = min(LPR, maxd - ts);
-        for (int t0 = 0; t0 < cnt; t0 += FU) {
-          f4 v[FU];
-          float w[FU];
-          bool in_x[FU];
-#pragma unroll
-          for (int uu = 0; uu < FU; ++uu) {
-            const int addr = grp_addr + ((t0 + uu) << 2);
-            const int j = bperm(addr, jx);
-            in_x[uu] = j != zrow;
-            v[uu] = *reinterpret_cast<const f4*>(bases_q + __umul24((unsigned)j, ldb_bytes));
-            w[uu] = bperm(addr, dd);
+        FAcc<NEED> acc;
+        acc.init();
+        if constexpr (NEED & NEED_SQ)     // the variance's shift: the row's first entry in the tile's CSR (FAcc::sh)
+          acc.sh = *reinterpret_cast<const f4*>(bq + __umul24((unsigned)((row_ok && nd > 0) ? (int)lds_col[start] : zrow), ldb_bytes));
+        int nself = 0;
+        for (int ts = 0; ts < maxd; ts += LPR) {
+          // lane q of the group stages entry ts + q of the row: its source row (the image's all-zero row when the entry is
+          // absent, or a self-entry the layer's x-part excludes: one 24-bit multiply-add then addresses every entry, and an
+          // entry takes part in the extrema iff its row is not that one) and its symnorm weight, whole
+          const bool pv = ts + q < nd;
+          const int jj = pv ? (int)lds_col[start + ts + q] : 0;
+          const bool self_e = pv && jj == r;
+          float dd = (pv && want_dis) ? lds_dis[jj] * dis_i : 0.f;
+          if (C::yl(a) && !C::xl(a)) dd = self_e ? 0.f : dd;     // mixed sets: the self-entry counts for sum / max only
+          if (looped_any) {
+            const unsigned long long sb = __ballot(self_e);
+            nself += __popcll((sb >> (g << LPR_LOG2)) & ((LPR == 64) ? ~0ull : ((1ull << LPR) - 1ull)));
           }
-          if constexpr (!(NEED & NEED_ARG) && FU == 4) {
-            // every lane's four entries present (wavefront-uniform; the common case of a regular graph): the sums as in fold,
-            // in the same order, and the extrema two entries at a time -- no lane masks
-            if (__ballot(!(in_x[0] && in_x[1] && in_x[2] && in_x[3])) == 0) {
-#pragma unroll
-              for (int uu = 0; uu < FU; ++uu) {
-                acc.sum += v[uu];
-                acc.ws = f4_fma(splat(w[uu]), v[uu], acc.ws);
-                if constexpr (NEED & NEED_SQ) acc.sq += f4_sqr_rn(v[uu] - acc.sh);
-              }
-              acc.mx = f4_vmax3(f4_vmax3(acc.mx, v[0], v[1]), v[2], v[3]);
-              if constexpr (NEED & NEED_MN) acc.mn = f4_vmin3(f4_vmin3(acc.mn, v[0], v[1]), v[2], v[3]);
-              continue;
+          const int jx = (pv && !(C::xl(a) && self_e)) ? jj : zrow;
+          const int cnt = min(LPR, maxd - ts);
+          for (int t0 = 0; t0 < cnt; t0 += FU) {
+            f4 v[FU];
+            float w[FU];
+            bool in_x[FU];
+  #pragma unroll
+            for (int uu = 0; uu < FU; ++uu) {
+              const int addr = grp_addr + ((t0 + uu) << 2);
+              const int j = bperm(addr, jx);
+              in_x[uu] = j != zrow;
+              v[uu] = *reinterpret_cast<const f4*>(bq + __umul24((unsigned)j, ldb_bytes));
+              w[uu] = bperm(addr, dd);
             }
+            if constexpr (!(NEED & NEED_ARG) && FU == 4) {
+              // every lane's four entries present (wavefront-uniform; the common case of a regular graph): the sums as in fold,
+              // in the same order, and the extrema two entries at a time -- no lane masks
+              if (__ballot(!(in_x[0] && in_x[1] && in_x[2] && in_x[3])) == 0) {
+  #pragma unroll
+                for (int uu = 0; uu < FU; ++uu) {
+                  acc.sum += v[uu];
+                  acc.ws = f4_fma(splat(w[uu]), v[uu], acc.ws);
+                  if constexpr (NEED & NEED_SQ) acc.sq += f4_sqr_rn(v[uu] - acc.sh);
+                }
+                acc.mx = f4_vmax3(f4_vmax3(acc.mx, v[0], v[1]), v[2], v[3]);
+                if constexpr (NEED & NEED_MN) acc.mn = f4_vmin3(f4_vmin3(acc.mn, v[0], v[1]), v[2], v[3]);
+                continue;
+              }
+            }
+  #pragma unroll
+            for (int uu = 0; uu < FU; ++uu) fold<NEED>(acc, v[uu], w[uu], in_x[uu], start + ts + t0 + uu);
           }
-#pragma unroll
-          for (int uu = 0; uu < FU; ++uu) fold<NEED>(acc, v[uu], w[uu], in_x[uu], start + ts + t0 + uu);
         }
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const f4 wdummy[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+        // the row's weightings sit in the LDS image as [h][b][4], nonlinearity applied (W_READY; a.w_lds_stride == 0)
+        finish_group<LPR_LOG2, HPB, NEED, C, true, WIDE != 0 ? 0 : 4>(as, R, ln, row, row_ok, acc, nd, nself, dis_i, vself, has_self, wdummy,
+                                                                 true, lds_wt + (row_ok ? r : 0) * t.wl_floats, lds_bias, lds_scale);
       }
-      int ln = lane;
-      asm volatile("" : "+v"(ln));
-      const f4 wdummy[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
-      // the row's weightings sit in the LDS image as [h][b][4], nonlinearity applied (W_READY; a.w_lds_stride == 0)
-      finish_group<LPR_LOG2, HPB, NEED, C, true, WIDE != 0 ? 0 : 4>(a, R, ln, row, row_ok, acc, nd, nself, dis_i, vself, has_self, wdummy,
-                                                               true, lds_wt + (row_ok ? r : 0) * t.wl_floats, lds_bias, lds_scale);
     }
     FT_STAMP(5)
     request_weights();

@@ -37,10 +37,10 @@ def _oracle(conv, kind, x, ei, H, B, aggrs, asl=True):
                                             add_self_loops=asl)
 
 
-def _messy_batch(seed, n_graphs=300):
-    """Graph sizes 1..90 incl. empty graphs' neighbours, self loops, duplicates, a hub row, isolated nodes."""
+def _messy_batch(seed, n_graphs=300, max_size=90):
+    """Graph sizes 1..max_size - 1 incl. empty graphs' neighbours, self loops, duplicates, a hub row, isolated nodes."""
     rng = np.random.default_rng(seed)
-    sizes = rng.integers(1, 90, size=n_graphs)
+    sizes = rng.integers(1, max_size, size=n_graphs)
     sizes[rng.integers(0, n_graphs, size=10)] = 1
     ptr = np.concatenate([[0], np.cumsum(sizes)])
     srcs, dsts = [], []

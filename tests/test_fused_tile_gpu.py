@@ -52,12 +52,15 @@ def _edge_ptr(ei, ptr):
     ("lay", 184, 8, 4, ["symadd", "std", "max"], True),                # std in the wide form (NEED_SQ), L = 23 padded to 24
     ("opt", 200, 4, 2, ["min", "max"], False),                         # RAW sets, min, B = 2, no symnorm, F_in % 32 != 0
     ("opt", 160, 16, 4, ["sum", "symnorm"], True),                     # H / B = 4 heads per basis, A = 2 (two floats per (h, b) block)
+    ("lay", 300, 4, 4, ["symadd", "min", "max"], True),                # ogbg-code EGC-M (run_pretrained.sh:48): 76 slots -> two passes of 40 / 36 lanes
+    ("lay", 304, 8, 8, ["symadd"], True),                              # ogbg-code EGC-S (run_pretrained.sh:47): 80 slots, B = 8, 384 columns
 ])
 @pytest.mark.parametrize("with_edge_ptr", [False, True])
 def test_one_launch_layer_matches_the_oracle_on_a_messy_batch(kind, hidden, H, B, aggrs, asl, with_edge_ptr):
     import egc_amd
     dev = _dev()
-    ei, n, ptr = _messy_batch(hidden + len(aggrs))
+    # (the 300- / 304-wide layers keep 64-row tiles: their messy batch has graphs of at most 63 nodes)
+    ei, n, ptr = _messy_batch(hidden + len(aggrs), max_size=90 if hidden < 300 else 64)
     torch.manual_seed(1)
     conv = _layer(kind, hidden, H, B, aggrs, asl)
     x = torch.randn(n, hidden)
@@ -69,7 +72,7 @@ def test_one_launch_layer_matches_the_oracle_on_a_messy_batch(kind, hidden, H, B
         g_of_edge = np.searchsorted(ptr.numpy(), ei[1].numpy(), side="right") - 1
         assert np.all(np.diff(g_of_edge) >= 0)
         eptr = torch.from_numpy(np.searchsorted(g_of_edge, np.arange(ptr.numel()), side="left").astype(np.int64)).to(dev)
-    gb = egc_amd.GraphBatch(ei.to(dev), ptr=ptr.to(dev), max_nodes=90, edge_ptr=eptr)
+    gb = egc_amd.GraphBatch(ei.to(dev), ptr=ptr.to(dev), max_nodes=90 if hidden < 300 else 64, edge_ptr=eptr)
     with torch.no_grad():
         out = conv(x.to(dev), gb) if kind == "opt" else conv(x=x.to(dev), edge_index=gb)
     gb.check()
@@ -176,6 +179,8 @@ def test_one_launch_layer_at_full_batch_sizes(workload, with_edge_ptr):
     ("cifar", 168, 8, 4, ["symadd"]),                # run_pretrained.sh:12  cifar EGC-S (graphs of up to 150 nodes: 160-row tiles)
     ("molhiv", 296, 8, 4, ["symadd"]),               # run_pretrained.sh:23  molhiv EGC-S
     ("molhiv", 224, 4, 4, ["add", "mean", "max"]),   # run_pretrained.sh:24  molhiv EGC-M (BASELINE config 3's own net)
+    ("zinc", 300, 4, 4, ["symadd", "min", "max"]),   # run_pretrained.sh:48  code EGC-M's layer (no code-shaped batch in BASELINE: the ZINC batch)
+    ("zinc", 304, 8, 8, ["symadd"]),                 # run_pretrained.sh:47  code EGC-S's layer
 ])
 def test_wide_one_launch_layer_at_full_batch_sizes(workload, hidden, H, B, aggrs):
     """The reference's own batched nets at the full batch of their dataset's shape through the WIDE one-launch form

@@ -43,3 +43,7 @@ for sizes, grid in (([20], None), ([40], None), ([70], None), ([100], None), ([1
 run([100], 224, 4, 4, ["add", "mean", "max"], None, 96)
 run([90], 224, 4, 4, ["add", "mean", "max"], None)
 run([60, 60], 296, 8, 4, ["symadd"], 1)
+run([20], 304, 8, 8, ["symadd"], None)
+run([60, 50, 40, 64], 304, 8, 8, ["symadd"], 1)
+run([20], 300, 4, 4, ["symadd", "min", "max"], None)
+run([60, 50, 40, 64] * 4, 300, 4, 4, ["symadd", "min", "max"], 2)
