@@ -177,10 +177,12 @@ __device__ inline void finish_row(const AggArgs& a, __amdgpu_buffer_rsrc_t rsrc,
         if (a.stats != nullptr) {  // training forward: keep the raw aggregates for the backward
           float* st = a.stats + ((int64_t)row * a.stat_k) * a.ldb + 4 * s;
           if (a.stat_slot[STAT_SUM] >= 0) *reinterpret_cast<f4*>(st + a.stat_slot[STAT_SUM] * a.ldb) = acc.sum[k];
-          if (a.stat_slot[STAT_SQ] >= 0) {   // the backward's record keeps the plain sum of squares: sq + sh (2 ds + cnt sh), ds + cnt sh = sum
+          if (a.stat_slot[STAT_SQ] >= 0) {   // the backward's record keeps the VARIANCE as this forward forms it (a
+            // reconstructed plain sum of squares, from which the backward re-derived var = sq / cnt - mean^2, gave (nearly) tied
+            // neighbourhoods a relu mask and a std that were not the forward's)
             const float nc = -(float)cnt;
             const f4 ds = f4_fma(f4{nc, nc, nc, nc}, acc.sh[k], acc.sum[k]);
-            *reinterpret_cast<f4*>(st + a.stat_slot[STAT_SQ] * a.ldb) = f4_fma(acc.sh[k], ds + acc.sum[k], acc.sq[k]);
+            *reinterpret_cast<f4*>(st + a.stat_slot[STAT_SQ] * a.ldb) = f4_var(f4_div(acc.sq[k], cntf), f4_div(ds, cntf));
           }
           if (a.stat_slot[STAT_MX] >= 0) *reinterpret_cast<f4*>(st + a.stat_slot[STAT_MX] * a.ldb) = acc.mx[k];
           if (a.stat_slot[STAT_MN] >= 0) *reinterpret_cast<f4*>(st + a.stat_slot[STAT_MN] * a.ldb) = acc.mn[k];

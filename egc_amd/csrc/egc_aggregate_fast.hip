@@ -45,7 +45,10 @@ namespace egc {
 template <int LPR_LOG2, int HPB, int NEED, class C>
 // Inference variants (NEED == 0) fit 80 VGPRs without spilling when asked to, which buys the sixth wavefront per
 // SIMD; the variants carrying more running aggregates are left to the register allocator.
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NEED == 0 ? EGC_AGG_WAVES : ((NEED & NEED_ARG) && (NEED & NEED_SQ)) ? 2 : (NEED == NEED_SQ || NEED == NEED_MN) ? 5 : 4)))
+#ifndef EGC_AGG_WAVES_SQ
+#define EGC_AGG_WAVES_SQ 5   // wavefronts per SIMD of the std / var (or min) variants: six spill
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NEED == 0 ? EGC_AGG_WAVES : ((NEED & NEED_ARG) && (NEED & NEED_SQ)) ? 2 : (NEED == NEED_SQ || NEED == NEED_MN) ? EGC_AGG_WAVES_SQ : 4)))
 agg_fast_kernel(AggArgs a) {
   constexpr int LPR = 1 << LPR_LOG2, G = 64 / LPR;
   extern __shared__ float smem[];
@@ -613,6 +616,8 @@ int launch_fast(AggArgs a, int64_t n_nodes, const PlanCaps& caps, hipStream_t st
     constexpr int S = EGC_AGGR_SUM, M = EGC_AGGR_MEAN, X = EGC_AGGR_MAX, Y = EGC_AGGR_SYMNORM;
     // EGConv / EGC-M north star: d=128, H=8, B=4, sum+mean+max+symnorm, gcn_norm self-loops on every node
     EGC_STATIC_CFG(8, 4, 16, 4, agg_pack(S, M, X, Y), EGC_ACT_NONE, true, true, true, 0)
+    // the same layer with `std` in place of `mean` (bench.py: std_layer): the squares about the row's first entry
+    EGC_STATIC_CFG(8, 4, 16, 4, agg_pack(S, EGC_AGGR_STD, X, Y), EGC_ACT_NONE, true, true, true, NEED_SQ)
     // EGConv / EGC-S default: symnorm only (optimized_layers.py:77)
     EGC_STATIC_CFG(8, 4, 16, 1, agg_pack(Y), EGC_ACT_NONE, true, true, true, 0)
     // EfficientGraphConv EGC-M / EGC-S flavours at d=128 (symadd looped, the others raw): layers.py:166-193

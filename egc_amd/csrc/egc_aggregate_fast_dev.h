@@ -415,9 +415,10 @@ __device__ inline void finish_group(const AggArgs& a, const FastRsrc& R, int lan
     if (a.stat_slot[STAT_MX] >= 0) __builtin_nontemporal_store(acc.mx, reinterpret_cast<f4*>(st + a.stat_slot[STAT_MX] * a.ldb));
     if (a.stat_slot[STAT_WS] >= 0) __builtin_nontemporal_store(acc.ws, reinterpret_cast<f4*>(st + a.stat_slot[STAT_WS] * a.ldb));
     if constexpr (NEED & NEED_SQ)
-      if (a.stat_slot[STAT_SQ] >= 0) {   // the backward's record keeps the plain sum of squares: sq + sh (2 ds + cnt sh), ds + cnt sh = sum
+      if (a.stat_slot[STAT_SQ] >= 0) {   // the backward's record keeps the VARIANCE exactly as the epilogue below forms it
+        const float cf = (float)max(cnt, 1);
         const f4 ds = f4_fma(splat(-(float)cnt), acc.sh, acc.sum);
-        __builtin_nontemporal_store(f4_fma(acc.sh, ds + acc.sum, acc.sq), reinterpret_cast<f4*>(st + a.stat_slot[STAT_SQ] * a.ldb));
+        __builtin_nontemporal_store(f4_var(f4_div(acc.sq, cf), f4_div(ds, cf)), reinterpret_cast<f4*>(st + a.stat_slot[STAT_SQ] * a.ldb));
       }
     if constexpr (NEED & NEED_MN)
       if (a.stat_slot[STAT_MN] >= 0) __builtin_nontemporal_store(acc.mn, reinterpret_cast<f4*>(st + a.stat_slot[STAT_MN] * a.ldb));

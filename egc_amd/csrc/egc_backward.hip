@@ -328,7 +328,7 @@ __global__ void __launch_bounds__(256) bwd_dst_kernel(BwdArgs a) {
     const float mn = a.stat_slot[STAT_MN] >= 0 ? st[a.stat_slot[STAT_MN] * a.ldb + c] : 0.f;
     const float ws = a.stat_slot[STAT_WS] >= 0 ? st[a.stat_slot[STAT_WS] * a.ldb + c] : 0.f;
     const float mean = sum / cntf;
-    const float var = __fsub_rn(sq / cntf, __fmul_rn(mean, mean));
+    const float var = sq;       // the record's STAT_SQ slot IS the forward's variance (same mask, same std as the forward's)
     const float sd = sqrtf(fmaxf(var, 0.f) + 1e-5f);
     for (int t = 0; t < a.A; ++t) {
       float val;
@@ -693,7 +693,7 @@ __global__ void __launch_bounds__(256) bwd_dst_fast_kernel(BwdArgs a) {
   const bool has_sq = AG::stat_slot(a, STAT_SQ) >= 0;
   const float rcnt = 1.0f / cntf;
   const f4 mean = has_sq ? f4_div(sum, cntf) : sum * f4{rcnt, rcnt, rcnt, rcnt};
-  const f4 var = has_sq ? f4_var(f4_div(sq, cntf), mean) : zero;
+  const f4 var = has_sq ? sq : zero;       // the record's STAT_SQ slot IS the forward's variance
   const f4 sd = has_sq ? f4_std(var) : zero;
   f4 val[4], dagg[4];
 #pragma unroll

@@ -294,9 +294,7 @@ int launch_fused_tile(AggArgs a, const int64_t* ptr, const int64_t* edge_ptr, in
   t.p0 = ((a.Ls >> 2) + 1) / 2;
   t.magic0 = (unsigned)(((uint64_t)1 << 32) / (uint64_t)t.p0) + 1u;
   t.magic1 = (unsigned)(((uint64_t)1 << 32) / (uint64_t)std::max(1, (a.Ls >> 2) - t.p0)) + 1u;
-#ifdef EGC_FT_STAMPS
-  if (const char* e = getenv("EGC_FT_DBG")) t.dbg = atoi(e);
-#endif
+  if (const char* e = getenv("EGC_FT_DBG")) t.dbg = atoi(e);     // (read by diagnostic builds of the kernel only: -DEGC_FT_STAMPS)
   if (tcap < FT_CHUNK || tcap > FT_CHUNK * FT_RING || (tcap % (wide ? FTW_CH : FT_CHUNK)) != 0 || emax < 0) return EGC_ERR_INVALID;
   const FtLds L = ft_lds(a, t.wl_floats, tcap, emax, a.post_scale != nullptr, wide);
   if (L.total > FT_LDS_BUDGET) return EGC_ERR_UNSUPPORTED;

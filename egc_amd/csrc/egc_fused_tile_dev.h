@@ -699,7 +699,10 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
     // through copies of all 40 registers of a chunk -- and as inline assembly with counted waits some of those copies ran while
     // the load into their source was in flight.)
     constexpr int NS = WIDE;             // k-slabs of 128 per chunk: ceil(F_in / 128) -- the host picks the instance
-    f4 xa[FTW_PP], xb[FTW_PP];
+    // 16-byte pieces per thread and chunk: a row's groups of eight pieces -- F_in <= 256 needs 8 of them, 320 needs 10 (the two
+    // fewer are 16 registers the split's temporaries otherwise spilled for, with a vmcnt(0) behind every reload)
+    constexpr int PP = NS == 3 ? FTW_PP : 8;
+    f4 xa[PP], xb[PP];
     const int hrow = ht >> 3, hj = ht & 7;
     constexpr unsigned XOOB = 0x80000000u;
     // piece i of a row = columns 4 (hj + 8 i) ..+3.  A row's pieces come in groups of eight: group i is whole for i < F_in / 32,
@@ -715,22 +718,22 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       return __builtin_amdgcn_make_buffer_rsrc((void*)(t.x + (int64_t)r.n0 * t.F_in), 0,
                                                (unsigned)(r.ok ? r.T : 0) * (unsigned)t.F_in * 4u, 0x00020000);
     };
-    auto request = [&](f4 (&xs)[FTW_PP], const __amdgpu_buffer_rsrc_t rs, int chunk) {
+    auto request = [&](f4 (&xs)[PP], const __amdgpu_buffer_rsrc_t rs, int chunk) {
       const int so = chunk * FTW_CH * t.F_in * 4;
 #pragma unroll
-      for (int i = 0; i < FTW_PP; ++i)
+      for (int i = 0; i < PP; ++i)
         xs[i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, xoff0 + 128u * i, i < npg ? so : (int)XOOB, 0));
     };
     // piece i of a landed chunk (the partial group's missing lanes read as zero)
-    auto piece = [&](const f4 (&xs)[FTW_PP], int i) -> f4 {
+    auto piece = [&](const f4 (&xs)[PP], int i) -> f4 {
       const bool cut = lane_cut && i == npf;
       return f4{cut ? 0.f : xs[i].x, cut ? 0.f : xs[i].y, cut ? 0.f : xs[i].z, cut ? 0.f : xs[i].w};
     };
     // exponent field of a row's largest magnitude (8 lanes hold a row), clamped as in the narrow form
-    auto row_exp = [&](const f4 (&xs)[FTW_PP]) -> unsigned {
+    auto row_exp = [&](const f4 (&xs)[PP]) -> unsigned {
       float m = 0.f;
 #pragma unroll
-      for (int i = 0; i < FTW_PP; ++i) {
+      for (int i = 0; i < PP; ++i) {
         const f4 v = piece(xs, i);
         m = fmaxf(fmaxf(fmaxf(m, fabsf(v.x)), fmaxf(fabsf(v.y), fabsf(v.z))), fabsf(v.w));
       }
@@ -742,14 +745,14 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       return min(max(e, 13u << 23), 253u << 23);
     };
     // slab sl of the chunk in xs -> plane buffer buf: pieces 4 sl .. 4 sl + 3 (k = 128 sl + 4 (hj + 8 (i - 4 sl)) ..+3)
-    auto split_slab = [&](const f4 (&xs)[FTW_PP], int sl, unsigned e, int buf) {
+    auto split_slab = [&](const f4 (&xs)[PP], int sl, unsigned e, int buf) {
       const float sc = __uint_as_float(0x7f000000u - e);                  // 2^-e
       const float sc2k = __uint_as_float(0x7f000000u + (11u << 23) - e);  // 2^(11-e)
       char* dst0 = lds_planes + buf * FTW_PBUF_BYTES + hrow * (FTW_LDX * 2) + 8 * hj;
 #pragma unroll
       for (int ii = 0; ii < 4; ++ii) {
         const int i = 4 * sl + ii;
-        if (i < FTW_PP) {
+        if (i < PP) {
           const f4 v = piece(xs, i);
           const ft_h2 h01 = __builtin_convertvector(ft_f2{v.x * sc, v.y * sc}, ft_h2);
           const ft_h2 h23 = __builtin_convertvector(ft_f2{v.z * sc, v.w * sc}, ft_h2);
@@ -766,7 +769,7 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
     };
     unsigned e_cur = 13u << 23;          // the exponent of the chunk whose slabs are being split
     // chunk `chunk` (in xs, landed) starts: its rows' scales, its slab 0 -> buf   (reads of xs only)
-    auto start_chunk = [&](const f4 (&xs)[FTW_PP], int chunk, int buf) {
+    auto start_chunk = [&](const f4 (&xs)[PP], int chunk, int buf) {
       e_cur = row_exp(xs);
       lds_rowinv_w[(chunk & 1) * FTW_CH + hrow] = __uint_as_float(e_cur);      // 2^e (the 8 lanes of a row write the same word)
       split_slab(xs, 0, e_cur, buf);
@@ -782,10 +785,10 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
     unsigned epk0[KEEP];
     {
       const __amdgpu_buffer_rsrc_t rs = x_rsrc_of(first);
-      if (csr_wave) csr_s0(first, xb + 2);
+      if (csr_wave) csr_s0(first, xb + (PP - 8));
       request(xa, rs, 0);
       if (csr_wave) {
-        csr_s1(first, 0, xb + 2, epk0);
+        csr_s1(first, 0, xb + (PP - 8), epk0);
         csr_s1_rest(first, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -811,15 +814,20 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       for (int c = 0; c < FTW_MAXCH; ++c) {
 #pragma unroll
         for (int sl = 0; sl < NS; ++sl) {
+#ifdef EGC_FT_STAMPS
+          const bool on = c < cur.nch, work = on && !(t.dbg & 1);       // (diagnostic build: EGC_FT_DBG bit 0 = no split)
+#else
           const bool on = c < cur.nch;                                  // the step exists (workgroup-uniform)
+          const bool work = on;
+#endif
           if (c & 1) {      // chunk c lives in xb, chunk c + 1 in xa
-            if (on && sl + 1 < NS) split_slab(xb, sl + 1, e_cur, qn);                       // the chunk's next slab ...
-            if (on && sl + 1 == NS && c + 1 < cur.nch) start_chunk(xa, c + 1, qn);          // ... or the next chunk's first
+            if (work && sl + 1 < NS) split_slab(xb, sl + 1, e_cur, qn);                     // the chunk's next slab ...
+            if (work && sl + 1 == NS && c + 1 < cur.nch) start_chunk(xa, c + 1, qn);        // ... or the next chunk's first
             if (NS >= 2 && sl + 2 == NS) request(xb, rsc, c + 2);                           // the chunk's last slab has left its registers
             if (NS == 1) request(xa, rsc, c + 3);
           } else {
-            if (on && sl + 1 < NS) split_slab(xa, sl + 1, e_cur, qn);
-            if (on && sl + 1 == NS && c + 1 < cur.nch) start_chunk(xb, c + 1, qn);
+            if (work && sl + 1 < NS) split_slab(xa, sl + 1, e_cur, qn);
+            if (work && sl + 1 == NS && c + 1 < cur.nch) start_chunk(xb, c + 1, qn);
             if (NS >= 2 && sl + 2 == NS) request(xa, rsc, c + 2);
             if (NS == 1) request(xb, rsc, c + 3);
           }
@@ -831,10 +839,10 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       }
       __builtin_amdgcn_s_setprio(3);
       if (wave == FT_WAVES - 1) plan_tile((it + 2) % 3);
-      if (csr_wave) csr_s0(nxt, xb + 2);
+      if (csr_wave) csr_s0(nxt, xb + (PP - 8));
       request(xa, rsn, 0);
       if (csr_wave) {
-        csr_s1(nxt, nset, xb + 2, epk);
+        csr_s1(nxt, nset, xb + (PP - 8), epk);
         csr_s1_rest(nxt, nset);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -1062,7 +1070,7 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
     //      k-step of 16 both planes of the weight fragment come from L2 (packed[tile][k-step][plane][lane][8]: one KiB per
     //      request), requested FOUR k-steps ahead into a ring of four (with one step ahead and a register copy at the end of
     //      the step every k-step paid the whole L2 latency: 22,000 cycles per chunk against 1,300 of matrix work); three
-    //      products, acc0 = xh wh, acc1 = xl wh + xh wl.  One barrier per k-slab of 128 the helpers stage; the D tile leaves
+    //      products, acc0 = xh wh, acc1 = xl wh, acc2 = xh wl.  One barrier per k-slab of 128 the helpers stage; the D tile leaves
     //      behind the chunk's last k-step. ----
     typedef float ft_f16v __attribute__((ext_vector_type(16)));
     int lvm = lane;
@@ -1083,12 +1091,20 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
     }
     int qb = 0;                         // plane buffer of the running slab step
     for (int c = 0; c < nch; ++c) {
-      ft_f16v acc0, acc1;
+      // three accumulators, one per product: a second product on the same accumulator waits for the first (64 cycles of a
+      // 32 x 32 x 16 MFMA's latency against 32 of issue) -- 2,300 cycles of matrix work per chunk where 1,150 do
+      ft_f16v acc0, acc1, acc2;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+      for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; }
       if (is_mfma) {
         const char* pa = lds_planes + qb * FTW_PBUF_BYTES + l31 * (FTW_LDX * 2) + hh * 16;
         for (int g = 0; g < NG; ++g) {
+#ifdef EGC_FT_STAMPS
+          if (t.dbg & 2) {                 // (diagnostic build: EGC_FT_DBG bit 1 = no matrix work, the barriers stay)
+            if ((g & 1) && g + 1 < NG) { qb ^= 1; lds_barrier(); }
+            continue;
+          }
+#endif
           const ft_h8* bnext = g + 1 < NG ? bsrc + (int64_t)(g + 1) * (BD * 128) : bsrc;
           // the A fragments of the group's four k-steps: requested together (their LDS latency passes once per group)
           ft_h8 xh[BD], xl[BD];
@@ -1102,7 +1118,7 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
           for (int j = 0; j < BD; ++j) {
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[j], wh[j], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[j], wh[j], acc1, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[j], wl[j], acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[j], wl[j], acc2, 0, 0, 0);
             wh[j] = bnext[j * 128];
             wl[j] = bnext[j * 128 + 64];
           }
@@ -1119,10 +1135,10 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
           for (int j = 0; j < 4; ++j) {
             const f4 ri = *reinterpret_cast<const f4*>(rinv + 8 * j);
             f4 o;
-            o.x = __builtin_fmaf(__builtin_fmaf(acc1[4 * j], 1.f / 2048.f, acc0[4 * j]), col_inv * ri.x, col_bias);
-            o.y = __builtin_fmaf(__builtin_fmaf(acc1[4 * j + 1], 1.f / 2048.f, acc0[4 * j + 1]), col_inv * ri.y, col_bias);
-            o.z = __builtin_fmaf(__builtin_fmaf(acc1[4 * j + 2], 1.f / 2048.f, acc0[4 * j + 2]), col_inv * ri.z, col_bias);
-            o.w = __builtin_fmaf(__builtin_fmaf(acc1[4 * j + 3], 1.f / 2048.f, acc0[4 * j + 3]), col_inv * ri.w, col_bias);
+            o.x = __builtin_fmaf(__builtin_fmaf(acc1[4 * j] + acc2[4 * j], 1.f / 2048.f, acc0[4 * j]), col_inv * ri.x, col_bias);
+            o.y = __builtin_fmaf(__builtin_fmaf(acc1[4 * j + 1] + acc2[4 * j + 1], 1.f / 2048.f, acc0[4 * j + 1]), col_inv * ri.y, col_bias);
+            o.z = __builtin_fmaf(__builtin_fmaf(acc1[4 * j + 2] + acc2[4 * j + 2], 1.f / 2048.f, acc0[4 * j + 2]), col_inv * ri.z, col_bias);
+            o.w = __builtin_fmaf(__builtin_fmaf(acc1[4 * j + 3] + acc2[4 * j + 3], 1.f / 2048.f, acc0[4 * j + 3]), col_inv * ri.w, col_bias);
             if (dst_act) o = w_act<C>(a, o);
             if (dst_off >= 0) {
               char* po = base + dst_off + (FTW_CH * c + 8 * j + 4 * hh) * dst_stride;

@@ -458,8 +458,9 @@ int egc_segment_mean_f32(const float* x, const int64_t* seg_ptr, int64_t n_segme
 
 /* Training form of egc_aggregate_combine_f32: same `out`, plus what the backward needs instead of a second
  * gather.  stats (n_nodes * egc_train_stats_floats(layer) floats, opaque to the caller, handed to the backward
- * as it is) receives every row's raw running aggregates after the self-loop term (those of sum / sum of squares /
- * max / min / symnorm-weighted sum that the aggregator list uses, [n_nodes][k][ldb]) and, behind them, the arg
+ * as it is) receives every row's raw running aggregates after the self-loop term (those of sum / variance -- as the
+ * forward forms it, so that the backward's relu mask and std are the forward's -- / max / min / symnorm-weighted sum
+ * that the aggregator list uses, [n_nodes][k][ldb]) and, behind them, the arg
  * positions below as one byte each relative to the row's first entry (what the backward gathers per transposed
  * entry: 64 instead of 256 bytes at the north star); cnt [n_nodes] the size of the row's aggregation set.  arg_max / arg_min
  * (each [n_nodes, ldb] int32; NULL allowed when the layer has no max / min aggregator) receive, per basis

@@ -66,6 +66,45 @@ def test_egconv_gradients(aggrs, kw):
         assert _rel(v.grad, p64[k].grad) <= gtol(aggrs), k
 
 
+@pytest.mark.parametrize("aggrs", [["sum", "std", "max"], ["mean", "var"]])
+def test_std_gradient_on_tied_neighbourhoods(aggrs):
+    """Neighbourhoods whose rows are identical (|x| ~ 10): the forward's variance is 0 (or -tiny -> relu -> 0) there, and the
+    backward must use THAT number -- its relu mask, its std -- not one re-derived from a sum of squares with the cancelling
+    formula (the training record now keeps the forward's variance).  Gradients against float64."""
+    import egc_amd
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(11)
+    n, fin, fout, H, B = 240, 32, 64, 8, 4
+    # destinations 0..79 gather from sources inside one of 8 groups of identical rows; the rest of the graph is random
+    src, dst = [], []
+    for i in range(80):
+        grp = 80 + 10 * (i % 8)
+        for j in rng.integers(0, 10, size=int(rng.integers(2, 9))):
+            src.append(grp + int(j)); dst.append(i)
+    rnd = _graph(rng, n, 1200, hub=60)
+    rnd = rnd[:, rnd[1] >= 80]
+    ei = np.concatenate([np.array([src, dst], dtype=np.int64), rnd], axis=1)
+    torch.manual_seed(4)
+    conv = egc_amd.EGConv(fin, fout, aggrs=aggrs, num_heads=H, num_bases=B, add_self_loops=False).to(dev)
+    x0 = torch.randn(n, fin)
+    for k in range(8):
+        x0[80 + 10 * k: 90 + 10 * k] = 10.0 * torch.randn(1, fin)      # ten identical rows of magnitude ~ 10
+    x = x0.to(dev).requires_grad_(True)
+    gout = torch.randn(n, fout, device=dev)
+    out = conv(x, torch.from_numpy(ei).to(dev))
+    out.backward(gout)
+    p64 = {k: v.detach().double().cpu().requires_grad_(True) for k, v in conv.named_parameters()}
+    x64 = x0.double().requires_grad_(True)
+    ref = tref.egconv_forward(x64, ei, p64["bases_weight"], p64["comb_weight.weight"], p64["comb_weight.bias"], p64["bias"], H, B,
+                              aggrs, add_self_loops=False, sigmoid=False)
+    ref.backward(gout.double().cpu())
+    assert torch.isfinite(x.grad).all()
+    assert _rel(out, ref) <= 1e-5
+    assert _rel(x.grad, x64.grad) <= gtol(aggrs)
+    for k, v in conv.named_parameters():
+        assert _rel(v.grad, p64[k].grad) <= gtol(aggrs), k
+
+
 @pytest.mark.parametrize("aggrs,kw", [
     (["symadd", "max", "mean"], {}),
     (["add", "std", "max"], {}),

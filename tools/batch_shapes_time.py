@@ -34,8 +34,8 @@ SHAPES = [  # (name, dataset, hidden, H, B, aggrs)   -- run_pretrained.sh line i
     ("cifar EGC-M", "cifar", 128, 4, 4, ["symadd", "std", "max"]),    # :13
     ("molhiv EGC-S", "molhiv", 296, 8, 4, ["symadd"]),                # :23
     ("molhiv EGC-M", "molhiv", 224, 4, 4, ["add", "mean", "max"]),    # :24
-    ("code EGC-S (on the molhiv batch)", "molhiv", 304, 8, 8, ["symadd"]),           # :47
-    ("code EGC-M (on the molhiv batch)", "molhiv", 300, 4, 4, ["symadd", "min", "max"]),   # :48
+    ("code EGC-S (on the ZINC batch)", "zinc", 304, 8, 8, ["symadd"]),               # :47 (64-row tiles: graphs of at most 64 nodes)
+    ("code EGC-M (on the ZINC batch)", "zinc", 300, 4, 4, ["symadd", "min", "max"]),   # :48
     ("north star EGC-M d128", "molhiv", 128, 8, 4, ["symadd", "max", "mean"]),
 ]
 
