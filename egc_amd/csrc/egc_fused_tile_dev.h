@@ -624,6 +624,15 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
           if (c + 2 < FT_RING && c + 2 < cur.nch) split(xr[2 * (c + 2)], xr[2 * (c + 2) + 1], (c + 2) % FT_PBUF);
           lds_barrier();
         }
+#ifdef EGC_FT_EARLY_X
+        // The NEXT tile's rows are requested as soon as the registers of a chunk are free -- chunks 0 and 1 at once (they were
+        // staged at the end of the tile before), chunk c + 2 behind its split -- instead of all in the rows phase: the launch's
+        // memory skeleton (no split, no matrix work, no rows: 110 k of a workgroup's 227 k cycles at config 4) is the x stream
+        // running in the rows-phase window only, 40 % of the time.  Unconditional, straight-line (a chunk beyond the next tile
+        // lies outside its descriptor); chunks 5 - 8 stay behind the CSR build's counts: its edges travel in their registers.
+        if (c == 0) { x_load(xr[0], xr[1], rsn, 0); x_load(xr[2], xr[3], rsn, 1); }
+        if (c + 2 < FT_RING && (c + 2 < FT_RING / 2 || c + 2 == FT_RING - 1)) x_load(xr[2 * (c + 2)], xr[2 * (c + 2) + 1], rsn, c + 2);
+#endif
       }
 #ifdef EGC_FT_STAMPS
       unsigned long long ft_h0;
@@ -647,8 +656,10 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       // then count the requests in flight.  (Requested chunk by chunk inside the loop above, its conservative vmcnt(0) in
       // front of every split made each step wait for the request it had just issued.)
       if (csr_wave) csr_s0(nxt, xr + FT_RING);
+#ifndef EGC_FT_EARLY_X
 #pragma unroll
       for (int c = 0; c < FT_RING / 2; ++c) x_load(xr[2 * c], xr[2 * c + 1], rsn, c);
+#endif
       if (csr_wave) {
         csr_s1(nxt, nset, xr + FT_RING, epk);
         csr_s1_rest(nxt, nset);
@@ -668,8 +679,13 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
 #endif
       // (chunks 5-9 are not split before the next tile's fifth step: their requests -- 1,300 cycles of the CU's one
       // vector-memory pipeline -- need not stand between the in-degrees and the scan)
+#ifdef EGC_FT_EARLY_X
+#pragma unroll
+      for (int c = FT_RING / 2; c < FT_RING - 1; ++c) x_load(xr[2 * c], xr[2 * c + 1], rsn, c);
+#else
 #pragma unroll
       for (int c = FT_RING / 2; c < FT_RING; ++c) x_load(xr[2 * c], xr[2 * c + 1], rsn, c);
+#endif
 #ifdef EGC_FT_STAMPS
       FT_HSTAMP(2, wave == FT_FIRST_HELPER)
 #endif
