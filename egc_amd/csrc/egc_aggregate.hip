@@ -955,6 +955,61 @@ int egc_layer_forward_batch_fused_f32(const int64_t* graph_ptr, const int64_t* e
                            tile_nodes, max_tile_edges, status, host_flag, (hipStream_t)stream);
 }
 
+// ---- the same batches, the layer's BACKWARD in one launch (egc_fused_tile.hip, MODE 1) ----
+int32_t egc_batch_fused_bwd_tile_nodes(const egc_layer* layer, int32_t max_tile_edges) {
+  AggArgs a;
+  if (tile_layer_args(layer, a) != EGC_OK) return 0;
+  return fused_tile_bwd_capacity(a, layer->in_channels, max_tile_edges);
+}
+
+int64_t egc_batch_fused_bwd_pack_bytes(const egc_layer* layer) {
+  AggArgs a;
+  if (tile_layer_args(layer, a) != EGC_OK || !fused_tile_bwd_shape(a, layer->in_channels)) return 0;
+  return (int64_t)fused_tile_bwd_pack_bytes();
+}
+
+int egc_batch_fused_bwd_pack(const egc_layer* layer, const float* wcat, void* packed_t, int64_t packed_bytes, egc_stream_t stream) {
+  AggArgs a;
+  int st = tile_layer_args(layer, a);
+  if (st != EGC_OK) return st;
+  if (!fused_tile_bwd_shape(a, layer->in_channels)) return EGC_ERR_UNSUPPORTED;
+  if (wcat == nullptr || packed_t == nullptr || packed_bytes < (int64_t)fused_tile_bwd_pack_bytes()) return EGC_ERR_INVALID;
+  return fused_tile_bwd_pack(a, wcat, layer->in_channels, packed_t, (hipStream_t)stream);
+}
+
+int egc_layer_backward_batch_fused_f32(const int64_t* graph_ptr, const int64_t* edge_ptr, int64_t n_graphs, const int64_t* src,
+                                       const int64_t* dst, int64_t n_edges, int64_t n_nodes, const int32_t* max_index,
+                                       const egc_layer* layer, const float* x, const void* packed, const void* packed_t,
+                                       const float* grad_out, float* d_x, float* d_cat, int32_t ld_dcat, int32_t tile_nodes,
+                                       int32_t max_tile_edges, int32_t* status, int32_t* host_flag, egc_stream_t stream) {
+  AggArgs a;
+  int st = tile_layer_args(layer, a);
+  if (st != EGC_OK) return st;
+  if (n_nodes < 0 || n_graphs < 0 || n_edges < 0 || n_nodes >= ((int64_t)1 << 31) - 1 || n_edges >= ((int64_t)1 << 31) - 1)
+    return EGC_ERR_INVALID;
+  if (n_nodes == 0 || n_graphs == 0) return EGC_OK;
+  if (graph_ptr == nullptr || x == nullptr || packed == nullptr || packed_t == nullptr || grad_out == nullptr || d_x == nullptr ||
+      status == nullptr)
+    return EGC_ERR_INVALID;
+  if (n_edges > 0 && (src == nullptr || dst == nullptr)) return EGC_ERR_INVALID;
+  if ((reinterpret_cast<uintptr_t>(x) & 15) != 0 || (reinterpret_cast<uintptr_t>(packed) & 15) != 0 ||
+      (reinterpret_cast<uintptr_t>(packed_t) & 15) != 0 || (reinterpret_cast<uintptr_t>(grad_out) & 15) != 0)
+    return EGC_ERR_INVALID;
+  if (d_cat != nullptr && (ld_dcat < a.ldb + a.W || (ld_dcat & 3) != 0 || (reinterpret_cast<uintptr_t>(d_cat) & 15) != 0)) return EGC_ERR_INVALID;
+  if (!a.loops_all && max_index == nullptr) return EGC_ERR_INVALID;
+  if ((uint64_t)n_nodes * (uint64_t)a.F_out * 4ull > (uint64_t)OOB) return EGC_ERR_UNSUPPORTED;
+  a.n_nodes = (int)n_nodes;
+  a.row_begin = 0;
+  a.row_end = (int)n_nodes;
+  a.bases = nullptr;
+  a.weightings = nullptr;
+  a.bases_bytes = 0;
+  a.dis = layer_uses_symnorm(layer) ? x : nullptr;   // (a flag: the deg^-1/2 tables are built per tile, in LDS)
+  a.self_pos = 0;
+  return launch_fused_tile_bwd(a, graph_ptr, edge_ptr, n_graphs, src, dst, n_edges, max_index, x, layer->in_channels, packed, packed_t,
+                               grad_out, d_x, d_cat, ld_dcat, tile_nodes, max_tile_edges, status, host_flag, (hipStream_t)stream);
+}
+
 int32_t egc_layer_gemm_flags(const egc_layer* layer) {
   // 0 for every layer since round 4: the variance is accumulated about the row's first entry (FAcc::sh), which takes the
   // cancellation -- and with it the amplification of what the 22-bit operand split drops -- out of std / var (44 fuzz seeds,

@@ -502,33 +502,39 @@ __device__ inline void finish_group(const AggArgs& a, const FastRsrc& R, int lan
       }
       o[hb] = dpp_reduce_scatter_4_bases(p[0], p[1], p[2], p[3]);
     }
-  } else if (!C::pow2(a) && B == 4 && (H & 3) == 0) {
-    // B = 4 bases of P lanes each, P not a power of two (the padded bases of the reference's 168 / 184 / 296 / 224 / 136-wide
-    // nets): the same reduce-scatter over the bases as above, by lane rotation -- lane (b, l4) forms the shares of the four
-    // heads of a block in ITS OWN order (head (b + j) mod 4 at step j) and receives step j's share from lane (b - j, l4), which
-    // formed it for head b.  12 cross-lane moves + 12 additions per head block instead of the 32 + 32 of a rotation butterfly
-    // per head (round 5: the rows phase of the one-launch kernels is bound by the vector instructions of a row turn).
+  } else if (!C::pow2(a) && (B == 4 || B == 8) && H % B == 0) {
+    // B = 4 (or 8) bases of P lanes each, P not a power of two (the padded bases of the reference's 168 / 184 / 296 / 224 / 136 /
+    // 300 / 304-wide nets): the same reduce-scatter over the bases as above, by lane rotation -- lane (b, l4) forms the shares of
+    // the B heads of a block in ITS OWN order (head (b + j) mod B at step j) and receives step j's share from lane (b - j, l4),
+    // which formed it for head b.  B - 1 cross-lane moves + additions of four components per head block instead of the
+    // B log2(B) of a rotation butterfly per head (round 5: the rows phase of the one-launch kernels is bound by the vector
+    // instructions of a row turn).
     const int P = C::lanes_pb(a), S = C::slots(a);
-    int s1 = q - P, s2 = q - 2 * P, s3 = q - 3 * P;
-    s1 = s1 < 0 ? s1 + S : s1; s2 = s2 < 0 ? s2 + S : s2; s3 = s3 < 0 ? s3 + S : s3;
     const int gb = g << LPR_LOG2;
-    const int a1 = (gb + (live ? s1 : q)) << 2, a2 = (gb + (live ? s2 : q)) << 2, a3 = (gb + (live ? s3 : q)) << 2;
 #pragma unroll
     for (int hb = 0; hb < HPB; ++hb) {
-      f4 p[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int h = hb * 4 + ((b + j) & 3);
-        const float* wp = wl + (min(h, H - 1) * 4 + b) * AW;
+      f4 r = zero;
+#pragma unroll 8
+      for (int j = 0; j < B; ++j) {     // (B is 4 or 8: wave-uniform)
+        const int h = hb * B + ((b + j) & (B - 1));
+        const float* wp = wl + (min(h, H - 1) * B + b) * AW;
+        f4 pj;
         if (A == 4 || (W_READY && AW == 4)) {  // wave-uniform
-          p[j] = combine_share(val, *reinterpret_cast<const f4*>(wp), A);
+          pj = combine_share(val, *reinterpret_cast<const f4*>(wp), A);
         } else {
-          p[j] = val[0] * splat(wp[0]);
-          if (A > 1) p[j] = f4_fma(splat(wp[1]), val[1], p[j]);
-          if (A > 2) p[j] = f4_fma(splat(wp[2]), val[2], p[j]);
+          pj = val[0] * splat(wp[0]);
+          if (A > 1) pj = f4_fma(splat(wp[1]), val[1], pj);
+          if (A > 2) pj = f4_fma(splat(wp[2]), val[2], pj);
+        }
+        if (j == 0) {
+          r = pj;
+        } else {
+          int sj = q - j * P;
+          sj = sj < 0 ? sj + S : sj;
+          r += bperm((gb + (live ? sj : q)) << 2, pj);
         }
       }
-      o[hb] = (p[0] + bperm(a1, p[1])) + (bperm(a2, p[2]) + bperm(a3, p[3]));
+      o[hb] = r;
     }
   } else
 #pragma unroll

@@ -146,20 +146,24 @@ struct FtLds {
   int off_rec, off_planes, off_rowinv, off_bases, off_wt;
   int off_col, off_rowptr, off_cnt, off_dis;   // the CSR areas of an even tile; csr_stride bytes further: those of an odd tile
   int csr_stride;
+  int off_db, off_eid, off_rowinv2;            // backward form
 };
 
-static FtLds ft_lds(const AggArgs& a, int wl_floats, int tcap, int emax, bool with_post, bool wide = false) {
-  FtLds L;
+static FtLds ft_lds(const AggArgs& a, int wl_floats, int tcap, int emax, bool with_post, bool wide = false, bool bwd = false) {
+  FtLds L = {};
   auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
   const int bias_floats = (a.H * a.Ls + 3) & ~3;
   size_t at = up16((size_t)(with_post ? 2 : 1) * bias_floats * sizeof(float));
   L.off_rec = (int)at; at += 128;
-  L.off_planes = (int)at; at += wide ? FTW_PLANES_BYTES : FT_PLANES_BYTES;
+  L.off_planes = (int)at; at += wide ? FTW_PLANES_BYTES : (bwd ? std::max(FT_PLANES_BYTES, FTB_PLANES_BYTES) : FT_PLANES_BYTES);
   L.off_rowinv = (int)at; at += wide ? up16(2 * FTW_CH * sizeof(float)) : up16(FT_PBUF * FT_CHUNK * sizeof(float));
+  if (bwd) { L.off_rowinv2 = (int)at; at += up16(2 * FT_CHUNK * sizeof(float)); }
   L.off_bases = (int)at; at += up16((size_t)(tcap + 1) * a.ldb * 4);   // (+ the all-zero row absent entries read)
   L.off_wt = (int)at; at += up16((size_t)tcap * wl_floats * 4);
+  if (bwd) { L.off_db = (int)at; at += up16((size_t)(tcap + 1) * a.ldb * 4); }   // d bases (+ a row the absent entries would address)
   const size_t csr0 = at;
   L.off_col = (int)at; at += up16((size_t)emax * 2);
+  if (bwd) { L.off_eid = (int)at; at += up16((size_t)emax * 2); }
   L.off_rowptr = (int)at; at += up16((size_t)(tcap + 1) * 4);
   L.off_cnt = (int)at; at += up16((size_t)tcap * 4);
   L.off_dis = (int)at; at += up16((size_t)tcap * 4);
@@ -330,6 +334,132 @@ int launch_fused_tile(AggArgs a, const int64_t* ptr, const int64_t* edge_ptr, in
     case 32: return launch_ft_rt<5>(a, t, need, (unsigned)grid, L.total, stream);
     default: return launch_ft_rt<6>(a, t, need, (unsigned)grid, L.total, stream);
   }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// The BACKWARD of the layer on batches of whole graphs, tile-local (fused_tile_kernel<..., MODE = 1>).  What autograd derives
+// through layers.py:89-140 / optimized_layers.py:177-210 for a PyG batch -- in the reference: the backward of two Linears, of
+// propagate's gathers and of the per-aggregator scatters -- as ONE launch per layer plus the weight gradient x^T d:
+//   x rows -> [bases | w'] on the matrix cores -> LDS (as the forward) -> CSR of the tile -> per destination row the
+//   aggregates again (with the entry attaining each maximum), d w' = <g, agg>, d agg = w' g, scattered to the sources' rows
+//   of a d bases image by LDS float atomics -> d x = [d bases | d w'] [bases_weight | comb_weight^T]^T on the matrix cores.
+// x, grad_out and the edge list in; d x and d_cat = the gradient of [bases | pre-activation weightings] out.  No CSR, no
+// transposed CSR, no `bases` / `weightings` / statistics in memory.  Envelope: the d = 128 / 64 layers (B = 4 bases of 16
+// channels, H = 4 or 8, F_in <= 128), aggregators of sum / mean / max / symnorm, no weight nonlinearity.
+// ---------------------------------------------------------------------------------------------
+// packed_t[feature tile of 16][k-step of 32][plane][lane][8]: the B operand of d x = d W^T -- lane 16 (k % 32 / 8) + f % 16 holds
+// W[f][k], k = 32 s + 8 (lane / 16) ..+7, where k runs over the LDS images' columns: [d bases 0 .. ldb) | d w' as [h][b][4]
+// (a = 0 .. A - 1 real, the rest zero).  Scale per output feature f; tail: float col_inv[128].
+__global__ void __launch_bounds__(64) ft_pack_t_kernel(const float* __restrict__ wcat, int K, int F_g, int W, int A, int ldb,
+                                                        int k2, ft_u16* __restrict__ packed) {
+  const int f = blockIdx.x;           // output feature (row of wcat), 0 .. 127
+  const int lane = threadIdx.x;
+  const int ncol = F_g + W;
+  auto src_col = [&](int k) -> int {  // image column k -> column of wcat, or -1
+    if (k < ldb) return k < F_g ? k : -1;
+    const int j = k - ldb, hb = j >> 2, aa = j & 3;
+    return (aa < A && hb * A + aa < W) ? F_g + hb * A + aa : -1;
+  };
+  unsigned amax = 0;
+  if (f < K)
+    for (int k = lane; k < k2; k += 64) {
+      const int c = src_col(k);
+      if (c >= 0) amax = max(amax, __float_as_uint(wcat[(int64_t)f * ncol + c]) & 0x7fffffffu);
+    }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) amax = max(amax, (unsigned)__shfl_xor((int)amax, d));
+  unsigned be = amax >> 23;
+  be = be > 253u ? 253u : be;
+  const float scale = __uint_as_float((254u - be) << 23);
+  const float inv = __uint_as_float(be << 23);
+  for (int k = lane; k < 192; k += 64) {
+    const int c = k < k2 ? src_col(k) : -1;
+    const float w = (f < K && c >= 0) ? wcat[(int64_t)f * ncol + c] * scale : 0.f;
+    const _Float16 h = (_Float16)w;
+    const _Float16 l = (_Float16)((w - (float)h) * 2048.f);
+    const int64_t base = ((((int64_t)(f >> 4) * 6 + (k >> 5)) * 2) * 64 + 16 * ((k & 31) >> 3) + (f & 15)) * 8 + (k & 7);
+    packed[base] = __builtin_bit_cast(ft_u16, h);
+    packed[base + 64 * 8] = __builtin_bit_cast(ft_u16, l);
+  }
+  if (lane == 0) reinterpret_cast<float*>(packed + (int64_t)8 * 6 * 2 * 64 * 8)[f] = inv;
+}
+
+bool fused_tile_bwd_shape(const AggArgs& a, int f_in) {
+  if (!ft_narrow_shape(a, f_in) || a.act != EGC_ACT_NONE) return false;
+  if (a.B != 4 || a.L != 16 || a.Ls != 16 || a.ldb != 64 || (a.H != 4 && a.H != 8)) return false;
+  for (int k = 0; k < a.A; ++k)
+    if (a.aggr[k] != EGC_AGGR_SUM && a.aggr[k] != EGC_AGGR_MEAN && a.aggr[k] != EGC_AGGR_MAX && a.aggr[k] != EGC_AGGR_SYMNORM) return false;
+  return true;
+}
+
+size_t fused_tile_bwd_pack_bytes() { return (size_t)8 * 6 * 2 * 64 * 8 * sizeof(ft_u16) + 128 * sizeof(float); }
+
+int fused_tile_bwd_pack(const AggArgs& a, const float* wcat, int f_in, void* packed, hipStream_t stream) {
+  ft_pack_t_kernel<<<128, 64, 0, stream>>>(wcat, f_in, a.B * a.Ls, a.W, a.A, a.ldb, a.ldb + a.H * a.B * 4, (ft_u16*)packed);
+  EGC_LAUNCH_CHECK("ft_pack_t_kernel");
+  return EGC_OK;
+}
+
+int fused_tile_bwd_capacity(const AggArgs& a, int f_in, int max_tile_edges) {
+  if (!fused_tile_bwd_shape(a, f_in) || max_tile_edges < 0) return 0;
+  int best = 0;
+  for (int tcap = FT_CHUNK; tcap <= FT_CHUNK * FT_RING; tcap += FT_CHUNK) {
+    if (ft_lds(a, a.H * a.B * 4, tcap, max_tile_edges, false, false, true).total <= FT_LDS_BUDGET) best = tcap; else break;
+  }
+  return best;
+}
+
+template <class C>
+static int launch_ftb_one(const AggArgs& a, const FusedTileArgs& t, unsigned grid, size_t lds, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_tile_kernel<4, 1, 0, C, 0, 1>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) { set_last_error("hipFuncSetAttribute(fused_tile_kernel, backward)", e); return EGC_ERR_HIP; }
+    attr_set = true;
+  }
+  fused_tile_kernel<4, 1, 0, C, 0, 1><<<grid, FT_THREADS, lds, stream>>>(a, t);
+  EGC_LAUNCH_CHECK("fused_tile_kernel (backward)");
+  return EGC_OK;
+}
+
+int launch_fused_tile_bwd(AggArgs a, const int64_t* ptr, const int64_t* edge_ptr, int64_t n_graphs, const int64_t* src,
+                          const int64_t* dst, int64_t n_edges, const int* max_index, const float* x, int f_in, const void* packed,
+                          const void* packed_t, const float* grad_out, float* d_x, float* d_cat, int ld_dcat, int tcap, int emax,
+                          int32_t* status, int32_t* host_flag, hipStream_t stream) {
+  if (!fused_tile_bwd_shape(a, f_in)) return EGC_ERR_UNSUPPORTED;
+  a.lanes_pb = a.Ls / 4;
+  a.magic_P = (unsigned)(((uint64_t)1 << 32) / (uint64_t)a.lanes_pb) + 1u;
+  a.lpb_log2 = 2;
+  a.need_mean = a.need_var = 0;
+  for (int k = 0; k < a.A; ++k)
+    if (a.aggr[k] == EGC_AGGR_MEAN) a.need_mean = 1;
+  a.w_lds_stride = 0;
+  a.bias_lds_floats = (a.H * a.Ls + 3) & ~3;
+  a.lds_floats_per_wave = 0;
+  a.w_aw = 4;
+  FusedTileArgs t = {};
+  t.ptr = ptr; t.edge_ptr = edge_ptr; t.n_graphs = n_graphs; t.src = src; t.dst = dst; t.n_edges = n_edges;
+  t.max_index = max_index; t.status = status; t.host_flag = host_flag; t.x = x; t.packed = (const ft_u16*)packed;
+  t.F_in = f_in;
+  t.n_ct = (a.ldb + a.W + 15) / 16;
+  t.tcap = tcap; t.emax = emax;
+  t.w_aw = 4;
+  t.wl_floats = a.H * a.B * 4;
+  t.nsets = 1;
+  t.grad_out = grad_out; t.d_x = d_x; t.d_cat = d_cat; t.ld_dcat = ld_dcat; t.packed_t = (const ft_u16*)packed_t;
+  if (tcap < FT_CHUNK || tcap > FT_CHUNK * FT_RING || (tcap % FT_CHUNK) != 0 || emax < 0 || emax > 65536) return EGC_ERR_INVALID;
+  const FtLds L = ft_lds(a, t.wl_floats, tcap, emax, false, false, true);
+  if (L.total > FT_LDS_BUDGET) return EGC_ERR_UNSUPPORTED;
+  t.off_rec = L.off_rec; t.off_planes = L.off_planes; t.off_rowinv = L.off_rowinv; t.off_bases = L.off_bases; t.off_wt = L.off_wt;
+  t.off_col = L.off_col; t.off_rowptr = L.off_rowptr; t.off_cnt = L.off_cnt; t.off_dis = L.off_dis; t.csr_stride = L.csr_stride;
+  t.off_db = L.off_db; t.off_eid = L.off_eid; t.off_rowinv2 = L.off_rowinv2;
+  int64_t grid = 256;
+  if (const char* e = getenv("EGC_FT_GRID")) grid = std::max(1, atoi(e));
+  grid = std::min<int64_t>(grid, std::max<int64_t>(1, n_graphs));
+  grid = std::min<int64_t>(grid, std::max<int64_t>(1, (int64_t)a.n_nodes / 16));
+  return launch_ftb_one<RtCfg>(a, t, (unsigned)grid, L.total, stream);
 }
 
 }  // namespace egc

@@ -33,6 +33,11 @@ constexpr int FT_NV = FT_MFMA_WAVES * 16;
 constexpr int FT_PLANE_BYTES = FT_CHUNK * FT_KP * 2;     // one plane of one chunk
 constexpr int FT_PBUF = 3;                                // chunk buffers: the helpers stage two chunks ahead of the workers' MFMAs
 constexpr int FT_PLANES_BYTES = FT_PBUF * 2 * FT_PLANE_BYTES;  // [3 buffers][2 planes]
+// The backward form's second GEMM: d rows of K2 = ldb + H B 4 <= 192 columns as two fp16 planes, rows padded by 16 bytes
+constexpr int FTB_ROW_BYTES = 192 * 2 + 16;                // (25 sixteen-byte pieces: conflict-free A-operand reads)
+constexpr int FTB_PLANE_BYTES = FT_CHUNK * FTB_ROW_BYTES;  // one plane of one 16-row chunk
+constexpr int FTB_PBUF_BYTES = 2 * FTB_PLANE_BYTES;        // [2 planes]
+constexpr int FTB_PLANES_BYTES = 2 * FTB_PBUF_BYTES;       // [2 buffers]: 25,600 bytes (the first GEMM's three buffers take 24,576)
 // The WIDE form (egc_fused_tile_wide.hip: 128 < F_in <= 320 or more than 192 virtual columns -- the reference's 168 / 224 / 296 /
 // 300 / 304-wide batched nets, run_pretrained.sh:7-48): 32-row GEMM chunks on v_mfma_f32_32x32x16_f16, one 32-column tile per
 // worker (at most 12: 384 virtual columns), the weight fragments streamed from L2 per k-step (a 320 x 384 operand does not fit the
@@ -83,6 +88,15 @@ struct FusedTileArgs {
   int w_aw;                  // floats per (h, b) block of a weightings row in LDS: 4 for A >= 3, else A
   int nsets, p0;             // rows of more than 64 slots: two passes, the first over p0 = ceil(P / 2) slots of every basis
   unsigned magic0, magic1;   // floor(2^32 / p0) + 1, floor(2^32 / (P - p0)) + 1
+  // backward form only (MODE == 1: fused_tile_bwd, egc_fused_tile_bwd.hip)
+  const float* grad_out;     // [n_nodes, F_out]
+  float* d_x;                // [n_nodes, F_in]
+  float* d_cat;              // [n_nodes, ld_dcat]: the gradient of [bases | pre-activation weightings] (what x^T d needs), or nullptr
+  int ld_dcat;
+  const ft_u16* packed_t;    // [8][6][2][64][8] fp16 fragments of [bases_weight | comb_weight^T]^T, float col_inv[128]
+  int off_db;                // LDS: d bases image [tcap][ldb]
+  int off_eid;               // LDS, per CSR set: input position (inside the tile's edge range) of every CSR entry, 16 bit
+  int off_rowinv2;           // LDS: row scales of the staged d chunks [2][16]
 };
 
 // first index i in [0, n) with arr[i] >= key (n if none), by HALF a wavefront (lanes [32 h, 32 h + 32) share `key`), as
@@ -152,8 +166,11 @@ __device__ inline unsigned ft_row_amax(const f4 v) {
   return max(a, (unsigned)__builtin_amdgcn_ds_swizzle((int)a, 0x401F));                 // lane ^ 16
 }
 
-template <int LPR_LOG2, int HPB, int NEED, class C, int WIDE = 0>
+// MODE 1 (WIDE == 0 only): the BACKWARD of the layer on the same tiles -- x, grad_out and the edge list in, d x and the
+// gradient of [bases | weightings] out (egc_fused_tile_bwd.hip has the description).
+template <int LPR_LOG2, int HPB, int NEED, class C, int WIDE = 0, int MODE = 0>
 __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, FusedTileArgs t) {
+  static_assert(MODE == 0 || WIDE == 0, "the backward form is built on the register-stationary GEMM");
   constexpr int LPR = 1 << LPR_LOG2, G = 64 / LPR;
   extern __shared__ float smem[];
   const int tid = threadIdx.x;
@@ -478,6 +495,7 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
     auto csr_s3 = [&](const Tile& r, int set, const unsigned (&epk)[KEEP]) {
       char* cb = base + set * t.csr_stride;
       unsigned short* col = reinterpret_cast<unsigned short*>(cb + t.off_col);
+      unsigned short* eid = reinterpret_cast<unsigned short*>(cb + t.off_eid);     // (MODE 1: the entries' input positions)
       const int* rowptr = reinterpret_cast<const int*>(cb + t.off_rowptr);
       int* cnt = reinterpret_cast<int*>(cb + t.off_cnt);
       const int T = r.ok ? r.T : 0, Et = r.ok ? r.Et : 0;
@@ -493,7 +511,11 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       }
 #pragma unroll
       for (int j = 0; j < KEEP; ++j)
-        if (epk[j] != NO_EDGE) col[pos[j] + old[j] - 1] = (unsigned short)(epk[j] & 0xffffu);
+        if (epk[j] != NO_EDGE) {
+          col[pos[j] + old[j] - 1] = (unsigned short)(epk[j] & 0xffffu);
+          // (edge 2 ht + (j & 1) of batch j / 2 of 2 x CT edges: csr_s0's order)
+          if constexpr (MODE == 1) eid[pos[j] + old[j] - 1] = (unsigned short)((j >> 1) * 2 * CT + 2 * ht + (j & 1));
+        }
       if (Et > KEEP * CT) {      // (larger tiles: the rest of their edges a second time, from L2)
         const __amdgpu_buffer_rsrc_t es = edge_rsrc(r, t.src), ed = edge_rsrc(r, t.dst);
         for (int i0 = KEEP * CT; i0 < Et; i0 += 4 * CT) {
@@ -507,8 +529,11 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
           for (int j = 0; j < 4; ++j) {
             if (i0 + j * CT + ht < Et) {
               unsigned sl, dl;
-              if (local_ids(s4[j], d4[j], r.n0, T, sl, dl))
-                col[rowptr[dl] + atomicSub(&cnt[dl], 1) - 1] = (unsigned short)sl;
+              if (local_ids(s4[j], d4[j], r.n0, T, sl, dl)) {
+                const int ps = rowptr[dl] + atomicSub(&cnt[dl], 1) - 1;
+                col[ps] = (unsigned short)sl;
+                if constexpr (MODE == 1) eid[ps] = (unsigned short)(i0 + j * CT + ht);
+              }
             }
           }
         }
@@ -689,9 +714,84 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
 #ifdef EGC_FT_STAMPS
       FT_HSTAMP(2, wave == FT_FIRST_HELPER)
 #endif
-      stage01(nxt);
-      __builtin_amdgcn_s_setprio(0);
-      lds_barrier();                                   // (end of tile)
+      if constexpr (MODE == 0) {
+        stage01(nxt);
+        __builtin_amdgcn_s_setprio(0);
+        lds_barrier();                                   // (end of tile)
+      } else {
+        // ---- backward: the rows pass has left d bases [T][ldb] and d weightings [T][H B 4] in the LDS images.  Their rows
+        //      are staged for the second GEMM (d x = [d bases | d weightings] [bases_weight | comb_weight^T]^T) exactly as x
+        //      was for the first -- row scale, two fp16 planes, one 16-row chunk ahead of the MFMAs -- by 16 threads per row
+        //      (thread j: the row's 16-byte pieces j, j + 16, j + 32), and leave for memory as d_cat on the way (the weight
+        //      gradient x^T d is a launch of its own).
+        __builtin_amdgcn_s_setprio(0);
+        lds_barrier();                                   // (B1: the rows pass is done)
+        const int drow = ht >> 4, dj = ht & 15;
+        const int np2 = (a.ldb + t.wl_floats) >> 6;      // pieces per thread: 2 (H = 4) or 3 (H = 8)
+        auto stage_d = [&](int c, int buf) {
+          const int r = FT_CHUNK * c + drow;
+          f4 pc[3];
+          pc[0] = *reinterpret_cast<const f4*>(base + t.off_db + (r * a.ldb + 4 * dj) * 4);
+          pc[1] = *reinterpret_cast<const f4*>(base + t.off_wt + (r * t.wl_floats + 4 * dj) * 4);
+          pc[2] = np2 > 2 ? *reinterpret_cast<const f4*>(base + t.off_wt + (r * t.wl_floats + 64 + 4 * dj) * 4) : f4{0.f, 0.f, 0.f, 0.f};
+          float m = 0.f;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) m = fmaxf(fmaxf(fmaxf(m, fabsf(pc[i].x)), fmaxf(fabsf(pc[i].y), fabsf(pc[i].z))), fabsf(pc[i].w));
+          unsigned am = __float_as_uint(m);
+          am = max(am, (unsigned)__builtin_amdgcn_update_dpp(0, (int)am, 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+          am = max(am, (unsigned)__builtin_amdgcn_update_dpp(0, (int)am, 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+          am = max(am, (unsigned)__builtin_amdgcn_update_dpp(0, (int)am, 0x141, 0xf, 0xf, true));  // row_half_mirror
+          am = max(am, (unsigned)__builtin_amdgcn_update_dpp(0, (int)am, 0x140, 0xf, 0xf, true));  // row_mirror
+          unsigned e = am & 0x7f800000u;
+          e = min(max(e, 13u << 23), 253u << 23);
+          const float sc = __uint_as_float(0x7f000000u - e), sc2k = __uint_as_float(0x7f000000u + (11u << 23) - e);
+          char* dst0 = lds_planes + buf * FTB_PBUF_BYTES + drow * FTB_ROW_BYTES + 8 * dj;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            if (i < np2) {
+              const f4 v = pc[i];
+              const ft_h2 h01 = __builtin_convertvector(ft_f2{v.x * sc, v.y * sc}, ft_h2);
+              const ft_h2 h23 = __builtin_convertvector(ft_f2{v.z * sc, v.w * sc}, ft_h2);
+              ft_h2 l01, l23;
+              l01[0] = (_Float16)__builtin_fmaf((float)h01[0], -2048.f, v.x * sc2k);
+              l01[1] = (_Float16)__builtin_fmaf((float)h01[1], -2048.f, v.y * sc2k);
+              l23[0] = (_Float16)__builtin_fmaf((float)h23[0], -2048.f, v.z * sc2k);
+              l23[1] = (_Float16)__builtin_fmaf((float)h23[1], -2048.f, v.w * sc2k);
+              char* dstp = dst0 + 128 * i;
+              *reinterpret_cast<ft_u2*>(dstp) = ft_u2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
+              *reinterpret_cast<ft_u2*>(dstp + FTB_PLANE_BYTES) = ft_u2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
+            }
+          }
+          reinterpret_cast<float*>(base + t.off_rowinv2)[buf * FT_CHUNK + drow] = __uint_as_float(e);
+          // d_cat [n_nodes][ld_dcat] = [d bases (ldb) | d weightings in the layer's column order (h B + b) A + a]
+          if (t.d_cat != nullptr && r < cur.T) {
+            float* dc = t.d_cat + (int64_t)(cur.n0 + r) * t.ld_dcat;
+            __builtin_nontemporal_store(pc[0], reinterpret_cast<f4*>(dc + 4 * dj));
+            const int A = C::A(a);
+            if (A == 4) {
+              __builtin_nontemporal_store(pc[1], reinterpret_cast<f4*>(dc + a.ldb + 4 * dj));
+              if (np2 > 2) __builtin_nontemporal_store(pc[2], reinterpret_cast<f4*>(dc + a.ldb + 64 + 4 * dj));
+            } else {
+#pragma unroll
+              for (int i = 1; i < 3; ++i) {
+                if (i < np2) {
+                  float* dw = dc + a.ldb + (dj + 16 * (i - 1)) * A;      // block (h, b) = dj + 16 (i - 1)
+                  dw[0] = pc[i].x;
+                  if (A > 1) dw[1] = pc[i].y;
+                  if (A > 2) dw[2] = pc[i].z;
+                }
+              }
+            }
+          }
+        };
+        if (cur.nch > 0) stage_d(0, 0);
+        lds_barrier();                                   // (A: chunk 0 of d staged)
+        for (int c = 0; c < cur.nch; ++c) {
+          if (c + 1 < cur.nch) stage_d(c + 1, (c + 1) & 1);
+          lds_barrier();
+        }
+        stage01(nxt);
+      }
     }
     return;
     } else {
@@ -780,6 +880,9 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
           char* dstp = dst0 + 64 * ii;
           *reinterpret_cast<ft_u2*>(dstp) = ft_u2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
           *reinterpret_cast<ft_u2*>(dstp + FTW_PLANE_BYTES) = ft_u2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
+          // (one piece at a time: interleaved, the four pieces' temporaries were a register too many next to the chunks in
+          // flight -- one spilled dword, reloaded inside the GEMM steps with a vmcnt(0) that also waited for the rows just requested)
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     };
@@ -839,13 +942,23 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
           if (c & 1) {      // chunk c lives in xb, chunk c + 1 in xa
             if (work && sl + 1 < NS) split_slab(xb, sl + 1, e_cur, qn);                     // the chunk's next slab ...
             if (work && sl + 1 == NS && c + 1 < cur.nch) start_chunk(xa, c + 1, qn);        // ... or the next chunk's first
+#ifdef EGC_FT_STAMPS
+            if (!(t.dbg & 8))        // (diagnostic build: EGC_FT_DBG bit 3 = no requests inside the GEMM steps)
+#endif
+            {
             if (NS >= 2 && sl + 2 == NS) request(xb, rsc, c + 2);                           // the chunk's last slab has left its registers
             if (NS == 1) request(xa, rsc, c + 3);
+            }
           } else {
             if (work && sl + 1 < NS) split_slab(xa, sl + 1, e_cur, qn);
             if (work && sl + 1 == NS && c + 1 < cur.nch) start_chunk(xb, c + 1, qn);
+#ifdef EGC_FT_STAMPS
+            if (!(t.dbg & 8))
+#endif
+            {
             if (NS >= 2 && sl + 2 == NS) request(xa, rsc, c + 2);
             if (NS == 1) request(xb, rsc, c + 3);
+            }
           }
           if (on) {
             lds_barrier();
@@ -991,6 +1104,10 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
     if constexpr (WIDE == 0) asm volatile("" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]), "+v"(u[6]), "+v"(u[7]));
     lds_barrier();       // chunk 0 is staged, the tile's CSR complete, the row counter zero
     FT_STAMP(0)
+    if constexpr (MODE == 1) {   // d bases of the tile: zero (the rows pass adds into it; the GEMM steps' barriers stand in between)
+      f4* db4 = reinterpret_cast<f4*>(base + t.off_db);
+      for (int i = tid; i < T * ldb4; i += FT_WORKER_THREADS) db4[i] = f4{0.f, 0.f, 0.f, 0.f};
+    }
 
     // ---- (G) [bases | weightings] of the tile, 16 rows per step.  The A fragments of a chunk are read in two halves: k-steps
     //      2, 3 at the start of its step (the MFMAs of k-steps 0, 1 run meanwhile), k-steps 0, 1 at the END OF THE STEP BEFORE
@@ -1144,6 +1261,9 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
             pa = lds_planes + qb * FTW_PBUF_BYTES + l31 * (FTW_LDX * 2) + hh * 16;
           }
         }
+#ifdef EGC_FT_STAMPS
+        if (!(t.dbg & 16))           // (diagnostic build: EGC_FT_DBG bit 4 = no D-tile epilogue)
+#endif
         {
           // D: lane -> column 32 wave + lane % 32, rows 8 j + 4 (lane / 32) + i.  2^ex 2^ew (acc0 + 2^-11 acc1) + bias
           const float* rinv = lds_rowinv + (c & 1) * FTW_CH + 4 * hh;
@@ -1179,6 +1299,7 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
 
     // ---- (E) rows: one lane group per row, G rows per wavefront and turn (turns handed out by an LDS counter: a wavefront
     //      whose rows are short takes the next ones), everything from LDS ----
+    if constexpr (MODE == 0) {
 #ifdef EGC_FT_STAMPS
     if (!(t.dbg & 4))
 #endif
@@ -1288,9 +1409,240 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
                                                                  true, lds_wt + (row_ok ? r : 0) * t.wl_floats, lds_bias, lds_scale);
       }
     }
+    } else {
+    // ---- (E, backward) rows: one lane group per DESTINATION row, as the forward -- the row's aggregates are formed again from
+    //      the LDS image (with the source and the input position of the entry attaining each maximum), then, head by head,
+    //      d agg[t] += w'[h][b][t] g[h] and d w'[h][b][t] = <g[h], agg[t]> (reduced over the four lanes of a basis and written
+    //      over w' in the image), and the row's gradients travel to its SOURCES' rows of the d bases image by LDS float
+    //      atomics: sum / mean / symnorm along every entry, max to the one entry that attained it.  (B = 4 bases of 16
+    //      channels: 16 slots, four lanes per basis; aggregators sum / mean / max / symnorm; no weight nonlinearity.)
+    const unsigned short* lds_eid = reinterpret_cast<const unsigned short*>(cb + t.off_eid);
+    float* lds_db = reinterpret_cast<float*>(base + t.off_db);
+    const __amdgpu_buffer_rsrc_t rgo =
+        __builtin_amdgcn_make_buffer_rsrc((void*)t.grad_out, 0, (unsigned)a.n_nodes * (unsigned)F_out * 4u, 0x00020000);
+    const int bq = q >> 2, l4 = q & 3;
+    const int A = C::A(a), H = C::H(a);
+    constexpr int SELF_POS = 0x10000;         // the appended self loop: behind every edge of the tile (16-bit positions)
+    for (; cur.ok;) {
+      int r0 = 0;
+      if (lane == 0) r0 = __hip_atomic_fetch_add(lds_rowctr, G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      r0 = __builtin_amdgcn_readfirstlane(r0);
+      if (r0 >= T) break;
+      const int r = r0 + g;
+      const bool row_ok = r < T;
+      const int row = n0 + (row_ok ? r : 0);
+      // the row's g, eight heads x 16 bytes per lane (lane (b, l4): channels 4 l4 ..+3 of every head): requested first
+      f4 gv[8];
+#pragma unroll
+      for (int h = 0; h < 8; ++h)
+        gv[h] = load_slot(rgo, (row_ok && h < H) ? ((unsigned)row * (unsigned)F_out + (unsigned)(h * 16 + 4 * l4)) * 4u : OOB);
+      const int start = row_ok ? lds_rowptr[r] : 0;
+      const int nd = row_ok ? lds_rowptr[r + 1] - start : 0;
+      int maxd = nd;
+#pragma unroll
+      for (int off = LPR; off < 64; off <<= 1) maxd = max(maxd, bperm((lane ^ off) << 2, maxd));
+      maxd = __builtin_amdgcn_readfirstlane(maxd);
+      const float dis_i = (want_dis && row_ok) ? lds_dis[r] : 0.f;
+      const bool has_self = row_ok && (C::loops_all(a) || row <= max_index);
+      f4 vself = f4{0.f, 0.f, 0.f, 0.f};
+      if (looped_any && has_self) vself = lds_bases4[r * ldb4 + q];
+      f4 sum = f4{0.f, 0.f, 0.f, 0.f}, ws = sum, mx = f4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      i4 ax = i4{ARG_NONE, ARG_NONE, ARG_NONE, ARG_NONE}, aj = i4{-1, -1, -1, -1};
+      auto take = [&](f4 v, int pos, int j) {     // (value, input position) lexicographic: the FIRST entry attaining the maximum
+        const bool cx = v.x > mx.x || (v.x == mx.x && pos < ax.x), cy = v.y > mx.y || (v.y == mx.y && pos < ax.y);
+        const bool cz = v.z > mx.z || (v.z == mx.z && pos < ax.z), cw = v.w > mx.w || (v.w == mx.w && pos < ax.w);
+        mx = f4{cx ? v.x : mx.x, cy ? v.y : mx.y, cz ? v.z : mx.z, cw ? v.w : mx.w};
+        ax = i4{cx ? pos : ax.x, cy ? pos : ax.y, cz ? pos : ax.z, cw ? pos : ax.w};
+        aj = i4{cx ? j : aj.x, cy ? j : aj.y, cz ? j : aj.z, cw ? j : aj.w};
+      };
+      int nself = 0;
+      for (int ts = 0; ts < maxd; ts += LPR) {
+        const bool pv = ts + q < nd;
+        const int jj = pv ? (int)lds_col[start + ts + q] : 0;
+        const int ee = pv ? (int)lds_eid[start + ts + q] : 0;
+        const bool self_e = pv && jj == r;
+        float dd = (pv && want_dis) ? lds_dis[jj] * dis_i : 0.f;
+        if (C::yl(a) && !C::xl(a)) dd = self_e ? 0.f : dd;
+        if (looped_any) {
+          const unsigned long long sb = __ballot(self_e);
+          nself += __popcll((sb >> (g << LPR_LOG2)) & ((LPR == 64) ? ~0ull : ((1ull << LPR) - 1ull)));
+        }
+        const int jx = (pv && !(C::xl(a) && self_e)) ? jj : zrow;
+        const int cnt_e = min(LPR, maxd - ts);
+        for (int t0 = 0; t0 < cnt_e; t0 += FU) {
+          f4 v[FU];
+          float w[FU];
+          int jn[FU], en[FU];
+#pragma unroll
+          for (int uu = 0; uu < FU; ++uu) {
+            const int addr = grp_addr + ((t0 + uu) << 2);
+            jn[uu] = bperm(addr, jx);
+            en[uu] = bperm(addr, ee);
+            v[uu] = *reinterpret_cast<const f4*>(bases_q + __umul24((unsigned)jn[uu], ldb_bytes));
+            w[uu] = bperm(addr, dd);
+          }
+#pragma unroll
+          for (int uu = 0; uu < FU; ++uu) {
+            sum += v[uu];
+            ws = f4_fma(splat(w[uu]), v[uu], ws);
+            if (jn[uu] != zrow) take(v[uu], en[uu], jn[uu]);
+          }
+        }
+      }
+      // the self-loop term, as finish_group
+      int cnt = nd;
+      if (C::xl(a)) {
+        cnt = nd - nself + (has_self ? 1 : 0);
+        sum += vself;                                          // (0 where the row has no self loop)
+        ws = f4_fma(splat(dis_i * dis_i), vself, ws);
+        if (has_self) take(vself, SELF_POS, r);
+      } else if (C::yl(a)) {
+        ws = f4_fma(splat(dis_i * dis_i), vself, ws);
+      }
+      const float rcnt = __builtin_amdgcn_rcpf((float)max(cnt, 1));
+      const bool nonempty = cnt > 0;
+      const f4 zero4 = f4{0.f, 0.f, 0.f, 0.f};
+      f4 val[4], dagg[4];
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        val[tt] = dagg[tt] = zero4;
+        if (tt < A) {
+          switch (C::aggr(a, tt)) {
+            case EGC_AGGR_SUM: val[tt] = sum; break;
+            case EGC_AGGR_MEAN: val[tt] = sum * splat(rcnt); break;
+            case EGC_AGGR_MAX: val[tt] = nonempty ? mx : zero4; break;
+            default: val[tt] = ws; break;      // EGC_AGGR_SYMNORM
+          }
+        }
+      }
+      // head by head: d agg, d w'
+      float* wrow = lds_wt + (row_ok ? r : 0) * t.wl_floats;
+#pragma unroll
+      for (int h = 0; h < 8; ++h) {
+        if (h < H) {
+          const f4 wv = *reinterpret_cast<const f4*>(wrow + (h * 4 + bq) * 4);
+          dagg[0] = f4_fma(splat(wv.x), gv[h], dagg[0]);
+          if (A > 1) dagg[1] = f4_fma(splat(wv.y), gv[h], dagg[1]);
+          if (A > 2) dagg[2] = f4_fma(splat(wv.z), gv[h], dagg[2]);
+          if (A > 3) dagg[3] = f4_fma(splat(wv.w), gv[h], dagg[3]);
+          float dw[4];
+#pragma unroll
+          for (int tt = 0; tt < 4; ++tt) {
+            float d = tt < A ? fmaf(gv[h].w, val[tt].w, fmaf(gv[h].z, val[tt].z, fmaf(gv[h].y, val[tt].y, gv[h].x * val[tt].x))) : 0.f;
+            d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+            d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+            dw[tt] = d;
+          }
+          // (the four lanes of the basis have read w'[h][b][.]: in-order LDS, the block can be overwritten)
+          if (row_ok && l4 == (h & 3)) *reinterpret_cast<f4*>(wrow + (h * 4 + bq) * 4) = f4{dw[0], dw[1], dw[2], dw[3]};
+        }
+      }
+      // the source side: d bases[j] += (sum / mean part) + weight x (symnorm part) along every entry; the maximum's to its entry
+      f4 d_t = zero4, d_s = zero4, d_x = zero4;
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        if (tt < A) {
+          switch (C::aggr(a, tt)) {
+            case EGC_AGGR_SUM: d_t += dagg[tt]; break;
+            case EGC_AGGR_MEAN: d_t += dagg[tt] * splat(rcnt); break;
+            case EGC_AGGR_MAX: d_x += nonempty ? dagg[tt] : zero4; break;
+            default: d_s += dagg[tt]; break;
+          }
+        }
+      }
+      auto add_row = [&](int j, f4 c) {
+        float* p = lds_db + j * a.ldb + 4 * q;
+        atomicAdd(p, c.x); atomicAdd(p + 1, c.y); atomicAdd(p + 2, c.z); atomicAdd(p + 3, c.w);
+      };
+      for (int ts = 0; ts < maxd; ts += LPR) {
+        const bool pv = ts + q < nd;
+        const int jj = pv ? (int)lds_col[start + ts + q] : 0;
+        const bool self_e = pv && jj == r;
+        float dd = (pv && want_dis) ? lds_dis[jj] * dis_i : 0.f;
+        if (C::yl(a) && !C::xl(a)) dd = self_e ? 0.f : dd;
+        const int jx = (pv && !(C::xl(a) && self_e)) ? jj : zrow;
+        const int cnt_e = min(LPR, maxd - ts);
+        for (int e0 = 0; e0 < cnt_e; ++e0) {
+          const int addr = grp_addr + (e0 << 2);
+          const int j = bperm(addr, jx);
+          const float w = bperm(addr, dd);
+          if (j != zrow) add_row(j, f4_fma(splat(w), d_s, d_t));
+        }
+      }
+      if (row_ok) {
+        if (C::xl(a)) { if (has_self) add_row(r, f4_fma(splat(dis_i * dis_i), d_s, d_t)); }
+        else if (C::yl(a) && has_self) add_row(r, d_s * splat(dis_i * dis_i));
+        if (nonempty) {
+          if (aj.x >= 0) atomicAdd(lds_db + aj.x * a.ldb + 4 * q, d_x.x);
+          if (aj.y >= 0) atomicAdd(lds_db + aj.y * a.ldb + 4 * q + 1, d_x.y);
+          if (aj.z >= 0) atomicAdd(lds_db + aj.z * a.ldb + 4 * q + 2, d_x.z);
+          if (aj.w >= 0) atomicAdd(lds_db + aj.w * a.ldb + 4 * q + 3, d_x.w);
+        }
+      }
+    }
+    }
     FT_STAMP(5)
-    request_weights();
-    lds_barrier();   // every wavefront is done with the tile's LDS image
+    if constexpr (MODE == 0) {
+      request_weights();
+      lds_barrier();   // every wavefront is done with the tile's LDS image
+    } else {
+      // ---- (G2, backward) d x [T][F_in] = [d bases | d w'] [T][K2] x [bases_weight | comb_weight^T]^T [K2][F_in]: the helpers stage
+      //      the rows of the two images as fp16 planes (above), wavefront w < F_in / 16 keeps the 16 output features 16 w ..+15
+      //      of the transposed operand (K2 / 32 k-steps x two planes: 48 registers at K2 = 192); three products, the D tile
+      //      scaled and stored straight to d_x (lane -> feature lane % 16, rows 4 (lane / 16) + i).
+      const int n_ft = (t.F_in + 15) >> 4;
+      const int K2S = (a.ldb + t.wl_floats) >> 5;          // k-steps of 32: 4 (H = 4) or 6 (H = 8)
+      const bool is_mfma2 = wave < n_ft;
+      f4 u2[12];
+      float col_inv2 = 0.f;
+      {
+        int lv = lane;
+        asm volatile("" : "+v"(lv));
+        const f4* wsrc = reinterpret_cast<const f4*>(t.packed_t) + (int64_t)(is_mfma2 ? wave : 0) * 12 * 64;
+#pragma unroll
+        for (int k2 = 0; k2 < 12; ++k2) u2[k2] = wsrc[k2 * 64 + lv];
+        col_inv2 = reinterpret_cast<const float*>(t.packed_t + (int64_t)8 * 6 * 2 * 64 * 8)[16 * (is_mfma2 ? wave : 0) + (lv & 15)];
+      }
+      lds_barrier();   // (B1: every row's d bases / d w' are in the images)
+      lds_barrier();   // (A: the helpers have staged chunk 0)
+      const __amdgpu_buffer_rsrc_t rdx = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(t.d_x + (int64_t)n0 * t.F_in), 0, (unsigned)(cur.ok ? T : 0) * (unsigned)t.F_in * 4u, 0x00020000);
+      int lvm = lane;
+      asm volatile("" : "+v"(lvm));
+      const int m2 = lvm & 15, qd2 = lvm >> 4;
+      int buf2 = 0;
+      for (int c = 0; c < nch; ++c) {
+        if (is_mfma2) {
+          const char* pa = lds_planes + buf2 * FTB_PBUF_BYTES + m2 * FTB_ROW_BYTES + qd2 * 16;
+          f4 acc0 = f4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0;
+#pragma unroll
+          for (int k2 = 0; k2 < 6; ++k2) {
+            if (k2 < K2S) {
+              const ft_h8 xh = *reinterpret_cast<const ft_h8*>(pa + k2 * 64);
+              const ft_h8 xl = *reinterpret_cast<const ft_h8*>(pa + k2 * 64 + FTB_PLANE_BYTES);
+              const ft_h8 wh = __builtin_bit_cast(ft_h8, u2[2 * k2]), wl = __builtin_bit_cast(ft_h8, u2[2 * k2 + 1]);
+              acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wh, acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, wh, acc1, 0, 0, 0);
+              acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wl, acc2, 0, 0, 0);
+            }
+          }
+          const f4 ri = *reinterpret_cast<const f4*>(reinterpret_cast<const float*>(base + t.off_rowinv2) + buf2 * FT_CHUNK + 4 * qd2);
+          const f4 tt4 = acc1 + acc2;
+          const f4 o = f4{__builtin_fmaf(tt4.x, 1.f / 2048.f, acc0.x) * (col_inv2 * ri.x), __builtin_fmaf(tt4.y, 1.f / 2048.f, acc0.y) * (col_inv2 * ri.y),
+                          __builtin_fmaf(tt4.z, 1.f / 2048.f, acc0.z) * (col_inv2 * ri.z), __builtin_fmaf(tt4.w, 1.f / 2048.f, acc0.w) * (col_inv2 * ri.w)};
+          const int f = 16 * wave + m2;
+          const unsigned off0 = f < t.F_in ? ((unsigned)(FT_CHUNK * c + 4 * qd2) * (unsigned)t.F_in + (unsigned)f) * 4u : OOB;
+          const unsigned rs4 = (unsigned)t.F_in * 4u;
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o.x), rdx, off0, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o.y), rdx, off0 == OOB ? OOB : off0 + rs4, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o.z), rdx, off0 == OOB ? OOB : off0 + 2 * rs4, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o.w), rdx, off0 == OOB ? OOB : off0 + 3 * rs4, 0, 0);
+        }
+        buf2 ^= 1;
+        lds_barrier();
+      }
+      request_weights();
+    }
     FT_STAMP(6)
   }
 #ifdef EGC_FT_STAMPS

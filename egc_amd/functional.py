@@ -394,7 +394,7 @@ def _batch_fused_setup(gb: GraphBatch, spec: LayerSpec, post, wcat, x=None):
     return gb.fused_setup(spec.c, post is not None and post.scale is not None)
 
 
-def egc_layer_forward_batch_fused(gb: GraphBatch, spec: LayerSpec, x, wcat, bcat, bias, post, setup):
+def egc_layer_forward_batch_fused(gb: GraphBatch, spec: LayerSpec, x, wcat, bcat, bias, post, setup, packed=None):
     """The whole layer on a batch of whole graphs in ONE launch (egc_layer_forward_batch_fused_f32): plan, basis transform +
     weightings on the matrix cores, the tiles' CSR, aggregation and combine -- x and the edge list in, out out."""
     lib = _C.load()
@@ -406,7 +406,8 @@ def egc_layer_forward_batch_fused(gb: GraphBatch, spec: LayerSpec, x, wcat, bcat
     if dev != gb.device:
         raise RuntimeError(f"egc_amd: x is on {dev} but the batch is on {gb.device}")
     x = x.contiguous()
-    packed = _batch_fused_pack(spec, wcat, bcat)
+    if packed is None:
+        packed = _batch_fused_pack(spec, wcat, bcat)
     with _device_guard(dev):
         out = torch.empty((n, spec.f_out), dtype=torch.float32, device=dev)
         keep = []
@@ -429,6 +430,99 @@ def egc_layer_forward_batch_fused(gb: GraphBatch, spec: LayerSpec, x, wcat, bcat
             out.data_ptr(), tile_nodes, emax, gb.status().data_ptr(), _IndexFlag.ptr(), _stream_ptr(dev)),
             "egc_layer_forward_batch_fused_f32")
     return out
+
+
+def _batch_fused_train_setup(gb: GraphBatch, spec: LayerSpec, x):
+    """((tile_nodes, emax) of the forward launch, (tile_nodes, emax) of the backward launch) when a TRAINING call of this layer on
+    this batch can run as one launch each way (egc_layer_forward_batch_fused_f32 + egc_layer_backward_batch_fused_f32), else
+    None: the CSR path (graph build + GEMM + aggregate + three backward kernels + the dense gradients) then.
+    EGC_NO_FUSED_BWD=1 switches the path off."""
+    if (_C.env_flag("EGC_NO_FUSED_TILE") or _C.env_flag("EGC_NO_TILE") or _C.env_flag("EGC_NO_FUSED_BWD") or gemm_exact()
+            or spec.gemm_flags != 0 or os.environ.get("EGC_XT_FP32") is not None):
+        return None
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous() and x.data_ptr() % 16 == 0):
+        return None
+    bs = gb.fused_bwd_setup(spec.c)
+    if bs is None:
+        return None
+    fs = gb.fused_setup(spec.c, False)
+    return (fs, bs) if fs is not None else None
+
+
+def egc_layer_backward_batch_fused(gb: GraphBatch, spec: LayerSpec, x, wcat, packed, grad_out, setup):
+    """(d x [N, F_in], d_cat [N, ldb + W]) of one layer on a batch of whole graphs in ONE launch (egc_layer_backward_batch_fused_f32):
+    the forward's intermediates are formed again in LDS, nothing was saved but x."""
+    lib = _C.load()
+    _IndexFlag.poll()
+    n = gb.n_nodes
+    tile_nodes, emax = setup
+    dev = x.device
+    grad_out = grad_out.contiguous()
+    _check_f32(grad_out, "grad_out", (n, spec.f_out))
+    with _device_guard(dev):
+        nb = int(lib.egc_batch_fused_bwd_pack_bytes(C.byref(spec.c)))
+        if nb <= 0:
+            raise RuntimeError("egc_amd: layer outside the envelope of the one-launch backward")
+        packed_t = torch.empty(nb, dtype=torch.uint8, device=dev)
+        stream = _stream_ptr(dev)
+        _C.check(lib.egc_batch_fused_bwd_pack(C.byref(spec.c), wcat.data_ptr(), packed_t.data_ptr(), nb, stream), "egc_batch_fused_bwd_pack")
+        d_x = torch.empty((n, spec.f_in), dtype=torch.float32, device=dev)
+        d_cat = torch.empty((n, spec.ldb + spec.w_cols), dtype=torch.float32, device=dev)
+        ei = gb.edge_index
+        needs_max = not bool(spec.c.loops_all_nodes)
+        _C.check(lib.egc_layer_backward_batch_fused_f32(
+            gb.ptr.data_ptr(), gb.edge_ptr.data_ptr() if gb.edge_ptr is not None else None, gb.n_graphs, ei[0].data_ptr(),
+            ei[1].data_ptr(), gb.n_edges, n, gb.max_index().data_ptr() if needs_max else None, C.byref(spec.c), x.data_ptr(),
+            packed.data_ptr(), packed_t.data_ptr(), grad_out.data_ptr(), d_x.data_ptr(), d_cat.data_ptr(), int(d_cat.stride(0)),
+            tile_nodes, emax, gb.status().data_ptr(), _IndexFlag.ptr(), stream), "egc_layer_backward_batch_fused_f32")
+    return d_x, d_cat
+
+
+class _BatchFusedTrainFunction(torch.autograd.Function):
+    """The layer on a batch of whole graphs under autograd, one launch each way (round 5): forward = the inference launch
+    (egc_layer_forward_batch_fused_f32: nothing but x is kept), backward = egc_layer_backward_batch_fused_f32 (d x, d_cat) + the
+    weight gradient x^T d_cat with the bias sums riding along.  Same arguments and gradients as _EGCLayerParamsFunction."""
+
+    @staticmethod
+    def forward(ctx, x, bias, comb_w, comb_b, bcat_direct, gb, spec, dims, permute, setups, *bases):
+        ctx.dims, ctx.permute, ctx.packed_b = dims, permute, comb_b is not None
+        ctx.shapes = (comb_w.shape, comb_b.shape if comb_b is not None else None, [b.shape for b in bases])
+        wcat, bcat = _pack_params(dims, permute, comb_w, comb_b, bases)
+        bc = bcat if comb_b is not None else bcat_direct
+        packed = _batch_fused_pack(spec, wcat, bc)
+        out = egc_layer_forward_batch_fused(gb, spec, x, wcat, bc, bias, None, setups[0], packed=packed)
+        ctx.save_for_backward(x, wcat, packed)
+        ctx.gb, ctx.spec, ctx.bsetup = gb, spec, setups[1]
+        ctx.has_bcat, ctx.has_bias = bc is not None, bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        need = ctx.needs_input_grad
+        x, wcat, packed = ctx.saved_tensors
+        spec = ctx.spec
+        grad_out = grad_out.contiguous()
+        dx, d_cat = egc_layer_backward_batch_fused(ctx.gb, spec, x, wcat, packed, grad_out, ctx.bsetup)
+        need_w = need[2] or any(need[10:])
+        need_b = ctx.has_bcat and (need[3] if ctx.packed_b else need[4])
+        need_bias = ctx.has_bias and need[1]
+        dwcat = dbcat = dbias = None
+        if need_w:
+            if need_bias and need_b:
+                dwcat, sums, dbias = _weight_grads(x, d_cat, col_sums=True, extra=grad_out)
+            else:
+                dwcat, sums = _weight_grads(x, d_cat, col_sums=need_b)
+            dbcat = sums[d_cat.size(1) - spec.w_cols:] if need_b else None
+        elif need_b:
+            dbcat = _column_sums(d_cat[:, spec.ldb:].contiguous())
+        if need_bias and dbias is None:
+            dbias = _column_sums(grad_out)
+        dcw = dcb = None
+        dparts = [None] * len(ctx.shapes[2])
+        if need_w or (need_b and ctx.packed_b):
+            dcw, dcb, dparts = _unpack_param_grads(ctx.dims, ctx.permute, ctx.shapes, ctx.packed_b, dwcat,
+                                                   dbcat if ctx.packed_b else None)
+        return (dx if need[0] else None, dbias, dcw, dcb, None if ctx.packed_b else dbcat, None, None, None, None, None, *dparts)
 
 
 def segment_mean(x: torch.Tensor, seg_ptr: torch.Tensor) -> torch.Tensor:
@@ -1105,6 +1199,12 @@ def egc_layer_apply_params(graph, spec, x, bias, comb_w, comb_b, bcat_direct, ba
     """The training-path layer call from the module parameters (one autograd node: _EGCLayerParamsFunction).  ``bases``:
     one [f_in, B L] matrix or B [f_in, L] matrices; ``comb_b`` a combination bias to permute with the weight's rows,
     ``bcat_direct`` one already in the operand's order (pass exactly one of the two, or neither)."""
+    if isinstance(graph, GraphBatch) and spec.ldb == spec.f_g:
+        setups = _batch_fused_train_setup(graph, spec, x)
+        if setups is not None:
+            return _BatchFusedTrainFunction.apply(x, bias, comb_w, comb_b, bcat_direct, graph, spec,
+                                                  (int(f_in), int(H), int(A), int(B), int(L), int(Ls)), bool(permute_hab), setups,
+                                                  *bases)
     return _EGCLayerParamsFunction.apply(x, bias, comb_w, comb_b, bcat_direct, _as_csr(graph), spec,
                                          (int(f_in), int(H), int(A), int(B), int(L), int(Ls)), bool(permute_hab), *bases)
 

@@ -622,6 +622,35 @@ class GraphBatch:
             self._setups[key] = hit
         return hit or None
 
+    def fused_bwd_setup(self, spec_c):
+        """(tile_nodes, max_tile_edges) for egc_layer_backward_batch_fused_f32 -- the layer's backward as one tile-local launch --
+        or None when the layer is outside that kernel's envelope or the declared largest graph does not fit its LDS image
+        (which also holds the d bases rows: smaller tiles than the forward's)."""
+        key = (C.string_at(C.addressof(spec_c), C.sizeof(spec_c)), "fused_bwd")
+        hit = self._setups.get(key)
+        if hit is None:
+            gkey = key + (self.max_nodes, self.edges_per_node)
+            hit = _TILE_SETUPS.get(gkey)
+            if hit is None:
+                lib = _C.load()
+                need = -(-self.max_nodes // 16) * 16
+                hit = False
+                for emax in (4096, max(64, -(-need * self.edges_per_node // 64) * 64)):
+                    if emax > 16384:
+                        continue
+                    cap = int(lib.egc_batch_fused_bwd_tile_nodes(C.byref(spec_c), emax))
+                    if cap >= need and cap * self.edges_per_node <= emax:
+                        hit = (cap, emax)
+                        break
+                    if cap >= need and need * self.edges_per_node <= emax:
+                        hit = (need, emax)
+                        break
+                if len(_TILE_SETUPS) > 256:
+                    _TILE_SETUPS.clear()
+                _TILE_SETUPS[gkey] = hit
+            self._setups[key] = hit
+        return hit or None
+
     def plan(self, slot: int):
         """(tiles int32 [n_slots, 4], n_tiles device scalar, n_slots) for slots of `slot` nodes; one launch, built once."""
         hit = self._plans.get(slot)

@@ -563,6 +563,33 @@ int egc_layer_forward_batch_fused_f32(const int64_t* graph_ptr, const int64_t* e
                                       const egc_post* post, float* out, int32_t tile_nodes, int32_t max_tile_edges,
                                       int32_t* status, int32_t* host_flag, egc_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * The BACKWARD of egc_layer_forward_batch_fused_f32, tile-local, in ONE launch (round 5; egc_fused_tile.hip, MODE 1): what
+ * PyTorch autograd derives through the layer for a PyG batch in the reference's training loops (zinc/configs.py:53-72:
+ * loss.backward() through zinc/models.py:60-74 -> layers.py:89-140 / optimized_layers.py:177-210) -- the backward of the two
+ * Linears, of propagate's gathers and of the per-aggregator scatters -- without a CSR, a transposed CSR or any saved
+ * intermediate: per tile of whole graphs the forward's `bases` / `weightings` and aggregates are formed again in LDS,
+ * d weightings = <grad_out, aggregates>, d aggregates = weightings x grad_out travel to the sources' rows by LDS float atomics
+ * (sum / mean / symnorm along every entry, max to the FIRST entry in input order attaining it: torch_scatter's arg rule), and
+ *   d_x   [n_nodes, in_channels]  = [d bases | d weightings] [bases_weight | comb_weight^T]^T   (split-precision MFMA GEMM)
+ *   d_cat [n_nodes, ld_dcat]      = the gradient of [bases (ldb) | pre-activation weightings (H B A, column (h B + b) A + a)]
+ * leave the launch (d_cat may be NULL; the caller's weight gradient is x^T d_cat: egc_weight_grad_*).  Sums are formed by float
+ * atomics: reproducible to rounding.  Envelope (egc_batch_fused_bwd_tile_nodes > 0): B = 4 bases of 16 channels, H = 4 or 8
+ * (the d = 64 / 128 layers), F_in <= 128, aggregators of sum / mean / max / symnorm, no weight nonlinearity.
+ *   egc_batch_fused_bwd_tile_nodes   rows of a tile (its image also holds d bases: 96 - 112 at the north star), 0 = outside
+ *   egc_batch_fused_bwd_pack[_bytes] wcat -> the transposed operand's fp16 planes; once per parameter update
+ *   egc_layer_backward_batch_fused_f32   `packed` = egc_batch_fused_pack's buffer (the forward operand, for the recompute);
+ *                                    status / host_flag as the forward launch.
+ * ------------------------------------------------------------------------------------------ */
+int32_t egc_batch_fused_bwd_tile_nodes(const egc_layer* layer, int32_t max_tile_edges);
+int64_t egc_batch_fused_bwd_pack_bytes(const egc_layer* layer);
+int egc_batch_fused_bwd_pack(const egc_layer* layer, const float* wcat, void* packed_t, int64_t packed_bytes, egc_stream_t stream);
+int egc_layer_backward_batch_fused_f32(const int64_t* graph_ptr, const int64_t* edge_ptr, int64_t n_graphs, const int64_t* src,
+                                       const int64_t* dst, int64_t n_edges, int64_t n_nodes, const int32_t* max_index,
+                                       const egc_layer* layer, const float* x, const void* packed, const void* packed_t,
+                                       const float* grad_out, float* d_x, float* d_cat, int32_t ld_dcat, int32_t tile_nodes,
+                                       int32_t max_tile_edges, int32_t* status, int32_t* host_flag, egc_stream_t stream);
+
 /* Whole layer forward = egc_basis_transform_f32 + egc_aggregate_combine_f32
  * (EfficientGraphConv.forward layers.py:89-140 / EGConv.forward optimized_layers.py:177-210
  * after graph preparation).  bases [N,ldb] and weightings [N,W] are caller-provided intermediates. */
