@@ -160,7 +160,7 @@ static FtLds ft_lds(const AggArgs& a, int wl_floats, int tcap, int emax, bool wi
   if (bwd) { L.off_rowinv2 = (int)at; at += up16(2 * FT_CHUNK * sizeof(float)); }
   L.off_bases = (int)at; at += up16((size_t)(tcap + 1) * a.ldb * 4);   // (+ the all-zero row absent entries read)
   L.off_wt = (int)at; at += up16((size_t)tcap * wl_floats * 4);
-  if (bwd) { L.off_db = (int)at; at += up16((size_t)(tcap + 1) * a.ldb * 4); }   // d bases (+ a row the absent entries would address)
+  if (bwd) { L.off_db = (int)at; at += up16((size_t)(tcap + 1) * a.ldb * 8); }   // d bases as 64-bit fixed point (+ a row absent entries would address)
   const size_t csr0 = at;
   L.off_col = (int)at; at += up16((size_t)emax * 2);
   if (bwd) { L.off_eid = (int)at; at += up16((size_t)emax * 2); }
@@ -404,7 +404,7 @@ int fused_tile_bwd_pack(const AggArgs& a, const float* wcat, int f_in, void* pac
 int fused_tile_bwd_capacity(const AggArgs& a, int f_in, int max_tile_edges) {
   if (!fused_tile_bwd_shape(a, f_in) || max_tile_edges < 0) return 0;
   int best = 0;
-  for (int tcap = FT_CHUNK; tcap <= FT_CHUNK * FT_RING; tcap += FT_CHUNK) {
+  for (int tcap = FT_CHUNK; tcap <= FT_CHUNK * 8; tcap += FT_CHUNK) {        // (the kernel keeps eight 16-row chunks of x in flight)
     if (ft_lds(a, a.H * a.B * 4, tcap, max_tile_edges, false, false, true).total <= FT_LDS_BUDGET) best = tcap; else break;
   }
   return best;
@@ -419,8 +419,34 @@ static int launch_ftb_one(const AggArgs& a, const FusedTileArgs& t, unsigned gri
     if (e != hipSuccess) { set_last_error("hipFuncSetAttribute(fused_tile_kernel, backward)", e); return EGC_ERR_HIP; }
     attr_set = true;
   }
+#ifdef EGC_FT_STAMPS
+  static unsigned long long* dbuf = nullptr;
+  if (dbuf == nullptr) {
+    hipMalloc(&dbuf, (256 * 9 + 96) * 8);
+    hipMemcpyToSymbol(HIP_SYMBOL(egc_ft_stamp_buf), &dbuf, sizeof(dbuf));
+  }
+  hipMemset(dbuf, 0, (256 * 9 + 96) * 8);
+#endif
   fused_tile_kernel<4, 1, 0, C, 0, 1><<<grid, FT_THREADS, lds, stream>>>(a, t);
   EGC_LAUNCH_CHECK("fused_tile_kernel (backward)");
+#ifdef EGC_FT_STAMPS
+  {
+    hipDeviceSynchronize();
+    static int calls = 0;
+    if ((++calls % 40) == 0) {
+      unsigned long long h[256 * 9 + 96];
+      hipMemcpy(h, dbuf, sizeof(h), hipMemcpyDeviceToHost);
+      double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tmax = 0;
+      for (unsigned b = 0; b < grid; ++b) {
+        for (int k = 0; k < 8; ++k) sum[k] += (double)h[b * 8 + k];
+        tmax = std::max(tmax, (double)h[b * 8 + 7]);
+      }
+      fprintf(stderr, "[ft bwd stamps] grid %u, n_nodes %d: per workgroup (shader cycles): start %.0f  GEMM1 %.0f  rows (backward) %.0f  "
+              "B1 + GEMM2 %.0f | total avg %.0f max %.0f\n", grid, a.n_nodes, sum[0] / grid, sum[4] / grid, sum[5] / grid, sum[6] / grid,
+              sum[7] / grid, tmax);
+    }
+  }
+#endif
   return EGC_OK;
 }
 
@@ -449,7 +475,8 @@ int launch_fused_tile_bwd(AggArgs a, const int64_t* ptr, const int64_t* edge_ptr
   t.wl_floats = a.H * a.B * 4;
   t.nsets = 1;
   t.grad_out = grad_out; t.d_x = d_x; t.d_cat = d_cat; t.ld_dcat = ld_dcat; t.packed_t = (const ft_u16*)packed_t;
-  if (tcap < FT_CHUNK || tcap > FT_CHUNK * FT_RING || (tcap % FT_CHUNK) != 0 || emax < 0 || emax > 65536) return EGC_ERR_INVALID;
+  if (const char* e = getenv("EGC_FT_DBG")) t.dbg = atoi(e);     // (read by diagnostic builds of the kernel only: -DEGC_FT_STAMPS)
+  if (tcap < FT_CHUNK || tcap > FT_CHUNK * 8 || (tcap % FT_CHUNK) != 0 || emax < 0 || emax > 16384) return EGC_ERR_INVALID;
   const FtLds L = ft_lds(a, t.wl_floats, tcap, emax, false, false, true);
   if (L.total > FT_LDS_BUDGET) return EGC_ERR_UNSUPPORTED;
   t.off_rec = L.off_rec; t.off_planes = L.off_planes; t.off_rowinv = L.off_rowinv; t.off_bases = L.off_bases; t.off_wt = L.off_wt;
@@ -459,6 +486,17 @@ int launch_fused_tile_bwd(AggArgs a, const int64_t* ptr, const int64_t* edge_ptr
   if (const char* e = getenv("EGC_FT_GRID")) grid = std::max(1, atoi(e));
   grid = std::min<int64_t>(grid, std::max<int64_t>(1, n_graphs));
   grid = std::min<int64_t>(grid, std::max<int64_t>(1, (int64_t)a.n_nodes / 16));
+  if (getenv("EGC_NO_STATIC_CFG") == nullptr && a.Ls == a.L) {
+    // the row pass is bound by its vector instructions: with the layer's constants compiled in the aggregator switches, the
+    // head count and the edge-set tests fold away (the run-time form is 2,000 instructions per turn, a quarter of them moves)
+    constexpr int S = EGC_AGGR_SUM, M = EGC_AGGR_MEAN, X = EGC_AGGR_MAX, Y = EGC_AGGR_SYMNORM;
+    unsigned pk = 0;
+    for (int k = 0; k < a.A; ++k) pk |= (unsigned)a.aggr[k] << (3 * k);
+    if (a.H == 8 && a.A == 4 && pk == agg_pack(S, M, X, Y) && a.x_looped && a.y_looped && a.loops_all)       // EGConv EGC-M north star
+      return launch_ftb_one<StCfg<8, 4, 16, 4, agg_pack(S, M, X, Y), EGC_ACT_NONE, true, true, true>>(a, t, (unsigned)grid, L.total, stream);
+    if (a.H == 8 && a.A == 3 && pk == agg_pack(Y, X, M) && !a.x_looped && a.y_looped && a.loops_all)          // EfficientGraphConv EGC-M at d = 128
+      return launch_ftb_one<StCfg<8, 4, 16, 3, agg_pack(Y, X, M), EGC_ACT_NONE, false, true, true>>(a, t, (unsigned)grid, L.total, stream);
+  }
   return launch_ftb_one<RtCfg>(a, t, (unsigned)grid, L.total, stream);
 }
 

@@ -550,7 +550,9 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
 
     const bool csr_wave = wave < FT_FIRST_HELPER + FT_CSR_WAVES;
     if constexpr (WIDE == 0) {
-    f4 xr[2 * FT_RING];
+    // (the backward form keeps d bases next to the images: tiles of at most 128 rows, 16 registers fewer for the rows in flight)
+    constexpr int RINGN = MODE == 1 ? 8 : FT_RING;
+    f4 xr[2 * RINGN];
     // 16-byte pieces p = ht + 256 i (i = 0, 1) of a 16-row chunk <-> (row p / 32, k 4 (p % 32)).  Per thread: the two byte
     // offsets inside a chunk (rows beyond the tile fall outside the tile's descriptor and read as 0; the chunk is a SCALAR
     // offset of the load) and the two destinations inside a plane buffer -- a few registers next to the 80 that carry x.
@@ -611,16 +613,16 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
     unsigned epk0[KEEP];
     {
       const __amdgpu_buffer_rsrc_t rs = x_rsrc_of(first);
-      if (csr_wave) csr_s0(first, xr + FT_RING);
+      if (csr_wave) csr_s0(first, xr + RINGN);
 #pragma unroll
-      for (int c = 0; c < FT_RING / 2; ++c) x_load(xr[2 * c], xr[2 * c + 1], rs, c);   // (chunks beyond the tile read as 0)
+      for (int c = 0; c < RINGN / 2; ++c) x_load(xr[2 * c], xr[2 * c + 1], rs, c);   // (chunks beyond the tile read as 0)
       if (csr_wave) {
-        csr_s1(first, 0, xr + FT_RING, epk0);
+        csr_s1(first, 0, xr + RINGN, epk0);
         csr_s1_rest(first, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int c = FT_RING / 2; c < FT_RING; ++c) x_load(xr[2 * c], xr[2 * c + 1], rs, c);
+      for (int c = RINGN / 2; c < RINGN; ++c) x_load(xr[2 * c], xr[2 * c + 1], rs, c);
     }
     if (csr_wave) {
       csr_sync();
@@ -639,14 +641,14 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       unsigned epk[KEEP];                      // (declared per tile: nothing of the build is carried over)
       const int nset = (it + 1) & 1;
 #pragma unroll
-      for (int c = 0; c < FT_RING; ++c) {
+      for (int c = 0; c < RINGN; ++c) {
         if (c < cur.nch) {   // workgroup-uniform
 #ifdef EGC_FT_STAMPS
           if (!(t.dbg & 1))
 #endif
           // two chunks ahead: the workers take the first half of chunk c + 1 while they are in step c, and chunk c - 1, whose
           // buffer this is, was read in step c - 1 at the latest
-          if (c + 2 < FT_RING && c + 2 < cur.nch) split(xr[2 * (c + 2)], xr[2 * (c + 2) + 1], (c + 2) % FT_PBUF);
+          if (c + 2 < RINGN && c + 2 < cur.nch) split(xr[2 * (c + 2)], xr[2 * (c + 2) + 1], (c + 2) % FT_PBUF);
           lds_barrier();
         }
 #ifdef EGC_FT_EARLY_X
@@ -656,9 +658,10 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
         // running in the rows-phase window only, 40 % of the time.  Unconditional, straight-line (a chunk beyond the next tile
         // lies outside its descriptor); chunks 5 - 8 stay behind the CSR build's counts: its edges travel in their registers.
         if (c == 0) { x_load(xr[0], xr[1], rsn, 0); x_load(xr[2], xr[3], rsn, 1); }
-        if (c + 2 < FT_RING && (c + 2 < FT_RING / 2 || c + 2 == FT_RING - 1)) x_load(xr[2 * (c + 2)], xr[2 * (c + 2) + 1], rsn, c + 2);
+        if (c + 2 < RINGN && (c + 2 < RINGN / 2 || c + 2 == RINGN - 1)) x_load(xr[2 * (c + 2)], xr[2 * (c + 2) + 1], rsn, c + 2);
 #endif
       }
+      if constexpr (MODE == 1) lds_barrier();       // (the workers' scale pre-pass: largest |g| and |w'| of the tile)
 #ifdef EGC_FT_STAMPS
       unsigned long long ft_h0;
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ft_h0) :: "memory");
@@ -680,13 +683,13 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       // requested, unconditionally (the ones beyond the tile lie outside its descriptor and cost no traffic): the compiler can
       // then count the requests in flight.  (Requested chunk by chunk inside the loop above, its conservative vmcnt(0) in
       // front of every split made each step wait for the request it had just issued.)
-      if (csr_wave) csr_s0(nxt, xr + FT_RING);
+      if (csr_wave) csr_s0(nxt, xr + RINGN);
 #ifndef EGC_FT_EARLY_X
 #pragma unroll
-      for (int c = 0; c < FT_RING / 2; ++c) x_load(xr[2 * c], xr[2 * c + 1], rsn, c);
+      for (int c = 0; c < RINGN / 2; ++c) x_load(xr[2 * c], xr[2 * c + 1], rsn, c);
 #endif
       if (csr_wave) {
-        csr_s1(nxt, nset, xr + FT_RING, epk);
+        csr_s1(nxt, nset, xr + RINGN, epk);
         csr_s1_rest(nxt, nset);
       }
       __builtin_amdgcn_sched_barrier(0);       // (the second half of the rows into the registers the edges have left)
@@ -706,10 +709,10 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       // vector-memory pipeline -- need not stand between the in-degrees and the scan)
 #ifdef EGC_FT_EARLY_X
 #pragma unroll
-      for (int c = FT_RING / 2; c < FT_RING - 1; ++c) x_load(xr[2 * c], xr[2 * c + 1], rsn, c);
+      for (int c = RINGN / 2; c < RINGN - 1; ++c) x_load(xr[2 * c], xr[2 * c + 1], rsn, c);
 #else
 #pragma unroll
-      for (int c = FT_RING / 2; c < FT_RING; ++c) x_load(xr[2 * c], xr[2 * c + 1], rsn, c);
+      for (int c = RINGN / 2; c < RINGN; ++c) x_load(xr[2 * c], xr[2 * c + 1], rsn, c);
 #endif
 #ifdef EGC_FT_STAMPS
       FT_HSTAMP(2, wave == FT_FIRST_HELPER)
@@ -731,7 +734,11 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
         auto stage_d = [&](int c, int buf) {
           const int r = FT_CHUNK * c + drow;
           f4 pc[3];
-          pc[0] = *reinterpret_cast<const f4*>(base + t.off_db + (r * a.ldb + 4 * dj) * 4);
+          {   // d bases: 64-bit fixed point (the rows pass adds with integer LDS atomics), scale 2^-dbs in lds_rec[28]
+            const long long* dq = reinterpret_cast<const long long*>(base + t.off_db) + (r * a.ldb + 4 * dj);
+            const double sinv = __builtin_ldexp(1.0, -lds_rec[28]);
+            pc[0] = f4{(float)((double)dq[0] * sinv), (float)((double)dq[1] * sinv), (float)((double)dq[2] * sinv), (float)((double)dq[3] * sinv)};
+          }
           pc[1] = *reinterpret_cast<const f4*>(base + t.off_wt + (r * t.wl_floats + 4 * dj) * 4);
           pc[2] = np2 > 2 ? *reinterpret_cast<const f4*>(base + t.off_wt + (r * t.wl_floats + 64 + 4 * dj) * 4) : f4{0.f, 0.f, 0.f, 0.f};
           float m = 0.f;
@@ -763,26 +770,6 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
             }
           }
           reinterpret_cast<float*>(base + t.off_rowinv2)[buf * FT_CHUNK + drow] = __uint_as_float(e);
-          // d_cat [n_nodes][ld_dcat] = [d bases (ldb) | d weightings in the layer's column order (h B + b) A + a]
-          if (t.d_cat != nullptr && r < cur.T) {
-            float* dc = t.d_cat + (int64_t)(cur.n0 + r) * t.ld_dcat;
-            __builtin_nontemporal_store(pc[0], reinterpret_cast<f4*>(dc + 4 * dj));
-            const int A = C::A(a);
-            if (A == 4) {
-              __builtin_nontemporal_store(pc[1], reinterpret_cast<f4*>(dc + a.ldb + 4 * dj));
-              if (np2 > 2) __builtin_nontemporal_store(pc[2], reinterpret_cast<f4*>(dc + a.ldb + 64 + 4 * dj));
-            } else {
-#pragma unroll
-              for (int i = 1; i < 3; ++i) {
-                if (i < np2) {
-                  float* dw = dc + a.ldb + (dj + 16 * (i - 1)) * A;      // block (h, b) = dj + 16 (i - 1)
-                  dw[0] = pc[i].x;
-                  if (A > 1) dw[1] = pc[i].y;
-                  if (A > 2) dw[2] = pc[i].z;
-                }
-              }
-            }
-          }
         };
         if (cur.nch > 0) stage_d(0, 0);
         lds_barrier();                                   // (A: chunk 0 of d staged)
@@ -1105,8 +1092,9 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
     lds_barrier();       // chunk 0 is staged, the tile's CSR complete, the row counter zero
     FT_STAMP(0)
     if constexpr (MODE == 1) {   // d bases of the tile: zero (the rows pass adds into it; the GEMM steps' barriers stand in between)
-      f4* db4 = reinterpret_cast<f4*>(base + t.off_db);
-      for (int i = tid; i < T * ldb4; i += FT_WORKER_THREADS) db4[i] = f4{0.f, 0.f, 0.f, 0.f};
+      f4* db4 = reinterpret_cast<f4*>(base + t.off_db);       // (64-bit fixed point: two 16-byte pieces per slot)
+      for (int i = tid; i < 2 * T * ldb4; i += FT_WORKER_THREADS) db4[i] = f4{0.f, 0.f, 0.f, 0.f};
+      if (tid == 0) { lds_rec[26] = 0; lds_rec[27] = 0; }
     }
 
     // ---- (G) [bases | weightings] of the tile, 16 rows per step.  The A fragments of a chunk are read in two halves: k-steps
@@ -1417,7 +1405,45 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
     //      atomics: sum / mean / symnorm along every entry, max to the one entry that attained it.  (B = 4 bases of 16
     //      channels: 16 slots, four lanes per basis; aggregators sum / mean / max / symnorm; no weight nonlinearity.)
     const unsigned short* lds_eid = reinterpret_cast<const unsigned short*>(cb + t.off_eid);
-    float* lds_db = reinterpret_cast<float*>(base + t.off_db);
+    long long* lds_db = reinterpret_cast<long long*>(base + t.off_db);
+    // The sources' gradients are summed by LDS atomics, and float LDS atomics run at ONE LANE PER CLOCK for the whole CU on
+    // gfx950 (tools/src/lds_atomic_bench.hip: 768 cycles per wave instruction with twelve wavefronts adding, 62 for ds_add_u64):
+    // d bases is kept as 64-bit fixed point.  Its scale comes from a pre-pass over the tile: every contribution is at most
+    // A H max|w'| max|g| in magnitude, so with 2^dbs = 2^(34 - e(max|g|) - e(H max|w'|)) a contribution stays below 2^36 and
+    // the sum of a tile's at most 2^14 entries below 2^50 -- 34 bits under the bound where fp32 carries 24.
+    int dbs_tile = 0;
+    {
+      unsigned gm = 0, wm = 0;
+      if (cur.ok) {
+        const f4* g4 = reinterpret_cast<const f4*>(t.grad_out + (int64_t)n0 * F_out);
+        for (int i = tid; i < T * (F_out >> 2); i += FT_WORKER_THREADS) {
+          const f4 v = g4[i];
+          gm = max(gm, __float_as_uint(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)))));
+        }
+        const f4* w4 = reinterpret_cast<const f4*>(lds_wt);
+        for (int i = tid; i < T * (t.wl_floats >> 2); i += FT_WORKER_THREADS) {
+          const f4 v = w4[i];
+          wm = max(wm, __float_as_uint(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)))));
+        }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          gm = max(gm, (unsigned)bperm((lane ^ off) << 2, (int)gm));
+          wm = max(wm, (unsigned)bperm((lane ^ off) << 2, (int)wm));
+        }
+        if (lane == 0) {
+          atomicMax(reinterpret_cast<unsigned*>(lds_rec) + 26, gm);
+          atomicMax(reinterpret_cast<unsigned*>(lds_rec) + 27, wm);
+        }
+      }
+      lds_barrier();
+      const int eg = (int)((unsigned)__builtin_amdgcn_readfirstlane(lds_rec[26]) >> 23) - 127;
+      const int ew = (int)((unsigned)__builtin_amdgcn_readfirstlane(lds_rec[27]) >> 23) - 127;
+      int dbs = 34 - (eg + 1) - (ew + 1) - 5;      // (H <= 8: 3 bits; A <= 4: 2 bits)
+      dbs = dbs < -1000 ? -1000 : (dbs > 1000 ? 1000 : dbs);
+      if (tid == 0) lds_rec[28] = dbs;             // (for the helpers, who stage d bases behind barrier B1; every wavefront here
+      dbs_tile = dbs;                               //  forms the same number from the two maxima itself)
+    }
+    const double db_scale = __builtin_ldexp(1.0, dbs_tile);
     const __amdgpu_buffer_rsrc_t rgo =
         __builtin_amdgcn_make_buffer_rsrc((void*)t.grad_out, 0, (unsigned)a.n_nodes * (unsigned)F_out * 4u, 0x00020000);
     const int bq = q >> 2, l4 = q & 3;
@@ -1435,7 +1461,11 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       f4 gv[8];
 #pragma unroll
       for (int h = 0; h < 8; ++h)
+#ifdef EGC_FT_STAMPS
+        gv[h] = load_slot(rgo, (row_ok && h < H && !(t.dbg & 256)) ? ((unsigned)row * (unsigned)F_out + (unsigned)(h * 16 + 4 * l4)) * 4u : OOB);
+#else
         gv[h] = load_slot(rgo, (row_ok && h < H) ? ((unsigned)row * (unsigned)F_out + (unsigned)(h * 16 + 4 * l4)) * 4u : OOB);
+#endif
       const int start = row_ok ? lds_rowptr[r] : 0;
       const int nd = row_ok ? lds_rowptr[r + 1] - start : 0;
       int maxd = nd;
@@ -1457,6 +1487,9 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       };
       int nself = 0;
       for (int ts = 0; ts < maxd; ts += LPR) {
+#ifdef EGC_FT_STAMPS
+        if (t.dbg & 512) break;
+#endif
         const bool pv = ts + q < nd;
         const int jj = pv ? (int)lds_col[start + ts + q] : 0;
         const int ee = pv ? (int)lds_eid[start + ts + q] : 0;
@@ -1485,6 +1518,9 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
           for (int uu = 0; uu < FU; ++uu) {
             sum += v[uu];
             ws = f4_fma(splat(w[uu]), v[uu], ws);
+#ifdef EGC_FT_STAMPS
+            if (!(t.dbg & 32))
+#endif
             if (jn[uu] != zrow) take(v[uu], en[uu], jn[uu]);
           }
         }
@@ -1519,6 +1555,9 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       float* wrow = lds_wt + (row_ok ? r : 0) * t.wl_floats;
 #pragma unroll
       for (int h = 0; h < 8; ++h) {
+#ifdef EGC_FT_STAMPS
+        if (t.dbg & 64) break;
+#endif
         if (h < H) {
           const f4 wv = *reinterpret_cast<const f4*>(wrow + (h * 4 + bq) * 4);
           dagg[0] = f4_fma(splat(wv.x), gv[h], dagg[0]);
@@ -1550,11 +1589,20 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
           }
         }
       }
+      // float -> 64-bit fixed point: x 2^dbs in double, + 1.5 2^52 (the integer then sits in the low bits of the mantissa), - its bits
+      auto fix = [&](float v) -> unsigned long long {
+        const double tq = (double)v * db_scale + 6755399441055744.0;
+        return (unsigned long long)(__builtin_bit_cast(long long, tq) - 0x4338000000000000ll);
+      };
+      auto add_at = [&](long long* p, float v) { atomicAdd(reinterpret_cast<unsigned long long*>(p), fix(v)); };
       auto add_row = [&](int j, f4 c) {
-        float* p = lds_db + j * a.ldb + 4 * q;
-        atomicAdd(p, c.x); atomicAdd(p + 1, c.y); atomicAdd(p + 2, c.z); atomicAdd(p + 3, c.w);
+        long long* p = lds_db + j * a.ldb + 4 * q;
+        add_at(p, c.x); add_at(p + 1, c.y); add_at(p + 2, c.z); add_at(p + 3, c.w);
       };
       for (int ts = 0; ts < maxd; ts += LPR) {
+#ifdef EGC_FT_STAMPS
+        if (t.dbg & 128) break;
+#endif
         const bool pv = ts + q < nd;
         const int jj = pv ? (int)lds_col[start + ts + q] : 0;
         const bool self_e = pv && jj == r;
@@ -1569,14 +1617,17 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
           if (j != zrow) add_row(j, f4_fma(splat(w), d_s, d_t));
         }
       }
+#ifdef EGC_FT_STAMPS
+      if (!(t.dbg & 1024))
+#endif
       if (row_ok) {
         if (C::xl(a)) { if (has_self) add_row(r, f4_fma(splat(dis_i * dis_i), d_s, d_t)); }
         else if (C::yl(a) && has_self) add_row(r, d_s * splat(dis_i * dis_i));
         if (nonempty) {
-          if (aj.x >= 0) atomicAdd(lds_db + aj.x * a.ldb + 4 * q, d_x.x);
-          if (aj.y >= 0) atomicAdd(lds_db + aj.y * a.ldb + 4 * q + 1, d_x.y);
-          if (aj.z >= 0) atomicAdd(lds_db + aj.z * a.ldb + 4 * q + 2, d_x.z);
-          if (aj.w >= 0) atomicAdd(lds_db + aj.w * a.ldb + 4 * q + 3, d_x.w);
+          if (aj.x >= 0) add_at(lds_db + aj.x * a.ldb + 4 * q, d_x.x);
+          if (aj.y >= 0) add_at(lds_db + aj.y * a.ldb + 4 * q + 1, d_x.y);
+          if (aj.z >= 0) add_at(lds_db + aj.z * a.ldb + 4 * q + 2, d_x.z);
+          if (aj.w >= 0) add_at(lds_db + aj.w * a.ldb + 4 * q + 3, d_x.w);
         }
       }
     }
@@ -1604,6 +1655,34 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
         col_inv2 = reinterpret_cast<const float*>(t.packed_t + (int64_t)8 * 6 * 2 * 64 * 8)[16 * (is_mfma2 ? wave : 0) + (lv & 15)];
       }
       lds_barrier();   // (B1: every row's d bases / d w' are in the images)
+      // d_cat [n_nodes][ld_dcat] = [d bases (ldb) | d weightings in the layer's column order (h B + b) A + a]: written by the
+      // wavefronts that have no column tile in the second GEMM (in the helpers' staging every reload of a spilled register
+      // waited for these stores: vmcnt counts stores too)
+      if (t.d_cat != nullptr && wave >= 8 && cur.ok) {
+        const int tw = tid - 8 * 64;
+        const int Ad = C::A(a), npr = (a.ldb + t.wl_floats) >> 2;      // 16-byte pieces per row of the two images
+        for (int p = tw; p < T * npr; p += (FT_MFMA_WAVES - 8) * 64) {
+          const int rr = p / npr, pc = p - rr * npr;
+          float* dc = t.d_cat + (int64_t)(n0 + rr) * t.ld_dcat;
+          if (pc < ldb4) {
+            const long long* dq = reinterpret_cast<const long long*>(base + t.off_db) + (rr * a.ldb + 4 * pc);
+            const double sinv = __builtin_ldexp(1.0, -__builtin_amdgcn_readfirstlane(lds_rec[28]));
+            __builtin_nontemporal_store(f4{(float)((double)dq[0] * sinv), (float)((double)dq[1] * sinv), (float)((double)dq[2] * sinv),
+                                           (float)((double)dq[3] * sinv)}, reinterpret_cast<f4*>(dc + 4 * pc));
+          } else {
+            const int hb = pc - ldb4;                                   // block (h, b)
+            const f4 v = *reinterpret_cast<const f4*>(base + t.off_wt + (rr * t.wl_floats + 4 * hb) * 4);
+            if (Ad == 4) {
+              __builtin_nontemporal_store(v, reinterpret_cast<f4*>(dc + a.ldb + 4 * hb));
+            } else {
+              float* dw = dc + a.ldb + hb * Ad;
+              dw[0] = v.x;
+              if (Ad > 1) dw[1] = v.y;
+              if (Ad > 2) dw[2] = v.z;
+            }
+          }
+        }
+      }
       lds_barrier();   // (A: the helpers have staged chunk 0)
       const __amdgpu_buffer_rsrc_t rdx = __builtin_amdgcn_make_buffer_rsrc(
           (void*)(t.d_x + (int64_t)n0 * t.F_in), 0, (unsigned)(cur.ok ? T : 0) * (unsigned)t.F_in * 4u, 0x00020000);

@@ -436,8 +436,9 @@ def _batch_fused_train_setup(gb: GraphBatch, spec: LayerSpec, x):
     """((tile_nodes, emax) of the forward launch, (tile_nodes, emax) of the backward launch) when a TRAINING call of this layer on
     this batch can run as one launch each way (egc_layer_forward_batch_fused_f32 + egc_layer_backward_batch_fused_f32), else
     None: the CSR path (graph build + GEMM + aggregate + three backward kernels + the dense gradients) then.
-    EGC_NO_FUSED_BWD=1 switches the path off."""
-    if (_C.env_flag("EGC_NO_FUSED_TILE") or _C.env_flag("EGC_NO_TILE") or _C.env_flag("EGC_NO_FUSED_BWD") or gemm_exact()
+    EGC_NO_FUSED_BWD=1 switches the path off.  (Graphs of at most 80 nodes at H = 8: the tile's LDS image also holds d bases
+    as 64-bit fixed point, summed by integer LDS atomics.)"""
+    if (_C.env_flag("EGC_NO_FUSED_BWD") or _C.env_flag("EGC_NO_FUSED_TILE") or _C.env_flag("EGC_NO_TILE") or gemm_exact()
             or spec.gemm_flags != 0 or os.environ.get("EGC_XT_FP32") is not None):
         return None
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous() and x.data_ptr() % 16 == 0):

@@ -1,0 +1,155 @@
+"""The tile-local backward of the batch path (egc_layer_backward_batch_fused_f32; egc_fused_tile.hip, MODE 1): what autograd derives through the layer for a PyG batch in the reference's training loops
+(zinc/configs.py:53-72 -> layers.py:89-140 / optimized_layers.py:177-210), as one launch + x^T d.  Gradients against float64
+autograd through the differentiable restatement (oracle/egc_torch_ref.py), against the CSR path on the same batch, the
+first-maximal-edge rule of scatter_max, and the fallbacks outside the kernel's envelope."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import egc_torch_ref as tref
+from test_batch_tile_gpu import _messy_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / max(1e-30, float(b.abs().max())))
+
+
+def _ran_bwd(gb):
+    return any(isinstance(k, tuple) and k[-1] == "fused_bwd" and v for k, v in gb._setups.items())
+
+
+@pytest.mark.parametrize("kind,hidden,H,aggrs,asl", [
+    ("opt", 128, 8, ["sum", "mean", "max", "symnorm"], True),      # EGConv EGC-M north star (static configuration)
+    ("lay", 128, 8, ["symadd", "max", "mean"], True),              # EfficientGraphConv EGC-M (static): symadd looped, the others raw
+    ("lay", 128, 8, ["symadd"], True),                             # EGC-S: one aggregator
+    ("opt", 64, 4, ["sum", "max"], True),                          # d = 64, H = 4: four k-steps in the second GEMM
+    ("opt", 128, 8, ["sum", "max", "mean"], False),                # RAW sets (add_self_loops=False), no symnorm
+    ("opt", 128, 8, ["symnorm", "max"], False),                    # RAW sets with symnorm
+])
+def test_gradients_match_float64_and_the_csr_path(kind, hidden, H, aggrs, asl, monkeypatch):
+    import egc_amd
+    dev = _dev()
+    ei, n, ptr = _messy_batch(31 + len(aggrs), max_size=80)      # (80-row tiles at H = 8: the image also holds d bases)
+    torch.manual_seed(2)
+    if kind == "opt":
+        conv = egc_amd.EGConv(hidden, hidden, aggrs=aggrs, num_heads=H, num_bases=4, add_self_loops=asl)
+    else:
+        conv = egc_amd.EfficientGraphConv(hidden, hidden, H, 4, False, aggrs=aggrs, add_self_loops=asl)
+    with torch.no_grad():
+        conv.bias.normal_()
+    conv = conv.to(dev).train()
+    x0 = torch.randn(n, hidden)
+    go = torch.randn(n, hidden)
+
+    def run(graph):
+        conv.zero_grad(set_to_none=True)
+        x = x0.to(dev).requires_grad_(True)
+        out = conv(x, graph) if kind == "opt" else conv(x=x, edge_index=graph)
+        out.backward(go.to(dev))
+        return out.detach(), x.grad.detach(), {k: v.grad.detach().clone() for k, v in conv.named_parameters()}
+    gb = egc_amd.GraphBatch(ei.to(dev), ptr=ptr.to(dev), max_nodes=80)
+    out, dx, gp = run(gb)
+    gb.check()
+    assert _ran_bwd(gb), "the one-launch backward did not run"
+    out_c, dx_c, gp_c = run(ei.to(dev))
+    # float64 autograd through the restatement of the reference
+    p64 = {k: v.detach().double().cpu().requires_grad_(True) for k, v in conv.named_parameters()}
+    x64 = x0.double().requires_grad_(True)
+    e = ei.numpy()
+    if kind == "opt":
+        ref = tref.egconv_forward(x64, e, p64["bases_weight"], p64["comb_weight.weight"], p64["comb_weight.bias"], p64["bias"], H, 4,
+                                  aggrs, add_self_loops=asl, sigmoid=False)
+    else:
+        ref = tref.efficient_graph_conv_forward(x64, e, [p64[f"bases_weight.{b}"] for b in range(4)], p64["comb_weights.weight"],
+                                                p64["comb_weights.bias"], p64["bias"], H, aggrs, softmax=False, hardtanh=False,
+                                                sigmoid=False, add_self_loops=asl)
+    ref.backward(go.double())
+    assert _rel(out, ref) <= 1e-5
+    assert _rel(dx, x64.grad) <= 1e-5, _rel(dx, x64.grad)
+    assert _rel(dx, dx_c) <= 1e-5
+    for k in gp:
+        assert _rel(gp[k], p64[k].grad) <= 1e-5, (k, _rel(gp[k], p64[k].grad))
+        assert _rel(gp[k], gp_c[k]) <= 1e-5, k
+
+
+def test_max_gradient_goes_to_the_first_maximal_edge_in_input_order(monkeypatch):
+    """torch_scatter's arg rule (SURVEY 8a note 8): among entries attaining a row's maximum the FIRST in input order takes the
+    gradient.  Sources with identical rows (one embedding, as ZINC's atom types give them) make exact ties; the tile's CSR is
+    built by LDS atomics in no particular order, so the kernel carries every entry's input position."""
+    import egc_amd
+    dev = _dev()
+    rng = np.random.default_rng(5)
+    sizes = rng.integers(4, 40, size=60)
+    ptr = np.concatenate([[0], np.cumsum(sizes)])
+    src, dst = [], []
+    for g in range(60):
+        n, o = int(sizes[g]), int(ptr[g])
+        e = 6 * n
+        s, d = rng.integers(0, n, size=e), rng.integers(0, n, size=e)
+        src.append(s + o); dst.append(d + o)
+    ei = torch.from_numpy(np.stack([np.concatenate(src), np.concatenate(dst)]).astype(np.int64))
+    n = int(ptr[-1])
+    torch.manual_seed(3)
+    conv = egc_amd.EGConv(128, 128, aggrs=["max", "sum"], num_heads=8, num_bases=4, add_self_loops=False).to(dev).train()
+    emb = torch.randn(5, 128)
+    x0 = emb[torch.from_numpy(rng.integers(0, 5, size=n))]       # five distinct rows only: every neighbourhood has exact ties
+    go = torch.randn(n, 128)
+    res = []
+    gb = egc_amd.GraphBatch(ei.to(dev), ptr=torch.from_numpy(ptr).to(dev), max_nodes=40)
+    for graph in (gb, ei.to(dev)):
+        conv.zero_grad(set_to_none=True)
+        x = x0.to(dev).requires_grad_(True)
+        conv(x, graph).backward(go.to(dev))
+        res.append(x.grad.detach().clone())
+    gb.check()
+    assert _ran_bwd(gb)
+    assert _rel(res[0], res[1]) <= 1e-5       # (a different routing among tied sources moves whole gradient rows)
+
+
+def test_layers_outside_the_envelope_take_the_csr_path(monkeypatch):
+    import egc_amd
+    dev = _dev()
+    ei, n, ptr = _messy_batch(3, n_graphs=80, max_size=80)
+    for conv, fin in ((egc_amd.EGConv(128, 128, aggrs=["sum", "std", "max"], num_heads=8, num_bases=4), 128),          # std
+                      (egc_amd.EfficientGraphConv(224, 224, 4, 4, False, aggrs=["add", "mean", "max"]), 224),          # the WIDE form has no backward
+                      (egc_amd.EGConv(128, 128, aggrs=["sum", "max"], num_heads=8, num_bases=4, sigmoid=True) if False else
+                       egc_amd.EfficientGraphConv(128, 128, 8, 4, False, aggrs=["symadd", "max"], sigmoid_weights=True), 128)):   # weight nonlinearity
+        conv = conv.to(dev).train()
+        x0 = torch.randn(n, fin, device=dev)
+        go = torch.randn(n, conv.out_channels, device=dev)
+        res = []
+        gb = egc_amd.GraphBatch(ei.to(dev), ptr=ptr.to(dev), max_nodes=80)
+        for graph in (gb, ei.to(dev)):
+            conv.zero_grad(set_to_none=True)
+            x = x0.clone().requires_grad_(True)
+            out = conv(x, graph) if isinstance(conv, egc_amd.EGConv) else conv(x=x, edge_index=graph)
+            out.backward(go)
+            res.append(x.grad.detach().clone())
+        gb.check()
+        assert not _ran_bwd(gb)
+        assert _rel(res[0], res[1]) <= 1e-5
+
+
+def test_switch_and_oversize_graphs(monkeypatch):
+    """EGC_NO_FUSED_BWD=1 and batches with a graph beyond the backward's tile (80 nodes at H = 8) take the CSR path."""
+    import egc_amd
+    dev = _dev()
+    conv = egc_amd.EGConv(128, 128, aggrs=["sum", "mean", "max", "symnorm"], num_heads=8, num_bases=4).to(dev).train()
+    ei, n, ptr = _messy_batch(4, n_graphs=40, max_size=80)
+    for env, mx, expect in ((None, 80, True), ("1", 80, False), (None, 150, False)):
+        if env is None:
+            monkeypatch.delenv("EGC_NO_FUSED_BWD", raising=False)
+        else:
+            monkeypatch.setenv("EGC_NO_FUSED_BWD", env)
+        gb = egc_amd.GraphBatch(ei.to(dev), ptr=ptr.to(dev), max_nodes=mx)
+        x = torch.randn(n, 128, device=dev, requires_grad=True)
+        conv(x, gb).sum().backward()
+        assert _ran_bwd(gb) == expect

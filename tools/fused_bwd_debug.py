@@ -55,6 +55,42 @@ for sizes in ([20], [40], [70], [20, 20, 30], [30] * 40):
     os.environ["EGC_FT_GRID"] = "1" if len(sizes) <= 3 else "4"
     run(f"north star rings {sizes[:4]}", ns, ei, n, ptr, max(sizes), 128)
 os.environ.pop("EGC_FT_GRID", None)
-ei, n, ptr = _messy_batch(7, max_size=90)
+ei, n, ptr = _messy_batch(7, max_size=80)
 for name, mk, fin in (("north star messy", ns, 128), ("EGC-M layers.py messy", lay, 128), ("EGC-S layers.py messy", egs, 128), ("d64 sum+max messy", d64, 64)):
-    run(name, mk, ei, n, ptr, 90, fin)
+    run(name, mk, ei, n, ptr, 80, fin)
+
+# ---- a stack of blocks (conv -> BatchNorm(train) -> ReLU -> + x), as the nets have it
+import torch.nn as nn
+from egc_amd import workloads as wl
+for nb in (1, 2, 4):
+    ei, n, batch = wl.molecule_batch(256, seed=0)
+    sizes = torch.bincount(batch, minlength=256)
+    ptr = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(sizes, 0)])
+    torch.manual_seed(0)
+    blocks = nn.ModuleList([egc_amd.FusedEGCBlock(ns(), nn.BatchNorm1d(128)) for _ in range(nb)]).to(dev).train()
+    params = list(blocks.parameters())
+    x0 = torch.randn(n, 128, device=dev)
+    go = torch.randn(n, 128, device=dev)
+    res = {}
+    for path in ("csr", "fused"):
+        for p in params: p.grad = None
+        g = ei.to(dev) if path == "csr" else egc_amd.GraphBatch(ei.to(dev), ptr=ptr.to(dev), max_nodes=int(sizes.max()), num_nodes=n)
+        h = x0
+        hs = []
+        for b in blocks:
+            h = b(h, g); hs.append(h.detach())
+        h.backward(go)
+        if path == "fused": g.check()
+        res[path] = (hs, [p.grad.clone() for p in params])
+    print(f"{nb} blocks: outputs per block " + " ".join(f"{rel(a, b):.1e}" for a, b in zip(res['fused'][0], res['csr'][0])) +
+          " | param grads " + " ".join(f"{rel(a, b):.1e}" for a, b in zip(res['fused'][1], res['csr'][1])), flush=True)
+
+# ---- full molhiv batch, one layer: where do the gradients differ?
+ei, n, batch = wl.molecule_batch(2048, seed=0)
+sizes = torch.bincount(batch, minlength=2048)
+ptr = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(sizes, 0)])
+run("north star molhiv b2048", ns, ei, n, ptr, int(sizes.max()), 128)
+_, ei, n, batch = wl.zinc_like_batch(128, seed=0)
+sizes = torch.bincount(batch, minlength=128)
+ptr = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(sizes, 0)])
+run("north star zinc b128", ns, ei, n, ptr, int(sizes.max()), 128)
