@@ -441,9 +441,9 @@ static int launch_ftb_one(const AggArgs& a, const FusedTileArgs& t, unsigned gri
         for (int k = 0; k < 8; ++k) sum[k] += (double)h[b * 8 + k];
         tmax = std::max(tmax, (double)h[b * 8 + 7]);
       }
-      fprintf(stderr, "[ft bwd stamps] grid %u, n_nodes %d: per workgroup (shader cycles): start %.0f  GEMM1 %.0f  rows (backward) %.0f  "
-              "B1 + GEMM2 %.0f | total avg %.0f max %.0f\n", grid, a.n_nodes, sum[0] / grid, sum[4] / grid, sum[5] / grid, sum[6] / grid,
-              sum[7] / grid, tmax);
+      fprintf(stderr, "[ft bwd stamps] grid %u, n_nodes %d: per workgroup (shader cycles): start %.0f  GEMM1 %.0f  scale %.0f  "
+              "rows (backward; wavefront 0) %.0f  B1 + GEMM2 %.0f | total avg %.0f max %.0f\n", grid, a.n_nodes,
+              sum[0] / grid, sum[4] / grid, sum[1] / grid, sum[5] / grid, sum[6] / grid, sum[7] / grid, tmax);
     }
   }
 #endif

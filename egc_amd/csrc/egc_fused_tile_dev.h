@@ -13,6 +13,7 @@ typedef _Float16 ft_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 ft_h2 __attribute__((ext_vector_type(2)));
 typedef float ft_f2 __attribute__((ext_vector_type(2)));
 typedef unsigned int ft_u2 __attribute__((ext_vector_type(2)));
+typedef unsigned int ft_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short ft_u16;
 
 constexpr int FT_THREADS = 1024;
@@ -166,6 +167,16 @@ __device__ inline unsigned ft_row_amax(const f4 v) {
   return max(a, (unsigned)__builtin_amdgcn_ds_swizzle((int)a, 0x401F));                 // lane ^ 16
 }
 
+// largest of a non-negative bit pattern over the wavefront, uniform (four row maxima by DPP, then four lane reads)
+__device__ inline unsigned ft_wave_umax(unsigned a) {
+  a = max(a, (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+  a = max(a, (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+  a = max(a, (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0x141, 0xf, 0xf, true));  // row_half_mirror
+  a = max(a, (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0x140, 0xf, 0xf, true));  // row_mirror
+  return max(max((unsigned)__builtin_amdgcn_readlane((int)a, 0), (unsigned)__builtin_amdgcn_readlane((int)a, 16)),
+             max((unsigned)__builtin_amdgcn_readlane((int)a, 32), (unsigned)__builtin_amdgcn_readlane((int)a, 48)));
+}
+
 // MODE 1 (WIDE == 0 only): the BACKWARD of the layer on the same tiles -- x, grad_out and the edge list in, d x and the
 // gradient of [bases | weightings] out (egc_fused_tile_bwd.hip has the description).
 template <int LPR_LOG2, int HPB, int NEED, class C, int WIDE = 0, int MODE = 0>
@@ -232,6 +243,7 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
     // =====================================================================================================================
     const int ht = tid - FT_FIRST_HELPER * 64;
     if (ht == 0) lds_rec[25] = 0;            // the CSR builders' synchronisation counter (first used behind the barrier below)
+    if constexpr (MODE == 1) { if (ht == 0) lds_rec[27] = 0; }     // (largest |w'| of a tile: zero again behind every B1)
     const int Gn = (int)t.n_graphs;          // (host: n_graphs, n_nodes, n_edges < 2^31)
     const int Nn = a.n_nodes, En = (int)t.n_edges;
     int cur_g = 0, g_hi = 0;                 // (meaningful in wavefront 15 only; wave-uniform)
@@ -281,6 +293,7 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       if (lane == 0) {
         lds_rec[slot * 8 + 0] = n0; lds_rec[slot * 8 + 1] = n1; lds_rec[slot * 8 + 2] = e0; lds_rec[slot * 8 + 3] = e1;
         lds_rec[slot * 8 + 4] = valid;
+        if constexpr (MODE == 1) lds_rec[slot * 8 + 5] = 0;       // (largest |g| of the tile: the helpers' g_max below)
       }
     };
     if (wave == FT_WAVES - 1) {
@@ -338,6 +351,7 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
             if (lane == 0) {
               lds_rec[0] = p0; lds_rec[1] = p1; lds_rec[2] = e0; lds_rec[3] = e1; lds_rec[4] = 1;
               lds_rec[8] = p1; lds_rec[9] = p2; lds_rec[10] = e1; lds_rec[11] = e2; lds_rec[12] = n1k >= 1 ? 1 : 0;
+              if constexpr (MODE == 1) { lds_rec[5] = 0; lds_rec[13] = 0; }
             }
             cur_g = g2;
             last_n = p2;
@@ -608,6 +622,37 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       return __builtin_amdgcn_make_buffer_rsrc((void*)(t.x + (int64_t)r.n0 * t.F_in), 0,
                                                (unsigned)(r.ok ? r.T : 0) * (unsigned)t.F_in * 4u, 0x00020000);
     };
+    // (backward) what the rows pass needs of a tile before it starts, done here a tile ahead: the largest |g| of its rows -- the
+    // scale of the 64-bit fixed point d bases is summed in comes from it and from the largest |w'| -- into the tile's record
+    // (four batches of four 16-byte pieces per thread cover 128 rows of 128 floats; pieces beyond the tile lie outside the
+    // descriptor), and the d bases area zeroed.  (As a pass of the twelve workers behind the first GEMM, with g brought in by
+    // LDS-DMA, this was 14 k cycles per tile: every instruction of straight-line code the workers all run costs twelve cycles.)
+    auto g_max = [&](const Tile& r, int slot) {
+      if constexpr (MODE == 1) {
+        const int F_o = C::F_out(a);
+        const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)(t.grad_out + (int64_t)r.n0 * F_o), 0,
+                                                                           (unsigned)(r.ok ? r.T : 0) * (unsigned)F_o * 4u, 0x00020000);
+        unsigned m = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          f4 v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = load_slot(rg, (unsigned)(ht + (4 * b + i) * FT_HELPER_THREADS) * 16u);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            m = max(m, __float_as_uint(fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w)))));
+        }
+        m = ft_wave_umax(m);
+        if (lane == 0) __hip_atomic_fetch_max(reinterpret_cast<unsigned*>(lds_rec) + slot * 8 + 5, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    };
+    auto zero_db = [&](const Tile& r) {
+      if constexpr (MODE == 1) {
+        f4* db4 = reinterpret_cast<f4*>(base + t.off_db);       // (64-bit fixed point: two 16-byte pieces per slot)
+        const int npd = r.ok ? r.T * (a.ldb >> 1) : 0;
+        for (int i = ht; i < npd; i += FT_HELPER_THREADS) db4[i] = f4{0.f, 0.f, 0.f, 0.f};
+      }
+    };
     const Tile first = read_tile(0);
     // the first tile's CSR while its rows travel (every later one is built during the GEMM steps of the tile before)
     unsigned epk0[KEEP];
@@ -630,6 +675,8 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       csr_sync();
       csr_s3(first, 0, epk0);
     }
+    g_max(first, 0);
+    zero_db(first);
     stage01(first);
     for (int it = 0;; ++it) {
       const Tile cur = read_tile(it % 3);
@@ -661,7 +708,6 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
         if (c + 2 < RINGN && (c + 2 < RINGN / 2 || c + 2 == RINGN - 1)) x_load(xr[2 * (c + 2)], xr[2 * (c + 2) + 1], rsn, c + 2);
 #endif
       }
-      if constexpr (MODE == 1) lds_barrier();       // (the workers' scale pre-pass: largest |g| and |w'| of the tile)
 #ifdef EGC_FT_STAMPS
       unsigned long long ft_h0;
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ft_h0) :: "memory");
@@ -717,6 +763,7 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
 #ifdef EGC_FT_STAMPS
       FT_HSTAMP(2, wave == FT_FIRST_HELPER)
 #endif
+      if (nxt.valid) g_max(nxt, (it + 1) % 3);
       if constexpr (MODE == 0) {
         stage01(nxt);
         __builtin_amdgcn_s_setprio(0);
@@ -729,6 +776,7 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
         //      gradient x^T d is a launch of its own).
         __builtin_amdgcn_s_setprio(0);
         lds_barrier();                                   // (B1: the rows pass is done)
+        const double sinv = __builtin_ldexp(1.0, -__builtin_amdgcn_readfirstlane(lds_rec[28]));
         const int drow = ht >> 4, dj = ht & 15;
         const int np2 = (a.ldb + t.wl_floats) >> 6;      // pieces per thread: 2 (H = 4) or 3 (H = 8)
         auto stage_d = [&](int c, int buf) {
@@ -736,11 +784,34 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
           f4 pc[3];
           {   // d bases: 64-bit fixed point (the rows pass adds with integer LDS atomics), scale 2^-dbs in lds_rec[28]
             const long long* dq = reinterpret_cast<const long long*>(base + t.off_db) + (r * a.ldb + 4 * dj);
-            const double sinv = __builtin_ldexp(1.0, -lds_rec[28]);
             pc[0] = f4{(float)((double)dq[0] * sinv), (float)((double)dq[1] * sinv), (float)((double)dq[2] * sinv), (float)((double)dq[3] * sinv)};
           }
           pc[1] = *reinterpret_cast<const f4*>(base + t.off_wt + (r * t.wl_floats + 4 * dj) * 4);
           pc[2] = np2 > 2 ? *reinterpret_cast<const f4*>(base + t.off_wt + (r * t.wl_floats + 64 + 4 * dj) * 4) : f4{0.f, 0.f, 0.f, 0.f};
+          // ... and leave for memory as d_cat [n_nodes][ld_dcat] = [d bases (ldb) | d weightings in the layer's column order
+          // (h B + b) A + a] on the way (block (h, b) = piece dj / 16 + dj of the w' image)
+#ifdef EGC_FT_STAMPS
+          if (!(t.dbg & 2048))
+#endif
+          if (t.d_cat != nullptr && r < cur.T) {
+            float* dc = t.d_cat + (int64_t)(cur.n0 + r) * t.ld_dcat;
+            __builtin_nontemporal_store(pc[0], reinterpret_cast<f4*>(dc + 4 * dj));
+            const int Ad = C::A(a);
+#pragma unroll
+            for (int i = 1; i < 3; ++i) {
+              if (i < np2) {
+                const int hb = 16 * (i - 1) + dj;
+                if (Ad == 4) {
+                  __builtin_nontemporal_store(pc[i], reinterpret_cast<f4*>(dc + a.ldb + 4 * hb));
+                } else {
+                  float* dw = dc + a.ldb + hb * Ad;
+                  dw[0] = pc[i].x;
+                  if (Ad > 1) dw[1] = pc[i].y;
+                  if (Ad > 2) dw[2] = pc[i].z;
+                }
+              }
+            }
+          }
           float m = 0.f;
 #pragma unroll
           for (int i = 0; i < 3; ++i) m = fmaxf(fmaxf(fmaxf(m, fabsf(pc[i].x)), fmaxf(fabsf(pc[i].y), fabsf(pc[i].z))), fabsf(pc[i].w));
@@ -771,12 +842,18 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
           }
           reinterpret_cast<float*>(base + t.off_rowinv2)[buf * FT_CHUNK + drow] = __uint_as_float(e);
         };
-        if (cur.nch > 0) stage_d(0, 0);
+#ifdef EGC_FT_STAMPS
+        const bool do_stage = !(t.dbg & 8192);
+#else
+        constexpr bool do_stage = true;
+#endif
+        if (cur.nch > 0 && do_stage) stage_d(0, 0);
         lds_barrier();                                   // (A: chunk 0 of d staged)
         for (int c = 0; c < cur.nch; ++c) {
-          if (c + 1 < cur.nch) stage_d(c + 1, (c + 1) & 1);
+          if (c + 1 < cur.nch && do_stage) stage_d(c + 1, (c + 1) & 1);
           lds_barrier();
         }
+        zero_db(nxt);
         stage01(nxt);
       }
     }
@@ -1091,11 +1168,7 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
     if constexpr (WIDE == 0) asm volatile("" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]), "+v"(u[6]), "+v"(u[7]));
     lds_barrier();       // chunk 0 is staged, the tile's CSR complete, the row counter zero
     FT_STAMP(0)
-    if constexpr (MODE == 1) {   // d bases of the tile: zero (the rows pass adds into it; the GEMM steps' barriers stand in between)
-      f4* db4 = reinterpret_cast<f4*>(base + t.off_db);       // (64-bit fixed point: two 16-byte pieces per slot)
-      for (int i = tid; i < 2 * T * ldb4; i += FT_WORKER_THREADS) db4[i] = f4{0.f, 0.f, 0.f, 0.f};
-      if (tid == 0) { lds_rec[26] = 0; lds_rec[27] = 0; }
-    }
+    unsigned wmx = 0;                      // (backward: largest |w'| of the tile, kept by the GEMM's epilogue below)
 
     // ---- (G) [bases | weightings] of the tile, 16 rows per step.  The A fragments of a chunk are read in two halves: k-steps
     //      2, 3 at the start of its step (the MFMAs of k-steps 0, 1 run meanwhile), k-steps 0, 1 at the END OF THE STEP BEFORE
@@ -1174,6 +1247,9 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
         const ft_f2 ol = __builtin_elementwise_fma(ul, sl, cb2), oh = __builtin_elementwise_fma(uh, sh2, cb2);
         f4 o = __builtin_shufflevector(ol, oh, 0, 1, 2, 3);
         if (dst_act) o = w_act<C>(a, o);
+        if constexpr (MODE == 1) {
+          if (dst_act) wmx = max(wmx, __float_as_uint(fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w)))));
+        }
         if (dst_off >= 0) {
           char* po = base + dst_off + (FT_CHUNK * c + 4 * qd) * dst_stride;
           *reinterpret_cast<float*>(po) = o.x;
@@ -1183,6 +1259,13 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
         }
       }
       buf = buf + 1 == FT_PBUF ? 0 : buf + 1;
+      if constexpr (MODE == 1) {
+        // (backward) the largest |w'| of the tile, for the scale of d bases: in front of the LAST step's barrier
+        if (c + 1 == nch && dst_act) {
+          const unsigned m = ft_wave_umax(wmx);
+          if (lane == 0) __hip_atomic_fetch_max(reinterpret_cast<unsigned*>(lds_rec) + 27, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
       lds_barrier();
     }
     } else {
@@ -1413,36 +1496,15 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
     // the sum of a tile's at most 2^14 entries below 2^50 -- 34 bits under the bound where fp32 carries 24.
     int dbs_tile = 0;
     {
-      unsigned gm = 0, wm = 0;
-      if (cur.ok) {
-        const f4* g4 = reinterpret_cast<const f4*>(t.grad_out + (int64_t)n0 * F_out);
-        for (int i = tid; i < T * (F_out >> 2); i += FT_WORKER_THREADS) {
-          const f4 v = g4[i];
-          gm = max(gm, __float_as_uint(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)))));
-        }
-        const f4* w4 = reinterpret_cast<const f4*>(lds_wt);
-        for (int i = tid; i < T * (t.wl_floats >> 2); i += FT_WORKER_THREADS) {
-          const f4 v = w4[i];
-          wm = max(wm, __float_as_uint(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)))));
-        }
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-          gm = max(gm, (unsigned)bperm((lane ^ off) << 2, (int)gm));
-          wm = max(wm, (unsigned)bperm((lane ^ off) << 2, (int)wm));
-        }
-        if (lane == 0) {
-          atomicMax(reinterpret_cast<unsigned*>(lds_rec) + 26, gm);
-          atomicMax(reinterpret_cast<unsigned*>(lds_rec) + 27, wm);
-        }
-      }
-      lds_barrier();
-      const int eg = (int)((unsigned)__builtin_amdgcn_readfirstlane(lds_rec[26]) >> 23) - 127;
+      // (largest |g|: by the helpers a tile ahead, in the tile's record; largest |w'|: the GEMM's epilogue, above)
+      const int eg = (int)((unsigned)__builtin_amdgcn_readfirstlane(lds_rec[(it % 3) * 8 + 5]) >> 23) - 127;
       const int ew = (int)((unsigned)__builtin_amdgcn_readfirstlane(lds_rec[27]) >> 23) - 127;
       int dbs = 34 - (eg + 1) - (ew + 1) - 5;      // (H <= 8: 3 bits; A <= 4: 2 bits)
       dbs = dbs < -1000 ? -1000 : (dbs > 1000 ? 1000 : dbs);
       if (tid == 0) lds_rec[28] = dbs;             // (for the helpers, who stage d bases behind barrier B1; every wavefront here
       dbs_tile = dbs;                               //  forms the same number from the two maxima itself)
     }
+    FT_STAMP(1)
     const double db_scale = __builtin_ldexp(1.0, dbs_tile);
     const __amdgpu_buffer_rsrc_t rgo =
         __builtin_amdgcn_make_buffer_rsrc((void*)t.grad_out, 0, (unsigned)a.n_nodes * (unsigned)F_out * 4u, 0x00020000);
@@ -1655,34 +1717,7 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
         col_inv2 = reinterpret_cast<const float*>(t.packed_t + (int64_t)8 * 6 * 2 * 64 * 8)[16 * (is_mfma2 ? wave : 0) + (lv & 15)];
       }
       lds_barrier();   // (B1: every row's d bases / d w' are in the images)
-      // d_cat [n_nodes][ld_dcat] = [d bases (ldb) | d weightings in the layer's column order (h B + b) A + a]: written by the
-      // wavefronts that have no column tile in the second GEMM (in the helpers' staging every reload of a spilled register
-      // waited for these stores: vmcnt counts stores too)
-      if (t.d_cat != nullptr && wave >= 8 && cur.ok) {
-        const int tw = tid - 8 * 64;
-        const int Ad = C::A(a), npr = (a.ldb + t.wl_floats) >> 2;      // 16-byte pieces per row of the two images
-        for (int p = tw; p < T * npr; p += (FT_MFMA_WAVES - 8) * 64) {
-          const int rr = p / npr, pc = p - rr * npr;
-          float* dc = t.d_cat + (int64_t)(n0 + rr) * t.ld_dcat;
-          if (pc < ldb4) {
-            const long long* dq = reinterpret_cast<const long long*>(base + t.off_db) + (rr * a.ldb + 4 * pc);
-            const double sinv = __builtin_ldexp(1.0, -__builtin_amdgcn_readfirstlane(lds_rec[28]));
-            __builtin_nontemporal_store(f4{(float)((double)dq[0] * sinv), (float)((double)dq[1] * sinv), (float)((double)dq[2] * sinv),
-                                           (float)((double)dq[3] * sinv)}, reinterpret_cast<f4*>(dc + 4 * pc));
-          } else {
-            const int hb = pc - ldb4;                                   // block (h, b)
-            const f4 v = *reinterpret_cast<const f4*>(base + t.off_wt + (rr * t.wl_floats + 4 * hb) * 4);
-            if (Ad == 4) {
-              __builtin_nontemporal_store(v, reinterpret_cast<f4*>(dc + a.ldb + 4 * hb));
-            } else {
-              float* dw = dc + a.ldb + hb * Ad;
-              dw[0] = v.x;
-              if (Ad > 1) dw[1] = v.y;
-              if (Ad > 2) dw[2] = v.z;
-            }
-          }
-        }
-      }
+      if (tid == 0) lds_rec[27] = 0;
       lds_barrier();   // (A: the helpers have staged chunk 0)
       const __amdgpu_buffer_rsrc_t rdx = __builtin_amdgcn_make_buffer_rsrc(
           (void*)(t.d_x + (int64_t)n0 * t.F_in), 0, (unsigned)(cur.ok ? T : 0) * (unsigned)t.F_in * 4u, 0x00020000);
@@ -1691,6 +1726,9 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       const int m2 = lvm & 15, qd2 = lvm >> 4;
       int buf2 = 0;
       for (int c = 0; c < nch; ++c) {
+#ifdef EGC_FT_STAMPS
+        if (!(t.dbg & 4096))
+#endif
         if (is_mfma2) {
           const char* pa = lds_planes + buf2 * FTB_PBUF_BYTES + m2 * FTB_ROW_BYTES + qd2 * 16;
           f4 acc0 = f4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0;
