@@ -980,8 +980,9 @@ int egc_batch_fused_bwd_pack(const egc_layer* layer, const float* wcat, void* pa
 int egc_layer_backward_batch_fused_f32(const int64_t* graph_ptr, const int64_t* edge_ptr, int64_t n_graphs, const int64_t* src,
                                        const int64_t* dst, int64_t n_edges, int64_t n_nodes, const int32_t* max_index,
                                        const egc_layer* layer, const float* x, const void* packed, const void* packed_t,
-                                       const float* grad_out, float* d_x, float* d_cat, int32_t ld_dcat, int32_t tile_nodes,
-                                       int32_t max_tile_edges, int32_t* status, int32_t* host_flag, egc_stream_t stream) {
+                                       const float* grad_out, float* d_x, const float* d_x_add, float* d_cat, int32_t ld_dcat,
+                                       int32_t tile_nodes, int32_t max_tile_edges, int32_t* status, int32_t* host_flag,
+                                       egc_stream_t stream) {
   AggArgs a;
   int st = tile_layer_args(layer, a);
   if (st != EGC_OK) return st;
@@ -993,7 +994,8 @@ int egc_layer_backward_batch_fused_f32(const int64_t* graph_ptr, const int64_t* 
     return EGC_ERR_INVALID;
   if (n_edges > 0 && (src == nullptr || dst == nullptr)) return EGC_ERR_INVALID;
   if ((reinterpret_cast<uintptr_t>(x) & 15) != 0 || (reinterpret_cast<uintptr_t>(packed) & 15) != 0 ||
-      (reinterpret_cast<uintptr_t>(packed_t) & 15) != 0 || (reinterpret_cast<uintptr_t>(grad_out) & 15) != 0)
+      (reinterpret_cast<uintptr_t>(packed_t) & 15) != 0 || (reinterpret_cast<uintptr_t>(grad_out) & 15) != 0 ||
+      (reinterpret_cast<uintptr_t>(d_x_add) & 3) != 0)
     return EGC_ERR_INVALID;
   if (d_cat != nullptr && (ld_dcat < a.ldb + a.W || (ld_dcat & 3) != 0 || (reinterpret_cast<uintptr_t>(d_cat) & 15) != 0)) return EGC_ERR_INVALID;
   if (!a.loops_all && max_index == nullptr) return EGC_ERR_INVALID;
@@ -1007,7 +1009,7 @@ int egc_layer_backward_batch_fused_f32(const int64_t* graph_ptr, const int64_t* 
   a.dis = layer_uses_symnorm(layer) ? x : nullptr;   // (a flag: the deg^-1/2 tables are built per tile, in LDS)
   a.self_pos = 0;
   return launch_fused_tile_bwd(a, graph_ptr, edge_ptr, n_graphs, src, dst, n_edges, max_index, x, layer->in_channels, packed, packed_t,
-                               grad_out, d_x, d_cat, ld_dcat, tile_nodes, max_tile_edges, status, host_flag, (hipStream_t)stream);
+                               grad_out, d_x, d_x_add, d_cat, ld_dcat, tile_nodes, max_tile_edges, status, host_flag, (hipStream_t)stream);
 }
 
 int32_t egc_layer_gemm_flags(const egc_layer* layer) {

@@ -452,7 +452,7 @@ static int launch_ftb_one(const AggArgs& a, const FusedTileArgs& t, unsigned gri
 
 int launch_fused_tile_bwd(AggArgs a, const int64_t* ptr, const int64_t* edge_ptr, int64_t n_graphs, const int64_t* src,
                           const int64_t* dst, int64_t n_edges, const int* max_index, const float* x, int f_in, const void* packed,
-                          const void* packed_t, const float* grad_out, float* d_x, float* d_cat, int ld_dcat, int tcap, int emax,
+                          const void* packed_t, const float* grad_out, float* d_x, const float* d_x_add, float* d_cat, int ld_dcat, int tcap, int emax,
                           int32_t* status, int32_t* host_flag, hipStream_t stream) {
   if (!fused_tile_bwd_shape(a, f_in)) return EGC_ERR_UNSUPPORTED;
   a.lanes_pb = a.Ls / 4;
@@ -474,7 +474,7 @@ int launch_fused_tile_bwd(AggArgs a, const int64_t* ptr, const int64_t* edge_ptr
   t.w_aw = 4;
   t.wl_floats = a.H * a.B * 4;
   t.nsets = 1;
-  t.grad_out = grad_out; t.d_x = d_x; t.d_cat = d_cat; t.ld_dcat = ld_dcat; t.packed_t = (const ft_u16*)packed_t;
+  t.grad_out = grad_out; t.d_x = d_x; t.d_x_add = d_x_add; t.d_cat = d_cat; t.ld_dcat = ld_dcat; t.packed_t = (const ft_u16*)packed_t;
   if (const char* e = getenv("EGC_FT_DBG")) t.dbg = atoi(e);     // (read by diagnostic builds of the kernel only: -DEGC_FT_STAMPS)
   if (tcap < FT_CHUNK || tcap > FT_CHUNK * 8 || (tcap % FT_CHUNK) != 0 || emax < 0 || emax > 16384) return EGC_ERR_INVALID;
   const FtLds L = ft_lds(a, t.wl_floats, tcap, emax, false, false, true);

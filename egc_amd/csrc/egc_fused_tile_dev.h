@@ -92,6 +92,7 @@ struct FusedTileArgs {
   // backward form only (MODE == 1: fused_tile_bwd, egc_fused_tile_bwd.hip)
   const float* grad_out;     // [n_nodes, F_out]
   float* d_x;                // [n_nodes, F_in]
+  const float* d_x_add;      // [n_nodes, F_in] added to d_x in its store (the gradient reaching x past the layer), or nullptr
   float* d_cat;              // [n_nodes, ld_dcat]: the gradient of [bases | pre-activation weightings] (what x^T d needs), or nullptr
   int ld_dcat;
   const ft_u16* packed_t;    // [8][6][2][64][8] fp16 fragments of [bases_weight | comb_weight^T]^T, float col_inv[128]
@@ -1721,6 +1722,10 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       lds_barrier();   // (A: the helpers have staged chunk 0)
       const __amdgpu_buffer_rsrc_t rdx = __builtin_amdgcn_make_buffer_rsrc(
           (void*)(t.d_x + (int64_t)n0 * t.F_in), 0, (unsigned)(cur.ok ? T : 0) * (unsigned)t.F_in * 4u, 0x00020000);
+      // (what reaches x past the layer: read at the start of a step, added in the store; without it a descriptor of no bytes)
+      const __amdgpu_buffer_rsrc_t rda = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(t.d_x_add != nullptr ? t.d_x_add + (int64_t)n0 * t.F_in : t.x), 0,
+          (unsigned)((cur.ok && t.d_x_add != nullptr) ? T : 0) * (unsigned)t.F_in * 4u, 0x00020000);
       int lvm = lane;
       asm volatile("" : "+v"(lvm));
       const int m2 = lvm & 15, qd2 = lvm >> 4;
@@ -1730,6 +1735,13 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
         if (!(t.dbg & 4096))
 #endif
         if (is_mfma2) {
+          const int f = 16 * wave + m2;
+          const unsigned off0 = f < t.F_in ? ((unsigned)(FT_CHUNK * c + 4 * qd2) * (unsigned)t.F_in + (unsigned)f) * 4u : OOB;
+          const unsigned rs4 = (unsigned)t.F_in * 4u;
+          const float ad0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rda, off0, 0, 0));
+          const float ad1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rda, off0 == OOB ? OOB : off0 + rs4, 0, 0));
+          const float ad2 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rda, off0 == OOB ? OOB : off0 + 2 * rs4, 0, 0));
+          const float ad3 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rda, off0 == OOB ? OOB : off0 + 3 * rs4, 0, 0));
           const char* pa = lds_planes + buf2 * FTB_PBUF_BYTES + m2 * FTB_ROW_BYTES + qd2 * 16;
           f4 acc0 = f4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0;
 #pragma unroll
@@ -1745,11 +1757,8 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
           }
           const f4 ri = *reinterpret_cast<const f4*>(reinterpret_cast<const float*>(base + t.off_rowinv2) + buf2 * FT_CHUNK + 4 * qd2);
           const f4 tt4 = acc1 + acc2;
-          const f4 o = f4{__builtin_fmaf(tt4.x, 1.f / 2048.f, acc0.x) * (col_inv2 * ri.x), __builtin_fmaf(tt4.y, 1.f / 2048.f, acc0.y) * (col_inv2 * ri.y),
-                          __builtin_fmaf(tt4.z, 1.f / 2048.f, acc0.z) * (col_inv2 * ri.z), __builtin_fmaf(tt4.w, 1.f / 2048.f, acc0.w) * (col_inv2 * ri.w)};
-          const int f = 16 * wave + m2;
-          const unsigned off0 = f < t.F_in ? ((unsigned)(FT_CHUNK * c + 4 * qd2) * (unsigned)t.F_in + (unsigned)f) * 4u : OOB;
-          const unsigned rs4 = (unsigned)t.F_in * 4u;
+          const f4 o = f4{__builtin_fmaf(tt4.x, 1.f / 2048.f, acc0.x) * (col_inv2 * ri.x) + ad0, __builtin_fmaf(tt4.y, 1.f / 2048.f, acc0.y) * (col_inv2 * ri.y) + ad1,
+                          __builtin_fmaf(tt4.z, 1.f / 2048.f, acc0.z) * (col_inv2 * ri.z) + ad2, __builtin_fmaf(tt4.w, 1.f / 2048.f, acc0.w) * (col_inv2 * ri.w) + ad3};
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o.x), rdx, off0, 0, 0);
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o.y), rdx, off0 == OOB ? OOB : off0 + rs4, 0, 0);
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o.z), rdx, off0 == OOB ? OOB : off0 + 2 * rs4, 0, 0);

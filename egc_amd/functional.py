@@ -450,9 +450,33 @@ def _batch_fused_train_setup(gb: GraphBatch, spec: LayerSpec, x):
     return (fs, bs) if fs is not None else None
 
 
-def egc_layer_backward_batch_fused(gb: GraphBatch, spec: LayerSpec, x, wcat, packed, grad_out, setup):
+class ResidualLink:
+    """What lets the gradient of a block's residual branch (x = x + relu(bn(conv(x))), zinc/models.py:70-73) join d x inside the
+    conv's backward launch instead of in a pass of autograd's own.  The block (egc_amd.FusedEGCBlock) offers one around its conv
+    call (`offer`); the one-launch training path takes it (`taken`); the tail's backward -- which autograd runs first -- then
+    leaves its incoming gradient here (`grad`) and reports none for the residual input, and the conv's backward hands it to
+    egc_layer_backward_batch_fused_f32 as `d_x_add`.  Only ever used when the residual input IS the conv's input."""
+    __slots__ = ("taken", "grad")
+    _offered = None
+
+    def __init__(self):
+        self.taken, self.grad = False, None
+
+    @classmethod
+    def offer(cls, link):
+        cls._offered = link
+
+    @classmethod
+    def take(cls):
+        link, cls._offered = cls._offered, None
+        if link is not None:
+            link.taken = True
+        return link
+
+
+def egc_layer_backward_batch_fused(gb: GraphBatch, spec: LayerSpec, x, wcat, packed, grad_out, setup, d_x_add=None):
     """(d x [N, F_in], d_cat [N, ldb + W]) of one layer on a batch of whole graphs in ONE launch (egc_layer_backward_batch_fused_f32):
-    the forward's intermediates are formed again in LDS, nothing was saved but x."""
+    the forward's intermediates are formed again in LDS, nothing was saved but x.  ``d_x_add`` [N, F_in]: added to d x in its store."""
     lib = _C.load()
     _IndexFlag.poll()
     n = gb.n_nodes
@@ -460,6 +484,9 @@ def egc_layer_backward_batch_fused(gb: GraphBatch, spec: LayerSpec, x, wcat, pac
     dev = x.device
     grad_out = grad_out.contiguous()
     _check_f32(grad_out, "grad_out", (n, spec.f_out))
+    if d_x_add is not None:
+        d_x_add = d_x_add.contiguous()
+        _check_f32(d_x_add, "d_x_add", (n, spec.f_in))
     with _device_guard(dev):
         nb = int(lib.egc_batch_fused_bwd_pack_bytes(C.byref(spec.c)))
         if nb <= 0:
@@ -474,8 +501,8 @@ def egc_layer_backward_batch_fused(gb: GraphBatch, spec: LayerSpec, x, wcat, pac
         _C.check(lib.egc_layer_backward_batch_fused_f32(
             gb.ptr.data_ptr(), gb.edge_ptr.data_ptr() if gb.edge_ptr is not None else None, gb.n_graphs, ei[0].data_ptr(),
             ei[1].data_ptr(), gb.n_edges, n, gb.max_index().data_ptr() if needs_max else None, C.byref(spec.c), x.data_ptr(),
-            packed.data_ptr(), packed_t.data_ptr(), grad_out.data_ptr(), d_x.data_ptr(), d_cat.data_ptr(), int(d_cat.stride(0)),
-            tile_nodes, emax, gb.status().data_ptr(), _IndexFlag.ptr(), stream), "egc_layer_backward_batch_fused_f32")
+            packed.data_ptr(), packed_t.data_ptr(), grad_out.data_ptr(), d_x.data_ptr(),
+            d_x_add.data_ptr() if d_x_add is not None else None, d_cat.data_ptr(), int(d_cat.stride(0)), tile_nodes, emax, gb.status().data_ptr(), _IndexFlag.ptr(), stream), "egc_layer_backward_batch_fused_f32")
     return d_x, d_cat
 
 
@@ -485,8 +512,8 @@ class _BatchFusedTrainFunction(torch.autograd.Function):
     weight gradient x^T d_cat with the bias sums riding along.  Same arguments and gradients as _EGCLayerParamsFunction."""
 
     @staticmethod
-    def forward(ctx, x, bias, comb_w, comb_b, bcat_direct, gb, spec, dims, permute, setups, *bases):
-        ctx.dims, ctx.permute, ctx.packed_b = dims, permute, comb_b is not None
+    def forward(ctx, x, bias, comb_w, comb_b, bcat_direct, gb, spec, dims, permute, setups, link, *bases):
+        ctx.dims, ctx.permute, ctx.packed_b, ctx.link = dims, permute, comb_b is not None, link
         ctx.shapes = (comb_w.shape, comb_b.shape if comb_b is not None else None, [b.shape for b in bases])
         wcat, bcat = _pack_params(dims, permute, comb_w, comb_b, bases)
         bc = bcat if comb_b is not None else bcat_direct
@@ -503,8 +530,13 @@ class _BatchFusedTrainFunction(torch.autograd.Function):
         x, wcat, packed = ctx.saved_tensors
         spec = ctx.spec
         grad_out = grad_out.contiguous()
-        dx, d_cat = egc_layer_backward_batch_fused(ctx.gb, spec, x, wcat, packed, grad_out, ctx.bsetup)
-        need_w = need[2] or any(need[10:])
+        add = None
+        if ctx.link is not None:                 # (the residual branch's gradient, left by the block's tail: see ResidualLink)
+            add, ctx.link.grad = ctx.link.grad, None
+            if add is not None and (add.shape != x.shape or add.dtype != torch.float32 or add.device != x.device):
+                raise RuntimeError("egc_amd: the residual gradient handed to the conv's backward does not have the shape of x")
+        dx, d_cat = egc_layer_backward_batch_fused(ctx.gb, spec, x, wcat, packed, grad_out, ctx.bsetup, add if need[0] else None)
+        need_w = need[2] or any(need[11:])
         need_b = ctx.has_bcat and (need[3] if ctx.packed_b else need[4])
         need_bias = ctx.has_bias and need[1]
         dwcat = dbcat = dbias = None
@@ -523,7 +555,7 @@ class _BatchFusedTrainFunction(torch.autograd.Function):
         if need_w or (need_b and ctx.packed_b):
             dcw, dcb, dparts = _unpack_param_grads(ctx.dims, ctx.permute, ctx.shapes, ctx.packed_b, dwcat,
                                                    dbcat if ctx.packed_b else None)
-        return (dx if need[0] else None, dbias, dcw, dcb, None if ctx.packed_b else dbcat, None, None, None, None, None, *dparts)
+        return (dx if need[0] else None, dbias, dcw, dcb, None if ctx.packed_b else dbcat, None, None, None, None, None, None, *dparts)
 
 
 def segment_mean(x: torch.Tensor, seg_ptr: torch.Tensor) -> torch.Tensor:
@@ -1060,10 +1092,11 @@ class _BatchNormActResidualFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, residual, gamma, beta, eps, relu, running_mean, running_var, momentum, n_tracked, keep, keep_scale,
-                n_valid, sync=None):
+                n_valid, sync=None, res_link=None):
         lib = _C.load()
         n, c = h.shape
         dev = h.device
+        ctx.res_link = res_link
         h = h.contiguous()
         gamma_c = gamma.detach().contiguous().float() if gamma is not None else None
         beta_c = beta.detach().contiguous().float() if beta is not None else None
@@ -1110,7 +1143,7 @@ class _BatchNormActResidualFunction(torch.autograd.Function):
         n, c = h.shape
         dev = h.device
         if dout is None:
-            return (None,) * 14
+            return (None,) * 15
         dout = dout.contiguous()
         dh = dgamma = dbeta = None
         if ctx.needs_input_grad[0] or (ctx.has_gamma and ctx.needs_input_grad[2]) or (ctx.has_beta and ctx.needs_input_grad[3]):
@@ -1148,7 +1181,9 @@ class _BatchNormActResidualFunction(torch.autograd.Function):
                                                              dh.data_ptr(), n_valid.data_ptr() if n_valid is not None else None,
                                                              stream), "egc_affine_act_backward_f32")
         dres = dout if ctx.has_res and ctx.needs_input_grad[1] else None
-        return dh, dres, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
+        if dres is not None and ctx.res_link is not None:
+            ctx.res_link.grad, dres = dres, None      # (joins d x inside the conv's backward launch: ResidualLink)
+        return dh, dres, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None
 
 
 def batch_norm_act_residual_supported(h: torch.Tensor) -> bool:
@@ -1158,7 +1193,7 @@ def batch_norm_act_residual_supported(h: torch.Tensor) -> bool:
 
 def batch_norm_act_residual(h, residual, gamma, beta, eps: float, relu: bool, running_mean=None, running_var=None,
                             momentum=None, num_batches_tracked=None, keep=None, keep_scale: float = 1.0, n_valid=None,
-                            sync=None):
+                            sync=None, res_link=None):
     """Training-mode BatchNorm1d (batch statistics) -> optional ReLU -> optional residual add, fused
     (_BatchNormActResidualFunction): returns (out, batch mean [C] float64, biased batch variance [C] float64).
     With ``running_mean`` / ``running_var`` (float32 [C], dense) the running statistics are updated in the same launch
@@ -1182,7 +1217,7 @@ def batch_norm_act_residual(h, residual, gamma, beta, eps: float, relu: bool, ru
     if n_valid is not None and (n_valid.dtype != torch.int64 or n_valid.numel() != 1 or n_valid.device != h.device):
         raise RuntimeError("egc_amd: n_valid must be an int64 scalar on the device of h")
     return _BatchNormActResidualFunction.apply(h, residual, gamma, beta, float(eps), bool(relu), running_mean, running_var,
-                                               momentum, num_batches_tracked, keep, float(keep_scale), n_valid, sync)
+                                               momentum, num_batches_tracked, keep, float(keep_scale), n_valid, sync, res_link)
 
 
 def egc_aggregate_combine_apply(graph, spec, bases, weightings, bias=None):
@@ -1205,7 +1240,7 @@ def egc_layer_apply_params(graph, spec, x, bias, comb_w, comb_b, bcat_direct, ba
         if setups is not None:
             return _BatchFusedTrainFunction.apply(x, bias, comb_w, comb_b, bcat_direct, graph, spec,
                                                   (int(f_in), int(H), int(A), int(B), int(L), int(Ls)), bool(permute_hab), setups,
-                                                  *bases)
+                                                  ResidualLink.take() if x.requires_grad else None, *bases)
     return _EGCLayerParamsFunction.apply(x, bias, comb_w, comb_b, bcat_direct, _as_csr(graph), spec,
                                          (int(f_in), int(H), int(A), int(B), int(L), int(Ls)), bool(permute_hab), *bases)
 

@@ -17,7 +17,7 @@ import torch
 from . import _C
 import torch.nn as nn
 
-from .functional import (PostOp, batch_norm_act_residual, batch_norm_act_residual_supported, egc_layer_forward,
+from .functional import (PostOp, ResidualLink, batch_norm_act_residual, batch_norm_act_residual_supported, egc_layer_forward,
                          segment_mean)
 from .graph import GraphBatch, graph_from_input
 
@@ -60,8 +60,18 @@ class FusedEGCBlock(nn.Module):
         """conv, then BatchNorm1d on batch statistics -> ReLU -> + input in two passes; the running statistics are
         updated as nn.BatchNorm1d does (momentum or cumulative average, unbiased variance)."""
         bn = self.bn
+        # the residual branch's gradient may join d x inside the conv's backward launch (functional.ResidualLink): offered when
+        # the residual adds the conv's own input, taken by the one-launch training path of a GraphBatch
+        link = None
+        if self.residual and identity is None and torch.is_grad_enabled() and x.requires_grad and not _C.env_flag("EGC_NO_RESIDUAL_LINK"):
+            link = ResidualLink()
         identity = x if identity is None else identity
-        h = self.conv(x=x, edge_index=edge_index) if hasattr(self.conv, "aggs") else self.conv(x, edge_index)
+        ResidualLink.offer(link)
+        try:
+            h = self.conv(x=x, edge_index=edge_index) if hasattr(self.conv, "aggs") else self.conv(x, edge_index)
+        finally:
+            ResidualLink.offer(None)
+        link = link if (link is not None and link.taken) else None
         if not batch_norm_act_residual_supported(h) or (self.residual and identity.shape != h.shape):
             if n_valid is not None:
                 raise RuntimeError("egc_amd: n_valid needs the fused training tail (float32 CUDA activations, channels % 4 == 0)")
@@ -85,7 +95,8 @@ class FusedEGCBlock(nn.Module):
             h, identity if self.residual else None, bn.weight if bn.affine else None, bn.bias if bn.affine else None, bn.eps,
             self.relu, bn.running_mean if in_place else None, bn.running_var if in_place else None, bn.momentum,
             bn.num_batches_tracked if counted else None, keep, 1.0 / (1.0 - self.dropout), n_valid,
-            sync=self._bn_sync if (self._bn_sync.device == h.device and _C.env_flag("EGC_BN_ONE_LAUNCH")) else None)
+            sync=self._bn_sync if (self._bn_sync.device == h.device and _C.env_flag("EGC_BN_ONE_LAUNCH")) else None,
+            res_link=link)
         if track and not in_place:               # running statistics kept in another dtype: torch's arithmetic
             with torch.no_grad():
                 n = h.size(0)

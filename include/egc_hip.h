@@ -579,6 +579,9 @@ int egc_layer_forward_batch_fused_f32(const int64_t* graph_ptr, const int64_t* e
  *   egc_batch_fused_bwd_tile_nodes   rows of a tile (its image also holds d bases: 96 - 112 at the north star), 0 = outside
  *   egc_batch_fused_bwd_pack[_bytes] wcat -> the transposed operand's fp16 planes; once per parameter update
  *   egc_layer_backward_batch_fused_f32   `packed` = egc_batch_fused_pack's buffer (the forward operand, for the recompute);
+ *                                    `d_x_add` [n_nodes, in_channels] or NULL: added to d_x in its store -- the gradient that
+ *                                    reaches x past the layer (the residual branch of the reference's blocks, zinc/models.py:
+ *                                    70-73: x = x + relu(bn(conv(x)))), which autograd otherwise adds in a pass of its own;
  *                                    status / host_flag as the forward launch.
  * ------------------------------------------------------------------------------------------ */
 int32_t egc_batch_fused_bwd_tile_nodes(const egc_layer* layer, int32_t max_tile_edges);
@@ -587,8 +590,9 @@ int egc_batch_fused_bwd_pack(const egc_layer* layer, const float* wcat, void* pa
 int egc_layer_backward_batch_fused_f32(const int64_t* graph_ptr, const int64_t* edge_ptr, int64_t n_graphs, const int64_t* src,
                                        const int64_t* dst, int64_t n_edges, int64_t n_nodes, const int32_t* max_index,
                                        const egc_layer* layer, const float* x, const void* packed, const void* packed_t,
-                                       const float* grad_out, float* d_x, float* d_cat, int32_t ld_dcat, int32_t tile_nodes,
-                                       int32_t max_tile_edges, int32_t* status, int32_t* host_flag, egc_stream_t stream);
+                                       const float* grad_out, float* d_x, const float* d_x_add, float* d_cat, int32_t ld_dcat,
+                                       int32_t tile_nodes, int32_t max_tile_edges, int32_t* status, int32_t* host_flag,
+                                       egc_stream_t stream);
 
 /* Whole layer forward = egc_basis_transform_f32 + egc_aggregate_combine_f32
  * (EfficientGraphConv.forward layers.py:89-140 / EGConv.forward optimized_layers.py:177-210

@@ -153,3 +153,90 @@ def test_switch_and_oversize_graphs(monkeypatch):
         x = torch.randn(n, 128, device=dev, requires_grad=True)
         conv(x, gb).sum().backward()
         assert _ran_bwd(gb) == expect
+
+
+def test_residual_gradient_joins_d_x_in_the_launch(monkeypatch):
+    """A block x + relu(bn(conv(x))) (zinc/models.py:70-73): the residual branch's gradient is added to d x inside the conv's
+    backward launch (`d_x_add`, functional.ResidualLink) -- same gradients as with autograd's own add (EGC_NO_RESIDUAL_LINK=1),
+    for a stack of blocks and for the first block, whose input takes no gradient."""
+    import egc_amd
+    import torch.nn as nn
+    from egc_amd import functional as F
+    dev = _dev()
+    ei, n, ptr = _messy_batch(9, max_size=80)
+    torch.manual_seed(3)
+    blocks = nn.ModuleList([egc_amd.FusedEGCBlock(
+        egc_amd.EGConv(128, 128, aggrs=["sum", "mean", "max", "symnorm"], num_heads=8, num_bases=4), nn.BatchNorm1d(128))
+        for _ in range(3)]).to(dev).train()
+    x0 = torch.randn(n, 128, device=dev)
+    go = torch.randn(n, 128, device=dev)
+    res = {}
+    calls = []
+    real = F.egc_layer_backward_batch_fused
+    monkeypatch.setattr(F, "egc_layer_backward_batch_fused", lambda *a, **k: (calls.append(len(a) > 7 and a[7] is not None), real(*a, **k))[1])
+    for mode in ("link", "plain"):
+        if mode == "plain":
+            monkeypatch.setenv("EGC_NO_RESIDUAL_LINK", "1")
+        else:
+            monkeypatch.delenv("EGC_NO_RESIDUAL_LINK", raising=False)
+        for p in blocks.parameters():
+            p.grad = None
+        calls.clear()
+        gb = egc_amd.GraphBatch(ei.to(dev), ptr=ptr.to(dev), max_nodes=80)
+        h = x0.clone().requires_grad_(mode == "link")      # (with and without a gradient for the first block's input)
+        hin = h
+        for b in blocks:
+            h = b(h, gb)
+        h.backward(go)
+        gb.check()
+        assert _ran_bwd(gb)
+        res[mode] = ([p.grad.clone() for p in blocks.parameters()], hin.grad.clone() if hin.grad is not None else None, list(calls))
+    # backward runs last block first: with the link every block whose input takes a gradient hands its residual gradient in
+    assert res["link"][2] == [True, True, True] and res["plain"][2] == [False, False, False]
+    # (one scale for all: the conv bias in front of BatchNorm has a gradient of exactly zero, i.e. rounding noise, in both)
+    scale = max(float(b.abs().max()) for b in res["plain"][0])
+    for a, b in zip(res["link"][0], res["plain"][0]):
+        assert float((a - b).abs().max()) <= 2e-5 * scale
+    # d x of the first block against float64 autograd of the same stack through the CSR path's modules is covered above;
+    # here: the linked d x equals grad through the plain path recomputed with a gradient for x
+    monkeypatch.setenv("EGC_NO_RESIDUAL_LINK", "1")
+    for p in blocks.parameters():
+        p.grad = None
+    gb = egc_amd.GraphBatch(ei.to(dev), ptr=ptr.to(dev), max_nodes=80)
+    h = x0.clone().requires_grad_(True)
+    hin = h
+    for b in blocks:
+        h = b(h, gb)
+    h.backward(go)
+    ref = hin.grad
+    assert float((res["link"][1] - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+def test_d_x_add_through_the_c_abi():
+    """egc_layer_backward_batch_fused_f32 with d_x_add: d x = (d x without it) + d_x_add (two launches differ by the rounding of
+    the recomputed aggregates' summation order, 1e-6 of the largest entry)."""
+    import egc_amd
+    from egc_amd import functional as F
+    dev = _dev()
+    ei, n, ptr = _messy_batch(12, n_graphs=60, max_size=80)
+    conv = egc_amd.EGConv(128, 128, aggrs=["sum", "mean", "max", "symnorm"], num_heads=8, num_bases=4).to(dev).train()
+    gb = egc_amd.GraphBatch(ei.to(dev), ptr=ptr.to(dev), max_nodes=80)
+    x = torch.randn(n, 128, device=dev, requires_grad=True)
+    got = {}
+    real = F.egc_layer_backward_batch_fused
+    add = torch.randn(n, 128, device=dev)
+
+    def spy(gbb, spec, xx, wcat, packed, grad_out, setup, d_x_add=None):
+        got["plain"] = real(gbb, spec, xx, wcat, packed, grad_out, setup)[0]
+        got["added"] = real(gbb, spec, xx, wcat, packed, grad_out, setup, add)[0]
+        return real(gbb, spec, xx, wcat, packed, grad_out, setup, d_x_add)
+    orig = F.egc_layer_backward_batch_fused
+    F.egc_layer_backward_batch_fused = spy
+    try:
+        conv(x, gb).backward(torch.randn(n, 128, device=dev))
+    finally:
+        F.egc_layer_backward_batch_fused = orig
+    gb.check()
+    err = float((got["added"] - (got["plain"] + add)).abs().max())
+    assert err <= 2e-6 * float(got["plain"].abs().max()), err
+    assert float((got["added"] - got["plain"]).abs().max()) > 0.5         # (it was added)
