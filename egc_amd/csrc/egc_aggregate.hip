@@ -977,6 +977,19 @@ int egc_batch_fused_bwd_pack(const egc_layer* layer, const float* wcat, void* pa
   return fused_tile_bwd_pack(a, wcat, layer->in_channels, packed_t, (hipStream_t)stream);
 }
 
+int egc_batch_fused_train_pack(const egc_layer* layer, const float* wcat, const float* bcat, void* packed, int64_t packed_bytes,
+                               void* packed_t, int64_t packed_t_bytes, egc_stream_t stream) {
+  AggArgs a, ab;
+  int st = tile_layer_args(layer, a, true);
+  if (st == EGC_OK) st = tile_layer_args(layer, ab);
+  if (st != EGC_OK) return st;
+  if (!fused_tile_shape(a, layer->in_channels) || !fused_tile_bwd_shape(ab, layer->in_channels)) return EGC_ERR_UNSUPPORTED;
+  if (wcat == nullptr || packed == nullptr || packed_t == nullptr || packed_bytes < (int64_t)fused_tile_pack_bytes(a, layer->in_channels) ||
+      packed_t_bytes < (int64_t)fused_tile_bwd_pack_bytes())
+    return EGC_ERR_INVALID;
+  return fused_tile_train_pack(ab, wcat, bcat, layer->in_channels, a.B * a.Ls, a.W, a.ldb, packed, packed_t, (hipStream_t)stream);
+}
+
 int egc_layer_backward_batch_fused_f32(const int64_t* graph_ptr, const int64_t* edge_ptr, int64_t n_graphs, const int64_t* src,
                                        const int64_t* dst, int64_t n_edges, int64_t n_nodes, const int32_t* max_index,
                                        const egc_layer* layer, const float* x, const void* packed, const void* packed_t,

@@ -36,9 +36,8 @@ namespace egc {
 // packed[column tile][k-step of 32][plane][lane][8]: lane 16 (k % 32 / 8) + column % 16 holds k = 32 s + 8 (lane / 16) ..+7 of
 // column 16 ct + lane % 16 -- the B operand of v_mfma_f32_16x16x32_f16 as it is loaded, one KiB per (ct, s, plane).
 // Column scales and the two planes as pack_f16x2_kernel (egc_gemm_f16x2.hip).
-__global__ void __launch_bounds__(64) ft_pack_kernel(const float* __restrict__ wcat, const float* __restrict__ bcat, int K,
-                                                      int F_g, int W, int ldb, ft_u16* __restrict__ packed) {
-  const int v = blockIdx.x;
+__device__ inline void ft_pack_column(int v, const float* __restrict__ wcat, const float* __restrict__ bcat, int K, int F_g, int W,
+                                      int ldb, ft_u16* __restrict__ packed) {
   const int lane = threadIdx.x;
   const int ncol = F_g + W;
   const int src = (v < F_g) ? v : ((v < ldb || v >= ldb + W) ? -1 : v - ldb + F_g);
@@ -65,6 +64,10 @@ __global__ void __launch_bounds__(64) ft_pack_kernel(const float* __restrict__ w
     const int wcol = v - ldb;
     tail[FT_NV + v] = (bcat != nullptr && wcol >= 0 && wcol < W) ? bcat[wcol] : 0.f;
   }
+}
+__global__ void __launch_bounds__(64) ft_pack_kernel(const float* __restrict__ wcat, const float* __restrict__ bcat, int K,
+                                                      int F_g, int W, int ldb, ft_u16* __restrict__ packed) {
+  ft_pack_column(blockIdx.x, wcat, bcat, K, F_g, W, ldb, packed);
 }
 
 // WIDE form: packed[32-column tile][k-step of 16][plane][lane][8] -- lane 32 (k % 16 / 8) + column % 32 holds k = 16 s + 8 (lane / 32) ..+7
@@ -351,10 +354,9 @@ int launch_fused_tile(AggArgs a, const int64_t* ptr, const int64_t* edge_ptr, in
 // packed_t[feature tile of 16][k-step of 32][plane][lane][8]: the B operand of d x = d W^T -- lane 16 (k % 32 / 8) + f % 16 holds
 // W[f][k], k = 32 s + 8 (lane / 16) ..+7, where k runs over the LDS images' columns: [d bases 0 .. ldb) | d w' as [h][b][4]
 // (a = 0 .. A - 1 real, the rest zero).  Scale per output feature f; tail: float col_inv[128].
-__global__ void __launch_bounds__(64) ft_pack_t_kernel(const float* __restrict__ wcat, int K, int F_g, int W, int A, int ldb,
-                                                        int k2, ft_u16* __restrict__ packed) {
-  const int f = blockIdx.x;           // output feature (row of wcat), 0 .. 127
-  const int lane = threadIdx.x;
+__device__ inline void ft_pack_t_feature(int f, const float* __restrict__ wcat, int K, int F_g, int W, int A, int ldb, int k2,
+                                         ft_u16* __restrict__ packed) {
+  const int lane = threadIdx.x;       // f: output feature (row of wcat), 0 .. 127
   const int ncol = F_g + W;
   auto src_col = [&](int k) -> int {  // image column k -> column of wcat, or -1
     if (k < ldb) return k < F_g ? k : -1;
@@ -384,6 +386,17 @@ __global__ void __launch_bounds__(64) ft_pack_t_kernel(const float* __restrict__
   }
   if (lane == 0) reinterpret_cast<float*>(packed + (int64_t)8 * 6 * 2 * 64 * 8)[f] = inv;
 }
+__global__ void __launch_bounds__(64) ft_pack_t_kernel(const float* __restrict__ wcat, int K, int F_g, int W, int A, int ldb,
+                                                        int k2, ft_u16* __restrict__ packed) {
+  ft_pack_t_feature(blockIdx.x, wcat, K, F_g, W, A, ldb, k2, packed);
+}
+// both operands of a training step in one launch: blocks 0 .. FT_NV - 1 the forward's columns, the next 128 the backward's features
+__global__ void __launch_bounds__(64) ft_pack_both_kernel(const float* __restrict__ wcat, const float* __restrict__ bcat, int K,
+                                                           int F_g, int W, int A, int ldb, int k2, ft_u16* __restrict__ packed,
+                                                           ft_u16* __restrict__ packed_t) {
+  if (blockIdx.x < FT_NV) ft_pack_column(blockIdx.x, wcat, bcat, K, F_g, W, ldb, packed);
+  else ft_pack_t_feature(blockIdx.x - FT_NV, wcat, K, F_g, W, A, ldb, k2, packed_t);
+}
 
 bool fused_tile_bwd_shape(const AggArgs& a, int f_in) {
   if (!ft_narrow_shape(a, f_in) || a.act != EGC_ACT_NONE) return false;
@@ -398,6 +411,15 @@ size_t fused_tile_bwd_pack_bytes() { return (size_t)8 * 6 * 2 * 64 * 8 * sizeof(
 int fused_tile_bwd_pack(const AggArgs& a, const float* wcat, int f_in, void* packed, hipStream_t stream) {
   ft_pack_t_kernel<<<128, 64, 0, stream>>>(wcat, f_in, a.B * a.Ls, a.W, a.A, a.ldb, a.ldb + a.H * a.B * 4, (ft_u16*)packed);
   EGC_LAUNCH_CHECK("ft_pack_t_kernel");
+  return EGC_OK;
+}
+
+int fused_tile_train_pack(const AggArgs& a, const float* wcat, const float* bcat, int f_in, int f_g, int w_cols, int ldb, void* packed,
+                          void* packed_t, hipStream_t stream) {
+  if (!fused_tile_bwd_shape(a, f_in)) return EGC_ERR_UNSUPPORTED;
+  ft_pack_both_kernel<<<FT_NV + 128, 64, 0, stream>>>(wcat, bcat, f_in, f_g, w_cols, a.A, ldb, a.ldb + a.H * a.B * 4, (ft_u16*)packed,
+                                                      (ft_u16*)packed_t);
+  EGC_LAUNCH_CHECK("ft_pack_both_kernel");
   return EGC_OK;
 }
 

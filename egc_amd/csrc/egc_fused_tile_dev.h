@@ -628,19 +628,20 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
     // (four batches of four 16-byte pieces per thread cover 128 rows of 128 floats; pieces beyond the tile lie outside the
     // descriptor), and the d bases area zeroed.  (As a pass of the twelve workers behind the first GEMM, with g brought in by
     // LDS-DMA, this was 14 k cycles per tile: every instruction of straight-line code the workers all run costs twelve cycles.)
-    auto g_max = [&](const Tile& r, int slot) {
+    auto g_max = [&](const Tile& r, int slot, auto wide_batches) {
       if constexpr (MODE == 1) {
+        constexpr int PB = decltype(wide_batches)::value ? 8 : 4, NB = 16 / PB;      // 16 pieces per thread, PB in flight
         const int F_o = C::F_out(a);
         const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)(t.grad_out + (int64_t)r.n0 * F_o), 0,
                                                                            (unsigned)(r.ok ? r.T : 0) * (unsigned)F_o * 4u, 0x00020000);
         unsigned m = 0;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          f4 v[4];
+        for (int b = 0; b < NB; ++b) {
+          f4 v[PB];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = load_slot(rg, (unsigned)(ht + (4 * b + i) * FT_HELPER_THREADS) * 16u);
+          for (int i = 0; i < PB; ++i) v[i] = load_slot(rg, (unsigned)(ht + (PB * b + i) * FT_HELPER_THREADS) * 16u);
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
+          for (int i = 0; i < PB; ++i)
             m = max(m, __float_as_uint(fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w)))));
         }
         m = ft_wave_umax(m);
@@ -676,7 +677,7 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       csr_sync();
       csr_s3(first, 0, epk0);
     }
-    g_max(first, 0);
+    if constexpr (MODE == 1) g_max(first, 0, std::true_type{});        // (in front of the first barrier: two round trips instead of four)
     zero_db(first);
     stage01(first);
     for (int it = 0;; ++it) {
@@ -764,7 +765,7 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
 #ifdef EGC_FT_STAMPS
       FT_HSTAMP(2, wave == FT_FIRST_HELPER)
 #endif
-      if (nxt.valid) g_max(nxt, (it + 1) % 3);
+      if constexpr (MODE == 1) { if (nxt.valid) g_max(nxt, (it + 1) % 3, std::false_type{}); }
       if constexpr (MODE == 0) {
         stage01(nxt);
         __builtin_amdgcn_s_setprio(0);

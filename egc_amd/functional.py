@@ -381,6 +381,25 @@ def _batch_fused_pack(spec: LayerSpec, wcat: torch.Tensor, bcat):
     return hit[2]
 
 
+def _batch_fused_train_pack(spec: LayerSpec, wcat: torch.Tensor, bcat):
+    """(packed, packed_t): the forward's and the backward's weight planes of one training step in ONE launch
+    (egc_batch_fused_train_pack); not cached -- the parameters change every step."""
+    lib = _C.load()
+    _check_f32(wcat, "wcat", (spec.f_in, spec.f_g + spec.w_cols))
+    dev = wcat.device
+    wc = wcat.contiguous()
+    with _device_guard(dev):
+        nb, nbt = int(lib.egc_batch_fused_pack_bytes(C.byref(spec.c))), int(lib.egc_batch_fused_bwd_pack_bytes(C.byref(spec.c)))
+        if nb <= 0 or nbt <= 0:
+            raise RuntimeError("egc_amd: layer outside the envelope of the one-launch training path")
+        packed = torch.empty(nb, dtype=torch.uint8, device=dev)
+        packed_t = torch.empty(nbt, dtype=torch.uint8, device=dev)
+        _C.check(lib.egc_batch_fused_train_pack(C.byref(spec.c), wc.data_ptr(), bcat.contiguous().data_ptr() if bcat is not None else None,
+                                                packed.data_ptr(), nb, packed_t.data_ptr(), nbt, _stream_ptr(dev)),
+                 "egc_batch_fused_train_pack")
+    return packed, packed_t
+
+
 def _batch_fused_setup(gb: GraphBatch, spec: LayerSpec, post, wcat, x=None):
     """(tile_nodes, max_tile_edges) when this layer call can run as ONE launch on the batch, else None.  A layer that asks for
     the 24-bit-operand GEMM (EGC_GEMM_STDVAR_24BIT=1 and std / var) keeps the two-launch path; EGC_NO_FUSED_TILE=1 switches
@@ -474,7 +493,7 @@ class ResidualLink:
         return link
 
 
-def egc_layer_backward_batch_fused(gb: GraphBatch, spec: LayerSpec, x, wcat, packed, grad_out, setup, d_x_add=None):
+def egc_layer_backward_batch_fused(gb: GraphBatch, spec: LayerSpec, x, wcat, packed, grad_out, setup, d_x_add=None, packed_t=None):
     """(d x [N, F_in], d_cat [N, ldb + W]) of one layer on a batch of whole graphs in ONE launch (egc_layer_backward_batch_fused_f32):
     the forward's intermediates are formed again in LDS, nothing was saved but x.  ``d_x_add`` [N, F_in]: added to d x in its store."""
     lib = _C.load()
@@ -491,9 +510,10 @@ def egc_layer_backward_batch_fused(gb: GraphBatch, spec: LayerSpec, x, wcat, pac
         nb = int(lib.egc_batch_fused_bwd_pack_bytes(C.byref(spec.c)))
         if nb <= 0:
             raise RuntimeError("egc_amd: layer outside the envelope of the one-launch backward")
-        packed_t = torch.empty(nb, dtype=torch.uint8, device=dev)
         stream = _stream_ptr(dev)
-        _C.check(lib.egc_batch_fused_bwd_pack(C.byref(spec.c), wcat.data_ptr(), packed_t.data_ptr(), nb, stream), "egc_batch_fused_bwd_pack")
+        if packed_t is None:
+            packed_t = torch.empty(nb, dtype=torch.uint8, device=dev)
+            _C.check(lib.egc_batch_fused_bwd_pack(C.byref(spec.c), wcat.data_ptr(), packed_t.data_ptr(), nb, stream), "egc_batch_fused_bwd_pack")
         d_x = torch.empty((n, spec.f_in), dtype=torch.float32, device=dev)
         d_cat = torch.empty((n, spec.ldb + spec.w_cols), dtype=torch.float32, device=dev)
         ei = gb.edge_index
@@ -517,9 +537,9 @@ class _BatchFusedTrainFunction(torch.autograd.Function):
         ctx.shapes = (comb_w.shape, comb_b.shape if comb_b is not None else None, [b.shape for b in bases])
         wcat, bcat = _pack_params(dims, permute, comb_w, comb_b, bases)
         bc = bcat if comb_b is not None else bcat_direct
-        packed = _batch_fused_pack(spec, wcat, bc)
+        packed, packed_t = _batch_fused_train_pack(spec, wcat, bc)
         out = egc_layer_forward_batch_fused(gb, spec, x, wcat, bc, bias, None, setups[0], packed=packed)
-        ctx.save_for_backward(x, wcat, packed)
+        ctx.save_for_backward(x, wcat, packed, packed_t)
         ctx.gb, ctx.spec, ctx.bsetup = gb, spec, setups[1]
         ctx.has_bcat, ctx.has_bias = bc is not None, bias is not None
         return out
@@ -527,7 +547,7 @@ class _BatchFusedTrainFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         need = ctx.needs_input_grad
-        x, wcat, packed = ctx.saved_tensors
+        x, wcat, packed, packed_t = ctx.saved_tensors
         spec = ctx.spec
         grad_out = grad_out.contiguous()
         add = None
@@ -535,7 +555,7 @@ class _BatchFusedTrainFunction(torch.autograd.Function):
             add, ctx.link.grad = ctx.link.grad, None
             if add is not None and (add.shape != x.shape or add.dtype != torch.float32 or add.device != x.device):
                 raise RuntimeError("egc_amd: the residual gradient handed to the conv's backward does not have the shape of x")
-        dx, d_cat = egc_layer_backward_batch_fused(ctx.gb, spec, x, wcat, packed, grad_out, ctx.bsetup, add if need[0] else None)
+        dx, d_cat = egc_layer_backward_batch_fused(ctx.gb, spec, x, wcat, packed, grad_out, ctx.bsetup, add if need[0] else None, packed_t)
         need_w = need[2] or any(need[11:])
         need_b = ctx.has_bcat and (need[3] if ctx.packed_b else need[4])
         need_bias = ctx.has_bias and need[1]

@@ -587,6 +587,9 @@ int egc_layer_forward_batch_fused_f32(const int64_t* graph_ptr, const int64_t* e
 int32_t egc_batch_fused_bwd_tile_nodes(const egc_layer* layer, int32_t max_tile_edges);
 int64_t egc_batch_fused_bwd_pack_bytes(const egc_layer* layer);
 int egc_batch_fused_bwd_pack(const egc_layer* layer, const float* wcat, void* packed_t, int64_t packed_bytes, egc_stream_t stream);
+/* egc_batch_fused_pack + egc_batch_fused_bwd_pack of the same wcat in one launch (a training step packs both once per update) */
+int egc_batch_fused_train_pack(const egc_layer* layer, const float* wcat, const float* bcat, void* packed, int64_t packed_bytes,
+                               void* packed_t, int64_t packed_t_bytes, egc_stream_t stream);
 int egc_layer_backward_batch_fused_f32(const int64_t* graph_ptr, const int64_t* edge_ptr, int64_t n_graphs, const int64_t* src,
                                        const int64_t* dst, int64_t n_edges, int64_t n_nodes, const int32_t* max_index,
                                        const egc_layer* layer, const float* x, const void* packed, const void* packed_t,

@@ -226,10 +226,10 @@ def test_d_x_add_through_the_c_abi():
     real = F.egc_layer_backward_batch_fused
     add = torch.randn(n, 128, device=dev)
 
-    def spy(gbb, spec, xx, wcat, packed, grad_out, setup, d_x_add=None):
-        got["plain"] = real(gbb, spec, xx, wcat, packed, grad_out, setup)[0]
-        got["added"] = real(gbb, spec, xx, wcat, packed, grad_out, setup, add)[0]
-        return real(gbb, spec, xx, wcat, packed, grad_out, setup, d_x_add)
+    def spy(gbb, spec, xx, wcat, packed, grad_out, setup, d_x_add=None, packed_t=None):
+        got["plain"] = real(gbb, spec, xx, wcat, packed, grad_out, setup)[0]                     # (packs the transposed operand itself)
+        got["added"] = real(gbb, spec, xx, wcat, packed, grad_out, setup, add, packed_t)[0]
+        return real(gbb, spec, xx, wcat, packed, grad_out, setup, d_x_add, packed_t)
     orig = F.egc_layer_backward_batch_fused
     F.egc_layer_backward_batch_fused = spy
     try:
