@@ -162,7 +162,9 @@ def zinc_cases(manifest):
     zm = _load("experiments.zinc.models", os.path.join(REF, "zinc", "models.py"))
     for name, hidden, H, B, aggrs, seed in (("net_zinc_egcs", 56, 8, 4, ["symadd"], 11),
                                             ("net_zinc_egcm", 48, 4, 4, ["add", "std", "max"], 12),
-                                            ("net_zinc_plumbing", 32, 1, 1, ["add"], 13)):     # BASELINE config 1's shape
+                                            ("net_zinc_plumbing", 32, 1, 1, ["add"], 13),      # BASELINE config 1's shape
+                                            # four bases of 16 channels: the shape of the one-launch training path of a batch
+                                            ("net_zinc_b64", 64, 4, 4, ["symadd", "max", "mean"], 14)):
         rng = np.random.default_rng(seed)
         torch.manual_seed(seed)
         atom, ei, n, batch = zinc_like_batch(24, seed=seed)

@@ -140,6 +140,9 @@ CASES = [
     dict(name="train_zinc_egcm", hidden=24, layers=4, H=2, B=2, aggrs=["add", "std", "max"], seed=32, lr=0.005, wd=1e-4,
          train_sizes=[12, 11], val_sizes=[9], test_sizes=[6], iterations=6),
     # long enough for the validation loss to stall: ReduceLROnPlateau halves the rate inside the run
+    # four bases of 16 channels (the one-launch training path of a batch: egc_layer_backward_batch_fused_f32)
+    dict(name="train_zinc_b64", hidden=64, layers=4, H=4, B=4, aggrs=["symadd", "max", "mean"], seed=34, lr=0.005, wd=1e-4,
+         train_sizes=[10, 10, 9], val_sizes=[8], test_sizes=[7], iterations=8),
     dict(name="train_zinc_plateau", hidden=16, layers=4, H=2, B=2, aggrs=["symadd", "max"], seed=33, lr=0.03, wd=0.0,
          train_sizes=[6, 6], val_sizes=[6], test_sizes=[6], iterations=26),
 ]

@@ -77,8 +77,11 @@ def _bound(g):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("as_batch", [False, True])
 @pytest.mark.parametrize("name", grad_names())
-def test_hip_backward_against_reference_gradients(name):
+def test_hip_backward_against_reference_gradients(name, as_batch):
+    """as_batch: the fixture's graph handed over as an egc_amd.GraphBatch of ONE graph -- the batch path's launches where the layer
+    is inside their envelopes (grad_opt_northstar: the one-launch forward AND backward), the CSR path's behind it otherwise."""
     import egc_amd
     assert torch.cuda.is_available(), "these tests need the MI355X"
     dev = torch.device("cuda:0")
@@ -95,9 +98,17 @@ def test_hip_backward_against_reference_gradients(name):
     layer = layer.to(dev).train()
     x = torch.from_numpy(g["x"]).to(dev).requires_grad_(True)
     ei = torch.from_numpy(g["edge_index"]).to(dev)
+    if as_batch:
+        n = int(x.size(0))
+        ei = egc_amd.GraphBatch(ei, ptr=torch.tensor([0, n], device=dev), max_nodes=n, num_nodes=n)
     out = layer(x, ei) if m["kind"] == "opt" else layer(x=x, edge_index=ei)
     out.backward(torch.from_numpy(g["gout"]).to(dev))
     torch.cuda.synchronize()
+    if as_batch:
+        ei.check()
+        if name == "grad_opt_northstar":
+            ran = {k[-1] for k, v in ei._setups.items() if isinstance(k, tuple) and isinstance(k[-1], str) and v}
+            assert "fused_bwd" in ran, ran
     integer = "ties" in name
     tol = 1e-6 if integer else _bound(g)
     assert _rel(out.detach().cpu().numpy(), g["out64"]) <= tol

@@ -62,8 +62,9 @@ def _restated(conv, x, edge_index):
 def _call(net, meta, z, dev, dtype, train, **kw):
     ei = torch.from_numpy(z["in:edge_index"])
     if meta["net"] == "EgcZincNet":
-        out = net(torch.from_numpy(z["in:atom"]).to(dev), ei.to(dev), torch.from_numpy(z["in:batch"]).to(dev),
-                  meta["n_graphs"], **kw)
+        graph = kw.pop("graph", None)
+        out = net(torch.from_numpy(z["in:atom"]).to(dev), graph if graph is not None else ei.to(dev),
+                  torch.from_numpy(z["in:batch"]).to(dev), meta["n_graphs"], **kw)
         return out, None
     x = torch.from_numpy(z["in:x"]).to(dev, dtype).requires_grad_(train)
     if meta["net"] == "mag EGC":
@@ -112,12 +113,17 @@ def _fuse(conv, bn, residual):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("fused", [False, True, "batch"])
 @pytest.mark.parametrize("name", _names("net_"))
 def test_nets_on_the_hip_layers_match_the_reference_float64(name, fused):
+    """fused = "batch": the ZINC nets with the PyG batch handed over as an egc_amd.GraphBatch (node offsets from the batch
+    vector) -- the one-launch forward of the batch path, and for net_zinc_b64 (four bases of 16 channels) the one-launch
+    BACKWARD with the residual gradient joined in the launch (egc_layer_backward_batch_fused_f32)."""
     z, meta = _load(name)
     if fused and meta["net"] == "mag EGC":
         pytest.skip("the mag net has no BatchNorm / residual tail to fuse")
+    if fused == "batch" and meta["net"] != "EgcZincNet":
+        pytest.skip("a batch of whole graphs: the ZINC nets")
     dev = torch.device("cuda:0")
     net = _build(meta)
     net.load_state_dict(_state(z), strict=True)
@@ -135,12 +141,23 @@ def test_nets_on_the_hip_layers_match_the_reference_float64(name, fused):
         kw["fuse"] = fuse
         if meta["net"] == "EgcZincNet":
             kw["pool"] = lambda x, batch, n_graphs: egc_amd.global_mean_pool(x, batch, n_graphs)
+    gb = None
+    if fused == "batch":
+        sizes = np.bincount(z["in:batch"], minlength=meta["n_graphs"])
+        gb = egc_amd.GraphBatch(torch.from_numpy(z["in:edge_index"]).to(dev), batch=torch.from_numpy(z["in:batch"]).to(dev),
+                                num_graphs=meta["n_graphs"], max_nodes=int(sizes.max()))
+        kw["graph"] = gb
     net.eval()
     with torch.no_grad():
-        out_eval, _ = _call(net, meta, z, dev, torch.float32, False, **kw)
+        out_eval, _ = _call(net, meta, z, dev, torch.float32, False, **dict(kw))
     net.train()
-    out, leaf = _call(net, meta, z, dev, torch.float32, True, **kw)
+    out, leaf = _call(net, meta, z, dev, torch.float32, True, **dict(kw))
     out.backward(torch.from_numpy(z["gout"]).to(dev))
+    if gb is not None:
+        gb.check()
+        ran = {k[-1] for k, v in gb._setups.items() if isinstance(k, tuple) and isinstance(k[-1], str) and v}
+        if name == "net_zinc_b64":
+            assert "fused_bwd" in ran, ran          # the one-launch backward, not a fallback
 
     def rel(a, b):
         b = torch.from_numpy(b).double()

@@ -72,9 +72,11 @@ def test_counterpart_loop_reproduces_the_reference_trajectory_in_float64(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("fused", [False, True, "batch"])
 @pytest.mark.parametrize("name", _names())
 def test_hip_layers_follow_the_reference_trajectory(name, fused):
+    """fused = "batch": every batch of the loop handed to the blocks as an egc_amd.GraphBatch -- the one-launch forward, and for
+    train_zinc_b64 (four bases of 16 channels) the one-launch backward of the batch path."""
     z, meta = _load(name)
     man = json.load(open(os.path.join(GOLDEN_DIR, "MANIFEST_TRAIN.json")))[name]
     dev = torch.device("cuda:0")
@@ -91,9 +93,21 @@ def test_hip_layers_follow_the_reference_trajectory(name, fused):
             return blocks[id(conv)]
         kw = dict(fuse=fuse, pool=lambda x, batch, n_graphs: egc_amd.global_mean_pool(x, batch, n_graphs))
 
+    ran = set()
+
     def forward(b):
-        return net(b["atom"], b["edge_index"], b["batch"], b["n_graphs"], **kw)
+        if fused != "batch":
+            return net(b["atom"], b["edge_index"], b["batch"], b["n_graphs"], **kw)
+        sizes = torch.bincount(b["batch"], minlength=b["n_graphs"])
+        gb = egc_amd.GraphBatch(b["edge_index"], batch=b["batch"], num_graphs=b["n_graphs"], max_nodes=int(sizes.max()))
+        out = net(b["atom"], gb, b["batch"], b["n_graphs"], **kw)
+        gb.check()
+        if torch.is_grad_enabled():        # (the training path settles both launches' tiles in the forward)
+            ran.update(k[-1] for k, v in gb._setups.items() if isinstance(k, tuple) and isinstance(k[-1], str) and v)
+        return out
     tr, va, lrs, te = fit_zinc(forward, modules, net.parameters(), data, meta["lr"], meta["wd"], meta["iterations"])
+    if fused == "batch" and name == "train_zinc_b64":
+        assert "fused_bwd" in ran, ran          # the one-launch backward, not a fallback
     # Calibrated bounds over the first ten iterations; beyond that a training run is a chaotic map of its rounding errors
     # (train_zinc_plateau: the reference's own float32 and float64 validation losses are 4e-2 apart after 26 iterations of
     # Adam at lr 0.03, although every single step agrees to 1e-6) and the whole trajectory is held to 2e-3 on losses of
