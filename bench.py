@@ -474,18 +474,25 @@ def _oc_small_batches(out, dev, seed):
     ns = _north_star_layer
     # the batch sizes the reference actually trains at (zinc/configs.py: 128 graphs per batch): a few thousand nodes,
     # where the step is bound by what launches the kernels -- eager against the whole step replayed as one hipGraph
-    for key, (ei, n, _), label in (("zinc_b128_training_step", wl.zinc_like_batch(128, seed=seed)[1:], "ZINC-shaped batch of 128 molecules"),
-                                   ("molhiv_b2048_training_step", wl.molecule_batch(2048, seed=seed), "molhiv-shaped batch of 2048 molecules")):
+    for key, (ei, n, bvec), label in (("zinc_b128_training_step", wl.zinc_like_batch(128, seed=seed)[1:], "ZINC-shaped batch of 128 molecules"),
+                                      ("molhiv_b2048_training_step", wl.molecule_batch(2048, seed=seed), "molhiv-shaped batch of 2048 molecules")):
         torch.manual_seed(seed)
         blocks = torch.nn.ModuleList([egc_amd.FusedEGCBlock(ns(), torch.nn.BatchNorm1d(F_OUT)) for _ in range(4)]).to(dev).train()
         params = list(blocks.parameters())
         ei = ei.to(dev)
         xs, gos = torch.randn(n, F_IN, device=dev), torch.randn(n, F_OUT, device=dev)
+        # what a PyG batch carries besides edge_index: the graphs' node offsets (Batch.ptr); with them the layer runs as one
+        # launch each way (egc_layer_forward_batch_fused_f32 / egc_layer_backward_batch_fused_f32), no graph build at all
+        sizes = torch.bincount(bvec.to(dev))
+        ptr = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(sizes, 0)])
+        max_nodes = int(sizes.max())
+        as_batch = [True]
 
         def step():
+            g = egc_amd.GraphBatch(ei, ptr=ptr, max_nodes=max_nodes, num_nodes=n) if as_batch[0] else ei
             h = xs
             for b in blocks:
-                h = b(h, ei)       # COO in: the per-batch graph build is part of the step
+                h = b(h, g)        # (COO in: the per-batch graph build is part of the step)
             h.backward(gos)
 
         def eager():
@@ -506,9 +513,17 @@ def _oc_small_batches(out, dev, seed):
         ms_eager = wall(eager)
         graphed = egc_amd.GraphedStep(step, params=params)
         ms_graph = wall(graphed)
-        out[key] = {"workload": f"{label} (N={n}, E={int(ei.size(1))}): graph build + 4 x [EGConv -> BatchNorm1d(train) -> ReLU -> + x], "
-                                "forward + backward", "eager_step_ms": ms_eager, "hipgraph_replay_ms": ms_graph}
-        log(f"  {key}: eager {ms_eager:.4f} ms, one hipGraph {ms_graph:.4f} ms")
+        del graphed
+        as_batch[0] = False
+        ms_eager_coo = wall(eager)
+        graphed = egc_amd.GraphedStep(step, params=params)
+        ms_graph_coo = wall(graphed)
+        out[key] = {"workload": f"{label} (N={n}, E={int(ei.size(1))}): 4 x [EGConv -> BatchNorm1d(train) -> ReLU -> + x], forward + backward",
+                    "path": "edge_index + the batch's node offsets (egc_amd.GraphBatch): one launch each way per layer, no graph build",
+                    "eager_step_ms": ms_eager, "hipgraph_replay_ms": ms_graph,
+                    "coo_path": "edge_index only: per-batch graph build + GEMM + aggregate, three backward kernels (rounds 2-4)",
+                    "coo_eager_step_ms": ms_eager_coo, "coo_hipgraph_replay_ms": ms_graph_coo}
+        log(f"  {key}: eager {ms_eager:.4f} ms, one hipGraph {ms_graph:.4f} ms (edge_index only: {ms_eager_coo:.4f} / {ms_graph_coo:.4f})")
         del graphed
         # the same net serving: eval mode (BatchNorm / ReLU / residual in the aggregate kernel's store), graph build included
         blocks.eval()
