@@ -240,3 +240,57 @@ def test_d_x_add_through_the_c_abi():
     err = float((got["added"] - (got["plain"] + add)).abs().max())
     assert err <= 2e-6 * float(got["plain"].abs().max()), err
     assert float((got["added"] - got["plain"]).abs().max()) > 0.5         # (it was added)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_against_the_csr_path(seed):
+    """Random batches (one graph to hundreds, graphs of one node, graphs without edges, hubs, self loops, duplicates; with and
+    without the graphs' edge offsets) x the layer kinds of the envelope (both layer classes, H = 4 / 8, every aggregator subset drawn
+    from sum / mean / max / symnorm, with and without added self loops): the one-launch backward against the CSR path's."""
+    import egc_amd
+    dev = _dev()
+    rng = np.random.default_rng(1000 + seed)
+    for trial in range(5):
+        n_graphs = int(rng.choice([1, 2, 9, 60, 300]))
+        max_size = int(rng.choice([2, 3, 17, 50, 81]))
+        ei, n, ptr = _messy_batch(int(rng.integers(1 << 30)), n_graphs=n_graphs, max_size=max_size)
+        hidden, H = (128, 8) if rng.integers(2) else (64, 4)
+        k = int(rng.integers(1, 5))
+        if rng.integers(2):
+            aggrs = list(rng.choice(["sum", "mean", "max", "symnorm"], size=k, replace=False))
+            asl = bool(rng.integers(4) != 0)
+            conv = egc_amd.EGConv(hidden, hidden, aggrs=aggrs, num_heads=H, num_bases=4, add_self_loops=asl)
+            call = lambda c, x, g: c(x, g)
+        else:
+            aggrs = list(rng.choice(["add", "mean", "max", "symadd"], size=k, replace=False))
+            asl = True
+            conv = egc_amd.EfficientGraphConv(hidden, hidden, H, 4, False, aggrs=aggrs)
+            call = lambda c, x, g: c(x=x, edge_index=g)
+        torch.manual_seed(seed * 10 + trial)
+        conv = conv.to(dev).train()
+        x0 = torch.randn(n, hidden, device=dev) * float(rng.choice([1e-3, 1.0, 50.0]))
+        go = torch.randn(n, hidden, device=dev) * float(rng.choice([1e-4, 1.0, 300.0]))
+        res = []
+        for path in ("batch", "csr"):
+            conv.zero_grad(set_to_none=True)
+            x = x0.clone().requires_grad_(True)
+            if path == "batch":
+                kw = {}
+                if rng.integers(2):       # the graphs' edge offsets (PyG's collation has them): edges sorted by graph already
+                    d = ei[1].numpy()
+                    kw["edge_ptr"] = torch.from_numpy(np.searchsorted(d, ptr.numpy(), side="left")).to(dev) if np.all(np.diff(np.searchsorted(ptr.numpy(), d, side="right")) >= 0) else None
+                g = egc_amd.GraphBatch(ei.to(dev), ptr=ptr.to(dev), max_nodes=max(1, max_size - 1), num_nodes=n, **{a: b for a, b in kw.items() if b is not None})
+            else:
+                g = ei.to(dev)
+            out = call(conv, x, g)
+            out.backward(go)
+            if path == "batch":
+                g.check()
+                assert _ran_bwd(g), (hidden, H, aggrs, asl, n_graphs, max_size)
+            res.append((out.detach(), x.grad.detach(), [p.grad.detach().clone() for p in conv.parameters()]))
+        tag = (seed, trial, hidden, H, aggrs, asl, n_graphs, max_size)
+        assert _rel(res[0][0], res[1][0]) <= 1e-5, tag
+        assert _rel(res[0][1], res[1][1]) <= 2e-5, (tag, _rel(res[0][1], res[1][1]))
+        scale = max(float(q.abs().max()) for q in res[1][2])
+        for p, q in zip(res[0][2], res[1][2]):
+            assert float((p - q).abs().max()) <= 2e-5 * scale, tag
