@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from dataclasses import dataclass
 
 import torch
@@ -476,18 +477,19 @@ class ResidualLink:
     leaves its incoming gradient here (`grad`) and reports none for the residual input, and the conv's backward hands it to
     egc_layer_backward_batch_fused_f32 as `d_x_add`.  Only ever used when the residual input IS the conv's input."""
     __slots__ = ("taken", "grad")
-    _offered = None
+    _local = threading.local()        # the offer lives on the thread that runs the block's forward
 
     def __init__(self):
         self.taken, self.grad = False, None
 
     @classmethod
     def offer(cls, link):
-        cls._offered = link
+        cls._local.offered = link
 
     @classmethod
     def take(cls):
-        link, cls._offered = cls._offered, None
+        link = getattr(cls._local, "offered", None)
+        cls._local.offered = None
         if link is not None:
             link.taken = True
         return link
