@@ -317,6 +317,9 @@ __global__ void __launch_bounds__(X3_THREADS) xt_gemm_bf16x3_kernel(const float*
     }
   };
   auto put = [&](int sb, const Regs& st) {
+#ifdef EGC_XT_NO_PUT
+    { float sink = st.x.x + st.d[0].x + st.d[LD - 1].x; asm volatile("" :: "v"(sink)); return; }
+#endif
     float* base = stage + sb * X3_STAGE_FLOATS;
     if (has_e) esum += st.e;
     *reinterpret_cast<f4*>(base + lds_x) = st.x;
@@ -329,6 +332,9 @@ __global__ void __launch_bounds__(X3_THREADS) xt_gemm_bf16x3_kernel(const float*
   const int cs_col = wave * 24 + (lane % 24), cs_part = lane / 24;   // lanes 48..63 idle
   float colsum = 0.f;
   auto split = [&](int sb) {   // fp32 stage sb -> planes sb (both indexed by the sub-tile's parity)
+#ifdef EGC_XT_NO_SPLIT
+    return;
+#endif
     const float* src = stage + sb * X3_STAGE_FLOATS;
     unsigned short* pl = planes + sb * 3 * X3_PLANE_HALVES;
     if (sums && cs_part < 2) {
@@ -360,6 +366,9 @@ __global__ void __launch_bounds__(X3_THREADS) xt_gemm_bf16x3_kernel(const float*
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   const int a_row = wm * 32 + c32, b_row = X3_TM + wn * 96 + c32;   // "rows" of the transposed planes = tile columns
   auto multiply = [&](int sb) {
+#ifdef EGC_XT_NO_MFMA
+    return;
+#endif
     const unsigned short* base = planes + sb * 3 * X3_PLANE_HALVES + 8 * g;
     Planes3 a, b[3];
     a.h = *reinterpret_cast<const bf16x8*>(base + a_row * X3_RP);
@@ -401,10 +410,25 @@ __global__ void __launch_bounds__(X3_THREADS) xt_gemm_bf16x3_kernel(const float*
   split(0);
   lds_barrier();
   // interval s: multiply s | split s + 1 | stage s + 2 | request s + 6        (unrolled by four: register sets are static)
+  // The two wavefronts of a SIMD (w and w + 4) take the interval's two halves in OPPOSITE order: a wavefront is held at the
+  // issue of its own MFMAs while they run, so in lock step both multiplied (sharing the one matrix pipe) and then both split
+  // (sharing the vector pipe) -- the SIMD's two pipes one after the other instead of side by side.
+#ifdef EGC_XT_LOCKSTEP
+  const bool split_first = false;
+#elif defined(EGC_XT_STAGGER_BIT)
+  const bool split_first = ((wave >> EGC_XT_STAGGER_BIT) & 1) != 0;
+#else
+  const bool split_first = wave >= 4;
+#endif
 #define X3_INTERVAL(S, SET)                      \
   {                                              \
-    if ((S) < n_sub) multiply((S) & 1);          \
-    split(((S) + 1) & 1);                        \
+    if (split_first) {                           \
+      split(((S) + 1) & 1);                      \
+      if ((S) < n_sub) multiply((S) & 1);        \
+    } else {                                     \
+      if ((S) < n_sub) multiply((S) & 1);        \
+      split(((S) + 1) & 1);                      \
+    }                                            \
     put((S) & 1, rg[SET]);                       \
     fetch((S) + 6, rg[SET]);                     \
     lds_barrier();                               \
