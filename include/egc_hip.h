@@ -569,14 +569,16 @@ int egc_layer_forward_batch_fused_f32(const int64_t* graph_ptr, const int64_t* e
  * loss.backward() through zinc/models.py:60-74 -> layers.py:89-140 / optimized_layers.py:177-210) -- the backward of the two
  * Linears, of propagate's gathers and of the per-aggregator scatters -- without a CSR, a transposed CSR or any saved
  * intermediate: per tile of whole graphs the forward's `bases` / `weightings` and aggregates are formed again in LDS,
- * d weightings = <grad_out, aggregates>, d aggregates = weightings x grad_out travel to the sources' rows by LDS float atomics
+ * d weightings = <grad_out, aggregates>, d aggregates = weightings x grad_out travel to the sources' rows of an LDS image kept as
+ * 64-bit fixed point (integer LDS atomics: order-independent sums; the scale comes from the tile's largest |grad_out| and |weightings|,
+ * 34 bits under the bound -- float LDS atomics run at one lane per clock per CU on gfx950)
  * (sum / mean / symnorm along every entry, max to the FIRST entry in input order attaining it: torch_scatter's arg rule), and
  *   d_x   [n_nodes, in_channels]  = [d bases | d weightings] [bases_weight | comb_weight^T]^T   (split-precision MFMA GEMM)
  *   d_cat [n_nodes, ld_dcat]      = the gradient of [bases (ldb) | pre-activation weightings (H B A, column (h B + b) A + a)]
- * leave the launch (d_cat may be NULL; the caller's weight gradient is x^T d_cat: egc_weight_grad_*).  Sums are formed by float
- * atomics: reproducible to rounding.  Envelope (egc_batch_fused_bwd_tile_nodes > 0): B = 4 bases of 16 channels, H = 4 or 8
+ * leave the launch (d_cat may be NULL; the caller's weight gradient is x^T d_cat: egc_weight_grad_*).  Two launches on the same inputs
+ * agree to rounding, not to the bit (the recomputed aggregates sum a row's entries in the order the LDS CSR build left them).  Envelope (egc_batch_fused_bwd_tile_nodes > 0): B = 4 bases of 16 channels, H = 4 or 8
  * (the d = 64 / 128 layers), F_in <= 128, aggregators of sum / mean / max / symnorm, no weight nonlinearity.
- *   egc_batch_fused_bwd_tile_nodes   rows of a tile (its image also holds d bases: 96 - 112 at the north star), 0 = outside
+ *   egc_batch_fused_bwd_tile_nodes   rows of a tile (its image also holds d bases, 512 B per row: 80 at the north star), 0 = outside
  *   egc_batch_fused_bwd_pack[_bytes] wcat -> the transposed operand's fp16 planes; once per parameter update
  *   egc_layer_backward_batch_fused_f32   `packed` = egc_batch_fused_pack's buffer (the forward operand, for the recompute);
  *                                    `d_x_add` [n_nodes, in_channels] or NULL: added to d_x in its store -- the gradient that
