@@ -561,6 +561,14 @@ class _BatchFusedTrainFunction(torch.autograd.Function):
         need_w = need[2] or any(need[11:])
         need_b = ctx.has_bcat and (need[3] if ctx.packed_b else need[4])
         need_bias = ctx.has_bias and need[1]
+        if need_w and need_b and need_bias and ctx.has_bcat and not _C.env_flag("EGC_NO_GRADS_INTO_PARAMS"):
+            # the usual training call: every parameter takes a gradient -- x^T d_cat and both bias sums land in the parameters'
+            # own layouts in the weight-gradient launch's reduction (no d wcat, no unpack launch)
+            got = _weight_grads_into_params(x, d_cat, grad_out, ctx.dims, ctx.permute, ctx.shapes, ctx.packed_b)
+            if got is not None:
+                dcw, dcb, dbc, dparts, dbias = got
+                return (dx if need[0] else None, dbias, dcw, dcb, None if ctx.packed_b else dbc, None, None, None, None, None, None,
+                        *dparts)
         dwcat = dbcat = dbias = None
         if need_w:
             if need_bias and need_b:
@@ -829,6 +837,40 @@ def _weight_grads(x: torch.Tensor, d: torch.Tensor, col_sums: bool = False, extr
     if extra is not None and not ride:
         es = _column_sums(extra)
     return done(out, cs, es)
+
+
+def _weight_grads_into_params(x, d, extra, dims, permute, shapes, packed_b):
+    """x^T @ d, the column sums of d's weightings part and of ``extra`` (= grad_out) written STRAIGHT into gradients of the
+    module's own parameters through the pack's index map (egc_weight_grad_params_f32: no d wcat array, no unpack launch), or None
+    when the call is outside that entry point's envelope.  Returns (d comb_w, d comb_b or None, d bcat or None, [d basis parts],
+    d bias)."""
+    f_in, H, A, B, L, Ls = dims
+    n, k = x.size(0), d.size(1)
+    if (n == 0 or f_in > 128 or k > 192 or f_in % 4 or k % 4 or x.dtype != torch.float32 or d.dtype != torch.float32
+            or x.stride(1) != 1 or d.stride(1) != 1 or x.stride(0) % 4 or d.stride(0) % 4 or x.data_ptr() % 16 or d.data_ptr() % 16
+            or extra.dim() != 2 or extra.size(0) != n or extra.size(1) % 4 or extra.size(1) > 128 or extra.dtype != torch.float32
+            or extra.stride(1) != 1 or extra.stride(0) % 4 or extra.data_ptr() % 16 or gemm_exact()
+            or os.environ.get("EGC_XT_FP32") is not None or k != B * Ls + H * B * A):
+        return None
+    lib = _C.load()
+    dev = x.device
+    with _device_guard(dev):
+        dcw = torch.empty(shapes[0], dtype=torch.float32, device=dev)
+        dcb = torch.empty(shapes[1], dtype=torch.float32, device=dev) if packed_b else None
+        dbc = None if packed_b else torch.empty(H * B * A, dtype=torch.float32, device=dev)
+        dparts = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in shapes[2]]
+        ptrs = (C.c_void_p * len(dparts))(*[p.data_ptr() for p in dparts])
+        e_cols = extra.size(1)
+        es = torch.empty(e_cols, dtype=torch.float32, device=dev)
+        nbytes = int(lib.egc_weight_grad_ex_workspace_bytes(n, f_in, k, e_cols))
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+        _C.check(lib.egc_weight_grad_params_f32(x.data_ptr(), x.stride(0), d.data_ptr(), d.stride(0), n, f_in, H, A, B, L, Ls,
+                                                int(permute), ptrs, len(dparts), dcw.data_ptr(),
+                                                dcb.data_ptr() if dcb is not None else None,
+                                                dbc.data_ptr() if dbc is not None else None, extra.data_ptr(), extra.stride(0),
+                                                e_cols, es.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(dev)),
+                 "egc_weight_grad_params_f32")
+    return dcw, dcb, dbc, dparts, es
 
 
 def _xt_library(x: torch.Tensor, d: torch.Tensor) -> torch.Tensor:
