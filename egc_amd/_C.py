@@ -180,6 +180,9 @@ SYMBOLS = {
     "egc_batch_fused_bwd_pack": (C.c_int, [C.POINTER(EgcLayer), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "egc_batch_fused_train_pack": (C.c_int, [C.POINTER(EgcLayer), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                              C.c_void_p]),
+    "egc_batch_fused_train_pack_params": (C.c_int, [C.POINTER(EgcLayer), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                    C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                                    C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "egc_layer_backward_batch_fused_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                                      C.c_void_p, C.POINTER(EgcLayer), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,

@@ -25,6 +25,7 @@
 #include <algorithm>
 
 #include "egc_aggregate_dev.h"
+#include "egc_pack_map.h"
 
 namespace egc {
 
@@ -988,6 +989,32 @@ int egc_batch_fused_train_pack(const egc_layer* layer, const float* wcat, const 
       packed_t_bytes < (int64_t)fused_tile_bwd_pack_bytes())
     return EGC_ERR_INVALID;
   return fused_tile_train_pack(ab, wcat, bcat, layer->in_channels, a.B * a.Ls, a.W, a.ldb, packed, packed_t, (hipStream_t)stream);
+}
+
+int egc_batch_fused_train_pack_params(const egc_layer* layer, const float* const* bases_parts, int32_t n_parts, const float* comb_weight,
+                                      const float* comb_bias, const float* bcat, int32_t num_heads, int32_t num_aggrs, int32_t num_bases,
+                                      int32_t basis_len, int32_t basis_stride, int32_t permute_hab, void* packed, int64_t packed_bytes,
+                                      void* packed_t, int64_t packed_t_bytes, egc_stream_t stream) {
+  AggArgs a, ab;
+  int st = tile_layer_args(layer, a, true);
+  if (st == EGC_OK) st = tile_layer_args(layer, ab);
+  if (st != EGC_OK) return st;
+  if (!fused_tile_shape(a, layer->in_channels) || !fused_tile_bwd_shape(ab, layer->in_channels)) return EGC_ERR_UNSUPPORTED;
+  if (bases_parts == nullptr || comb_weight == nullptr || packed == nullptr || packed_t == nullptr ||
+      (n_parts != 1 && n_parts != num_bases) || n_parts > PACK_MAX_PARTS || (comb_bias != nullptr && bcat != nullptr) ||
+      packed_bytes < (int64_t)fused_tile_pack_bytes(a, layer->in_channels) || packed_t_bytes < (int64_t)fused_tile_bwd_pack_bytes())
+    return EGC_ERR_INVALID;
+  // the parameters must describe the layer the planes are packed for
+  if (num_bases != a.B || basis_stride != a.Ls || basis_len <= 0 || basis_len > basis_stride || num_heads != a.H ||
+      num_heads * num_bases * num_aggrs != a.W)
+    return EGC_ERR_INVALID;
+  PackPtrs ptrs;
+  for (int i = 0; i < PACK_MAX_PARTS; ++i) ptrs.part[i] = i < n_parts ? const_cast<float*>(bases_parts[i]) : nullptr;
+  for (int i = 0; i < n_parts; ++i)
+    if (ptrs.part[i] == nullptr) return EGC_ERR_INVALID;
+  const PackDims d{layer->in_channels, num_heads, num_aggrs, num_bases, basis_len, basis_stride, n_parts, permute_hab != 0};
+  return fused_tile_train_pack_params(ab, ptrs, comb_weight, comb_bias, bcat, d, a.B * a.Ls, a.W, a.ldb, packed, packed_t,
+                                      (hipStream_t)stream);
 }
 
 int egc_layer_backward_batch_fused_f32(const int64_t* graph_ptr, const int64_t* edge_ptr, int64_t n_graphs, const int64_t* src,

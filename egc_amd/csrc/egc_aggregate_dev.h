@@ -221,6 +221,10 @@ bool fused_tile_bwd_shape(const AggArgs& a, int f_in);
 int fused_tile_bwd_capacity(const AggArgs& a, int f_in, int max_tile_edges);
 size_t fused_tile_bwd_pack_bytes();
 int fused_tile_bwd_pack(const AggArgs& a, const float* wcat, int f_in, void* packed, hipStream_t stream);
+struct PackPtrs;
+struct PackDims;
+int fused_tile_train_pack_params(const AggArgs& a, const PackPtrs& bases, const float* comb_w, const float* comb_b, const float* bcat,
+                                 const PackDims& d, int f_g, int w_cols, int ldb, void* packed, void* packed_t, hipStream_t stream);
 int fused_tile_train_pack(const AggArgs& a, const float* wcat, const float* bcat, int f_in, int f_g, int w_cols, int ldb, void* packed,
                           void* packed_t, hipStream_t stream);
 int launch_fused_tile_bwd(AggArgs a, const int64_t* ptr, const int64_t* edge_ptr, int64_t n_graphs, const int64_t* src,

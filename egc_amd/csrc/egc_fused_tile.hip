@@ -29,6 +29,7 @@
 // Tiles beyond the LDS image (a single graph with more than `tcap` nodes, more than `emax` edges) and edges that leave
 // their tile raise *status and the sticky host flag; the host routes batches whose declared largest graph exceeds the
 // capacity to the two-launch path.
+#include "egc_pack_map.h"
 #include "egc_fused_tile_dev.h"
 
 namespace egc {
@@ -36,14 +37,33 @@ namespace egc {
 // packed[column tile][k-step of 32][plane][lane][8]: lane 16 (k % 32 / 8) + column % 16 holds k = 32 s + 8 (lane / 16) ..+7 of
 // column 16 ct + lane % 16 -- the B operand of v_mfma_f32_16x16x32_f16 as it is loaded, one KiB per (ct, s, plane).
 // Column scales and the two planes as pack_f16x2_kernel (egc_gemm_f16x2.hip).
-__device__ inline void ft_pack_column(int v, const float* __restrict__ wcat, const float* __restrict__ bcat, int K, int F_g, int W,
-                                      int ldb, ft_u16* __restrict__ packed) {
+// (the operand's source: wcat [K][F_g + W] + bcat [W], or -- FtParamSrc -- the layer's parameters through the pack's index map)
+struct FtWcatSrc {
+  const float* wcat;
+  const float* bcat;
+  int ncol;
+  __device__ inline float w(int k, int c) const { return wcat[(int64_t)k * ncol + c]; }
+  __device__ inline float b(int j) const { return bcat != nullptr ? bcat[j] : 0.f; }
+};
+struct FtParamSrc {
+  PackPtrs bases;
+  const float* comb_w;
+  const float* comb_b;      // the combination Linear's bias (its rows permuted as the weight's), or nullptr
+  const float* bcat;        // or a bias already in the operand's order, or nullptr
+  PackDims d;
+  __device__ inline float w(int k, int c) const {
+    const float* p = pack_param_ptr(bases, const_cast<float*>(comb_w), d, k, c);
+    return p != nullptr ? *p : 0.f;
+  }
+  __device__ inline float b(int j) const { return comb_b != nullptr ? comb_b[pack_comb_row(d, j)] : (bcat != nullptr ? bcat[j] : 0.f); }
+};
+template <class S>
+__device__ inline void ft_pack_column(int v, const S& src_of, int K, int F_g, int W, int ldb, ft_u16* __restrict__ packed) {
   const int lane = threadIdx.x;
-  const int ncol = F_g + W;
   const int src = (v < F_g) ? v : ((v < ldb || v >= ldb + W) ? -1 : v - ldb + F_g);
   unsigned amax = 0;
   if (src >= 0)
-    for (int k = lane; k < K; k += 64) amax = max(amax, __float_as_uint(wcat[(int64_t)k * ncol + src]) & 0x7fffffffu);
+    for (int k = lane; k < K; k += 64) amax = max(amax, __float_as_uint(src_of.w(k, src)) & 0x7fffffffu);
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) amax = max(amax, (unsigned)__shfl_xor((int)amax, d));
   unsigned be = amax >> 23;
@@ -51,7 +71,7 @@ __device__ inline void ft_pack_column(int v, const float* __restrict__ wcat, con
   const float scale = __uint_as_float((254u - be) << 23);
   const float inv = __uint_as_float(be << 23);
   for (int k = lane; k < FT_KP; k += 64) {
-    const float w = (src >= 0 && k < K) ? wcat[(int64_t)k * ncol + src] * scale : 0.f;
+    const float w = (src >= 0 && k < K) ? src_of.w(k, src) * scale : 0.f;
     const _Float16 h = (_Float16)w;
     const _Float16 l = (_Float16)((w - (float)h) * 2048.f);
     const int64_t base = ((((int64_t)(v >> 4) * 4 + (k >> 5)) * 2) * 64 + 16 * ((k & 31) >> 3) + (v & 15)) * 8 + (k & 7);
@@ -62,12 +82,12 @@ __device__ inline void ft_pack_column(int v, const float* __restrict__ wcat, con
     float* tail = reinterpret_cast<float*>(packed + (int64_t)FT_MFMA_WAVES * 4 * 2 * 64 * 8);
     tail[v] = inv;
     const int wcol = v - ldb;
-    tail[FT_NV + v] = (bcat != nullptr && wcol >= 0 && wcol < W) ? bcat[wcol] : 0.f;
+    tail[FT_NV + v] = (wcol >= 0 && wcol < W) ? src_of.b(wcol) : 0.f;
   }
 }
 __global__ void __launch_bounds__(64) ft_pack_kernel(const float* __restrict__ wcat, const float* __restrict__ bcat, int K,
                                                       int F_g, int W, int ldb, ft_u16* __restrict__ packed) {
-  ft_pack_column(blockIdx.x, wcat, bcat, K, F_g, W, ldb, packed);
+  ft_pack_column(blockIdx.x, FtWcatSrc{wcat, bcat, F_g + W}, K, F_g, W, ldb, packed);
 }
 
 // WIDE form: packed[32-column tile][k-step of 16][plane][lane][8] -- lane 32 (k % 16 / 8) + column % 32 holds k = 16 s + 8 (lane / 32) ..+7
@@ -354,10 +374,10 @@ int launch_fused_tile(AggArgs a, const int64_t* ptr, const int64_t* edge_ptr, in
 // packed_t[feature tile of 16][k-step of 32][plane][lane][8]: the B operand of d x = d W^T -- lane 16 (k % 32 / 8) + f % 16 holds
 // W[f][k], k = 32 s + 8 (lane / 16) ..+7, where k runs over the LDS images' columns: [d bases 0 .. ldb) | d w' as [h][b][4]
 // (a = 0 .. A - 1 real, the rest zero).  Scale per output feature f; tail: float col_inv[128].
-__device__ inline void ft_pack_t_feature(int f, const float* __restrict__ wcat, int K, int F_g, int W, int A, int ldb, int k2,
+template <class S>
+__device__ inline void ft_pack_t_feature(int f, const S& src_of, int K, int F_g, int W, int A, int ldb, int k2,
                                          ft_u16* __restrict__ packed) {
   const int lane = threadIdx.x;       // f: output feature (row of wcat), 0 .. 127
-  const int ncol = F_g + W;
   auto src_col = [&](int k) -> int {  // image column k -> column of wcat, or -1
     if (k < ldb) return k < F_g ? k : -1;
     const int j = k - ldb, hb = j >> 2, aa = j & 3;
@@ -367,7 +387,7 @@ __device__ inline void ft_pack_t_feature(int f, const float* __restrict__ wcat, 
   if (f < K)
     for (int k = lane; k < k2; k += 64) {
       const int c = src_col(k);
-      if (c >= 0) amax = max(amax, __float_as_uint(wcat[(int64_t)f * ncol + c]) & 0x7fffffffu);
+      if (c >= 0) amax = max(amax, __float_as_uint(src_of.w(f, c)) & 0x7fffffffu);
     }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) amax = max(amax, (unsigned)__shfl_xor((int)amax, d));
@@ -377,7 +397,7 @@ __device__ inline void ft_pack_t_feature(int f, const float* __restrict__ wcat, 
   const float inv = __uint_as_float(be << 23);
   for (int k = lane; k < 192; k += 64) {
     const int c = k < k2 ? src_col(k) : -1;
-    const float w = (f < K && c >= 0) ? wcat[(int64_t)f * ncol + c] * scale : 0.f;
+    const float w = (f < K && c >= 0) ? src_of.w(f, c) * scale : 0.f;
     const _Float16 h = (_Float16)w;
     const _Float16 l = (_Float16)((w - (float)h) * 2048.f);
     const int64_t base = ((((int64_t)(f >> 4) * 6 + (k >> 5)) * 2) * 64 + 16 * ((k & 31) >> 3) + (f & 15)) * 8 + (k & 7);
@@ -388,14 +408,21 @@ __device__ inline void ft_pack_t_feature(int f, const float* __restrict__ wcat, 
 }
 __global__ void __launch_bounds__(64) ft_pack_t_kernel(const float* __restrict__ wcat, int K, int F_g, int W, int A, int ldb,
                                                         int k2, ft_u16* __restrict__ packed) {
-  ft_pack_t_feature(blockIdx.x, wcat, K, F_g, W, A, ldb, k2, packed);
+  ft_pack_t_feature(blockIdx.x, FtWcatSrc{wcat, nullptr, F_g + W}, K, F_g, W, A, ldb, k2, packed);
 }
 // both operands of a training step in one launch: blocks 0 .. FT_NV - 1 the forward's columns, the next 128 the backward's features
 __global__ void __launch_bounds__(64) ft_pack_both_kernel(const float* __restrict__ wcat, const float* __restrict__ bcat, int K,
                                                            int F_g, int W, int A, int ldb, int k2, ft_u16* __restrict__ packed,
                                                            ft_u16* __restrict__ packed_t) {
-  if (blockIdx.x < FT_NV) ft_pack_column(blockIdx.x, wcat, bcat, K, F_g, W, ldb, packed);
-  else ft_pack_t_feature(blockIdx.x - FT_NV, wcat, K, F_g, W, A, ldb, k2, packed_t);
+  const FtWcatSrc src{wcat, bcat, F_g + W};
+  if (blockIdx.x < FT_NV) ft_pack_column(blockIdx.x, src, K, F_g, W, ldb, packed);
+  else ft_pack_t_feature(blockIdx.x - FT_NV, src, K, F_g, W, A, ldb, k2, packed_t);
+}
+// ... straight from the layer's parameters (no wcat / bcat arrays, no egc_weights_pack_f32 launch in front)
+__global__ void __launch_bounds__(64) ft_pack_both_params_kernel(FtParamSrc src, int K, int F_g, int W, int A, int ldb, int k2,
+                                                                  ft_u16* __restrict__ packed, ft_u16* __restrict__ packed_t) {
+  if (blockIdx.x < FT_NV) ft_pack_column(blockIdx.x, src, K, F_g, W, ldb, packed);
+  else ft_pack_t_feature(blockIdx.x - FT_NV, src, K, F_g, W, A, ldb, k2, packed_t);
 }
 
 bool fused_tile_bwd_shape(const AggArgs& a, int f_in) {
@@ -420,6 +447,16 @@ int fused_tile_train_pack(const AggArgs& a, const float* wcat, const float* bcat
   ft_pack_both_kernel<<<FT_NV + 128, 64, 0, stream>>>(wcat, bcat, f_in, f_g, w_cols, a.A, ldb, a.ldb + a.H * a.B * 4, (ft_u16*)packed,
                                                       (ft_u16*)packed_t);
   EGC_LAUNCH_CHECK("ft_pack_both_kernel");
+  return EGC_OK;
+}
+
+int fused_tile_train_pack_params(const AggArgs& a, const PackPtrs& bases, const float* comb_w, const float* comb_b, const float* bcat,
+                                 const PackDims& d, int f_g, int w_cols, int ldb, void* packed, void* packed_t, hipStream_t stream) {
+  if (!fused_tile_bwd_shape(a, d.F_in)) return EGC_ERR_UNSUPPORTED;
+  FtParamSrc src{bases, comb_w, comb_b, bcat, d};
+  ft_pack_both_params_kernel<<<FT_NV + 128, 64, 0, stream>>>(src, d.F_in, f_g, w_cols, a.A, ldb, a.ldb + a.H * a.B * 4, (ft_u16*)packed,
+                                                             (ft_u16*)packed_t);
+  EGC_LAUNCH_CHECK("ft_pack_both_params_kernel");
   return EGC_OK;
 }
 

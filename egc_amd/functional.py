@@ -401,6 +401,34 @@ def _batch_fused_train_pack(spec: LayerSpec, wcat: torch.Tensor, bcat):
     return packed, packed_t
 
 
+def _batch_fused_train_pack_params(spec: LayerSpec, dims, permute, comb_w, comb_b, bcat_direct, bases):
+    """(packed, packed_t) straight from the module's parameters (egc_batch_fused_train_pack_params: the index map of
+    egc_weights_pack_f32 inside the pack launch -- no wcat / bcat arrays, one launch instead of two), or None when a parameter is
+    not a dense float32 tensor on the device."""
+    f_in, H, A, B, L, Ls = dims
+    ts = [comb_w, *bases] + [t for t in (comb_b, bcat_direct) if t is not None]
+    dev = comb_w.device
+    if not all(t.is_cuda and t.device == dev and t.dtype == torch.float32 and t.is_contiguous() for t in ts):
+        return None
+    if comb_b is not None and bcat_direct is not None:
+        return None
+    lib = _C.load()
+    with _device_guard(dev):
+        nb, nbt = int(lib.egc_batch_fused_pack_bytes(C.byref(spec.c))), int(lib.egc_batch_fused_bwd_pack_bytes(C.byref(spec.c)))
+        if nb <= 0 or nbt <= 0:
+            return None
+        packed = torch.empty(nb, dtype=torch.uint8, device=dev)
+        packed_t = torch.empty(nbt, dtype=torch.uint8, device=dev)
+        ptrs = (C.c_void_p * len(bases))(*[b.data_ptr() for b in bases])
+        st = lib.egc_batch_fused_train_pack_params(C.byref(spec.c), ptrs, len(bases), comb_w.data_ptr(),
+                                                   comb_b.data_ptr() if comb_b is not None else None,
+                                                   bcat_direct.data_ptr() if bcat_direct is not None else None, H, A, B, L, Ls,
+                                                   int(permute), packed.data_ptr(), nb, packed_t.data_ptr(), nbt, _stream_ptr(dev))
+        if st != 0:
+            return None
+    return packed, packed_t
+
+
 def _batch_fused_setup(gb: GraphBatch, spec: LayerSpec, post, wcat, x=None):
     """(tile_nodes, max_tile_edges) when this layer call can run as ONE launch on the batch, else None.  A layer that asks for
     the 24-bit-operand GEMM (EGC_GEMM_STDVAR_24BIT=1 and std / var) keeps the two-launch path; EGC_NO_FUSED_TILE=1 switches
@@ -537,13 +565,19 @@ class _BatchFusedTrainFunction(torch.autograd.Function):
     def forward(ctx, x, bias, comb_w, comb_b, bcat_direct, gb, spec, dims, permute, setups, link, *bases):
         ctx.dims, ctx.permute, ctx.packed_b, ctx.link = dims, permute, comb_b is not None, link
         ctx.shapes = (comb_w.shape, comb_b.shape if comb_b is not None else None, [b.shape for b in bases])
-        wcat, bcat = _pack_params(dims, permute, comb_w, comb_b, bases)
-        bc = bcat if comb_b is not None else bcat_direct
-        packed, packed_t = _batch_fused_train_pack(spec, wcat, bc)
+        both = None if _C.env_flag("EGC_NO_PACK_FROM_PARAMS") else _batch_fused_train_pack_params(spec, dims, permute, comb_w, comb_b,
+                                                                                                    bcat_direct, bases)
+        if both is not None:           # the planes of both launches straight from the parameters: no wcat / bcat arrays
+            packed, packed_t = both
+            wcat = bc = None
+        else:
+            wcat, bcat = _pack_params(dims, permute, comb_w, comb_b, bases)
+            bc = bcat if comb_b is not None else bcat_direct
+            packed, packed_t = _batch_fused_train_pack(spec, wcat, bc)
         out = egc_layer_forward_batch_fused(gb, spec, x, wcat, bc, bias, None, setups[0], packed=packed)
         ctx.save_for_backward(x, wcat, packed, packed_t)
         ctx.gb, ctx.spec, ctx.bsetup = gb, spec, setups[1]
-        ctx.has_bcat, ctx.has_bias = bc is not None, bias is not None
+        ctx.has_bcat, ctx.has_bias = (comb_b is not None or bcat_direct is not None), bias is not None
         return out
 
     @staticmethod

@@ -592,6 +592,13 @@ int egc_batch_fused_bwd_pack(const egc_layer* layer, const float* wcat, void* pa
 /* egc_batch_fused_pack + egc_batch_fused_bwd_pack of the same wcat in one launch (a training step packs both once per update) */
 int egc_batch_fused_train_pack(const egc_layer* layer, const float* wcat, const float* bcat, void* packed, int64_t packed_bytes,
                                void* packed_t, int64_t packed_t_bytes, egc_stream_t stream);
+/* ... straight from the module's parameters through the index map of egc_weights_pack_f32 (bases_parts: ONE [F_in][B L] matrix or B of
+ * [F_in][L]; comb_weight [H B A][F_in], its rows [h][a][b] with permute_hab (EGConv) or [h][b][a]; comb_bias in the rows' order, or
+ * bcat in the operand's order, or neither): no wcat / bcat arrays and no pack launch in front. */
+int egc_batch_fused_train_pack_params(const egc_layer* layer, const float* const* bases_parts, int32_t n_parts, const float* comb_weight,
+                                      const float* comb_bias, const float* bcat, int32_t num_heads, int32_t num_aggrs, int32_t num_bases,
+                                      int32_t basis_len, int32_t basis_stride, int32_t permute_hab, void* packed, int64_t packed_bytes,
+                                      void* packed_t, int64_t packed_t_bytes, egc_stream_t stream);
 int egc_layer_backward_batch_fused_f32(const int64_t* graph_ptr, const int64_t* edge_ptr, int64_t n_graphs, const int64_t* src,
                                        const int64_t* dst, int64_t n_edges, int64_t n_nodes, const int32_t* max_index,
                                        const egc_layer* layer, const float* x, const void* packed, const void* packed_t,

@@ -231,7 +231,7 @@ def test_d_x_add_through_the_c_abi():
     add = torch.randn(n, 128, device=dev)
 
     def spy(gbb, spec, xx, wcat, packed, grad_out, setup, d_x_add=None, packed_t=None):
-        got["plain"] = real(gbb, spec, xx, wcat, packed, grad_out, setup)[0]                     # (packs the transposed operand itself)
+        got["plain"] = real(gbb, spec, xx, wcat, packed, grad_out, setup, None, packed_t)[0]
         got["added"] = real(gbb, spec, xx, wcat, packed, grad_out, setup, add, packed_t)[0]
         return real(gbb, spec, xx, wcat, packed, grad_out, setup, d_x_add, packed_t)
     orig = F.egc_layer_backward_batch_fused
@@ -298,3 +298,41 @@ def test_fuzz_against_the_csr_path(seed):
         scale = max(float(q.abs().max()) for q in res[1][2])
         for p, q in zip(res[0][2], res[1][2]):
             assert float((p - q).abs().max()) <= 2e-5 * scale, tag
+
+
+@pytest.mark.parametrize("kind", ["opt", "lay"])
+def test_planes_packed_from_the_parameters_are_those_packed_from_wcat(kind):
+    """egc_batch_fused_train_pack_params (the index map of egc_weights_pack_f32 inside the pack launch) against
+    egc_weights_pack_f32 + egc_batch_fused_train_pack: the same bytes, for both layer classes (EGConv: one bases matrix, the
+    combination Linear's rows [h][a][b]; EfficientGraphConv: B basis matrices, rows [h][b][a])."""
+    import egc_amd
+    from egc_amd import functional as F
+    dev = _dev()
+    torch.manual_seed(5)
+    if kind == "opt":
+        conv = egc_amd.EGConv(128, 128, aggrs=["sum", "mean", "max", "symnorm"], num_heads=8, num_bases=4).to(dev)
+    else:
+        conv = egc_amd.EfficientGraphConv(64, 64, 4, 4, False, aggrs=["symadd", "max", "mean"]).to(dev)
+    with torch.no_grad():
+        for p in conv.parameters():
+            p.copy_(torch.randn_like(p) * 3.0)
+    seen = {}
+    real_params, real_wcat = F._batch_fused_train_pack_params, F._batch_fused_train_pack
+
+    def spy_params(spec, dims, permute, comb_w, comb_b, bcat_direct, bases):
+        got = real_params(spec, dims, permute, comb_w, comb_b, bcat_direct, bases)
+        wcat, bcat = F._pack_params(dims, permute, comb_w, comb_b, bases)
+        seen["params"], seen["wcat"] = got, real_wcat(spec, wcat, bcat if comb_b is not None else bcat_direct)
+        return got
+    F._batch_fused_train_pack_params = spy_params
+    try:
+        ei, n, ptr = _messy_batch(2, n_graphs=20, max_size=40)
+        gb = egc_amd.GraphBatch(ei.to(dev), ptr=ptr.to(dev), max_nodes=40)
+        x = torch.randn(n, conv.in_channels, device=dev, requires_grad=True)
+        out = conv(x, gb) if kind == "opt" else conv(x=x, edge_index=gb)
+        out.sum().backward()
+    finally:
+        F._batch_fused_train_pack_params = real_params
+    gb.check()
+    assert _ran_bwd(gb) and seen["params"] is not None
+    assert torch.equal(seen["params"][0], seen["wcat"][0]) and torch.equal(seen["params"][1], seen["wcat"][1])
