@@ -191,6 +191,136 @@ def roofline_terms(n, e_eff, f_in, f_g, f_out, w_cols, symnorm):
 
 
 # -------------------------------------------------------------------------------------------------
+# the ONE JSON line: compact (the driver keeps a bounded tail of stdout: round 5's 23 KB line did not parse).
+# The full record goes to bench_detail.json (and to stderr); the line carries the contract keys, `roofline`,
+# `cpu_baseline`, the kernel times and -- per side config -- {workload, layer_ms | step_ms, frac, traffic} only.
+# -------------------------------------------------------------------------------------------------
+LINE_LIMIT_BYTES = 6000
+DETAIL_FILE = "bench_detail.json"
+
+
+def _r(v, sig=6):
+    """Floats to `sig` significant digits (the line's budget goes to fields, not to digits); containers recursively."""
+    if isinstance(v, float):
+        return float(f"{v:.{sig}g}")
+    if isinstance(v, dict):
+        return {k: _r(x, sig) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_r(x, sig) for x in v]
+    return v
+
+
+def _short(s, n):
+    s = str(s)
+    return s if len(s) <= n else s[:n - 1] + "~"
+
+
+def _shorten_strings(v, n):
+    if isinstance(v, str):
+        return _short(v, n)
+    if isinstance(v, dict):
+        return {k: _shorten_strings(x, n) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_shorten_strings(x, n) for x in v][:16]
+    return v
+
+
+def _side_record(rec):
+    """One side config on the line: what it is, how long it took, its fraction and counter traffic.  Everything else of the
+    record (every path's timings, byte models, its own cpu_baseline sample text) is in the detail file."""
+    if not isinstance(rec, dict):
+        return _short(rec, 120)
+    out = {"workload": _short(rec.get("workload", ""), 96)}
+    for k in ("layer_ms", "step_ms", "eager_step_ms", "hipgraph_replay_ms", "eager_ms", "coo_hipgraph_replay_ms", "csr_path_step_ms",
+              "speedup_vs_csr_path"):
+        if k in rec:
+            out[k] = rec[k]
+    rf = rec.get("roofline") if isinstance(rec.get("roofline"), dict) else {}
+    frac = rf.get("frac", rec.get("layer_frac", rec.get("step_frac")))
+    if frac is not None:
+        out["frac"] = frac
+    if "layer_frac" in rec and rf:
+        out["layer_frac"] = rec["layer_frac"]
+    if rf:
+        out["traffic"] = rf.get("traffic")
+    cb = rec.get("cpu_baseline")
+    if isinstance(cb, dict) and cb.get("value") is not None:
+        out["cpu_edges_per_s"] = cb["value"]
+        out["cpu_cores"] = cb.get("cores")
+    if "roofline_error" in rec:
+        out["error"] = _short(rec["roofline_error"], 120)
+    return out
+
+
+def compact_line(result):
+    """The line the driver parses, built from the full record.  Keeps every key of the contract; shrinks prose."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "gemm", "data")
+    line = {k: result[k] for k in keep if k in result}
+    if "gemm" in line:
+        line["gemm"] = _short(line["gemm"], 100)
+    cfg = dict(result.get("config", {}))
+    if "workload" in cfg:
+        cfg["workload"] = _short(cfg["workload"], 200)
+    line["config"] = cfg
+    rf = result.get("roofline")
+    if isinstance(rf, dict):
+        line["roofline"] = {k: rf[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
+                                               "algorithmic_bytes_per_launch", "launch_ms", "frac_vs_measured_copy_ceiling") if k in rf}
+        if "kernel" in line["roofline"]:
+            line["roofline"]["kernel"] = _short(line["roofline"]["kernel"], 80)
+    else:
+        line["roofline"] = rf
+    cb = result.get("cpu_baseline")
+    if isinstance(cb, dict):
+        line["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample", "host_cores", "hip_vs_port_rel_err", "error")
+                                if k in cb}
+        if "sample" in line["cpu_baseline"]:
+            line["cpu_baseline"]["sample"] = _short(line["cpu_baseline"]["sample"], 200)
+    else:
+        line["cpu_baseline"] = cb
+    for k in ("kernels_ms", "layer_frac", "layer_frac_by_gemm", "layer_algorithmic_bytes", "ms_per_step_median_of_5_regions"):
+        if k in result:
+            line[k] = result[k]
+    sl = result.get("std_layer")
+    if isinstance(sl, dict):
+        line["std_layer"] = {k: sl[k] for k in ("layer_ms", "layer_frac", "error") if k in sl}
+    oc = result.get("other_configs")
+    if isinstance(oc, dict):
+        line["other_configs"] = {k: _side_record(v) for k, v in oc.items()}
+    if "bench_scale" in result:
+        line["bench_scale"] = result["bench_scale"]
+    ss = result.get("strong_scaling")      # bench_multi.py: per workload a flat record of numbers + a few descriptions
+    if isinstance(ss, dict):
+        line["strong_scaling"] = {k: _shorten_strings(v, 80) for k, v in ss.items()}
+    line["detail"] = DETAIL_FILE
+    line = _r(line)
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) > LINE_LIMIT_BYTES:      # never print a line the driver cannot hold: drop side records, largest first
+        for field in ("other_configs", "strong_scaling"):
+            oc = line.get(field) or {}
+            while len(text) > LINE_LIMIT_BYTES and oc:
+                oc.pop(max(oc, key=lambda k: len(json.dumps(oc[k]))))
+                line[field + "_truncated"] = True
+                text = json.dumps(line, separators=(",", ":"))
+    return text
+
+
+def emit(result):
+    """Full record -> bench_detail.json (next to this file; EGC_BENCH_DETAIL overrides the path) and stderr; compact line -> stdout."""
+    path = os.environ.get("EGC_BENCH_DETAIL", os.path.join(ROOT, DETAIL_FILE))
+    full = json.dumps(result, indent=1)
+    try:
+        with open(path, "w") as f:
+            f.write(full + "\n")
+    except OSError as ex:
+        log(f"bench.py: could not write {path}: {ex!r}")
+    log("full record (" + path + "):")
+    log(json.dumps(result))
+    print(compact_line(result), flush=True)
+
+
+# -------------------------------------------------------------------------------------------------
 # other configs (N = 1): measured in the same run, module-level calls (what a caller of the layer pays)
 # -------------------------------------------------------------------------------------------------
 def measure_layer_config(name, ei_cpu, n, conv, f_in, dev, per_batch_csr, iters=30, batch=None, max_nodes=None, traffic_key=None,
@@ -575,14 +705,14 @@ def bench_rmag(args, world, dev):
             conv(x, adj)
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / args.steps * 1e3
-    print(json.dumps({
+    emit({
         "metric": METRIC, "value": entries / (ms * 1e-3), "unit": "edges/s", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": None, "vs_baseline": None,
         "dtype": "f32", "gemm": "fp16x2 / bf16x3 split, one GEMM per node type", "data": "synthetic",
         "config": {"workload": f"ogbn-mag-shaped typed graph ({sum(nodes.values())} nodes of {len(nodes)} types, "
                                f"{entries} CSR entries in {len(rel)} relations), REGConv {F_IN}->{F_OUT} H={HEADS} B={BASES}",
                    "layer": "REGConv", "parallelism": "single GPU"},
-        "roofline": None, "cpu_baseline": None}))
+        "roofline": None, "cpu_baseline": None})
 
 
 def main():
@@ -822,7 +952,7 @@ def main():
             log(f"cpu baseline failed: {ex!r}")
             result["cpu_baseline"] = {"value": None, "unit": "edges/s", "cores": 0, "kind": "port", "sample": "failed",
                                       "error": repr(ex)[:500]}
-    print(json.dumps(result), flush=True)
+    emit(result)
 
 
 if __name__ == "__main__":

@@ -482,7 +482,8 @@ def run(args, world, rank, local, workload):
             "strong_scaling": dict({("config2_arxiv" if workload in ("all", "arxiv") else workload): head}, **nested),
         }
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        import bench
+        bench.emit(line)      # compact line on stdout (bounded size), the full record in bench_detail.json + stderr
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
