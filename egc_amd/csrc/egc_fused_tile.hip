@@ -169,7 +169,7 @@ struct FtLds {
   int off_rec, off_planes, off_rowinv, off_bases, off_wt;
   int off_col, off_rowptr, off_cnt, off_dis;   // the CSR areas of an even tile; csr_stride bytes further: those of an odd tile
   int csr_stride;
-  int off_db, off_eid, off_rowinv2;            // backward form
+  int off_db, off_rowinv2;                     // backward form
 };
 
 static FtLds ft_lds(const AggArgs& a, int wl_floats, int tcap, int emax, bool with_post, bool wide = false, bool bwd = false) {
@@ -186,9 +186,8 @@ static FtLds ft_lds(const AggArgs& a, int wl_floats, int tcap, int emax, bool wi
   if (bwd) { L.off_db = (int)at; at += up16((size_t)(tcap + 1) * a.ldb * 8); }   // d bases as 64-bit fixed point (+ a row absent entries would address)
   const size_t csr0 = at;
   L.off_col = (int)at; at += up16((size_t)emax * 2);
-  if (bwd) { L.off_eid = (int)at; at += up16((size_t)emax * 2); }
   L.off_rowptr = (int)at; at += up16((size_t)(tcap + 1) * 4);
-  L.off_cnt = (int)at; at += up16((size_t)tcap * 4);
+  L.off_cnt = (int)at; at += up16((size_t)tcap * 4);      // (with rowptr: one 16-bit counter, then cursor, per CSR wavefront and row)
   L.off_dis = (int)at; at += up16((size_t)tcap * 4);
   L.csr_stride = (int)(at - csr0);
   at += L.csr_stride;       // the second set: tile it + 1's CSR is built while tile it's is being read
@@ -322,7 +321,7 @@ int launch_fused_tile(AggArgs a, const int64_t* ptr, const int64_t* edge_ptr, in
   t.magic0 = (unsigned)(((uint64_t)1 << 32) / (uint64_t)t.p0) + 1u;
   t.magic1 = (unsigned)(((uint64_t)1 << 32) / (uint64_t)std::max(1, (a.Ls >> 2) - t.p0)) + 1u;
   if (const char* e = getenv("EGC_FT_DBG")) t.dbg = atoi(e);     // (read by diagnostic builds of the kernel only: -DEGC_FT_STAMPS)
-  if (tcap < FT_CHUNK || tcap > FT_CHUNK * FT_RING || (tcap % (wide ? FTW_CH : FT_CHUNK)) != 0 || emax < 0) return EGC_ERR_INVALID;
+  if (tcap < FT_CHUNK || tcap > FT_CHUNK * FT_RING || (tcap % (wide ? FTW_CH : FT_CHUNK)) != 0 || emax < 0 || emax > 65535) return EGC_ERR_INVALID;   // (16-bit cursors of the CSR build)
   const FtLds L = ft_lds(a, t.wl_floats, tcap, emax, a.post_scale != nullptr, wide);
   if (L.total > FT_LDS_BUDGET) return EGC_ERR_UNSUPPORTED;
   t.off_rec = L.off_rec; t.off_planes = L.off_planes; t.off_rowinv = L.off_rowinv; t.off_bases = L.off_bases; t.off_wt = L.off_wt;
@@ -540,7 +539,7 @@ int launch_fused_tile_bwd(AggArgs a, const int64_t* ptr, const int64_t* edge_ptr
   if (L.total > FT_LDS_BUDGET) return EGC_ERR_UNSUPPORTED;
   t.off_rec = L.off_rec; t.off_planes = L.off_planes; t.off_rowinv = L.off_rowinv; t.off_bases = L.off_bases; t.off_wt = L.off_wt;
   t.off_col = L.off_col; t.off_rowptr = L.off_rowptr; t.off_cnt = L.off_cnt; t.off_dis = L.off_dis; t.csr_stride = L.csr_stride;
-  t.off_db = L.off_db; t.off_eid = L.off_eid; t.off_rowinv2 = L.off_rowinv2;
+  t.off_db = L.off_db; t.off_rowinv2 = L.off_rowinv2;
   int64_t grid = 256;
   if (const char* e = getenv("EGC_FT_GRID")) grid = std::max(1, atoi(e));
   grid = std::min<int64_t>(grid, std::max<int64_t>(1, n_graphs));

@@ -97,7 +97,6 @@ struct FusedTileArgs {
   int ld_dcat;
   const ft_u16* packed_t;    // [8][6][2][64][8] fp16 fragments of [bases_weight | comb_weight^T]^T, float col_inv[128]
   int off_db;                // LDS: d bases image [tcap][ldb]
-  int off_eid;               // LDS, per CSR set: input position (inside the tile's edge range) of every CSR entry, 16 bit
   int off_rowinv2;           // LDS: row scales of the staged d chunks [2][16]
 };
 
@@ -391,23 +390,51 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
     // three wavefronts in front of S2 and S3; the caller interleaves them with the requests for the tile's rows.  The first 8
     // edges of every lane stay in registers between S1 and S3 as packed local ids (tiles of up to 8 x 192 edges -- all of
     // configs 3 and 4 -- read their edges once).
-    constexpr int CT = FT_CSR_WAVES * 64;
-    constexpr int KEEP = 8;                                  // edges per lane kept between the stages
+    //
+    // DETERMINISTIC, INPUT ORDER (round 6): a row's entries sit in the CSR in the order of the edge list, as the reference's
+    // scatter sums them (SURVEY.md 8a note 9: "reference CPU order = edge order"), so two launches give the same bits and the
+    // first entry of a row attaining a maximum is the first in input order (torch_scatter's arg rule) without a position array.
+    //   * wavefront w of the three owns a CONTIGUOUS range of the tile's edges, [w S, (w + 1) S) with S = ceil(Et / 3) rounded
+    //     up to 64, and walks it in rounds of 64: lane l of round j holds edge w S + 64 j + l;
+    //   * per row one counter PER WAVEFRONT, 16 bits each, in the two words the finished CSR keeps for the row anyway:
+    //     cnt[i] = c0 | c1 << 16 and rowptr[i] = c2 | self loops << 16 (no LDS beyond round 5's: the image's rows are what it
+    //     costs); S2 turns them in place into the row's start and three cursors -- cnt[i] = start | (start + c0) << 16,
+    //     rowptr[i] = start | (start + c0 + c1) << 16: the rows phase reads the LOW half of a rowptr word;
+    //   * S3 takes an entry's position from a RETURNING add to its wavefront's cursor: the adds of one wavefront execute in
+    //     program order (rounds), and the lanes of one instruction that hit the same word are served in ascending lane order
+    //     (tools/src/lds_atomic_order.hip checks exactly this on the device; tests/test_fused_tile_gpu.py checks the result).
+    // The two words of every row of a set are zeroed at the top of the tile loop's iteration that builds into it (csr_zero: the
+    // set was last read in the rows phase of the tile before the current one, and the GEMM steps' barriers stand between the
+    // zeroing and the first count).
+    constexpr int KEEP = 8;                                  // rounds (edges per lane) kept in registers between the stages
     constexpr unsigned NO_EDGE = 0xffffffffu;
+    const int cw = wave - FT_FIRST_HELPER;                   // 0 .. 2 in the CSR wavefronts
     auto edge_rsrc = [&](const Tile& r, const int64_t* p) {
       return __builtin_amdgcn_make_buffer_rsrc((void*)(p + r.e0), 0, (unsigned)(r.ok ? r.Et : 0) * 8u, 0x00020000);
     };
-    // S0: the first KEEP edges of every lane, two consecutive ones per 16-byte request (edges 2 ht, 2 ht + 1 of batch j of
-    // 2 x 192), INTO THE REGISTERS OF THE ROW CHUNKS 5-8 (e = xr + 10: eight 16-byte values -- four of sources, four of
-    // destinations): those chunks were split long ago, their requests for the next tile follow S1, and so the edges in
-    // flight cost no register next to the tile of x.  (Entries beyond the tile's range read as 0 and are skipped below; the
-    // batch is a SCALAR offset -- it takes part in the range check -- so that one register addresses all of them.)
+    // a wavefront's span of the tile's edges, and how many of them exist
+    auto span_of = [&](const Tile& r, int& S, int& nw) {
+      const int Et = r.ok ? r.Et : 0;
+      S = (((Et + FT_CSR_WAVES - 1) / FT_CSR_WAVES) + 63) & ~63;
+      const int left = Et - cw * S;
+      nw = left < 0 ? 0 : (left > S ? S : left);
+    };
+    // S0: the first KEEP rounds of this wavefront's span, one edge per lane and 8-byte request, INTO THE REGISTERS OF ROW
+    // CHUNKS that were split long ago (e: eight 16-byte values -- e[j] = sources of rounds 2 j, 2 j + 1, e[4 + j] = their
+    // destinations; those chunks' requests for the next tile follow S1), so the edges in flight cost no register next to the
+    // tile of x.  (Entries beyond the tile's range read as 0, without traffic, and are skipped below.)
     auto csr_s0 = [&](const Tile& r, f4* e) {
       const __amdgpu_buffer_rsrc_t es = edge_rsrc(r, t.src), ed = edge_rsrc(r, t.dst);
+      int S, nw;
+      span_of(r, S, nw);
 #pragma unroll
-      for (int j = 0; j < KEEP / 2; ++j) {
-        e[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(es, (unsigned)ht * 16u, j * 2 * CT * 8, 0));
-        e[KEEP / 2 + j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(ed, (unsigned)ht * 16u, j * 2 * CT * 8, 0));
+      for (int j = 0; j < KEEP; ++j) {
+        // (one scalar offset for the span, the round in the instruction's immediate; rounds beyond the span's end fetch the next
+        // wavefront's first edges, from the same lines -- they are masked in S1 -- and nothing beyond the tile's range)
+        const ft_u2 sv = __builtin_bit_cast(ft_u2, __builtin_amdgcn_raw_buffer_load_b64(es, (unsigned)lane * 8u + 512u * j, cw * S * 8, 0));
+        const ft_u2 dv = __builtin_bit_cast(ft_u2, __builtin_amdgcn_raw_buffer_load_b64(ed, (unsigned)lane * 8u + 512u * j, cw * S * 8, 0));
+        if (j & 1) { e[j >> 1].z = __uint_as_float(sv.x); e[j >> 1].w = __uint_as_float(sv.y); e[KEEP / 2 + (j >> 1)].z = __uint_as_float(dv.x); e[KEEP / 2 + (j >> 1)].w = __uint_as_float(dv.y); }
+        else { e[j >> 1].x = __uint_as_float(sv.x); e[j >> 1].y = __uint_as_float(sv.y); e[KEEP / 2 + (j >> 1)].x = __uint_as_float(dv.x); e[KEEP / 2 + (j >> 1)].y = __uint_as_float(dv.y); }
       }
     };
     // an edge's ends as tile-local ids, or false: 64-bit ids whose upper halves are not zero lie outside every tile
@@ -419,9 +446,26 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       return hi == 0u && sl < (unsigned)T && dl < (unsigned)T;
     };
     typedef long long ft_l2 __attribute__((ext_vector_type(2)));
+    // one edge into its row's counters: this wavefront's 16 bits; a self loop also into the row's self-loop count (rare: one
+    // wave-uniform test per edge, the second add inside it)
+    auto count_edge = [&](int* cnt, int* rowptr, unsigned sl, unsigned dl) {
+      if (cw == 2) atomicAdd(&rowptr[dl], sl != dl ? 1 : 0x10001);
+      else {
+        atomicAdd(&cnt[dl], cw == 0 ? 1 : 0x10000);
+        if (__ballot(sl == dl) != 0) { if (sl == dl) atomicAdd(&rowptr[dl], 0x10000); }
+      }
+    };
+    // the building set's two words per row back to zero (every CSR thread one row: tcap <= 160 < 192)
+    auto csr_zero = [&](int set) {
+      char* cb = base + set * t.csr_stride;
+      if (ht < t.tcap) { reinterpret_cast<int*>(cb + t.off_cnt)[ht] = 0; reinterpret_cast<int*>(cb + t.off_rowptr)[ht] = 0; }
+    };
     auto csr_s1 = [&](const Tile& r, int set, const f4* e, unsigned (&epk)[KEEP]) {
       int* cnt = reinterpret_cast<int*>(base + set * t.csr_stride + t.off_cnt);
-      const int T = r.ok ? r.T : 0, Et = r.ok ? r.Et : 0;
+      int* rowptr = reinterpret_cast<int*>(base + set * t.csr_stride + t.off_rowptr);
+      const int T = r.ok ? r.T : 0;
+      int S, nw;
+      span_of(r, S, nw);
       bool bad = false;
 #pragma unroll
       for (int j = 0; j < KEEP / 2; ++j) {
@@ -429,11 +473,11 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
           unsigned pk = NO_EDGE;
-          if (j * 2 * CT + 2 * ht + k < Et) {
+          if (64 * (2 * j + k) + lane < nw) {
             unsigned sl, dl;
             if (!local_ids(s2[k], d2[k], r.n0, T, sl, dl)) bad = true;
             else {
-              atomicAdd(&cnt[dl], sl != dl ? 0x10001 : 1);
+              count_edge(cnt, rowptr, sl, dl);
               pk = sl | (dl << 16);
             }
           }
@@ -442,26 +486,29 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       }
       if (__ballot(bad) != 0 && lane == 0) ft_error(t, 1);
     };
-    // the edges beyond the first KEEP of every lane (tiles of more than 8 x 192 edges): requested and counted in one go
+    // the rounds beyond the first KEEP of a wavefront's span (tiles of more than 8 x 192 edges): requested and counted in one go
     auto csr_s1_rest = [&](const Tile& r, int set) {
       int* cnt = reinterpret_cast<int*>(base + set * t.csr_stride + t.off_cnt);
-      const int T = r.ok ? r.T : 0, Et = r.ok ? r.Et : 0;
-      if (Et <= KEEP * CT) return;
+      int* rowptr = reinterpret_cast<int*>(base + set * t.csr_stride + t.off_rowptr);
+      const int T = r.ok ? r.T : 0;
+      int S, nw;
+      span_of(r, S, nw);
+      if (__builtin_amdgcn_readfirstlane(nw) <= KEEP * 64) return;
       bool bad = false;
       const __amdgpu_buffer_rsrc_t es = edge_rsrc(r, t.src), ed = edge_rsrc(r, t.dst);
-      for (int i0 = KEEP * CT; i0 < Et; i0 += 4 * CT) {
+      for (int i0 = KEEP * 64; i0 < nw; i0 += 4 * 64) {
         long long s4[4], d4[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          s4[j] = __builtin_bit_cast(long long, __builtin_amdgcn_raw_buffer_load_b64(es, (unsigned)ht * 8u, (i0 + j * CT) * 8, 0));
-          d4[j] = __builtin_bit_cast(long long, __builtin_amdgcn_raw_buffer_load_b64(ed, (unsigned)ht * 8u, (i0 + j * CT) * 8, 0));
+          s4[j] = __builtin_bit_cast(long long, __builtin_amdgcn_raw_buffer_load_b64(es, (unsigned)lane * 8u + 512u * j, (cw * S + i0) * 8, 0));
+          d4[j] = __builtin_bit_cast(long long, __builtin_amdgcn_raw_buffer_load_b64(ed, (unsigned)lane * 8u + 512u * j, (cw * S + i0) * 8, 0));
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          if (i0 + j * CT + ht < Et) {
+          if (i0 + 64 * j + lane < nw) {
             unsigned sl, dl;
             if (!local_ids(s4[j], d4[j], r.n0, T, sl, dl)) bad = true;
-            else atomicAdd(&cnt[dl], sl != dl ? 0x10001 : 1);
+            else count_edge(cnt, rowptr, sl, dl);
           }
         }
       }
@@ -478,12 +525,17 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       // hundreds of cycles: all reads of a stage are issued before the first is used)
       const int per = (T + 63) >> 6;           // <= 3: T <= 160
       const int b0 = lane * per;
-      int cv[FT_PER];
+      int ca[FT_PER], cb2[FT_PER];
 #pragma unroll
-      for (int j = 0; j < FT_PER; ++j) cv[j] = cnt[min(b0 + j, t.tcap - 1)];
+      for (int j = 0; j < FT_PER; ++j) { ca[j] = cnt[min(b0 + j, t.tcap - 1)]; cb2[j] = rowptr[min(b0 + j, t.tcap - 1)]; }
       int mine = 0;
 #pragma unroll
-      for (int j = 0; j < FT_PER; ++j) { cv[j] = (j < per && b0 + j < T) ? cv[j] : 0; mine += cv[j] & 0xffff; }
+      for (int j = 0; j < FT_PER; ++j) {
+        const bool on = j < per && b0 + j < T;
+        ca[j] = on ? ca[j] : 0;
+        cb2[j] = on ? cb2[j] : 0;
+        mine += (ca[j] & 0xffff) + (int)((unsigned)ca[j] >> 16) + (cb2[j] & 0xffff);
+      }
       // inclusive scan over the wavefront on the DPP network (row shifts inside the rows of 16, then the two row broadcasts)
       int incl = mine;
       incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);   // row_shr:1
@@ -497,69 +549,62 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       for (int j = 0; j < FT_PER; ++j) {
         const int i = b0 + j;
         if (j < per && i < T) {
-          const int c = cv[j] & 0xffff, ns = cv[j] >> 16;
-          rowptr[i] = run;
+          const int c0 = ca[j] & 0xffff, c1 = (int)((unsigned)ca[j] >> 16), c2 = cb2[j] & 0xffff;
+          const int c = c0 + c1 + c2, ns = c - (int)((unsigned)cb2[j] >> 16);
+          cnt[i] = run | ((run + c0) << 16);                                  // the scatter's cursors, one per wavefront;
+          rowptr[i] = run | ((run + c0 + c1) << 16);                          // the row's start (what the rows phase reads)
           run += c;
-          cnt[i] = c;                                                          // the scatter's cursor
           // deg^-1/2 of the layer's symnorm edge set, as prepare_kernel / build_scan_kernel (egc_graph.hip)
           dis[i] = C::yl(a) ? 1.0f / sqrtf((float)(ns + 1)) : (c > 0 ? 1.0f / sqrtf((float)c) : 0.0f);
         }
       }
       if (lane == 63) rowptr[T] = incl;
     };
+    // an entry's position: a returning add to its wavefront's cursor of the row (in-order per wavefront, ascending lanes)
+    auto take_pos = [&](int* cnt, int* rowptr, unsigned dl) -> int {
+      if (cw == 0) return __hip_atomic_fetch_add(&cnt[dl], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & 0xffff;
+      return (int)((unsigned)__hip_atomic_fetch_add(cw == 1 ? &cnt[dl] : &rowptr[dl], 0x10000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 16);
+    };
     auto csr_s3 = [&](const Tile& r, int set, const unsigned (&epk)[KEEP]) {
       char* cb = base + set * t.csr_stride;
       unsigned short* col = reinterpret_cast<unsigned short*>(cb + t.off_col);
-      unsigned short* eid = reinterpret_cast<unsigned short*>(cb + t.off_eid);     // (MODE 1: the entries' input positions)
-      const int* rowptr = reinterpret_cast<const int*>(cb + t.off_rowptr);
       int* cnt = reinterpret_cast<int*>(cb + t.off_cnt);
-      const int T = r.ok ? r.T : 0, Et = r.ok ? r.Et : 0;
-      int pos[KEEP], old[KEEP];
+      int* rowptr = reinterpret_cast<int*>(cb + t.off_rowptr);
+      const int T = r.ok ? r.T : 0;
+      int S, nw;
+      span_of(r, S, nw);
+      int pos[KEEP];
 #pragma unroll
-      for (int j = 0; j < KEEP; ++j) {
-        pos[j] = 0; old[j] = 0;
-        if (epk[j] != NO_EDGE) {
-          const int dl = (int)(epk[j] >> 16);
-          pos[j] = rowptr[dl];
-          old[j] = __hip_atomic_fetch_add(&cnt[dl], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
+      for (int j = 0; j < KEEP; ++j) {         // (all the adds issued before the first position is used)
+        pos[j] = 0;
+        if (epk[j] != NO_EDGE) pos[j] = take_pos(cnt, rowptr, epk[j] >> 16);
       }
 #pragma unroll
       for (int j = 0; j < KEEP; ++j)
-        if (epk[j] != NO_EDGE) {
-          col[pos[j] + old[j] - 1] = (unsigned short)(epk[j] & 0xffffu);
-          // (edge 2 ht + (j & 1) of batch j / 2 of 2 x CT edges: csr_s0's order)
-          if constexpr (MODE == 1) eid[pos[j] + old[j] - 1] = (unsigned short)((j >> 1) * 2 * CT + 2 * ht + (j & 1));
-        }
-      if (Et > KEEP * CT) {      // (larger tiles: the rest of their edges a second time, from L2)
+        if (epk[j] != NO_EDGE) col[pos[j]] = (unsigned short)(epk[j] & 0xffffu);
+      if (__builtin_amdgcn_readfirstlane(nw) > KEEP * 64) {      // (larger tiles: the rest of their edges a second time, from L2)
         const __amdgpu_buffer_rsrc_t es = edge_rsrc(r, t.src), ed = edge_rsrc(r, t.dst);
-        for (int i0 = KEEP * CT; i0 < Et; i0 += 4 * CT) {
+        for (int i0 = KEEP * 64; i0 < nw; i0 += 4 * 64) {
           long long s4[4], d4[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            s4[j] = __builtin_bit_cast(long long, __builtin_amdgcn_raw_buffer_load_b64(es, (unsigned)ht * 8u, (i0 + j * CT) * 8, 0));
-            d4[j] = __builtin_bit_cast(long long, __builtin_amdgcn_raw_buffer_load_b64(ed, (unsigned)ht * 8u, (i0 + j * CT) * 8, 0));
+            s4[j] = __builtin_bit_cast(long long, __builtin_amdgcn_raw_buffer_load_b64(es, (unsigned)lane * 8u + 512u * j, (cw * S + i0) * 8, 0));
+            d4[j] = __builtin_bit_cast(long long, __builtin_amdgcn_raw_buffer_load_b64(ed, (unsigned)lane * 8u + 512u * j, (cw * S + i0) * 8, 0));
           }
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            if (i0 + j * CT + ht < Et) {
+            if (i0 + 64 * j + lane < nw) {
               unsigned sl, dl;
-              if (local_ids(s4[j], d4[j], r.n0, T, sl, dl)) {
-                const int ps = rowptr[dl] + atomicSub(&cnt[dl], 1) - 1;
-                col[ps] = (unsigned short)sl;
-                if constexpr (MODE == 1) eid[ps] = (unsigned short)(i0 + j * CT + ht);
-              }
+              if (local_ids(s4[j], d4[j], r.n0, T, sl, dl)) col[take_pos(cnt, rowptr, dl)] = (unsigned short)sl;
             }
           }
         }
       }
     };
-    // both sets of counts start at zero (afterwards every build leaves its set zero)
+    // both sets' counters start at zero (afterwards: csr_zero at the top of the tile loop)
     if (wave < FT_FIRST_HELPER + FT_CSR_WAVES) {
-      for (int i = ht; i < t.tcap; i += FT_CSR_WAVES * 64) {
-        reinterpret_cast<int*>(base + t.off_cnt)[i] = 0;
-        reinterpret_cast<int*>(base + t.csr_stride + t.off_cnt)[i] = 0;
-      }
+      csr_zero(0);
+      csr_zero(1);
       csr_sync();
     }
 
@@ -639,7 +684,9 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
         for (int b = 0; b < NB; ++b) {
           f4 v[PB];
 #pragma unroll
-          for (int i = 0; i < PB; ++i) v[i] = load_slot(rg, (unsigned)(ht + (PB * b + i) * FT_HELPER_THREADS) * 16u);
+          for (int i = 0; i < PB; ++i)       // (the piece is a SCALAR offset: as per-lane offsets the sixteen addresses were spilled, and
+                                             //  every reload stood, with a vmcnt(0), in front of its request -- one round trip per piece)
+            v[i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rg, (unsigned)ht * 16u, (PB * b + i) * FT_HELPER_THREADS * 16, 0));
 #pragma unroll
           for (int i = 0; i < PB; ++i)
             m = max(m, __float_as_uint(fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w)))));
@@ -689,6 +736,9 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       lds_barrier();                                   // (chunks 0 and 1 staged; the CSR of this tile complete)
       unsigned epk[KEEP];                      // (declared per tile: nothing of the build is carried over)
       const int nset = (it + 1) & 1;
+      // the counters of the set the next tile's CSR is built into (last read in the rows phase of tile it - 1); the GEMM steps'
+      // barriers stand between this and the build's first count (a tile without steps: the builders' own synchronisation)
+      if (csr_wave) { csr_zero(nset); if (cur.nch == 0) csr_sync(); }
 #pragma unroll
       for (int c = 0; c < RINGN; ++c) {
         if (c < cur.nch) {   // workgroup-uniform
@@ -1002,6 +1052,7 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       lds_barrier();                                   // (slab 0 of chunk 0 staged; the CSR of this tile complete)
       unsigned epk[KEEP];
       const int nset = (it + 1) & 1;
+      if (csr_wave) { csr_zero(nset); if (cur.nch == 0) csr_sync(); }     // (as in the narrow form)
       int qn = 1;                                      // plane buffer of the step being staged (the step after the one running)
 #pragma unroll
       for (int c = 0; c < FTW_MAXCH; ++c) {
@@ -1169,7 +1220,8 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
     // this tile's CSR (built by wavefront 14 during the previous tile's rows phase)
     char* cb = base + (it & 1) * t.csr_stride;
     const unsigned short* lds_col = reinterpret_cast<const unsigned short*>(cb + t.off_col);
-    const int* lds_rowptr = reinterpret_cast<const int*>(cb + t.off_rowptr);
+    // (a row's start is the LOW half of its rowptr word; the high half is a cursor of the CSR build: csr_s2)
+    const unsigned short* lds_rowptr = reinterpret_cast<const unsigned short*>(cb + t.off_rowptr);
     const float* lds_dis = reinterpret_cast<const float*>(cb + t.off_dis);
 
     // ---- this wavefront's weight tile: requested when the wavefront left the rows of the tile before (below); the row counter ----
@@ -1394,8 +1446,8 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       const int r = r0 + g;
       const bool row_ok = r < T;
       const int row = n0 + (row_ok ? r : 0);
-      const int start = row_ok ? lds_rowptr[r] : 0;
-      const int nd = row_ok ? lds_rowptr[r + 1] - start : 0;
+      const int start = row_ok ? (int)lds_rowptr[2 * r] : 0;
+      const int nd = row_ok ? (int)lds_rowptr[2 * r + 2] - start : 0;
       int maxd = nd;
 #pragma unroll
       for (int off = LPR; off < 64; off <<= 1) maxd = max(maxd, bperm((lane ^ off) << 2, maxd));
@@ -1497,7 +1549,6 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
     //      over w' in the image), and the row's gradients travel to its SOURCES' rows of the d bases image by LDS float
     //      atomics: sum / mean / symnorm along every entry, max to the one entry that attained it.  (B = 4 bases of 16
     //      channels: 16 slots, four lanes per basis; aggregators sum / mean / max / symnorm; no weight nonlinearity.)
-    const unsigned short* lds_eid = reinterpret_cast<const unsigned short*>(cb + t.off_eid);
     long long* lds_db = reinterpret_cast<long long*>(base + t.off_db);
     // The sources' gradients are summed by LDS atomics, and float LDS atomics run at ONE LANE PER CLOCK for the whole CU on
     // gfx950 (tools/src/lds_atomic_bench.hip: 768 cycles per wave instruction with twelve wavefronts adding, 62 for ds_add_u64):
@@ -1538,8 +1589,8 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
 #else
         gv[h] = load_slot(rgo, (row_ok && h < H) ? ((unsigned)row * (unsigned)F_out + (unsigned)(h * 16 + 4 * l4)) * 4u : OOB);
 #endif
-      const int start = row_ok ? lds_rowptr[r] : 0;
-      const int nd = row_ok ? lds_rowptr[r + 1] - start : 0;
+      const int start = row_ok ? (int)lds_rowptr[2 * r] : 0;
+      const int nd = row_ok ? (int)lds_rowptr[2 * r + 2] - start : 0;
       int maxd = nd;
 #pragma unroll
       for (int off = LPR; off < 64; off <<= 1) maxd = max(maxd, bperm((lane ^ off) << 2, maxd));
@@ -1550,7 +1601,7 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       if (looped_any && has_self) vself = lds_bases4[r * ldb4 + q];
       f4 sum = f4{0.f, 0.f, 0.f, 0.f}, ws = sum, mx = f4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
       i4 ax = i4{ARG_NONE, ARG_NONE, ARG_NONE, ARG_NONE}, aj = i4{-1, -1, -1, -1};
-      auto take = [&](f4 v, int pos, int j) {     // (value, input position) lexicographic: the FIRST entry attaining the maximum
+      auto take = [&](f4 v, int pos, int j) {     // (value, position in the row = input order) lexicographic: the FIRST entry attaining the maximum
         const bool cx = v.x > mx.x || (v.x == mx.x && pos < ax.x), cy = v.y > mx.y || (v.y == mx.y && pos < ax.y);
         const bool cz = v.z > mx.z || (v.z == mx.z && pos < ax.z), cw = v.w > mx.w || (v.w == mx.w && pos < ax.w);
         mx = f4{cx ? v.x : mx.x, cy ? v.y : mx.y, cz ? v.z : mx.z, cw ? v.w : mx.w};
@@ -1564,7 +1615,6 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
 #endif
         const bool pv = ts + q < nd;
         const int jj = pv ? (int)lds_col[start + ts + q] : 0;
-        const int ee = pv ? (int)lds_eid[start + ts + q] : 0;
         const bool self_e = pv && jj == r;
         float dd = (pv && want_dis) ? lds_dis[jj] * dis_i : 0.f;
         if (C::yl(a) && !C::xl(a)) dd = self_e ? 0.f : dd;
@@ -1577,12 +1627,11 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
         for (int t0 = 0; t0 < cnt_e; t0 += FU) {
           f4 v[FU];
           float w[FU];
-          int jn[FU], en[FU];
+          int jn[FU];
 #pragma unroll
           for (int uu = 0; uu < FU; ++uu) {
             const int addr = grp_addr + ((t0 + uu) << 2);
             jn[uu] = bperm(addr, jx);
-            en[uu] = bperm(addr, ee);
             v[uu] = *reinterpret_cast<const f4*>(bases_q + __umul24((unsigned)jn[uu], ldb_bytes));
             w[uu] = bperm(addr, dd);
           }
@@ -1593,7 +1642,7 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
 #ifdef EGC_FT_STAMPS
             if (!(t.dbg & 32))
 #endif
-            if (jn[uu] != zrow) take(v[uu], en[uu], jn[uu]);
+            if (jn[uu] != zrow) take(v[uu], ts + t0 + uu, jn[uu]);     // (the row's entries are in input order: csr_s3)
           }
         }
       }

@@ -25,6 +25,7 @@ def _run(nproc, port, env_extra):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
+    assert len(lines[0]) < 6000, len(lines[0])      # the driver keeps a bounded tail of stdout
     return json.loads(lines[0])
 
 
@@ -42,7 +43,8 @@ def _check_line(line, world, partitioned):
             ex = rec["exchange"]
             assert len(ex["halo_rows_per_rank"]) == world and ex["row_bytes"] % 16 == 0
             assert ex["max_peer_bytes"] == ex["max_peer_rows"] * ex["row_bytes"]
-            assert abs(ex["predicted_exchange_ms"] - ex["max_peer_bytes"] / 153e9 * 1e3) < 1e-9
+            # (the line carries six significant digits: bench.compact_line)
+            assert abs(ex["predicted_exchange_ms"] - ex["max_peer_bytes"] / 153e9 * 1e3) <= 1e-5 * ex["predicted_exchange_ms"] + 1e-12
             assert ex["measured_exchange_alone_ms_rank0"] >= 0
             if world > 1:
                 assert ex["max_peer_rows"] > 0 and sum(ex["halo_rows_per_rank"]) > 0

@@ -1,0 +1,148 @@
+"""The one-launch batch kernels build a tile's CSR in INPUT ORDER (round 6; egc_fused_tile_dev.h, csr_s1 .. csr_s3): a row's
+entries sit in the order of the edge list, as the reference's CPU scatter sums them (SURVEY.md 8a note 9: "reference CPU order =
+edge order"; torch_scatter's scatter_cpu walks the edges once, in order).  Two consequences, both checked here:
+
+  * a `sum` over a row equals the SEQUENTIAL float32 sum of its entries in edge order, bit for bit (the layer is set up so that
+    everything around the sum is exact: identity bases, weightings == 1);
+  * two launches on the same inputs give the same bits -- forward outputs and every gradient of the 4-block training step of
+    the reference's batched nets (zinc/models.py:60-74) on the batch path.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _ran(gb, what):
+    return any(isinstance(k, tuple) and k[-1] == what and v for k, v in gb._setups.items())
+
+
+def _exact_rows(n, f, rng):
+    """float32 values with 22 significant bits and exponents within 2^4 of each other: the fp16x2 split of the in-launch GEMM
+    (two 11-bit planes under one row scale) carries them exactly."""
+    m = rng.integers(1 << 21, 1 << 22, size=(n, f)).astype(np.float64) / (1 << 21)          # [1, 2), 22 bits
+    e = rng.integers(-2, 3, size=(n, f))
+    s = rng.choice([-1.0, 1.0], size=(n, f))
+    return (s * m * np.exp2(e)).astype(np.float32)
+
+
+def _sequential_sum(x, src, dst, n):
+    out = np.zeros((n, x.shape[1]), np.float32)
+    np.add.at(out, dst, x[src])          # unbuffered: one float32 add per edge, in edge order
+    return out
+
+
+@pytest.mark.parametrize("workload,deg", [("molecules", 3), ("dense", 24), ("one wavefront's span", 2), ("beyond the registers", 90)])
+def test_row_sums_follow_the_edge_order_bit_for_bit(workload, deg):
+    import egc_amd
+    dev = _dev()
+    rng = np.random.default_rng(11 + deg)
+    f = 64
+    # graphs of 20 .. 60 nodes; `deg` random in-edges per node in random ORDER (a destination's edges are scattered over the
+    # graph's edge range, as a collated batch has them: sorted by graph, not by destination); duplicates and self loops included
+    n_graphs = 40 if deg < 90 else 12
+    sizes = rng.integers(20, 61, size=n_graphs)
+    if deg == 90:
+        sizes = rng.integers(100, 150, size=n_graphs)          # tiles of > 8 x 192 edges: the streamed rounds of the build
+    ptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    src, dst = [], []
+    for g in range(n_graphs):
+        m, o = int(sizes[g]), int(ptr[g])
+        e = deg * m
+        s, d = rng.integers(0, m, size=e) + o, rng.integers(0, m, size=e) + o
+        p = rng.permutation(e)
+        src.append(s[p]); dst.append(d[p])
+    src, dst = np.concatenate(src), np.concatenate(dst)
+    n = int(ptr[-1])
+    x = _exact_rows(n, f, rng)
+    conv = egc_amd.EGConv(f, f, aggrs=["sum"], num_heads=1, num_bases=1, add_self_loops=False, bias=False)
+    with torch.no_grad():
+        conv.bases_weight.copy_(torch.eye(f))
+        conv.comb_weight.weight.zero_()
+        conv.comb_weight.bias.fill_(1.0)
+    conv = conv.to(dev).eval()
+    ei = torch.from_numpy(np.stack([src, dst])).to(dev)
+    gb = egc_amd.GraphBatch(ei, ptr=torch.from_numpy(ptr).to(dev), max_nodes=int(sizes.max()), edges_per_node=max(16, deg))
+    with torch.no_grad():
+        out = conv(torch.from_numpy(x).to(dev), gb)
+    gb.check()
+    assert _ran(gb, "fused"), "the one-launch kernel did not run"
+    want = _sequential_sum(x, src, dst, n)
+    got = out.cpu().numpy()
+    # the test has teeth: the same entries summed in the reverse order give other bits in a good share of the elements
+    rev = _sequential_sum(x, src[::-1], dst[::-1], n)
+    assert (rev.view(np.uint32) != want.view(np.uint32)).mean() > (0.02 if deg <= 3 else 0.2)
+    bad = got.view(np.uint32) != want.view(np.uint32)
+    assert not bad.any(), f"{int(bad.sum())} of {bad.size} elements are not the edge-order sum (rows {np.unique(np.nonzero(bad)[0])[:8]})"
+
+
+def _blocks_step(blocks, graph, x0, go):
+    for p in blocks.parameters():
+        p.grad = None
+    x = x0.clone().requires_grad_(True)
+    h = x
+    for b in blocks:
+        h = b(h, graph)
+    h.backward(go)
+    return h.detach().clone(), x.grad.detach().clone(), [p.grad.detach().clone() for p in blocks.parameters()]
+
+
+@pytest.mark.parametrize("workload", ["molhiv_b2048", "zinc_b128"])
+def test_training_step_on_the_batch_path_is_bit_reproducible(workload):
+    """4 x [EGConv -> BatchNorm1d(train) -> ReLU -> + x] forward + backward, twice, on new GraphBatch objects: every output and
+    gradient identical.  (Round 5: the LDS-atomic CSR order made two runs differ by rounding, and a ReLU mask could flip.)"""
+    import egc_amd
+    from egc_amd import workloads as wl
+    dev = _dev()
+    if workload == "molhiv_b2048":
+        ei, n, bvec = wl.molecule_batch(2048, seed=0)
+    else:
+        ei, n, bvec = wl.zinc_like_batch(128, seed=0)[1:]
+    torch.manual_seed(0)
+    blocks = torch.nn.ModuleList([egc_amd.FusedEGCBlock(egc_amd.EGConv(128, 128, aggrs=["sum", "mean", "max", "symnorm"], num_heads=8,
+                                                                        num_bases=4), torch.nn.BatchNorm1d(128)) for _ in range(4)]).to(dev).train()
+    ei = ei.to(dev)
+    sizes = torch.bincount(bvec.to(dev))
+    ptr = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(sizes, 0)])
+    x0, go = torch.randn(n, 128, device=dev), torch.randn(n, 128, device=dev)
+    runs = []
+    for _ in range(3):
+        gb = egc_amd.GraphBatch(ei, ptr=ptr, max_nodes=int(sizes.max()), num_nodes=n)
+        runs.append(_blocks_step(blocks, gb, x0, go))
+        gb.check()
+        assert _ran(gb, "fused_bwd"), "the one-launch backward did not run"
+    for r in runs[1:]:
+        assert torch.equal(r[0], runs[0][0]), "forward outputs differ between two runs"
+        assert torch.equal(r[1], runs[0][1]), "d x differs between two runs"
+        for a, b in zip(r[2], runs[0][2]):
+            assert torch.equal(a, b), "a parameter gradient differs between two runs"
+
+
+def test_eval_forward_is_bit_reproducible_on_every_one_launch_form():
+    """narrow (d = 128) and WIDE (the reference's 168 / 224 / 296-wide nets) forward launches, twice each."""
+    import egc_amd
+    from egc_amd import workloads as wl
+    dev = _dev()
+    ei, n, bvec = wl.molecule_batch(512, seed=1)
+    ei = ei.to(dev)
+    sizes = torch.bincount(bvec.to(dev))
+    ptr = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(sizes, 0)])
+    for hidden, H, aggrs, asl in ((128, 8, ["sum", "mean", "max", "symnorm"], True), (168, 8, ["symnorm"], True),
+                                  (224, 4, ["sum", "mean", "max"], False), (296, 8, ["symnorm"], True), (128, 8, ["sum", "std", "max"], True)):
+        torch.manual_seed(hidden)
+        conv = egc_amd.EGConv(hidden, hidden, aggrs=aggrs, num_heads=H, num_bases=4, add_self_loops=asl).to(dev).eval()
+        x = torch.randn(n, hidden, device=dev)
+        outs = []
+        for _ in range(3):
+            gb = egc_amd.GraphBatch(ei, ptr=ptr, max_nodes=int(sizes.max()), num_nodes=n)
+            with torch.no_grad():
+                outs.append(conv(x, gb).clone())
+            gb.check()
+            assert _ran(gb, "fused"), (hidden, "the one-launch kernel did not run")
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), hidden
