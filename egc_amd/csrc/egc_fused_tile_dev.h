@@ -429,12 +429,15 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       span_of(r, S, nw);
 #pragma unroll
       for (int j = 0; j < KEEP; ++j) {
-        // (one scalar offset for the span, the round in the instruction's immediate; rounds beyond the span's end fetch the next
-        // wavefront's first edges, from the same lines -- they are masked in S1 -- and nothing beyond the tile's range)
-        const ft_u2 sv = __builtin_bit_cast(ft_u2, __builtin_amdgcn_raw_buffer_load_b64(es, (unsigned)lane * 8u + 512u * j, cw * S * 8, 0));
-        const ft_u2 dv = __builtin_bit_cast(ft_u2, __builtin_amdgcn_raw_buffer_load_b64(ed, (unsigned)lane * 8u + 512u * j, cw * S * 8, 0));
-        if (j & 1) { e[j >> 1].z = __uint_as_float(sv.x); e[j >> 1].w = __uint_as_float(sv.y); e[KEEP / 2 + (j >> 1)].z = __uint_as_float(dv.x); e[KEEP / 2 + (j >> 1)].w = __uint_as_float(dv.y); }
-        else { e[j >> 1].x = __uint_as_float(sv.x); e[j >> 1].y = __uint_as_float(sv.y); e[KEEP / 2 + (j >> 1)].x = __uint_as_float(dv.x); e[KEEP / 2 + (j >> 1)].y = __uint_as_float(dv.y); }
+        // (only the rounds the span has -- wave-uniform: a molecule tile has one or two, a superpixel tile five -- each behind
+        // one scalar offset for the span with the round in the instruction's immediate; what follows the edges in the
+        // vector-memory queue, the tile's rows, is unconditional, so the counted waits stay exact)
+        if (64 * j < nw) {
+          const ft_u2 sv = __builtin_bit_cast(ft_u2, __builtin_amdgcn_raw_buffer_load_b64(es, (unsigned)lane * 8u + 512u * j, cw * S * 8, 0));
+          const ft_u2 dv = __builtin_bit_cast(ft_u2, __builtin_amdgcn_raw_buffer_load_b64(ed, (unsigned)lane * 8u + 512u * j, cw * S * 8, 0));
+          if (j & 1) { e[j >> 1].z = __uint_as_float(sv.x); e[j >> 1].w = __uint_as_float(sv.y); e[KEEP / 2 + (j >> 1)].z = __uint_as_float(dv.x); e[KEEP / 2 + (j >> 1)].w = __uint_as_float(dv.y); }
+          else { e[j >> 1].x = __uint_as_float(sv.x); e[j >> 1].y = __uint_as_float(sv.y); e[KEEP / 2 + (j >> 1)].x = __uint_as_float(dv.x); e[KEEP / 2 + (j >> 1)].y = __uint_as_float(dv.y); }
+        }
       }
     };
     // an edge's ends as tile-local ids, or false: 64-bit ids whose upper halves are not zero lie outside every tile
@@ -473,6 +476,7 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
           unsigned pk = NO_EDGE;
+          if (64 * (2 * j + k) >= nw) { epk[2 * j + k] = pk; continue; }     // (wave-uniform: the span has no such round)
           if (64 * (2 * j + k) + lane < nw) {
             unsigned sl, dl;
             if (!local_ids(s2[k], d2[k], r.n0, T, sl, dl)) bad = true;
@@ -577,11 +581,11 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
 #pragma unroll
       for (int j = 0; j < KEEP; ++j) {         // (all the adds issued before the first position is used)
         pos[j] = 0;
-        if (epk[j] != NO_EDGE) pos[j] = take_pos(cnt, rowptr, epk[j] >> 16);
+        if (64 * j < nw && epk[j] != NO_EDGE) pos[j] = take_pos(cnt, rowptr, epk[j] >> 16);
       }
 #pragma unroll
       for (int j = 0; j < KEEP; ++j)
-        if (epk[j] != NO_EDGE) col[pos[j]] = (unsigned short)(epk[j] & 0xffffu);
+        if (64 * j < nw && epk[j] != NO_EDGE) col[pos[j]] = (unsigned short)(epk[j] & 0xffffu);
       if (__builtin_amdgcn_readfirstlane(nw) > KEEP * 64) {      // (larger tiles: the rest of their edges a second time, from L2)
         const __amdgpu_buffer_rsrc_t es = edge_rsrc(r, t.src), ed = edge_rsrc(r, t.dst);
         for (int i0 = KEEP * 64; i0 < nw; i0 += 4 * 64) {
@@ -1221,7 +1225,7 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
     char* cb = base + (it & 1) * t.csr_stride;
     const unsigned short* lds_col = reinterpret_cast<const unsigned short*>(cb + t.off_col);
     // (a row's start is the LOW half of its rowptr word; the high half is a cursor of the CSR build: csr_s2)
-    const unsigned short* lds_rowptr = reinterpret_cast<const unsigned short*>(cb + t.off_rowptr);
+    const int* lds_rowptr = reinterpret_cast<const int*>(cb + t.off_rowptr);
     const float* lds_dis = reinterpret_cast<const float*>(cb + t.off_dis);
 
     // ---- this wavefront's weight tile: requested when the wavefront left the rows of the tile before (below); the row counter ----
@@ -1446,8 +1450,8 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       const int r = r0 + g;
       const bool row_ok = r < T;
       const int row = n0 + (row_ok ? r : 0);
-      const int start = row_ok ? (int)lds_rowptr[2 * r] : 0;
-      const int nd = row_ok ? (int)lds_rowptr[2 * r + 2] - start : 0;
+      const int start = row_ok ? (lds_rowptr[r] & 0xffff) : 0;             // (two adjacent words: one ds_read2_b32)
+      const int nd = row_ok ? (lds_rowptr[r + 1] & 0xffff) - start : 0;
       int maxd = nd;
 #pragma unroll
       for (int off = LPR; off < 64; off <<= 1) maxd = max(maxd, bperm((lane ^ off) << 2, maxd));
@@ -1589,8 +1593,8 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
 #else
         gv[h] = load_slot(rgo, (row_ok && h < H) ? ((unsigned)row * (unsigned)F_out + (unsigned)(h * 16 + 4 * l4)) * 4u : OOB);
 #endif
-      const int start = row_ok ? (int)lds_rowptr[2 * r] : 0;
-      const int nd = row_ok ? (int)lds_rowptr[2 * r + 2] - start : 0;
+      const int start = row_ok ? (lds_rowptr[r] & 0xffff) : 0;             // (two adjacent words: one ds_read2_b32)
+      const int nd = row_ok ? (lds_rowptr[r + 1] & 0xffff) - start : 0;
       int maxd = nd;
 #pragma unroll
       for (int off = LPR; off < 64; off <<= 1) maxd = max(maxd, bperm((lane ^ off) << 2, maxd));
