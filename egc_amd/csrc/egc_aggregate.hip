@@ -29,6 +29,15 @@
 
 namespace egc {
 
+// EGC_STDVAR_REFERENCE set (not "" / "0") and the layer has a var / std aggregator; read on every call
+bool stdvar_reference(const egc_layer* layer) {
+  const char* e = getenv("EGC_STDVAR_REFERENCE");
+  if (layer == nullptr || e == nullptr || e[0] == '\0' || (e[0] == '0' && e[1] == '\0')) return false;
+  for (int t = 0; t < layer->num_aggrs && t < EGC_MAX_AGGRS; ++t)
+    if (layer->aggrs[t] == EGC_AGGR_VAR || layer->aggrs[t] == EGC_AGGR_STD) return true;
+  return false;
+}
+
 // Reduce CSR entries [start, end) of `row` into per-lane partial aggregates.
 // Lane (g, q): group g = lane >> lpr_log2 takes entries g, g+G, ...; q = slot inside the basis row.
 // The variance's shift (Acc::sh): the row's first entry, for every partial accumulator of the row.
@@ -37,6 +46,7 @@ __device__ inline void set_shift(const AggArgs& a, __amdgpu_buffer_rsrc_t rsrc, 
   bool need = false;                       // (a.need_var belongs to the register-resident family's launchers)
   for (int t = 0; t < a.A; ++t) need = need || a.aggr[t] == EGC_AGGR_VAR || a.aggr[t] == EGC_AGGR_STD;
   if (!need && a.stats == nullptr) return;
+  if (a.var_ref) return;                   // (the reference's formula: squares about zero)
   const int rs = __builtin_amdgcn_readfirstlane(a.rowptr[row]), re = __builtin_amdgcn_readfirstlane(a.rowptr[row + 1]);
   if (re <= rs) return;
   const int first = __builtin_amdgcn_readfirstlane(a.col[rs]);
@@ -729,11 +739,16 @@ static int aggregate_combine_impl(const egc_graph* graph, const egc_layer* layer
   if (stats != nullptr) arg8_tables(layer, n, stats, a.arg_max != nullptr, a.arg_min != nullptr, &a.arg8_max, &a.arg8_min);
   a.self_pos = (int)e;
 
+  // EGC_STDVAR_REFERENCE=1 and a var / std layer: the variance by the reference's own float32 formula, mean(x^2) - mean(x)^2
+  // (layers.py:203-214, optimized_layers.py:237-244; SURVEY.md 8a note 5) -- squares about zero instead of about the row's
+  // first entry -- on the general kernels, one row per wavefront (a row's entries are then summed one after the other in
+  // CSR = input order, as the reference's scatter sums them).  Speed is not the point of this mode.
+  a.var_ref = stdvar_reference(layer) ? 1 : 0;
   int chunks = 1;
   if (a.slots <= 64) {
     int lg = 0;
     while ((1 << lg) < a.slots) ++lg;
-    a.lpr_log2 = lg;
+    a.lpr_log2 = a.var_ref ? 6 : lg;
   } else {
     a.lpr_log2 = 6;
     chunks = (a.slots + 63) / 64;
@@ -759,7 +774,7 @@ static int aggregate_combine_impl(const egc_graph* graph, const egc_layer* layer
   a.rows_per_wave = 0;
   a.n_chunks_hint = (graph->n_chunks >= 0 && graph->n_chunks <= caps.cap_chunks) ? (int)graph->n_chunks : -1;
   if (const char* env = getenv("EGC_ROWS_PER_WAVE")) a.rows_per_wave = atoi(env);
-  const bool force_generic = getenv("EGC_FORCE_GENERIC") != nullptr;
+  const bool force_generic = getenv("EGC_FORCE_GENERIC") != nullptr || a.var_ref != 0;
   if (!force_generic && fast_path_supported(a, layer->weight_layout, chunks)) {
     if (arg_done != nullptr) *arg_done = true;  // the register-resident kernels track the arg positions themselves
     return launch_fast(a, n, caps, stream);
@@ -1058,6 +1073,7 @@ int32_t egc_layer_gemm_flags(const egc_layer* layer) {
   // 5,280 configurations: every std / var layer within 7e-7 of float64 with either GEMM, where the float32 restatement
   // itself is up to 3.7e-4 off; profiles/r04_stdvar_shift.md).  EGC_GEMM_STDVAR_24BIT=1 brings the old choice back.
   if (layer == nullptr) return 0;
+  if (egc::stdvar_reference(layer)) return EGC_GEMM_24BIT;     // (the reference-formula mode: 24-bit operands, no one-launch path)
   const char* e = getenv("EGC_GEMM_STDVAR_24BIT");
   if (e == nullptr || e[0] == '\0' || (e[0] == '0' && e[1] == '\0')) return 0;
   for (int t = 0; t < layer->num_aggrs && t < EGC_MAX_AGGRS; ++t)

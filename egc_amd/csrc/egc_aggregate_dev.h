@@ -71,6 +71,7 @@ struct AggArgs {
   int rows_per_wave;
   int chunk_blocks;        // leading blocks of the grid that take long-row chunks
   int need_mean, need_var;
+  int var_ref;             // EGC_STDVAR_REFERENCE=1: var as the reference's float32 E[x^2] - E[x]^2 (no shift; egc_aggregate.hip)
   int n_chunks_hint;       // host-known number of long-row chunks, or -1 (launch for the capacity)
   int l4_off;              // two-slots-per-lane kernel: first slot (inside a basis) of the set being finished (else 0)
   int wide_p0, wide_p1;    // two-slots-per-lane kernel: slots per basis of the lane's first / second set (P0 + P1 = Ls / 4)

@@ -307,9 +307,18 @@ def egc_aggregate_combine(graph: CSRGraph, spec: LayerSpec, bases: torch.Tensor,
     return out
 
 
+def stdvar_reference(spec: LayerSpec) -> bool:
+    """EGC_STDVAR_REFERENCE=1 and a var / std layer: the variance by the reference's own float32 formula, mean(x^2) - mean(x)^2
+    (layers.py:203-214; SURVEY.md 8a note 5), on the library's general kernels -- no tile / one-launch path (their kernels
+    accumulate the squares about the row's first entry), 24-bit GEMM operands (egc_layer_gemm_flags)."""
+    if not _C.env_flag("EGC_STDVAR_REFERENCE"):
+        return False
+    return any(int(spec.c.aggrs[t]) in (_C.AGGR_VAR, _C.AGGR_STD) for t in range(int(spec.c.num_aggrs)))
+
+
 def _batch_tile_setup(gb: GraphBatch, spec: LayerSpec, post):
     """What the tile kernels need for this layer on this batch (GraphBatch.tile_setup), or None."""
-    if _C.env_flag("EGC_NO_TILE"):
+    if _C.env_flag("EGC_NO_TILE") or stdvar_reference(spec):
         return None
     return gb.tile_setup(spec.c, post is not None and post.scale is not None)
 

@@ -146,3 +146,78 @@ def test_eval_forward_is_bit_reproducible_on_every_one_launch_form():
             gb.check()
             assert _ran(gb, "fused"), (hidden, "the one-launch kernel did not run")
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), hidden
+
+
+def _ref_step(params, bn_params, x0, go, ei_np, dtype):
+    """4 x [EGConv -> BatchNorm1d (batch statistics) -> ReLU -> + x] and its gradients through the differentiable restatement
+    (oracle/egc_torch_ref.py) on the CPU in `dtype`."""
+    from oracle import egc_torch_ref as tref
+    leaves = [{k: v.detach().cpu().to(dtype).requires_grad_(True) for k, v in p.items()} for p in params]
+    bns = [{k: v.detach().cpu().to(dtype).requires_grad_(True) for k, v in b.items()} for b in bn_params]
+    x = x0.detach().cpu().to(dtype).requires_grad_(True)
+    h = x
+    for p, b in zip(leaves, bns):
+        c = tref.egconv_forward(h, ei_np, p["bases_weight"], p["comb_weight.weight"], p["comb_weight.bias"], p["bias"], 8, 4,
+                                ["sum", "mean", "max", "symnorm"])
+        mu, var = c.mean(0), c.var(0, unbiased=False)
+        h = h + torch.relu((c - mu) / torch.sqrt(var + 1e-5) * b["weight"] + b["bias"])
+    h.backward(go.detach().cpu().to(dtype))
+    grads = []
+    for p, b in zip(leaves, bns):
+        grads += [p["bases_weight"].grad, p["bias"].grad, p["comb_weight.weight"].grad, p["comb_weight.bias"].grad, b["weight"].grad, b["bias"].grad]
+    return h.detach(), x.grad, grads
+
+
+def test_molhiv_step_against_float64_on_both_paths():
+    """Round 5 left a 6.4e-4 difference (of the largest gradient) between the parameter gradients of the GraphBatch path and the
+    CSR path on the molhiv batch of 2,048 graphs with nothing saying which was right.  Here the same 4-block step is evaluated
+    in float64 (and in float32, on the CPU, to calibrate what float32 arithmetic alone costs on this step: pre-activations
+    within rounding of zero flip their ReLU mask in ANY float32 evaluation), and BOTH HIP paths are held to the bound the
+    reference-generated fixtures use (tests/test_nets_golden.py): max(1e-5, 5 x the float32 restatement's own error)."""
+    import egc_amd
+    from egc_amd import workloads as wl
+    dev = _dev()
+    ei, n, bvec = wl.molecule_batch(2048, seed=0)
+    torch.manual_seed(0)
+    blocks = torch.nn.ModuleList([egc_amd.FusedEGCBlock(egc_amd.EGConv(128, 128, aggrs=["sum", "mean", "max", "symnorm"], num_heads=8,
+                                                                        num_bases=4), torch.nn.BatchNorm1d(128)) for _ in range(4)])
+    with torch.no_grad():
+        for b in blocks:
+            b.bn.weight.uniform_(0.5, 1.5)
+            b.bn.bias.normal_(0, 0.3)
+            b.conv.bias.normal_(0, 0.1)
+    params = [dict(b.conv.named_parameters()) for b in blocks]
+    bn_params = [dict(b.bn.named_parameters()) for b in blocks]
+    x0, go = torch.randn(n, 128), torch.randn(n, 128)
+    out64, dx64, g64 = _ref_step(params, bn_params, x0, go, ei.numpy(), torch.float64)
+    out32, dx32, g32 = _ref_step(params, bn_params, x0, go, ei.numpy(), torch.float32)
+
+    def errs(out, dx, grads):
+        gscale = max(float(g.abs().max()) for g in g64)
+        e = {"out": float((out.double() - out64).abs().max() / out64.abs().max()), "dx": float((dx.double() - dx64).abs().max() / dx64.abs().max())}
+        for i, (g, w) in enumerate(zip(grads, g64)):
+            wmax = float(w.abs().max())
+            # (the conv bias in front of BatchNorm has an analytically zero gradient: held to the step's gradient scale, as the fixtures are)
+            denom = gscale if wmax < 1e-6 * gscale else max(1e-2 * gscale, wmax)
+            e[f"g{i}"] = float((g.double() - w).abs().max() / denom)
+        return e
+    cal = errs(out32, dx32, g32)
+    blocks = blocks.to(dev).train()
+    order = []
+    for b in blocks:
+        p, q = dict(b.conv.named_parameters()), dict(b.bn.named_parameters())
+        order += [p["bases_weight"], p["bias"], p["comb_weight.weight"], p["comb_weight.bias"], q["weight"], q["bias"]]
+    eid = ei.to(dev)
+    sizes = torch.bincount(bvec.to(dev))
+    ptr = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(sizes, 0)])
+    got = {}
+    for path in ("batch", "csr"):
+        graph = egc_amd.GraphBatch(eid, ptr=ptr, max_nodes=int(sizes.max()), num_nodes=n) if path == "batch" else eid
+        out, dx, _ = _blocks_step(blocks, graph, x0.to(dev), go.to(dev))
+        if path == "batch":
+            graph.check()
+            assert _ran(graph, "fused_bwd")
+        got[path] = errs(out.cpu(), dx.cpu(), [p.grad.cpu() for p in order])
+    for path, e in got.items():
+        for k, v in e.items():
+            assert v <= max(1e-5, 5.0 * cal[k]), (path, k, v, cal[k])

@@ -84,6 +84,7 @@ def test_one_launch_layer_matches_the_oracle_on_a_messy_batch(kind, hidden, H, B
         # neighbourhoods (tests/test_fuzz_gpu.py); the kernels' variance about the row's first entry is not: against float64
         truth = _truth64(conv.cpu(), kind, x, ei, H, B, aggrs, asl)
         assert rel_err(got, truth) <= TOL, rel_err(got, truth)
+        assert elementwise_excess(got, truth, TOL) <= 1.0, elementwise_excess(got, truth, TOL)      # (every element, on its row's scale)
         assert rel_err(got, ref) <= 1e-4
         return
     assert rel_err(got, ref) <= TOL, rel_err(got, ref)

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import elementwise_excess, golden_names, load_golden, oracle_forward, rel_err
+from golden_util import elementwise_excess, float64_forward, golden_names, load_golden, oracle_forward, rel_err
 from oracle import egc_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -61,12 +61,33 @@ def test_golden(name):
     out = run_layer(layer, g, dev)
     assert out.shape == g["out"].shape
     assert rel_err(out, g["out"]) <= TOL, f"{name}: rel err {rel_err(out, g['out']):.3e}"
-    # element by element against the element's own row scale (small rows next to large ones); layers with std / var
-    # amplify the last bits of `bases` 158x on (nearly) constant neighbourhoods: 1e-4 there
-    etol = 1e-4 if any(a in ("std", "var") for a in g["meta"]["aggrs"]) else TOL
-    assert elementwise_excess(out, g["out"], etol) <= 1.0, f"{name}: element-wise excess {elementwise_excess(out, g['out'], etol):.3f}"
+    # element by element against the element's own row scale (small rows next to large ones) -- std / var layers included
+    # since round 6 (tools/stdvar_modes.py: largest excess 0.32 at 1e-5 over the 16 std / var fixtures, with the default
+    # formula and with EGC_STDVAR_REFERENCE=1 alike; rounds 4-5 allowed 1e-4 there)
+    assert elementwise_excess(out, g["out"], TOL) <= 1.0, f"{name}: element-wise excess {elementwise_excess(out, g['out'], TOL):.3f}"
     # and against the oracle (pins the oracle and the HIP path to each other as well)
     assert rel_err(out, oracle_forward(g, orc)) <= TOL
+
+
+def _stdvar_goldens():
+    return [n for n in golden_names() if any(a in ("std", "var") for a in load_golden(n)["meta"]["aggrs"])]
+
+
+@pytest.mark.parametrize("name", _stdvar_goldens())
+def test_golden_stdvar_reference_formula(name, monkeypatch):
+    """EGC_STDVAR_REFERENCE=1: std / var by the reference's own float32 formula, mean(x^2) - mean(x)^2 (layers.py:203-214,
+    optimized_layers.py:237-244; SURVEY.md 8a note 5: "match the formula, not a better one") -- the general kernels, one row per
+    wavefront, squares about zero, 24-bit GEMM operands -- against the fixture the reference's own code produced: 1e-5 on the
+    array's scale AND element by element (the default formula, about the row's first entry, is held to 1e-4 element-wise there:
+    it is nearer float64 than the fixture is)."""
+    monkeypatch.setenv("EGC_STDVAR_REFERENCE", "1")
+    dev = _dev()
+    g = load_golden(name)
+    layer = build_layer(g["meta"], g["params"], dev)
+    out = run_layer(layer, g, dev)
+    assert rel_err(out, g["out"]) <= TOL, f"{name}: rel err {rel_err(out, g['out']):.3e}"
+    ex = elementwise_excess(out, g["out"], TOL)
+    assert ex <= 1.0, f"{name}: element-wise excess {ex:.3f} at 1e-5 with the reference's formula"
 
 
 def test_repr_matches_reference_goldens():
@@ -130,6 +151,11 @@ def _oracle_case(kind, rng, n, ei, fin, fout, H, B, aggrs, dev, **flags):
                 add_self_loops=flags.get("add_self_loops", True), bias=True, sparse=False)
     g = dict(meta=meta, params=sd, x=x, edge_index=ei)
     out = run_layer(layer.to(dev).eval(), g, dev)
+    if flags.get("check64", False):
+        # every element against a float64 evaluation of the reference's formula, on the scale of the element's OWN row (rel_err
+        # alone measures against the largest output of the whole array and says nothing about small rows next to large ones)
+        ex = elementwise_excess(out, float64_forward(g), TOL)
+        assert ex <= 1.0, f"element-wise excess {ex:.3f} against float64 ({kind} {fin} H{H} B{B} {aggrs})"
     return out, oracle_forward(g, orc)
 
 
@@ -156,7 +182,7 @@ def test_long_rows_chunk_merge_path(kind, aggrs):
     T, K = _C.LONG_ROW_THRESHOLD, _C.LONG_ROW_CHUNK
     hubs = [(0, 5000), (17, K + 1), (18, K), (19, T), (20, T + 1), (21, 2 * K), (22, 2 * K + 1), (999, 1300), (n - 1, 257), (5, 4096)]
     ei = _hub_graph(rng, n, 12000, hubs)
-    out, ref = _oracle_case(kind, rng, n, ei, 64, 64, 8, 4, aggrs, dev)
+    out, ref = _oracle_case(kind, rng, n, ei, 64, 64, 8, 4, aggrs, dev, check64=True)
     assert rel_err(out, ref) <= TOL
 
 
@@ -172,9 +198,9 @@ def test_shipped_and_odd_shapes(hidden, H, B):
     rng = np.random.default_rng(hidden * 31 + H)
     n = 400
     ei = _hub_graph(rng, n, 3000, [(3, 300)])
-    out, ref = _oracle_case("opt", rng, n, ei, hidden, hidden, H, B, ["symnorm", "max", "std"], dev)
+    out, ref = _oracle_case("opt", rng, n, ei, hidden, hidden, H, B, ["symnorm", "max", "std"], dev, check64=True)
     assert rel_err(out, ref) <= TOL
-    out, ref = _oracle_case("lay", rng, n, ei, hidden, hidden, H, B, ["symadd", "min", "mean"], dev, softmax=True)
+    out, ref = _oracle_case("lay", rng, n, ei, hidden, hidden, H, B, ["symadd", "min", "mean"], dev, softmax=True, check64=True)
     assert rel_err(out, ref) <= TOL
 
 
@@ -193,7 +219,7 @@ def test_register_kernels_on_non_power_of_two_rows(hidden, H, B, kind, aggrs):
     rng = np.random.default_rng(hidden + 13 * len(aggrs))
     n = 1500
     ei = _hub_graph(rng, n, 9000, [(0, 2100), (77, 129), (n - 1, 40), (400, 33)])
-    out, ref = _oracle_case(kind, rng, n, ei, hidden, hidden, H, B, aggrs, dev)
+    out, ref = _oracle_case(kind, rng, n, ei, hidden, hidden, H, B, aggrs, dev, check64=True)
     assert rel_err(out, ref) <= TOL
     os.environ["EGC_FORCE_GENERIC"] = "1"
     try:
@@ -623,7 +649,8 @@ def test_multi_chunk_hub_rows_with_few_slots_on_small_graphs(hidden, H, B, kind,
     rng = np.random.default_rng(hidden * 7 + len(aggrs))
     n = 200
     ei = _hub_graph(rng, n, 500, [(3, 300), (77, 700)])
-    out, ref = _oracle_case(kind, rng, n, ei, hidden, hidden, H, B, aggrs, dev)
+    out, ref = _oracle_case(kind, rng, n, ei, hidden, hidden, H, B, aggrs, dev, check64=True)    # (every element against float64 at 1e-5)
+    # (against the float32 restatement: its own E[x^2] - E[x]^2 is up to 1e-4 off on hub rows of nearly tied entries)
     assert rel_err(out, ref) <= (1e-4 if any(a in ("std", "var") for a in aggrs) else TOL)
 
 
