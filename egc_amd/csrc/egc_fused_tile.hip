@@ -131,7 +131,7 @@ static bool ft_narrow_shape(const AggArgs& a, int f_in) {
 }
 // the WIDE form's envelope: F_in <= 320, at most 12 column tiles of 32 (bases padded to a multiple of 32, then the weightings)
 static bool ft_wide_shape(const AggArgs& a, int f_in) {
-  static const bool off = getenv("EGC_NO_FUSED_WIDE") != nullptr;
+  const bool off = getenv("EGC_NO_FUSED_WIDE") != nullptr;      // (read on every call, like the Python side's EGC_NO_* switches)
   if (a.slots > 64 && (a.slots > 128 || a.B * (((a.Ls >> 2) + 1) / 2) > 64)) return false;    // two passes of at most 64 lanes
   return !off && f_in >= 4 && f_in <= FTW_MAX_FIN && (f_in & 3) == 0 && ((a.ldb + 31) & ~31) + a.W <= FTW_MAX_CT * 32 && a.A <= AMAX;
 }
@@ -365,7 +365,7 @@ int launch_fused_tile(AggArgs a, const int64_t* ptr, const int64_t* edge_ptr, in
 // propagate's gathers and of the per-aggregator scatters -- as ONE launch per layer plus the weight gradient x^T d:
 //   x rows -> [bases | w'] on the matrix cores -> LDS (as the forward) -> CSR of the tile -> per destination row the
 //   aggregates again (with the entry attaining each maximum), d w' = <g, agg>, d agg = w' g, scattered to the sources' rows
-//   of a d bases image by LDS float atomics -> d x = [d bases | d w'] [bases_weight | comb_weight^T]^T on the matrix cores.
+//   of a d bases image kept as 64-bit fixed point (integer LDS atomics: order-independent sums) -> d x = [d bases | d w'] [bases_weight | comb_weight^T]^T on the matrix cores.
 // x, grad_out and the edge list in; d x and d_cat = the gradient of [bases | pre-activation weightings] out.  No CSR, no
 // transposed CSR, no `bases` / `weightings` / statistics in memory.  Envelope: the d = 128 / 64 layers (B = 4 bases of 16
 // channels, H = 4 or 8, F_in <= 128), aggregators of sum / mean / max / symnorm, no weight nonlinearity.

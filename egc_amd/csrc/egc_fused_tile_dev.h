@@ -53,6 +53,7 @@ constexpr int FTW_PBUF_BYTES = 2 * FTW_PLANE_BYTES;        // [2 planes]
 constexpr int FTW_PLANES_BYTES = 2 * FTW_PBUF_BYTES;       // [2 buffers]
 constexpr int FTW_MAXCH = FT_CHUNK * FT_RING / FTW_CH;     // chunks of a tile (160 rows)
 constexpr int FTW_MAX_CT = FT_MFMA_WAVES;                  // 32-column tiles
+constexpr int FT_DBS_POISON = 0x7fffffff;                  // backward: the tile's fixed-point scale when its g or w' holds an Inf / NaN
 
 #ifdef EGC_FT_STAMPS
 __device__ unsigned long long* egc_ft_stamp_buf = nullptr;   // diagnostic build only: [grid][8] accumulated cycles per phase
@@ -89,7 +90,7 @@ struct FusedTileArgs {
   int w_aw;                  // floats per (h, b) block of a weightings row in LDS: 4 for A >= 3, else A
   int nsets, p0;             // rows of more than 64 slots: two passes, the first over p0 = ceil(P / 2) slots of every basis
   unsigned magic0, magic1;   // floor(2^32 / p0) + 1, floor(2^32 / (P - p0)) + 1
-  // backward form only (MODE == 1: fused_tile_bwd, egc_fused_tile_bwd.hip)
+  // backward form only (MODE == 1: egc_layer_backward_batch_fused_f32, egc_fused_tile.hip)
   const float* grad_out;     // [n_nodes, F_out]
   float* d_x;                // [n_nodes, F_in]
   const float* d_x_add;      // [n_nodes, F_in] added to d_x in its store (the gradient reaching x past the layer), or nullptr
@@ -167,6 +168,14 @@ __device__ inline unsigned ft_row_amax(const f4 v) {
   return max(a, (unsigned)__builtin_amdgcn_ds_swizzle((int)a, 0x401F));                 // lane ^ 16
 }
 
+// largest magnitude of four floats as a bit pattern, Inf / NaN INCLUDED (integer maximum of the patterns without their sign: a NaN
+// compares above everything; fmaxf would drop it, and the backward's fixed-point sums must know -- FT_DBS_POISON)
+__device__ inline unsigned ft_amax_bits(const f4 v) {
+  const unsigned a = __float_as_uint(v.x) & 0x7fffffffu, b = __float_as_uint(v.y) & 0x7fffffffu;
+  const unsigned c = __float_as_uint(v.z) & 0x7fffffffu, d = __float_as_uint(v.w) & 0x7fffffffu;
+  return max(max(a, b), max(c, d));
+}
+
 // largest of a non-negative bit pattern over the wavefront, uniform (four row maxima by DPP, then four lane reads)
 __device__ inline unsigned ft_wave_umax(unsigned a) {
   a = max(a, (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
@@ -178,7 +187,7 @@ __device__ inline unsigned ft_wave_umax(unsigned a) {
 }
 
 // MODE 1 (WIDE == 0 only): the BACKWARD of the layer on the same tiles -- x, grad_out and the edge list in, d x and the
-// gradient of [bases | weightings] out (egc_fused_tile_bwd.hip has the description).
+// gradient of [bases | weightings] out (described at egc_layer_backward_batch_fused_f32, egc_fused_tile.hip).
 template <int LPR_LOG2, int HPB, int NEED, class C, int WIDE = 0, int MODE = 0>
 __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, FusedTileArgs t) {
   static_assert(MODE == 0 || WIDE == 0, "the backward form is built on the register-stationary GEMM");
@@ -325,7 +334,8 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
           const unsigned long long m1 = __ballot(ok1) >> n0k;
           const int n1k = m1 == 0 ? 0 : (__ffsll((long long)~m1) - 1);
           const int g1 = cur_g + n0k, g2 = g1 + n1k;
-          const bool mono = !(gi <= g_hi && lane < n0k + n1k && pv < (lane == 0 ? p0 : __shfl_up(pv, 1)));
+          const int pprev = __shfl_up(pv, 1);       // (unconditionally, every lane active: inside the short-circuit lane 1 read an inactive lane 0)
+          const bool mono = !(gi <= g_hi && lane < n0k + n1k && pv < (lane == 0 ? p0 : pprev));
           // (a second tile that would hold no graph although graphs remain, or a window that ends inside it: the general path)
           if ((n1k >= 1 || g1 >= g_hi) && n0k + n1k < 64 && __ballot(!mono) == 0) {
             const int p2 = n1k >= 1 ? __builtin_amdgcn_readfirstlane(__shfl(pv, n0k + n1k - 1)) : p1;
@@ -693,7 +703,7 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
             v[i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rg, (unsigned)ht * 16u, (PB * b + i) * FT_HELPER_THREADS * 16, 0));
 #pragma unroll
           for (int i = 0; i < PB; ++i)
-            m = max(m, __float_as_uint(fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w)))));
+            m = max(m, ft_amax_bits(v[i]));
         }
         m = ft_wave_umax(m);
         if (lane == 0) __hip_atomic_fetch_max(reinterpret_cast<unsigned*>(lds_rec) + slot * 8 + 5, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -840,7 +850,9 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
         //      gradient x^T d is a launch of its own).
         __builtin_amdgcn_s_setprio(0);
         lds_barrier();                                   // (B1: the rows pass is done)
-        const double sinv = __builtin_ldexp(1.0, -__builtin_amdgcn_readfirstlane(lds_rec[28]));
+        const int dbs_h = __builtin_amdgcn_readfirstlane(lds_rec[28]);
+        const bool poison = dbs_h == FT_DBS_POISON;      // (a non-finite g or w' in the tile: its d bases rows leave as NaN)
+        const double sinv = __builtin_ldexp(1.0, -(poison ? 0 : dbs_h));
         const int drow = ht >> 4, dj = ht & 15;
         const int np2 = (a.ldb + t.wl_floats) >> 6;      // pieces per thread: 2 (H = 4) or 3 (H = 8)
         auto stage_d = [&](int c, int buf) {
@@ -849,6 +861,7 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
           {   // d bases: 64-bit fixed point (the rows pass adds with integer LDS atomics), scale 2^-dbs in lds_rec[28]
             const long long* dq = reinterpret_cast<const long long*>(base + t.off_db) + (r * a.ldb + 4 * dj);
             pc[0] = f4{(float)((double)dq[0] * sinv), (float)((double)dq[1] * sinv), (float)((double)dq[2] * sinv), (float)((double)dq[3] * sinv)};
+            if (poison) pc[0] = f4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
           }
           pc[1] = *reinterpret_cast<const f4*>(base + t.off_wt + (r * t.wl_floats + 4 * dj) * 4);
           pc[2] = np2 > 2 ? *reinterpret_cast<const f4*>(base + t.off_wt + (r * t.wl_floats + 64 + 4 * dj) * 4) : f4{0.f, 0.f, 0.f, 0.f};
@@ -1314,7 +1327,7 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
         f4 o = __builtin_shufflevector(ol, oh, 0, 1, 2, 3);
         if (dst_act) o = w_act<C>(a, o);
         if constexpr (MODE == 1) {
-          if (dst_act) wmx = max(wmx, __float_as_uint(fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w)))));
+          if (dst_act) wmx = max(wmx, ft_amax_bits(o));
         }
         if (dst_off >= 0) {
           char* po = base + dst_off + (FT_CHUNK * c + 4 * qd) * dst_stride;
@@ -1550,8 +1563,8 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
     // ---- (E, backward) rows: one lane group per DESTINATION row, as the forward -- the row's aggregates are formed again from
     //      the LDS image (with the source and the input position of the entry attaining each maximum), then, head by head,
     //      d agg[t] += w'[h][b][t] g[h] and d w'[h][b][t] = <g[h], agg[t]> (reduced over the four lanes of a basis and written
-    //      over w' in the image), and the row's gradients travel to its SOURCES' rows of the d bases image by LDS float
-    //      atomics: sum / mean / symnorm along every entry, max to the one entry that attained it.  (B = 4 bases of 16
+    //      over w' in the image), and the row's gradients travel to its SOURCES' rows of the d bases image as 64-bit fixed
+    //      point on integer LDS atomics: sum / mean / symnorm along every entry, max to the one entry that attained it.  (B = 4 bases of 16
     //      channels: 16 slots, four lanes per basis; aggregators sum / mean / max / symnorm; no weight nonlinearity.)
     long long* lds_db = reinterpret_cast<long long*>(base + t.off_db);
     // The sources' gradients are summed by LDS atomics, and float LDS atomics run at ONE LANE PER CLOCK for the whole CU on
@@ -1566,8 +1579,12 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       const int ew = (int)((unsigned)__builtin_amdgcn_readfirstlane(lds_rec[27]) >> 23) - 127;
       int dbs = 34 - (eg + 1) - (ew + 1) - 5;      // (H <= 8: 3 bits; A <= 4: 2 bits)
       dbs = dbs < -1000 ? -1000 : (dbs > 1000 ? 1000 : dbs);
-      if (tid == 0) lds_rec[28] = dbs;             // (for the helpers, who stage d bases behind barrier B1; every wavefront here
-      dbs_tile = dbs;                               //  forms the same number from the two maxima itself)
+      // An Inf or NaN among the tile's g or w' (exponent field 255 in either maximum) has no fixed-point image: the integer sums
+      // would come out as finite garbage where autograd -- and the CSR path -- give Inf / NaN, and a GradScaler or
+      // clip_grad_norm_(error_if_nonfinite=True) would not see it.  The tile's d bases rows are then staged as NaN (FT_DBS_POISON).
+      const bool nonfinite = eg >= 128 || ew >= 128;
+      if (tid == 0) lds_rec[28] = nonfinite ? FT_DBS_POISON : dbs;     // (for the helpers, who stage d bases behind barrier B1;
+      dbs_tile = nonfinite ? 0 : dbs;                                   //  every wavefront here forms the same number itself)
     }
     FT_STAMP(1)
     const double db_scale = __builtin_ldexp(1.0, dbs_tile);

@@ -512,21 +512,25 @@ class ResidualLink:
     conv's backward launch instead of in a pass of autograd's own.  The block (egc_amd.FusedEGCBlock) offers one around its conv
     call (`offer`); the one-launch training path takes it (`taken`); the tail's backward -- which autograd runs first -- then
     leaves its incoming gradient here (`grad`) and reports none for the residual input, and the conv's backward hands it to
-    egc_layer_backward_batch_fused_f32 as `d_x_add`.  Only ever used when the residual input IS the conv's input."""
-    __slots__ = ("taken", "grad")
+    egc_layer_backward_batch_fused_f32 as `d_x_add`.  Only ever used when the residual input IS the conv's input: the offer
+    records that tensor, and a layer call whose x is another tensor (a wrapper module that casts / drops out / projects in front
+    of the EGC layer) leaves the offer untaken -- autograd then adds the residual gradient itself."""
+    __slots__ = ("taken", "grad", "x")
     _local = threading.local()        # the offer lives on the thread that runs the block's forward
 
-    def __init__(self):
-        self.taken, self.grad = False, None
+    def __init__(self, x=None):
+        self.taken, self.grad, self.x = False, None, x
 
     @classmethod
     def offer(cls, link):
         cls._local.offered = link
 
     @classmethod
-    def take(cls):
+    def take(cls, x=None):
         link = getattr(cls._local, "offered", None)
         cls._local.offered = None
+        if link is not None and link.x is not None and link.x is not x:
+            return None               # (this call's x is not the block's residual input)
         if link is not None:
             link.taken = True
         return link
@@ -1347,7 +1351,7 @@ def egc_layer_apply_params(graph, spec, x, bias, comb_w, comb_b, bcat_direct, ba
         if setups is not None:
             return _BatchFusedTrainFunction.apply(x, bias, comb_w, comb_b, bcat_direct, graph, spec,
                                                   (int(f_in), int(H), int(A), int(B), int(L), int(Ls)), bool(permute_hab), setups,
-                                                  ResidualLink.take() if x.requires_grad else None, *bases)
+                                                  ResidualLink.take(x) if x.requires_grad else None, *bases)
     return _EGCLayerParamsFunction.apply(x, bias, comb_w, comb_b, bcat_direct, _as_csr(graph), spec,
                                          (int(f_in), int(H), int(A), int(B), int(L), int(Ls)), bool(permute_hab), *bases)
 

@@ -64,7 +64,7 @@ class FusedEGCBlock(nn.Module):
         # the residual adds the conv's own input, taken by the one-launch training path of a GraphBatch
         link = None
         if self.residual and identity is None and torch.is_grad_enabled() and x.requires_grad and not _C.env_flag("EGC_NO_RESIDUAL_LINK"):
-            link = ResidualLink()
+            link = ResidualLink(x)
         identity = x if identity is None else identity
         ResidualLink.offer(link)
         try:

@@ -334,3 +334,69 @@ def test_planes_packed_from_the_parameters_are_those_packed_from_wcat(kind):
     gb.check()
     assert _ran_bwd(gb) and seen["params"] is not None
     assert torch.equal(seen["params"][0], seen["wcat"][0]) and torch.equal(seen["params"][1], seen["wcat"][1])
+
+
+def test_non_finite_gradients_stay_non_finite():
+    """An Inf or a NaN in grad_out has no image in the 64-bit fixed point d bases is summed in: the tile that holds it
+    stages its d bases rows as NaN, so d x and the bases_weight gradient are non-finite there -- as autograd and the CSR path
+    give -- and the other tiles are untouched.  (GradScaler / clip_grad_norm_(error_if_nonfinite=True) rely on this.)"""
+    import egc_amd
+    dev = _dev()
+    ei, n, ptr = _messy_batch(9, n_graphs=600, max_size=60)
+    torch.manual_seed(4)
+    conv = egc_amd.EGConv(128, 128, aggrs=["sum", "mean", "max", "symnorm"], num_heads=8, num_bases=4).to(dev).train()
+    x0 = torch.randn(n, 128, device=dev)
+    for bad in (float("inf"), float("nan")):
+        go = torch.randn(n, 128, device=dev)
+        victim = n // 2
+        go[victim, 5] = bad
+        res = {}
+        for path in ("batch", "csr"):
+            conv.zero_grad(set_to_none=True)
+            x = x0.clone().requires_grad_(True)
+            gb = egc_amd.GraphBatch(ei.to(dev), ptr=ptr.to(dev), max_nodes=60) if path == "batch" else ei.to(dev)
+            conv(x, gb).backward(go)
+            if path == "batch":
+                gb.check()
+                assert _ran_bwd(gb)
+            res[path] = (x.grad.detach().clone(), conv.bases_weight.grad.detach().clone())
+        for path, (dx, dbw) in res.items():
+            assert not torch.isfinite(dx[victim]).all(), (path, bad)       # the row that received the Inf / NaN
+            assert not torch.isfinite(dbw).all(), (path, bad)              # ... and x^T d bases with it
+        # rows far from the victim's tile (first and last graphs of the batch) are finite and equal on both paths
+        for rows in (slice(0, 50), slice(n - 50, n)):
+            a, b = res["batch"][0][rows], res["csr"][0][rows]
+            assert torch.isfinite(a).all() and float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+
+
+def test_residual_link_is_left_alone_when_the_conv_sees_another_tensor(monkeypatch):
+    """FusedEGCBlock accepts any module as its conv.  One that transforms x in front of the EGC layer (here: a scaling) must not
+    get the residual branch's gradient folded into d(x') inside the launch -- the offer records the block's input and is taken
+    only by a layer call on that very tensor; autograd then adds the residual gradient itself."""
+    import egc_amd
+    dev = _dev()
+    ei, n, ptr = _messy_batch(12, n_graphs=100, max_size=60)
+
+    class Scaled(torch.nn.Module):
+        def __init__(self, conv):
+            super().__init__()
+            self.conv = conv
+
+        def forward(self, x, edge_index):
+            return self.conv(x * 0.5, edge_index)
+    torch.manual_seed(6)
+    inner = egc_amd.EGConv(128, 128, aggrs=["sum", "mean", "max", "symnorm"], num_heads=8, num_bases=4)
+    block = egc_amd.FusedEGCBlock(Scaled(inner), torch.nn.BatchNorm1d(128)).to(dev).train()
+    x0, go = torch.randn(n, 128, device=dev), torch.randn(n, 128, device=dev)
+    grads = {}
+    for mode in ("link", "plain"):
+        if mode == "plain":
+            monkeypatch.setenv("EGC_NO_RESIDUAL_LINK", "1")
+        block.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        gb = egc_amd.GraphBatch(ei.to(dev), ptr=ptr.to(dev), max_nodes=60)
+        block(x, gb).backward(go)
+        gb.check()
+        assert _ran_bwd(gb)
+        grads[mode] = x.grad.detach().clone()
+    assert torch.equal(grads["link"], grads["plain"])
