@@ -11,6 +11,7 @@
 // ctypes path uses as well (torch._C._cuda_getCurrentRawStream).
 #include <ATen/ATen.h>
 #include <c10/core/DeviceGuard.h>
+#include <torch/csrc/autograd/custom_function.h>
 #include <torch/library.h>
 
 #include <algorithm>
@@ -230,6 +231,244 @@ std::vector<at::Tensor> train_backward(const at::Tensor& grad_out, const at::Ten
   return out;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Training on a BATCH of whole graphs (round 6): the reference's block  x -> x + relu(bn(conv(x)))  (zinc/models.py:66-73,
+// mol/pna_style_models.py:71-78; its loop, zinc/configs.py:53-72, is an eager Python loop) as ONE autograd node written in C++:
+//   forward   pack both launches' weight planes straight from the parameters (egc_batch_fused_train_pack_params) | the layer as one
+//             launch (egc_layer_forward_batch_fused_f32) | BatchNorm's batch statistics + running statistics
+//             (egc_bn_forward_stats_f32) | normalise, ReLU, + x (egc_affine_act_residual_f32)
+//   backward  BatchNorm / ReLU backward (egc_bn_backward_stats_f32, egc_affine_act_backward_f32) | the layer's backward as one
+//             launch with the residual branch's gradient added to d x in its store (egc_layer_backward_batch_fused_f32) | x^T d_cat
+//             and both bias sums into the parameters' gradients (egc_weight_grad_params_f32)
+// -- the same library calls, in the same order, as egc_amd/functional.py's _BatchFusedTrainFunction +
+// _BatchNormActResidualFunction + ResidualLink, without their ctypes marshalling, the two Python autograd Functions and the
+// hand-over between them (the eager ZINC step was ~1 ms of host time for 0.37 ms of kernels: profiles/r06_eager_step.md).
+// `with_tail` false: the layer alone (a conv called outside a FusedEGCBlock).  Envelope: checked by the Python caller
+// (functional._native_block_train); everything outside it stays on the Python path, same kernels.
+// ---------------------------------------------------------------------------------------------------------------------
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+
+struct BlockStatic {
+  at::Tensor ptr, edge_ptr, src, dst, max_index, status;      // the batch (kept alive for the backward): edge_ptr / max_index may be undefined
+  at::Tensor running_mean, running_var, n_tracked;            // BatchNorm's buffers, updated in place by the forward (may be undefined)
+  int64_t host_flag, layer, stream;
+  int64_t f_in, H, A, B, L, Ls;
+  bool permute_hab;
+  int64_t tile_f, emax_f, tile_b, emax_b;
+  double eps, momentum;                                        // momentum < 0: cumulative average over n_tracked
+  bool relu, residual, with_tail;
+};
+
+// BlockStatic <-> AutogradContext::saved_data (plain IValues: tensor list with presence flags, ints, doubles)
+static void save_static(AutogradContext* ctx, const BlockStatic& s);
+static BlockStatic load_static(AutogradContext* ctx);
+
+
+static const int64_t* iptr(const at::Tensor& t) { return t.defined() ? t.data_ptr<int64_t>() : nullptr; }
+
+struct BatchBlockTrainFn : public torch::autograd::Function<BatchBlockTrainFn> {
+  static at::Tensor forward(AutogradContext* ctx, const at::Tensor& x, const c10::optional<at::Tensor>& bias, const at::Tensor& comb_w,
+                            const c10::optional<at::Tensor>& comb_b, const c10::optional<at::Tensor>& bcat_direct,
+                            const c10::optional<at::Tensor>& gamma, const c10::optional<at::Tensor>& beta, at::TensorList parts,
+                            const BlockStatic& s) {
+    check_f32(x, "x");
+    check_f32(comb_w, "comb weight");
+    const auto* l = reinterpret_cast<const egc_layer*>(s.layer);
+    auto st = reinterpret_cast<egc_stream_t>(s.stream);
+    const int64_t n = x.size(0), f_out = l->out_channels;
+    TORCH_CHECK(x.dim() == 2 && x.size(1) == s.f_in && s.f_in == l->in_channels, "egc_amd: x has the wrong shape");
+    TORCH_CHECK(reinterpret_cast<uintptr_t>(x.data_ptr()) % 16 == 0, "egc_amd: x must be 16-byte aligned");
+    TORCH_CHECK(!(comb_b.has_value() && bcat_direct.has_value()), "egc_amd: one combination bias, not two");
+    const c10::OptionalDeviceGuard device_guard(x.device());
+    const auto opts = x.options();
+    // (1) the weight planes of both launches from the parameters
+    const int64_t nb = egc_batch_fused_pack_bytes(l), nbt = egc_batch_fused_bwd_pack_bytes(l);
+    TORCH_CHECK(nb > 0 && nbt > 0, "egc_amd: layer outside the envelope of the one-launch training path");
+    at::Tensor packed = at::empty({nb}, opts.dtype(at::kByte)), packed_t = at::empty({nbt}, opts.dtype(at::kByte));
+    std::vector<const float*> pp;
+    for (const auto& t : parts) { check_f32(t, "basis matrix"); pp.push_back(t.data_ptr<float>()); }
+    if (comb_b.has_value()) check_f32(*comb_b, "comb bias");
+    if (bcat_direct.has_value()) check_f32(*bcat_direct, "comb bias");
+    if (bias.has_value()) check_f32(*bias, "bias");
+    check_status(egc_batch_fused_train_pack_params(l, pp.data(), (int32_t)pp.size(), comb_w.data_ptr<float>(), fptr(comb_b), fptr(bcat_direct),
+                                                   (int32_t)s.H, (int32_t)s.A, (int32_t)s.B, (int32_t)s.L, (int32_t)s.Ls, s.permute_hab ? 1 : 0,
+                                                   packed.data_ptr(), nb, packed_t.data_ptr(), nbt, st), "egc_batch_fused_train_pack_params");
+    // (2) the layer, one launch
+    at::Tensor h = at::empty({n, f_out}, opts);
+    const int64_t n_graphs = s.ptr.numel() - 1, n_edges = s.src.numel();
+    check_status(egc_layer_forward_batch_fused_f32(iptr(s.ptr), iptr(s.edge_ptr), n_graphs, iptr(s.src), iptr(s.dst), n_edges, n,
+                                                   s.max_index.defined() ? s.max_index.data_ptr<int32_t>() : nullptr, l, x.data_ptr<float>(),
+                                                   packed.data_ptr(), fptr(bias), nullptr, h.data_ptr<float>(), (int32_t)s.tile_f, (int32_t)s.emax_f,
+                                                   s.status.data_ptr<int32_t>(), reinterpret_cast<int32_t*>(s.host_flag), st),
+                 "egc_layer_forward_batch_fused_f32");
+    save_static(ctx, s);
+    ctx->saved_data["has"] = std::vector<bool>{bias.has_value(), comb_b.has_value(), bcat_direct.has_value(), gamma.has_value(), beta.has_value()};
+    std::vector<std::vector<int64_t>> shapes;
+    shapes.push_back(comb_w.sizes().vec());
+    shapes.push_back(comb_b.has_value() ? comb_b->sizes().vec() : std::vector<int64_t>{});
+    for (const auto& t : parts) shapes.push_back(t.sizes().vec());
+    ctx->saved_data["shapes"] = shapes;
+    if (!s.with_tail) {
+      ctx->save_for_backward({x, packed, packed_t});
+      return h;
+    }
+    // (3) BatchNorm on batch statistics (running statistics updated as nn.BatchNorm1d does), (4) normalise -> ReLU -> + x
+    const int64_t c = f_out;
+    const int64_t n_parts = std::max<int64_t>(1, std::min<int64_t>(1024, (n + 127) / 128));
+    at::Tensor partials = at::empty({n_parts, 2, c}, opts.dtype(at::kDouble)), stats = at::empty({3, c}, opts.dtype(at::kDouble));
+    at::Tensor affine = at::empty({2, c}, opts), out = at::empty({n, c}, opts);
+    at::Tensor gamma_c = gamma.has_value() ? gamma->detach() : at::Tensor();
+    if (gamma.has_value()) check_f32(*gamma, "BatchNorm weight");
+    if (beta.has_value()) check_f32(*beta, "BatchNorm bias");
+    const bool track = s.running_mean.defined();
+    int64_t* cnt = s.n_tracked.defined() ? s.n_tracked.data_ptr<int64_t>() : nullptr;
+    check_status(egc_bn_forward_stats_f32(h.data_ptr<float>(), n, (int32_t)c, partials.data_ptr<double>(), (int32_t)n_parts,
+                                          track ? cnt : nullptr, nullptr, fptr(gamma), fptr(beta), s.eps, stats.data_ptr<double>(),
+                                          affine.data_ptr<float>(), track ? s.running_mean.data_ptr<float>() : nullptr,
+                                          track ? s.running_var.data_ptr<float>() : nullptr, s.momentum, cnt, nullptr, st),
+                 "egc_bn_forward_stats_f32");
+    check_status(egc_affine_act_residual_f32(h.data_ptr<float>(), affine.data_ptr<float>(), affine.data_ptr<float>() + c,
+                                             s.residual ? x.data_ptr<float>() : nullptr, s.relu ? 1 : 0, nullptr, 1.0f, n, (int32_t)c,
+                                             out.data_ptr<float>(), nullptr, st), "egc_affine_act_residual_f32");
+    ctx->save_for_backward({x, packed, packed_t, h, affine, stats, gamma_c});
+    return out;
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    const auto saved = ctx->get_saved_variables();
+    const BlockStatic s = load_static(ctx);
+    const auto has = ctx->saved_data["has"].toBoolList();
+    const auto shapes = ctx->saved_data["shapes"].to<std::vector<std::vector<int64_t>>>();
+    const int64_t n_parts_w = (int64_t)shapes.size() - 2;
+    variable_list out(8 + n_parts_w);            // x, bias, comb_w, comb_b, bcat_direct, gamma, beta, parts..., static
+    if (!grads[0].defined()) return out;
+    const at::Tensor& x = saved[0];
+    const at::Tensor &packed = saved[1], &packed_t = saved[2];
+    const auto* l = reinterpret_cast<const egc_layer*>(s.layer);
+    auto st = reinterpret_cast<egc_stream_t>(s.stream);
+    const c10::OptionalDeviceGuard device_guard(x.device());
+    const auto opts = x.options();
+    const int64_t n = x.size(0), f_in = s.f_in, f_out = l->out_channels, W = s.H * s.B * s.A, ldb = egc_bases_ld(l), k = ldb + W;
+    at::Tensor go = grads[0].contiguous();
+    check_f32(go, "grad_out");
+    at::Tensor g_conv = go;
+    if (s.with_tail) {
+      const at::Tensor &h = saved[3], &affine = saved[4], &stats = saved[5], &gamma_c = saved[6];
+      const int64_t c = f_out;
+      const int64_t n_parts = std::max<int64_t>(1, std::min<int64_t>(1024, (n + 127) / 128));
+      at::Tensor partials = at::empty({n_parts, 2, c}, opts.dtype(at::kDouble)), out5 = at::empty({5, c}, opts);
+      const float* a0 = affine.data_ptr<float>();
+      check_status(egc_bn_backward_stats_f32(go.data_ptr<float>(), h.data_ptr<float>(), a0, a0 + c, s.relu ? 1 : 0, nullptr, 1.0f, n, (int32_t)c,
+                                             partials.data_ptr<double>(), (int32_t)n_parts, nullptr, stats.data_ptr<double>(),
+                                             gamma_c.defined() ? gamma_c.data_ptr<float>() : nullptr, out5.data_ptr<float>(), nullptr, st),
+                   "egc_bn_backward_stats_f32");
+      at::Tensor dh = at::empty({n, c}, opts);
+      const float* o5 = out5.data_ptr<float>();
+      check_status(egc_affine_act_backward_f32(go.data_ptr<float>(), h.data_ptr<float>(), a0, a0 + c, s.relu ? 1 : 0, nullptr, 1.0f, o5 + 2 * c,
+                                               o5 + 3 * c, o5 + 4 * c, n, (int32_t)c, dh.data_ptr<float>(), nullptr, st),
+                   "egc_affine_act_backward_f32");
+      if (has[3]) out[5] = out5[0];
+      if (has[4]) out[6] = out5[1];
+      g_conv = dh;
+    }
+    // the layer's backward, one launch; the residual branch's gradient (x = x + ...) joins d x in its store
+    at::Tensor dx = at::empty({n, f_in}, opts), d_cat = at::empty({n, k}, opts);
+    const int64_t n_graphs = s.ptr.numel() - 1, n_edges = s.src.numel();
+    check_status(egc_layer_backward_batch_fused_f32(iptr(s.ptr), iptr(s.edge_ptr), n_graphs, iptr(s.src), iptr(s.dst), n_edges, n,
+                                                    s.max_index.defined() ? s.max_index.data_ptr<int32_t>() : nullptr, l, x.data_ptr<float>(),
+                                                    packed.data_ptr(), packed_t.data_ptr(), g_conv.data_ptr<float>(), dx.data_ptr<float>(),
+                                                    (s.with_tail && s.residual) ? go.data_ptr<float>() : nullptr, d_cat.data_ptr<float>(),
+                                                    (int32_t)k, (int32_t)s.tile_b, (int32_t)s.emax_b, s.status.data_ptr<int32_t>(),
+                                                    reinterpret_cast<int32_t*>(s.host_flag), st), "egc_layer_backward_batch_fused_f32");
+    out[0] = dx;
+    // x^T d_cat + the column sums of d_cat's weightings part (combination bias) and of the layer's incoming gradient (its bias)
+    at::Tensor es = at::empty({f_out}, opts), dcw = at::empty(shapes[0], opts);
+    at::Tensor dcb = has[1] ? at::empty(shapes[1], opts) : at::empty({W}, opts);
+    std::vector<at::Tensor> dparts;
+    std::vector<float*> ptrs;
+    for (int64_t i = 0; i < n_parts_w; ++i) {
+      dparts.push_back(at::empty(shapes[2 + i], opts));
+      ptrs.push_back(dparts.back().data_ptr<float>());
+    }
+    const int64_t gbytes = egc_weight_grad_ex_workspace_bytes(n, (int32_t)f_in, (int32_t)k, (int32_t)f_out);
+    at::Tensor gws = at::empty({std::max<int64_t>(gbytes, 16)}, opts.dtype(at::kByte));
+    check_status(egc_weight_grad_params_f32(x.data_ptr<float>(), f_in, d_cat.data_ptr<float>(), k, n, (int32_t)f_in, (int32_t)s.H, (int32_t)s.A,
+                                            (int32_t)s.B, (int32_t)s.L, (int32_t)s.Ls, s.permute_hab ? 1 : 0, ptrs.data(), (int32_t)n_parts_w,
+                                            dcw.data_ptr<float>(), has[1] ? dcb.data_ptr<float>() : nullptr, has[1] ? nullptr : dcb.data_ptr<float>(),
+                                            g_conv.data_ptr<float>(), f_out, (int32_t)f_out, es.data_ptr<float>(), gws.data_ptr(), gws.numel(),
+                                            reinterpret_cast<void*>(s.stream)), "egc_weight_grad_params_f32");
+    if (has[0]) out[1] = es;
+    out[2] = dcw;
+    if (has[1]) out[3] = dcb;
+    if (has[2]) out[4] = dcb;
+    for (int64_t i = 0; i < n_parts_w; ++i) out[7 + i] = dparts[i];
+    return out;
+  }
+};
+
+static void save_static(AutogradContext* ctx, const BlockStatic& s) {
+  // (the batch's tensors are kept alive for the backward; BatchNorm's buffers are not needed there)
+  std::vector<at::Tensor> ts;
+  std::vector<int64_t> present;
+  for (const at::Tensor* t : {&s.ptr, &s.edge_ptr, &s.src, &s.dst, &s.max_index, &s.status}) {
+    present.push_back(t->defined() ? 1 : 0);
+    ts.push_back(t->defined() ? *t : s.ptr);
+  }
+  ctx->saved_data["batch"] = ts;
+  ctx->saved_data["present"] = present;
+  ctx->saved_data["ints"] = std::vector<int64_t>{s.host_flag, s.layer, s.stream, s.f_in, s.H, s.A, s.B, s.L, s.Ls, s.permute_hab ? 1 : 0, s.tile_f,
+                                                s.emax_f, s.tile_b, s.emax_b, s.relu ? 1 : 0, s.residual ? 1 : 0, s.with_tail ? 1 : 0};
+}
+static BlockStatic load_static(AutogradContext* ctx) {
+  BlockStatic s;
+  const auto ts = ctx->saved_data["batch"].toTensorVector();
+  const auto pr = ctx->saved_data["present"].toIntVector();
+  at::Tensor* dst[6] = {&s.ptr, &s.edge_ptr, &s.src, &s.dst, &s.max_index, &s.status};
+  for (int i = 0; i < 6; ++i) if (pr[i]) *dst[i] = ts[i];
+  const auto v = ctx->saved_data["ints"].toIntVector();
+  s.host_flag = v[0]; s.layer = v[1]; s.stream = v[2]; s.f_in = v[3]; s.H = v[4]; s.A = v[5]; s.B = v[6]; s.L = v[7]; s.Ls = v[8];
+  s.permute_hab = v[9] != 0; s.tile_f = v[10]; s.emax_f = v[11]; s.tile_b = v[12]; s.emax_b = v[13];
+  s.relu = v[14] != 0; s.residual = v[15] != 0; s.with_tail = v[16] != 0;
+  s.eps = 0; s.momentum = 0;
+  return s;
+}
+
+at::Tensor batch_block_train(const at::Tensor& x, const c10::optional<at::Tensor>& bias, const at::Tensor& comb_w,
+                             const c10::optional<at::Tensor>& comb_b, const c10::optional<at::Tensor>& bcat_direct,
+                             const c10::optional<at::Tensor>& gamma, const c10::optional<at::Tensor>& beta, at::TensorList parts,
+                             const c10::optional<at::Tensor>& running_mean, const c10::optional<at::Tensor>& running_var,
+                             const c10::optional<at::Tensor>& n_tracked, const at::Tensor& ptr, const c10::optional<at::Tensor>& edge_ptr,
+                             const at::Tensor& src, const at::Tensor& dst, const c10::optional<at::Tensor>& max_index, const at::Tensor& status,
+                             int64_t host_flag, int64_t layer, int64_t stream, at::IntArrayRef dims, bool permute_hab, at::IntArrayRef setups,
+                             double eps, double momentum, bool relu, bool residual, bool with_tail) {
+  TORCH_CHECK(dims.size() == 6 && setups.size() == 4, "egc_amd: dims = (f_in, H, A, B, L, Ls), setups = (tile_f, emax_f, tile_b, emax_b)");
+  auto i64 = [](const at::Tensor& t, const char* name) {
+    TORCH_CHECK(t.is_cuda() && t.scalar_type() == at::kLong && t.is_contiguous(), "egc_amd: ", name, " must be a dense int64 tensor on the device");
+  };
+  i64(ptr, "ptr"); i64(src, "edge_index[0]"); i64(dst, "edge_index[1]");
+  TORCH_CHECK(src.numel() == dst.numel() && ptr.numel() >= 1, "egc_amd: malformed batch");
+  TORCH_CHECK(status.is_cuda() && status.scalar_type() == at::kInt, "egc_amd: status word");
+  BlockStatic s;
+  s.ptr = ptr; s.src = src; s.dst = dst; s.status = status;
+  if (edge_ptr.has_value()) { i64(*edge_ptr, "edge_ptr"); TORCH_CHECK(edge_ptr->numel() == ptr.numel(), "egc_amd: edge_ptr"); s.edge_ptr = *edge_ptr; }
+  if (max_index.has_value()) { TORCH_CHECK(max_index->is_cuda() && max_index->scalar_type() == at::kInt, "egc_amd: max_index"); s.max_index = *max_index; }
+  if (running_mean.has_value()) {
+    TORCH_CHECK(running_var.has_value(), "egc_amd: running_mean and running_var come together");
+    check_f32(*running_mean, "running_mean"); check_f32(*running_var, "running_var");
+    s.running_mean = *running_mean; s.running_var = *running_var;
+  }
+  if (n_tracked.has_value()) { TORCH_CHECK(n_tracked->is_cuda() && n_tracked->scalar_type() == at::kLong && n_tracked->numel() == 1, "egc_amd: num_batches_tracked"); s.n_tracked = *n_tracked; }
+  TORCH_CHECK(momentum >= 0 || !s.running_mean.defined() || s.n_tracked.defined(), "egc_amd: a cumulative average needs num_batches_tracked");
+  s.host_flag = host_flag; s.layer = layer; s.stream = stream;
+  s.f_in = dims[0]; s.H = dims[1]; s.A = dims[2]; s.B = dims[3]; s.L = dims[4]; s.Ls = dims[5];
+  s.permute_hab = permute_hab;
+  s.tile_f = setups[0]; s.emax_f = setups[1]; s.tile_b = setups[2]; s.emax_b = setups[3];
+  s.eps = eps; s.momentum = momentum; s.relu = relu; s.residual = residual; s.with_tail = with_tail;
+  return BatchBlockTrainFn::apply(x, bias, comb_w, comb_b, bcat_direct, gamma, beta, parts, s);
+}
+
 }  // namespace
 
 TORCH_LIBRARY(egc_amd_native, m) {
@@ -244,6 +483,10 @@ TORCH_LIBRARY(egc_amd_native, m) {
         "Tensor arg_max, Tensor arg_min, int graph, int t_graph, int layer, int stream, int H, int A, int B, int L, int Ls, "
         "bool permute_hab, bool packed_bias, bool need_x, int[] comb_w_shape, int[] comb_b_shape, int n_parts, int[] part_shape) "
         "-> Tensor[]");
+  m.def("batch_block_train(Tensor x, Tensor? bias, Tensor comb_w, Tensor? comb_b, Tensor? bcat_direct, Tensor? gamma, Tensor? beta, "
+        "Tensor[] parts, Tensor(a!)? running_mean, Tensor(b!)? running_var, Tensor(c!)? n_tracked, Tensor ptr, Tensor? edge_ptr, Tensor src, "
+        "Tensor dst, Tensor? max_index, Tensor status, int host_flag, int layer, int stream, int[] dims, bool permute_hab, int[] setups, "
+        "float eps, float momentum, bool relu, bool residual, bool with_tail) -> Tensor");
 }
 
 // HIP devices only (PyTorch-ROCm dispatches them under the CUDA key): a CPU tensor finds no kernel and the dispatcher raises
@@ -252,4 +495,10 @@ TORCH_LIBRARY_IMPL(egc_amd_native, CUDA, m) {
   m.impl("layer_forward_post", &layer_forward_post);
   m.impl("train_forward", &train_forward);
   m.impl("train_backward", &train_backward);
+}
+
+// the batch training block carries its own autograd node (BatchBlockTrainFn): registered at the Autograd key, which is where a call
+// with parameters that require gradients enters; the node's forward issues the library's launches itself (no dispatcher re-entry)
+TORCH_LIBRARY_IMPL(egc_amd_native, Autograd, m) {
+  m.impl("batch_block_train", &batch_block_train);
 }

@@ -685,6 +685,60 @@ def _native_train_ops(graph, spec, x, bias, comb_w, comb_b, bcat_direct, bases):
     return nat
 
 
+def native_block_train(call, bn=None, relu=True, residual=True, with_tail=True):
+    """The training call of a layer on a GraphBatch -- with ``with_tail`` the whole block x -> x + relu(bn(conv(x))) of the
+    reference's batched nets (zinc/models.py:66-73) -- as ONE autograd node of the compiled binding (egc_torch_ext.cpp:
+    batch_block_train), or None when the call is outside its envelope (the Python Functions below then, same kernels).
+    ``call``: the arguments of egc_layer_apply_params, as the layer modules' ``_train_call`` returns them."""
+    graph, spec, x, bias, comb_w, comb_b, bcat_direct, bases, f_in, H, A, B, L, Ls, permute = call
+    if not isinstance(graph, GraphBatch) or _C.env_flag("EGC_NO_NATIVE_TRAIN") or not torch.is_grad_enabled():
+        return None
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.size(0) > 1 and x.is_contiguous()):
+        return None
+    nat = _native_ops(x.device)
+    if nat is None or not hasattr(nat, "batch_block_train"):
+        return None
+    cb = comb_b if comb_b is not None else bcat_direct
+    params = [bias, comb_w, cb, *bases]
+    if any(t is None or not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.requires_grad) for t in params):
+        return None
+    if comb_b is not None and bcat_direct is not None:
+        return None
+    k = spec.ldb + spec.w_cols
+    if not (spec.ldb == spec.f_g and k % 4 == 0 and k <= 192 and spec.f_in % 4 == 0 and spec.f_in <= 128
+            and spec.f_out % 4 == 0 and spec.f_out <= 128 and k == B * Ls + H * B * A):
+        return None
+    if graph.n_nodes is None:
+        graph.n_nodes = int(x.size(0))
+    if x.size(0) != graph.n_nodes or x.device != graph.device:
+        return None
+    gamma = beta = rm = rv = nt = None
+    eps, momentum = 1e-5, 0.1
+    if with_tail:
+        if not (relu and bn.training and bn.affine and spec.f_out % 4 == 0):
+            return None
+        gamma, beta, eps = bn.weight, bn.bias, float(bn.eps)
+        if any(not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()) for t in (gamma, beta)):
+            return None
+        if bn.track_running_stats:
+            rm, rv, nt = bn.running_mean, bn.running_var, bn.num_batches_tracked
+            if not (_f32_vec(rm, spec.f_out) and _f32_vec(rv, spec.f_out) and rm.is_cuda and nt is not None and nt.dtype == torch.int64
+                    and nt.is_cuda):
+                return None
+        momentum = -1.0 if bn.momentum is None else float(bn.momentum)
+    setups = _batch_fused_train_setup(graph, spec, x)
+    if setups is None:
+        return None
+    _IndexFlag.poll()
+    src, dst = graph.rows()
+    needs_max = not bool(spec.c.loops_all_nodes)
+    return nat.batch_block_train(x, bias, comb_w, comb_b, bcat_direct, gamma, beta, list(bases), rm, rv, nt, graph.ptr, graph.edge_ptr,
+                                 src, dst, graph.max_index() if needs_max else None, graph.status(), _IndexFlag.ptr() or 0, spec.c_addr,
+                                 _stream_ptr(x.device), (int(f_in), int(H), int(A), int(B), int(L), int(Ls)), bool(permute),
+                                 (setups[0][0], setups[0][1], setups[1][0], setups[1][1]), eps, momentum, bool(relu), bool(residual),
+                                 bool(with_tail))
+
+
 def _layer_forward_one_call(graph: CSRGraph, spec: LayerSpec, x, packed, bcat, bias):
     """The common inference case (one GPU, packed weights at hand, no fused tail) as ONE library call
     (egc_layer_forward_packed: both launches from C) -- small batched graphs are bound by the host side.  Through the
@@ -1349,6 +1403,11 @@ def egc_layer_apply_params(graph, spec, x, bias, comb_w, comb_b, bcat_direct, ba
     if isinstance(graph, GraphBatch) and spec.ldb == spec.f_g:
         setups = _batch_fused_train_setup(graph, spec, x)
         if setups is not None:
+            if getattr(ResidualLink._local, "offered", None) is None:        # (a block's Python tail would hand its gradient over)
+                out = native_block_train((graph, spec, x, bias, comb_w, comb_b, bcat_direct, bases, f_in, H, A, B, L, Ls, permute_hab),
+                                         with_tail=False)
+                if out is not None:
+                    return out
             return _BatchFusedTrainFunction.apply(x, bias, comb_w, comb_b, bcat_direct, graph, spec,
                                                   (int(f_in), int(H), int(A), int(B), int(L), int(Ls)), bool(permute_hab), setups,
                                                   ResidualLink.take(x) if x.requires_grad else None, *bases)

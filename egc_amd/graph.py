@@ -510,6 +510,13 @@ class GraphBatch:
         self._csr = None
         self._status = None
         self._max_index = None
+        self._rows = None
+
+    def rows(self):
+        """(edge_index[0], edge_index[1]) as dense views, made once per batch (the compiled binding takes them as tensors)."""
+        if self._rows is None:
+            self._rows = (self.edge_index[0], self.edge_index[1])
+        return self._rows
 
     @property
     def n_src_rows(self):

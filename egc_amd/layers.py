@@ -139,6 +139,17 @@ class EfficientGraphConv(nn.Module):
             self._planes = pack_weights(self._spec, wcat)
         return self._planes
 
+    def _train_call(self, x, edge_index):
+        """The arguments of functional.egc_layer_apply_params for a training call on a GraphBatch, or None (see EGConv._train_call)."""
+        w = self.comb_weights.weight
+        if (self.cache or not isinstance(edge_index, GraphBatch) or not (w.is_cuda and w.dtype == torch.float32 and self.num_bases <= 32
+                                                                         and x.is_cuda) or ops.use_torch_op()):
+            return None
+        sp = self._spec
+        A = w.size(0) // (self.num_heads * self.num_bases)
+        return (edge_index, sp, x, self.bias, w, None, self.comb_weights.bias, list(self.bases_weight._parameters.values()),
+                self.in_channels, self.num_heads, A, self.num_bases, sp.basis_len, sp.basis_stride, False)
+
     def forward(self, x, edge_index):
         if _is_adj_t(edge_index) and any(a.aggr_fun in ("var", "std") for a in self.aggs):      # (also a real torch_sparse.SparseTensor)
             raise NotImplementedError  # layers.py:221-224

@@ -122,6 +122,17 @@ class EGConv(nn.Module):
             self._planes = pack_weights(spec, wcat)
         return self._planes
 
+    def _train_call(self, x, edge_index):
+        """The arguments of functional.egc_layer_apply_params for a training call on a GraphBatch, or None (what forward() below
+        passes on that path; egc_amd.FusedEGCBlock hands them to the compiled binding's block node)."""
+        bw, cw, cb = self.bases_weight, self.comb_weight.weight, self.comb_weight.bias
+        if (self.cached or not isinstance(edge_index, GraphBatch) or not (bw.is_cuda and bw.dtype == torch.float32 and cb is not None
+                                                                          and x.is_cuda) or ops.use_torch_op()):
+            return None
+        spec = self._spec_coo
+        return (edge_index, spec, x, self.bias, cw, cb, None, [bw], self.in_channels, self.num_heads, len(self.aggregators),
+                self.num_bases, spec.basis_len, spec.basis_stride, True)
+
     def forward(self, x, edge_index):
         if self.cached and self._cached_graph is not None:
             graph, spec = self._cached_graph

@@ -52,3 +52,82 @@ def test_native_binding_equals_the_ctypes_path_bit_for_bit(kind, aggrs, monkeypa
         bp = block(x, ei)
     assert _native.ops() is None
     assert torch.equal(a, b) and torch.equal(ap, bp)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["opt", "lay"])
+@pytest.mark.parametrize("residual", [True, False])
+def test_batch_block_train_node_equals_the_python_functions(kind, residual, monkeypatch):
+    """The reference's block x -> x + relu(bn(conv(x))) on a GraphBatch in training as ONE autograd node of the compiled binding
+    (csrc_ext: batch_block_train) against the Python Functions (EGC_NO_NATIVE_TRAIN=1): the same library calls in the same
+    order on deterministic kernels -- outputs, every gradient and BatchNorm's running statistics bit for bit."""
+    import egc_amd
+    from egc_amd import _native
+    from test_batch_tile_gpu import _messy_batch
+    assert _native.ops() is not None and hasattr(_native.ops(), "batch_block_train")
+    dev = torch.device("cuda:0")
+    ei, n, ptr = _messy_batch(21, n_graphs=200, max_size=70)
+    x0, go = torch.randn(n, 128), torch.randn(n, 128)
+
+    def build():
+        torch.manual_seed(5)
+        if kind == "opt":
+            conv = egc_amd.EGConv(128, 128, aggrs=["sum", "mean", "max", "symnorm"], num_heads=8, num_bases=4)
+        else:
+            conv = egc_amd.EfficientGraphConv(128, 128, 8, 4, False, aggrs=["symadd", "max", "mean"])
+        blocks = torch.nn.ModuleList([egc_amd.FusedEGCBlock(conv, torch.nn.BatchNorm1d(128), residual=residual),
+                                      egc_amd.FusedEGCBlock(egc_amd.EGConv(128, 128, aggrs=["sum", "max"], num_heads=8, num_bases=4),
+                                                            torch.nn.BatchNorm1d(128, momentum=None), residual=residual)])
+        return blocks.to(dev).train()
+    res = {}
+    for mode in ("native", "python"):
+        if mode == "python":
+            monkeypatch.setenv("EGC_NO_NATIVE_TRAIN", "1")
+        blocks = build()
+        for step in range(2):           # (two steps: the running statistics and num_batches_tracked move twice)
+            for p in blocks.parameters():
+                p.grad = None
+            x = x0.to(dev).requires_grad_(True)
+            gb = egc_amd.GraphBatch(ei.to(dev), ptr=ptr.to(dev), max_nodes=70)
+            h = x
+            for b in blocks:
+                h = b(h, gb)
+            h.backward(go.to(dev))
+            gb.check()
+        node = h.grad_fn.name() if h.grad_fn is not None else ""
+        res[mode] = (h.detach().clone(), x.grad.clone(), [p.grad.clone() for p in blocks.parameters()],
+                     [b.clone() for b in blocks.buffers() if b.dtype != torch.int32], node)
+    assert "BatchBlockTrainFn" in res["native"][4] and "BatchBlockTrainFn" not in res["python"][4], (res["native"][4], res["python"][4])
+    assert torch.equal(res["native"][0], res["python"][0])
+    assert torch.equal(res["native"][1], res["python"][1])
+    for a, b in zip(res["native"][2], res["python"][2]):
+        assert torch.equal(a, b)
+    for a, b in zip(res["native"][3], res["python"][3]):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_batch_conv_train_node_outside_a_block(monkeypatch):
+    """conv(x, GraphBatch) in training outside a FusedEGCBlock: the same node without the tail."""
+    import egc_amd
+    from test_batch_tile_gpu import _messy_batch
+    dev = torch.device("cuda:0")
+    ei, n, ptr = _messy_batch(22, n_graphs=150, max_size=70)
+    torch.manual_seed(7)
+    conv = egc_amd.EGConv(128, 128, aggrs=["sum", "mean", "max", "symnorm"], num_heads=8, num_bases=4).to(dev).train()
+    x0, go = torch.randn(n, 128, device=dev), torch.randn(n, 128, device=dev)
+    res = {}
+    for mode in ("native", "python"):
+        if mode == "python":
+            monkeypatch.setenv("EGC_NO_NATIVE_TRAIN", "1")
+        conv.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        gb = egc_amd.GraphBatch(ei.to(dev), ptr=ptr.to(dev), max_nodes=70)
+        out = conv(x, gb)
+        out.backward(go)
+        gb.check()
+        res[mode] = (out.detach().clone(), x.grad.clone(), [p.grad.clone() for p in conv.parameters()], out.grad_fn.name())
+    assert "BatchBlockTrainFn" in res["native"][3] and "BatchBlockTrainFn" not in res["python"][3]
+    assert torch.equal(res["native"][0], res["python"][0]) and torch.equal(res["native"][1], res["python"][1])
+    for a, b in zip(res["native"][2], res["python"][2]):
+        assert torch.equal(a, b)
