@@ -773,7 +773,6 @@ static int aggregate_combine_impl(const egc_graph* graph, const egc_layer* layer
   PlanCaps caps = plan_caps(n, e);
   a.rows_per_wave = 0;
   a.n_chunks_hint = (graph->n_chunks >= 0 && graph->n_chunks <= caps.cap_chunks) ? (int)graph->n_chunks : -1;
-  if (const char* env = getenv("EGC_ROWS_PER_WAVE")) a.rows_per_wave = atoi(env);
   const bool force_generic = getenv("EGC_FORCE_GENERIC") != nullptr || a.var_ref != 0;
   if (!force_generic && fast_path_supported(a, layer->weight_layout, chunks)) {
     if (arg_done != nullptr) *arg_done = true;  // the register-resident kernels track the arg positions themselves

@@ -606,7 +606,6 @@ int launch_fast(AggArgs a, int64_t n_nodes, const PlanCaps& caps, hipStream_t st
   a.bias_lds_floats = (a.H * a.Ls + 3) & ~3;  // >= F_out: the bias strip follows the (padded) head layout
   a.lds_floats_per_wave = (a.post_scale != nullptr ? 2 : 1) * a.bias_lds_floats + G * a.w_lds_stride;
   size_t lds = (size_t)4 * a.lds_floats_per_wave * sizeof(float);
-  if (const char* e = getenv("EGC_AGG_LDS_PAD")) lds += (size_t)atoi(e);  // experiments: caps the blocks per CU
   if (lds > 64 * 1024) return EGC_ERR_UNSUPPORTED;
   const int64_t row_blocks = ceil_div((int64_t)a.row_end - a.row_begin, (int64_t)4 * a.rows_per_wave * G);
   const unsigned grid = (unsigned)(a.chunk_blocks + row_blocks);

@@ -23,8 +23,13 @@
 // Every edge is range-checked against ITS TILE: an edge that leaves its graph's tile (an edge list that is not grouped by
 // graph, an id outside [0, N)), a tile with more nodes or edges than the LDS areas hold -> *status and the sticky
 // host flag are raised (codes below) and the tile's rows are left unwritten.
-// The order of a row's entries inside the LDS CSR follows the LDS atomics (not the input order): sums may differ in the
-// last bits from run to run (as the reference's own GPU scatter does); max / min are exact.
+// A row's entries sit in the LDS CSR in INPUT ORDER (round 6, as in egc_fused_tile_dev.h): the tile's edges are cut into eight
+// contiguous spans, wavefront w holds span 2 (w % 4) + w / 4; the two wavefronts of a PAIR (w, w + 4) -- two adjacent spans --
+// share one 16-bit counter per row (four counters: two words), which the scan turns into the pair's cursor; the scatter takes an
+// entry's position from a returning LDS add to that cursor -- one wavefront's instructions execute in program order and serve
+// equal addresses in ascending lane order (tools/src/lds_atomic_order.hip) -- in two passes, wavefronts 0-3 then 4-7, so a pair's
+// second span follows its first.  The reference's CPU scatter sums a row in edge order (SURVEY.md 8a note 9), and two launches
+// give the same bits.
 #include <algorithm>
 
 #include "egc_aggregate_fast_dev.h"
@@ -221,7 +226,7 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
   f4* lds_bases4 = reinterpret_cast<f4*>(base + t.off_bases);
   unsigned short* lds_col = reinterpret_cast<unsigned short*>(base + t.off_col);
   int* lds_rowptr = reinterpret_cast<int*>(base + t.off_rowptr);
-  int* lds_cnt = reinterpret_cast<int*>(base + t.off_cnt);       // in-degree, then the scatter cursor
+  int* lds_cnt = reinterpret_cast<int*>(base + t.off_cnt);       // [2][tmax]: per row and PAIR of wavefronts a 16-bit count, then cursor
   int* lds_ns = reinterpret_cast<int*>(base + t.off_ns);         // non-self in-degree
   float* lds_dis_raw = reinterpret_cast<float*>(base + t.off_dis_raw);
   float* lds_dis_looped = reinterpret_cast<float*>(base + t.off_dis_looped);
@@ -246,22 +251,30 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
   int es[TILE_EDGE_REGS], ed[TILE_EDGE_REGS];
   bool bad = false;
   int edges_of = -1;            // the tile whose edges es / ed hold (requested one tile ahead, during the rows phase)
+  static_assert(TILE_WAVES == 8, "the CSR build pairs wavefront w with w + 4");
+  auto span_len = [](int tE) -> int { return (((tE + TILE_WAVES - 1) / TILE_WAVES) + 63) & ~63; };
+  const int my_span = 2 * (wave & 3) + (wave >> 2);
   auto request_edges = [&](const int4 rec, int which) {
     const int tn0 = rec.x, tT = rec.y - rec.x, te0 = rec.z, tE = rec.w - rec.z;
     bad = false;
     edges_of = which;
     if (tT <= 0 || tE > TILE_THREADS * TILE_EDGE_REGS) return;
+    const int S = span_len(tE);
 #pragma unroll
     for (int j = 0; j < TILE_EDGE_REGS; ++j) {
-      const int i = tid + j * TILE_THREADS;
+      const int i = my_span * S + 64 * j + lane;    // this wavefront's span of the tile's edges, in rounds of 64
       es[j] = ed[j] = -1;
-      if (i < tE) {
+      if (64 * j + lane < S && i < tE) {
         const int64_t s = t.src[(int64_t)te0 + i] - tn0, d = t.dst[(int64_t)te0 + i] - tn0;
         if (s < 0 || s >= tT || d < 0 || d >= tT) bad = true;
         else { es[j] = (int)s; ed[j] = (int)d; }
       }
     }
   };
+  // this wavefront's pair p = wave % 4: 16 bits of a row's two counter words -- word p / 2, half p % 2
+  int* my_cnt = lds_cnt + ((wave & 3) >> 1) * t.tmax;
+  const int my_inc = (wave & 1) ? 0x10000 : 1;
+  auto my_half = [&](int v) -> int { return (wave & 1) ? (int)((unsigned)v >> 16) : (v & 0xffff); };
 
   for (; k < n_tiles; k += gridDim.x) {
     const int4 cur = tl;
@@ -288,7 +301,11 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
       load_weightings_row<LPR_LOG2, C>(a, q, n0 + r + RPP, r + RPP < T, wn1);
     }
     if (in_regs && edges_of != k) request_edges(cur, k);
-    for (int i = tid; i < T; i += TILE_THREADS) { lds_cnt[i] = 0; lds_ns[i] = 0; }
+    for (int i = tid; i < T; i += TILE_THREADS) {
+      lds_cnt[i] = 0;
+      lds_cnt[t.tmax + i] = 0;
+      lds_ns[i] = 0;
+    }
     lds_barrier();
 
     // ---- (B) in-degrees; every edge checked against the tile ----
@@ -296,16 +313,19 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
 #pragma unroll
       for (int j = 0; j < TILE_EDGE_REGS; ++j)
         if (ed[j] >= 0) {
-          atomicAdd(&lds_cnt[ed[j]], 1);
+          atomicAdd(&my_cnt[ed[j]], my_inc);
           if (es[j] != ed[j]) atomicAdd(&lds_ns[ed[j]], 1);
         }
     } else {
       bad = false;
+      const int S = span_len(Et);
 #pragma unroll 4
-      for (int i = tid; i < Et; i += TILE_THREADS) {
+      for (int i0 = 0; i0 < S; i0 += 64) {
+        const int i = my_span * S + i0 + lane;
+        if (i >= Et) continue;
         const int64_t s = t.src[(int64_t)e0 + i] - n0, d = t.dst[(int64_t)e0 + i] - n0;
         if (s < 0 || s >= T || d < 0 || d >= T) { bad = true; continue; }
-        atomicAdd(&lds_cnt[(int)d], 1);
+        atomicAdd(&my_cnt[(int)d], my_inc);
         if (s != d) atomicAdd(&lds_ns[(int)d], 1);
       }
     }
@@ -327,7 +347,11 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
       const int per = (T + 63) >> 6;
       const int b0 = lane * per;
       int mine = 0;
-      for (int j = 0; j < per; ++j) mine += (b0 + j < T) ? lds_cnt[b0 + j] : 0;
+      auto row_count = [&](int i) -> int {      // the row's in-degree: its four 16-bit counters
+        const int v0 = lds_cnt[i], v1 = lds_cnt[t.tmax + i];
+        return (v0 & 0xffff) + (int)((unsigned)v0 >> 16) + (v1 & 0xffff) + (int)((unsigned)v1 >> 16);
+      };
+      for (int j = 0; j < per; ++j) mine += (b0 + j < T) ? row_count(b0 + j) : 0;
       int incl = mine;
 #pragma unroll
       for (int off = 1; off < 64; off <<= 1) {
@@ -338,11 +362,17 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
       for (int j = 0; j < per; ++j) {
         const int i = b0 + j;
         if (i < T) {
-          const int c = lds_cnt[i];
           lds_rowptr[i] = run;
+          int c = 0;
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {                                     // counts -> cursors: where each pair's entries start
+            const int v = lds_cnt[p * t.tmax + i];
+            const int lo = v & 0xffff, hi = (int)((unsigned)v >> 16);
+            lds_cnt[p * t.tmax + i] = (run + c) | ((run + c + lo) << 16);
+            c += lo + hi;
+          }
           lds_dis_raw[i] = c > 0 ? 1.0f / sqrtf((float)c) : 0.0f;          // as prepare_kernel / build_scan_kernel
           lds_dis_looped[i] = 1.0f / sqrtf((float)(lds_ns[i] + 1));
-          lds_cnt[i] = 0;                                                   // becomes the cursor
           run += c;
         }
       }
@@ -350,18 +380,26 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
     }
     lds_barrier();
 
-    // ---- (D) scatter ----
-    if (in_regs) {
+    // ---- (D) scatter, in two passes: wavefronts 0-3 (the pairs' first spans), then 4-7 (their second spans) ----
+    for (int pass = 0; pass < 2; ++pass) {
+      if ((wave >> 2) == pass) {
+        if (in_regs) {
 #pragma unroll
-      for (int j = 0; j < TILE_EDGE_REGS; ++j)
-        if (ed[j] >= 0) lds_col[lds_rowptr[ed[j]] + atomicAdd(&lds_cnt[ed[j]], 1)] = (unsigned short)es[j];
-    } else {
+          for (int j = 0; j < TILE_EDGE_REGS; ++j)
+            if (ed[j] >= 0) lds_col[my_half(atomicAdd(&my_cnt[ed[j]], my_inc))] = (unsigned short)es[j];
+        } else {
+          const int S = span_len(Et);
 #pragma unroll 4
-      for (int i = tid; i < Et; i += TILE_THREADS) {
-        const int64_t s = t.src[(int64_t)e0 + i] - n0, d = t.dst[(int64_t)e0 + i] - n0;
-        if (s < 0 || s >= T || d < 0 || d >= T) continue;
-        lds_col[lds_rowptr[(int)d] + atomicAdd(&lds_cnt[(int)d], 1)] = (unsigned short)s;
+          for (int i0 = 0; i0 < S; i0 += 64) {
+            const int i = my_span * S + i0 + lane;
+            if (i >= Et) continue;
+            const int64_t s = t.src[(int64_t)e0 + i] - n0, d = t.dst[(int64_t)e0 + i] - n0;
+            if (s < 0 || s >= T || d < 0 || d >= T) continue;
+            lds_col[my_half(atomicAdd(&my_cnt[(int)d], my_inc))] = (unsigned short)s;
+          }
+        }
       }
+      if (pass == 0) lds_barrier();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's pieces of the basis rows have landed ...
     lds_barrier();                                       // ... and so have everybody else's
@@ -451,7 +489,7 @@ static TileLds tile_lds(const AggArgs& a, int tlds, int tmax, int emax) {
   L.off_bases = (int)at; at += up16((size_t)tlds * a.ldb * 4);
   L.off_col = (int)at; at += up16((size_t)emax * 2);
   L.off_rowptr = (int)at; at += up16((size_t)(tmax + 1) * 4);
-  L.off_cnt = (int)at; at += up16((size_t)tmax * 4);
+  L.off_cnt = (int)at; at += up16((size_t)tmax * 4 * 2);      // a 16-bit counter / cursor per pair of wavefronts and row
   L.off_ns = (int)at; at += up16((size_t)tmax * 4);
   L.off_dis_raw = (int)at; at += up16((size_t)tmax * 4);
   L.off_dis_looped = (int)at; at += up16((size_t)tmax * 4);
@@ -534,7 +572,7 @@ int launch_tile(AggArgs a, TileArgs t, int n_tiles, hipStream_t stream) {
   a.bias_lds_floats = (a.H * a.Ls + 3) & ~3;
   a.lds_floats_per_wave = (a.post_scale != nullptr ? 2 : 1) * a.bias_lds_floats + G * a.w_lds_stride;
   const TileLds L = tile_lds(a, t.tlds, t.tmax, t.emax);
-  if (L.total > TILE_LDS_BUDGET || t.tmax > TILE_MAX_NODES || t.tlds > t.tmax || t.tlds < 1) return EGC_ERR_UNSUPPORTED;
+  if (L.total > TILE_LDS_BUDGET || t.tmax > TILE_MAX_NODES || t.tlds > t.tmax || t.tlds < 1 || t.emax > 65535) return EGC_ERR_UNSUPPORTED;   // (16-bit cursors)
   t.off_bases = L.off_bases; t.off_col = L.off_col; t.off_rowptr = L.off_rowptr; t.off_cnt = L.off_cnt; t.off_ns = L.off_ns;
   t.off_dis_raw = L.off_dis_raw; t.off_dis_looped = L.off_dis_looped;
   const unsigned grid = (unsigned)std::min(n_tiles, 256 * TILE_WGS_PER_CU);   // persistent: n_tiles = upper bound of the tile count

@@ -131,9 +131,8 @@ static bool ft_narrow_shape(const AggArgs& a, int f_in) {
 }
 // the WIDE form's envelope: F_in <= 320, at most 12 column tiles of 32 (bases padded to a multiple of 32, then the weightings)
 static bool ft_wide_shape(const AggArgs& a, int f_in) {
-  const bool off = getenv("EGC_NO_FUSED_WIDE") != nullptr;      // (read on every call, like the Python side's EGC_NO_* switches)
   if (a.slots > 64 && (a.slots > 128 || a.B * (((a.Ls >> 2) + 1) / 2) > 64)) return false;    // two passes of at most 64 lanes
-  return !off && f_in >= 4 && f_in <= FTW_MAX_FIN && (f_in & 3) == 0 && ((a.ldb + 31) & ~31) + a.W <= FTW_MAX_CT * 32 && a.A <= AMAX;
+  return f_in >= 4 && f_in <= FTW_MAX_FIN && (f_in & 3) == 0 && ((a.ldb + 31) & ~31) + a.W <= FTW_MAX_CT * 32 && a.A <= AMAX;
 }
 static inline int ftw_k16(int f_in) { return (((f_in + 15) / 16) + 3) & ~3; }   // k-steps of 16, padded (zero fragments) to the kernel's ring of four
 static inline int ftw_n_ct(const AggArgs& a) { return (((a.ldb + 31) & ~31) + a.W + 31) / 32; }

@@ -442,7 +442,9 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
         // (only the rounds the span has -- wave-uniform: a molecule tile has one or two, a superpixel tile five -- each behind
         // one scalar offset for the span with the round in the instruction's immediate; what follows the edges in the
         // vector-memory queue, the tile's rows, is unconditional, so the counted waits stay exact)
-        if (64 * j < nw) {
+        // (the WIDE form requests every round: under the branches the compiler carried the chunk's registers the edges travel
+        // in through copies -- up to 860 spilled registers in its 168 / 224-wide instances)
+        if (WIDE != 0 || 64 * j < nw) {
           const ft_u2 sv = __builtin_bit_cast(ft_u2, __builtin_amdgcn_raw_buffer_load_b64(es, (unsigned)lane * 8u + 512u * j, cw * S * 8, 0));
           const ft_u2 dv = __builtin_bit_cast(ft_u2, __builtin_amdgcn_raw_buffer_load_b64(ed, (unsigned)lane * 8u + 512u * j, cw * S * 8, 0));
           if (j & 1) { e[j >> 1].z = __uint_as_float(sv.x); e[j >> 1].w = __uint_as_float(sv.y); e[KEEP / 2 + (j >> 1)].z = __uint_as_float(dv.x); e[KEEP / 2 + (j >> 1)].w = __uint_as_float(dv.y); }
@@ -486,7 +488,7 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
           unsigned pk = NO_EDGE;
-          if (64 * (2 * j + k) >= nw) { epk[2 * j + k] = pk; continue; }     // (wave-uniform: the span has no such round)
+          if (WIDE == 0 && 64 * (2 * j + k) >= nw) { epk[2 * j + k] = pk; continue; }     // (wave-uniform: the span has no such round)
           if (64 * (2 * j + k) + lane < nw) {
             unsigned sl, dl;
             if (!local_ids(s2[k], d2[k], r.n0, T, sl, dl)) bad = true;
@@ -591,11 +593,11 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
 #pragma unroll
       for (int j = 0; j < KEEP; ++j) {         // (all the adds issued before the first position is used)
         pos[j] = 0;
-        if (64 * j < nw && epk[j] != NO_EDGE) pos[j] = take_pos(cnt, rowptr, epk[j] >> 16);
+        if ((WIDE != 0 || 64 * j < nw) && epk[j] != NO_EDGE) pos[j] = take_pos(cnt, rowptr, epk[j] >> 16);
       }
 #pragma unroll
       for (int j = 0; j < KEEP; ++j)
-        if (64 * j < nw && epk[j] != NO_EDGE) col[pos[j]] = (unsigned short)(epk[j] & 0xffffu);
+        if ((WIDE != 0 || 64 * j < nw) && epk[j] != NO_EDGE) col[pos[j]] = (unsigned short)(epk[j] & 0xffffu);
       if (__builtin_amdgcn_readfirstlane(nw) > KEEP * 64) {      // (larger tiles: the rest of their edges a second time, from L2)
         const __amdgpu_buffer_rsrc_t es = edge_rsrc(r, t.src), ed = edge_rsrc(r, t.dst);
         for (int i0 = KEEP * 64; i0 < nw; i0 += 4 * 64) {

@@ -595,7 +595,7 @@ size_t egc_basis_pack_bytes(int32_t f_in, int32_t f_g, int32_t w_cols) {
 // flags & EGC_GEMM_24BIT: operands split into THREE bf16 planes (24 significand bits: nothing of an fp32 operand is
 // dropped) whatever the shape -- the fp16x2 forms keep 22 bits, which layers with std / var amplify (egc_hip.h)
 static bool use_f16x2(int f_in, int ldb, int NV, int flags) {
-  return (flags & EGC_GEMM_24BIT) == 0 && f16x2_shape(f_in, ldb, NV) && getenv("EGC_GEMM_BF16X3") == nullptr;
+  return (flags & EGC_GEMM_24BIT) == 0 && f16x2_shape(f_in, ldb, NV);
 }
 static bool use_f16x2k(int f_in, int f_g, int ldb, int w_cols, int flags) {
   return (flags & EGC_GEMM_24BIT) == 0 && f16x2k_shape(f_in, f_g, ldb, w_cols);
@@ -651,7 +651,7 @@ int egc_basis_transform_packed_ex(const float* x, const void* packed, const floa
     return f16x2_launch(x, packed, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, stream);
   if (use_f16x2k(f_in, f_g, ldb, w_cols, flags))  // likewise: its planes are in its own fragment order
     return f16x2k_launch(x, packed, bcat, n_nodes, f_in, f_g, ldb, w_cols, bases, weightings, stream);
-  if (f_in <= 128 && NV <= 256 && getenv("EGC_GEMM_NO_WS") == nullptr) {  // weight-stationary form (<= 8 wavefronts)
+  if (f_in <= 128 && NV <= 256) {  // weight-stationary form (<= 8 wavefronts)
     const u16* pk = (const u16*)packed;
     int st;
     if (f_in <= 32) st = launch_ws<2>(x, pk, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, stream);
@@ -665,7 +665,7 @@ int egc_basis_transform_packed_ex(const float* x, const void* packed, const floa
   const bool vec4 = (f_in % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
   const int full = NV / XBN;  // column blocks of the full 192 columns; a narrower remainder block follows
   const u16* pk = (const u16*)packed;
-  if (NV == 224 && vec4 && getenv("EGC_GEMM_NO_NT7") == nullptr) {  // 193..224 columns: one 7-tile block, one pass over x
+  if (NV == 224 && vec4) {  // 193..224 columns: one 7-tile block, one pass over x
     dim3 grid((unsigned)mblocks, 1);
     basis_gemm_bf16x3_kernel<true, 7><<<grid, 256, 0, stream>>>(x, pk, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, KS, 0);
     EGC_LAUNCH_CHECK("basis_gemm_bf16x3_kernel");

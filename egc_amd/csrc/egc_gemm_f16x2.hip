@@ -440,7 +440,6 @@ static int f16x2_launch_rows(const float* x, const void* packed, const float* bc
     attr_set = true;
   }
   int grid = 256;  // one 12-wavefront block per CU (registers: 3 wavefronts per SIMD)
-  if (const char* e = getenv("EGC_GEMM_GRID")) grid = atoi(e);
   if (grid > n_tiles) grid = n_tiles;
   const int rows_per_block = (int)((M + grid - 1) / grid);   // contiguous, equal row ranges
 #ifdef EGC_GEMM_STAMPS

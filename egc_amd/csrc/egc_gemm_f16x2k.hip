@@ -587,7 +587,6 @@ __global__ void __launch_bounds__(WAVES * 64) basis_gemm_f16x2k_spec_kernel(cons
 }
 
 bool f16x2k_shape(int f_in, int f_g, int ldb, int w_cols) {
-  if (getenv("EGC_GEMM_NO_F16X2K") != nullptr) return false;
   if (f_in <= 128 || f_in > 384 || (f_in & 3) != 0) return false;
   const int NT = (ldb + 15) / 16 + (w_cols + 15) / 16;
   const int per_launch = NT <= 16 ? NT : (NT + 1) / 2;   // two launches beyond 16 column tiles
@@ -648,12 +647,11 @@ static int launch_k(const float* x, const u16* packed, const float* bcat, int64_
     const size_t lds0 = (size_t)2 * R0 * threads * 16 + fixed;
     two_per_cu = KS <= 9 && std::min<size_t>((size_t)160 * 1024 / lds0, (size_t)(20 / ntl)) >= 2;
   }
-  if (nh >= 2 && !two_per_cu && getenv("EGC_GEMMK_LEGACY") == nullptr) {
+  if (nh >= 2 && !two_per_cu) {
     const int hthreads = nh * 64;
     const int R = (int)ceil_div((int64_t)KROWS * (K / 4), hthreads);
     const int slot_bytes = R * hthreads * 16;
     int ring = (int)std::min<size_t>(4, ((size_t)160 * 1024 - fixed) / (size_t)slot_bytes);
-    if (const char* e = getenv("EGC_GEMMK_RING")) ring = std::min(ring, atoi(e));
     while (ring > 2 && (ring - 2) * R > 32) --ring;
     if (ring >= 2 && R <= 16) {
       const size_t lds = (size_t)ring * slot_bytes + fixed;
@@ -665,7 +663,6 @@ static int launch_k(const float* x, const u16* packed, const float* bcat, int64_
         attr_set = true;
       }
       int grid = 256;
-      if (const char* e = getenv("EGC_GEMM_GRID")) grid = atoi(e);
       if (grid > n_tiles) grid = n_tiles;
       kern<<<grid, (ntl + nh) * 64, lds, stream>>>(x, packed, bcat, M, K, c, bases, weightings, n_tiles, LDX, R, slot_bytes, tile0, ring,
                                                    ntl);
@@ -707,14 +704,12 @@ static int launch_k(const float* x, const u16* packed, const float* bcat, int64_
   int per_cu = (int)std::min<size_t>((size_t)160 * 1024 / lds, (size_t)(20 / ntl));
   if (KS > 9 || per_cu < 1) per_cu = 1;
   int grid = 256 * per_cu;
-  if (const char* e = getenv("EGC_GEMM_GRID")) grid = atoi(e);
   if (grid > n_tiles) grid = n_tiles;
   // depth of the raw-tile ring: what the LDS share of a workgroup holds next to the planes, at most 4 (and within the
   // counted wait's range); a workgroup that shares its CU keeps 2
   int ring = 2;
   if (per_cu == 1) {
     ring = (int)std::min<size_t>(4, ((size_t)160 * 1024 - fixed) / (size_t)slot_bytes);
-    if (const char* e = getenv("EGC_GEMMK_RING")) ring = atoi(e);
     while (ring > 2 && ((ring - 2) * R + 4 > 32 || (size_t)ring * slot_bytes + fixed > (size_t)160 * 1024)) --ring;
     if (ring < 2) ring = 2;
     lds = (size_t)ring * slot_bytes + fixed;

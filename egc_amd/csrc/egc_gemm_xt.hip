@@ -5,7 +5,7 @@
 //
 // Two kernels, same decomposition.  Outputs of up to 128 x 192 (the north-star layer): xt_gemm_bf16x3_kernel, split
 // bf16 on the 16-bit matrix cores (further down, with the optional column sums of a third array riding along).  Larger
-// outputs, and EGC_GEMM_EXACT=1 / EGC_XT_FP32: xt_gemm_kernel, exact fp32 on the fp32 matrix cores, described here.
+// outputs, and EGC_GEMM_EXACT=1: xt_gemm_kernel, exact fp32 on the fp32 matrix cores, described here.
 //
 // The reduction runs over the N rows, the output is tiny (128 x 192 at config 2): a split over row ranges.  Every
 // workgroup keeps one whole output tile (up to 128 x 192) in accumulators, streams its row range through a
@@ -548,12 +548,11 @@ struct XtPlan {
 constexpr int XT_WN = 4;     // wavefronts along the output columns (K): 8 wavefronts per workgroup, one workgroup per CU
 constexpr int XT_STAGE = 32;  // rows of the reduction per LDS stage
 
-// EGC_XT_FP32 (any value) or EGC_GEMM_EXACT=1 (the switch of the forward GEMMs): exact fp32 products on the fp32 MFMA
+// EGC_GEMM_EXACT=1 (the switch of the forward GEMMs): exact fp32 products on the fp32 MFMA
 // instead of the split-bf16 form
 // Read per call (a getenv is nothing next to a launch): the host side decides from the same variables at every call
 // (functional._weight_grads), and a value cached here at first use would disagree with it once the environment changes.
 bool xt_fp32_only() {
-  if (getenv("EGC_XT_FP32") != nullptr) return true;
   const char* e = getenv("EGC_GEMM_EXACT");
   return e != nullptr && e[0] != '\0' && !(e[0] == '0' && e[1] == '\0');
 }

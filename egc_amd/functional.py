@@ -496,7 +496,7 @@ def _batch_fused_train_setup(gb: GraphBatch, spec: LayerSpec, x):
     EGC_NO_FUSED_BWD=1 switches the path off.  (Graphs of at most 80 nodes at H = 8: the tile's LDS image also holds d bases
     as 64-bit fixed point, summed by integer LDS atomics.)"""
     if (_C.env_flag("EGC_NO_FUSED_BWD") or _C.env_flag("EGC_NO_FUSED_TILE") or _C.env_flag("EGC_NO_TILE") or gemm_exact()
-            or spec.gemm_flags != 0 or os.environ.get("EGC_XT_FP32") is not None):
+            or spec.gemm_flags != 0):
         return None
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous() and x.data_ptr() % 16 == 0):
         return None
@@ -578,8 +578,7 @@ class _BatchFusedTrainFunction(torch.autograd.Function):
     def forward(ctx, x, bias, comb_w, comb_b, bcat_direct, gb, spec, dims, permute, setups, link, *bases):
         ctx.dims, ctx.permute, ctx.packed_b, ctx.link = dims, permute, comb_b is not None, link
         ctx.shapes = (comb_w.shape, comb_b.shape if comb_b is not None else None, [b.shape for b in bases])
-        both = None if _C.env_flag("EGC_NO_PACK_FROM_PARAMS") else _batch_fused_train_pack_params(spec, dims, permute, comb_w, comb_b,
-                                                                                                    bcat_direct, bases)
+        both = _batch_fused_train_pack_params(spec, dims, permute, comb_w, comb_b, bcat_direct, bases)
         if both is not None:           # the planes of both launches straight from the parameters: no wcat / bcat arrays
             packed, packed_t = both
             wcat = bc = None
@@ -608,7 +607,7 @@ class _BatchFusedTrainFunction(torch.autograd.Function):
         need_w = need[2] or any(need[11:])
         need_b = ctx.has_bcat and (need[3] if ctx.packed_b else need[4])
         need_bias = ctx.has_bias and need[1]
-        if need_w and need_b and need_bias and ctx.has_bcat and not _C.env_flag("EGC_NO_GRADS_INTO_PARAMS"):
+        if need_w and need_b and need_bias and ctx.has_bcat:
             # the usual training call: every parameter takes a gradient -- x^T d_cat and both bias sums land in the parameters'
             # own layouts in the weight-gradient launch's reduction (no d wcat, no unpack launch)
             got = _weight_grads_into_params(x, d_cat, grad_out, ctx.dims, ctx.permute, ctx.shapes, ctx.packed_b)
@@ -668,7 +667,7 @@ def _native_train_ops(graph, spec, x, bias, comb_w, comb_b, bcat_direct, bases):
     nat = _native_ops(x.device)
     if nat is None or not hasattr(nat, "train_forward") or _C.env_flag("EGC_NO_NATIVE_TRAIN"):
         return None
-    if graph.halo is not None or graph.n_src_rows != graph.n_nodes or gemm_exact() or os.environ.get("EGC_XT_FP32") is not None:
+    if graph.halo is not None or graph.n_src_rows != graph.n_nodes or gemm_exact():
         return None
     cb = comb_b if comb_b is not None else bcat_direct
     if bias is None or cb is None or (comb_b is not None and bcat_direct is not None):
@@ -921,8 +920,7 @@ def _weight_grads(x: torch.Tensor, d: torch.Tensor, col_sums: bool = False, extr
     dev = x.device
     ride = (extra is not None and col_sums and f <= 128 and k <= 192 and extra.dim() == 2 and extra.size(0) == n
             and extra.size(1) % 4 == 0 and extra.size(1) <= 128 and extra.dtype == torch.float32 and extra.stride(1) == 1
-            and extra.stride(0) % 4 == 0 and extra.data_ptr() % 16 == 0 and not gemm_exact()
-            and os.environ.get("EGC_XT_FP32") is None)   # (the fp32-MFMA form has no third stream)
+            and extra.stride(0) % 4 == 0 and extra.data_ptr() % 16 == 0 and not gemm_exact())   # (the fp32-MFMA form has no third stream)
     with _device_guard(dev):
         out = torch.empty((f, k), dtype=torch.float32, device=dev)
         cs = torch.empty(k, dtype=torch.float32, device=dev) if col_sums else None
@@ -951,7 +949,7 @@ def _weight_grads_into_params(x, d, extra, dims, permute, shapes, packed_b):
             or x.stride(1) != 1 or d.stride(1) != 1 or x.stride(0) % 4 or d.stride(0) % 4 or x.data_ptr() % 16 or d.data_ptr() % 16
             or extra.dim() != 2 or extra.size(0) != n or extra.size(1) % 4 or extra.size(1) > 128 or extra.dtype != torch.float32
             or extra.stride(1) != 1 or extra.stride(0) % 4 or extra.data_ptr() % 16 or gemm_exact()
-            or os.environ.get("EGC_XT_FP32") is not None or k != B * Ls + H * B * A):
+            or k != B * Ls + H * B * A):
         return None
     lib = _C.load()
     dev = x.device

@@ -327,12 +327,8 @@ class CSRGraph:
         if self._n_chunks is None:
             # A host copy of the chunk count would trim the launch to the chunks that exist, at the price of one
             # synchronisation per graph.  Measured (ogbn-mag shape: 208 k chunk slots, 52 k idle workgroups per
-            # launch), the idle workgroups cost nothing that shows, so by default nothing is read back and no
-            # call ever synchronises; EGC_SYNC_MIN_CHUNKS=<capacity> switches the read-back on above that capacity.
-            cap_long = min(self.n_edges // (_C.LONG_ROW_THRESHOLD + 1) + 1, self.n_nodes + 1)
-            cap_chunks = self.n_edges // _C.LONG_ROW_CHUNK + cap_long
-            sync_min = int(os.environ.get("EGC_SYNC_MIN_CHUNKS", "0"))
-            self._n_chunks = int(self.plan[1].item()) if (sync_min > 0 and cap_chunks > sync_min) else -1
+            # launch), the idle workgroups cost nothing that shows: nothing is read back and no call ever synchronises.
+            self._n_chunks = -1
         return _C.EgcGraph(self.n_nodes, self.n_edges, self.rowptr.data_ptr(), self.col.data_ptr(),
                            self.edge_id.data_ptr(), self.dis_raw.data_ptr(), self.dis_looped.data_ptr(),
                            self.max_index.data_ptr(), self.plan.data_ptr(), self._n_chunks, self.n_src_rows,

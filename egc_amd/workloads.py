@@ -2,6 +2,8 @@
 available offline, so every benchmark / full-size parity input is generated here, seeded, on the CPU."""
 from __future__ import annotations
 
+import math
+
 import torch
 
 ARXIV_NODES = 169_343
@@ -98,6 +100,33 @@ def zinc_like_batch(n_graphs: int = 128, seed: int = 0):
     ei, n, batch = molecule_batch(n_graphs, mean_nodes=23.2, std_nodes=4.5, min_nodes=9, max_nodes=37, seed=seed)
     g = torch.Generator().manual_seed(seed + 1)
     return torch.randint(0, 28, (n,), generator=g), ei, n, batch
+
+
+def code_like_batch(n_graphs: int = 128, mean_nodes: float = 125.0, min_nodes: int = 20, max_nodes: int = 250, seed: int = 0):
+    """ogbg-code2-shaped batch (code/models.py:103-115, run_pretrained.sh:47-48; batch size 128: code/configs.py:163): the AST of a
+    Python function with its nodes in depth-first order -- a tree -- plus, as the reference's ``augment_edge`` adds them
+    (code/utils.py:74-135), the inverse AST edges, next-token edges chaining the attributed nodes (about half the nodes) in
+    depth-first order, and their inverses: about 3 directed edges per node, a graph's edges contiguous and in the order
+    [AST | inverse AST | next-token | inverse next-token] -- NOT sorted by destination.  Sizes: log-normal around ``mean_nodes``
+    (ogbg-code2: 125 nodes on average), clipped to [min_nodes, max_nodes].  Returns (edge_index, n_nodes, batch)."""
+    g = torch.Generator().manual_seed(seed)
+    sizes = torch.exp(torch.randn(n_graphs, generator=g) * 0.45 + math.log(mean_nodes) - 0.1).round().long().clamp_(min_nodes, max_nodes)
+    offs = torch.cumsum(sizes, 0) - sizes
+    parts = []
+    for k in range(n_graphs):
+        n, o = int(sizes[k]), int(offs[k])
+        child = torch.arange(1, n)
+        # depth-first numbering: a node's parent is a recent node (the current path of the traversal)
+        back = (torch.rand(n - 1, generator=g) ** 2 * torch.clamp(child, max=12).float()).long()
+        parent = child - 1 - torch.minimum(back, child - 1)
+        attributed = torch.nonzero(torch.rand(n, generator=g) < 0.5).view(-1)
+        nt_a, nt_b = attributed[:-1], attributed[1:]
+        src = torch.cat([parent, child, nt_a, nt_b]) + o
+        dst = torch.cat([child, parent, nt_b, nt_a]) + o
+        parts.append(torch.stack([src, dst]))
+    ei = torch.cat(parts, dim=1)
+    batch = torch.repeat_interleave(torch.arange(n_graphs), sizes)
+    return ei, int(sizes.sum()), batch
 
 
 def knn_superpixel_batch(n_graphs: int = 2048, k: int = 8, lo: int = 85, hi: int = 150, seed: int = 0):

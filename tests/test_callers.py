@@ -343,3 +343,41 @@ def test_batch_norm_statistics_in_one_launch_equal_the_two_launches(n, momentum,
     for a, b in zip(two[1], one[1]):
         assert torch.equal(a, b)
     assert int(blk_b._bn_sync.item()) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hidden,H,B,aggrs", [(304, 8, 8, ["symadd"]), (300, 4, 4, ["symadd", "min", "max"]), (128, 8, 4, ["symadd", "max", "mean"])])
+def test_code_shaped_batch_against_the_oracle(hidden, H, B, aggrs):
+    """ogbg-code2-shaped batches (egc_amd.workloads.code_like_batch: ASTs of ~125 nodes, up to 250, edges in the order the
+    reference's augment_edge leaves them -- code/utils.py:74-135) through the reference's code nets' layers
+    (run_pretrained.sh:47-48) handed over as a GraphBatch, full batch against the numpy oracle and every element against float64.
+    Which kernel serves it is asserted: a 250-node graph's `bases` rows (1,216 - 1,280 bytes each at these widths) do not fit the
+    LDS of a CU, so the 300 / 304-wide layers take the CSR path; the d = 128 layer's 160-row tiles do not hold a 250-node graph
+    either and go through the two-launch tile path."""
+    import egc_amd
+    from egc_amd import workloads as wl
+    from golden_util import elementwise_excess, float64_forward, oracle_forward, rel_err
+    from oracle import egc_oracle as orc
+    dev = torch.device("cuda:0")
+    ei, n, batch = wl.code_like_batch(128, seed=3)
+    sizes = torch.bincount(batch)
+    ptr = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(sizes, 0)])
+    torch.manual_seed(hidden)
+    layer = egc_amd.EfficientGraphConv(hidden, hidden, H, B, False, aggrs=aggrs)
+    with torch.no_grad():
+        layer.bias.normal_()
+    x = torch.randn(n, hidden)
+    meta = dict(kind="lay", fin=hidden, fout=hidden, H=H, B=B, aggrs=aggrs, softmax=False, sigmoid=False, hardtanh=False,
+                add_self_loops=True, bias=True, sparse=False)
+    g = dict(meta=meta, params={k: v.numpy() for k, v in layer.state_dict().items()}, x=x.numpy(), edge_index=ei.numpy())
+    ref = oracle_forward(g, orc)
+    layer = layer.to(dev).eval()
+    gb = egc_amd.GraphBatch(ei.to(dev), ptr=ptr.to(dev), max_nodes=int(sizes.max()))
+    with torch.no_grad():
+        out = layer(x=x.to(dev), edge_index=gb).cpu().numpy()
+    gb.check()
+    ran = sorted({(k[-1] if isinstance(k[-1], str) else "tile") for k, v in gb._setups.items() if v})
+    assert ran == ([] if hidden >= 300 else ["tile"]), ran          # [] = neither tile kernel: the CSR of the batch (gb.csr())
+    assert (gb._csr is not None) == (hidden >= 300)
+    assert rel_err(out, ref) <= 1e-5, rel_err(out, ref)
+    assert elementwise_excess(out, float64_forward(g), 1e-5) <= 1.0

@@ -221,3 +221,44 @@ def test_molhiv_step_against_float64_on_both_paths():
     for path, e in got.items():
         for k, v in e.items():
             assert v <= max(1e-5, 5.0 * cal[k]), (path, k, v, cal[k])
+
+
+def test_two_launch_tile_path_is_in_edge_order_and_reproducible(monkeypatch):
+    """The plan + GEMM + agg_tile_kernel path (graphs beyond the one-launch kernel's tile, EGC_NO_FUSED_TILE=1) builds its tiles' CSR
+    in input order as well: sums bit-identical to the sequential edge-order sums, and to a second run."""
+    import egc_amd
+    dev = _dev()
+    monkeypatch.setenv("EGC_NO_FUSED_TILE", "1")
+    rng = np.random.default_rng(77)
+    f = 64
+    for deg, n_graphs, lo, hi in ((4, 60, 20, 200), (40, 10, 150, 250)):      # (the second: tiles whose edges do not fit the registers)
+        sizes = rng.integers(lo, hi, size=n_graphs)
+        ptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        src, dst = [], []
+        for g in range(n_graphs):
+            m, o = int(sizes[g]), int(ptr[g])
+            e = deg * m
+            s, d = rng.integers(0, m, size=e) + o, rng.integers(0, m, size=e) + o
+            p = rng.permutation(e)
+            src.append(s[p]); dst.append(d[p])
+        src, dst = np.concatenate(src), np.concatenate(dst)
+        n = int(ptr[-1])
+        x = _exact_rows(n, f, rng)
+        conv = egc_amd.EGConv(f, f, aggrs=["sum"], num_heads=1, num_bases=1, add_self_loops=False, bias=False)
+        with torch.no_grad():
+            conv.bases_weight.copy_(torch.eye(f))
+            conv.comb_weight.weight.zero_()
+            conv.comb_weight.bias.fill_(1.0)
+        conv = conv.to(dev).eval()
+        ei = torch.from_numpy(np.stack([src, dst])).to(dev)
+        outs = []
+        for _ in range(2):
+            gb = egc_amd.GraphBatch(ei, ptr=torch.from_numpy(ptr).to(dev), max_nodes=int(sizes.max()), edges_per_node=max(16, deg))
+            with torch.no_grad():
+                outs.append(conv(torch.from_numpy(x).to(dev), gb).cpu().numpy())
+            gb.check()
+            assert gb._plans and not _ran(gb, "fused"), "the two-launch tile path did not run"
+        want = _sequential_sum(x, src, dst, n)
+        # (the GEMM in front of agg_tile_kernel is the split-precision one: identity weights on 22-bit inputs are exact there too)
+        assert np.array_equal(outs[0].view(np.uint32), want.view(np.uint32)), int((outs[0].view(np.uint32) != want.view(np.uint32)).sum())
+        assert np.array_equal(outs[0], outs[1])

@@ -269,7 +269,7 @@ def test_envelope_and_fallbacks(monkeypatch):
     x = torch.randn(n, 128, device=dev)
     with torch.no_grad():
         ref = conv(x, ei.to(dev))
-        gb = egc_amd.GraphBatch(ei.to(dev), ptr=ptr.to(dev), max_nodes=1000)     # beyond the image: two-launch tile path
+        gb = egc_amd.GraphBatch(ei.to(dev), ptr=ptr.to(dev), max_nodes=600)      # beyond the image: two-launch tile path
         out = conv(x, gb)
         gb.check()
         assert not _ran_fused(gb) and gb._plans

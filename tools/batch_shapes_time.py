@@ -37,6 +37,10 @@ SHAPES = [  # (name, dataset, hidden, H, B, aggrs)   -- run_pretrained.sh line i
     ("code EGC-S (on the ZINC batch)", "zinc", 304, 8, 8, ["symadd"]),               # :47 (64-row tiles: graphs of at most 64 nodes)
     ("code EGC-M (on the ZINC batch)", "zinc", 300, 4, 4, ["symadd", "min", "max"]),   # :48
     ("north star EGC-M d128", "molhiv", 128, 8, 4, ["symadd", "max", "mean"]),
+    # round 6: the code nets on a code-SHAPED batch (egc_amd.workloads.code_like_batch: 128 ASTs of ~125 nodes, up to 250)
+    ("code EGC-S (code-shaped batch)", "code", 304, 8, 8, ["symadd"]),               # :47
+    ("code EGC-M (code-shaped batch)", "code", 300, 4, 4, ["symadd", "min", "max"]),   # :48
+    ("north star EGC-M d128 (code-shaped batch)", "code", 128, 8, 4, ["symadd", "max", "mean"]),
 ]
 
 
@@ -50,6 +54,9 @@ def main():
         if ds not in data:
             if ds == "zinc":
                 _, ei, n, batch = wl.zinc_like_batch(128, seed=0)
+                G = 128
+            elif ds == "code":
+                ei, n, batch = wl.code_like_batch(128, seed=0)
                 G = 128
             elif ds == "cifar":
                 ei, n, batch = wl.knn_superpixel_batch(2048, seed=0)

@@ -1,7 +1,9 @@
 """Training step of the reference's batched nets' core -- 4 x [EGConv -> BatchNorm1d(train) -> ReLU -> + x], forward + backward -- on a
 ZINC-shaped batch of 128 and a molhiv-shaped batch of 2048 graphs, with the layer taking (a) the COO edge list (per-batch graph
 build + GEMM + aggregate, three backward kernels + dense gradients) and (b) an egc_amd.GraphBatch (one launch each way:
-egc_layer_forward_batch_fused_f32 / egc_layer_backward_batch_fused_f32); eager and as ONE hipGraph.  EGC_SMALL_ONLY=zinc|molhiv."""
+egc_layer_forward_batch_fused_f32 / egc_layer_backward_batch_fused_f32); eager and as ONE hipGraph.  EGC_SMALL_ONLY=zinc|molhiv.
+EGC_STEP_SHAPE="hidden,H,B,aggr+aggr+...,self_loops" runs the blocks at another layer shape, e.g. the reference's own molhiv net
+"224,4,4,sum+mean+max,0" (run_pretrained.sh:24) or "296,8,4,symnorm,1" (:23)."""
 import os, sys, time
 import torch, torch.nn as nn
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,6 +11,8 @@ import egc_amd
 from egc_amd import workloads as wl
 dev = torch.device("cuda:0")
 only = os.environ.get("EGC_SMALL_ONLY", "")
+shape = os.environ.get("EGC_STEP_SHAPE", "128,8,4,sum+mean+max+symnorm,1").split(",")
+HID, HEADS, BASES, AGGRS, LOOPS = int(shape[0]), int(shape[1]), int(shape[2]), shape[3].split("+"), shape[4] != "0"
 for name, gen, G in (("zinc b128", lambda: wl.zinc_like_batch(128, seed=0)[1:], 128), ("molhiv b2048", lambda: wl.molecule_batch(2048, seed=0), 2048)):
     if only and only not in name:
         continue
@@ -18,11 +22,11 @@ for name, gen, G in (("zinc b128", lambda: wl.zinc_like_batch(128, seed=0)[1:], 
     mx = int(sizes.max())
     ptr = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(sizes, 0)])
     torch.manual_seed(0)
-    blocks = nn.ModuleList([egc_amd.FusedEGCBlock(egc_amd.EGConv(128, 128, aggrs=["sum", "mean", "max", "symnorm"], num_heads=8, num_bases=4),
-                                                  nn.BatchNorm1d(128)) for _ in range(4)]).to(dev).train()
+    blocks = nn.ModuleList([egc_amd.FusedEGCBlock(egc_amd.EGConv(HID, HID, aggrs=AGGRS, num_heads=HEADS, num_bases=BASES, add_self_loops=LOOPS),
+                                                  nn.BatchNorm1d(HID)) for _ in range(4)]).to(dev).train()
     params = list(blocks.parameters())
-    x = torch.randn(n, 128, device=dev)
-    gout = torch.randn(n, 128, device=dev)
+    x = torch.randn(n, HID, device=dev)
+    gout = torch.randn(n, HID, device=dev)
     grads = {}
     for label, graph_of in (("COO (CSR path)", lambda: ei), ("GraphBatch (one launch each way)", lambda: egc_amd.GraphBatch(ei, ptr=ptr, max_nodes=mx, num_nodes=n))):
         def step():
