@@ -30,6 +30,7 @@ constexpr int ARG_NONE = 0x7fffffff;  // "no entry yet": loses every position co
 // layer-constant accessors
 // ---------------------------------------------------------------------------------------------
 struct RtCfg {
+  static constexpr int kH = 0;     // (the number of heads as a compile-time constant, 0 = not known)
   static __device__ inline int H(const AggArgs& a) { return a.H; }
   static __device__ inline int B(const AggArgs& a) { return a.B; }
   static __device__ inline int L(const AggArgs& a) { return a.L; }
@@ -63,6 +64,7 @@ constexpr unsigned agg_pack(int a0, int a1 = 0, int a2 = 0, int a3 = 0) {
 // LS_ = floats between consecutive bases in a row (L_ rounded up to 4 when the layer pads them).
 template <int H_, int B_, int L_, int A_, unsigned AGG, int ACT_, bool XL_, bool YL_, bool LOOPS_ALL_, int LS_ = L_>
 struct StCfg {
+  static constexpr int kH = H_;
   static constexpr int P_ = LS_ / 4;                       // lanes per basis
   static constexpr bool POW2_ = (P_ & (P_ - 1)) == 0;
   static constexpr int agg_at(int t) { return (int)((AGG >> (3 * t)) & 7u); }

@@ -461,7 +461,9 @@ int fused_tile_train_pack_params(const AggArgs& a, const PackPtrs& bases, const 
 int fused_tile_bwd_capacity(const AggArgs& a, int f_in, int max_tile_edges) {
   if (!fused_tile_bwd_shape(a, f_in) || max_tile_edges < 0) return 0;
   int best = 0;
-  for (int tcap = FT_CHUNK; tcap <= FT_CHUNK * 8; tcap += FT_CHUNK) {        // (the kernel keeps eight 16-row chunks of x in flight)
+  // (the kernel keeps eight 16-row chunks of x in flight; six at H = 8, where the LDS image -- d bases next to bases and w' -- holds
+  // no more than 96 rows anyway and the static configuration's helpers give the registers of the other two to their working set)
+  for (int tcap = FT_CHUNK; tcap <= FT_CHUNK * (a.H == 8 ? 6 : 8); tcap += FT_CHUNK) {
     if (ft_lds(a, a.H * a.B * 4, tcap, max_tile_edges, false, false, true).total <= FT_LDS_BUDGET) best = tcap; else break;
   }
   return best;
@@ -533,7 +535,7 @@ int launch_fused_tile_bwd(AggArgs a, const int64_t* ptr, const int64_t* edge_ptr
   t.nsets = 1;
   t.grad_out = grad_out; t.d_x = d_x; t.d_x_add = d_x_add; t.d_cat = d_cat; t.ld_dcat = ld_dcat; t.packed_t = (const ft_u16*)packed_t;
   if (const char* e = getenv("EGC_FT_DBG")) t.dbg = atoi(e);     // (read by diagnostic builds of the kernel only: -DEGC_FT_STAMPS)
-  if (tcap < FT_CHUNK || tcap > FT_CHUNK * 8 || (tcap % FT_CHUNK) != 0 || emax < 0 || emax > 16384) return EGC_ERR_INVALID;
+  if (tcap < FT_CHUNK || tcap > FT_CHUNK * (a.H == 8 ? 6 : 8) || (tcap % FT_CHUNK) != 0 || emax < 0 || emax > 16384) return EGC_ERR_INVALID;
   const FtLds L = ft_lds(a, t.wl_floats, tcap, emax, false, false, true);
   if (L.total > FT_LDS_BUDGET) return EGC_ERR_UNSUPPORTED;
   t.off_rec = L.off_rec; t.off_planes = L.off_planes; t.off_rowinv = L.off_rowinv; t.off_bases = L.off_bases; t.off_wt = L.off_wt;

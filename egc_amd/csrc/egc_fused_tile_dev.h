@@ -627,7 +627,12 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
     const bool csr_wave = wave < FT_FIRST_HELPER + FT_CSR_WAVES;
     if constexpr (WIDE == 0) {
     // (the backward form keeps d bases next to the images: tiles of at most 128 rows, 16 registers fewer for the rows in flight)
-    constexpr int RINGN = MODE == 1 ? 8 : FT_RING;
+    // (H = 8 in a static configuration: tiles of at most 96 rows -- the host's capacity, fused_tile_bwd_capacity -- so six chunks; the
+    // sixteen registers fewer keep the helpers' working set in the register file: with eight chunks the allocator spilled ~30
+    // registers into the per-tile loops, 22 MB of scratch traffic per launch on the molhiv batch)
+    constexpr int RINGN = MODE == 1 ? (C::kH == 8 ? 6 : 8) : FT_RING;
+    constexpr int EREG = 2 * RINGN - 8 < RINGN ? 2 * RINGN - 8 : RINGN;     // first register of the eight the edges travel in ...
+    constexpr int H1 = EREG / 2;                                            // ... = the chunks requested behind the CSR build's counts
     f4 xr[2 * RINGN];
     // 16-byte pieces p = ht + 256 i (i = 0, 1) of a 16-row chunk <-> (row p / 32, k 4 (p % 32)).  Per thread: the two byte
     // offsets inside a chunk (rows beyond the tile fall outside the tile's descriptor and read as 0; the chunk is a SCALAR
@@ -723,16 +728,16 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
     unsigned epk0[KEEP];
     {
       const __amdgpu_buffer_rsrc_t rs = x_rsrc_of(first);
-      if (csr_wave) csr_s0(first, xr + RINGN);
+      if (csr_wave) csr_s0(first, xr + EREG);
 #pragma unroll
-      for (int c = 0; c < RINGN / 2; ++c) x_load(xr[2 * c], xr[2 * c + 1], rs, c);   // (chunks beyond the tile read as 0)
+      for (int c = 0; c < H1; ++c) x_load(xr[2 * c], xr[2 * c + 1], rs, c);   // (chunks beyond the tile read as 0)
       if (csr_wave) {
-        csr_s1(first, 0, xr + RINGN, epk0);
+        csr_s1(first, 0, xr + EREG, epk0);
         csr_s1_rest(first, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int c = RINGN / 2; c < RINGN; ++c) x_load(xr[2 * c], xr[2 * c + 1], rs, c);
+      for (int c = H1; c < RINGN; ++c) x_load(xr[2 * c], xr[2 * c + 1], rs, c);
     }
     if (csr_wave) {
       csr_sync();
@@ -805,13 +810,13 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       // requested, unconditionally (the ones beyond the tile lie outside its descriptor and cost no traffic): the compiler can
       // then count the requests in flight.  (Requested chunk by chunk inside the loop above, its conservative vmcnt(0) in
       // front of every split made each step wait for the request it had just issued.)
-      if (csr_wave) csr_s0(nxt, xr + RINGN);
+      if (csr_wave) csr_s0(nxt, xr + EREG);
 #ifndef EGC_FT_EARLY_X
 #pragma unroll
-      for (int c = 0; c < RINGN / 2; ++c) x_load(xr[2 * c], xr[2 * c + 1], rsn, c);
+      for (int c = 0; c < H1; ++c) x_load(xr[2 * c], xr[2 * c + 1], rsn, c);
 #endif
       if (csr_wave) {
-        csr_s1(nxt, nset, xr + RINGN, epk);
+        csr_s1(nxt, nset, xr + EREG, epk);
         csr_s1_rest(nxt, nset);
       }
       __builtin_amdgcn_sched_barrier(0);       // (the second half of the rows into the registers the edges have left)
@@ -831,10 +836,10 @@ __global__ void __launch_bounds__(FT_THREADS) fused_tile_kernel(AggArgs a, Fused
       // vector-memory pipeline -- need not stand between the in-degrees and the scan)
 #ifdef EGC_FT_EARLY_X
 #pragma unroll
-      for (int c = RINGN / 2; c < RINGN - 1; ++c) x_load(xr[2 * c], xr[2 * c + 1], rsn, c);
+      for (int c = H1; c < RINGN - 1; ++c) x_load(xr[2 * c], xr[2 * c + 1], rsn, c);
 #else
 #pragma unroll
-      for (int c = RINGN / 2; c < RINGN; ++c) x_load(xr[2 * c], xr[2 * c + 1], rsn, c);
+      for (int c = H1; c < RINGN; ++c) x_load(xr[2 * c], xr[2 * c + 1], rsn, c);
 #endif
 #ifdef EGC_FT_STAMPS
       FT_HSTAMP(2, wave == FT_FIRST_HELPER)
