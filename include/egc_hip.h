@@ -506,7 +506,8 @@ int egc_aggregate_combine_train_rows_f32(const egc_graph* graph, const egc_layer
  * Every edge is checked against its tile: an edge that leaves the tile (list not grouped by graph, id out of range) or a
  * tile beyond max_tile_nodes / max_tile_edges raises *status (bit 0 / bit 1; zero it before the call) and the sticky
  * *host_flag (see egc_coo_to_csr_checked); the rows of such a tile are written as zeros.  A row's entries are summed in the order of
- * the LDS atomics that built the CSR: sums are reproducible to rounding, max / min exactly.
+ * the edge list (round 6: the tile's CSR is built in input order -- the order the reference's CPU scatter sums a row in): results are
+ * bit-reproducible and bit-identical to egc_aggregate_combine_post_f32 on the CSR of the same batch.
  * ------------------------------------------------------------------------------------------ */
 int32_t egc_batch_tile_nodes(const egc_layer* layer, int32_t max_tile_nodes, int32_t max_tile_edges, int32_t with_post);
 int egc_batch_plan(const int64_t* graph_ptr, const int64_t* edge_ptr, int64_t n_graphs, const int64_t* dst, int64_t n_edges,
@@ -551,6 +552,8 @@ int egc_aggregate_combine_batch_f32(const int32_t* tiles, const int32_t* n_tiles
  *                               the wavefronts that build a tile's CSR timed out -- a bounded spin, never a hang; the
  *                               launch's output is then undefined).  Inference form, fp16x2-split GEMM (22-bit operands,
  *                               fp32 accumulate: the arithmetic of egc_basis_transform_packed at the north-star shape).
+ *                               A row's entries are summed in the order of the edge list (round 6; the reference's CPU
+ *                               scatter order): bit-reproducible; max_tile_edges <= 65535 (16-bit cursors of the CSR build).
  * ------------------------------------------------------------------------------------------ */
 int32_t egc_batch_fused_tile_nodes(const egc_layer* layer, int32_t max_tile_edges, int32_t with_post);
 int32_t egc_batch_fused_tile_quantum(const egc_layer* layer);
@@ -576,7 +579,8 @@ int egc_layer_forward_batch_fused_f32(const int64_t* graph_ptr, const int64_t* e
  *   d_x   [n_nodes, in_channels]  = [d bases | d weightings] [bases_weight | comb_weight^T]^T   (split-precision MFMA GEMM)
  *   d_cat [n_nodes, ld_dcat]      = the gradient of [bases (ldb) | pre-activation weightings (H B A, column (h B + b) A + a)]
  * leave the launch (d_cat may be NULL; the caller's weight gradient is x^T d_cat: egc_weight_grad_*).  Two launches on the same inputs
- * agree to rounding, not to the bit (the recomputed aggregates sum a row's entries in the order the LDS CSR build left them).  Envelope (egc_batch_fused_bwd_tile_nodes > 0): B = 4 bases of 16 channels, H = 4 or 8
+ * agree to the bit (round 6: the tile's CSR is built in input order; a tile whose grad_out or weightings hold an Inf / NaN leaves its
+ * d bases rows -- and with them its rows of d_x -- as NaN instead of a fixed-point image of them).  Envelope (egc_batch_fused_bwd_tile_nodes > 0): B = 4 bases of 16 channels, H = 4 or 8
  * (the d = 64 / 128 layers), F_in <= 128, aggregators of sum / mean / max / symnorm, no weight nonlinearity.
  *   egc_batch_fused_bwd_tile_nodes   rows of a tile (its image also holds d bases, 512 B per row: 80 at the north star), 0 = outside
  *   egc_batch_fused_bwd_pack[_bytes] wcat -> the transposed operand's fp16 planes; once per parameter update
