@@ -15,6 +15,8 @@
 #include <torch/library.h>
 
 #include <algorithm>
+#include <cstring>
+#include <string>
 #include <vector>
 
 #include "egc_hip.h"
@@ -169,8 +171,9 @@ std::vector<at::Tensor> train_forward(const at::Tensor& x, const at::Tensor& com
 }
 
 // -> [dx (or empty), d comb_w, d comb_b or d bcat_direct (or empty), d bias (or empty), d basis matrices ...]
-// Requires (checked by the caller): ldb == B Ls, (ldb + W) % 4 == 0, f_in % 4 == 0, f_in <= 128, ldb + W <= 192,
-// f_out % 4 == 0, f_out <= 128 -- the one-pass dense-gradient kernel's envelope; a bias and a combination bias present.
+// Requires (checked by the caller): ldb == B Ls, (ldb + W) % 4 == 0, f_in % 4 == 0, f_out % 4 == 0; a bias and a combination bias
+// present.  The one-pass dense-gradient kernel inside its envelope (f_in <= 128, ldb + W <= 192, f_out <= 128), the general
+// sequence outside it (round 6).
 std::vector<at::Tensor> train_backward(const at::Tensor& grad_out, const at::Tensor& x, const at::Tensor& wcat,
                                        const at::Tensor& bases, const at::Tensor& weightings, const at::Tensor& stats,
                                        const at::Tensor& cnt, const at::Tensor& arg_max, const at::Tensor& arg_min, int64_t graph,
@@ -207,8 +210,13 @@ std::vector<at::Tensor> train_backward(const at::Tensor& grad_out, const at::Ten
     check_status(egc_basis_transform_packed(d_cat.data_ptr<float>(), packed.data_ptr(), nullptr, n, (int32_t)k, (int32_t)f_in, 0,
                                             dx.data_ptr<float>(), (int32_t)f_in, nullptr, st), "egc_basis_transform_packed");
   }
-  // (3) x^T d_cat with the column sums of d_cat (combination bias) and of grad_out (the layer's bias) in one pass, written
-  // straight into the parameters' gradients through the pack's index map (egc_weight_grad_params_f32): no d wcat, no unpack
+  // (3) the dense gradients of the parameters.  Inside the one-pass kernel's envelope (f_in <= 128, ldb + W <= 192, f_out <= 128):
+  // x^T d_cat with the column sums of d_cat (combination bias) and of grad_out (the layer's bias) in one pass, written straight
+  // into the parameters' gradients through the pack's index map (egc_weight_grad_params_f32): no d wcat, no unpack.  Outside it
+  // (round 6: the reference's own batched nets -- 168 / 224 / 296 wide, run_pretrained.sh:7,12,23,24 -- and every other shape the
+  // library's GEMMs take): x^T d_cat + the column sums of d_cat (egc_weight_grad_ex_f32), the column sums of grad_out
+  // (egc_column_sums_f32 + egc_sum_partials_f32), and the pack's index map read backwards (egc_weights_pack_f32, grad = 1) --
+  // the calls egc_amd/functional.py's _layer_train_backward + _unpack_param_grads make, in their order.
   at::Tensor es = at::empty({f_out}, opts);
   at::Tensor dcw = at::empty(comb_w_shape, opts);
   at::Tensor dcb = packed_bias ? at::empty(comb_b_shape, opts) : at::empty({W}, opts);
@@ -219,13 +227,36 @@ std::vector<at::Tensor> train_backward(const at::Tensor& grad_out, const at::Ten
     dparts.push_back(at::empty(part_shape, opts));
     ptrs.push_back(dparts.back().data_ptr<float>());
   }
-  const int64_t gbytes = (int64_t)egc_weight_grad_ex_workspace_bytes(n, (int32_t)f_in, (int32_t)k, (int32_t)f_out);
-  at::Tensor gws = at::empty({std::max<int64_t>(gbytes, 16)}, opts.dtype(at::kByte));
-  check_status(egc_weight_grad_params_f32(x.data_ptr<float>(), f_in, d_cat.data_ptr<float>(), k, n, (int32_t)f_in, (int32_t)H,
-                                          (int32_t)A, (int32_t)B, (int32_t)L, (int32_t)Ls, permute_hab ? 1 : 0, ptrs.data(),
-                                          (int32_t)n_parts, dcw.data_ptr<float>(), packed_bias ? dcb.data_ptr<float>() : nullptr,
-                                          packed_bias ? nullptr : dcb.data_ptr<float>(), go.data_ptr<float>(), f_out, (int32_t)f_out,
-                                          es.data_ptr<float>(), gws.data_ptr(), gws.numel(), st), "egc_weight_grad_params_f32");
+  const bool one_pass = f_in <= 128 && k <= 192 && f_out <= 128 && (f_out % 4) == 0;
+  if (one_pass) {
+    const int64_t gbytes = (int64_t)egc_weight_grad_ex_workspace_bytes(n, (int32_t)f_in, (int32_t)k, (int32_t)f_out);
+    at::Tensor gws = at::empty({std::max<int64_t>(gbytes, 16)}, opts.dtype(at::kByte));
+    check_status(egc_weight_grad_params_f32(x.data_ptr<float>(), f_in, d_cat.data_ptr<float>(), k, n, (int32_t)f_in, (int32_t)H,
+                                            (int32_t)A, (int32_t)B, (int32_t)L, (int32_t)Ls, permute_hab ? 1 : 0, ptrs.data(),
+                                            (int32_t)n_parts, dcw.data_ptr<float>(), packed_bias ? dcb.data_ptr<float>() : nullptr,
+                                            packed_bias ? nullptr : dcb.data_ptr<float>(), go.data_ptr<float>(), f_out, (int32_t)f_out,
+                                            es.data_ptr<float>(), gws.data_ptr(), gws.numel(), st), "egc_weight_grad_params_f32");
+  } else {
+    at::Tensor dwcat = at::empty({f_in, k}, opts), cs = at::empty({k}, opts);
+    const int64_t gbytes = (int64_t)egc_weight_grad_ex_workspace_bytes(n, (int32_t)f_in, (int32_t)k, 0);
+    at::Tensor gws = at::empty({std::max<int64_t>(gbytes, 16)}, opts.dtype(at::kByte));
+    check_status(egc_weight_grad_ex_f32(x.data_ptr<float>(), f_in, d_cat.data_ptr<float>(), k, n, (int32_t)f_in, (int32_t)k,
+                                        dwcat.data_ptr<float>(), cs.data_ptr<float>(), nullptr, 0, 0, nullptr, gws.data_ptr(), gws.numel(),
+                                        st), "egc_weight_grad_ex_f32");
+    const int64_t parts = std::max<int64_t>(1, std::min<int64_t>(1024, (n + 127) / 128));
+    at::Tensor psum = at::empty({parts, f_out}, opts);
+    check_status(egc_column_sums_f32(go.data_ptr<float>(), n, (int32_t)f_out, (int32_t)f_out, psum.data_ptr<float>(), (int32_t)parts, st),
+                 "egc_column_sums_f32");
+    if (parts == 1) es = psum[0];
+    else check_status(egc_sum_partials_f32(psum.data_ptr<float>(), (int32_t)parts, (int32_t)f_out, es.data_ptr<float>(), st), "egc_sum_partials_f32");
+    // d bcat = the weightings part of d_cat's column sums: through the pack's row permutation for a module bias (EGConv), as it is
+    // for a bias already in the operand's order (EfficientGraphConv)
+    float* dbc = cs.data_ptr<float>() + (k - W);
+    check_status(egc_weights_pack_f32(ptrs.data(), (int32_t)n_parts, dcw.data_ptr<float>(), packed_bias ? dcb.data_ptr<float>() : nullptr,
+                                      (int32_t)f_in, (int32_t)H, (int32_t)A, (int32_t)B, (int32_t)L, (int32_t)Ls, permute_hab ? 1 : 0,
+                                      dwcat.data_ptr<float>(), packed_bias ? dbc : nullptr, 1, st), "egc_weights_pack_f32");
+    if (!packed_bias) dcb = cs.slice(0, k - W, k).contiguous();
+  }
   std::vector<at::Tensor> out{dx, dcw, dcb, es};
   out.insert(out.end(), dparts.begin(), dparts.end());
   return out;
@@ -435,6 +466,153 @@ static BlockStatic load_static(AutogradContext* ctx) {
   return s;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same block on the CSR path (round 6): x -> x + relu(bn(conv(x))) for layers and batches outside the one-launch training
+// envelope -- the reference's own batched nets (168 / 224 / 296 / 300 / 304 wide: run_pretrained.sh:7-48), full graphs -- as ONE
+// autograd node: train_forward (pack, planes, GEMM, training aggregate) + the BatchNorm tail forward; the tail's backward +
+// train_backward (sparse backward, d x GEMM, dense gradients into the parameters) + the residual branch's gradient backward.
+// The graph structs are COPIED into the node (their Python owners may be gone when the backward runs); `keep` holds the device
+// tensors they point into.
+// ---------------------------------------------------------------------------------------------------------------------
+struct CsrStatic {
+  egc_graph g, tg;
+  at::Tensor workspace, running_mean, running_var, n_tracked;
+  std::vector<at::Tensor> keep;
+  int64_t layer, stream, H, A, B, L, Ls, gemm_flags;
+  bool permute_hab;
+  double eps, momentum;
+  bool relu, residual, with_tail;
+};
+
+struct CsrBlockTrainFn : public torch::autograd::Function<CsrBlockTrainFn> {
+  static at::Tensor forward(AutogradContext* ctx, const at::Tensor& x, const c10::optional<at::Tensor>& bias, const at::Tensor& comb_w,
+                            const c10::optional<at::Tensor>& comb_b, const c10::optional<at::Tensor>& bcat_direct,
+                            const c10::optional<at::Tensor>& gamma, const c10::optional<at::Tensor>& beta, at::TensorList parts,
+                            const CsrStatic& s) {
+    const c10::OptionalDeviceGuard device_guard(x.device());
+    auto r = train_forward(x, comb_w, comb_b, bcat_direct, parts, bias, reinterpret_cast<int64_t>(&s.g), s.layer, s.workspace, s.stream,
+                           s.H, s.A, s.B, s.L, s.Ls, s.permute_hab, s.gemm_flags);
+    const at::Tensor& h = r[0];
+    const auto* l = reinterpret_cast<const egc_layer*>(s.layer);
+    auto st = reinterpret_cast<egc_stream_t>(s.stream);
+    const int64_t n = x.size(0), c = l->out_channels;
+    const auto opts = x.options();
+    ctx->saved_data["graphs"] = std::string(reinterpret_cast<const char*>(&s.g), sizeof(egc_graph)) +
+                                std::string(reinterpret_cast<const char*>(&s.tg), sizeof(egc_graph));
+    ctx->saved_data["keep"] = s.keep;
+    ctx->saved_data["ints"] = std::vector<int64_t>{s.layer, s.stream, s.H, s.A, s.B, s.L, s.Ls, s.permute_hab ? 1 : 0, s.relu ? 1 : 0,
+                                                  s.residual ? 1 : 0, s.with_tail ? 1 : 0, comb_b.has_value() ? 1 : 0,
+                                                  bias.has_value() ? 1 : 0, gamma.has_value() ? 1 : 0, beta.has_value() ? 1 : 0,
+                                                  (int64_t)parts.size()};
+    ctx->saved_data["comb_w_shape"] = comb_w.sizes().vec();
+    ctx->saved_data["comb_b_shape"] = comb_b.has_value() ? comb_b->sizes().vec() : std::vector<int64_t>{0};
+    ctx->saved_data["part_shape"] = parts[0].sizes().vec();
+    if (!s.with_tail) {
+      ctx->save_for_backward({x, r[1], r[3], r[4], r[5], r[6], r[7], r[8]});
+      return h;
+    }
+    const int64_t n_parts = std::max<int64_t>(1, std::min<int64_t>(1024, (n + 127) / 128));
+    at::Tensor partials = at::empty({n_parts, 2, c}, opts.dtype(at::kDouble)), stats = at::empty({3, c}, opts.dtype(at::kDouble));
+    at::Tensor affine = at::empty({2, c}, opts), out = at::empty({n, c}, opts);
+    at::Tensor gamma_c = gamma.has_value() ? gamma->detach() : at::Tensor();
+    if (gamma.has_value()) check_f32(*gamma, "BatchNorm weight");
+    if (beta.has_value()) check_f32(*beta, "BatchNorm bias");
+    const bool track = s.running_mean.defined();
+    int64_t* cnt = s.n_tracked.defined() ? s.n_tracked.data_ptr<int64_t>() : nullptr;
+    check_status(egc_bn_forward_stats_f32(h.data_ptr<float>(), n, (int32_t)c, partials.data_ptr<double>(), (int32_t)n_parts,
+                                          track ? cnt : nullptr, nullptr, fptr(gamma), fptr(beta), s.eps, stats.data_ptr<double>(),
+                                          affine.data_ptr<float>(), track ? s.running_mean.data_ptr<float>() : nullptr,
+                                          track ? s.running_var.data_ptr<float>() : nullptr, s.momentum, cnt, nullptr, st),
+                 "egc_bn_forward_stats_f32");
+    check_status(egc_affine_act_residual_f32(h.data_ptr<float>(), affine.data_ptr<float>(), affine.data_ptr<float>() + c,
+                                             s.residual ? x.data_ptr<float>() : nullptr, s.relu ? 1 : 0, nullptr, 1.0f, n, (int32_t)c,
+                                             out.data_ptr<float>(), nullptr, st), "egc_affine_act_residual_f32");
+    ctx->save_for_backward({x, r[1], r[3], r[4], r[5], r[6], r[7], r[8], h, affine, stats, gamma_c});
+    return out;
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    const auto saved = ctx->get_saved_variables();
+    const auto v = ctx->saved_data["ints"].toIntVector();
+    const int64_t layer = v[0], stream = v[1], H = v[2], A = v[3], B = v[4], L = v[5], Ls = v[6], n_parts_w = v[15];
+    const bool permute = v[7] != 0, relu = v[8] != 0, residual = v[9] != 0, with_tail = v[10] != 0, packed_bias = v[11] != 0;
+    const bool has_bias = v[12] != 0, has_gamma = v[13] != 0, has_beta = v[14] != 0;
+    variable_list out(8 + n_parts_w);            // x, bias, comb_w, comb_b, bcat_direct, gamma, beta, parts..., static
+    if (!grads[0].defined()) return out;
+    const std::string gs = ctx->saved_data["graphs"].toStringRef();
+    egc_graph g, tg;
+    std::memcpy(&g, gs.data(), sizeof(egc_graph));
+    std::memcpy(&tg, gs.data() + sizeof(egc_graph), sizeof(egc_graph));
+    const at::Tensor& x = saved[0];
+    const c10::OptionalDeviceGuard device_guard(x.device());
+    const auto opts = x.options();
+    auto st = reinterpret_cast<egc_stream_t>(stream);
+    const auto* l = reinterpret_cast<const egc_layer*>(layer);
+    const int64_t n = x.size(0), c = l->out_channels;
+    at::Tensor go = grads[0].contiguous();
+    check_f32(go, "grad_out");
+    at::Tensor g_conv = go;
+    if (with_tail) {
+      const at::Tensor &h = saved[8], &affine = saved[9], &stats = saved[10], &gamma_c = saved[11];
+      const int64_t n_parts = std::max<int64_t>(1, std::min<int64_t>(1024, (n + 127) / 128));
+      at::Tensor partials = at::empty({n_parts, 2, c}, opts.dtype(at::kDouble)), out5 = at::empty({5, c}, opts);
+      const float* a0 = affine.data_ptr<float>();
+      check_status(egc_bn_backward_stats_f32(go.data_ptr<float>(), h.data_ptr<float>(), a0, a0 + c, relu ? 1 : 0, nullptr, 1.0f, n, (int32_t)c,
+                                             partials.data_ptr<double>(), (int32_t)n_parts, nullptr, stats.data_ptr<double>(),
+                                             gamma_c.defined() ? gamma_c.data_ptr<float>() : nullptr, out5.data_ptr<float>(), nullptr, st),
+                   "egc_bn_backward_stats_f32");
+      at::Tensor dh = at::empty({n, c}, opts);
+      const float* o5 = out5.data_ptr<float>();
+      check_status(egc_affine_act_backward_f32(go.data_ptr<float>(), h.data_ptr<float>(), a0, a0 + c, relu ? 1 : 0, nullptr, 1.0f, o5 + 2 * c,
+                                               o5 + 3 * c, o5 + 4 * c, n, (int32_t)c, dh.data_ptr<float>(), nullptr, st),
+                   "egc_affine_act_backward_f32");
+      if (has_gamma) out[5] = out5[0];
+      if (has_beta) out[6] = out5[1];
+      g_conv = dh;
+    }
+    const auto cws = ctx->saved_data["comb_w_shape"].toIntVector(), cbs = ctx->saved_data["comb_b_shape"].toIntVector();
+    const auto ps = ctx->saved_data["part_shape"].toIntVector();
+    auto r = train_backward(g_conv, x, saved[1], saved[2], saved[3], saved[4], saved[5], saved[6], saved[7], reinterpret_cast<int64_t>(&g),
+                            reinterpret_cast<int64_t>(&tg), layer, stream, H, A, B, L, Ls, permute, packed_bias, true, cws, cbs, n_parts_w, ps);
+    at::Tensor dx = r[0];
+    if (with_tail && residual) dx.add_(go);       // the residual branch's gradient (x = x + ...): autograd's own add, in place
+    out[0] = dx;
+    if (has_bias) out[1] = r[3];
+    out[2] = r[1];
+    if (packed_bias) out[3] = r[2]; else out[4] = r[2];
+    for (int64_t i = 0; i < n_parts_w; ++i) out[7 + i] = r[4 + i];
+    return out;
+  }
+};
+
+at::Tensor csr_block_train(const at::Tensor& x, const c10::optional<at::Tensor>& bias, const at::Tensor& comb_w,
+                           const c10::optional<at::Tensor>& comb_b, const c10::optional<at::Tensor>& bcat_direct,
+                           const c10::optional<at::Tensor>& gamma, const c10::optional<at::Tensor>& beta, at::TensorList parts,
+                           const c10::optional<at::Tensor>& running_mean, const c10::optional<at::Tensor>& running_var,
+                           const c10::optional<at::Tensor>& n_tracked, int64_t graph, int64_t t_graph, at::TensorList keep,
+                           const at::Tensor& workspace, int64_t layer, int64_t stream, at::IntArrayRef dims, bool permute_hab,
+                           int64_t gemm_flags, double eps, double momentum, bool relu, bool residual, bool with_tail) {
+  TORCH_CHECK(dims.size() == 5, "egc_amd: dims = (H, A, B, L, Ls)");
+  TORCH_CHECK(parts.size() >= 1, "egc_amd: at least one basis matrix");
+  CsrStatic s;
+  s.g = *reinterpret_cast<const egc_graph*>(graph);
+  s.tg = *reinterpret_cast<const egc_graph*>(t_graph);
+  s.keep = keep.vec();
+  s.workspace = workspace;
+  if (running_mean.has_value()) {
+    TORCH_CHECK(running_var.has_value(), "egc_amd: running_mean and running_var come together");
+    check_f32(*running_mean, "running_mean"); check_f32(*running_var, "running_var");
+    s.running_mean = *running_mean; s.running_var = *running_var;
+  }
+  if (n_tracked.has_value()) { TORCH_CHECK(n_tracked->is_cuda() && n_tracked->scalar_type() == at::kLong && n_tracked->numel() == 1, "egc_amd: num_batches_tracked"); s.n_tracked = *n_tracked; }
+  TORCH_CHECK(momentum >= 0 || !s.running_mean.defined() || s.n_tracked.defined(), "egc_amd: a cumulative average needs num_batches_tracked");
+  s.layer = layer; s.stream = stream;
+  s.H = dims[0]; s.A = dims[1]; s.B = dims[2]; s.L = dims[3]; s.Ls = dims[4];
+  s.gemm_flags = gemm_flags; s.permute_hab = permute_hab;
+  s.eps = eps; s.momentum = momentum; s.relu = relu; s.residual = residual; s.with_tail = with_tail;
+  return CsrBlockTrainFn::apply(x, bias, comb_w, comb_b, bcat_direct, gamma, beta, parts, s);
+}
+
 at::Tensor batch_block_train(const at::Tensor& x, const c10::optional<at::Tensor>& bias, const at::Tensor& comb_w,
                              const c10::optional<at::Tensor>& comb_b, const c10::optional<at::Tensor>& bcat_direct,
                              const c10::optional<at::Tensor>& gamma, const c10::optional<at::Tensor>& beta, at::TensorList parts,
@@ -487,6 +665,10 @@ TORCH_LIBRARY(egc_amd_native, m) {
         "Tensor[] parts, Tensor(a!)? running_mean, Tensor(b!)? running_var, Tensor(c!)? n_tracked, Tensor ptr, Tensor? edge_ptr, Tensor src, "
         "Tensor dst, Tensor? max_index, Tensor status, int host_flag, int layer, int stream, int[] dims, bool permute_hab, int[] setups, "
         "float eps, float momentum, bool relu, bool residual, bool with_tail) -> Tensor");
+  m.def("csr_block_train(Tensor x, Tensor? bias, Tensor comb_w, Tensor? comb_b, Tensor? bcat_direct, Tensor? gamma, Tensor? beta, "
+        "Tensor[] parts, Tensor(a!)? running_mean, Tensor(b!)? running_var, Tensor(c!)? n_tracked, int graph, int t_graph, Tensor[] keep, "
+        "Tensor workspace, int layer, int stream, int[] dims, bool permute_hab, int gemm_flags, float eps, float momentum, bool relu, "
+        "bool residual, bool with_tail) -> Tensor");
 }
 
 // HIP devices only (PyTorch-ROCm dispatches them under the CUDA key): a CPU tensor finds no kernel and the dispatcher raises
@@ -501,4 +683,5 @@ TORCH_LIBRARY_IMPL(egc_amd_native, CUDA, m) {
 // with parameters that require gradients enters; the node's forward issues the library's launches itself (no dispatcher re-entry)
 TORCH_LIBRARY_IMPL(egc_amd_native, Autograd, m) {
   m.impl("batch_block_train", &batch_block_train);
+  m.impl("csr_block_train", &csr_block_train);
 }

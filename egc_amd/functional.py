@@ -673,9 +673,15 @@ def _native_train_ops(graph, spec, x, bias, comb_w, comb_b, bcat_direct, bases):
     if bias is None or cb is None or (comb_b is not None and bcat_direct is not None):
         return None
     k = spec.ldb + spec.w_cols
-    if not (spec.ldb == spec.f_g and k % 4 == 0 and k <= 192 and spec.f_in % 4 == 0 and spec.f_in <= 128
-            and spec.f_out % 4 == 0 and spec.f_out <= 128):
+    if not (spec.ldb == spec.f_g and k % 4 == 0 and spec.f_in % 4 == 0 and spec.f_out % 4 == 0):
         return None
+    if not (k <= 192 and spec.f_in <= 128 and spec.f_out <= 128):
+        # outside the one-pass dense-gradient kernel: the general sequence (round 6: the reference's own 168 / 224 / 296-wide
+        # batched nets), where the split GEMMs take the shape and x^T d stays on the library's own kernel (long reductions of
+        # wide outputs go to rocBLAS on the Python path: _weight_grads)
+        if (k > 384 or spec.f_in > 384 or spec.f_out > 1024 or x.size(0) > 65536 or x.data_ptr() % 16
+                or int(_C.load().egc_basis_pack_bytes(k, spec.f_in, 0)) <= 0):
+            return None
     for t in (bias, comb_w, cb, *bases):
         if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
             return None
@@ -736,6 +742,47 @@ def native_block_train(call, bn=None, relu=True, residual=True, with_tail=True):
                                  _stream_ptr(x.device), (int(f_in), int(H), int(A), int(B), int(L), int(Ls)), bool(permute),
                                  (setups[0][0], setups[0][1], setups[1][0], setups[1][1]), eps, momentum, bool(relu), bool(residual),
                                  bool(with_tail))
+
+
+def native_csr_block_train(call, bn, relu=True, residual=True):
+    """The block x -> x + relu(bn(conv(x))) in training on the CSR path -- layers and batches outside the one-launch training
+    envelope: the reference's own 168 - 304-wide batched nets, full graphs -- as ONE autograd node of the compiled binding
+    (egc_torch_ext.cpp: csr_block_train = train_forward + the BatchNorm tail / its backward + train_backward + the residual
+    gradient), or None outside its envelope (the Python Functions then, same kernels).  ``call``: as for native_block_train; a
+    GraphBatch is taken through its CSR."""
+    graph, spec, x, bias, comb_w, comb_b, bcat_direct, bases, f_in, H, A, B, L, Ls, permute = call
+    if _C.env_flag("EGC_NO_NATIVE_TRAIN") or not torch.is_grad_enabled():
+        return None
+    if isinstance(graph, GraphBatch):
+        if graph.n_nodes is None:
+            graph.n_nodes = int(x.size(0))
+        if graph.n_nodes != x.size(0):
+            return None
+        graph = graph.csr()
+    if not isinstance(graph, CSRGraph) or x.device != graph.device or x.size(0) != graph.n_nodes or x.size(0) < 2:
+        return None
+    nat = _native_train_ops(graph, spec, x, bias, comb_w, comb_b, bcat_direct, bases)
+    if nat is None or not hasattr(nat, "csr_block_train"):
+        return None
+    cb = comb_b if comb_b is not None else bcat_direct
+    if any(not t.requires_grad for t in (bias, comb_w, cb, *bases)):
+        return None
+    if not (relu and bn.training and bn.affine and spec.f_out % 4 == 0 and spec.f_out <= 1024):
+        return None
+    gamma, beta = bn.weight, bn.bias
+    if any(not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()) for t in (gamma, beta)):
+        return None
+    rm = rv = nt = None
+    if bn.track_running_stats:
+        rm, rv, nt = bn.running_mean, bn.running_var, bn.num_batches_tracked
+        if not (_f32_vec(rm, spec.f_out) and _f32_vec(rv, spec.f_out) and rm.is_cuda and nt is not None and nt.dtype == torch.int64
+                and nt.is_cuda):
+            return None
+    tg = graph.transposed()
+    return nat.csr_block_train(x, bias, comb_w, comb_b, bcat_direct, gamma, beta, list(bases), rm, rv, nt, graph.c_addr(), tg.c_addr(),
+                               graph.tensors() + tg.tensors(), graph.workspace_for(spec), spec.c_addr, _stream_ptr(x.device),
+                               (int(H), int(A), int(B), int(L), int(Ls)), bool(permute), spec.gemm_flags, float(bn.eps),
+                               -1.0 if bn.momentum is None else float(bn.momentum), True, bool(residual), True)
 
 
 def _layer_forward_one_call(graph: CSRGraph, spec: LayerSpec, x, packed, bcat, bias):

@@ -17,7 +17,7 @@ import torch
 from . import _C
 import torch.nn as nn
 
-from .functional import (PostOp, ResidualLink, native_block_train, batch_norm_act_residual, batch_norm_act_residual_supported, egc_layer_forward,
+from .functional import (PostOp, ResidualLink, native_block_train, native_csr_block_train, batch_norm_act_residual, batch_norm_act_residual_supported, egc_layer_forward,
                          segment_mean)
 from .graph import GraphBatch, graph_from_input
 
@@ -63,12 +63,14 @@ class FusedEGCBlock(nn.Module):
         # A GraphBatch in training: the whole block as ONE autograd node of the compiled binding (csrc_ext: batch_block_train --
         # the launches of the path below issued from C++, the residual branch's gradient handed to the conv's backward launch
         # inside the node), when the call is inside its envelope; else the Python Functions below, same kernels.
-        if (isinstance(edge_index, GraphBatch) and identity is None and n_valid is None and not self._dropping() and self.relu
+        if (identity is None and n_valid is None and not self._dropping() and self.relu
                 and bn.training and hasattr(self.conv, "_train_call") and torch.is_grad_enabled()
                 and not (self.residual and _C.env_flag("EGC_NO_RESIDUAL_LINK"))):
             call = self.conv._train_call(x, edge_index)
             if call is not None:
                 out = native_block_train(call, bn, relu=True, residual=bool(self.residual), with_tail=True)
+                if out is None:      # outside the one-launch envelope (the reference's wide nets, full graphs): the CSR path's node
+                    out = native_csr_block_train(call, bn, relu=True, residual=bool(self.residual))
                 if out is not None:
                     return out
         # the residual branch's gradient may join d x inside the conv's backward launch (functional.ResidualLink): offered when

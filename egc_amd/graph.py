@@ -335,6 +335,11 @@ class CSRGraph:
                            self.edge_dis_raw.data_ptr() if self.edge_dis_raw is not None else None,
                            self.edge_dis_looped.data_ptr() if self.edge_dis_looped is not None else None)
 
+    def tensors(self) -> list:
+        """The device tensors the C view points into (what a compiled autograd node keeps alive next to its copy of the struct)."""
+        ts = [self.rowptr, self.col, self.edge_id, self.dis_raw, self.dis_looped, self.max_index, self.plan]
+        return ts + [t for t in (self.edge_dis_raw, self.edge_dis_looped) if t is not None]
+
     def c_addr(self) -> int:
         """Address of a C view of this graph that stays valid (and current) while the graph lives: what the compiled
         binding takes (egc_amd/_native.py).  Rebuilt when something the struct carries has changed."""

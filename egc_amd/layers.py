@@ -142,12 +142,21 @@ class EfficientGraphConv(nn.Module):
     def _train_call(self, x, edge_index):
         """The arguments of functional.egc_layer_apply_params for a training call on a GraphBatch, or None (see EGConv._train_call)."""
         w = self.comb_weights.weight
-        if (self.cache or not isinstance(edge_index, GraphBatch) or not (w.is_cuda and w.dtype == torch.float32 and self.num_bases <= 32
-                                                                         and x.is_cuda) or ops.use_torch_op()):
+        if not (w.is_cuda and w.dtype == torch.float32 and self.num_bases <= 32 and x.is_cuda) or ops.use_torch_op():
             return None
+        if _is_adj_t(edge_index) and any(a.aggr_fun in ("var", "std") for a in self.aggs):
+            return None              # (forward() raises NotImplementedError for it, as layers.py:221-224 does)
+        if self.cache and self._cached_graph is not None:
+            graph = self._cached_graph
+        elif isinstance(edge_index, GraphBatch):
+            graph = edge_index
+        else:
+            if self.cache:
+                return None          # (forward() builds and caches the graph first)
+            graph = graph_from_input(edge_index, x.size(0))
         sp = self._spec
         A = w.size(0) // (self.num_heads * self.num_bases)
-        return (edge_index, sp, x, self.bias, w, None, self.comb_weights.bias, list(self.bases_weight._parameters.values()),
+        return (graph, sp, x, self.bias, w, None, self.comb_weights.bias, list(self.bases_weight._parameters.values()),
                 self.in_channels, self.num_heads, A, self.num_bases, sp.basis_len, sp.basis_stride, False)
 
     def forward(self, x, edge_index):

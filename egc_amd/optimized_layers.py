@@ -123,14 +123,21 @@ class EGConv(nn.Module):
         return self._planes
 
     def _train_call(self, x, edge_index):
-        """The arguments of functional.egc_layer_apply_params for a training call on a GraphBatch, or None (what forward() below
-        passes on that path; egc_amd.FusedEGCBlock hands them to the compiled binding's block node)."""
+        """The arguments of functional.egc_layer_apply_params for a training call, or None (what forward() below passes on its
+        training path; egc_amd.FusedEGCBlock hands them to the compiled binding's block nodes)."""
         bw, cw, cb = self.bases_weight, self.comb_weight.weight, self.comb_weight.bias
-        if (self.cached or not isinstance(edge_index, GraphBatch) or not (bw.is_cuda and bw.dtype == torch.float32 and cb is not None
-                                                                          and x.is_cuda) or ops.use_torch_op()):
+        if not (bw.is_cuda and bw.dtype == torch.float32 and cb is not None and x.is_cuda) or ops.use_torch_op():
             return None
-        spec = self._spec_coo
-        return (edge_index, spec, x, self.bias, cw, cb, None, [bw], self.in_channels, self.num_heads, len(self.aggregators),
+        if self.cached and self._cached_graph is not None:
+            graph, spec = self._cached_graph
+        elif isinstance(edge_index, GraphBatch):
+            graph, spec = edge_index, self._spec_coo
+        else:
+            if self.cached:
+                return None          # (forward() builds and caches the graph first)
+            graph = graph_from_input(edge_index, x.size(self.node_dim))
+            spec = self._spec_coo if (isinstance(edge_index, torch.Tensor) and edge_index.layout == torch.strided) else self._spec_adj
+        return (graph, spec, x, self.bias, cw, cb, None, [bw], self.in_channels, self.num_heads, len(self.aggregators),
                 self.num_bases, spec.basis_len, spec.basis_stride, True)
 
     def forward(self, x, edge_index):

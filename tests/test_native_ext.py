@@ -131,3 +131,76 @@ def test_batch_conv_train_node_outside_a_block(monkeypatch):
     assert torch.equal(res["native"][0], res["python"][0]) and torch.equal(res["native"][1], res["python"][1])
     for a, b in zip(res["native"][2], res["python"][2]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hidden,H,B,aggrs", [(168, 8, 4, ["symadd"]), (224, 4, 4, ["add", "mean", "max"]), (296, 8, 4, ["symadd"]),
+                                             (300, 4, 4, ["symadd", "min", "max"]), (128, 8, 4, ["symadd", "max", "mean"])])
+def test_csr_path_training_through_the_binding_at_the_reference_widths(hidden, H, B, aggrs, monkeypatch):
+    """The reference's own batched nets (run_pretrained.sh:7,12,23,24,48: 168 / 224 / 296 / 300 wide EfficientGraphConv layers) train on the
+    CSR path; since round 6 its compiled calls (csrc_ext: train_forward / train_backward) take those shapes too -- the dense
+    gradients through the general sequence instead of the one-pass kernel.  Same library calls in the same order as the Python
+    path (EGC_NO_NATIVE_TRAIN=1): outputs and every gradient bit for bit."""
+    from egc_amd import functional as F
+    from test_batch_tile_gpu import _messy_batch
+    dev = torch.device("cuda:0")
+    ei, n, ptr = _messy_batch(hidden, n_graphs=120, max_size=60)
+    torch.manual_seed(hidden)
+    conv = egc_amd.EfficientGraphConv(hidden, hidden, H, B, False, aggrs=aggrs).to(dev).train()
+    x0, go = torch.randn(n, hidden, device=dev), torch.randn(n, hidden, device=dev)
+    seen = []
+    real = F._native_train_ops
+    monkeypatch.setattr(F, "_native_train_ops", lambda *a, **k: (seen.append(real(*a, **k) is not None), real(*a, **k))[1])
+    res = {}
+    for mode in ("native", "python"):
+        if mode == "python":
+            monkeypatch.setenv("EGC_NO_NATIVE_TRAIN", "1")
+        conv.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        out = conv(x=x, edge_index=ei.to(dev))
+        out.backward(go)
+        res[mode] = (out.detach().clone(), x.grad.clone(), [p.grad.clone() for p in conv.parameters()])
+    assert seen == [True, False], seen
+    assert torch.equal(res["native"][0], res["python"][0]) and torch.equal(res["native"][1], res["python"][1])
+    for a, b in zip(res["native"][2], res["python"][2]):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hidden,H,B,aggrs,as_batch", [(168, 8, 4, ["symadd"], True), (224, 4, 4, ["add", "mean", "max"], True),
+                                                      (296, 8, 4, ["symadd"], False), (128, 8, 4, ["symadd", "max", "mean"], False)])
+def test_csr_block_train_node_equals_the_python_functions(hidden, H, B, aggrs, as_batch, monkeypatch):
+    """x -> x + relu(bn(conv(x))) in training OUTSIDE the one-launch envelope (the reference's wide batched nets handed over as a
+    GraphBatch; a plain edge_index at any width) as ONE autograd node of the compiled binding (csr_block_train) against the Python
+    Functions: outputs, every gradient and BatchNorm's running statistics bit for bit, over two steps."""
+    from test_batch_tile_gpu import _messy_batch
+    dev = torch.device("cuda:0")
+    ei, n, ptr = _messy_batch(hidden + 1, n_graphs=150, max_size=60)
+    x0, go = torch.randn(n, hidden), torch.randn(n, hidden)
+
+    def build():
+        torch.manual_seed(11)
+        return torch.nn.ModuleList([egc_amd.FusedEGCBlock(egc_amd.EfficientGraphConv(hidden, hidden, H, B, False, aggrs=aggrs),
+                                                          torch.nn.BatchNorm1d(hidden)) for _ in range(2)]).to(dev).train()
+    res = {}
+    for mode in ("native", "python"):
+        if mode == "python":
+            monkeypatch.setenv("EGC_NO_NATIVE_TRAIN", "1")
+        blocks = build()
+        for step in range(2):
+            for p in blocks.parameters():
+                p.grad = None
+            x = x0.to(dev).requires_grad_(True)
+            g = egc_amd.GraphBatch(ei.to(dev), ptr=ptr.to(dev), max_nodes=60) if as_batch else ei.to(dev)
+            h = x
+            for b in blocks:
+                h = b(h, g)
+            h.backward(go.to(dev))
+        res[mode] = (h.detach().clone(), x.grad.clone(), [p.grad.clone() for p in blocks.parameters()],
+                     [b.clone() for b in blocks.buffers() if b.dtype != torch.int32], h.grad_fn.name())
+    assert "CsrBlockTrainFn" in res["native"][4] and "BlockTrainFn" not in res["python"][4], (res["native"][4], res["python"][4])
+    assert torch.equal(res["native"][0], res["python"][0]) and torch.equal(res["native"][1], res["python"][1])
+    for a, b in zip(res["native"][2], res["python"][2]):
+        assert torch.equal(a, b)
+    for a, b in zip(res["native"][3], res["python"][3]):
+        assert torch.equal(a, b)

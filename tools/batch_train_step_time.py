@@ -3,7 +3,8 @@ ZINC-shaped batch of 128 and a molhiv-shaped batch of 2048 graphs, with the laye
 build + GEMM + aggregate, three backward kernels + dense gradients) and (b) an egc_amd.GraphBatch (one launch each way:
 egc_layer_forward_batch_fused_f32 / egc_layer_backward_batch_fused_f32); eager and as ONE hipGraph.  EGC_SMALL_ONLY=zinc|molhiv.
 EGC_STEP_SHAPE="hidden,H,B,aggr+aggr+...,self_loops" runs the blocks at another layer shape, e.g. the reference's own molhiv net
-"224,4,4,sum+mean+max,0" (run_pretrained.sh:24) or "296,8,4,symnorm,1" (:23)."""
+"224,4,4,sum+mean+max,0" (run_pretrained.sh:24) or "296,8,4,symnorm,1" (:23); a sixth field "lay" builds experiments/layers.py's EfficientGraphConv instead of EGConv:
+"224,4,4,add+mean+max,1,lay" is the reference's molhiv EGC-M layer as its net constructs it."""
 import os, sys, time
 import torch, torch.nn as nn
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,6 +14,13 @@ dev = torch.device("cuda:0")
 only = os.environ.get("EGC_SMALL_ONLY", "")
 shape = os.environ.get("EGC_STEP_SHAPE", "128,8,4,sum+mean+max+symnorm,1").split(",")
 HID, HEADS, BASES, AGGRS, LOOPS = int(shape[0]), int(shape[1]), int(shape[2]), shape[3].split("+"), shape[4] != "0"
+KIND = shape[5] if len(shape) > 5 else "opt"      # "lay": experiments/layers.py's EfficientGraphConv (aggregator names add / symadd / ...), as the reference's batched nets use it
+
+
+def make_conv():
+    if KIND == "lay":
+        return egc_amd.EfficientGraphConv(HID, HID, HEADS, BASES, False, aggrs=AGGRS, add_self_loops=LOOPS)
+    return egc_amd.EGConv(HID, HID, aggrs=AGGRS, num_heads=HEADS, num_bases=BASES, add_self_loops=LOOPS)
 for name, gen, G in (("zinc b128", lambda: wl.zinc_like_batch(128, seed=0)[1:], 128), ("molhiv b2048", lambda: wl.molecule_batch(2048, seed=0), 2048)):
     if only and only not in name:
         continue
@@ -22,7 +30,7 @@ for name, gen, G in (("zinc b128", lambda: wl.zinc_like_batch(128, seed=0)[1:], 
     mx = int(sizes.max())
     ptr = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(sizes, 0)])
     torch.manual_seed(0)
-    blocks = nn.ModuleList([egc_amd.FusedEGCBlock(egc_amd.EGConv(HID, HID, aggrs=AGGRS, num_heads=HEADS, num_bases=BASES, add_self_loops=LOOPS),
+    blocks = nn.ModuleList([egc_amd.FusedEGCBlock(make_conv(),
                                                   nn.BatchNorm1d(HID)) for _ in range(4)]).to(dev).train()
     params = list(blocks.parameters())
     x = torch.randn(n, HID, device=dev)

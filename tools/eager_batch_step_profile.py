@@ -13,10 +13,16 @@ sizes = torch.bincount(batch, minlength=128)
 ptr = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(sizes, 0)])
 mx = int(sizes.max())
 torch.manual_seed(0)
-blocks = nn.ModuleList([FusedEGCBlock(egc_amd.EGConv(128, 128, aggrs=["sum", "mean", "max", "symnorm"], num_heads=8, num_bases=4),
-                                      nn.BatchNorm1d(128)) for _ in range(4)]).to(dev).train()
-x = torch.randn(n, 128, device=dev).requires_grad_(True)
-gout = torch.randn(n, 128, device=dev)
+# EGC_STEP_SHAPE="hidden,H,B,aggr+aggr,self_loops[,lay]": another layer shape, e.g. the reference's ZINC EGC-S layer "168,8,4,symadd,1,lay"
+shape = os.environ.get("EGC_STEP_SHAPE", "128,8,4,sum+mean+max+symnorm,1").split(",")
+HID, HEADS, BASES, AGGRS, LOOPS = int(shape[0]), int(shape[1]), int(shape[2]), shape[3].split("+"), shape[4] != "0"
+def make_conv():
+    if len(shape) > 5 and shape[5] == "lay":
+        return egc_amd.EfficientGraphConv(HID, HID, HEADS, BASES, False, aggrs=AGGRS, add_self_loops=LOOPS)
+    return egc_amd.EGConv(HID, HID, aggrs=AGGRS, num_heads=HEADS, num_bases=BASES, add_self_loops=LOOPS)
+blocks = nn.ModuleList([FusedEGCBlock(make_conv(), nn.BatchNorm1d(HID)) for _ in range(4)]).to(dev).train()
+x = torch.randn(n, HID, device=dev).requires_grad_(True)
+gout = torch.randn(n, HID, device=dev)
 params = list(blocks.parameters())
 def step():
     for p in params: p.grad = None
