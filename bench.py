@@ -230,7 +230,7 @@ def _side_record(rec):
     record (every path's timings, byte models, its own cpu_baseline sample text) is in the detail file."""
     if not isinstance(rec, dict):
         return _short(rec, 120)
-    out = {"workload": _short(rec.get("workload", ""), 96)}
+    out = {"workload": _short(rec.get("workload", ""), 72)}
     for k in ("layer_ms", "step_ms", "eager_step_ms", "hipgraph_replay_ms", "eager_ms", "coo_hipgraph_replay_ms", "csr_path_step_ms",
               "speedup_vs_csr_path"):
         if k in rec:
@@ -535,6 +535,13 @@ def _oc_layer_configs(out, dev, seed):
     out["config4_cifar_b2048"] = measure_layer_config(
         "CIFAR10-superpixel-shaped batch of 2048 8-NN graphs, EGC-M d=128 H=8 B=4 sum+mean+max+symnorm", ei, n, ns(),
         F_IN, dev, True, batch=batch, max_nodes=150, traffic_key="config4_cifar_b2048")
+    # the reference's ogbg-code EGC-S layer on a code-SHAPED batch (run_pretrained.sh:47; egc_amd.workloads.code_like_batch: ASTs of ~125
+    # nodes, up to 250): no LDS tile of a CU holds a 250-node graph's 1,280-byte `bases` rows, so this is the CSR path with its
+    # per-batch graph build
+    ei, n, batch = wl.code_like_batch(128, seed=seed)
+    out["code_b128_ref304"] = measure_layer_config(
+        "ogbg-code2-shaped batch of 128 ASTs, the reference's code EGC-S layer d=304 H=8 B=8 symadd (CSR path: per-batch graph build)", ei, n,
+        egc_amd.EGConv(304, 304, aggrs=["symnorm"], num_heads=8, num_bases=8), 304, dev, True)
     ei, n = wl.mag_like(seed=seed)
     out["config5_mag_homogeneous_1gpu"] = measure_layer_config(
         "ogbn-mag-shaped homogeneous graph (mag/configs.py:73-88), EGConv 352->352 H=8 B=4 symnorm (mag/models.py:23-53)",
@@ -604,13 +611,18 @@ def _oc_small_batches(out, dev, seed):
     ns = _north_star_layer
     # the batch sizes the reference actually trains at (zinc/configs.py: 128 graphs per batch): a few thousand nodes,
     # where the step is bound by what launches the kernels -- eager against the whole step replayed as one hipGraph
-    for key, (ei, n, bvec), label in (("zinc_b128_training_step", wl.zinc_like_batch(128, seed=seed)[1:], "ZINC-shaped batch of 128 molecules"),
-                                      ("molhiv_b2048_training_step", wl.molecule_batch(2048, seed=seed), "molhiv-shaped batch of 2048 molecules")):
+    def ref168():     # the reference's ZINC EGC-S layer as its net constructs it (zinc/models.py:125-135, run_pretrained.sh:7)
+        return egc_amd.EfficientGraphConv(168, 168, 8, 4, False, aggrs=["symadd"])
+    for key, (ei, n, bvec), label, make, width in (
+            ("zinc_b128_training_step", wl.zinc_like_batch(128, seed=seed)[1:], "ZINC-shaped batch of 128 molecules", ns, F_IN),
+            ("molhiv_b2048_training_step", wl.molecule_batch(2048, seed=seed), "molhiv-shaped batch of 2048 molecules", ns, F_IN),
+            ("zinc_b128_ref168_training_step", wl.zinc_like_batch(128, seed=seed)[1:],
+             "ZINC-shaped batch of 128 molecules, the reference's own EGC-S net width (EfficientGraphConv 168 / H8 / B4 symadd: CSR path)", ref168, 168)):
         torch.manual_seed(seed)
-        blocks = torch.nn.ModuleList([egc_amd.FusedEGCBlock(ns(), torch.nn.BatchNorm1d(F_OUT)) for _ in range(4)]).to(dev).train()
+        blocks = torch.nn.ModuleList([egc_amd.FusedEGCBlock(make(), torch.nn.BatchNorm1d(width)) for _ in range(4)]).to(dev).train()
         params = list(blocks.parameters())
         ei = ei.to(dev)
-        xs, gos = torch.randn(n, F_IN, device=dev), torch.randn(n, F_OUT, device=dev)
+        xs, gos = torch.randn(n, width, device=dev), torch.randn(n, width, device=dev)
         # what a PyG batch carries besides edge_index: the graphs' node offsets (Batch.ptr); with them the layer runs as one
         # launch each way (egc_layer_forward_batch_fused_f32 / egc_layer_backward_batch_fused_f32), no graph build at all
         sizes = torch.bincount(bvec.to(dev))
