@@ -38,18 +38,19 @@ def _sequential_sum(x, src, dst, n):
     return out
 
 
-@pytest.mark.parametrize("workload,deg", [("molecules", 3), ("dense", 24), ("one wavefront's span", 2), ("beyond the registers", 90)])
-def test_row_sums_follow_the_edge_order_bit_for_bit(workload, deg):
+@pytest.mark.parametrize("workload,deg,f", [("molecules", 3, 64), ("dense", 24, 64), ("one wavefront's span", 2, 64), ("beyond the registers", 90, 64),
+                                            ("WIDE form, two k-slabs", 5, 168), ("WIDE form beyond the registers", 40, 168),
+                                            ("WIDE form, three k-slabs", 7, 296)])
+def test_row_sums_follow_the_edge_order_bit_for_bit(workload, deg, f):
     import egc_amd
     dev = _dev()
-    rng = np.random.default_rng(11 + deg)
-    f = 64
+    rng = np.random.default_rng(11 + deg + f)
     # graphs of 20 .. 60 nodes; `deg` random in-edges per node in random ORDER (a destination's edges are scattered over the
     # graph's edge range, as a collated batch has them: sorted by graph, not by destination); duplicates and self loops included
-    n_graphs = 40 if deg < 90 else 12
+    n_graphs = 40 if deg < 40 else 12
     sizes = rng.integers(20, 61, size=n_graphs)
-    if deg == 90:
-        sizes = rng.integers(100, 150, size=n_graphs)          # tiles of > 8 x 192 edges: the streamed rounds of the build
+    if deg >= 40:
+        sizes = rng.integers(100, 150, size=n_graphs) if f == 64 else rng.integers(60, 90, size=n_graphs)   # tiles of > 8 x 192 edges: the streamed rounds of the build
     ptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     src, dst = [], []
     for g in range(n_graphs):
