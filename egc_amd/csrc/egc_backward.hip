@@ -590,8 +590,11 @@ struct BwdAggs {
   static __device__ inline int act(const BwdArgs& a) { return fixed ? (int)EGC_ACT_NONE : a.act; }
 };
 
+#ifndef EGC_BWD_DST_MINW
+#define EGC_BWD_DST_MINW 1     // wavefronts per SIMD the register allocation must leave room for (tuning constant)
+#endif
 template <int LPR_LOG2, int HT, int AT, unsigned AGG = 0>
-__global__ void __launch_bounds__(256) bwd_dst_fast_kernel(BwdArgs a) {
+__global__ void __launch_bounds__(256, EGC_BWD_DST_MINW) bwd_dst_fast_kernel(BwdArgs a) {
   using AG = BwdAggs<AGG, AT>;
   extern __shared__ float smem[];
   constexpr int LPR = 1 << LPR_LOG2, G = 64 / LPR;
@@ -1325,7 +1328,18 @@ int egc_aggregate_combine_backward_f32(const egc_graph* graph, const egc_graph* 
       unsigned packed = BWD_STATIC;
       for (int t = 0; t < a.A; ++t) packed |= (unsigned)a.aggr[t] << (3 * t);
       constexpr int S = EGC_AGGR_SUM, M = EGC_AGGR_MEAN, X = EGC_AGGR_MAX, Y = EGC_AGGR_SYMNORM;
-      if (a.slots > 32 && a.H == 4) bwd_dst_fast_kernel<6, 4, 3><<<fgrid, 256, flds, stream>>>(a);
+      // the reference's own batched nets with their aggregator lists compiled in (round 6: these layers train on this path --
+      // DESIGN.md section 3.7 -- and the run-time form's per-aggregator switches are most of its instructions): molhiv EGC-M
+      // 224 / H4 / B4 add, mean, max; molhiv EGC-S 296 / H8 / B4 and zinc / cifar EGC-S 168 / H8 / B4 symadd
+      const bool plain = a.act == EGC_ACT_NONE;
+      if (a.slots > 32 && a.H == 4 && plain && packed == bwd_agg_pack(S, M, X)) bwd_dst_fast_kernel<6, 4, 3, bwd_agg_pack(S, M, X)><<<fgrid, 256, flds, stream>>>(a);
+      else if (a.slots > 32 && a.H == 8 && plain && packed == bwd_agg_pack(Y)) bwd_dst_fast_kernel<6, 8, 1, bwd_agg_pack(Y)><<<fgrid, 256, flds, stream>>>(a);
+      else if (a.slots > 16 && a.slots <= 32 && a.H == 8 && plain && packed == bwd_agg_pack(Y)) bwd_dst_fast_kernel<5, 8, 1, bwd_agg_pack(Y)><<<fgrid, 256, flds, stream>>>(a);
+      // arxiv EGC-M 136 / H4 / B4 symadd, max, mean (36 slots); zinc EGC-M 124 / H4 / B4 add, std, max and cifar EGC-M 128 / H4 / B4 symadd, std, max (32)
+      else if (a.slots > 32 && a.H == 4 && plain && packed == bwd_agg_pack(Y, X, M)) bwd_dst_fast_kernel<6, 4, 3, bwd_agg_pack(Y, X, M)><<<fgrid, 256, flds, stream>>>(a);
+      else if (a.slots > 16 && a.slots <= 32 && a.H == 4 && plain && packed == bwd_agg_pack(S, EGC_AGGR_STD, X)) bwd_dst_fast_kernel<5, 4, 3, bwd_agg_pack(S, EGC_AGGR_STD, X)><<<fgrid, 256, flds, stream>>>(a);
+      else if (a.slots > 16 && a.slots <= 32 && a.H == 4 && plain && packed == bwd_agg_pack(Y, EGC_AGGR_STD, X)) bwd_dst_fast_kernel<5, 4, 3, bwd_agg_pack(Y, EGC_AGGR_STD, X)><<<fgrid, 256, flds, stream>>>(a);
+      else if (a.slots > 32 && a.H == 4) bwd_dst_fast_kernel<6, 4, 3><<<fgrid, 256, flds, stream>>>(a);
       else if (a.slots > 32) bwd_dst_fast_kernel<6, 8, 1><<<fgrid, 256, flds, stream>>>(a);
       else if (a.slots > 16 && a.H == 4) bwd_dst_fast_kernel<5, 4, 3><<<fgrid, 256, flds, stream>>>(a);
       else if (a.slots > 16) bwd_dst_fast_kernel<5, 8, 1><<<fgrid, 256, flds, stream>>>(a);

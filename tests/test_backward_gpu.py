@@ -333,6 +333,7 @@ def test_d_bases_needs_no_fill_on_square_graphs(generic, monkeypatch):
     (136, 4, 4, ["symadd", "max", "mean"]),    # arxiv EGC-M: 36 slots -> generic destination kernel
     (168, 8, 4, ["symadd"]),                   # zinc / CIFAR EGC-S
     (224, 4, 4, ["add", "mean", "max"]),       # molhiv EGC-M
+    (296, 8, 4, ["symadd"]),                   # molhiv EGC-S: 37 slots
 ])
 def test_trained_reference_shapes_gradients(hidden, H, B, aggrs):
     """Gradients of EfficientGraphConv at the layer shapes of the reference's trained nets (hyperparameters.md) -- the
