@@ -117,6 +117,7 @@ SYMBOLS = {
                                                     C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(EgcPost), C.c_void_p,
                                                     C.c_void_p, C.c_size_t, C.c_void_p]),
     "egc_weight_grad_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
+    "egc_weight_grad_plan": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "egc_weight_grad_ex_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
     "egc_weight_grad_ex_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,

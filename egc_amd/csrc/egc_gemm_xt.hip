@@ -22,6 +22,7 @@
 // library's split batched GEMM, its sum, and the separate column-sum pass this call replaces.  Shapes that need
 // several output tiles (F > 128 or K > 192) re-read the operands once per tile; the host routes the large ones to
 // the library GEMM (egc_amd/functional.py).
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <algorithm>
@@ -541,12 +542,19 @@ __global__ void __launch_bounds__(256) xt_reduce_kernel(const float* __restrict_
 }
 
 struct XtPlan {
-  int mt, nt, m_tiles, n_tiles, chunks;
+  int mt, nt, wn, m_tiles, n_tiles, chunks;
   int64_t rows_per_chunk;
 };
 
-constexpr int XT_WN = 4;     // wavefronts along the output columns (K): 8 wavefronts per workgroup, one workgroup per CU
 constexpr int XT_STAGE = 32;  // rows of the reduction per LDS stage
+
+// The compiled block tiles of xt_gemm_kernel: 32 mt rows of F by 16 wn nt columns of K, 2 x wn wavefronts (one workgroup per CU).
+// The tall ones (mt 5 / 7: 160 / 224 rows, 60 - 84 accumulator registers per lane) are for the reference's batched nets, whose
+// outputs a grid of 128 x 192 tiles pads by half (224 x 272 of molhiv EGC-M -> 256 x 384; 296 x 180 of EGC-S re-read d five times
+// as 64-row tiles): round 6, DESIGN.md 3.7.
+struct XtShape { int mt, nt, wn; };
+constexpr XtShape XT_SHAPES[] = {{1, 1, 4}, {1, 2, 4}, {1, 3, 4}, {2, 1, 4}, {2, 2, 4}, {2, 3, 4}, {4, 1, 4}, {4, 2, 4}, {4, 3, 4},
+                                 {5, 2, 4}, {5, 3, 4}, {7, 2, 4}, {7, 3, 3}, {7, 3, 4}, {7, 5, 4}};
 
 // EGC_GEMM_EXACT=1 (the switch of the forward GEMMs): exact fp32 products on the fp32 MFMA
 // instead of the split-bf16 form
@@ -558,33 +566,49 @@ bool xt_fp32_only() {
 }
 
 XtPlan xt_plan(int64_t n_rows, int F, int K) {
-  // tile shape: modelled time per row of the reduction = the larger of the MFMA time of the padded tile grid
-  // (157 flop/ps) and the operand bytes every output tile re-reads (6 B/ps), plus a quarter of the smaller
-  static const int mts[] = {1, 2, 4}, nts[] = {1, 2, 3};
+  // Tile shape and row split together, by modelled time: a workgroup's time per row of the reduction is the larger of its tile's MFMA
+  // time on one CU's share of the fp32 matrix rate (157 flop/ps over 256 CUs; six wavefronts leave two of the four SIMDs with twice
+  // the work) and of the operand bytes it stages (6 B/ps over 256 CUs: the tiles of one row range re-read them from their XCD's
+  // L2), plus a quarter of the smaller; times the rows of a workgroup and the rounds of workgroups on the fullest XCD; plus the partial tiles'
+  // way through the workspace and back.  Short reductions (a batch of 128 molecules: 3 k rows) want many small tiles, long ones
+  // the tallest tile that fits the registers.
   XtPlan p{};
   double best = 1e300;
   const bool one_tile = F <= 128 && K <= 192 && !xt_fp32_only();   // xt_gemm_bf16x3_kernel
-  for (int mt : mts)
-    for (int nt : nts) {
-      const int64_t mtl = ceil_div(F, 32 * mt), ntl = ceil_div(K, 64 * nt);
-      const double mfma = 2.0 * (double)(mtl * 32 * mt) * (double)(ntl * 64 * nt) / 157.0;
-      const double mem = 4.0 * (double)(mtl * ntl * (32 * mt + 64 * nt)) / 6.0;
-      const double cost = (mfma > mem ? mfma : mem) + 0.25 * (mfma > mem ? mem : mfma);
-      if (one_tile && (mt != 4 || nt != 3)) continue;
-      if (cost < best) {
-        best = cost;
-        p.mt = mt;
-        p.nt = nt;
-        p.m_tiles = (int)mtl;
-        p.n_tiles = (int)ntl;
-      }
+  const int64_t n = n_rows > 0 ? n_rows : 1;
+  const int64_t max_chunks = ceil_div(n, XT_STAGE);
+  // EGC_XT_TILE="mt,nt,wn": this tile of XT_SHAPES for every multi-tile call (tools/xt_wide_time.py: how the model above was fitted)
+  int force[3] = {0, 0, 0};
+  if (const char* e = getenv("EGC_XT_TILE")) {
+    if (sscanf(e, "%d,%d,%d", &force[0], &force[1], &force[2]) != 3) force[0] = 0;
+  }
+  for (const XtShape& sh : XT_SHAPES) {
+    if (one_tile && (sh.mt != 4 || sh.nt != 3 || sh.wn != 4)) continue;
+    if (!one_tile && force[0] != 0 && (sh.mt != force[0] || sh.nt != force[1] || sh.wn != force[2])) continue;
+    const int tm = 32 * sh.mt, tn = 16 * sh.wn * sh.nt;
+    const int64_t mtl = ceil_div(F, tm), ntl = ceil_div(K, tn), tiles = mtl * ntl;
+    // row ranges: the tiles of a range share an XCD (xt_gemm_kernel's id mapping), 32 CUs each -- as many ranges as keep every
+    // XCD at one round of workgroups (86 ranges of three tiles were 33 workgroups on some XCDs: two rounds, 206 instead of 99 us
+    // at 136 x 184 and 169 k rows)
+    int64_t chunks = std::min<int64_t>(8 * std::max<int64_t>(1, 32 / tiles), max_chunks);
+    const int64_t rows = ceil_div(ceil_div(n, chunks), XT_STAGE) * XT_STAGE;
+    chunks = ceil_div(n, rows);
+    const int64_t rounds = ceil_div(ceil_div(chunks, 8) * tiles, 32);
+    const double mfma = 2.0 * tm * tn * 256.0 / 157.0 * (sh.wn == 3 ? 4.0 / 3.0 : 1.0);
+    const double mem = 4.0 * (tm + tn) * 256.0 / 6.0;
+    const double per_row = (mfma > mem ? mfma : mem) + 0.25 * (mfma > mem ? mem : mfma);
+    const double cost = (double)rounds * (double)rows * per_row + 2.0 * (double)chunks * F * K * 4.0 / 6.0;
+    if (cost < best) {
+      best = cost;
+      p.mt = sh.mt;
+      p.nt = sh.nt;
+      p.wn = sh.wn;
+      p.m_tiles = (int)mtl;
+      p.n_tiles = (int)ntl;
+      p.rows_per_chunk = rows;
+      p.chunks = (int)chunks;
     }
-  const int64_t tiles = (int64_t)p.m_tiles * p.n_tiles;
-  int64_t chunks = ceil_div(256, tiles);
-  const int64_t max_chunks = ceil_div(n_rows > 0 ? n_rows : 1, XT_STAGE);
-  if (chunks > max_chunks) chunks = max_chunks;
-  p.rows_per_chunk = ceil_div(ceil_div(n_rows > 0 ? n_rows : 1, chunks), XT_STAGE) * XT_STAGE;
-  p.chunks = (int)ceil_div(n_rows > 0 ? n_rows : 1, p.rows_per_chunk);
+  }
   return p;
 }
 
@@ -616,6 +640,18 @@ int64_t egc_weight_grad_ex_workspace_bytes(int64_t n_rows, int32_t f_in, int32_t
   return (int64_t)p.chunks * ((int64_t)f_in * k_cols + k_cols + e_cols) * 4;
 }
 
+int egc_weight_grad_plan(int64_t n_rows, int32_t f_in, int32_t k_cols, int32_t* plan8) {
+  if (n_rows < 0 || f_in <= 0 || k_cols <= 0 || plan8 == nullptr) return EGC_ERR_INVALID;
+  const egc::XtPlan p = egc::xt_plan(n_rows, f_in, k_cols);
+  if (p.mt == 0) return EGC_ERR_UNSUPPORTED;   // (EGC_XT_TILE names a tile that is not compiled)
+  const bool one_tile = !egc::xt_fp32_only() && f_in <= egc::X3_TM && k_cols <= egc::X3_TN;
+  const int32_t v[8] = {one_tile ? 1 : 0, one_tile ? egc::X3_TM : 32 * p.mt, one_tile ? egc::X3_TN : 16 * p.wn * p.nt,
+                        one_tile ? 1 : p.m_tiles, one_tile ? 1 : p.n_tiles, p.chunks, (int32_t)p.rows_per_chunk,
+                        one_tile ? egc::X3_THREADS : 64 * egc::XT_WM * p.wn};
+  for (int i = 0; i < 8; ++i) plan8[i] = v[i];
+  return EGC_OK;
+}
+
 int64_t egc_weight_grad_workspace_bytes(int64_t n_rows, int32_t f_in, int32_t k_cols) {
   return egc_weight_grad_ex_workspace_bytes(n_rows, f_in, k_cols, 0);
 }
@@ -639,6 +675,7 @@ static int weight_grad_impl(const float* x, int64_t ldx, const float* d, int64_t
   if (workspace_bytes < egc_weight_grad_ex_workspace_bytes(n_rows, f_in, k_cols, e_cols) || workspace == nullptr)
     return EGC_ERR_INVALID;
   const XtPlan p = xt_plan(n_rows, f_in, k_cols);
+  if (p.mt == 0) return EGC_ERR_UNSUPPORTED;
   // 32-bit buffer offsets inside a workgroup's row range (plus the look-ahead past its end)
   const int64_t widest = std::max(std::max(ldx, ldd), e != nullptr ? lde : (int64_t)0);
   if ((double)(p.rows_per_chunk + 160) * (double)widest * 4.0 >= 4.0e9) return EGC_ERR_UNSUPPORTED;
@@ -658,11 +695,13 @@ static int weight_grad_impl(const float* x, int64_t ldx, const float* d, int64_t
     EGC_LAUNCH_CHECK("xt_gemm_bf16x3_kernel");
     rc = EGC_OK;
   } else {
-#define EGC_XT_CASE(MT, NT) \
-  if (p.mt == MT && p.nt == NT) rc = launch_xt<MT, NT, XT_WN, XT_STAGE>(p, x, ldx, f_in, d, ldd, k_cols, n_rows, partial, want_sums, stream);
-  EGC_XT_CASE(1, 1) EGC_XT_CASE(1, 2) EGC_XT_CASE(1, 3)
-  EGC_XT_CASE(2, 1) EGC_XT_CASE(2, 2) EGC_XT_CASE(2, 3)
-  EGC_XT_CASE(4, 1) EGC_XT_CASE(4, 2) EGC_XT_CASE(4, 3)
+#define EGC_XT_CASE(MT, NT, WN) \
+  if (p.mt == MT && p.nt == NT && p.wn == WN) rc = launch_xt<MT, NT, WN, (MT * NT > 21 ? XT_STAGE / 2 : XT_STAGE)>(p, x, ldx, f_in, d, ldd, k_cols, n_rows, partial, want_sums, stream);
+  EGC_XT_CASE(1, 1, 4) EGC_XT_CASE(1, 2, 4) EGC_XT_CASE(1, 3, 4)
+  EGC_XT_CASE(2, 1, 4) EGC_XT_CASE(2, 2, 4) EGC_XT_CASE(2, 3, 4)
+  EGC_XT_CASE(4, 1, 4) EGC_XT_CASE(4, 2, 4) EGC_XT_CASE(4, 3, 4)
+  EGC_XT_CASE(5, 2, 4) EGC_XT_CASE(5, 3, 4)
+  EGC_XT_CASE(7, 2, 4) EGC_XT_CASE(7, 3, 3) EGC_XT_CASE(7, 3, 4) EGC_XT_CASE(7, 5, 4)
 #undef EGC_XT_CASE
   }
   if (rc != EGC_OK) return rc;

@@ -677,9 +677,8 @@ def _native_train_ops(graph, spec, x, bias, comb_w, comb_b, bcat_direct, bases):
         return None
     if not (k <= 192 and spec.f_in <= 128 and spec.f_out <= 128):
         # outside the one-pass dense-gradient kernel: the general sequence (round 6: the reference's own 168 / 224 / 296-wide
-        # batched nets), where the split GEMMs take the shape and x^T d stays on the library's own kernel (long reductions of
-        # wide outputs go to rocBLAS on the Python path: _weight_grads)
-        if (k > 384 or spec.f_in > 384 or spec.f_out > 1024 or x.size(0) > 65536 or x.data_ptr() % 16
+        # batched nets), where the split GEMMs take the shape and x^T d goes through the exact-fp32 tile grid
+        if (k > 384 or spec.f_in > 384 or spec.f_out > 1024 or x.data_ptr() % 16
                 or int(_C.load().egc_basis_pack_bytes(k, spec.f_in, 0)) <= 0):
             return None
     for t in (bias, comb_w, cb, *bases):
@@ -949,17 +948,18 @@ def _weight_grads(x: torch.Tensor, d: torch.Tensor, col_sums: bool = False, extr
     """(x^T @ d, d.sum(0) or None[, extra.sum(0)]) for tall x [N, F], d [N, K]: the gradient of [bases_weight |
     comb_weights.weight], of comb_weights.bias and -- with ``extra`` = grad_out -- of the layer's bias (autograd's
     products behind optimized_layers.py:177-178,207-208) in one pass over the operands through egc_weight_grad_ex_f32:
-    split-bf16 matrix-core products with fp32-level accuracy over row ranges, added in a fixed order.  Shapes outside
-    that entry point's envelope (a dimension not a multiple of 4), and outputs larger than one 128 x 192 accumulator
-    tile on long reductions (ogbn-mag widths: the library's split GEMM is faster there), take torch's GEMM on the
-    device.  Returns a pair without ``extra``, a triple with it."""
+    split-bf16 matrix-core products with fp32-level accuracy over row ranges (outputs of up to 128 x 192) or exact fp32
+    products on a grid of output tiles (wider ones), added in a fixed order.  Shapes outside that entry point's envelope
+    (a dimension not a multiple of 4) take torch's GEMM on the device.  (Rounds 2 - 5 also sent wide outputs on long
+    reductions there; with the tall tiles and the per-XCD row split of round 6 the entry point is level with the library's
+    split GEMM at the ogbn-mag widths -- 1.26 against 1.32 ms at 736 k x 352 x 208 -- and ahead below them, so one
+    deterministic path serves every width.)  Returns a pair without ``extra``, a triple with it."""
     n, f = x.shape
     k = d.size(1)
-    big = (f > 128 or k > 192) and n > 65536
 
     def done(w, s, e):
         return (w, s) if extra is None else (w, s, e)
-    if (n == 0 or big or f % 4 or k % 4 or not x.is_cuda or x.dtype != torch.float32 or d.dtype != torch.float32
+    if (n == 0 or f % 4 or k % 4 or not x.is_cuda or x.dtype != torch.float32 or d.dtype != torch.float32
             or x.stride(1) != 1 or d.stride(1) != 1 or x.stride(0) % 4 or d.stride(0) % 4
             or x.data_ptr() % 16 or d.data_ptr() % 16):
         return done(_xt_library(x, d), _column_sums(d) if col_sums else None, _column_sums(extra) if extra is not None else None)

@@ -323,6 +323,11 @@ int egc_aggregate_combine_strided_f32(const egc_graph* graph, const egc_layer* l
  * else EGC_ERR_UNSUPPORTED.  workspace: egc_weight_grad_workspace_bytes(n_rows, f_in, k_cols) bytes, contents
  * irrelevant on entry and on exit. */
 int64_t egc_weight_grad_workspace_bytes(int64_t n_rows, int32_t f_in, int32_t k_cols);
+/* How a call of that shape is laid out (host only, no GPU work; round 6): plan8 = {split-bf16 one-tile kernel (1) or exact-fp32
+ * kernel (0), rows of an output tile, columns of an output tile, tiles along f_in, tiles along k_cols, row ranges, rows per range,
+ * threads per workgroup}.  The exact-fp32 kernel is compiled for a list of tile shapes (32 .. 224 rows by 64 .. 320 columns) and
+ * the host picks shape and row split together by modelled time; tests use this to see that every compiled shape is exercised. */
+int egc_weight_grad_plan(int64_t n_rows, int32_t f_in, int32_t k_cols, int32_t* plan8);
 /* The same with the column sums of a THIRD array riding along: e [n_rows][e_cols] (row stride lde; e_cols <= 128, a
  * multiple of 4) -> e_sums[e_cols].  A training step wants three reductions over the nodes -- the weight gradient, the
  * column sums of d weightings (bias of the combination Linear) and the column sums of grad_out (the layer's bias,

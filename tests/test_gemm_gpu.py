@@ -214,6 +214,33 @@ def test_weight_grad_matches_float64(n, f, k):
     assert float(((cs.double() - rs).abs() / (bs + tiny)).max() if n else cs.abs().max()) <= tol
 
 
+XT_TILES = [(1, 1, 4), (1, 2, 4), (1, 3, 4), (2, 1, 4), (2, 2, 4), (2, 3, 4), (4, 1, 4), (4, 2, 4), (4, 3, 4), (5, 2, 4), (5, 3, 4),
+            (7, 2, 4), (7, 3, 3), (7, 3, 4), (7, 5, 4)]
+
+
+@pytest.mark.parametrize("tile", XT_TILES, ids=lambda t: "%dx%d" % (32 * t[0], 16 * t[2] * t[1]))
+@pytest.mark.parametrize("n,f,k", [(4133, 224, 272), (1501, 296, 180), (777, 132, 196)])
+def test_weight_grad_every_compiled_tile(tile, n, f, k, monkeypatch):
+    """Every tile shape of the exact-fp32 kernel (round 6: 160 / 224-row tiles for the reference's 168 - 296-wide nets), forced
+    through EGC_XT_TILE at the output shapes of those nets (ragged against every tile), against float64; the plan query names the
+    tile that ran."""
+    import ctypes as C
+    from egc_amd import _C
+    monkeypatch.setenv("EGC_XT_TILE", "%d,%d,%d" % tile)
+    plan = (C.c_int32 * 8)()
+    _C.check(_C.load().egc_weight_grad_plan(n, f, k, C.cast(plan, C.c_void_p)), "egc_weight_grad_plan")
+    assert list(plan)[:3] == [0, 32 * tile[0], 16 * tile[2] * tile[1]] and plan[7] == 128 * tile[2]
+    assert plan[3] * plan[1] >= f and plan[4] * plan[2] >= k and plan[5] * plan[6] >= n
+    g = torch.Generator(device="cpu").manual_seed(n + f + k)
+    x = torch.randn(n, f, generator=g).to(DEV)
+    d = (torch.randn(n, k, generator=g) * torch.logspace(-4, 2, k)).to(DEV)
+    out, cs = _weight_grad(x, d)
+    ref = x.double().t() @ d.double()
+    budget = x.double().abs().t() @ d.double().abs()
+    assert float(((out.double() - ref).abs() / budget).max()) <= 2e-6
+    assert float(((cs.double() - d.double().sum(0)).abs() / d.double().abs().sum(0)).max()) <= 2e-6
+
+
 def test_weight_grad_strided_operands_and_no_sums():
     g = torch.Generator(device="cpu").manual_seed(9)
     xs = torch.randn(5000, 160, generator=g).to(DEV)

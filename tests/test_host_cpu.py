@@ -255,3 +255,26 @@ def test_own_graph_objects_are_not_taken_for_an_adj_t():
     assert not _is_adj_t(torch.zeros(2, 3, dtype=torch.long))
     assert not _is_adj_t(object.__new__(G.GraphBatch)) and not _is_adj_t(object.__new__(G.CSRGraph))
     assert _is_adj_t(object.__new__(G.SparseTensor))
+
+
+def test_weight_gradient_plan_keeps_every_xcd_at_one_round(monkeypatch):
+    """egc_weight_grad_plan (host only): the tile grid covers the output, the row ranges cover the rows, the workspace holds one
+    record per range, and -- the round-6 fix -- the tiles of the ranges that land on one XCD fit its 32 CUs whenever the output has
+    at most 32 tiles (86 ranges of three tiles used to put 33 workgroups on some XCDs: two rounds)."""
+    import ctypes as C
+    lib = _C.load()
+    monkeypatch.delenv("EGC_XT_TILE", raising=False)
+    monkeypatch.delenv("EGC_GEMM_EXACT", raising=False)
+    plan = (C.c_int32 * 8)()
+    for n in (0, 1, 700, 2998, 52771, 169343, 736389):
+        for f, k in ((128, 192), (168, 116), (224, 272), (296, 180), (136, 184), (304, 368), (352, 208), (4, 4), (384, 384)):
+            assert lib.egc_weight_grad_plan(n, f, k, C.cast(plan, C.c_void_p)) == 0
+            x3, tm, tn, mt, nt, ranges, rows, threads = list(plan)
+            assert x3 == int(f <= 128 and k <= 192)
+            assert mt * tm >= f and nt * tn >= k and ranges * rows >= n and rows % 32 == 0 and threads in (384, 512)
+            assert lib.egc_weight_grad_workspace_bytes(n, f, k) == ranges * (f * k + k) * 4
+            if not x3 and mt * nt <= 32:
+                assert -(-ranges // 8) * mt * nt <= 32, (n, f, k, list(plan))
+    monkeypatch.setenv("EGC_XT_TILE", "3,3,3")          # not a compiled tile
+    assert lib.egc_weight_grad_plan(1000, 224, 272, C.cast(plan, C.c_void_p)) == 4
+    assert lib.egc_weight_grad_plan(1000, 0, 272, C.cast(plan, C.c_void_p)) == 1
