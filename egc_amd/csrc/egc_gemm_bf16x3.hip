@@ -638,6 +638,17 @@ int egc_basis_transform_packed(const float* x, const void* packed, const float* 
   return egc_basis_transform_packed_ex(x, packed, bcat, n_nodes, f_in, f_g, w_cols, 0, bases, ldb, weightings, stream_);
 }
 
+int egc_basis_transform_packed_add(const float* x, const void* packed, const float* bcat, int64_t n_nodes, int32_t f_in,
+                                   int32_t f_g, int32_t w_cols, int32_t flags, const float* bases_addend, float* bases, int32_t ldb,
+                                   float* weightings, egc_stream_t stream_) {
+  if (bases_addend == nullptr) return egc_basis_transform_packed_ex(x, packed, bcat, n_nodes, f_in, f_g, w_cols, flags, bases, ldb, weightings, stream_);
+  if (n_nodes < 0 || f_in <= 0 || f_g <= 0 || w_cols < 0 || ldb != ((f_g + 3) & ~3)) return EGC_ERR_INVALID;
+  if (n_nodes == 0) return EGC_OK;
+  if (x == nullptr || packed == nullptr || bases == nullptr || (w_cols > 0 && weightings == nullptr)) return EGC_ERR_INVALID;
+  if (!use_f16x2k(f_in, f_g, ldb, w_cols, flags)) return EGC_ERR_UNSUPPORTED;   // only the long-k kernels carry the addend
+  return f16x2k_launch(x, packed, bcat, n_nodes, f_in, f_g, ldb, w_cols, bases, weightings, (hipStream_t)stream_, bases_addend);
+}
+
 int egc_basis_transform_packed_ex(const float* x, const void* packed, const float* bcat, int64_t n_nodes, int32_t f_in,
                                   int32_t f_g, int32_t w_cols, int32_t flags, float* bases, int32_t ldb, float* weightings,
                                   egc_stream_t stream_) {

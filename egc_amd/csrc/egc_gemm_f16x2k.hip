@@ -118,7 +118,8 @@ __global__ void __launch_bounds__(WAVES * 64) basis_gemm_f16x2k_kernel(const flo
                                                                       const float* __restrict__ bcat, int64_t M, int K,
                                                                       KCols c, float* __restrict__ bases,
                                                                       float* __restrict__ weightings, int n_tiles, int LDX,
-                                                                      int R, int slot_bytes, int tile0, int ring) {
+                                                                      int R, int slot_bytes, int tile0, int ring,
+                                                                      const float* __restrict__ addend) {
   extern __shared__ __attribute__((aligned(16))) char smem_k[];
   char* raw = smem_k;                                                    // [ring][slot_bytes] raw fp32 tiles (DMA ring)
   u16* xs = reinterpret_cast<u16*>(smem_k + ring * slot_bytes);          // [2 buffers][2 planes][KROWS][LDX] fp16
@@ -186,6 +187,12 @@ __global__ void __launch_bounds__(WAVES * 64) basis_gemm_f16x2k_kernel(const flo
     colinfo[2 * v + 1] = (w >= 0 && w < c.W && bcat != nullptr) ? bcat[w] : 0.f;
   }
   const bool vec_store = (out_ld & 3) == 0;
+  // `addend` (the host passes it only where the bases rows are stored as 16-byte pieces): out = x W + addend on the bases columns --
+  // the residual branch's gradient joining d x in the d x GEMM's store (one 16-byte load per lane and tile, requested right after
+  // the barrier, ahead of the tile's DMA requests, by inline assembly: the compiler, which cannot see the DMAs, would wait for
+  // everything)
+  const bool add = addend != nullptr && to_bases;    // wave-uniform
+  const u32x4k ra = {(unsigned)(uintptr_t)addend, (unsigned)((uintptr_t)addend >> 32) & 0xffffu, add ? (unsigned)(M * out_ld * 4) : 0u, 0x00020000u};
   vmwait_k<0>();
   // the compiler counts only its own loads: let it retire the weight loads HERE
 #pragma unroll
@@ -255,12 +262,19 @@ __global__ void __launch_bounds__(WAVES * 64) basis_gemm_f16x2k_kernel(const flo
   // the matrix work of another.  The wait at the top is for this wavefront's own pieces of tile t + 1: behind them in the
   // (in-order) counter are the pieces of tiles t + 2 ... t + ring - 1 and the last tile's stores.
   int cur = 0, slot = 0;
-  const int behind = (ring - 2) * R + n_stores;
+  const int behind = (ring - 2) * (R + (add ? 1 : 0)) + n_stores;
   for (bool first = true; tile < n_tiles; tile += stride, first = false) {
     if (first) vmwait_k<0>(); else vmwait_rt(behind);
     KST(0)
     lds_barrier_k();
     KST(1)
+    f32x4k av;                  // (no initial value: a second definition would be a copy the compiler may place ahead of the wait)
+    asm volatile("" : "=v"(av));
+    if (add) {
+      const int64_t arow = (int64_t)tile * KROWS + j;
+      const unsigned aoff = (arow < M && col0 + 3 < lim) ? (unsigned)((arow * out_ld + col0) * 4) : GOOB;
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "+v"(av) : "v"(aoff), "s"(ra) : "memory");
+    }
     const int nslot = slot + 1 == ring ? 0 : slot + 1;
     split(nslot, cur ^ 1);
     KST(3)
@@ -294,6 +308,11 @@ __global__ void __launch_bounds__(WAVES * 64) basis_gemm_f16x2k_kernel(const flo
       // the top of the loop relies on a fixed number of vector-memory operations per tile.
       const bool row_ok = grow < M;
       const unsigned off = (unsigned)((grow * out_ld + col0) * 4);
+      if (add) {        // behind the addend's load in the counter: this iteration's R DMA requests
+        vmwait_rt(R);
+        asm volatile("" : "+v"(av));
+        o += av;
+      }
       if (vec_store) {
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4k, o), ro, (row_ok && col0 + 3 < lim) ? off : GOOB, 0, 0);
       } else {
@@ -327,7 +346,8 @@ __global__ void __launch_bounds__(WAVES * 64) basis_gemm_f16x2k_spec_kernel(cons
                                                                            const float* __restrict__ bcat, int64_t M, int K,
                                                                            KCols c, float* __restrict__ bases,
                                                                            float* __restrict__ weightings, int n_tiles, int LDX,
-                                                                           int R, int slot_bytes, int tile0, int ring, int nmf) {
+                                                                           int R, int slot_bytes, int tile0, int ring, int nmf,
+                                                                           const float* __restrict__ addend) {
   extern __shared__ __attribute__((aligned(16))) char smem_k[];
   char* raw = smem_k;                                                    // [ring][slot_bytes] raw fp32 tiles (DMA ring)
   u16* xs = reinterpret_cast<u16*>(smem_k + ring * slot_bytes);          // [2 buffers][2 planes][KROWS][LDX] fp16
@@ -514,6 +534,9 @@ __global__ void __launch_bounds__(WAVES * 64) basis_gemm_f16x2k_spec_kernel(cons
   float* outp = to_bases ? bases : weightings;
   const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, (unsigned)(M * out_ld * 4), 0x00020000);
   const bool vec_store = (out_ld & 3) == 0;
+  // `addend`: as in the kernel above; the multipliers issue no DMA, so the compiler's own count of this load is right
+  const bool add = addend != nullptr && to_bases;    // wave-uniform
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(add ? addend : outp), 0, add ? (unsigned)(M * out_ld * 4) : 0u, 0x00020000);
   vmwait_k<0>();
 #pragma unroll
   for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(wf[s][0]), "+v"(wf[s][1]));
@@ -528,6 +551,11 @@ __global__ void __launch_bounds__(WAVES * 64) basis_gemm_f16x2k_spec_kernel(cons
   for (; tile < n_tiles; tile += stride) {
     lds_barrier_k();
     KST(4)
+    f32x4k av = {0.f, 0.f, 0.f, 0.f};
+    if (add) {
+      const int64_t arow = (int64_t)tile * KROWS + j;
+      av = __builtin_bit_cast(f32x4k, __builtin_amdgcn_raw_buffer_load_b128(ra, (arow < M && col0 + 3 < lim) ? (unsigned)((arow * out_ld + col0) * 4) : GOOB, 0, 0));
+    }
     f32x4k acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     const u16* xb = xs + cur * 2 * KROWS * LDX + j * LDX + 8 * quad;
     // PF operand sets in rotation: the operands of k-step s + PF - 1 are requested before the products of k-step s, and the
@@ -567,6 +595,7 @@ __global__ void __launch_bounds__(WAVES * 64) basis_gemm_f16x2k_spec_kernel(cons
     for (int r = 0; r < 4; ++r) o[r] = __builtin_fmaf(__builtin_fmaf(acc1[r], 1.f / 2048.f, acc0[r]), cinv[r] * ri, cbias[r]);
     const bool row_ok = grow < M;
     const unsigned off = (unsigned)((grow * out_ld + col0) * 4);
+    if (add) o += av;
     if (vec_store) {
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4k, o), ro, (row_ok && col0 + 3 < lim) ? off : GOOB, 0, 0);
     } else {
@@ -627,7 +656,7 @@ int f16x2k_pack(const float* wcat, int64_t rs, int64_t cs, int f_in, int f_g, in
 
 template <int KS, int WAVES>
 static int launch_k(const float* x, const u16* packed, const float* bcat, int64_t M, int K, const KCols& c, float* bases,
-                    float* weightings, hipStream_t stream, int tile0, int ntl) {
+                    float* weightings, hipStream_t stream, int tile0, int ntl, const float* addend) {
   const int64_t n_tiles64 = ceil_div(M, KROWS);
   if (n_tiles64 >= ((int64_t)1 << 31)) return EGC_ERR_INVALID;
   const int n_tiles = (int)n_tiles64;
@@ -665,7 +694,7 @@ static int launch_k(const float* x, const u16* packed, const float* bcat, int64_
       int grid = 256;
       if (grid > n_tiles) grid = n_tiles;
       kern<<<grid, (ntl + nh) * 64, lds, stream>>>(x, packed, bcat, M, K, c, bases, weightings, n_tiles, LDX, R, slot_bytes, tile0, ring,
-                                                   ntl);
+                                                   ntl, addend);
       EGC_LAUNCH_CHECK("basis_gemm_f16x2k_spec_kernel");
 #ifdef EGC_GEMMK_STAMPS
       {
@@ -710,18 +739,18 @@ static int launch_k(const float* x, const u16* packed, const float* bcat, int64_
   int ring = 2;
   if (per_cu == 1) {
     ring = (int)std::min<size_t>(4, ((size_t)160 * 1024 - fixed) / (size_t)slot_bytes);
-    while (ring > 2 && ((ring - 2) * R + 4 > 32 || (size_t)ring * slot_bytes + fixed > (size_t)160 * 1024)) --ring;
+    while (ring > 2 && ((ring - 2) * (R + 1) + 4 > 32 || (size_t)ring * slot_bytes + fixed > (size_t)160 * 1024)) --ring;
     if (ring < 2) ring = 2;
     lds = (size_t)ring * slot_bytes + fixed;
   }
-  kern<<<grid, threads, lds, stream>>>(x, packed, bcat, M, K, c, bases, weightings, n_tiles, LDX, R, slot_bytes, tile0, ring);
+  kern<<<grid, threads, lds, stream>>>(x, packed, bcat, M, K, c, bases, weightings, n_tiles, LDX, R, slot_bytes, tile0, ring, addend);
   EGC_LAUNCH_CHECK("basis_gemm_f16x2k_kernel");
   return EGC_OK;
 }
 
 template <int KS>
 static int launch_ks(const float* x, const u16* packed, const float* bcat, int64_t M, int K, const KCols& c, float* bases,
-                     float* weightings, hipStream_t stream) {
+                     float* weightings, hipStream_t stream, const float* addend) {
   // more than 16 column tiles (e.g. 224/H4/B4 with three aggregators: 14 + 3; 300/H4/B4: 19 + 3; 304/H8/B8: 20 + 4): two
   // launches over half of the tiles each -- x is read twice, which still beats the LDS-staged bf16x3 kernel 2 x
   const int launches = c.NT <= 16 ? 1 : 2;
@@ -729,8 +758,8 @@ static int launch_ks(const float* x, const u16* packed, const float* bcat, int64
     const int ntl = (c.NT - t0 + (launches - l) - 1) / (launches - l);
     // up to 9 column tiles: 12 wavefronts (168 registers), 3-4 of them helpers; more: 16 wavefronts (128 registers) with
     // 16 - ntl helpers (none at 16 tiles: the kernel in which every wavefront does everything)
-    const int st = ntl <= 9 ? launch_k<KS, 12>(x, packed, bcat, M, K, c, bases, weightings, stream, t0, ntl)
-                            : launch_k<KS, 16>(x, packed, bcat, M, K, c, bases, weightings, stream, t0, ntl);
+    const int st = ntl <= 9 ? launch_k<KS, 12>(x, packed, bcat, M, K, c, bases, weightings, stream, t0, ntl, addend)
+                            : launch_k<KS, 16>(x, packed, bcat, M, K, c, bases, weightings, stream, t0, ntl, addend);
     if (st != EGC_OK) return st;
     t0 += ntl;
   }
@@ -738,10 +767,11 @@ static int launch_ks(const float* x, const u16* packed, const float* bcat, int64
 }
 
 int f16x2k_launch(const float* x, const void* packed, const float* bcat, int64_t M, int K, int f_g, int ldb, int W,
-                  float* bases, float* weightings, hipStream_t stream) {
+                  float* bases, float* weightings, hipStream_t stream, const float* addend) {
   if ((reinterpret_cast<uintptr_t>(x) & 15) != 0 || (reinterpret_cast<uintptr_t>(bases) & 15) != 0 ||
       (W > 0 && (W & 3) == 0 && (reinterpret_cast<uintptr_t>(weightings) & 15) != 0))
     return EGC_ERR_UNSUPPORTED;
+  if (addend != nullptr && ((reinterpret_cast<uintptr_t>(addend) & 15) != 0 || (ldb & 3) != 0)) return EGC_ERR_UNSUPPORTED;
   const KCols c = kcols(f_g, ldb, W);
   const u16* pk = (const u16*)packed;
   const int64_t widest = std::max(std::max(K, ldb), W);
@@ -752,16 +782,17 @@ int f16x2k_launch(const float* x, const void* packed, const float* bcat, int64_t
     const float* xr = x + r0 * K;
     float* br = bases + r0 * ldb;
     float* wr = weightings != nullptr ? weightings + r0 * W : nullptr;
+    const float* ar = addend != nullptr ? addend + r0 * ldb : nullptr;
     int st;
     switch ((K + 31) / 32) {
-      case 5: st = launch_ks<5>(xr, pk, bcat, rows, K, c, br, wr, stream); break;
-      case 6: st = launch_ks<6>(xr, pk, bcat, rows, K, c, br, wr, stream); break;
-      case 7: st = launch_ks<7>(xr, pk, bcat, rows, K, c, br, wr, stream); break;
-      case 8: st = launch_ks<8>(xr, pk, bcat, rows, K, c, br, wr, stream); break;
-      case 9: st = launch_ks<9>(xr, pk, bcat, rows, K, c, br, wr, stream); break;
-      case 10: st = launch_ks<10>(xr, pk, bcat, rows, K, c, br, wr, stream); break;
-      case 11: st = launch_ks<11>(xr, pk, bcat, rows, K, c, br, wr, stream); break;
-      case 12: st = launch_ks<12>(xr, pk, bcat, rows, K, c, br, wr, stream); break;
+      case 5: st = launch_ks<5>(xr, pk, bcat, rows, K, c, br, wr, stream, ar); break;
+      case 6: st = launch_ks<6>(xr, pk, bcat, rows, K, c, br, wr, stream, ar); break;
+      case 7: st = launch_ks<7>(xr, pk, bcat, rows, K, c, br, wr, stream, ar); break;
+      case 8: st = launch_ks<8>(xr, pk, bcat, rows, K, c, br, wr, stream, ar); break;
+      case 9: st = launch_ks<9>(xr, pk, bcat, rows, K, c, br, wr, stream, ar); break;
+      case 10: st = launch_ks<10>(xr, pk, bcat, rows, K, c, br, wr, stream, ar); break;
+      case 11: st = launch_ks<11>(xr, pk, bcat, rows, K, c, br, wr, stream, ar); break;
+      case 12: st = launch_ks<12>(xr, pk, bcat, rows, K, c, br, wr, stream, ar); break;
       default: return EGC_ERR_UNSUPPORTED;
     }
     if (st != EGC_OK) return st;

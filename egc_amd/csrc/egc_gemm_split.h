@@ -26,7 +26,8 @@ bool f16x2k_shape(int f_in, int f_g, int ldb, int w_cols);
 size_t f16x2k_pack_bytes(int f_in, int f_g, int ldb, int w_cols);
 int f16x2k_pack(const float* wcat, int64_t rs, int64_t cs, int f_in, int f_g, int ldb, int w_cols, void* packed,
                 hipStream_t stream);
+// addend (or nullptr): [M][ldb] added to the bases columns in the store
 int f16x2k_launch(const float* x, const void* packed, const float* bcat, int64_t M, int K, int f_g, int ldb, int W,
-                  float* bases, float* weightings, hipStream_t stream);
+                  float* bases, float* weightings, hipStream_t stream, const float* addend = nullptr);
 
 }  // namespace egc

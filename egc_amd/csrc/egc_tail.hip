@@ -50,6 +50,7 @@ struct FinArgs {
   const int64_t* n_tracked;
   const double* bstats;         // backward: the forward's stats
   float* outv;                  // backward: [5][cols]
+  float* dh_sums;               // backward: column sums of dh [cols], or nullptr
 };
 
 template <bool COHERENT>
@@ -59,7 +60,7 @@ __device__ inline void bn_forward_column(double s1, double s2, int col, int cols
                                          double eps, double* stats, float* affine, float* running_mean, float* running_var,
                                          double momentum, double n_tracked);
 __device__ inline void bn_backward_column(double s1, double sgh, int col, int cols, double n_rows, const double* stats,
-                                          const float* gamma, float* outv);
+                                          const float* gamma, float* outv, float* dh_sums);
 
 template <bool MASKED, int FIN = 0>   // FIN: 0 partials only, 1 + forward finalize, 2 + backward finalize
 __global__ void __launch_bounds__(256) column_moments_kernel(const float* __restrict__ a, const float* __restrict__ b,
@@ -173,7 +174,7 @@ __global__ void __launch_bounds__(256) column_moments_kernel(const float* __rest
         bn_forward_column(t1, t2, col, cols, nr, fin.gamma, fin.beta, fin.eps, fin.stats, fin.affine, fin.running_mean,
                           fin.running_var, fin.momentum, tracked);
       } else {
-        bn_backward_column(t1, t2, col, cols, nr, fin.bstats, fin.gamma, fin.outv);
+        bn_backward_column(t1, t2, col, cols, nr, fin.bstats, fin.gamma, fin.outv, fin.dh_sums);
       }
     }
   }
@@ -246,15 +247,20 @@ __device__ inline void bn_forward_column(double s1, double s2, int col, int cols
 }
 
 __device__ inline void bn_backward_column(double s1, double sgh, int col, int cols, double n_rows, const double* stats,
-                                          const float* gamma, float* outv) {
+                                          const float* gamma, float* outv, float* dh_sums) {
   const double mean = stats[col], rstd = stats[2 * cols + col];
   const double s2 = (sgh - mean * s1) * rstd;                 // sum g * h_hat
   const double a = (gamma != nullptr ? (double)gamma[col] : 1.0) * rstd;
+  const float cg = (float)a, ch = (float)(-(a / n_rows) * rstd * s2), c1 = (float)(-(a / n_rows) * (s1 - mean * rstd * s2));
   outv[col] = (float)s2;                                      // d gamma
   outv[cols + col] = (float)s1;                               // d beta
-  outv[2 * cols + col] = (float)a;                            // dh = a g - (a / n) (s1 + (h - mean) rstd s2)
-  outv[3 * cols + col] = (float)(-(a / n_rows) * rstd * s2);
-  outv[4 * cols + col] = (float)(-(a / n_rows) * (s1 - mean * rstd * s2));
+  outv[2 * cols + col] = cg;                                  // dh = a g - (a / n) (s1 + (h - mean) rstd s2)
+  outv[3 * cols + col] = ch;
+  outv[4 * cols + col] = c1;
+  // The column sum of the dh the elementwise pass will write (the gradient of a bias in front of the BatchNorm: zero but for
+  // rounding -- autograd's value is the float sum of its own dh): sum_rows (cg g + ch h + c1) with the three coefficients AS
+  // ROUNDED above, from the sums this step already holds (sum g = s1, sum h = n mean) -- no pass over dh.
+  if (dh_sums != nullptr) dh_sums[col] = (float)((double)cg * s1 + (double)ch * (n_rows * mean) + n_rows * (double)c1);
 }
 
 // Everything between the statistics pass and the elementwise pass of the training-mode BatchNorm tail, per column:
@@ -284,14 +290,14 @@ __global__ void __launch_bounds__(256) bn_forward_finalize_kernel(const double* 
 __global__ void __launch_bounds__(256) bn_backward_finalize_kernel(const double* __restrict__ partials, int n_partials, int cols,
                                                                    double n_rows, const double* __restrict__ stats,
                                                                    const float* __restrict__ gamma, float* __restrict__ outv,
-                                                                   const int64_t* __restrict__ n_valid) {
+                                                                   const int64_t* __restrict__ n_valid, float* __restrict__ dh_sums) {
   __shared__ double red[2][FIN_COLS][FIN_LANES + 1];
   if (n_valid != nullptr) n_rows = fmax(fmin(n_rows, (double)*n_valid), 1.0);
   const int col = blockIdx.x * FIN_COLS + threadIdx.x % FIN_COLS, pl = threadIdx.x / FIN_COLS;
   double s1, sgh;
   moment_totals<false>(partials, n_partials, cols, col, pl, red, s1, sgh);
   if (pl != 0 || col >= cols) return;
-  bn_backward_column(s1, sgh, col, cols, n_rows, stats, gamma, outv);
+  bn_backward_column(s1, sgh, col, cols, n_rows, stats, gamma, outv, dh_sums);
 }
 
 // out = act(h * scale + shift) + residual, 16 bytes per thread
@@ -432,16 +438,34 @@ int egc_bn_forward_stats_f32(const float* h, int64_t n_rows, int32_t cols, doubl
   return EGC_OK;
 }
 
+static int bn_backward_finalize_impl(const double* partials, int32_t n_partials, int32_t cols, int64_t n_rows, const double* stats,
+                                     const float* gamma, float* out5, const int64_t* n_valid, float* dh_sums, hipStream_t stream) {
+  if (partials == nullptr || n_partials <= 0 || cols <= 0 || n_rows <= 0 || stats == nullptr || out5 == nullptr)
+    return EGC_ERR_INVALID;
+  bn_backward_finalize_kernel<<<(unsigned)ceil_div(cols, FIN_COLS), FIN_COLS * FIN_LANES, 0, stream>>>(partials, n_partials, cols, (double)n_rows, stats,
+                                                                              gamma, out5, n_valid, dh_sums);
+  EGC_LAUNCH_CHECK("bn_backward_finalize_kernel");
+  return EGC_OK;
+}
+
 int egc_bn_backward_stats_f32(const float* dout, const float* h, const float* scale, const float* shift, int32_t relu,
                               const uint8_t* keep, float keep_scale, int64_t n_rows, int32_t cols, double* partials,
                               int32_t n_partials, const int64_t* n_valid, const double* stats, const float* gamma, float* out5,
                               int32_t* sync, egc_stream_t stream_) {
+  return egc_bn_backward_stats_sums_f32(dout, h, scale, shift, relu, keep, keep_scale, n_rows, cols, partials, n_partials, n_valid, stats,
+                                        gamma, out5, nullptr, sync, stream_);
+}
+
+int egc_bn_backward_stats_sums_f32(const float* dout, const float* h, const float* scale, const float* shift, int32_t relu,
+                                   const uint8_t* keep, float keep_scale, int64_t n_rows, int32_t cols, double* partials,
+                                   int32_t n_partials, const int64_t* n_valid, const double* stats, const float* gamma, float* out5,
+                                   float* dh_col_sums, int32_t* sync, egc_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (sync == nullptr || n_partials > BN_FUSE_MAX_PARTIALS) {
     const int st = egc_column_moments_f64(dout, h, scale, shift, relu, keep, keep_scale, n_rows, cols, partials, n_partials, nullptr,
                                           n_valid, stream_);
     if (st != EGC_OK) return st;
-    return egc_bn_backward_finalize(partials, n_partials, cols, n_rows, stats, gamma, out5, n_valid, stream_);
+    return bn_backward_finalize_impl(partials, n_partials, cols, n_rows, stats, gamma, out5, n_valid, dh_col_sums, stream);
   }
   if (n_rows <= 0 || cols <= 0 || partials == nullptr || n_partials <= 0 || dout == nullptr || h == nullptr || stats == nullptr ||
       out5 == nullptr)
@@ -452,7 +476,7 @@ int egc_bn_backward_stats_f32(const float* dout, const float* h, const float* sc
   if (relu && (scale == nullptr || shift == nullptr)) return EGC_ERR_INVALID;
   if (keep != nullptr && (reinterpret_cast<uintptr_t>(keep) & 3) != 0) return EGC_ERR_INVALID;
   FinArgs f = FinArgs();
-  f.sync = sync; f.gamma = gamma; f.bstats = stats; f.outv = out5;
+  f.sync = sync; f.gamma = gamma; f.bstats = stats; f.outv = out5; f.dh_sums = dh_col_sums;
   const int rows_per_block = (int)std::max<int64_t>(ceil_div(n_rows, (int64_t)n_partials), 1);
   column_moments_kernel<true, 2><<<(unsigned)n_partials, 256, 0, stream>>>(dout, h, scale, shift, n_rows, cols, rows_per_block, partials,
                                                                              relu, keep, keep_scale, nullptr, n_valid, f);
@@ -480,13 +504,7 @@ int egc_bn_forward_finalize(const double* partials, int32_t n_partials, int32_t 
 
 int egc_bn_backward_finalize(const double* partials, int32_t n_partials, int32_t cols, int64_t n_rows, const double* stats,
                              const float* gamma, float* out5, const int64_t* n_valid, egc_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  if (partials == nullptr || n_partials <= 0 || cols <= 0 || n_rows <= 0 || stats == nullptr || out5 == nullptr)
-    return EGC_ERR_INVALID;
-  bn_backward_finalize_kernel<<<(unsigned)ceil_div(cols, FIN_COLS), FIN_COLS * FIN_LANES, 0, stream>>>(partials, n_partials, cols, (double)n_rows, stats,
-                                                                              gamma, out5, n_valid);
-  EGC_LAUNCH_CHECK("bn_backward_finalize_kernel");
-  return EGC_OK;
+  return bn_backward_finalize_impl(partials, n_partials, cols, n_rows, stats, gamma, out5, n_valid, nullptr, (hipStream_t)stream_);
 }
 
 int egc_affine_act_residual_f32(const float* h, const float* scale, const float* shift, const float* residual,

@@ -174,12 +174,16 @@ std::vector<at::Tensor> train_forward(const at::Tensor& x, const at::Tensor& com
 // Requires (checked by the caller): ldb == B Ls, (ldb + W) % 4 == 0, f_in % 4 == 0, f_out % 4 == 0; a bias and a combination bias
 // present.  The one-pass dense-gradient kernel inside its envelope (f_in <= 128, ldb + W <= 192, f_out <= 128), the general
 // sequence outside it (round 6).
-std::vector<at::Tensor> train_backward(const at::Tensor& grad_out, const at::Tensor& x, const at::Tensor& wcat,
-                                       const at::Tensor& bases, const at::Tensor& weightings, const at::Tensor& stats,
-                                       const at::Tensor& cnt, const at::Tensor& arg_max, const at::Tensor& arg_min, int64_t graph,
-                                       int64_t t_graph, int64_t layer, int64_t stream, int64_t H, int64_t A, int64_t B, int64_t L,
-                                       int64_t Ls, bool permute_hab, bool packed_bias, bool need_x, at::IntArrayRef comb_w_shape,
-                                       at::IntArrayRef comb_b_shape, int64_t n_parts, at::IntArrayRef part_shape) {
+// dx_addend (or nullptr): [N, f_in] added to d x -- the residual branch's gradient; joins the d x GEMM's store where the kernel
+// carries an addend (egc_basis_transform_packed_add), else one in-place add.  bias_grad (or nullptr): the column sums of grad_out
+// when the caller holds them already (the BatchNorm tail's backward: egc_bn_backward_stats_sums_f32) -- no pass over grad_out.
+static std::vector<at::Tensor> train_backward_impl(const at::Tensor& grad_out, const at::Tensor& x, const at::Tensor& wcat,
+                                                   const at::Tensor& bases, const at::Tensor& weightings, const at::Tensor& stats,
+                                                   const at::Tensor& cnt, const at::Tensor& arg_max, const at::Tensor& arg_min, int64_t graph,
+                                                   int64_t t_graph, int64_t layer, int64_t stream, int64_t H, int64_t A, int64_t B, int64_t L,
+                                                   int64_t Ls, bool permute_hab, bool packed_bias, bool need_x, at::IntArrayRef comb_w_shape,
+                                                   at::IntArrayRef comb_b_shape, int64_t n_parts, at::IntArrayRef part_shape,
+                                                   const at::Tensor* dx_addend, const at::Tensor* bias_grad) {
   const auto* g = reinterpret_cast<const egc_graph*>(graph);
   const auto* tg = reinterpret_cast<const egc_graph*>(t_graph);
   const auto* l = reinterpret_cast<const egc_layer*>(layer);
@@ -207,8 +211,17 @@ std::vector<at::Tensor> train_backward(const at::Tensor& grad_out, const at::Ten
     dx = at::empty({n, f_in}, opts);
     check_status(egc_basis_pack_transposed(wcat.data_ptr<float>(), k, (int32_t)k, (int32_t)f_in, 0, packed.data_ptr(), pb, st),
                  "egc_basis_pack_transposed");
-    check_status(egc_basis_transform_packed(d_cat.data_ptr<float>(), packed.data_ptr(), nullptr, n, (int32_t)k, (int32_t)f_in, 0,
-                                            dx.data_ptr<float>(), (int32_t)f_in, nullptr, st), "egc_basis_transform_packed");
+    int rc = EGC_ERR_UNSUPPORTED;
+    if (dx_addend != nullptr && (f_in % 4) == 0)
+      rc = egc_basis_transform_packed_add(d_cat.data_ptr<float>(), packed.data_ptr(), nullptr, n, (int32_t)k, (int32_t)f_in, 0, 0,
+                                          dx_addend->data_ptr<float>(), dx.data_ptr<float>(), (int32_t)f_in, nullptr, st);
+    if (rc == EGC_ERR_UNSUPPORTED) {
+      check_status(egc_basis_transform_packed(d_cat.data_ptr<float>(), packed.data_ptr(), nullptr, n, (int32_t)k, (int32_t)f_in, 0,
+                                              dx.data_ptr<float>(), (int32_t)f_in, nullptr, st), "egc_basis_transform_packed");
+      if (dx_addend != nullptr) dx.add_(*dx_addend);       // autograd's own add, in place
+    } else {
+      check_status(rc, "egc_basis_transform_packed_add");
+    }
   }
   // (3) the dense gradients of the parameters.  Inside the one-pass kernel's envelope (f_in <= 128, ldb + W <= 192, f_out <= 128):
   // x^T d_cat with the column sums of d_cat (combination bias) and of grad_out (the layer's bias) in one pass, written straight
@@ -217,7 +230,8 @@ std::vector<at::Tensor> train_backward(const at::Tensor& grad_out, const at::Ten
   // library's GEMMs take): x^T d_cat + the column sums of d_cat (egc_weight_grad_ex_f32), the column sums of grad_out
   // (egc_column_sums_f32 + egc_sum_partials_f32), and the pack's index map read backwards (egc_weights_pack_f32, grad = 1) --
   // the calls egc_amd/functional.py's _layer_train_backward + _unpack_param_grads make, in their order.
-  at::Tensor es = at::empty({f_out}, opts);
+  const bool have_es = bias_grad != nullptr;
+  at::Tensor es = have_es ? *bias_grad : at::empty({f_out}, opts);
   at::Tensor dcw = at::empty(comb_w_shape, opts);
   at::Tensor dcb = packed_bias ? at::empty(comb_b_shape, opts) : at::empty({W}, opts);
   std::vector<at::Tensor> dparts;
@@ -234,8 +248,9 @@ std::vector<at::Tensor> train_backward(const at::Tensor& grad_out, const at::Ten
     check_status(egc_weight_grad_params_f32(x.data_ptr<float>(), f_in, d_cat.data_ptr<float>(), k, n, (int32_t)f_in, (int32_t)H,
                                             (int32_t)A, (int32_t)B, (int32_t)L, (int32_t)Ls, permute_hab ? 1 : 0, ptrs.data(),
                                             (int32_t)n_parts, dcw.data_ptr<float>(), packed_bias ? dcb.data_ptr<float>() : nullptr,
-                                            packed_bias ? nullptr : dcb.data_ptr<float>(), go.data_ptr<float>(), f_out, (int32_t)f_out,
-                                            es.data_ptr<float>(), gws.data_ptr(), gws.numel(), st), "egc_weight_grad_params_f32");
+                                            packed_bias ? nullptr : dcb.data_ptr<float>(), have_es ? nullptr : go.data_ptr<float>(), f_out,
+                                            have_es ? 0 : (int32_t)f_out, have_es ? nullptr : es.data_ptr<float>(), gws.data_ptr(), gws.numel(), st),
+                 "egc_weight_grad_params_f32");
   } else {
     at::Tensor dwcat = at::empty({f_in, k}, opts), cs = at::empty({k}, opts);
     const int64_t gbytes = (int64_t)egc_weight_grad_ex_workspace_bytes(n, (int32_t)f_in, (int32_t)k, 0);
@@ -243,12 +258,14 @@ std::vector<at::Tensor> train_backward(const at::Tensor& grad_out, const at::Ten
     check_status(egc_weight_grad_ex_f32(x.data_ptr<float>(), f_in, d_cat.data_ptr<float>(), k, n, (int32_t)f_in, (int32_t)k,
                                         dwcat.data_ptr<float>(), cs.data_ptr<float>(), nullptr, 0, 0, nullptr, gws.data_ptr(), gws.numel(),
                                         st), "egc_weight_grad_ex_f32");
-    const int64_t parts = std::max<int64_t>(1, std::min<int64_t>(1024, (n + 127) / 128));
-    at::Tensor psum = at::empty({parts, f_out}, opts);
-    check_status(egc_column_sums_f32(go.data_ptr<float>(), n, (int32_t)f_out, (int32_t)f_out, psum.data_ptr<float>(), (int32_t)parts, st),
-                 "egc_column_sums_f32");
-    if (parts == 1) es = psum[0];
-    else check_status(egc_sum_partials_f32(psum.data_ptr<float>(), (int32_t)parts, (int32_t)f_out, es.data_ptr<float>(), st), "egc_sum_partials_f32");
+    if (!have_es) {
+      const int64_t parts = std::max<int64_t>(1, std::min<int64_t>(1024, (n + 127) / 128));
+      at::Tensor psum = at::empty({parts, f_out}, opts);
+      check_status(egc_column_sums_f32(go.data_ptr<float>(), n, (int32_t)f_out, (int32_t)f_out, psum.data_ptr<float>(), (int32_t)parts, st),
+                   "egc_column_sums_f32");
+      if (parts == 1) es = psum[0];
+      else check_status(egc_sum_partials_f32(psum.data_ptr<float>(), (int32_t)parts, (int32_t)f_out, es.data_ptr<float>(), st), "egc_sum_partials_f32");
+    }
     // d bcat = the weightings part of d_cat's column sums: through the pack's row permutation for a module bias (EGConv), as it is
     // for a bias already in the operand's order (EfficientGraphConv)
     float* dbc = cs.data_ptr<float>() + (k - W);
@@ -260,6 +277,16 @@ std::vector<at::Tensor> train_backward(const at::Tensor& grad_out, const at::Ten
   std::vector<at::Tensor> out{dx, dcw, dcb, es};
   out.insert(out.end(), dparts.begin(), dparts.end());
   return out;
+}
+
+std::vector<at::Tensor> train_backward(const at::Tensor& grad_out, const at::Tensor& x, const at::Tensor& wcat,
+                                       const at::Tensor& bases, const at::Tensor& weightings, const at::Tensor& stats,
+                                       const at::Tensor& cnt, const at::Tensor& arg_max, const at::Tensor& arg_min, int64_t graph,
+                                       int64_t t_graph, int64_t layer, int64_t stream, int64_t H, int64_t A, int64_t B, int64_t L,
+                                       int64_t Ls, bool permute_hab, bool packed_bias, bool need_x, at::IntArrayRef comb_w_shape,
+                                       at::IntArrayRef comb_b_shape, int64_t n_parts, at::IntArrayRef part_shape) {
+  return train_backward_impl(grad_out, x, wcat, bases, weightings, stats, cnt, arg_max, arg_min, graph, t_graph, layer, stream, H, A, B, L, Ls,
+                             permute_hab, packed_bias, need_x, comb_w_shape, comb_b_shape, n_parts, part_shape, nullptr, nullptr);
 }
 
 
@@ -384,17 +411,19 @@ struct BatchBlockTrainFn : public torch::autograd::Function<BatchBlockTrainFn> {
     const int64_t n = x.size(0), f_in = s.f_in, f_out = l->out_channels, W = s.H * s.B * s.A, ldb = egc_bases_ld(l), k = ldb + W;
     at::Tensor go = grads[0].contiguous();
     check_f32(go, "grad_out");
-    at::Tensor g_conv = go;
+    at::Tensor g_conv = go, dh_sums;
     if (s.with_tail) {
       const at::Tensor &h = saved[3], &affine = saved[4], &stats = saved[5], &gamma_c = saved[6];
       const int64_t c = f_out;
       const int64_t n_parts = std::max<int64_t>(1, std::min<int64_t>(1024, (n + 127) / 128));
       at::Tensor partials = at::empty({n_parts, 2, c}, opts.dtype(at::kDouble)), out5 = at::empty({5, c}, opts);
       const float* a0 = affine.data_ptr<float>();
-      check_status(egc_bn_backward_stats_f32(go.data_ptr<float>(), h.data_ptr<float>(), a0, a0 + c, s.relu ? 1 : 0, nullptr, 1.0f, n, (int32_t)c,
-                                             partials.data_ptr<double>(), (int32_t)n_parts, nullptr, stats.data_ptr<double>(),
-                                             gamma_c.defined() ? gamma_c.data_ptr<float>() : nullptr, out5.data_ptr<float>(), nullptr, st),
-                   "egc_bn_backward_stats_f32");
+      if (has[0]) dh_sums = at::empty({c}, opts);      // the layer's bias gradient = the column sums of dh: from this step's own sums
+      check_status(egc_bn_backward_stats_sums_f32(go.data_ptr<float>(), h.data_ptr<float>(), a0, a0 + c, s.relu ? 1 : 0, nullptr, 1.0f, n, (int32_t)c,
+                                                  partials.data_ptr<double>(), (int32_t)n_parts, nullptr, stats.data_ptr<double>(),
+                                                  gamma_c.defined() ? gamma_c.data_ptr<float>() : nullptr, out5.data_ptr<float>(),
+                                                  dh_sums.defined() ? dh_sums.data_ptr<float>() : nullptr, nullptr, st),
+                   "egc_bn_backward_stats_sums_f32");
       at::Tensor dh = at::empty({n, c}, opts);
       const float* o5 = out5.data_ptr<float>();
       check_status(egc_affine_act_backward_f32(go.data_ptr<float>(), h.data_ptr<float>(), a0, a0 + c, s.relu ? 1 : 0, nullptr, 1.0f, o5 + 2 * c,
@@ -423,14 +452,17 @@ struct BatchBlockTrainFn : public torch::autograd::Function<BatchBlockTrainFn> {
       dparts.push_back(at::empty(shapes[2 + i], opts));
       ptrs.push_back(dparts.back().data_ptr<float>());
     }
-    const int64_t gbytes = egc_weight_grad_ex_workspace_bytes(n, (int32_t)f_in, (int32_t)k, (int32_t)f_out);
+    // (the layer's bias gradient: from the BatchNorm step above where there is one, else -- and when nobody asks -- no third stream)
+    const bool ride = has[0] && !dh_sums.defined();
+    const int64_t gbytes = egc_weight_grad_ex_workspace_bytes(n, (int32_t)f_in, (int32_t)k, ride ? (int32_t)f_out : 0);
     at::Tensor gws = at::empty({std::max<int64_t>(gbytes, 16)}, opts.dtype(at::kByte));
     check_status(egc_weight_grad_params_f32(x.data_ptr<float>(), f_in, d_cat.data_ptr<float>(), k, n, (int32_t)f_in, (int32_t)s.H, (int32_t)s.A,
                                             (int32_t)s.B, (int32_t)s.L, (int32_t)s.Ls, s.permute_hab ? 1 : 0, ptrs.data(), (int32_t)n_parts_w,
                                             dcw.data_ptr<float>(), has[1] ? dcb.data_ptr<float>() : nullptr, has[1] ? nullptr : dcb.data_ptr<float>(),
-                                            g_conv.data_ptr<float>(), f_out, (int32_t)f_out, es.data_ptr<float>(), gws.data_ptr(), gws.numel(),
+                                            ride ? g_conv.data_ptr<float>() : nullptr, f_out, ride ? (int32_t)f_out : 0,
+                                            ride ? es.data_ptr<float>() : nullptr, gws.data_ptr(), gws.numel(),
                                             reinterpret_cast<void*>(s.stream)), "egc_weight_grad_params_f32");
-    if (has[0]) out[1] = es;
+    if (has[0]) out[1] = dh_sums.defined() ? dh_sums : es;
     out[2] = dcw;
     if (has[1]) out[3] = dcb;
     if (has[2]) out[4] = dcb;
@@ -551,16 +583,18 @@ struct CsrBlockTrainFn : public torch::autograd::Function<CsrBlockTrainFn> {
     const int64_t n = x.size(0), c = l->out_channels;
     at::Tensor go = grads[0].contiguous();
     check_f32(go, "grad_out");
-    at::Tensor g_conv = go;
+    at::Tensor g_conv = go, dh_sums;
     if (with_tail) {
       const at::Tensor &h = saved[8], &affine = saved[9], &stats = saved[10], &gamma_c = saved[11];
       const int64_t n_parts = std::max<int64_t>(1, std::min<int64_t>(1024, (n + 127) / 128));
       at::Tensor partials = at::empty({n_parts, 2, c}, opts.dtype(at::kDouble)), out5 = at::empty({5, c}, opts);
       const float* a0 = affine.data_ptr<float>();
-      check_status(egc_bn_backward_stats_f32(go.data_ptr<float>(), h.data_ptr<float>(), a0, a0 + c, relu ? 1 : 0, nullptr, 1.0f, n, (int32_t)c,
-                                             partials.data_ptr<double>(), (int32_t)n_parts, nullptr, stats.data_ptr<double>(),
-                                             gamma_c.defined() ? gamma_c.data_ptr<float>() : nullptr, out5.data_ptr<float>(), nullptr, st),
-                   "egc_bn_backward_stats_f32");
+      dh_sums = at::empty({c}, opts);                   // the layer's bias gradient = the column sums of dh: from this step's own sums
+      check_status(egc_bn_backward_stats_sums_f32(go.data_ptr<float>(), h.data_ptr<float>(), a0, a0 + c, relu ? 1 : 0, nullptr, 1.0f, n, (int32_t)c,
+                                                  partials.data_ptr<double>(), (int32_t)n_parts, nullptr, stats.data_ptr<double>(),
+                                                  gamma_c.defined() ? gamma_c.data_ptr<float>() : nullptr, out5.data_ptr<float>(),
+                                                  dh_sums.data_ptr<float>(), nullptr, st),
+                   "egc_bn_backward_stats_sums_f32");
       at::Tensor dh = at::empty({n, c}, opts);
       const float* o5 = out5.data_ptr<float>();
       check_status(egc_affine_act_backward_f32(go.data_ptr<float>(), h.data_ptr<float>(), a0, a0 + c, relu ? 1 : 0, nullptr, 1.0f, o5 + 2 * c,
@@ -572,10 +606,11 @@ struct CsrBlockTrainFn : public torch::autograd::Function<CsrBlockTrainFn> {
     }
     const auto cws = ctx->saved_data["comb_w_shape"].toIntVector(), cbs = ctx->saved_data["comb_b_shape"].toIntVector();
     const auto ps = ctx->saved_data["part_shape"].toIntVector();
-    auto r = train_backward(g_conv, x, saved[1], saved[2], saved[3], saved[4], saved[5], saved[6], saved[7], reinterpret_cast<int64_t>(&g),
-                            reinterpret_cast<int64_t>(&tg), layer, stream, H, A, B, L, Ls, permute, packed_bias, true, cws, cbs, n_parts_w, ps);
+    // the residual branch's gradient (x = x + ...) joins d x in the d x GEMM's store where that kernel takes an addend
+    auto r = train_backward_impl(g_conv, x, saved[1], saved[2], saved[3], saved[4], saved[5], saved[6], saved[7], reinterpret_cast<int64_t>(&g),
+                                 reinterpret_cast<int64_t>(&tg), layer, stream, H, A, B, L, Ls, permute, packed_bias, true, cws, cbs, n_parts_w, ps,
+                                 (with_tail && residual) ? &go : nullptr, dh_sums.defined() ? &dh_sums : nullptr);
     at::Tensor dx = r[0];
-    if (with_tail && residual) dx.add_(go);       // the residual branch's gradient (x = x + ...): autograd's own add, in place
     out[0] = dx;
     if (has_bias) out[1] = r[3];
     out[2] = r[1];

@@ -250,6 +250,14 @@ int egc_basis_pack_transposed(const float* wt, int64_t ld, int32_t f_in, int32_t
 int egc_basis_transform_packed(const float* x, const void* packed, const float* bcat, int64_t n_nodes,
                                int32_t f_in, int32_t f_g, int32_t w_cols, float* bases, int32_t ldb,
                                float* weightings, egc_stream_t stream);
+/* egc_basis_transform_packed_ex with bases = x W + bases_addend (round 6): bases_addend [n_nodes][ldb], 16-byte aligned, joins the
+ * bases columns in the kernel's store.  The gradient of a residual block  x + f(conv(x))  w.r.t. x is the layer's d x GEMM plus the
+ * upstream gradient itself (autograd's add behind zinc/models.py:66-72): with the addend that sum costs no pass of its own.  Only
+ * the long-k kernels (128 < f_in <= 384, the d x GEMM of the reference's 224- and 296-wide nets) carry it: EGC_ERR_UNSUPPORTED
+ * elsewhere, and the caller adds; bases_addend == NULL: egc_basis_transform_packed_ex. */
+int egc_basis_transform_packed_add(const float* x, const void* packed, const float* bcat, int64_t n_nodes, int32_t f_in,
+                                   int32_t f_g, int32_t w_cols, int32_t flags, const float* bases_addend, float* bases, int32_t ldb,
+                                   float* weightings, egc_stream_t stream);
 
 /* Scratch bytes egc_aggregate_combine_f32 needs for this layer on this graph.
  * CONTRACT: its first egc_aggregate_workspace_zero_bytes() bytes must be zero before its FIRST use (the long-row
@@ -413,6 +421,15 @@ int egc_bn_backward_stats_f32(const float* dout, const float* h, const float* sc
                               const uint8_t* keep, float keep_scale, int64_t n_rows, int32_t cols, double* partials,
                               int32_t n_partials, const int64_t* n_valid, const double* stats, const float* gamma, float* out5,
                               int32_t* sync, egc_stream_t stream);
+/* egc_bn_backward_stats_f32 that also returns the column sums of the dh egc_affine_act_backward_f32 will write, dh_col_sums[cols]
+ * (round 6; NULL: the call above).  In the reference's blocks the conv's bias sits in front of the BatchNorm (zinc/models.py:66-72), so
+ * its gradient -- autograd's sum of dh over the rows -- is zero but for rounding; here it is formed per channel from the sums this
+ * step holds anyway (coef_g sum g + coef_h sum h + n coef_1 with the float32 coefficients as stored), which spares a training step
+ * of the wide nets one pass over [n_rows, cols] per layer. */
+int egc_bn_backward_stats_sums_f32(const float* dout, const float* h, const float* scale, const float* shift, int32_t relu,
+                                   const uint8_t* keep, float keep_scale, int64_t n_rows, int32_t cols, double* partials,
+                                   int32_t n_partials, const int64_t* n_valid, const double* stats, const float* gamma, float* out5,
+                                   float* dh_col_sums, int32_t* sync, egc_stream_t stream);
 int egc_bn_forward_finalize(const double* partials, int32_t n_partials, int32_t cols, int64_t n_rows, const float* gamma,
                             const float* beta, double eps, double* stats, float* affine, float* running_mean,
                             float* running_var, double momentum, const int64_t* n_tracked, const int64_t* n_valid,

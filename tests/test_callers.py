@@ -381,3 +381,56 @@ def test_code_shaped_batch_against_the_oracle(hidden, H, B, aggrs):
     assert (gb._csr is not None) == (hidden >= 300)
     assert rel_err(out, ref) <= 1e-5, rel_err(out, ref)
     assert elementwise_excess(out, float64_forward(g), 1e-5) <= 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("relu", [True, False])
+@pytest.mark.parametrize("n,c,one_launch", [(300, 64, False), (4000, 128, True), (52771, 224, False)])
+def test_dh_column_sums_from_the_batch_norm_backward_step(n, c, one_launch, relu):
+    """egc_bn_backward_stats_sums_f32: the column sums of the dh the elementwise pass writes -- the gradient of a conv bias in
+    front of the BatchNorm -- from the sums the step already holds, against the float64 sum of the ACTUAL dh: within the rounding
+    of the dh elements themselves (the float32 sum autograd forms is no closer; a wrong term would be off by n |coef|), and
+    equal to the exact sum with the stored coefficients, which is zero but for those coefficients' rounding."""
+    from egc_amd import _C, functional as Fn
+    lib = _C.load()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(n + c)
+    h = (torch.randn(n, c, device=dev) * torch.logspace(-1, 1, c, device=dev) + torch.linspace(-3, 3, c, device=dev)).contiguous()
+    dout = torch.randn(n, c, device=dev)
+    gamma, beta = torch.rand(c, device=dev) + 0.5, torch.randn(c, device=dev)
+    n_parts = max(1, min(1024, (n + 127) // 128))
+    parts = torch.empty((n_parts, 2, c), dtype=torch.float64, device=dev)
+    stats = torch.empty((3, c), dtype=torch.float64, device=dev)
+    affine = torch.empty((2, c), dtype=torch.float32, device=dev)
+    stream = Fn._stream_ptr(dev)
+    _C.check(lib.egc_bn_forward_stats_f32(h.data_ptr(), n, c, parts.data_ptr(), n_parts, None, None, gamma.data_ptr(), beta.data_ptr(), 1e-5,
+                                          stats.data_ptr(), affine.data_ptr(), None, None, 0.1, None, None, stream), "egc_bn_forward_stats_f32")
+    out5 = torch.empty((5, c), dtype=torch.float32, device=dev)
+    sums = torch.full((c,), float("nan"), device=dev)
+    sync = torch.zeros(1, dtype=torch.int32, device=dev) if one_launch else None
+    _C.check(lib.egc_bn_backward_stats_sums_f32(dout.data_ptr(), h.data_ptr(), affine[0].data_ptr(), affine[1].data_ptr(), int(relu), None, 1.0, n, c,
+                                                parts.data_ptr(), n_parts, None, stats.data_ptr(), gamma.data_ptr(), out5.data_ptr(),
+                                                sums.data_ptr(), sync.data_ptr() if one_launch else None, stream), "egc_bn_backward_stats_sums_f32")
+    dh = torch.empty_like(h)
+    _C.check(lib.egc_affine_act_backward_f32(dout.data_ptr(), h.data_ptr(), affine[0].data_ptr(), affine[1].data_ptr(), int(relu), None, 1.0,
+                                             out5[2].data_ptr(), out5[3].data_ptr(), out5[4].data_ptr(), n, c, dh.data_ptr(), None, stream),
+             "egc_affine_act_backward_f32")
+    torch.cuda.synchronize()
+    ref = dh.double().sum(0)
+    # every dh element carries up to ~2 ulp of its three terms' sizes: |cg g| + |ch h| + |c1|
+    g = dout * ((h * affine[0] + affine[1]) > 0) if relu else dout
+    terms = (out5[2].abs() * g.abs() + out5[3].abs() * h.abs() + out5[4].abs()).double()
+    # (the roundings do not average out: adding coef_1 last is biased on structured data -- measured -6.6e-8 per element against an
+    # rms of 1.2e-7 at 52,771 x 224 with the ReLU mask -- so the float32 dh sums drift by up to half an ulp per ROW from the exact sum)
+    bound = 2.0 ** -24 * n * terms.max(0).values + 1e-30
+    assert bool(((sums.double() - ref).abs() <= bound).all()), float(((sums.double() - ref).abs() / bound).max())
+    # ... and the true value is zero: what is left is the rounding of the three float32 coefficients (coef_h h and coef_1 cancel
+    # where a channel's mean is large against its spread), a few ulp of the terms' total
+    assert bool((sums.double().abs() <= 2.0 ** -22 * terms.sum(0)).all()), float((sums.double().abs() / terms.sum(0)).max())
+    exact = out5[2].double() * g.double().sum(0) + out5[3].double() * h.double().sum(0) + n * out5[4].double()
+    assert bool(((sums.double() - exact).abs() <= 2.0 ** -40 * terms.sum(0) + 2.0 ** -23 * sums.double().abs()).all())
+    out5b = torch.empty_like(out5)
+    _C.check(lib.egc_bn_backward_stats_f32(dout.data_ptr(), h.data_ptr(), affine[0].data_ptr(), affine[1].data_ptr(), int(relu), None, 1.0, n, c,
+                                           parts.data_ptr(), n_parts, None, stats.data_ptr(), gamma.data_ptr(), out5b.data_ptr(), None, stream),
+             "egc_bn_backward_stats_f32")
+    assert torch.equal(out5, out5b)

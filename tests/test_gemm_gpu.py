@@ -179,6 +179,48 @@ def test_long_k_kernel_row_ranges_launched_separately(monkeypatch):
     _check(x, wcat, bcat, f_g, w_cols, *_transform(x, wcat, bcat, f_g, w_cols))
 
 
+# --- bases = x W + addend (egc_basis_transform_packed_add: the residual branch's gradient joining d x in the d x GEMM) ------------
+
+@pytest.mark.parametrize("n", [1, 16, 1000, 52771])
+@pytest.mark.parametrize("k,f", [(272, 224), (192, 296), (368, 304), (208, 352), (184, 136), (132, 100)])
+def test_gemm_addend_equals_gemm_then_add(n, k, f):
+    """out = x W + addend in the long-k kernels' store (both forms of the kernel, one and two launches over the column tiles) against
+    the plain call followed by a float32 add: the same bits (one rounding of the same two numbers); rows past the last full tile and
+    the padding columns of the last column tile included."""
+    from egc_amd import _C
+    lib = _C.load()
+    g = torch.Generator(device="cpu").manual_seed(n + k + f)
+    x = torch.randn(n, k, generator=g).to(DEV)
+    wt = torch.randn(f, k, generator=g).to(DEV)            # the transposed operand, as the d x GEMM has it
+    add = torch.randn(n, f, generator=g).to(DEV)
+    pb = int(lib.egc_basis_pack_bytes(k, f, 0))
+    packed = torch.empty(pb, dtype=torch.uint8, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    _C.check(lib.egc_basis_pack_transposed(wt.data_ptr(), k, k, f, 0, packed.data_ptr(), pb, st), "egc_basis_pack_transposed")
+    plain = torch.full((n, f), float("nan"), device=DEV)
+    _C.check(lib.egc_basis_transform_packed(x.data_ptr(), packed.data_ptr(), None, n, k, f, 0, plain.data_ptr(), f, None, st),
+             "egc_basis_transform_packed")
+    fused = torch.full((n, f), float("nan"), device=DEV)
+    rc = lib.egc_basis_transform_packed_add(x.data_ptr(), packed.data_ptr(), None, n, k, f, 0, 0, add.data_ptr(), fused.data_ptr(), f, None, st)
+    torch.cuda.synchronize()
+    assert rc == 0
+    assert torch.equal(fused, plain + add)
+    assert float((plain.double() - x.double() @ wt.double().t()).abs().max()) <= 1e-5 * float((x.double().abs() @ wt.double().abs().t()).max())
+
+
+def test_gemm_addend_outside_the_long_k_kernels_is_refused():
+    from egc_amd import _C
+    lib = _C.load()
+    n, k, f = 100, 128, 168                               # the 168-wide nets' d x GEMM: k = 96 + 32, not a long-k shape
+    x, add, out = torch.randn(n, k, device=DEV), torch.randn(n, f, device=DEV), torch.empty(n, f, device=DEV)
+    pb = int(lib.egc_basis_pack_bytes(k, f, 0))
+    packed = torch.empty(pb, dtype=torch.uint8, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    _C.check(lib.egc_basis_pack_transposed(torch.randn(f, k, device=DEV).data_ptr(), k, k, f, 0, packed.data_ptr(), pb, st), "pack")
+    assert lib.egc_basis_transform_packed_add(x.data_ptr(), packed.data_ptr(), None, n, k, f, 0, 0, add.data_ptr(), out.data_ptr(), f, None, st) == 4
+    assert lib.egc_basis_transform_packed_add(x.data_ptr(), packed.data_ptr(), None, n, k, f, 0, 0, None, out.data_ptr(), f, None, st) == 0
+
+
 # --- weight gradient x^T @ d + column sums (egc_weight_grad_f32, egc_gemm_xt.hip) ---------------------------------
 
 def _weight_grad(x, d, sums=True):

@@ -53,6 +53,17 @@ def test_native_binding_equals_the_ctypes_path_bit_for_bit(kind, aggrs, monkeypa
     assert _native.ops() is None
     assert torch.equal(a, b) and torch.equal(ap, bp)
 
+def _same_gradient(name, a, b, go):
+    """Bit for bit -- except the bias of a conv in front of a BatchNorm on batch statistics: its gradient is the column sum of the
+    BatchNorm's dh, zero but for rounding.  The Python Functions add dh up in float32 (as autograd does); the block node takes
+    coef_g sum g + coef_h sum h + n coef_1 from the sums its BatchNorm step already holds (egc_bn_backward_stats_sums_f32: held
+    against the float64 sum of the actual dh in tests/test_callers.py).  Both are noise around zero: the same to within it."""
+    if name.endswith("conv.bias"):
+        noise = 4e-6 * go.size(0) ** 0.5 * float(go.abs().max())
+        assert float(a.abs().max()) <= noise and float(b.abs().max()) <= noise, (name, float(a.abs().max()), float(b.abs().max()), noise)
+    else:
+        assert torch.equal(a, b), name
+
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["opt", "lay"])
@@ -95,13 +106,13 @@ def test_batch_block_train_node_equals_the_python_functions(kind, residual, monk
             h.backward(go.to(dev))
             gb.check()
         node = h.grad_fn.name() if h.grad_fn is not None else ""
-        res[mode] = (h.detach().clone(), x.grad.clone(), [p.grad.clone() for p in blocks.parameters()],
+        res[mode] = (h.detach().clone(), x.grad.clone(), [(k, p.grad.clone()) for k, p in blocks.named_parameters()],
                      [b.clone() for b in blocks.buffers() if b.dtype != torch.int32], node)
     assert "BatchBlockTrainFn" in res["native"][4] and "BatchBlockTrainFn" not in res["python"][4], (res["native"][4], res["python"][4])
     assert torch.equal(res["native"][0], res["python"][0])
     assert torch.equal(res["native"][1], res["python"][1])
-    for a, b in zip(res["native"][2], res["python"][2]):
-        assert torch.equal(a, b)
+    for (k, a), (_, b) in zip(res["native"][2], res["python"][2]):
+        _same_gradient(k, a, b, go)
     for a, b in zip(res["native"][3], res["python"][3]):
         assert torch.equal(a, b)
 
@@ -196,11 +207,11 @@ def test_csr_block_train_node_equals_the_python_functions(hidden, H, B, aggrs, a
             for b in blocks:
                 h = b(h, g)
             h.backward(go.to(dev))
-        res[mode] = (h.detach().clone(), x.grad.clone(), [p.grad.clone() for p in blocks.parameters()],
+        res[mode] = (h.detach().clone(), x.grad.clone(), [(k, p.grad.clone()) for k, p in blocks.named_parameters()],
                      [b.clone() for b in blocks.buffers() if b.dtype != torch.int32], h.grad_fn.name())
     assert "CsrBlockTrainFn" in res["native"][4] and "BlockTrainFn" not in res["python"][4], (res["native"][4], res["python"][4])
     assert torch.equal(res["native"][0], res["python"][0]) and torch.equal(res["native"][1], res["python"][1])
-    for a, b in zip(res["native"][2], res["python"][2]):
-        assert torch.equal(a, b)
+    for (k, a), (_, b) in zip(res["native"][2], res["python"][2]):
+        _same_gradient(k, a, b, go)
     for a, b in zip(res["native"][3], res["python"][3]):
         assert torch.equal(a, b)
