@@ -407,6 +407,7 @@ __global__ void __launch_bounds__(256) bwd_dst_kernel(BwdArgs a) {
 #endif
 constexpr int REC_ITEMS = 12;             // (value, column) pairs per record
 constexpr unsigned REC_OVERFLOW = 0xffu;  // dword 15: count, or this
+constexpr int REC_BALLOT_MAX = 8;         // entries of a one-row wavefront up to which the columns are ranked by ballots
 // record = 16 dwords: [0..11] values, [12..14] their columns (one byte each: ldb <= 256), [15] count
 
 struct RecArgs {
@@ -418,6 +419,38 @@ struct RecArgs {
   int n_nodes, ldb, slots, chunk_blocks, group_u32;
   int short_rows;      // 0: the destination kernel writes the short rows' records itself (bwd_dst_fast_kernel)
 };
+
+// Four lanes per entry, 16 bytes of its record each: a store instruction writes whole 64-byte lines (a lane per
+// record would touch 64 lines per instruction).  Parts 0..2: values o + 4 v .. + 3; part 3: the column bytes
+// o .. o + 11 (three dwords cut out of four aligned ones) and the count.
+template <int GS>
+__device__ inline void records_store(const unsigned* cnt, const unsigned* off, const unsigned* vals, const unsigned char* cols,
+                                     unsigned* rec0, int n_entries, int q) {
+  const int v = q & 3;
+  for (int e = q >> 2; e < n_entries; e += GS / 4) {
+    const unsigned cn = cnt[e], o = off[e];
+    const unsigned m = min(cn, (unsigned)REC_ITEMS);
+    const unsigned* src = v < 3 ? vals + o + 4 * v : reinterpret_cast<const unsigned*>(cols) + (o >> 2);
+    const unsigned d0 = src[0], d1 = src[1], d2 = src[2], d3 = src[3];
+    uint4 w;
+    if (v < 3) {
+      const unsigned i0 = 4 * v;
+      w = uint4{i0 < m ? d0 : 0u, i0 + 1 < m ? d1 : 0u, i0 + 2 < m ? d2 : 0u, i0 + 3 < m ? d3 : 0u};
+    } else {
+      const unsigned sh = o & 3u;
+      auto keep = [&](unsigned first) -> unsigned {   // bytes first .. first + 3 of the list that exist
+        return m >= first + 4 ? 0xffffffffu : m > first ? (1u << (8 * (m - first))) - 1u : 0u;
+      };
+      w = uint4{__builtin_amdgcn_alignbyte(d1, d0, sh) & keep(0), __builtin_amdgcn_alignbyte(d2, d1, sh) & keep(4),
+                __builtin_amdgcn_alignbyte(d3, d2, sh) & keep(8), cn <= (unsigned)REC_ITEMS ? cn : REC_OVERFLOW};
+    }
+#ifdef EGC_REC_NT_STORE
+    __builtin_nontemporal_store(w, reinterpret_cast<uint4*>(rec0 + (int64_t)e * 16) + v);
+#else
+    reinterpret_cast<uint4*>(rec0 + (int64_t)e * 16)[v] = w;
+#endif
+  }
+}
 
 // One lane group (GS lanes, NS slots of four columns per lane: slot q + k GS) builds the records of n_entries <= TS
 // consecutive entries of a destination row; rel[k][c] = the entry (relative to the first of them) that column
@@ -433,6 +466,42 @@ __device__ inline void records_from_columns(unsigned* lds, int ldb, unsigned* re
   unsigned* off = lds + TS;
   unsigned* vals = lds + 2 * TS;                                       // [ldb] values, sorted by entry
   unsigned char* cols = reinterpret_cast<unsigned char*>(vals + ldb);  // [ldb] their columns
+  // A whole wavefront on ONE row of a few entries (the 64-lane groups of the reference's wide nets on molecule batches: two to
+  // four entries per row): every column's place by ballots -- entry by entry, column slot by column slot, lanes ascending: the
+  // order the returning LDS atomics below produce, so the records are the same bits -- with the counts and offsets falling out
+  // of the same popcounts.  The atomics of such a row all land on two to four LDS words and run one lane per clock: 224 columns
+  // were ~260 cycles of a CU's LDS pipe per row, 22 of the 31 us this function cost at 224 / H4 / B4 on molhiv b2048 (round 6).
+  if constexpr (GS == 64 && NS == 1) {
+    const int ne = __builtin_amdgcn_readfirstlane(n_entries);
+    if (ne <= REC_BALLOT_MAX) {
+      unsigned pos[4] = {0u, 0u, 0u, 0u};
+      unsigned run = 0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (!((unsigned)rel[0][c] < (unsigned)ne)) rel[0][c] = -1;
+      for (int e = 0; e < ne; ++e) {
+        unsigned base = run;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const bool mine = rel[0][c] == e;
+          const unsigned long long mask = __ballot(mine);
+          const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+          if (mine) pos[c] = base + below;
+          base += (unsigned)__builtin_popcountll(mask);
+        }
+        if (lane == 0) { cnt[e] = base - run; off[e] = run; }
+        run = base;
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (rel[0][c] >= 0) {
+          vals[pos[c]] = __float_as_uint(xv[0][c]);
+          cols[pos[c]] = (unsigned char)(4 * q + c);
+        }
+      records_store<GS>(cnt, off, vals, cols, rec0, ne, q);
+      return;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < CPL; ++i) cnt[CPL * q + i] = 0u;
   unsigned rank[NS][4];
@@ -466,33 +535,7 @@ __device__ inline void records_from_columns(unsigned* lds, int ldb, unsigned* re
         vals[p] = __float_as_uint(xv[k][c]);
         cols[p] = (unsigned char)(4 * (q + k * GS) + c);
       }
-  // Four lanes per entry, 16 bytes of its record each: a store instruction writes whole 64-byte lines (a lane per
-  // record would touch 64 lines per instruction).  Parts 0..2: values o + 4 v .. + 3; part 3: the column bytes
-  // o .. o + 11 (three dwords cut out of four aligned ones) and the count.
-  const int v = q & 3;
-  for (int e = q >> 2; e < n_entries; e += GS / 4) {
-    const unsigned cn = cnt[e], o = off[e];
-    const unsigned m = min(cn, (unsigned)REC_ITEMS);
-    const unsigned* src = v < 3 ? vals + o + 4 * v : reinterpret_cast<const unsigned*>(cols) + (o >> 2);
-    const unsigned d0 = src[0], d1 = src[1], d2 = src[2], d3 = src[3];
-    uint4 w;
-    if (v < 3) {
-      const unsigned i0 = 4 * v;
-      w = uint4{i0 < m ? d0 : 0u, i0 + 1 < m ? d1 : 0u, i0 + 2 < m ? d2 : 0u, i0 + 3 < m ? d3 : 0u};
-    } else {
-      const unsigned sh = o & 3u;
-      auto keep = [&](unsigned first) -> unsigned {   // bytes first .. first + 3 of the list that exist
-        return m >= first + 4 ? 0xffffffffu : m > first ? (1u << (8 * (m - first))) - 1u : 0u;
-      };
-      w = uint4{__builtin_amdgcn_alignbyte(d1, d0, sh) & keep(0), __builtin_amdgcn_alignbyte(d2, d1, sh) & keep(4),
-                __builtin_amdgcn_alignbyte(d3, d2, sh) & keep(8), cn <= (unsigned)REC_ITEMS ? cn : REC_OVERFLOW};
-    }
-#ifdef EGC_REC_NT_STORE
-    __builtin_nontemporal_store(w, reinterpret_cast<uint4*>(rec0 + (int64_t)e * 16) + v);
-#else
-    reinterpret_cast<uint4*>(rec0 + (int64_t)e * 16)[v] = w;
-#endif
-  }
+  records_store<GS>(cnt, off, vals, cols, rec0, n_entries, q);
 }
 
 // the same from the (arg, X) rows in memory
@@ -773,8 +816,11 @@ __global__ void __launch_bounds__(256, EGC_BWD_DST_MINW) bwd_dst_fast_kernel(Bwd
   }
 
   // ---- d w': sum over the P lanes of a basis.  P a power of two: xor butterfly (every lane ends with the sum), then
-  // lane l4 keeps heads [l4 H/P, (l4+1) H/P); otherwise a segmented shift-down reduction (lane l4 = 0 ends with the
-  // sum) and that lane keeps every head
+  // lane l4 keeps heads [l4 H/P, (l4+1) H/P).  Otherwise (the reference's 168 / 224 / 296 / 136-wide nets: P = 6 / 14 / 10 / 9)
+  // the shares cross the group's LDS strip transposed: lane q writes its H A shares into rows of LPR + 1 floats, lane k of
+  // the group then adds the P shares of weighting k = (h B + b) A + t in lane order and stores d w'[k] -- one coalesced store
+  // per row.  (Round 6; before: a segmented shift-down reduction, 4 rounds x H A ds_bpermute + select + add, and a store per
+  // (head, aggregator) from one lane per basis -- 20 of the 87 us of this kernel at 224 / H4 / B4, 16 of 66 at 296 / H8 / B4.)
   if (p2) {
     for (int off = 1; off < P; off <<= 1) {
 #pragma unroll
@@ -785,38 +831,50 @@ __global__ void __launch_bounds__(256, EGC_BWD_DST_MINW) bwd_dst_fast_kernel(Bwd
             if (t < A) dwp[h][t] += __shfl_xor(dwp[h][t], off);
         }
     }
+    const int hpl = H >= P ? H / P : 1;   // heads per lane (host: P divides H, or H < P: lanes 0 .. H-1 keep one head each)
+#pragma unroll
+    for (int h = 0; h < HM; ++h) {
+      if (h >= H) break;
+      if (!(wr && h / hpl == l4)) continue;
+      const int k0 = (h * a.B + b) * A;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (t >= A) break;
+        float d = dwp[h][t];
+        const float w = lds_w[k0 + t];
+        if (AG::act(a) == EGC_ACT_SIGMOID) d = d * w * (1.0f - w);
+        else if (AG::act(a) == EGC_ACT_HARDTANH) {
+          const float pre = a.weightings[(int64_t)row * a.W + k0 + t];
+          d = (pre > -1.0f && pre < 1.0f) ? d : 0.f;
+        }
+        __builtin_nontemporal_store(d, &a.d_weightings[(int64_t)row * a.ld_dw + k0 + t]);
+      }
+    }
   } else {
-    for (int off = 1; off < P; off <<= 1) {
-      const bool take = l4 + off < P;
+    float* tr = lds_w + ((a.W + 3) & ~3);      // [H A][LPR + 1], behind the strips of g and w' (the host sized the group for it)
+    constexpr int TP = LPR + 1;
+    if (live) {
 #pragma unroll
       for (int h = 0; h < HM; ++h)
         if (h < H) {
 #pragma unroll
           for (int t = 0; t < 4; ++t)
-            if (t < A) {
-              const float o = __shfl_down(dwp[h][t], off);
-              dwp[h][t] += take ? o : 0.f;
-            }
+            if (t < A) tr[(h * A + t) * TP + q] = dwp[h][t];
         }
     }
-  }
-  const int hpl = H >= P ? H / P : 1;   // heads per lane (host: P divides H, or H < P: lanes 0 .. H-1 keep one head each)
-#pragma unroll
-  for (int h = 0; h < HM; ++h) {
-    if (h >= H) break;
-    if (!(wr && (p2 ? h / hpl == l4 : l4 == 0))) continue;
-    const int k0 = (h * a.B + b) * A;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      if (t >= A) break;
-      float d = dwp[h][t];
-      const float w = lds_w[k0 + t];
+    const int blog = 31 - __builtin_clz(a.B);  // B is a power of two (host)
+    for (int k = q; k < a.W; k += LPR) {
+      const int hb = k / A, t = k - hb * A, hh = hb >> blog, bb = hb & (a.B - 1);
+      const float* src = tr + (hh * A + t) * TP + bb * P;
+      float d = 0.f;
+      for (int i = 0; i < P; ++i) d += src[i];
+      const float w = lds_w[k];
       if (AG::act(a) == EGC_ACT_SIGMOID) d = d * w * (1.0f - w);
       else if (AG::act(a) == EGC_ACT_HARDTANH) {
-        const float pre = a.weightings[(int64_t)row * a.W + k0 + t];
+        const float pre = a.weightings[(int64_t)rr * a.W + k];
         d = (pre > -1.0f && pre < 1.0f) ? d : 0.f;
       }
-      __builtin_nontemporal_store(d, &a.d_weightings[(int64_t)row * a.ld_dw + k0 + t]);
+      if (row_ok) __builtin_nontemporal_store(d, &a.d_weightings[(int64_t)row * a.ld_dw + k]);
     }
   }
 
@@ -1313,7 +1371,8 @@ int egc_aggregate_combine_backward_f32(const egc_graph* graph, const egc_graph* 
       a.rec_fused = a.rec_bytes != 0 && getenv("EGC_BWD_REC_SEPARATE") == nullptr;
       // per lane group: the strips of g and w'; afterwards the record builder's count | offset | values | column bytes
       // (64 entries per group in the row role; 256 per WAVEFRONT in the hub-chunk role of the trailing blocks)
-      a.dst_group_floats = std::max(((a.H * a.Ls + 3) & ~3) + ((a.W + 3) & ~3),
+      // (+ the transposed d w' shares of a basis that is not a power-of-two number of lanes wide: [H A][lpr + 1])
+      a.dst_group_floats = std::max(((a.H * a.Ls + 3) & ~3) + ((a.W + 3) & ~3) + (p2 ? 0 : a.H * a.A * (lpr + 1)),
                                     a.rec_fused ? std::max(128 + a.ldb + a.ldb / 4 + 4, (512 + a.ldb + a.ldb / 4 + 4 + G - 1) / G) : 0);
       const size_t flds = (size_t)4 * G * a.dst_group_floats * sizeof(float);
       a.dst_row_blocks = (int)ceil_div(n, (int64_t)4 * G);
