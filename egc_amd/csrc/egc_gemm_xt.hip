@@ -554,7 +554,7 @@ constexpr int XT_STAGE = 32;  // rows of the reduction per LDS stage
 // as 64-row tiles): round 6, DESIGN.md 3.7.
 struct XtShape { int mt, nt, wn; };
 constexpr XtShape XT_SHAPES[] = {{1, 1, 4}, {1, 2, 4}, {1, 3, 4}, {2, 1, 4}, {2, 2, 4}, {2, 3, 4}, {4, 1, 4}, {4, 2, 4}, {4, 3, 4},
-                                 {5, 2, 4}, {5, 3, 4}, {7, 2, 4}, {7, 3, 3}, {7, 3, 4}, {7, 5, 4}};
+                                 {5, 2, 4}, {5, 3, 4}, {7, 2, 4}, {7, 3, 3}, {7, 3, 4}, {7, 5, 4}, {7, 3, 6}};
 
 // EGC_GEMM_EXACT=1 (the switch of the forward GEMMs): exact fp32 products on the fp32 MFMA
 // instead of the split-bf16 form
@@ -696,12 +696,12 @@ static int weight_grad_impl(const float* x, int64_t ldx, const float* d, int64_t
     rc = EGC_OK;
   } else {
 #define EGC_XT_CASE(MT, NT, WN) \
-  if (p.mt == MT && p.nt == NT && p.wn == WN) rc = launch_xt<MT, NT, WN, (MT * NT > 21 ? XT_STAGE / 2 : XT_STAGE)>(p, x, ldx, f_in, d, ldd, k_cols, n_rows, partial, want_sums, stream);
+  if (p.mt == MT && p.nt == NT && p.wn == WN) rc = launch_xt<MT, NT, WN, ((MT * NT > 21 || WN > 4) ? XT_STAGE / 2 : XT_STAGE)>(p, x, ldx, f_in, d, ldd, k_cols, n_rows, partial, want_sums, stream);
   EGC_XT_CASE(1, 1, 4) EGC_XT_CASE(1, 2, 4) EGC_XT_CASE(1, 3, 4)
   EGC_XT_CASE(2, 1, 4) EGC_XT_CASE(2, 2, 4) EGC_XT_CASE(2, 3, 4)
   EGC_XT_CASE(4, 1, 4) EGC_XT_CASE(4, 2, 4) EGC_XT_CASE(4, 3, 4)
   EGC_XT_CASE(5, 2, 4) EGC_XT_CASE(5, 3, 4)
-  EGC_XT_CASE(7, 2, 4) EGC_XT_CASE(7, 3, 3) EGC_XT_CASE(7, 3, 4) EGC_XT_CASE(7, 5, 4)
+  EGC_XT_CASE(7, 2, 4) EGC_XT_CASE(7, 3, 3) EGC_XT_CASE(7, 3, 4) EGC_XT_CASE(7, 5, 4) EGC_XT_CASE(7, 3, 6)
 #undef EGC_XT_CASE
   }
   if (rc != EGC_OK) return rc;

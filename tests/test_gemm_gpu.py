@@ -257,7 +257,7 @@ def test_weight_grad_matches_float64(n, f, k):
 
 
 XT_TILES = [(1, 1, 4), (1, 2, 4), (1, 3, 4), (2, 1, 4), (2, 2, 4), (2, 3, 4), (4, 1, 4), (4, 2, 4), (4, 3, 4), (5, 2, 4), (5, 3, 4),
-            (7, 2, 4), (7, 3, 3), (7, 3, 4), (7, 5, 4)]
+            (7, 2, 4), (7, 3, 3), (7, 3, 4), (7, 5, 4), (7, 3, 6)]
 
 
 @pytest.mark.parametrize("tile", XT_TILES, ids=lambda t: "%dx%d" % (32 * t[0], 16 * t[2] * t[1]))

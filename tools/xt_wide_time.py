@@ -36,7 +36,7 @@ def timed(fn, reps=100):
 
 
 TILES = [(1, 1, 4), (1, 2, 4), (1, 3, 4), (2, 1, 4), (2, 2, 4), (2, 3, 4), (4, 1, 4), (4, 2, 4), (4, 3, 4), (5, 2, 4), (5, 3, 4), (7, 2, 4),
-         (7, 3, 3), (7, 3, 4), (7, 5, 4)]
+         (7, 3, 3), (7, 3, 4), (7, 5, 4), (7, 3, 6)]
 
 
 def plan(n, f, k):
