@@ -223,13 +223,13 @@ static std::vector<at::Tensor> train_backward_impl(const at::Tensor& grad_out, c
       check_status(rc, "egc_basis_transform_packed_add");
     }
   }
-  // (3) the dense gradients of the parameters.  Inside the one-pass kernel's envelope (f_in <= 128, ldb + W <= 192, f_out <= 128):
-  // x^T d_cat with the column sums of d_cat (combination bias) and of grad_out (the layer's bias) in one pass, written straight
-  // into the parameters' gradients through the pack's index map (egc_weight_grad_params_f32): no d wcat, no unpack.  Outside it
-  // (round 6: the reference's own batched nets -- 168 / 224 / 296 wide, run_pretrained.sh:7,12,23,24 -- and every other shape the
-  // library's GEMMs take): x^T d_cat + the column sums of d_cat (egc_weight_grad_ex_f32), the column sums of grad_out
-  // (egc_column_sums_f32 + egc_sum_partials_f32), and the pack's index map read backwards (egc_weights_pack_f32, grad = 1) --
-  // the calls egc_amd/functional.py's _layer_train_backward + _unpack_param_grads make, in their order.
+  // (3) the dense gradients of the parameters: x^T d_cat with the column sums of d_cat (combination bias), written straight into
+  // the parameters' gradients through the pack's index map (egc_weight_grad_params_f32: no d wcat array, no unpack launch), at
+  // every width (round 6: the reference's own batched nets -- 168 / 224 / 296 wide, run_pretrained.sh:7,12,23,24 -- go through
+  // the exact-fp32 tile grid; same sums in the same order as egc_weight_grad_ex_f32 + egc_weights_pack_f32(grad = 1), the calls
+  // of egc_amd/functional.py's _layer_train_backward + _unpack_param_grads).  The column sums of grad_out (the layer's bias) ride
+  // along inside the one-tile kernel's envelope (f_in <= 128, ldb + W <= 192, f_out <= 128), come from the caller when it holds
+  // them (the block node's BatchNorm step), or take their own pass.
   const bool have_es = bias_grad != nullptr;
   at::Tensor es = have_es ? *bias_grad : at::empty({f_out}, opts);
   at::Tensor dcw = at::empty(comb_w_shape, opts);
@@ -241,38 +241,25 @@ static std::vector<at::Tensor> train_backward_impl(const at::Tensor& grad_out, c
     dparts.push_back(at::empty(part_shape, opts));
     ptrs.push_back(dparts.back().data_ptr<float>());
   }
-  const bool one_pass = f_in <= 128 && k <= 192 && f_out <= 128 && (f_out % 4) == 0;
-  if (one_pass) {
-    const int64_t gbytes = (int64_t)egc_weight_grad_ex_workspace_bytes(n, (int32_t)f_in, (int32_t)k, (int32_t)f_out);
+  // e rides along only in the one-tile kernel (f_in <= 128, ldb + W <= 192) and for at most 128 columns
+  const bool ride = !have_es && f_in <= 128 && k <= 192 && f_out <= 128 && (f_out % 4) == 0;
+  {
+    const int64_t gbytes = (int64_t)egc_weight_grad_ex_workspace_bytes(n, (int32_t)f_in, (int32_t)k, ride ? (int32_t)f_out : 0);
     at::Tensor gws = at::empty({std::max<int64_t>(gbytes, 16)}, opts.dtype(at::kByte));
     check_status(egc_weight_grad_params_f32(x.data_ptr<float>(), f_in, d_cat.data_ptr<float>(), k, n, (int32_t)f_in, (int32_t)H,
                                             (int32_t)A, (int32_t)B, (int32_t)L, (int32_t)Ls, permute_hab ? 1 : 0, ptrs.data(),
                                             (int32_t)n_parts, dcw.data_ptr<float>(), packed_bias ? dcb.data_ptr<float>() : nullptr,
-                                            packed_bias ? nullptr : dcb.data_ptr<float>(), have_es ? nullptr : go.data_ptr<float>(), f_out,
-                                            have_es ? 0 : (int32_t)f_out, have_es ? nullptr : es.data_ptr<float>(), gws.data_ptr(), gws.numel(), st),
+                                            packed_bias ? nullptr : dcb.data_ptr<float>(), ride ? go.data_ptr<float>() : nullptr, f_out,
+                                            ride ? (int32_t)f_out : 0, ride ? es.data_ptr<float>() : nullptr, gws.data_ptr(), gws.numel(), st),
                  "egc_weight_grad_params_f32");
-  } else {
-    at::Tensor dwcat = at::empty({f_in, k}, opts), cs = at::empty({k}, opts);
-    const int64_t gbytes = (int64_t)egc_weight_grad_ex_workspace_bytes(n, (int32_t)f_in, (int32_t)k, 0);
-    at::Tensor gws = at::empty({std::max<int64_t>(gbytes, 16)}, opts.dtype(at::kByte));
-    check_status(egc_weight_grad_ex_f32(x.data_ptr<float>(), f_in, d_cat.data_ptr<float>(), k, n, (int32_t)f_in, (int32_t)k,
-                                        dwcat.data_ptr<float>(), cs.data_ptr<float>(), nullptr, 0, 0, nullptr, gws.data_ptr(), gws.numel(),
-                                        st), "egc_weight_grad_ex_f32");
-    if (!have_es) {
-      const int64_t parts = std::max<int64_t>(1, std::min<int64_t>(1024, (n + 127) / 128));
-      at::Tensor psum = at::empty({parts, f_out}, opts);
-      check_status(egc_column_sums_f32(go.data_ptr<float>(), n, (int32_t)f_out, (int32_t)f_out, psum.data_ptr<float>(), (int32_t)parts, st),
-                   "egc_column_sums_f32");
-      if (parts == 1) es = psum[0];
-      else check_status(egc_sum_partials_f32(psum.data_ptr<float>(), (int32_t)parts, (int32_t)f_out, es.data_ptr<float>(), st), "egc_sum_partials_f32");
-    }
-    // d bcat = the weightings part of d_cat's column sums: through the pack's row permutation for a module bias (EGConv), as it is
-    // for a bias already in the operand's order (EfficientGraphConv)
-    float* dbc = cs.data_ptr<float>() + (k - W);
-    check_status(egc_weights_pack_f32(ptrs.data(), (int32_t)n_parts, dcw.data_ptr<float>(), packed_bias ? dcb.data_ptr<float>() : nullptr,
-                                      (int32_t)f_in, (int32_t)H, (int32_t)A, (int32_t)B, (int32_t)L, (int32_t)Ls, permute_hab ? 1 : 0,
-                                      dwcat.data_ptr<float>(), packed_bias ? dbc : nullptr, 1, st), "egc_weights_pack_f32");
-    if (!packed_bias) dcb = cs.slice(0, k - W, k).contiguous();
+  }
+  if (!have_es && !ride) {      // the layer's bias gradient on its own: the column sums of grad_out
+    const int64_t parts = std::max<int64_t>(1, std::min<int64_t>(1024, (n + 127) / 128));
+    at::Tensor psum = at::empty({parts, f_out}, opts);
+    check_status(egc_column_sums_f32(go.data_ptr<float>(), n, (int32_t)f_out, (int32_t)f_out, psum.data_ptr<float>(), (int32_t)parts, st),
+                 "egc_column_sums_f32");
+    if (parts == 1) es = psum[0];
+    else check_status(egc_sum_partials_f32(psum.data_ptr<float>(), (int32_t)parts, (int32_t)f_out, es.data_ptr<float>(), st), "egc_sum_partials_f32");
   }
   std::vector<at::Tensor> out{dx, dcw, dcb, es};
   out.insert(out.end(), dparts.begin(), dparts.end());

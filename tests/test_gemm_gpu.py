@@ -345,6 +345,49 @@ def test_pack_transposed_equals_pack(f_in, f_g, w_cols):
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("n", [7, 3000, 52771])
+@pytest.mark.parametrize("f_in,H,A,B,L,Ls,n_parts", [(224, 4, 3, 4, 56, 56, 4), (296, 8, 1, 4, 37, 40, 4), (168, 8, 1, 4, 21, 24, 4), (304, 8, 1, 8, 38, 40, 1)])
+def test_weight_grad_params_at_the_wide_nets_shapes(n, f_in, H, A, B, L, Ls, n_parts):
+    """The same entry point beyond one accumulator tile (the exact-fp32 tile grid; round 6: the compiled training nodes write the
+    reference's wide nets' parameter gradients through it): == egc_weight_grad_ex_f32 + the gradient unpack, bit for bit, no third
+    array (that rides only in the one-tile kernel: EGC_ERR_UNSUPPORTED)."""
+    import ctypes as C
+    from egc_amd import _C
+    lib = _C.load()
+    torch.manual_seed(n + f_in)
+    W, f_g = H * B * A, B * Ls
+    k = f_g + W
+    x = torch.randn(n, f_in, device=DEV)
+    d = torch.randn(n, k, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    nb = lib.egc_weight_grad_ex_workspace_bytes(n, f_in, k, 0)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=DEV)
+    part_shape = (f_in, B * L) if n_parts == 1 else (f_in, L)
+
+    def fresh():
+        return ([torch.full(part_shape, float("nan"), device=DEV) for _ in range(n_parts)],
+                torch.full((W, f_in), float("nan"), device=DEV), torch.full((W,), float("nan"), device=DEV))
+    dwcat, cs = torch.empty(f_in, k, device=DEV), torch.empty(k, device=DEV)
+    _C.check(lib.egc_weight_grad_ex_f32(x.data_ptr(), f_in, d.data_ptr(), k, n, f_in, k, dwcat.data_ptr(), cs.data_ptr(), None, 0, 0, None,
+                                        ws.data_ptr(), ws.numel(), st), "ex")
+    parts_a, cw_a, cb_a = fresh()
+    ptrs = (C.c_void_p * n_parts)(*[p.data_ptr() for p in parts_a])
+    dbcat = cs[f_g:].contiguous()
+    _C.check(lib.egc_weights_pack_f32(ptrs, n_parts, cw_a.data_ptr(), None, f_in, H, A, B, L, Ls, 0, dwcat.data_ptr(), None, 1, st), "unpack")
+    parts_b, cw_b, cb_b = fresh()
+    ptrs_b = (C.c_void_p * n_parts)(*[p.data_ptr() for p in parts_b])
+    _C.check(lib.egc_weight_grad_params_f32(x.data_ptr(), f_in, d.data_ptr(), k, n, f_in, H, A, B, L, Ls, 0, ptrs_b, n_parts, cw_b.data_ptr(), None,
+                                            cb_b.data_ptr(), None, 0, 0, None, ws.data_ptr(), ws.numel(), st), "params")
+    torch.cuda.synchronize()
+    for a, b in zip(parts_a + [cw_a, dbcat], parts_b + [cw_b, cb_b]):
+        assert torch.equal(a, b) and not torch.isnan(b).any()
+    e = torch.randn(n, 128, device=DEV)
+    es = torch.empty(128, device=DEV)
+    ws2 = torch.empty(max(lib.egc_weight_grad_ex_workspace_bytes(n, f_in, k, 128), 16), dtype=torch.uint8, device=DEV)
+    assert lib.egc_weight_grad_params_f32(x.data_ptr(), f_in, d.data_ptr(), k, n, f_in, H, A, B, L, Ls, 0, ptrs_b, n_parts, cw_b.data_ptr(), None,
+                                          cb_b.data_ptr(), e.data_ptr(), 128, 128, es.data_ptr(), ws2.data_ptr(), ws2.numel(), st) == 4
+
+
 @pytest.mark.parametrize("n", [5, 1000, 40001])
 @pytest.mark.parametrize("f_in,H,A,B,L,Ls,permute,n_parts", [
     (128, 8, 4, 4, 16, 16, True, 1),      # EGConv north star: one [F_in, B L] basis matrix, Linear rows [h][a][b]
