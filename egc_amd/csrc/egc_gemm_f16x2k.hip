@@ -341,13 +341,18 @@ __global__ void __launch_bounds__(WAVES * 64) basis_gemm_f16x2k_kernel(const flo
 // `nh` further wavefronts only move x: LDS-DMA requests `ring` tiles ahead, the fp16x2 split of tile t + 1 while tile t is
 // being multiplied (their registers are free: each row's pieces are read once and kept).  Same numerics, same packed weights.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int KS, int WAVES>
+// TPW (round 6): column tiles per multiplier wavefront.  Two (32 columns, 16 KS weight registers: K <= 224 at twelve wavefronts) let ONE
+// launch cover the 17 - 20 column tiles of the reference's 224-wide forward GEMM (224 + 48 columns) and 296-wide d x GEMM, which
+// sixteen single-tile wavefronts cannot: x is read once, the per-tile pipeline (a barrier, a split, the LDS round trips of the
+// operands) runs once instead of once per launch, and both tiles' products share every operand read.  `ntl`: column tiles of
+// this launch; the multipliers are wavefronts [0, nmf), nmf = ceil(ntl / TPW).  Per tile the same products in the same order.
+template <int KS, int WAVES, int TPW = 1>
 __global__ void __launch_bounds__(WAVES * 64) basis_gemm_f16x2k_spec_kernel(const float* __restrict__ x, const u16* __restrict__ packed,
                                                                            const float* __restrict__ bcat, int64_t M, int K,
                                                                            KCols c, float* __restrict__ bases,
                                                                            float* __restrict__ weightings, int n_tiles, int LDX,
                                                                            int R, int slot_bytes, int tile0, int ring, int nmf,
-                                                                           const float* __restrict__ addend) {
+                                                                           const float* __restrict__ addend, int ntl) {
   extern __shared__ __attribute__((aligned(16))) char smem_k[];
   char* raw = smem_k;                                                    // [ring][slot_bytes] raw fp32 tiles (DMA ring)
   u16* xs = reinterpret_cast<u16*>(smem_k + ring * slot_bytes);          // [2 buffers][2 planes][KROWS][LDX] fp16
@@ -515,31 +520,46 @@ __global__ void __launch_bounds__(WAVES * 64) basis_gemm_f16x2k_spec_kernel(cons
   }
 
   // ================= the multipliers =================
-  const int ct = tile0 + wave;
   const int j = lane & 15, quad = lane >> 4;
-  f16x8k wf[KS][2];
-  {
-    const u16* src = packed + ((int64_t)ct * KS * 2 * 64 + lane) * 8;
+  constexpr unsigned GOOB = 0xFFFFFFF0u;
+  int ct[TPW];
+  bool live[TPW];
+#pragma unroll
+  for (int u = 0; u < TPW; ++u) {
+    live[u] = wave * TPW + u < ntl;                                    // (an odd tile count leaves the last wavefront's second tile idle:
+    ct[u] = tile0 + (live[u] ? wave * TPW + u : wave * TPW);           //  it repeats its first tile and stores nothing)
+  }
+  f16x8k wf[TPW][KS][2];
+#pragma unroll
+  for (int u = 0; u < TPW; ++u) {
+    const u16* src = packed + ((int64_t)ct[u] * KS * 2 * 64 + lane) * 8;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      wf[s][0] = *reinterpret_cast<const f16x8k*>(src + (s * 2) * 64 * 8);
-      wf[s][1] = *reinterpret_cast<const f16x8k*>(src + (s * 2 + 1) * 64 * 8);
+      wf[u][s][0] = *reinterpret_cast<const f16x8k*>(src + (s * 2) * 64 * 8);
+      wf[u][s][1] = *reinterpret_cast<const f16x8k*>(src + (s * 2 + 1) * 64 * 8);
     }
   }
-  constexpr unsigned GOOB = 0xFFFFFFF0u;
-  const bool to_bases = ct < c.TB;
-  const int out_ld = to_bases ? c.ldb : c.W;
-  const int col0 = to_bases ? 16 * ct + 4 * quad : 16 * (ct - c.TB) + 4 * quad;
-  const int lim = to_bases ? c.ldb : c.W;
-  float* outp = to_bases ? bases : weightings;
-  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, (unsigned)(M * out_ld * 4), 0x00020000);
-  const bool vec_store = (out_ld & 3) == 0;
-  // `addend`: as in the kernel above; the multipliers issue no DMA, so the compiler's own count of this load is right
-  const bool add = addend != nullptr && to_bases;    // wave-uniform
-  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(add ? addend : outp), 0, add ? (unsigned)(M * out_ld * 4) : 0u, 0x00020000);
+  bool to_bases[TPW], vec_store[TPW], add[TPW];
+  int out_ld[TPW], col0[TPW], lim[TPW];
+  __amdgpu_buffer_rsrc_t ro[TPW], ra[TPW];
+#pragma unroll
+  for (int u = 0; u < TPW; ++u) {
+    to_bases[u] = ct[u] < c.TB;
+    out_ld[u] = to_bases[u] ? c.ldb : c.W;
+    col0[u] = to_bases[u] ? 16 * ct[u] + 4 * quad : 16 * (ct[u] - c.TB) + 4 * quad;
+    lim[u] = live[u] ? (to_bases[u] ? c.ldb : c.W) : 0;                // (an idle tile: every column out of range)
+    float* outp = to_bases[u] ? bases : weightings;
+    ro[u] = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, (unsigned)(M * out_ld[u] * 4), 0x00020000);
+    vec_store[u] = (out_ld[u] & 3) == 0;
+    // `addend`: as in the kernel above; the multipliers issue no DMA, so the compiler's own count of this load is right
+    add[u] = addend != nullptr && to_bases[u] && live[u];              // wave-uniform
+    ra[u] = __builtin_amdgcn_make_buffer_rsrc((void*)(add[u] ? addend : outp), 0, add[u] ? (unsigned)(M * out_ld[u] * 4) : 0u, 0x00020000);
+  }
   vmwait_k<0>();
 #pragma unroll
-  for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(wf[s][0]), "+v"(wf[s][1]));
+  for (int u = 0; u < TPW; ++u)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(wf[u][s][0]), "+v"(wf[u][s][1]));
   lds_barrier_k();
   int cur = 0;
 #ifdef EGC_GEMMK_STAMPS
@@ -551,16 +571,20 @@ __global__ void __launch_bounds__(WAVES * 64) basis_gemm_f16x2k_spec_kernel(cons
   for (; tile < n_tiles; tile += stride) {
     lds_barrier_k();
     KST(4)
-    f32x4k av = {0.f, 0.f, 0.f, 0.f};
-    if (add) {
-      const int64_t arow = (int64_t)tile * KROWS + j;
-      av = __builtin_bit_cast(f32x4k, __builtin_amdgcn_raw_buffer_load_b128(ra, (arow < M && col0 + 3 < lim) ? (unsigned)((arow * out_ld + col0) * 4) : GOOB, 0, 0));
+    f32x4k av[TPW], acc0[TPW], acc1[TPW];
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+      av[u] = acc0[u] = acc1[u] = f32x4k{0.f, 0.f, 0.f, 0.f};
+      if (add[u]) {
+        const int64_t arow = (int64_t)tile * KROWS + j;
+        av[u] = __builtin_bit_cast(f32x4k, __builtin_amdgcn_raw_buffer_load_b128(
+                                               ra[u], (arow < M && col0[u] + 3 < lim[u]) ? (unsigned)((arow * out_ld[u] + col0[u]) * 4) : GOOB, 0, 0));
+      }
     }
-    f32x4k acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     const u16* xb = xs + cur * 2 * KROWS * LDX + j * LDX + 8 * quad;
     // PF operand sets in rotation: the operands of k-step s + PF - 1 are requested before the products of k-step s, and the
     // order is pinned (left alone the scheduler folds the sets back into one and waits for a read two MFMAs after issuing it)
-    constexpr int PF = 3;
+    constexpr int PF = TPW == 1 ? 3 : 2;      // (two tiles: six products per operand pair, and the registers are the weights')
     f16x8k xh[PF], xl[PF];
 #pragma unroll
     for (int p = 0; p < PF - 1; ++p)
@@ -575,33 +599,39 @@ __global__ void __launch_bounds__(WAVES * 64) basis_gemm_f16x2k_spec_kernel(cons
         xl[(s + PF - 1) % PF] = *reinterpret_cast<const f16x8k*>(xb + KROWS * LDX + 32 * (s + PF - 1));
       }
       __builtin_amdgcn_sched_barrier(0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[s][0], xh[s % PF], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[s][0], xl[s % PF], acc1, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[s][1], xh[s % PF], acc1, 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < TPW; ++u) acc0[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[u][s][0], xh[s % PF], acc0[u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < TPW; ++u) acc1[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[u][s][0], xl[s % PF], acc1[u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < TPW; ++u) acc1[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[u][s][1], xh[s % PF], acc1[u], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     KST(5)
     const float ri = row_inv[cur * KROWS + j];
-    f32x4k cinv, cbias;
-    {
-      const float* ci = colinfo + 2 * (16 * ct + 4 * quad);
-      const f32x4k c01 = *reinterpret_cast<const f32x4k*>(ci), c23 = *reinterpret_cast<const f32x4k*>(ci + 4);
-      cinv = f32x4k{c01[0], c01[2], c23[0], c23[2]};
-      cbias = f32x4k{c01[1], c01[3], c23[1], c23[3]};
-    }
     const int64_t grow = (int64_t)tile * KROWS + j;
-    f32x4k o;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] = __builtin_fmaf(__builtin_fmaf(acc1[r], 1.f / 2048.f, acc0[r]), cinv[r] * ri, cbias[r]);
     const bool row_ok = grow < M;
-    const unsigned off = (unsigned)((grow * out_ld + col0) * 4);
-    if (add) o += av;
-    if (vec_store) {
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4k, o), ro, (row_ok && col0 + 3 < lim) ? off : GOOB, 0, 0);
-    } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o[r]), ro, (row_ok && col0 + r < lim) ? off + 4u * r : GOOB, 0, 0);
+    for (int u = 0; u < TPW; ++u) {
+      f32x4k cinv, cbias;
+      {
+        const float* ci = colinfo + 2 * (16 * ct[u] + 4 * quad);
+        const f32x4k c01 = *reinterpret_cast<const f32x4k*>(ci), c23 = *reinterpret_cast<const f32x4k*>(ci + 4);
+        cinv = f32x4k{c01[0], c01[2], c23[0], c23[2]};
+        cbias = f32x4k{c01[1], c01[3], c23[1], c23[3]};
+      }
+      f32x4k o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = __builtin_fmaf(__builtin_fmaf(acc1[u][r], 1.f / 2048.f, acc0[u][r]), cinv[r] * ri, cbias[r]);
+      const unsigned off = (unsigned)((grow * out_ld[u] + col0[u]) * 4);
+      if (add[u]) o += av[u];
+      if (vec_store[u]) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4k, o), ro[u], (row_ok && col0[u] + 3 < lim[u]) ? off : GOOB, 0, 0);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o[r]), ro[u], (row_ok && col0[u] + r < lim[u]) ? off + 4u * r : GOOB, 0, 0);
+      }
     }
     KST(6)
     cur ^= 1;
@@ -694,7 +724,7 @@ static int launch_k(const float* x, const u16* packed, const float* bcat, int64_
       int grid = 256;
       if (grid > n_tiles) grid = n_tiles;
       kern<<<grid, (ntl + nh) * 64, lds, stream>>>(x, packed, bcat, M, K, c, bases, weightings, n_tiles, LDX, R, slot_bytes, tile0, ring,
-                                                   ntl, addend);
+                                                   ntl, addend, ntl);
       EGC_LAUNCH_CHECK("basis_gemm_f16x2k_spec_kernel");
 #ifdef EGC_GEMMK_STAMPS
       {
@@ -748,9 +778,50 @@ static int launch_k(const float* x, const u16* packed, const float* bcat, int64_
   return EGC_OK;
 }
 
+// One launch over ALL column tiles with two tiles per multiplier wavefront (K <= 224: 16 KS weight registers fit twelve wavefronts):
+// ceil(NT / 2) multipliers + the helpers that move and split x.  EGC_ERR_UNSUPPORTED where the tile ring does not fit.
+template <int KS>
+static int launch_k2(const float* x, const u16* packed, const float* bcat, int64_t M, int K, const KCols& c, float* bases,
+                     float* weightings, hipStream_t stream, const float* addend) {
+  constexpr int WAVES = 12;
+  const int64_t n_tiles64 = ceil_div(M, KROWS);
+  if (n_tiles64 >= ((int64_t)1 << 31)) return EGC_ERR_INVALID;
+  const int n_tiles = (int)n_tiles64;
+  const int LDX = 32 * KS + 16;
+  const size_t fixed = (size_t)4 * KROWS * LDX * sizeof(u16) + (2 * KROWS + 2 * 16 * c.NT) * sizeof(float);
+  const int nmf = (c.NT + 1) / 2, nh = WAVES - nmf;
+  if (nh < 2) return EGC_ERR_UNSUPPORTED;
+  const int hthreads = nh * 64;
+  const int R = (int)ceil_div((int64_t)KROWS * (K / 4), hthreads);
+  const int slot_bytes = R * hthreads * 16;
+  int ring = (int)std::min<size_t>(4, ((size_t)160 * 1024 - fixed) / (size_t)slot_bytes);
+  while (ring > 2 && (ring - 2) * R > 32) --ring;
+  if (ring < 2 || R > 16) return EGC_ERR_UNSUPPORTED;
+  const size_t lds = (size_t)ring * slot_bytes + fixed;
+  auto kern = &basis_gemm_f16x2k_spec_kernel<KS, WAVES, 2>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) { set_last_error("hipFuncSetAttribute(f16x2k spec, two tiles)", e); return EGC_ERR_HIP; }
+    attr_set = true;
+  }
+  int grid = 256;
+  if (grid > n_tiles) grid = n_tiles;
+  kern<<<grid, WAVES * 64, lds, stream>>>(x, packed, bcat, M, K, c, bases, weightings, n_tiles, LDX, R, slot_bytes, 0, ring, nmf, addend, c.NT);
+  EGC_LAUNCH_CHECK("basis_gemm_f16x2k_spec_kernel (two tiles per wavefront)");
+  return EGC_OK;
+}
+
 template <int KS>
 static int launch_ks(const float* x, const u16* packed, const float* bcat, int64_t M, int K, const KCols& c, float* bases,
                      float* weightings, hipStream_t stream, const float* addend) {
+  if constexpr (KS <= 7) {
+    // 17 - 20 column tiles (224 / H4 / B4 with three aggregators forward: 14 + 3; the d x GEMM of 296 / H8 / B4: 19): ONE launch
+    if (c.NT > 16 && c.NT <= 20) {
+      const int st = launch_k2<KS>(x, packed, bcat, M, K, c, bases, weightings, stream, addend);
+      if (st != EGC_ERR_UNSUPPORTED) return st;
+    }
+  }
   // more than 16 column tiles (e.g. 224/H4/B4 with three aggregators: 14 + 3; 300/H4/B4: 19 + 3; 304/H8/B8: 20 + 4): two
   // launches over half of the tiles each -- x is read twice, which still beats the LDS-staged bf16x3 kernel 2 x
   const int launches = c.NT <= 16 ? 1 : 2;
