@@ -584,7 +584,9 @@ __global__ void __launch_bounds__(WAVES * 64) basis_gemm_f16x2k_spec_kernel(cons
     const u16* xb = xs + cur * 2 * KROWS * LDX + j * LDX + 8 * quad;
     // PF operand sets in rotation: the operands of k-step s + PF - 1 are requested before the products of k-step s, and the
     // order is pinned (left alone the scheduler folds the sets back into one and waits for a read two MFMAs after issuing it)
-    constexpr int PF = TPW == 1 ? 3 : 2;      // (two tiles: six products per operand pair, and the registers are the weights')
+    // (two tiles: six products per operand pair, and the registers are the weights'; K > 320 at sixteen wavefronts: the third set
+    // was paid for in spilled weight registers -- 12 / 20 at KS = 11 / 12 --, 570 -> 540 us at the ogbn-mag shape without it)
+    constexpr int PF = (TPW == 1 && KS <= 10) ? 3 : 2;
     f16x8k xh[PF], xl[PF];
 #pragma unroll
     for (int p = 0; p < PF - 1; ++p)
