@@ -818,8 +818,11 @@ template <int KS>
 static int launch_ks(const float* x, const u16* packed, const float* bcat, int64_t M, int K, const KCols& c, float* bases,
                      float* weightings, hipStream_t stream, const float* addend) {
   if constexpr (KS <= 7) {
-    // 17 - 20 column tiles (224 / H4 / B4 with three aggregators forward: 14 + 3; the d x GEMM of 296 / H8 / B4: 19): ONE launch
-    if (c.NT > 16 && c.NT <= 20) {
+    // 17 - 20 column tiles (224 / H4 / B4 with three aggregators forward: 14 + 3; the d x GEMM of 296 / H8 / B4: 19): ONE launch.
+    // From nine tiles on the two-tile form is also the faster single launch (half the operand reads per product, five to eight
+    // multipliers and as many wavefronts left to move and split x: 3 - 20 % at 9 - 16 tiles and 169 k rows, same bits; at eight tiles
+    // and fewer two workgroups of the all-in-one kernel per CU win: 60.6 against 67.0 us at 192 -> 128).
+    if (c.NT >= 9 && c.NT <= 20) {
       const int st = launch_k2<KS>(x, packed, bcat, M, K, c, bases, weightings, stream, addend);
       if (st != EGC_ERR_UNSUPPORTED) return st;
     }
