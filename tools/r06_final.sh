@@ -20,6 +20,14 @@ for w in molhiv zinc; do
 done
 EGC_SMALL_ONLY=molhiv rocprofv3 --pmc FETCH_SIZE -d $O/pmc_step_fetch -o pmc --output-format csv -- python3 $R/tools/batch_train_step_time.py > /dev/null 2>&1
 EGC_SMALL_ONLY=molhiv rocprofv3 --pmc WRITE_SIZE -d $O/pmc_step_write -o pmc --output-format csv -- python3 $R/tools/batch_train_step_time.py > /dev/null 2>&1
+# (3b) the reference's own wide batched nets: the CSR-path training step, kernel times + the un-profiled step time
+for sh in "224,4,4,add+mean+max,1,lay" "296,8,4,symadd,1,lay" "168,8,4,symadd,1,lay"; do
+  tag=$(echo $sh | cut -d, -f1); w=molhiv; [ $tag = 168 ] && w=zinc
+  EGC_SMALL_ONLY=$w EGC_STEP_SHAPE="$sh" rocprofv3 --kernel-trace --stats -d $O/wide_$tag -o kt --output-format csv -- python3 $R/tools/batch_train_step_time.py > /dev/null 2>&1
+  EGC_SMALL_ONLY=$w EGC_STEP_SHAPE="$sh" python3 $R/tools/batch_train_step_time.py 2>&1 | grep -v amdgpu > $O/wide_step_$tag.log
+done
+python3 $R/tools/gemm_rows_scan.py 2>&1 | grep -v amdgpu > $O/gemm_rows_scan.log
+EGC_XT_SWEEP=1 python3 $R/tools/xt_wide_time.py 2>&1 | grep -v amdgpu > $O/xt_wide_sweep.log
 find $O -name "*kernel_trace.csv" -delete
 cd $R
 # (4) un-profiled logs: eager / replayed training step, layer shapes per path, std / var modes, eager host profile

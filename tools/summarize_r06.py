@@ -60,6 +60,11 @@ def main():
         cp(f"fused_{w}/kt_kernel_stats.csv", f"r06_fused_tile_{w}_kernel_stats.csv")
     for w in ("molhiv", "zinc"):
         cp(f"step_{w}/kt_kernel_stats.csv", f"r06_batch_train_step_{w}_kernel_stats.csv")
+    for t in ("224", "296", "168"):
+        cp(f"wide_{t}/kt_kernel_stats.csv", f"r06_wide_train_step_{t}_kernel_stats.csv")
+        cp(f"wide_step_{t}.log", f"r06_wide_train_step_{t}.log")
+    cp("gemm_rows_scan.log", "r06_gemm_rows_scan.log")
+    cp("xt_wide_sweep.log", "r06_xt_wide_sweep.log")
     for a, b in (("batch_train_step.log", "r06_batch_train_step.log"), ("batch_shapes.log", "r06_batch_shapes.log"),
                  ("stdvar_modes.log", "r06_stdvar_modes.log"), ("eager_step_native.log", "r06_eager_step_native.log"),
                  ("eager_step_python.log", "r06_eager_step_python.log"), ("eager_step_variants.log", "r06_eager_step_variants.log"),
