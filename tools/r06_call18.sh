@@ -1,3 +1,4 @@
+# (round 6 ablation: needs the var_abl_* builds of egc_backward.hip with the temporary EGC_ABL_NO_DW / EGC_ABL_NO_REC hooks -- removed again after the measurement; numbers in DESIGN.md section 3.7)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r06p; mkdir -p $O
 export EGC_SMALL_ONLY=molhiv EGC_NO_NATIVE_TRAIN=1
