@@ -74,7 +74,11 @@ def _check(x, wcat, bcat, f_g, w_cols, bases, wt, tol=4e-6):
     (124, 124, 48),   # bf16x3 (F_g % 32 != 0)
     (168, 84, 32),    # long-k fp16x2 kernel (128 < F_in <= 384, <= 16 column tiles of 16)
     (352, 176, 32),   # long-k fp16x2: the ogbn-mag layer (13 column tiles, 11 k-steps)
-    (224, 224, 48),   # long-k fp16x2: molhiv 224/H4/B4 (17 tiles -> falls back to bf16x3)
+    (224, 224, 48),   # long-k fp16x2: molhiv 224/H4/B4 (17 column tiles: ONE launch, two tiles per multiplier wavefront, the last one idle)
+    (200, 150, 30),   # two tiles per wavefront (12 tiles): padded bases (ldb 152), ragged weightings width (dword stores)
+    (160, 296, 0),    # 19 tiles, no weightings: the d x GEMM of 296 / H8 / B4
+    (224, 200, 100),  # 13 + 7 = 20 tiles: the most one launch takes; a wavefront whose two tiles straddle bases | weightings
+    (192, 320, 16),   # 21 tiles: two launches
     (384, 64, 128),   # long-k fp16x2: the longest k it takes
     (132, 20, 7),     # long-k fp16x2: ragged weightings width (dword stores), partial column tiles
     (300, 300, 48),   # bf16x3, LDS-staged general kernel (too many column tiles for the long-k kernel)
@@ -87,7 +91,7 @@ def test_packed_gemm_matches_float64(n, f_in, f_g, w_cols):
     bcat = torch.randn(w_cols, generator=g).to(DEV)
     # the shapes the fp16x2 kernels serve (egc_gemm_split.h: f16x2_shape / f16x2k_shape) are held to 5e-7
     f16x2 = (f_in, f_g, w_cols) in {(128, 64, 128), (100, 64, 126), (128, 32, 160), (168, 84, 32), (352, 176, 32), (384, 64, 128),
-                                    (132, 20, 7)}
+                                    (132, 20, 7), (224, 224, 48), (200, 150, 30), (160, 296, 0), (224, 200, 100), (192, 320, 16)}
     _check(x, wcat, bcat, f_g, w_cols, *_transform(x, wcat, bcat, f_g, w_cols), tol=F16X2_TOL if f16x2 else 4e-6)
 
 
