@@ -363,6 +363,41 @@ def test_trained_reference_shapes_gradients(hidden, H, B, aggrs):
         assert _rel(v.grad, p64[k].grad) <= gtol(aggrs), k
 
 
+@pytest.mark.parametrize("hidden,H,B,aggrs", [(296, 8, 4, ["symadd"]), (224, 4, 4, ["add", "mean", "max"]), (136, 4, 4, ["symadd", "max", "mean"])])
+def test_one_row_groups_on_a_graph_of_33k_rows(hidden, H, B, aggrs):
+    """33 - 64-slot layers on >= 32,768 rows: the forward aggregate runs four row groups per wavefront there (the next group's
+    bounds and indices requested ahead; round 6) -- a ragged row count (the last wavefront's groups run past the end), a hub row
+    beyond the long-row threshold in the middle of a wavefront's groups, empty rows; forward and every gradient against float64
+    autograd through the restatement."""
+    import egc_amd
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(hidden)
+    n = 32768 + 1003
+    ei = _graph(rng, n, 3 * n, hub=900, self_loops=11)
+    ei[1][ei[1] % 7 == 3] = 5                       # rows without entries; row 5 becomes a second long row
+    torch.manual_seed(hidden)
+    conv = egc_amd.EfficientGraphConv(hidden, hidden, H, B, False, aggrs=aggrs).to(dev)
+    with torch.no_grad():
+        conv.bias.normal_()
+    x = torch.randn(n, hidden, device=dev, requires_grad=True)
+    gout = torch.randn(n, hidden, device=dev)
+    out = conv(x=x, edge_index=torch.from_numpy(ei).to(dev))
+    out.backward(gout)
+    conv.eval()
+    with torch.no_grad():
+        out_eval = conv(x=x.detach(), edge_index=torch.from_numpy(ei).to(dev))
+    p64 = {k: v.detach().double().cpu().requires_grad_(True) for k, v in conv.named_parameters()}
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    ref = tref.efficient_graph_conv_forward(
+        x64, ei, [p64[f"bases_weight.{b}"] for b in range(B)], p64["comb_weights.weight"], p64["comb_weights.bias"],
+        p64["bias"], H, aggrs)
+    ref.backward(gout.double().cpu())
+    assert _rel(out, ref) <= 1e-5 and _rel(out_eval, ref) <= 1e-5
+    assert _rel(x.grad, x64.grad) <= gtol(aggrs)
+    for k, v in conv.named_parameters():
+        assert _rel(v.grad, p64[k].grad) <= gtol(aggrs), k
+
+
 @pytest.mark.parametrize("kind", ["opt", "lay"])
 def test_frozen_parameters_take_the_operand_level_node_and_agree(kind):
     """With trainable parameters the modules run pack + layer + unpack as one autograd node (_EGCLayerParamsFunction);
