@@ -615,13 +615,17 @@ def _oc_small_batches(out, dev, seed):
         return egc_amd.EfficientGraphConv(168, 168, 8, 4, False, aggrs=["symadd"])
     def ref224():     # the reference's molhiv EGC-M layer (mol/pna_style_models.py, run_pretrained.sh:23)
         return egc_amd.EfficientGraphConv(224, 224, 4, 4, False, aggrs=["add", "mean", "max"])
+    def ref296():     # the reference's molhiv EGC-S layer (run_pretrained.sh:23)
+        return egc_amd.EfficientGraphConv(296, 296, 8, 4, False, aggrs=["symadd"])
     for key, (ei, n, bvec), label, make, width in (
             ("zinc_b128_training_step", wl.zinc_like_batch(128, seed=seed)[1:], "ZINC-shaped batch of 128 molecules", ns, F_IN),
             ("molhiv_b2048_training_step", wl.molecule_batch(2048, seed=seed), "molhiv-shaped batch of 2048 molecules", ns, F_IN),
             ("zinc_b128_ref168_training_step", wl.zinc_like_batch(128, seed=seed)[1:],
              "ZINC-shaped batch of 128 molecules, the reference's own EGC-S net width (EfficientGraphConv 168 / H8 / B4 symadd: CSR path)", ref168, 168),
             ("molhiv_b2048_ref224_training_step", wl.molecule_batch(2048, seed=seed),
-             "molhiv-shaped batch of 2048 molecules, the reference's own EGC-M net width (EfficientGraphConv 224 / H4 / B4 add, mean, max: CSR path)", ref224, 224)):
+             "molhiv-shaped batch of 2048 molecules, the reference's own EGC-M net width (EfficientGraphConv 224 / H4 / B4 add, mean, max: CSR path)", ref224, 224),
+            ("molhiv_b2048_ref296_training_step", wl.molecule_batch(2048, seed=seed),
+             "molhiv-shaped batch of 2048 molecules, the reference's own EGC-S net width (EfficientGraphConv 296 / H8 / B4 symadd: CSR path)", ref296, 296)):
         torch.manual_seed(seed)
         blocks = torch.nn.ModuleList([egc_amd.FusedEGCBlock(make(), torch.nn.BatchNorm1d(width)) for _ in range(4)]).to(dev).train()
         params = list(blocks.parameters())
@@ -672,7 +676,7 @@ def _oc_small_batches(out, dev, seed):
                     "coo_eager_step_ms": ms_eager_coo, "coo_hipgraph_replay_ms": ms_graph_coo}
         log(f"  {key}: eager {ms_eager:.4f} ms, one hipGraph {ms_graph:.4f} ms (edge_index only: {ms_eager_coo:.4f} / {ms_graph_coo:.4f})")
         del graphed
-        if "ref224" in key:       # (training only: the line the driver parses has room for one more record, not two)
+        if "ref224" in key or "ref296" in key:       # (training only: the line the driver parses has room for one more record each, not two)
             del blocks, params
             continue
         # the same net serving: eval mode (BatchNorm / ReLU / residual in the aggregate kernel's store), graph build included
