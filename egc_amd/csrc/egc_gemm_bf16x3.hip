@@ -594,8 +594,8 @@ size_t egc_basis_pack_bytes(int32_t f_in, int32_t f_g, int32_t w_cols) {
 
 // flags & EGC_GEMM_24BIT: operands split into THREE bf16 planes (24 significand bits: nothing of an fp32 operand is
 // dropped) whatever the shape -- the fp16x2 forms keep 22 bits, which layers with std / var amplify (egc_hip.h)
-static bool use_f16x2(int f_in, int ldb, int NV, int flags) {
-  return (flags & EGC_GEMM_24BIT) == 0 && f16x2_shape(f_in, ldb, NV);
+static bool use_f16x2(int f_in, int ldb, int NV, int flags, int w_cols) {
+  return (flags & EGC_GEMM_24BIT) == 0 && f16x2_shape(f_in, ldb, NV, w_cols);
 }
 static bool use_f16x2k(int f_in, int f_g, int ldb, int w_cols, int flags) {
   return (flags & EGC_GEMM_24BIT) == 0 && f16x2k_shape(f_in, f_g, ldb, w_cols);
@@ -608,7 +608,7 @@ static int basis_pack_strided(const float* wcat, int64_t rs, int64_t cs, int32_t
   const int ldb = (f_g + 3) & ~3;
   const int NV = round_up32(ldb + w_cols);
   const int KS = (f_in + XKT - 1) / XKT;
-  if (use_f16x2(f_in, ldb, NV, flags)) return f16x2_pack(wcat, rs, cs, f_in, f_g, w_cols, ldb, NV, KS, packed, stream);
+  if (use_f16x2(f_in, ldb, NV, flags, w_cols)) return f16x2_pack(wcat, rs, cs, f_in, f_g, w_cols, ldb, NV, KS, packed, stream);
   if (use_f16x2k(f_in, f_g, ldb, w_cols, flags)) return f16x2k_pack(wcat, rs, cs, f_in, f_g, ldb, w_cols, packed, stream);
   const int total = KS * NV * XKT;
   pack_bf16x3_kernel<<<(total + 255) / 256, 256, 0, stream>>>(wcat, rs, cs, f_in, f_g, w_cols, ldb, NV, KS, (u16*)packed);
@@ -658,7 +658,7 @@ int egc_basis_transform_packed_ex(const float* x, const void* packed, const floa
   if (x == nullptr || packed == nullptr || bases == nullptr || (w_cols > 0 && weightings == nullptr)) return EGC_ERR_INVALID;
   const int NV = round_up32(ldb + w_cols);
   const int KS = (f_in + XKT - 1) / XKT;
-  if (use_f16x2(f_in, ldb, NV, flags))  // the planes were packed for this kernel: no other form can read them
+  if (use_f16x2(f_in, ldb, NV, flags, w_cols))  // the planes were packed for this kernel: no other form can read them
     return f16x2_launch(x, packed, bcat, n_nodes, f_in, w_cols, bases, ldb, weightings, NV, stream);
   if (use_f16x2k(f_in, f_g, ldb, w_cols, flags))  // likewise: its planes are in its own fragment order
     return f16x2k_launch(x, packed, bcat, n_nodes, f_in, f_g, ldb, w_cols, bases, weightings, stream);

@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(F16X2_THREADS) basis_gemm_f16x2_kernel(const f
   constexpr unsigned GOOB = 0xFFFFFFF0u;  // out-of-range offset: loads return 0 -- no branches
   constexpr unsigned SOOB = 0x80000000u;  // same for the stores, which add a scalar offset (host: buffers < 2 GiB)
   const u32x4 rx = {(unsigned)(uintptr_t)x, (unsigned)((uintptr_t)x >> 32) & 0xffffu, (unsigned)(M * K * 4), 0x00020000u};
-  // this wavefront's 32 columns lie either in `bases` or in `weightings` (host: ldb % 32 == 0)
+  // this wavefront's 32 columns lie either in `bases` or in `weightings` (host: ldb % 32 == 0, or W == 0: every tile in `bases`)
   const bool to_bases = cb < ldb;
   const __amdgpu_buffer_rsrc_t ro =
       to_bases ? __builtin_amdgcn_make_buffer_rsrc((void*)bases, 0, (unsigned)(row_hi * ldb * 4), 0x00020000)
@@ -499,7 +499,7 @@ static int f16x2_launch_rows(const float* x, const void* packed, const float* bc
 // offset 2^31 + scalar row offset): row ranges of less than 2 GiB per array are launched one after another.
 int f16x2_launch(const float* x, const void* packed, const float* bcat, int64_t M, int K, int W, float* bases, int ldb,
                  float* weightings, int NV, hipStream_t stream) {
-  if (NV != 192 || K > F16X2_KP || K % 4 != 0 || ldb % 32 != 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0)
+  if (NV != 192 || K > F16X2_KP || K % 4 != 0 || (ldb % 32 != 0 && W != 0) || (reinterpret_cast<uintptr_t>(x) & 15) != 0)
     return EGC_ERR_UNSUPPORTED;
   const int64_t widest = std::max(std::max(K, ldb), W);
   int64_t max_rows = ((int64_t)0x7FFFFFF0 / (4 * widest)) & ~(int64_t)(F16X2_ROWS - 1);

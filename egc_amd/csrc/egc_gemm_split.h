@@ -9,8 +9,11 @@ namespace egc {
 constexpr int GEMM_KT = 32;  // k per packed staging step
 
 // Shapes served by the fp16x2 register-stationary kernel: everything else uses the bf16x3 planes.
-inline bool f16x2_shape(int f_in, int ldb, int NV) {
-  return f_in > 96 && f_in <= 128 && f_in % 4 == 0 && NV == 192 && ldb % 32 == 0;
+// (a wavefront's 32 columns lie in `bases` or in `weightings`: ldb % 32 == 0 -- or there are no weightings at all, as in the d x
+// GEMM of the 168- and 184-wide nets, [d bases | d weightings] (128 columns) x wcat^T -> 168 / 184: round 6, 117.7 -> ~60 us at
+// CIFAR b2048 against the three-plane kernel those shapes took before)
+inline bool f16x2_shape(int f_in, int ldb, int NV, int w_cols) {
+  return f_in > 96 && f_in <= 128 && f_in % 4 == 0 && NV == 192 && (ldb % 32 == 0 || w_cols == 0);
 }
 
 size_t f16x2_pack_bytes(int KS, int NV);

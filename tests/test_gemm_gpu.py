@@ -79,6 +79,8 @@ def _check(x, wcat, bcat, f_g, w_cols, bases, wt, tol=4e-6):
     (160, 296, 0),    # 19 tiles, no weightings: the d x GEMM of 296 / H8 / B4
     (224, 200, 100),  # 13 + 7 = 20 tiles: the most one launch takes; a wavefront whose two tiles straddle bases | weightings
     (192, 320, 16),   # 21 tiles: two launches
+    (128, 168, 0),    # fp16x2 kernel without weightings, ldb % 32 != 0: the d x GEMM of the 168-wide nets (round 6)
+    (116, 184, 0),    # the same, F_in < 128: arxiv EGC-S's d x GEMM shape class
     (384, 64, 128),   # long-k fp16x2: the longest k it takes
     (132, 20, 7),     # long-k fp16x2: ragged weightings width (dword stores), partial column tiles
     (300, 300, 48),   # bf16x3, LDS-staged general kernel (too many column tiles for the long-k kernel)
@@ -91,7 +93,7 @@ def test_packed_gemm_matches_float64(n, f_in, f_g, w_cols):
     bcat = torch.randn(w_cols, generator=g).to(DEV)
     # the shapes the fp16x2 kernels serve (egc_gemm_split.h: f16x2_shape / f16x2k_shape) are held to 5e-7
     f16x2 = (f_in, f_g, w_cols) in {(128, 64, 128), (100, 64, 126), (128, 32, 160), (168, 84, 32), (352, 176, 32), (384, 64, 128),
-                                    (132, 20, 7), (224, 224, 48), (200, 150, 30), (160, 296, 0), (224, 200, 100), (192, 320, 16)}
+                                    (132, 20, 7), (224, 224, 48), (200, 150, 30), (160, 296, 0), (224, 200, 100), (192, 320, 16), (128, 168, 0), (116, 184, 0)}
     _check(x, wcat, bcat, f_g, w_cols, *_transform(x, wcat, bcat, f_g, w_cols), tol=F16X2_TOL if f16x2 else 4e-6)
 
 

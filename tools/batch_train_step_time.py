@@ -1,7 +1,8 @@
 """Training step of the reference's batched nets' core -- 4 x [EGConv -> BatchNorm1d(train) -> ReLU -> + x], forward + backward -- on a
 ZINC-shaped batch of 128 and a molhiv-shaped batch of 2048 graphs, with the layer taking (a) the COO edge list (per-batch graph
 build + GEMM + aggregate, three backward kernels + dense gradients) and (b) an egc_amd.GraphBatch (one launch each way:
-egc_layer_forward_batch_fused_f32 / egc_layer_backward_batch_fused_f32); eager and as ONE hipGraph.  EGC_SMALL_ONLY=zinc|molhiv.
+egc_layer_forward_batch_fused_f32 / egc_layer_backward_batch_fused_f32); eager and as ONE hipGraph.  EGC_SMALL_ONLY=zinc|molhiv|cifar (the
+CIFAR10-superpixel-shaped batch of 2048 graphs, 241 k nodes, runs only on request).
 EGC_STEP_SHAPE="hidden,H,B,aggr+aggr+...,self_loops" runs the blocks at another layer shape, e.g. the reference's own molhiv net
 "224,4,4,sum+mean+max,0" (run_pretrained.sh:24) or "296,8,4,symnorm,1" (:23); a sixth field "lay" builds experiments/layers.py's EfficientGraphConv instead of EGConv:
 "224,4,4,add+mean+max,1,lay" is the reference's molhiv EGC-M layer as its net constructs it."""
@@ -21,8 +22,9 @@ def make_conv():
     if KIND == "lay":
         return egc_amd.EfficientGraphConv(HID, HID, HEADS, BASES, False, aggrs=AGGRS, add_self_loops=LOOPS)
     return egc_amd.EGConv(HID, HID, aggrs=AGGRS, num_heads=HEADS, num_bases=BASES, add_self_loops=LOOPS)
-for name, gen, G in (("zinc b128", lambda: wl.zinc_like_batch(128, seed=0)[1:], 128), ("molhiv b2048", lambda: wl.molecule_batch(2048, seed=0), 2048)):
-    if only and only not in name:
+for name, gen, G in (("zinc b128", lambda: wl.zinc_like_batch(128, seed=0)[1:], 128), ("molhiv b2048", lambda: wl.molecule_batch(2048, seed=0), 2048),
+                     ("cifar b2048", lambda: wl.knn_superpixel_batch(2048, seed=0), 2048)):     # (cifar: only on request -- EGC_SMALL_ONLY=cifar)
+    if (only and only not in name) or (not only and name.startswith("cifar")):
         continue
     ei, n, batch = gen()
     ei, batch = ei.to(dev), batch.to(dev)
