@@ -597,7 +597,8 @@ int launch_fast(AggArgs a, int64_t n_nodes, const PlanCaps& caps, hipStream_t st
   // thousands of wavefronts take four: row pointers -> indices -> gathers are three dependent round trips per row otherwise --
   // ogbn-mag 352 / H8 / B4 1.46 -> 1.32 ms, molhiv b2048 296 / H8 / B4 53 -> 44 us (round 6; two: 1.33 ms / 45.5 us, eight: 49.5 us).
   // The 16- and 32-lane groups keep one (config 2: 101 -> 105 -> 110 us with two / four), and so do small batches, which need
-  // the wavefronts (ZINC b128 at 124 / H4 / B4: 5.6 -> 7.6 -> 12.3 us).
+  // the wavefronts (ZINC b128 at 124 / H4 / B4: 5.6 -> 7.6 -> 12.3 us).  (Two-row groups at CIFAR b2048: 168 / H8 / B4 160 -> 152 -> 157 us
+  // with two / four, 128 / H4 / B4 symadd, std, max 294 -> 294 -> 291: left at one.)
   if (a.rows_per_wave <= 0) a.rows_per_wave = (G == 1 && (int64_t)a.row_end - a.row_begin >= 32768) ? 4 : 1;
   if (a.rows_per_wave * G > 60) a.rows_per_wave = 60 / G;
   a.chunk_blocks = (int)ceil_div(a.n_chunks_hint >= 0 ? a.n_chunks_hint : caps.cap_chunks, 4);
