@@ -407,6 +407,7 @@ __global__ void __launch_bounds__(256) bwd_dst_kernel(BwdArgs a) {
 #endif
 constexpr int REC_ITEMS = 12;             // (value, column) pairs per record
 constexpr unsigned REC_OVERFLOW = 0xffu;  // dword 15: count, or this
+constexpr int REC_FIT_COLUMNS = 10;        // records are built where an entry receives at most this many columns on average (ldb N / E)
 constexpr int REC_BALLOT_MAX = 8;         // entries of a one-row wavefront up to which the columns are ranked by ballots
 // record = 16 dwords: [0..11] values, [12..14] their columns (one byte each: ldb <= 256), [15] count
 
@@ -1220,16 +1221,23 @@ static int layer_extrema(const egc_layer* layer) {
 }
 
 // records of the extremum gradients (bwd_records_kernel): one 64-byte line per entry and extremum, behind the tables
-static bool records_apply(const egc_layer* layer, int64_t n_edges) {
+// A record holds REC_ITEMS (value, column) pairs; an entry that receives more is marked REC_OVERFLOW and the source side reads
+// the destination's whole X row and int32 arg row for it on top of the record.  An entry receives ldb / degree columns on
+// average: 4.6 on the ogbn-arxiv graph at 64 basis columns, but 108 on a molhiv batch at 224 (two entries per row) -- there
+// EVERY record overflowed, the source kernel fetched 282 MB per launch for 110 MB of payload (FETCH_SIZE, round 6) and the
+// destination kernel spent a fifth of its time building records nobody could use.  Records only where they mostly fit.
+static bool records_apply(const egc_layer* layer, int64_t n_nodes, int64_t n_edges) {
   const int ldb = egc_bases_ld(layer);
-  return layer_extrema(layer) > 0 && n_edges > 0 && ldb <= 256 && (uint64_t)n_edges * 64ull < (uint64_t)OOB &&
-         getenv("EGC_BWD_NO_REC") == nullptr;
+  if (!(layer_extrema(layer) > 0 && n_edges > 0 && ldb <= 256 && (uint64_t)n_edges * 64ull < (uint64_t)OOB &&
+        getenv("EGC_BWD_NO_REC") == nullptr))
+    return false;
+  return (double)ldb * (double)std::max<int64_t>(n_nodes, 1) <= (double)REC_FIT_COLUMNS * (double)n_edges;
 }
 
 size_t egc_backward_workspace_bytes_for(const egc_layer* layer, const egc_graph* graph) {
   if (layer == nullptr || graph == nullptr || graph->n_nodes < 0 || graph->n_edges < 0) return 0;
   const size_t base = egc_backward_workspace_bytes(layer, graph->n_nodes);
-  if (base == 0 || !records_apply(layer, graph->n_edges)) return base;
+  if (base == 0 || !records_apply(layer, graph->n_nodes, graph->n_edges)) return base;
   return base + (size_t)layer_extrema(layer) * (size_t)graph->n_edges * 64;
 }
 
@@ -1336,7 +1344,7 @@ int egc_aggregate_combine_backward_f32(const egc_graph* graph, const egc_graph* 
   a.rec_x = a.rec_n = nullptr;
   a.rec_bytes = 0;
   const size_t tables_bytes = egc_backward_workspace_bytes(layer, n);   // (a multiple of 256: 64-byte aligned records)
-  if ((a.tab_x != nullptr || a.tab_n != nullptr) && records_apply(layer, graph->n_edges) && graph->plan != nullptr &&
+  if ((a.tab_x != nullptr || a.tab_n != nullptr) && records_apply(layer, graph->n_nodes, graph->n_edges) && graph->plan != nullptr &&
       workspace_bytes >= tables_bytes + (size_t)layer_extrema(layer) * (size_t)graph->n_edges * 64) {
     unsigned char* r = reinterpret_cast<unsigned char*>(workspace) + tables_bytes;
     if (a.tab_x != nullptr) { a.rec_x = reinterpret_cast<const unsigned*>(r); r += (size_t)graph->n_edges * 64; }
@@ -1459,6 +1467,18 @@ int egc_aggregate_combine_backward_f32(const egc_graph* graph, const egc_graph* 
                 (a.tab_x != nullptr ? SRC_X : 0u) | (a.tab_n != nullptr ? SRC_N : 0u) | (a.x_looped ? SRC_XL : 0u) |
                 (a.y_looped ? SRC_YL : 0u) | (a.rec_bytes != 0 ? SRC_REC : 0u);
   if (getenv("EGC_BWD_GENERIC") != nullptr) fl = 0;
+  // the same layer kinds on low-degree batches, where no records are built (records_apply): the arg-byte form, compiled in
+  if (ns == 1 && fl == (SRC_STATIC | SRC_T | SRC_X | SRC_YL)) {                                // add+mean+max (molhiv EGC-M)
+    bwd_src_kernel<1, SRC_STATIC | SRC_T | SRC_X | SRC_YL><<<grid, 256, 0, stream>>>(a);
+  } else if (ns == 1 && fl == (SRC_STATIC | SRC_T | SRC_S | SRC_X | SRC_YL)) {                 // symadd+max+mean
+    bwd_src_kernel<1, SRC_STATIC | SRC_T | SRC_S | SRC_X | SRC_YL><<<grid, 256, 0, stream>>>(a);
+  } else if (ns == 1 && fl == (SRC_STATIC | SRC_T | SRC_V | SRC_X | SRC_YL)) {                 // add+std+max (zinc EGC-M)
+    bwd_src_kernel<1, SRC_STATIC | SRC_T | SRC_V | SRC_X | SRC_YL><<<grid, 256, 0, stream>>>(a);
+  } else if (ns == 1 && fl == (SRC_STATIC | SRC_T | SRC_S | SRC_V | SRC_X | SRC_YL)) {         // symadd+std+max (CIFAR EGC-M)
+    bwd_src_kernel<1, SRC_STATIC | SRC_T | SRC_S | SRC_V | SRC_X | SRC_YL><<<grid, 256, 0, stream>>>(a);
+  } else if (ns == 1 && fl == (SRC_STATIC | SRC_T | SRC_S | SRC_X | SRC_XL | SRC_YL)) {        // EGConv sum+mean+max+symnorm
+    bwd_src_kernel<1, SRC_STATIC | SRC_T | SRC_S | SRC_X | SRC_XL | SRC_YL><<<grid, 256, 0, stream>>>(a);
+  } else
   if (ns == 1 && fl == (SRC_STATIC | SRC_T | SRC_S | SRC_X | SRC_XL | SRC_YL | SRC_REC)) {  // EGConv sum+mean+max+symnorm (north star)
     bwd_src_kernel<1, SRC_STATIC | SRC_T | SRC_S | SRC_X | SRC_XL | SRC_YL | SRC_REC><<<grid, 256, 0, stream>>>(a);
   } else if (ns == 1 && fl == (SRC_STATIC | SRC_T | SRC_S | SRC_X | SRC_YL | SRC_REC)) {     // EfficientGraphConv symadd+max+mean
