@@ -663,7 +663,10 @@ int egc_layer_forward_packed(const egc_graph* graph, const egc_layer* layer, con
  * Workspace: egc_backward_workspace_bytes(layer, n_nodes) holds the per-destination tables; with
  * egc_backward_workspace_bytes_for(layer, graph) bytes (64 more per entry and max / min aggregator) the gradients of
  * max / min travel as one 64-byte record per entry instead of arg bytes + pieces of the X rows (round 3: the source
- * kernel then fetches payload, not sectors).  Either size is accepted; the results are the same. */
+ * kernel then fetches payload, not sectors).  Either size is accepted; the results are the same.  Round 6: the larger size is
+ * returned (and records are built) only where an entry receives at most ten columns on average (ldb * n_nodes / n_edges: 4.6 on
+ * the ogbn-arxiv graph at 64 basis columns); on batches of small graphs at wide layers (108 at 224 columns on a molecule batch)
+ * every 12-item record overflowed, and both sizes are the tables' size there. */
 size_t egc_backward_workspace_bytes(const egc_layer* layer, int64_t n_nodes);
 size_t egc_backward_workspace_bytes_for(const egc_layer* layer, const egc_graph* graph);
 int egc_aggregate_combine_backward_f32(const egc_graph* graph, const egc_graph* t_graph, const egc_layer* layer,
